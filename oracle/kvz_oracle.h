@@ -1,0 +1,129 @@
+/*
+ * kvz_oracle.h -- TEST INFRASTRUCTURE.  CPU restatement of kvazaar's strategy hot path.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * the product (kvazaar_amd/, libkvz_hip.so) never links, imports or calls it.
+ *
+ * Every function restates, in plain C, what the reference's *generic* strategy computes
+ * (src/strategies/generic/*.c of ultravideo/kvazaar v2.3.2); each definition in kvz_oracle.c cites
+ * the file:line it follows.  Signatures mirror include/kvz_hip.h one-to-one (prefix kvz_oracle_
+ * instead of kvz_hip_) so the parity tests can call oracle, reference build (oracle/_ref) and the
+ * HIP library with identical arguments.
+ *
+ * Pinning: tests/test_oracle_*.py check this file against (a) the golden values of the
+ * reference's own unit tests (tests/satd_tests.c, sad_tests.c, intra_sad_tests.c, dct_tests.c,
+ * coeff_sum_tests.c) and (b) the compiled reference itself (oracle/_ref/libkvazaar_ref.so, generic
+ * AND avx2 function pointers) on seeded random and adversarial inputs.
+ */
+#ifndef KVZ_ORACLE_H_
+#define KVZ_ORACLE_H_
+
+#include "../include/kvz_hip_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- tables (generated, verified against the reference's exported tables) ---- */
+const int16_t *kvz_oracle_dct_matrix(int n);               /* n in {4,8,16,32}: row-major n*n */
+const int16_t *kvz_oracle_dst_matrix(void);                /* 4x4 */
+const uint32_t *kvz_oracle_scan_table(int scan_idx, int log2_size); /* scan 0 diag,1 hor,2 ver; log2 1..5 */
+
+/* ---- picture ---- */
+unsigned kvz_oracle_reg_sad(const uint8_t *d1, const uint8_t *d2, int w, int h, unsigned s1, unsigned s2);
+unsigned kvz_oracle_sad_nxn(int n, const uint8_t *b1, const uint8_t *b2);
+unsigned kvz_oracle_satd_nxn(int n, const uint8_t *b1, const uint8_t *b2);
+void     kvz_oracle_sad_nxn_dual(int n, const uint8_t *preds /* 2 x 1024 */, const uint8_t *orig,
+                                 unsigned num_modes, unsigned *costs_out);
+void     kvz_oracle_satd_nxn_dual(int n, const uint8_t *preds /* 2 x 1024 */, const uint8_t *orig,
+                                  unsigned num_modes, unsigned *costs_out);
+unsigned kvz_oracle_satd_any_size(int w, int h, const uint8_t *b1, int s1, const uint8_t *b2, int s2);
+void     kvz_oracle_satd_any_size_quad(int w, int h, const uint8_t *const *preds, int stride,
+                                       const uint8_t *orig, int orig_stride, unsigned num_modes,
+                                       unsigned *costs_out, int8_t *valid);
+unsigned kvz_oracle_pixels_calc_ssd(const uint8_t *ref, const uint8_t *rec, int ref_stride, int rec_stride, int width);
+uint32_t kvz_oracle_ver_sad(const uint8_t *pic, const uint8_t *ref, int32_t bw, int32_t bh, uint32_t pic_stride);
+uint32_t kvz_oracle_hor_sad(const uint8_t *pic, const uint8_t *ref, int32_t w, int32_t h, uint32_t pic_stride,
+                            uint32_t ref_stride, uint32_t left, uint32_t right);
+double   kvz_oracle_pixel_var(const uint8_t *buf, uint32_t len);
+/* One plane of bipred_average: exactly one of (px0, im0) and one of (px1, im1) is non-NULL. */
+void     kvz_oracle_bipred_average_plane(uint8_t *dst, unsigned dst_stride, const uint8_t *px0, const int16_t *im0,
+                                         const uint8_t *px1, const int16_t *im1, unsigned w, unsigned h);
+
+/* Frame-edge SAD (image.c:407 kvz_image_calc_sad): SAD of the bw x bh block of `pic` at (pic_x,pic_y) against
+ * `ref` at (ref_x,ref_y) with edge replication outside the ref_w x ref_h frame. */
+unsigned kvz_oracle_image_calc_sad(const uint8_t *pic, int pic_stride, const uint8_t *ref, int ref_w, int ref_h,
+                                   int ref_stride, int pic_x, int pic_y, int ref_x, int ref_y, int bw, int bh);
+
+/* ---- dct ---- */
+void kvz_oracle_transform(int kind, int8_t bitdepth, const int16_t *in, int16_t *out);
+
+/* ---- quant ---- */
+void kvz_oracle_quant(const kvz_hip_quant_params *p, const int16_t *coef, int16_t *q_coef, int32_t width,
+                      int32_t height, int8_t type, int8_t scan_idx, int8_t block_type);
+void kvz_oracle_dequant(const kvz_hip_quant_params *p, const int16_t *q_coef, int16_t *coef, int32_t width,
+                        int32_t height, int8_t type, int8_t block_type);
+int  kvz_oracle_quantize_residual(const kvz_hip_quant_params *p, int width, int color, int scan_order,
+                                  int use_trskip, int in_stride, int out_stride, const uint8_t *ref_in,
+                                  const uint8_t *pred_in, uint8_t *rec_out, int16_t *coeff_out, int early_skip);
+uint32_t kvz_oracle_coeff_abs_sum(const int16_t *coeffs, size_t length);
+double   kvz_oracle_fast_coeff_cost(const int16_t *coeff, int32_t width, uint64_t weights);
+/* find_last_scanpos: returns through the same out-pointers as the reference; sig_coeff_inc_out is the
+ * sh_rates->sig_coeff_inc array (int32 per coefficient), only the entry at the found blkpos is written. */
+void kvz_oracle_find_last_scanpos(const int16_t *coef, int16_t *dest_coeff, int8_t type, int32_t q_bits,
+                                  const int16_t *quant_coeff, int32_t *sig_coeff_inc_out, uint32_t cg_size,
+                                  uint16_t *ctx_set, const uint32_t *scan, int32_t *cg_last_scanpos,
+                                  int32_t *last_scanpos, uint32_t cg_num, int32_t *cg_scanpos, int32_t width,
+                                  int8_t scan_mode);
+int32_t kvz_oracle_get_scaled_qp(int8_t type, int8_t qp, int8_t qp_offset);
+
+/* ---- intra ---- */
+void kvz_oracle_angular_pred(int log2_width, int intra_mode, const uint8_t *ref_above, const uint8_t *ref_left, uint8_t *dst);
+void kvz_oracle_intra_pred_planar(int log2_width, const uint8_t *ref_top, const uint8_t *ref_left, uint8_t *dst);
+void kvz_oracle_intra_pred_filtered_dc(int log2_width, const uint8_t *ref_top, const uint8_t *ref_left, uint8_t *dst);
+
+/* ---- ipol ---- */
+void kvz_oracle_sample_quarterpel_luma(const uint8_t *src, int16_t src_stride, int w, int h, uint8_t *dst,
+                                       int16_t dst_stride, int8_t hor_flag, int8_t ver_flag, const int16_t mv[2]);
+void kvz_oracle_sample_quarterpel_luma_hi(const uint8_t *src, int16_t src_stride, int w, int h, int16_t *dst,
+                                          int16_t dst_stride, int8_t hor_flag, int8_t ver_flag, const int16_t mv[2]);
+void kvz_oracle_sample_octpel_chroma(const uint8_t *src, int16_t src_stride, int w, int h, uint8_t *dst,
+                                     int16_t dst_stride, int8_t hor_flag, int8_t ver_flag, const int16_t mv[2]);
+void kvz_oracle_sample_octpel_chroma_hi(const uint8_t *src, int16_t src_stride, int w, int h, int16_t *dst,
+                                        int16_t dst_stride, int8_t hor_flag, int8_t ver_flag, const int16_t mv[2]);
+/* The four FME block filters.  filtered = 4 planes of 64*64 u8 (stride 64); hor_intermediate = 5 planes of
+ * KVZ_HIP_IPOL_IM_PLANE int16; hor_first_cols = 5 rows of KVZ_HIP_IPOL_COL_LEN int16.  State carried between
+ * calls (hpel hor_ver -> hpel diag -> qpel hor_ver -> qpel diag) lives in those caller buffers exactly as in
+ * the reference. */
+#define KVZ_HIP_IPOL_IM_PLANE ((64 + 7 + 1) * 64 + 1)   /* KVZ_IPOL_MAX_IM_SIZE_LUMA_SIMD, strategies-ipol.h:54 */
+#define KVZ_HIP_IPOL_COL_LEN  (64 + 7 + 1)              /* KVZ_EXT_BLOCK_W_LUMA + 1 */
+void kvz_oracle_filter_hpel_blocks_hor_ver_luma(const uint8_t *src, int16_t src_stride, int w, int h, uint8_t *filtered,
+                                                int16_t *hor_intermediate, int8_t fme_level, int16_t *hor_first_cols,
+                                                int8_t hpel_off_x, int8_t hpel_off_y);
+void kvz_oracle_filter_hpel_blocks_diag_luma(const uint8_t *src, int16_t src_stride, int w, int h, uint8_t *filtered,
+                                             int16_t *hor_intermediate, int8_t fme_level, int16_t *hor_first_cols,
+                                             int8_t hpel_off_x, int8_t hpel_off_y);
+void kvz_oracle_filter_qpel_blocks_hor_ver_luma(const uint8_t *src, int16_t src_stride, int w, int h, uint8_t *filtered,
+                                                int16_t *hor_intermediate, int8_t fme_level, int16_t *hor_first_cols,
+                                                int8_t hpel_off_x, int8_t hpel_off_y);
+void kvz_oracle_filter_qpel_blocks_diag_luma(const uint8_t *src, int16_t src_stride, int w, int h, uint8_t *filtered,
+                                             int16_t *hor_intermediate, int8_t fme_level, int16_t *hor_first_cols,
+                                             int8_t hpel_off_x, int8_t hpel_off_y);
+/* get_extended_block: returns 1 and fills buf (stride = pad_l+blk_w+pad_r) when the window leaves the frame,
+ * returns 0 when the reference would hand back a pointer into the frame. */
+int kvz_oracle_get_extended_block(const kvz_hip_epol_params *a, const uint8_t *src, uint8_t *buf);
+
+/* ---- sao ---- */
+int  kvz_oracle_sao_edge_ddistortion(int bitdepth, const uint8_t *orig, const uint8_t *rec, int bw, int bh,
+                                     int eo_class, const int offsets[5]);
+void kvz_oracle_calc_sao_edge_dir(int bitdepth, const uint8_t *orig, const uint8_t *rec, int eo_class, int bw,
+                                  int bh, int cat_sum_cnt[10] /* [2][5], accumulated */);
+void kvz_oracle_sao_reconstruct_color(const kvz_hip_sao_params *sao, const uint8_t *rec /* may be read at -1 row/col */,
+                                      uint8_t *new_rec, int stride, int new_stride, int bw, int bh, int color);
+int  kvz_oracle_sao_band_ddistortion(int bitdepth, const uint8_t *orig, const uint8_t *rec, int bw, int bh,
+                                     int band_pos, const int sao_bands[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,76 @@
+"""Pin the oracle against the compiled reference itself (oracle/_ref built from /root/reference by
+oracle/Makefile): every function of the flat API, generic AND AVX2 function pointers, bit-exact on the
+seeded cases of tests/cases.py.  Skipped when oracle/_ref has not been built."""
+import numpy as np
+import pytest
+
+import cases
+import flatapi
+from flatapi import ptr
+
+# Inputs on which the reference's own AVX2 and generic strategies disagree (both pass the reference's parity
+# bar because the encoder never produces them -- SURVEY.md section 8a "AVX2-vs-generic behavioural
+# differences").  The oracle follows GENERIC; these labels are only skipped for the AVX2 comparison.
+AVX2_OUT_OF_DOMAIN = ()
+
+
+def test_tables_match_reference(oracle, reflib):
+    for n in (4, 8, 16, 32):
+        a = np.ctypeslib.as_array(oracle.lib.kvz_oracle_dct_matrix(n), shape=(n * n,))
+        b = np.ctypeslib.as_array(reflib.lib.kvz_ref_dct_matrix(n), shape=(n * n,))
+        assert np.array_equal(a, b), f"dct matrix {n}"
+    a = np.ctypeslib.as_array(oracle.lib.kvz_oracle_dst_matrix(), shape=(16,))
+    b = np.ctypeslib.as_array(reflib.lib.kvz_ref_dst_matrix(), shape=(16,))
+    assert np.array_equal(a, b)
+    for scan in range(3):
+        for l2 in range(1, 6):
+            n = 1 << (2 * l2)
+            a = np.ctypeslib.as_array(oracle.lib.kvz_oracle_scan_table(scan, l2), shape=(n,))
+            b = np.ctypeslib.as_array(reflib.lib.kvz_ref_scan_table(scan, l2), shape=(n,))
+            assert np.array_equal(a, b), f"scan {scan} log2 {l2}"
+
+
+def _scan_table(oracle):
+    def f(scan_idx, l2):
+        n = 1 << (2 * l2)
+        return np.ctypeslib.as_array(oracle.lib.kvz_oracle_scan_table(scan_idx, l2), shape=(n,)).copy()
+    return f
+
+
+@pytest.mark.parametrize("gen", cases.ALL_GENERATORS, ids=lambda g: g.__name__)
+def test_oracle_equals_reference(oracle, reflib, ref, gen):
+    bad = []
+    n = 0
+    for label, run in gen():
+        if ref == 1 and label in AVX2_OUT_OF_DOMAIN:
+            continue
+        n += 1
+        a, b = run(oracle), run(reflib)
+        if label.startswith("pixel_var") and ref == 1:
+            # the one floating-point function of the path: the reference's own AVX2 version accumulates in
+            # float32 (picture-avx2.c), so only generic is compared exactly (SURVEY.md App. A "floating point")
+            if abs(a[0] - b[0]) > 1e-6 * max(1.0, abs(a[0])):
+                bad.append(label)
+        elif a != b:
+            bad.append(label)
+    assert not bad, f"{len(bad)}/{n} cases differ: {bad[:12]}"
+    assert n > 0
+
+
+def test_find_last_scanpos(oracle, reflib):
+    bad = [label for label, run in cases.cases_find_last_scanpos(_scan_table(oracle)) if run(oracle) != run(reflib)]
+    assert not bad, bad[:10]
+
+
+def test_optimized_sad_matches_reg_sad(oracle, reflib, ref):
+    """get_optimized_sad (picture-generic.c:671 returns NULL; AVX2 returns width-specialised kernels): whatever
+    the strategy hands back must equal reg_sad of that width."""
+    rng = np.random.default_rng(7)
+    a = rng.integers(0, 256, 80 * 70, dtype=np.uint8)
+    b = rng.integers(0, 256, 90 * 70, dtype=np.uint8)
+    for w in (4, 8, 12, 16, 24, 32, 48, 64):
+        for h in (4, 8, 16, 64):
+            got = reflib.lib.kvz_ref_optimized_sad(w, ptr(a), ptr(b), h, 80, 90)
+            if got == 0xFFFFFFFF:
+                continue
+            assert got == oracle.reg_sad(ptr(a), ptr(b), w, h, 80, 90)
