@@ -1,0 +1,33 @@
+"""Builds libkvz_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB_DIR = os.path.join(PKG, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libkvz_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+SOURCES = ["kvz_hip.hip"]
+# -ffp-contract=off: pixel_var / cost arithmetic must not be contracted into FMAs (bit-exact double results)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    inc = os.path.join(os.path.dirname(PKG), "include")
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(inc, f) for f in os.listdir(inc)]
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def build_library(force=False, verbose=False):
+    """Compile every HIP source into kvazaar_amd/lib/libkvz_hip.so.  Returns the library path."""
+    if not force and not _stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [HIPCC] + FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH

@@ -1,0 +1,148 @@
+// kvz_tables.hpp -- host-side construction of the constant tables the ops read (kvz::Tables) and of the
+// small per-call descriptors (SATD tile lists, FME plane descriptors, quantiser scalars).
+//
+// The transform matrices are generated from the 32 distinct HEVC magnitudes (first column of the transposed
+// 32-point matrix, /root/reference/src/strategies/generic/dct-generic.c:170); the scan tables from the
+// up-right-diagonal / raster / column-major patterns applied to 4x4 coefficient groups (tables.c:9-67).
+// tests/test_hostsim.py checks the generated tables against the reference's through the oracle.
+#pragma once
+#include <string.h>
+
+#include "kvz_ops.hpp"
+
+namespace kvz {
+
+inline int dct32_entry(int k, int n)
+{
+  static const int mag[32] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67,
+                               64, 61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9,  4 };
+  if (k == 0) return 64;
+  const int m = (k * (2 * n + 1)) % 128;  // angle in units of pi/64
+  if (m < 32) return mag[m];
+  if (m < 64) return -mag[64 - m];
+  if (m < 96) return -mag[m - 64];
+  return mag[128 - m];
+}
+
+inline void scan_pattern(int type, int size, int *xs, int *ys)
+{
+  int n = 0;
+  if (type == 0) {
+    for (int d = 0; d < 2 * size - 1; d++)
+      for (int y = d < size - 1 ? d : size - 1; y >= 0 && d - y < size; y--) { xs[n] = d - y; ys[n] = y; n++; }
+  } else if (type == 1) {
+    for (int y = 0; y < size; y++) for (int x = 0; x < size; x++) { xs[n] = x; ys[n] = y; n++; }
+  } else {
+    for (int x = 0; x < size; x++) for (int y = 0; y < size; y++) { xs[n] = x; ys[n] = y; n++; }
+  }
+}
+
+inline void build_tables(Tables *t)
+{
+  memset(t, 0, sizeof(*t));
+  for (int l = 0; l < 4; l++) {
+    const int n = 4 << l, step = 32 / n;
+    for (int k = 0; k < n; k++) for (int j = 0; j < n; j++) t->dct[l][k * n + j] = (i16)dct32_entry(k * step, j);
+  }
+  static const i16 dst4[16] = { 29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29 };
+  memcpy(t->dst4, dst4, sizeof dst4);
+  for (int type = 0; type < 3; type++)
+    for (int l2 = 2; l2 <= 5; l2++) {
+      const int size = 1 << l2, cgs = size / 4;
+      int gx[64], gy[64], px[16], py[16], n = 0;
+      scan_pattern(type, cgs, gx, gy);
+      scan_pattern(type, 4, px, py);
+      for (int g = 0; g < cgs * cgs; g++)
+        for (int i = 0; i < 16; i++) t->scan[type][l2 - 2][n++] = (u32)((gy[g] * 4 + py[i]) * size + gx[g] * 4 + px[i]);
+    }
+  static const int8_t lf[4][8] = { { 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 }, { -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+  static const int8_t cf[8][4] = { { 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 }, { -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
+  memcpy(t->luma_filter, lf, sizeof lf);
+  memcpy(t->chroma_filter, cf, sizeof cf);
+}
+
+inline int ilog2(int w) { int l = 0; while ((1 << l) < w) l++; return l; }
+
+// transform.c:141-155 kvz_get_scaled_qp
+inline int scaled_qp(int type, int qp, int qp_offset)
+{
+  static const uint8_t chroma_scale[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32,
+                                            33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };
+  if (type == 0) return qp + qp_offset;
+  int q = qp < -qp_offset ? -qp_offset : (qp > 57 ? 57 : qp);
+  return q < 0 ? q + qp_offset : chroma_scale[q] + qp_offset;
+}
+
+// quant-generic.c:57-66 (forward) and :303-339 (inverse) scalars for a width x width block of plane type
+// (`type` as the reference passes it: 0 luma, 2/3 chroma).
+inline QuantScalars quant_scalars(int qp, int bitdepth, int slice_is_intra, int scaling_list, int width, int type)
+{
+  static const int quant_scales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };  // scalinglist.c:78
+  static const int inv_quant_scales[6] = { 40, 45, 51, 57, 64, 72 };                // scalinglist.c:79
+  QuantScalars q;
+  const int log2_tr = ilog2(width);
+  const int qps = scaled_qp(type, qp, (bitdepth - 8) * 6);
+  const int transform_shift = 15 - bitdepth - log2_tr;
+  q.q_bits = 14 + qps / 6 + transform_shift;
+  q.add = (slice_is_intra ? 171 : 85) << (q.q_bits - 9);
+  q.flat_q = quant_scales[qps % 6];
+  q.dq_shift = 20 - 14 - transform_shift + (scaling_list ? 4 : 0);
+  q.dq_scale = inv_quant_scales[qps % 6] << (qps / 6);
+  q.dq_list = scaling_list;
+  q.dq_qp_per = qps / 6;
+  return q;
+}
+
+// Tile lists.  kind 0: n x n as strategies-picture.h:53-69 (8x8 tiles, or one 4x4); kind 1: satd_any_size
+// (:75-113); kind 2: satd_any_size_quad with the reference's offsets (picture-generic.c:404-471): the first-row
+// pass restarts at column 0 and the 8x8 pass starts at row 0 even when the first 4 rows were already covered.
+inline int satd_tiles(int kind, int w, int h, SatdTile *out)
+{
+  int n = 0;
+  if (kind == 0) {
+    if (w == 4) { out[n++] = SatdTile{ 0, 0, 4, 0 }; return n; }
+    for (int y = 0; y < h; y += 8) for (int x = 0; x < w; x += 8) out[n++] = SatdTile{ (i16)x, (i16)y, 8, 0 };
+    return n;
+  }
+  if (kind == 1) {
+    int x0 = 0, y0 = 0;
+    if (w % 8 != 0) { for (int y = 0; y < h; y += 4) out[n++] = SatdTile{ 0, (i16)y, 4, 0 }; x0 = 4; }
+    if (h % 8 != 0) { for (int x = x0; x < w; x += 4) out[n++] = SatdTile{ (i16)x, 0, 4, 0 }; y0 = 4; }
+    for (int y = y0; y < h; y += 8) for (int x = x0; x < w; x += 8) out[n++] = SatdTile{ (i16)x, (i16)y, 8, 0 };
+    return n;
+  }
+  int width = w, height = h;
+  const int wm8 = w % 8;
+  if (wm8 != 0) { for (int y = 0; y < height; y += 4) out[n++] = SatdTile{ 0, (i16)y, 4, 0 }; width -= 4; }
+  if (height % 8 != 0) { for (int x = 0; x < width; x += 4) out[n++] = SatdTile{ (i16)x, 0, 4, 0 }; height -= 4; }
+  for (int y = height % 8; y < height; y += 8) for (int x = wm8; x < width; x += 8) out[n++] = SatdTile{ (i16)x, (i16)y, 8, 0 };
+  return n;
+}
+
+// Plane descriptors of the four FME block filters (ipol-generic.c:213-679), derived in kvz_ops.hpp's notation:
+//   which 0: hpel hor_ver  left  = H(f2)(y+1, x)      right = H(f2)(y+1, x+1)   top = V(f2)(y, x+1)   bottom = V(f2)(y+1, x+1)
+//   which 1: hpel diag     tl = HV(f2,f2)(y, x)   tr = HV(f2,f2)(y, x+1)   bl = HV(f2,f2)(y+1, x)   br = HV(f2,f2)(y+1, x+1)
+//   which 2: qpel hor_ver  l = HV(hl, vl)(y+soy, x+ofl)   r = HV(hr, vl)(y+soy, x+ofr)   t = HV(hh, vt)(y+oft, x+sox)   b = HV(hh, vb)(y+ofb, x+sox)
+//   which 3: qpel diag     tl/tr/bl/br = HV(hl|hr, vt|vb)(y+oft|ofb, x+ofl|ofr)
+inline void fme_planes(int which, int ox, int oy, FmePlane pl[4])
+{
+  const int hl = ox != 0 ? 1 : 3, hr = ox != 0 ? 3 : 1, hh = ox != 0 ? 2 : 0;
+  const int vl = oy != 0 ? 2 : 0, vt = oy != 0 ? 1 : 3, vb = oy != 0 ? 3 : 1;
+  const int ofl = ox < 1 ? 0 : 1, ofr = ox < 0 ? 0 : 1, oft = oy < 1 ? 0 : 1, ofb = oy < 0 ? 0 : 1;
+  const int soy = oy < 0 ? 0 : 1, sox = ox > -1 ? 1 : 0;
+  if (which == 0) {
+    pl[0] = FmePlane{ 0, 2, 0, 1, 0 }; pl[1] = FmePlane{ 0, 2, 0, 1, 1 };
+    pl[2] = FmePlane{ 1, 0, 2, 0, 1 }; pl[3] = FmePlane{ 1, 0, 2, 1, 1 };
+  } else if (which == 1) {
+    pl[0] = FmePlane{ 2, 2, 2, 0, 0 }; pl[1] = FmePlane{ 2, 2, 2, 0, 1 };
+    pl[2] = FmePlane{ 2, 2, 2, 1, 0 }; pl[3] = FmePlane{ 2, 2, 2, 1, 1 };
+  } else if (which == 2) {
+    pl[0] = FmePlane{ 2, hl, vl, soy, ofl }; pl[1] = FmePlane{ 2, hr, vl, soy, ofr };
+    pl[2] = FmePlane{ 2, hh, vt, oft, sox }; pl[3] = FmePlane{ 2, hh, vb, ofb, sox };
+  } else {
+    pl[0] = FmePlane{ 2, hl, vt, oft, ofl }; pl[1] = FmePlane{ 2, hr, vt, oft, ofr };
+    pl[2] = FmePlane{ 2, hl, vb, ofb, ofl }; pl[3] = FmePlane{ 2, hr, vb, ofb, ofr };
+  }
+}
+
+}  // namespace kvz
