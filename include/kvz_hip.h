@@ -36,6 +36,7 @@ extern "C" {
 int         kvz_hip_device_count(void);        /* usable devices; 0 when there is none (no abort)                    */
 int         kvz_hip_init(int device);          /* bind this process to `device` (default 0 / $KVZ_HIP_DEVICE); 1 = ok */
 const char *kvz_hip_version(void);
+unsigned long long kvz_hip_call_count(void); /* per-call entry points served so far (KVZ_HIP_STATS=1 prints it at exit) */
 
 /* ---- 1. typedef-exact: strategies-picture.h ---------------------------------------------------------------------- */
 /* reg_sad_func (strategies-picture.h:115-117), "reg_sad" (picture-generic.c:98) */

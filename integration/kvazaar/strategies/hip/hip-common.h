@@ -1,0 +1,32 @@
+/*
+ * strategies/hip/hip-common.h -- kvazaar-side registration shim for the MI355X `hip` strategy.
+ *
+ * This directory is what a kvazaar maintainer adds under src/strategies/hip/ (see INTEGRATION.md): plain C that
+ * includes kvazaar's own headers, reads the few scalars a kernel needs out of kvazaar's host structs
+ * (encoder_state_t, encoder_control_t, cu_info_t, lcu_t, sao_info_t, kvz_epol_args) and calls the struct-free C ABI
+ * of libkvz_hip.so (include/kvz_hip.h).  It compiles only against a kvazaar source tree; in this repository
+ * oracle/Makefile builds it against /root/reference into oracle/_ref/ (kvazaar_hip, libkvazaar_hip.so).
+ *
+ * Priority 50 > avx2's 40 (strategyselector.c:296 picks the highest); KVAZAAR_OVERRIDE_<type>=generic|avx2|hip still
+ * selects per function (strategyselector.c:285-306).  Like the AVX2 strategies, nothing is registered unless
+ * bitdepth == 8 (quant-avx2.c:939-945), and nothing is registered when no HIP device is usable.
+ */
+#ifndef STRATEGIES_HIP_COMMON_H_
+#define STRATEGIES_HIP_COMMON_H_
+
+#include "global.h" // IWYU pragma: keep
+#include "kvz_hip.h"
+
+#define KVZ_HIP_PRIORITY 50
+
+int kvz_strategy_register_picture_hip(void *opaque, uint8_t bitdepth);
+int kvz_strategy_register_dct_hip(void *opaque, uint8_t bitdepth);
+int kvz_strategy_register_quant_hip(void *opaque, uint8_t bitdepth);
+int kvz_strategy_register_intra_hip(void *opaque, uint8_t bitdepth);
+int kvz_strategy_register_ipol_hip(void *opaque, uint8_t bitdepth);
+int kvz_strategy_register_sao_hip(void *opaque, uint8_t bitdepth);
+
+/* 1 when the strategy should register (8-bit build, a usable device, not disabled by KVZ_HIP_DISABLE=1) */
+int kvz_hip_strategy_usable(uint8_t bitdepth);
+
+#endif

@@ -1,0 +1,120 @@
+/* strategies/hip/quant-hip.c -- strategies-quant.h:78-84.  encoder_state_t / cu_info_t are reduced to kvz_hip_quant_params
+ * on the host; the device never sees a kvazaar struct. */
+#include "strategies/hip/hip-common.h"
+
+#include "cu.h"
+#include "encoder.h"
+#include "encoderstate.h"
+#include "rdo.h"
+#include "scalinglist.h"
+#include "strategies/strategies-quant.h"
+#include "strategyselector.h"
+#include "tables.h"
+#include "transform.h"
+
+static void fill_params(const encoder_state_t *state, int width, int8_t type, int8_t block_type, kvz_hip_quant_params *p)
+{
+  const encoder_control_t *enc = state->encoder_control;
+  const uint32_t log2_tr_size = kvz_g_convert_to_bit[width] + 2;
+  const int32_t qp_scaled = kvz_get_scaled_qp(type, state->qp, (enc->bitdepth - 8) * 6);
+  const int32_t list = (block_type == CU_INTRA ? 0 : 3) + (int8_t)("\0\3\1\2"[type]);
+  p->qp = state->qp;
+  p->bitdepth = enc->bitdepth;
+  p->slice_is_intra = state->frame->slicetype == KVZ_SLICE_I;
+  p->signhide = enc->cfg.signhide_enable;
+  p->scaling_list = enc->scaling_list.enable;
+  p->cu_is_intra = block_type == CU_INTRA;
+  /* flat lists hold kvz_g_quant_scales[qp%6] in every entry (scalinglist.c:327-330): only real lists are shipped */
+  p->quant_coeff = enc->scaling_list.enable ? enc->scaling_list.quant_coeff[log2_tr_size - 2][list][qp_scaled % 6] : NULL;
+  p->dequant_coeff = enc->scaling_list.enable ? enc->scaling_list.de_quant_coeff[log2_tr_size - 2][list][qp_scaled % 6] : NULL;
+}
+
+static void quant_hip(const encoder_state_t *const state, coeff_t *coef, coeff_t *q_coef, int32_t width, int32_t height, int8_t type,
+                      int8_t scan_idx, int8_t block_type)
+{
+  kvz_hip_quant_params p;
+  fill_params(state, width, type, block_type, &p);
+  kvz_hip_quant(&p, coef, q_coef, width, height, type, scan_idx, block_type);
+}
+
+static void dequant_hip(const encoder_state_t *const state, coeff_t *q_coef, coeff_t *coef, int32_t width, int32_t height, int8_t type,
+                        int8_t block_type)
+{
+  kvz_hip_quant_params p;
+  fill_params(state, width, type, block_type, &p);
+  kvz_hip_dequant(&p, q_coef, coef, width, height, type, block_type);
+}
+
+/* quant_residual_func.  rdoq off: one fused device call.  rdoq on: kvz_rdoq is host code in the reference (rdo.c:661, double
+ * precision, CABAC-context driven), so the steps are chained through the strategy pointers exactly as
+ * quant-generic.c:198-292 does -- transform / dequant / inverse transform still run on the device. */
+static int quantize_residual_hip(encoder_state_t *const state, const cu_info_t *const cur_cu, const int width, const color_t color,
+                                 const coeff_scan_order_t scan_order, const int use_trskip, const int in_stride, const int out_stride,
+                                 const kvz_pixel *const ref_in, const kvz_pixel *const pred_in, kvz_pixel *rec_out, coeff_t *coeff_out,
+                                 bool early_skip)
+{
+  const encoder_control_t *enc = state->encoder_control;
+  if (!(enc->cfg.rdoq_enable && (width > 4 || !enc->cfg.rdoq_skip)) && !enc->cfg.lossless) {
+    kvz_hip_quant_params p;
+    fill_params(state, width, color == COLOR_Y ? 0 : 2, cur_cu->type, &p);
+    if (enc->scaling_list.enable) {
+      /* the inverse pass of a V block uses list type 3 (quant-generic.c:263) */
+      const int8_t dq_type = color == COLOR_Y ? 0 : (color == COLOR_U ? 2 : 3);
+      const int32_t qp_scaled = kvz_get_scaled_qp(dq_type, state->qp, (enc->bitdepth - 8) * 6);
+      const int32_t list = (cur_cu->type == CU_INTRA ? 0 : 3) + (int8_t)("\0\3\1\2"[dq_type]);
+      p.dequant_coeff = enc->scaling_list.de_quant_coeff[kvz_g_convert_to_bit[width]][list][qp_scaled % 6];
+    }
+    return kvz_hip_quantize_residual(&p, width, color, scan_order, use_trskip, in_stride, out_stride, ref_in, pred_in, rec_out,
+                                     coeff_out, early_skip);
+  }
+
+  ALIGNED(64) int16_t residual[TR_MAX_WIDTH * TR_MAX_WIDTH];
+  ALIGNED(64) coeff_t coeff[TR_MAX_WIDTH * TR_MAX_WIDTH];
+  int has_coeffs = 0;
+  for (int y = 0; y < width; ++y)
+    for (int x = 0; x < width; ++x) residual[x + y * width] = (int16_t)(ref_in[x + y * in_stride] - pred_in[x + y * in_stride]);
+  if (use_trskip) kvz_transformskip(enc, residual, coeff, width);
+  else kvz_transform2d(enc, residual, coeff, width, color, cur_cu->type);
+  {
+    int8_t tr_depth = cur_cu->tr_depth - cur_cu->depth;
+    tr_depth += (cur_cu->part_size == SIZE_NxN ? 1 : 0);
+    kvz_rdoq(state, coeff, coeff_out, width, width, (color == COLOR_Y ? 0 : 2), scan_order, cur_cu->type, tr_depth);
+  }
+  for (int i = 0; i < width * width; ++i) if (coeff_out[i] != 0) { has_coeffs = 1; break; }
+  if (has_coeffs && !early_skip) {
+    kvz_dequant(state, coeff_out, coeff, width, width, (color == COLOR_Y ? 0 : (color == COLOR_U ? 2 : 3)), cur_cu->type);
+    if (use_trskip) kvz_itransformskip(enc, residual, coeff, width);
+    else kvz_itransform2d(enc, residual, coeff, width, color, cur_cu->type);
+    for (int y = 0; y < width; ++y)
+      for (int x = 0; x < width; ++x) {
+        int16_t val = residual[x + y * width] + pred_in[x + y * in_stride];
+        rec_out[x + y * out_stride] = (kvz_pixel)CLIP(0, PIXEL_MAX, val);
+      }
+  } else if (rec_out != pred_in) {
+    for (int y = 0; y < width; ++y)
+      for (int x = 0; x < width; ++x) rec_out[x + y * out_stride] = pred_in[x + y * in_stride];
+  }
+  return has_coeffs;
+}
+
+static void find_last_scanpos_hip(coeff_t *coef, coeff_t *dest_coeff, int8_t type, int32_t q_bits, const coeff_t *quant_coeff,
+                                  struct kvz_sh_rates_t *sh_rates, const uint32_t cg_size, uint16_t *ctx_set, const uint32_t *scan,
+                                  int32_t *cg_last_scanpos, int32_t *last_scanpos, uint32_t cg_num, int32_t *cg_scanpos, int32_t width,
+                                  int8_t scan_mode)
+{
+  kvz_hip_find_last_scanpos(coef, dest_coeff, type, q_bits, quant_coeff, sh_rates->sig_coeff_inc, cg_size, ctx_set, scan, cg_last_scanpos,
+                            last_scanpos, cg_num, cg_scanpos, width, scan_mode);
+}
+
+int kvz_strategy_register_quant_hip(void *opaque, uint8_t bitdepth)
+{
+  bool success = true;
+  if (!kvz_hip_strategy_usable(bitdepth)) return 1;
+  success &= kvz_strategyselector_register(opaque, "quant", "hip", KVZ_HIP_PRIORITY, (void *)&quant_hip);
+  success &= kvz_strategyselector_register(opaque, "quantize_residual", "hip", KVZ_HIP_PRIORITY, (void *)&quantize_residual_hip);
+  success &= kvz_strategyselector_register(opaque, "dequant", "hip", KVZ_HIP_PRIORITY, (void *)&dequant_hip);
+  success &= kvz_strategyselector_register(opaque, "coeff_abs_sum", "hip", KVZ_HIP_PRIORITY, (void *)&kvz_hip_coeff_abs_sum);
+  success &= kvz_strategyselector_register(opaque, "fast_coeff_cost", "hip", KVZ_HIP_PRIORITY, (void *)&kvz_hip_fast_coeff_cost);
+  success &= kvz_strategyselector_register(opaque, "find_last_scanpos", "hip", KVZ_HIP_PRIORITY, (void *)&find_last_scanpos_hip);
+  return success;
+}

@@ -37,7 +37,7 @@ struct HipBackend : ArenaBase {
     tb = device_tables();
   }
   // intentionally no destructor: thread_local teardown may run after the HIP runtime is gone
-  void begin() { reset(); }
+  void begin() { reset(); runtime().calls.fetch_add(1, std::memory_order_relaxed); }
   void upload()
   {
     if (up_end) KVZ_HIP_CHECK(hipMemcpyAsync(d, h, up_end, hipMemcpyHostToDevice, stream));
@@ -138,4 +138,5 @@ int kvz_hip_init(int device)
   return 1;
 }
 const char *kvz_hip_version(void) { return "kvz_hip 0.1 (gfx950)"; }
+unsigned long long kvz_hip_call_count(void) { return kvz::runtime().calls.load(); }
 }

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 
 #include "kvz_tables.hpp"
@@ -24,6 +25,7 @@ struct Runtime {
   int device = -1;
   Tables *d_tables = nullptr;
   Tables h_tables;
+  std::atomic<unsigned long long> calls{0};  // per-call entry points served (kvz_hip_call_count)
 };
 
 inline Runtime &runtime()
@@ -56,6 +58,7 @@ inline void runtime_init(int device)
     build_tables(&r.h_tables);
     KVZ_HIP_CHECK(hipMalloc((void **)&r.d_tables, sizeof(Tables)));
     KVZ_HIP_CHECK(hipMemcpy(r.d_tables, &r.h_tables, sizeof(Tables), hipMemcpyHostToDevice));
+    if (getenv("KVZ_HIP_STATS")) atexit([]() { fprintf(stderr, "kvz_hip: %llu strategy calls served on device %d\n", runtime().calls.load(), runtime().device); });
   });
   KVZ_HIP_CHECK(hipSetDevice(r.device));
 }
