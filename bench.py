@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- CTUs/s of the batched all-intra hot path on MI355X (BASELINE.json metric, config[1]: 1920x1080 yuv420p
+8-bit, --preset ultrafast all-intra).
+
+A "step" is one pass of the hot path (kvz_hip_intra_frames: search + reconstruct every CTU) over one batch of synthetic
+1080p frames that is already resident in HBM.  N GPUs = N processes (torch.distributed.run), each with its own batch
+(frames are independent pictures with -p 1: weak scaling, no data-path collective).
+
+Prints ONE JSON line on rank 0; see DESIGN.md "Measurement" for every field.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+BYTES_PER_CTU = 24576        # 6144 source + 6144 reconstruction + 12288 coefficient bytes per CTU
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+COEFF_WEIGHTS_QP22 = 0x065403F0052C0004  # kvazaar's default fast-coeff-cost weights at QP 22 (fast_coeff_cost.h:48)
+
+
+def synth_frames(w, h, n, seed):
+    """SURVEY.md App. C generator (1080p / 2160p branch), distinct frames"""
+    import synth
+    return [np.concatenate([p.reshape(-1) for p in planes]) for planes in synth.frames(w, h, n, seed, "large")]
+
+
+def cpu_baseline(args, frames, model):
+    """The oracle's restatement of the same pass (kind "port") on ONE host core over a bounded sample of the same
+    frames, plus -- when the prebuilt reference encoder is present -- kvazaar's own AVX2 encoder on all host cores."""
+    import ctu_common as cc
+    import flatapi
+    out = {}
+    oracle = flatapi.load_oracle()
+    n = max(1, min(len(frames), args.cpu_frames))
+    t = time.time()
+    for f in frames[:n]:
+        cc.run_oracle(oracle, model, args.width, args.height, f)
+    dt = time.time() - t
+    ctus = n * ((args.width + 63) // 64) * ((args.height + 63) // 64)
+    out.update(value=ctus / dt, unit="CTUs/s", cores=1, kind="port",
+               sample=f"{n} of the benchmark's {args.width}x{args.height} frames through oracle/kvz_oracle_ctu.c (single thread, {dt:.1f} s)")
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "kvazaar_ref")
+    if os.path.exists(ref_bin) and not args.no_ref_encoder:
+        import tempfile
+        nf = min(len(frames), 16)
+        with tempfile.NamedTemporaryFile(suffix=".yuv", dir="/tmp") as tmp:
+            for f in frames[:nf]:
+                tmp.write(f.tobytes())
+            tmp.flush()
+            threads = os.cpu_count() or 1
+            cmd = [ref_bin, "-i", tmp.name, "--input-res", f"{args.width}x{args.height}", "--preset", "ultrafast", "-p", "1",
+                   "--threads", str(threads), "-o", "/dev/null"]
+            best = None
+            for _ in range(2):
+                t = time.time()
+                r = subprocess.run(cmd, capture_output=True, text=True)
+                dt = time.time() - t
+                if r.returncode == 0 and (best is None or dt < best):
+                    best = dt
+            if best:
+                out["reference_encoder"] = {
+                    "value": nf * ((args.width + 63) // 64) * ((args.height + 63) // 64) / best, "unit": "CTUs/s", "cores": threads,
+                    "kind": "reference", "sample": f"oracle/_ref/kvazaar_ref (AVX2, whole encoder incl. CABAC+deblock) --preset ultrafast -p 1 --threads {threads}, {nf} frames, best of 2, wall incl. file read"}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--frames", type=int, default=96, help="frames per GPU and step (the batch resident in HBM)")
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames generated on the host; the batch cycles through them")
+    ap.add_argument("--qp", type=int, default=22)
+    ap.add_argument("--cpu-frames", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ref-encoder", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("KVZ_HIP_DEVICE", str(local_rank))
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl")
+    else:
+        torch.cuda.set_device(local_rank)
+
+    import ctu_common as cc
+    import kvazaar_amd
+    lib = kvazaar_amd.load_library()  # raises when libkvz_hip.so is missing: no fallback
+    model = cc.hip_cost_model(lib, args.qp, COEFF_WEIGHTS_QP22)
+
+    distinct = synth_frames(args.width, args.height, max(1, min(args.distinct, args.frames)), 1 + rank)
+    batch = cc.HipBatch(lib, args.width, args.height, args.frames)
+    for i in range(args.frames):
+        batch.upload(i, distinct[i % len(distinct)])
+    ctus_per_frame = lib.kvz_hip_batch_ctus_per_frame(C.c_void_p(batch.handle))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.run(model)
+    kernel_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    launches = 0
+    for _ in range(args.steps):
+        launches = lib.kvz_hip_intra_frames(batch.handle, C.byref(model))
+        lib.kvz_hip_batch_sync(batch.handle)
+        kernel_ms.append(batch.kernel_ms())
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        total_ctus = args.frames * ctus_per_frame * args.steps * world
+        value = total_ctus / dt
+        # dominant kernel = intra_ctu_wave_kernel: all launches of a step are that kernel; HIP events on the batch's own stream
+        k_ms = float(np.mean(kernel_ms))
+        per_launch_s = k_ms / 1e3 / launches
+        bytes_per_launch = args.frames * ctus_per_frame * BYTES_PER_CTU / launches
+        achieved = bytes_per_launch / per_launch_s / 1e9
+        result = {
+            "metric": "CTUs/s (all-intra ultrafast hot path)", "value": value, "unit": "CTUs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/i16 (f64 RD costs)", "data": "synthetic",
+            "fps": value / ctus_per_frame,
+            "config": {"workload": f"{args.width}x{args.height} yuv420p 8-bit all-intra ultrafast CTU pass (kvz_hip_intra_frames), QP {args.qp}",
+                       "frames_per_gpu_per_step": args.frames, "ctus_per_frame": ctus_per_frame, "distinct_frames": len(distinct),
+                       "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": "intra_ctu_wave_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches_per_step": launches,
+                         "avg_launch_us": per_launch_s * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "note": "latency/dependency-bound CTU search: see DESIGN.md"},
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args, distinct, model)
+        print(json.dumps(result))
+    batch.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,58 @@
+/*
+ * kvz_hip_batch.h -- batched, device-resident entry points of libkvz_hip.so (group 3 of kvz_hip.h).
+ *
+ * The per-call strategy functions (kvz_hip.h) are bit-exact drop-ins but pay a PCIe round trip per call; kvazaar
+ * makes ~3 500 such calls per CTU.  The throughput path keeps whole batches of frames in HBM and runs kvazaar's
+ * per-CTU flow (search.c:1209 kvz_search_lcu and everything below it that SURVEY.md section 8a lists for the
+ * all-intra `ultrafast` configuration: angular / planar / DC prediction, SATD mode costs, DCT 4..32, quantisation,
+ * dequantisation, IDCT, reconstruction, SSD and fast coefficient cost) as ONE workgroup per CTU out of LDS.
+ *
+ * Frame independence: with `-p 1` every frame is an IDR picture (encoderstate.c:1599-1620), so a batch of N frames
+ * is N independent problems; inside a frame CTU (x, y) needs its left, above and above-right neighbours, i.e. the
+ * WPP order of encoderstate.c:793-903.  One kernel launch processes the anti-diagonal x + 2y = const of EVERY
+ * frame of the batch.
+ *
+ * Decisions use kvazaar's own cost formulas with CABAC contexts frozen at slice-init state
+ * (kvz_hip_intra_cost_model); all pixel / coefficient results are bit-exact with the generic strategy kernels.
+ * The checker for this path is oracle/kvz_oracle_ctu.c.
+ */
+#ifndef KVZ_HIP_BATCH_H_
+#define KVZ_HIP_BATCH_H_
+
+#include "kvz_hip_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kvz_hip_batch kvz_hip_batch; /* device buffers for n_frames pictures of width x height (yuv420p, 8 bit) */
+
+/* width and height must be multiples of 8 (kvazaar pads its input the same way).  NULL on failure. */
+kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames);
+void           kvz_hip_batch_destroy(kvz_hip_batch *b);
+
+/* Host <-> HBM.  Planes are tightly packed (stride = width; chroma width/2 x height/2). */
+void kvz_hip_batch_upload(kvz_hip_batch *b, int frame, const uint8_t *y, const uint8_t *u, const uint8_t *v);
+/* Any output pointer may be NULL.  coeff: KVZ_HIP_CTU_COEFFS int16 per CTU (raster CTU order, lcu_t z-order inside);
+ * cu_depth / cu_mode: one byte per 8x8 block (raster, stride width/8); ctu_cost: one double per CTU. */
+void kvz_hip_batch_download(kvz_hip_batch *b, int frame, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, int16_t *coeff,
+                            uint8_t *cu_depth, uint8_t *cu_mode, double *ctu_cost);
+
+/* The hot path: search + reconstruct every CTU of every frame in the batch.  Asynchronous on the batch's stream;
+ * kvz_hip_batch_sync() waits.  Returns the number of kernel launches issued (one per CTU anti-diagonal). */
+int  kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model);
+void kvz_hip_batch_sync(kvz_hip_batch *b);
+/* Device time of the launches of the last kvz_hip_intra_frames call, from HIP events recorded on the batch's own
+ * stream around the launch sequence (milliseconds); call after kvz_hip_batch_sync(). */
+float kvz_hip_batch_last_kernel_ms(kvz_hip_batch *b);
+int   kvz_hip_batch_ctus_per_frame(const kvz_hip_batch *b);
+
+/* Frozen-context cost model of an I slice at `qp` (kvz_hip_intra_cost_model): HEVC context init values
+ * (context.c:96-134), kvz_ctx_init (context.c:202-213), the HM entropy table (rdo.c:69-80), lambda of
+ * rate_control.c:678-691.  coeff_weights = kvz_fast_coeff_get_weights(state) of the encoder (fast_coeff_cost.c:84-88). */
+void kvz_hip_intra_cost_model_init(int qp, uint64_t coeff_weights, kvz_hip_intra_cost_model *model);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -60,6 +60,28 @@ typedef struct kvz_hip_epol_params {
   int32_t pad_l, pad_r, pad_t, pad_b, pad_b_simd;
 } kvz_hip_epol_params;
 
+/* Bit-cost model of the batched all-intra CTU pass (kvz_hip_batch.h).  kvazaar prices syntax elements with
+ * CTX_ENTROPY_FBITS(ctx, val) = kvz_f_entropy_bits[ctx->uc_state ^ val] (cabac.h:131) on a CABAC context copy that
+ * adapts while it searches (search.c:1211, encode_coding_tree.c:948); the batched pass keeps every context at the
+ * state kvz_init_contexts gives it for an I slice at this QP (context.c:202-282) -- "frozen contexts" -- so that CTUs
+ * only depend on each other through reconstructed pixels and CU info.  Each entry is fbits[val] of one context. */
+typedef struct kvz_hip_intra_cost_model {
+  double   lambda;            /* state->lambda: 0.57 * 2^((qp-12)/3) at constant QP (rate_control.c:678-691) */
+  double   lambda_sqrt;       /* state->lambda_sqrt */
+  float    split_flag[3][2];  /* ctx.split_flag_model[0..2]      (search.c:952-956, encode_coding_tree.c:985-997) */
+  float    part_size[2];      /* ctx.part_size_model[0]          (encode_coding_tree.c:695-703) */
+  float    intra_mode[2];     /* ctx.intra_mode_model            (search_intra.c:641-676) */
+  float    chroma_mode[2];    /* ctx.chroma_pred_model[0]        (search_intra.c:679-690) */
+  float    cbf_luma[2][2];    /* ctx.qt_cbf_model_luma[0..1]     (search.c:489-497) */
+  float    cbf_chroma[2][2];  /* ctx.qt_cbf_model_chroma[0..1]   (search.c:463-470) */
+  uint64_t coeff_weights;     /* kvz_fast_coeff_get_weights(state): 4 x Q8.8 (fast_coeff_cost.c:84-88) */
+  int32_t  qp;                /* state->qp (constant over the frame) */
+  int32_t  reserved;
+} kvz_hip_intra_cost_model;
+
+/* Per-CTU result record of the batched pass: what kvazaar keeps in cu_array / lcu_t for the CTU. */
+#define KVZ_HIP_CTU_COEFFS 6144 /* 64*64 Y + 32*32 U + 32*32 V coefficients, each plane in lcu_t z-order (cu.h:385-421) */
+
 #ifdef __cplusplus
 }
 #endif

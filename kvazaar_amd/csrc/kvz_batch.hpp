@@ -1,0 +1,192 @@
+// kvz_batch.hpp -- host side of the batched CTU pass: device buffers of a frame batch, the wave-front launch
+// schedule and the frozen-context cost model.  Included by kvz_hip.hip only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/kvz_hip_batch.h"
+#include "kvz_ctu.hpp"
+#include "kvz_runtime.hpp"
+
+namespace kvz {
+
+// One workgroup per CTU of the anti-diagonal `wave` (x + 2y == wave) of every frame.
+__global__ void __launch_bounds__(KVZ_CTU_THREADS) intra_ctu_wave_kernel(const CtuFrames F, const kvz_hip_intra_cost_model model, const Tables *tb,
+                                                                        const int wave, const int y_min, const int n_diag)
+{
+  __shared__ CtuShared shared;
+  __shared__ kvz_hip_intra_cost_model m;
+  if (threadIdx.x == 0) m = model;
+  __syncthreads();
+  CtuProgram p;
+  p.m = &m; p.tb = tb; p.F = F; p.s = &shared;
+  p.frame = blockIdx.x / n_diag;
+  const int y = y_min + (int)(blockIdx.x % n_diag);
+  p.cx = (wave - 2 * y) * 64;
+  p.cy = y * 64;
+  p.run();
+}
+
+}  // namespace kvz
+
+struct kvz_hip_batch {
+  kvz::CtuFrames F;
+  int n_frames;
+  hipStream_t stream;
+  hipEvent_t ev0, ev1;
+  uint8_t *d_src, *d_rec, *d_depth, *d_mode;
+  int16_t *d_coeff, *d_scratch;
+  double *d_cost;
+};
+
+namespace kvz {
+
+// Entropy bits of the HEVC CABAC state machine, fixed point 1<<15 (HM 12.0 sm_entropyBits, as tabulated in
+// rdo.c:69-80 kvz_entropy_bits); CTX_ENTROPY_FBITS = value / 32768 (rdo.c:83, cabac.h:131).  Standard constant data.
+static const uint32_t kEntropyBits[128] = {
+  0x08000, 0x08000, 0x076da, 0x089a0, 0x06e92, 0x09340, 0x0670a, 0x09cdf, 0x06029, 0x0a67f, 0x059dd, 0x0b01f, 0x05413, 0x0b9bf, 0x04ebf, 0x0c35f,
+  0x049d3, 0x0ccff, 0x04546, 0x0d69e, 0x0410d, 0x0e03e, 0x03d22, 0x0e9de, 0x0397d, 0x0f37e, 0x03619, 0x0fd1e, 0x032ee, 0x106be, 0x02ffa, 0x1105d,
+  0x02d37, 0x119fd, 0x02aa2, 0x1239d, 0x02836, 0x12d3d, 0x025f2, 0x136dd, 0x023d1, 0x1407c, 0x021d2, 0x14a1c, 0x01ff2, 0x153bc, 0x01e2f, 0x15d5c,
+  0x01c87, 0x166fc, 0x01af7, 0x1709b, 0x0197f, 0x17a3b, 0x0181d, 0x183db, 0x016d0, 0x18d7b, 0x01595, 0x1971b, 0x0146c, 0x1a0bb, 0x01354, 0x1aa5a,
+  0x0124c, 0x1b3fa, 0x01153, 0x1bd9a, 0x01067, 0x1c73a, 0x00f89, 0x1d0da, 0x00eb7, 0x1da79, 0x00df0, 0x1e419, 0x00d34, 0x1edb9, 0x00c82, 0x1f759,
+  0x00bda, 0x200f9, 0x00b3c, 0x20a99, 0x00aa5, 0x21438, 0x00a17, 0x21dd8, 0x00990, 0x22778, 0x00911, 0x23118, 0x00898, 0x23ab8, 0x00826, 0x24458,
+  0x007ba, 0x24df7, 0x00753, 0x25797, 0x006f2, 0x26137, 0x00696, 0x26ad7, 0x0063f, 0x27477, 0x005ed, 0x27e17, 0x0059f, 0x287b6, 0x00554, 0x29156,
+  0x0050e, 0x29af6, 0x004cc, 0x2a497, 0x0048d, 0x2ae35, 0x00451, 0x2b7d6, 0x00418, 0x2c176, 0x003e2, 0x2cb15, 0x003af, 0x2d4b5, 0x0037f, 0x2de55
+};
+
+// context.c:202-213 kvz_ctx_init
+inline int ctx_state(int qp, int init_value)
+{
+  const int slope = (init_value >> 4) * 5 - 45, offset = ((init_value & 15) << 3) - 16;
+  int st = ((slope * qp) >> 4) + offset;
+  st = st < 1 ? 1 : (st > 126 ? 126 : st);
+  return st >= 64 ? ((st - 64) << 1) + 1 : (63 - st) << 1;
+}
+
+inline void cost_model_init(int qp, uint64_t coeff_weights, kvz_hip_intra_cost_model *m)
+{
+  // I-slice rows of context.c:96-134 (HEVC spec tables 9-5 ff.)
+  static const uint8_t init_split[3] = { 139, 141, 157 }, init_cbf_luma[2] = { 111, 141 }, init_cbf_chroma[2] = { 94, 138 };
+  memset(m, 0, sizeof *m);
+  m->qp = qp;
+  m->lambda = 0.57 * pow(2.0, (qp - 12) / 3.0);
+  m->lambda_sqrt = sqrt(m->lambda);
+  m->coeff_weights = coeff_weights;
+  auto fill = [&](float dst[2], int init) {
+    const int st = ctx_state(qp, init);
+    dst[0] = (float)kEntropyBits[st ^ 0] / 32768.0f;
+    dst[1] = (float)kEntropyBits[st ^ 1] / 32768.0f;
+  };
+  for (int i = 0; i < 3; i++) fill(m->split_flag[i], init_split[i]);
+  fill(m->part_size, 184);
+  fill(m->intra_mode, 184);
+  fill(m->chroma_mode, 63);
+  for (int i = 0; i < 2; i++) { fill(m->cbf_luma[i], init_cbf_luma[i]); fill(m->cbf_chroma[i], init_cbf_chroma[i]); }
+}
+
+}  // namespace kvz
+
+extern "C" {
+
+void kvz_hip_intra_cost_model_init(int qp, uint64_t coeff_weights, kvz_hip_intra_cost_model *model) { kvz::cost_model_init(qp, coeff_weights, model); }
+
+kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
+{
+  if (width <= 0 || height <= 0 || n_frames <= 0 || (width & 7) || (height & 7)) {
+    fprintf(stderr, "kvz_hip_batch_create: width and height must be positive multiples of 8\n");
+    return nullptr;
+  }
+  kvz::runtime_init(-1);
+  kvz_hip_batch *b = new kvz_hip_batch();
+  kvz::CtuFrames &F = b->F;
+  F.W = width; F.H = height; F.wc = (width + 63) / 64; F.hc = (height + 63) / 64;
+  F.frame_px = (long)width * height * 3 / 2;
+  b->n_frames = n_frames;
+  const size_t nctu = (size_t)F.wc * F.hc * n_frames, ncu = (size_t)(width / 8) * (height / 8) * n_frames;
+  KVZ_HIP_CHECK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+  KVZ_HIP_CHECK(hipEventCreate(&b->ev0));
+  KVZ_HIP_CHECK(hipEventCreate(&b->ev1));
+  KVZ_HIP_CHECK(hipMalloc((void **)&b->d_src, F.frame_px * n_frames));
+  KVZ_HIP_CHECK(hipMalloc((void **)&b->d_rec, F.frame_px * n_frames));
+  KVZ_HIP_CHECK(hipMalloc((void **)&b->d_coeff, nctu * 6144 * sizeof(int16_t)));
+  KVZ_HIP_CHECK(hipMalloc((void **)&b->d_scratch, nctu * 3 * 6144 * sizeof(int16_t)));
+  KVZ_HIP_CHECK(hipMalloc((void **)&b->d_depth, ncu));
+  KVZ_HIP_CHECK(hipMalloc((void **)&b->d_mode, ncu));
+  KVZ_HIP_CHECK(hipMalloc((void **)&b->d_cost, nctu * sizeof(double)));
+  KVZ_HIP_CHECK(hipMemset(b->d_rec, 0, F.frame_px * n_frames));
+  F.src = b->d_src; F.rec = b->d_rec; F.coeff = b->d_coeff; F.coeff_scratch = b->d_scratch;
+  F.cu_depth = b->d_depth; F.cu_mode = b->d_mode; F.ctu_cost = b->d_cost;
+  return b;
+}
+
+void kvz_hip_batch_destroy(kvz_hip_batch *b)
+{
+  if (!b) return;
+  hipStreamSynchronize(b->stream);
+  hipFree(b->d_src); hipFree(b->d_rec); hipFree(b->d_coeff); hipFree(b->d_scratch); hipFree(b->d_depth); hipFree(b->d_mode); hipFree(b->d_cost);
+  hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
+  hipStreamDestroy(b->stream);
+  delete b;
+}
+
+int kvz_hip_batch_ctus_per_frame(const kvz_hip_batch *b) { return b->F.wc * b->F.hc; }
+
+void kvz_hip_batch_upload(kvz_hip_batch *b, int frame, const uint8_t *y, const uint8_t *u, const uint8_t *v)
+{
+  const long ys = (long)b->F.W * b->F.H, cs = ys / 4;
+  uint8_t *dst = b->d_src + (long)frame * b->F.frame_px;
+  KVZ_HIP_CHECK(hipMemcpyAsync(dst, y, ys, hipMemcpyHostToDevice, b->stream));
+  KVZ_HIP_CHECK(hipMemcpyAsync(dst + ys, u, cs, hipMemcpyHostToDevice, b->stream));
+  KVZ_HIP_CHECK(hipMemcpyAsync(dst + ys + cs, v, cs, hipMemcpyHostToDevice, b->stream));
+  KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+}
+
+void kvz_hip_batch_download(kvz_hip_batch *b, int frame, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, int16_t *coeff, uint8_t *cu_depth,
+                            uint8_t *cu_mode, double *ctu_cost)
+{
+  const kvz::CtuFrames &F = b->F;
+  const long ys = (long)F.W * F.H, cs = ys / 4, nctu = (long)F.wc * F.hc, ncu = (long)(F.W / 8) * (F.H / 8);
+  const uint8_t *src = b->d_rec + (long)frame * F.frame_px;
+  KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+  if (rec_y) KVZ_HIP_CHECK(hipMemcpy(rec_y, src, ys, hipMemcpyDeviceToHost));
+  if (rec_u) KVZ_HIP_CHECK(hipMemcpy(rec_u, src + ys, cs, hipMemcpyDeviceToHost));
+  if (rec_v) KVZ_HIP_CHECK(hipMemcpy(rec_v, src + ys + cs, cs, hipMemcpyDeviceToHost));
+  if (coeff) KVZ_HIP_CHECK(hipMemcpy(coeff, b->d_coeff + frame * nctu * 6144, nctu * 6144 * sizeof(int16_t), hipMemcpyDeviceToHost));
+  if (cu_depth) KVZ_HIP_CHECK(hipMemcpy(cu_depth, b->d_depth + frame * ncu, ncu, hipMemcpyDeviceToHost));
+  if (cu_mode) KVZ_HIP_CHECK(hipMemcpy(cu_mode, b->d_mode + frame * ncu, ncu, hipMemcpyDeviceToHost));
+  if (ctu_cost) KVZ_HIP_CHECK(hipMemcpy(ctu_cost, b->d_cost + frame * nctu, nctu * sizeof(double), hipMemcpyDeviceToHost));
+}
+
+int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model)
+{
+  const kvz::CtuFrames &F = b->F;
+  int launches = 0;
+  KVZ_HIP_CHECK(hipEventRecord(b->ev0, b->stream));
+  // CTU (x, y) needs (x-1, y), (x, y-1), (x+1, y-1): all of them lie on earlier anti-diagonals x + 2y (the WPP order of
+  // encoderstate.c:793-903), so one launch per diagonal needs no synchronisation inside the launch.
+  for (int wave = 0; wave <= (F.wc - 1) + 2 * (F.hc - 1); wave++) {
+    int y_min = (wave - (F.wc - 1) + 1) / 2;
+    if (y_min < 0) y_min = 0;
+    int y_max = wave / 2;
+    if (y_max > F.hc - 1) y_max = F.hc - 1;
+    const int n_diag = y_max - y_min + 1;
+    if (n_diag <= 0) continue;
+    hipLaunchKernelGGL(kvz::intra_ctu_wave_kernel, dim3(n_diag * b->n_frames), dim3(KVZ_CTU_THREADS), 0, b->stream, F, *model, kvz::device_tables(), wave,
+                       y_min, n_diag);
+    launches++;
+  }
+  KVZ_HIP_CHECK(hipGetLastError());
+  KVZ_HIP_CHECK(hipEventRecord(b->ev1, b->stream));
+  return launches;
+}
+
+void kvz_hip_batch_sync(kvz_hip_batch *b) { KVZ_HIP_CHECK(hipStreamSynchronize(b->stream)); }
+
+float kvz_hip_batch_last_kernel_ms(kvz_hip_batch *b)
+{
+  float ms = 0;
+  KVZ_HIP_CHECK(hipEventSynchronize(b->ev1));
+  KVZ_HIP_CHECK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+  return ms;
+}
+}

@@ -1,0 +1,770 @@
+// kvz_ctu.hpp -- the batched all-intra CTU pass: one workgroup (256 threads) searches and reconstructs one 64x64
+// CTU entirely out of LDS.
+//
+// What it computes: kvazaar's per-CTU flow for an I slice under `--preset ultrafast` (search.c:646 search_cu ->
+// search_intra.c:391 search_intra_rough -> intra.c:623 kvz_intra_recon_cu -> quant-generic.c:198
+// kvz_quantize_residual -> search.c:425 cu_rd_cost_tr_split_accurate), CU quadtree 64/32/16/8, with the CABAC
+// contexts frozen at slice-init state (kvz_hip_intra_cost_model; see oracle/kvz_oracle_ctu.c for the function-by-
+// function restatement this kernel is checked against, bit for bit: modes, depths, coefficients, reconstruction
+// and the double-precision RD costs).
+//
+// How it is laid out for CDNA4:
+//   * LDS holds the CTU's source pixels (6 KB), the four work-tree levels of reconstruction kvazaar keeps in
+//     lcu_t copies (4 x 6 KB, search.c:103-122), the 35 candidate predictions of the CU being searched (<= 9 KB)
+//     and the transform scratch (6 KB): ~50 KB per workgroup -> 3 workgroups per CU.
+//   * All 35 intra modes of a CU are predicted and SATD-scored at once (kvazaar tries 8..17 of them one pair at a
+//     time, search_intra.c:433-519); one lane then replays kvazaar's selection order on the cost table, which picks
+//     the same winner because every cost is a pure function of (references, source).
+//   * Y, U and V of a CU go through residual -> DCT -> quant -> dequant -> IDCT -> reconstruction together, one
+//     barrier per stage; SSD and coefficient-cost sums are LDS atomics.
+//   * CTUs only depend on their left / above / above-right neighbours' reconstructed border and CU info, read
+//     from HBM; the host launches one grid per anti-diagonal (x + 2y = const) over ALL frames of the batch, so no
+//     inter-workgroup synchronisation exists inside a launch.
+//
+// The program is a sequence of phases `KVZ_FOR_THREADS(tid) { ... } KVZ_SYNC();` with uniform control flow in
+// between.  tests/hostsim compiles it with KVZ_HOSTSIM, where a phase is a loop over tid -- exact emulation as long
+// as threads of one phase do not communicate, which is the discipline followed here (LDS atomics are integer adds).
+#pragma once
+#include "../../include/kvz_hip_types.h"
+#include "kvz_ops.hpp"
+
+namespace kvz {
+
+#define KVZ_CTU_THREADS 256
+#ifdef KVZ_HOSTSIM
+#define KVZ_FOR_THREADS(tid) for (int tid = 0; tid < KVZ_CTU_THREADS; ++tid)
+#define KVZ_SYNC()
+#define KVZ_LDS_ADD(p, v) (*(p) += (v))
+#else
+#define KVZ_FOR_THREADS(tid) for (int tid = threadIdx.x, once_ = 1; once_; once_ = 0)
+#define KVZ_SYNC() __syncthreads()
+#define KVZ_LDS_ADD(p, v) atomicAdd((p), (v))
+#endif
+
+struct CtuCu { u8 type, depth, mode, tr_depth; uint16_t cbf; uint16_t pad; };  // one per 8x8 (min CU)
+
+// Frame-level device buffers of one batch (all frames share the geometry).
+struct CtuFrames {
+  int W, H, wc, hc;          // luma size, CTU grid
+  long frame_px;             // bytes per frame of one YUV420 image: W*H*3/2
+  const u8 *src;             // [frames][Y|U|V]
+  u8 *rec;                   // [frames][Y|U|V]
+  i16 *coeff;                // [frames][ctu][6144]
+  i16 *coeff_scratch;        // [frames][ctu][3 levels][6144]  (work-tree levels 1..3)
+  u8 *cu_depth, *cu_mode;    // [frames][(H/8)*(W/8)]
+  double *ctu_cost;          // [frames][ctu]
+};
+
+struct CtuShared {
+  u8 org[6144];              // Y 64x64 | U 32x32 | V 32x32
+  u8 rec[4][6144];           // work-tree levels 0..3
+  CtuCu cu[4][64];
+  u8 ref[3][2][132];         // [plane][0 top / 1 left][2w+1]
+  u8 fref[2][132];           // filtered luma refs
+  u8 pred[35 * 256];         // candidate predictions of the CU being searched (<= 16x16)
+  i16 tb[2][1536];           // transform scratch: Y (<= 1024) | U (<= 256) | V (<= 256)
+  u32 satd[35];
+  u32 acc[16];               // [0..2] ssd per plane, [3..5] coeff weight sums, [6..8] non-zero counts
+  int8_t preds[3];
+  int best_mode;
+  u8 tbl_top[16][16], tbl_left[16][16];
+  // uniform scalars carried between phases (written by lane 0, read by everybody after the barrier)
+  double cost[4], split_cost[4];  // per depth
+  double child_rd[4];
+  u32 child_acc[4][9];
+  int cbf_any;
+};
+
+static const int kPlaneOff[3] = { 0, 4096, 5120 };
+
+struct CtuProgram {
+  const kvz_hip_intra_cost_model *m;
+  const Tables *tb;
+  CtuFrames F;
+  CtuShared *s;
+  int frame, cx, cy;  // CTU origin (luma px)
+
+  // ---------------------------------------------------------------- small uniform helpers
+  KVZ_DEV const u8 *frame_rec(int c) const { return F.rec + (long)frame * F.frame_px + (c == 0 ? 0 : c == 1 ? (long)F.W * F.H : (long)F.W * F.H * 5 / 4); }
+  KVZ_DEV const u8 *frame_src(int c) const { return F.src + (long)frame * F.frame_px + (c == 0 ? 0 : c == 1 ? (long)F.W * F.H : (long)F.W * F.H * 5 / 4); }
+  KVZ_DEV int ctu_index() const { return (cy >> 6) * F.wc + (cx >> 6); }
+  KVZ_DEV i16 *coeff_level(int level) const
+  {
+    const long ci = (long)frame * F.wc * F.hc + ctu_index();
+    return level == 0 ? F.coeff + ci * 6144 : F.coeff_scratch + (ci * 3 + (level - 1)) * 6144;
+  }
+  KVZ_DEV static unsigned zorder(int x, int y)  // cu.h:385-421
+  {
+    unsigned r = 0;
+    for (int b = 0; b < 4; b++) r |= (((x >> (2 + b)) & 1) << (2 * b)) | (((y >> (2 + b)) & 1) << (2 * b + 1));
+    return r * 16;
+  }
+  KVZ_DEV static int cbf_is_set(uint16_t cbf, int depth, int plane) { return (cbf & ((0x1f >> depth) << (5 * plane))) != 0; }
+  KVZ_DEV static void cbf_set(uint16_t *cbf, int depth, int plane) { *cbf |= (0x10 >> depth) << (5 * plane); }
+  KVZ_DEV static void cbf_clear(uint16_t *cbf, int depth, int plane) { *cbf &= ~((0x1f >> depth) << (5 * plane)); }
+
+  // CU info at luma frame position (fx, fy) as seen from work-tree level lv; false = not available
+  KVZ_DEV bool neighbour_cu(int lv, int fx, int fy, CtuCu *out) const
+  {
+    if (fx < 0 || fy < 0 || fx >= F.W || fy >= F.H) return false;
+    if (fx >= cx && fx < cx + 64 && fy >= cy && fy < cy + 64) { *out = s->cu[lv][((fy - cy) >> 3) * 8 + ((fx - cx) >> 3)]; return true; }
+    const long i = (long)frame * (F.H >> 3) * (F.W >> 3) + (long)(fy >> 3) * (F.W >> 3) + (fx >> 3);
+    out->type = 1; out->depth = F.cu_depth[i]; out->mode = F.cu_mode[i]; out->tr_depth = out->depth; out->cbf = 0;
+    return true;
+  }
+  KVZ_DEV u8 rec_px(int lv, int c, int px, int py) const
+  {
+    const int sh = c ? 1 : 0, w = 64 >> sh, ox = cx >> sh, oy = cy >> sh;
+    if (px >= ox && px < ox + w && py >= oy && py < oy + w) return s->rec[lv][kPlaneOff[c] + (py - oy) * w + (px - ox)];
+    return frame_rec(c)[(long)py * (F.W >> sh) + px];
+  }
+
+  // intra.c:84-126 kvz_intra_get_dir_luma_predictor
+  KVZ_DEV static void mpm_candidates(int y, const CtuCu *left, const CtuCu *above, int8_t preds[3])
+  {
+    int l = 1, a = 1;
+    if (left && left->type == 1) l = left->mode;
+    if (above && above->type == 1 && (y & 63) != 0) a = above->mode;
+    if (l == a) {
+      if (l > 1) { preds[0] = (int8_t)l; preds[1] = (int8_t)(((l + 29) % 32) + 2); preds[2] = (int8_t)(((l - 1) % 32) + 2); }
+      else { preds[0] = 0; preds[1] = 1; preds[2] = 26; }
+    } else {
+      preds[0] = (int8_t)l; preds[1] = (int8_t)a;
+      if (l && a) preds[2] = 0; else preds[2] = (l + a) < 2 ? 26 : 1;
+    }
+  }
+  // search_intra.c:641-676 kvz_luma_mode_bits
+  KVZ_DEV double luma_mode_bits(int mode, const int8_t preds[3]) const
+  {
+    double bits = 0;
+    int in = 0;
+    for (int i = 0; i < 3; i++) if (mode == preds[i]) in = 1;
+    bits += (double)m->intra_mode[in];
+    if (in) bits += (mode == preds[0]) ? 1 : 2; else bits += 5;
+    return bits;
+  }
+  KVZ_DEV int split_model(int lv, int x, int y, int depth) const
+  {
+    CtuCu n;
+    int model = 0;
+    if (x > 0 && neighbour_cu(lv, x - 1, y, &n) && n.depth > depth) model++;
+    if (y > 0 && neighbour_cu(lv, x, y - 1, &n) && n.depth > depth) model++;
+    return model;
+  }
+  KVZ_DEV double intra_mode_syntax_bits(int lv, int x, int y, int mode) const
+  {
+    CtuCu lc, ac, *left = nullptr, *above = nullptr;
+    if (x > 0 && neighbour_cu(lv, x - 1, y, &lc)) left = &lc;
+    if ((y & 63) > 0 && y > 0 && neighbour_cu(lv, x, y - 1, &ac)) above = &ac;
+    int8_t preds[3];
+    mpm_candidates(y, left, above, preds);
+    double bits = luma_mode_bits(mode, preds);
+    bits += (double)m->chroma_mode[0];
+    return bits;
+  }
+  // encode_coding_tree.c:948-1049 kvz_mock_encode_coding_unit, intra 2Nx2N in an I slice
+  KVZ_DEV double cu_bits(int lv, int x, int y, int depth, int mode) const
+  {
+    double bits = 0;
+    const int w = 64 >> depth;
+    if (depth != 3 && !(F.W < x + w || F.H < y + w)) bits += (double)m->split_flag[split_model(lv, x, y, depth)][0];
+    if (depth == 3) bits += (double)m->part_size[1];
+    bits += intra_mode_syntax_bits(lv, x, y, mode);
+    return bits;
+  }
+
+  // ---------------------------------------------------------------- phases
+  // One reference sample of intra.c:305-425 kvz_intra_build_reference_any.  side 0 = top, 1 = left; i in [0, 2w].
+  KVZ_DEV u8 ref_sample(int lv, int log2w, int c, int lx, int ly, int side, int i) const
+  {
+    const int sh = c ? 1 : 0, w = 1 << log2w, px = lx >> sh, py = ly >> sh;
+    if (i == 0) {
+      if (lx > 0 && ly > 0) return rec_px(lv, c, px - 1, py - 1);
+      i = 1; side = 1;  // corner = left[1]
+    }
+    const int k = i - 1;
+    if (side == 1) {
+      if (lx > 0) {
+        int avail = s->tbl_left[(ly & 63) >> 2][(lx & 63) >> 2] >> sh;
+        avail = imin(avail, imin(2 * w, (F.H - ly) >> sh));
+        return rec_px(lv, c, px - 1, py + imin(k, avail - 1));
+      }
+      return ly > 0 ? rec_px(lv, c, px, py - 1) : 128;
+    }
+    if (ly > 0) {
+      int avail = s->tbl_top[(ly & 63) >> 2][(lx & 63) >> 2] >> sh;
+      avail = imin(avail, imin(2 * w, (F.W - lx) >> sh));
+      return rec_px(lv, c, px + imin(k, avail - 1), py - 1);
+    }
+    return lx > 0 ? rec_px(lv, c, px - 1, py) : 128;
+  }
+
+  // Builds the unfiltered references of the listed planes, then the [1 2 1]-filtered luma references (intra.c:176-204).
+  KVZ_DEV void build_refs(int lv, int x, int y, int log2w_y, int log2w_c, bool luma, bool chroma)
+  {
+    KVZ_FOR_THREADS(tid) {
+      for (int c = luma ? 0 : 1; c <= (chroma ? 2 : 0); c++) {
+        const int l2 = c ? log2w_c : log2w_y, n = 2 * (1 << l2) + 1;
+        for (int i = tid; i < 2 * n; i += KVZ_CTU_THREADS) {
+          const int side = i >= n, k = side ? i - n : i;
+          s->ref[c][side][k] = ref_sample(lv, l2, c, x, y, side, k);
+        }
+      }
+    }
+    KVZ_SYNC();
+    if (luma) {
+      KVZ_FOR_THREADS(tid) {
+        const int n = 2 * (1 << log2w_y) + 1;
+        for (int i = tid; i < 2 * n; i += KVZ_CTU_THREADS) {
+          const int side = i >= n, k = side ? i - n : i;
+          const u8 *r = s->ref[0][side];
+          u8 v;
+          if (k == 0) v = (u8)((s->ref[0][1][1] + 2 * s->ref[0][1][0] + s->ref[0][0][1] + 2) / 4);
+          else if (k == n - 1) v = r[k];
+          else v = (u8)((r[k - 1] + 2 * r[k] + r[k + 1] + 2) / 4);
+          s->fref[side][k] = v;
+        }
+      }
+      KVZ_SYNC();
+    }
+  }
+
+  // intra.c:252-301 kvz_intra_predict for one pixel (filter_boundary on for luma)
+  KVZ_DEV u8 predict_pixel(int log2w, int mode, int c, int x, int y) const
+  {
+    const int w = 1 << log2w;
+    const u8 *top = s->ref[c][0], *left = s->ref[c][1];
+    if (c == 0 && mode != 1 && w != 4) {
+      bool filt;
+      if (mode == 0) filt = true;
+      else {
+        const int thres = log2w == 3 ? 7 : (log2w == 4 ? 1 : 0);
+        filt = imin(iabs(mode - 26), iabs(mode - 10)) > thres;
+      }
+      if (filt) { top = s->fref[0]; left = s->fref[1]; }
+    }
+    if (mode == 0) return planar_pixel(log2w, x, y, top, left);
+    if (mode == 1) {
+      const int dc = dc_value(log2w, top, left);
+      return (c == 0 && w < 32) ? filtered_dc_pixel(dc, x, y, top, left) : (u8)dc;
+    }
+    int v = angular_pixel(mode, x, y, top, left);
+    if (c == 0 && w < 32) {  // intra.c:207-219 intra_post_process_angular
+      if (mode == 10 && y == 0) v = iclip(0, 255, v + ((top[x + 1] - top[0]) >> 1));
+      else if (mode == 26 && x == 0) v = iclip(0, 255, v + ((left[y + 1] - left[0]) >> 1));
+    }
+    return (u8)v;
+  }
+
+  // search_intra.c:391-530 search_intra_rough: all 35 modes predicted + SATD-scored, then the reference's selection
+  // order replayed on the cost table by one lane.  Leaves the winner in s->best_mode.
+  KVZ_DEV void rough_search(int lv, int x, int y, int depth)
+  {
+    const int log2w = 6 - depth, w = 1 << log2w, xl = x - cx, yl = y - cy, nblk = (w >> 3) * (w >> 3);
+    build_refs(lv, x, y, log2w, 0, true, false);
+    KVZ_FOR_THREADS(tid) {
+      for (int i = tid; i < 35 * w * w; i += KVZ_CTU_THREADS) {
+        const int mode = i >> (2 * log2w), e = i & (w * w - 1);
+        s->pred[i] = predict_pixel(log2w, mode, 0, e & (w - 1), e >> log2w);
+      }
+      if (tid < 35) s->satd[tid] = 0;
+      if (tid == 0) {
+        CtuCu lc, ac, *left = nullptr, *above = nullptr;
+        if (x >= 4 && neighbour_cu(lv, x - 1, y, &lc)) left = &lc;
+        if (y >= 4 && yl > 0 && neighbour_cu(lv, x, y - 1, &ac)) above = &ac;
+        mpm_candidates(y, left, above, s->preds);
+      }
+    }
+    KVZ_SYNC();
+    KVZ_FOR_THREADS(tid) {
+      for (int t = tid; t < 35 * nblk; t += KVZ_CTU_THREADS) {
+        const int mode = t / nblk, b = t - mode * nblk, bx = (b & ((w >> 3) - 1)) * 8, by = (b / (w >> 3)) * 8;
+        const u32 v = satd8(s->pred + mode * w * w + by * w + bx, w, s->org + (yl + by) * 64 + xl + bx, 64);
+        KVZ_LDS_ADD(&s->satd[mode], v);
+      }
+    }
+    KVZ_SYNC();
+    KVZ_FOR_THREADS(tid) {
+      if (tid == 0) {
+        int8_t modes[35];
+        double costs[35];
+        int n = 0, offset = log2w == 2 ? 2 : (log2w == 3 ? 4 : 8);
+        int32_t min_cost = 0x7fffffff, max_cost = -0x7fffffff - 1;
+        for (int mode = 2; mode <= 34; mode += 2 * offset)
+          for (int i = 0; i < 2; i++) if (mode + i * offset <= 34) {
+            costs[n] = (double)s->satd[mode + i * offset]; modes[n] = (int8_t)(mode + i * offset);
+            if (costs[n] < min_cost) min_cost = (int32_t)costs[n];
+            if (costs[n] > max_cost) max_cost = (int32_t)costs[n];
+            n++;
+          }
+        int bi = 0;
+        for (int i = 1; i < n; i++) if (costs[i] < costs[bi]) bi = i;
+        int best_mode = modes[bi];
+        double best_cost = min_cost;
+        if (min_cost != max_cost) {
+          while (offset > 1) {
+            offset >>= 1;
+            const int tm[2] = { best_mode - offset, best_mode + offset };
+            for (int i = 0; i < 2; i++) if (tm[i] >= 2 && tm[i] <= 34) {
+              costs[n] = (double)s->satd[tm[i]]; modes[n] = (int8_t)tm[i];
+              if (costs[n] < best_cost) { best_cost = costs[n]; best_mode = modes[n]; }
+              n++;
+            }
+          }
+        }
+        const int8_t add_modes[5] = { s->preds[0], s->preds[1], s->preds[2], 0, 1 };
+        for (int p = 0; p < 5; p++) {
+          bool has = false;
+          for (int i = 0; i < n; i++) if (modes[i] == add_modes[p]) { has = true; break; }
+          if (!has) { costs[n] = (double)s->satd[add_modes[p]]; modes[n] = add_modes[p]; n++; }
+        }
+        for (int i = 0; i < n; i++) costs[i] += m->lambda_sqrt * luma_mode_bits(modes[i], s->preds);
+        bi = 0;
+        for (int i = 1; i < n; i++) if (costs[i] < costs[bi]) bi = i;
+        s->best_mode = modes[bi];
+      }
+    }
+    KVZ_SYNC();
+  }
+
+  // Transform-unit geometry of one reconstruction step: luma w x w at (x, y) and/or chroma cw x cw.
+  struct TuSet { int x, y, lw /* log2 luma or 0 */, lc /* log2 chroma or 0 */; };
+  KVZ_DEV static int tu_log2(const TuSet &t, int c) { return c ? t.lc : t.lw; }
+  KVZ_DEV static int tb_off(int c) { return c == 0 ? 0 : (c == 1 ? 1024 : 1280); }
+
+  // intra_recon_tb_leaf (intra.c:561-608) + kvz_quantize_residual (quant-generic.c:198-292) for the planes of `t`,
+  // written into work-tree level lv.  Sets the cbf bits of the CU's info entry.  One barrier per stage.
+  KVZ_DEV void recon_tus(int lv, const TuSet &t, int depth, int mode)
+  {
+    const int xl = t.x - cx, yl = t.y - cy;
+    build_refs(lv, t.x, t.y, t.lw, t.lc, t.lw != 0, t.lc != 0);
+    // stage 1: prediction -> rec (as kvazaar blits it before quantising) and residual
+    KVZ_FOR_THREADS(tid) {
+      if (tid < 16) s->acc[tid] = 0;
+      for (int c = 0; c < 3; c++) {
+        const int l2 = tu_log2(t, c);
+        if (!l2) continue;
+        const int w = 1 << l2, sh = c ? 1 : 0, lw = 64 >> sh;
+        for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) {
+          const int px = e & (w - 1), py = e >> l2;
+          const u8 p = predict_pixel(l2, mode, c, px, py);
+          const int o = kPlaneOff[c] + ((yl >> sh) + py) * lw + (xl >> sh) + px;
+          s->rec[lv][o] = p;
+          s->tb[0][tb_off(c) + e] = (i16)((int)s->org[o] - (int)p);
+        }
+      }
+    }
+    KVZ_SYNC();
+    // stages 2-3: forward transform (dct-generic.c:559-568; 4x4 chroma uses the DCT, strategies-dct.c:82-86)
+    for (int pass = 0; pass < 2; pass++) {
+      KVZ_FOR_THREADS(tid) {
+        for (int c = 0; c < 3; c++) {
+          const int l2 = tu_log2(t, c);
+          if (!l2) continue;
+          const int n = 1 << l2, shift = pass == 0 ? l2 - 1 : l2 + 6, add = 1 << (shift - 1);
+          const i16 *C = tb->dct[l2 - 2], *src = s->tb[pass] + tb_off(c);
+          i16 *dst = s->tb[pass ^ 1] + tb_off(c);
+          for (int e = tid; e < n * n; e += KVZ_CTU_THREADS) {
+            const int k = e >> l2, j = e & (n - 1);
+            int a = 0;
+            for (int i = 0; i < n; i++) a += (int)C[k * n + i] * (int)src[j * n + i];
+            dst[e] = (i16)((a + add) >> shift);
+          }
+        }
+      }
+      KVZ_SYNC();
+    }
+    // stage 4: quantise (quant-generic.c:57-81) -> coefficient store + cost sums; dequantise (:335-339) -> tb[1]
+    KVZ_FOR_THREADS(tid) {
+      for (int c = 0; c < 3; c++) {
+        const int l2 = tu_log2(t, c);
+        if (!l2) continue;
+        const int n2 = 1 << (2 * l2), sh = c ? 1 : 0;
+        const QuantScalars qf = quant_scalars_dev(l2, c == 0 ? 0 : 2), qi = quant_scalars_dev(l2, c == 0 ? 0 : (c == 1 ? 2 : 3));
+        i16 *cout = coeff_level(lv) + kPlaneOff[c] + zorder(xl >> sh, yl >> sh);
+        const i16 *src = s->tb[0] + tb_off(c);
+        i16 *dq = s->tb[1] + tb_off(c);
+        u32 wsum = 0, nz = 0;
+        for (int e = tid; e < n2; e += KVZ_CTU_THREADS) {
+          const int cf = src[e];
+          int level = (int)(((int64_t)iabs(cf) * qf.flat_q + qf.add) >> qf.q_bits);
+          if (cf < 0) level = -level;
+          level = iclip(-32768, 32767, level);
+          cout[e] = (i16)level;
+          int a = iabs(level);
+          nz += a != 0;
+          if (a > 3) a = 3;
+          wsum += (u32)((m->coeff_weights >> (16 * a)) & 0xffff);
+          dq[e] = (i16)iclip(-32768, 32767, (level * qi.dq_scale + (1 << (qi.dq_shift - 1))) >> qi.dq_shift);
+        }
+        if (wsum) KVZ_LDS_ADD(&s->acc[3 + c], wsum);
+        if (nz) KVZ_LDS_ADD(&s->acc[6 + c], nz);
+      }
+    }
+    KVZ_SYNC();
+    // stages 5-6: inverse transform (dct-generic.c:570-579), only observable when the plane has coefficients
+    for (int pass = 0; pass < 2; pass++) {
+      KVZ_FOR_THREADS(tid) {
+        for (int c = 0; c < 3; c++) {
+          const int l2 = tu_log2(t, c);
+          if (!l2 || !s->acc[6 + c]) continue;
+          const int n = 1 << l2, shift = pass == 0 ? 7 : 12, add = 1 << (shift - 1);
+          const i16 *C = tb->dct[l2 - 2], *src = s->tb[pass ^ 1] + tb_off(c);
+          i16 *dst = s->tb[pass] + tb_off(c);
+          for (int e = tid; e < n * n; e += KVZ_CTU_THREADS) {
+            const int j = e >> l2, i = e & (n - 1);
+            int a = 0;
+            for (int k = 0; k < n; k++) a += (int)C[k * n + i] * (int)src[k * n + j];
+            dst[e] = (i16)iclip(-32768, 32767, (a + add) >> shift);
+          }
+        }
+      }
+      KVZ_SYNC();
+    }
+    // stage 7: reconstruction (quant-generic.c:266-277) + SSD against the source (search.c:500-505, 512-523)
+    KVZ_FOR_THREADS(tid) {
+      for (int c = 0; c < 3; c++) {
+        const int l2 = tu_log2(t, c);
+        if (!l2) continue;
+        const int w = 1 << l2, sh = c ? 1 : 0, lw = 64 >> sh;
+        const bool has = s->acc[6 + c] != 0;
+        u32 ssd = 0;
+        for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) {
+          const int o = kPlaneOff[c] + ((yl >> sh) + (e >> l2)) * lw + (xl >> sh) + (e & (w - 1));
+          int v = s->rec[lv][o];
+          if (has) { v = iclip(0, 255, (int)(i16)(s->tb[1][tb_off(c) + e] + v)); s->rec[lv][o] = (u8)v; }
+          const int d = (int)s->org[o] - v;
+          ssd += (u32)(d * d);
+        }
+        if (ssd) KVZ_LDS_ADD(&s->acc[c], ssd);
+      }
+      if (tid == 0) {  // cbf bits of the TU's top-left CU entry (transform.c:314, 409-411)
+        CtuCu *cu = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
+        for (int c = 0; c < 3; c++) if (tu_log2(t, c)) { cbf_clear(&cu->cbf, depth, c); if (s->acc[6 + c]) cbf_set(&cu->cbf, depth, c); }
+      }
+    }
+    KVZ_SYNC();
+  }
+
+  KVZ_DEV QuantScalars quant_scalars_dev(int log2w, int type) const
+  {
+    // quant-generic.c:57-66, 303-339 with flat scaling lists, 8 bit, I slice (kvz_tables.hpp quant_scalars)
+    const int quant_scales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 }, inv_scales[6] = { 40, 45, 51, 57, 64, 72 };
+    const u8 chroma_scale[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32,
+                                  33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };
+    int qps = m->qp;
+    if (type != 0) { int q = iclip(0, 57, m->qp); qps = chroma_scale[q]; }
+    QuantScalars q;
+    const int transform_shift = 15 - 8 - log2w;
+    q.q_bits = 14 + qps / 6 + transform_shift;
+    q.add = 171 << (q.q_bits - 9);
+    q.flat_q = quant_scales[qps % 6];
+    q.dq_shift = 20 - 14 - transform_shift;
+    q.dq_scale = inv_scales[qps % 6] << (qps / 6);
+    q.dq_list = 0; q.dq_qp_per = qps / 6;
+    return q;
+  }
+
+  // search.c:425-541 cu_rd_cost_tr_split_accurate for one leaf TU group whose sums sit in s->acc (lane 0 only)
+  KVZ_DEV double leaf_rd_cost(int lv, int xl, int yl, int depth, int cu_depth, bool code_cbf_u, bool code_cbf_v) const
+  {
+    const CtuCu *tr_cu = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
+    double tr_tree_bits = 0, coeff_bits = 0;
+    const int cb_u = cbf_is_set(tr_cu->cbf, depth, 1), cb_v = cbf_is_set(tr_cu->cbf, depth, 2), cb_y = cbf_is_set(tr_cu->cbf, depth, 0);
+    if (code_cbf_u) tr_tree_bits += (double)m->cbf_chroma[depth - cu_depth][cb_u];
+    if (code_cbf_v) tr_tree_bits += (double)m->cbf_chroma[depth - cu_depth][cb_v];
+    tr_tree_bits += (double)m->cbf_luma[depth == cu_depth ? 1 : 0][cb_y];
+    if (cb_y) coeff_bits += (double)s->acc[3] / 256.0;
+    if (cb_u) coeff_bits += (double)s->acc[4] / 256.0;
+    if (cb_v) coeff_bits += (double)s->acc[5] / 256.0;
+    const unsigned luma_ssd = s->acc[0], chroma_ssd = s->acc[1] + s->acc[2];
+    const double bits = tr_tree_bits + coeff_bits;
+    return luma_ssd * 0.8 + chroma_ssd * 1.5 + bits * m->lambda;
+  }
+
+  KVZ_DEV void fill_cu(int lv, int xl, int yl, int w, int type, int depth, int mode, int tr_depth)
+  {
+    KVZ_FOR_THREADS(tid) {
+      const int n = w >> 3;
+      if (tid < n * n) {
+        CtuCu *c = &s->cu[lv][((yl >> 3) + tid / n) * 8 + (xl >> 3) + tid % n];
+        c->type = (u8)type; c->depth = (u8)depth; c->mode = (u8)mode; c->tr_depth = (u8)tr_depth;
+      }
+    }
+    KVZ_SYNC();
+  }
+
+  // search.c:55-122 copy_cu_{info,pixels,coeffs}: region (xl, yl, w) from level `from` to level `to`
+  KVZ_DEV void copy_region(int from, int to, int xl, int yl, int w, bool coeffs)
+  {
+    KVZ_FOR_THREADS(tid) {
+      const int n = w >> 3;
+      if (tid < n * n) { const int i = ((yl >> 3) + tid / n) * 8 + (xl >> 3) + tid % n; s->cu[to][i] = s->cu[from][i]; }
+      for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) { const int o = (yl + e / w) * 64 + xl + e % w; s->rec[to][o] = s->rec[from][o]; }
+      const int cw = w >> 1;
+      for (int e = tid; e < 2 * cw * cw; e += KVZ_CTU_THREADS) {
+        const int c = e >= cw * cw, k = c ? e - cw * cw : e;
+        const int o = kPlaneOff[1 + c] + ((yl >> 1) + k / cw) * 32 + (xl >> 1) + k % cw;
+        s->rec[to][o] = s->rec[from][o];
+      }
+      if (coeffs) {
+        const i16 *src = coeff_level(from);
+        i16 *dst = coeff_level(to);
+        const unsigned zy = zorder(xl, yl), zc = zorder(xl >> 1, yl >> 1);
+        for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) dst[zy + e] = src[zy + e];
+        for (int e = tid; e < 2 * cw * cw; e += KVZ_CTU_THREADS) {
+          const int c = e >= cw * cw, k = c ? e - cw * cw : e;
+          dst[kPlaneOff[1 + c] + zc + k] = src[kPlaneOff[1 + c] + zc + k];
+        }
+      }
+    }
+    KVZ_SYNC();
+  }
+
+  // search_cu at depth 2 or 3 (search.c:646-1063): searched CU.  Returns the cost through *out (LDS).
+  KVZ_DEV void eval_cu(int lv, int x, int y, int depth, double *out_cost, int *out_cbf)
+  {
+    const int log2w = 6 - depth, w = 1 << log2w, xl = x - cx, yl = y - cy;
+    rough_search(lv, x, y, depth);
+    const int mode = s->best_mode;
+    fill_cu(lv, xl, yl, w, 1, depth, mode, depth);
+    // kvz_intra_recon_cu luma, then chroma (search.c:807-827); chroma TUs are 4x4 for 8x8 CUs (transform.c:326)
+    TuSet t{ x, y, log2w, depth == 3 ? 2 : log2w - 1 };
+    recon_tus(lv, t, depth, mode);
+    KVZ_FOR_THREADS(tid) {
+      if (tid == 0) {
+        const double bits = cu_bits(lv, x, y, depth, mode);
+        double cost = bits * m->lambda;
+        cost += leaf_rd_cost(lv, xl, yl, depth, depth, true, true);
+        *out_cost = cost;
+        const CtuCu *cu = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
+        *out_cbf = cbf_is_set(cu->cbf, depth, 0) || cbf_is_set(cu->cbf, depth, 1) || cbf_is_set(cu->cbf, depth, 2);
+      }
+    }
+    KVZ_SYNC();
+  }
+
+  // ---------------------------------------------------------------- CTU driver
+  KVZ_DEV void init()
+  {
+    KVZ_FOR_THREADS(tid) {
+      // source pixels, zero outside the picture (search.c:1084 FILL + :1151-1171)
+      for (int c = 0; c < 3; c++) {
+        const int sh = c ? 1 : 0, lw = 64 >> sh, fw = F.W >> sh, fh = F.H >> sh, ox = cx >> sh, oy = cy >> sh;
+        const u8 *src = frame_src(c);
+        for (int e = tid; e < lw * lw; e += KVZ_CTU_THREADS) {
+          const int px = ox + e % lw, py = oy + e / lw;
+          s->org[kPlaneOff[c] + e] = (px < fw && py < fh) ? src[(long)py * fw + px] : 0;
+        }
+      }
+      for (int lv = 0; lv < 4; lv++) {
+        for (int e = tid; e < 6144; e += KVZ_CTU_THREADS) s->rec[lv][e] = 0;
+        if (tid < 64) { CtuCu z = { 0, 0, 0, 0, 0, 0 }; s->cu[lv][tid] = z; }
+      }
+      {  // intra.c:47-82 num_ref_pixels_{top,left}, regenerated from the z-order of 4x4 units
+        const int r = tid >> 4, c = tid & 15;
+        int n = 0;
+        if (r == 0) s->tbl_top[r][c] = 64;
+        else { for (int cc = c; cc < 16 && zorder(cc * 4, (r - 1) * 4) < zorder(c * 4, r * 4); cc++) n++; s->tbl_top[r][c] = (u8)(4 * n); }
+        n = 0;
+        if (c == 0) s->tbl_left[r][c] = (u8)(64 - 4 * r);
+        else { for (int rr = r; rr < 16 && zorder((c - 1) * 4, rr * 4) < zorder(c * 4, r * 4); rr++) n++; s->tbl_left[r][c] = (u8)(4 * n); }
+      }
+      // coefficient buffers of all levels start zeroed like the lcu_t copies (search.c:1084)
+      for (int lv = 0; lv < 4; lv++) { i16 *cf = coeff_level(lv); for (int e = tid; e < 6144; e += KVZ_CTU_THREADS) cf[e] = 0; }
+    }
+    KVZ_SYNC();
+  }
+
+  // copy_lcu_to_cu_data (search.c:1180-1207): level 0 -> frame reconstruction + CU info; coefficients already there
+  KVZ_DEV void finish()
+  {
+    KVZ_FOR_THREADS(tid) {
+      for (int c = 0; c < 3; c++) {
+        const int sh = c ? 1 : 0, lw = 64 >> sh, fw = F.W >> sh, fh = F.H >> sh, ox = cx >> sh, oy = cy >> sh;
+        u8 *dst = const_cast<u8 *>(frame_rec(c));
+        for (int e = tid; e < lw * lw; e += KVZ_CTU_THREADS) {
+          const int px = ox + e % lw, py = oy + e / lw;
+          if (px < fw && py < fh) dst[(long)py * fw + px] = s->rec[0][kPlaneOff[c] + e];
+        }
+      }
+      if (tid < 64) {
+        const int fx = cx + (tid & 7) * 8, fy = cy + (tid >> 3) * 8;
+        if (fx < F.W && fy < F.H) {
+          const long i = (long)frame * (F.H >> 3) * (F.W >> 3) + (long)(fy >> 3) * (F.W >> 3) + (fx >> 3);
+          F.cu_depth[i] = s->cu[0][tid].depth;
+          F.cu_mode[i] = s->cu[0][tid].mode;
+        }
+      }
+      if (tid == 0) F.ctu_cost[(long)frame * F.wc * F.hc + ctu_index()] = s->cost[0];
+    }
+    KVZ_SYNC();
+  }
+
+  KVZ_DEV void set_cu_header(int lv, int xl, int yl, int depth)
+  {
+    KVZ_FOR_THREADS(tid) {
+      if (tid == 0) {  // search.c:694-700
+        CtuCu *c = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
+        c->depth = (u8)(depth > 3 ? 3 : depth); c->tr_depth = (u8)(depth > 0 ? depth : 1); c->type = 0;
+      }
+    }
+    KVZ_SYNC();
+  }
+
+  // The combine_intra_cus attempt of search.c:996-1044 at depth 0 or 1: reconstruct the whole CU with the mode of its
+  // top-left child and price it.  Result in s->cost[depth].
+  KVZ_DEV void try_merge(int x, int y, int depth)
+  {
+    const int w = 64 >> depth, xl = x - cx, yl = y - cy, lv = depth;
+    const CtuCu d1 = s->cu[depth + 1][(yl >> 3) * 8 + (xl >> 3)];  // uniform read
+    if (!(d1.type == 1 && d1.depth == depth + 1)) return;
+    const int mode = d1.mode;
+    fill_cu(lv, xl, yl, w, 1, depth, mode, depth > 0 ? depth : 1);
+    if (depth == 1) {
+      TuSet t{ x, y, 5, 4 };
+      recon_tus(lv, t, 1, mode);
+      KVZ_FOR_THREADS(tid) {
+        if (tid == 0) {
+          double bits = 0;
+          bits += (double)m->split_flag[split_model(lv, x, y, depth)][0];
+          const double mode_bits = intra_mode_syntax_bits(lv, x, y, mode) + bits;  // calc_mode_bits search.c:517-540
+          double cost = 0;
+          cost += mode_bits * m->lambda;
+          cost += leaf_rd_cost(lv, xl, yl, 1, 1, true, true);
+          s->cost[1] = cost;
+        }
+      }
+      KVZ_SYNC();
+      return;
+    }
+    // depth 0: four 32x32 transform units in z-order (intra.c:656-679), each predicted from the previous ones
+    for (int q = 0; q < 4; q++) {
+      const int qx = x + (q & 1) * 32, qy = y + (q >> 1) * 32;
+      TuSet t{ qx, qy, 5, 4 };
+      recon_tus(lv, t, 1, mode);
+      KVZ_FOR_THREADS(tid) { if (tid < 9) s->child_acc[q][tid] = s->acc[tid]; }
+      KVZ_SYNC();
+    }
+    KVZ_FOR_THREADS(tid) {
+      if (tid == 0) {
+        CtuCu *cu = &s->cu[lv][0];
+        // cbf_set_conditionally (intra.c:681-696): depth-0 bit if any of the other three children has a depth-1 bit
+        for (int c = 0; c < 3; c++) {
+          cbf_clear(&cu->cbf, 0, c);  // intra.c:641-647 cleared levels >= 0 before the recursion; the TL child then set its depth-1 bit
+        }
+        // re-apply the TL child's own depth-1 bits (they live in the same entry and were set during q = 0)
+        for (int c = 0; c < 3; c++) if (s->child_acc[0][6 + c]) cbf_set(&cu->cbf, 1, c);
+        for (int c = 0; c < 3; c++) {
+          const bool any_other = cbf_is_set(s->cu[lv][4].cbf, 1, c) || cbf_is_set(s->cu[lv][32].cbf, 1, c) || cbf_is_set(s->cu[lv][36].cbf, 1, c);
+          if (any_other) cbf_set(&cu->cbf, 0, c);
+        }
+        // cu_rd_cost_tr_split_accurate at depth 0 (search.c:425-541): chroma cbf at depth 0, then the four children
+        double tr_tree_bits = 0;
+        tr_tree_bits += (double)m->cbf_chroma[0][cbf_is_set(cu->cbf, 0, 1)];
+        tr_tree_bits += (double)m->cbf_chroma[0][cbf_is_set(cu->cbf, 0, 2)];
+        double sum = 0;
+        for (int q = 0; q < 4; q++) {
+          const int qxl = (q & 1) * 32, qyl = (q >> 1) * 32;
+          const CtuCu *tr_cu = &s->cu[lv][(qyl >> 3) * 8 + (qxl >> 3)];
+          for (int i = 0; i < 9; i++) s->acc[i] = s->child_acc[q][i];
+          // search.c:466-471: child cbf_cb/cbf_cr are coded when the entry has any chroma bit at depth >= 0
+          sum += leaf_rd_cost(lv, qxl, qyl, 1, 0, cbf_is_set(tr_cu->cbf, 0, 1), cbf_is_set(tr_cu->cbf, 0, 2));
+        }
+        const double rd = sum + tr_tree_bits * m->lambda;
+        double bits = 0;
+        bits += (double)m->split_flag[split_model(lv, x, y, 0)][0];
+        const double mode_bits = intra_mode_syntax_bits(lv, x, y, mode) + bits;
+        double cost = 0;
+        cost += mode_bits * m->lambda;
+        cost += rd;
+        s->cost[0] = cost;
+      }
+    }
+    KVZ_SYNC();
+  }
+
+  // search_cu for depth 2 (16x16) including its depth-3 children (search.c:646-1063)
+  KVZ_DEV void search_d2(int x, int y)
+  {
+    const int xl = x - cx, yl = y - cy;
+    if (x >= F.W || y >= F.H) { KVZ_FOR_THREADS(tid) { if (tid == 0) s->cost[2] = 0; } KVZ_SYNC(); return; }
+    set_cu_header(2, xl, yl, 2);
+    const bool inside = x + 16 <= F.W && y + 16 <= F.H;
+    KVZ_FOR_THREADS(tid) { if (tid == 0) { s->cost[2] = 1.7e+308; s->cbf_any = 0; } }
+    KVZ_SYNC();
+    if (inside) eval_cu(2, x, y, 2, &s->cost[2], &s->cbf_any);
+    KVZ_FOR_THREADS(tid) {
+      if (tid == 0) {
+        double split_bits = 0;
+        split_bits += (double)m->split_flag[split_model(2, x, y, 2)][1];
+        double sc = 0.0;
+        sc += split_bits * m->lambda;
+        if (inside && !s->cbf_any) sc = 2147483647;  // cu_split_termination = zero (search.c:975-984)
+        s->split_cost[2] = sc;
+      }
+    }
+    KVZ_SYNC();
+    if (!inside || s->cbf_any) {
+      for (int q = 0; q < 4; q++) {
+        if (!(s->split_cost[2] < s->cost[2])) break;  // uniform: both are LDS scalars
+        const int qx = x + (q & 1) * 8, qy = y + (q >> 1) * 8;
+        if (qx >= F.W || qy >= F.H) continue;  // child outside the picture costs 0
+        set_cu_header(3, qx - cx, qy - cy, 3);
+        eval_cu(3, qx, qy, 3, &s->cost[3], &s->cbf_any);
+        KVZ_FOR_THREADS(tid) { if (tid == 0) s->split_cost[2] += s->cost[3]; }
+        KVZ_SYNC();
+      }
+    }
+    if (s->split_cost[2] < s->cost[2]) {
+      KVZ_FOR_THREADS(tid) { if (tid == 0) s->cost[2] = s->split_cost[2]; }
+      KVZ_SYNC();
+      copy_region(3, 2, xl, yl, 16, true);  // work_tree_copy_up
+    } else {
+      copy_region(2, 3, xl, yl, 16, false);  // work_tree_copy_down
+    }
+  }
+
+  KVZ_DEV void run()
+  {
+    init();
+    set_cu_header(0, 0, 0, 0);
+    KVZ_FOR_THREADS(tid) {
+      if (tid == 0) { s->cost[0] = 1.7e+308; double sb = 0; sb += (double)m->split_flag[split_model(0, cx, cy, 0)][1]; double sc = 0.0; sc += sb * m->lambda; s->split_cost[0] = sc; }
+    }
+    KVZ_SYNC();
+    for (int q1 = 0; q1 < 4; q1++) {
+      const int x1 = cx + (q1 & 1) * 32, y1 = cy + (q1 >> 1) * 32;
+      if (x1 >= F.W || y1 >= F.H) continue;  // search_cu returns 0 outside the picture
+      set_cu_header(1, x1 - cx, y1 - cy, 1);
+      KVZ_FOR_THREADS(tid) {
+        if (tid == 0) { s->cost[1] = 1.7e+308; double sb = 0; sb += (double)m->split_flag[split_model(1, x1, y1, 1)][1]; double sc = 0.0; sc += sb * m->lambda; s->split_cost[1] = sc; }
+      }
+      KVZ_SYNC();
+      for (int q2 = 0; q2 < 4; q2++) {
+        search_d2(x1 + (q2 & 1) * 16, y1 + (q2 >> 1) * 16);
+        KVZ_FOR_THREADS(tid) { if (tid == 0) s->split_cost[1] += s->cost[2]; }
+        KVZ_SYNC();
+      }
+      if (x1 + 32 <= F.W && y1 + 32 <= F.H) try_merge(x1, y1, 1);
+      if (s->split_cost[1] < s->cost[1]) {
+        KVZ_FOR_THREADS(tid) { if (tid == 0) s->cost[1] = s->split_cost[1]; }
+        KVZ_SYNC();
+        copy_region(2, 1, x1 - cx, y1 - cy, 32, true);
+      } else {
+        for (int lv = 2; lv < 4; lv++) copy_region(1, lv, x1 - cx, y1 - cy, 32, false);
+      }
+      KVZ_FOR_THREADS(tid) { if (tid == 0) s->split_cost[0] += s->cost[1]; }
+      KVZ_SYNC();
+    }
+    if (cx + 64 <= F.W && cy + 64 <= F.H) try_merge(cx, cy, 0);
+    if (s->split_cost[0] < s->cost[0]) {
+      KVZ_FOR_THREADS(tid) { if (tid == 0) s->cost[0] = s->split_cost[0]; }
+      KVZ_SYNC();
+      copy_region(1, 0, 0, 0, 64, true);
+    }
+    finish();
+  }
+};
+
+}  // namespace kvz

@@ -140,3 +140,6 @@ int kvz_hip_init(int device)
 const char *kvz_hip_version(void) { return "kvz_hip 0.1 (gfx950)"; }
 unsigned long long kvz_hip_call_count(void) { return kvz::runtime().calls.load(); }
 }
+
+// ---- batched, device-resident path (include/kvz_hip_batch.h) ------------------------------------------------------
+#include "kvz_batch.hpp"

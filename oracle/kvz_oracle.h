@@ -123,6 +123,12 @@ void kvz_oracle_sao_reconstruct_color(const kvz_hip_sao_params *sao, const uint8
 int  kvz_oracle_sao_band_ddistortion(int bitdepth, const uint8_t *orig, const uint8_t *rec, int bw, int bh,
                                      int band_pos, const int sao_bands[4]);
 
+/* ---- batched all-intra CTU pass (kvz_oracle_ctu.c) ---- */
+void kvz_oracle_intra_frame(const kvz_hip_intra_cost_model *m, int width, int height, const uint8_t *src_y, const uint8_t *src_u,
+                            const uint8_t *src_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, int16_t *coeff, uint8_t *cu_depth,
+                            uint8_t *cu_mode, double *ctu_cost);
+void kvz_oracle_intra_cost_model(int qp, const float entropy_fbits[128], uint64_t coeff_weights, kvz_hip_intra_cost_model *m);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,581 @@
+/*
+ * kvz_oracle_ctu.c -- TEST INFRASTRUCTURE (see kvz_oracle.h).  CPU restatement of the all-intra CTU search +
+ * reconstruction that the batched device pass (include/kvz_hip_batch.h, kvz_hip_intra_frames) implements.
+ *
+ * It restates kvazaar v2.3.2's per-CTU flow for an I slice under the `ultrafast` preset
+ *   (cfg.c:485-512: rd=0, pu-depth-intra 2-3, rdoq 0, signhide 0, transform-skip 0, fast-residual-cost > QP,
+ *    cu-split-termination zero, combine_intra_cus on (cfg.c:187), tr_depth_intra 0, 4:2:0, 8 bit)
+ * function by function, recursion and work-tree copies included:
+ *   search_cu                      search.c:646-1063     -> search_cu()
+ *   kvz_search_cu_intra            search_intra.c:812    -> search_cu_intra()
+ *   search_intra_rough             search_intra.c:391    -> rough_search()
+ *   kvz_luma_mode_bits             search_intra.c:641    -> luma_mode_bits()
+ *   kvz_intra_get_dir_luma_predictor  intra.c:84         -> mpm_candidates()
+ *   kvz_intra_build_reference_any  intra.c:305           -> build_reference()
+ *   kvz_intra_predict              intra.c:252           -> intra_predict()
+ *   kvz_intra_recon_cu             intra.c:623           -> recon_cu()
+ *   kvz_quantize_lcu_residual      transform.c:439       -> (inside recon_cu: leaf TUs only, tr_depth_intra = 0)
+ *   kvz_mock_encode_coding_unit    encode_coding_tree.c:948 + encode_intra_coding_unit :467 -> cu_bits()
+ *   calc_mode_bits                 search.c:517          -> calc_mode_bits()
+ *   cu_rd_cost_tr_split_accurate   search.c:425          -> rd_cost()
+ * The pixel/coefficient kernels are the pinned kvz_oracle_* functions of kvz_oracle.c.
+ *
+ * ONE documented divergence from the encoder: CABAC contexts are FROZEN at their slice-init state
+ * (kvz_hip_intra_cost_model), i.e. the `cabac->update` side effects of CABAC_FBITS_UPDATE (cabac.h:133-139) and
+ * the carry-over of state->cabac between CTUs (search.c:1211) are not modelled.  That is what makes CTUs
+ * independent up to reconstructed pixels, and it is why the batched pass does not reproduce kvazaar's bitstream
+ * (the per-call drop-in does; tests/test_e2e_dropin.py).  Decisions are otherwise kvazaar's own formulas, in
+ * double precision with the reference's operation order.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "kvz_oracle.h"
+
+/* context.c:202-213 kvz_ctx_init: init value + QP -> uc_state */
+static int ctx_state(int qp, int init_value)
+{
+  int slope = (init_value >> 4) * 5 - 45, offset = ((init_value & 15) << 3) - 16;
+  int st = ((slope * qp) >> 4) + offset;
+  st = st < 1 ? 1 : st > 126 ? 126 : st;
+  return st >= 64 ? ((st - 64) << 1) + 1 : (63 - st) << 1;
+}
+
+#define LCU 64
+#define NLEVELS 5
+#define MAX_COST 1.7e+308 /* global.h:293 MAX_DOUBLE */
+
+typedef struct { uint8_t type /* 0 not set, 1 intra */, depth, mode, tr_depth; uint16_t cbf; } cu_t;
+
+typedef struct {
+  uint8_t rec[3][LCU * LCU];
+  int16_t coeff[3][LCU * LCU];
+  cu_t cu[16 * 16]; /* one per 4x4 SCU */
+} level_t;
+
+typedef struct {
+  const kvz_hip_intra_cost_model *m;
+  int W, H;                  /* luma frame size */
+  const uint8_t *src[3];     /* source planes, stride W (luma) / W/2 */
+  uint8_t *frec[3];          /* frame reconstruction */
+  uint8_t *fdepth, *fmode;   /* frame CU info per 8x8 (stride W/8) */
+  int cx, cy;                /* luma origin of the current CTU */
+  uint8_t org[3][LCU * LCU]; /* lcu->ref, zero outside the picture (search.c:1084 FILL) */
+  level_t lv[NLEVELS];
+  uint8_t tbl_top[16][16], tbl_left[16][16];
+} ctu_t;
+
+/* ---- cbf bit helpers (cu.h:510-569: 5 depth bits per plane, is_set tests levels >= depth) ---- */
+static const uint16_t cbf_masks[5] = { 0x1f, 0x0f, 0x07, 0x03, 0x1 };
+static int cbf_is_set(uint16_t cbf, int depth, int plane) { return (cbf & (cbf_masks[depth] << (5 * plane))) != 0; }
+static int cbf_is_set_any(uint16_t cbf, int depth) { return cbf_is_set(cbf, depth, 0) || cbf_is_set(cbf, depth, 1) || cbf_is_set(cbf, depth, 2); }
+static void cbf_set(uint16_t *cbf, int depth, int plane) { *cbf |= (0x10 >> depth) << (5 * plane); }
+static void cbf_clear(uint16_t *cbf, int depth, int plane) { *cbf &= ~(cbf_masks[depth] << (5 * plane)); }
+
+static unsigned zorder(int x, int y) /* cu.h:385-421 with width 64: Morton index of the 4x4 block times 16 */
+{
+  unsigned r = 0;
+  for (int b = 0; b < 4; b++) r |= (((x >> (2 + b)) & 1) << (2 * b)) | (((y >> (2 + b)) & 1) << (2 * b + 1));
+  return r * 16;
+}
+
+/* intra.c:47-82 num_ref_pixels_{top,left}: how many reference pixels to the right / below are already coded for
+ * the 4x4 unit at (c, r) -- a pure function of z-order (tools/generate_ref_pixel_tables.py), regenerated here. */
+static int zidx(int c, int r) { int v = 0; for (int b = 0; b < 4; b++) v |= ((c >> b) & 1) << (2 * b) | ((r >> b) & 1) << (2 * b + 1); return v; }
+static void build_avail_tables(ctu_t *t)
+{
+  for (int r = 0; r < 16; r++)
+    for (int c = 0; c < 16; c++) {
+      int n = 0;
+      if (r == 0) t->tbl_top[r][c] = 64;
+      else { for (int cc = c; cc < 16 && zidx(cc, r - 1) < zidx(c, r); cc++) n++; t->tbl_top[r][c] = (uint8_t)(4 * n); }
+      n = 0;
+      if (c == 0) t->tbl_left[r][c] = (uint8_t)(64 - 4 * r);
+      else { for (int rr = r; rr < 16 && zidx(c - 1, rr) < zidx(c, r); rr++) n++; t->tbl_left[r][c] = (uint8_t)(4 * n); }
+    }
+}
+
+static cu_t *cu_at(level_t *lv, int xl, int yl) { return &lv->cu[(yl >> 2) * 16 + (xl >> 2)]; }
+
+/* CU info of a neighbour at luma frame position (fx, fy): inside the current CTU from the work-tree level, otherwise
+ * from the frame arrays (init_lcu_t copies those into the lcu_t border, search.c:1088-1120).  NULL = not available. */
+static int neighbour_cu(ctu_t *t, level_t *lv, int fx, int fy, cu_t *out)
+{
+  if (fx < 0 || fy < 0 || fx >= t->W || fy >= t->H) return 0;
+  if (fx >= t->cx && fx < t->cx + LCU && fy >= t->cy && fy < t->cy + LCU) { *out = *cu_at(lv, fx - t->cx, fy - t->cy); return 1; }
+  const int i = (fy >> 3) * (t->W >> 3) + (fx >> 3);
+  out->type = 1; out->depth = t->fdepth[i]; out->mode = t->fmode[i]; out->tr_depth = out->depth; out->cbf = 0;
+  return 1;
+}
+
+/* reconstructed pixel of plane c at plane coordinates (px, py): current CTU -> level buffer, else frame */
+static uint8_t rec_px(ctu_t *t, level_t *lv, int c, int px, int py)
+{
+  const int sh = c ? 1 : 0, w = LCU >> sh, ox = t->cx >> sh, oy = t->cy >> sh;
+  if (px >= ox && px < ox + w && py >= oy && py < oy + w) return lv->rec[c][(py - oy) * w + (px - ox)];
+  return t->frec[c][py * (t->W >> sh) + px];
+}
+
+/* intra.c:305-425 kvz_intra_build_reference_any (the _inner variant :427-543 is the same function away from the
+ * picture edge when the picture size is a multiple of 8).  refs = [2w+1], index 0 = top-left corner. */
+static void build_reference(ctu_t *t, level_t *lv, int log2w, int c, int lx, int ly /* luma frame coords */, uint8_t *top, uint8_t *left)
+{
+  const int sh = c ? 1 : 0, w = 1 << log2w;
+  const int px = lx >> sh, py = ly >> sh; /* plane coords */
+  const int llx = lx & 63, lly = ly & 63;
+  if (lx > 0) {
+    int avail = t->tbl_left[lly / 4][llx / 4] >> sh;
+    if (avail > 2 * w) avail = 2 * w;
+    if (avail > ((t->H - ly) >> sh)) avail = (t->H - ly) >> sh;
+    for (int i = 0; i < avail; i++) left[i + 1] = rec_px(t, lv, c, px - 1, py + i);
+    const uint8_t nearest = left[avail];
+    for (int i = avail; i < 2 * w; i++) left[i + 1] = nearest;
+  } else {
+    const uint8_t nearest = ly > 0 ? rec_px(t, lv, c, px, py - 1) : 128;
+    for (int i = 0; i < 2 * w; i++) left[i + 1] = nearest;
+  }
+  if (lx > 0 && ly > 0) left[0] = top[0] = rec_px(t, lv, c, px - 1, py - 1);
+  else left[0] = top[0] = left[1];
+  if (ly > 0) {
+    int avail = t->tbl_top[lly / 4][llx / 4] >> sh;
+    if (avail > 2 * w) avail = 2 * w;
+    if (avail > ((t->W - lx) >> sh)) avail = (t->W - lx) >> sh;
+    for (int i = 0; i < avail; i++) top[i + 1] = rec_px(t, lv, c, px + i, py - 1);
+    const uint8_t nearest = rec_px(t, lv, c, px + avail - 1, py - 1);
+    for (int i = avail; i < 2 * w; i++) top[i + 1] = nearest;
+  } else {
+    const uint8_t nearest = lx > 0 ? rec_px(t, lv, c, px - 1, py) : 128;
+    for (int i = 0; i < 2 * w; i++) top[i + 1] = nearest;
+  }
+}
+
+/* intra.c:176-204 intra_filter_reference ([1 2 1] smoothing) */
+static void filter_reference(int log2w, const uint8_t *top, const uint8_t *left, uint8_t *ftop, uint8_t *fleft)
+{
+  const int n = 2 * (1 << log2w) + 1;
+  fleft[0] = ftop[0] = (uint8_t)((left[1] + 2 * left[0] + top[1] + 2) / 4);
+  for (int i = 1; i < n - 1; i++) {
+    fleft[i] = (uint8_t)((left[i - 1] + 2 * left[i] + left[i + 1] + 2) / 4);
+    ftop[i] = (uint8_t)((top[i - 1] + 2 * top[i] + top[i + 1] + 2) / 4);
+  }
+  fleft[n - 1] = left[n - 1];
+  ftop[n - 1] = top[n - 1];
+}
+
+/* intra.c:252-301 kvz_intra_predict (filter_boundary = luma; lossless off) */
+static void intra_predict(int log2w, int mode, int c, const uint8_t *top, const uint8_t *left, uint8_t *dst)
+{
+  const int w = 1 << log2w;
+  uint8_t ftop[2 * 32 + 1], fleft[2 * 32 + 1];
+  const uint8_t *ut = top, *ul = left;
+  int use_filtered = 0;
+  if (c != 0 || mode == 1 || w == 4) use_filtered = 0;
+  else if (mode == 0) use_filtered = 1;
+  else {
+    static const int thres[5] = { 0, 7, 1, 0, 0 };
+    const int d26 = abs(mode - 26), d10 = abs(mode - 10);
+    if ((d26 < d10 ? d26 : d10) > thres[log2w - 2]) use_filtered = 1;
+  }
+  if (use_filtered) { filter_reference(log2w, top, left, ftop, fleft); ut = ftop; ul = fleft; }
+  if (mode == 0) kvz_oracle_intra_pred_planar(log2w, ut, ul, dst);
+  else if (mode == 1) {
+    if (c == 0 && w < 32) kvz_oracle_intra_pred_filtered_dc(log2w, ut, ul, dst);
+    else { /* intra.c:229-249 intra_pred_dc */
+      int sum = 0;
+      for (int i = 0; i < w; i++) sum += ut[i + 1] + ul[i + 1];
+      memset(dst, (uint8_t)((sum + w) >> (log2w + 1)), w * w);
+    }
+  } else {
+    kvz_oracle_angular_pred(log2w, mode, ut, ul, dst);
+    if (c == 0 && w < 32 && (mode == 10 || mode == 26)) { /* intra.c:207-219 intra_post_process_angular */
+      const uint8_t *ref = mode == 10 ? ut : ul;
+      const int stride = mode == 10 ? 1 : w;
+      for (int i = 0; i < w; i++) {
+        int v = dst[i * stride] + ((ref[i + 1] - ref[0]) >> 1);
+        dst[i * stride] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+      }
+    }
+  }
+}
+
+/* intra.c:84-126 kvz_intra_get_dir_luma_predictor */
+static void mpm_candidates(int y, const cu_t *left, const cu_t *above, int8_t preds[3])
+{
+  int l = 1, a = 1;
+  if (left && left->type == 1) l = left->mode;
+  if (above && above->type == 1 && y % LCU != 0) a = above->mode;
+  if (l == a) {
+    if (l > 1) { preds[0] = (int8_t)l; preds[1] = (int8_t)(((l + 29) % 32) + 2); preds[2] = (int8_t)(((l - 1) % 32) + 2); }
+    else { preds[0] = 0; preds[1] = 1; preds[2] = 26; }
+  } else {
+    preds[0] = (int8_t)l; preds[1] = (int8_t)a;
+    if (l && a) preds[2] = 0; else preds[2] = (l + a) < 2 ? 26 : 1;
+  }
+}
+
+/* search_intra.c:641-676 kvz_luma_mode_bits (only_count path) */
+static double luma_mode_bits(const kvz_hip_intra_cost_model *m, int mode, const int8_t preds[3])
+{
+  double bits = 0;
+  int in = 0;
+  for (int i = 0; i < 3; i++) if (mode == preds[i]) in = 1;
+  bits += m->intra_mode[in];
+  if (in) bits += (mode == preds[0]) ? 1 : 2; else bits += 5;
+  return bits;
+}
+
+/* search_intra.c:391-530 search_intra_rough (trskip off).  Returns the number of modes tried. */
+static int rough_search(ctu_t *t, int log2w, const uint8_t *orig /* contiguous */, const uint8_t *top, const uint8_t *left,
+                        const int8_t preds[3], int8_t modes[35], double costs[35])
+{
+  const int w = 1 << log2w;
+  static const int8_t offsets[4] = { 2, 4, 8, 8 };
+  uint8_t pr[2 * 1024];
+  unsigned sc[2];
+  int n = 0, offset = offsets[log2w - 2];
+  int32_t min_cost = 0x7fffffff, max_cost = -0x7fffffff - 1;
+  for (int mode = 2; mode <= 34; mode += 2 * offset) {
+    for (int i = 0; i < 2; i++) if (mode + i * offset <= 34) intra_predict(log2w, mode + i * offset, 0, top, left, pr + 1024 * i);
+    kvz_oracle_satd_nxn_dual(w, pr, orig, 2, sc);
+    for (int i = 0; i < 2; i++) if (mode + i * offset <= 34) {
+      costs[n] = (double)sc[i]; modes[n] = (int8_t)(mode + i * offset);
+      if (costs[n] < min_cost) min_cost = (int32_t)costs[n];
+      if (costs[n] > max_cost) max_cost = (int32_t)costs[n];
+      n++;
+    }
+  }
+  int bi = 0;
+  for (int i = 1; i < n; i++) if (costs[i] < costs[bi]) bi = i;
+  int8_t best_mode = modes[bi];
+  double best_cost = min_cost;
+  if (min_cost != max_cost) {
+    while (offset > 1) {
+      offset >>= 1;
+      const int8_t tm[2] = { (int8_t)(best_mode - offset), (int8_t)(best_mode + offset) };
+      int in_range = 0;
+      for (int i = 0; i < 2; i++) in_range |= (tm[i] >= 2 && tm[i] <= 34);
+      if (!in_range) continue;
+      for (int i = 0; i < 2; i++) if (tm[i] >= 2 && tm[i] <= 34) intra_predict(log2w, tm[i], 0, top, left, pr + 1024 * i);
+      kvz_oracle_satd_nxn_dual(w, pr, orig, 2, sc);
+      for (int i = 0; i < 2; i++) if (tm[i] >= 2 && tm[i] <= 34) {
+        costs[n] = (double)sc[i]; modes[n] = tm[i];
+        if (costs[n] < best_cost) { best_cost = costs[n]; best_mode = modes[n]; }
+        n++;
+      }
+    }
+  }
+  const int8_t add_modes[5] = { preds[0], preds[1], preds[2], 0, 1 };
+  for (int p = 0; p < 5; p++) {
+    int has = 0;
+    for (int i = 0; i < n; i++) if (modes[i] == add_modes[p]) { has = 1; break; }
+    if (!has) {
+      intra_predict(log2w, add_modes[p], 0, top, left, pr);
+      costs[n] = (double)kvz_oracle_satd_nxn(w, pr, orig);
+      modes[n] = add_modes[p];
+      n++;
+    }
+  }
+  for (int i = 0; i < n; i++) costs[i] += t->m->lambda_sqrt * luma_mode_bits(t->m, modes[i], preds);
+  return n;
+}
+
+/* search_intra.c:812-900 kvz_search_cu_intra (rd=0: rough search only) */
+static int search_cu_intra(ctu_t *t, level_t *lv, int x, int y, int depth)
+{
+  const int log2w = 6 - depth, w = 1 << log2w, xl = x - t->cx, yl = y - t->cy;
+  cu_t lc, ac, *left = NULL, *above = NULL;
+  if (x >= 4 && neighbour_cu(t, lv, x - 1, y, &lc)) left = &lc;
+  if (y >= 4 && yl > 0 && neighbour_cu(t, lv, x, y - 1, &ac)) above = &ac;
+  int8_t preds[3], modes[35];
+  double costs[35];
+  mpm_candidates(y, left, above, preds);
+  uint8_t top[2 * 32 + 1], lft[2 * 32 + 1], orig[32 * 32];
+  build_reference(t, lv, log2w, 0, x, y, top, lft);
+  for (int r = 0; r < w; r++) memcpy(orig + r * w, &t->org[0][(yl + r) * LCU + xl], w);
+  const int n = rough_search(t, log2w, orig, top, lft, preds, modes, costs);
+  int bi = 0;
+  for (int i = 1; i < n; i++) if (costs[i] < costs[bi]) bi = i;
+  return modes[bi];
+}
+
+/* One leaf TU: intra_recon_tb_leaf (intra.c:561-608) + quantize_tr_residual (transform.c:294-412).  Returns has_coeffs. */
+static int recon_tu(ctu_t *t, level_t *lv, int c, int x, int y /* luma frame coords */, int log2w, int mode)
+{
+  const int sh = c ? 1 : 0, w = 1 << log2w, lw = LCU >> sh;
+  const int xl = (x - t->cx) >> sh, yl = (y - t->cy) >> sh;
+  uint8_t top[2 * 32 + 1], lft[2 * 32 + 1], pred[32 * 32];
+  build_reference(t, lv, log2w, c, x, y, top, lft);
+  intra_predict(log2w, mode, c, top, lft, pred);
+  uint8_t *rec = &lv->rec[c][yl * lw + xl];
+  for (int r = 0; r < w; r++) memcpy(rec + r * lw, pred + r * w, w);
+  kvz_hip_quant_params p;
+  memset(&p, 0, sizeof p);
+  p.qp = t->m->qp; p.bitdepth = 8; p.slice_is_intra = 1; p.cu_is_intra = 1;
+  int16_t *coeff = &lv->coeff[c][zorder(xl, yl)];
+  return kvz_oracle_quantize_residual(&p, w, c, 0, 0, lw, lw, &t->org[c][yl * lw + xl], rec, rec, coeff, 0);
+}
+
+/* intra.c:623-717 kvz_intra_recon_cu: depth 0 splits into four 32x32 transform units (tr_depth = 1), every other
+ * depth is one luma TU (+ chroma TUs of half the size, 4x4 for 8x8 CUs; transform.c:322-328). */
+static void recon_cu(ctu_t *t, level_t *lv, int x, int y, int depth, int mode, int do_luma, int do_chroma)
+{
+  const int w = LCU >> depth;
+  cu_t *cu = cu_at(lv, x - t->cx, y - t->cy);
+  if (do_luma) cbf_clear(&cu->cbf, depth, 0);
+  if (do_chroma) { cbf_clear(&cu->cbf, depth, 1); cbf_clear(&cu->cbf, depth, 2); }
+  if (depth == 0) {
+    const int o = w / 2;
+    recon_cu(t, lv, x, y, 1, mode, do_luma, do_chroma);
+    recon_cu(t, lv, x + o, y, 1, mode, do_luma, do_chroma);
+    recon_cu(t, lv, x, y + o, 1, mode, do_luma, do_chroma);
+    recon_cu(t, lv, x + o, y + o, 1, mode, do_luma, do_chroma);
+    const uint16_t ch[3] = { cu_at(lv, x - t->cx + o, y - t->cy)->cbf, cu_at(lv, x - t->cx, y - t->cy + o)->cbf, cu_at(lv, x - t->cx + o, y - t->cy + o)->cbf };
+    for (int c = 0; c < 3; c++) {
+      if ((c == 0 && !do_luma) || (c > 0 && !do_chroma)) continue;
+      if (cbf_is_set(ch[0], 1, c) || cbf_is_set(ch[1], 1, c) || cbf_is_set(ch[2], 1, c)) cbf_set(&cu->cbf, 0, c); /* cbf_set_conditionally */
+    }
+    return;
+  }
+  const int log2w = 6 - depth;
+  if (do_luma) {
+    cbf_clear(&cu->cbf, depth, 0);
+    if (recon_tu(t, lv, 0, x, y, log2w, mode)) cbf_set(&cu->cbf, depth, 0);
+  }
+  if (do_chroma && x % 8 == 0 && y % 8 == 0) {
+    const int cl2 = depth == 3 ? 2 : log2w - 1; /* transform.c:326-327 */
+    for (int c = 1; c <= 2; c++) {
+      cbf_clear(&cu->cbf, depth, c);
+      if (recon_tu(t, lv, c, x, y, cl2, mode)) cbf_set(&cu->cbf, depth, c);
+    }
+  }
+}
+
+/* search.c:425-541 cu_rd_cost_tr_split_accurate (intra CU, frozen contexts, fast coefficient cost rdo.c:311-326) */
+static double rd_cost(ctu_t *t, level_t *lv, int xl, int yl, int depth, const cu_t *pred_cu)
+{
+  const kvz_hip_intra_cost_model *m = t->m;
+  const int width = LCU >> depth;
+  const cu_t *tr_cu = cu_at(lv, xl, yl);
+  double coeff_bits = 0, tr_tree_bits = 0;
+  const int tr_depth = tr_cu->tr_depth - depth;
+  const int cb_u = cbf_is_set(tr_cu->cbf, depth, 1), cb_v = cbf_is_set(tr_cu->cbf, depth, 2);
+  (void)pred_cu;
+  /* transform_tree split flag: never coded with tr_depth_intra = 0 (search.c:451-464) */
+  if (tr_cu->depth == depth || cbf_is_set(tr_cu->cbf, depth - 1, 1)) tr_tree_bits += m->cbf_chroma[depth - tr_cu->depth][cb_u];
+  if (tr_cu->depth == depth || cbf_is_set(tr_cu->cbf, depth - 1, 2)) tr_tree_bits += m->cbf_chroma[depth - tr_cu->depth][cb_v];
+  if (tr_depth > 0) {
+    const int o = LCU >> (depth + 1);
+    double sum = 0;
+    sum += rd_cost(t, lv, xl, yl, depth + 1, pred_cu);
+    sum += rd_cost(t, lv, xl + o, yl, depth + 1, pred_cu);
+    sum += rd_cost(t, lv, xl, yl + o, depth + 1, pred_cu);
+    sum += rd_cost(t, lv, xl + o, yl + o, depth + 1, pred_cu);
+    return sum + tr_tree_bits * m->lambda;
+  }
+  const int cb_y = cbf_is_set(tr_cu->cbf, depth, 0);
+  const int is_tr_split = depth - tr_cu->depth;
+  tr_tree_bits += m->cbf_luma[!is_tr_split][cb_y];
+  unsigned luma_ssd = kvz_oracle_pixels_calc_ssd(&t->org[0][yl * LCU + xl], &lv->rec[0][yl * LCU + xl], LCU, LCU, width);
+  if (cb_y) coeff_bits += kvz_oracle_fast_coeff_cost(&lv->coeff[0][zorder(xl, yl)], width, m->coeff_weights);
+  unsigned chroma_ssd = 0;
+  if (xl % 8 == 0 && yl % 8 == 0) {
+    const int cw = depth <= 3 ? LCU >> (depth + 1) : LCU >> depth, i = (yl / 2) * 32 + xl / 2;
+    chroma_ssd = kvz_oracle_pixels_calc_ssd(&t->org[1][i], &lv->rec[1][i], 32, 32, cw) + kvz_oracle_pixels_calc_ssd(&t->org[2][i], &lv->rec[2][i], 32, 32, cw);
+    const unsigned zi = zorder(xl / 2, yl / 2);
+    if (cb_u) coeff_bits += kvz_oracle_fast_coeff_cost(&lv->coeff[1][zi], cw, m->coeff_weights);
+    if (cb_v) coeff_bits += kvz_oracle_fast_coeff_cost(&lv->coeff[2][zi], cw, m->coeff_weights);
+  }
+  const double bits = tr_tree_bits + coeff_bits;
+  return luma_ssd * 0.8 + chroma_ssd * 1.5 + bits * m->lambda; /* KVZ_LUMA_MULT / KVZ_CHROMA_MULT search.h:50-56 */
+}
+
+/* search.c:629-635 get_ctx_cu_split_model == the split_model of encode_coding_tree.c:985-994 */
+static int split_model(ctu_t *t, level_t *lv, int x, int y, int depth)
+{
+  cu_t n;
+  int model = 0;
+  if (x > 0 && neighbour_cu(t, lv, x - 1, y, &n) && n.depth > depth) model++;
+  if (y > 0 && neighbour_cu(t, lv, x, y - 1, &n) && n.depth > depth) model++;
+  return model;
+}
+
+/* intra-mode part of the CU syntax: prev_intra_luma_pred_flag + mpm_idx / rem_intra_luma_pred_mode + chroma mode
+ * (encode_coding_tree.c:467-652; chroma mode == luma mode -> one context bin "0") */
+static double intra_mode_syntax_bits(ctu_t *t, level_t *lv, int x, int y, int mode, int with_chroma)
+{
+  cu_t lc, ac, *left = NULL, *above = NULL;
+  if (x > 0 && neighbour_cu(t, lv, x - 1, y, &lc)) left = &lc;
+  if (y % LCU > 0 && y > 0 && neighbour_cu(t, lv, x, y - 1, &ac)) above = &ac;
+  int8_t preds[3];
+  mpm_candidates(y, left, above, preds);
+  double bits = luma_mode_bits(t->m, mode, preds);
+  if (with_chroma) bits += t->m->chroma_mode[0];
+  return bits;
+}
+
+/* encode_coding_tree.c:948-1049 kvz_mock_encode_coding_unit for an intra 2Nx2N CU in an I slice */
+static double cu_bits(ctu_t *t, level_t *lv, int x, int y, int depth, int mode)
+{
+  double bits = 0;
+  const int w = LCU >> depth;
+  if (depth != 3 && !(t->W < x + w || t->H < y + w)) bits += t->m->split_flag[split_model(t, lv, x, y, depth)][0];
+  if (depth == 3) bits += t->m->part_size[1];
+  /* encode_intra_coding_unit adds the flag first and the bypass bins after it; same sum order as luma_mode_bits */
+  bits += intra_mode_syntax_bits(t, lv, x, y, mode, 1);
+  return bits;
+}
+
+static void fill_cu(level_t *lv, int xl, int yl, int w, const cu_t *src) /* search.c:137-159 lcu_fill_cu_info (+ tr_depth) */
+{
+  for (int yy = yl; yy < yl + w; yy += 4)
+    for (int xx = xl; xx < xl + w; xx += 4) { cu_t *c = cu_at(lv, xx, yy); c->type = src->type; c->depth = src->depth; c->mode = src->mode; c->tr_depth = src->tr_depth; }
+}
+
+static void copy_region(ctu_t *t, level_t *from, level_t *to, int xl, int yl, int w, int coeffs) /* search.c:55-100 copy_cu_{info,pixels,coeffs} */
+{
+  (void)t;
+  for (int yy = yl; yy < yl + w; yy += 4) for (int xx = xl; xx < xl + w; xx += 4) *cu_at(to, xx, yy) = *cu_at(from, xx, yy);
+  for (int r = 0; r < w; r++) memcpy(&to->rec[0][(yl + r) * LCU + xl], &from->rec[0][(yl + r) * LCU + xl], w);
+  for (int c = 1; c <= 2; c++) for (int r = 0; r < w / 2; r++) memcpy(&to->rec[c][(yl / 2 + r) * 32 + xl / 2], &from->rec[c][(yl / 2 + r) * 32 + xl / 2], w / 2);
+  if (coeffs) {
+    memcpy(&to->coeff[0][zorder(xl, yl)], &from->coeff[0][zorder(xl, yl)], w * w * sizeof(int16_t));
+    for (int c = 1; c <= 2; c++) memcpy(&to->coeff[c][zorder(xl / 2, yl / 2)], &from->coeff[c][zorder(xl / 2, yl / 2)], (w / 2) * (w / 2) * sizeof(int16_t));
+  }
+}
+
+/* search.c:646-1063 search_cu, I slice, pu_depth_intra = [2,3] */
+static double search_cu(ctu_t *t, int x, int y, int depth)
+{
+  const kvz_hip_intra_cost_model *m = t->m;
+  const int w = LCU >> depth, xl = x - t->cx, yl = y - t->cy;
+  level_t *lv = &t->lv[depth];
+  double cost = MAX_COST;
+  if (x >= t->W || y >= t->H) return 0;
+  cu_t *cur = cu_at(lv, xl, yl);
+  cur->depth = (uint8_t)(depth > 3 ? 3 : depth);
+  cur->tr_depth = (uint8_t)(depth > 0 ? depth : 1);
+  cur->type = 0;
+  const int inside = x + w <= t->W && y + w <= t->H;
+  if (inside && depth >= 2 && depth <= 3) {
+    const int mode = search_cu_intra(t, lv, x, y, depth);
+    cur->type = 1; cur->mode = (uint8_t)mode;
+    fill_cu(lv, xl, yl, w, cur);
+    recon_cu(t, lv, x, y, depth, mode, 1, 0);
+    if (x % 8 == 0 && y % 8 == 0) recon_cu(t, lv, x, y, depth, mode, 0, 1);
+  }
+  if (cur->type == 1) {
+    const double bits = cu_bits(t, lv, x, y, depth, cur->mode);
+    cost = bits * m->lambda;
+    cost += rd_cost(t, lv, xl, yl, depth, cur);
+  }
+  const int can_split = cur->type == 0 || depth < 3;
+  if (can_split) {
+    const int half = w / 2;
+    double split_cost = 0.0;
+    const int cbf = cbf_is_set_any(cur->cbf, depth);
+    double split_bits = 0;
+    if (depth < 3) split_bits += m->split_flag[split_model(t, lv, x, y, depth)][1];
+    split_cost += split_bits * m->lambda;
+    if (cur->type == 0 || cbf) {
+      if (split_cost < cost) split_cost += search_cu(t, x, y, depth + 1);
+      if (split_cost < cost) split_cost += search_cu(t, x + half, y, depth + 1);
+      if (split_cost < cost) split_cost += search_cu(t, x, y + half, depth + 1);
+      if (split_cost < cost) split_cost += search_cu(t, x + half, y + half, depth + 1);
+    } else {
+      split_cost = 2147483647; /* INT_MAX */
+    }
+    /* search.c:996-1044 combine_intra_cus: try the top-left child's mode for the whole CU */
+    if (cur->type == 0 && depth < 4 && inside) {
+      const cu_t *d1 = cu_at(&t->lv[depth + 1], xl, yl);
+      if (d1->type == 1 && d1->depth == depth + 1) {
+        cost = 0;
+        double bits = 0;
+        if (depth < 3) bits += m->split_flag[split_model(t, lv, x, y, depth)][0];
+        cur->mode = d1->mode; cur->type = 1;
+        fill_cu(lv, xl, yl, w, cur);
+        recon_cu(t, lv, x, y, depth, cur->mode, 1, 1);
+        const double mode_bits = intra_mode_syntax_bits(t, lv, x, y, cur->mode, 1) /* calc_mode_bits search.c:517-540 */ + bits;
+        cost += mode_bits * m->lambda;
+        cost += rd_cost(t, lv, xl, yl, depth, cur);
+      }
+    }
+    if (split_cost < cost) {
+      cost = split_cost;
+      copy_region(t, &t->lv[depth + 1], lv, xl, yl, w, 1); /* work_tree_copy_up */
+    } else if (depth > 0) {
+      for (int i = depth + 1; i < NLEVELS; i++) copy_region(t, lv, &t->lv[i], xl, yl, w, 0); /* work_tree_copy_down */
+    }
+  } else if (depth >= 0 && depth < 4) {
+    for (int i = depth + 1; i < NLEVELS; i++) copy_region(t, lv, &t->lv[i], xl, yl, w, 0);
+  }
+  return cost;
+}
+
+/* kvz_search_lcu (search.c:1209-1249): init the work tree for the CTU at (cx, cy), search, copy the result out. */
+static double encode_ctu(ctu_t *t, int cx, int cy, int16_t *coeff_out)
+{
+  t->cx = cx; t->cy = cy;
+  memset(t->lv, 0, sizeof t->lv);
+  memset(t->org, 0, sizeof t->org);
+  const int xmax = (cx + LCU < t->W ? LCU : t->W - cx), ymax = (cy + LCU < t->H ? LCU : t->H - cy);
+  for (int r = 0; r < ymax; r++) memcpy(&t->org[0][r * LCU], &t->src[0][(cy + r) * t->W + cx], xmax);
+  for (int c = 1; c <= 2; c++)
+    for (int r = 0; r < ymax / 2; r++) memcpy(&t->org[c][r * 32], &t->src[c][(cy / 2 + r) * (t->W / 2) + cx / 2], xmax / 2);
+  const double cost = search_cu(t, cx, cy, 0);
+  level_t *l0 = &t->lv[0];
+  for (int r = 0; r < ymax; r++) memcpy(&t->frec[0][(cy + r) * t->W + cx], &l0->rec[0][r * LCU], xmax);
+  for (int c = 1; c <= 2; c++)
+    for (int r = 0; r < ymax / 2; r++) memcpy(&t->frec[c][(cy / 2 + r) * (t->W / 2) + cx / 2], &l0->rec[c][r * 32], xmax / 2);
+  for (int yy = 0; yy < ymax; yy += 8)
+    for (int xx = 0; xx < xmax; xx += 8) {
+      const int i = ((cy + yy) >> 3) * (t->W >> 3) + ((cx + xx) >> 3);
+      t->fdepth[i] = cu_at(l0, xx, yy)->depth;
+      t->fmode[i] = cu_at(l0, xx, yy)->mode;
+    }
+  memcpy(coeff_out, l0->coeff[0], 4096 * sizeof(int16_t));
+  memcpy(coeff_out + 4096, l0->coeff[1], 1024 * sizeof(int16_t));
+  memcpy(coeff_out + 5120, l0->coeff[2], 1024 * sizeof(int16_t));
+  return cost;
+}
+
+/* One frame, CTUs in raster order.  Planes are tightly packed (stride = width, chroma = width/2); width and height
+ * must be multiples of 8 (kvazaar pads its input to that, encoder.c).  Outputs: rec planes, KVZ_HIP_CTU_COEFFS
+ * coefficients per CTU (raster CTU order), CU depth and luma mode per 8x8 block (raster, stride width/8), and the
+ * RD cost of every CTU. */
+void kvz_oracle_intra_frame(const kvz_hip_intra_cost_model *m, int width, int height, const uint8_t *src_y, const uint8_t *src_u,
+                            const uint8_t *src_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, int16_t *coeff, uint8_t *cu_depth,
+                            uint8_t *cu_mode, double *ctu_cost)
+{
+  ctu_t *t = (ctu_t *)calloc(1, sizeof(ctu_t));
+  t->m = m; t->W = width; t->H = height;
+  t->src[0] = src_y; t->src[1] = src_u; t->src[2] = src_v;
+  t->frec[0] = rec_y; t->frec[1] = rec_u; t->frec[2] = rec_v;
+  t->fdepth = cu_depth; t->fmode = cu_mode;
+  build_avail_tables(t);
+  const int wc = (width + 63) / 64, hc = (height + 63) / 64;
+  for (int cy = 0; cy < hc; cy++)
+    for (int cx = 0; cx < wc; cx++) ctu_cost[cy * wc + cx] = encode_ctu(t, cx * 64, cy * 64, coeff + (size_t)(cy * wc + cx) * KVZ_HIP_CTU_COEFFS);
+  free(t);
+}
+
+/* The frozen-context cost model for QP `qp` of an I slice (kvz_hip_intra_cost_model): context init values of the
+ * HEVC spec as kvazaar tabulates them (context.c:96-134, I-slice row), kvz_ctx_init (context.c:202-213) and the
+ * entropy table passed in by the caller (kvz_f_entropy_bits, rdo.c:83) -- tests take it from the reference build. */
+void kvz_oracle_intra_cost_model(int qp, const float entropy_fbits[128], uint64_t coeff_weights, kvz_hip_intra_cost_model *m)
+{
+  static const uint8_t init_split[3] = { 139, 141, 157 }, init_part = 184, init_intra = 184, init_chroma = 63;
+  static const uint8_t init_cbf_luma[2] = { 111, 141 }, init_cbf_chroma[2] = { 94, 138 };
+  memset(m, 0, sizeof *m);
+  m->qp = qp;
+  m->lambda = 0.57 * pow(2.0, (qp - 12) / 3.0);
+  m->lambda_sqrt = sqrt(m->lambda);
+  m->coeff_weights = coeff_weights;
+#define CTX_STATE(init) ctx_state(qp, init)
+#define FILL2(dst, init) do { int s_ = CTX_STATE(init); (dst)[0] = entropy_fbits[s_ ^ 0]; (dst)[1] = entropy_fbits[s_ ^ 1]; } while (0)
+  for (int i = 0; i < 3; i++) FILL2(m->split_flag[i], init_split[i]);
+  FILL2(m->part_size, init_part);
+  FILL2(m->intra_mode, init_intra);
+  FILL2(m->chroma_mode, init_chroma);
+  for (int i = 0; i < 2; i++) { FILL2(m->cbf_luma[i], init_cbf_luma[i]); FILL2(m->cbf_chroma[i], init_cbf_chroma[i]); }
+}

@@ -29,3 +29,27 @@ typedef kvz::Api<HostBackend> A;
 #define KVZ_API_PREFIX(name) kvz_hostsim_##name
 #define KVZ_API_BACKEND be()
 #include "../../kvazaar_amd/csrc/kvz_capi_exports.inc"
+
+// ---- the batched CTU program (kvz_ctu.hpp) run on the host: CTUs in raster order, each one as 256 looped "threads" ----
+#include "../../kvazaar_amd/csrc/kvz_ctu.hpp"
+extern "C" void kvz_hostsim_intra_frame(const kvz_hip_intra_cost_model *m, int width, int height, const uint8_t *src /* Y|U|V */, uint8_t *rec,
+                                        int16_t *coeff, uint8_t *cu_depth, uint8_t *cu_mode, double *ctu_cost)
+{
+  static kvz::Tables tb;
+  kvz::build_tables(&tb);
+  kvz::CtuFrames F;
+  F.W = width; F.H = height; F.wc = (width + 63) / 64; F.hc = (height + 63) / 64; F.frame_px = (long)width * height * 3 / 2;
+  F.src = src; F.rec = rec; F.coeff = coeff; F.cu_depth = cu_depth; F.cu_mode = cu_mode; F.ctu_cost = ctu_cost;
+  int16_t *scratch = (int16_t *)calloc((size_t)F.wc * F.hc * 3 * 6144, sizeof(int16_t));
+  F.coeff_scratch = scratch;
+  kvz::CtuShared *sh = (kvz::CtuShared *)calloc(1, sizeof(kvz::CtuShared));
+  for (int cy = 0; cy < F.hc; cy++)
+    for (int cx = 0; cx < F.wc; cx++) {
+      kvz::CtuProgram p;
+      p.m = m; p.tb = &tb; p.F = F; p.s = sh; p.frame = 0; p.cx = cx * 64; p.cy = cy * 64;
+      p.run();
+    }
+  free(sh);
+  free(scratch);
+}
+extern "C" unsigned kvz_hostsim_ctu_shared_bytes(void) { return (unsigned)sizeof(kvz::CtuShared); }

@@ -27,8 +27,11 @@ def _encode(binary, yuv, out, extra, env=None):
     return hashlib.md5(open(out, "rb").read()).hexdigest(), time.time() - t, r.stderr
 
 
-@pytest.mark.parametrize("frames,preset", [(2, ["--preset", "ultrafast", "-p", "1"]),
-                                           (1, ["--preset", "medium", "-p", "1", "--rdoq", "0"])])
+@pytest.mark.parametrize("frames,preset", [(2, ["--preset", "ultrafast", "-p", "1"]),            # BASELINE config 1
+                                           (1, ["--preset", "medium", "-p", "1"]),               # config 3: rdoq, sao, 4x4 DST
+                                           (3, ["--preset", "veryfast", "--gop", "lp-g4d3t1"]),  # config 4: ME, FME, bipred
+                                           (1, ["--preset", "ultrafast", "-p", "1", "--tiles", "2x2"])],  # config 5 (tiles)
+                         ids=["ultrafast-intra", "medium-intra", "veryfast-inter", "ultrafast-tiles"])
 def test_bitstream_identical_to_generic(tmp_path, frames, preset):
     if not os.path.exists(os.path.join(REF, "kvazaar_hip")):
         pytest.skip("oracle/_ref/kvazaar_hip not built")

@@ -1,0 +1,94 @@
+"""Batched all-intra CTU pass on the MI355X (-m gpu): kvz_hip_intra_frames (include/kvz_hip_batch.h) against the
+oracle restatement of kvazaar's search (oracle/kvz_oracle_ctu.c) -- reconstruction, coefficients, CU depths, intra
+modes and double-precision RD costs all bit-exact -- plus size-independent properties at BASELINE's full sizes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import ctu_common as cc
+import flatapi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hiplib():
+    import kvazaar_amd
+    lib = kvazaar_amd.load_library()
+    assert lib.kvz_hip_device_count() >= 1
+    return lib
+
+
+def _model(hiplib, oracle, qp):
+    m = cc.hip_cost_model(hiplib, qp)
+    if flatapi.os.path.exists(flatapi.refshim_path()):
+        # the product's own cost-model builder must equal the one derived from the reference's tables
+        import test_ctu_pipeline as t
+        assert t.oracle_model(oracle, flatapi.load_ref(0), qp).key() == m.key()
+    return m
+
+
+def _run_batch(hiplib, model, w, h, frames):
+    b = cc.HipBatch(hiplib, w, h, len(frames))
+    try:
+        for i, f in enumerate(frames):
+            b.upload(i, f)
+        b.run(model)
+        return [b.download(i) for i in range(len(frames))]
+    finally:
+        b.close()
+
+
+@pytest.mark.parametrize("size", [(64, 64), (416, 240), (72, 88), (200, 136)], ids=lambda s: f"{s[0]}x{s[1]}")
+def test_hip_ctu_equals_oracle(oracle, hiplib, size):
+    w, h = size
+    model = _model(hiplib, oracle, 22)
+    frames = cc.yuv_frames(w, h, 3, 1234, "small")
+    got = _run_batch(hiplib, model, w, h, frames)
+    for i, f in enumerate(frames):
+        want = cc.run_oracle(oracle, model, w, h, f)
+        assert not cc.compare(want, got[i]), (size, i, cc.compare(want, got[i]))
+
+
+def test_hip_ctu_adversarial_and_qps(oracle, hiplib):
+    w, h = 192, 136
+    frames = list(cc.adversarial_frames(w, h).values())
+    for qp in (10, 22, 37):
+        model = _model(hiplib, oracle, qp)
+        got = _run_batch(hiplib, model, w, h, frames)
+        for i, f in enumerate(frames):
+            want = cc.run_oracle(oracle, model, w, h, f)
+            assert not cc.compare(want, got[i]), (qp, i, cc.compare(want, got[i]))
+
+
+def test_hip_ctu_1080p_frame_equals_oracle(oracle, hiplib):
+    """BASELINE config 2 geometry (1920x1080: 30x17 CTUs, partial bottom row), one frame against the oracle"""
+    w, h = 1920, 1080
+    model = _model(hiplib, oracle, 22)
+    frames = cc.yuv_frames(w, h, 1, 1, "large")
+    got = _run_batch(hiplib, model, w, h, frames)
+    want = cc.run_oracle(oracle, model, w, h, frames[0])
+    assert not cc.compare(want, got[0]), cc.compare(want, got[0])
+
+
+def test_hip_ctu_full_size_properties(oracle, hiplib):
+    """4K (BASELINE configs 3-5 geometry), properties that need no oracle run: frames of a batch are independent
+    (a frame encodes identically alone and inside a batch), repeated runs are deterministic, and the reconstruction is
+    a plausible QP-22 encode (PSNR band) whose coefficients are consistent with the CU costs being finite."""
+    w, h = 3840, 2160
+    model = _model(hiplib, oracle, 22)
+    frames = cc.yuv_frames(w, h, 2, 2, "large")
+    batch = _run_batch(hiplib, model, w, h, frames)
+    again = _run_batch(hiplib, model, w, h, frames)
+    alone = _run_batch(hiplib, model, w, h, frames[1:])
+    for i in range(2):
+        assert not cc.compare(batch[i], again[i])
+    assert not cc.compare(batch[1], alone[0])
+    for i in range(2):
+        y, ry = frames[i][:w * h].astype(np.float64), batch[i]["rec"][:w * h].astype(np.float64)
+        psnr = 10 * np.log10(255 ** 2 / np.mean((y - ry) ** 2))
+        assert 38.0 < psnr < 46.0, psnr
+        assert np.isfinite(batch[i]["cost"]).all() and (batch[i]["cost"] > 0).all()
+        assert set(np.unique(batch[i]["depth"])) <= {0, 1, 2, 3}
+        assert batch[i]["mode"].max() <= 34
