@@ -41,6 +41,18 @@ namespace kvz {
 #define KVZ_LDS_ADD(p, v) atomicAdd((p), (v))
 #endif
 
+// Sum of `v` over the workgroup added to the LDS word *dst.  Must be reached by every lane of the wave (uniform control
+// flow): wave64 shuffle reduction, then one LDS atomic per wave.  Integer adds, so the result does not depend on the order.
+KVZ_DEV void block_add(u32 *dst, u32 v)
+{
+#ifdef KVZ_HOSTSIM
+  *dst += v;
+#else
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
+#endif
+}
+
 struct CtuCu { u8 type, depth, mode, tr_depth; uint16_t cbf; uint16_t pad; };  // one per 8x8 (min CU)
 
 // Frame-level device buffers of one batch (all frames share the geometry).
@@ -73,6 +85,14 @@ struct CtuShared {
   double child_rd[4];
   u32 child_acc[4][9];
   int cbf_any;
+  // neighbour CTUs' data, staged once per CTU: reconstructed border pixels and CU info of the left column / top row
+  u8 bpx_left[3][66];        // x = ox-1, y = oy-1 .. oy+63   (index 0 = corner)
+  u8 bpx_top[3][98];         // y = oy-1, x = ox-1 .. ox+95   (index 0 = corner)
+  u8 nb_depth[2][8], nb_mode[2][8];  // [0 left / 1 top][8x8 index]
+  i16 dct32[32 * 32];        // HEVC core transform matrix; the 16/8/4-point matrices are its rows 2k/4k/8k (dct-generic.c:46-120)
+  u8 dcval[3];               // DC value of the current references per plane
+  double sel_costs[35];      // rough-search replay scratch (lane 0)
+  int8_t sel_modes[35];
 };
 
 static const int kPlaneOff[3] = { 0, 4096, 5120 };
@@ -108,15 +128,17 @@ struct CtuProgram {
   {
     if (fx < 0 || fy < 0 || fx >= F.W || fy >= F.H) return false;
     if (fx >= cx && fx < cx + 64 && fy >= cy && fy < cy + 64) { *out = s->cu[lv][((fy - cy) >> 3) * 8 + ((fx - cx) >> 3)]; return true; }
-    const long i = (long)frame * (F.H >> 3) * (F.W >> 3) + (long)(fy >> 3) * (F.W >> 3) + (fx >> 3);
-    out->type = 1; out->depth = F.cu_depth[i]; out->mode = F.cu_mode[i]; out->tr_depth = out->depth; out->cbf = 0;
+    // outside the CTU only the left column (fx == cx-1) and the top row (fy == cy-1) are ever asked for
+    const int side = fx < cx ? 0 : 1, i = side == 0 ? (fy - cy) >> 3 : (fx - cx) >> 3;
+    out->type = 1; out->depth = s->nb_depth[side][i]; out->mode = s->nb_mode[side][i]; out->tr_depth = out->depth; out->cbf = 0;
     return true;
   }
   KVZ_DEV u8 rec_px(int lv, int c, int px, int py) const
   {
     const int sh = c ? 1 : 0, w = 64 >> sh, ox = cx >> sh, oy = cy >> sh;
     if (px >= ox && px < ox + w && py >= oy && py < oy + w) return s->rec[lv][kPlaneOff[c] + (py - oy) * w + (px - ox)];
-    return frame_rec(c)[(long)py * (F.W >> sh) + px];
+    // neighbour CTUs: left column (px == ox-1) or top row (py == oy-1), staged in LDS by init()
+    return px < ox ? s->bpx_left[c][py - oy + 1] : s->bpx_top[c][px - ox + 1];
   }
 
   // intra.c:84-126 kvz_intra_get_dir_luma_predictor
@@ -227,6 +249,10 @@ struct CtuProgram {
       }
       KVZ_SYNC();
     }
+    KVZ_FOR_THREADS(tid) {
+      if (tid < 3 && ((tid == 0 && luma) || (tid > 0 && chroma))) s->dcval[tid] = (u8)dc_value(tid ? log2w_c : log2w_y, s->ref[tid][0], s->ref[tid][1]);
+    }
+    KVZ_SYNC();
   }
 
   // intra.c:252-301 kvz_intra_predict for one pixel (filter_boundary on for luma)
@@ -245,7 +271,7 @@ struct CtuProgram {
     }
     if (mode == 0) return planar_pixel(log2w, x, y, top, left);
     if (mode == 1) {
-      const int dc = dc_value(log2w, top, left);
+      const int dc = s->dcval[c];
       return (c == 0 && w < 32) ? filtered_dc_pixel(dc, x, y, top, left) : (u8)dc;
     }
     int v = angular_pixel(mode, x, y, top, left);
@@ -277,8 +303,9 @@ struct CtuProgram {
     }
     KVZ_SYNC();
     KVZ_FOR_THREADS(tid) {
+      const int lb = 2 * (log2w - 3);  // log2(nblk)
       for (int t = tid; t < 35 * nblk; t += KVZ_CTU_THREADS) {
-        const int mode = t / nblk, b = t - mode * nblk, bx = (b & ((w >> 3) - 1)) * 8, by = (b / (w >> 3)) * 8;
+        const int mode = t >> lb, b = t & (nblk - 1), bx = (b & ((w >> 3) - 1)) * 8, by = (b >> (log2w - 3)) * 8;
         const u32 v = satd8(s->pred + mode * w * w + by * w + bx, w, s->org + (yl + by) * 64 + xl + bx, 64);
         KVZ_LDS_ADD(&s->satd[mode], v);
       }
@@ -286,8 +313,8 @@ struct CtuProgram {
     KVZ_SYNC();
     KVZ_FOR_THREADS(tid) {
       if (tid == 0) {
-        int8_t modes[35];
-        double costs[35];
+        int8_t *modes = s->sel_modes;
+        double *costs = s->sel_costs;
         int n = 0, offset = log2w == 2 ? 2 : (log2w == 3 ? 4 : 8);
         int32_t min_cost = 0x7fffffff, max_cost = -0x7fffffff - 1;
         for (int mode = 2; mode <= 34; mode += 2 * offset)
@@ -362,12 +389,13 @@ struct CtuProgram {
           const int l2 = tu_log2(t, c);
           if (!l2) continue;
           const int n = 1 << l2, shift = pass == 0 ? l2 - 1 : l2 + 6, add = 1 << (shift - 1);
-          const i16 *C = tb->dct[l2 - 2], *src = s->tb[pass] + tb_off(c);
+          const i16 *C = s->dct32, *src = s->tb[pass] + tb_off(c);
+          const int rs = 10 - l2;  // row k of the n-point matrix = row k * (32 / n) of the 32-point one
           i16 *dst = s->tb[pass ^ 1] + tb_off(c);
           for (int e = tid; e < n * n; e += KVZ_CTU_THREADS) {
             const int k = e >> l2, j = e & (n - 1);
             int a = 0;
-            for (int i = 0; i < n; i++) a += (int)C[k * n + i] * (int)src[j * n + i];
+            for (int i = 0; i < n; i++) a += (int)C[(k << rs) + i] * (int)src[(j << l2) + i];
             dst[e] = (i16)((a + add) >> shift);
           }
         }
@@ -397,8 +425,8 @@ struct CtuProgram {
           wsum += (u32)((m->coeff_weights >> (16 * a)) & 0xffff);
           dq[e] = (i16)iclip(-32768, 32767, (level * qi.dq_scale + (1 << (qi.dq_shift - 1))) >> qi.dq_shift);
         }
-        if (wsum) KVZ_LDS_ADD(&s->acc[3 + c], wsum);
-        if (nz) KVZ_LDS_ADD(&s->acc[6 + c], nz);
+        block_add(&s->acc[3 + c], wsum);
+        block_add(&s->acc[6 + c], nz);
       }
     }
     KVZ_SYNC();
@@ -409,12 +437,13 @@ struct CtuProgram {
           const int l2 = tu_log2(t, c);
           if (!l2 || !s->acc[6 + c]) continue;
           const int n = 1 << l2, shift = pass == 0 ? 7 : 12, add = 1 << (shift - 1);
-          const i16 *C = tb->dct[l2 - 2], *src = s->tb[pass ^ 1] + tb_off(c);
+          const i16 *C = s->dct32, *src = s->tb[pass ^ 1] + tb_off(c);
+          const int rs = 10 - l2;
           i16 *dst = s->tb[pass] + tb_off(c);
           for (int e = tid; e < n * n; e += KVZ_CTU_THREADS) {
             const int j = e >> l2, i = e & (n - 1);
             int a = 0;
-            for (int k = 0; k < n; k++) a += (int)C[k * n + i] * (int)src[k * n + j];
+            for (int k = 0; k < n; k++) a += (int)C[(k << rs) + i] * (int)src[(k << l2) + j];
             dst[e] = (i16)iclip(-32768, 32767, (a + add) >> shift);
           }
         }
@@ -436,7 +465,7 @@ struct CtuProgram {
           const int d = (int)s->org[o] - v;
           ssd += (u32)(d * d);
         }
-        if (ssd) KVZ_LDS_ADD(&s->acc[c], ssd);
+        block_add(&s->acc[c], ssd);
       }
       if (tid == 0) {  // cbf bits of the TU's top-left CU entry (transform.c:314, 409-411)
         CtuCu *cu = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
@@ -485,9 +514,9 @@ struct CtuProgram {
   KVZ_DEV void fill_cu(int lv, int xl, int yl, int w, int type, int depth, int mode, int tr_depth)
   {
     KVZ_FOR_THREADS(tid) {
-      const int n = w >> 3;
+      const int n = w >> 3, ln = w == 8 ? 0 : (w == 16 ? 1 : (w == 32 ? 2 : 3));
       if (tid < n * n) {
-        CtuCu *c = &s->cu[lv][((yl >> 3) + tid / n) * 8 + (xl >> 3) + tid % n];
+        CtuCu *c = &s->cu[lv][((yl >> 3) + (tid >> ln)) * 8 + (xl >> 3) + (tid & (n - 1))];
         c->type = (u8)type; c->depth = (u8)depth; c->mode = (u8)mode; c->tr_depth = (u8)tr_depth;
       }
     }
@@ -498,13 +527,13 @@ struct CtuProgram {
   KVZ_DEV void copy_region(int from, int to, int xl, int yl, int w, bool coeffs)
   {
     KVZ_FOR_THREADS(tid) {
-      const int n = w >> 3;
-      if (tid < n * n) { const int i = ((yl >> 3) + tid / n) * 8 + (xl >> 3) + tid % n; s->cu[to][i] = s->cu[from][i]; }
-      for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) { const int o = (yl + e / w) * 64 + xl + e % w; s->rec[to][o] = s->rec[from][o]; }
+      const int n = w >> 3, lw = w == 16 ? 4 : (w == 32 ? 5 : 6), ln = lw - 3;
+      if (tid < n * n) { const int i = ((yl >> 3) + (tid >> ln)) * 8 + (xl >> 3) + (tid & (n - 1)); s->cu[to][i] = s->cu[from][i]; }
+      for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) { const int o = (yl + (e >> lw)) * 64 + xl + (e & (w - 1)); s->rec[to][o] = s->rec[from][o]; }
       const int cw = w >> 1;
       for (int e = tid; e < 2 * cw * cw; e += KVZ_CTU_THREADS) {
         const int c = e >= cw * cw, k = c ? e - cw * cw : e;
-        const int o = kPlaneOff[1 + c] + ((yl >> 1) + k / cw) * 32 + (xl >> 1) + k % cw;
+        const int o = kPlaneOff[1 + c] + ((yl >> 1) + (k >> (lw - 1))) * 32 + (xl >> 1) + (k & (cw - 1));
         s->rec[to][o] = s->rec[from][o];
       }
       if (coeffs) {
@@ -570,8 +599,34 @@ struct CtuProgram {
         if (c == 0) s->tbl_left[r][c] = (u8)(64 - 4 * r);
         else { for (int rr = r; rr < 16 && zorder((c - 1) * 4, rr * 4) < zorder(c * 4, r * 4); rr++) n++; s->tbl_left[r][c] = (u8)(4 * n); }
       }
-      // coefficient buffers of all levels start zeroed like the lcu_t copies (search.c:1084)
-      for (int lv = 0; lv < 4; lv++) { i16 *cf = coeff_level(lv); for (int e = tid; e < 6144; e += KVZ_CTU_THREADS) cf[e] = 0; }
+      // Coefficient buffers start zeroed like the lcu_t copies (search.c:1084).  Only observable for CTUs that stick out
+      // of the picture: inside the picture every coefficient that reaches level 0 was written by a transform unit first.
+      if (cx + 64 > F.W || cy + 64 > F.H)
+        for (int lv = 0; lv < 4; lv++) { i16 *cf = coeff_level(lv); for (int e = tid; e < 6144; e += KVZ_CTU_THREADS) cf[e] = 0; }
+      for (int e = tid; e < 1024; e += KVZ_CTU_THREADS) s->dct32[e] = tb->dct[3][e];
+      // neighbour CTUs (complete: they lie on earlier anti-diagonals): border pixels and CU info
+      for (int c = 0; c < 3; c++) {
+        const int sh = c ? 1 : 0, lw = 64 >> sh, fw = F.W >> sh, fh = F.H >> sh, ox = cx >> sh, oy = cy >> sh;
+        const u8 *rec = frame_rec(c);
+        for (int i = tid; i < lw + 2; i += KVZ_CTU_THREADS) {  // left column incl. corner, y = oy-1+i
+          const int py = oy - 1 + i;
+          s->bpx_left[c][i] = (cx > 0 && py >= 0 && py < fh) ? rec[(long)py * fw + ox - 1] : 0;
+        }
+        for (int i = tid; i < lw + (lw >> 1) + 2; i += KVZ_CTU_THREADS) {  // top row incl. corner, x = ox-1+i
+          const int px = ox - 1 + i;
+          s->bpx_top[c][i] = (cy > 0 && px >= 0 && px < fw) ? rec[(long)(oy - 1) * fw + px] : 0;
+        }
+      }
+      if (tid < 16) {
+        const int side = tid >> 3, i = tid & 7;
+        const int fx = side == 0 ? cx - 1 : cx + i * 8, fy = side == 0 ? cy + i * 8 : cy - 1;
+        u8 d = 0, md = 0;
+        if (fx >= 0 && fy >= 0 && fx < F.W && fy < F.H) {
+          const long gi = (long)frame * (F.H >> 3) * (F.W >> 3) + (long)(fy >> 3) * (F.W >> 3) + (fx >> 3);
+          d = F.cu_depth[gi]; md = F.cu_mode[gi];
+        }
+        s->nb_depth[side][i] = d; s->nb_mode[side][i] = md;
+      }
     }
     KVZ_SYNC();
   }
