@@ -46,6 +46,8 @@ void kvz_hip_batch_sync(kvz_hip_batch *b);
  * stream around the launch sequence (milliseconds); call after kvz_hip_batch_sync(). */
 float kvz_hip_batch_last_kernel_ms(kvz_hip_batch *b);
 int   kvz_hip_batch_ctus_per_frame(const kvz_hip_batch *b);
+/* Developer aid: per-stage shader-cycle counters of a -DKVZ_CTU_PROFILE build of the library (zeros otherwise). */
+int   kvz_hip_batch_profile(kvz_hip_batch *b, unsigned long long *out, int n);
 
 /* Frozen-context cost model of an I slice at `qp` (kvz_hip_intra_cost_model): HEVC context init values
  * (context.c:96-134), kvz_ctx_init (context.c:202-213), the HM entropy table (rdo.c:69-80), lambda of

@@ -5,7 +5,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libkvz_hip.so")
+LIB_PATH = os.environ.get("KVZ_HIP_LIB") or os.path.join(LIB_DIR, "libkvz_hip.so")  # KVZ_HIP_LIB: developer override (kernel variants)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 SOURCES = ["kvz_hip.hip"]
 # -ffp-contract=off: pixel_var / cost arithmetic must not be contracted into FMAs (bit-exact double results)
@@ -23,7 +23,7 @@ def _stale():
 
 def build_library(force=False, verbose=False):
     """Compile every HIP source into kvazaar_amd/lib/libkvz_hip.so.  Returns the library path."""
-    if not force and not _stale():
+    if os.environ.get("KVZ_HIP_LIB") or (not force and not _stale()):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     cmd = [HIPCC] + FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]

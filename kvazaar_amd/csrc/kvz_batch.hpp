@@ -11,7 +11,10 @@
 namespace kvz {
 
 // One workgroup per CTU of the anti-diagonal `wave` (x + 2y == wave) of every frame.
-__global__ void __launch_bounds__(KVZ_CTU_THREADS) intra_ctu_wave_kernel(const CtuFrames F, const kvz_hip_intra_cost_model model, const Tables *tb,
+#ifndef KVZ_CTU_WAVES_PER_EU
+#define KVZ_CTU_WAVES_PER_EU 3  /* 3 workgroups of 256 lanes per CU: the LDS footprint (~53 KB) allows no more */
+#endif
+__global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) intra_ctu_wave_kernel(const CtuFrames F, const kvz_hip_intra_cost_model model, const Tables *tb,
                                                                         const int wave, const int y_min, const int n_diag)
 {
   __shared__ CtuShared shared;
@@ -37,6 +40,7 @@ struct kvz_hip_batch {
   uint8_t *d_src, *d_rec, *d_depth, *d_mode;
   int16_t *d_coeff, *d_scratch;
   double *d_cost;
+  unsigned long long *d_prof;
 };
 
 namespace kvz {
@@ -114,6 +118,9 @@ kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_mode, ncu));
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_cost, nctu * sizeof(double)));
   KVZ_HIP_CHECK(hipMemset(b->d_rec, 0, F.frame_px * n_frames));
+  KVZ_HIP_CHECK(hipMalloc((void **)&b->d_prof, kvz::KVZ_P_COUNT * sizeof(unsigned long long)));
+  KVZ_HIP_CHECK(hipMemset(b->d_prof, 0, kvz::KVZ_P_COUNT * sizeof(unsigned long long)));
+  F.prof = b->d_prof;
   F.src = b->d_src; F.rec = b->d_rec; F.coeff = b->d_coeff; F.coeff_scratch = b->d_scratch;
   F.cu_depth = b->d_depth; F.cu_mode = b->d_mode; F.ctu_cost = b->d_cost;
   return b;
@@ -181,6 +188,16 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
 }
 
 void kvz_hip_batch_sync(kvz_hip_batch *b) { KVZ_HIP_CHECK(hipStreamSynchronize(b->stream)); }
+
+/* cycle counters of a -DKVZ_CTU_PROFILE build (all zero otherwise); reading resets them */
+int kvz_hip_batch_profile(kvz_hip_batch *b, unsigned long long *out, int n)
+{
+  KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+  if (n > kvz::KVZ_P_COUNT) n = kvz::KVZ_P_COUNT;
+  KVZ_HIP_CHECK(hipMemcpy(out, b->d_prof, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  KVZ_HIP_CHECK(hipMemset(b->d_prof, 0, kvz::KVZ_P_COUNT * sizeof(unsigned long long)));
+  return kvz::KVZ_P_COUNT;
+}
 
 float kvz_hip_batch_last_kernel_ms(kvz_hip_batch *b)
 {

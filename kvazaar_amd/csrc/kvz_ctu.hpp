@@ -30,7 +30,9 @@
 
 namespace kvz {
 
+#ifndef KVZ_CTU_THREADS
 #define KVZ_CTU_THREADS 256
+#endif
 #ifdef KVZ_HOSTSIM
 #define KVZ_FOR_THREADS(tid) for (int tid = 0; tid < KVZ_CTU_THREADS; ++tid)
 #define KVZ_SYNC()
@@ -53,6 +55,16 @@ KVZ_DEV void block_add(u32 *dst, u32 v)
 #endif
 }
 
+// Optional in-kernel timeline (build with -DKVZ_CTU_PROFILE): lane 0 of every workgroup adds the shader-clock cycles
+// spent since the previous mark to a per-category counter in HBM.  Categories are the KVZ_P_* constants.
+enum { KVZ_P_INIT = 0, KVZ_P_REFS, KVZ_P_PRED35, KVZ_P_SATD, KVZ_P_SELECT, KVZ_P_RPRED, KVZ_P_FDCT, KVZ_P_QUANT, KVZ_P_IDCT, KVZ_P_RECON,
+       KVZ_P_COST, KVZ_P_COPY, KVZ_P_FINISH, KVZ_P_MISC, KVZ_P_COUNT };
+#if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
+#define KVZ_PROF(cat) prof_mark(cat)
+#else
+#define KVZ_PROF(cat)
+#endif
+
 struct CtuCu { u8 type, depth, mode, tr_depth; uint16_t cbf; uint16_t pad; };  // one per 8x8 (min CU)
 
 // Frame-level device buffers of one batch (all frames share the geometry).
@@ -65,6 +77,7 @@ struct CtuFrames {
   i16 *coeff_scratch;        // [frames][ctu][3 levels][6144]  (work-tree levels 1..3)
   u8 *cu_depth, *cu_mode;    // [frames][(H/8)*(W/8)]
   double *ctu_cost;          // [frames][ctu]
+  unsigned long long *prof;  // [KVZ_P_COUNT] cycle counters (KVZ_CTU_PROFILE builds only, else unused)
 };
 
 struct CtuShared {
@@ -91,8 +104,11 @@ struct CtuShared {
   u8 nb_depth[2][8], nb_mode[2][8];  // [0 left / 1 top][8x8 index]
   i16 dct32[32 * 32];        // HEVC core transform matrix; the 16/8/4-point matrices are its rows 2k/4k/8k (dct-generic.c:46-120)
   u8 dcval[3];               // DC value of the current references per plane
-  double sel_costs[35];      // rough-search replay scratch (lane 0)
-  int8_t sel_modes[35];
+  u32 satd_raw[35][4];       // sum |Hadamard| per (mode, 8x8 block) before the per-block rounding
+  int8_t mode_disp[35];      // angular parameters per mode (intra-generic.c:59-60, 70-76): signed sample displacement,
+  int16_t mode_inv[35];      //   inverse angle, and whether the mode projects on the top reference
+  QuantScalars qs[4][2];     // [log2w - 2][0 luma / 1 chroma] for this QP (quant-generic.c:57-66, 303-339)
+  double mode_bits_cost[3];  // lambda_sqrt * kvz_luma_mode_bits for: not an MPM, MPM 0, MPM 1/2
 };
 
 static const int kPlaneOff[3] = { 0, 4096, 5120 };
@@ -103,6 +119,17 @@ struct CtuProgram {
   CtuFrames F;
   CtuShared *s;
   int frame, cx, cy;  // CTU origin (luma px)
+#if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
+  unsigned long long t_last;
+  __device__ void prof_mark(int cat)
+  {
+    if (threadIdx.x == 0) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      atomicAdd(&F.prof[cat], t - t_last);
+      t_last = t;
+    }
+  }
+#endif
 
   // ---------------------------------------------------------------- small uniform helpers
   KVZ_DEV const u8 *frame_rec(int c) const { return F.rec + (long)frame * F.frame_px + (c == 0 ? 0 : c == 1 ? (long)F.W * F.H : (long)F.W * F.H * 5 / 4); }
@@ -221,7 +248,8 @@ struct CtuProgram {
     return lx > 0 ? rec_px(lv, c, px - 1, py) : 128;
   }
 
-  // Builds the unfiltered references of the listed planes, then the [1 2 1]-filtered luma references (intra.c:176-204).
+  // Builds the unfiltered references of the listed planes; second phase: the [1 2 1]-filtered luma references
+  // (intra.c:176-204) and the DC value of every plane (intra-generic.c:219-225).
   KVZ_DEV void build_refs(int lv, int x, int y, int log2w_y, int log2w_c, bool luma, bool chroma)
   {
     KVZ_FOR_THREADS(tid) {
@@ -234,8 +262,8 @@ struct CtuProgram {
       }
     }
     KVZ_SYNC();
-    if (luma) {
-      KVZ_FOR_THREADS(tid) {
+    KVZ_FOR_THREADS(tid) {
+      if (luma) {
         const int n = 2 * (1 << log2w_y) + 1;
         for (int i = tid; i < 2 * n; i += KVZ_CTU_THREADS) {
           const int side = i >= n, k = side ? i - n : i;
@@ -247,12 +275,11 @@ struct CtuProgram {
           s->fref[side][k] = v;
         }
       }
-      KVZ_SYNC();
-    }
-    KVZ_FOR_THREADS(tid) {
-      if (tid < 3 && ((tid == 0 && luma) || (tid > 0 && chroma))) s->dcval[tid] = (u8)dc_value(tid ? log2w_c : log2w_y, s->ref[tid][0], s->ref[tid][1]);
+      const int c = tid - (KVZ_CTU_THREADS - 3);  // the last three lanes: one DC value each
+      if (c >= 0 && ((c == 0 && luma) || (c > 0 && chroma))) s->dcval[c] = (u8)dc_value(c ? log2w_c : log2w_y, s->ref[c][0], s->ref[c][1]);
     }
     KVZ_SYNC();
+    KVZ_PROF(KVZ_P_REFS);
   }
 
   // intra.c:252-301 kvz_intra_predict for one pixel (filter_boundary on for luma)
@@ -274,7 +301,20 @@ struct CtuProgram {
       const int dc = s->dcval[c];
       return (c == 0 && w < 32) ? filtered_dc_pixel(dc, x, y, top, left) : (u8)dc;
     }
-    int v = angular_pixel(mode, x, y, top, left);
+    int v;
+    {  // intra-generic.c:49-155 with the per-mode parameters taken from the LDS table
+      const int sample_disp = s->mode_disp[mode];
+      const bool vertical = mode >= 18;
+      const u8 *main_ref = vertical ? top : left, *side_ref = vertical ? left : top;
+      const int px = vertical ? x : y, py = vertical ? y : x;
+      if (sample_disp == 0) v = main_ref[px + 1];
+      else {
+        const int delta_pos = (py + 1) * sample_disp, di = delta_pos >> 5, df = delta_pos & 31, inv = s->mode_inv[mode];
+        const int r1 = angular_ref(main_ref, side_ref, px + di, inv);
+        if (!df) v = r1;
+        else v = ((32 - df) * r1 + df * angular_ref(main_ref, side_ref, px + di + 1, inv) + 16) >> 5;
+      }
+    }
     if (c == 0 && w < 32) {  // intra.c:207-219 intra_post_process_angular
       if (mode == 10 && y == 0) v = iclip(0, 255, v + ((top[x + 1] - top[0]) >> 1));
       else if (mode == 26 && x == 0) v = iclip(0, 255, v + ((left[y + 1] - left[0]) >> 1));
@@ -282,19 +322,49 @@ struct CtuProgram {
     return (u8)v;
   }
 
+  // Partial 8x8 SATD: column `col` of the Hadamard transform of (a - b).  Row responses are the branch of the butterfly
+  // tree selected by the bits of `col` (picture-generic.c:252-340 computes all of them), then the 8-point butterfly down
+  // the column and the sum of magnitudes.  The eight columns of a block add up to the block's sum |coefficients|.
+  KVZ_DEV static u32 satd8_column(const u8 *a, int as, const u8 *b, int bs, int col)
+  {
+    int t[8];
+    for (int r = 0; r < 8; r++) {
+      const u8 *pa = a + r * as, *pb = b + r * bs;
+      int d[8];
+      for (int x = 0; x < 8; x++) d[x] = (int)pa[x] - (int)pb[x];
+      int u0, u1, u2, u3;
+      if (col & 4) { u0 = d[0] - d[4]; u1 = d[1] - d[5]; u2 = d[2] - d[6]; u3 = d[3] - d[7]; }
+      else { u0 = d[0] + d[4]; u1 = d[1] + d[5]; u2 = d[2] + d[6]; u3 = d[3] + d[7]; }
+      const int v0 = (col & 2) ? u0 - u2 : u0 + u2, v1 = (col & 2) ? u1 - u3 : u1 + u3;
+      t[r] = (col & 1) ? v0 - v1 : v0 + v1;
+    }
+    KVZ_HAD8(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+    u32 sum = 0;
+    for (int r = 0; r < 8; r++) sum += (u32)iabs(t[r]);
+    return sum;
+  }
+
+  KVZ_DEV u32 mode_satd(int mode, int nblk) const  // SATD_NxN: sum of (block sum + 2) >> 2 (strategies-picture.h:53-69)
+  {
+    u32 v = 0;
+    for (int b = 0; b < nblk; b++) v += (s->satd_raw[mode][b] + 2) >> 2;
+    return v;
+  }
+
   // search_intra.c:391-530 search_intra_rough: all 35 modes predicted + SATD-scored, then the reference's selection
-  // order replayed on the cost table by one lane.  Leaves the winner in s->best_mode.
+  // order replayed on the cost table by one lane.  Leaves the winner in s->best_mode and the CU's info entries filled.
+  // Also builds the chroma references of the CU (they only depend on neighbouring chroma reconstruction).
   KVZ_DEV void rough_search(int lv, int x, int y, int depth)
   {
     const int log2w = 6 - depth, w = 1 << log2w, xl = x - cx, yl = y - cy, nblk = (w >> 3) * (w >> 3);
-    build_refs(lv, x, y, log2w, 0, true, false);
+    build_refs(lv, x, y, log2w, depth == 3 ? 2 : log2w - 1, true, true);
     KVZ_FOR_THREADS(tid) {
       for (int i = tid; i < 35 * w * w; i += KVZ_CTU_THREADS) {
         const int mode = i >> (2 * log2w), e = i & (w * w - 1);
         s->pred[i] = predict_pixel(log2w, mode, 0, e & (w - 1), e >> log2w);
       }
-      if (tid < 35) s->satd[tid] = 0;
-      if (tid == 0) {
+      if (tid < 35 * 4) s->satd_raw[tid >> 2][tid & 3] = 0;
+      if (tid == KVZ_CTU_THREADS - 1) {
         CtuCu lc, ac, *left = nullptr, *above = nullptr;
         if (x >= 4 && neighbour_cu(lv, x - 1, y, &lc)) left = &lc;
         if (y >= 4 && yl > 0 && neighbour_cu(lv, x, y - 1, &ac)) above = &ac;
@@ -302,56 +372,70 @@ struct CtuProgram {
       }
     }
     KVZ_SYNC();
+    KVZ_PROF(KVZ_P_PRED35);
     KVZ_FOR_THREADS(tid) {
       const int lb = 2 * (log2w - 3);  // log2(nblk)
-      for (int t = tid; t < 35 * nblk; t += KVZ_CTU_THREADS) {
-        const int mode = t >> lb, b = t & (nblk - 1), bx = (b & ((w >> 3) - 1)) * 8, by = (b >> (log2w - 3)) * 8;
-        const u32 v = satd8(s->pred + mode * w * w + by * w + bx, w, s->org + (yl + by) * 64 + xl + bx, 64);
-        KVZ_LDS_ADD(&s->satd[mode], v);
+      for (int t = tid; t < 35 * nblk * 8; t += KVZ_CTU_THREADS) {
+        const int col = t & 7, mb = t >> 3, mode = mb >> lb, b = mb & (nblk - 1), bx = (b & ((w >> 3) - 1)) * 8, by = (b >> (log2w - 3)) * 8;
+        const u32 v = satd8_column(s->pred + mode * w * w + by * w + bx, w, s->org + (yl + by) * 64 + xl + bx, 64, col);
+        KVZ_LDS_ADD(&s->satd_raw[mode][b], v);
       }
     }
     KVZ_SYNC();
+    KVZ_PROF(KVZ_P_SATD);
     KVZ_FOR_THREADS(tid) {
       if (tid == 0) {
-        int8_t *modes = s->sel_modes;
-        double *costs = s->sel_costs;
-        int n = 0, offset = log2w == 2 ? 2 : (log2w == 3 ? 4 : 8);
+        // The list kvazaar builds (modes[], costs[]) is only ever read back as "first minimum in append order", so it is
+        // replayed with a visited mask and running minima instead of arrays.
+        unsigned long long visited = 0;
+        double final_cost = 0;
+        int final_mode = -1;
+        const int8_t p0 = s->preds[0], p1 = s->preds[1], p2 = s->preds[2];
+#define KVZ_APPEND(md, raw)                                                                                         \
+        {                                                                                                           \
+          const int md_ = (md);                                                                                     \
+          visited |= 1ull << md_;                                                                                   \
+          const double c_ = (double)(raw) + s->mode_bits_cost[md_ == p0 ? 1 : ((md_ == p1 || md_ == p2) ? 2 : 0)];  \
+          if (final_mode < 0 || c_ < final_cost) { final_cost = c_; final_mode = md_; }                             \
+        }
+        int offset = log2w == 2 ? 2 : (log2w == 3 ? 4 : 8);
         int32_t min_cost = 0x7fffffff, max_cost = -0x7fffffff - 1;
+        int best_mode = -1;
+        u32 first_min = 0;
         for (int mode = 2; mode <= 34; mode += 2 * offset)
           for (int i = 0; i < 2; i++) if (mode + i * offset <= 34) {
-            costs[n] = (double)s->satd[mode + i * offset]; modes[n] = (int8_t)(mode + i * offset);
-            if (costs[n] < min_cost) min_cost = (int32_t)costs[n];
-            if (costs[n] > max_cost) max_cost = (int32_t)costs[n];
-            n++;
+            const u32 raw = mode_satd(mode + i * offset, nblk);
+            KVZ_APPEND(mode + i * offset, raw);
+            if ((int32_t)raw < min_cost) min_cost = (int32_t)raw;
+            if ((int32_t)raw > max_cost) max_cost = (int32_t)raw;
+            if (best_mode < 0 || raw < first_min) { first_min = raw; best_mode = mode + i * offset; }
           }
-        int bi = 0;
-        for (int i = 1; i < n; i++) if (costs[i] < costs[bi]) bi = i;
-        int best_mode = modes[bi];
         double best_cost = min_cost;
         if (min_cost != max_cost) {
           while (offset > 1) {
             offset >>= 1;
             const int tm[2] = { best_mode - offset, best_mode + offset };
             for (int i = 0; i < 2; i++) if (tm[i] >= 2 && tm[i] <= 34) {
-              costs[n] = (double)s->satd[tm[i]]; modes[n] = (int8_t)tm[i];
-              if (costs[n] < best_cost) { best_cost = costs[n]; best_mode = modes[n]; }
-              n++;
+              const u32 raw = mode_satd(tm[i], nblk);
+              KVZ_APPEND(tm[i], raw);
+              if ((double)raw < best_cost) { best_cost = (double)raw; best_mode = tm[i]; }
             }
           }
         }
-        const int8_t add_modes[5] = { s->preds[0], s->preds[1], s->preds[2], 0, 1 };
-        for (int p = 0; p < 5; p++) {
-          bool has = false;
-          for (int i = 0; i < n; i++) if (modes[i] == add_modes[p]) { has = true; break; }
-          if (!has) { costs[n] = (double)s->satd[add_modes[p]]; modes[n] = add_modes[p]; n++; }
+        const int add_modes[5] = { p0, p1, p2, 0, 1 };
+        for (int p = 0; p < 5; p++)
+          if (!((visited >> add_modes[p]) & 1)) { const u32 raw = mode_satd(add_modes[p], nblk); KVZ_APPEND(add_modes[p], raw); }
+#undef KVZ_APPEND
+        s->best_mode = final_mode;
+        // lcu_fill_cu_info (search.c:137-159) for the searched CU: at most 2x2 entries
+        for (int i = 0; i < (w >> 3) * (w >> 3); i++) {
+          CtuCu *cu = &s->cu[lv][((yl >> 3) + i / (w >> 3)) * 8 + (xl >> 3) + i % (w >> 3)];
+          cu->type = 1; cu->depth = (u8)depth; cu->mode = (u8)final_mode; cu->tr_depth = (u8)depth;
         }
-        for (int i = 0; i < n; i++) costs[i] += m->lambda_sqrt * luma_mode_bits(modes[i], s->preds);
-        bi = 0;
-        for (int i = 1; i < n; i++) if (costs[i] < costs[bi]) bi = i;
-        s->best_mode = modes[bi];
       }
     }
     KVZ_SYNC();
+    KVZ_PROF(KVZ_P_SELECT);
   }
 
   // Transform-unit geometry of one reconstruction step: luma w x w at (x, y) and/or chroma cw x cw.
@@ -361,10 +445,10 @@ struct CtuProgram {
 
   // intra_recon_tb_leaf (intra.c:561-608) + kvz_quantize_residual (quant-generic.c:198-292) for the planes of `t`,
   // written into work-tree level lv.  Sets the cbf bits of the CU's info entry.  One barrier per stage.
-  KVZ_DEV void recon_tus(int lv, const TuSet &t, int depth, int mode)
+  KVZ_DEV void recon_tus(int lv, const TuSet &t, int depth, int mode, bool refs_ready = false)
   {
     const int xl = t.x - cx, yl = t.y - cy;
-    build_refs(lv, t.x, t.y, t.lw, t.lc, t.lw != 0, t.lc != 0);
+    if (!refs_ready) build_refs(lv, t.x, t.y, t.lw, t.lc, t.lw != 0, t.lc != 0);
     // stage 1: prediction -> rec (as kvazaar blits it before quantising) and residual
     KVZ_FOR_THREADS(tid) {
       if (tid < 16) s->acc[tid] = 0;
@@ -382,6 +466,7 @@ struct CtuProgram {
       }
     }
     KVZ_SYNC();
+    KVZ_PROF(KVZ_P_RPRED);
     // stages 2-3: forward transform (dct-generic.c:559-568; 4x4 chroma uses the DCT, strategies-dct.c:82-86)
     for (int pass = 0; pass < 2; pass++) {
       KVZ_FOR_THREADS(tid) {
@@ -402,20 +487,23 @@ struct CtuProgram {
       }
       KVZ_SYNC();
     }
+    KVZ_PROF(KVZ_P_FDCT);
     // stage 4: quantise (quant-generic.c:57-81) -> coefficient store + cost sums; dequantise (:335-339) -> tb[1]
     KVZ_FOR_THREADS(tid) {
       for (int c = 0; c < 3; c++) {
         const int l2 = tu_log2(t, c);
         if (!l2) continue;
         const int n2 = 1 << (2 * l2), sh = c ? 1 : 0;
-        const QuantScalars qf = quant_scalars_dev(l2, c == 0 ? 0 : 2), qi = quant_scalars_dev(l2, c == 0 ? 0 : (c == 1 ? 2 : 3));
+        const QuantScalars qf = s->qs[l2 - 2][c ? 1 : 0];  // forward and inverse share the plane's scaled QP (U and V alike)
+        const QuantScalars qi = qf;
         i16 *cout = coeff_level(lv) + kPlaneOff[c] + zorder(xl >> sh, yl >> sh);
         const i16 *src = s->tb[0] + tb_off(c);
         i16 *dq = s->tb[1] + tb_off(c);
         u32 wsum = 0, nz = 0;
         for (int e = tid; e < n2; e += KVZ_CTU_THREADS) {
           const int cf = src[e];
-          int level = (int)(((int64_t)iabs(cf) * qf.flat_q + qf.add) >> qf.q_bits);
+          // |cf| * q + add < 2^31 for 8-bit flat lists (32767 * 26214 + (171 << 18)), so 32-bit arithmetic is exact
+          int level = (int)(((u32)iabs(cf) * (u32)qf.flat_q + (u32)qf.add) >> qf.q_bits);
           if (cf < 0) level = -level;
           level = iclip(-32768, 32767, level);
           cout[e] = (i16)level;
@@ -430,6 +518,7 @@ struct CtuProgram {
       }
     }
     KVZ_SYNC();
+    KVZ_PROF(KVZ_P_QUANT);
     // stages 5-6: inverse transform (dct-generic.c:570-579), only observable when the plane has coefficients
     for (int pass = 0; pass < 2; pass++) {
       KVZ_FOR_THREADS(tid) {
@@ -450,6 +539,7 @@ struct CtuProgram {
       }
       KVZ_SYNC();
     }
+    KVZ_PROF(KVZ_P_IDCT);
     // stage 7: reconstruction (quant-generic.c:266-277) + SSD against the source (search.c:500-505, 512-523)
     KVZ_FOR_THREADS(tid) {
       for (int c = 0; c < 3; c++) {
@@ -473,6 +563,7 @@ struct CtuProgram {
       }
     }
     KVZ_SYNC();
+    KVZ_PROF(KVZ_P_RECON);
   }
 
   KVZ_DEV QuantScalars quant_scalars_dev(int log2w, int type) const
@@ -548,6 +639,7 @@ struct CtuProgram {
       }
     }
     KVZ_SYNC();
+    KVZ_PROF(KVZ_P_COPY);
   }
 
   // search_cu at depth 2 or 3 (search.c:646-1063): searched CU.  Returns the cost through *out (LDS).
@@ -556,10 +648,11 @@ struct CtuProgram {
     const int log2w = 6 - depth, w = 1 << log2w, xl = x - cx, yl = y - cy;
     rough_search(lv, x, y, depth);
     const int mode = s->best_mode;
-    fill_cu(lv, xl, yl, w, 1, depth, mode, depth);
-    // kvz_intra_recon_cu luma, then chroma (search.c:807-827); chroma TUs are 4x4 for 8x8 CUs (transform.c:326)
+    (void)w;
+    // kvz_intra_recon_cu luma, then chroma (search.c:807-827); chroma TUs are 4x4 for 8x8 CUs (transform.c:326).
+    // All three planes' references were built by rough_search.
     TuSet t{ x, y, log2w, depth == 3 ? 2 : log2w - 1 };
-    recon_tus(lv, t, depth, mode);
+    recon_tus(lv, t, depth, mode, true);
     KVZ_FOR_THREADS(tid) {
       if (tid == 0) {
         const double bits = cu_bits(lv, x, y, depth, mode);
@@ -571,6 +664,7 @@ struct CtuProgram {
       }
     }
     KVZ_SYNC();
+    KVZ_PROF(KVZ_P_COST);
   }
 
   // ---------------------------------------------------------------- CTU driver
@@ -590,7 +684,7 @@ struct CtuProgram {
         for (int e = tid; e < 6144; e += KVZ_CTU_THREADS) s->rec[lv][e] = 0;
         if (tid < 64) { CtuCu z = { 0, 0, 0, 0, 0, 0 }; s->cu[lv][tid] = z; }
       }
-      {  // intra.c:47-82 num_ref_pixels_{top,left}, regenerated from the z-order of 4x4 units
+      if (tid < 256) {  // intra.c:47-82 num_ref_pixels_{top,left}, regenerated from the z-order of 4x4 units
         const int r = tid >> 4, c = tid & 15;
         int n = 0;
         if (r == 0) s->tbl_top[r][c] = 64;
@@ -616,6 +710,18 @@ struct CtuProgram {
           const int px = ox - 1 + i;
           s->bpx_top[c][i] = (cy > 0 && px >= 0 && px < fw) ? rec[(long)(oy - 1) * fw + px] : 0;
         }
+      }
+      if (tid >= 64 && tid < 64 + 35) {  // angular parameters (intra-generic.c:59-76)
+        const int disp_tab[9] = { 0, 2, 5, 9, 13, 17, 21, 26, 32 }, inv_tab[9] = { 0, 4096, 1638, 910, 630, 482, 390, 315, 256 };
+        const int mode = tid - 64, md = mode >= 18 ? mode - 26 : 10 - mode, ad = iabs(md);
+        s->mode_disp[mode] = (int8_t)(mode < 2 ? 0 : (md < 0 ? -disp_tab[ad] : disp_tab[ad]));
+        s->mode_inv[mode] = (int16_t)(mode < 2 ? 0 : inv_tab[ad]);
+      }
+      if (tid >= 128 && tid < 136) s->qs[(tid - 128) >> 1][tid & 1] = quant_scalars_dev(2 + ((tid - 128) >> 1), (tid & 1) ? 2 : 0);
+      if (tid == 140) {  // lambda_sqrt * kvz_luma_mode_bits (search_intra.c:524, 641-676) for the three possible outcomes
+        s->mode_bits_cost[0] = m->lambda_sqrt * ((double)m->intra_mode[0] + 5);
+        s->mode_bits_cost[1] = m->lambda_sqrt * ((double)m->intra_mode[1] + 1);
+        s->mode_bits_cost[2] = m->lambda_sqrt * ((double)m->intra_mode[1] + 2);
       }
       if (tid < 16) {
         const int side = tid >> 3, i = tid & 7;
@@ -782,7 +888,11 @@ struct CtuProgram {
 
   KVZ_DEV void run()
   {
+#if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
+    t_last = __builtin_amdgcn_s_memtime();
+#endif
     init();
+    KVZ_PROF(KVZ_P_INIT);
     set_cu_header(0, 0, 0, 0);
     KVZ_FOR_THREADS(tid) {
       if (tid == 0) { s->cost[0] = 1.7e+308; double sb = 0; sb += (double)m->split_flag[split_model(0, cx, cy, 0)][1]; double sc = 0.0; sc += sb * m->lambda; s->split_cost[0] = sc; }
@@ -818,7 +928,9 @@ struct CtuProgram {
       KVZ_SYNC();
       copy_region(1, 0, 0, 0, 64, true);
     }
+    KVZ_PROF(KVZ_P_MISC);
     finish();
+    KVZ_PROF(KVZ_P_FINISH);
   }
 };
 

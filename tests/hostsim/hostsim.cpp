@@ -39,7 +39,7 @@ extern "C" void kvz_hostsim_intra_frame(const kvz_hip_intra_cost_model *m, int w
   kvz::build_tables(&tb);
   kvz::CtuFrames F;
   F.W = width; F.H = height; F.wc = (width + 63) / 64; F.hc = (height + 63) / 64; F.frame_px = (long)width * height * 3 / 2;
-  F.src = src; F.rec = rec; F.coeff = coeff; F.cu_depth = cu_depth; F.cu_mode = cu_mode; F.ctu_cost = ctu_cost;
+  F.src = src; F.rec = rec; F.coeff = coeff; F.cu_depth = cu_depth; F.cu_mode = cu_mode; F.ctu_cost = ctu_cost; F.prof = nullptr;
   int16_t *scratch = (int16_t *)calloc((size_t)F.wc * F.hc * 3 * 6144, sizeof(int16_t));
   F.coeff_scratch = scratch;
   kvz::CtuShared *sh = (kvz::CtuShared *)calloc(1, sizeof(kvz::CtuShared));

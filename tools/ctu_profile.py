@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Developer tool: per-stage cycle breakdown of the CTU kernel.  Builds a -DKVZ_CTU_PROFILE copy of the library into
+gpurun_out/, runs one 1080p batch and prints the share of each stage (lane-0 shader clock, summed over workgroups)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+NAMES = ["init", "refs", "pred35", "satd", "select", "recon_pred", "fdct", "quant", "idct", "recon", "cost", "copy", "finish", "misc"]
+
+
+def main():
+    out = os.path.join(ROOT, "gpurun_out", "libkvz_hip_prof.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                           "-DKVZ_CTU_PROFILE", "-o", out, os.path.join(ROOT, "kvazaar_amd", "csrc", "kvz_hip.hip")])
+    import numpy as np
+    import ctu_common as cc
+    import bench
+    lib = C.CDLL(out)
+    model = cc.hip_cost_model(lib, 22)
+    frames = bench.synth_frames(1920, 1080, 4, 1)
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    b = cc.HipBatch(lib, 1920, 1080, n)
+    for i in range(n):
+        b.upload(i, frames[i % len(frames)])
+    b.run(model)
+    buf = (C.c_ulonglong * 16)()
+    lib.kvz_hip_batch_profile.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
+    lib.kvz_hip_batch_profile(b.handle, buf, 16)
+    b.run(model)
+    lib.kvz_hip_batch_profile(b.handle, buf, 16)
+    tot = sum(buf[:len(NAMES)])
+    nctu = n * 510
+    print(f"kernel_ms {b.kernel_ms():.2f}  cycles/CTU {tot / nctu:.0f}")
+    for i, nm in enumerate(NAMES):
+        print(f"{nm:11s} {buf[i] / nctu:10.0f} cyc/CTU  {100.0 * buf[i] / tot:5.1f}%")
+
+
+if __name__ == "__main__":
+    main()
