@@ -113,28 +113,20 @@ def main():
         batch.upload(i, distinct[i % len(distinct)])
     ctus_per_frame = lib.kvz_hip_batch_ctus_per_frame(C.c_void_p(batch.handle))
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    from kvazaar_amd import sharding
     for _ in range(args.warmup):
         batch.run(model)
     kernel_ms = []
-    barrier()
-    t0 = time.perf_counter()
-    launches = 0
-    for _ in range(args.steps):
-        launches = lib.kvz_hip_intra_frames(batch.handle, C.byref(model))
+    state = {"launches": 0}
+
+    def step():
+        state["launches"] = lib.kvz_hip_intra_frames(batch.handle, C.byref(model))
         lib.kvz_hip_batch_sync(batch.handle)
         kernel_ms.append(batch.kernel_ms())
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+
+    # EXACTLY `steps` steps between (synchronize + barrier) pairs; MAX over ranks
+    dt = sharding.timed_steps(step, args.steps, dist, torch.cuda.synchronize, "cuda")
+    launches = state["launches"]
 
     if rank == 0:
         total_ctus = args.frames * ctus_per_frame * args.steps * world

@@ -1,0 +1,87 @@
+"""Multi-process path on CPU (gloo, world_size 2): the sharding + timing plumbing bench.py uses under
+torch.distributed.run, exercised with the oracle as the per-rank worker.  Property: the CTU pass over a clip is the
+same whether one process does all frames or two ranks do half each (frames are independent), checked through a
+checksum of per-frame checksums gathered across ranks."""
+import hashlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import ctu_common as cc
+import flatapi
+from kvazaar_amd import sharding
+
+W, H, NFRAMES = 64, 64, 5
+
+
+def _model():
+    m = cc.CostModel()
+    m.lambda_, m.lambda_sqrt, m.qp, m.coeff_weights = 5.745, 5.745 ** 0.5, 22, cc.COEFF_WEIGHTS_QP22
+    for arr in (m.split_flag[0], m.split_flag[1], m.split_flag[2], m.part_size, m.intra_mode, m.chroma_mode, m.cbf_luma[0], m.cbf_luma[1],
+                m.cbf_chroma[0], m.cbf_chroma[1]):
+        arr[0], arr[1] = 0.75, 1.5
+    return m
+
+
+def _frame_digest(oracle, model, frame):
+    o = cc.run_oracle(oracle, model, W, H, frame)
+    h = hashlib.sha256()
+    for k in ("rec", "coeff", "depth", "mode", "cost"):
+        h.update(o[k].tobytes())
+    return np.frombuffer(h.digest(), np.uint8).copy()
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    oracle = flatapi.load_oracle()
+    model = _model()
+    frames = cc.yuv_frames(W, H, NFRAMES, 4321, "small")
+    lo, hi = sharding.frames_for_rank(NFRAMES, rank, world)
+    digests = torch.zeros((NFRAMES, 32), dtype=torch.uint8)
+
+    def step():
+        for i in range(lo, hi):
+            digests[i] = torch.from_numpy(_frame_digest(oracle, model, frames[i]))
+    dt = sharding.timed_steps(step, 1, dist)
+    dist.all_reduce(digests.view(torch.uint8).to(torch.int32), op=dist.ReduceOp.SUM)  # smoke: collective works on CPU
+    gathered = [torch.zeros_like(digests) for _ in range(world)]
+    dist.all_gather(gathered, digests)
+    total = sum(g.to(torch.int32) for g in gathered).to(torch.uint8)  # shards are disjoint, the rest is zero
+    if rank == 0:
+        out.put((hashlib.sha256(total.numpy().tobytes()).hexdigest(), dt))
+    dist.destroy_process_group()
+
+
+def test_frames_for_rank_partitions():
+    for n in (1, 5, 8, 96, 97):
+        for world in (1, 2, 3, 8):
+            spans = [sharding.frames_for_rank(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_checksum_equals_single_process(oracle):
+    frames = cc.yuv_frames(W, H, NFRAMES, 4321, "small")
+    model = _model()
+    single = np.stack([_frame_digest(oracle, model, f) for f in frames])
+    want = hashlib.sha256(single.tobytes()).hexdigest()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got, dt = q.get(timeout=120)
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert got == want and dt > 0
