@@ -49,7 +49,9 @@ def cases_dual():
     rng = _rng(101)
     for n in SIZES:
         for rep in range(3):
-            preds = A(rng.integers(0, 256, 2048, dtype=np.uint8))
+            # pred_buffer is kvz_pixel(*)[32*32]: candidate 1 starts 1024 bytes after candidate 0 whatever n is, so the
+            # 64x64 variants (never called by the encoder) read overlapping 4096-byte windows
+            preds = A(rng.integers(0, 256, 1024 + max(1024, n * n), dtype=np.uint8))
             orig = A(rng.integers(0, 256, n * n, dtype=np.uint8))
             if rep == 2:
                 preds[:1024] = 0
