@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include <vector>
+
 #include "../../include/kvz_hip_batch.h"
 #include "kvz_ctu.hpp"
 #include "kvz_runtime.hpp"
@@ -30,6 +32,70 @@ __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_p
   p.run();
 }
 
+// ---- single-launch schedule: in-order tickets --------------------------------------------------------------------
+// Work items (one CTU each) are listed in an order in which every CTU comes after the CTUs it depends on (anti-diagonal
+// x + 2y ascending, all frames interleaved).  Workgroups draw tickets from an atomic counter and process the item behind
+// the ticket; before touching neighbour data they wait for the `done` flags of the left and the above-right CTU.
+// Deadlock-free for ANY number of resident workgroups: an item only ever waits for items with smaller tickets, and every
+// smaller ticket has been drawn by a workgroup that is running (induction over the ticket order) -- no co-residency of
+// the whole grid is assumed.  Hand-off follows the agent-scope release/acquire recipe of the CDNA guide (G16): producer
+// drains its stores, one lane releases at agent scope and stores the flag; consumer polls relaxed, one lane acquires,
+// then the workgroup barrier.  Compared with one launch per diagonal this removes the per-launch tail (a diagonal of
+// n CTUs x F frames rarely is a multiple of the resident workgroup count) and 61 of 62 launches.
+struct CtuSched {
+  const uint32_t *items;  // [total]: frame << 16 | y << 8 | x  (CTU coordinates)
+  unsigned *ticket;       // atomic ticket counter, zeroed before every launch
+  unsigned *done;         // [frames * ctus_per_frame]: epoch of the last call that completed the CTU
+  unsigned *error;        // set when a wait exceeds its spin bound (never in a healthy run)
+  unsigned total, epoch;
+};
+
+__device__ __forceinline__ bool wait_done(unsigned *flag, unsigned epoch, unsigned *error)
+{
+  for (unsigned spins = 0;; ++spins) {
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
+    if (spins > (1u << 22)) { atomicExch(error, 1u); return false; }  // bounded: a lost hand-off must not hang the GPU
+    __builtin_amdgcn_s_sleep(16);
+  }
+}
+
+__global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) intra_ctu_ticket_kernel(const CtuFrames F, const kvz_hip_intra_cost_model model, const Tables *tb,
+                                                                        const CtuSched sched)
+{
+  __shared__ CtuShared shared;
+  __shared__ kvz_hip_intra_cost_model m;
+  __shared__ unsigned s_ticket;
+  if (threadIdx.x == 0) m = model;
+  const int ctus = F.wc * F.hc;
+  for (;;) {
+    __syncthreads();  // previous item fully retired (and m visible on the first trip)
+    if (threadIdx.x == 0) s_ticket = atomicAdd(sched.ticket, 1u);
+    __syncthreads();
+    const unsigned t = s_ticket;
+    if (t >= sched.total) break;
+    const uint32_t item = sched.items[t];
+    const int frame = item >> 16, y = (item >> 8) & 0xff, x = item & 0xff;
+    if (threadIdx.x == 0) {
+      unsigned *done = sched.done + (long)frame * ctus;
+      if (x > 0) wait_done(&done[y * F.wc + x - 1], sched.epoch, sched.error);
+      if (y > 0) wait_done(&done[(y - 1) * F.wc + (x + 1 < F.wc ? x + 1 : x)], sched.epoch, sched.error);  // above-right implies above and above-left
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    CtuProgram p;
+    p.m = &m; p.tb = tb; p.F = F; p.s = &shared;
+    p.frame = frame; p.cx = x * 64; p.cy = y * 64;
+    p.run();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its stores (reconstruction, CU info, coefficients)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&sched.done[(long)frame * ctus + y * F.wc + x], sched.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 }  // namespace kvz
 
 struct kvz_hip_batch {
@@ -41,6 +107,10 @@ struct kvz_hip_batch {
   int16_t *d_coeff, *d_scratch;
   double *d_cost;
   unsigned long long *d_prof;
+  uint32_t *d_items;
+  unsigned *d_ticket, *d_done, *d_error;
+  unsigned total_items, epoch;
+  int sched_ticket, grid_ticket;
 };
 
 namespace kvz {
@@ -121,6 +191,34 @@ kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_prof, kvz::KVZ_P_COUNT * sizeof(unsigned long long)));
   KVZ_HIP_CHECK(hipMemset(b->d_prof, 0, kvz::KVZ_P_COUNT * sizeof(unsigned long long)));
   F.prof = b->d_prof;
+  {  // ticket schedule: items in dependency order (anti-diagonal, frame, row)
+    std::vector<uint32_t> items;
+    items.reserve(nctu);
+    for (int wave = 0; wave <= (F.wc - 1) + 2 * (F.hc - 1); wave++)
+      for (int f = 0; f < n_frames; f++)
+        for (int y = 0; y < F.hc; y++) {
+          const int x = wave - 2 * y;
+          if (x >= 0 && x < F.wc) items.push_back((uint32_t)f << 16 | (uint32_t)y << 8 | (uint32_t)x);
+        }
+    b->total_items = (unsigned)items.size();
+    b->epoch = 0;
+    KVZ_HIP_CHECK(hipMalloc((void **)&b->d_items, items.size() * sizeof(uint32_t)));
+    KVZ_HIP_CHECK(hipMemcpy(b->d_items, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    KVZ_HIP_CHECK(hipMalloc((void **)&b->d_done, nctu * sizeof(unsigned)));
+    KVZ_HIP_CHECK(hipMemset(b->d_done, 0, nctu * sizeof(unsigned)));
+    KVZ_HIP_CHECK(hipMalloc((void **)&b->d_ticket, 2 * sizeof(unsigned)));
+    KVZ_HIP_CHECK(hipMemset(b->d_ticket, 0, 2 * sizeof(unsigned)));
+    b->d_error = b->d_ticket + 1;
+    const char *e = getenv("KVZ_HIP_SCHED");  // "wave": one launch per anti-diagonal (the simpler schedule, kept for A/B)
+    b->sched_ticket = !(e && e[0] == 'w') && n_frames < 65536 && F.wc < 256 && F.hc < 256;
+    int per_cu = 0, dev = 0, cus = 0;
+    KVZ_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kvz::intra_ctu_ticket_kernel, KVZ_CTU_THREADS, 0));
+    KVZ_HIP_CHECK(hipGetDevice(&dev));
+    KVZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (per_cu < 1) per_cu = 1;
+    b->grid_ticket = per_cu * cus;
+    if ((unsigned)b->grid_ticket > b->total_items) b->grid_ticket = (int)b->total_items;
+  }
   F.src = b->d_src; F.rec = b->d_rec; F.coeff = b->d_coeff; F.coeff_scratch = b->d_scratch;
   F.cu_depth = b->d_depth; F.cu_mode = b->d_mode; F.ctu_cost = b->d_cost;
   return b;
@@ -130,6 +228,7 @@ void kvz_hip_batch_destroy(kvz_hip_batch *b)
 {
   if (!b) return;
   hipStreamSynchronize(b->stream);
+  hipFree(b->d_items); hipFree(b->d_done); hipFree(b->d_ticket); hipFree(b->d_prof);
   hipFree(b->d_src); hipFree(b->d_rec); hipFree(b->d_coeff); hipFree(b->d_scratch); hipFree(b->d_depth); hipFree(b->d_mode); hipFree(b->d_cost);
   hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
   hipStreamDestroy(b->stream);
@@ -168,6 +267,16 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
 {
   const kvz::CtuFrames &F = b->F;
   int launches = 0;
+  if (b->sched_ticket) {
+    b->epoch++;
+    KVZ_HIP_CHECK(hipMemsetAsync(b->d_ticket, 0, 2 * sizeof(unsigned), b->stream));
+    KVZ_HIP_CHECK(hipEventRecord(b->ev0, b->stream));
+    kvz::CtuSched sc{ b->d_items, b->d_ticket, b->d_done, b->d_error, b->total_items, b->epoch };
+    hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, *model, kvz::device_tables(), sc);
+    KVZ_HIP_CHECK(hipGetLastError());
+    KVZ_HIP_CHECK(hipEventRecord(b->ev1, b->stream));
+    return 1;
+  }
   KVZ_HIP_CHECK(hipEventRecord(b->ev0, b->stream));
   // CTU (x, y) needs (x-1, y), (x, y-1), (x+1, y-1): all of them lie on earlier anti-diagonals x + 2y (the WPP order of
   // encoderstate.c:793-903), so one launch per diagonal needs no synchronisation inside the launch.
@@ -187,7 +296,15 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
   return launches;
 }
 
-void kvz_hip_batch_sync(kvz_hip_batch *b) { KVZ_HIP_CHECK(hipStreamSynchronize(b->stream)); }
+void kvz_hip_batch_sync(kvz_hip_batch *b)
+{
+  KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+  if (b->sched_ticket) {
+    unsigned err = 0;
+    KVZ_HIP_CHECK(hipMemcpy(&err, b->d_error, sizeof err, hipMemcpyDeviceToHost));
+    if (err) { fprintf(stderr, "kvz_hip: CTU hand-off wait timed out -- results are invalid, aborting\n"); abort(); }
+  }
+}
 
 /* cycle counters of a -DKVZ_CTU_PROFILE build (all zero otherwise); reading resets them */
 int kvz_hip_batch_profile(kvz_hip_batch *b, unsigned long long *out, int n)
