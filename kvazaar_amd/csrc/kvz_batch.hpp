@@ -106,6 +106,7 @@ struct kvz_hip_batch {
   uint8_t *d_src, *d_rec, *d_depth, *d_mode;
   int16_t *d_coeff, *d_scratch;
   double *d_cost;
+  uint8_t *d_border;
   unsigned long long *d_prof;
   uint32_t *d_items;
   unsigned *d_ticket, *d_done, *d_error;
@@ -187,10 +188,13 @@ kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_depth, ncu));
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_mode, ncu));
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_cost, nctu * sizeof(double)));
-  KVZ_HIP_CHECK(hipMemset(b->d_rec, 0, F.frame_px * n_frames));
+  KVZ_HIP_CHECK(hipMemsetAsync(b->d_rec, 0, F.frame_px * n_frames, b->stream));  // on the batch's stream: a non-blocking stream does not order against the null stream
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_prof, kvz::KVZ_P_COUNT * sizeof(unsigned long long)));
-  KVZ_HIP_CHECK(hipMemset(b->d_prof, 0, kvz::KVZ_P_COUNT * sizeof(unsigned long long)));
+  KVZ_HIP_CHECK(hipMemsetAsync(b->d_prof, 0, kvz::KVZ_P_COUNT * sizeof(unsigned long long), b->stream));
   F.prof = b->d_prof;
+  KVZ_HIP_CHECK(hipMalloc((void **)&b->d_border, nctu * KVZ_BORDER_BYTES));
+  KVZ_HIP_CHECK(hipMemsetAsync(b->d_border, 0, nctu * KVZ_BORDER_BYTES, b->stream));
+  F.border = b->d_border;
   {  // ticket schedule: items in dependency order (anti-diagonal, frame, row)
     std::vector<uint32_t> items;
     items.reserve(nctu);
@@ -205,9 +209,9 @@ kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
     KVZ_HIP_CHECK(hipMalloc((void **)&b->d_items, items.size() * sizeof(uint32_t)));
     KVZ_HIP_CHECK(hipMemcpy(b->d_items, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     KVZ_HIP_CHECK(hipMalloc((void **)&b->d_done, nctu * sizeof(unsigned)));
-    KVZ_HIP_CHECK(hipMemset(b->d_done, 0, nctu * sizeof(unsigned)));
+    KVZ_HIP_CHECK(hipMemsetAsync(b->d_done, 0, nctu * sizeof(unsigned), b->stream));
     KVZ_HIP_CHECK(hipMalloc((void **)&b->d_ticket, 2 * sizeof(unsigned)));
-    KVZ_HIP_CHECK(hipMemset(b->d_ticket, 0, 2 * sizeof(unsigned)));
+    KVZ_HIP_CHECK(hipMemsetAsync(b->d_ticket, 0, 2 * sizeof(unsigned), b->stream));
     b->d_error = b->d_ticket + 1;
     const char *e = getenv("KVZ_HIP_SCHED");  // "wave": one launch per anti-diagonal (the simpler schedule, kept for A/B)
     b->sched_ticket = !(e && e[0] == 'w') && n_frames < 65536 && F.wc < 256 && F.hc < 256;
@@ -219,6 +223,7 @@ kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
     b->grid_ticket = per_cu * cus;
     if ((unsigned)b->grid_ticket > b->total_items) b->grid_ticket = (int)b->total_items;
   }
+  KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
   F.src = b->d_src; F.rec = b->d_rec; F.coeff = b->d_coeff; F.coeff_scratch = b->d_scratch;
   F.cu_depth = b->d_depth; F.cu_mode = b->d_mode; F.ctu_cost = b->d_cost;
   return b;
@@ -228,7 +233,7 @@ void kvz_hip_batch_destroy(kvz_hip_batch *b)
 {
   if (!b) return;
   hipStreamSynchronize(b->stream);
-  hipFree(b->d_items); hipFree(b->d_done); hipFree(b->d_ticket); hipFree(b->d_prof);
+  hipFree(b->d_border); hipFree(b->d_items); hipFree(b->d_done); hipFree(b->d_ticket); hipFree(b->d_prof);
   hipFree(b->d_src); hipFree(b->d_rec); hipFree(b->d_coeff); hipFree(b->d_scratch); hipFree(b->d_depth); hipFree(b->d_mode); hipFree(b->d_cost);
   hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
   hipStreamDestroy(b->stream);
@@ -312,7 +317,8 @@ int kvz_hip_batch_profile(kvz_hip_batch *b, unsigned long long *out, int n)
   KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
   if (n > kvz::KVZ_P_COUNT) n = kvz::KVZ_P_COUNT;
   KVZ_HIP_CHECK(hipMemcpy(out, b->d_prof, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  KVZ_HIP_CHECK(hipMemset(b->d_prof, 0, kvz::KVZ_P_COUNT * sizeof(unsigned long long)));
+  KVZ_HIP_CHECK(hipMemsetAsync(b->d_prof, 0, kvz::KVZ_P_COUNT * sizeof(unsigned long long), b->stream));
+  KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
   return kvz::KVZ_P_COUNT;
 }
 

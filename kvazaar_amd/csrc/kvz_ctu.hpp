@@ -65,6 +65,19 @@ enum { KVZ_P_INIT = 0, KVZ_P_REFS, KVZ_P_PRED35, KVZ_P_SATD, KVZ_P_SELECT, KVZ_P
 #define KVZ_PROF(cat)
 #endif
 
+// One byte of another workgroup's border record.  On the device the containing dword is read with an agent-scope
+// atomic load (sc1: served from the coherent memory side, never from a stale non-coherent L2/L1 line).
+KVZ_DEV u8 load_shared_byte(const u8 *p)
+{
+#ifdef KVZ_HOSTSIM
+  return *p;
+#else
+  const unsigned long long a = (unsigned long long)p;
+  const unsigned w = __hip_atomic_load((const unsigned *)(a & ~3ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return (u8)(w >> (8 * (a & 3)));
+#endif
+}
+
 struct CtuCu { u8 type, depth, mode, tr_depth; uint16_t cbf; uint16_t pad; };  // one per 8x8 (min CU)
 
 // Frame-level device buffers of one batch (all frames share the geometry).
@@ -78,7 +91,14 @@ struct CtuFrames {
   u8 *cu_depth, *cu_mode;    // [frames][(H/8)*(W/8)]
   double *ctu_cost;          // [frames][ctu]
   unsigned long long *prof;  // [KVZ_P_COUNT] cycle counters (KVZ_CTU_PROFILE builds only, else unused)
+  // What a CTU hands to its right / lower neighbours: KVZ_BORDER_BYTES per CTU = three 128-byte lines with ONE producer each
+  //   [0..127]   bottom row   Y 64 | U 32 | V 32        [128..255] right column Y 64 | U 32 | V 32
+  //   [256..287] CU info: depth of the bottom 8x8 row [8], mode [8], depth of the right 8x8 column [8], mode [8]
+  // Neighbour data is exchanged ONLY through these records: the frame-level rec / cu arrays share cache lines between CTUs
+  // produced on different XCDs, and a line that is dirty in the reader's L2 cannot be invalidated by its acquire.
+  u8 *border;                // [frames][ctu][KVZ_BORDER_BYTES]
 };
+#define KVZ_BORDER_BYTES 384
 
 struct CtuShared {
   u8 org[6144];              // Y 64x64 | U 32x32 | V 32x32
@@ -698,17 +718,35 @@ struct CtuProgram {
       if (cx + 64 > F.W || cy + 64 > F.H)
         for (int lv = 0; lv < 4; lv++) { i16 *cf = coeff_level(lv); for (int e = tid; e < 6144; e += KVZ_CTU_THREADS) cf[e] = 0; }
       for (int e = tid; e < 1024; e += KVZ_CTU_THREADS) s->dct32[e] = tb->dct[3][e];
-      // neighbour CTUs (complete: they lie on earlier anti-diagonals): border pixels and CU info
-      for (int c = 0; c < 3; c++) {
-        const int sh = c ? 1 : 0, lw = 64 >> sh, fw = F.W >> sh, fh = F.H >> sh, ox = cx >> sh, oy = cy >> sh;
-        const u8 *rec = frame_rec(c);
-        for (int i = tid; i < lw + 2; i += KVZ_CTU_THREADS) {  // left column incl. corner, y = oy-1+i
-          const int py = oy - 1 + i;
-          s->bpx_left[c][i] = (cx > 0 && py >= 0 && py < fh) ? rec[(long)py * fw + ox - 1] : 0;
+      // neighbour CTUs (complete: they come earlier in the dependency order): border pixels and CU info from their records
+      {
+        const int ctx = cx >> 6, cty = cy >> 6;
+        const u8 *base = F.border + (long)frame * F.wc * F.hc * KVZ_BORDER_BYTES;
+        const u8 *r_left = ctx > 0 ? base + (long)(cty * F.wc + ctx - 1) * KVZ_BORDER_BYTES : nullptr;
+        const u8 *r_top = cty > 0 ? base + (long)((cty - 1) * F.wc + ctx) * KVZ_BORDER_BYTES : nullptr;
+        const u8 *r_tl = (ctx > 0 && cty > 0) ? base + (long)((cty - 1) * F.wc + ctx - 1) * KVZ_BORDER_BYTES : nullptr;
+        const u8 *r_tr = (cty > 0 && ctx + 1 < F.wc) ? base + (long)((cty - 1) * F.wc + ctx + 1) * KVZ_BORDER_BYTES : nullptr;
+        for (int c = 0; c < 3; c++) {
+          const int lw = c ? 32 : 64, po = c == 0 ? 0 : (c == 1 ? 64 : 96);  // plane offset inside a 128-byte row / column record
+          for (int i = tid; i < lw + 2; i += KVZ_CTU_THREADS) {  // left column incl. corner: index i <-> y = oy - 1 + i
+            u8 v = 0;
+            if (i == 0) { if (r_tl) v = load_shared_byte(r_tl + po + lw - 1); }
+            else if (i <= lw) { if (r_left) v = load_shared_byte(r_left + 128 + po + i - 1); }
+            s->bpx_left[c][i] = v;
+          }
+          for (int i = tid; i < lw + (lw >> 1) + 2; i += KVZ_CTU_THREADS) {  // top row incl. corner: index i <-> x = ox - 1 + i
+            u8 v = 0;
+            if (i == 0) { if (r_tl) v = load_shared_byte(r_tl + po + lw - 1); }
+            else if (i <= lw) { if (r_top) v = load_shared_byte(r_top + po + i - 1); }
+            else if (r_tr) v = load_shared_byte(r_tr + po + i - 1 - lw);
+            s->bpx_top[c][i] = v;
+          }
         }
-        for (int i = tid; i < lw + (lw >> 1) + 2; i += KVZ_CTU_THREADS) {  // top row incl. corner, x = ox-1+i
-          const int px = ox - 1 + i;
-          s->bpx_top[c][i] = (cy > 0 && px >= 0 && px < fw) ? rec[(long)(oy - 1) * fw + px] : 0;
+        if (tid < 16) {
+          const int side = tid >> 3, i = tid & 7;
+          const u8 *r = side == 0 ? r_left : r_top;
+          s->nb_depth[side][i] = r ? load_shared_byte(r + 256 + (side == 0 ? 16 : 0) + i) : 0;
+          s->nb_mode[side][i] = r ? load_shared_byte(r + 256 + (side == 0 ? 24 : 8) + i) : 0;
         }
       }
       if (tid >= 64 && tid < 64 + 35) {  // angular parameters (intra-generic.c:59-76)
@@ -723,16 +761,7 @@ struct CtuProgram {
         s->mode_bits_cost[1] = m->lambda_sqrt * ((double)m->intra_mode[1] + 1);
         s->mode_bits_cost[2] = m->lambda_sqrt * ((double)m->intra_mode[1] + 2);
       }
-      if (tid < 16) {
-        const int side = tid >> 3, i = tid & 7;
-        const int fx = side == 0 ? cx - 1 : cx + i * 8, fy = side == 0 ? cy + i * 8 : cy - 1;
-        u8 d = 0, md = 0;
-        if (fx >= 0 && fy >= 0 && fx < F.W && fy < F.H) {
-          const long gi = (long)frame * (F.H >> 3) * (F.W >> 3) + (long)(fy >> 3) * (F.W >> 3) + (fx >> 3);
-          d = F.cu_depth[gi]; md = F.cu_mode[gi];
-        }
-        s->nb_depth[side][i] = d; s->nb_mode[side][i] = md;
-      }
+
     }
     KVZ_SYNC();
   }
@@ -758,6 +787,18 @@ struct CtuProgram {
         }
       }
       if (tid == 0) F.ctu_cost[(long)frame * F.wc * F.hc + ctu_index()] = s->cost[0];
+      {  // border record for the right / lower neighbours
+        u8 *r = F.border + ((long)frame * F.wc * F.hc + ctu_index()) * KVZ_BORDER_BYTES;
+        if (tid < 128) {
+          const int c = tid < 64 ? 0 : (tid < 96 ? 1 : 2), i = tid < 64 ? tid : (tid - 64) & 31, lw = c ? 32 : 64;
+          r[tid] = s->rec[0][kPlaneOff[c] + (lw - 1) * lw + i];        // bottom row
+          r[128 + tid] = s->rec[0][kPlaneOff[c] + i * lw + lw - 1];    // right column
+        } else if (tid < 128 + 32) {
+          const int k = tid - 128, i = k & 7;
+          const CtuCu *cu = &s->cu[0][k < 16 ? 56 + i : i * 8 + 7];
+          r[256 + k] = ((k >> 3) & 1) ? cu->mode : cu->depth;
+        }
+      }
     }
     KVZ_SYNC();
   }
@@ -877,7 +918,11 @@ struct CtuProgram {
         KVZ_SYNC();
       }
     }
-    if (s->split_cost[2] < s->cost[2]) {
+    // Every lane reads the verdict BEFORE lane 0 may overwrite its operands: without the barrier a lagging wave could
+    // read cost[2] after the update and take the other branch (the host simulation cannot show that race).
+    const bool split_wins2 = s->split_cost[2] < s->cost[2];
+    KVZ_SYNC();
+    if (split_wins2) {
       KVZ_FOR_THREADS(tid) { if (tid == 0) s->cost[2] = s->split_cost[2]; }
       KVZ_SYNC();
       copy_region(3, 2, xl, yl, 16, true);  // work_tree_copy_up
@@ -912,7 +957,9 @@ struct CtuProgram {
         KVZ_SYNC();
       }
       if (x1 + 32 <= F.W && y1 + 32 <= F.H) try_merge(x1, y1, 1);
-      if (s->split_cost[1] < s->cost[1]) {
+      const bool split_wins1 = s->split_cost[1] < s->cost[1];
+      KVZ_SYNC();
+      if (split_wins1) {
         KVZ_FOR_THREADS(tid) { if (tid == 0) s->cost[1] = s->split_cost[1]; }
         KVZ_SYNC();
         copy_region(2, 1, x1 - cx, y1 - cy, 32, true);
@@ -923,7 +970,9 @@ struct CtuProgram {
       KVZ_SYNC();
     }
     if (cx + 64 <= F.W && cy + 64 <= F.H) try_merge(cx, cy, 0);
-    if (s->split_cost[0] < s->cost[0]) {
+    const bool split_wins0 = s->split_cost[0] < s->cost[0];
+    KVZ_SYNC();
+    if (split_wins0) {
       KVZ_FOR_THREADS(tid) { if (tid == 0) s->cost[0] = s->split_cost[0]; }
       KVZ_SYNC();
       copy_region(1, 0, 0, 0, 64, true);

@@ -40,6 +40,8 @@ extern "C" void kvz_hostsim_intra_frame(const kvz_hip_intra_cost_model *m, int w
   kvz::CtuFrames F;
   F.W = width; F.H = height; F.wc = (width + 63) / 64; F.hc = (height + 63) / 64; F.frame_px = (long)width * height * 3 / 2;
   F.src = src; F.rec = rec; F.coeff = coeff; F.cu_depth = cu_depth; F.cu_mode = cu_mode; F.ctu_cost = ctu_cost; F.prof = nullptr;
+  uint8_t *border = (uint8_t *)calloc((size_t)F.wc * F.hc, KVZ_BORDER_BYTES);
+  F.border = border;
   int16_t *scratch = (int16_t *)calloc((size_t)F.wc * F.hc * 3 * 6144, sizeof(int16_t));
   F.coeff_scratch = scratch;
   kvz::CtuShared *sh = (kvz::CtuShared *)calloc(1, sizeof(kvz::CtuShared));
@@ -51,5 +53,6 @@ extern "C" void kvz_hostsim_intra_frame(const kvz_hip_intra_cost_model *m, int w
     }
   free(sh);
   free(scratch);
+  free(border);
 }
 extern "C" unsigned kvz_hostsim_ctu_shared_bytes(void) { return (unsigned)sizeof(kvz::CtuShared); }

@@ -94,3 +94,25 @@ def test_hip_ctu_full_size_properties(oracle, hiplib):
         assert np.isfinite(batch[i]["cost"]).all() and (batch[i]["cost"] > 0).all()
         assert set(np.unique(batch[i]["depth"])) <= {0, 1, 2, 3}
         assert batch[i]["mode"].max() <= 34
+
+
+def test_hip_ctu_large_batch_stress(oracle, hiplib):
+    """A full-machine batch (36 x 1080p = 18 360 CTUs, more than the ~768 resident workgroups, so the in-order ticket
+    schedule hands CTUs between workgroups and XCDs all the time), run repeatedly: every frame must equal the oracle's
+    result for its picture, every time.  Guards the inter-workgroup hand-off and the barrier discipline of the kernel."""
+    w, h = 1920, 1080
+    model = _model(hiplib, oracle, 22)
+    distinct = cc.yuv_frames(w, h, 3, 5, "large")
+    want = [cc.run_oracle(oracle, model, w, h, f) for f in distinct]
+    n = 36
+    b = cc.HipBatch(hiplib, w, h, n)
+    try:
+        for i in range(n):
+            b.upload(i, distinct[i % 3])
+        for rep in range(4):
+            b.run(model)
+            for i in range(n):
+                got = b.download(i)
+                assert not cc.compare(want[i % 3], got), (rep, i, cc.compare(want[i % 3], got))
+    finally:
+        b.close()
