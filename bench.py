@@ -33,6 +33,24 @@ def synth_frames(w, h, n, seed):
     return [np.concatenate([p.reshape(-1) for p in planes]) for planes in synth.frames(w, h, n, seed, "large")]
 
 
+def pmc_traffic(args, launches):
+    """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE + WRITE_SIZE, collected with
+    rocprofv3 in separate passes and committed under profiles/): only reported when the committed measurement was taken
+    on this exact workload, otherwise null."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json"))):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        w = d.get("workload", {})
+        if (w.get("width"), w.get("height"), w.get("frames")) == (args.width, args.height, args.frames) and \
+                (w.get("schedule") == "ticket") == (launches == 1):
+            best = d
+    return None if best is None else {"bytes_per_launch": best["bytes_per_launch"], "source": "profiles (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, raw counters x1024)"}
+
+
 def cpu_baseline(args, frames, model):
     """The oracle's restatement of the same pass (kind "port") on ONE host core over a bounded sample of the same
     frames, plus -- when the prebuilt reference encoder is present -- kvazaar's own AVX2 encoder on all host cores."""
@@ -145,7 +163,7 @@ def main():
                        "frames_per_gpu_per_step": args.frames, "ctus_per_frame": ctus_per_frame, "distinct_frames": len(distinct),
                        "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": "intra_ctu_wave_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches_per_step": launches,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, launches), "launches_per_step": launches,
                          "avg_launch_us": per_launch_s * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "latency/dependency-bound CTU search: see DESIGN.md"},
         }
