@@ -14,7 +14,7 @@ namespace kvz {
 
 // One workgroup per CTU of the anti-diagonal `wave` (x + 2y == wave) of every frame.
 #ifndef KVZ_CTU_WAVES_PER_EU
-#define KVZ_CTU_WAVES_PER_EU 3  /* 3 workgroups of 256 lanes per CU: the LDS footprint (~53 KB) allows no more */
+#define KVZ_CTU_WAVES_PER_EU 4  /* 4 workgroups of 256 lanes per CU: what the LDS footprint (~37 KB) allows */
 #endif
 __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) intra_ctu_wave_kernel(const CtuFrames F, const kvz_hip_intra_cost_model model, const Tables *tb,
                                                                         const int wave, const int y_min, const int n_diag)
@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_p
     CtuProgram p;
     p.m = &m; p.tb = tb; p.F = F; p.s = &shared;
     p.frame = frame; p.cx = x * 64; p.cy = y * 64;
+    p.lane_rot = (t * 64) & (KVZ_CTU_THREADS - 1);
     p.run();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its stores (reconstruction, CU info, coefficients)
     __syncthreads();
@@ -184,7 +185,7 @@ kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_src, F.frame_px * n_frames));
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_rec, F.frame_px * n_frames));
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_coeff, nctu * 6144 * sizeof(int16_t)));
-  KVZ_HIP_CHECK(hipMalloc((void **)&b->d_scratch, nctu * 3 * 6144 * sizeof(int16_t)));
+  KVZ_HIP_CHECK(hipMalloc((void **)&b->d_scratch, nctu * 6144 * sizeof(int16_t)));
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_depth, ncu));
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_mode, ncu));
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_cost, nctu * sizeof(double)));
@@ -232,11 +233,11 @@ kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
 void kvz_hip_batch_destroy(kvz_hip_batch *b)
 {
   if (!b) return;
-  hipStreamSynchronize(b->stream);
-  hipFree(b->d_border); hipFree(b->d_items); hipFree(b->d_done); hipFree(b->d_ticket); hipFree(b->d_prof);
-  hipFree(b->d_src); hipFree(b->d_rec); hipFree(b->d_coeff); hipFree(b->d_scratch); hipFree(b->d_depth); hipFree(b->d_mode); hipFree(b->d_cost);
-  hipEventDestroy(b->ev0); hipEventDestroy(b->ev1);
-  hipStreamDestroy(b->stream);
+  (void)hipStreamSynchronize(b->stream);
+  (void)hipFree(b->d_border); (void)hipFree(b->d_items); (void)hipFree(b->d_done); (void)hipFree(b->d_ticket); (void)hipFree(b->d_prof);
+  (void)hipFree(b->d_src); (void)hipFree(b->d_rec); (void)hipFree(b->d_coeff); (void)hipFree(b->d_scratch); (void)hipFree(b->d_depth); (void)hipFree(b->d_mode); (void)hipFree(b->d_cost);
+  (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1);
+  (void)hipStreamDestroy(b->stream);
   delete b;
 }
 

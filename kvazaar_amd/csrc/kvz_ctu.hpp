@@ -38,7 +38,10 @@ namespace kvz {
 #define KVZ_SYNC()
 #define KVZ_LDS_ADD(p, v) (*(p) += (v))
 #else
-#define KVZ_FOR_THREADS(tid) for (int tid = threadIdx.x, once_ = 1; once_; once_ = 0)
+// lane_rot (a multiple of 64, wavefront-uniform) rotates which wavefront plays "threads 0..63": the lane-starved stages of a
+// small CU only occupy the first wavefront's worth of thread ids, and without the rotation that would always be the
+// wavefront on SIMD 0 of every workgroup.
+#define KVZ_FOR_THREADS(tid) for (int tid = (threadIdx.x + lane_rot) & (KVZ_CTU_THREADS - 1), once_ = 1; once_; once_ = 0)
 #define KVZ_SYNC() __syncthreads()
 #define KVZ_LDS_ADD(p, v) atomicAdd((p), (v))
 #endif
@@ -54,6 +57,29 @@ KVZ_DEV void block_add(u32 *dst, u32 v)
   if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
 #endif
 }
+
+#define KVZ_MREF_STRIDE 52  // q in [-16, 33] for a 16x16 CU (odd number of dwords: modes fall in different banks)
+#define KVZ_MREF_ORG 16
+
+// Two int16 lanes in one register (v_pk_add_i16 / v_pk_sub_i16 / v_pk_max_i16 on the device).  The 8x8 Hadamard of 9-bit
+// differences stays within 15 bits + sign, so nothing here can wrap.
+#ifdef KVZ_HOSTSIM
+struct Pk16 { i16 lo, hi; };
+KVZ_DEV Pk16 pk_make(int lo, int hi) { Pk16 r = { (i16)lo, (i16)hi }; return r; }
+KVZ_DEV Pk16 pk_add(Pk16 a, Pk16 b) { return pk_make(a.lo + b.lo, a.hi + b.hi); }
+KVZ_DEV Pk16 pk_sub(Pk16 a, Pk16 b) { return pk_make(a.lo - b.lo, a.hi - b.hi); }
+KVZ_DEV u32 pk_absmax(Pk16 a) { return (u32)imax(iabs(a.lo), iabs(a.hi)); }
+#else
+typedef short Pk16 __attribute__((ext_vector_type(2)));
+KVZ_DEV Pk16 pk_make(int lo, int hi) { Pk16 r; r.x = (short)lo; r.y = (short)hi; return r; }
+KVZ_DEV Pk16 pk_add(Pk16 a, Pk16 b) { return a + b; }
+KVZ_DEV Pk16 pk_sub(Pk16 a, Pk16 b) { return a - b; }
+KVZ_DEV u32 pk_absmax(Pk16 a)
+{
+  const Pk16 m = __builtin_elementwise_max(a, -a);
+  return (u32)imax((int)m.x, (int)m.y);
+}
+#endif
 
 // Optional in-kernel timeline (build with -DKVZ_CTU_PROFILE): lane 0 of every workgroup adds the shader-clock cycles
 // spent since the previous mark to a per-category counter in HBM.  Categories are the KVZ_P_* constants.
@@ -102,11 +128,23 @@ struct CtuFrames {
 
 struct CtuShared {
   u8 org[6144];              // Y 64x64 | U 32x32 | V 32x32
-  u8 rec[4][6144];           // work-tree levels 0..3
+  // Reconstruction.  kvazaar keeps one full lcu_t per depth (search.c:103-122); what those copies hold at any time is
+  // (a) the pixels already decided, identical in every level that can see them, plus (b) one candidate per depth for the
+  // CU being tried.  So: one decided picture + one candidate buffer per depth, sized to that depth's CU.
+  u8 dec[6144];              // decided pixels, Y 64x64 | U 32x32 | V 32x32
+  u8 c1[1536];               // depth-1 candidate (32x32 merge): Y 1024 | U 256 | V 256
+  u8 c2[384];                // depth-2 candidate (16x16 CU):     Y 256 | U 64 | V 64
+  u8 c3[384];                // depth-3 candidates (the four 8x8 CUs of the current 16x16)
+  int final_c0;              // 1 when the 64x64 merge won: the CTU's result is c0 instead of dec
   CtuCu cu[4][64];
   u8 ref[3][2][132];         // [plane][0 top / 1 left][2w+1]
   u8 fref[2][132];           // filtered luma refs
-  u8 pred[35 * 256];         // candidate predictions of the CU being searched (<= 16x16)
+  u8 c0[6144];               // depth-0 candidate (64x64 merge), only live at the very end of the CTU
+  u8 pred[2 * 256];          // planar and DC predictions of the CU being searched (<= 16x16)
+  // Rough search, angular modes: per mode the main reference with its projected extension (intra-generic.c:97-123),
+  // already picked from the filtered / unfiltered, top / left arrays.  Entry [mode - 2][KVZ_MREF_ORG + q] is ref_main[q].
+  u8 mref[33][KVZ_MREF_STRIDE];
+  u8 org_t[256];             // the CU's source block transposed (horizontal modes are predicted and scored transposed)
   i16 tb[2][1536];           // transform scratch: Y (<= 1024) | U (<= 256) | V (<= 256)
   u32 satd[35];
   u32 acc[16];               // [0..2] ssd per plane, [3..5] coeff weight sums, [6..8] non-zero counts
@@ -139,6 +177,8 @@ struct CtuProgram {
   CtuFrames F;
   CtuShared *s;
   int frame, cx, cy;  // CTU origin (luma px)
+  int a1x, a1y, a2x, a2y;  // CTU-local luma origin of the depth-1 / depth-2 CU whose candidates are live (uniform)
+  int lane_rot = 0;        // see KVZ_FOR_THREADS
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
   unsigned long long t_last;
   __device__ void prof_mark(int cat)
@@ -157,8 +197,40 @@ struct CtuProgram {
   KVZ_DEV int ctu_index() const { return (cy >> 6) * F.wc + (cx >> 6); }
   KVZ_DEV i16 *coeff_level(int level) const
   {
+    // 8x8 CUs write straight into the CTU's output block; every larger CU is a challenger that writes the scratch block
+    // and is copied over only if it wins (commit()).  One scratch block is enough: a depth's challenger is dead by the
+    // time the next shallower depth writes the same z-order range.
     const long ci = (long)frame * F.wc * F.hc + ctu_index();
-    return level == 0 ? F.coeff + ci * 6144 : F.coeff_scratch + (ci * 3 + (level - 1)) * 6144;
+    return level == 3 ? F.coeff + ci * 6144 : F.coeff_scratch + ci * 6144;
+  }
+  // Candidate buffer of depth `lv`, addressed with plane-local CTU coordinates: pixel (x, y) of plane c is
+  // buf[bias[c] + (y << lw[c]) + x].  Everything in it is wavefront-uniform.
+  struct CandView {
+    u8 *buf;
+    int bias[3], lw[3];
+    KVZ_DEV u8 &at(int c, int x, int y) const { return buf[bias[c] + (y << lw[c]) + x]; }
+  };
+  KVZ_DEV CandView cand_view(int lv) const
+  {
+    CandView v;
+    if (lv == 0) {
+      v.buf = s->c0;
+      v.lw[0] = 6; v.lw[1] = v.lw[2] = 5;
+      v.bias[0] = 0; v.bias[1] = 4096; v.bias[2] = 5120;
+    } else if (lv == 1) {
+      v.buf = s->c1;
+      v.lw[0] = 5; v.lw[1] = v.lw[2] = 4;
+      v.bias[0] = -(a1y * 32 + a1x);
+      v.bias[1] = 1024 - ((a1y >> 1) * 16 + (a1x >> 1));
+      v.bias[2] = v.bias[1] + 256;
+    } else {
+      v.buf = lv == 2 ? s->c2 : s->c3;
+      v.lw[0] = 4; v.lw[1] = v.lw[2] = 3;
+      v.bias[0] = -(a2y * 16 + a2x);
+      v.bias[1] = 256 - ((a2y >> 1) * 8 + (a2x >> 1));
+      v.bias[2] = v.bias[1] + 64;
+    }
+    return v;
   }
   KVZ_DEV static unsigned zorder(int x, int y)  // cu.h:385-421
   {
@@ -183,7 +255,15 @@ struct CtuProgram {
   KVZ_DEV u8 rec_px(int lv, int c, int px, int py) const
   {
     const int sh = c ? 1 : 0, w = 64 >> sh, ox = cx >> sh, oy = cy >> sh;
-    if (px >= ox && px < ox + w && py >= oy && py < oy + w) return s->rec[lv][kPlaneOff[c] + (py - oy) * w + (px - ox)];
+    if (px >= ox && px < ox + w && py >= oy && py < oy + w) {
+      const int pxl = px - ox, pyl = py - oy;
+      if (lv == 0) return s->c0[kPlaneOff[c] + pyl * w + pxl];  // the 64x64 merge predicts its 32x32 units from each other
+      if (lv == 3) {  // an 8x8 CU sees its already-tried siblings inside the current 16x16, decided pixels elsewhere
+        const int rx = a2x >> sh, ry = a2y >> sh, rw = 16 >> sh;
+        if (pxl >= rx && pxl < rx + rw && pyl >= ry && pyl < ry + rw) return s->c3[(c == 0 ? 0 : (c == 1 ? 256 : 320)) + (pyl - ry) * rw + pxl - rx];
+      }
+      return s->dec[kPlaneOff[c] + pyl * w + pxl];  // depths 1 and 2 never look inside their own CU
+    }
     // neighbour CTUs: left column (px == ox-1) or top row (py == oy-1), staged in LDS by init()
     return px < ox ? s->bpx_left[c][py - oy + 1] : s->bpx_top[c][px - ox + 1];
   }
@@ -364,6 +444,54 @@ struct CtuProgram {
     return sum;
   }
 
+  // One angular mode on one 8x8 block of the CU, predicted and Hadamard-scored by a single lane without leaving
+  // registers.  Equals the block's sum |H D H^T| of picture-generic.c:252-340 (before the (s + 2) >> 2 rounding) for
+  // D = intra-generic.c:49-155 prediction minus source:
+  //  - horizontal modes run the same code on the transposed problem (main reference = left, source block transposed);
+  //    the Hadamard magnitudes of D^T are those of D;
+  //  - butterfly stages commute, so the one stage that would pair the two halves of a packed register is done last and
+  //    folded into the magnitude sum: |a + b| + |a - b| = 2 max(|a|, |b|).
+  KVZ_DEV u32 angular_block_satd(int log2w, int mode, int bx, int by, int xl, int yl) const
+  {
+    const int w = 1 << log2w;
+    const bool vertical = mode >= 18;
+    const int disp = s->mode_disp[mode];
+    const int p0 = vertical ? bx : by, q0 = vertical ? by : bx;  // block origin along / across the main reference
+    const u8 *mr = s->mref[mode - 2] + KVZ_MREF_ORG + p0 + 1;
+    const u8 *org = vertical ? s->org + (yl + by) * 64 + xl + bx : s->org_t + bx * w + by;
+    const int ostride = vertical ? 64 : w;
+    const u8 *side = vertical ? s->ref[0][1] : s->ref[0][0];  // intra.c:207-219: modes 10 / 26 use the unfiltered references
+    const bool edge = disp == 0 && p0 == 0;
+    Pk16 d[8][4];
+    for (int r = 0; r < 8; r++) {
+      const int qa = q0 + r + 1, delta = qa * disp, di = delta >> 5, df = delta & 31;
+      const u8 *m = mr + di;
+      const u8 *o = org + r * ostride;
+      int v[8], a = m[0];
+      for (int k = 0; k < 8; k++) {
+        const int b = m[k + 1];
+        v[k] = ((32 - df) * a + df * b + 16) >> 5;
+        a = b;
+      }
+      if (edge) v[0] = iclip(0, 255, v[0] + (((int)side[qa] - (int)side[0]) >> 1));
+      for (int j = 0; j < 4; j++) d[r][j] = pk_make(v[2 * j] - (int)o[2 * j], v[2 * j + 1] - (int)o[2 * j + 1]);
+    }
+    for (int r = 0; r < 8; r++) {  // along the rows: columns k and k + 4, then k and k + 2 (k and k + 1 is the folded stage)
+      const Pk16 a0 = pk_add(d[r][0], d[r][2]), a1 = pk_add(d[r][1], d[r][3]), a2 = pk_sub(d[r][0], d[r][2]), a3 = pk_sub(d[r][1], d[r][3]);
+      d[r][0] = pk_add(a0, a1); d[r][1] = pk_sub(a0, a1); d[r][2] = pk_add(a2, a3); d[r][3] = pk_sub(a2, a3);
+    }
+    u32 sum = 0;
+    for (int j = 0; j < 4; j++) {  // down the columns, two columns per register
+      const Pk16 a0 = pk_add(d[0][j], d[4][j]), a1 = pk_add(d[1][j], d[5][j]), a2 = pk_add(d[2][j], d[6][j]), a3 = pk_add(d[3][j], d[7][j]);
+      const Pk16 a4 = pk_sub(d[0][j], d[4][j]), a5 = pk_sub(d[1][j], d[5][j]), a6 = pk_sub(d[2][j], d[6][j]), a7 = pk_sub(d[3][j], d[7][j]);
+      const Pk16 b0 = pk_add(a0, a2), b1 = pk_add(a1, a3), b2 = pk_sub(a0, a2), b3 = pk_sub(a1, a3);
+      const Pk16 b4 = pk_add(a4, a6), b5 = pk_add(a5, a7), b6 = pk_sub(a4, a6), b7 = pk_sub(a5, a7);
+      sum += pk_absmax(pk_add(b0, b1)) + pk_absmax(pk_sub(b0, b1)) + pk_absmax(pk_add(b2, b3)) + pk_absmax(pk_sub(b2, b3));
+      sum += pk_absmax(pk_add(b4, b5)) + pk_absmax(pk_sub(b4, b5)) + pk_absmax(pk_add(b6, b7)) + pk_absmax(pk_sub(b6, b7));
+    }
+    return 2 * sum;
+  }
+
   KVZ_DEV u32 mode_satd(int mode, int nblk) const  // SATD_NxN: sum of (block sum + 2) >> 2 (strategies-picture.h:53-69)
   {
     u32 v = 0;
@@ -379,11 +507,25 @@ struct CtuProgram {
     const int log2w = 6 - depth, w = 1 << log2w, xl = x - cx, yl = y - cy, nblk = (w >> 3) * (w >> 3);
     build_refs(lv, x, y, log2w, depth == 3 ? 2 : log2w - 1, true, true);
     KVZ_FOR_THREADS(tid) {
-      for (int i = tid; i < 35 * w * w; i += KVZ_CTU_THREADS) {
-        const int mode = i >> (2 * log2w), e = i & (w * w - 1);
-        s->pred[i] = predict_pixel(log2w, mode, 0, e & (w - 1), e >> log2w);
+      // extended main reference per angular mode
+      const int nq = 3 * w + 2, thres = log2w == 3 ? 7 : 1;
+      for (int i = tid; i < 33 * nq; i += KVZ_CTU_THREADS) {
+        const int mode = 2 + i / nq, q = i % nq - w;
+        const bool vertical = mode >= 18, filt = imin(iabs(mode - 26), iabs(mode - 10)) > thres;
+        const u8 *top = filt ? s->fref[0] : s->ref[0][0], *left = filt ? s->fref[1] : s->ref[0][1];
+        const u8 *main_ref = vertical ? top : left, *side_ref = vertical ? left : top;
+        const int idx = q >= 0 ? q : (128 + (-q) * (int)s->mode_inv[mode]) >> 8;
+        s->mref[mode - 2][KVZ_MREF_ORG + q] = (q >= 0 ? main_ref : side_ref)[imin(idx, 2 * w)];
       }
-      if (tid < 35 * 4) s->satd_raw[tid >> 2][tid & 3] = 0;
+      for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) {
+        const int ex = e >> log2w, ey = e & (w - 1);
+        s->org_t[e] = s->org[(yl + ey) * 64 + xl + ex];
+      }
+      for (int i = tid; i < 2 * w * w; i += KVZ_CTU_THREADS) {  // planar and DC
+        const int mode = i >> (2 * log2w), e = i & (w * w - 1);
+        s->pred[mode * 256 + e] = predict_pixel(log2w, mode, 0, e & (w - 1), e >> log2w);
+      }
+      for (int v = tid; v < 2 * 4; v += KVZ_CTU_THREADS) s->satd_raw[v >> 2][v & 3] = 0;
       if (tid == KVZ_CTU_THREADS - 1) {
         CtuCu lc, ac, *left = nullptr, *above = nullptr;
         if (x >= 4 && neighbour_cu(lv, x - 1, y, &lc)) left = &lc;
@@ -395,9 +537,15 @@ struct CtuProgram {
     KVZ_PROF(KVZ_P_PRED35);
     KVZ_FOR_THREADS(tid) {
       const int lb = 2 * (log2w - 3);  // log2(nblk)
-      for (int t = tid; t < 35 * nblk * 8; t += KVZ_CTU_THREADS) {
+      for (int t = tid; t < 33 * nblk; t += KVZ_CTU_THREADS) {  // angular: one lane per (mode, block)
+        const int mode = 2 + (t >> lb), b = t & (nblk - 1), bx = (b & ((w >> 3) - 1)) * 8, by = (b >> (log2w - 3)) * 8;
+        s->satd_raw[mode][b] = angular_block_satd(log2w, mode, bx, by, xl, yl);
+      }
+      // planar and DC: one lane per (mode, block, Hadamard column), taken from the far end of the thread ids so that
+      // they land on another wavefront than the angular lanes
+      for (int t = KVZ_CTU_THREADS - 1 - tid; t < 2 * nblk * 8; t += KVZ_CTU_THREADS) {
         const int col = t & 7, mb = t >> 3, mode = mb >> lb, b = mb & (nblk - 1), bx = (b & ((w >> 3) - 1)) * 8, by = (b >> (log2w - 3)) * 8;
-        const u32 v = satd8_column(s->pred + mode * w * w + by * w + bx, w, s->org + (yl + by) * 64 + xl + bx, 64, col);
+        const u32 v = satd8_column(s->pred + mode * 256 + by * w + bx, w, s->org + (yl + by) * 64 + xl + bx, 64, col);
         KVZ_LDS_ADD(&s->satd_raw[mode][b], v);
       }
     }
@@ -468,6 +616,7 @@ struct CtuProgram {
   KVZ_DEV void recon_tus(int lv, const TuSet &t, int depth, int mode, bool refs_ready = false)
   {
     const int xl = t.x - cx, yl = t.y - cy;
+    const CandView cv = cand_view(lv);
     if (!refs_ready) build_refs(lv, t.x, t.y, t.lw, t.lc, t.lw != 0, t.lc != 0);
     // stage 1: prediction -> rec (as kvazaar blits it before quantising) and residual
     KVZ_FOR_THREADS(tid) {
@@ -480,7 +629,7 @@ struct CtuProgram {
           const int px = e & (w - 1), py = e >> l2;
           const u8 p = predict_pixel(l2, mode, c, px, py);
           const int o = kPlaneOff[c] + ((yl >> sh) + py) * lw + (xl >> sh) + px;
-          s->rec[lv][o] = p;
+          cv.at(c, (xl >> sh) + px, (yl >> sh) + py) = p;
           s->tb[0][tb_off(c) + e] = (i16)((int)s->org[o] - (int)p);
         }
       }
@@ -570,8 +719,9 @@ struct CtuProgram {
         u32 ssd = 0;
         for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) {
           const int o = kPlaneOff[c] + ((yl >> sh) + (e >> l2)) * lw + (xl >> sh) + (e & (w - 1));
-          int v = s->rec[lv][o];
-          if (has) { v = iclip(0, 255, (int)(i16)(s->tb[1][tb_off(c) + e] + v)); s->rec[lv][o] = (u8)v; }
+          u8 *rp = &cv.at(c, (xl >> sh) + (e & (w - 1)), (yl >> sh) + (e >> l2));
+          int v = *rp;
+          if (has) { v = iclip(0, 255, (int)(i16)(s->tb[1][tb_off(c) + e] + v)); *rp = (u8)v; }
           const int d = (int)s->org[o] - v;
           ssd += (u32)(d * d);
         }
@@ -634,22 +784,32 @@ struct CtuProgram {
     KVZ_SYNC();
   }
 
-  // search.c:55-122 copy_cu_{info,pixels,coeffs}: region (xl, yl, w) from level `from` to level `to`
-  KVZ_DEV void copy_region(int from, int to, int xl, int yl, int w, bool coeffs)
+  // The work-tree copies of search.c:55-122 for the region (xl, yl, w), in one phase:
+  //   CU info      level cu_from -> levels cu_to_lo..cu_to_hi (copy_cu_info),
+  //   pixels       candidate of depth pix_lv -> decided picture (copy_cu_pixels; -1: the decided picture already holds them),
+  //   coefficients challenger block -> output block (copy_cu_coeffs) when `coeffs`.
+  KVZ_DEV void commit(int cu_from, int cu_to_lo, int cu_to_hi, int pix_lv, bool coeffs, int xl, int yl, int w)
   {
+    const CandView cv = cand_view(pix_lv < 0 ? 0 : pix_lv);
     KVZ_FOR_THREADS(tid) {
-      const int n = w >> 3, lw = w == 16 ? 4 : (w == 32 ? 5 : 6), ln = lw - 3;
-      if (tid < n * n) { const int i = ((yl >> 3) + (tid >> ln)) * 8 + (xl >> 3) + (tid & (n - 1)); s->cu[to][i] = s->cu[from][i]; }
-      for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) { const int o = (yl + (e >> lw)) * 64 + xl + (e & (w - 1)); s->rec[to][o] = s->rec[from][o]; }
-      const int cw = w >> 1;
-      for (int e = tid; e < 2 * cw * cw; e += KVZ_CTU_THREADS) {
-        const int c = e >= cw * cw, k = c ? e - cw * cw : e;
-        const int o = kPlaneOff[1 + c] + ((yl >> 1) + (k >> (lw - 1))) * 32 + (xl >> 1) + (k & (cw - 1));
-        s->rec[to][o] = s->rec[from][o];
+      const int n = w >> 3, lw = w == 16 ? 4 : (w == 32 ? 5 : 6), ln = lw - 3, cw = w >> 1;
+      if (tid < n * n) {
+        const int i = ((yl >> 3) + (tid >> ln)) * 8 + (xl >> 3) + (tid & (n - 1));
+        for (int to = cu_to_lo; to <= cu_to_hi; to++) s->cu[to][i] = s->cu[cu_from][i];
+      }
+      if (pix_lv >= 0) {
+        for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) {
+          const int px = xl + (e & (w - 1)), py = yl + (e >> lw);
+          s->dec[py * 64 + px] = cv.at(0, px, py);
+        }
+        for (int e = tid; e < 2 * cw * cw; e += KVZ_CTU_THREADS) {
+          const int c = 1 + (e >= cw * cw), k = e & (cw * cw - 1), px = (xl >> 1) + (k & (cw - 1)), py = (yl >> 1) + (k >> (lw - 1));
+          s->dec[kPlaneOff[c] + py * 32 + px] = cv.at(c, px, py);
+        }
       }
       if (coeffs) {
-        const i16 *src = coeff_level(from);
-        i16 *dst = coeff_level(to);
+        const i16 *src = coeff_level(0);
+        i16 *dst = coeff_level(3);
         const unsigned zy = zorder(xl, yl), zc = zorder(xl >> 1, yl >> 1);
         for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) dst[zy + e] = src[zy + e];
         for (int e = tid; e < 2 * cw * cw; e += KVZ_CTU_THREADS) {
@@ -665,6 +825,7 @@ struct CtuProgram {
   // search_cu at depth 2 or 3 (search.c:646-1063): searched CU.  Returns the cost through *out (LDS).
   KVZ_DEV void eval_cu(int lv, int x, int y, int depth, double *out_cost, int *out_cbf)
   {
+    lane_rot = (lane_rot + 64) & (KVZ_CTU_THREADS - 1);
     const int log2w = 6 - depth, w = 1 << log2w, xl = x - cx, yl = y - cy;
     rough_search(lv, x, y, depth);
     const int mode = s->best_mode;
@@ -700,12 +861,12 @@ struct CtuProgram {
           s->org[kPlaneOff[c] + e] = (px < fw && py < fh) ? src[(long)py * fw + px] : 0;
         }
       }
-      for (int lv = 0; lv < 4; lv++) {
-        for (int e = tid; e < 6144; e += KVZ_CTU_THREADS) s->rec[lv][e] = 0;
+      for (int e = tid; e < 6144; e += KVZ_CTU_THREADS) s->dec[e] = 0;
+      for (int lv = 0; lv < 4; lv++)
         if (tid < 64) { CtuCu z = { 0, 0, 0, 0, 0, 0 }; s->cu[lv][tid] = z; }
-      }
-      if (tid < 256) {  // intra.c:47-82 num_ref_pixels_{top,left}, regenerated from the z-order of 4x4 units
-        const int r = tid >> 4, c = tid & 15;
+      if (tid == 0) s->final_c0 = 0;
+      for (int v = tid; v < 256; v += KVZ_CTU_THREADS) {  // intra.c:47-82 num_ref_pixels_{top,left}, regenerated from the z-order of 4x4 units
+        const int r = v >> 4, c = v & 15;
         int n = 0;
         if (r == 0) s->tbl_top[r][c] = 64;
         else { for (int cc = c; cc < 16 && zorder(cc * 4, (r - 1) * 4) < zorder(c * 4, r * 4); cc++) n++; s->tbl_top[r][c] = (u8)(4 * n); }
@@ -716,7 +877,7 @@ struct CtuProgram {
       // Coefficient buffers start zeroed like the lcu_t copies (search.c:1084).  Only observable for CTUs that stick out
       // of the picture: inside the picture every coefficient that reaches level 0 was written by a transform unit first.
       if (cx + 64 > F.W || cy + 64 > F.H)
-        for (int lv = 0; lv < 4; lv++) { i16 *cf = coeff_level(lv); for (int e = tid; e < 6144; e += KVZ_CTU_THREADS) cf[e] = 0; }
+        for (int lv = 0; lv < 4; lv += 3) { i16 *cf = coeff_level(lv); for (int e = tid; e < 6144; e += KVZ_CTU_THREADS) cf[e] = 0; }
       for (int e = tid; e < 1024; e += KVZ_CTU_THREADS) s->dct32[e] = tb->dct[3][e];
       // neighbour CTUs (complete: they come earlier in the dependency order): border pixels and CU info from their records
       {
@@ -749,17 +910,19 @@ struct CtuProgram {
           s->nb_mode[side][i] = r ? load_shared_byte(r + 256 + (side == 0 ? 24 : 8) + i) : 0;
         }
       }
-      if (tid >= 64 && tid < 64 + 35) {  // angular parameters (intra-generic.c:59-76)
+      for (int v = tid; v < 256; v += KVZ_CTU_THREADS) {
+      if (v >= 64 && v < 64 + 35) {  // angular parameters (intra-generic.c:59-76)
         const int disp_tab[9] = { 0, 2, 5, 9, 13, 17, 21, 26, 32 }, inv_tab[9] = { 0, 4096, 1638, 910, 630, 482, 390, 315, 256 };
-        const int mode = tid - 64, md = mode >= 18 ? mode - 26 : 10 - mode, ad = iabs(md);
+        const int mode = v - 64, md = mode >= 18 ? mode - 26 : 10 - mode, ad = iabs(md);
         s->mode_disp[mode] = (int8_t)(mode < 2 ? 0 : (md < 0 ? -disp_tab[ad] : disp_tab[ad]));
         s->mode_inv[mode] = (int16_t)(mode < 2 ? 0 : inv_tab[ad]);
       }
-      if (tid >= 128 && tid < 136) s->qs[(tid - 128) >> 1][tid & 1] = quant_scalars_dev(2 + ((tid - 128) >> 1), (tid & 1) ? 2 : 0);
-      if (tid == 140) {  // lambda_sqrt * kvz_luma_mode_bits (search_intra.c:524, 641-676) for the three possible outcomes
+      if (v >= 128 && v < 136) s->qs[(v - 128) >> 1][v & 1] = quant_scalars_dev(2 + ((v - 128) >> 1), (v & 1) ? 2 : 0);
+      if (v == 140) {  // lambda_sqrt * kvz_luma_mode_bits (search_intra.c:524, 641-676) for the three possible outcomes
         s->mode_bits_cost[0] = m->lambda_sqrt * ((double)m->intra_mode[0] + 5);
         s->mode_bits_cost[1] = m->lambda_sqrt * ((double)m->intra_mode[1] + 1);
         s->mode_bits_cost[2] = m->lambda_sqrt * ((double)m->intra_mode[1] + 2);
+      }
       }
 
     }
@@ -769,13 +932,14 @@ struct CtuProgram {
   // copy_lcu_to_cu_data (search.c:1180-1207): level 0 -> frame reconstruction + CU info; coefficients already there
   KVZ_DEV void finish()
   {
+    const u8 *fin = s->final_c0 ? s->c0 : s->dec;  // uniform: written before the last barrier
     KVZ_FOR_THREADS(tid) {
       for (int c = 0; c < 3; c++) {
         const int sh = c ? 1 : 0, lw = 64 >> sh, fw = F.W >> sh, fh = F.H >> sh, ox = cx >> sh, oy = cy >> sh;
         u8 *dst = const_cast<u8 *>(frame_rec(c));
         for (int e = tid; e < lw * lw; e += KVZ_CTU_THREADS) {
           const int px = ox + e % lw, py = oy + e / lw;
-          if (px < fw && py < fh) dst[(long)py * fw + px] = s->rec[0][kPlaneOff[c] + e];
+          if (px < fw && py < fh) dst[(long)py * fw + px] = fin[kPlaneOff[c] + e];
         }
       }
       if (tid < 64) {
@@ -789,14 +953,16 @@ struct CtuProgram {
       if (tid == 0) F.ctu_cost[(long)frame * F.wc * F.hc + ctu_index()] = s->cost[0];
       {  // border record for the right / lower neighbours
         u8 *r = F.border + ((long)frame * F.wc * F.hc + ctu_index()) * KVZ_BORDER_BYTES;
-        if (tid < 128) {
-          const int c = tid < 64 ? 0 : (tid < 96 ? 1 : 2), i = tid < 64 ? tid : (tid - 64) & 31, lw = c ? 32 : 64;
-          r[tid] = s->rec[0][kPlaneOff[c] + (lw - 1) * lw + i];        // bottom row
-          r[128 + tid] = s->rec[0][kPlaneOff[c] + i * lw + lw - 1];    // right column
-        } else if (tid < 128 + 32) {
-          const int k = tid - 128, i = k & 7;
-          const CtuCu *cu = &s->cu[0][k < 16 ? 56 + i : i * 8 + 7];
-          r[256 + k] = ((k >> 3) & 1) ? cu->mode : cu->depth;
+        for (int v = tid; v < 128 + 32; v += KVZ_CTU_THREADS) {
+          if (v < 128) {
+            const int c = v < 64 ? 0 : (v < 96 ? 1 : 2), i = v < 64 ? v : (v - 64) & 31, lw = c ? 32 : 64;
+            r[v] = fin[kPlaneOff[c] + (lw - 1) * lw + i];        // bottom row
+            r[128 + v] = fin[kPlaneOff[c] + i * lw + lw - 1];    // right column
+          } else {
+            const int k = v - 128, i = k & 7;
+            const CtuCu *cu = &s->cu[0][k < 16 ? 56 + i : i * 8 + 7];
+            r[256 + k] = ((k >> 3) & 1) ? cu->mode : cu->depth;
+          }
         }
       }
     }
@@ -891,6 +1057,7 @@ struct CtuProgram {
   {
     const int xl = x - cx, yl = y - cy;
     if (x >= F.W || y >= F.H) { KVZ_FOR_THREADS(tid) { if (tid == 0) s->cost[2] = 0; } KVZ_SYNC(); return; }
+    a2x = xl; a2y = yl;
     set_cu_header(2, xl, yl, 2);
     const bool inside = x + 16 <= F.W && y + 16 <= F.H;
     KVZ_FOR_THREADS(tid) { if (tid == 0) { s->cost[2] = 1.7e+308; s->cbf_any = 0; } }
@@ -925,9 +1092,9 @@ struct CtuProgram {
     if (split_wins2) {
       KVZ_FOR_THREADS(tid) { if (tid == 0) s->cost[2] = s->split_cost[2]; }
       KVZ_SYNC();
-      copy_region(3, 2, xl, yl, 16, true);  // work_tree_copy_up
+      commit(3, 2, 2, 3, false, xl, yl, 16);  // work_tree_copy_up: the 8x8 CUs win (their coefficients are already in place)
     } else {
-      copy_region(2, 3, xl, yl, 16, false);  // work_tree_copy_down
+      commit(2, 3, 3, 2, true, xl, yl, 16);   // work_tree_copy_down: the 16x16 CU wins
     }
   }
 
@@ -946,6 +1113,7 @@ struct CtuProgram {
     for (int q1 = 0; q1 < 4; q1++) {
       const int x1 = cx + (q1 & 1) * 32, y1 = cy + (q1 >> 1) * 32;
       if (x1 >= F.W || y1 >= F.H) continue;  // search_cu returns 0 outside the picture
+      a1x = x1 - cx; a1y = y1 - cy;
       set_cu_header(1, x1 - cx, y1 - cy, 1);
       KVZ_FOR_THREADS(tid) {
         if (tid == 0) { s->cost[1] = 1.7e+308; double sb = 0; sb += (double)m->split_flag[split_model(1, x1, y1, 1)][1]; double sc = 0.0; sc += sb * m->lambda; s->split_cost[1] = sc; }
@@ -962,9 +1130,9 @@ struct CtuProgram {
       if (split_wins1) {
         KVZ_FOR_THREADS(tid) { if (tid == 0) s->cost[1] = s->split_cost[1]; }
         KVZ_SYNC();
-        copy_region(2, 1, x1 - cx, y1 - cy, 32, true);
+        commit(2, 1, 1, -1, false, x1 - cx, y1 - cy, 32);
       } else {
-        for (int lv = 2; lv < 4; lv++) copy_region(1, lv, x1 - cx, y1 - cy, 32, false);
+        commit(1, 2, 3, 1, true, x1 - cx, y1 - cy, 32);  // the 32x32 merge wins
       }
       KVZ_FOR_THREADS(tid) { if (tid == 0) s->split_cost[0] += s->cost[1]; }
       KVZ_SYNC();
@@ -975,7 +1143,11 @@ struct CtuProgram {
     if (split_wins0) {
       KVZ_FOR_THREADS(tid) { if (tid == 0) s->cost[0] = s->split_cost[0]; }
       KVZ_SYNC();
-      copy_region(1, 0, 0, 0, 64, true);
+      commit(1, 0, 0, -1, false, 0, 0, 64);
+    } else {  // the 64x64 merge wins: its pixels stay in c0, its coefficients move to the output block
+      KVZ_FOR_THREADS(tid) { if (tid == 0) s->final_c0 = 1; }
+      KVZ_SYNC();
+      commit(0, 0, -1, -1, true, 0, 0, 64);
     }
     KVZ_PROF(KVZ_P_MISC);
     finish();

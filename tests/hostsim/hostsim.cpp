@@ -42,7 +42,7 @@ extern "C" void kvz_hostsim_intra_frame(const kvz_hip_intra_cost_model *m, int w
   F.src = src; F.rec = rec; F.coeff = coeff; F.cu_depth = cu_depth; F.cu_mode = cu_mode; F.ctu_cost = ctu_cost; F.prof = nullptr;
   uint8_t *border = (uint8_t *)calloc((size_t)F.wc * F.hc, KVZ_BORDER_BYTES);
   F.border = border;
-  int16_t *scratch = (int16_t *)calloc((size_t)F.wc * F.hc * 3 * 6144, sizeof(int16_t));
+  int16_t *scratch = (int16_t *)calloc((size_t)F.wc * F.hc * 6144, sizeof(int16_t));
   F.coeff_scratch = scratch;
   kvz::CtuShared *sh = (kvz::CtuShared *)calloc(1, sizeof(kvz::CtuShared));
   for (int cy = 0; cy < F.hc; cy++)

@@ -16,7 +16,7 @@ def main():
     out = os.path.join(ROOT, "gpurun_out", "libkvz_hip_prof.so")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                           "-DKVZ_CTU_PROFILE", "-o", out, os.path.join(ROOT, "kvazaar_amd", "csrc", "kvz_hip.hip")])
+                           "-DKVZ_CTU_PROFILE", *os.environ.get("KVZ_PROFILE_FLAGS", "").split(), "-o", out, os.path.join(ROOT, "kvazaar_amd", "csrc", "kvz_hip.hip")])
     import numpy as np
     import ctu_common as cc
     import bench
