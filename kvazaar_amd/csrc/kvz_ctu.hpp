@@ -81,6 +81,93 @@ KVZ_DEV u32 pk_absmax(Pk16 a)
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------------------------
+// 16x16 and 32x32 transform passes on the matrix cores (device only; the host build of this file keeps the scalar loops,
+// which compute the same integers).  One wavefront forms D = A * B for an n x n problem where
+//   A[r][k] and B[k][c] are both given "row-contiguous in k":  a_rows[r * n + k],  b_rows[c * n + k],
+// one of them the DCT matrix as IEEE halves (global memory, Tables::dct_h), the other int16 data in LDS.
+// Exactness: every matrix entry (|v| <= 90) and every data operand fed to the unit (9-bit residuals, or the high / low
+// byte of a 16-bit value) is an integer that binary16 holds exactly, products are exact in binary32, and every partial
+// sum is an integer below 32 * 90 * 255 < 2^24 -- so the binary32 accumulators hold exact integers whatever the
+// summation order.  A 16-bit operand x is split as x = 256 * (x >> 8) + (x & 255): two accumulators, recombined in int32.
+#ifndef KVZ_HOSTSIM
+typedef _Float16 kvz_half4 __attribute__((ext_vector_type(4)));
+typedef float kvz_float4 __attribute__((ext_vector_type(4)));
+typedef float kvz_float16 __attribute__((ext_vector_type(16)));
+
+struct MfmaPass {
+  const u16 *table;   // n x n halves, rows contiguous in k
+  const i16 *data;    // n x n int16 in LDS, rows contiguous in k
+  i16 *dst;           // n x n int16 in LDS
+  int table_is_a;     // 1: D rows come from the table (forward passes), 0: D rows come from the data (inverse passes)
+  int split;          // data needs 16 bits
+  int add, shift, clip, transposed_store;
+};
+
+__device__ __forceinline__ kvz_half4 kvz_load_half4(const u16 *p)
+{
+  return *reinterpret_cast<const kvz_half4 *>(p);  // 8-byte aligned: k0 is a multiple of 4
+}
+__device__ __forceinline__ void kvz_load_data4(const i16 *p, bool split, kvz_half4 *hi, kvz_half4 *lo)
+{
+  const short4 v = *reinterpret_cast<const short4 *>(p);
+  const int x[4] = { v.x, v.y, v.z, v.w };
+  for (int i = 0; i < 4; i++) {
+    if (split) { (*hi)[i] = (_Float16)(x[i] >> 8); (*lo)[i] = (_Float16)(x[i] & 255); }
+    else (*lo)[i] = (_Float16)x[i];
+  }
+}
+__device__ __forceinline__ void kvz_store_result(const MfmaPass &ps, int n, int row, int col, float hi, float lo)
+{
+  int a = (int)lo;
+  if (ps.split) a += (int)hi * 256;
+  int v = (a + ps.add) >> ps.shift;
+  if (ps.clip) v = iclip(-32768, 32767, v);
+  ps.dst[ps.transposed_store ? col * n + row : row * n + col] = (i16)v;
+}
+
+// n = 32: v_mfma_f32_32x32x8_f16, four k-steps.  Lane l feeds row / column l & 31 at k = 8 * step + 4 * (l >> 5) .. + 3 and
+// receives D[8 * (reg >> 2) + 4 * (l >> 5) + (reg & 3)][l & 31].
+__device__ __forceinline__ void mfma_pass_32(const MfmaPass &ps, int lane)
+{
+  const int idx = lane & 31, kq = lane >> 5;
+  kvz_float16 acc_lo = { 0 }, acc_hi = { 0 };
+  for (int step = 0; step < 4; step++) {
+    const int k0 = 8 * step + 4 * kq;
+    const kvz_half4 tv = kvz_load_half4(ps.table + idx * 32 + k0);
+    kvz_half4 dh = { 0 }, dl = { 0 };
+    kvz_load_data4(ps.data + idx * 32 + k0, ps.split, &dh, &dl);
+    if (ps.table_is_a) {
+      acc_lo = __builtin_amdgcn_mfma_f32_32x32x8f16(tv, dl, acc_lo, 0, 0, 0);
+      if (ps.split) acc_hi = __builtin_amdgcn_mfma_f32_32x32x8f16(tv, dh, acc_hi, 0, 0, 0);
+    } else {
+      acc_lo = __builtin_amdgcn_mfma_f32_32x32x8f16(dl, tv, acc_lo, 0, 0, 0);
+      if (ps.split) acc_hi = __builtin_amdgcn_mfma_f32_32x32x8f16(dh, tv, acc_hi, 0, 0, 0);
+    }
+  }
+  for (int r = 0; r < 16; r++) kvz_store_result(ps, 32, 8 * (r >> 2) + 4 * kq + (r & 3), idx, acc_hi[r], acc_lo[r]);
+}
+
+// n = 16: v_mfma_f32_16x16x16_f16, one k-step.  Lane l feeds row / column l & 15 at k = 4 * (l >> 4) .. + 3 and receives
+// D[4 * (l >> 4) + reg][l & 15].
+__device__ __forceinline__ void mfma_pass_16(const MfmaPass &ps, int lane)
+{
+  const int idx = lane & 15, kq = lane >> 4, k0 = 4 * kq;
+  kvz_float4 acc_lo = { 0 }, acc_hi = { 0 };
+  const kvz_half4 tv = kvz_load_half4(ps.table + idx * 16 + k0);
+  kvz_half4 dh = { 0 }, dl = { 0 };
+  kvz_load_data4(ps.data + idx * 16 + k0, ps.split, &dh, &dl);
+  if (ps.table_is_a) {
+    acc_lo = __builtin_amdgcn_mfma_f32_16x16x16f16(tv, dl, acc_lo, 0, 0, 0);
+    if (ps.split) acc_hi = __builtin_amdgcn_mfma_f32_16x16x16f16(tv, dh, acc_hi, 0, 0, 0);
+  } else {
+    acc_lo = __builtin_amdgcn_mfma_f32_16x16x16f16(dl, tv, acc_lo, 0, 0, 0);
+    if (ps.split) acc_hi = __builtin_amdgcn_mfma_f32_16x16x16f16(dh, tv, acc_hi, 0, 0, 0);
+  }
+  for (int r = 0; r < 4; r++) kvz_store_result(ps, 16, 4 * kq + r, idx, acc_hi[r], acc_lo[r]);
+}
+#endif
+
 // Optional in-kernel timeline (build with -DKVZ_CTU_PROFILE): lane 0 of every workgroup adds the shader-clock cycles
 // spent since the previous mark to a per-category counter in HBM.  Categories are the KVZ_P_* constants.
 enum { KVZ_P_INIT = 0, KVZ_P_REFS, KVZ_P_PRED35, KVZ_P_SATD, KVZ_P_SELECT, KVZ_P_RPRED, KVZ_P_FDCT, KVZ_P_QUANT, KVZ_P_IDCT, KVZ_P_RECON,
@@ -145,7 +232,7 @@ struct CtuShared {
   // already picked from the filtered / unfiltered, top / left arrays.  Entry [mode - 2][KVZ_MREF_ORG + q] is ref_main[q].
   u8 mref[33][KVZ_MREF_STRIDE];
   u8 org_t[256];             // the CU's source block transposed (horizontal modes are predicted and scored transposed)
-  i16 tb[2][1536];           // transform scratch: Y (<= 1024) | U (<= 256) | V (<= 256)
+  alignas(16) i16 tb[2][1536];           // transform scratch: Y (<= 1024) | U (<= 256) | V (<= 256)
   u32 satd[35];
   u32 acc[16];               // [0..2] ssd per plane, [3..5] coeff weight sums, [6..8] non-zero counts
   int8_t preds[3];
@@ -646,6 +733,15 @@ struct CtuProgram {
           const i16 *C = s->dct32, *src = s->tb[pass] + tb_off(c);
           const int rs = 10 - l2;  // row k of the n-point matrix = row k * (32 / n) of the 32-point one
           i16 *dst = s->tb[pass ^ 1] + tb_off(c);
+#ifndef KVZ_HOSTSIM
+          if (l2 >= 4) {  // D[k][j] = sum_i C[k][i] * src[j][i]: table rows x data rows, one wavefront per plane
+            if ((tid >> 6) == c % (KVZ_CTU_THREADS / 64)) {
+              const MfmaPass ps = { tb->dct_h[l2 - 4][0], src, dst, 1, pass, add, shift, 0, 0 };
+              if (l2 == 5) mfma_pass_32(ps, tid & 63); else mfma_pass_16(ps, tid & 63);
+            }
+            continue;
+          }
+#endif
           for (int e = tid; e < n * n; e += KVZ_CTU_THREADS) {
             const int k = e >> l2, j = e & (n - 1);
             int a = 0;
@@ -680,7 +776,12 @@ struct CtuProgram {
           nz += a != 0;
           if (a > 3) a = 3;
           wsum += (u32)((m->coeff_weights >> (16 * a)) & 0xffff);
-          dq[e] = (i16)iclip(-32768, 32767, (level * qi.dq_scale + (1 << (qi.dq_shift - 1))) >> qi.dq_shift);
+#ifndef KVZ_HOSTSIM
+          const int de = l2 >= 4 ? ((e & ((1 << l2) - 1)) << l2) + (e >> l2) : e;  // transposed for the matrix-core inverse
+#else
+          const int de = e;
+#endif
+          dq[de] = (i16)iclip(-32768, 32767, (level * qi.dq_scale + (1 << (qi.dq_shift - 1))) >> qi.dq_shift);
         }
         block_add(&s->acc[3 + c], wsum);
         block_add(&s->acc[6 + c], nz);
@@ -698,6 +799,15 @@ struct CtuProgram {
           const i16 *C = s->dct32, *src = s->tb[pass ^ 1] + tb_off(c);
           const int rs = 10 - l2;
           i16 *dst = s->tb[pass] + tb_off(c);
+#ifndef KVZ_HOSTSIM
+          if (l2 >= 4) {  // D[j][i] = sum_k src[k][j] * C[k][i]: data arrives transposed, first pass leaves it transposed again
+            if ((tid >> 6) == c % (KVZ_CTU_THREADS / 64)) {
+              const MfmaPass ps = { tb->dct_h[l2 - 4][1], src, dst, 0, 1, add, shift, 1, pass == 0 };
+              if (l2 == 5) mfma_pass_32(ps, tid & 63); else mfma_pass_16(ps, tid & 63);
+            }
+            continue;
+          }
+#endif
           for (int e = tid; e < n * n; e += KVZ_CTU_THREADS) {
             const int j = e >> l2, i = e & (n - 1);
             int a = 0;

@@ -27,6 +27,7 @@ namespace kvz {
 
 typedef uint8_t u8;
 typedef int16_t i16;
+typedef uint16_t u16;
 typedef uint32_t u32;
 typedef int32_t i32;
 
@@ -47,6 +48,9 @@ KVZ_DEV u8 clip_pixel(int v) { return (u8)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 struct Tables {
   i16 dct[4][32 * 32];   // [log2n-2] row-major n*n (dct-generic.c:46-120)
   i16 dst4[16];          // dct-generic.c:38-44
+  // The 16- and 32-point matrices again as IEEE half bit patterns (every entry is an integer of magnitude <= 90, exact
+  // in half): [0: n = 16, 1: n = 32][0: C row-major, 1: C transposed], the table operand of the MFMA transforms.
+  alignas(16) u16 dct_h[2][2][32 * 32];
   u32 scan[3][4][1024];  // [scan_idx][log2-2] (tables.c kvz_g_sig_last_scan), sizes 4..32
   int8_t luma_filter[4][8];    // filter.c:66-72
   int8_t chroma_filter[8][4];  // filter.c:74-84

@@ -37,12 +37,31 @@ inline void scan_pattern(int type, int size, int *xs, int *ys)
   }
 }
 
+// IEEE binary16 bit pattern of a small integer (|v| < 2048: exactly representable)
+inline u16 half_bits_of_int(int v)
+{
+  if (v == 0) return 0;
+  const u16 sign = v < 0 ? 0x8000 : 0;
+  unsigned a = (unsigned)(v < 0 ? -v : v);
+  int e = 0;
+  while ((a >> (e + 1)) != 0) e++;  // a in [2^e, 2^(e+1))
+  return (u16)(sign | ((e + 15) << 10) | ((a << (10 - e)) & 0x3ff));
+}
+
 inline void build_tables(Tables *t)
 {
   memset(t, 0, sizeof(*t));
   for (int l = 0; l < 4; l++) {
     const int n = 4 << l, step = 32 / n;
     for (int k = 0; k < n; k++) for (int j = 0; j < n; j++) t->dct[l][k * n + j] = (i16)dct32_entry(k * step, j);
+  }
+  for (int l = 2; l < 4; l++) {
+    const int n = 4 << l;
+    for (int k = 0; k < n; k++)
+      for (int j = 0; j < n; j++) {
+        t->dct_h[l - 2][0][k * n + j] = half_bits_of_int(t->dct[l][k * n + j]);
+        t->dct_h[l - 2][1][j * n + k] = half_bits_of_int(t->dct[l][k * n + j]);
+      }
   }
   static const i16 dst4[16] = { 29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29 };
   memcpy(t->dst4, dst4, sizeof dst4);
