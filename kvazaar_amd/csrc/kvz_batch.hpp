@@ -13,8 +13,13 @@
 namespace kvz {
 
 // One workgroup per CTU of the anti-diagonal `wave` (x + 2y == wave) of every frame.
+#ifdef KVZ_CTU_NUM_VGPR  /* register-cap experiments */
+#define KVZ_CTU_VGPR_ATTR __attribute__((amdgpu_num_vgpr(KVZ_CTU_NUM_VGPR)))
+#else
+#define KVZ_CTU_VGPR_ATTR
+#endif
 #ifndef KVZ_CTU_WAVES_PER_EU
-#define KVZ_CTU_WAVES_PER_EU 4  /* 4 workgroups of 256 lanes per CU: what the LDS footprint (~37 KB) allows */
+#define KVZ_CTU_WAVES_PER_EU 3  /* 6 workgroups of 128 lanes per CU (LDS ~25 KB each) = 3 wavefronts per SIMD */
 #endif
 __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) intra_ctu_wave_kernel(const CtuFrames F, const kvz_hip_intra_cost_model model, const Tables *tb,
                                                                         const int wave, const int y_min, const int n_diag)
@@ -59,7 +64,7 @@ __device__ __forceinline__ bool wait_done(unsigned *flag, unsigned epoch, unsign
   }
 }
 
-__global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) intra_ctu_ticket_kernel(const CtuFrames F, const kvz_hip_intra_cost_model model, const Tables *tb,
+__global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) KVZ_CTU_VGPR_ATTR intra_ctu_ticket_kernel(const CtuFrames F, const kvz_hip_intra_cost_model model, const Tables *tb,
                                                                         const CtuSched sched)
 {
   __shared__ CtuShared shared;
@@ -190,8 +195,8 @@ kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_mode, ncu));
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_cost, nctu * sizeof(double)));
   KVZ_HIP_CHECK(hipMemsetAsync(b->d_rec, 0, F.frame_px * n_frames, b->stream));  // on the batch's stream: a non-blocking stream does not order against the null stream
-  KVZ_HIP_CHECK(hipMalloc((void **)&b->d_prof, kvz::KVZ_P_COUNT * sizeof(unsigned long long)));
-  KVZ_HIP_CHECK(hipMemsetAsync(b->d_prof, 0, kvz::KVZ_P_COUNT * sizeof(unsigned long long), b->stream));
+  KVZ_HIP_CHECK(hipMalloc((void **)&b->d_prof, 2 * kvz::KVZ_P_COUNT * sizeof(unsigned long long)));
+  KVZ_HIP_CHECK(hipMemsetAsync(b->d_prof, 0, 2 * kvz::KVZ_P_COUNT * sizeof(unsigned long long), b->stream));
   F.prof = b->d_prof;
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_border, nctu * KVZ_BORDER_BYTES));
   KVZ_HIP_CHECK(hipMemsetAsync(b->d_border, 0, nctu * KVZ_BORDER_BYTES, b->stream));
@@ -221,6 +226,7 @@ kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
     KVZ_HIP_CHECK(hipGetDevice(&dev));
     KVZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (per_cu < 1) per_cu = 1;
+    if (const char *lim = getenv("KVZ_HIP_WG_PER_CU")) { const int v = atoi(lim); if (v >= 1 && v < per_cu) per_cu = v; }  // occupancy experiments
     b->grid_ticket = per_cu * cus;
     if ((unsigned)b->grid_ticket > b->total_items) b->grid_ticket = (int)b->total_items;
   }
@@ -316,9 +322,9 @@ void kvz_hip_batch_sync(kvz_hip_batch *b)
 int kvz_hip_batch_profile(kvz_hip_batch *b, unsigned long long *out, int n)
 {
   KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
-  if (n > kvz::KVZ_P_COUNT) n = kvz::KVZ_P_COUNT;
+  if (n > 2 * kvz::KVZ_P_COUNT) n = 2 * kvz::KVZ_P_COUNT;  // cycles per category, then marks per category
   KVZ_HIP_CHECK(hipMemcpy(out, b->d_prof, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  KVZ_HIP_CHECK(hipMemsetAsync(b->d_prof, 0, kvz::KVZ_P_COUNT * sizeof(unsigned long long), b->stream));
+  KVZ_HIP_CHECK(hipMemsetAsync(b->d_prof, 0, 2 * kvz::KVZ_P_COUNT * sizeof(unsigned long long), b->stream));
   KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
   return kvz::KVZ_P_COUNT;
 }

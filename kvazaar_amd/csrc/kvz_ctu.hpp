@@ -30,12 +30,20 @@
 
 namespace kvz {
 
+// Lanes per CTU.  Measured on MI355X (gpurun_out sweeps, 1080p): with the ~25 KB LDS footprint six workgroups fit a CU;
+// two wavefronts per CTU (168 VGPRs each, three wavefronts per SIMD) beat four (80-96 VGPRs, spills, and twice the
+// wavefronts that only skip through the lane-starved stages).  Any multiple of 64 works.
 #ifndef KVZ_CTU_THREADS
-#define KVZ_CTU_THREADS 256
+#define KVZ_CTU_THREADS 128
 #endif
 #ifdef KVZ_HOSTSIM
 #define KVZ_FOR_THREADS(tid) for (int tid = 0; tid < KVZ_CTU_THREADS; ++tid)
+#ifdef KVZ_HOSTSIM_COUNT_SYNCS
+static unsigned long long g_kvz_syncs;
+#define KVZ_SYNC() (++g_kvz_syncs)
+#else
 #define KVZ_SYNC()
+#endif
 #define KVZ_LDS_ADD(p, v) (*(p) += (v))
 #else
 // lane_rot (a multiple of 64, wavefront-uniform) rotates which wavefront plays "threads 0..63": the lane-starved stages of a
@@ -218,22 +226,32 @@ struct CtuShared {
   // Reconstruction.  kvazaar keeps one full lcu_t per depth (search.c:103-122); what those copies hold at any time is
   // (a) the pixels already decided, identical in every level that can see them, plus (b) one candidate per depth for the
   // CU being tried.  So: one decided picture + one candidate buffer per depth, sized to that depth's CU.
-  u8 dec[6144];              // decided pixels, Y 64x64 | U 32x32 | V 32x32
+  u8 dec[6144];              // decided pixels, Y 64x64 | U 32x32 | V 32x32.  The depth-0 candidate (64x64 merge) reuses it:
+                             // by then the split result has been written to the frame (run()).
   u8 c1[1536];               // depth-1 candidate (32x32 merge): Y 1024 | U 256 | V 256
-  u8 c2[384];                // depth-2 candidate (16x16 CU):     Y 256 | U 64 | V 64
-  u8 c3[384];                // depth-3 candidates (the four 8x8 CUs of the current 16x16)
-  int final_c0;              // 1 when the 64x64 merge won: the CTU's result is c0 instead of dec
+#if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
+  unsigned long long prof_acc[32];  // [category] cycles, [KVZ_P_COUNT + category] marks
+#endif
   CtuCu cu[4][64];
   u8 ref[3][2][132];         // [plane][0 top / 1 left][2w+1]
   u8 fref[2][132];           // filtered luma refs
-  u8 c0[6144];               // depth-0 candidate (64x64 merge), only live at the very end of the CTU
-  u8 pred[2 * 256];          // planar and DC predictions of the CU being searched (<= 16x16)
-  // Rough search, angular modes: per mode the main reference with its projected extension (intra-generic.c:97-123),
-  // already picked from the filtered / unfiltered, top / left arrays.  Entry [mode - 2][KVZ_MREF_ORG + q] is ref_main[q].
-  u8 mref[33][KVZ_MREF_STRIDE];
-  u8 org_t[256];             // the CU's source block transposed (horizontal modes are predicted and scored transposed)
-  alignas(16) i16 tb[2][1536];           // transform scratch: Y (<= 1024) | U (<= 256) | V (<= 256)
-  u32 satd[35];
+  // Transform scratch, two buffers of Y | U | V int16.  Only a 32x32 transform set (the depth-0 / depth-1 merges) needs
+  // the full 2 x 1536 entries, and while one of those runs everything the search of 16x16 / 8x8 CUs keeps is dead -- so
+  // those buffers live in the upper part of the same storage; smaller sets use the first 2 x 384 entries (tbuf()).
+  union {
+    alignas(16) i16 tb_all[2 * 1536];
+    struct {
+      u8 tb_small_pad[2332];
+      u8 c2[384];            // depth-2 candidate (16x16 CU):     Y 256 | U 64 | V 64
+      u8 c3[384];            // depth-3 candidates (the four 8x8 CUs of the current 16x16)
+      u8 pred[2 * 256];      // planar and DC predictions of the CU being searched (<= 16x16)
+      // Rough search, angular modes: per mode the main reference with its projected extension (intra-generic.c:97-123),
+      // already picked from the filtered / unfiltered, top / left arrays.  Entry [mode - 2][KVZ_MREF_ORG + q] is ref_main[q].
+      u8 mref[33][KVZ_MREF_STRIDE];
+      u8 org_t[256];         // the CU's source block transposed (horizontal modes are predicted and scored transposed)
+      u32 satd_raw[35][4];   // sum |Hadamard| per (mode, 8x8 block) before the per-block rounding
+    };
+  };
   u32 acc[16];               // [0..2] ssd per plane, [3..5] coeff weight sums, [6..8] non-zero counts
   int8_t preds[3];
   int best_mode;
@@ -247,9 +265,12 @@ struct CtuShared {
   u8 bpx_left[3][66];        // x = ox-1, y = oy-1 .. oy+63   (index 0 = corner)
   u8 bpx_top[3][98];         // y = oy-1, x = ox-1 .. ox+95   (index 0 = corner)
   u8 nb_depth[2][8], nb_mode[2][8];  // [0 left / 1 top][8x8 index]
+#ifdef KVZ_HOSTSIM
   i16 dct32[32 * 32];        // HEVC core transform matrix; the 16/8/4-point matrices are its rows 2k/4k/8k (dct-generic.c:46-120)
+#else
+  i16 dct_small[64 + 16];    // the 8- and 4-point matrices: larger transforms run on the matrix cores from Tables::dct_h
+#endif
   u8 dcval[3];               // DC value of the current references per plane
-  u32 satd_raw[35][4];       // sum |Hadamard| per (mode, 8x8 block) before the per-block rounding
   int8_t mode_disp[35];      // angular parameters per mode (intra-generic.c:59-60, 70-76): signed sample displacement,
   int16_t mode_inv[35];      //   inverse angle, and whether the mode projects on the top reference
   QuantScalars qs[4][2];     // [log2w - 2][0 luma / 1 chroma] for this QP (quant-generic.c:57-66, 303-339)
@@ -272,8 +293,9 @@ struct CtuProgram {
   {
     if (threadIdx.x == 0) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
-      atomicAdd(&F.prof[cat], t - t_last);
-      t_last = t;
+      s->prof_acc[cat] += t - t_last;  // LDS: a global atomic per mark would dominate what is being measured
+      s->prof_acc[KVZ_P_COUNT + cat] += 1;
+      t_last = __builtin_amdgcn_s_memtime();
     }
   }
 #endif
@@ -301,7 +323,7 @@ struct CtuProgram {
   {
     CandView v;
     if (lv == 0) {
-      v.buf = s->c0;
+      v.buf = s->dec;  // see CtuShared::dec
       v.lw[0] = 6; v.lw[1] = v.lw[2] = 5;
       v.bias[0] = 0; v.bias[1] = 4096; v.bias[2] = 5120;
     } else if (lv == 1) {
@@ -344,7 +366,7 @@ struct CtuProgram {
     const int sh = c ? 1 : 0, w = 64 >> sh, ox = cx >> sh, oy = cy >> sh;
     if (px >= ox && px < ox + w && py >= oy && py < oy + w) {
       const int pxl = px - ox, pyl = py - oy;
-      if (lv == 0) return s->c0[kPlaneOff[c] + pyl * w + pxl];  // the 64x64 merge predicts its 32x32 units from each other
+      if (lv == 0) return s->dec[kPlaneOff[c] + pyl * w + pxl];  // the 64x64 merge predicts its 32x32 units from each other
       if (lv == 3) {  // an 8x8 CU sees its already-tried siblings inside the current 16x16, decided pixels elsewhere
         const int rx = a2x >> sh, ry = a2y >> sh, rw = 16 >> sh;
         if (pxl >= rx && pxl < rx + rw && pyl >= ry && pyl < ry + rw) return s->c3[(c == 0 ? 0 : (c == 1 ? 256 : 320)) + (pyl - ry) * rw + pxl - rx];
@@ -696,7 +718,21 @@ struct CtuProgram {
   // Transform-unit geometry of one reconstruction step: luma w x w at (x, y) and/or chroma cw x cw.
   struct TuSet { int x, y, lw /* log2 luma or 0 */, lc /* log2 chroma or 0 */; };
   KVZ_DEV static int tu_log2(const TuSet &t, int c) { return c ? t.lc : t.lw; }
-  KVZ_DEV static int tb_off(int c) { return c == 0 ? 0 : (c == 1 ? 1024 : 1280); }
+  // Plane c of transform scratch buffer p for the TU set t (see CtuShared::tb_all)
+  KVZ_DEV i16 *tbuf(const TuSet &t, int p, int c) const
+  {
+    if (t.lw == 5) return s->tb_all + p * 1536 + (c == 0 ? 0 : (c == 1 ? 1024 : 1280));
+    return s->tb_all + p * 384 + (c == 0 ? 0 : (c == 1 ? 256 : 320));
+  }
+  // Entry (k, i) of the 2^l2-point transform matrix
+  KVZ_DEV int dct_at(int l2, int k, int i) const
+  {
+#ifdef KVZ_HOSTSIM
+    return s->dct32[(k << (10 - l2)) + i];
+#else
+    return s->dct_small[(l2 == 3 ? 0 : 64) + (k << l2) + i];  // 16 and 32 points never come here on the device
+#endif
+  }
 
   // intra_recon_tb_leaf (intra.c:561-608) + kvz_quantize_residual (quant-generic.c:198-292) for the planes of `t`,
   // written into work-tree level lv.  Sets the cbf bits of the CU's info entry.  One barrier per stage.
@@ -717,7 +753,7 @@ struct CtuProgram {
           const u8 p = predict_pixel(l2, mode, c, px, py);
           const int o = kPlaneOff[c] + ((yl >> sh) + py) * lw + (xl >> sh) + px;
           cv.at(c, (xl >> sh) + px, (yl >> sh) + py) = p;
-          s->tb[0][tb_off(c) + e] = (i16)((int)s->org[o] - (int)p);
+          tbuf(t, 0, c)[e] = (i16)((int)s->org[o] - (int)p);
         }
       }
     }
@@ -730,9 +766,8 @@ struct CtuProgram {
           const int l2 = tu_log2(t, c);
           if (!l2) continue;
           const int n = 1 << l2, shift = pass == 0 ? l2 - 1 : l2 + 6, add = 1 << (shift - 1);
-          const i16 *C = s->dct32, *src = s->tb[pass] + tb_off(c);
-          const int rs = 10 - l2;  // row k of the n-point matrix = row k * (32 / n) of the 32-point one
-          i16 *dst = s->tb[pass ^ 1] + tb_off(c);
+          const i16 *src = tbuf(t, pass, c);
+          i16 *dst = tbuf(t, pass ^ 1, c);
 #ifndef KVZ_HOSTSIM
           if (l2 >= 4) {  // D[k][j] = sum_i C[k][i] * src[j][i]: table rows x data rows, one wavefront per plane
             if ((tid >> 6) == c % (KVZ_CTU_THREADS / 64)) {
@@ -745,7 +780,7 @@ struct CtuProgram {
           for (int e = tid; e < n * n; e += KVZ_CTU_THREADS) {
             const int k = e >> l2, j = e & (n - 1);
             int a = 0;
-            for (int i = 0; i < n; i++) a += (int)C[(k << rs) + i] * (int)src[(j << l2) + i];
+            for (int i = 0; i < n; i++) a += dct_at(l2, k, i) * (int)src[(j << l2) + i];
             dst[e] = (i16)((a + add) >> shift);
           }
         }
@@ -762,8 +797,8 @@ struct CtuProgram {
         const QuantScalars qf = s->qs[l2 - 2][c ? 1 : 0];  // forward and inverse share the plane's scaled QP (U and V alike)
         const QuantScalars qi = qf;
         i16 *cout = coeff_level(lv) + kPlaneOff[c] + zorder(xl >> sh, yl >> sh);
-        const i16 *src = s->tb[0] + tb_off(c);
-        i16 *dq = s->tb[1] + tb_off(c);
+        const i16 *src = tbuf(t, 0, c);
+        i16 *dq = tbuf(t, 1, c);
         u32 wsum = 0, nz = 0;
         for (int e = tid; e < n2; e += KVZ_CTU_THREADS) {
           const int cf = src[e];
@@ -796,9 +831,8 @@ struct CtuProgram {
           const int l2 = tu_log2(t, c);
           if (!l2 || !s->acc[6 + c]) continue;
           const int n = 1 << l2, shift = pass == 0 ? 7 : 12, add = 1 << (shift - 1);
-          const i16 *C = s->dct32, *src = s->tb[pass ^ 1] + tb_off(c);
-          const int rs = 10 - l2;
-          i16 *dst = s->tb[pass] + tb_off(c);
+          const i16 *src = tbuf(t, pass ^ 1, c);
+          i16 *dst = tbuf(t, pass, c);
 #ifndef KVZ_HOSTSIM
           if (l2 >= 4) {  // D[j][i] = sum_k src[k][j] * C[k][i]: data arrives transposed, first pass leaves it transposed again
             if ((tid >> 6) == c % (KVZ_CTU_THREADS / 64)) {
@@ -811,7 +845,7 @@ struct CtuProgram {
           for (int e = tid; e < n * n; e += KVZ_CTU_THREADS) {
             const int j = e >> l2, i = e & (n - 1);
             int a = 0;
-            for (int k = 0; k < n; k++) a += (int)C[(k << rs) + i] * (int)src[(k << l2) + j];
+            for (int k = 0; k < n; k++) a += dct_at(l2, k, i) * (int)src[(k << l2) + j];
             dst[e] = (i16)iclip(-32768, 32767, (a + add) >> shift);
           }
         }
@@ -831,7 +865,7 @@ struct CtuProgram {
           const int o = kPlaneOff[c] + ((yl >> sh) + (e >> l2)) * lw + (xl >> sh) + (e & (w - 1));
           u8 *rp = &cv.at(c, (xl >> sh) + (e & (w - 1)), (yl >> sh) + (e >> l2));
           int v = *rp;
-          if (has) { v = iclip(0, 255, (int)(i16)(s->tb[1][tb_off(c) + e] + v)); *rp = (u8)v; }
+          if (has) { v = iclip(0, 255, (int)(i16)(tbuf(t, 1, c)[e] + v)); *rp = (u8)v; }
           const int d = (int)s->org[o] - v;
           ssd += (u32)(d * d);
         }
@@ -974,7 +1008,6 @@ struct CtuProgram {
       for (int e = tid; e < 6144; e += KVZ_CTU_THREADS) s->dec[e] = 0;
       for (int lv = 0; lv < 4; lv++)
         if (tid < 64) { CtuCu z = { 0, 0, 0, 0, 0, 0 }; s->cu[lv][tid] = z; }
-      if (tid == 0) s->final_c0 = 0;
       for (int v = tid; v < 256; v += KVZ_CTU_THREADS) {  // intra.c:47-82 num_ref_pixels_{top,left}, regenerated from the z-order of 4x4 units
         const int r = v >> 4, c = v & 15;
         int n = 0;
@@ -988,7 +1021,11 @@ struct CtuProgram {
       // of the picture: inside the picture every coefficient that reaches level 0 was written by a transform unit first.
       if (cx + 64 > F.W || cy + 64 > F.H)
         for (int lv = 0; lv < 4; lv += 3) { i16 *cf = coeff_level(lv); for (int e = tid; e < 6144; e += KVZ_CTU_THREADS) cf[e] = 0; }
+#ifdef KVZ_HOSTSIM
       for (int e = tid; e < 1024; e += KVZ_CTU_THREADS) s->dct32[e] = tb->dct[3][e];
+#else
+      for (int e = tid; e < 80; e += KVZ_CTU_THREADS) s->dct_small[e] = e < 64 ? tb->dct[1][e] : tb->dct[0][e - 64];
+#endif
       // neighbour CTUs (complete: they come earlier in the dependency order): border pixels and CU info from their records
       {
         const int ctx = cx >> 6, cty = cy >> 6;
@@ -1039,10 +1076,12 @@ struct CtuProgram {
     KVZ_SYNC();
   }
 
-  // copy_lcu_to_cu_data (search.c:1180-1207): level 0 -> frame reconstruction + CU info; coefficients already there
-  KVZ_DEV void finish()
+  // copy_lcu_to_cu_data (search.c:1180-1207), pixel half: CtuShared::dec -> frame reconstruction and the pixel part of the
+  // border record the right / lower neighbours read.  May run twice for a CTU (see run()): every lane rewrites the
+  // addresses it wrote the first time, so the later values win.
+  KVZ_DEV void write_rec()
   {
-    const u8 *fin = s->final_c0 ? s->c0 : s->dec;  // uniform: written before the last barrier
+    const u8 *fin = s->dec;
     KVZ_FOR_THREADS(tid) {
       for (int c = 0; c < 3; c++) {
         const int sh = c ? 1 : 0, lw = 64 >> sh, fw = F.W >> sh, fh = F.H >> sh, ox = cx >> sh, oy = cy >> sh;
@@ -1052,6 +1091,19 @@ struct CtuProgram {
           if (px < fw && py < fh) dst[(long)py * fw + px] = fin[kPlaneOff[c] + e];
         }
       }
+      u8 *r = F.border + ((long)frame * F.wc * F.hc + ctu_index()) * KVZ_BORDER_BYTES;
+      for (int v = tid; v < 128; v += KVZ_CTU_THREADS) {
+        const int c = v < 64 ? 0 : (v < 96 ? 1 : 2), i = v < 64 ? v : (v - 64) & 31, lw = c ? 32 : 64;
+        r[v] = fin[kPlaneOff[c] + (lw - 1) * lw + i];        // bottom row
+        r[128 + v] = fin[kPlaneOff[c] + i * lw + lw - 1];    // right column
+      }
+    }
+    KVZ_SYNC();
+  }
+  // ... and the CU-info half: level 0 -> cu arrays, CTU cost, CU part of the border record; coefficients already there
+  KVZ_DEV void finish_info()
+  {
+    KVZ_FOR_THREADS(tid) {
       if (tid < 64) {
         const int fx = cx + (tid & 7) * 8, fy = cy + (tid >> 3) * 8;
         if (fx < F.W && fy < F.H) {
@@ -1061,19 +1113,11 @@ struct CtuProgram {
         }
       }
       if (tid == 0) F.ctu_cost[(long)frame * F.wc * F.hc + ctu_index()] = s->cost[0];
-      {  // border record for the right / lower neighbours
-        u8 *r = F.border + ((long)frame * F.wc * F.hc + ctu_index()) * KVZ_BORDER_BYTES;
-        for (int v = tid; v < 128 + 32; v += KVZ_CTU_THREADS) {
-          if (v < 128) {
-            const int c = v < 64 ? 0 : (v < 96 ? 1 : 2), i = v < 64 ? v : (v - 64) & 31, lw = c ? 32 : 64;
-            r[v] = fin[kPlaneOff[c] + (lw - 1) * lw + i];        // bottom row
-            r[128 + v] = fin[kPlaneOff[c] + i * lw + lw - 1];    // right column
-          } else {
-            const int k = v - 128, i = k & 7;
-            const CtuCu *cu = &s->cu[0][k < 16 ? 56 + i : i * 8 + 7];
-            r[256 + k] = ((k >> 3) & 1) ? cu->mode : cu->depth;
-          }
-        }
+      u8 *r = F.border + ((long)frame * F.wc * F.hc + ctu_index()) * KVZ_BORDER_BYTES;
+      for (int v = tid; v < 32; v += KVZ_CTU_THREADS) {
+        const int i = v & 7;
+        const CtuCu *cu = &s->cu[0][v < 16 ? 56 + i : i * 8 + 7];
+        r[256 + v] = ((v >> 3) & 1) ? cu->mode : cu->depth;
       }
     }
     KVZ_SYNC();
@@ -1211,6 +1255,7 @@ struct CtuProgram {
   KVZ_DEV void run()
   {
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
+    if (threadIdx.x == 0) for (int i = 0; i < 2 * KVZ_P_COUNT; i++) s->prof_acc[i] = 0;
     t_last = __builtin_amdgcn_s_memtime();
 #endif
     init();
@@ -1247,21 +1292,27 @@ struct CtuProgram {
       KVZ_FOR_THREADS(tid) { if (tid == 0) s->split_cost[0] += s->cost[1]; }
       KVZ_SYNC();
     }
-    if (cx + 64 <= F.W && cy + 64 <= F.H) try_merge(cx, cy, 0);
+    // The 64x64 merge builds its candidate in the storage of the decided picture, so the split result goes out first
+    bool attempt0 = false;
+    if (cx + 64 <= F.W && cy + 64 <= F.H) { const CtuCu d1 = s->cu[1][0]; attempt0 = d1.type == 1 && d1.depth == 1; }  // try_merge's own test
+    if (attempt0) { write_rec(); try_merge(cx, cy, 0); }
     const bool split_wins0 = s->split_cost[0] < s->cost[0];
     KVZ_SYNC();
     if (split_wins0) {
       KVZ_FOR_THREADS(tid) { if (tid == 0) s->cost[0] = s->split_cost[0]; }
       KVZ_SYNC();
       commit(1, 0, 0, -1, false, 0, 0, 64);
-    } else {  // the 64x64 merge wins: its pixels stay in c0, its coefficients move to the output block
-      KVZ_FOR_THREADS(tid) { if (tid == 0) s->final_c0 = 1; }
-      KVZ_SYNC();
+      if (!attempt0) write_rec();
+    } else {  // the 64x64 merge wins: its pixels replace the ones written above, its coefficients move to the output block
       commit(0, 0, -1, -1, true, 0, 0, 64);
+      write_rec();
     }
     KVZ_PROF(KVZ_P_MISC);
-    finish();
+    finish_info();
     KVZ_PROF(KVZ_P_FINISH);
+#if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
+    if (threadIdx.x == 0) for (int i = 0; i < 2 * KVZ_P_COUNT; i++) atomicAdd(&F.prof[i], s->prof_acc[i]);
+#endif
   }
 };
 

@@ -56,3 +56,7 @@ extern "C" void kvz_hostsim_intra_frame(const kvz_hip_intra_cost_model *m, int w
   free(border);
 }
 extern "C" unsigned kvz_hostsim_ctu_shared_bytes(void) { return (unsigned)sizeof(kvz::CtuShared); }
+
+#ifdef KVZ_HOSTSIM_COUNT_SYNCS
+extern "C" unsigned long long kvz_hostsim_syncs(void) { return g_kvz_syncs; }
+#endif

@@ -28,16 +28,16 @@ def main():
     for i in range(n):
         b.upload(i, frames[i % len(frames)])
     b.run(model)
-    buf = (C.c_ulonglong * 16)()
+    buf = (C.c_ulonglong * 32)()
     lib.kvz_hip_batch_profile.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
-    lib.kvz_hip_batch_profile(b.handle, buf, 16)
+    lib.kvz_hip_batch_profile(b.handle, buf, 32)
     b.run(model)
-    lib.kvz_hip_batch_profile(b.handle, buf, 16)
+    lib.kvz_hip_batch_profile(b.handle, buf, 32)
     tot = sum(buf[:len(NAMES)])
     nctu = n * 510
     print(f"kernel_ms {b.kernel_ms():.2f}  cycles/CTU {tot / nctu:.0f}")
     for i, nm in enumerate(NAMES):
-        print(f"{nm:11s} {buf[i] / nctu:10.0f} cyc/CTU  {100.0 * buf[i] / tot:5.1f}%")
+        print(f"{nm:11s} {buf[i] / nctu:10.0f} cyc/CTU  {100.0 * buf[i] / tot:5.1f}%  {buf[len(NAMES) + i] / nctu:7.1f} marks/CTU")
 
 
 if __name__ == "__main__":

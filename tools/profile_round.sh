@@ -1,0 +1,15 @@
+#!/bin/bash
+# On the GPU box: the measurements a round commits under profiles/ -- full bench line, rocprofv3 kernel stats of the same
+# command, and HBM traffic of the CTU kernel from PMC (FETCH_SIZE and WRITE_SIZE in separate passes, no trace domains
+# besides --kernel-trace).  usage: tools/profile_round.sh <tag> ; results under gpurun_out/<tag>_*
+tag=$1
+repo=$PWD
+python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+cd /tmp && export TMPDIR=/tmp
+B="python $repo/bench.py --no-cpu-baseline --no-ref-encoder"
+rocprofv3 --kernel-trace --stats --output-format csv -d $repo/gpurun_out/${tag}_stats -o ${tag} -- $B > $repo/gpurun_out/${tag}_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $repo/gpurun_out/${tag}_pmc_f -o ${tag}_f -- $B --steps 1 --warmup 1 > $repo/gpurun_out/${tag}_pmc_f.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $repo/gpurun_out/${tag}_pmc_w -o ${tag}_w -- $B --steps 1 --warmup 1 > $repo/gpurun_out/${tag}_pmc_w.log 2>&1
+cd $repo
+cat gpurun_out/${tag}_bench.json
+find gpurun_out/${tag}_stats gpurun_out/${tag}_pmc_f gpurun_out/${tag}_pmc_w -name "*.csv" | head -20
