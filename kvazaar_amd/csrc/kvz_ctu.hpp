@@ -257,7 +257,8 @@ struct CtuShared {
   int best_mode;
   u8 tbl_top[16][16], tbl_left[16][16];
   // uniform scalars carried between phases (written by lane 0, read by everybody after the barrier)
-  double cost[4], split_cost[4];  // per depth
+  double cost[4], split_cost[4];  // per depth: the CU as one unit / split in four
+  double res[4];                  // per depth: the cheaper of the two, what the parent adds up
   double child_rd[4];
   u32 child_acc[4][9];
   int cbf_any;
@@ -459,9 +460,13 @@ struct CtuProgram {
 
   // Builds the unfiltered references of the listed planes; second phase: the [1 2 1]-filtered luma references
   // (intra.c:176-204) and the DC value of every plane (intra-generic.c:219-225).
-  KVZ_DEV void build_refs(int lv, int x, int y, int log2w_y, int log2w_c, bool luma, bool chroma)
+  struct NoHook { KVZ_DEV void operator()() const {} };
+  // `first` runs on thread 0 inside the first phase: bookkeeping of the caller that no lane reads before the next barrier
+  template <class First = NoHook>
+  KVZ_DEV void build_refs(int lv, int x, int y, int log2w_y, int log2w_c, bool luma, bool chroma, First first = First())
   {
     KVZ_FOR_THREADS(tid) {
+      if (tid == 0) first();
       for (int c = luma ? 0 : 1; c <= (chroma ? 2 : 0); c++) {
         const int l2 = c ? log2w_c : log2w_y, n = 2 * (1 << l2) + 1;
         for (int i = tid; i < 2 * n; i += KVZ_CTU_THREADS) {
@@ -601,6 +606,27 @@ struct CtuProgram {
     return 2 * sum;
   }
 
+  // Extended main reference of every angular mode (see CtuShared::mref) for a 2^L2 CU.  All reads first, then all
+  // writes: the loop bounds are compile-time constants, so the LDS round trips of different entries overlap.
+  template <int L2>
+  KVZ_DEV void build_mref(int tid)
+  {
+    constexpr int W = 1 << L2, NQ = 3 * W + 2, THRES = L2 == 3 ? 7 : 1, N = (33 * NQ + KVZ_CTU_THREADS - 1) / KVZ_CTU_THREADS;
+    u8 vals[N];
+    for (int k = 0; k < N; k++) {
+      const int i = imin(tid + k * KVZ_CTU_THREADS, 33 * NQ - 1), mode = 2 + i / NQ, q = i % NQ - W;
+      const bool vertical = mode >= 18, filt = imin(iabs(mode - 26), iabs(mode - 10)) > THRES;
+      const u8 *top = filt ? s->fref[0] : s->ref[0][0], *left = filt ? s->fref[1] : s->ref[0][1];
+      const u8 *main_ref = vertical ? top : left, *side_ref = vertical ? left : top;
+      const int idx = q >= 0 ? q : (128 + (-q) * (int)s->mode_inv[mode]) >> 8;
+      vals[k] = (q >= 0 ? main_ref : side_ref)[imin(idx, 2 * W)];
+    }
+    for (int k = 0; k < N; k++) {
+      const int i = tid + k * KVZ_CTU_THREADS;
+      if (i < 33 * NQ) s->mref[i / NQ][KVZ_MREF_ORG + i % NQ - W] = vals[k];
+    }
+  }
+
   KVZ_DEV u32 mode_satd(int mode, int nblk) const  // SATD_NxN: sum of (block sum + 2) >> 2 (strategies-picture.h:53-69)
   {
     u32 v = 0;
@@ -611,21 +637,14 @@ struct CtuProgram {
   // search_intra.c:391-530 search_intra_rough: all 35 modes predicted + SATD-scored, then the reference's selection
   // order replayed on the cost table by one lane.  Leaves the winner in s->best_mode and the CU's info entries filled.
   // Also builds the chroma references of the CU (they only depend on neighbouring chroma reconstruction).
-  KVZ_DEV void rough_search(int lv, int x, int y, int depth)
+  template <class First>
+  KVZ_DEV void rough_search(int lv, int x, int y, int depth, First first)
   {
     const int log2w = 6 - depth, w = 1 << log2w, xl = x - cx, yl = y - cy, nblk = (w >> 3) * (w >> 3);
-    build_refs(lv, x, y, log2w, depth == 3 ? 2 : log2w - 1, true, true);
+    build_refs(lv, x, y, log2w, depth == 3 ? 2 : log2w - 1, true, true, first);
     KVZ_FOR_THREADS(tid) {
       // extended main reference per angular mode
-      const int nq = 3 * w + 2, thres = log2w == 3 ? 7 : 1;
-      for (int i = tid; i < 33 * nq; i += KVZ_CTU_THREADS) {
-        const int mode = 2 + i / nq, q = i % nq - w;
-        const bool vertical = mode >= 18, filt = imin(iabs(mode - 26), iabs(mode - 10)) > thres;
-        const u8 *top = filt ? s->fref[0] : s->ref[0][0], *left = filt ? s->fref[1] : s->ref[0][1];
-        const u8 *main_ref = vertical ? top : left, *side_ref = vertical ? left : top;
-        const int idx = q >= 0 ? q : (128 + (-q) * (int)s->mode_inv[mode]) >> 8;
-        s->mref[mode - 2][KVZ_MREF_ORG + q] = (q >= 0 ? main_ref : side_ref)[imin(idx, 2 * w)];
-      }
+      if (log2w == 3) build_mref<3>(tid); else build_mref<4>(tid);
       for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) {
         const int ex = e >> log2w, ey = e & (w - 1);
         s->org_t[e] = s->org[(yl + ey) * 64 + xl + ex];
@@ -661,7 +680,22 @@ struct CtuProgram {
     KVZ_SYNC();
     KVZ_PROF(KVZ_P_SATD);
     KVZ_FOR_THREADS(tid) {
+      // The replay below is serial and uniform.  On the device the first wavefront's worth of thread ids runs it together:
+      // lane m first works out mode m's SATD and cost, the replay then picks values out of those registers by lane index
+      // (v_readlane) instead of recomputing them from LDS.  The host build computes them on demand -- same formulas.
+#ifdef KVZ_HOSTSIM
       if (tid == 0) {
+#define KVZ_RAW(md) mode_satd((md), nblk)
+#define KVZ_COST(md, raw) ((double)(raw) + s->mode_bits_cost[(md) == p0 ? 1 : (((md) == p1 || (md) == p2) ? 2 : 0)])
+#else
+      if (tid < 64) {
+        const int my_mode = tid < 35 ? tid : 0;
+        const u32 my_raw = mode_satd(my_mode, nblk);
+        const double my_cost = (double)my_raw + s->mode_bits_cost[my_mode == s->preds[0] ? 1 : ((my_mode == s->preds[1] || my_mode == s->preds[2]) ? 2 : 0)];
+        const int my_cost_lo = __double2loint(my_cost), my_cost_hi = __double2hiint(my_cost);
+#define KVZ_RAW(md) ((u32)__builtin_amdgcn_readlane((int)my_raw, __builtin_amdgcn_readfirstlane(md)))
+#define KVZ_COST(md, raw) __hiloint2double(__builtin_amdgcn_readlane(my_cost_hi, __builtin_amdgcn_readfirstlane(md)), __builtin_amdgcn_readlane(my_cost_lo, __builtin_amdgcn_readfirstlane(md)))
+#endif
         // The list kvazaar builds (modes[], costs[]) is only ever read back as "first minimum in append order", so it is
         // replayed with a visited mask and running minima instead of arrays.
         unsigned long long visited = 0;
@@ -672,7 +706,7 @@ struct CtuProgram {
         {                                                                                                           \
           const int md_ = (md);                                                                                     \
           visited |= 1ull << md_;                                                                                   \
-          const double c_ = (double)(raw) + s->mode_bits_cost[md_ == p0 ? 1 : ((md_ == p1 || md_ == p2) ? 2 : 0)];  \
+          const double c_ = KVZ_COST(md_, raw);                                                                     \
           if (final_mode < 0 || c_ < final_cost) { final_cost = c_; final_mode = md_; }                             \
         }
         int offset = log2w == 2 ? 2 : (log2w == 3 ? 4 : 8);
@@ -681,7 +715,7 @@ struct CtuProgram {
         u32 first_min = 0;
         for (int mode = 2; mode <= 34; mode += 2 * offset)
           for (int i = 0; i < 2; i++) if (mode + i * offset <= 34) {
-            const u32 raw = mode_satd(mode + i * offset, nblk);
+            const u32 raw = KVZ_RAW(mode + i * offset);
             KVZ_APPEND(mode + i * offset, raw);
             if ((int32_t)raw < min_cost) min_cost = (int32_t)raw;
             if ((int32_t)raw > max_cost) max_cost = (int32_t)raw;
@@ -693,7 +727,7 @@ struct CtuProgram {
             offset >>= 1;
             const int tm[2] = { best_mode - offset, best_mode + offset };
             for (int i = 0; i < 2; i++) if (tm[i] >= 2 && tm[i] <= 34) {
-              const u32 raw = mode_satd(tm[i], nblk);
+              const u32 raw = KVZ_RAW(tm[i]);
               KVZ_APPEND(tm[i], raw);
               if ((double)raw < best_cost) { best_cost = (double)raw; best_mode = tm[i]; }
             }
@@ -701,11 +735,14 @@ struct CtuProgram {
         }
         const int add_modes[5] = { p0, p1, p2, 0, 1 };
         for (int p = 0; p < 5; p++)
-          if (!((visited >> add_modes[p]) & 1)) { const u32 raw = mode_satd(add_modes[p], nblk); KVZ_APPEND(add_modes[p], raw); }
+          if (!((visited >> add_modes[p]) & 1)) { const u32 raw = KVZ_RAW(add_modes[p]); KVZ_APPEND(add_modes[p], raw); }
 #undef KVZ_APPEND
-        s->best_mode = final_mode;
+#undef KVZ_RAW
+#undef KVZ_COST
+        (void)p0; (void)p1; (void)p2;
+        if (tid == 0) s->best_mode = final_mode;
         // lcu_fill_cu_info (search.c:137-159) for the searched CU: at most 2x2 entries
-        for (int i = 0; i < (w >> 3) * (w >> 3); i++) {
+        for (int i = 0; tid == 0 && i < (w >> 3) * (w >> 3); i++) {
           CtuCu *cu = &s->cu[lv][((yl >> 3) + i / (w >> 3)) * 8 + (xl >> 3) + i % (w >> 3)];
           cu->type = 1; cu->depth = (u8)depth; cu->mode = (u8)final_mode; cu->tr_depth = (u8)depth;
         }
@@ -932,10 +969,16 @@ struct CtuProgram {
   //   CU info      level cu_from -> levels cu_to_lo..cu_to_hi (copy_cu_info),
   //   pixels       candidate of depth pix_lv -> decided picture (copy_cu_pixels; -1: the decided picture already holds them),
   //   coefficients challenger block -> output block (copy_cu_coeffs) when `coeffs`.
-  KVZ_DEV void commit(int cu_from, int cu_to_lo, int cu_to_hi, int pix_lv, bool coeffs, int xl, int yl, int w)
+  // Thread 0 also records the verdict of depth `res_depth`: res[d] = the cost search_cu returns for the CU (search.c:1046-1060).
+  KVZ_DEV void commit(int cu_from, int cu_to_lo, int cu_to_hi, int pix_lv, bool coeffs, int xl, int yl, int w, int res_depth, bool split_won)
   {
     const CandView cv = cand_view(pix_lv < 0 ? 0 : pix_lv);
     KVZ_FOR_THREADS(tid) {
+      if (tid == 0) {
+        const double r = split_won ? s->split_cost[res_depth] : s->cost[res_depth];
+        s->res[res_depth] = r;
+        if (res_depth > 0) s->split_cost[res_depth - 1] += r;  // the parent's running sum (search.c:1005-1010)
+      }
       const int n = w >> 3, lw = w == 16 ? 4 : (w == 32 ? 5 : 6), ln = lw - 3, cw = w >> 1;
       if (tid < n * n) {
         const int i = ((yl >> 3) + (tid >> ln)) * 8 + (xl >> 3) + (tid & (n - 1));
@@ -967,11 +1010,13 @@ struct CtuProgram {
   }
 
   // search_cu at depth 2 or 3 (search.c:646-1063): searched CU.  Returns the cost through *out (LDS).
-  KVZ_DEV void eval_cu(int lv, int x, int y, int depth, double *out_cost, int *out_cbf)
+  // `first` / `last`: thread-0 bookkeeping of the caller folded into the first / last phase (see build_refs)
+  template <class First, class Last>
+  KVZ_DEV void eval_cu(int lv, int x, int y, int depth, double *out_cost, int *out_cbf, First first, Last last)
   {
     lane_rot = (lane_rot + 64) & (KVZ_CTU_THREADS - 1);
     const int log2w = 6 - depth, w = 1 << log2w, xl = x - cx, yl = y - cy;
-    rough_search(lv, x, y, depth);
+    rough_search(lv, x, y, depth, first);
     const int mode = s->best_mode;
     (void)w;
     // kvz_intra_recon_cu luma, then chroma (search.c:807-827); chroma TUs are 4x4 for 8x8 CUs (transform.c:326).
@@ -986,6 +1031,7 @@ struct CtuProgram {
         *out_cost = cost;
         const CtuCu *cu = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
         *out_cbf = cbf_is_set(cu->cbf, depth, 0) || cbf_is_set(cu->cbf, depth, 1) || cbf_is_set(cu->cbf, depth, 2);
+        last();
       }
     }
     KVZ_SYNC();
@@ -1112,7 +1158,7 @@ struct CtuProgram {
           F.cu_mode[i] = s->cu[0][tid].mode;
         }
       }
-      if (tid == 0) F.ctu_cost[(long)frame * F.wc * F.hc + ctu_index()] = s->cost[0];
+      if (tid == 0) F.ctu_cost[(long)frame * F.wc * F.hc + ctu_index()] = s->res[0];
       u8 *r = F.border + ((long)frame * F.wc * F.hc + ctu_index()) * KVZ_BORDER_BYTES;
       for (int v = tid; v < 32; v += KVZ_CTU_THREADS) {
         const int i = v & 7;
@@ -1123,14 +1169,14 @@ struct CtuProgram {
     KVZ_SYNC();
   }
 
+  KVZ_DEV void cu_header(int lv, int xl, int yl, int depth) const  // search.c:694-700, one thread
+  {
+    CtuCu *c = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
+    c->depth = (u8)(depth > 3 ? 3 : depth); c->tr_depth = (u8)(depth > 0 ? depth : 1); c->type = 0;
+  }
   KVZ_DEV void set_cu_header(int lv, int xl, int yl, int depth)
   {
-    KVZ_FOR_THREADS(tid) {
-      if (tid == 0) {  // search.c:694-700
-        CtuCu *c = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
-        c->depth = (u8)(depth > 3 ? 3 : depth); c->tr_depth = (u8)(depth > 0 ? depth : 1); c->type = 0;
-      }
-    }
+    KVZ_FOR_THREADS(tid) { if (tid == 0) cu_header(lv, xl, yl, depth); }
     KVZ_SYNC();
   }
 
@@ -1210,45 +1256,40 @@ struct CtuProgram {
   KVZ_DEV void search_d2(int x, int y)
   {
     const int xl = x - cx, yl = y - cy;
-    if (x >= F.W || y >= F.H) { KVZ_FOR_THREADS(tid) { if (tid == 0) s->cost[2] = 0; } KVZ_SYNC(); return; }
+    if (x >= F.W || y >= F.H) return;  // search_cu returns 0 outside the picture: nothing to add to the parent's sum
     a2x = xl; a2y = yl;
-    set_cu_header(2, xl, yl, 2);
     const bool inside = x + 16 <= F.W && y + 16 <= F.H;
-    KVZ_FOR_THREADS(tid) { if (tid == 0) { s->cost[2] = 1.7e+308; s->cbf_any = 0; } }
-    KVZ_SYNC();
-    if (inside) eval_cu(2, x, y, 2, &s->cost[2], &s->cbf_any);
-    KVZ_FOR_THREADS(tid) {
-      if (tid == 0) {
-        double split_bits = 0;
-        split_bits += (double)m->split_flag[split_model(2, x, y, 2)][1];
-        double sc = 0.0;
-        sc += split_bits * m->lambda;
-        if (inside && !s->cbf_any) sc = 2147483647;  // cu_split_termination = zero (search.c:975-984)
-        s->split_cost[2] = sc;
-      }
+    // thread-0 bookkeeping around the 16x16 CU: header + cost initialisation before, split cost after
+    auto d2_first = [&]() { cu_header(2, xl, yl, 2); s->cost[2] = 1.7e+308; s->cbf_any = 0; };
+    auto d2_last = [&]() {
+      double split_bits = 0;
+      split_bits += (double)m->split_flag[split_model(2, x, y, 2)][1];
+      double sc = 0.0;
+      sc += split_bits * m->lambda;
+      if (inside && !s->cbf_any) sc = 2147483647;  // cu_split_termination = zero (search.c:975-984)
+      s->split_cost[2] = sc;
+    };
+    if (inside) eval_cu(2, x, y, 2, &s->cost[2], &s->cbf_any, d2_first, d2_last);
+    else {
+      KVZ_FOR_THREADS(tid) { if (tid == 0) { d2_first(); d2_last(); } }
+      KVZ_SYNC();
     }
-    KVZ_SYNC();
     if (!inside || s->cbf_any) {
       for (int q = 0; q < 4; q++) {
         if (!(s->split_cost[2] < s->cost[2])) break;  // uniform: both are LDS scalars
         const int qx = x + (q & 1) * 8, qy = y + (q >> 1) * 8;
         if (qx >= F.W || qy >= F.H) continue;  // child outside the picture costs 0
-        set_cu_header(3, qx - cx, qy - cy, 3);
-        eval_cu(3, qx, qy, 3, &s->cost[3], &s->cbf_any);
-        KVZ_FOR_THREADS(tid) { if (tid == 0) s->split_cost[2] += s->cost[3]; }
-        KVZ_SYNC();
+        eval_cu(3, qx, qy, 3, &s->cost[3], &s->cbf_any, [&]() { cu_header(3, qx - cx, qy - cy, 3); }, [&]() { s->split_cost[2] += s->cost[3]; });
       }
     }
-    // Every lane reads the verdict BEFORE lane 0 may overwrite its operands: without the barrier a lagging wave could
-    // read cost[2] after the update and take the other branch (the host simulation cannot show that race).
+    // Every lane reads the verdict here; thread 0 only touches its operands again after the barrier that ends commit()
+    // (the result goes to res[2]).  Without that a lagging wavefront could read an updated cost and take the other branch
+    // (the host simulation cannot show such a race).
     const bool split_wins2 = s->split_cost[2] < s->cost[2];
-    KVZ_SYNC();
     if (split_wins2) {
-      KVZ_FOR_THREADS(tid) { if (tid == 0) s->cost[2] = s->split_cost[2]; }
-      KVZ_SYNC();
-      commit(3, 2, 2, 3, false, xl, yl, 16);  // work_tree_copy_up: the 8x8 CUs win (their coefficients are already in place)
+      commit(3, 2, 2, 3, false, xl, yl, 16, 2, true);   // work_tree_copy_up: the 8x8 CUs win (their coefficients are already in place)
     } else {
-      commit(2, 3, 3, 2, true, xl, yl, 16);   // work_tree_copy_down: the 16x16 CU wins
+      commit(2, 3, 3, 2, true, xl, yl, 16, 2, false);   // work_tree_copy_down: the 16x16 CU wins
     }
   }
 
@@ -1260,51 +1301,34 @@ struct CtuProgram {
 #endif
     init();
     KVZ_PROF(KVZ_P_INIT);
-    set_cu_header(0, 0, 0, 0);
     KVZ_FOR_THREADS(tid) {
-      if (tid == 0) { s->cost[0] = 1.7e+308; double sb = 0; sb += (double)m->split_flag[split_model(0, cx, cy, 0)][1]; double sc = 0.0; sc += sb * m->lambda; s->split_cost[0] = sc; }
+      if (tid == 0) { cu_header(0, 0, 0, 0); s->cost[0] = 1.7e+308; double sb = 0; sb += (double)m->split_flag[split_model(0, cx, cy, 0)][1]; double sc = 0.0; sc += sb * m->lambda; s->split_cost[0] = sc; }
     }
     KVZ_SYNC();
     for (int q1 = 0; q1 < 4; q1++) {
       const int x1 = cx + (q1 & 1) * 32, y1 = cy + (q1 >> 1) * 32;
       if (x1 >= F.W || y1 >= F.H) continue;  // search_cu returns 0 outside the picture
       a1x = x1 - cx; a1y = y1 - cy;
-      set_cu_header(1, x1 - cx, y1 - cy, 1);
       KVZ_FOR_THREADS(tid) {
-        if (tid == 0) { s->cost[1] = 1.7e+308; double sb = 0; sb += (double)m->split_flag[split_model(1, x1, y1, 1)][1]; double sc = 0.0; sc += sb * m->lambda; s->split_cost[1] = sc; }
+        if (tid == 0) { cu_header(1, x1 - cx, y1 - cy, 1); s->cost[1] = 1.7e+308; double sb = 0; sb += (double)m->split_flag[split_model(1, x1, y1, 1)][1]; double sc = 0.0; sc += sb * m->lambda; s->split_cost[1] = sc; }
       }
       KVZ_SYNC();
-      for (int q2 = 0; q2 < 4; q2++) {
-        search_d2(x1 + (q2 & 1) * 16, y1 + (q2 >> 1) * 16);
-        KVZ_FOR_THREADS(tid) { if (tid == 0) s->split_cost[1] += s->cost[2]; }
-        KVZ_SYNC();
-      }
+      for (int q2 = 0; q2 < 4; q2++) search_d2(x1 + (q2 & 1) * 16, y1 + (q2 >> 1) * 16);
       if (x1 + 32 <= F.W && y1 + 32 <= F.H) try_merge(x1, y1, 1);
-      const bool split_wins1 = s->split_cost[1] < s->cost[1];
-      KVZ_SYNC();
-      if (split_wins1) {
-        KVZ_FOR_THREADS(tid) { if (tid == 0) s->cost[1] = s->split_cost[1]; }
-        KVZ_SYNC();
-        commit(2, 1, 1, -1, false, x1 - cx, y1 - cy, 32);
-      } else {
-        commit(1, 2, 3, 1, true, x1 - cx, y1 - cy, 32);  // the 32x32 merge wins
-      }
-      KVZ_FOR_THREADS(tid) { if (tid == 0) s->split_cost[0] += s->cost[1]; }
-      KVZ_SYNC();
+      const bool split_wins1 = s->split_cost[1] < s->cost[1];  // operands stay put until the barrier that ends commit()
+      if (split_wins1) commit(2, 1, 1, -1, false, x1 - cx, y1 - cy, 32, 1, true);
+      else commit(1, 2, 3, 1, true, x1 - cx, y1 - cy, 32, 1, false);  // the 32x32 merge wins
     }
     // The 64x64 merge builds its candidate in the storage of the decided picture, so the split result goes out first
     bool attempt0 = false;
     if (cx + 64 <= F.W && cy + 64 <= F.H) { const CtuCu d1 = s->cu[1][0]; attempt0 = d1.type == 1 && d1.depth == 1; }  // try_merge's own test
     if (attempt0) { write_rec(); try_merge(cx, cy, 0); }
     const bool split_wins0 = s->split_cost[0] < s->cost[0];
-    KVZ_SYNC();
     if (split_wins0) {
-      KVZ_FOR_THREADS(tid) { if (tid == 0) s->cost[0] = s->split_cost[0]; }
-      KVZ_SYNC();
-      commit(1, 0, 0, -1, false, 0, 0, 64);
+      commit(1, 0, 0, -1, false, 0, 0, 64, 0, true);
       if (!attempt0) write_rec();
     } else {  // the 64x64 merge wins: its pixels replace the ones written above, its coefficients move to the output block
-      commit(0, 0, -1, -1, true, 0, 0, 64);
+      commit(0, 0, -1, -1, true, 0, 0, 64, 0, false);
       write_rec();
     }
     KVZ_PROF(KVZ_P_MISC);
