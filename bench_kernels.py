@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Micro-benchmarks of the device-resident batch primitives (include/kvz_hip_dev.h) against their rooflines -- SURVEY.md 8(d).
+
+Shapes follow the reference's tests/speed_tests.c (N x N cost functions and transforms on its gradient data), batched over
+BATCH_CTUS CTUs' worth of blocks that are resident in HBM before the timed region.  For every kernel one JSON line:
+  achieved GB/s = algorithmic bytes (2 N^2 per SAD/SATD block, 4 N^2 per transform block, (4N+2)+N^2 per angular
+  block) / mean launch time measured with HIP events on the launch stream; frac = achieved / 8000 GB/s (MI355X HBM3E peak);
+  16/32-point transforms additionally report matrix-core utilisation = blocks/s * 4 N^3 / 2.5e15 (dense f16 peak; the kernels
+  issue twice that many MFMA operations because 16-bit operands are split in bytes -- stated as mfma_issued_frac).
+bench.py remains the headline (CTUs/s); this file is the per-kernel view."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0
+F16_DENSE_PEAK = 2.5e15
+
+
+def gradient_blocks(n, count, seed):
+    """speed_tests.c init_gradient flavour: per-block offset + horizontal ramp, plus noise on the second operand"""
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 200, (count, 1), dtype=np.int32) + (np.arange(n * n, dtype=np.int32)[None, :] % n)
+    a = np.clip(base, 0, 255).astype(np.uint8)
+    b = np.clip(base + rng.integers(-8, 9, (count, n * n), dtype=np.int32), 0, 255).astype(np.uint8)
+    return a, b
+
+
+def time_call(dev, fn, reps, warmup):
+    for _ in range(warmup):
+        fn()
+    dev.lib.kvz_hip_dev_sync()
+    dev.lib.kvz_hip_dev_timer_start()
+    for _ in range(reps):
+        fn()
+    return dev.lib.kvz_hip_dev_timer_stop() / reps  # ms per launch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch-ctus", type=int, default=2040 * 64, help="CTUs' worth of blocks per launch (speed_tests shapes x this); the default puts >= 1 GB through every cost kernel so that the 256 MB Infinity Cache cannot hold the working set")
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    args = ap.parse_args()
+
+    import kvazaar_amd
+    import devapi
+    dev = devapi.Dev(kvazaar_amd.load_library())
+    results = []
+
+    def report(name, n, count, ms, bytes_per_block, extra=None):
+        gbps = count * bytes_per_block / (ms * 1e-3) / 1e9
+        r = {"kernel": name, "n": n, "blocks": count, "ms": round(ms, 4), "bytes_per_block": bytes_per_block,
+             "achieved_GBps": round(gbps, 1), "peak_GBps": HBM_PEAK_GBPS, "frac": round(gbps / HBM_PEAK_GBPS, 4), "blocks_per_s": round(count / (ms * 1e-3))}
+        if extra:
+            r.update(extra)
+        results.append(r)
+        print(json.dumps(r), flush=True)
+
+    for n in (8, 16, 32, 64):
+        count = args.batch_ctus * (64 // n) ** 2
+        a, b = gradient_blocks(n, min(count, 4096), n)
+        reps_needed = (count + a.shape[0] - 1) // a.shape[0]
+        a, b = np.tile(a, (reps_needed, 1))[:count], np.tile(b, (reps_needed, 1))[:count]
+        da, db, do = dev.put(a), dev.put(b), dev.empty(4 * count)
+        for cost in ("sad", "satd"):
+            f = getattr(dev.lib, f"kvz_hip_dev_{cost}_nxn")
+            ms = time_call(dev, lambda: f(n, da, db, count, do), args.reps, args.warmup)
+            report(f"{cost}_{n}x{n}", n, count, ms, 2 * n * n + 4)
+        dev.free(da, db, do)
+
+    for name in ("dct4", "dct8", "dct16", "dct32", "idct4", "idct8", "idct16", "idct32"):
+        kind = devapi.TRANSFORM_KINDS[name]
+        n = devapi.TRANSFORM_SIZE[kind]
+        count = args.batch_ctus * (64 // n) ** 2 // 2
+        rng = np.random.default_rng(kind)
+        x = np.tile(rng.integers(-255, 256, (min(count, 2048), n * n)).astype(np.int16), ((count + 2047) // 2048, 1))[:count]
+        di, dt, do = dev.put(x), dev.empty(x.nbytes), dev.empty(x.nbytes)
+        for mfma in ((0, 1) if n >= 16 else (0,)):
+            ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_transform(kind, di, dt, do, count, mfma), args.reps, args.warmup)
+            extra = {"path": "matrix cores (v_mfma_f32_*_f16)" if mfma else "scalar item kernel, two passes through HBM"}
+            if mfma:
+                ops = count * 4 * n ** 3 / (ms * 1e-3)
+                extra.update({"mfma_algorithmic_frac": round(ops / F16_DENSE_PEAK, 5), "mfma_issued_frac": round(2 * ops / F16_DENSE_PEAK, 5)})
+            report(f"{name}" + ("_mfma" if mfma else "_scalar"), n, count, ms, 4 * n * n, extra)
+        dev.free(di, dt, do)
+
+    for log2w in (2, 3, 4, 5):
+        w = 1 << log2w
+        count = args.batch_ctus * (64 // w) ** 2 // 2
+        rng = np.random.default_rng(log2w)
+        refs = rng.integers(0, 256, (2, count, 2 * w + 1), dtype=np.uint8)
+        da, dl, do = dev.put(refs[0]), dev.put(refs[1]), dev.empty(count * w * w)
+        ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_angular_pred(log2w, 7, da, dl, count, do), args.reps, args.warmup)
+        report(f"angular_{w}x{w}", w, count, ms, (4 * w + 2) + w * w)
+        dev.free(da, dl, do)
+
+    print(json.dumps({"summary": "bench_kernels", "batch_ctus": args.batch_ctus, "reps": args.reps, "kernels": len(results)}))
+
+
+if __name__ == "__main__":
+    main()

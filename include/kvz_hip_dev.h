@@ -1,0 +1,49 @@
+/*
+ * kvz_hip_dev.h -- device-resident batch entry points of the hot-path primitives.
+ *
+ * The drop-in entry points of kvz_hip.h keep the reference's synchronous, host-pointer semantics (one block per
+ * call); these take DEVICE pointers and a block count, so that a caller that already keeps frames / CTU data in HBM
+ * (the batched CTU pass, a future inter pass, the micro-benchmarks of SURVEY.md 8d) pays no staging.  Layouts are the
+ * reference's: blocks are the contiguous n*n arrays kvz_sad_NxN / kvz_satd_NxN / kvz_dct_NxN take
+ * (strategies-picture.h:115-131, strategies-dct.h:44), `count` of them back to back.
+ *
+ * All work is queued on the calling thread's stream; kvz_hip_dev_sync() waits for it.  Results are bit-exact with the
+ * per-call entry points (tests/test_gpu_dev.py compares against the oracle).
+ */
+#ifndef KVZ_HIP_DEV_H_
+#define KVZ_HIP_DEV_H_
+
+#include "kvz_hip_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* memory + stream helpers (abort with a message on failure, like the rest of the runtime) */
+void *kvz_hip_dev_alloc(size_t bytes);
+void  kvz_hip_dev_free(void *p);
+void  kvz_hip_dev_upload(void *dev_dst, const void *host_src, size_t bytes);
+void  kvz_hip_dev_download(void *host_dst, const void *dev_src, size_t bytes);
+void  kvz_hip_dev_sync(void);
+/* Event pair on the calling thread's stream: milliseconds the device spent between start and stop. */
+void  kvz_hip_dev_timer_start(void);
+float kvz_hip_dev_timer_stop(void);
+
+/* kvz_sad_NxN / kvz_satd_NxN (picture-generic.c:475-501, 252-340 + strategies-picture.h:53-69), n in {4 (satd only), 8, 16, 32, 64}:
+ * out[i] = cost of blocks a[i], b[i].  2 n^2 bytes read per block, 4 written. */
+void kvz_hip_dev_sad_nxn(int n, const uint8_t *a, const uint8_t *b, int count, uint32_t *out);
+void kvz_hip_dev_satd_nxn(int n, const uint8_t *a, const uint8_t *b, int count, uint32_t *out);
+
+/* kvz_dct_NxN / kvz_idct_NxN / 4x4 DST (dct-generic.c:559-630), 8-bit: `kind` = enum kvz_hip_transform_kind.
+ * 16- and 32-point transforms run on the matrix cores (v_mfma_f32_*_f16, exact integer arithmetic) unless
+ * use_matrix_cores == 0; `tmp` is count * n^2 int16 of scratch for the scalar path (may be NULL with matrix cores). */
+void kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *out, int count, int use_matrix_cores);
+
+/* kvz_angular_pred (intra-generic.c:49-155): block i is predicted from ref_above + i * (2w+1) and ref_left + i * (2w+1)
+ * into out + i * w * w.  (4w + 2) + w^2 bytes per block. */
+void kvz_hip_dev_angular_pred(int log2_width, int mode, const uint8_t *ref_above, const uint8_t *ref_left, int count, uint8_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

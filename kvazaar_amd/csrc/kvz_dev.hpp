@@ -1,0 +1,296 @@
+// kvz_dev.hpp -- device-resident batch kernels behind include/kvz_hip_dev.h.  Included by kvz_hip.hip.
+//
+// These are the HBM-streaming forms of the primitives: every byte of the inputs is read once with 8- or 16-byte loads
+// that are contiguous across the lanes of a wavefront, the arithmetic happens in registers (v_sad_u8, packed int16
+// Hadamard, MFMA), and one value per block goes back.  Rooflines: 2 n^2 bytes per SAD / SATD block,
+// 4 n^2 bytes per transform block (+ 4 n^3 integer multiply-adds for the 16 / 32-point ones on the matrix cores).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/kvz_hip_dev.h"
+#include "kvz_ops.hpp"
+
+namespace kvz {
+
+// Sum over aligned groups of G consecutive lanes (G a power of two <= 64); the result is valid in the group's first lane.
+template <int G> __device__ __forceinline__ u32 group_sum(u32 v)
+{
+  for (int off = G / 2; off > 0; off >>= 1) v += __shfl_down(v, off, G);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SAD: one lane per 16 bytes of each input (dwordx4 loads, lane-contiguous), v_sad_u8 per dword, then a segmented sum
+// over the n^2 / 16 lanes of a block.  64x64 blocks span four wavefronts: one atomic per wavefront into the zeroed output.
+template <int N> __global__ void __launch_bounds__(256) dev_sad_kernel(const uint4 *a, const uint4 *b, const long chunks, u32 *out)
+{
+  constexpr int G = N * N / 16;  // lanes per block
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  u32 v = 0;
+  if (i < chunks) {
+    const uint4 x = a[i], y = b[i];
+    v = __builtin_amdgcn_sad_u8(x.x, y.x, 0);
+    v = __builtin_amdgcn_sad_u8(x.y, y.y, v);
+    v = __builtin_amdgcn_sad_u8(x.z, y.z, v);
+    v = __builtin_amdgcn_sad_u8(x.w, y.w, v);
+  }
+  if (G <= 64) {
+    v = group_sum<(G <= 64 ? G : 64)>(v);
+    if ((threadIdx.x & (G - 1)) == 0 && i < chunks) out[i / G] = v;
+  } else {
+    v = group_sum<64>(v);
+    if ((threadIdx.x & 63) == 0 && i < chunks) atomicAdd(&out[i / G], v);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SATD: one lane per 8x8 tile.  The lane reads its eight rows of both blocks as 8-byte loads (the lanes of a block row
+// read consecutive addresses), forms the differences as packed int16 and runs the 8x8 Hadamard in registers: two packed
+// stages along the rows, three down the columns, the last row stage folded into the magnitude sum
+// (|p + q| + |p - q| = 2 max(|p|, |q|)).  Per tile (sum + 2) >> 2 (picture-generic.c:252-340), then the sum over the
+// (n/8)^2 tiles of the block (strategies-picture.h:53-69).
+typedef short dev_pk16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32 dev_absmax(dev_pk16 a)
+{
+  const dev_pk16 m = __builtin_elementwise_max(a, -a);
+  return (u32)imax((int)m.x, (int)m.y);
+}
+__device__ __forceinline__ void dev_diff_row(uint2 x, uint2 y, dev_pk16 *d)
+{
+  const u32 xs[2] = { x.x, x.y }, ys[2] = { y.x, y.y };
+  for (int h = 0; h < 2; h++) {
+    dev_pk16 lo, hi;
+    lo.x = (short)((int)(xs[h] & 0xff) - (int)(ys[h] & 0xff));
+    lo.y = (short)((int)((xs[h] >> 8) & 0xff) - (int)((ys[h] >> 8) & 0xff));
+    hi.x = (short)((int)((xs[h] >> 16) & 0xff) - (int)((ys[h] >> 16) & 0xff));
+    hi.y = (short)((int)(xs[h] >> 24) - (int)(ys[h] >> 24));
+    d[2 * h] = lo; d[2 * h + 1] = hi;
+  }
+}
+__device__ __forceinline__ u32 dev_satd8_regs(dev_pk16 d[8][4])
+{
+  for (int r = 0; r < 8; r++) {
+    const dev_pk16 a0 = d[r][0] + d[r][2], a1 = d[r][1] + d[r][3], a2 = d[r][0] - d[r][2], a3 = d[r][1] - d[r][3];
+    d[r][0] = a0 + a1; d[r][1] = a0 - a1; d[r][2] = a2 + a3; d[r][3] = a2 - a3;
+  }
+  u32 sum = 0;
+  for (int j = 0; j < 4; j++) {
+    const dev_pk16 a0 = d[0][j] + d[4][j], a1 = d[1][j] + d[5][j], a2 = d[2][j] + d[6][j], a3 = d[3][j] + d[7][j];
+    const dev_pk16 a4 = d[0][j] - d[4][j], a5 = d[1][j] - d[5][j], a6 = d[2][j] - d[6][j], a7 = d[3][j] - d[7][j];
+    const dev_pk16 b0 = a0 + a2, b1 = a1 + a3, b2 = a0 - a2, b3 = a1 - a3, b4 = a4 + a6, b5 = a5 + a7, b6 = a4 - a6, b7 = a5 - a7;
+    sum += dev_absmax(b0 + b1) + dev_absmax(b0 - b1) + dev_absmax(b2 + b3) + dev_absmax(b2 - b3);
+    sum += dev_absmax(b4 + b5) + dev_absmax(b4 - b5) + dev_absmax(b6 + b7) + dev_absmax(b6 - b7);
+  }
+  return 2 * sum;
+}
+template <int N> __global__ void __launch_bounds__(256) dev_satd_kernel(const u8 *a, const u8 *b, const long tiles, u32 *out)
+{
+  constexpr int TW = N / 8, T = TW * TW;  // tiles per block row / per block
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  u32 v = 0;
+  if (t < tiles) {
+    const long blk = t / T;
+    const int tt = (int)(t % T), ty = tt / TW, tx = tt % TW;
+    const long base = blk * (N * N) + (long)(ty * 8) * N + tx * 8;
+    dev_pk16 d[8][4];
+    for (int r = 0; r < 8; r++) {
+      const uint2 x = *reinterpret_cast<const uint2 *>(a + base + r * N), y = *reinterpret_cast<const uint2 *>(b + base + r * N);
+      dev_diff_row(x, y, d[r]);
+    }
+    v = (dev_satd8_regs(d) + 2) >> 2;
+  }
+  if (T <= 64) {
+    v = group_sum<(T <= 64 ? T : 64)>(v);
+    if ((threadIdx.x & (T - 1)) == 0 && t < tiles) out[t / T] = v;
+  }
+}
+__global__ void __launch_bounds__(256) dev_satd4_kernel(const u8 *a, const u8 *b, const long blocks, u32 *out)
+{
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= blocks) return;
+  const uint4 x = reinterpret_cast<const uint4 *>(a)[i], y = reinterpret_cast<const uint4 *>(b)[i];
+  u8 pa[16], pb[16];
+  const u32 xs[4] = { x.x, x.y, x.z, x.w }, ys[4] = { y.x, y.y, y.z, y.w };
+  for (int k = 0; k < 16; k++) { pa[k] = (u8)(xs[k >> 2] >> (8 * (k & 3))); pb[k] = (u8)(ys[k >> 2] >> (8 * (k & 3))); }
+  out[i] = satd4(pa, 4, pb, 4);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 16- and 32-point DCT / IDCT on the matrix cores: one wavefront per block, both passes chained through registers.
+// With T the transform matrix (Tables::dct_h, exact in binary16) and X the n x n input:
+//   forward: D0^T = X T^T, K = T D0^T   -> out = K       (dct-generic.c partial_butterfly_*, intermediate wraps to int16)
+//   inverse: U = X^T T,    O = U^T T    -> out = O       (partial_butterfly_inverse_*, both stages clip to int16)
+// The accumulator layout of v_mfma (lane = column, registers = 4 consecutive rows per k-step) is the B operand layout of
+// the next product and, read as A, the transposed matrix, so the first result feeds the second product directly.
+// Exactness: 16-bit operands are split x = 256 (x >> 8) + (x & 255); every operand is then an integer binary16 holds
+// exactly, products are exact in binary32 and all partial sums stay below 32 * 90 * 255 < 2^24.
+typedef _Float16 dev_half4 __attribute__((ext_vector_type(4)));
+typedef float dev_float4 __attribute__((ext_vector_type(4)));
+typedef float dev_float16 __attribute__((ext_vector_type(16)));
+
+template <int N> struct DevMma;
+template <> struct DevMma<16> {  // v_mfma_f32_16x16x16_f16
+  typedef dev_float4 Acc;
+  static constexpr int NREG = 4, STEPS = 1;
+  static __device__ __forceinline__ int idx(int lane) { return lane & 15; }
+  static __device__ __forceinline__ int k0(int lane, int) { return 4 * (lane >> 4); }
+  static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
+  static __device__ __forceinline__ Acc mma(dev_half4 a, dev_half4 b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+};
+template <> struct DevMma<32> {  // v_mfma_f32_32x32x8_f16
+  typedef dev_float16 Acc;
+  static constexpr int NREG = 16, STEPS = 4;
+  static __device__ __forceinline__ int idx(int lane) { return lane & 31; }
+  static __device__ __forceinline__ int k0(int lane, int step) { return 8 * step + 4 * (lane >> 5); }
+  static __device__ __forceinline__ int row(int lane, int r) { return 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3); }
+  static __device__ __forceinline__ Acc mma(dev_half4 a, dev_half4 b, Acc c) { return __builtin_amdgcn_mfma_f32_32x32x8f16(a, b, c, 0, 0, 0); }
+};
+
+// out[] = (register matrix v, accumulator layout) x (table) when table_is_a == false, (table) x (register matrix) otherwise
+template <int N> __device__ __forceinline__ void dev_product(const int *v, const u16 *table, bool table_is_a, int lane, int *out)
+{
+  typedef DevMma<N> M;
+  typename M::Acc lo = { 0 }, hi = { 0 };
+  for (int st = 0; st < M::STEPS; st++) {
+    const dev_half4 tv = *reinterpret_cast<const dev_half4 *>(table + M::idx(lane) * N + M::k0(lane, st));
+    dev_half4 dl, dh;
+    for (int i = 0; i < 4; i++) { const int x = v[4 * st + i]; dh[i] = (_Float16)(x >> 8); dl[i] = (_Float16)(x & 255); }
+    if (table_is_a) { lo = M::mma(tv, dl, lo); hi = M::mma(tv, dh, hi); }
+    else { lo = M::mma(dl, tv, lo); hi = M::mma(dh, tv, hi); }
+  }
+  for (int r = 0; r < M::NREG; r++) out[r] = (int)hi[r] * 256 + (int)lo[r];
+}
+
+template <int N> __global__ void __launch_bounds__(256) dev_transform_mfma_kernel(const i16 *in, i16 *out, const int count, const int inverse, const Tables *tb)
+{
+  typedef DevMma<N> M;
+  constexpr int L2 = N == 16 ? 4 : 5;
+  const int lane = threadIdx.x & 63;
+  const long blk = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blk >= count) return;  // wavefront-uniform
+  const i16 *x = in + blk * (N * N);
+  i16 *o = out + blk * (N * N);
+  const int col = M::idx(lane);
+  int v[M::NREG], t[M::NREG];
+  if (!inverse) {
+    // A operand = rows of X: lane <-> row, four consecutive k per step
+    for (int st = 0; st < M::STEPS; st++) {
+      const short4 q = *reinterpret_cast<const short4 *>(x + col * N + M::k0(lane, st));
+      v[4 * st] = q.x; v[4 * st + 1] = q.y; v[4 * st + 2] = q.z; v[4 * st + 3] = q.w;
+    }
+    dev_product<N>(v, tb->dct_h[L2 - 4][0], false, lane, t);   // D0^T = X T^T
+    { const int shift = L2 - 1, add = 1 << (shift - 1); for (int r = 0; r < M::NREG; r++) v[r] = (int)(i16)((t[r] + add) >> shift); }
+    dev_product<N>(v, tb->dct_h[L2 - 4][0], true, lane, t);    // K = T D0^T
+    { const int shift = L2 + 6, add = 1 << (shift - 1); for (int r = 0; r < M::NREG; r++) o[M::row(lane, r) * N + col] = (i16)((t[r] + add) >> shift); }
+  } else {
+    // A operand = rows of X^T: lane <-> column of X, four consecutive rows per step (lane-contiguous 2-byte loads)
+    for (int st = 0; st < M::STEPS; st++)
+      for (int i = 0; i < 4; i++) v[4 * st + i] = x[(M::k0(lane, st) + i) * N + col];
+    dev_product<N>(v, tb->dct_h[L2 - 4][1], false, lane, t);   // U = X^T T
+    for (int r = 0; r < M::NREG; r++) v[r] = iclip(-32768, 32767, (t[r] + 64) >> 7);
+    dev_product<N>(v, tb->dct_h[L2 - 4][1], false, lane, t);   // O = U^T T  (the accumulator read as A is U^T)
+    for (int r = 0; r < M::NREG; r++) o[M::row(lane, r) * N + col] = (i16)iclip(-32768, 32767, (t[r] + 2048) >> 12);
+  }
+}
+
+struct DevTimer { hipEvent_t e0 = nullptr, e1 = nullptr; };
+static DevTimer &dev_timer() { static thread_local DevTimer t; return t; }
+
+}  // namespace kvz
+
+extern "C" {
+
+void *kvz_hip_dev_alloc(size_t bytes)
+{
+  kvz::runtime_init(-1);
+  void *p = nullptr;
+  KVZ_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1));
+  return p;
+}
+void kvz_hip_dev_free(void *p) { if (p) KVZ_HIP_CHECK(hipFree(p)); }
+void kvz_hip_dev_upload(void *d, const void *h, size_t n)
+{
+  KVZ_HIP_CHECK(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, be().stream));
+  KVZ_HIP_CHECK(hipStreamSynchronize(be().stream));
+}
+void kvz_hip_dev_download(void *h, const void *d, size_t n)
+{
+  KVZ_HIP_CHECK(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, be().stream));
+  KVZ_HIP_CHECK(hipStreamSynchronize(be().stream));
+}
+void kvz_hip_dev_sync(void) { KVZ_HIP_CHECK(hipStreamSynchronize(be().stream)); }
+void kvz_hip_dev_timer_start(void)
+{
+  kvz::DevTimer &t = kvz::dev_timer();
+  if (!t.e0) { KVZ_HIP_CHECK(hipEventCreate(&t.e0)); KVZ_HIP_CHECK(hipEventCreate(&t.e1)); }
+  KVZ_HIP_CHECK(hipEventRecord(t.e0, be().stream));
+}
+float kvz_hip_dev_timer_stop(void)
+{
+  kvz::DevTimer &t = kvz::dev_timer();
+  float ms = 0;
+  KVZ_HIP_CHECK(hipEventRecord(t.e1, be().stream));
+  KVZ_HIP_CHECK(hipEventSynchronize(t.e1));
+  KVZ_HIP_CHECK(hipEventElapsedTime(&ms, t.e0, t.e1));
+  return ms;
+}
+
+#define KVZ_DEV_LAUNCH(kernel, items, ...)                                                                        \
+  do {                                                                                                            \
+    const long items_ = (items);                                                                                  \
+    if (items_ > 0) {                                                                                             \
+      hipLaunchKernelGGL(kernel, dim3((unsigned)((items_ + 255) / 256)), dim3(256), 0, be().stream, __VA_ARGS__); \
+      KVZ_HIP_CHECK(hipGetLastError());                                                                           \
+    }                                                                                                             \
+  } while (0)
+
+void kvz_hip_dev_sad_nxn(int n, const uint8_t *a, const uint8_t *b, int count, uint32_t *out)
+{
+  const long chunks = (long)count * n * n / 16;
+  const uint4 *pa = reinterpret_cast<const uint4 *>(a), *pb = reinterpret_cast<const uint4 *>(b);
+  switch (n) {
+  case 8: KVZ_DEV_LAUNCH(kvz::dev_sad_kernel<8>, chunks, pa, pb, chunks, out); break;
+  case 16: KVZ_DEV_LAUNCH(kvz::dev_sad_kernel<16>, chunks, pa, pb, chunks, out); break;
+  case 32: KVZ_DEV_LAUNCH(kvz::dev_sad_kernel<32>, chunks, pa, pb, chunks, out); break;
+  case 64:
+    KVZ_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)count * sizeof(uint32_t), be().stream));
+    KVZ_DEV_LAUNCH(kvz::dev_sad_kernel<64>, chunks, pa, pb, chunks, out);
+    break;
+  default: fprintf(stderr, "kvz_hip_dev_sad_nxn: unsupported n=%d\n", n); abort();
+  }
+}
+
+void kvz_hip_dev_satd_nxn(int n, const uint8_t *a, const uint8_t *b, int count, uint32_t *out)
+{
+  const long tiles = n >= 8 ? (long)count * (n / 8) * (n / 8) : count;
+  switch (n) {
+  case 4: KVZ_DEV_LAUNCH(kvz::dev_satd4_kernel, tiles, a, b, tiles, out); break;
+  case 8: KVZ_DEV_LAUNCH(kvz::dev_satd_kernel<8>, tiles, a, b, tiles, out); break;
+  case 16: KVZ_DEV_LAUNCH(kvz::dev_satd_kernel<16>, tiles, a, b, tiles, out); break;
+  case 32: KVZ_DEV_LAUNCH(kvz::dev_satd_kernel<32>, tiles, a, b, tiles, out); break;
+  case 64: KVZ_DEV_LAUNCH(kvz::dev_satd_kernel<64>, tiles, a, b, tiles, out); break;
+  default: fprintf(stderr, "kvz_hip_dev_satd_nxn: unsupported n=%d\n", n); abort();
+  }
+}
+
+void kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *out, int count, int use_matrix_cores)
+{
+  static const int sizes[5] = { 4, 8, 16, 32, 4 };
+  const int inverse = kind >= KVZ_HIP_IDCT_4, idx = inverse ? kind - KVZ_HIP_IDCT_4 : kind, n = sizes[idx];
+  if (use_matrix_cores && (n == 16 || n == 32) && idx != 4) {
+    const long threads = ((long)count + 3) / 4 * 256;
+    if (n == 16) KVZ_DEV_LAUNCH(kvz::dev_transform_mfma_kernel<16>, threads, in, out, count, inverse, kvz::device_tables());
+    else KVZ_DEV_LAUNCH(kvz::dev_transform_mfma_kernel<32>, threads, in, out, count, inverse, kvz::device_tables());
+    return;
+  }
+  if (!tmp) { fprintf(stderr, "kvz_hip_dev_transform: the scalar path needs tmp\n"); abort(); }
+  A::transform_dev(be(), kind, 8, in, tmp, out, count);
+}
+
+void kvz_hip_dev_angular_pred(int log2_width, int mode, const uint8_t *ref_above, const uint8_t *ref_left, int count, uint8_t *out)
+{
+  const int w = 1 << log2_width;
+  be().run(kvz::IntraPredOp{ 3 + mode, log2_width, nullptr, ref_above, ref_left, 2 * w + 1, out }, count * w * w);
+}
+
+}  // extern "C"

@@ -143,3 +143,4 @@ unsigned long long kvz_hip_call_count(void) { return kvz::runtime().calls.load()
 
 // ---- batched, device-resident path (include/kvz_hip_batch.h) ------------------------------------------------------
 #include "kvz_batch.hpp"
+#include "kvz_dev.hpp"

@@ -476,6 +476,7 @@ struct IntraPredOp {
     const u8 *t = above + blk * ref_bstride, *l = left + blk * ref_bstride;
     u8 v;
     if (kind == 0) v = angular_pixel(modes[blk], x, y, t, l);
+    else if (kind >= 3) v = angular_pixel(kind - 3, x, y, t, l);  // one mode (kind - 3) for every block of the batch
     else if (kind == 1) v = planar_pixel(log2w, x, y, t, l);
     else v = filtered_dc_pixel(dc_value(log2w, t, l), x, y, t, l);
     dst[item] = v;

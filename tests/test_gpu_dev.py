@@ -1,0 +1,98 @@
+"""Parity of the device-resident batch entry points (include/kvz_hip_dev.h) with the oracle, block by block, bit-exact."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import devapi
+import flatapi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import kvazaar_amd
+    return devapi.Dev(kvazaar_amd.load_library())
+
+
+def blocks(rng, n, count, kind):
+    if kind == "noise":
+        return rng.integers(0, 256, (count, n * n), dtype=np.uint8)
+    if kind == "extreme":
+        return rng.choice(np.array([0, 255], dtype=np.uint8), (count, n * n))
+    base = rng.integers(0, 256, (count, 1), dtype=np.int32) + np.arange(n * n, dtype=np.int32)[None, :] % n  # speed_tests.c style gradient
+    return np.clip(base, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("n", [8, 16, 32, 64])
+@pytest.mark.parametrize("cost", ["sad", "satd"])
+def test_dev_cost_nxn(oracle, dev, cost, n):
+    rng = np.random.default_rng(100 + n)
+    count = 333  # not a multiple of anything: exercises the ragged last workgroup
+    for kind in ("noise", "extreme", "gradient"):
+        a, b = blocks(rng, n, count, kind), blocks(rng, n, count, "noise")
+        da, db, do = dev.put(a), dev.put(b), dev.empty(4 * count)
+        getattr(dev.lib, f"kvz_hip_dev_{cost}_nxn")(n, da, db, count, do)
+        got = dev.get(do, (count,), np.uint32)
+        f = getattr(oracle, f"{cost}_nxn")
+        want = np.array([f(n, flatapi.ptr(a[i]), flatapi.ptr(b[i])) for i in range(count)], dtype=np.uint32)
+        dev.free(da, db, do)
+        assert np.array_equal(got, want), (kind, np.flatnonzero(got != want)[:8])
+
+
+def test_dev_satd_4x4(oracle, dev):
+    rng = np.random.default_rng(4)
+    count = 1001
+    a, b = blocks(rng, 4, count, "noise"), blocks(rng, 4, count, "extreme")
+    da, db, do = dev.put(a), dev.put(b), dev.empty(4 * count)
+    dev.lib.kvz_hip_dev_satd_nxn(4, da, db, count, do)
+    got = dev.get(do, (count,), np.uint32)
+    want = np.array([oracle.satd_nxn(4, flatapi.ptr(a[i]), flatapi.ptr(b[i])) for i in range(count)], dtype=np.uint32)
+    dev.free(da, db, do)
+    assert np.array_equal(got, want)
+
+
+def test_dev_empty_batch(dev):
+    dev.lib.kvz_hip_dev_sad_nxn(8, None, None, 0, None)
+    dev.lib.kvz_hip_dev_satd_nxn(16, None, None, 0, None)
+    dev.lib.kvz_hip_dev_sync()
+
+
+@pytest.mark.parametrize("name", sorted(devapi.TRANSFORM_KINDS))
+@pytest.mark.parametrize("mfma", [0, 1])
+def test_dev_transform(oracle, dev, name, mfma):
+    kind = devapi.TRANSFORM_KINDS[name]
+    n = devapi.TRANSFORM_SIZE[kind]
+    rng = np.random.default_rng(kind)
+    count = 67
+    x = np.empty((count, n * n), dtype=np.int16)
+    x[:20] = rng.integers(-255, 256, (20, n * n))            # residuals
+    x[20:40] = rng.integers(-32768, 32768, (20, n * n))      # full range: exercises the int16 wrap / clip of both passes
+    x[40:] = rng.choice(np.array([-32768, 32767, 0], dtype=np.int16), (count - 40, n * n))
+    di, dt, do = dev.put(x), dev.empty(x.nbytes), dev.empty(x.nbytes)
+    dev.lib.kvz_hip_dev_transform(kind, di, dt, do, count, mfma)
+    got = dev.get(do, x.shape, np.int16)
+    want = np.empty_like(x)
+    for i in range(count):
+        oracle.transform(kind, 8, flatapi.ptr(x[i]), flatapi.ptr(want[i]))
+    dev.free(di, dt, do)
+    assert np.array_equal(got, want), np.argwhere(got != want)[:8]
+
+
+@pytest.mark.parametrize("log2w", [2, 3, 4, 5])
+def test_dev_angular(oracle, dev, log2w):
+    rng = np.random.default_rng(log2w)
+    w, count = 1 << log2w, 50
+    above = rng.integers(0, 256, (count, 2 * w + 1), dtype=np.uint8)
+    left = rng.integers(0, 256, (count, 2 * w + 1), dtype=np.uint8)
+    left[:, 0] = above[:, 0]
+    for mode in (2, 7, 10, 18, 26, 34):
+        da, dl, do = dev.put(above), dev.put(left), dev.empty(count * w * w)
+        dev.lib.kvz_hip_dev_angular_pred(log2w, mode, da, dl, count, do)
+        got = dev.get(do, (count, w * w), np.uint8)
+        want = np.empty_like(got)
+        for i in range(count):
+            oracle.angular_pred(log2w, mode, flatapi.ptr(above[i]), flatapi.ptr(left[i]), flatapi.ptr(want[i]))
+        dev.free(da, dl, do)
+        assert np.array_equal(got, want), mode
