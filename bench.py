@@ -39,6 +39,8 @@ def pmc_traffic(args, launches):
     on this exact workload, otherwise null."""
     import glob
     best = None
+    if args.tiles:
+        return None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json"))):
         try:
             d = json.load(open(path))
@@ -104,6 +106,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-encoder", action="store_true")
+    ap.add_argument("--tiles", default="", help="COLSxROWS: strong-scaling variant (BASELINE config 5): --frames pictures in total, cut into kvazaar's "
+                                                "uniform tiles, the tiles dealt to the ranks; every tile is an independent sub-picture (SURVEY.md 8e)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -125,43 +129,72 @@ def main():
     lib = kvazaar_amd.load_library()  # raises when libkvz_hip.so is missing: no fallback
     model = cc.hip_cost_model(lib, args.qp, COEFF_WEIGHTS_QP22)
 
-    distinct = synth_frames(args.width, args.height, max(1, min(args.distinct, args.frames)), 1 + rank)
-    batch = cc.HipBatch(lib, args.width, args.height, args.frames)
-    for i in range(args.frames):
-        batch.upload(i, distinct[i % len(distinct)])
-    ctus_per_frame = lib.kvz_hip_batch_ctus_per_frame(C.c_void_p(batch.handle))
-
     from kvazaar_amd import sharding
-    for _ in range(args.warmup):
-        batch.run(model)
+    batches = []  # (HipBatch, CTUs per picture of that batch, pictures)
+    if args.tiles:
+        cols, rows = (int(v) for v in args.tiles.lower().split("x"))
+        tiles = sharding.tile_grid(args.width, args.height, cols, rows)
+        lo, hi = sharding.frames_for_rank(len(tiles), rank, world)
+        distinct = synth_frames(args.width, args.height, max(1, min(args.distinct, args.frames)), 1)  # every rank cuts the same clip
+        by_geometry = {}
+        for t in tiles[lo:hi]:
+            by_geometry.setdefault((t[2], t[3]), []).append(t)
+        for (tw, th), ts in sorted(by_geometry.items()):
+            b = cc.HipBatch(lib, tw, th, args.frames * len(ts))
+            subs = [[sharding.crop_tile(f, args.width, args.height, t) for f in distinct] for t in ts]
+            for i in range(args.frames):
+                for j in range(len(ts)):
+                    b.upload(i * len(ts) + j, subs[j][i % len(distinct)])
+            batches.append((b, lib.kvz_hip_batch_ctus_per_frame(C.c_void_p(b.handle)), args.frames * len(ts)))
+        ctus_per_frame = sum(((t[2] + 63) // 64) * ((t[3] + 63) // 64) for t in tiles)
+        job_ctus_per_step = args.frames * ctus_per_frame  # whole job, all ranks
+    else:
+        distinct = synth_frames(args.width, args.height, max(1, min(args.distinct, args.frames)), 1 + rank)
+        batch = cc.HipBatch(lib, args.width, args.height, args.frames)
+        for i in range(args.frames):
+            batch.upload(i, distinct[i % len(distinct)])
+        ctus_per_frame = lib.kvz_hip_batch_ctus_per_frame(C.c_void_p(batch.handle))
+        batches.append((batch, ctus_per_frame, args.frames))
+        job_ctus_per_step = args.frames * ctus_per_frame * world
+
     kernel_ms = []
     state = {"launches": 0}
 
     def step():
-        state["launches"] = lib.kvz_hip_intra_frames(batch.handle, C.byref(model))
-        lib.kvz_hip_batch_sync(batch.handle)
-        kernel_ms.append(batch.kernel_ms())
+        n = 0
+        for b, _, _ in batches:  # asynchronous: batches of different geometry overlap on their own streams
+            n += lib.kvz_hip_intra_frames(b.handle, C.byref(model))
+        for b, _, _ in batches:
+            lib.kvz_hip_batch_sync(b.handle)
+        state["launches"] = n
+        kernel_ms.append(sum(b.kernel_ms() for b, _, _ in batches))
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms.clear()
 
     # EXACTLY `steps` steps between (synchronize + barrier) pairs; MAX over ranks
     dt = sharding.timed_steps(step, args.steps, dist, torch.cuda.synchronize, "cuda")
     launches = state["launches"]
 
     if rank == 0:
-        total_ctus = args.frames * ctus_per_frame * args.steps * world
+        total_ctus = job_ctus_per_step * args.steps
         value = total_ctus / dt
         # dominant kernel = the CTU kernel: all launches of a step are that kernel; HIP events on the batch's own stream
-        k_ms = float(np.mean(kernel_ms))
+        k_ms = float(np.mean(kernel_ms))  # rank 0's launches
         per_launch_s = k_ms / 1e3 / launches
-        bytes_per_launch = args.frames * ctus_per_frame * BYTES_PER_CTU / launches
+        bytes_per_launch = sum(c * n for _, c, n in batches) * BYTES_PER_CTU / launches
         achieved = bytes_per_launch / per_launch_s / 1e9
         result = {
             "metric": "CTUs/s (all-intra ultrafast hot path)", "value": value, "unit": "CTUs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.tiles else "weak", "vs_baseline": None,
             "dtype": "u8/i16 (f64 RD costs)", "data": "synthetic",
             "fps": value / ctus_per_frame,
             "config": {"workload": f"{args.width}x{args.height} yuv420p 8-bit all-intra ultrafast CTU pass (kvz_hip_intra_frames), QP {args.qp}",
-                       "frames_per_gpu_per_step": args.frames, "ctus_per_frame": ctus_per_frame, "distinct_frames": len(distinct),
-                       "parallelism": f"frames sharded over {world} GPU(s), no data-path collective"},
+                       "frames_per_gpu_per_step": None if args.tiles else args.frames, "frames_per_step": args.frames if args.tiles else args.frames * world,
+                       "ctus_per_frame": ctus_per_frame, "distinct_frames": len(distinct),
+                       "parallelism": (f"--tiles {args.tiles}: tiles sharded over {world} GPU(s), no data-path collective" if args.tiles
+                                       else f"frames sharded over {world} GPU(s), no data-path collective")},
             "roofline": {"bound": "hbm", "kernel": "intra_ctu_ticket_kernel" if launches == 1 else "intra_ctu_wave_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, launches), "traffic_source": "profiles/*pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, raw counters x 1024) on this workload, else null",
                          "launches_per_step": launches,
@@ -171,7 +204,8 @@ def main():
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, distinct, model)
         print(json.dumps(result))
-    batch.close()
+    for b, _, _ in batches:
+        b.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -85,3 +85,78 @@ def test_two_rank_checksum_equals_single_process(oracle):
     [p.join(timeout=60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert got == want and dt > 0
+
+
+def test_tile_grid_matches_reference_geometry():
+    """encoder.c:383-404 uniform spacing; the 4K 4x2 split of BASELINE config 5 is 8 tiles of 15x17 CTUs"""
+    t = sharding.tile_grid(3840, 2160, 4, 2)
+    assert len(t) == 8 and all(w == 960 for _, _, w, _ in t)
+    assert [h for _, _, _, h in t] == [1088] * 4 + [1072] * 4
+    assert t[5] == (960, 1088, 960, 1072)
+    # 416x240 --tiles 2x2: 7x4 CTUs -> columns of 3 and 4 CTUs, rows of 2 and 2
+    assert sharding.tile_grid(416, 240, 2, 2) == [(0, 0, 192, 128), (192, 0, 224, 128), (0, 128, 192, 112), (192, 128, 224, 112)]
+    with pytest.raises(ValueError):
+        sharding.tile_grid(128, 128, 3, 1)
+    # a partition: every pixel in exactly one tile
+    for (w, h, c, r) in ((1920, 1080, 3, 2), (416, 240, 2, 2), (3840, 2160, 4, 2)):
+        cover = np.zeros((h, w), np.uint8)
+        for x, y, tw, th in sharding.tile_grid(w, h, c, r):
+            cover[y:y + th, x:x + tw] += 1
+        assert (cover == 1).all()
+
+
+def test_crop_and_paste_tile_round_trip():
+    w, h = 192, 128
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 256, w * h * 3 // 2, dtype=np.uint8)
+    out = np.zeros_like(frame)
+    for tile in sharding.tile_grid(w, h, 3, 2):
+        sub = sharding.crop_tile(frame, w, h, tile)
+        assert sub.size == tile[2] * tile[3] * 3 // 2
+        sharding.paste_tile(out, w, h, tile, sub)
+    assert np.array_equal(out, frame)
+
+
+def _tile_worker(rank, world, port, out):
+    """tile-sharded job: rank r runs the CTU pass on its tiles of every frame (sub-pictures), rank 0 assembles the frame"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    oracle = flatapi.load_oracle()
+    model = _model()
+    w, h = 128, 128
+    frame = cc.yuv_frames(w, h, 1, 77, "small")[0]
+    tiles = sharding.tile_grid(w, h, 2, 2)
+    lo, hi = sharding.frames_for_rank(len(tiles), rank, world)
+    rec = np.zeros(w * h * 3 // 2, dtype=np.uint8)
+    for t in tiles[lo:hi]:
+        o = cc.run_oracle(oracle, model, t[2], t[3], sharding.crop_tile(frame, w, h, t))
+        sharding.paste_tile(rec, w, h, t, o["rec"])
+    total = torch.from_numpy(rec.astype(np.int32))
+    dist.all_reduce(total, op=dist.ReduceOp.SUM)  # host-side gather of the tiles (disjoint supports)
+    if rank == 0:
+        out.put(total.numpy().astype(np.uint8).tobytes())
+    dist.destroy_process_group()
+
+
+def test_two_rank_tile_sharding_equals_single_process(oracle):
+    w, h = 128, 128
+    frame = cc.yuv_frames(w, h, 1, 77, "small")[0]
+    model = _model()
+    want = np.zeros(w * h * 3 // 2, dtype=np.uint8)
+    for t in sharding.tile_grid(w, h, 2, 2):
+        sharding.paste_tile(want, w, h, t, cc.run_oracle(oracle, model, t[2], t[3], sharding.crop_tile(frame, w, h, t))["rec"])
+    # tiles really are independent pictures: the tiled reconstruction differs from the untiled one only because prediction stops at tile edges
+    untiled = cc.run_oracle(oracle, model, w, h, frame)["rec"]
+    assert np.array_equal(want[:64 * w].reshape(64, w)[:, :64], untiled[:64 * w].reshape(64, w)[:, :64])  # first tile == first CTU of the frame
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tile_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = q.get(timeout=120)
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert got == want.tobytes()
