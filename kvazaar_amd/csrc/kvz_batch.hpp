@@ -19,7 +19,7 @@ namespace kvz {
 #define KVZ_CTU_VGPR_ATTR
 #endif
 #ifndef KVZ_CTU_WAVES_PER_EU
-#define KVZ_CTU_WAVES_PER_EU 3  /* 6 workgroups of 128 lanes per CU (LDS ~25 KB each) = 3 wavefronts per SIMD */
+#define KVZ_CTU_WAVES_PER_EU 4  /* 8 workgroups of 128 lanes per CU (LDS just under 20 KB each) = 4 wavefronts per SIMD, 128 VGPRs */
 #endif
 __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) intra_ctu_wave_kernel(const CtuFrames F, const kvz_hip_intra_cost_model model, const Tables *tb,
                                                                         const int wave, const int y_min, const int n_diag)

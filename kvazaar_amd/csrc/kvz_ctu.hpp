@@ -30,9 +30,9 @@
 
 namespace kvz {
 
-// Lanes per CTU.  Measured on MI355X (gpurun_out sweeps, 1080p): with the ~25 KB LDS footprint six workgroups fit a CU;
-// two wavefronts per CTU (168 VGPRs each, three wavefronts per SIMD) beat four (80-96 VGPRs, spills, and twice the
-// wavefronts that only skip through the lane-starved stages).  Any multiple of 64 works.
+// Lanes per CTU.  Measured on MI355X (profiles/experiments, 1080p): two wavefronts per CTU beat four (twice the
+// wavefronts that only skip through the lane-starved stages, half the registers each); with the LDS footprint just
+// under 20 KB eight such workgroups fit a CU = four wavefronts per SIMD at 128 VGPRs.  Any multiple of 64 works.
 #ifndef KVZ_CTU_THREADS
 #define KVZ_CTU_THREADS 128
 #endif
@@ -222,7 +222,7 @@ struct CtuFrames {
 #define KVZ_BORDER_BYTES 384
 
 struct CtuShared {
-  u8 org[6144];              // Y 64x64 | U 32x32 | V 32x32
+  u8 org[1536];              // source pixels of the 32x32 quadrant being searched: Y 32x32 | U 16x16 | V 16x16 (load_org())
   // Reconstruction.  kvazaar keeps one full lcu_t per depth (search.c:103-122); what those copies hold at any time is
   // (a) the pixels already decided, identical in every level that can see them, plus (b) one candidate per depth for the
   // CU being tried.  So: one decided picture + one candidate buffer per depth, sized to that depth's CU.
@@ -233,8 +233,8 @@ struct CtuShared {
   unsigned long long prof_acc[32];  // [category] cycles, [KVZ_P_COUNT + category] marks
 #endif
   CtuCu cu[4][64];
-  u8 ref[3][2][132];         // [plane][0 top / 1 left][2w+1]
-  u8 fref[2][132];           // filtered luma refs
+  u8 ref[3][2][68];          // [plane][0 top / 1 left][2w+1], w <= 32
+  u8 fref[2][68];            // filtered luma refs
   // Transform scratch, two buffers of Y | U | V int16.  Only a 32x32 transform set (the depth-0 / depth-1 merges) needs
   // the full 2 x 1536 entries, and while one of those runs everything the search of 16x16 / 8x8 CUs keeps is dead -- so
   // those buffers live in the upper part of the same storage; smaller sets use the first 2 x 384 entries (tbuf()).
@@ -341,6 +341,12 @@ struct CtuProgram {
       v.bias[2] = v.bias[1] + 64;
     }
     return v;
+  }
+  // Source pixel at plane-local CTU coordinates (inside the quadrant load_org() staged); rows are 32 >> sh apart
+  KVZ_DEV const u8 *org_at(int c, int pxl, int pyl) const
+  {
+    const int sh = c ? 1 : 0;
+    return s->org + (c == 0 ? 0 : (c == 1 ? 1024 : 1280)) + (pyl - (a1y >> sh)) * (32 >> sh) + pxl - (a1x >> sh);
   }
   KVZ_DEV static unsigned zorder(int x, int y)  // cu.h:385-421
   {
@@ -572,8 +578,8 @@ struct CtuProgram {
     const int disp = s->mode_disp[mode];
     const int p0 = vertical ? bx : by, q0 = vertical ? by : bx;  // block origin along / across the main reference
     const u8 *mr = s->mref[mode - 2] + KVZ_MREF_ORG + p0 + 1;
-    const u8 *org = vertical ? s->org + (yl + by) * 64 + xl + bx : s->org_t + bx * w + by;
-    const int ostride = vertical ? 64 : w;
+    const u8 *org = vertical ? org_at(0, xl + bx, yl + by) : s->org_t + bx * w + by;
+    const int ostride = vertical ? 32 : w;
     const u8 *side = vertical ? s->ref[0][1] : s->ref[0][0];  // intra.c:207-219: modes 10 / 26 use the unfiltered references
     const bool edge = disp == 0 && p0 == 0;
     Pk16 d[8][4];
@@ -647,7 +653,7 @@ struct CtuProgram {
       if (log2w == 3) build_mref<3>(tid); else build_mref<4>(tid);
       for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) {
         const int ex = e >> log2w, ey = e & (w - 1);
-        s->org_t[e] = s->org[(yl + ey) * 64 + xl + ex];
+        s->org_t[e] = *org_at(0, xl + ex, yl + ey);
       }
       for (int i = tid; i < 2 * w * w; i += KVZ_CTU_THREADS) {  // planar and DC
         const int mode = i >> (2 * log2w), e = i & (w * w - 1);
@@ -673,7 +679,7 @@ struct CtuProgram {
       // they land on another wavefront than the angular lanes
       for (int t = KVZ_CTU_THREADS - 1 - tid; t < 2 * nblk * 8; t += KVZ_CTU_THREADS) {
         const int col = t & 7, mb = t >> 3, mode = mb >> lb, b = mb & (nblk - 1), bx = (b & ((w >> 3) - 1)) * 8, by = (b >> (log2w - 3)) * 8;
-        const u32 v = satd8_column(s->pred + mode * 256 + by * w + bx, w, s->org + (yl + by) * 64 + xl + bx, 64, col);
+        const u32 v = satd8_column(s->pred + mode * 256 + by * w + bx, w, org_at(0, xl + bx, yl + by), 32, col);
         KVZ_LDS_ADD(&s->satd_raw[mode][b], v);
       }
     }
@@ -784,13 +790,12 @@ struct CtuProgram {
       for (int c = 0; c < 3; c++) {
         const int l2 = tu_log2(t, c);
         if (!l2) continue;
-        const int w = 1 << l2, sh = c ? 1 : 0, lw = 64 >> sh;
+        const int w = 1 << l2, sh = c ? 1 : 0;
         for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) {
           const int px = e & (w - 1), py = e >> l2;
           const u8 p = predict_pixel(l2, mode, c, px, py);
-          const int o = kPlaneOff[c] + ((yl >> sh) + py) * lw + (xl >> sh) + px;
           cv.at(c, (xl >> sh) + px, (yl >> sh) + py) = p;
-          tbuf(t, 0, c)[e] = (i16)((int)s->org[o] - (int)p);
+          tbuf(t, 0, c)[e] = (i16)((int)*org_at(c, (xl >> sh) + px, (yl >> sh) + py) - (int)p);
         }
       }
     }
@@ -895,15 +900,14 @@ struct CtuProgram {
       for (int c = 0; c < 3; c++) {
         const int l2 = tu_log2(t, c);
         if (!l2) continue;
-        const int w = 1 << l2, sh = c ? 1 : 0, lw = 64 >> sh;
+        const int w = 1 << l2, sh = c ? 1 : 0;
         const bool has = s->acc[6 + c] != 0;
         u32 ssd = 0;
         for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) {
-          const int o = kPlaneOff[c] + ((yl >> sh) + (e >> l2)) * lw + (xl >> sh) + (e & (w - 1));
           u8 *rp = &cv.at(c, (xl >> sh) + (e & (w - 1)), (yl >> sh) + (e >> l2));
           int v = *rp;
           if (has) { v = iclip(0, 255, (int)(i16)(tbuf(t, 1, c)[e] + v)); *rp = (u8)v; }
-          const int d = (int)s->org[o] - v;
+          const int d = (int)*org_at(c, (xl >> sh) + (e & (w - 1)), (yl >> sh) + (e >> l2)) - v;
           ssd += (u32)(d * d);
         }
         block_add(&s->acc[c], ssd);
@@ -1039,18 +1043,28 @@ struct CtuProgram {
   }
 
   // ---------------------------------------------------------------- CTU driver
+  // Stages the source pixels of the 32x32 quadrant at (a1x, a1y), zero outside the picture (search.c:1084 FILL + :1151-1171).
+  // One thread also runs `first` (bookkeeping of the caller that nobody reads before the barrier).
+  template <class First = NoHook>
+  KVZ_DEV void load_org(First first = First())
+  {
+    KVZ_FOR_THREADS(tid) {
+      if (tid == 0) first();
+      for (int c = 0; c < 3; c++) {
+        const int sh = c ? 1 : 0, l2 = 5 - sh, qw = 1 << l2, fw = F.W >> sh, fh = F.H >> sh, ox = (cx + a1x) >> sh, oy = (cy + a1y) >> sh;
+        const u8 *src = frame_src(c);
+        u8 *dst = s->org + (c == 0 ? 0 : (c == 1 ? 1024 : 1280));
+        for (int e = tid; e < qw * qw; e += KVZ_CTU_THREADS) {
+          const int px = ox + (e & (qw - 1)), py = oy + (e >> l2);
+          dst[e] = (px < fw && py < fh) ? src[(long)py * fw + px] : 0;
+        }
+      }
+    }
+    KVZ_SYNC();
+  }
   KVZ_DEV void init()
   {
     KVZ_FOR_THREADS(tid) {
-      // source pixels, zero outside the picture (search.c:1084 FILL + :1151-1171)
-      for (int c = 0; c < 3; c++) {
-        const int sh = c ? 1 : 0, lw = 64 >> sh, fw = F.W >> sh, fh = F.H >> sh, ox = cx >> sh, oy = cy >> sh;
-        const u8 *src = frame_src(c);
-        for (int e = tid; e < lw * lw; e += KVZ_CTU_THREADS) {
-          const int px = ox + e % lw, py = oy + e / lw;
-          s->org[kPlaneOff[c] + e] = (px < fw && py < fh) ? src[(long)py * fw + px] : 0;
-        }
-      }
       for (int e = tid; e < 6144; e += KVZ_CTU_THREADS) s->dec[e] = 0;
       for (int lv = 0; lv < 4; lv++)
         if (tid < 64) { CtuCu z = { 0, 0, 0, 0, 0, 0 }; s->cu[lv][tid] = z; }
@@ -1210,6 +1224,8 @@ struct CtuProgram {
     for (int q = 0; q < 4; q++) {
       const int qx = x + (q & 1) * 32, qy = y + (q >> 1) * 32;
       TuSet t{ qx, qy, 5, 4 };
+      a1x = qx - cx; a1y = qy - cy;
+      load_org();
       recon_tus(lv, t, 1, mode);
       KVZ_FOR_THREADS(tid) { if (tid < 9) s->child_acc[q][tid] = s->acc[tid]; }
       KVZ_SYNC();
@@ -1309,10 +1325,7 @@ struct CtuProgram {
       const int x1 = cx + (q1 & 1) * 32, y1 = cy + (q1 >> 1) * 32;
       if (x1 >= F.W || y1 >= F.H) continue;  // search_cu returns 0 outside the picture
       a1x = x1 - cx; a1y = y1 - cy;
-      KVZ_FOR_THREADS(tid) {
-        if (tid == 0) { cu_header(1, x1 - cx, y1 - cy, 1); s->cost[1] = 1.7e+308; double sb = 0; sb += (double)m->split_flag[split_model(1, x1, y1, 1)][1]; double sc = 0.0; sc += sb * m->lambda; s->split_cost[1] = sc; }
-      }
-      KVZ_SYNC();
+      load_org([&]() { cu_header(1, x1 - cx, y1 - cy, 1); s->cost[1] = 1.7e+308; double sb = 0; sb += (double)m->split_flag[split_model(1, x1, y1, 1)][1]; double sc = 0.0; sc += sb * m->lambda; s->split_cost[1] = sc; });
       for (int q2 = 0; q2 < 4; q2++) search_d2(x1 + (q2 & 1) * 16, y1 + (q2 >> 1) * 16);
       if (x1 + 32 <= F.W && y1 + 32 <= F.H) try_merge(x1, y1, 1);
       const bool split_wins1 = s->split_cost[1] < s->cost[1];  // operands stay put until the barrier that ends commit()
