@@ -66,7 +66,7 @@ KVZ_DEV void block_add(u32 *dst, u32 v)
 #endif
 }
 
-#define KVZ_MREF_STRIDE 52  // q in [-16, 33] for a 16x16 CU (odd number of dwords: modes fall in different banks)
+#define KVZ_MREF_STRIDE 36  // q in [-16, 17] for a 16x16 CU (odd number of dwords: modes fall in different banks)
 #define KVZ_MREF_ORG 16
 
 // Two int16 lanes in one register (v_pk_add_i16 / v_pk_sub_i16 / v_pk_max_i16 on the device).  The 8x8 Hadamard of 9-bit
@@ -241,13 +241,15 @@ struct CtuShared {
   union {
     alignas(16) i16 tb_all[2 * 1536];
     struct {
-      u8 tb_small_pad[2332];
+      u8 tb_small_pad[3508];
       u8 c2[384];            // depth-2 candidate (16x16 CU):     Y 256 | U 64 | V 64
       u8 c3[384];            // depth-3 candidates (the four 8x8 CUs of the current 16x16)
       u8 pred[2 * 256];      // planar and DC predictions of the CU being searched (<= 16x16)
-      // Rough search, angular modes: per mode the main reference with its projected extension (intra-generic.c:97-123),
-      // already picked from the filtered / unfiltered, top / left arrays.  Entry [mode - 2][KVZ_MREF_ORG + q] is ref_main[q].
-      u8 mref[33][KVZ_MREF_STRIDE];
+      // Rough search, the 15 angular modes with a negative displacement (11..25): the main reference with its projected
+      // extension (intra-generic.c:97-123), already picked from the filtered / unfiltered, top / left arrays.  Entry
+      // [mode - 11][KVZ_MREF_ORG + q] is ref_main[q], q in [-w, w + 1] -- all such a mode can touch.  The other modes read
+      // ref / fref directly.
+      u8 mref[15][KVZ_MREF_STRIDE];
       u8 org_t[256];         // the CU's source block transposed (horizontal modes are predicted and scored transposed)
       u32 satd_raw[35][4];   // sum |Hadamard| per (mode, 8x8 block) before the per-block rounding
     };
@@ -416,25 +418,30 @@ struct CtuProgram {
     if (y > 0 && neighbour_cu(lv, x, y - 1, &n) && n.depth > depth) model++;
     return model;
   }
-  KVZ_DEV double intra_mode_syntax_bits(int lv, int x, int y, int mode) const
+  // `known_preds`: the CU's most probable modes when the caller already has them (rough_search derives the same three from
+  // the same neighbours: for the 8-aligned CU origins x >= 4 <=> x > 0 and yl > 0 <=> (y & 63) > 0)
+  KVZ_DEV double intra_mode_syntax_bits(int lv, int x, int y, int mode, const int8_t *known_preds = nullptr) const
   {
-    CtuCu lc, ac, *left = nullptr, *above = nullptr;
-    if (x > 0 && neighbour_cu(lv, x - 1, y, &lc)) left = &lc;
-    if ((y & 63) > 0 && y > 0 && neighbour_cu(lv, x, y - 1, &ac)) above = &ac;
     int8_t preds[3];
-    mpm_candidates(y, left, above, preds);
+    if (known_preds) { preds[0] = known_preds[0]; preds[1] = known_preds[1]; preds[2] = known_preds[2]; }
+    else {
+      CtuCu lc, ac, *left = nullptr, *above = nullptr;
+      if (x > 0 && neighbour_cu(lv, x - 1, y, &lc)) left = &lc;
+      if ((y & 63) > 0 && y > 0 && neighbour_cu(lv, x, y - 1, &ac)) above = &ac;
+      mpm_candidates(y, left, above, preds);
+    }
     double bits = luma_mode_bits(mode, preds);
     bits += (double)m->chroma_mode[0];
     return bits;
   }
   // encode_coding_tree.c:948-1049 kvz_mock_encode_coding_unit, intra 2Nx2N in an I slice
-  KVZ_DEV double cu_bits(int lv, int x, int y, int depth, int mode) const
+  KVZ_DEV double cu_bits(int lv, int x, int y, int depth, int mode, const int8_t *known_preds = nullptr) const
   {
     double bits = 0;
     const int w = 64 >> depth;
     if (depth != 3 && !(F.W < x + w || F.H < y + w)) bits += (double)m->split_flag[split_model(lv, x, y, depth)][0];
     if (depth == 3) bits += (double)m->part_size[1];
-    bits += intra_mode_syntax_bits(lv, x, y, mode);
+    bits += intra_mode_syntax_bits(lv, x, y, mode, known_preds);
     return bits;
   }
 
@@ -577,7 +584,13 @@ struct CtuProgram {
     const bool vertical = mode >= 18;
     const int disp = s->mode_disp[mode];
     const int p0 = vertical ? bx : by, q0 = vertical ? by : bx;  // block origin along / across the main reference
-    const u8 *mr = s->mref[mode - 2] + KVZ_MREF_ORG + p0 + 1;
+    const u8 *mr;
+    if (disp < 0) mr = s->mref[mode - 11] + KVZ_MREF_ORG;
+    else {
+      const bool filt = imin(iabs(mode - 26), iabs(mode - 10)) > (log2w == 3 ? 7 : 1);
+      mr = filt ? s->fref[vertical ? 0 : 1] : s->ref[0][vertical ? 0 : 1];
+    }
+    mr += p0 + 1;
     const u8 *org = vertical ? org_at(0, xl + bx, yl + by) : s->org_t + bx * w + by;
     const int ostride = vertical ? 32 : w;
     const u8 *side = vertical ? s->ref[0][1] : s->ref[0][0];  // intra.c:207-219: modes 10 / 26 use the unfiltered references
@@ -612,15 +625,15 @@ struct CtuProgram {
     return 2 * sum;
   }
 
-  // Extended main reference of every angular mode (see CtuShared::mref) for a 2^L2 CU.  All reads first, then all
+  // Extended main reference of the angular modes 11..25 (see CtuShared::mref) for a 2^L2 CU.  All reads first, then all
   // writes: the loop bounds are compile-time constants, so the LDS round trips of different entries overlap.
   template <int L2>
   KVZ_DEV void build_mref(int tid)
   {
-    constexpr int W = 1 << L2, NQ = 3 * W + 2, THRES = L2 == 3 ? 7 : 1, N = (33 * NQ + KVZ_CTU_THREADS - 1) / KVZ_CTU_THREADS;
+    constexpr int W = 1 << L2, NQ = 2 * W + 2, THRES = L2 == 3 ? 7 : 1, N = (15 * NQ + KVZ_CTU_THREADS - 1) / KVZ_CTU_THREADS;
     u8 vals[N];
     for (int k = 0; k < N; k++) {
-      const int i = imin(tid + k * KVZ_CTU_THREADS, 33 * NQ - 1), mode = 2 + i / NQ, q = i % NQ - W;
+      const int i = imin(tid + k * KVZ_CTU_THREADS, 15 * NQ - 1), mode = 11 + i / NQ, q = i % NQ - W;
       const bool vertical = mode >= 18, filt = imin(iabs(mode - 26), iabs(mode - 10)) > THRES;
       const u8 *top = filt ? s->fref[0] : s->ref[0][0], *left = filt ? s->fref[1] : s->ref[0][1];
       const u8 *main_ref = vertical ? top : left, *side_ref = vertical ? left : top;
@@ -629,7 +642,7 @@ struct CtuProgram {
     }
     for (int k = 0; k < N; k++) {
       const int i = tid + k * KVZ_CTU_THREADS;
-      if (i < 33 * NQ) s->mref[i / NQ][KVZ_MREF_ORG + i % NQ - W] = vals[k];
+      if (i < 15 * NQ) s->mref[i / NQ][KVZ_MREF_ORG + i % NQ - W] = vals[k];
     }
   }
 
@@ -1029,7 +1042,7 @@ struct CtuProgram {
     recon_tus(lv, t, depth, mode, true);
     KVZ_FOR_THREADS(tid) {
       if (tid == 0) {
-        const double bits = cu_bits(lv, x, y, depth, mode);
+        const double bits = cu_bits(lv, x, y, depth, mode, s->preds);
         double cost = bits * m->lambda;
         cost += leaf_rd_cost(lv, xl, yl, depth, depth, true, true);
         *out_cost = cost;
