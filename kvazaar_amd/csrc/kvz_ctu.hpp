@@ -55,14 +55,21 @@ static unsigned long long g_kvz_syncs;
 #endif
 
 // Sum of `v` over the workgroup added to the LDS word *dst.  Must be reached by every lane of the wave (uniform control
-// flow): wave64 shuffle reduction, then one LDS atomic per wave.  Integer adds, so the result does not depend on the order.
+// flow): wave64 DPP reduction, then one LDS atomic per wave.  Integer adds, so the result does not depend on the order.
 KVZ_DEV void block_add(u32 *dst, u32 v)
 {
 #ifdef KVZ_HOSTSIM
   *dst += v;
 #else
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-  if ((threadIdx.x & 63) == 0 && v) atomicAdd(dst, v);
+  // row_shr 8 / 4 / 2 / 1 within each row of 16 lanes (lanes shifted in from outside the row read 0): lane 15 of a row ends
+  // up with the row's sum; the four row sums are then picked out by lane index.  No LDS traffic, no dependent shuffles.
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+  const u32 total = (u32)(__builtin_amdgcn_readlane(x, 15) + __builtin_amdgcn_readlane(x, 31) + __builtin_amdgcn_readlane(x, 47) + __builtin_amdgcn_readlane(x, 63));
+  if ((threadIdx.x & 63) == 0 && total) atomicAdd(dst, total);
 #endif
 }
 
