@@ -229,7 +229,7 @@ struct CtuFrames {
 #define KVZ_BORDER_BYTES 384
 
 struct CtuShared {
-  u8 org[1536];              // source pixels of the 32x32 quadrant being searched: Y 32x32 | U 16x16 | V 16x16 (load_org())
+  alignas(8) u8 org[1536];   // source pixels of the 32x32 quadrant being searched: Y 32x32 | U 16x16 | V 16x16 (load_org())
   // Reconstruction.  kvazaar keeps one full lcu_t per depth (search.c:103-122); what those copies hold at any time is
   // (a) the pixels already decided, identical in every level that can see them, plus (b) one candidate per depth for the
   // CU being tried.  So: one decided picture + one candidate buffer per depth, sized to that depth's CU.
@@ -257,7 +257,7 @@ struct CtuShared {
       // [mode - 11][KVZ_MREF_ORG + q] is ref_main[q], q in [-w, w + 1] -- all such a mode can touch.  The other modes read
       // ref / fref directly.
       u8 mref[15][KVZ_MREF_STRIDE];
-      u8 org_t[256];         // the CU's source block transposed (horizontal modes are predicted and scored transposed)
+      alignas(8) u8 org_t[256];  // the CU's source block transposed (horizontal modes are predicted and scored transposed)
       u32 satd_raw[35][4];   // sum |Hadamard| per (mode, 8x8 block) before the per-block rounding
     };
   };
@@ -606,7 +606,9 @@ struct CtuProgram {
     for (int r = 0; r < 8; r++) {
       const int qa = q0 + r + 1, delta = qa * disp, di = delta >> 5, df = delta & 31;
       const u8 *m = mr + di;
-      const u8 *o = org + r * ostride;
+      // the eight source pixels of the row in one 8-byte load (block origins are multiples of 8 in 8-byte aligned arrays)
+      unsigned long long ow;
+      __builtin_memcpy(&ow, __builtin_assume_aligned(org + r * ostride, 8), 8);
       int v[8], a = m[0];
       for (int k = 0; k < 8; k++) {
         const int b = m[k + 1];
@@ -614,7 +616,7 @@ struct CtuProgram {
         a = b;
       }
       if (edge) v[0] = iclip(0, 255, v[0] + (((int)side[qa] - (int)side[0]) >> 1));
-      for (int j = 0; j < 4; j++) d[r][j] = pk_make(v[2 * j] - (int)o[2 * j], v[2 * j + 1] - (int)o[2 * j + 1]);
+      for (int j = 0; j < 4; j++) d[r][j] = pk_make(v[2 * j] - (int)((ow >> (16 * j)) & 0xff), v[2 * j + 1] - (int)((ow >> (16 * j + 8)) & 0xff));
     }
     for (int r = 0; r < 8; r++) {  // along the rows: columns k and k + 4, then k and k + 2 (k and k + 1 is the folded stage)
       const Pk16 a0 = pk_add(d[r][0], d[r][2]), a1 = pk_add(d[r][1], d[r][3]), a2 = pk_sub(d[r][0], d[r][2]), a3 = pk_sub(d[r][1], d[r][3]);
