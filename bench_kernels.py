@@ -101,6 +101,23 @@ def main():
         report(f"angular_{w}x{w}", w, count, ms, (4 * w + 2) + w * w)
         dev.free(da, dl, do)
 
+    # deblocking of whole 1080p frames (kvz_hip_dev_deblock_frames): every sample is read and (for the filtered ones) written once
+    # per direction at most; algorithmic bytes = read + write of the picture = 2 * 1.5 * W * H
+    import ctypes as C
+    w, h = 1920, 1080
+    nfr = max(8, args.batch_ctus // 510 // 2)
+    rng = np.random.default_rng(7)
+    yy, xx = np.mgrid[0:h, 0:w]
+    luma = ((xx // 8 + yy // 8) % 2 * 6 + 100 + rng.integers(-1, 2, (h, w))).astype(np.uint8)
+    frame = np.concatenate([luma.reshape(-1), np.full(w * h // 2, 128, np.uint8)])
+    depth = rng.integers(1, 4, (h // 8, w // 8), dtype=np.uint8)
+    dfr, ddp = dev.put(np.tile(frame, (nfr, 1))), dev.put(np.tile(depth.reshape(-1), (nfr, 1)))
+    dev.lib.kvz_hip_dev_deblock_frames.restype = None
+    dev.lib.kvz_hip_dev_deblock_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_deblock_frames(dfr, w, h, nfr, ddp, 32, 0, 0), args.reps, args.warmup)
+    report("deblock_1080p_frame", 0, nfr, ms, 2 * (w * h * 3 // 2), {"path": "4 launches: luma / chroma x vertical / horizontal edges", "fps": round(nfr / (ms * 1e-3))})
+    dev.free(dfr, ddp)
+
     print(json.dumps({"summary": "bench_kernels", "batch_ctus": args.batch_ctus, "reps": args.reps, "kernels": len(results)}))
 
 

@@ -49,6 +49,12 @@ int   kvz_hip_batch_ctus_per_frame(const kvz_hip_batch *b);
 /* Developer aid: per-stage shader-cycle counters of a -DKVZ_CTU_PROFILE build of the library (zeros otherwise). */
 int   kvz_hip_batch_profile(kvz_hip_batch *b, unsigned long long *out, int n);
 
+/* Deblocks the batch's reconstruction in place on the batch's stream (kvz_filter_deblock_lcu, filter.c:783, over every LCU of
+ * every frame; see kvz_hip_dev_deblock_frames in kvz_hip_dev.h) using the CU depths the last kvz_hip_intra_frames() left.
+ * kvazaar runs it right after an LCU's reconstruction (encoderstate.c:669-671); downloads after this call return the
+ * deblocked picture.  The next kvz_hip_intra_frames() overwrites the reconstruction. */
+void kvz_hip_batch_deblock(kvz_hip_batch *b, int qp, int beta_offset_div2, int tc_offset_div2);
+
 /* Frozen-context cost model of an I slice at `qp` (kvz_hip_intra_cost_model): HEVC context init values
  * (context.c:96-134), kvz_ctx_init (context.c:202-213), the HM entropy table (rdo.c:69-80), lambda of
  * rate_control.c:678-691.  coeff_weights = kvz_fast_coeff_get_weights(state) of the encoder (fast_coeff_cost.c:84-88). */

@@ -43,6 +43,14 @@ void kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *o
  * into out + i * w * w.  (4w + 2) + w^2 bytes per block. */
 void kvz_hip_dev_angular_pred(int log2_width, int mode, const uint8_t *ref_above, const uint8_t *ref_left, int count, uint8_t *out);
 
+/* Deblocking of all-intra, constant-QP pictures in place: kvz_filter_deblock_lcu (filter.c:783) over every LCU of every
+ * frame.  frames = n_frames x [Y | U | V] tight planar 4:2:0 (the batch layout), cu_depth = n_frames x [H/8][W/8] CU depths
+ * as the CTU pass returns them; beta / tc offsets are cfg.deblock_beta / cfg.deblock_tc (cfg.c: 0, 0).  Not a strategy in
+ * the reference: kvazaar calls it per LCU from encoder_state_worker_encode_lcu_search
+ * (encoderstate.c:669-671) between reconstruction and SAO.  ~3 w h bytes read and written per frame. */
+void kvz_hip_dev_deblock_frames(uint8_t *frames, int width, int height, int n_frames, const uint8_t *cu_depth, int qp, int beta_offset_div2,
+                                int tc_offset_div2);
+
 #ifdef __cplusplus
 }
 #endif

@@ -193,6 +193,133 @@ template <int N> __global__ void __launch_bounds__(256) dev_transform_mfma_kerne
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Deblocking of all-intra, constant-QP pictures in place (filter.c:783 kvz_filter_deblock_lcu over every LCU): picture-level
+// order -- every vertical edge, then every horizontal edge on the result (H.265 8.7.2; equal to kvazaar's LCU order because
+// edges of one direction lie 8 samples apart and a filter touches at most 3 / reads 4 samples on either side).  One lane per
+// 4-sample part of an edge; lanes run along the direction that makes a wavefront's loads contiguous (x fastest).  Every CU
+// is intra: boundary strength 2 wherever an edge is filtered at all (filter.c:418-421).
+struct DeblockGeom { int W, H, beta, tc, tc_c; long frame_bytes; const u8 *cu_depth; };
+
+__device__ __forceinline__ bool deblock_edge_on(const DeblockGeom &g, long frame, int x, int y, bool vertical)  // filter.c:202-216
+{
+  const int w8 = g.W >> 3, d = g.cu_depth[frame * (long)w8 * (g.H >> 3) + (long)(y >> 3) * w8 + (x >> 3)];
+  const int tu_w = 64 >> (d ? d : 1);
+  return ((vertical ? x : y) & (tu_w - 1)) == 0;
+}
+// b[i][k]: sample k (edge between 3 and 4) of line i (filter.c:386-561)
+__device__ __forceinline__ void deblock_luma_lines(int b[4][8], int beta, int tc)
+{
+  const int dp0 = iabs(b[0][1] - 2 * b[0][2] + b[0][3]), dq0 = iabs(b[0][4] - 2 * b[0][5] + b[0][6]);
+  const int dp3 = iabs(b[3][1] - 2 * b[3][2] + b[3][3]), dq3 = iabs(b[3][4] - 2 * b[3][5] + b[3][6]);
+  const int dp = dp0 + dp3, dq = dq0 + dq3;
+  if (dp + dq >= beta) return;
+  const bool strong = 2 * (dp0 + dq0) < (beta >> 2) && 2 * (dp3 + dq3) < (beta >> 2) &&
+                      iabs(b[0][3] - b[0][4]) < ((5 * tc + 1) >> 1) && iabs(b[3][3] - b[3][4]) < ((5 * tc + 1) >> 1) &&
+                      iabs(b[0][0] - b[0][3]) + iabs(b[0][4] - b[0][7]) < (beta >> 3) && iabs(b[3][0] - b[3][3]) + iabs(b[3][4] - b[3][7]) < (beta >> 3);
+  const int side = (beta + (beta >> 1)) >> 3;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int m0 = b[i][0], m1 = b[i][1], m2 = b[i][2], m3 = b[i][3], m4 = b[i][4], m5 = b[i][5], m6 = b[i][6], m7 = b[i][7];
+    if (strong) {
+      b[i][1] = iclip(m1 - 2 * tc, m1 + 2 * tc, (2 * m0 + 3 * m1 + m2 + m3 + m4 + 4) >> 3);
+      b[i][2] = iclip(m2 - 2 * tc, m2 + 2 * tc, (m1 + m2 + m3 + m4 + 2) >> 2);
+      b[i][3] = iclip(m3 - 2 * tc, m3 + 2 * tc, (m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4) >> 3);
+      b[i][4] = iclip(m4 - 2 * tc, m4 + 2 * tc, (m2 + 2 * m3 + 2 * m4 + 2 * m5 + m6 + 4) >> 3);
+      b[i][5] = iclip(m5 - 2 * tc, m5 + 2 * tc, (m3 + m4 + m5 + m6 + 2) >> 2);
+      b[i][6] = iclip(m6 - 2 * tc, m6 + 2 * tc, (m3 + m4 + m5 + 3 * m6 + 2 * m7 + 4) >> 3);
+    } else {
+      int delta = (9 * (m4 - m3) - 3 * (m5 - m2) + 8) >> 4;
+      if (iabs(delta) < tc * 10) {
+        const int tc2 = tc >> 1;
+        delta = iclip(-tc, tc, delta);
+        b[i][3] = iclip(0, 255, m3 + delta);
+        b[i][4] = iclip(0, 255, m4 - delta);
+        if (dp < side) b[i][2] = iclip(0, 255, m2 + iclip(-tc2, tc2, (((m1 + m3 + 1) >> 1) - m2 + delta) >> 1));
+        if (dq < side) b[i][5] = iclip(0, 255, m5 + iclip(-tc2, tc2, (((m6 + m4 + 1) >> 1) - m5 - delta) >> 1));
+      }
+    }
+  }
+}
+// Luma.  VERTICAL: part (x = 8 * x8, y = 4 * y4): 4 rows of the 8 samples x - 4 .. x + 3 (one 8-byte access per row, 4-byte
+// aligned); !VERTICAL: part (x = 4 * x4, y = 8 * y8): the 8 rows y - 4 .. y + 3 of 4 samples (one dword per row).
+template <bool VERTICAL> __global__ void __launch_bounds__(256) dev_deblock_luma_kernel(u8 *frames, const DeblockGeom g, const long parts)
+{
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= parts) return;
+  const int nx = VERTICAL ? g.W >> 3 : g.W >> 2, ny = VERTICAL ? g.H >> 2 : g.H >> 3;
+  const long frame = p / ((long)nx * ny);
+  const int r = (int)(p % ((long)nx * ny)), ix = r % nx, iy = r / nx;
+  const int x = VERTICAL ? 8 * ix : 4 * ix, y = VERTICAL ? 4 * iy : 8 * iy;
+  if ((VERTICAL ? x : y) == 0 || !deblock_edge_on(g, frame, x, y, VERTICAL)) return;
+  u8 *Y = frames + frame * g.frame_bytes;
+  int b[4][8];
+  if (VERTICAL) {
+    for (int i = 0; i < 4; i++) {
+      const u32 *row = reinterpret_cast<const u32 *>(Y + (long)(y + i) * g.W + x - 4);
+      const u32 lo = row[0], hi = row[1];
+      for (int k = 0; k < 4; k++) { b[i][k] = (lo >> (8 * k)) & 0xff; b[i][4 + k] = (hi >> (8 * k)) & 0xff; }
+    }
+  } else {
+    for (int k = 0; k < 8; k++) {
+      const u32 v = *reinterpret_cast<const u32 *>(Y + (long)(y - 4 + k) * g.W + x);
+      for (int i = 0; i < 4; i++) b[i][k] = (v >> (8 * i)) & 0xff;
+    }
+  }
+  deblock_luma_lines(b, g.beta, g.tc);
+  if (VERTICAL) {
+    for (int i = 0; i < 4; i++) {
+      u32 *row = reinterpret_cast<u32 *>(Y + (long)(y + i) * g.W + x - 4);
+      row[0] = (u32)b[i][0] | ((u32)b[i][1] << 8) | ((u32)b[i][2] << 16) | ((u32)b[i][3] << 24);
+      row[1] = (u32)b[i][4] | ((u32)b[i][5] << 8) | ((u32)b[i][6] << 16) | ((u32)b[i][7] << 24);
+    }
+  } else {
+    for (int k = 1; k < 7; k++)
+      *reinterpret_cast<u32 *>(Y + (long)(y - 4 + k) * g.W + x) = (u32)b[0][k] | ((u32)b[1][k] << 8) | ((u32)b[2][k] << 16) | ((u32)b[3][k] << 24);
+  }
+}
+// Chroma (filter.c:567-632, 170-190): edges on the 8x8 chroma grid, 4 samples per part, both planes (part index carries the plane)
+template <bool VERTICAL> __global__ void __launch_bounds__(256) dev_deblock_chroma_kernel(u8 *frames, const DeblockGeom g, const long parts)
+{
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= parts) return;
+  const int cw = g.W >> 1, ch = g.H >> 1;
+  const int nx = VERTICAL ? (cw + 7) >> 3 : cw >> 2, ny = VERTICAL ? ch >> 2 : (ch + 7) >> 3;  // same counts as deblock_frames_on
+  const long per_frame = 2L * nx * ny, frame = p / per_frame;
+  const int r = (int)(p % per_frame), plane = r / (nx * ny), q = r % (nx * ny), ix = q % nx, iy = q / nx;
+  const int xc = VERTICAL ? 8 * ix : 4 * ix, yc = VERTICAL ? 4 * iy : 8 * iy;
+  if ((VERTICAL ? xc : yc) == 0 || !deblock_edge_on(g, frame, 2 * xc, 2 * yc, VERTICAL)) return;
+  u8 *P = frames + frame * g.frame_bytes + (long)g.W * g.H + (long)plane * cw * ch;
+  const int across = VERTICAL ? 1 : cw, along = VERTICAL ? cw : 1;
+  for (int i = 0; i < 4; i++) {
+    u8 *s = P + (long)yc * cw + xc + i * along;
+    const int m2 = s[-2 * across], m3 = s[-across], m4 = s[0], m5 = s[across];
+    const int delta = iclip(-g.tc_c, g.tc_c, (((m4 - m3) * 4) + m2 - m5 + 4) >> 3);
+    s[-across] = (u8)iclip(0, 255, m3 + delta);
+    s[0] = (u8)iclip(0, 255, m4 - delta);
+  }
+}
+
+inline void deblock_frames_on(hipStream_t stream, u8 *frames, int width, int height, int n_frames, const u8 *cu_depth, int qp, int beta_off, int tc_off)
+{
+  if (n_frames <= 0) return;
+  DeblockGeom g;
+  g.W = width; g.H = height; g.cu_depth = cu_depth; g.frame_bytes = (long)width * height * 3 / 2;
+  g.beta = deblock_beta(iclip(0, 51, qp + 2 * beta_off));
+  g.tc = deblock_tc(iclip(0, 53, qp + 2 + 2 * tc_off));                  // filter.c:496-497 with strength 2
+  g.tc_c = deblock_tc(iclip(0, 53, chroma_qp_of(qp) + 2 + 2 * tc_off));  // filter.c:592-595
+  const long lv = (long)n_frames * (width >> 3) * (height >> 2), lh = (long)n_frames * (width >> 2) * (height >> 3);
+  const int cw = width >> 1, ch = height >> 1;
+  const long cv = 2L * n_frames * ((cw + 7) >> 3) * (ch >> 2), chh = 2L * n_frames * (cw >> 2) * ((ch + 7) >> 3);
+  auto grid = [](long n) { return dim3((unsigned)((n + 255) / 256)); };
+  if (lv) hipLaunchKernelGGL(dev_deblock_luma_kernel<true>, grid(lv), dim3(256), 0, stream, frames, g, lv);
+  if (cv) hipLaunchKernelGGL(dev_deblock_chroma_kernel<true>, grid(cv), dim3(256), 0, stream, frames, g, cv);
+  if (lh) hipLaunchKernelGGL(dev_deblock_luma_kernel<false>, grid(lh), dim3(256), 0, stream, frames, g, lh);
+  if (chh) hipLaunchKernelGGL(dev_deblock_chroma_kernel<false>, grid(chh), dim3(256), 0, stream, frames, g, chh);
+  KVZ_HIP_CHECK(hipGetLastError());
+}
+
 struct DevTimer { hipEvent_t e0 = nullptr, e1 = nullptr; };
 static DevTimer &dev_timer() { static thread_local DevTimer t; return t; }
 
@@ -291,6 +418,17 @@ void kvz_hip_dev_angular_pred(int log2_width, int mode, const uint8_t *ref_above
 {
   const int w = 1 << log2_width;
   be().run(kvz::IntraPredOp{ 3 + mode, log2_width, nullptr, ref_above, ref_left, 2 * w + 1, out }, count * w * w);
+}
+
+void kvz_hip_dev_deblock_frames(uint8_t *frames, int width, int height, int n_frames, const uint8_t *cu_depth, int qp, int beta_offset_div2,
+                                int tc_offset_div2)
+{
+  kvz::deblock_frames_on(be().stream, frames, width, height, n_frames, cu_depth, qp, beta_offset_div2, tc_offset_div2);
+}
+
+void kvz_hip_batch_deblock(kvz_hip_batch *b, int qp, int beta_offset_div2, int tc_offset_div2)
+{
+  kvz::deblock_frames_on(b->stream, b->d_rec, b->F.W, b->F.H, b->n_frames, b->d_depth, qp, beta_offset_div2, tc_offset_div2);
 }
 
 }  // extern "C"

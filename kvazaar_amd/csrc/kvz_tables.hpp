@@ -48,6 +48,25 @@ inline u16 half_bits_of_int(int v)
   return (u16)(sign | ((e + 15) << 10) | ((a << (10 - e)) & 0x3ff));
 }
 
+// Deblocking thresholds, H.265 Table 8-12 (filter.c:46-65 kvz_g_tc_table_8x8 / kvz_g_beta_table_8x8) and the chroma QP
+// mapping of Table 8-10 (transform.c:56-62 kvz_g_chroma_scale)
+inline int deblock_tc(int q)  // q in [0, 53]
+{
+  static const unsigned char first_q_of_next[] = { 18, 27, 31, 35, 38, 40, 42, 43, 44, 45, 46 };  // tc' steps 0 -> 1 -> ... -> 10 -> 11
+  static const unsigned char from_46[] = { 11, 13, 14, 16, 18, 20, 22, 24 };
+  if (q >= 46) return from_46[q - 46];
+  int v = 0;
+  while (q >= first_q_of_next[v]) v++;
+  return v;
+}
+inline int deblock_beta(int q) { return q < 16 ? 0 : (q <= 28 ? q - 10 : 2 * q - 38); }  // q in [0, 51]
+inline int chroma_qp_of(int qp)
+{
+  static const unsigned char t[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32,
+                                       33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };
+  return t[qp < 0 ? 0 : (qp > 57 ? 57 : qp)];
+}
+
 inline void build_tables(Tables *t)
 {
   memset(t, 0, sizeof(*t));

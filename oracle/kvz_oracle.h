@@ -129,6 +129,11 @@ void kvz_oracle_intra_frame(const kvz_hip_intra_cost_model *m, int width, int he
                             uint8_t *cu_mode, double *ctu_cost);
 void kvz_oracle_intra_cost_model(int qp, const float entropy_fbits[128], uint64_t coeff_weights, kvz_hip_intra_cost_model *m);
 
+/* ---- deblocking of an all-intra, constant-QP picture in place (kvz_oracle_deblock.c; filter.c:783 kvz_filter_deblock_lcu over
+ * every LCU).  Planes are tight (stride = width), cu_depth is the CU depth per 8x8 unit as the CTU pass returns it. ---- */
+void kvz_oracle_deblock_frame(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,
+                              const uint8_t *cu_depth);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,119 @@
+/*
+ * kvz_oracle_deblock.c -- TEST INFRASTRUCTURE (see kvz_oracle.h): CPU restatement of kvazaar's deblocking filter for the
+ * all-intra, constant-QP configuration of the batched pass.
+ *
+ * Reference: filter.c:783 kvz_filter_deblock_lcu and everything it calls.  kvazaar walks LCU by LCU (vertical edges of the
+ * LCU, the 4 deferred rightmost pixels of the previous LCU's horizontal edges, then the horizontal edges); because edges
+ * of one direction lie 8 pixels apart and a filter reads 4 / writes at most 3 pixels on either side, that order equals
+ * H.265 8.7.2's picture-level order -- every vertical edge first, then every horizontal edge on the result -- which is what
+ * this file (and the device kernel) does.  tests/test_oracle_vs_ref.py checks it against the compiled reference.
+ *
+ * Restrictions taken from the configuration: every CU is intra 2Nx2N (boundary strength 2 on every filtered edge,
+ * filter.c:418-421, 622), one QP for the picture (filter.c:277-279), 8-bit, 4:2:0, no PCM / lossless.
+ */
+#include <stdlib.h>
+
+#include "kvz_oracle.h"
+
+/* H.265 Table 8-12 as kvazaar stores it (filter.c:46-65): tc' as run lengths, beta' as two ramps */
+static int tc_prime(int q)
+{
+  static const unsigned char run_end[] = { 18, 27, 31, 35, 38, 40, 42, 43, 44, 45, 46 };  /* first Q with the next value: 0,1,2,...,10 */
+  static const unsigned char tail[] = { 11, 13, 14, 16, 18, 20, 22, 24 };               /* Q = 46..53 */
+  if (q >= 46) return tail[q - 46];
+  int v = 0;
+  while (q >= run_end[v]) v++;
+  return v;
+}
+static int beta_prime(int q) { return q < 16 ? 0 : (q <= 28 ? q - 10 : 2 * q - 38); }
+
+static int clip3(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static const unsigned char chroma_qp[58] = { /* H.265 Table 8-10, transform.c:56-62 */
+  0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32,
+  33, 33, 34, 34, 35, 35, 36, 36, 37, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51 };
+
+/* filter.c:202-216 is_tu_boundary (is_pu_boundary adds nothing for 2Nx2N: CU edges are TU edges) for the 8x8 unit at (x, y) */
+static int edge_is_filtered(const uint8_t *cu_depth, int w8, int x, int y, int vertical)
+{
+  const int d = cu_depth[(y >> 3) * w8 + (x >> 3)], tr_depth = d ? d : 1, tu_w = 64 >> tr_depth;
+  return ((vertical ? x : y) & (tu_w - 1)) == 0;
+}
+
+/* One 4-sample part of a luma edge (filter.c:386-561): p[i][k] = sample k (0..7, edge between 3 and 4) of line i, in place */
+static void luma_part(uint8_t *px, int step_across, int step_along, int beta, int tc)
+{
+  int b[4][8];
+  for (int i = 0; i < 4; i++) for (int k = 0; k < 8; k++) b[i][k] = px[i * step_along + (k - 4) * step_across];
+  const int dp0 = abs(b[0][1] - 2 * b[0][2] + b[0][3]), dq0 = abs(b[0][4] - 2 * b[0][5] + b[0][6]);
+  const int dp3 = abs(b[3][1] - 2 * b[3][2] + b[3][3]), dq3 = abs(b[3][4] - 2 * b[3][5] + b[3][6]);
+  const int dp = dp0 + dp3, dq = dq0 + dq3;
+  if (dp + dq >= beta) return;
+  const int strong = 2 * (dp0 + dq0) < (beta >> 2) && 2 * (dp3 + dq3) < (beta >> 2) &&
+                     abs(b[0][3] - b[0][4]) < ((5 * tc + 1) >> 1) && abs(b[3][3] - b[3][4]) < ((5 * tc + 1) >> 1) &&
+                     abs(b[0][0] - b[0][3]) + abs(b[0][4] - b[0][7]) < (beta >> 3) && abs(b[3][0] - b[3][3]) + abs(b[3][4] - b[3][7]) < (beta >> 3);
+  const int side_threshold = (beta + (beta >> 1)) >> 3;
+  for (int i = 0; i < 4; i++) {
+    const int m0 = b[i][0], m1 = b[i][1], m2 = b[i][2], m3 = b[i][3], m4 = b[i][4], m5 = b[i][5], m6 = b[i][6], m7 = b[i][7];
+    int o[8] = { m0, m1, m2, m3, m4, m5, m6, m7 };
+    if (strong) {  /* filter.c:95-118 */
+      o[1] = clip3(m1 - 2 * tc, m1 + 2 * tc, (2 * m0 + 3 * m1 + m2 + m3 + m4 + 4) >> 3);
+      o[2] = clip3(m2 - 2 * tc, m2 + 2 * tc, (m1 + m2 + m3 + m4 + 2) >> 2);
+      o[3] = clip3(m3 - 2 * tc, m3 + 2 * tc, (m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4) >> 3);
+      o[4] = clip3(m4 - 2 * tc, m4 + 2 * tc, (m2 + 2 * m3 + 2 * m4 + 2 * m5 + m6 + 4) >> 3);
+      o[5] = clip3(m5 - 2 * tc, m5 + 2 * tc, (m3 + m4 + m5 + m6 + 2) >> 2);
+      o[6] = clip3(m6 - 2 * tc, m6 + 2 * tc, (m3 + m4 + m5 + 3 * m6 + 2 * m7 + 4) >> 3);
+    } else {       /* filter.c:126-165 */
+      int delta = (9 * (m4 - m3) - 3 * (m5 - m2) + 8) >> 4;
+      if (abs(delta) < tc * 10) {
+        const int tc2 = tc >> 1;
+        delta = clip3(-tc, tc, delta);
+        o[3] = clip3(0, 255, m3 + delta);
+        o[4] = clip3(0, 255, m4 - delta);
+        if (dp < side_threshold) o[2] = clip3(0, 255, m2 + clip3(-tc2, tc2, (((m1 + m3 + 1) >> 1) - m2 + delta) >> 1));
+        if (dq < side_threshold) o[5] = clip3(0, 255, m5 + clip3(-tc2, tc2, (((m6 + m4 + 1) >> 1) - m5 - delta) >> 1));
+      }
+    }
+    for (int k = 1; k < 7; k++) px[i * step_along + (k - 4) * step_across] = (uint8_t)o[k];
+  }
+}
+
+/* One 4-sample part of a chroma edge (filter.c:170-190, 622-629) */
+static void chroma_part(uint8_t *px, int step_across, int step_along, int tc)
+{
+  for (int i = 0; i < 4; i++) {
+    uint8_t *s = px + i * step_along;
+    const int m2 = s[-2 * step_across], m3 = s[-step_across], m4 = s[0], m5 = s[step_across];
+    const int delta = clip3(-tc, tc, (((m4 - m3) * 4) + m2 - m5 + 4) >> 3);
+    s[-step_across] = (uint8_t)clip3(0, 255, m3 + delta);
+    s[0] = (uint8_t)clip3(0, 255, m4 - delta);
+  }
+}
+
+void kvz_oracle_deblock_frame(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,
+                              const uint8_t *cu_depth)
+{
+  const int w8 = width >> 3, cw = width >> 1, ch = height >> 1;
+  const int beta = beta_prime(clip3(0, 51, qp + (beta_offset_div2 << 1)));
+  const int tc = tc_prime(clip3(0, 53, qp + 2 * (2 - 1) + (tc_offset_div2 << 1)));                       /* filter.c:496-497, strength 2 */
+  const int tc_c = tc_prime(clip3(0, 53, chroma_qp[qp] + 2 * (2 - 1) + (tc_offset_div2 << 1)));        /* filter.c:592-595 */
+  for (int dir = 0; dir < 2; dir++) {  /* 0: vertical edges (filtering across x), 1: horizontal edges */
+    const int vertical = dir == 0;
+    for (int ey = 0; ey < height; ey += 8)
+      for (int ex = 0; ex < width; ex += 8) {
+        if ((vertical ? ex : ey) == 0) continue;                        /* picture border, filter.c:648-649 */
+        if (!edge_is_filtered(cu_depth, w8, ex, ey, vertical)) continue;
+        for (int part = 0; part < 2; part++) {                          /* 8 samples of edge = two 4-sample parts */
+          uint8_t *p = y + (ey + (vertical ? 4 * part : 0)) * width + ex + (vertical ? 0 : 4 * part);
+          luma_part(p, vertical ? 1 : width, vertical ? width : 1, beta, tc);
+        }
+        /* chroma: only edges on the 8x8 chroma grid (filter.c:680), 4 chroma samples per 8 luma samples of edge */
+        const int xc = ex >> 1, yc = ey >> 1;
+        if (((vertical ? xc : yc) & 7) == 0) {
+          chroma_part(u + yc * cw + xc, vertical ? 1 : cw, vertical ? cw : 1, tc_c);
+          chroma_part(v + yc * cw + xc, vertical ? 1 : cw, vertical ? cw : 1, tc_c);
+        }
+      }
+  }
+  (void)ch;
+}

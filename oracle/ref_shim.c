@@ -213,3 +213,51 @@ void kvz_ref_sao_reconstruct_color(const kvz_hip_sao_params *s, const uint8_t *r
 }
 int kvz_ref_sao_band_ddistortion(int bitdepth, const uint8_t *orig, const uint8_t *rec, int bw, int bh, int band_pos, const int sao_bands[4])
 { (void)bitdepth; return kvz_sao_band_ddistortion(&g_state, orig, rec, bw, bh, band_pos, sao_bands); }
+
+/* ---- deblocking: the reference's kvz_filter_deblock_lcu (filter.c:783) over every LCU of an all-intra, constant-QP picture.
+ * Planes are tight (stride = width) and filtered in place; cu_depth holds the CU depth per 8x8 unit. ---- */
+#include "filter.h"
+#include "videoframe.h"
+void kvz_ref_deblock_frame(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,
+                           const uint8_t *cu_depth)
+{
+  encoder_state_config_tile_t tile;
+  videoframe_t frame;
+  memset(&tile, 0, sizeof tile);
+  memset(&frame, 0, sizeof frame);
+  frame.width = width; frame.height = height;
+  frame.width_in_lcu = (width + LCU_WIDTH - 1) / LCU_WIDTH; frame.height_in_lcu = (height + LCU_WIDTH - 1) / LCU_WIDTH;
+  frame.rec = kvz_image_alloc(KVZ_CSP_420, width, height);
+  frame.cu_array = kvz_cu_array_alloc(width, height);
+  for (int r = 0; r < height; r++) memcpy(frame.rec->y + r * frame.rec->stride, y + r * width, width);
+  for (int r = 0; r < height / 2; r++) {
+    memcpy(frame.rec->u + r * (frame.rec->stride / 2), u + r * (width / 2), width / 2);
+    memcpy(frame.rec->v + r * (frame.rec->stride / 2), v + r * (width / 2), width / 2);
+  }
+  for (int py = 0; py < height; py += 4)
+    for (int px = 0; px < width; px += 4) {
+      cu_info_t *cu = kvz_cu_array_at(frame.cu_array, px, py);
+      const int d = cu_depth[(py >> 3) * (width >> 3) + (px >> 3)];
+      memset(cu, 0, sizeof *cu);
+      cu->type = CU_INTRA; cu->depth = d; cu->tr_depth = d ? d : 1; cu->part_size = SIZE_2Nx2N; cu->qp = (int8_t)qp;
+    }
+  tile.frame = &frame;
+  g_state.tile = &tile;
+  g_state.qp = (int8_t)qp;
+  g_frame.max_qp_delta_depth = -1;
+  g_frame.slicetype = KVZ_SLICE_I;
+  g_frame.QP = (int8_t)qp;
+  g_ctrl.cfg.deblock_beta = beta_offset_div2; g_ctrl.cfg.deblock_tc = tc_offset_div2;
+  g_ctrl.cfg.lossless = 0;
+  g_ctrl.chroma_format = KVZ_CSP_420;
+  for (int ly = 0; ly < height; ly += LCU_WIDTH)
+    for (int lx = 0; lx < width; lx += LCU_WIDTH) kvz_filter_deblock_lcu(&g_state, lx, ly);
+  for (int r = 0; r < height; r++) memcpy(y + r * width, frame.rec->y + r * frame.rec->stride, width);
+  for (int r = 0; r < height / 2; r++) {
+    memcpy(u + r * (width / 2), frame.rec->u + r * (frame.rec->stride / 2), width / 2);
+    memcpy(v + r * (width / 2), frame.rec->v + r * (frame.rec->stride / 2), width / 2);
+  }
+  kvz_image_free(frame.rec);
+  kvz_cu_array_free(&frame.cu_array);
+  g_state.tile = NULL;
+}

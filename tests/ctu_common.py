@@ -100,6 +100,12 @@ class HipBatch:
         self.lib.kvz_hip_batch_sync(self.handle)
         return n
 
+    def deblock(self, qp, beta_offset_div2=0, tc_offset_div2=0):
+        self.lib.kvz_hip_batch_deblock.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        self.lib.kvz_hip_batch_deblock.restype = None
+        self.lib.kvz_hip_batch_deblock(self.handle, qp, beta_offset_div2, tc_offset_div2)
+        self.lib.kvz_hip_batch_sync(self.handle)
+
     def kernel_ms(self):
         return self.lib.kvz_hip_batch_last_kernel_ms(self.handle)
 

@@ -116,3 +116,24 @@ def test_hip_ctu_large_batch_stress(oracle, hiplib):
                 assert not cc.compare(want[i % 3], got), (rep, i, cc.compare(want[i % 3], got))
     finally:
         b.close()
+
+
+def test_batch_deblock_after_ctu_pass(oracle, hiplib):
+    """kvz_hip_batch_deblock on the batch's own reconstruction + CU depths == the oracle's deblocking of the oracle's pass
+    (the two stages kvazaar runs back to back per LCU, encoderstate.c:669-671)"""
+    import deblock_common as dc
+    w, h = 192, 136
+    model22 = _model(hiplib, oracle, 22)
+    frames = cc.yuv_frames(w, h, 3, 31, "small")
+    batch = cc.HipBatch(hiplib, w, h, len(frames))
+    for i, f in enumerate(frames):
+        batch.upload(i, f)
+    batch.run(model22)
+    batch.deblock(22)
+    for i, f in enumerate(frames):
+        o = cc.run_oracle(oracle, model22, w, h, f)
+        want = dc.run_cpu(oracle.lib.kvz_oracle_deblock_frame, w, h, 22, 0, 0, o["rec"], o["depth"].reshape(h // 8, w // 8))
+        got = batch.download(i)["rec"]
+        assert np.array_equal(got, want), i
+        assert not np.array_equal(want, o["rec"])
+    batch.close()

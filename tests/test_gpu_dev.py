@@ -96,3 +96,29 @@ def test_dev_angular(oracle, dev, log2w):
             oracle.angular_pred(log2w, mode, flatapi.ptr(above[i]), flatapi.ptr(left[i]), flatapi.ptr(want[i]))
         dev.free(da, dl, do)
         assert np.array_equal(got, want), mode
+
+
+@pytest.mark.parametrize("size", [(64, 64), (192, 136), (416, 240), (1920, 1080)])
+def test_dev_deblock_frames(oracle, dev, size):
+    """device deblocking of a batch of frames == the oracle's kvz_filter_deblock_lcu restatement (itself pinned against the
+    compiled reference in tests/test_oracle_vs_ref.py), random CU quadtrees"""
+    import ctypes as C
+    import deblock_common as dc
+    w, h = size
+    rng = np.random.default_rng(w + h)
+    kinds = ("smooth", "steps", "noise", "steps")
+    frames, depths = [], []
+    for k in kinds:
+        f, _ = dc.test_picture(w, h, rng, k)
+        frames.append(f)
+        depths.append(dc.random_depth_map(w, h, rng))
+    for qp, b_off, t_off in ((22, 0, 0), (37, 2, -1), (51, 0, 3)):
+        dfr, ddp = dev.put(np.stack(frames)), dev.put(np.stack(depths))
+        dev.lib.kvz_hip_dev_deblock_frames.restype = None
+        dev.lib.kvz_hip_dev_deblock_frames.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        dev.lib.kvz_hip_dev_deblock_frames(dfr, w, h, len(frames), ddp, qp, b_off, t_off)
+        got = dev.get(dfr, (len(frames), w * h * 3 // 2), np.uint8)
+        dev.free(dfr, ddp)
+        for i in range(len(frames)):
+            want = dc.run_cpu(oracle.lib.kvz_oracle_deblock_frame, w, h, qp, b_off, t_off, frames[i], depths[i])
+            assert np.array_equal(got[i], want), (kinds[i], qp, np.flatnonzero(got[i] != want)[:8])

@@ -74,3 +74,22 @@ def test_optimized_sad_matches_reg_sad(oracle, reflib, ref):
             if got == 0xFFFFFFFF:
                 continue
             assert got == oracle.reg_sad(ptr(a), ptr(b), w, h, 80, 90)
+
+
+@pytest.mark.parametrize("size", [(64, 64), (192, 136), (416, 240)])
+def test_deblock_frame_matches_reference(oracle, reflib, size):
+    """kvz_oracle_deblock_frame (picture-level: all vertical edges, then all horizontal ones) == the reference's LCU-by-LCU
+    kvz_filter_deblock_lcu (filter.c:783) on random CU quadtrees, QPs and offsets"""
+    import deblock_common as dc
+    w, h = size
+    rng = np.random.default_rng(w * 7 + h)
+    for trial, kind in enumerate(("smooth", "steps", "noise", "steps", "smooth")):
+        frame, _ = dc.test_picture(w, h, rng, kind)
+        depth = dc.random_depth_map(w, h, rng)
+        qp = int(rng.choice([17, 22, 27, 32, 37, 45, 51]))
+        b_off, t_off = (0, 0) if trial < 3 else (int(rng.integers(-3, 4)), int(rng.integers(-3, 4)))
+        a = dc.run_cpu(oracle.lib.kvz_oracle_deblock_frame, w, h, qp, b_off, t_off, frame, depth)
+        b = dc.run_cpu(reflib.lib.kvz_ref_deblock_frame, w, h, qp, b_off, t_off, frame, depth)
+        assert np.array_equal(a, b), (kind, qp, b_off, t_off, np.flatnonzero(a != b)[:8])
+        if kind != "noise" and qp >= 22:
+            assert not np.array_equal(a, frame), "the filter should have changed something"
