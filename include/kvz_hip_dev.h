@@ -51,6 +51,10 @@ void kvz_hip_dev_angular_pred(int log2_width, int mode, const uint8_t *ref_above
 void kvz_hip_dev_deblock_frames(uint8_t *frames, int width, int height, int n_frames, const uint8_t *cu_depth, int qp, int beta_offset_div2,
                                 int tc_offset_div2);
 
+/* Picture-hash SEI checksums (nal.c:73-86 kvz_image_checksum): out[3 * f + p] = kvz_array_checksum of plane p of frame f
+ * (nal-generic.c:57-82) for n_frames tight planar 4:2:0 frames; width a multiple of 8.  1.5 w h bytes read per frame. */
+void kvz_hip_dev_picture_checksums(const uint8_t *frames, int width, int height, int n_frames, uint32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@ int kvz_strategy_register_quant_hip(void *opaque, uint8_t bitdepth);
 int kvz_strategy_register_intra_hip(void *opaque, uint8_t bitdepth);
 int kvz_strategy_register_ipol_hip(void *opaque, uint8_t bitdepth);
 int kvz_strategy_register_sao_hip(void *opaque, uint8_t bitdepth);
+int kvz_strategy_register_nal_hip(void *opaque, uint8_t bitdepth);
 
 /* 1 when the strategy should register (8-bit build, a usable device, not disabled by KVZ_HIP_DISABLE=1) */
 int kvz_hip_strategy_usable(uint8_t bitdepth);

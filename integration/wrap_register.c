@@ -22,3 +22,4 @@ WRAP(quant)
 WRAP(intra)
 WRAP(ipol)
 WRAP(sao)
+WRAP(nal)

@@ -286,6 +286,19 @@ template <class B> struct Api {
     be.download();
     return *be.host(o);
   }
+  // ---------------------------------------------------------------- nal
+  static u32 plane_checksum(B &be, const u8 *data, int height, int width, int stride)
+  {
+    if (height <= 0 || width <= 0) return 0;
+    be.begin();
+    const u8 *d = be.in_rows(data, width, height, stride);
+    u32 *o = be.template zeroed<u32>(1);
+    be.upload();
+    be.run(PlaneChecksumOp{ d, width, width, o }, height);
+    be.download();
+    return *be.host(o);
+  }
+
   static double fast_coeff_cost(B &be, const i16 *coeff, int width, uint64_t weights)
   {
     be.begin();

@@ -320,6 +320,38 @@ inline void deblock_frames_on(hipStream_t stream, u8 *frames, int width, int hei
   KVZ_HIP_CHECK(hipGetLastError());
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Picture-hash checksums of whole frames (nal.c:73-86 kvz_image_checksum -> nal-generic.c:57-82 per plane): one lane per dword
+// of a plane row, the four masks of a dword are c ^ {0, 1, 2, 3} for the lane's c = (x & 255) ^ (y & 255) ^ (x >> 8) ^ (y >> 8),
+// v_sad_u8 against zero adds the four bytes, then a wavefront sum and one atomic per wavefront.  out[frame][plane].
+__global__ void __launch_bounds__(256) dev_checksum_kernel(const u8 *frames, int W, int H, long frame_bytes, long dwords_per_frame, long total, u32 *out)
+{
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  u32 v = 0;
+  long frame = 0;
+  int plane = 0;
+  if (i < total) {
+    frame = i / dwords_per_frame;
+    long r = i % dwords_per_frame;
+    const long yd = (long)(W >> 2) * H, cd = (long)(W >> 3) * (H >> 1);
+    plane = r < yd ? 0 : (r < yd + cd ? 1 : 2);
+    r -= plane == 0 ? 0 : (plane == 1 ? yd : yd + cd);
+    const int wd = plane ? W >> 3 : W >> 2;  // dwords per row of the plane
+    const int y = (int)(r / wd), x = 4 * (int)(r % wd);
+    const u32 w = reinterpret_cast<const u32 *>(frames + frame * frame_bytes + (plane == 0 ? 0 : (plane == 1 ? (long)W * H : (long)W * H * 5 / 4)))[r];
+    const u32 c = ((x & 0xff) ^ (y & 0xff) ^ (x >> 8) ^ (y >> 8)) & 0xff;
+    v = __builtin_amdgcn_sad_u8(w ^ (c * 0x01010101u) ^ 0x03020100u, 0u, 0u);
+  }
+  // a wavefront may straddle a plane / frame boundary: lanes add into their own (frame, plane) slot, wavefront-summed when uniform
+  const long first = __shfl(i < total ? frame * 3 + plane : -1, 0), last = __shfl(i < total ? frame * 3 + plane : -1, 63);
+  if (first == last && first >= 0) {
+    const u32 s = group_sum<64>(v);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&out[first], s);
+  } else if (i < total) {
+    atomicAdd(&out[frame * 3 + plane], v);
+  }
+}
+
 struct DevTimer { hipEvent_t e0 = nullptr, e1 = nullptr; };
 static DevTimer &dev_timer() { static thread_local DevTimer t; return t; }
 
@@ -424,6 +456,14 @@ void kvz_hip_dev_deblock_frames(uint8_t *frames, int width, int height, int n_fr
                                 int tc_offset_div2)
 {
   kvz::deblock_frames_on(be().stream, frames, width, height, n_frames, cu_depth, qp, beta_offset_div2, tc_offset_div2);
+}
+
+void kvz_hip_dev_picture_checksums(const uint8_t *frames, int width, int height, int n_frames, uint32_t *out)
+{
+  if (n_frames <= 0) return;
+  const long per_frame = (long)(width >> 2) * height + 2L * (width >> 3) * (height >> 1), total = per_frame * n_frames;
+  KVZ_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)n_frames * 3 * sizeof(uint32_t), be().stream));
+  KVZ_DEV_LAUNCH(kvz::dev_checksum_kernel, total, frames, width, height, (long)width * height * 3 / 2, per_frame, total, out);
 }
 
 void kvz_hip_batch_deblock(kvz_hip_batch *b, int qp, int beta_offset_div2, int tc_offset_div2)

@@ -98,6 +98,15 @@ KVZ_TR(idct_16x16, KVZ_HIP_IDCT_16)
 KVZ_TR(idct_32x32, KVZ_HIP_IDCT_32)
 KVZ_TR(fast_inverse_dst_4x4, KVZ_HIP_IDST_4)
 
+void kvz_hip_array_checksum(const uint8_t *data, const int height, const int width, const int stride, unsigned char checksum_out[16],
+                            const uint8_t bitdepth)
+{
+  (void)bitdepth;  // 8-bit build (the registration shim does not register otherwise)
+  const uint32_t v = kvz_hip_plane_checksum(data, height, width, stride);
+  checksum_out[0] = (unsigned char)(v >> 24); checksum_out[1] = (unsigned char)(v >> 16);
+  checksum_out[2] = (unsigned char)(v >> 8); checksum_out[3] = (unsigned char)v;
+}
+
 // get_optimized_sad (strategies-picture.h:128): the widths kvazaar's PUs can have (square, SMP and AMP partitions)
 #define KVZ_OPT_SAD(w) \
   static uint32_t opt_sad_##w(const uint8_t *pic, const uint8_t *ref, int32_t height, uint32_t s1, uint32_t s2) { return kvz_hip_reg_sad(pic, ref, w, height, s1, s2); }

@@ -371,6 +371,19 @@ struct AbsSumOp {
   KVZ_DEV void operator()(int i) const { KVZ_ATOMIC_ADD(out, (u32)iabs((int)c[i])); }
 };
 
+// nal-generic.c:57-82 array_checksum (SEI decoded picture hash, method "checksum"): sum over the plane of sample ^ mask(x, y),
+// 32-bit wrap-around.  One item per row.
+struct PlaneChecksumOp {
+  const u8 *data; int width, stride; u32 *out;
+  KVZ_DEV void operator()(int y) const
+  {
+    const u8 *row = data + (long)y * stride;
+    u32 sum = 0;
+    for (int x = 0; x < width; x++) sum += (u32)(row[x] ^ (u8)((x & 0xff) ^ (y & 0xff) ^ (x >> 8) ^ (y >> 8)));
+    KVZ_ATOMIC_ADD(out, sum);
+  }
+};
+
 // quant-generic.c:351-375: sum of Q8.8 weights[min(|c|,3)]; the /256.0 happens on the host (exact)
 struct FastCoeffCostOp {
   const i16 *c; uint64_t weights; u32 *out;

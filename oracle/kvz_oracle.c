@@ -512,6 +512,16 @@ int kvz_oracle_quantize_residual(const kvz_hip_quant_params *p, int width, int c
 }
 
 /* quant-generic.c:342-349 */
+/* nal-generic.c:57-82 array_checksum_generic: the picture-hash SEI's per-plane checksum (returned as the 32-bit value the
+ * reference then stores big-endian in checksum_out[0..3]) */
+uint32_t kvz_oracle_plane_checksum(const uint8_t *data, int height, int width, int stride)
+{
+  uint32_t sum = 0;
+  for (int y = 0; y < height; y++)
+    for (int x = 0; x < width; x++) sum += (uint32_t)(data[y * stride + x] ^ (uint8_t)((x & 0xff) ^ (y & 0xff) ^ (x >> 8) ^ (y >> 8)));
+  return sum;
+}
+
 uint32_t kvz_oracle_coeff_abs_sum(const int16_t *coeffs, size_t length)
 {
   uint32_t sum = 0;

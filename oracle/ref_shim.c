@@ -146,6 +146,13 @@ int kvz_ref_quantize_residual(const kvz_hip_quant_params *p, int width, int colo
                                in_stride, out_stride, ref_in, pred_in, rec_out, coeff_out, early_skip);
 }
 uint32_t kvz_ref_coeff_abs_sum(const int16_t *coeffs, size_t length) { return kvz_coeff_abs_sum(coeffs, length); }
+#include "strategies/strategies-nal.h"
+uint32_t kvz_ref_plane_checksum(const uint8_t *data, int height, int width, int stride)
+{
+  unsigned char out[SEI_HASH_MAX_LENGTH] = { 0 };
+  kvz_array_checksum(data, height, width, stride, out, KVZ_BIT_DEPTH);
+  return ((uint32_t)out[0] << 24) | ((uint32_t)out[1] << 16) | ((uint32_t)out[2] << 8) | out[3];
+}
 double kvz_ref_fast_coeff_cost(const int16_t *coeff, int32_t width, uint64_t weights) { return kvz_fast_coeff_cost(coeff, width, weights); }
 void kvz_ref_find_last_scanpos(const int16_t *coef, int16_t *dest_coeff, int8_t type, int32_t q_bits, const int16_t *quant_coeff,
                                int32_t *sig_coeff_inc_out, uint32_t cg_size, uint16_t *ctx_set, const uint32_t *scan,

@@ -491,7 +491,17 @@ def cases_find_last_scanpos(scan_table):
                 yield (f"last_scanpos{w}-s{scan_idx}-{rep}", run)
 
 
-ALL_GENERATORS = [cases_sad_satd_nxn, cases_dual, cases_reg_sad, cases_any_size, cases_ssd_versad_horsad_var,
+def cases_plane_checksum():
+    """nal-generic.c:57-82: planes wider / taller than 256 exercise the x >> 8 / y >> 8 terms of the mask, strides > width the row step"""
+    rng = _rng(120)
+    for (h, w, stride) in ((1, 1, 1), (8, 8, 8), (16, 24, 40), (120, 208, 208), (270, 300, 304), (64, 520, 520), (515, 64, 72)):
+        d = A(rng.integers(0, 256, h * stride, dtype=np.uint8))
+        yield (f"plane_checksum{w}x{h}s{stride}", lambda lib, d=d, h=h, w=w, stride=stride: (lib.plane_checksum(ptr(d), h, w, stride),))
+    full = A(np.full(64 * 64, 255, np.uint8))
+    yield ("plane_checksum-ff", lambda lib: (lib.plane_checksum(ptr(full), 64, 64, 64),))
+
+
+ALL_GENERATORS = [cases_plane_checksum, cases_sad_satd_nxn, cases_dual, cases_reg_sad, cases_any_size, cases_ssd_versad_horsad_var,
                   cases_image_calc_sad, cases_bipred, cases_transform, cases_quant, cases_quantize_residual,
                   cases_coeff_misc, cases_intra, cases_ipol_sample, cases_ipol_blocks, cases_extended_block, cases_sao]
 

@@ -122,3 +122,23 @@ def test_dev_deblock_frames(oracle, dev, size):
         for i in range(len(frames)):
             want = dc.run_cpu(oracle.lib.kvz_oracle_deblock_frame, w, h, qp, b_off, t_off, frames[i], depths[i])
             assert np.array_equal(got[i], want), (kinds[i], qp, np.flatnonzero(got[i] != want)[:8])
+
+
+def test_dev_picture_checksums(oracle, dev):
+    """kvz_hip_dev_picture_checksums over a batch == the oracle's per-plane checksum (nal-generic.c:57-82) of every frame; sizes
+    whose planes cross the 256-sample mask periods and whose wavefronts straddle plane / frame boundaries"""
+    import ctypes as C
+    rng = np.random.default_rng(12)
+    for (w, h, n) in ((8, 8, 3), (72, 40, 5), (416, 240, 4), (1920, 1080, 2)):
+        frames = rng.integers(0, 256, (n, w * h * 3 // 2), dtype=np.uint8)
+        dfr, dout = dev.put(frames), dev.empty(4 * 3 * n)
+        dev.lib.kvz_hip_dev_picture_checksums.restype = None
+        dev.lib.kvz_hip_dev_picture_checksums.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        dev.lib.kvz_hip_dev_picture_checksums(dfr, w, h, n, dout)
+        got = dev.get(dout, (n, 3), np.uint32)
+        dev.free(dfr, dout)
+        for f in range(n):
+            y, u, v = frames[f][:w * h], frames[f][w * h:w * h * 5 // 4], frames[f][w * h * 5 // 4:]
+            want = [oracle.plane_checksum(flatapi.ptr(y), h, w, w), oracle.plane_checksum(flatapi.ptr(u), h // 2, w // 2, w // 2),
+                    oracle.plane_checksum(flatapi.ptr(v), h // 2, w // 2, w // 2)]
+            assert list(got[f]) == want, (w, h, f)
