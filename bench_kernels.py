@@ -82,7 +82,7 @@ def main():
         rng = np.random.default_rng(kind)
         x = np.tile(rng.integers(-255, 256, (min(count, 2048), n * n)).astype(np.int16), ((count + 2047) // 2048, 1))[:count]
         di, dt, do = dev.put(x), dev.empty(x.nbytes), dev.empty(x.nbytes)
-        for mfma in ((0, 1) if n >= 16 else (0,)):
+        for mfma in (0, 1):
             ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_transform(kind, di, dt, do, count, mfma), args.reps, args.warmup)
             extra = {"path": "matrix cores (v_mfma_f32_*_f16)" if mfma else "scalar item kernel, two passes through HBM"}
             if mfma:

@@ -35,8 +35,8 @@ void kvz_hip_dev_sad_nxn(int n, const uint8_t *a, const uint8_t *b, int count, u
 void kvz_hip_dev_satd_nxn(int n, const uint8_t *a, const uint8_t *b, int count, uint32_t *out);
 
 /* kvz_dct_NxN / kvz_idct_NxN / 4x4 DST (dct-generic.c:559-630), 8-bit: `kind` = enum kvz_hip_transform_kind.
- * 16- and 32-point transforms run on the matrix cores (v_mfma_f32_*_f16, exact integer arithmetic) unless
- * use_matrix_cores == 0; `tmp` is count * n^2 int16 of scratch for the scalar path (may be NULL with matrix cores). */
+ * All of them run on the matrix cores (v_mfma_f32_*_f16, exact integer arithmetic; 4- and 8-point blocks ride 4 / 2 at a time on
+ * the diagonal of a 16x16 product) unless use_matrix_cores == 0; `tmp` is count * n^2 int16 of scratch for the scalar path (may be NULL with matrix cores). */
 void kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *out, int count, int use_matrix_cores);
 
 /* kvz_angular_pred (intra-generic.c:49-155): block i is predicted from ref_above + i * (2w+1) and ref_left + i * (2w+1)

@@ -200,6 +200,43 @@ template <int N> __global__ void __launch_bounds__(256) dev_transform_mfma_kerne
 // edges of one direction lie 8 samples apart and a filter touches at most 3 / reads 4 samples on either side).  One lane per
 // 4-sample part of an edge; lanes run along the direction that makes a wavefront's loads contiguous (x fastest).  Every CU
 // is intra: boundary strength 2 wherever an edge is filtered at all (filter.c:418-421).
+// 4- and 8-point transforms (and the 4x4 DST): 16 / n blocks sit on the diagonal of one 16x16 problem, the matrix is the
+// matching block-diagonal one (Tables::bd_h), everything else as above.  Off-diagonal results are exact zeros and never stored.
+template <int NB /* block size: 4 or 8 */> __global__ void __launch_bounds__(256)
+dev_transform_small_mfma_kernel(const i16 *in, i16 *out, const int count, const int inverse, const u16 *T, const u16 *Tt)
+{
+  typedef DevMma<16> M;
+  constexpr int L2 = NB == 4 ? 2 : 3, G = 16 / NB;
+  const int lane = threadIdx.x & 63;
+  const long first = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * G;  // first block of this wavefront
+  if (first >= count) return;  // wavefront-uniform
+  const int col = M::idx(lane), g = col / NB, cc = col - g * NB, k0 = M::k0(lane, 0);
+  const bool have = first + g < count;          // the lane's own block exists
+  const bool diag = k0 / NB == g;               // the lane's four k lie in its block
+  const i16 *x = in + (first + g) * (NB * NB);
+  i16 *o = out + (first + g) * (NB * NB);
+  int v[4], t[4];
+  for (int i = 0; i < 4; i++) {
+    const int kk = k0 - g * NB + i;
+    v[i] = (have && diag) ? (int)(inverse ? x[kk * NB + cc] : x[cc * NB + kk]) : 0;
+  }
+  if (!inverse) {
+    dev_product<16>(v, T, false, lane, t);
+    { const int shift = L2 - 1, add = 1 << (shift - 1); for (int r = 0; r < 4; r++) v[r] = (int)(i16)((t[r] + add) >> shift); }
+    dev_product<16>(v, T, true, lane, t);
+    { const int shift = L2 + 6, add = 1 << (shift - 1); for (int r = 0; r < 4; r++) v[r] = (int)(i16)((t[r] + add) >> shift); }
+  } else {
+    dev_product<16>(v, Tt, false, lane, t);
+    for (int r = 0; r < 4; r++) v[r] = iclip(-32768, 32767, (t[r] + 64) >> 7);
+    dev_product<16>(v, Tt, false, lane, t);
+    for (int r = 0; r < 4; r++) v[r] = iclip(-32768, 32767, (t[r] + 2048) >> 12);
+  }
+  for (int r = 0; r < 4; r++) {
+    const int row = M::row(lane, r);
+    if (have && row / NB == g) o[(row - g * NB) * NB + cc] = (i16)v[r];
+  }
+}
+
 struct DeblockGeom { int W, H, beta, tc, tc_c; long frame_bytes; const u8 *cu_depth; };
 
 __device__ __forceinline__ bool deblock_edge_on(const DeblockGeom &g, long frame, int x, int y, bool vertical)  // filter.c:202-216
@@ -440,6 +477,14 @@ void kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *o
     const long threads = ((long)count + 3) / 4 * 256;
     if (n == 16) KVZ_DEV_LAUNCH(kvz::dev_transform_mfma_kernel<16>, threads, in, out, count, inverse, kvz::device_tables());
     else KVZ_DEV_LAUNCH(kvz::dev_transform_mfma_kernel<32>, threads, in, out, count, inverse, kvz::device_tables());
+    return;
+  }
+  if (use_matrix_cores) {
+    const kvz::Tables *tb = kvz::device_tables();
+    const int kind_bd = idx == 4 ? 2 : (n == 8 ? 1 : 0), per_wave = 16 / n;
+    const long threads = ((long)count + 4 * per_wave - 1) / (4 * per_wave) * 256;
+    if (n == 4) KVZ_DEV_LAUNCH(kvz::dev_transform_small_mfma_kernel<4>, threads, in, out, count, inverse, tb->bd_h[kind_bd][0], tb->bd_h[kind_bd][1]);
+    else KVZ_DEV_LAUNCH(kvz::dev_transform_small_mfma_kernel<8>, threads, in, out, count, inverse, tb->bd_h[kind_bd][0], tb->bd_h[kind_bd][1]);
     return;
   }
   if (!tmp) { fprintf(stderr, "kvz_hip_dev_transform: the scalar path needs tmp\n"); abort(); }

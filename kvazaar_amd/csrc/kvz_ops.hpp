@@ -51,6 +51,9 @@ struct Tables {
   // The 16- and 32-point matrices again as IEEE half bit patterns (every entry is an integer of magnitude <= 90, exact
   // in half): [0: n = 16, 1: n = 32][0: C row-major, 1: C transposed], the table operand of the MFMA transforms.
   alignas(16) u16 dct_h[2][2][32 * 32];
+  // ... and 16 x 16 block-diagonal matrices for the small transforms, so that one 16x16x16 MFMA carries several blocks:
+  // [0: diag(C4 x4), 1: diag(C8 x2), 2: diag(DST4 x4)][0: T, 1: T transposed]
+  alignas(16) u16 bd_h[3][2][16 * 16];
   u32 scan[3][4][1024];  // [scan_idx][log2-2] (tables.c kvz_g_sig_last_scan), sizes 4..32
   int8_t luma_filter[4][8];    // filter.c:66-72
   int8_t chroma_filter[8][4];  // filter.c:74-84

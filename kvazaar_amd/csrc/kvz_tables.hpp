@@ -84,6 +84,16 @@ inline void build_tables(Tables *t)
   }
   static const i16 dst4[16] = { 29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29 };
   memcpy(t->dst4, dst4, sizeof dst4);
+  for (int kind = 0; kind < 3; kind++) {
+    const int n = kind == 1 ? 8 : 4;
+    const i16 *m = kind == 2 ? t->dst4 : t->dct[kind == 1 ? 1 : 0];
+    for (int g = 0; g < 16 / n; g++)
+      for (int k = 0; k < n; k++)
+        for (int j = 0; j < n; j++) {
+          t->bd_h[kind][0][(g * n + k) * 16 + g * n + j] = half_bits_of_int(m[k * n + j]);
+          t->bd_h[kind][1][(g * n + j) * 16 + g * n + k] = half_bits_of_int(m[k * n + j]);
+        }
+  }
   for (int type = 0; type < 3; type++)
     for (int l2 = 2; l2 <= 5; l2++) {
       const int size = 1 << l2, cgs = size / 4;
