@@ -237,6 +237,27 @@ dev_transform_small_mfma_kernel(const i16 *in, i16 *out, const int count, const 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Angular prediction of a batch of blocks with one mode (intra-generic.c:49-155): a workgroup stages the reference rows of its
+// blocks in LDS (they are re-read by every lane of the block), then one lane produces four horizontally adjacent samples and
+// stores them as one dword, lane-contiguous in the output.
+template <int L2> __global__ void __launch_bounds__(256) dev_angular_kernel(const u8 *above, const u8 *left, const int count, const int mode, u8 *out)
+{
+  constexpr int W = 1 << L2, LANES = W * W / 4, BLOCKS = 256 / LANES, RS = 2 * W + 1, RP = (RS + 3) & ~3;
+  __shared__ u8 refs[BLOCKS][2][RP];
+  const long blk0 = (long)blockIdx.x * BLOCKS;
+  for (int i = threadIdx.x; i < BLOCKS * 2 * RS; i += 256) {
+    const int b = i / (2 * RS), r = i % (2 * RS), side = r / RS, k = r % RS;
+    if (blk0 + b < count) refs[b][side][k] = (side ? left : above)[(blk0 + b) * RS + k];
+  }
+  __syncthreads();
+  const int b = threadIdx.x / LANES, e = threadIdx.x % LANES, y = e / (W / 4), x = 4 * (e % (W / 4));
+  if (blk0 + b >= count) return;
+  u32 v = 0;
+  for (int k = 0; k < 4; k++) v |= (u32)angular_pixel(mode, x + k, y, refs[b][0], refs[b][1]) << (8 * k);
+  reinterpret_cast<u32 *>(out + (blk0 + b) * (W * W))[e] = v;
+}
+
 struct DeblockGeom { int W, H, beta, tc, tc_c; long frame_bytes; const u8 *cu_depth; };
 
 __device__ __forceinline__ bool deblock_edge_on(const DeblockGeom &g, long frame, int x, int y, bool vertical)  // filter.c:202-216
@@ -493,8 +514,16 @@ void kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *o
 
 void kvz_hip_dev_angular_pred(int log2_width, int mode, const uint8_t *ref_above, const uint8_t *ref_left, int count, uint8_t *out)
 {
-  const int w = 1 << log2_width;
-  be().run(kvz::IntraPredOp{ 3 + mode, log2_width, nullptr, ref_above, ref_left, 2 * w + 1, out }, count * w * w);
+  if (count <= 0) return;
+  const int lanes = (1 << (2 * log2_width)) / 4, blocks_per_wg = 256 / lanes;
+  const long threads = ((long)count + blocks_per_wg - 1) / blocks_per_wg * 256;
+  switch (log2_width) {
+  case 2: KVZ_DEV_LAUNCH(kvz::dev_angular_kernel<2>, threads, ref_above, ref_left, count, mode, out); break;
+  case 3: KVZ_DEV_LAUNCH(kvz::dev_angular_kernel<3>, threads, ref_above, ref_left, count, mode, out); break;
+  case 4: KVZ_DEV_LAUNCH(kvz::dev_angular_kernel<4>, threads, ref_above, ref_left, count, mode, out); break;
+  case 5: KVZ_DEV_LAUNCH(kvz::dev_angular_kernel<5>, threads, ref_above, ref_left, count, mode, out); break;
+  default: fprintf(stderr, "kvz_hip_dev_angular_pred: unsupported log2_width=%d\n", log2_width); abort();
+  }
 }
 
 void kvz_hip_dev_deblock_frames(uint8_t *frames, int width, int height, int n_frames, const uint8_t *cu_depth, int qp, int beta_offset_div2,
