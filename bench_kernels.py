@@ -118,6 +118,23 @@ def main():
     report("deblock_1080p_frame", 0, nfr, ms, 2 * (w * h * 3 // 2), {"path": "4 launches: luma / chroma x vertical / horizontal edges", "fps": round(nfr / (ms * 1e-3))})
     dev.free(dfr, ddp)
 
+    # motion cost surface: every 16x16 block of a 1080p picture, +-16 full search (1089 candidates per block)
+    bw, rng_ = 16, 16
+    cur = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    ref = np.roll(cur, (2, -3), (0, 1))
+    xy = np.array([(x, y) for y in range(0, h - bw + 1, bw) for x in range(0, w - bw + 1, bw)], dtype=np.int16)
+    side = 2 * rng_ + 1
+    dc, dr, dxy, dout = dev.put(cur), dev.put(ref), dev.put(xy), dev.empty(4 * len(xy) * side * side)
+    dev.lib.kvz_hip_dev_sad_surface.restype = None
+    dev.lib.kvz_hip_dev_sad_surface.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_sad_surface(dc, dr, w, h, bw, rng_, dxy, len(xy), dout), args.reps, args.warmup)
+    diffs = len(xy) * side * side * bw * bw / (ms * 1e-3)
+    report("sad_surface_16x16_r16", bw, len(xy), ms, bw * bw + (bw + 2 * rng_) ** 2 + 4 * side * side,
+           {"path": "LDS-staged window, v_alignbyte + v_sad_u8", "candidates_per_s": round(len(xy) * side * side / (ms * 1e-3)),
+            "abs_diffs_per_s": round(diffs), "valu_sad_frac": round(diffs / (256 * 4 * 16 * 4 * 2.4e9), 4),
+            "note": "bound: v_sad_u8 issue (4 differences per lane per instruction, 256 CUs x 4 SIMDs x 16 lanes at 2.4 GHz); the window is read from HBM once"})
+    dev.free(dc, dr, dxy, dout)
+
     print(json.dumps({"summary": "bench_kernels", "batch_ctus": args.batch_ctus, "reps": args.reps, "kernels": len(results)}))
 
 

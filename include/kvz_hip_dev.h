@@ -51,6 +51,14 @@ void kvz_hip_dev_angular_pred(int log2_width, int mode, const uint8_t *ref_above
 void kvz_hip_dev_deblock_frames(uint8_t *frames, int width, int height, int n_frames, const uint8_t *cu_depth, int qp, int beta_offset_div2,
                                 int tc_offset_div2);
 
+/* Integer-pel motion cost surface (the candidate scoring of the inter search, search_inter.c:1000-1005 -> kvz_image_calc_sad,
+ * image.c:407): for block b = the bw x bw block of `cur` at (blk_xy[2b], blk_xy[2b+1]) and every displacement (dx, dy) in
+ * [-range, range]^2,   out[b * side^2 + (dy + range) * side + dx + range] = kvz_image_calc_sad(cur, ref, x, y, x + dx, y + dy, bw, bw)
+ * with side = 2 range + 1 -- the reference picture is edge-replicated outside the frame as image.c:279-397 does.  Both
+ * pictures are width x height luma planes (stride = width); bw in {8, 16, 32, 64}, range <= 32, blocks inside the picture. */
+void kvz_hip_dev_sad_surface(const uint8_t *cur, const uint8_t *ref, int width, int height, int bw, int range, const int16_t *blk_xy, int count,
+                             uint32_t *out);
+
 /* Picture-hash SEI checksums (nal.c:73-86 kvz_image_checksum): out[3 * f + p] = kvz_array_checksum of plane p of frame f
  * (nal-generic.c:57-82) for n_frames tight planar 4:2:0 frames; width a multiple of 8.  1.5 w h bytes read per frame. */
 void kvz_hip_dev_picture_checksums(const uint8_t *frames, int width, int height, int n_frames, uint32_t *out);

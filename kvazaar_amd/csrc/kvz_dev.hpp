@@ -258,6 +258,47 @@ template <int L2> __global__ void __launch_bounds__(256) dev_angular_kernel(cons
   reinterpret_cast<u32 *>(out + (blk0 + b) * (W * W))[e] = v;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Integer-pel motion cost surface: SAD of one BW x BW block of the current picture against the reference at every
+// displacement of a (2 range + 1)^2 window -- kvz_image_calc_sad (image.c:407) per candidate, i.e. the reference is
+// edge-replicated outside the frame (image.c:279-397).  One workgroup per block: the block and the (BW + 2 range)^2 window are
+// staged in LDS once (clamped addressing does the replication), then every lane scores whole candidates: per row it walks
+// aligned dwords of the window, funnel-shifts them to the candidate's column (v_alignbyte_b32) and accumulates v_sad_u8
+// against the block's dwords (a broadcast read).  Window re-use between candidates never touches HBM again.
+template <int BW> __global__ void __launch_bounds__(256)
+dev_sad_surface_kernel(const u8 *cur, const u8 *ref, const int W, const int H, const int range, const i16 *blk_xy, u32 *out)
+{
+  constexpr int MAXR = 32, WD = (BW + 2 * MAXR + 4) / 4;  // dwords per staged window row
+  __shared__ u32 s_cur[BW * BW / 4];
+  __shared__ u32 s_win[(BW + 2 * MAXR) * WD];
+  const int b = blockIdx.x, bx = blk_xy[2 * b], by = blk_xy[2 * b + 1], side = 2 * range + 1, wrows = BW + 2 * range, wcols = BW + 2 * range;
+  u8 *cur8 = reinterpret_cast<u8 *>(s_cur), *win8 = reinterpret_cast<u8 *>(s_win);
+  for (int i = threadIdx.x; i < BW * BW; i += 256) cur8[i] = cur[(long)(by + i / BW) * W + bx + i % BW];
+  for (int i = threadIdx.x; i < wrows * wcols; i += 256) {
+    const int r = i / wcols, c = i % wcols;
+    const int y = iclip(0, H - 1, by - range + r), x = iclip(0, W - 1, bx - range + c);
+    win8[r * (WD * 4) + c] = ref[(long)y * W + x];
+  }
+  __syncthreads();
+  for (int cand = threadIdx.x; cand < side * side; cand += 256) {
+    const int dy = cand / side, dx = cand % side;  // window-relative displacement: column dx, row dy
+    const int d0 = dx >> 2;
+    const u32 sh = (u32)(dx & 3);
+    u32 sad = 0;
+    for (int r = 0; r < BW; r++) {
+      const u32 *wr = s_win + (dy + r) * WD + d0;
+      u32 lo = wr[0];
+#pragma unroll
+      for (int k = 0; k < BW / 4; k++) {
+        const u32 hi = wr[k + 1];
+        sad = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(hi, lo, sh), s_cur[r * (BW / 4) + k], sad);
+        lo = hi;
+      }
+    }
+    out[(long)b * side * side + cand] = sad;
+  }
+}
+
 struct DeblockGeom { int W, H, beta, tc, tc_c; long frame_bytes; const u8 *cu_depth; };
 
 __device__ __forceinline__ bool deblock_edge_on(const DeblockGeom &g, long frame, int x, int y, bool vertical)  // filter.c:202-216
@@ -530,6 +571,22 @@ void kvz_hip_dev_deblock_frames(uint8_t *frames, int width, int height, int n_fr
                                 int tc_offset_div2)
 {
   kvz::deblock_frames_on(be().stream, frames, width, height, n_frames, cu_depth, qp, beta_offset_div2, tc_offset_div2);
+}
+
+void kvz_hip_dev_sad_surface(const uint8_t *cur, const uint8_t *ref, int width, int height, int bw, int range, const int16_t *blk_xy, int count,
+                             uint32_t *out)
+{
+  if (count <= 0) return;
+  if (range < 0 || range > 32) { fprintf(stderr, "kvz_hip_dev_sad_surface: range %d not in [0, 32]\n", range); abort(); }
+  const dim3 grid((unsigned)count), block(256);
+  switch (bw) {
+  case 8: hipLaunchKernelGGL(kvz::dev_sad_surface_kernel<8>, grid, block, 0, be().stream, cur, ref, width, height, range, blk_xy, out); break;
+  case 16: hipLaunchKernelGGL(kvz::dev_sad_surface_kernel<16>, grid, block, 0, be().stream, cur, ref, width, height, range, blk_xy, out); break;
+  case 32: hipLaunchKernelGGL(kvz::dev_sad_surface_kernel<32>, grid, block, 0, be().stream, cur, ref, width, height, range, blk_xy, out); break;
+  case 64: hipLaunchKernelGGL(kvz::dev_sad_surface_kernel<64>, grid, block, 0, be().stream, cur, ref, width, height, range, blk_xy, out); break;
+  default: fprintf(stderr, "kvz_hip_dev_sad_surface: unsupported block width %d\n", bw); abort();
+  }
+  KVZ_HIP_CHECK(hipGetLastError());
 }
 
 void kvz_hip_dev_picture_checksums(const uint8_t *frames, int width, int height, int n_frames, uint32_t *out)

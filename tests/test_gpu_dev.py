@@ -142,3 +142,28 @@ def test_dev_picture_checksums(oracle, dev):
             want = [oracle.plane_checksum(flatapi.ptr(y), h, w, w), oracle.plane_checksum(flatapi.ptr(u), h // 2, w // 2, w // 2),
                     oracle.plane_checksum(flatapi.ptr(v), h // 2, w // 2, w // 2)]
             assert list(got[f]) == want, (w, h, f)
+
+
+@pytest.mark.parametrize("bw,rng_", [(8, 4), (16, 16), (32, 9), (64, 32)])
+def test_dev_sad_surface(oracle, dev, bw, rng_):
+    """every candidate of the motion cost surface == kvz_image_calc_sad (edge-replicated reference), blocks in the picture
+    interior and touching all four borders / corners so that the window leaves the frame"""
+    import ctypes as C
+    w, h = 200, 136
+    rng = np.random.default_rng(bw)
+    cur = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    ref = np.roll(cur, (3, -5), (0, 1)) ^ rng.integers(0, 4, (h, w), dtype=np.uint8)
+    pos = [(0, 0), (w - bw, 0), (0, h - bw), (w - bw, h - bw), ((w - bw) // 2 // 8 * 8, (h - bw) // 2 // 8 * 8), (8, h - bw), (w - bw, 8)]
+    xy = np.array(pos, dtype=np.int16)
+    side = 2 * rng_ + 1
+    dc, dr, dxy, dout = dev.put(cur), dev.put(ref), dev.put(xy), dev.empty(4 * len(pos) * side * side)
+    dev.lib.kvz_hip_dev_sad_surface.restype = None
+    dev.lib.kvz_hip_dev_sad_surface.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    dev.lib.kvz_hip_dev_sad_surface(dc, dr, w, h, bw, rng_, dxy, len(pos), dout)
+    got = dev.get(dout, (len(pos), side, side), np.uint32)
+    dev.free(dc, dr, dxy, dout)
+    picks = [(-rng_, -rng_), (rng_, rng_), (0, 0), (-rng_, rng_), (1, -2), (rng_ // 2, -rng_)] + [tuple(rng.integers(-rng_, rng_ + 1, 2)) for _ in range(40)]
+    for b, (x, y) in enumerate(pos):
+        for dx, dy in picks:
+            want = oracle.image_calc_sad(flatapi.ptr(cur), w, flatapi.ptr(ref), w, h, w, x, y, x + int(dx), y + int(dy), bw, bw)
+            assert got[b, dy + rng_, dx + rng_] == want, (b, dx, dy)
