@@ -137,3 +137,32 @@ def test_batch_deblock_after_ctu_pass(oracle, hiplib):
         assert np.array_equal(got, want), i
         assert not np.array_equal(want, o["rec"])
     batch.close()
+
+
+def test_c_host_example_matches_oracle_chain(oracle, hiplib, tmp_path):
+    """examples/batch_intra.c -- a plain C host over the C ABI -- compiled with gcc and run as a process: its per-frame checksums
+    must be those of the oracle's CTU pass + deblocking + picture checksum"""
+    import re
+    import subprocess
+    import deblock_common as dc
+    import kvazaar_amd
+    root = flatapi.ROOT
+    exe = str(tmp_path / "batch_intra")
+    libdir = flatapi.os.path.dirname(kvazaar_amd.LIB_PATH)
+    subprocess.check_call(["gcc", "-O2", "-I" + flatapi.os.path.join(root, "include"), flatapi.os.path.join(root, "examples", "batch_intra.c"),
+                           "-L" + libdir, "-lkvz_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    w, h = 128, 72
+    frames = cc.yuv_frames(w, h, 2, 5, "small")
+    yuv = tmp_path / "in.yuv"
+    yuv.write_bytes(b"".join(f.tobytes() for f in frames))
+    out = subprocess.run([exe, str(yuv), str(w), str(h), "22"], capture_output=True, text=True, check=True).stdout
+    got = [tuple(int(v, 16) for v in m) for m in re.findall(r"checksum Y ([0-9a-f]+) U ([0-9a-f]+) V ([0-9a-f]+)", out)]
+    model22 = _model(hiplib, oracle, 22)
+    want = []
+    for f in frames:
+        o = cc.run_oracle(oracle, model22, w, h, f)
+        r = dc.run_cpu(oracle.lib.kvz_oracle_deblock_frame, w, h, 22, 0, 0, o["rec"], o["depth"].reshape(h // 8, w // 8))
+        ys, cs = w * h, w * h // 4
+        want.append((oracle.plane_checksum(flatapi.ptr(r), h, w, w), oracle.plane_checksum(flatapi.ptr(r, offset=ys), h // 2, w // 2, w // 2),
+                     oracle.plane_checksum(flatapi.ptr(r, offset=ys + cs), h // 2, w // 2, w // 2)))
+    assert got == want, out
