@@ -19,7 +19,7 @@ namespace kvz {
 #define KVZ_CTU_VGPR_ATTR
 #endif
 #ifndef KVZ_CTU_WAVES_PER_EU
-#define KVZ_CTU_WAVES_PER_EU 4  /* 8 workgroups of 128 lanes per CU (LDS just under 20 KB each) = 4 wavefronts per SIMD, 128 VGPRs */
+#define KVZ_CTU_WAVES_PER_EU 4  /* 8 workgroups of 128 lanes per CU = 4 wavefronts per SIMD at 128 VGPRs (LDS 16.5 KB would allow 9, but 96 VGPRs cost more than the ninth workgroup gives: profiles/experiments/r01_ab13*) */
 #endif
 __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) intra_ctu_wave_kernel(const CtuFrames F, const kvz_hip_intra_cost_model model, const Tables *tb,
                                                                         const int wave, const int y_min, const int n_diag)

@@ -96,91 +96,10 @@ KVZ_DEV u32 pk_absmax(Pk16 a)
 }
 #endif
 
-// ---------------------------------------------------------------------------------------------------------------
-// 16x16 and 32x32 transform passes on the matrix cores (device only; the host build of this file keeps the scalar loops,
-// which compute the same integers).  One wavefront forms D = A * B for an n x n problem where
-//   A[r][k] and B[k][c] are both given "row-contiguous in k":  a_rows[r * n + k],  b_rows[c * n + k],
-// one of them the DCT matrix as IEEE halves (global memory, Tables::dct_h), the other int16 data in LDS.
-// Exactness: every matrix entry (|v| <= 90) and every data operand fed to the unit (9-bit residuals, or the high / low
-// byte of a 16-bit value) is an integer that binary16 holds exactly, products are exact in binary32, and every partial
-// sum is an integer below 32 * 90 * 255 < 2^24 -- so the binary32 accumulators hold exact integers whatever the
-// summation order.  A 16-bit operand x is split as x = 256 * (x >> 8) + (x & 255): two accumulators, recombined in int32.
 #ifndef KVZ_HOSTSIM
-typedef _Float16 kvz_half4 __attribute__((ext_vector_type(4)));
-typedef float kvz_float4 __attribute__((ext_vector_type(4)));
-typedef float kvz_float16 __attribute__((ext_vector_type(16)));
-
-struct MfmaPass {
-  const u16 *table;   // n x n halves, rows contiguous in k
-  const i16 *data;    // n x n int16 in LDS, rows contiguous in k
-  i16 *dst;           // n x n int16 in LDS
-  int table_is_a;     // 1: D rows come from the table (forward passes), 0: D rows come from the data (inverse passes)
-  int split;          // data needs 16 bits
-  int add, shift, clip, transposed_store;
-};
-
-__device__ __forceinline__ kvz_half4 kvz_load_half4(const u16 *p)
-{
-  return *reinterpret_cast<const kvz_half4 *>(p);  // 8-byte aligned: k0 is a multiple of 4
-}
-__device__ __forceinline__ void kvz_load_data4(const i16 *p, bool split, kvz_half4 *hi, kvz_half4 *lo)
-{
-  const short4 v = *reinterpret_cast<const short4 *>(p);
-  const int x[4] = { v.x, v.y, v.z, v.w };
-  for (int i = 0; i < 4; i++) {
-    if (split) { (*hi)[i] = (_Float16)(x[i] >> 8); (*lo)[i] = (_Float16)(x[i] & 255); }
-    else (*lo)[i] = (_Float16)x[i];
-  }
-}
-__device__ __forceinline__ void kvz_store_result(const MfmaPass &ps, int n, int row, int col, float hi, float lo)
-{
-  int a = (int)lo;
-  if (ps.split) a += (int)hi * 256;
-  int v = (a + ps.add) >> ps.shift;
-  if (ps.clip) v = iclip(-32768, 32767, v);
-  ps.dst[ps.transposed_store ? col * n + row : row * n + col] = (i16)v;
-}
-
-// n = 32: v_mfma_f32_32x32x8_f16, four k-steps.  Lane l feeds row / column l & 31 at k = 8 * step + 4 * (l >> 5) .. + 3 and
-// receives D[8 * (reg >> 2) + 4 * (l >> 5) + (reg & 3)][l & 31].
-__device__ __forceinline__ void mfma_pass_32(const MfmaPass &ps, int lane)
-{
-  const int idx = lane & 31, kq = lane >> 5;
-  kvz_float16 acc_lo = { 0 }, acc_hi = { 0 };
-  for (int step = 0; step < 4; step++) {
-    const int k0 = 8 * step + 4 * kq;
-    const kvz_half4 tv = kvz_load_half4(ps.table + idx * 32 + k0);
-    kvz_half4 dh = { 0 }, dl = { 0 };
-    kvz_load_data4(ps.data + idx * 32 + k0, ps.split, &dh, &dl);
-    if (ps.table_is_a) {
-      acc_lo = __builtin_amdgcn_mfma_f32_32x32x8f16(tv, dl, acc_lo, 0, 0, 0);
-      if (ps.split) acc_hi = __builtin_amdgcn_mfma_f32_32x32x8f16(tv, dh, acc_hi, 0, 0, 0);
-    } else {
-      acc_lo = __builtin_amdgcn_mfma_f32_32x32x8f16(dl, tv, acc_lo, 0, 0, 0);
-      if (ps.split) acc_hi = __builtin_amdgcn_mfma_f32_32x32x8f16(dh, tv, acc_hi, 0, 0, 0);
-    }
-  }
-  for (int r = 0; r < 16; r++) kvz_store_result(ps, 32, 8 * (r >> 2) + 4 * kq + (r & 3), idx, acc_hi[r], acc_lo[r]);
-}
-
-// n = 16: v_mfma_f32_16x16x16_f16, one k-step.  Lane l feeds row / column l & 15 at k = 4 * (l >> 4) .. + 3 and receives
-// D[4 * (l >> 4) + reg][l & 15].
-__device__ __forceinline__ void mfma_pass_16(const MfmaPass &ps, int lane)
-{
-  const int idx = lane & 15, kq = lane >> 4, k0 = 4 * kq;
-  kvz_float4 acc_lo = { 0 }, acc_hi = { 0 };
-  const kvz_half4 tv = kvz_load_half4(ps.table + idx * 16 + k0);
-  kvz_half4 dh = { 0 }, dl = { 0 };
-  kvz_load_data4(ps.data + idx * 16 + k0, ps.split, &dh, &dl);
-  if (ps.table_is_a) {
-    acc_lo = __builtin_amdgcn_mfma_f32_16x16x16f16(tv, dl, acc_lo, 0, 0, 0);
-    if (ps.split) acc_hi = __builtin_amdgcn_mfma_f32_16x16x16f16(tv, dh, acc_hi, 0, 0, 0);
-  } else {
-    acc_lo = __builtin_amdgcn_mfma_f32_16x16x16f16(dl, tv, acc_lo, 0, 0, 0);
-    if (ps.split) acc_hi = __builtin_amdgcn_mfma_f32_16x16x16f16(dh, tv, acc_hi, 0, 0, 0);
-  }
-  for (int r = 0; r < 4; r++) kvz_store_result(ps, 16, 4 * kq + r, idx, acc_hi[r], acc_lo[r]);
-}
+}  // namespace kvz
+#include "kvz_mfma.hpp"  // 16- and 32-point transforms on the matrix cores (device only; the host build keeps scalar loops that compute the same integers)
+namespace kvz {
 #endif
 
 // Optional in-kernel timeline (build with -DKVZ_CTU_PROFILE): lane 0 of every workgroup adds the shader-clock cycles
@@ -235,30 +154,34 @@ struct CtuShared {
   // CU being tried.  So: one decided picture + one candidate buffer per depth, sized to that depth's CU.
   u8 dec[6144];              // decided pixels, Y 64x64 | U 32x32 | V 32x32.  The depth-0 candidate (64x64 merge) reuses it:
                              // by then the split result has been written to the frame (run()).
-  u8 c1[1536];               // depth-1 candidate (32x32 merge): Y 1024 | U 256 | V 256
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
   unsigned long long prof_acc[32];  // [category] cycles, [KVZ_P_COUNT + category] marks
 #endif
   CtuCu cu[4][64];
   u8 ref[3][2][68];          // [plane][0 top / 1 left][2w+1], w <= 32
   u8 fref[2][68];            // filtered luma refs
-  // Transform scratch, two buffers of Y | U | V int16.  Only a 32x32 transform set (the depth-0 / depth-1 merges) needs
-  // the full 2 x 1536 entries, and while one of those runs everything the search of 16x16 / 8x8 CUs keeps is dead -- so
-  // those buffers live in the upper part of the same storage; smaller sets use the first 2 x 384 entries (tbuf()).
+  // Transform scratch and everything whose lifetime fits around it, in one union:
+  //  - a 32x32 transform set (depth-0 / depth-1 merges) works in place on ONE buffer of Y 1024 | U 256 | V 256 int16 -- both
+  //    passes of a 16/32-point transform run chained through MFMA registers -- and its 32x32 candidate sits behind it;
+  //  - smaller sets use two buffers of 384 (the 8/4-point planes ping-pong between them), and while one of those runs the
+  //    buffers of the 16x16 / 8x8 search are live behind them.  The two regimes never overlap in time (tbuf()).
   union {
-    alignas(16) i16 tb_all[2 * 1536];
     struct {
-      u8 tb_small_pad[3508];
-      u8 c2[384];            // depth-2 candidate (16x16 CU):     Y 256 | U 64 | V 64
-      u8 c3[384];            // depth-3 candidates (the four 8x8 CUs of the current 16x16)
-      u8 pred[2 * 256];      // planar and DC predictions of the CU being searched (<= 16x16)
+      alignas(16) i16 tb_big[1536];
+      u8 c1[1536];             // depth-1 candidate (32x32 merge): Y 1024 | U 256 | V 256
+    };
+    struct {
+      alignas(16) i16 tb_small[2 * 384];
+      alignas(8) u8 org_t[256];  // the CU's source block transposed (horizontal modes are predicted and scored transposed)
+      u8 c2[384];              // depth-2 candidate (16x16 CU):     Y 256 | U 64 | V 64
+      u8 c3[384];              // depth-3 candidates (the four 8x8 CUs of the current 16x16)
+      u8 pred[2 * 256];        // planar and DC predictions of the CU being searched (<= 16x16)
       // Rough search, the 15 angular modes with a negative displacement (11..25): the main reference with its projected
       // extension (intra-generic.c:97-123), already picked from the filtered / unfiltered, top / left arrays.  Entry
       // [mode - 11][KVZ_MREF_ORG + q] is ref_main[q], q in [-w, w + 1] -- all such a mode can touch.  The other modes read
       // ref / fref directly.
       u8 mref[15][KVZ_MREF_STRIDE];
-      alignas(8) u8 org_t[256];  // the CU's source block transposed (horizontal modes are predicted and scored transposed)
-      u32 satd_raw[35][4];   // sum |Hadamard| per (mode, 8x8 block) before the per-block rounding
+      u32 satd_raw[35][4];     // sum |Hadamard| per (mode, 8x8 block) before the per-block rounding
     };
   };
   u32 acc[16];               // [0..2] ssd per plane, [3..5] coeff weight sums, [6..8] non-zero counts
@@ -783,11 +706,11 @@ struct CtuProgram {
   // Transform-unit geometry of one reconstruction step: luma w x w at (x, y) and/or chroma cw x cw.
   struct TuSet { int x, y, lw /* log2 luma or 0 */, lc /* log2 chroma or 0 */; };
   KVZ_DEV static int tu_log2(const TuSet &t, int c) { return c ? t.lc : t.lw; }
-  // Plane c of transform scratch buffer p for the TU set t (see CtuShared::tb_all)
+  // Plane c of transform scratch buffer p for the TU set t (see the union in CtuShared)
   KVZ_DEV i16 *tbuf(const TuSet &t, int p, int c) const
   {
-    if (t.lw == 5) return s->tb_all + p * 1536 + (c == 0 ? 0 : (c == 1 ? 1024 : 1280));
-    return s->tb_all + p * 384 + (c == 0 ? 0 : (c == 1 ? 256 : 320));
+    if (t.lw == 5) return s->tb_big + (c == 0 ? 0 : (c == 1 ? 1024 : 1280));  // one buffer, every stage in place
+    return s->tb_small + p * 384 + (c == 0 ? 0 : (c == 1 ? 256 : 320));
   }
   // Entry (k, i) of the 2^l2-point transform matrix
   KVZ_DEV int dct_at(int l2, int k, int i) const
@@ -796,6 +719,33 @@ struct CtuProgram {
     return s->dct32[(k << (10 - l2)) + i];
 #else
     return s->dct_small[(l2 == 3 ? 0 : 64) + (k << l2) + i];  // 16 and 32 points never come here on the device
+#endif
+  }
+
+  // Both passes of a 16- or 32-point transform of plane c, in place on x.  Device: wavefront c (mod the wavefronts of the
+  // workgroup) runs them chained through MFMA registers (kvz_mfma.hpp).  Host: one thread, scalar loops through a temporary --
+  // the same integers (dct-generic.c:559-579: the forward intermediate wraps to int16, both inverse stages clip).
+  KVZ_DEV void transform_big(int l2, i16 *x, bool inverse, int tid, int c) const
+  {
+#ifndef KVZ_HOSTSIM
+    if ((tid >> 6) != c % (KVZ_CTU_THREADS / 64)) return;
+    if (l2 == 5) mfma_transform_block<32>(x, x, inverse, tb->dct_h[1][0], tb->dct_h[1][1], tid & 63);
+    else mfma_transform_block<16>(x, x, inverse, tb->dct_h[0][0], tb->dct_h[0][1], tid & 63);
+#else
+    if (tid != 0) return;
+    const int n = 1 << l2;
+    i16 tmp[32 * 32];
+    for (int pass = 0; pass < 2; pass++) {
+      const i16 *src = pass == 0 ? x : tmp;
+      i16 *dst = pass == 0 ? tmp : x;
+      const int shift = inverse ? (pass == 0 ? 7 : 12) : (pass == 0 ? l2 - 1 : l2 + 6), add = 1 << (shift - 1);
+      for (int e = 0; e < n * n; e++) {
+        int a = 0;
+        if (!inverse) { const int k = e >> l2, j = e & (n - 1); for (int i = 0; i < n; i++) a += dct_at(l2, k, i) * (int)src[(j << l2) + i]; }
+        else { const int j = e >> l2, i = e & (n - 1); for (int k = 0; k < n; k++) a += dct_at(l2, k, i) * (int)src[(k << l2) + j]; }
+        dst[e] = inverse ? (i16)iclip(-32768, 32767, (a + add) >> shift) : (i16)((a + add) >> shift);
+      }
+    }
 #endif
   }
 
@@ -832,15 +782,10 @@ struct CtuProgram {
           const int n = 1 << l2, shift = pass == 0 ? l2 - 1 : l2 + 6, add = 1 << (shift - 1);
           const i16 *src = tbuf(t, pass, c);
           i16 *dst = tbuf(t, pass ^ 1, c);
-#ifndef KVZ_HOSTSIM
-          if (l2 >= 4) {  // D[k][j] = sum_i C[k][i] * src[j][i]: table rows x data rows, one wavefront per plane
-            if ((tid >> 6) == c % (KVZ_CTU_THREADS / 64)) {
-              const MfmaPass ps = { tb->dct_h[l2 - 4][0], src, dst, 1, pass, add, shift, 0, 0 };
-              if (l2 == 5) mfma_pass_32(ps, tid & 63); else mfma_pass_16(ps, tid & 63);
-            }
+          if (l2 >= 4) {  // 16 / 32 points: both passes at once (pass 0 only), in place on buffer 0, by one wavefront per plane
+            if (pass == 0) transform_big(l2, tbuf(t, 0, c), false, tid, c);
             continue;
           }
-#endif
           for (int e = tid; e < n * n; e += KVZ_CTU_THREADS) {
             const int k = e >> l2, j = e & (n - 1);
             int a = 0;
@@ -875,12 +820,7 @@ struct CtuProgram {
           nz += a != 0;
           if (a > 3) a = 3;
           wsum += (u32)((m->coeff_weights >> (16 * a)) & 0xffff);
-#ifndef KVZ_HOSTSIM
-          const int de = l2 >= 4 ? ((e & ((1 << l2) - 1)) << l2) + (e >> l2) : e;  // transposed for the matrix-core inverse
-#else
-          const int de = e;
-#endif
-          dq[de] = (i16)iclip(-32768, 32767, (level * qi.dq_scale + (1 << (qi.dq_shift - 1))) >> qi.dq_shift);
+          dq[e] = (i16)iclip(-32768, 32767, (level * qi.dq_scale + (1 << (qi.dq_shift - 1))) >> qi.dq_shift);
         }
         block_add(&s->acc[3 + c], wsum);
         block_add(&s->acc[6 + c], nz);
@@ -897,15 +837,10 @@ struct CtuProgram {
           const int n = 1 << l2, shift = pass == 0 ? 7 : 12, add = 1 << (shift - 1);
           const i16 *src = tbuf(t, pass ^ 1, c);
           i16 *dst = tbuf(t, pass, c);
-#ifndef KVZ_HOSTSIM
-          if (l2 >= 4) {  // D[j][i] = sum_k src[k][j] * C[k][i]: data arrives transposed, first pass leaves it transposed again
-            if ((tid >> 6) == c % (KVZ_CTU_THREADS / 64)) {
-              const MfmaPass ps = { tb->dct_h[l2 - 4][1], src, dst, 0, 1, add, shift, 1, pass == 0 };
-              if (l2 == 5) mfma_pass_32(ps, tid & 63); else mfma_pass_16(ps, tid & 63);
-            }
+          if (l2 >= 4) {  // both passes at once, in place on buffer 1 (where the dequantised coefficients are)
+            if (pass == 0) transform_big(l2, tbuf(t, 1, c), true, tid, c);
             continue;
           }
-#endif
           for (int e = tid; e < n * n; e += KVZ_CTU_THREADS) {
             const int j = e >> l2, i = e & (n - 1);
             int a = 0;

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/kvz_hip_dev.h"
+#include "kvz_mfma.hpp"
 #include "kvz_ops.hpp"
 
 namespace kvz {
@@ -124,82 +125,14 @@ __global__ void __launch_bounds__(256) dev_satd4_kernel(const u8 *a, const u8 *b
 // the next product and, read as A, the transposed matrix, so the first result feeds the second product directly.
 // Exactness: 16-bit operands are split x = 256 (x >> 8) + (x & 255); every operand is then an integer binary16 holds
 // exactly, products are exact in binary32 and all partial sums stay below 32 * 90 * 255 < 2^24.
-typedef _Float16 dev_half4 __attribute__((ext_vector_type(4)));
-typedef float dev_float4 __attribute__((ext_vector_type(4)));
-typedef float dev_float16 __attribute__((ext_vector_type(16)));
-
-template <int N> struct DevMma;
-template <> struct DevMma<16> {  // v_mfma_f32_16x16x16_f16
-  typedef dev_float4 Acc;
-  static constexpr int NREG = 4, STEPS = 1;
-  static __device__ __forceinline__ int idx(int lane) { return lane & 15; }
-  static __device__ __forceinline__ int k0(int lane, int) { return 4 * (lane >> 4); }
-  static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
-  static __device__ __forceinline__ Acc mma(dev_half4 a, dev_half4 b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
-};
-template <> struct DevMma<32> {  // v_mfma_f32_32x32x8_f16
-  typedef dev_float16 Acc;
-  static constexpr int NREG = 16, STEPS = 4;
-  static __device__ __forceinline__ int idx(int lane) { return lane & 31; }
-  static __device__ __forceinline__ int k0(int lane, int step) { return 8 * step + 4 * (lane >> 5); }
-  static __device__ __forceinline__ int row(int lane, int r) { return 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3); }
-  static __device__ __forceinline__ Acc mma(dev_half4 a, dev_half4 b, Acc c) { return __builtin_amdgcn_mfma_f32_32x32x8f16(a, b, c, 0, 0, 0); }
-};
-
-// out[] = (register matrix v, accumulator layout) x (table) when table_is_a == false, (table) x (register matrix) otherwise
-template <int N> __device__ __forceinline__ void dev_product(const int *v, const u16 *table, bool table_is_a, int lane, int *out)
-{
-  typedef DevMma<N> M;
-  typename M::Acc lo = { 0 }, hi = { 0 };
-  for (int st = 0; st < M::STEPS; st++) {
-    const dev_half4 tv = *reinterpret_cast<const dev_half4 *>(table + M::idx(lane) * N + M::k0(lane, st));
-    dev_half4 dl, dh;
-    for (int i = 0; i < 4; i++) { const int x = v[4 * st + i]; dh[i] = (_Float16)(x >> 8); dl[i] = (_Float16)(x & 255); }
-    if (table_is_a) { lo = M::mma(tv, dl, lo); hi = M::mma(tv, dh, hi); }
-    else { lo = M::mma(dl, tv, lo); hi = M::mma(dh, tv, hi); }
-  }
-  for (int r = 0; r < M::NREG; r++) out[r] = (int)hi[r] * 256 + (int)lo[r];
-}
-
 template <int N> __global__ void __launch_bounds__(256) dev_transform_mfma_kernel(const i16 *in, i16 *out, const int count, const int inverse, const Tables *tb)
 {
-  typedef DevMma<N> M;
-  constexpr int L2 = N == 16 ? 4 : 5;
-  const int lane = threadIdx.x & 63;
   const long blk = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blk >= count) return;  // wavefront-uniform
-  const i16 *x = in + blk * (N * N);
-  i16 *o = out + blk * (N * N);
-  const int col = M::idx(lane);
-  int v[M::NREG], t[M::NREG];
-  if (!inverse) {
-    // A operand = rows of X: lane <-> row, four consecutive k per step
-    for (int st = 0; st < M::STEPS; st++) {
-      const short4 q = *reinterpret_cast<const short4 *>(x + col * N + M::k0(lane, st));
-      v[4 * st] = q.x; v[4 * st + 1] = q.y; v[4 * st + 2] = q.z; v[4 * st + 3] = q.w;
-    }
-    dev_product<N>(v, tb->dct_h[L2 - 4][0], false, lane, t);   // D0^T = X T^T
-    { const int shift = L2 - 1, add = 1 << (shift - 1); for (int r = 0; r < M::NREG; r++) v[r] = (int)(i16)((t[r] + add) >> shift); }
-    dev_product<N>(v, tb->dct_h[L2 - 4][0], true, lane, t);    // K = T D0^T
-    { const int shift = L2 + 6, add = 1 << (shift - 1); for (int r = 0; r < M::NREG; r++) o[M::row(lane, r) * N + col] = (i16)((t[r] + add) >> shift); }
-  } else {
-    // A operand = rows of X^T: lane <-> column of X, four consecutive rows per step (lane-contiguous 2-byte loads)
-    for (int st = 0; st < M::STEPS; st++)
-      for (int i = 0; i < 4; i++) v[4 * st + i] = x[(M::k0(lane, st) + i) * N + col];
-    dev_product<N>(v, tb->dct_h[L2 - 4][1], false, lane, t);   // U = X^T T
-    for (int r = 0; r < M::NREG; r++) v[r] = iclip(-32768, 32767, (t[r] + 64) >> 7);
-    dev_product<N>(v, tb->dct_h[L2 - 4][1], false, lane, t);   // O = U^T T  (the accumulator read as A is U^T)
-    for (int r = 0; r < M::NREG; r++) o[M::row(lane, r) * N + col] = (i16)iclip(-32768, 32767, (t[r] + 2048) >> 12);
-  }
+  constexpr int L2 = N == 16 ? 4 : 5;
+  mfma_transform_block<N>(in + blk * (N * N), out + blk * (N * N), inverse != 0, tb->dct_h[L2 - 4][0], tb->dct_h[L2 - 4][1], threadIdx.x & 63);
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------
-// Deblocking of all-intra, constant-QP pictures in place (filter.c:783 kvz_filter_deblock_lcu over every LCU): picture-level
-// order -- every vertical edge, then every horizontal edge on the result (H.265 8.7.2; equal to kvazaar's LCU order because
-// edges of one direction lie 8 samples apart and a filter touches at most 3 / reads 4 samples on either side).  One lane per
-// 4-sample part of an edge; lanes run along the direction that makes a wavefront's loads contiguous (x fastest).  Every CU
-// is intra: boundary strength 2 wherever an edge is filtered at all (filter.c:418-421).
 // 4- and 8-point transforms (and the 4x4 DST): 16 / n blocks sit on the diagonal of one 16x16 problem, the matrix is the
 // matching block-diagonal one (Tables::bd_h), everything else as above.  Off-diagonal results are exact zeros and never stored.
 template <int NB /* block size: 4 or 8 */> __global__ void __launch_bounds__(256)

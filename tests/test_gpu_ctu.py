@@ -150,7 +150,7 @@ def test_c_host_example_matches_oracle_chain(oracle, hiplib, tmp_path):
     exe = str(tmp_path / "batch_intra")
     libdir = flatapi.os.path.dirname(kvazaar_amd.LIB_PATH)
     subprocess.check_call(["gcc", "-O2", "-I" + flatapi.os.path.join(root, "include"), flatapi.os.path.join(root, "examples", "batch_intra.c"),
-                           "-L" + libdir, "-lkvz_hip", "-Wl,-rpath," + libdir, "-o", exe])
+                           "-L" + libdir, "-l:" + flatapi.os.path.basename(kvazaar_amd.LIB_PATH), "-Wl,-rpath," + libdir, "-o", exe])
     w, h = 128, 72
     frames = cc.yuv_frames(w, h, 2, 5, "small")
     yuv = tmp_path / "in.yuv"
