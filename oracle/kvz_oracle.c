@@ -484,7 +484,7 @@ int kvz_oracle_quantize_residual(const kvz_hip_quant_params *p, int width, int c
                                  int use_trskip, int in_stride, int out_stride, const uint8_t *ref_in,
                                  const uint8_t *pred_in, uint8_t *rec_out, int16_t *coeff_out, int early_skip)
 {
-  int16_t residual[32 * 32], coeff[32 * 32];
+  int16_t residual[32 * 32], coeff[32 * 32] = { 0 };  /* (zeroed only to keep -Wmaybe-uninitialized quiet: every used entry is written below) */
   int has_coeffs = 0;
   for (int y = 0; y < width; y++)
     for (int x = 0; x < width; x++) residual[x + y * width] = (int16_t)(ref_in[x + y * in_stride] - pred_in[x + y * in_stride]);

@@ -5,7 +5,7 @@
  * the product (kvazaar_amd/, libkvz_hip.so) never links, imports or calls it.
  *
  * Every function restates, in plain C, what the reference's *generic* strategy computes
- * (src/strategies/generic/*.c of ultravideo/kvazaar v2.3.2); each definition in kvz_oracle.c cites
+ * (the files under src/strategies/generic/ of ultravideo/kvazaar v2.3.2); each definition in kvz_oracle.c cites
  * the file:line it follows.  Signatures mirror include/kvz_hip.h one-to-one (prefix kvz_oracle_
  * instead of kvz_hip_) so the parity tests can call oracle, reference build (oracle/_ref) and the
  * HIP library with identical arguments.
