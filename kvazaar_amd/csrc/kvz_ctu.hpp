@@ -184,10 +184,11 @@ struct CtuShared {
       u32 satd_raw[35][4];     // sum |Hadamard| per (mode, 8x8 block) before the per-block rounding
     };
   };
+  i16 lv2_coeff[384];        // quantised levels of the 16x16 CU being tried (Y 256 | U 64 | V 64): they only go to HBM if it wins
+  i16 lv1_coeff[1536];       // ... and of the 32x32 merge being tried (Y 1024 | U 256 | V 256)
   u32 acc[16];               // [0..2] ssd per plane, [3..5] coeff weight sums, [6..8] non-zero counts
   int8_t preds[3];
   int best_mode;
-  u8 tbl_top[16][16], tbl_left[16][16];
   // uniform scalars carried between phases (written by lane 0, read by everybody after the barrier)
   double cost[4], split_cost[4];  // per depth: the CU as one unit / split in four
   double res[4];                  // per depth: the cheaper of the two, what the parent adds up
@@ -239,9 +240,10 @@ struct CtuProgram {
   KVZ_DEV int ctu_index() const { return (cy >> 6) * F.wc + (cx >> 6); }
   KVZ_DEV i16 *coeff_level(int level) const
   {
-    // 8x8 CUs write straight into the CTU's output block; every larger CU is a challenger that writes the scratch block
-    // and is copied over only if it wins (commit()).  One scratch block is enough: a depth's challenger is dead by the
-    // time the next shallower depth writes the same z-order range.
+    // 8x8 CUs write straight into the CTU's output block; every larger CU is a challenger whose levels are copied over only
+    // if it wins (commit()): a 16x16 CU and a 32x32 merge keep them in LDS (CtuShared::lv2_coeff / lv1_coeff), the 64x64
+    // merge writes the scratch block in HBM.  One scratch block is enough: a depth's challenger is dead by the time the next shallower depth writes
+    // the same z-order range.
     const long ci = (long)frame * F.wc * F.hc + ctu_index();
     return level == 3 ? F.coeff + ci * 6144 : F.coeff_scratch + ci * 6144;
   }
@@ -377,7 +379,8 @@ struct CtuProgram {
 
   // ---------------------------------------------------------------- phases
   // One reference sample of intra.c:305-425 kvz_intra_build_reference_any.  side 0 = top, 1 = left; i in [0, 2w].
-  KVZ_DEV u8 ref_sample(int lv, int log2w, int c, int lx, int ly, int side, int i) const
+  // avail_top / avail_left: Tables::avail_* of the block origin in luma samples (uniform for the call, hoisted by build_refs)
+  KVZ_DEV u8 ref_sample(int lv, int log2w, int c, int lx, int ly, int side, int i, int avail_top, int avail_left) const
   {
     const int sh = c ? 1 : 0, w = 1 << log2w, px = lx >> sh, py = ly >> sh;
     if (i == 0) {
@@ -387,14 +390,14 @@ struct CtuProgram {
     const int k = i - 1;
     if (side == 1) {
       if (lx > 0) {
-        int avail = s->tbl_left[(ly & 63) >> 2][(lx & 63) >> 2] >> sh;
+        int avail = avail_left >> sh;
         avail = imin(avail, imin(2 * w, (F.H - ly) >> sh));
         return rec_px(lv, c, px - 1, py + imin(k, avail - 1));
       }
       return ly > 0 ? rec_px(lv, c, px, py - 1) : 128;
     }
     if (ly > 0) {
-      int avail = s->tbl_top[(ly & 63) >> 2][(lx & 63) >> 2] >> sh;
+      int avail = avail_top >> sh;
       avail = imin(avail, imin(2 * w, (F.W - lx) >> sh));
       return rec_px(lv, c, px + imin(k, avail - 1), py - 1);
     }
@@ -408,13 +411,14 @@ struct CtuProgram {
   template <class First = NoHook>
   KVZ_DEV void build_refs(int lv, int x, int y, int log2w_y, int log2w_c, bool luma, bool chroma, First first = First())
   {
+    const int avail_top = tb->avail_top[(y & 63) >> 2][(x & 63) >> 2], avail_left = tb->avail_left[(y & 63) >> 2][(x & 63) >> 2];
     KVZ_FOR_THREADS(tid) {
       if (tid == 0) first();
       for (int c = luma ? 0 : 1; c <= (chroma ? 2 : 0); c++) {
         const int l2 = c ? log2w_c : log2w_y, n = 2 * (1 << l2) + 1;
         for (int i = tid; i < 2 * n; i += KVZ_CTU_THREADS) {
           const int side = i >= n, k = side ? i - n : i;
-          s->ref[c][side][k] = ref_sample(lv, l2, c, x, y, side, k);
+          s->ref[c][side][k] = ref_sample(lv, l2, c, x, y, side, k, avail_top, avail_left);
         }
       }
     }
@@ -805,7 +809,8 @@ struct CtuProgram {
         const int n2 = 1 << (2 * l2), sh = c ? 1 : 0;
         const QuantScalars qf = s->qs[l2 - 2][c ? 1 : 0];  // forward and inverse share the plane's scaled QP (U and V alike)
         const QuantScalars qi = qf;
-        i16 *cout = coeff_level(lv) + kPlaneOff[c] + zorder(xl >> sh, yl >> sh);
+        i16 *cout = lv == 2 ? s->lv2_coeff + (c == 0 ? 0 : (c == 1 ? 256 : 320))
+                  : lv == 1 ? s->lv1_coeff + (c == 0 ? 0 : (c == 1 ? 1024 : 1280)) : coeff_level(lv) + kPlaneOff[c] + zorder(xl >> sh, yl >> sh);
         const i16 *src = tbuf(t, 0, c);
         i16 *dq = tbuf(t, 1, c);
         u32 wsum = 0, nz = 0;
@@ -956,13 +961,19 @@ struct CtuProgram {
         }
       }
       if (coeffs) {
-        const i16 *src = coeff_level(0);
         i16 *dst = coeff_level(3);
         const unsigned zy = zorder(xl, yl), zc = zorder(xl >> 1, yl >> 1);
-        for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) dst[zy + e] = src[zy + e];
-        for (int e = tid; e < 2 * cw * cw; e += KVZ_CTU_THREADS) {
-          const int c = e >= cw * cw, k = c ? e - cw * cw : e;
-          dst[kPlaneOff[1 + c] + zc + k] = src[kPlaneOff[1 + c] + zc + k];
+        if (w == 16) {  // the 16x16 / 32x32 challenger's levels never left LDS
+          for (int e = tid; e < 384; e += KVZ_CTU_THREADS) dst[e < 256 ? zy + e : kPlaneOff[1 + ((e - 256) >> 6)] + zc + ((e - 256) & 63)] = s->lv2_coeff[e];
+        } else if (w == 32) {
+          for (int e = tid; e < 1536; e += KVZ_CTU_THREADS) dst[e < 1024 ? zy + e : kPlaneOff[1 + ((e - 1024) >> 8)] + zc + ((e - 1024) & 255)] = s->lv1_coeff[e];
+        } else {
+          const i16 *src = coeff_level(0);
+          for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) dst[zy + e] = src[zy + e];
+          for (int e = tid; e < 2 * cw * cw; e += KVZ_CTU_THREADS) {
+            const int c = e >= cw * cw, k = c ? e - cw * cw : e;
+            dst[kPlaneOff[1 + c] + zc + k] = src[kPlaneOff[1 + c] + zc + k];
+          }
         }
       }
     }
@@ -1025,15 +1036,6 @@ struct CtuProgram {
       for (int e = tid; e < 6144; e += KVZ_CTU_THREADS) s->dec[e] = 0;
       for (int lv = 0; lv < 4; lv++)
         if (tid < 64) { CtuCu z = { 0, 0, 0, 0, 0, 0 }; s->cu[lv][tid] = z; }
-      for (int v = tid; v < 256; v += KVZ_CTU_THREADS) {  // intra.c:47-82 num_ref_pixels_{top,left}, regenerated from the z-order of 4x4 units
-        const int r = v >> 4, c = v & 15;
-        int n = 0;
-        if (r == 0) s->tbl_top[r][c] = 64;
-        else { for (int cc = c; cc < 16 && zorder(cc * 4, (r - 1) * 4) < zorder(c * 4, r * 4); cc++) n++; s->tbl_top[r][c] = (u8)(4 * n); }
-        n = 0;
-        if (c == 0) s->tbl_left[r][c] = (u8)(64 - 4 * r);
-        else { for (int rr = r; rr < 16 && zorder((c - 1) * 4, rr * 4) < zorder(c * 4, r * 4); rr++) n++; s->tbl_left[r][c] = (u8)(4 * n); }
-      }
       // Coefficient buffers start zeroed like the lcu_t copies (search.c:1084).  Only observable for CTUs that stick out
       // of the picture: inside the picture every coefficient that reaches level 0 was written by a transform unit first.
       if (cx + 64 > F.W || cy + 64 > F.H)

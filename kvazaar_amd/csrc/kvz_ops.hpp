@@ -55,6 +55,9 @@ struct Tables {
   // [0: diag(C4 x4), 1: diag(C8 x2), 2: diag(DST4 x4)][0: T, 1: T transposed]
   alignas(16) u16 bd_h[3][2][16 * 16];
   u32 scan[3][4][1024];  // [scan_idx][log2-2] (tables.c kvz_g_sig_last_scan), sizes 4..32
+  // intra.c:47-82 num_ref_pixels_top / num_ref_pixels_left: reference samples available above-right / below-left of the 4x4
+  // unit at [y / 4][x / 4] of a CTU, regenerated from the z-order of the units (kvz_tables.hpp)
+  u8 avail_top[16][16], avail_left[16][16];
   int8_t luma_filter[4][8];    // filter.c:66-72
   int8_t chroma_filter[8][4];  // filter.c:74-84
 };

@@ -82,6 +82,18 @@ inline void build_tables(Tables *t)
         t->dct_h[l - 2][1][j * n + k] = half_bits_of_int(t->dct[l][k * n + j]);
       }
   }
+  {  // a unit to the above-right / below-left is usable iff it comes earlier in z-order (cu.h:385-421) than the unit itself
+    auto z = [](int x4, int y4) { unsigned r = 0; for (int b = 0; b < 4; b++) r |= (((x4 >> b) & 1u) << (2 * b)) | (((y4 >> b) & 1u) << (2 * b + 1)); return r; };
+    for (int r = 0; r < 16; r++)
+      for (int c = 0; c < 16; c++) {
+        int n = 0;
+        if (r == 0) t->avail_top[r][c] = 64;
+        else { for (int cc = c; cc < 16 && z(cc, r - 1) < z(c, r); cc++) n++; t->avail_top[r][c] = (u8)(4 * n); }
+        n = 0;
+        if (c == 0) t->avail_left[r][c] = (u8)(64 - 4 * r);
+        else { for (int rr = r; rr < 16 && z(c - 1, rr) < z(c, r); rr++) n++; t->avail_left[r][c] = (u8)(4 * n); }
+      }
+  }
   static const i16 dst4[16] = { 29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29 };
   memcpy(t->dst4, dst4, sizeof dst4);
   for (int kind = 0; kind < 3; kind++) {
