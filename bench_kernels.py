@@ -118,6 +118,19 @@ def main():
     report("deblock_1080p_frame", 0, nfr, ms, 2 * (w * h * 3 // 2), {"path": "4 launches: luma / chroma x vertical / horizontal edges", "fps": round(nfr / (ms * 1e-3))})
     dev.free(dfr, ddp)
 
+    # SAO of whole 1080p frames with random per-CTU parameters (kvz_hip_dev_sao_frames): read + write of the picture
+    import sao_common as sc
+    nctu = 30 * 17
+    lum, chr_ = sc.random_params(rng, nctu, False), sc.random_params(rng, nctu, True)
+    dl = dev.put(np.tile(np.frombuffer(bytes(lum), dtype=np.uint8), nfr))
+    dch = dev.put(np.tile(np.frombuffer(bytes(chr_), dtype=np.uint8), nfr))
+    din, dout2 = dev.put(np.tile(frame, (nfr, 1))), dev.empty(nfr * frame.nbytes)
+    dev.lib.kvz_hip_dev_sao_frames.restype = None
+    dev.lib.kvz_hip_dev_sao_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_sao_frames(din, dout2, w, h, nfr, dl, dch), args.reps, args.warmup)
+    report("sao_1080p_frame", 0, nfr, ms, 2 * (w * h * 3 // 2), {"path": "one lane per 4 samples, per-CTU parameter records", "fps": round(nfr / (ms * 1e-3))})
+    dev.free(dl, dch, din, dout2)
+
     # motion cost surface: every 16x16 block of a 1080p picture, +-16 full search (1089 candidates per block)
     bw, rng_ = 16, 16
     cur = rng.integers(0, 256, (h, w), dtype=np.uint8)

@@ -59,6 +59,14 @@ void kvz_hip_dev_deblock_frames(uint8_t *frames, int width, int height, int n_fr
 void kvz_hip_dev_sad_surface(const uint8_t *cur, const uint8_t *ref, int width, int height, int bw, int range, const int16_t *blk_xy, int count,
                              uint32_t *out);
 
+/* SAO applied to whole pictures: kvz_sao_reconstruct (sao.c:302-361) for every CTU and plane of n_frames tight planar 4:2:0
+ * frames.  in = the deblocked pictures, out = a different buffer of the same layout (SAO reads pre-SAO neighbours);
+ * luma / chroma = n_frames x CTUs (raster order) parameter records, chroma carrying U in offsets[0..4] / band_position[0] and V
+ * in offsets[5..9] / band_position[1] like sao_info_t (sao.h:55-63).  The parameter decision (sao.c:671 kvz_sao_search_lcu)
+ * is not part of this entry point.  2 x 1.5 w h bytes per frame. */
+void kvz_hip_dev_sao_frames(const uint8_t *in, uint8_t *out, int width, int height, int n_frames, const kvz_hip_sao_params *luma,
+                            const kvz_hip_sao_params *chroma);
+
 /* Picture-hash SEI checksums (nal.c:73-86 kvz_image_checksum): out[3 * f + p] = kvz_array_checksum of plane p of frame f
  * (nal-generic.c:57-82) for n_frames tight planar 4:2:0 frames; width a multiple of 8.  1.5 w h bytes read per frame. */
 void kvz_hip_dev_picture_checksums(const uint8_t *frames, int width, int height, int n_frames, uint32_t *out);

@@ -232,6 +232,78 @@ dev_sad_surface_kernel(const u8 *cur, const u8 *ref, const int W, const int H, c
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// SAO applied to whole pictures (kvz_sao_reconstruct, sao.c:302-361, for every CTU and plane): out = in + offset[category], the
+// category from the sample and its two neighbours along the CTU's edge class, or from its band (sao-generic.c:84-124).
+// Neighbours always come from `in` (the deblocked picture); samples whose neighbour would lie outside the picture keep their
+// value (sao.c:324-349).  One lane per 4 samples of a plane row: dword load of the centre, byte loads of the six outer
+// neighbours it does not already hold, dword store.
+// Per (frame, CTU, plane) parameter record packed into 8 bytes for the sample kernel: type | class | band position | offsets[0..4]
+__global__ void __launch_bounds__(256) dev_sao_pack_kernel(const kvz_hip_sao_params *luma, const kvz_hip_sao_params *chroma, const long n_ctus, unsigned long long *packed)
+{
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= 3 * n_ctus) return;
+  const long ctu = i / 3;
+  const int color = (int)(i % 3), base = color == 2 ? 5 : 0;
+  const kvz_hip_sao_params *p = color ? &chroma[ctu] : &luma[ctu];
+  unsigned long long v = (unsigned long long)(p->type & 0xff) | ((unsigned long long)(p->eo_class & 0xff) << 8) |
+                         ((unsigned long long)(p->band_position[color == 2 ? 1 : 0] & 0xff) << 16);
+  for (int k = 0; k < 5; k++) v |= (unsigned long long)(u8)(int8_t)p->offsets[base + k] << (24 + 8 * k);
+  packed[i] = v;
+}
+__global__ void __launch_bounds__(256) dev_sao_kernel(const u8 *in, u8 *out, const int W, const int H, const long dwords_per_frame, const long total,
+                                                      const unsigned long long *packed)
+{
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long frame = i / dwords_per_frame;
+  long r = i % dwords_per_frame;
+  const long yd = (long)(W >> 2) * H, cd = (long)(W >> 3) * (H >> 1);
+  const int color = r < yd ? 0 : (r < yd + cd ? 1 : 2);
+  r -= color == 0 ? 0 : (color == 1 ? yd : yd + cd);
+  const int sh = color ? 1 : 0, fw = W >> sh, fh = H >> sh, wd = fw >> 2;
+  const int y = (int)(r / wd), x = 4 * (int)(r % wd);
+  const long plane = frame * ((long)W * H * 3 / 2) + (color == 0 ? 0 : (color == 1 ? (long)W * H : (long)W * H * 5 / 4));
+  const u8 *src = in + plane;
+  const int wc = (W + 63) >> 6, lcu_shift = 6 - sh;
+  const unsigned long long rec = packed[(frame * wc * ((H + 63) >> 6) + (long)(y >> lcu_shift) * wc + (x >> lcu_shift)) * 3 + color];  // 4 | CTU width: one CTU per dword
+  const u32 centre = *reinterpret_cast<const u32 *>(src + (long)y * fw + x);
+  const int type = (int)(rec & 0xff);
+  u32 result = centre;
+  if (type == 1) {
+    const int bp = (int)((rec >> 16) & 0xff);
+    result = 0;
+    for (int k = 0; k < 4; k++) {
+      int v = (centre >> (8 * k)) & 0xff;
+      const int d = (v >> 3) - bp;
+      if (d >= 0 && d <= 3) v = iclip(0, 255, v + (int)(int8_t)(rec >> (24 + 8 * (d + 1))));
+      result |= (u32)v << (8 * k);
+    }
+  } else if (type == 2) {
+    // the 3 x 6 neighbourhood of the four samples: three dwords + the bytes left and right of them (clamped at the picture edge;
+    // samples whose neighbour is really outside keep their value below)
+    const int ym = y > 0 ? y - 1 : y, yp = y + 1 < fh ? y + 1 : y, xm = x > 0 ? x - 1 : x, xp = x + 4 < fw ? x + 4 : x + 3;
+    const u32 up = *reinterpret_cast<const u32 *>(src + (long)ym * fw + x), dn = *reinterpret_cast<const u32 *>(src + (long)yp * fw + x);
+    const unsigned long long row_u = ((unsigned long long)src[(long)ym * fw + xp] << 40) | ((unsigned long long)up << 8) | src[(long)ym * fw + xm];
+    const unsigned long long row_c = ((unsigned long long)src[(long)y * fw + xp] << 40) | ((unsigned long long)centre << 8) | src[(long)y * fw + xm];
+    const unsigned long long row_d = ((unsigned long long)src[(long)yp * fw + xp] << 40) | ((unsigned long long)dn << 8) | src[(long)yp * fw + xm];
+    int ax, ay, bx, by;
+    eo_offsets((int)((rec >> 8) & 0xff), ax, ay, bx, by);
+    const unsigned long long ra = ay < 0 ? row_u : (ay > 0 ? row_d : row_c), rb = by < 0 ? row_u : (by > 0 ? row_d : row_c);
+    result = 0;
+    for (int k = 0; k < 4; k++) {
+      int v = (centre >> (8 * k)) & 0xff;
+      const int xa = x + k + ax, ya = y + ay, xb = x + k + bx, yb = y + by;
+      if (xa >= 0 && xa < fw && ya >= 0 && ya < fh && xb >= 0 && xb < fw && yb >= 0 && yb < fh) {
+        const int a = (int)((ra >> (8 * (k + 1 + ax))) & 0xff), b = (int)((rb >> (8 * (k + 1 + bx))) & 0xff);
+        v = iclip(0, 255, v + (int)(int8_t)(rec >> (24 + 8 * eo_cat(a, b, v))));
+      }
+      result |= (u32)v << (8 * k);
+    }
+  }
+  *reinterpret_cast<u32 *>(out + plane + (long)y * fw + x) = result;
+}
+
 struct DeblockGeom { int W, H, beta, tc, tc_c; long frame_bytes; const u8 *cu_depth; };
 
 __device__ __forceinline__ bool deblock_edge_on(const DeblockGeom &g, long frame, int x, int y, bool vertical)  // filter.c:202-216
@@ -520,6 +592,19 @@ void kvz_hip_dev_sad_surface(const uint8_t *cur, const uint8_t *ref, int width, 
   default: fprintf(stderr, "kvz_hip_dev_sad_surface: unsupported block width %d\n", bw); abort();
   }
   KVZ_HIP_CHECK(hipGetLastError());
+}
+
+void kvz_hip_dev_sao_frames(const uint8_t *in, uint8_t *out, int width, int height, int n_frames, const kvz_hip_sao_params *luma,
+                            const kvz_hip_sao_params *chroma)
+{
+  if (n_frames <= 0) return;
+  const long per_frame = (long)(width >> 2) * height + 2L * (width >> 3) * (height >> 1), total = per_frame * n_frames;
+  const long n_ctus = (long)n_frames * ((width + 63) >> 6) * ((height + 63) >> 6);
+  unsigned long long *packed = nullptr;
+  KVZ_HIP_CHECK(hipMallocAsync((void **)&packed, (size_t)n_ctus * 3 * sizeof(unsigned long long), be().stream));
+  KVZ_DEV_LAUNCH(kvz::dev_sao_pack_kernel, 3 * n_ctus, luma, chroma, n_ctus, packed);
+  KVZ_DEV_LAUNCH(kvz::dev_sao_kernel, total, in, out, width, height, per_frame, total, packed);
+  KVZ_HIP_CHECK(hipFreeAsync(packed, be().stream));
 }
 
 void kvz_hip_dev_picture_checksums(const uint8_t *frames, int width, int height, int n_frames, uint32_t *out)

@@ -910,6 +910,34 @@ void kvz_oracle_sao_reconstruct_color(const kvz_hip_sao_params *sao, const uint8
   }
 }
 
+/* SAO applied to a whole picture: kvz_sao_reconstruct (sao.c:302-361) for every CTU and plane with that CTU's parameters.
+ * `in` is the deblocked picture (tight planar 4:2:0), neighbours are always taken from it (SAO never reads its own output,
+ * H.265 8.7.3); `out` receives the result.  luma[ctu] / chroma[ctu] in raster CTU order; chroma carries U offsets in
+ * offsets[0..4] / band_position[0] and V in offsets[5..9] / band_position[1] (sao.h:55-63). */
+void kvz_oracle_sao_frame(int width, int height, const uint8_t *in, uint8_t *out, const kvz_hip_sao_params *luma, const kvz_hip_sao_params *chroma)
+{
+  const int wc = (width + 63) / 64, hc = (height + 63) / 64;
+  memcpy(out, in, (size_t)width * height * 3 / 2);
+  for (int color = 0; color < 3; color++) {
+    const int sh = color ? 1 : 0, fw = width >> sh, fh = height >> sh, lcu = 64 >> sh;
+    const size_t plane = color == 0 ? 0 : (color == 1 ? (size_t)width * height : (size_t)width * height * 5 / 4);
+    for (int cy = 0; cy < hc; cy++)
+      for (int cx = 0; cx < wc; cx++) {
+        const kvz_hip_sao_params *sao = color ? &chroma[cy * wc + cx] : &luma[cy * wc + cx];
+        if (sao->type == 0) continue;
+        int x = cx * lcu, y = cy * lcu, w = fw - x < lcu ? fw - x : lcu, h = fh - y < lcu ? fh - y : lcu;
+        if (sao->type == 2) {  /* sao.c:324-349: rows / columns whose neighbour would lie outside the picture are left alone */
+          const int ax = g_sao_ofs[sao->eo_class][0][0], ay = g_sao_ofs[sao->eo_class][0][1], bx = g_sao_ofs[sao->eo_class][1][0], by = g_sao_ofs[sao->eo_class][1][1];
+          if (x + w + ax > fw || x + w + bx > fw) w -= 1;
+          if (x + ax < 0 || x + bx < 0) { x += 1; w -= 1; }
+          if (y + h + ay > fh || y + h + by > fh) h -= 1;
+          if (y + ay < 0 || y + by < 0) { y += 1; h -= 1; }
+        }
+        if (w > 0 && h > 0) kvz_oracle_sao_reconstruct_color(sao, in + plane + (size_t)y * fw + x, out + plane + (size_t)y * fw + x, fw, fw, w, h, color);
+      }
+  }
+}
+
 /* sao_shared_generics.h:93-130 */
 int kvz_oracle_sao_band_ddistortion(int bitdepth, const uint8_t *orig, const uint8_t *rec, int bw, int bh, int band_pos, const int sao_bands[4])
 {

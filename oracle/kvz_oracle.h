@@ -121,6 +121,8 @@ void kvz_oracle_calc_sao_edge_dir(int bitdepth, const uint8_t *orig, const uint8
                                   int bh, int cat_sum_cnt[10] /* [2][5], accumulated */);
 void kvz_oracle_sao_reconstruct_color(const kvz_hip_sao_params *sao, const uint8_t *rec /* may be read at -1 row/col */,
                                       uint8_t *new_rec, int stride, int new_stride, int bw, int bh, int color);
+void kvz_oracle_sao_frame(int width, int height, const uint8_t *in, uint8_t *out, const kvz_hip_sao_params *luma,
+                          const kvz_hip_sao_params *chroma);  /* sao.c:302-361 for every CTU and plane */
 int  kvz_oracle_sao_band_ddistortion(int bitdepth, const uint8_t *orig, const uint8_t *rec, int bw, int bh,
                                      int band_pos, const int sao_bands[4]);
 

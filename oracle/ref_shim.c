@@ -268,3 +268,49 @@ void kvz_ref_deblock_frame(int width, int height, int qp, int beta_offset_div2, 
   kvz_cu_array_free(&frame.cu_array);
   g_state.tile = NULL;
 }
+
+/* ---- SAO applied to a whole picture with the reference's own border logic: kvz_sao_reconstruct (sao.c:302-361) per CTU and
+ * plane, input = a separate copy of the deblocked picture (neighbours are pre-SAO samples), output = frame->rec ---- */
+void kvz_ref_sao_frame(int width, int height, const uint8_t *in, uint8_t *out, const kvz_hip_sao_params *luma, const kvz_hip_sao_params *chroma)
+{
+  encoder_state_config_tile_t tile;
+  videoframe_t frame;
+  memset(&tile, 0, sizeof tile);
+  memset(&frame, 0, sizeof frame);
+  frame.width = width; frame.height = height;
+  frame.rec = kvz_image_alloc(KVZ_CSP_420, width, height);
+  kvz_picture *src = kvz_image_alloc(KVZ_CSP_420, width, height);
+  for (int color = 0; color < 3; color++) {
+    const int sh = color ? 1 : 0, fw = width >> sh, fh = height >> sh;
+    const size_t plane = color == 0 ? 0 : (color == 1 ? (size_t)width * height : (size_t)width * height * 5 / 4);
+    for (int r = 0; r < fh; r++) {
+      memcpy(src->data[color] + r * (src->stride >> sh), in + plane + (size_t)r * fw, fw);
+      memcpy(frame.rec->data[color] + r * (frame.rec->stride >> sh), in + plane + (size_t)r * fw, fw);
+    }
+  }
+  tile.frame = &frame;
+  g_state.tile = &tile;
+  const int wc = (width + 63) / 64, hc = (height + 63) / 64;
+  for (int color = 0; color < 3; color++) {
+    const int sh = color ? 1 : 0, fw = width >> sh, fh = height >> sh, lcu = 64 >> sh;
+    for (int cy = 0; cy < hc; cy++)
+      for (int cx = 0; cx < wc; cx++) {
+        const kvz_hip_sao_params *s = color ? &chroma[cy * wc + cx] : &luma[cy * wc + cx];
+        sao_info_t sao;
+        memset(&sao, 0, sizeof sao);
+        sao.type = (sao_type)s->type; sao.eo_class = (sao_eo_class)s->eo_class;
+        sao.band_position[0] = s->band_position[0]; sao.band_position[1] = s->band_position[1];
+        for (int i = 0; i < 10; i++) sao.offsets[i] = s->offsets[i];
+        const int x = cx * lcu, y = cy * lcu, w = fw - x < lcu ? fw - x : lcu, h = fh - y < lcu ? fh - y : lcu;
+        kvz_sao_reconstruct(&g_state, src->data[color] + y * (src->stride >> sh) + x, src->stride >> sh, x, y, w, h, &sao, (color_t)color);
+      }
+  }
+  for (int color = 0; color < 3; color++) {
+    const int sh = color ? 1 : 0, fw = width >> sh, fh = height >> sh;
+    const size_t plane = color == 0 ? 0 : (color == 1 ? (size_t)width * height : (size_t)width * height * 5 / 4);
+    for (int r = 0; r < fh; r++) memcpy(out + plane + (size_t)r * fw, frame.rec->data[color] + r * (frame.rec->stride >> sh), fw);
+  }
+  kvz_image_free(frame.rec);
+  kvz_image_free(src);
+  g_state.tile = NULL;
+}

@@ -8,6 +8,7 @@ Fixtures (small, committed; the GPU box and any machine without the reference tr
   strategy_cases.json   sha256 of the reference's GENERIC strategy output for every seeded case of tests/cases.py
                         (label -> digest of repr(outputs)), incl. tests/cases.py cases_find_last_scanpos
   deblock.json          sha256 of kvz_filter_deblock_lcu's result (filter.c:783, all LCUs) for seeded pictures / CU quadtrees
+  sao_frame.json        sha256 of kvz_sao_reconstruct's result (sao.c:302-361, every CTU and plane) for seeded pictures / parameters
 (the bitstream md5s of the reference encoder are asserted by tests/test_e2e_dropin.py)
 tests/test_oracle_golden.py holds the known answers of the reference's own unit tests; this file adds outputs of the
 compiled reference for the functions those tests do not pin."""
@@ -60,6 +61,19 @@ def deblock_digests(func):
     return out
 
 
+def sao_digests(func):
+    import sao_common as sc
+    out = {}
+    for (w, h, seed) in ((64, 64, 11), (136, 72, 12), (416, 240, 13)):
+        rng = np.random.default_rng(seed)
+        n = ((w + 63) // 64) * ((h + 63) // 64)
+        for trial in range(3):
+            frame = rng.integers(0, 256, w * h * 3 // 2, dtype=np.uint8)
+            luma, chroma = sc.random_params(rng, n, False), sc.random_params(rng, n, True)
+            out[f"{w}x{h}/{trial}"] = hashlib.sha256(sc.run_cpu(func, w, h, frame, luma, chroma).tobytes()).hexdigest()[:24]
+    return out
+
+
 def main():
     ref = flatapi.load_ref(0)  # generic strategies
     oracle = flatapi.load_oracle()
@@ -70,7 +84,8 @@ def main():
 
     json.dump(strategy_digests(ref, scan_table), open(os.path.join(HERE, "strategy_cases.json"), "w"), indent=0, sort_keys=True)
     json.dump(deblock_digests(ref.lib.kvz_ref_deblock_frame), open(os.path.join(HERE, "deblock.json"), "w"), indent=0, sort_keys=True)
-    print("wrote strategy_cases.json, deblock.json")
+    json.dump(sao_digests(ref.lib.kvz_ref_sao_frame), open(os.path.join(HERE, "sao_frame.json"), "w"), indent=0, sort_keys=True)
+    print("wrote strategy_cases.json, deblock.json, sao_frame.json")
 
 
 if __name__ == "__main__":

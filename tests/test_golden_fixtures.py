@@ -43,6 +43,10 @@ def test_oracle_deblock_reproduces_reference_fixtures(oracle):
     assert mg.deblock_digests(oracle.lib.kvz_oracle_deblock_frame) == _fixture("deblock.json")
 
 
+def test_oracle_sao_frame_reproduces_reference_fixtures(oracle):
+    assert mg.sao_digests(oracle.lib.kvz_oracle_sao_frame) == _fixture("sao_frame.json")
+
+
 @pytest.mark.gpu
 def test_hip_reproduces_reference_fixtures(oracle):
     import kvazaar_amd

@@ -167,3 +167,28 @@ def test_dev_sad_surface(oracle, dev, bw, rng_):
         for dx, dy in picks:
             want = oracle.image_calc_sad(flatapi.ptr(cur), w, flatapi.ptr(ref), w, h, w, x, y, x + int(dx), y + int(dy), bw, bw)
             assert got[b, dy + rng_, dx + rng_] == want, (b, dx, dy)
+
+
+@pytest.mark.parametrize("size", [(64, 64), (136, 72), (416, 240), (1920, 1080)])
+def test_dev_sao_frames(oracle, dev, size):
+    """device SAO over a batch of frames == the oracle's kvz_sao_reconstruct restatement (pinned against the compiled reference
+    in tests/test_oracle_vs_ref.py), random per-CTU parameters"""
+    import ctypes as C
+    import sao_common as sc
+    w, h = size
+    rng = np.random.default_rng(2 * w + h)
+    nf, n = 3, ((w + 63) // 64) * ((h + 63) // 64)
+    frames = rng.integers(0, 256, (nf, w * h * 3 // 2), dtype=np.uint8)
+    lumas = [sc.random_params(rng, n, False) for _ in range(nf)]
+    chromas = [sc.random_params(rng, n, True) for _ in range(nf)]
+    din, dout = dev.put(frames), dev.empty(frames.nbytes)
+    dl = dev.put(np.frombuffer(b"".join(bytes(x) for x in lumas), dtype=np.uint8))
+    dc_ = dev.put(np.frombuffer(b"".join(bytes(x) for x in chromas), dtype=np.uint8))
+    dev.lib.kvz_hip_dev_sao_frames.restype = None
+    dev.lib.kvz_hip_dev_sao_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    dev.lib.kvz_hip_dev_sao_frames(din, dout, w, h, nf, dl, dc_)
+    got = dev.get(dout, frames.shape, np.uint8)
+    dev.free(din, dout, dl, dc_)
+    for f in range(nf):
+        want = sc.run_cpu(oracle.lib.kvz_oracle_sao_frame, w, h, frames[f], lumas[f], chromas[f])
+        assert np.array_equal(got[f], want), (f, np.flatnonzero(got[f] != want)[:8])

@@ -93,3 +93,20 @@ def test_deblock_frame_matches_reference(oracle, reflib, size):
         assert np.array_equal(a, b), (kind, qp, b_off, t_off, np.flatnonzero(a != b)[:8])
         if kind != "noise" and qp >= 22:
             assert not np.array_equal(a, frame), "the filter should have changed something"
+
+
+@pytest.mark.parametrize("size", [(64, 64), (136, 72), (416, 240)])
+def test_sao_frame_matches_reference(oracle, reflib, size):
+    """kvz_oracle_sao_frame == the reference's kvz_sao_reconstruct (sao.c:302-361) called per CTU and plane with a separate copy
+    of the deblocked picture as input: random per-CTU types, classes, band positions and offsets"""
+    import sao_common as sc
+    w, h = size
+    rng = np.random.default_rng(w + 3 * h)
+    n = ((w + 63) // 64) * ((h + 63) // 64)
+    for _ in range(4):
+        frame = rng.integers(0, 256, w * h * 3 // 2, dtype=np.uint8)
+        luma, chroma = sc.random_params(rng, n, False), sc.random_params(rng, n, True)
+        a = sc.run_cpu(oracle.lib.kvz_oracle_sao_frame, w, h, frame, luma, chroma)
+        b = sc.run_cpu(reflib.lib.kvz_ref_sao_frame, w, h, frame, luma, chroma)
+        assert np.array_equal(a, b), np.flatnonzero(a != b)[:8]
+        assert not np.array_equal(a, frame)
