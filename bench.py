@@ -201,6 +201,20 @@ def main():
                          "avg_launch_us": per_launch_s * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "instruction-issue / latency-bound CTU search, not a streaming kernel (DESIGN.md 5); per-kernel HBM and MFMA fractions of the streaming primitives: bench_kernels.py"},
         }
+        # auxiliary: the per-picture chain an encoder needs from the device before entropy coding -- CTU pass, deblocking, picture
+        # hash -- timed the same way on rank 0's batches (not the headline: BASELINE's metric is the CTU pass)
+        lib.kvz_hip_batch_deblock.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        lib.kvz_hip_batch_checksums.argtypes = [C.c_void_p, C.c_void_p]
+        sums = [np.zeros((n, 3), np.uint32) for _, _, n in batches]
+        t0 = time.perf_counter()
+        for b, _, _ in batches:
+            lib.kvz_hip_intra_frames(b.handle, C.byref(model))
+            lib.kvz_hip_batch_deblock(b.handle, args.qp, 0, 0)
+        for (b, _, _), o in zip(batches, sums):
+            lib.kvz_hip_batch_checksums(b.handle, o.ctypes.data)
+        chain_s = time.perf_counter() - t0
+        result["chain"] = {"stages": "CTU pass + deblocking + picture-hash checksums (rank 0)", "value": sum(c * n for _, c, n in batches) / chain_s,
+                           "unit": "CTUs/s", "ms": chain_s * 1e3}
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, distinct, model)
         print(json.dumps(result))

@@ -55,6 +55,10 @@ int   kvz_hip_batch_profile(kvz_hip_batch *b, unsigned long long *out, int n);
  * deblocked picture.  The next kvz_hip_intra_frames() overwrites the reconstruction. */
 void kvz_hip_batch_deblock(kvz_hip_batch *b, int qp, int beta_offset_div2, int tc_offset_div2);
 
+/* Picture-hash checksums (nal.c:73-86 kvz_image_checksum) of every frame's current reconstruction: host_out[3 * f + plane].
+ * Queued behind whatever the batch's stream holds (CTU pass, deblocking) and waited for. */
+void kvz_hip_batch_checksums(kvz_hip_batch *b, uint32_t *host_out);
+
 /* Frozen-context cost model of an I slice at `qp` (kvz_hip_intra_cost_model): HEVC context init values
  * (context.c:96-134), kvz_ctx_init (context.c:202-213), the HM entropy table (rdo.c:69-80), lambda of
  * rate_control.c:678-691.  coeff_weights = kvz_fast_coeff_get_weights(state) of the encoder (fast_coeff_cost.c:84-88). */

@@ -620,4 +620,20 @@ void kvz_hip_batch_deblock(kvz_hip_batch *b, int qp, int beta_offset_div2, int t
   kvz::deblock_frames_on(b->stream, b->d_rec, b->F.W, b->F.H, b->n_frames, b->d_depth, qp, beta_offset_div2, tc_offset_div2);
 }
 
+void kvz_hip_batch_checksums(kvz_hip_batch *b, uint32_t *host_out)
+{
+  const int n = b->n_frames;
+  if (n <= 0) return;
+  uint32_t *d = nullptr;
+  KVZ_HIP_CHECK(hipMallocAsync((void **)&d, (size_t)n * 3 * sizeof(uint32_t), b->stream));
+  KVZ_HIP_CHECK(hipMemsetAsync(d, 0, (size_t)n * 3 * sizeof(uint32_t), b->stream));
+  const long per_frame = (long)(b->F.W >> 2) * b->F.H + 2L * (b->F.W >> 3) * (b->F.H >> 1), total = per_frame * n;
+  hipLaunchKernelGGL(kvz::dev_checksum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, b->stream, b->d_rec, b->F.W, b->F.H,
+                     (long)b->F.W * b->F.H * 3 / 2, per_frame, total, d);
+  KVZ_HIP_CHECK(hipGetLastError());
+  KVZ_HIP_CHECK(hipMemcpyAsync(host_out, d, (size_t)n * 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+  KVZ_HIP_CHECK(hipFreeAsync(d, b->stream));
+  KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+}
+
 }  // extern "C"

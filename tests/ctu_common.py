@@ -106,6 +106,13 @@ class HipBatch:
         self.lib.kvz_hip_batch_deblock(self.handle, qp, beta_offset_div2, tc_offset_div2)
         self.lib.kvz_hip_batch_sync(self.handle)
 
+    def checksums(self):
+        out = np.zeros((self.n, 3), np.uint32)
+        self.lib.kvz_hip_batch_checksums.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.kvz_hip_batch_checksums.restype = None
+        self.lib.kvz_hip_batch_checksums(self.handle, out.ctypes.data)
+        return out
+
     def kernel_ms(self):
         return self.lib.kvz_hip_batch_last_kernel_ms(self.handle)
 

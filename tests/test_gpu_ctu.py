@@ -136,6 +136,10 @@ def test_batch_deblock_after_ctu_pass(oracle, hiplib):
         got = batch.download(i)["rec"]
         assert np.array_equal(got, want), i
         assert not np.array_equal(want, o["rec"])
+        ys, cs = w * h, w * h // 4
+        sums = [oracle.plane_checksum(flatapi.ptr(want), h, w, w), oracle.plane_checksum(flatapi.ptr(want, offset=ys), h // 2, w // 2, w // 2),
+                oracle.plane_checksum(flatapi.ptr(want, offset=ys + cs), h // 2, w // 2, w // 2)]
+        assert list(batch.checksums()[i]) == sums
     batch.close()
 
 
