@@ -54,8 +54,9 @@ def pmc_traffic(args, launches):
 
 
 def cpu_baseline(args, frames, model):
-    """The oracle's restatement of the same pass (kind "port") on ONE host core over a bounded sample of the same
-    frames, plus -- when the prebuilt reference encoder is present -- kvazaar's own AVX2 encoder on all host cores."""
+    """kvazaar's own AVX2 encoder (oracle/_ref, built from the reference sources) on all host cores over 64 of the benchmark's
+    frames (kind "reference"), with the oracle's single-core restatement of exactly this pass nested as "port"; only the port when
+    the prebuilt reference encoder is absent."""
     import ctu_common as cc
     import flatapi
     out = {}
@@ -87,9 +88,12 @@ def cpu_baseline(args, frames, model):
                     times.append(time.time() - t)
             best = sorted(times)[len(times) // 2] if times else None
             if best:
-                out["reference_encoder"] = {
-                    "value": nf * ((args.width + 63) // 64) * ((args.height + 63) // 64) / best, "unit": "CTUs/s", "cores": threads,
-                    "kind": "reference", "sample": f"oracle/_ref/kvazaar_ref (AVX2, whole encoder incl. CABAC+deblock) --preset ultrafast -p 1 --threads {threads}, {nf} frames, median of 3, wall incl. file read"}
+                # the reference's own CPU path is the headline baseline; the single-core port of exactly this pass rides along
+                port = dict(out)
+                out = {"value": nf * ((args.width + 63) // 64) * ((args.height + 63) // 64) / best, "unit": "CTUs/s", "cores": threads, "kind": "reference",
+                       "sample": f"oracle/_ref/kvazaar_ref (kvazaar's AVX2 strategies, whole encoder incl. CABAC + deblocking) --preset ultrafast -p 1 --threads {threads}, "
+                                 f"{nf} frames of the benchmark's clip, median of 3, wall incl. file read",
+                       "port": port}
     return out
 
 
