@@ -76,7 +76,13 @@ typedef struct kvz_hip_intra_cost_model {
   float    cbf_chroma[2][2];  /* ctx.qt_cbf_model_chroma[0..1]   (search.c:463-470) */
   uint64_t coeff_weights;     /* kvz_fast_coeff_get_weights(state): 4 x Q8.8 (fast_coeff_cost.c:84-88) */
   int32_t  qp;                /* state->qp (constant over the frame) */
-  int32_t  reserved;
+  /* adaptive != 0: the contexts evolve exactly as in kvazaar -- updated by the mock encode of every CU the search evaluates
+   * with the save / restore points of search_cu (search.c:655-1060), by the real syntax of every finished CTU in coding order
+   * (encode_coding_tree.c:745), and handed from CTU to CTU along a row and from the second CTU of a row to the row below
+   * (WPP, encoderstate.c:763-771).  The float tables above are then unused; ctx_init / entropy_fbits drive the pricing. */
+  int32_t  adaptive;
+  uint8_t  ctx_init[16];      /* uc_state at slice start of: split_flag[0..2], part_size[0], intra_mode, chroma_pred[0], cbf_luma[0..1], cbf_chroma[0..1] */
+  float    entropy_fbits[128];/* kvz_f_entropy_bits (rdo.c:69-83) */
 } kvz_hip_intra_cost_model;
 
 /* Per-CTU result record of the batched pass: what kvazaar keeps in cu_array / lcu_t for the CTU. */

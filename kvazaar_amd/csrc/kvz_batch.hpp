@@ -1,5 +1,5 @@
 // kvz_batch.hpp -- host side of the batched CTU pass: device buffers of a frame batch, the wave-front launch
-// schedule and the frozen-context cost model.  Included by kvz_hip.hip only.
+// schedule and the cost model.  Included by kvz_hip.hip only.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -21,11 +21,11 @@ namespace kvz {
 #ifndef KVZ_CTU_WAVES_PER_EU
 #define KVZ_CTU_WAVES_PER_EU 4  /* 8 workgroups of 128 lanes per CU = 4 wavefronts per SIMD at 128 VGPRs (LDS 16.5 KB would allow 9, but 96 VGPRs cost more than the ninth workgroup gives: profiles/experiments/r01_ab13*) */
 #endif
-__global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) intra_ctu_wave_kernel(const CtuFrames F, const kvz_hip_intra_cost_model model, const Tables *tb,
+__global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) intra_ctu_wave_kernel(const CtuFrames F, const CtuModel model, const Tables *tb,
                                                                         const int wave, const int y_min, const int n_diag)
 {
   __shared__ CtuShared shared;
-  __shared__ kvz_hip_intra_cost_model m;
+  __shared__ CtuModel m;  // scalars in LDS; its price table stays in HBM (kvz_hip_batch::d_entropy)
   if (threadIdx.x == 0) m = model;
   __syncthreads();
   CtuProgram p;
@@ -64,11 +64,11 @@ __device__ __forceinline__ bool wait_done(unsigned *flag, unsigned epoch, unsign
   }
 }
 
-__global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) KVZ_CTU_VGPR_ATTR intra_ctu_ticket_kernel(const CtuFrames F, const kvz_hip_intra_cost_model model, const Tables *tb,
+__global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) KVZ_CTU_VGPR_ATTR intra_ctu_ticket_kernel(const CtuFrames F, const CtuModel model, const Tables *tb,
                                                                         const CtuSched sched)
 {
   __shared__ CtuShared shared;
-  __shared__ kvz_hip_intra_cost_model m;
+  __shared__ CtuModel m;  // scalars in LDS; its price table stays in HBM (kvz_hip_batch::d_entropy)
   __shared__ unsigned s_ticket;
   if (threadIdx.x == 0) m = model;
   const int ctus = F.wc * F.hc;
@@ -114,6 +114,7 @@ struct kvz_hip_batch {
   double *d_cost;
   uint8_t *d_border;
   unsigned long long *d_prof;
+  float *d_entropy;  // the model's entropy_fbits of the run in flight
   uint32_t *d_items;
   unsigned *d_ticket, *d_done, *d_error;
   unsigned total_items, epoch;
@@ -153,16 +154,21 @@ inline void cost_model_init(int qp, uint64_t coeff_weights, kvz_hip_intra_cost_m
   m->lambda = 0.57 * pow(2.0, (qp - 12) / 3.0);
   m->lambda_sqrt = sqrt(m->lambda);
   m->coeff_weights = coeff_weights;
+  for (int i = 0; i < 128; i++) m->entropy_fbits[i] = (float)kEntropyBits[i] / 32768.0f;
+  int n = 0;
   auto fill = [&](float dst[2], int init) {
     const int st = ctx_state(qp, init);
-    dst[0] = (float)kEntropyBits[st ^ 0] / 32768.0f;
-    dst[1] = (float)kEntropyBits[st ^ 1] / 32768.0f;
+    m->ctx_init[n++] = (uint8_t)st;  // same order as the KVZ_CX_* indices
+    dst[0] = m->entropy_fbits[st ^ 0];
+    dst[1] = m->entropy_fbits[st ^ 1];
   };
   for (int i = 0; i < 3; i++) fill(m->split_flag[i], init_split[i]);
   fill(m->part_size, 184);
   fill(m->intra_mode, 184);
   fill(m->chroma_mode, 63);
-  for (int i = 0; i < 2; i++) { fill(m->cbf_luma[i], init_cbf_luma[i]); fill(m->cbf_chroma[i], init_cbf_chroma[i]); }
+  for (int i = 0; i < 2; i++) fill(m->cbf_luma[i], init_cbf_luma[i]);
+  for (int i = 0; i < 2; i++) fill(m->cbf_chroma[i], init_cbf_chroma[i]);
+  m->adaptive = 1;
 }
 
 }  // namespace kvz
@@ -198,6 +204,7 @@ kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_prof, 2 * kvz::KVZ_P_COUNT * sizeof(unsigned long long)));
   KVZ_HIP_CHECK(hipMemsetAsync(b->d_prof, 0, 2 * kvz::KVZ_P_COUNT * sizeof(unsigned long long), b->stream));
   F.prof = b->d_prof;
+  KVZ_HIP_CHECK(hipMalloc((void **)&b->d_entropy, 128 * sizeof(float)));
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_border, nctu * KVZ_BORDER_BYTES));
   KVZ_HIP_CHECK(hipMemsetAsync(b->d_border, 0, nctu * KVZ_BORDER_BYTES, b->stream));
   F.border = b->d_border;
@@ -240,7 +247,7 @@ void kvz_hip_batch_destroy(kvz_hip_batch *b)
 {
   if (!b) return;
   (void)hipStreamSynchronize(b->stream);
-  (void)hipFree(b->d_border); (void)hipFree(b->d_items); (void)hipFree(b->d_done); (void)hipFree(b->d_ticket); (void)hipFree(b->d_prof);
+  (void)hipFree(b->d_border); (void)hipFree(b->d_items); (void)hipFree(b->d_done); (void)hipFree(b->d_ticket); (void)hipFree(b->d_prof); (void)hipFree(b->d_entropy);
   (void)hipFree(b->d_src); (void)hipFree(b->d_rec); (void)hipFree(b->d_coeff); (void)hipFree(b->d_scratch); (void)hipFree(b->d_depth); (void)hipFree(b->d_mode); (void)hipFree(b->d_cost);
   (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1);
   (void)hipStreamDestroy(b->stream);
@@ -279,12 +286,16 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
 {
   const kvz::CtuFrames &F = b->F;
   int launches = 0;
+  kvz::CtuModel cm;
+  kvz::ctu_model_from(model, &cm);
+  cm.entropy_fbits = b->d_entropy;
+  KVZ_HIP_CHECK(hipMemcpyAsync(b->d_entropy, model->entropy_fbits, 128 * sizeof(float), hipMemcpyHostToDevice, b->stream));
   if (b->sched_ticket) {
     b->epoch++;
     KVZ_HIP_CHECK(hipMemsetAsync(b->d_ticket, 0, 2 * sizeof(unsigned), b->stream));
     KVZ_HIP_CHECK(hipEventRecord(b->ev0, b->stream));
     kvz::CtuSched sc{ b->d_items, b->d_ticket, b->d_done, b->d_error, b->total_items, b->epoch };
-    hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, *model, kvz::device_tables(), sc);
+    hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);
     KVZ_HIP_CHECK(hipGetLastError());
     KVZ_HIP_CHECK(hipEventRecord(b->ev1, b->stream));
     return 1;
@@ -299,7 +310,7 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
     if (y_max > F.hc - 1) y_max = F.hc - 1;
     const int n_diag = y_max - y_min + 1;
     if (n_diag <= 0) continue;
-    hipLaunchKernelGGL(kvz::intra_ctu_wave_kernel, dim3(n_diag * b->n_frames), dim3(KVZ_CTU_THREADS), 0, b->stream, F, *model, kvz::device_tables(), wave,
+    hipLaunchKernelGGL(kvz::intra_ctu_wave_kernel, dim3(n_diag * b->n_frames), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), wave,
                        y_min, n_diag);
     launches++;
   }

@@ -127,6 +127,26 @@ KVZ_DEV u8 load_shared_byte(const u8 *p)
 
 struct CtuCu { u8 type, depth, mode, tr_depth; uint16_t cbf; uint16_t pad; };  // one per 8x8 (min CU)
 
+// The ten CABAC contexts the all-intra search prices syntax with (cabac.h:63-100), each as kvazaar's uc_state = state << 1 | MPS
+enum { KVZ_CX_SPLIT = 0 /* ..2 */, KVZ_CX_PART = 3, KVZ_CX_INTRA = 4, KVZ_CX_CHROMA = 5, KVZ_CX_CBF_LUMA = 6 /* ..7 */, KVZ_CX_CBF_CHROMA = 8 /* ..9 */, KVZ_CX_COUNT = 10 };
+struct CtxSet { u8 s[12]; };
+
+// What the CTU program reads of kvz_hip_intra_cost_model, compact (the device keeps it in LDS; the 128-entry price table stays
+// behind a pointer: a copy in HBM on the device)
+struct CtuModel {
+  double lambda, lambda_sqrt;
+  uint64_t coeff_weights;
+  int qp, adaptive;
+  u8 ctx_init[16];
+  const float *entropy_fbits;
+};
+KVZ_HD void ctu_model_from(const kvz_hip_intra_cost_model *src, CtuModel *dst)
+{
+  dst->lambda = src->lambda; dst->lambda_sqrt = src->lambda_sqrt; dst->coeff_weights = src->coeff_weights; dst->qp = src->qp; dst->adaptive = src->adaptive;
+  for (int i = 0; i < 16; i++) dst->ctx_init[i] = src->ctx_init[i];
+  dst->entropy_fbits = src->entropy_fbits;
+}
+
 // Frame-level device buffers of one batch (all frames share the geometry).
 struct CtuFrames {
   int W, H, wc, hc;          // luma size, CTU grid
@@ -141,6 +161,8 @@ struct CtuFrames {
   // What a CTU hands to its right / lower neighbours: KVZ_BORDER_BYTES per CTU = three 128-byte lines with ONE producer each
   //   [0..127]   bottom row   Y 64 | U 32 | V 32        [128..255] right column Y 64 | U 32 | V 32
   //   [256..287] CU info: depth of the bottom 8x8 row [8], mode [8], depth of the right 8x8 column [8], mode [8]
+  //   [288..297] the row's CABAC contexts after this CTU's syntax (KVZ_CX_*): what the CTU to the right starts from, and -- from
+  //              the second CTU of a row -- the first CTU of the row below (WPP, encoderstate.c:763-771)
   // Neighbour data is exchanged ONLY through these records: the frame-level rec / cu arrays share cache lines between CTUs
   // produced on different XCDs, and a line that is dirty in the reader's L2 cannot be invalidated by its acquire.
   u8 *border;                // [frames][ctu][KVZ_BORDER_BYTES]
@@ -209,12 +231,16 @@ struct CtuShared {
   int16_t mode_inv[35];      //   inverse angle, and whether the mode projects on the top reference
   QuantScalars qs[4][2];     // [log2w - 2][0 luma / 1 chroma] for this QP (quant-generic.c:57-66, 303-339)
   double mode_bits_cost[3];  // lambda_sqrt * kvz_luma_mode_bits for: not an MPM, MPM 0, MPM 1/2
+  // CABAC contexts (lane 0 only).  cab = state->search_cabac while the CTU is searched; pre[d] = its value when search_cu entered
+  // depth d (search.c:655; pre[0] is the row's state->cabac the search started from, search.c:1211, and what the CTU's real syntax
+  // is replayed on afterwards); post2 = after the 16x16 CU was evaluated (search.c:956)
+  CtxSet cab, pre[3], post2;
 };
 
 static const int kPlaneOff[3] = { 0, 4096, 5120 };
 
 struct CtuProgram {
-  const kvz_hip_intra_cost_model *m;
+  const CtuModel *m;
   const Tables *tb;
   CtuFrames F;
   CtuShared *s;
@@ -332,13 +358,34 @@ struct CtuProgram {
       if (l && a) preds[2] = 0; else preds[2] = (l + a) < 2 ? 26 : 1;
     }
   }
+  // CABAC_FBITS_UPDATE (cabac.h:133-139) on context idx of `c`: the price of `bin` (CTX_ENTROPY_FBITS, cabac.h:131), then -- if
+  // `update`, and unless the model freezes the contexts at their slice-start state -- the transition kvz_cabac_encode_bin
+  // applies (cabac.c:104-132).  One lane.
+  KVZ_DEV double ctx_price(CtxSet *c, int idx, int bin, bool update) const
+  {
+    const int st = c->s[idx];
+    const double bits = (double)m->entropy_fbits[st ^ bin];
+    if (update && m->adaptive) c->s[idx] = tb->ctx_next[bin != (st & 1)][st];
+    return bits;
+  }
+  KVZ_DEV void ctx_code(CtxSet *c, int idx, int bin) const { const int st = c->s[idx]; c->s[idx] = tb->ctx_next[bin != (st & 1)][st]; }
+  // lambda_sqrt * kvz_luma_mode_bits of the three possible outcomes at the current state of the intra-mode context; the rough
+  // search prices with it without touching the context (search_intra.c:524: search_cabac.update == 0 there).  One lane.
+  KVZ_DEV void price_modes() const
+  {
+    const int st = s->cab.s[KVZ_CX_INTRA];
+    const double f0 = (double)m->entropy_fbits[st ^ 0], f1 = (double)m->entropy_fbits[st ^ 1];
+    s->mode_bits_cost[0] = m->lambda_sqrt * (f0 + 5);
+    s->mode_bits_cost[1] = m->lambda_sqrt * (f1 + 1);
+    s->mode_bits_cost[2] = m->lambda_sqrt * (f1 + 2);
+  }
   // search_intra.c:641-676 kvz_luma_mode_bits
-  KVZ_DEV double luma_mode_bits(int mode, const int8_t preds[3]) const
+  KVZ_DEV double luma_mode_bits(CtxSet *c, int mode, const int8_t preds[3], bool update) const
   {
     double bits = 0;
     int in = 0;
     for (int i = 0; i < 3; i++) if (mode == preds[i]) in = 1;
-    bits += (double)m->intra_mode[in];
+    bits += ctx_price(c, KVZ_CX_INTRA, in, update);
     if (in) bits += (mode == preds[0]) ? 1 : 2; else bits += 5;
     return bits;
   }
@@ -351,30 +398,43 @@ struct CtuProgram {
     return model;
   }
   // `known_preds`: the CU's most probable modes when the caller already has them (rough_search derives the same three from
-  // the same neighbours: for the 8-aligned CU origins x >= 4 <=> x > 0 and yl > 0 <=> (y & 63) > 0)
-  KVZ_DEV double intra_mode_syntax_bits(int lv, int x, int y, int mode, const int8_t *known_preds = nullptr) const
+  // the same neighbours: for the 8-aligned CU origins x >= 4 <=> x > 0 and yl > 0 <=> (y & 63) > 0).
+  // `mock`: the mock encode looks its left neighbour up at LCU-local column SUB_SCU(x - 1) (encode_coding_tree.c:516), which
+  // for a CU on the LCU's left edge is column 63 of the work tree -- a cell the z-order search has not reached yet (CU_NOTSET),
+  // so the left candidate falls back to DC there; calc_mode_bits (search.c:566) and the real encode use the true neighbour.
+  KVZ_DEV double intra_mode_syntax_bits(CtxSet *c, bool update, int lv, int x, int y, int mode, bool mock, const int8_t *known_preds = nullptr) const
   {
     int8_t preds[3];
-    if (known_preds) { preds[0] = known_preds[0]; preds[1] = known_preds[1]; preds[2] = known_preds[2]; }
+    const bool no_left = mock && (x & 63) == 0;
+    if (known_preds && !(no_left && x > 0)) { preds[0] = known_preds[0]; preds[1] = known_preds[1]; preds[2] = known_preds[2]; }
     else {
       CtuCu lc, ac, *left = nullptr, *above = nullptr;
-      if (x > 0 && neighbour_cu(lv, x - 1, y, &lc)) left = &lc;
+      if (x > 0 && !no_left && neighbour_cu(lv, x - 1, y, &lc)) left = &lc;
       if ((y & 63) > 0 && y > 0 && neighbour_cu(lv, x, y - 1, &ac)) above = &ac;
       mpm_candidates(y, left, above, preds);
     }
-    double bits = luma_mode_bits(mode, preds);
-    bits += (double)m->chroma_mode[0];
+    double bits = luma_mode_bits(c, mode, preds, update);
+    bits += ctx_price(c, KVZ_CX_CHROMA, 0, update);
     return bits;
   }
-  // encode_coding_tree.c:948-1049 kvz_mock_encode_coding_unit, intra 2Nx2N in an I slice
+  // encode_coding_tree.c:948-1049 kvz_mock_encode_coding_unit, intra 2Nx2N in an I slice; updates the search contexts
   KVZ_DEV double cu_bits(int lv, int x, int y, int depth, int mode, const int8_t *known_preds = nullptr) const
   {
     double bits = 0;
     const int w = 64 >> depth;
-    if (depth != 3 && !(F.W < x + w || F.H < y + w)) bits += (double)m->split_flag[split_model(lv, x, y, depth)][0];
-    if (depth == 3) bits += (double)m->part_size[1];
-    bits += intra_mode_syntax_bits(lv, x, y, mode, known_preds);
+    if (depth != 3 && !(F.W < x + w || F.H < y + w)) bits += ctx_price(&s->cab, KVZ_CX_SPLIT + split_model(lv, x, y, depth), 0, true);
+    if (depth == 3) bits += ctx_price(&s->cab, KVZ_CX_PART, 1, true);
+    bits += intra_mode_syntax_bits(&s->cab, true, lv, x, y, mode, true, known_preds);
     return bits;
+  }
+  // cost of cu_split_flag = 1 at (x, y, depth) added to split_cost (search.c:962-971); updates the search contexts
+  KVZ_DEV double split_flag_cost(int lv, int x, int y, int depth) const
+  {
+    double sb = 0;
+    sb += ctx_price(&s->cab, KVZ_CX_SPLIT + split_model(lv, x, y, depth), 1, true);
+    double sc = 0.0;
+    sc += sb * m->lambda;
+    return sc;
   }
 
   // ---------------------------------------------------------------- phases
@@ -903,14 +963,14 @@ struct CtuProgram {
   }
 
   // search.c:425-541 cu_rd_cost_tr_split_accurate for one leaf TU group whose sums sit in s->acc (lane 0 only)
-  KVZ_DEV double leaf_rd_cost(int lv, int xl, int yl, int depth, int cu_depth, bool code_cbf_u, bool code_cbf_v) const
+  KVZ_DEV double leaf_rd_cost(CtxSet *c, bool update, int lv, int xl, int yl, int depth, int cu_depth, bool code_cbf_u, bool code_cbf_v) const
   {
     const CtuCu *tr_cu = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
     double tr_tree_bits = 0, coeff_bits = 0;
     const int cb_u = cbf_is_set(tr_cu->cbf, depth, 1), cb_v = cbf_is_set(tr_cu->cbf, depth, 2), cb_y = cbf_is_set(tr_cu->cbf, depth, 0);
-    if (code_cbf_u) tr_tree_bits += (double)m->cbf_chroma[depth - cu_depth][cb_u];
-    if (code_cbf_v) tr_tree_bits += (double)m->cbf_chroma[depth - cu_depth][cb_v];
-    tr_tree_bits += (double)m->cbf_luma[depth == cu_depth ? 1 : 0][cb_y];
+    if (code_cbf_u) tr_tree_bits += ctx_price(c, KVZ_CX_CBF_CHROMA + depth - cu_depth, cb_u, update);
+    if (code_cbf_v) tr_tree_bits += ctx_price(c, KVZ_CX_CBF_CHROMA + depth - cu_depth, cb_v, update);
+    tr_tree_bits += ctx_price(c, KVZ_CX_CBF_LUMA + (depth == cu_depth ? 1 : 0), cb_y, update);
     if (cb_y) coeff_bits += (double)s->acc[3] / 256.0;
     if (cb_u) coeff_bits += (double)s->acc[4] / 256.0;
     if (cb_v) coeff_bits += (double)s->acc[5] / 256.0;
@@ -944,6 +1004,10 @@ struct CtuProgram {
         const double r = split_won ? s->split_cost[res_depth] : s->cost[res_depth];
         s->res[res_depth] = r;
         if (res_depth > 0) s->split_cost[res_depth - 1] += r;  // the parent's running sum (search.c:1005-1010)
+        // search.c:1051: an unsplit CU below depth 0 continues from the contexts as they were after it was priced -- for a merge
+        // those at entry, since the merge is priced with updates off (search.c:1005-1041)
+        if (!split_won && res_depth == 2) s->cab = s->post2;
+        if (!split_won && res_depth == 1) s->cab = s->pre[1];
       }
       const int n = w >> 3, lw = w == 16 ? 4 : (w == 32 ? 5 : 6), ln = lw - 3, cw = w >> 1;
       if (tid < n * n) {
@@ -997,9 +1061,9 @@ struct CtuProgram {
     recon_tus(lv, t, depth, mode, true);
     KVZ_FOR_THREADS(tid) {
       if (tid == 0) {
-        const double bits = cu_bits(lv, x, y, depth, mode, s->preds);
+        const double bits = cu_bits(lv, x, y, depth, mode, s->preds);  // search.c:895-940: cabac->update = 1 around the mock encode ...
         double cost = bits * m->lambda;
-        cost += leaf_rd_cost(lv, xl, yl, depth, depth, true, true);
+        cost += leaf_rd_cost(&s->cab, true, lv, xl, yl, depth, depth, true, true);  // ... and the transform tree's flags
         *out_cost = cost;
         const CtuCu *cu = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
         *out_cbf = cbf_is_set(cu->cbf, depth, 0) || cbf_is_set(cu->cbf, depth, 1) || cbf_is_set(cu->cbf, depth, 2);
@@ -1084,10 +1148,14 @@ struct CtuProgram {
         s->mode_inv[mode] = (int16_t)(mode < 2 ? 0 : inv_tab[ad]);
       }
       if (v >= 128 && v < 136) s->qs[(v - 128) >> 1][v & 1] = quant_scalars_dev(2 + ((v - 128) >> 1), (v & 1) ? 2 : 0);
-      if (v == 140) {  // lambda_sqrt * kvz_luma_mode_bits (search_intra.c:524, 641-676) for the three possible outcomes
-        s->mode_bits_cost[0] = m->lambda_sqrt * ((double)m->intra_mode[0] + 5);
-        s->mode_bits_cost[1] = m->lambda_sqrt * ((double)m->intra_mode[1] + 1);
-        s->mode_bits_cost[2] = m->lambda_sqrt * ((double)m->intra_mode[1] + 2);
+      if (v >= 144 && v < 144 + KVZ_CX_COUNT) {
+        // the row's contexts: from the CTU to the left; a row's first CTU from the second CTU of the row above (WPP; rows of a
+        // one-CTU-wide picture and the first row start from the slice-start state, encoderstate.c:1218)
+        const int ctx = cx >> 6, cty = cy >> 6, i = v - 144;
+        const u8 *base = F.border + (long)frame * F.wc * F.hc * KVZ_BORDER_BYTES;
+        const u8 *r = ctx > 0 ? base + (long)(cty * F.wc + ctx - 1) * KVZ_BORDER_BYTES : ((cty > 0 && F.wc > 1) ? base + (long)((cty - 1) * F.wc + 1) * KVZ_BORDER_BYTES : nullptr);
+        const u8 st = (r && m->adaptive) ? load_shared_byte(r + 288 + i) : m->ctx_init[i];
+        s->pre[0].s[i] = st; s->cab.s[i] = st;
       }
       }
 
@@ -1119,6 +1187,55 @@ struct CtuProgram {
     }
     KVZ_SYNC();
   }
+  // The syntax kvazaar writes for the finished CTU (kvz_encode_coding_tree, encode_coding_tree.c:745-940, with
+  // encode_intra_coding_unit :467-652 and encode_transform_coeff :193-309), reduced to the bins that touch the ten contexts:
+  // this is how the row's state->cabac moves from one CTU to the next.  Coefficient bins have contexts of their own that the
+  // fast coefficient cost never prices with.  The recursion over the coding quadtree unrolled along the z-order of the 8x8
+  // cells: at a cell, the nodes that start there and were not visited from an earlier cell are those of depth >= d0, d0 from
+  // the cell's alignment.  One lane.
+  KVZ_DEV void code_ctu_syntax(CtxSet *c) const
+  {
+    int i = 0;
+    while (i < 64) {
+      const int xl = ((i & 1) | ((i >> 1) & 2) | ((i >> 2) & 4)) * 8, yl = (((i >> 1) & 1) | ((i >> 2) & 2) | ((i >> 3) & 4)) * 8, x = cx + xl, y = cy + yl;
+      int d = i == 0 ? 0 : ((i & 15) == 0 ? 1 : ((i & 3) == 0 ? 2 : 3));
+      if (x >= F.W || y >= F.H) { i += 1 << (2 * (3 - d)); continue; }  // the parent's border rule leaves this whole block out
+      const CtuCu *cu = &s->cu[0][(yl >> 3) * 8 + (xl >> 3)];
+      for (;; d++) {
+        const int w = 64 >> d;
+        if (d != 3) {
+          const bool border = F.W < x + w || F.H < y + w;
+          const bool split = cu->depth > d;  // GET_SPLITDATA
+          if (!border) ctx_code(c, KVZ_CX_SPLIT + split_model(0, x, y, d), split);
+          if (split || border) continue;
+        }
+        break;
+      }
+      if (d == 3) ctx_code(c, KVZ_CX_PART, 1);  // part_mode 2Nx2N at the minimum CU size
+      {
+        CtuCu lc, ac, *left = nullptr, *above = nullptr;
+        if (x > 0 && neighbour_cu(0, x - 1, y, &lc)) left = &lc;
+        if ((y & 63) > 0 && neighbour_cu(0, x, y - 1, &ac)) above = &ac;
+        int8_t preds[3];
+        mpm_candidates(y, left, above, preds);
+        ctx_code(c, KVZ_CX_INTRA, cu->mode == preds[0] || cu->mode == preds[1] || cu->mode == preds[2]);  // prev_intra_luma_pred_flag; mpm_idx / rem mode are bypass
+        ctx_code(c, KVZ_CX_CHROMA, 0);  // intra_chroma_pred_mode: derived from luma
+      }
+      // transform tree: split_transform_flag is never coded (tr_depth_intra = 0; the 64x64 split is inferred, encode_coding_tree.c:236-243)
+      const int cb_u = cbf_is_set(cu->cbf, d, 1), cb_v = cbf_is_set(cu->cbf, d, 2);
+      ctx_code(c, KVZ_CX_CBF_CHROMA, cb_u);
+      ctx_code(c, KVZ_CX_CBF_CHROMA, cb_v);
+      if (d == 0) {
+        for (int q = 0; q < 4; q++) {
+          const CtuCu *t = &s->cu[0][(q >> 1) * 32 + (q & 1) * 4];
+          if (cb_u) ctx_code(c, KVZ_CX_CBF_CHROMA + 1, cbf_is_set(t->cbf, 1, 1));
+          if (cb_v) ctx_code(c, KVZ_CX_CBF_CHROMA + 1, cbf_is_set(t->cbf, 1, 2));
+          ctx_code(c, KVZ_CX_CBF_LUMA, cbf_is_set(t->cbf, 1, 0));
+        }
+      } else ctx_code(c, KVZ_CX_CBF_LUMA + 1, cbf_is_set(cu->cbf, d, 0));  // always present for intra (encode_coding_tree.c:276-279)
+      i += 1 << (2 * (3 - d));
+    }
+  }
   // ... and the CU-info half: level 0 -> cu arrays, CTU cost, CU part of the border record; coefficients already there
   KVZ_DEV void finish_info()
   {
@@ -1131,8 +1248,12 @@ struct CtuProgram {
           F.cu_mode[i] = s->cu[0][tid].mode;
         }
       }
-      if (tid == 0) F.ctu_cost[(long)frame * F.wc * F.hc + ctu_index()] = s->res[0];
       u8 *r = F.border + ((long)frame * F.wc * F.hc + ctu_index()) * KVZ_BORDER_BYTES;
+      if (tid == 0) {
+        F.ctu_cost[(long)frame * F.wc * F.hc + ctu_index()] = s->res[0];
+        if (m->adaptive) code_ctu_syntax(&s->pre[0]);
+        for (int i = 0; i < KVZ_CX_COUNT; i++) r[288 + i] = s->pre[0].s[i];
+      }
       for (int v = tid; v < 32; v += KVZ_CTU_THREADS) {
         const int i = v & 7;
         const CtuCu *cu = &s->cu[0][v < 16 ? 56 + i : i * 8 + 7];
@@ -1167,12 +1288,15 @@ struct CtuProgram {
       recon_tus(lv, t, 1, mode);
       KVZ_FOR_THREADS(tid) {
         if (tid == 0) {
+          // search.c:1005-1041: priced from the contexts at entry; pre_search_cabac carries update == 0 (it was copied while the
+          // caller had updates off), so nothing here moves a context
+          CtxSet *pc = &s->pre[1];
           double bits = 0;
-          bits += (double)m->split_flag[split_model(lv, x, y, depth)][0];
-          const double mode_bits = intra_mode_syntax_bits(lv, x, y, mode) + bits;  // calc_mode_bits search.c:517-540
+          bits += ctx_price(pc, KVZ_CX_SPLIT + split_model(lv, x, y, depth), 0, false);
+          const double mode_bits = intra_mode_syntax_bits(pc, false, lv, x, y, mode, false) + bits;  // calc_mode_bits search.c:557-581
           double cost = 0;
           cost += mode_bits * m->lambda;
-          cost += leaf_rd_cost(lv, xl, yl, 1, 1, true, true);
+          cost += leaf_rd_cost(pc, false, lv, xl, yl, 1, 1, true, true);
           s->cost[1] = cost;
         }
       }
@@ -1203,21 +1327,22 @@ struct CtuProgram {
           if (any_other) cbf_set(&cu->cbf, 0, c);
         }
         // cu_rd_cost_tr_split_accurate at depth 0 (search.c:425-541): chroma cbf at depth 0, then the four children
+        CtxSet *pc = &s->pre[0];
         double tr_tree_bits = 0;
-        tr_tree_bits += (double)m->cbf_chroma[0][cbf_is_set(cu->cbf, 0, 1)];
-        tr_tree_bits += (double)m->cbf_chroma[0][cbf_is_set(cu->cbf, 0, 2)];
+        tr_tree_bits += ctx_price(pc, KVZ_CX_CBF_CHROMA, cbf_is_set(cu->cbf, 0, 1), false);
+        tr_tree_bits += ctx_price(pc, KVZ_CX_CBF_CHROMA, cbf_is_set(cu->cbf, 0, 2), false);
         double sum = 0;
         for (int q = 0; q < 4; q++) {
           const int qxl = (q & 1) * 32, qyl = (q >> 1) * 32;
           const CtuCu *tr_cu = &s->cu[lv][(qyl >> 3) * 8 + (qxl >> 3)];
           for (int i = 0; i < 9; i++) s->acc[i] = s->child_acc[q][i];
           // search.c:466-471: child cbf_cb/cbf_cr are coded when the entry has any chroma bit at depth >= 0
-          sum += leaf_rd_cost(lv, qxl, qyl, 1, 0, cbf_is_set(tr_cu->cbf, 0, 1), cbf_is_set(tr_cu->cbf, 0, 2));
+          sum += leaf_rd_cost(pc, false, lv, qxl, qyl, 1, 0, cbf_is_set(tr_cu->cbf, 0, 1), cbf_is_set(tr_cu->cbf, 0, 2));
         }
         const double rd = sum + tr_tree_bits * m->lambda;
         double bits = 0;
-        bits += (double)m->split_flag[split_model(lv, x, y, 0)][0];
-        const double mode_bits = intra_mode_syntax_bits(lv, x, y, mode) + bits;
+        bits += ctx_price(pc, KVZ_CX_SPLIT + split_model(lv, x, y, 0), 0, false);
+        const double mode_bits = intra_mode_syntax_bits(pc, false, lv, x, y, mode, false) + bits;
         double cost = 0;
         cost += mode_bits * m->lambda;
         cost += rd;
@@ -1235,12 +1360,11 @@ struct CtuProgram {
     a2x = xl; a2y = yl;
     const bool inside = x + 16 <= F.W && y + 16 <= F.H;
     // thread-0 bookkeeping around the 16x16 CU: header + cost initialisation before, split cost after
-    auto d2_first = [&]() { cu_header(2, xl, yl, 2); s->cost[2] = 1.7e+308; s->cbf_any = 0; };
+    auto d2_first = [&]() { cu_header(2, xl, yl, 2); s->cost[2] = 1.7e+308; s->cbf_any = 0; s->pre[2] = s->cab; price_modes(); };
     auto d2_last = [&]() {
-      double split_bits = 0;
-      split_bits += (double)m->split_flag[split_model(2, x, y, 2)][1];
-      double sc = 0.0;
-      sc += split_bits * m->lambda;
+      s->post2 = s->cab;  // search.c:956-959: the split alternative starts again from the contexts at entry
+      s->cab = s->pre[2];
+      double sc = split_flag_cost(2, x, y, 2);
       if (inside && !s->cbf_any) sc = 2147483647;  // cu_split_termination = zero (search.c:975-984)
       s->split_cost[2] = sc;
     };
@@ -1254,7 +1378,7 @@ struct CtuProgram {
         if (!(s->split_cost[2] < s->cost[2])) break;  // uniform: both are LDS scalars
         const int qx = x + (q & 1) * 8, qy = y + (q >> 1) * 8;
         if (qx >= F.W || qy >= F.H) continue;  // child outside the picture costs 0
-        eval_cu(3, qx, qy, 3, &s->cost[3], &s->cbf_any, [&]() { cu_header(3, qx - cx, qy - cy, 3); }, [&]() { s->split_cost[2] += s->cost[3]; });
+        eval_cu(3, qx, qy, 3, &s->cost[3], &s->cbf_any, [&]() { cu_header(3, qx - cx, qy - cy, 3); price_modes(); }, [&]() { s->split_cost[2] += s->cost[3]; });
       }
     }
     // Every lane reads the verdict here; thread 0 only touches its operands again after the barrier that ends commit()
@@ -1277,14 +1401,14 @@ struct CtuProgram {
     init();
     KVZ_PROF(KVZ_P_INIT);
     KVZ_FOR_THREADS(tid) {
-      if (tid == 0) { cu_header(0, 0, 0, 0); s->cost[0] = 1.7e+308; double sb = 0; sb += (double)m->split_flag[split_model(0, cx, cy, 0)][1]; double sc = 0.0; sc += sb * m->lambda; s->split_cost[0] = sc; }
+      if (tid == 0) { cu_header(0, 0, 0, 0); s->cost[0] = 1.7e+308; s->split_cost[0] = split_flag_cost(0, cx, cy, 0); }
     }
     KVZ_SYNC();
     for (int q1 = 0; q1 < 4; q1++) {
       const int x1 = cx + (q1 & 1) * 32, y1 = cy + (q1 >> 1) * 32;
       if (x1 >= F.W || y1 >= F.H) continue;  // search_cu returns 0 outside the picture
       a1x = x1 - cx; a1y = y1 - cy;
-      load_org([&]() { cu_header(1, x1 - cx, y1 - cy, 1); s->cost[1] = 1.7e+308; double sb = 0; sb += (double)m->split_flag[split_model(1, x1, y1, 1)][1]; double sc = 0.0; sc += sb * m->lambda; s->split_cost[1] = sc; });
+      load_org([&]() { cu_header(1, x1 - cx, y1 - cy, 1); s->cost[1] = 1.7e+308; s->pre[1] = s->cab; s->split_cost[1] = split_flag_cost(1, x1, y1, 1); });
       for (int q2 = 0; q2 < 4; q2++) search_d2(x1 + (q2 & 1) * 16, y1 + (q2 >> 1) * 16);
       if (x1 + 32 <= F.W && y1 + 32 <= F.H) try_merge(x1, y1, 1);
       const bool split_wins1 = s->split_cost[1] < s->cost[1];  // operands stay put until the barrier that ends commit()

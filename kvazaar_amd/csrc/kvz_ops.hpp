@@ -58,6 +58,9 @@ struct Tables {
   // intra.c:47-82 num_ref_pixels_top / num_ref_pixels_left: reference samples available above-right / below-left of the 4x4
   // unit at [y / 4][x / 4] of a CTU, regenerated from the z-order of the units (kvz_tables.hpp)
   u8 avail_top[16][16], avail_left[16][16];
+  // CABAC context state machine (H.265 table 9-41) on kvazaar's packed state (state << 1 | MPS, cabac.c:40-62):
+  // [0] after coding the more probable symbol, [1] after the less probable one
+  u8 ctx_next[2][128];
   int8_t luma_filter[4][8];    // filter.c:66-72
   int8_t chroma_filter[8][4];  // filter.c:74-84
 };

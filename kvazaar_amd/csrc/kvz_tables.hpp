@@ -94,6 +94,15 @@ inline void build_tables(Tables *t)
         else { for (int rr = r; rr < 16 && z(c - 1, rr) < z(c, r); rr++) n++; t->avail_left[r][c] = (u8)(4 * n); }
       }
   }
+  {  // H.265 table 9-41 transIdxLps; transIdxMps = min(state + 1, 62)
+    static const u8 lps[64] = { 0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9, 11, 11, 12, 13, 13, 15, 15, 16, 16, 18, 18, 19, 19, 21, 21, 22, 22, 23, 24,
+                                24, 25, 26, 26, 27, 27, 28, 29, 29, 30, 30, 30, 31, 32, 32, 33, 33, 33, 34, 34, 35, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 63 };
+    for (int u = 0; u < 128; u++) {
+      const int st = u >> 1, mps = u & 1;
+      t->ctx_next[0][u] = (u8)(st >= 62 ? u : ((st + 1) << 1) | mps);
+      t->ctx_next[1][u] = (u8)(st == 0 ? (mps ^ 1) : (lps[st] << 1) | mps);
+    }
+  }
   static const i16 dst4[16] = { 29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29 };
   memcpy(t->dst4, dst4, sizeof dst4);
   for (int kind = 0; kind < 3; kind++) {

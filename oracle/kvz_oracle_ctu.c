@@ -42,6 +42,25 @@ static int ctx_state(int qp, int init_value)
   return st >= 64 ? ((st - 64) << 1) + 1 : (63 - st) << 1;
 }
 
+/* The ten contexts the all-intra ultrafast search prices syntax with (cabac.h:63-100), as uc_state = (state << 1) | mps */
+enum { CX_SPLIT = 0 /* ..2 */, CX_PART = 3, CX_INTRA = 4, CX_CHROMA = 5, CX_CBF_LUMA = 6 /* ..7 */, CX_CBF_CHROMA = 8 /* ..9 */, CX_COUNT = 10 };
+typedef struct { uint8_t s[CX_COUNT]; } ctxs_t;
+
+/* H.265 Table 9-41 state transitions in kvazaar's packing (cabac.c:40-62 kvz_g_auc_next_state_mps / _lps) */
+static uint8_t g_next_mps[128], g_next_lps[128];
+static void build_transitions(void)
+{
+  static const uint8_t trans_lps[64] = { 0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9, 11, 11, 12, 13, 13, 15, 15, 16, 16, 18, 18, 19, 19, 21, 21, 22, 22, 23, 24,
+                                          24, 25, 26, 26, 27, 27, 28, 29, 29, 30, 30, 30, 31, 32, 32, 33, 33, 33, 34, 34, 35, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 63 };
+  for (int u = 0; u < 128; u++) {
+    const int st = u >> 1, mps = u & 1;
+    g_next_mps[u] = (uint8_t)(st >= 62 ? u : ((st + 1) << 1) | mps);
+    g_next_lps[u] = (uint8_t)(st == 0 ? (0 << 1) | (mps ^ 1) : (trans_lps[st] << 1) | mps);
+  }
+  g_next_lps[126] = 127; g_next_lps[127] = 126;  /* the terminating state, never reached by these contexts */
+}
+const uint8_t *kvz_oracle_next_state_table(int lps) { build_transitions(); return lps ? g_next_lps : g_next_mps; }
+
 #define LCU 64
 #define NLEVELS 5
 #define MAX_COST 1.7e+308 /* global.h:293 MAX_DOUBLE */
@@ -64,7 +83,20 @@ typedef struct {
   uint8_t org[3][LCU * LCU]; /* lcu->ref, zero outside the picture (search.c:1084 FILL) */
   level_t lv[NLEVELS];
   uint8_t tbl_top[16][16], tbl_left[16][16];
+  ctxs_t cab;                /* state->search_cabac's contexts (adaptive mode) */
 } ctu_t;
+
+/* CABAC_FBITS_UPDATE (cabac.h:133-139) on context idx of t->cab: the price of `bin`, then -- if `update` -- the state change
+ * kvz_cabac_encode_bin applies (cabac.c:104-132).  Frozen mode prices from the model's float tables instead. */
+static double ctx_price(ctu_t *t, int idx, int bin, int update, float frozen_price)
+{
+  if (!t->m->adaptive) return frozen_price;
+  uint8_t *st = &t->cab.s[idx];
+  const double bits = t->m->entropy_fbits[*st ^ bin];
+  if (update) *st = (bin != (*st & 1)) ? g_next_lps[*st] : g_next_mps[*st];
+  return bits;
+}
+static void ctx_code(ctxs_t *c, int idx, int bin) { uint8_t *st = &c->s[idx]; *st = (bin != (*st & 1)) ? g_next_lps[*st] : g_next_mps[*st]; }
 
 /* ---- cbf bit helpers (cu.h:510-569: 5 depth bits per plane, is_set tests levels >= depth) ---- */
 static const uint16_t cbf_masks[5] = { 0x1f, 0x0f, 0x07, 0x03, 0x1 };
@@ -215,12 +247,12 @@ static void mpm_candidates(int y, const cu_t *left, const cu_t *above, int8_t pr
 }
 
 /* search_intra.c:641-676 kvz_luma_mode_bits (only_count path) */
-static double luma_mode_bits(const kvz_hip_intra_cost_model *m, int mode, const int8_t preds[3])
+static double luma_mode_bits(ctu_t *t, int mode, const int8_t preds[3], int update)
 {
   double bits = 0;
   int in = 0;
   for (int i = 0; i < 3; i++) if (mode == preds[i]) in = 1;
-  bits += m->intra_mode[in];
+  bits += ctx_price(t, CX_INTRA, in, update, t->m->intra_mode[in]);
   if (in) bits += (mode == preds[0]) ? 1 : 2; else bits += 5;
   return bits;
 }
@@ -276,7 +308,7 @@ static int rough_search(ctu_t *t, int log2w, const uint8_t *orig /* contiguous *
       n++;
     }
   }
-  for (int i = 0; i < n; i++) costs[i] += t->m->lambda_sqrt * luma_mode_bits(t->m, modes[i], preds);
+  for (int i = 0; i < n; i++) costs[i] += t->m->lambda_sqrt * luma_mode_bits(t, modes[i], preds, 0);  /* search_cabac.update == 0 here */
   return n;
 }
 
@@ -352,7 +384,7 @@ static void recon_cu(ctu_t *t, level_t *lv, int x, int y, int depth, int mode, i
 }
 
 /* search.c:425-541 cu_rd_cost_tr_split_accurate (intra CU, frozen contexts, fast coefficient cost rdo.c:311-326) */
-static double rd_cost(ctu_t *t, level_t *lv, int xl, int yl, int depth, const cu_t *pred_cu)
+static double rd_cost(ctu_t *t, level_t *lv, int xl, int yl, int depth, const cu_t *pred_cu, int update)
 {
   const kvz_hip_intra_cost_model *m = t->m;
   const int width = LCU >> depth;
@@ -362,20 +394,20 @@ static double rd_cost(ctu_t *t, level_t *lv, int xl, int yl, int depth, const cu
   const int cb_u = cbf_is_set(tr_cu->cbf, depth, 1), cb_v = cbf_is_set(tr_cu->cbf, depth, 2);
   (void)pred_cu;
   /* transform_tree split flag: never coded with tr_depth_intra = 0 (search.c:451-464) */
-  if (tr_cu->depth == depth || cbf_is_set(tr_cu->cbf, depth - 1, 1)) tr_tree_bits += m->cbf_chroma[depth - tr_cu->depth][cb_u];
-  if (tr_cu->depth == depth || cbf_is_set(tr_cu->cbf, depth - 1, 2)) tr_tree_bits += m->cbf_chroma[depth - tr_cu->depth][cb_v];
+  if (tr_cu->depth == depth || cbf_is_set(tr_cu->cbf, depth - 1, 1)) tr_tree_bits += ctx_price(t, CX_CBF_CHROMA + depth - tr_cu->depth, cb_u, update, m->cbf_chroma[depth - tr_cu->depth][cb_u]);
+  if (tr_cu->depth == depth || cbf_is_set(tr_cu->cbf, depth - 1, 2)) tr_tree_bits += ctx_price(t, CX_CBF_CHROMA + depth - tr_cu->depth, cb_v, update, m->cbf_chroma[depth - tr_cu->depth][cb_v]);
   if (tr_depth > 0) {
     const int o = LCU >> (depth + 1);
     double sum = 0;
-    sum += rd_cost(t, lv, xl, yl, depth + 1, pred_cu);
-    sum += rd_cost(t, lv, xl + o, yl, depth + 1, pred_cu);
-    sum += rd_cost(t, lv, xl, yl + o, depth + 1, pred_cu);
-    sum += rd_cost(t, lv, xl + o, yl + o, depth + 1, pred_cu);
+    sum += rd_cost(t, lv, xl, yl, depth + 1, pred_cu, update);
+    sum += rd_cost(t, lv, xl + o, yl, depth + 1, pred_cu, update);
+    sum += rd_cost(t, lv, xl, yl + o, depth + 1, pred_cu, update);
+    sum += rd_cost(t, lv, xl + o, yl + o, depth + 1, pred_cu, update);
     return sum + tr_tree_bits * m->lambda;
   }
   const int cb_y = cbf_is_set(tr_cu->cbf, depth, 0);
   const int is_tr_split = depth - tr_cu->depth;
-  tr_tree_bits += m->cbf_luma[!is_tr_split][cb_y];
+  tr_tree_bits += ctx_price(t, CX_CBF_LUMA + !is_tr_split, cb_y, update, m->cbf_luma[!is_tr_split][cb_y]);
   unsigned luma_ssd = kvz_oracle_pixels_calc_ssd(&t->org[0][yl * LCU + xl], &lv->rec[0][yl * LCU + xl], LCU, LCU, width);
   if (cb_y) coeff_bits += kvz_oracle_fast_coeff_cost(&lv->coeff[0][zorder(xl, yl)], width, m->coeff_weights);
   unsigned chroma_ssd = 0;
@@ -402,27 +434,30 @@ static int split_model(ctu_t *t, level_t *lv, int x, int y, int depth)
 
 /* intra-mode part of the CU syntax: prev_intra_luma_pred_flag + mpm_idx / rem_intra_luma_pred_mode + chroma mode
  * (encode_coding_tree.c:467-652; chroma mode == luma mode -> one context bin "0") */
-static double intra_mode_syntax_bits(ctu_t *t, level_t *lv, int x, int y, int mode, int with_chroma)
+static double intra_mode_syntax_bits(ctu_t *t, level_t *lv, int x, int y, int mode, int with_chroma, int update, int mock)
 {
   cu_t lc, ac, *left = NULL, *above = NULL;
-  if (x > 0 && neighbour_cu(t, lv, x - 1, y, &lc)) left = &lc;
+  /* The mock encode looks its left neighbour up at LCU-local column SUB_SCU(x - 1) (encode_coding_tree.c:516), which for a CU on
+   * the LCU's left edge is column 63 of the work tree -- a cell the z-order search has not reached yet (type CU_NOTSET), so the left
+   * candidate falls back to DC there.  calc_mode_bits (search.c:566) and the real encode (lcu == NULL) use the true neighbour. */
+  if (x > 0 && !(mock && x % LCU == 0) && neighbour_cu(t, lv, x - 1, y, &lc)) left = &lc;
   if (y % LCU > 0 && y > 0 && neighbour_cu(t, lv, x, y - 1, &ac)) above = &ac;
   int8_t preds[3];
   mpm_candidates(y, left, above, preds);
-  double bits = luma_mode_bits(t->m, mode, preds);
-  if (with_chroma) bits += t->m->chroma_mode[0];
+  double bits = luma_mode_bits(t, mode, preds, update);
+  if (with_chroma) bits += ctx_price(t, CX_CHROMA, 0, update, t->m->chroma_mode[0]);
   return bits;
 }
 
 /* encode_coding_tree.c:948-1049 kvz_mock_encode_coding_unit for an intra 2Nx2N CU in an I slice */
-static double cu_bits(ctu_t *t, level_t *lv, int x, int y, int depth, int mode)
+static double cu_bits(ctu_t *t, level_t *lv, int x, int y, int depth, int mode, int update)
 {
   double bits = 0;
   const int w = LCU >> depth;
-  if (depth != 3 && !(t->W < x + w || t->H < y + w)) bits += t->m->split_flag[split_model(t, lv, x, y, depth)][0];
-  if (depth == 3) bits += t->m->part_size[1];
+  if (depth != 3 && !(t->W < x + w || t->H < y + w)) { const int sm = split_model(t, lv, x, y, depth); bits += ctx_price(t, CX_SPLIT + sm, 0, update, t->m->split_flag[sm][0]); }
+  if (depth == 3) bits += ctx_price(t, CX_PART, 1, update, t->m->part_size[1]);
   /* encode_intra_coding_unit adds the flag first and the bypass bins after it; same sum order as luma_mode_bits */
-  bits += intra_mode_syntax_bits(t, lv, x, y, mode, 1);
+  bits += intra_mode_syntax_bits(t, lv, x, y, mode, 1, update, 1);
   return bits;
 }
 
@@ -451,6 +486,7 @@ static double search_cu(ctu_t *t, int x, int y, int depth)
   const int w = LCU >> depth, xl = x - t->cx, yl = y - t->cy;
   level_t *lv = &t->lv[depth];
   double cost = MAX_COST;
+  const ctxs_t pre_search = t->cab;  /* search.c:655-656 */
   if (x >= t->W || y >= t->H) return 0;
   cu_t *cur = cu_at(lv, xl, yl);
   cur->depth = (uint8_t)(depth > 3 ? 3 : depth);
@@ -465,17 +501,19 @@ static double search_cu(ctu_t *t, int x, int y, int depth)
     if (x % 8 == 0 && y % 8 == 0) recon_cu(t, lv, x, y, depth, mode, 0, 1);
   }
   if (cur->type == 1) {
-    const double bits = cu_bits(t, lv, x, y, depth, cur->mode);
+    const double bits = cu_bits(t, lv, x, y, depth, cur->mode, 1);  /* search.c:895-940: cabac->update = 1 around the mock encode ... */
     cost = bits * m->lambda;
-    cost += rd_cost(t, lv, xl, yl, depth, cur);
+    cost += rd_cost(t, lv, xl, yl, depth, cur, 1);                  /* ... and the transform-tree flags */
   }
   const int can_split = cur->type == 0 || depth < 3;
   if (can_split) {
     const int half = w / 2;
     double split_cost = 0.0;
     const int cbf = cbf_is_set_any(cur->cbf, depth);
+    ctxs_t post_search = t->cab;  /* search.c:956-959: the split alternative starts again from the state at entry */
+    t->cab = pre_search;
     double split_bits = 0;
-    if (depth < 3) split_bits += m->split_flag[split_model(t, lv, x, y, depth)][1];
+    if (depth < 3) { const int sm = split_model(t, lv, x, y, depth); split_bits += ctx_price(t, CX_SPLIT + sm, 1, 1, m->split_flag[sm][1]); }
     split_cost += split_bits * m->lambda;
     if (cur->type == 0 || cbf) {
       if (split_cost < cost) split_cost += search_cu(t, x, y, depth + 1);
@@ -489,21 +527,28 @@ static double search_cu(ctu_t *t, int x, int y, int depth)
     if (cur->type == 0 && depth < 4 && inside) {
       const cu_t *d1 = cu_at(&t->lv[depth + 1], xl, yl);
       if (d1->type == 1 && d1->depth == depth + 1) {
+        /* search.c:1005-1041: priced from the state at entry; pre_search_cabac carries update == 0 (it was copied while the
+         * caller had it switched off), so nothing here changes a context */
+        const ctxs_t temp = t->cab;
+        t->cab = pre_search;
         cost = 0;
         double bits = 0;
-        if (depth < 3) bits += m->split_flag[split_model(t, lv, x, y, depth)][0];
+        if (depth < 3) { const int sm = split_model(t, lv, x, y, depth); bits += ctx_price(t, CX_SPLIT + sm, 0, 0, m->split_flag[sm][0]); }
         cur->mode = d1->mode; cur->type = 1;
         fill_cu(lv, xl, yl, w, cur);
         recon_cu(t, lv, x, y, depth, cur->mode, 1, 1);
-        const double mode_bits = intra_mode_syntax_bits(t, lv, x, y, cur->mode, 1) /* calc_mode_bits search.c:517-540 */ + bits;
+        const double mode_bits = intra_mode_syntax_bits(t, lv, x, y, cur->mode, 1, 0, 0) /* calc_mode_bits search.c:557-581 */ + bits;
         cost += mode_bits * m->lambda;
-        cost += rd_cost(t, lv, xl, yl, depth, cur);
+        cost += rd_cost(t, lv, xl, yl, depth, cur, 0);
+        post_search = t->cab;
+        t->cab = temp;
       }
     }
     if (split_cost < cost) {
       cost = split_cost;
       copy_region(t, &t->lv[depth + 1], lv, xl, yl, w, 1); /* work_tree_copy_up */
     } else if (depth > 0) {
+      t->cab = post_search;  /* search.c:1051 */
       for (int i = depth + 1; i < NLEVELS; i++) copy_region(t, lv, &t->lv[i], xl, yl, w, 0); /* work_tree_copy_down */
     }
   } else if (depth >= 0 && depth < 4) {
@@ -539,6 +584,66 @@ static double encode_ctu(ctu_t *t, int cx, int cy, int16_t *coeff_out)
   return cost;
 }
 
+/* The syntax kvazaar writes for a finished CTU (kvz_encode_coding_tree, encode_coding_tree.c:745-940, with
+ * encode_intra_coding_unit :467-652 and encode_transform_coeff :193-309), reduced to the bins that touch the ten contexts:
+ * this is how state->cabac moves from one CTU to the next.  Reads the frame-level CU arrays (neighbours may lie in other
+ * CTUs) and, for the coded block flags, level 0 of the CTU just searched. */
+static void code_transform_tree(ctu_t *t, ctxs_t *c, int xl, int yl, int depth, int tr_depth, int parent_u, int parent_v)
+{
+  const cu_t *cu = cu_at(&t->lv[0], xl, yl);
+  const int split = cu->tr_depth > depth;
+  const int cb_y = cbf_is_set(cu->cbf, depth, 0), cb_u = cbf_is_set(cu->cbf, depth, 1), cb_v = cbf_is_set(cu->cbf, depth, 2);
+  /* split_transform_flag is never coded: tr_depth_intra = 0, and the 64x64 split is inferred (encode_coding_tree.c:236-243) */
+  if (depth < 4) {
+    if (tr_depth == 0 || parent_u) ctx_code(c, CX_CBF_CHROMA + tr_depth, cb_u);
+    if (tr_depth == 0 || parent_v) ctx_code(c, CX_CBF_CHROMA + tr_depth, cb_v);
+  }
+  if (split) {
+    const int o = LCU >> (depth + 1);
+    code_transform_tree(t, c, xl, yl, depth + 1, tr_depth + 1, cb_u, cb_v);
+    code_transform_tree(t, c, xl + o, yl, depth + 1, tr_depth + 1, cb_u, cb_v);
+    code_transform_tree(t, c, xl, yl + o, depth + 1, tr_depth + 1, cb_u, cb_v);
+    code_transform_tree(t, c, xl + o, yl + o, depth + 1, tr_depth + 1, cb_u, cb_v);
+    return;
+  }
+  ctx_code(c, CX_CBF_LUMA + !tr_depth, cb_y);  /* always present for intra (encode_coding_tree.c:276-279) */
+}
+static void code_coding_tree(ctu_t *t, ctxs_t *c, int x, int y, int depth)
+{
+  const int w = LCU >> depth, half = w / 2, w8 = t->W >> 3;
+  const int cur_depth = t->fdepth[(y >> 3) * w8 + (x >> 3)];
+  const int split_flag = cur_depth > depth;  /* GET_SPLITDATA */
+  const int border_x = t->W < x + w, border_y = t->H < y + w, border = border_x || border_y;
+  const int border_split_x = t->W >= x + 8 + half, border_split_y = t->H >= y + 8 + half;
+  if (depth != 3) {
+    if (!border) {
+      int sm = 0;
+      if (x > 0 && t->fdepth[(y >> 3) * w8 + ((x - 1) >> 3)] > depth) sm++;
+      if (y > 0 && t->fdepth[((y - 1) >> 3) * w8 + (x >> 3)] > depth) sm++;
+      ctx_code(c, CX_SPLIT + sm, split_flag);
+    }
+    if (split_flag || border) {
+      code_coding_tree(t, c, x, y, depth + 1);
+      if (!border_x || border_split_x) code_coding_tree(t, c, x + half, y, depth + 1);
+      if (!border_y || border_split_y) code_coding_tree(t, c, x, y + half, depth + 1);
+      if (!border || (border_split_x && border_split_y)) code_coding_tree(t, c, x + half, y + half, depth + 1);
+      return;
+    }
+  }
+  if (depth == 3) ctx_code(c, CX_PART, 1);  /* part_mode 2Nx2N at the minimum CU size */
+  {
+    cu_t lc = { 1, 0, 0, 0, 0 }, ac = { 1, 0, 0, 0, 0 }, *left = NULL, *above = NULL;
+    const int mode = t->fmode[(y >> 3) * w8 + (x >> 3)];
+    if (x > 0) { lc.mode = t->fmode[(y >> 3) * w8 + ((x - 1) >> 3)]; left = &lc; }
+    if (y % LCU > 0 && y > 0) { ac.mode = t->fmode[((y - 1) >> 3) * w8 + (x >> 3)]; above = &ac; }
+    int8_t preds[3];
+    mpm_candidates(y, left, above, preds);
+    ctx_code(c, CX_INTRA, mode == preds[0] || mode == preds[1] || mode == preds[2]);  /* prev_intra_luma_pred_flag; mpm_idx / rem mode are bypass */
+    ctx_code(c, CX_CHROMA, 0);                                                         /* intra_chroma_pred_mode: derived from luma */
+  }
+  code_transform_tree(t, c, x - t->cx, y - t->cy, depth, 0, 0, 0);
+}
+
 /* One frame, CTUs in raster order.  Planes are tightly packed (stride = width, chroma = width/2); width and height
  * must be multiples of 8 (kvazaar pads its input to that, encoder.c).  Outputs: rec planes, KVZ_HIP_CTU_COEFFS
  * coefficients per CTU (raster CTU order), CU depth and luma mode per 8x8 block (raster, stride width/8), and the
@@ -553,9 +658,22 @@ void kvz_oracle_intra_frame(const kvz_hip_intra_cost_model *m, int width, int he
   t->frec[0] = rec_y; t->frec[1] = rec_u; t->frec[2] = rec_v;
   t->fdepth = cu_depth; t->fmode = cu_mode;
   build_avail_tables(t);
+  build_transitions();
   const int wc = (width + 63) / 64, hc = (height + 63) / 64;
+  /* one context set per CTU row, as kvazaar's wavefront rows have one encoder state each: all start at the slice-init state
+   * (encoderstate.c:1218), a row's state after its second CTU seeds the row below (encoderstate.c:763-771) */
+  ctxs_t *rows = (ctxs_t *)calloc((size_t)hc, sizeof(ctxs_t));
+  for (int r = 0; r < hc; r++) for (int i = 0; i < CX_COUNT; i++) rows[r].s[i] = m->ctx_init[i];
   for (int cy = 0; cy < hc; cy++)
-    for (int cx = 0; cx < wc; cx++) ctu_cost[cy * wc + cx] = encode_ctu(t, cx * 64, cy * 64, coeff + (size_t)(cy * wc + cx) * KVZ_HIP_CTU_COEFFS);
+    for (int cx = 0; cx < wc; cx++) {
+      t->cab = rows[cy];  /* kvz_search_lcu: search_cabac = state->cabac (search.c:1211) */
+      ctu_cost[cy * wc + cx] = encode_ctu(t, cx * 64, cy * 64, coeff + (size_t)(cy * wc + cx) * KVZ_HIP_CTU_COEFFS);
+      if (m->adaptive) {
+        code_coding_tree(t, &rows[cy], cx * 64, cy * 64, 0);
+        if (cx == 1 && cy + 1 < hc) rows[cy + 1] = rows[cy];
+      }
+    }
+  free(rows);
   free(t);
 }
 
@@ -571,6 +689,13 @@ void kvz_oracle_intra_cost_model(int qp, const float entropy_fbits[128], uint64_
   m->lambda = 0.57 * pow(2.0, (qp - 12) / 3.0);
   m->lambda_sqrt = sqrt(m->lambda);
   m->coeff_weights = coeff_weights;
+  {
+    const uint8_t inits[CX_COUNT] = { init_split[0], init_split[1], init_split[2], init_part, init_intra, init_chroma, init_cbf_luma[0], init_cbf_luma[1],
+                                      init_cbf_chroma[0], init_cbf_chroma[1] };
+    for (int i = 0; i < CX_COUNT; i++) m->ctx_init[i] = (uint8_t)ctx_state(qp, inits[i]);
+    memcpy(m->entropy_fbits, entropy_fbits, sizeof m->entropy_fbits);
+    m->adaptive = 1;  /* kvazaar's behaviour; 0 freezes every context at its slice-start state */
+  }
 #define CTX_STATE(init) ctx_state(qp, init)
 #define FILL2(dst, init) do { int s_ = CTX_STATE(init); (dst)[0] = entropy_fbits[s_ ^ 0]; (dst)[1] = entropy_fbits[s_ ^ 1]; } while (0)
   for (int i = 0; i < 3; i++) FILL2(m->split_flag[i], init_split[i]);

@@ -11,7 +11,7 @@ class CostModel(C.Structure):
     _fields_ = [("lambda_", C.c_double), ("lambda_sqrt", C.c_double), ("split_flag", (C.c_float * 2) * 3),
                 ("part_size", C.c_float * 2), ("intra_mode", C.c_float * 2), ("chroma_mode", C.c_float * 2),
                 ("cbf_luma", (C.c_float * 2) * 2), ("cbf_chroma", (C.c_float * 2) * 2), ("coeff_weights", C.c_uint64),
-                ("qp", C.c_int32), ("reserved", C.c_int32)]
+                ("qp", C.c_int32), ("adaptive", C.c_int32), ("ctx_init", C.c_uint8 * 16), ("entropy_fbits", C.c_float * 128)]
 
     def key(self):
         return bytes(self)
@@ -20,6 +20,17 @@ class CostModel(C.Structure):
 # kvz_fast_coeff_get_weights(state) for QP 22 of the reference's default table (fast_coeff_cost.h:48-...), as packed by
 # to_4xq88 (fast_coeff_cost.c:39-52); tests/test_ctu_pipeline.py checks it against the reference build.
 COEFF_WEIGHTS_QP22 = 0x065403F0052C0004
+
+
+def model_constants():
+    """tests/golden/model_constants.json: the entropy table and the per-QP fast-coefficient-cost weights of the reference build"""
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_constants.json")))
+
+
+def coeff_weights(qp):
+    return int(model_constants()["coeff_weights"][str(qp)])
 
 
 def outputs(width, height):

@@ -9,6 +9,11 @@ Fixtures (small, committed; the GPU box and any machine without the reference tr
                         (label -> digest of repr(outputs)), incl. tests/cases.py cases_find_last_scanpos
   deblock.json          sha256 of kvz_filter_deblock_lcu's result (filter.c:783, all LCUs) for seeded pictures / CU quadtrees
   sao_frame.json        sha256 of kvz_sao_reconstruct's result (sao.c:302-361, every CTU and plane) for seeded pictures / parameters
+  model_constants.json  kvz_f_entropy_bits (rdo.c:83) and kvz_fast_coeff_get_weights per QP (fast_coeff_cost.c:84-88) as the reference build
+                        returns them: the cost-model inputs of tests that run without the reference tree
+  encoder_recon.json    the reference ENCODER end to end: sha256 of the reconstruction `kvazaar --preset ultrafast -p 1 -q QP` (the CLI
+                        built from /root/reference, all-intra, deblocking on / off) writes with --debug for seeded clips -- what the
+                        batched CTU pass (+ deblocking) must reproduce picture for picture
 (the bitstream md5s of the reference encoder are asserted by tests/test_e2e_dropin.py)
 tests/test_oracle_golden.py holds the known answers of the reference's own unit tests; this file adds outputs of the
 compiled reference for the functions those tests do not pin."""
@@ -74,6 +79,40 @@ def sao_digests(func):
     return out
 
 
+# (width, height, frames, seed, kind, qp): sizes with partial CTUs, several QPs below fast_residual_cost_limit (28: above it
+# ultrafast prices coefficients with the full CABAC model, cfg.c / rdo.c:311-326, which the batched pass does not cover yet)
+ENCODER_CLIPS = [(64, 64, 2, 9, "small", 22), (72, 88, 2, 1, "small", 12), (200, 136, 2, 3, "small", 27), (416, 240, 3, 1234, "small", 22),
+                 (416, 240, 2, 99, "small", 17), (832, 480, 1, 5, "large", 22), (1920, 1080, 1, 1, "large", 22)]
+
+
+def clip_key(w, h, n, seed, kind, qp, deblock):
+    return f"{w}x{h}/n{n}/seed{seed}/{kind}/qp{qp}/{'deblock' if deblock else 'nodeblock'}"
+
+
+def reference_encoder_recon(w, h, frames, qp, deblock, workdir):
+    """runs the reference CLI (oracle/_ref/kvazaar_ref) on the clip; returns its --debug reconstruction, one array per frame"""
+    exe = os.path.join(flatapi.ROOT, "oracle", "_ref", "kvazaar_ref")
+    src, rec = os.path.join(workdir, "in.yuv"), os.path.join(workdir, "rec.yuv")
+    with open(src, "wb") as f:
+        f.write(b"".join(fr.tobytes() for fr in frames))
+    cmd = [exe, "-i", src, "--input-res", f"{w}x{h}", "--preset", "ultrafast", "-p", "1", "-q", str(qp), "--debug", rec, "-o", os.path.join(workdir, "out.hevc")]
+    if not deblock:
+        cmd.append("--no-deblock")
+    subprocess.run(cmd, check=True, capture_output=True)
+    return list(np.fromfile(rec, dtype=np.uint8).reshape(len(frames), -1))
+
+
+def encoder_digests(workdir):
+    import ctu_common as cc
+    out = {}
+    for (w, h, n, seed, kind, qp) in ENCODER_CLIPS:
+        frames = cc.yuv_frames(w, h, n, seed, kind)
+        for deblock in (0, 1):
+            recs = reference_encoder_recon(w, h, frames, qp, deblock, workdir)
+            out[clip_key(w, h, n, seed, kind, qp, deblock)] = [hashlib.sha256(r.tobytes()).hexdigest()[:24] for r in recs]
+    return out
+
+
 def main():
     ref = flatapi.load_ref(0)  # generic strategies
     oracle = flatapi.load_oracle()
@@ -85,7 +124,13 @@ def main():
     json.dump(strategy_digests(ref, scan_table), open(os.path.join(HERE, "strategy_cases.json"), "w"), indent=0, sort_keys=True)
     json.dump(deblock_digests(ref.lib.kvz_ref_deblock_frame), open(os.path.join(HERE, "deblock.json"), "w"), indent=0, sort_keys=True)
     json.dump(sao_digests(ref.lib.kvz_ref_sao_frame), open(os.path.join(HERE, "sao_frame.json"), "w"), indent=0, sort_keys=True)
-    print("wrote strategy_cases.json, deblock.json, sao_frame.json")
+    json.dump({"entropy_fbits": [float(ref.lib.kvz_ref_entropy_fbits(i)) for i in range(128)],
+               "coeff_weights": {str(qp): int(ref.lib.kvz_ref_fast_coeff_weights(qp)) for qp in range(52)}},
+              open(os.path.join(HERE, "model_constants.json"), "w"), sort_keys=True)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        json.dump(encoder_digests(d), open(os.path.join(HERE, "encoder_recon.json"), "w"), indent=0, sort_keys=True)
+    print("wrote strategy_cases.json, deblock.json, sao_frame.json, model_constants.json, encoder_recon.json")
 
 
 if __name__ == "__main__":

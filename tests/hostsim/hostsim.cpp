@@ -48,7 +48,9 @@ extern "C" void kvz_hostsim_intra_frame(const kvz_hip_intra_cost_model *m, int w
   for (int cy = 0; cy < F.hc; cy++)
     for (int cx = 0; cx < F.wc; cx++) {
       kvz::CtuProgram p;
-      p.m = m; p.tb = &tb; p.F = F; p.s = sh; p.frame = 0; p.cx = cx * 64; p.cy = cy * 64;
+      kvz::CtuModel cm;
+      kvz::ctu_model_from(m, &cm);
+      p.m = &cm; p.tb = &tb; p.F = F; p.s = sh; p.frame = 0; p.cx = cx * 64; p.cy = cy * 64;
       p.run();
     }
   free(sh);

@@ -1,0 +1,126 @@
+"""End-to-end parity with the reference ENCODER: tests/golden/encoder_recon.json holds digests of the reconstruction that
+`kvazaar --preset ultrafast -p 1 -q QP --debug` (the CLI compiled from the reference tree, tests/golden/make_golden.py) writes for
+seeded clips.  The oracle's CTU pass (+ picture-level deblocking) must produce exactly those pictures -- which pins the search
+restatement (CU quadtree, modes, coefficients, adaptive CABAC contexts, WPP context hand-off) against the real encoder, not
+only against per-function outputs -- and so must the device sources (host simulation here, the MI355X under -m gpu)."""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import ctu_common as cc
+import deblock_common as dc
+import flatapi
+from test_hostsim import hostsim  # noqa: F401  (fixture)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden as mg  # noqa: E402
+
+GOLDEN = json.load(open(os.path.join(HERE, "golden", "encoder_recon.json")))
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:24]
+
+
+def _entropy_table():
+    return cc.model_constants()["entropy_fbits"]
+
+
+def oracle_model(oracle, qp):
+    import ctypes as C
+    fb = (C.c_float * 128)(*_entropy_table())
+    m = cc.CostModel()
+    f = oracle.lib.kvz_oracle_intra_cost_model
+    f.restype = None
+    f.argtypes = [C.c_int, C.c_float * 128, C.c_uint64, C.POINTER(cc.CostModel)]
+    f(qp, fb, cc.coeff_weights(qp), C.byref(m))
+    return m
+
+
+def _oracle_chain(oracle, model, w, h, frame, qp, deblock):
+    o = cc.run_oracle(oracle, model, w, h, frame)
+    if not deblock:
+        return o["rec"]
+    return dc.run_cpu(oracle.lib.kvz_oracle_deblock_frame, w, h, qp, 0, 0, o["rec"], o["depth"].reshape(h // 8, w // 8))
+
+
+CPU_CLIPS = [c for c in mg.ENCODER_CLIPS if c[0] * c[1] * c[2] <= 832 * 480]
+
+
+@pytest.mark.parametrize("clip", CPU_CLIPS, ids=lambda c: f"{c[0]}x{c[1]}-qp{c[5]}")
+def test_oracle_chain_reproduces_reference_encoder(oracle, clip):
+    w, h, n, seed, kind, qp = clip
+    model = oracle_model(oracle, qp)
+    frames = cc.yuv_frames(w, h, n, seed, kind)
+    for deblock in (0, 1):
+        got = [_sha(_oracle_chain(oracle, model, w, h, f, qp, deblock)) for f in frames]
+        assert got == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, deblock)], (clip, deblock)
+
+
+def test_frozen_contexts_do_not_reproduce_the_encoder(oracle):
+    """the adaptive contexts matter: with every context frozen at its slice-start state the pass is still a valid encode,
+    but not kvazaar's"""
+    w, h, n, seed, kind, qp = mg.ENCODER_CLIPS[3]
+    model = oracle_model(oracle, qp)
+    model.adaptive = 0
+    frames = cc.yuv_frames(w, h, n, seed, kind)
+    got = [_sha(_oracle_chain(oracle, model, w, h, f, qp, 0)) for f in frames]
+    assert got != GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0)]
+
+
+def test_encoder_fixture_matches_reference_build(tmp_path):
+    """where oracle/_ref exists, the committed fixture is what the reference CLI produces today (two small clips)"""
+    if not os.path.exists(os.path.join(flatapi.ROOT, "oracle", "_ref", "kvazaar_ref")):
+        pytest.skip("oracle/_ref not built")
+    for (w, h, n, seed, kind, qp) in mg.ENCODER_CLIPS[:3]:
+        frames = cc.yuv_frames(w, h, n, seed, kind)
+        for deblock in (0, 1):
+            recs = mg.reference_encoder_recon(w, h, frames, qp, deblock, str(tmp_path))
+            assert [_sha(r) for r in recs] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, deblock)]
+
+
+def test_entropy_fixture_matches_reference_build():
+    if not os.path.exists(flatapi.refshim_path()):
+        pytest.skip("oracle/_ref not built")
+    ref = flatapi.load_ref(0)
+    assert [float(ref.lib.kvz_ref_entropy_fbits(i)) for i in range(128)] == _entropy_table()
+    for qp in (10, 17, 22, 27, 37):
+        assert ref.lib.kvz_ref_fast_coeff_weights(qp) == cc.coeff_weights(qp)
+
+
+@pytest.mark.parametrize("clip", mg.ENCODER_CLIPS[:3], ids=lambda c: f"{c[0]}x{c[1]}-qp{c[5]}")
+def test_hostsim_pass_reproduces_reference_encoder(oracle, hostsim, clip):
+    """the device sources compiled for the host (tests/hostsim): their CTU pass is kvazaar's, picture for picture"""
+    hs = hostsim
+    w, h, n, seed, kind, qp = clip
+    model = oracle_model(oracle, qp)
+    frames = cc.yuv_frames(w, h, n, seed, kind)
+    got = [_sha(cc.run_hostsim(hs.lib, model, w, h, f)["rec"]) for f in frames]
+    assert got == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip", mg.ENCODER_CLIPS, ids=lambda c: f"{c[0]}x{c[1]}-qp{c[5]}")
+def test_hip_batch_reproduces_reference_encoder(clip):
+    """the product on the MI355X, no oracle in between: kvz_hip_intra_frames (+ kvz_hip_batch_deblock) with the model the
+    library builds itself == the reference encoder's reconstruction"""
+    import kvazaar_amd
+    lib = kvazaar_amd.load_library()
+    w, h, n, seed, kind, qp = clip
+    model = cc.hip_cost_model(lib, qp, cc.coeff_weights(qp))
+    frames = cc.yuv_frames(w, h, n, seed, kind)
+    b = cc.HipBatch(lib, w, h, n)
+    try:
+        for i, f in enumerate(frames):
+            b.upload(i, f)
+        b.run(model)
+        assert [_sha(b.download(i)["rec"]) for i in range(n)] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0)]
+        b.deblock(qp)
+        assert [_sha(b.download(i)["rec"]) for i in range(n)] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 1)]
+    finally:
+        b.close()
