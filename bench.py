@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-encoder", action="store_true")
+    ap.add_argument("--frozen-contexts", action="store_true", help="A/B only: freeze the CABAC contexts at slice start (not kvazaar's behaviour)")
     ap.add_argument("--tiles", default="", help="COLSxROWS: strong-scaling variant (BASELINE config 5): --frames pictures in total, cut into kvazaar's "
                                                 "uniform tiles, the tiles dealt to the ranks; every tile is an independent sub-picture (SURVEY.md 8e)")
     args = ap.parse_args()
@@ -131,7 +132,9 @@ def main():
     import ctu_common as cc
     import kvazaar_amd
     lib = kvazaar_amd.load_library()  # raises when libkvz_hip.so is missing: no fallback
-    model = cc.hip_cost_model(lib, args.qp, COEFF_WEIGHTS_QP22)
+    model = cc.hip_cost_model(lib, args.qp, cc.coeff_weights(args.qp))
+    if args.frozen_contexts:
+        model.adaptive = 0
 
     from kvazaar_amd import sharding
     batches = []  # (HipBatch, CTUs per picture of that batch, pictures)

@@ -125,7 +125,7 @@ KVZ_DEV u8 load_shared_byte(const u8 *p)
 #endif
 }
 
-struct CtuCu { u8 type, depth, mode, tr_depth; uint16_t cbf; uint16_t pad; };  // one per 8x8 (min CU)
+struct CtuCu { u8 type : 1, depth : 2, tr_depth : 2; u8 mode; uint16_t cbf; };  // one per 8x8 (min CU), 4 bytes: 4 levels x 64 of them live in LDS
 
 // The ten CABAC contexts the all-intra search prices syntax with (cabac.h:63-100), each as kvazaar's uc_state = state << 1 | MPS
 enum { KVZ_CX_SPLIT = 0 /* ..2 */, KVZ_CX_PART = 3, KVZ_CX_INTRA = 4, KVZ_CX_CHROMA = 5, KVZ_CX_CBF_LUMA = 6 /* ..7 */, KVZ_CX_CBF_CHROMA = 8 /* ..9 */, KVZ_CX_COUNT = 10 };
@@ -235,6 +235,8 @@ struct CtuShared {
   // depth d (search.c:655; pre[0] is the row's state->cabac the search started from, search.c:1211, and what the CTU's real syntax
   // is replayed on afterwards); post2 = after the 16x16 CU was evaluated (search.c:956)
   CtxSet cab, pre[3], post2;
+  float entropy_fbits[128];  // the model's price table and Tables::ctx_next, staged per CTU: every lookup sits on lane 0's critical path
+  u8 ctx_next[2][128];
 };
 
 static const int kPlaneOff[3] = { 0, 4096, 5120 };
@@ -364,17 +366,16 @@ struct CtuProgram {
   KVZ_DEV double ctx_price(CtxSet *c, int idx, int bin, bool update) const
   {
     const int st = c->s[idx];
-    const double bits = (double)m->entropy_fbits[st ^ bin];
-    if (update && m->adaptive) c->s[idx] = tb->ctx_next[bin != (st & 1)][st];
+    const double bits = (double)s->entropy_fbits[st ^ bin];
+    if (update && m->adaptive) c->s[idx] = s->ctx_next[bin != (st & 1)][st];
     return bits;
   }
-  KVZ_DEV void ctx_code(CtxSet *c, int idx, int bin) const { const int st = c->s[idx]; c->s[idx] = tb->ctx_next[bin != (st & 1)][st]; }
   // lambda_sqrt * kvz_luma_mode_bits of the three possible outcomes at the current state of the intra-mode context; the rough
   // search prices with it without touching the context (search_intra.c:524: search_cabac.update == 0 there).  One lane.
   KVZ_DEV void price_modes() const
   {
     const int st = s->cab.s[KVZ_CX_INTRA];
-    const double f0 = (double)m->entropy_fbits[st ^ 0], f1 = (double)m->entropy_fbits[st ^ 1];
+    const double f0 = (double)s->entropy_fbits[st ^ 0], f1 = (double)s->entropy_fbits[st ^ 1];
     s->mode_bits_cost[0] = m->lambda_sqrt * (f0 + 5);
     s->mode_bits_cost[1] = m->lambda_sqrt * (f1 + 1);
     s->mode_bits_cost[2] = m->lambda_sqrt * (f1 + 2);
@@ -1099,7 +1100,7 @@ struct CtuProgram {
     KVZ_FOR_THREADS(tid) {
       for (int e = tid; e < 6144; e += KVZ_CTU_THREADS) s->dec[e] = 0;
       for (int lv = 0; lv < 4; lv++)
-        if (tid < 64) { CtuCu z = { 0, 0, 0, 0, 0, 0 }; s->cu[lv][tid] = z; }
+        if (tid < 64) { CtuCu z = { 0, 0, 0, 0, 0 }; s->cu[lv][tid] = z; }
       // Coefficient buffers start zeroed like the lcu_t copies (search.c:1084).  Only observable for CTUs that stick out
       // of the picture: inside the picture every coefficient that reaches level 0 was written by a transform unit first.
       if (cx + 64 > F.W || cy + 64 > F.H)
@@ -1148,6 +1149,8 @@ struct CtuProgram {
         s->mode_inv[mode] = (int16_t)(mode < 2 ? 0 : inv_tab[ad]);
       }
       if (v >= 128 && v < 136) s->qs[(v - 128) >> 1][v & 1] = quant_scalars_dev(2 + ((v - 128) >> 1), (v & 1) ? 2 : 0);
+      if (v < 128) s->entropy_fbits[v] = m->entropy_fbits[v];
+      s->ctx_next[v >> 7][v & 127] = tb->ctx_next[v >> 7][v & 127];
       if (v >= 144 && v < 144 + KVZ_CX_COUNT) {
         // the row's contexts: from the CTU to the left; a row's first CTU from the second CTU of the row above (WPP; rows of a
         // one-CTU-wide picture and the first row start from the slice-start state, encoderstate.c:1218)
@@ -1195,6 +1198,17 @@ struct CtuProgram {
   // the cell's alignment.  One lane.
   KVZ_DEV void code_ctu_syntax(CtxSet *c) const
   {
+    // the ten states travel in two registers (8 bits each): every bin then costs one table lookup instead of an LDS round trip
+    // for the state as well -- this loop is serial, on one lane, and the row's next CTU waits for its result
+    unsigned long long lo = 0, hi = 0;
+    for (int k = 0; k < 8; k++) lo |= (unsigned long long)c->s[k] << (8 * k);
+    hi = (unsigned long long)c->s[8] | ((unsigned long long)c->s[9] << 8);
+    auto ctx_code = [&](int idx, int bin) {
+      const int sh = (idx & 7) * 8;
+      const int st = (int)(((idx < 8 ? lo : hi) >> sh) & 0xff);
+      const unsigned long long nx = s->ctx_next[bin != (st & 1)][st], keep = ~(0xffull << sh);
+      if (idx < 8) lo = (lo & keep) | (nx << sh); else hi = (hi & keep) | (nx << sh);
+    };
     int i = 0;
     while (i < 64) {
       const int xl = ((i & 1) | ((i >> 1) & 2) | ((i >> 2) & 4)) * 8, yl = (((i >> 1) & 1) | ((i >> 2) & 2) | ((i >> 3) & 4)) * 8, x = cx + xl, y = cy + yl;
@@ -1206,35 +1220,37 @@ struct CtuProgram {
         if (d != 3) {
           const bool border = F.W < x + w || F.H < y + w;
           const bool split = cu->depth > d;  // GET_SPLITDATA
-          if (!border) ctx_code(c, KVZ_CX_SPLIT + split_model(0, x, y, d), split);
+          if (!border) ctx_code(KVZ_CX_SPLIT + split_model(0, x, y, d), split);
           if (split || border) continue;
         }
         break;
       }
-      if (d == 3) ctx_code(c, KVZ_CX_PART, 1);  // part_mode 2Nx2N at the minimum CU size
+      if (d == 3) ctx_code(KVZ_CX_PART, 1);  // part_mode 2Nx2N at the minimum CU size
       {
         CtuCu lc, ac, *left = nullptr, *above = nullptr;
         if (x > 0 && neighbour_cu(0, x - 1, y, &lc)) left = &lc;
         if ((y & 63) > 0 && neighbour_cu(0, x, y - 1, &ac)) above = &ac;
         int8_t preds[3];
         mpm_candidates(y, left, above, preds);
-        ctx_code(c, KVZ_CX_INTRA, cu->mode == preds[0] || cu->mode == preds[1] || cu->mode == preds[2]);  // prev_intra_luma_pred_flag; mpm_idx / rem mode are bypass
-        ctx_code(c, KVZ_CX_CHROMA, 0);  // intra_chroma_pred_mode: derived from luma
+        ctx_code(KVZ_CX_INTRA, cu->mode == preds[0] || cu->mode == preds[1] || cu->mode == preds[2]);  // prev_intra_luma_pred_flag; mpm_idx / rem mode are bypass
+        ctx_code(KVZ_CX_CHROMA, 0);  // intra_chroma_pred_mode: derived from luma
       }
       // transform tree: split_transform_flag is never coded (tr_depth_intra = 0; the 64x64 split is inferred, encode_coding_tree.c:236-243)
       const int cb_u = cbf_is_set(cu->cbf, d, 1), cb_v = cbf_is_set(cu->cbf, d, 2);
-      ctx_code(c, KVZ_CX_CBF_CHROMA, cb_u);
-      ctx_code(c, KVZ_CX_CBF_CHROMA, cb_v);
+      ctx_code(KVZ_CX_CBF_CHROMA, cb_u);
+      ctx_code(KVZ_CX_CBF_CHROMA, cb_v);
       if (d == 0) {
         for (int q = 0; q < 4; q++) {
           const CtuCu *t = &s->cu[0][(q >> 1) * 32 + (q & 1) * 4];
-          if (cb_u) ctx_code(c, KVZ_CX_CBF_CHROMA + 1, cbf_is_set(t->cbf, 1, 1));
-          if (cb_v) ctx_code(c, KVZ_CX_CBF_CHROMA + 1, cbf_is_set(t->cbf, 1, 2));
-          ctx_code(c, KVZ_CX_CBF_LUMA, cbf_is_set(t->cbf, 1, 0));
+          if (cb_u) ctx_code(KVZ_CX_CBF_CHROMA + 1, cbf_is_set(t->cbf, 1, 1));
+          if (cb_v) ctx_code(KVZ_CX_CBF_CHROMA + 1, cbf_is_set(t->cbf, 1, 2));
+          ctx_code(KVZ_CX_CBF_LUMA, cbf_is_set(t->cbf, 1, 0));
         }
-      } else ctx_code(c, KVZ_CX_CBF_LUMA + 1, cbf_is_set(cu->cbf, d, 0));  // always present for intra (encode_coding_tree.c:276-279)
+      } else ctx_code(KVZ_CX_CBF_LUMA + 1, cbf_is_set(cu->cbf, d, 0));  // always present for intra (encode_coding_tree.c:276-279)
       i += 1 << (2 * (3 - d));
     }
+    for (int k = 0; k < 8; k++) c->s[k] = (u8)(lo >> (8 * k));
+    c->s[8] = (u8)hi; c->s[9] = (u8)(hi >> 8);
   }
   // ... and the CU-info half: level 0 -> cu arrays, CTU cost, CU part of the border record; coefficients already there
   KVZ_DEV void finish_info()
