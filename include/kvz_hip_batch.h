@@ -12,9 +12,10 @@
  * WPP order of encoderstate.c:793-903.  One kernel launch processes the anti-diagonal x + 2y = const of EVERY
  * frame of the batch.
  *
- * Decisions use kvazaar's own cost formulas with CABAC contexts frozen at slice-init state
- * (kvz_hip_intra_cost_model); all pixel / coefficient results are bit-exact with the generic strategy kernels.
- * The checker for this path is oracle/kvz_oracle_ctu.c.
+ * Decisions use kvazaar's own cost formulas, in double precision with the reference's operation order, on CABAC contexts
+ * that evolve as kvazaar's do (kvz_hip_intra_cost_model): for QP < 28 the reconstruction, CU quadtree, modes and coefficients
+ * are those of `kvazaar --preset ultrafast -p 1`, picture for picture (tests/test_encoder_parity.py checks the pass against
+ * digests of the reference CLI's --debug output).  The checker for every intermediate is oracle/kvz_oracle_ctu.c.
  */
 #ifndef KVZ_HIP_BATCH_H_
 #define KVZ_HIP_BATCH_H_
@@ -59,7 +60,7 @@ void kvz_hip_batch_deblock(kvz_hip_batch *b, int qp, int beta_offset_div2, int t
  * Queued behind whatever the batch's stream holds (CTU pass, deblocking) and waited for. */
 void kvz_hip_batch_checksums(kvz_hip_batch *b, uint32_t *host_out);
 
-/* Frozen-context cost model of an I slice at `qp` (kvz_hip_intra_cost_model): HEVC context init values
+/* Cost model of an I slice at `qp` (kvz_hip_intra_cost_model, adaptive contexts): HEVC context init values
  * (context.c:96-134), kvz_ctx_init (context.c:202-213), the HM entropy table (rdo.c:69-80), lambda of
  * rate_control.c:678-691.  coeff_weights = kvz_fast_coeff_get_weights(state) of the encoder (fast_coeff_cost.c:84-88). */
 void kvz_hip_intra_cost_model_init(int qp, uint64_t coeff_weights, kvz_hip_intra_cost_model *model);

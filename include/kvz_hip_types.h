@@ -61,13 +61,20 @@ typedef struct kvz_hip_epol_params {
 } kvz_hip_epol_params;
 
 /* Bit-cost model of the batched all-intra CTU pass (kvz_hip_batch.h).  kvazaar prices syntax elements with
- * CTX_ENTROPY_FBITS(ctx, val) = kvz_f_entropy_bits[ctx->uc_state ^ val] (cabac.h:131) on a CABAC context copy that
- * adapts while it searches (search.c:1211, encode_coding_tree.c:948); the batched pass keeps every context at the
- * state kvz_init_contexts gives it for an I slice at this QP (context.c:202-282) -- "frozen contexts" -- so that CTUs
- * only depend on each other through reconstructed pixels and CU info.  Each entry is fbits[val] of one context. */
+ * CTX_ENTROPY_FBITS(ctx, val) = kvz_f_entropy_bits[ctx->uc_state ^ val] (cabac.h:131) on a copy of the row's CABAC contexts that
+ * adapts while it searches (search.c:1211, encode_coding_tree.c:948).  With adaptive != 0 (what kvz_hip_intra_cost_model_init
+ * sets) the pass does the same: the ten contexts the all-intra ultrafast search touches are updated by the mock encode of every
+ * CU the search evaluates, with the save / restore points of search_cu (search.c:655-1060), then by the real syntax of the
+ * finished CTU in coding order (encode_coding_tree.c:745), and handed from CTU to CTU along a row and from the second CTU of a
+ * row to the first of the row below (WPP, encoderstate.c:763-771) -- the reconstruction is then kvazaar's own, picture for
+ * picture (tests/test_encoder_parity.py), for QP < fast_residual_cost_limit (cfg.c: 28 in `ultrafast`; above it kvazaar
+ * prices coefficients with the full CABAC model, which the pass does not cover).  adaptive == 0 keeps every context at its
+ * slice-start state: CTUs then depend on each other through pixels and CU info only; a valid encode, not kvazaar's. */
 typedef struct kvz_hip_intra_cost_model {
   double   lambda;            /* state->lambda: 0.57 * 2^((qp-12)/3) at constant QP (rate_control.c:678-691) */
   double   lambda_sqrt;       /* state->lambda_sqrt */
+  /* fbits[val] of each context at its slice-start state (= entropy_fbits[ctx_init[i] ^ val]; informational, the pass prices
+   * from ctx_init / entropy_fbits): */
   float    split_flag[3][2];  /* ctx.split_flag_model[0..2]      (search.c:952-956, encode_coding_tree.c:985-997) */
   float    part_size[2];      /* ctx.part_size_model[0]          (encode_coding_tree.c:695-703) */
   float    intra_mode[2];     /* ctx.intra_mode_model            (search_intra.c:641-676) */
@@ -76,12 +83,9 @@ typedef struct kvz_hip_intra_cost_model {
   float    cbf_chroma[2][2];  /* ctx.qt_cbf_model_chroma[0..1]   (search.c:463-470) */
   uint64_t coeff_weights;     /* kvz_fast_coeff_get_weights(state): 4 x Q8.8 (fast_coeff_cost.c:84-88) */
   int32_t  qp;                /* state->qp (constant over the frame) */
-  /* adaptive != 0: the contexts evolve exactly as in kvazaar -- updated by the mock encode of every CU the search evaluates
-   * with the save / restore points of search_cu (search.c:655-1060), by the real syntax of every finished CTU in coding order
-   * (encode_coding_tree.c:745), and handed from CTU to CTU along a row and from the second CTU of a row to the row below
-   * (WPP, encoderstate.c:763-771).  The float tables above are then unused; ctx_init / entropy_fbits drive the pricing. */
-  int32_t  adaptive;
-  uint8_t  ctx_init[16];      /* uc_state at slice start of: split_flag[0..2], part_size[0], intra_mode, chroma_pred[0], cbf_luma[0..1], cbf_chroma[0..1] */
+  int32_t  adaptive;          /* see above */
+  uint8_t  ctx_init[16];      /* uc_state at slice start (kvz_init_contexts, context.c:202-282) of: split_flag[0..2], part_size[0], intra_mode,
+                                 chroma_pred[0], cbf_luma[0..1], cbf_chroma[0..1]; the rest unused */
   float    entropy_fbits[128];/* kvz_f_entropy_bits (rdo.c:69-83) */
 } kvz_hip_intra_cost_model;
 

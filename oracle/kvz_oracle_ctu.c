@@ -20,12 +20,16 @@
  *   cu_rd_cost_tr_split_accurate   search.c:425          -> rd_cost()
  * The pixel/coefficient kernels are the pinned kvz_oracle_* functions of kvz_oracle.c.
  *
- * ONE documented divergence from the encoder: CABAC contexts are FROZEN at their slice-init state
- * (kvz_hip_intra_cost_model), i.e. the `cabac->update` side effects of CABAC_FBITS_UPDATE (cabac.h:133-139) and
- * the carry-over of state->cabac between CTUs (search.c:1211) are not modelled.  That is what makes CTUs
- * independent up to reconstructed pixels, and it is why the batched pass does not reproduce kvazaar's bitstream
- * (the per-call drop-in does; tests/test_e2e_dropin.py).  Decisions are otherwise kvazaar's own formulas, in
- * double precision with the reference's operation order.
+ * CABAC contexts (kvz_hip_intra_cost_model::adaptive, the default): the ten contexts this configuration prices syntax with
+ * follow kvazaar's life cycle -- search_cabac = copy of the row's state->cabac per CTU (search.c:1211), updates only around
+ * the mock encode and cu_rd_cost_tr_split_accurate of an evaluated CU (search.c:895-940), the pre / post / temp copies of
+ * search_cu (search.c:655, 956-959, 1005-1041, 1051), the real syntax of each finished CTU on the row's state
+ * (code_coding_tree below), WPP seeding of the next row from a row's second CTU (encoderstate.c:763-771).  The mock encode's
+ * left-neighbour lookup at the LCU's left edge is followed as well (intra_mode_syntax_bits).  PINNED END TO END: the pass
+ * (+ kvz_oracle_deblock_frame) reproduces the reconstruction `kvazaar --preset ultrafast -p 1 --debug` writes, picture for
+ * picture, for QP < 28 (tests/test_encoder_parity.py, tests/golden/encoder_recon.json).  At QP >= 28 `ultrafast` switches to
+ * the full CABAC coefficient cost (fast_residual_cost_limit, rdo.c:311-326), which is not restated here.
+ * adaptive == 0 freezes every context at its slice-start state (CTUs then interact through pixels and CU info only).
  */
 #include <math.h>
 #include <stdlib.h>
@@ -383,7 +387,7 @@ static void recon_cu(ctu_t *t, level_t *lv, int x, int y, int depth, int mode, i
   }
 }
 
-/* search.c:425-541 cu_rd_cost_tr_split_accurate (intra CU, frozen contexts, fast coefficient cost rdo.c:311-326) */
+/* search.c:425-541 cu_rd_cost_tr_split_accurate (intra CU, fast coefficient cost rdo.c:311-326) */
 static double rd_cost(ctu_t *t, level_t *lv, int xl, int yl, int depth, const cu_t *pred_cu, int update)
 {
   const kvz_hip_intra_cost_model *m = t->m;
@@ -677,7 +681,7 @@ void kvz_oracle_intra_frame(const kvz_hip_intra_cost_model *m, int width, int he
   free(t);
 }
 
-/* The frozen-context cost model for QP `qp` of an I slice (kvz_hip_intra_cost_model): context init values of the
+/* The cost model for QP `qp` of an I slice (kvz_hip_intra_cost_model): context init values of the
  * HEVC spec as kvazaar tabulates them (context.c:96-134, I-slice row), kvz_ctx_init (context.c:202-213) and the
  * entropy table passed in by the caller (kvz_f_entropy_bits, rdo.c:83) -- tests take it from the reference build. */
 void kvz_oracle_intra_cost_model(int qp, const float entropy_fbits[128], uint64_t coeff_weights, kvz_hip_intra_cost_model *m)
