@@ -70,6 +70,29 @@ typedef struct kvz_hip_epol_params {
  * picture (tests/test_encoder_parity.py), for QP < fast_residual_cost_limit (cfg.c: 28 in `ultrafast`; above it kvazaar
  * prices coefficients with the full CABAC model, which the pass does not cover).  adaptive == 0 keeps every context at its
  * slice-start state: CTUs then depend on each other through pixels and CU info only; a valid encode, not kvazaar's. */
+/* Index of each context in kvz_hip_intra_cost_model::ctx_init (cabac.h:63-100): CU / transform-tree syntax, then the residual-coding
+ * contexts, which only matter when coefficients are priced with the CABAC model (coeff_cabac). */
+enum {
+  KVZ_HIP_CX_SPLIT = 0,          /* split_flag_model[0..2] */
+  KVZ_HIP_CX_PART = 3,           /* part_size_model[0] */
+  KVZ_HIP_CX_INTRA = 4,          /* intra_mode_model */
+  KVZ_HIP_CX_CHROMA = 5,         /* chroma_pred_model[0] */
+  KVZ_HIP_CX_CBF_LUMA = 6,       /* qt_cbf_model_luma[0..1] */
+  KVZ_HIP_CX_CBF_CHROMA = 8,     /* qt_cbf_model_chroma[0..1] */
+  KVZ_HIP_CX_SIG_CG = 10,        /* cu_sig_coeff_group_model[0..3] */
+  KVZ_HIP_CX_SIG_LUMA = 14,      /* cu_sig_model_luma[0..26] */
+  KVZ_HIP_CX_SIG_CHROMA = 41,    /* cu_sig_model_chroma[0..14] */
+  KVZ_HIP_CX_LAST_Y_LUMA = 56,   /* cu_ctx_last_y_luma[0..14] */
+  KVZ_HIP_CX_LAST_Y_CHROMA = 71, /* cu_ctx_last_y_chroma[0..14] */
+  KVZ_HIP_CX_LAST_X_LUMA = 86,   /* cu_ctx_last_x_luma[0..14] */
+  KVZ_HIP_CX_LAST_X_CHROMA = 101,/* cu_ctx_last_x_chroma[0..14] */
+  KVZ_HIP_CX_ONE_LUMA = 116,     /* cu_one_model_luma[0..15] */
+  KVZ_HIP_CX_ONE_CHROMA = 132,   /* cu_one_model_chroma[0..7] */
+  KVZ_HIP_CX_ABS_LUMA = 140,     /* cu_abs_model_luma[0..3] */
+  KVZ_HIP_CX_ABS_CHROMA = 144,   /* cu_abs_model_chroma[0..1] */
+  KVZ_HIP_CX_COUNT = 146
+};
+
 typedef struct kvz_hip_intra_cost_model {
   double   lambda;            /* state->lambda: 0.57 * 2^((qp-12)/3) at constant QP (rate_control.c:678-691) */
   double   lambda_sqrt;       /* state->lambda_sqrt */
@@ -84,8 +107,11 @@ typedef struct kvz_hip_intra_cost_model {
   uint64_t coeff_weights;     /* kvz_fast_coeff_get_weights(state): 4 x Q8.8 (fast_coeff_cost.c:84-88) */
   int32_t  qp;                /* state->qp (constant over the frame) */
   int32_t  adaptive;          /* see above */
-  uint8_t  ctx_init[16];      /* uc_state at slice start (kvz_init_contexts, context.c:202-282) of: split_flag[0..2], part_size[0], intra_mode,
-                                 chroma_pred[0], cbf_luma[0..1], cbf_chroma[0..1]; the rest unused */
+  /* != 0: coefficients are priced by running the residual coder in counting mode (get_coeff_cabac_cost, rdo.c:220-263) instead of
+   * the fast estimate (kvz_fast_coeff_cost); what kvazaar does for QP >= fast_residual_cost_limit (28 in `ultrafast`), rdo.c:311-340 */
+  int32_t  coeff_cabac;
+  int32_t  reserved;
+  uint8_t  ctx_init[160];     /* uc_state at slice start (kvz_init_contexts, context.c:202-305) of the KVZ_HIP_CX_* contexts; the rest unused */
   float    entropy_fbits[128];/* kvz_f_entropy_bits (rdo.c:69-83) */
 } kvz_hip_intra_cost_model;
 

@@ -114,7 +114,7 @@ struct kvz_hip_batch {
   double *d_cost;
   uint8_t *d_border;
   unsigned long long *d_prof;
-  float *d_entropy;  // the model's entropy_fbits of the run in flight
+  float *d_entropy;  // the model's entropy_fbits [128 floats] followed by its ctx_init [160 bytes] of the run in flight
   uint32_t *d_items;
   unsigned *d_ticket, *d_done, *d_error;
   unsigned total_items, epoch;
@@ -147,8 +147,15 @@ inline int ctx_state(int qp, int init_value)
 
 inline void cost_model_init(int qp, uint64_t coeff_weights, kvz_hip_intra_cost_model *m)
 {
-  // I-slice rows of context.c:96-134 (HEVC spec tables 9-5 ff.)
+  // I-slice rows of context.c:96-193 (HEVC spec tables 9-5 ff.); 154 = CNU, never coded
   static const uint8_t init_split[3] = { 139, 141, 157 }, init_cbf_luma[2] = { 111, 141 }, init_cbf_chroma[2] = { 94, 138 };
+  static const uint8_t init_sig_cg[4] = { 91, 171, 134, 141 };
+  static const uint8_t init_sig[42] = { 111, 111, 125, 110, 110, 94, 124, 108, 124, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125,
+                                        140, 139, 182, 182, 152, 136, 152, 136, 153, 136, 139, 111, 136, 139, 111 };
+  static const uint8_t init_last[30] = { 110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63,
+                                         154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154 };
+  static const uint8_t init_one[24] = { 140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166, 182, 140, 227, 122, 197 };
+  static const uint8_t init_abs[6] = { 138, 153, 136, 167, 152, 152 };
   memset(m, 0, sizeof *m);
   m->qp = qp;
   m->lambda = 0.57 * pow(2.0, (qp - 12) / 3.0);
@@ -158,7 +165,7 @@ inline void cost_model_init(int qp, uint64_t coeff_weights, kvz_hip_intra_cost_m
   int n = 0;
   auto fill = [&](float dst[2], int init) {
     const int st = ctx_state(qp, init);
-    m->ctx_init[n++] = (uint8_t)st;  // same order as the KVZ_CX_* indices
+    m->ctx_init[n++] = (uint8_t)st;  // same order as the KVZ_HIP_CX_* indices
     dst[0] = m->entropy_fbits[st ^ 0];
     dst[1] = m->entropy_fbits[st ^ 1];
   };
@@ -168,7 +175,20 @@ inline void cost_model_init(int qp, uint64_t coeff_weights, kvz_hip_intra_cost_m
   fill(m->chroma_mode, 63);
   for (int i = 0; i < 2; i++) fill(m->cbf_luma[i], init_cbf_luma[i]);
   for (int i = 0; i < 2; i++) fill(m->cbf_chroma[i], init_cbf_chroma[i]);
+  auto put = [&](int at, const uint8_t *init, int count) { for (int i = 0; i < count; i++) m->ctx_init[at + i] = (uint8_t)ctx_state(qp, init[i]); };
+  put(KVZ_HIP_CX_SIG_CG, init_sig_cg, 4);
+  put(KVZ_HIP_CX_SIG_LUMA, init_sig, 27);
+  put(KVZ_HIP_CX_SIG_CHROMA, init_sig + 27, 15);
+  put(KVZ_HIP_CX_LAST_Y_LUMA, init_last, 15);
+  put(KVZ_HIP_CX_LAST_Y_CHROMA, init_last + 15, 15);
+  put(KVZ_HIP_CX_LAST_X_LUMA, init_last, 15);
+  put(KVZ_HIP_CX_LAST_X_CHROMA, init_last + 15, 15);
+  put(KVZ_HIP_CX_ONE_LUMA, init_one, 16);
+  put(KVZ_HIP_CX_ONE_CHROMA, init_one + 16, 8);
+  put(KVZ_HIP_CX_ABS_LUMA, init_abs, 4);
+  put(KVZ_HIP_CX_ABS_CHROMA, init_abs + 4, 2);
   m->adaptive = 1;
+  m->coeff_cabac = qp >= 28;  // `ultrafast`: fast-residual-cost 28 (cfg.c:485-512), rdo.c:311-340
 }
 
 }  // namespace kvz
@@ -204,7 +224,7 @@ kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_prof, 2 * kvz::KVZ_P_COUNT * sizeof(unsigned long long)));
   KVZ_HIP_CHECK(hipMemsetAsync(b->d_prof, 0, 2 * kvz::KVZ_P_COUNT * sizeof(unsigned long long), b->stream));
   F.prof = b->d_prof;
-  KVZ_HIP_CHECK(hipMalloc((void **)&b->d_entropy, 128 * sizeof(float)));
+  KVZ_HIP_CHECK(hipMalloc((void **)&b->d_entropy, 128 * sizeof(float) + sizeof(((kvz_hip_intra_cost_model *)0)->ctx_init)));
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_border, nctu * KVZ_BORDER_BYTES));
   KVZ_HIP_CHECK(hipMemsetAsync(b->d_border, 0, nctu * KVZ_BORDER_BYTES, b->stream));
   F.border = b->d_border;
@@ -289,7 +309,9 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
   kvz::CtuModel cm;
   kvz::ctu_model_from(model, &cm);
   cm.entropy_fbits = b->d_entropy;
+  cm.ctx_init = (const uint8_t *)(b->d_entropy + 128);
   KVZ_HIP_CHECK(hipMemcpyAsync(b->d_entropy, model->entropy_fbits, 128 * sizeof(float), hipMemcpyHostToDevice, b->stream));
+  KVZ_HIP_CHECK(hipMemcpyAsync(b->d_entropy + 128, model->ctx_init, sizeof model->ctx_init, hipMemcpyHostToDevice, b->stream));
   if (b->sched_ticket) {
     b->epoch++;
     KVZ_HIP_CHECK(hipMemsetAsync(b->d_ticket, 0, 2 * sizeof(unsigned), b->stream));

@@ -127,24 +127,28 @@ KVZ_DEV u8 load_shared_byte(const u8 *p)
 
 struct CtuCu { u8 type : 1, depth : 2, tr_depth : 2; u8 mode; uint16_t cbf; };  // one per 8x8 (min CU), 4 bytes: 4 levels x 64 of them live in LDS
 
-// The ten CABAC contexts the all-intra search prices syntax with (cabac.h:63-100), each as kvazaar's uc_state = state << 1 | MPS
-enum { KVZ_CX_SPLIT = 0 /* ..2 */, KVZ_CX_PART = 3, KVZ_CX_INTRA = 4, KVZ_CX_CHROMA = 5, KVZ_CX_CBF_LUMA = 6 /* ..7 */, KVZ_CX_CBF_CHROMA = 8 /* ..9 */, KVZ_CX_COUNT = 10 };
-struct CtxSet { u8 s[12]; };
+// The CABAC contexts the all-intra search prices syntax with (cabac.h:63-100; indices: KVZ_HIP_CX_* of kvz_hip_types.h), each as
+// kvazaar's uc_state = state << 1 | MPS: ten for the CU / transform-tree syntax, then the residual-coding ones, which only move
+// when coefficients are priced with the CABAC model (CtuModel::coeff_cabac)
+enum { KVZ_CX_SPLIT = KVZ_HIP_CX_SPLIT, KVZ_CX_PART = KVZ_HIP_CX_PART, KVZ_CX_INTRA = KVZ_HIP_CX_INTRA, KVZ_CX_CHROMA = KVZ_HIP_CX_CHROMA,
+       KVZ_CX_CBF_LUMA = KVZ_HIP_CX_CBF_LUMA, KVZ_CX_CBF_CHROMA = KVZ_HIP_CX_CBF_CHROMA, KVZ_CX_SYNTAX_COUNT = KVZ_HIP_CX_SIG_CG, KVZ_CX_COUNT = KVZ_HIP_CX_COUNT };
+struct CtxSet { alignas(4) u8 s[148]; };
 
 // What the CTU program reads of kvz_hip_intra_cost_model, compact (the device keeps it in LDS; the 128-entry price table stays
 // behind a pointer: a copy in HBM on the device)
 struct CtuModel {
   double lambda, lambda_sqrt;
   uint64_t coeff_weights;
-  int qp, adaptive;
-  u8 ctx_init[16];
-  const float *entropy_fbits;
+  int qp, adaptive, coeff_cabac;
+  const float *entropy_fbits;  // [128]
+  const u8 *ctx_init;          // [KVZ_CX_COUNT]
 };
 KVZ_HD void ctu_model_from(const kvz_hip_intra_cost_model *src, CtuModel *dst)
 {
   dst->lambda = src->lambda; dst->lambda_sqrt = src->lambda_sqrt; dst->coeff_weights = src->coeff_weights; dst->qp = src->qp; dst->adaptive = src->adaptive;
-  for (int i = 0; i < 16; i++) dst->ctx_init[i] = src->ctx_init[i];
+  dst->coeff_cabac = src->coeff_cabac;
   dst->entropy_fbits = src->entropy_fbits;
+  dst->ctx_init = src->ctx_init;
 }
 
 // Frame-level device buffers of one batch (all frames share the geometry).
@@ -161,13 +165,13 @@ struct CtuFrames {
   // What a CTU hands to its right / lower neighbours: KVZ_BORDER_BYTES per CTU = three 128-byte lines with ONE producer each
   //   [0..127]   bottom row   Y 64 | U 32 | V 32        [128..255] right column Y 64 | U 32 | V 32
   //   [256..287] CU info: depth of the bottom 8x8 row [8], mode [8], depth of the right 8x8 column [8], mode [8]
-  //   [288..297] the row's CABAC contexts after this CTU's syntax (KVZ_CX_*): what the CTU to the right starts from, and -- from
+  //   [288..433] the row's CABAC contexts after this CTU's syntax (KVZ_CX_*): what the CTU to the right starts from, and -- from
   //              the second CTU of a row -- the first CTU of the row below (WPP, encoderstate.c:763-771)
   // Neighbour data is exchanged ONLY through these records: the frame-level rec / cu arrays share cache lines between CTUs
   // produced on different XCDs, and a line that is dirty in the reader's L2 cannot be invalidated by its acquire.
   u8 *border;                // [frames][ctu][KVZ_BORDER_BYTES]
 };
-#define KVZ_BORDER_BYTES 384
+#define KVZ_BORDER_BYTES 512
 
 struct CtuShared {
   alignas(8) u8 org[1536];   // source pixels of the 32x32 quadrant being searched: Y 32x32 | U 16x16 | V 16x16 (load_org())
@@ -197,7 +201,7 @@ struct CtuShared {
       alignas(8) u8 org_t[256];  // the CU's source block transposed (horizontal modes are predicted and scored transposed)
       u8 c2[384];              // depth-2 candidate (16x16 CU):     Y 256 | U 64 | V 64
       u8 c3[384];              // depth-3 candidates (the four 8x8 CUs of the current 16x16)
-      u8 pred[2 * 256];        // planar and DC predictions of the CU being searched (<= 16x16)
+      alignas(8) u8 pred[2 * 256];  // planar and DC predictions of the CU being searched (<= 16x16)
       // Rough search, the 15 angular modes with a negative displacement (11..25): the main reference with its projected
       // extension (intra-generic.c:97-123), already picked from the filtered / unfiltered, top / left arrays.  Entry
       // [mode - 11][KVZ_MREF_ORG + q] is ref_main[q], q in [-w, w + 1] -- all such a mode can touch.  The other modes read
@@ -206,15 +210,15 @@ struct CtuShared {
       u32 satd_raw[35][4];     // sum |Hadamard| per (mode, 8x8 block) before the per-block rounding
     };
   };
-  i16 lv2_coeff[384];        // quantised levels of the 16x16 CU being tried (Y 256 | U 64 | V 64): they only go to HBM if it wins
-  i16 lv1_coeff[1536];       // ... and of the 32x32 merge being tried (Y 1024 | U 256 | V 256)
+  alignas(8) i16 lv2_coeff[384];        // quantised levels of the 16x16 CU being tried (Y 256 | U 64 | V 64): they only go to HBM if it wins
+  alignas(8) i16 lv1_coeff[1536];       // ... and of the 32x32 merge being tried (Y 1024 | U 256 | V 256)
   u32 acc[16];               // [0..2] ssd per plane, [3..5] coeff weight sums, [6..8] non-zero counts
   int8_t preds[3];
   int best_mode;
   // uniform scalars carried between phases (written by lane 0, read by everybody after the barrier)
   double cost[4], split_cost[4];  // per depth: the CU as one unit / split in four
   double res[4];                  // per depth: the cheaper of the two, what the parent adds up
-  double child_rd[4];
+  double child_bits[4];           // 64x64 attempt: CABAC-model bits of each 32x32 unit's coefficients (priced right after its reconstruction)
   u32 child_acc[4][9];
   int cbf_any;
   // neighbour CTUs' data, staged once per CTU: reconstructed border pixels and CU info of the left column / top row
@@ -235,8 +239,8 @@ struct CtuShared {
   // depth d (search.c:655; pre[0] is the row's state->cabac the search started from, search.c:1211, and what the CTU's real syntax
   // is replayed on afterwards); post2 = after the 16x16 CU was evaluated (search.c:956)
   CtxSet cab, pre[3], post2;
-  float entropy_fbits[128];  // the model's price table and Tables::ctx_next, staged per CTU: every lookup sits on lane 0's critical path
-  u8 ctx_next[2][128];
+  float entropy_fbits[128];  // the model's price table and the LPS transitions of Tables::ctx_next, staged per CTU: every lookup sits on lane 0's critical path
+  u8 ctx_lps[64];            // state (without the MPS bit) after a less probable symbol
 };
 
 static const int kPlaneOff[3] = { 0, 4096, 5120 };
@@ -367,8 +371,20 @@ struct CtuProgram {
   {
     const int st = c->s[idx];
     const double bits = (double)s->entropy_fbits[st ^ bin];
-    if (update && m->adaptive) c->s[idx] = s->ctx_next[bin != (st & 1)][st];
+    if (update && m->adaptive) c->s[idx] = (u8)ctx_next(st, bin);
     return bits;
+  }
+  // kvz_g_auc_next_state_mps / _lps (cabac.c:40-62) on the packed state
+  KVZ_DEV int ctx_next(int st, int bin) const
+  {
+    if (bin == (st & 1)) return st >= 124 ? st : st + 2;
+    return st < 2 ? st ^ 1 : ((int)s->ctx_lps[st >> 1] << 1) | (st & 1);
+  }
+  // copy of a context set: the residual-coding part only matters (and only moves) when coefficients are priced with the CABAC model
+  KVZ_DEV void ctx_copy(CtxSet *dst, const CtxSet *src) const
+  {
+    const int n = m->coeff_cabac ? 37 : 3;
+    for (int i = 0; i < n; i++) ((unsigned *)dst->s)[i] = ((const unsigned *)src->s)[i];
   }
   // lambda_sqrt * kvz_luma_mode_bits of the three possible outcomes at the current state of the intra-mode context; the rough
   // search prices with it without touching the context (search_intra.c:524: search_cabac.update == 0 there).  One lane.
@@ -436,6 +452,155 @@ struct CtuProgram {
     double sc = 0.0;
     sc += sb * m->lambda;
     return sc;
+  }
+
+  // ---------------------------------------------------------------- residual coding in counting mode
+  // kvz_encode_coeff_nxn (strategies/generic/encode_coding_tree-generic.c:40-283) as get_coeff_cabac_cost runs it (rdo.c:220-263):
+  // the bits of one transform block's residual syntax priced on context set *c, whose states move only with `update` (the coder works
+  // on a copy of the search contexts, `update` flag included).  Sign data hiding, transform skip and encryption are off in this
+  // configuration.  coeff: log2w x log2w levels, row-major, in LDS; type 0 luma / 2 chroma; scan 0 diagonal, 1 horizontal, 2 vertical.
+  // One lane.  HEVC scans are hierarchical -- 4x4 groups in group order, the same 16-position pattern inside each group -- so both
+  // orders come from three packed constants instead of the 1024-entry tables.
+  KVZ_DEV static int scan_in_group(int scan, int k)  // raster index inside the 4x4 group of the k-th position (tables.c kvz_g_sig_last_scan, 4x4 entries)
+  {
+    const unsigned long long pat = scan == 0 ? 0xfbe7ad369c258140ull : (scan == 1 ? 0xfedcba9876543210ull : 0xfb73ea62d951c840ull);
+    return (int)((pat >> (4 * k)) & 15);
+  }
+  KVZ_DEV int group_of(int log2w, int scan, int i) const  // raster index of the i-th group in group order (tables.h:45-89 g_sig_last_scan_cg)
+  {
+    if (log2w == 2) return 0;
+    if (log2w == 3) return scan == 1 ? i : ((0x3120 >> (4 * i)) & 3);
+    if (log2w == 4) return scan_in_group(0, i);
+    return tb->diag8[i];
+  }
+  KVZ_DEV double coeff_bin(CtxSet *c, bool update, int idx, int bin) const
+  {
+    const int st = c->s[idx];
+    const double bits = (double)s->entropy_fbits[st ^ bin];
+    if (update) c->s[idx] = (u8)ctx_next(st, bin);
+    return bits;
+  }
+  KVZ_DEV static int coeff_remain_bits(int symbol, int r_param)  // cabac.c:275-301 kvz_cabac_write_coeff_remain: number of bypass bins
+  {
+    if (symbol < (3 << r_param)) return (symbol >> r_param) + 1 + r_param;
+    int length = r_param, code = symbol - (3 << r_param);
+    while (code >= (1 << length)) { code -= 1 << length; length++; }
+    return 3 + length + 1 - r_param + length;
+  }
+  KVZ_DEV static int sig_ctx_inc(int pattern, int scan, int px, int py, int log2w, int type)  // context.c:366-399 kvz_context_get_sig_ctx_inc
+  {
+    if (px + py == 0) return 0;
+    if (log2w == 2) return (int)((0x8877886654325410ull >> (4 * (4 * py + px))) & 15);  // ctx_ind_map
+    const int offset = log2w == 3 ? (scan == 0 ? 9 : 15) : (type == 0 ? 21 : 12), xs = px & 3, ys = py & 3;
+    int cnt;
+    if (pattern == 0) cnt = xs + ys <= 2 ? (xs + ys == 0 ? 2 : 1) : 0;
+    else if (pattern == 1) cnt = ys <= 1 ? (ys == 0 ? 2 : 1) : 0;
+    else if (pattern == 2) cnt = xs <= 1 ? (xs == 0 ? 2 : 1) : 0;
+    else cnt = 2;
+    return ((type == 0 && ((px >> 2) + (py >> 2)) > 0) ? 3 : 0) + offset + cnt;
+  }
+  KVZ_DEV double coeff_cabac_bits(CtxSet *c, bool update, const i16 *coeff, int log2w, int type, int scan) const
+  {
+    update = update && m->adaptive;
+    const int w = 1 << log2w, side = w >> 2, ngroups = side * side;
+    // which groups hold a level: four levels per 8-byte LDS read
+    unsigned long long sig = 0;
+    for (int g = 0; g < ngroups; g++) {
+      const int gy = g >> (log2w - 2), gx = g & (side - 1);
+      unsigned long long any = 0;
+      for (int r = 0; r < 4; r++) { unsigned long long four; __builtin_memcpy(&four, coeff + ((gy * 4 + r) << log2w) + gx * 4, 8); any |= four; }
+      if (any) sig |= 1ull << g;
+    }
+    if (!sig) return 0;  // get_coeff_cabac_cost: no coefficient, no bits
+    int last_group = ngroups - 1;
+    while (!((sig >> group_of(log2w, scan, last_group)) & 1)) last_group--;
+    double bits = 0;
+    int c1 = 1;
+    bool first = true;
+    for (int i = last_group; i >= 0; i--) {
+      const int g = group_of(log2w, scan, i), gy = g >> (log2w - 2), gx = g & (side - 1);
+      const i16 *base = coeff + ((gy * 4) << log2w) + gx * 4;
+      int abs_coeff[16], num = 0, k = 15;
+      if (first) {
+        // the last significant position and its coding (encode_coding_tree.c:63-115 kvz_encode_last_significant_xy)
+        while (!base[((scan_in_group(scan, k) >> 2) << log2w) + (scan_in_group(scan, k) & 3)]) k--;
+        const int r = scan_in_group(scan, k);
+        int lx = gx * 4 + (r & 3), ly = gy * 4 + (r >> 2);
+        abs_coeff[num++] = iabs(base[((r >> 2) << log2w) + (r & 3)]);
+        k--;
+        if (scan == 2) { const int tmp = lx; lx = ly; ly = tmp; }
+        const int index = log2w - 2, ctx_offset = type ? 0 : (index * 3 + (index + 1) / 4), shift = type ? index : (index + 3) / 4;
+        const int bx = (type ? KVZ_HIP_CX_LAST_X_CHROMA : KVZ_HIP_CX_LAST_X_LUMA) + ctx_offset, by = (type ? KVZ_HIP_CX_LAST_Y_CHROMA : KVZ_HIP_CX_LAST_Y_LUMA) + ctx_offset;
+        const unsigned long long gidx_lo = 0x7777666655443210ull;  // g_group_idx[0..15] (encoderstate.h:397); [16..23] = 8, [24..31] = 9
+        const int gxi = lx < 16 ? (int)((gidx_lo >> (4 * lx)) & 15) : (lx < 24 ? 8 : 9), gyi = ly < 16 ? (int)((gidx_lo >> (4 * ly)) & 15) : (ly < 24 ? 8 : 9);
+        const int gmax = w - 1 < 16 ? (int)((gidx_lo >> (4 * (w - 1))) & 15) : 9;
+        for (int q = 0; q < gxi; q++) bits += coeff_bin(c, update, bx + (q >> shift), 1);
+        if (gxi < gmax) bits += coeff_bin(c, update, bx + (gxi >> shift), 0);
+        for (int q = 0; q < gyi; q++) bits += coeff_bin(c, update, by + (q >> shift), 1);
+        if (gyi < gmax) bits += coeff_bin(c, update, by + (gyi >> shift), 0);
+        if (gxi > 3) bits += (gxi - 2) / 2;  // suffixes: bypass bins
+        if (gyi > 3) bits += (gyi - 2) / 2;
+      }
+      const bool right = gx < side - 1 && ((sig >> (g + 1)) & 1), lower = gy < side - 1 && ((sig >> (g + side)) & 1);
+      bool coded = (sig >> g) & 1;
+      if (i == last_group || i == 0) coded = true;  // inferred; the DC group is then scanned like a significant one
+      else bits += coeff_bin(c, update, KVZ_HIP_CX_SIG_CG + type + (right || lower), coded);  // context.c:315-327
+      if (coded) {
+        const int pattern = log2w == 2 ? -1 : (int)right + ((int)lower << 1);  // context.c:339-351
+        for (; k >= 0; k--) {
+          const int r = scan_in_group(scan, k), px = gx * 4 + (r & 3), py = gy * 4 + (r >> 2);
+          const int level = base[((r >> 2) << log2w) + (r & 3)];
+          if (k > 0 || i == 0 || num) bits += coeff_bin(c, update, (type == 0 ? KVZ_HIP_CX_SIG_LUMA : KVZ_HIP_CX_SIG_CHROMA) + sig_ctx_inc(pattern, scan, px, py, log2w, type), level != 0);
+          if (level) abs_coeff[num++] = iabs(level);
+        }
+      }
+      first = false;
+      if (num > 0) {
+        int ctx_set = (i > 0 && type == 0) ? 2 : 0;
+        if (c1 == 0) ctx_set++;
+        c1 = 1;
+        const int base_one = (type == 0 ? KVZ_HIP_CX_ONE_LUMA : KVZ_HIP_CX_ONE_CHROMA) + 4 * ctx_set, num_c1 = num < 8 ? num : 8;
+        int first_c2 = -1;
+        for (int q = 0; q < num_c1; q++) {
+          const int symbol = abs_coeff[q] > 1;
+          bits += coeff_bin(c, update, base_one + c1, symbol);
+          if (symbol) { c1 = 0; if (first_c2 == -1) first_c2 = q; }
+          else if (c1 < 3 && c1 > 0) c1++;
+        }
+        if (c1 == 0 && first_c2 != -1) bits += coeff_bin(c, update, (type == 0 ? KVZ_HIP_CX_ABS_LUMA : KVZ_HIP_CX_ABS_CHROMA) + ctx_set, abs_coeff[first_c2] > 2);
+        bits += num;  // signs
+        if (c1 == 0 || num > 8) {
+          int first_coeff2 = 1, go_rice = 0;
+          for (int q = 0; q < num; q++) {
+            const int base_level = q < 8 ? 2 + first_coeff2 : 1;
+            if (abs_coeff[q] >= base_level) {
+              bits += coeff_remain_bits(abs_coeff[q] - base_level, go_rice);
+              if (abs_coeff[q] > 3 * (1 << go_rice)) go_rice = go_rice + 1 < 4 ? go_rice + 1 : 4;
+            }
+            if (abs_coeff[q] >= 2) first_coeff2 = 0;
+          }
+        }
+      }
+    }
+    return bits;
+  }
+  // encoderstate.c:1761-1775 kvz_get_scan_order for an intra CU (the chroma mode is the luma mode here)
+  KVZ_DEV static int scan_order(int mode, int depth)
+  {
+    if (depth >= 3) {
+      if (mode >= 6 && mode <= 14) return 2;
+      if (mode >= 22 && mode <= 30) return 1;
+    }
+    return 0;
+  }
+  // Levels of the unit being priced, in LDS: 16x16 CUs and 32x32 merges keep theirs there anyway (lv2_coeff / lv1_coeff); with the
+  // CABAC model the 8x8 CUs stage a copy in the (by then dead) rough-search prediction buffer and the 32x32 units of the 64x64
+  // attempt in lv1_coeff (recon_tus stage 4)
+  KVZ_DEV i16 *levels_lds(int lv, int c) const
+  {
+    if (lv == 3) return (i16 *)s->pred + (c == 0 ? 0 : (c == 1 ? 64 : 80));
+    if (lv == 2) return s->lv2_coeff + (c == 0 ? 0 : (c == 1 ? 256 : 320));
+    return s->lv1_coeff + (c == 0 ? 0 : (c == 1 ? 1024 : 1280));
   }
 
   // ---------------------------------------------------------------- phases
@@ -872,6 +1037,7 @@ struct CtuProgram {
         const QuantScalars qi = qf;
         i16 *cout = lv == 2 ? s->lv2_coeff + (c == 0 ? 0 : (c == 1 ? 256 : 320))
                   : lv == 1 ? s->lv1_coeff + (c == 0 ? 0 : (c == 1 ? 1024 : 1280)) : coeff_level(lv) + kPlaneOff[c] + zorder(xl >> sh, yl >> sh);
+        i16 *stage = (m->coeff_cabac && (lv == 3 || lv == 0)) ? levels_lds(lv, c) : nullptr;  // see levels_lds()
         const i16 *src = tbuf(t, 0, c);
         i16 *dq = tbuf(t, 1, c);
         u32 wsum = 0, nz = 0;
@@ -882,6 +1048,7 @@ struct CtuProgram {
           if (cf < 0) level = -level;
           level = iclip(-32768, 32767, level);
           cout[e] = (i16)level;
+          if (stage) stage[e] = (i16)level;
           int a = iabs(level);
           nz += a != 0;
           if (a > 3) a = 3;
@@ -963,8 +1130,20 @@ struct CtuProgram {
     return q;
   }
 
+  // get_coeff_cabac_cost (rdo.c:220-263) of the planes of one transform unit that have levels, luma first (search.c:518-547)
+  KVZ_DEV double unit_coeff_bits(CtxSet *c, bool update, int lv, int depth, int mode, int cb_y, int cb_u, int cb_v) const
+  {
+    const int lw = 6 - depth, lc = depth == 3 ? 2 : lw - 1, scan = scan_order(mode, depth);
+    double bits = 0;
+    if (cb_y) bits += coeff_cabac_bits(c, update, levels_lds(lv, 0), lw, 0, scan);
+    if (cb_u) bits += coeff_cabac_bits(c, update, levels_lds(lv, 1), lc, 2, scan);
+    if (cb_v) bits += coeff_cabac_bits(c, update, levels_lds(lv, 2), lc, 2, scan);
+    return bits;
+  }
   // search.c:425-541 cu_rd_cost_tr_split_accurate for one leaf TU group whose sums sit in s->acc (lane 0 only)
-  KVZ_DEV double leaf_rd_cost(CtxSet *c, bool update, int lv, int xl, int yl, int depth, int cu_depth, bool code_cbf_u, bool code_cbf_v) const
+  // `known_coeff_bits`: the units of the 64x64 attempt had their coefficients priced when their levels were staged (try_merge)
+  KVZ_DEV double leaf_rd_cost(CtxSet *c, bool update, int lv, int xl, int yl, int depth, int cu_depth, bool code_cbf_u, bool code_cbf_v,
+                              const double *known_coeff_bits = nullptr) const
   {
     const CtuCu *tr_cu = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
     double tr_tree_bits = 0, coeff_bits = 0;
@@ -972,9 +1151,13 @@ struct CtuProgram {
     if (code_cbf_u) tr_tree_bits += ctx_price(c, KVZ_CX_CBF_CHROMA + depth - cu_depth, cb_u, update);
     if (code_cbf_v) tr_tree_bits += ctx_price(c, KVZ_CX_CBF_CHROMA + depth - cu_depth, cb_v, update);
     tr_tree_bits += ctx_price(c, KVZ_CX_CBF_LUMA + (depth == cu_depth ? 1 : 0), cb_y, update);
-    if (cb_y) coeff_bits += (double)s->acc[3] / 256.0;
-    if (cb_u) coeff_bits += (double)s->acc[4] / 256.0;
-    if (cb_v) coeff_bits += (double)s->acc[5] / 256.0;
+    if (known_coeff_bits) coeff_bits += *known_coeff_bits;
+    else if (m->coeff_cabac) coeff_bits += unit_coeff_bits(c, update, lv, depth, tr_cu->mode, cb_y, cb_u, cb_v);
+    else {  // kvz_fast_coeff_cost (rdo.c:311-326): the weight sums of the quantisation stage
+      if (cb_y) coeff_bits += (double)s->acc[3] / 256.0;
+      if (cb_u) coeff_bits += (double)s->acc[4] / 256.0;
+      if (cb_v) coeff_bits += (double)s->acc[5] / 256.0;
+    }
     const unsigned luma_ssd = s->acc[0], chroma_ssd = s->acc[1] + s->acc[2];
     const double bits = tr_tree_bits + coeff_bits;
     return luma_ssd * 0.8 + chroma_ssd * 1.5 + bits * m->lambda;
@@ -1007,8 +1190,8 @@ struct CtuProgram {
         if (res_depth > 0) s->split_cost[res_depth - 1] += r;  // the parent's running sum (search.c:1005-1010)
         // search.c:1051: an unsplit CU below depth 0 continues from the contexts as they were after it was priced -- for a merge
         // those at entry, since the merge is priced with updates off (search.c:1005-1041)
-        if (!split_won && res_depth == 2) s->cab = s->post2;
-        if (!split_won && res_depth == 1) s->cab = s->pre[1];
+        if (!split_won && res_depth == 2) ctx_copy(&s->cab, &s->post2);
+        if (!split_won && res_depth == 1) ctx_copy(&s->cab, &s->pre[1]);
       }
       const int n = w >> 3, lw = w == 16 ? 4 : (w == 32 ? 5 : 6), ln = lw - 3, cw = w >> 1;
       if (tid < n * n) {
@@ -1150,15 +1333,15 @@ struct CtuProgram {
       }
       if (v >= 128 && v < 136) s->qs[(v - 128) >> 1][v & 1] = quant_scalars_dev(2 + ((v - 128) >> 1), (v & 1) ? 2 : 0);
       if (v < 128) s->entropy_fbits[v] = m->entropy_fbits[v];
-      s->ctx_next[v >> 7][v & 127] = tb->ctx_next[v >> 7][v & 127];
-      if (v >= 144 && v < 144 + KVZ_CX_COUNT) {
+      if (v < 64) s->ctx_lps[v] = (u8)(tb->ctx_next[1][2 * v] >> 1);
+      if (v < (m->coeff_cabac ? KVZ_CX_COUNT : KVZ_CX_SYNTAX_COUNT)) {  // the residual contexts are only looked at with the CABAC coefficient cost
         // the row's contexts: from the CTU to the left; a row's first CTU from the second CTU of the row above (WPP; rows of a
         // one-CTU-wide picture and the first row start from the slice-start state, encoderstate.c:1218)
-        const int ctx = cx >> 6, cty = cy >> 6, i = v - 144;
+        const int ctx = cx >> 6, cty = cy >> 6;
         const u8 *base = F.border + (long)frame * F.wc * F.hc * KVZ_BORDER_BYTES;
         const u8 *r = ctx > 0 ? base + (long)(cty * F.wc + ctx - 1) * KVZ_BORDER_BYTES : ((cty > 0 && F.wc > 1) ? base + (long)((cty - 1) * F.wc + 1) * KVZ_BORDER_BYTES : nullptr);
-        const u8 st = (r && m->adaptive) ? load_shared_byte(r + 288 + i) : m->ctx_init[i];
-        s->pre[0].s[i] = st; s->cab.s[i] = st;
+        const u8 st = (r && m->adaptive) ? load_shared_byte(r + 288 + v) : m->ctx_init[v];
+        s->pre[0].s[v] = st; s->cab.s[v] = st;
       }
       }
 
@@ -1206,7 +1389,7 @@ struct CtuProgram {
     auto ctx_code = [&](int idx, int bin) {
       const int sh = (idx & 7) * 8;
       const int st = (int)(((idx < 8 ? lo : hi) >> sh) & 0xff);
-      const unsigned long long nx = s->ctx_next[bin != (st & 1)][st], keep = ~(0xffull << sh);
+      const unsigned long long nx = (unsigned long long)ctx_next(st, bin), keep = ~(0xffull << sh);
       if (idx < 8) lo = (lo & keep) | (nx << sh); else hi = (hi & keep) | (nx << sh);
     };
     int i = 0;
@@ -1252,6 +1435,42 @@ struct CtuProgram {
     for (int k = 0; k < 8; k++) c->s[k] = (u8)(lo >> (8 * k));
     c->s[8] = (u8)hi; c->s[9] = (u8)(hi >> 8);
   }
+  // ... and its residual part (encode_transform_unit, encode_coding_tree.c:117-190), only when coefficients are priced with the
+  // CABAC model: the residual contexts of the row move with the levels of every coded block, transform units in z-order, Y U V
+  // inside a unit.  The two sets of contexts are disjoint, so the order between this and code_ctu_syntax() is free.  The final
+  // levels come back from the CTU's output block one 32x32 quadrant at a time, staged in lv1_coeff by all lanes.
+  KVZ_DEV void code_ctu_residual()
+  {
+    const i16 *fin = coeff_level(3);
+    for (int q = 0; q < 4; q++) {
+      const int qxl = (q & 1) * 32, qyl = (q >> 1) * 32;
+      if (cx + qxl >= F.W || cy + qyl >= F.H) continue;
+      KVZ_FOR_THREADS(tid) {
+        for (int e = tid; e < 1536; e += KVZ_CTU_THREADS)
+          s->lv1_coeff[e] = fin[e < 1024 ? q * 1024 + e : kPlaneOff[1 + ((e - 1024) >> 8)] + q * 256 + ((e - 1024) & 255)];
+      }
+      KVZ_SYNC();
+      KVZ_FOR_THREADS(tid) {
+        if (tid == 0) {
+          CtxSet *c = &s->pre[0];
+          int i = 16 * q;
+          while (i < 16 * q + 16) {
+            const int xl = ((i & 1) | ((i >> 1) & 2) | ((i >> 2) & 4)) * 8, yl = (((i >> 1) & 1) | ((i >> 2) & 2) | ((i >> 3) & 4)) * 8;
+            if (cx + xl >= F.W || cy + yl >= F.H) { i++; continue; }
+            const CtuCu *cu = &s->cu[0][(yl >> 3) * 8 + (xl >> 3)];
+            const int td = cu->depth < 1 ? 1 : cu->depth;  // a 64x64 CU codes four 32x32 units, each read at its own origin
+            const int lw = 6 - td, lc = td == 3 ? 2 : lw - 1, scan = scan_order(cu->mode, td);
+            const i16 *y = s->lv1_coeff + (zorder(xl, yl) - q * 1024), *u = s->lv1_coeff + 1024 + (zorder(xl >> 1, yl >> 1) - q * 256);
+            if (cbf_is_set(cu->cbf, td, 0)) coeff_cabac_bits(c, true, y, lw, 0, scan);
+            if (cbf_is_set(cu->cbf, td, 1)) coeff_cabac_bits(c, true, u, lc, 2, scan);
+            if (cbf_is_set(cu->cbf, td, 2)) coeff_cabac_bits(c, true, u + 256, lc, 2, scan);
+            i += 1 << (2 * (3 - td));
+          }
+        }
+      }
+      KVZ_SYNC();
+    }
+  }
   // ... and the CU-info half: level 0 -> cu arrays, CTU cost, CU part of the border record; coefficients already there
   KVZ_DEV void finish_info()
   {
@@ -1267,9 +1486,11 @@ struct CtuProgram {
       u8 *r = F.border + ((long)frame * F.wc * F.hc + ctu_index()) * KVZ_BORDER_BYTES;
       if (tid == 0) {
         F.ctu_cost[(long)frame * F.wc * F.hc + ctu_index()] = s->res[0];
-        if (m->adaptive) code_ctu_syntax(&s->pre[0]);
-        for (int i = 0; i < KVZ_CX_COUNT; i++) r[288 + i] = s->pre[0].s[i];
+        if (m->adaptive) code_ctu_syntax(&s->pre[0]);  // moves the syntax contexts only
+        for (int i = 0; i < KVZ_CX_SYNTAX_COUNT; i++) r[288 + i] = s->pre[0].s[i];
       }
+      if (m->coeff_cabac)
+        for (int v = KVZ_CX_SYNTAX_COUNT + tid; v < KVZ_CX_COUNT; v += KVZ_CTU_THREADS) r[288 + v] = s->pre[0].s[v];  // residual contexts: final since code_ctu_residual()
       for (int v = tid; v < 32; v += KVZ_CTU_THREADS) {
         const int i = v & 7;
         const CtuCu *cu = &s->cu[0][v < 16 ? 56 + i : i * 8 + 7];
@@ -1326,7 +1547,11 @@ struct CtuProgram {
       a1x = qx - cx; a1y = qy - cy;
       load_org();
       recon_tus(lv, t, 1, mode);
-      KVZ_FOR_THREADS(tid) { if (tid < 9) s->child_acc[q][tid] = s->acc[tid]; }
+      KVZ_FOR_THREADS(tid) {
+        if (tid < 9) s->child_acc[q][tid] = s->acc[tid];
+        // priced from the contexts at entry with updates off (search.c:1005-1041), so each unit's bits stand alone
+        if (tid == 0 && m->coeff_cabac) s->child_bits[q] = unit_coeff_bits(&s->pre[0], false, 0, 1, mode, s->acc[6] != 0, s->acc[7] != 0, s->acc[8] != 0);
+      }
       KVZ_SYNC();
     }
     KVZ_FOR_THREADS(tid) {
@@ -1353,7 +1578,7 @@ struct CtuProgram {
           const CtuCu *tr_cu = &s->cu[lv][(qyl >> 3) * 8 + (qxl >> 3)];
           for (int i = 0; i < 9; i++) s->acc[i] = s->child_acc[q][i];
           // search.c:466-471: child cbf_cb/cbf_cr are coded when the entry has any chroma bit at depth >= 0
-          sum += leaf_rd_cost(pc, false, lv, qxl, qyl, 1, 0, cbf_is_set(tr_cu->cbf, 0, 1), cbf_is_set(tr_cu->cbf, 0, 2));
+          sum += leaf_rd_cost(pc, false, lv, qxl, qyl, 1, 0, cbf_is_set(tr_cu->cbf, 0, 1), cbf_is_set(tr_cu->cbf, 0, 2), m->coeff_cabac ? &s->child_bits[q] : nullptr);
         }
         const double rd = sum + tr_tree_bits * m->lambda;
         double bits = 0;
@@ -1376,10 +1601,10 @@ struct CtuProgram {
     a2x = xl; a2y = yl;
     const bool inside = x + 16 <= F.W && y + 16 <= F.H;
     // thread-0 bookkeeping around the 16x16 CU: header + cost initialisation before, split cost after
-    auto d2_first = [&]() { cu_header(2, xl, yl, 2); s->cost[2] = 1.7e+308; s->cbf_any = 0; s->pre[2] = s->cab; price_modes(); };
+    auto d2_first = [&]() { cu_header(2, xl, yl, 2); s->cost[2] = 1.7e+308; s->cbf_any = 0; ctx_copy(&s->pre[2], &s->cab); price_modes(); };
     auto d2_last = [&]() {
-      s->post2 = s->cab;  // search.c:956-959: the split alternative starts again from the contexts at entry
-      s->cab = s->pre[2];
+      ctx_copy(&s->post2, &s->cab);  // search.c:956-959: the split alternative starts again from the contexts at entry
+      ctx_copy(&s->cab, &s->pre[2]);
       double sc = split_flag_cost(2, x, y, 2);
       if (inside && !s->cbf_any) sc = 2147483647;  // cu_split_termination = zero (search.c:975-984)
       s->split_cost[2] = sc;
@@ -1424,7 +1649,7 @@ struct CtuProgram {
       const int x1 = cx + (q1 & 1) * 32, y1 = cy + (q1 >> 1) * 32;
       if (x1 >= F.W || y1 >= F.H) continue;  // search_cu returns 0 outside the picture
       a1x = x1 - cx; a1y = y1 - cy;
-      load_org([&]() { cu_header(1, x1 - cx, y1 - cy, 1); s->cost[1] = 1.7e+308; s->pre[1] = s->cab; s->split_cost[1] = split_flag_cost(1, x1, y1, 1); });
+      load_org([&]() { cu_header(1, x1 - cx, y1 - cy, 1); s->cost[1] = 1.7e+308; ctx_copy(&s->pre[1], &s->cab); s->split_cost[1] = split_flag_cost(1, x1, y1, 1); });
       for (int q2 = 0; q2 < 4; q2++) search_d2(x1 + (q2 & 1) * 16, y1 + (q2 >> 1) * 16);
       if (x1 + 32 <= F.W && y1 + 32 <= F.H) try_merge(x1, y1, 1);
       const bool split_wins1 = s->split_cost[1] < s->cost[1];  // operands stay put until the barrier that ends commit()
@@ -1444,6 +1669,7 @@ struct CtuProgram {
       write_rec();
     }
     KVZ_PROF(KVZ_P_MISC);
+    if (m->adaptive && m->coeff_cabac) code_ctu_residual();
     finish_info();
     KVZ_PROF(KVZ_P_FINISH);
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)

@@ -103,6 +103,10 @@ inline void build_tables(Tables *t)
       t->ctx_next[1][u] = (u8)(st == 0 ? (mps ^ 1) : (lps[st] << 1) | mps);
     }
   }
+  {
+    int n = 0;
+    for (int d = 0; d < 15; d++) for (int x = 0; x <= d; x++) if (x < 8 && d - x < 8) t->diag8[n++] = (u8)((d - x) * 8 + x);
+  }
   static const i16 dst4[16] = { 29, 55, 74, 84, 74, 74, 0, -74, 84, -29, -74, 55, 55, -84, 74, -29 };
   memcpy(t->dst4, dst4, sizeof dst4);
   for (int kind = 0; kind < 3; kind++) {

@@ -46,8 +46,16 @@ static int ctx_state(int qp, int init_value)
   return st >= 64 ? ((st - 64) << 1) + 1 : (63 - st) << 1;
 }
 
-/* The ten contexts the all-intra ultrafast search prices syntax with (cabac.h:63-100), as uc_state = (state << 1) | mps */
-enum { CX_SPLIT = 0 /* ..2 */, CX_PART = 3, CX_INTRA = 4, CX_CHROMA = 5, CX_CBF_LUMA = 6 /* ..7 */, CX_CBF_CHROMA = 8 /* ..9 */, CX_COUNT = 10 };
+/* The contexts the all-intra ultrafast search prices syntax with (cabac.h:63-100), as uc_state = (state << 1) | mps: ten for the
+ * CU / transform-tree syntax, and -- only touched when coefficients are priced with the CABAC model (coeff_cabac, QP >= 28) --
+ * the residual-coding contexts in the order of cabac.h:78-88 */
+enum { CX_SPLIT = KVZ_HIP_CX_SPLIT /* ..2 */, CX_PART = KVZ_HIP_CX_PART, CX_INTRA = KVZ_HIP_CX_INTRA, CX_CHROMA = KVZ_HIP_CX_CHROMA,
+       CX_CBF_LUMA = KVZ_HIP_CX_CBF_LUMA /* ..7 */, CX_CBF_CHROMA = KVZ_HIP_CX_CBF_CHROMA /* ..9 */,
+       CX_SIG_CG = KVZ_HIP_CX_SIG_CG /* 4 */, CX_SIG_LUMA = KVZ_HIP_CX_SIG_LUMA /* 27 */, CX_SIG_CHROMA = KVZ_HIP_CX_SIG_CHROMA /* 15 */,
+       CX_LAST_Y_LUMA = KVZ_HIP_CX_LAST_Y_LUMA /* 15 */, CX_LAST_Y_CHROMA = KVZ_HIP_CX_LAST_Y_CHROMA /* 15 */,
+       CX_LAST_X_LUMA = KVZ_HIP_CX_LAST_X_LUMA /* 15 */, CX_LAST_X_CHROMA = KVZ_HIP_CX_LAST_X_CHROMA /* 15 */,
+       CX_ONE_LUMA = KVZ_HIP_CX_ONE_LUMA /* 16 */, CX_ONE_CHROMA = KVZ_HIP_CX_ONE_CHROMA /* 8 */, CX_ABS_LUMA = KVZ_HIP_CX_ABS_LUMA /* 4 */,
+       CX_ABS_CHROMA = KVZ_HIP_CX_ABS_CHROMA /* 2 */, CX_COUNT = KVZ_HIP_CX_COUNT };
 typedef struct { uint8_t s[CX_COUNT]; } ctxs_t;
 
 /* H.265 Table 9-41 state transitions in kvazaar's packing (cabac.c:40-62 kvz_g_auc_next_state_mps / _lps) */
@@ -101,6 +109,135 @@ static double ctx_price(ctu_t *t, int idx, int bin, int update, float frozen_pri
   return bits;
 }
 static void ctx_code(ctxs_t *c, int idx, int bin) { uint8_t *st = &c->s[idx]; *st = (bin != (*st & 1)) ? g_next_lps[*st] : g_next_mps[*st]; }
+
+/* ---- residual coding: kvz_encode_coeff_nxn (strategies/generic/encode_coding_tree-generic.c:40-283) in counting mode ---- */
+static const uint8_t g_group_idx[32] = { 0, 1, 2, 3, 4, 4, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 9, 9, 9, 9, 9, 9, 9, 9 }; /* encoderstate.h:397 */
+
+/* CABAC_FBITS_UPDATE (cabac.h:133-139) inside the residual coder: the price of `bin` on context idx of *c, then -- only while the
+ * coder's contexts have `update` on (they are a copy of the search's, flag included) -- the state change */
+static double bin_cost(const kvz_hip_intra_cost_model *m, ctxs_t *c, int update, int idx, int bin)
+{
+  const double bits = m->entropy_fbits[c->s[idx] ^ bin];
+  if (update) ctx_code(c, idx, bin);
+  return bits;
+}
+/* encode_coding_tree.c:63-115 kvz_encode_last_significant_xy */
+static double last_xy_cost(const kvz_hip_intra_cost_model *m, ctxs_t *c, int update, int lastpos_x, int lastpos_y, int width, int type, int scan)
+{
+  int index = 0;
+  while ((4 << index) < width) index++;
+  const int ctx_offset = type ? 0 : (index * 3 + (index + 1) / 4), shift = type ? index : (index + 3) / 4;
+  const int base_x = type ? CX_LAST_X_CHROMA : CX_LAST_X_LUMA, base_y = type ? CX_LAST_Y_CHROMA : CX_LAST_Y_LUMA;
+  double bits = 0;
+  if (scan == 2) { const int tmp = lastpos_x; lastpos_x = lastpos_y; lastpos_y = tmp; }
+  const int gx = g_group_idx[lastpos_x], gy = g_group_idx[lastpos_y];
+  for (int i = 0; i < gx; i++) bits += bin_cost(m, c, update, base_x + ctx_offset + (i >> shift), 1);
+  if (gx < g_group_idx[width - 1]) bits += bin_cost(m, c, update, base_x + ctx_offset + (gx >> shift), 0);
+  for (int i = 0; i < gy; i++) bits += bin_cost(m, c, update, base_y + ctx_offset + (i >> shift), 1);
+  if (gy < g_group_idx[width - 1]) bits += bin_cost(m, c, update, base_y + ctx_offset + (gy >> shift), 0);
+  if (gx > 3) bits += (gx - 2) / 2;  /* suffixes: bypass bins */
+  if (gy > 3) bits += (gy - 2) / 2;
+  return bits;
+}
+/* context.c:366-399 kvz_context_get_sig_ctx_inc */
+static int sig_ctx_inc(int pattern_sig_ctx, int scan_idx, int pos_x, int pos_y, int log2_size, int type)
+{
+  static const int ctx_ind_map[16] = { 0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8 };
+  if (pos_x + pos_y == 0) return 0;
+  if (log2_size == 2) return ctx_ind_map[4 * pos_y + pos_x];
+  const int offset = log2_size == 3 ? (scan_idx == 0 ? 9 : 15) : (type == 0 ? 21 : 12);
+  const int xs = pos_x & 3, ys = pos_y & 3;
+  int cnt;
+  if (pattern_sig_ctx == 0) cnt = xs + ys <= 2 ? (xs + ys == 0 ? 2 : 1) : 0;
+  else if (pattern_sig_ctx == 1) cnt = ys <= 1 ? (ys == 0 ? 2 : 1) : 0;
+  else if (pattern_sig_ctx == 2) cnt = xs <= 1 ? (xs == 0 ? 2 : 1) : 0;
+  else cnt = 2;
+  return ((type == 0 && ((pos_x >> 2) + (pos_y >> 2)) > 0) ? 3 : 0) + offset + cnt;
+}
+/* cabac.c:275-301 kvz_cabac_write_coeff_remain: number of bypass bins */
+static int coeff_remain_bits(int symbol, int r_param)
+{
+  if (symbol < (3 << r_param)) return (symbol >> r_param) + 1 + r_param;
+  int length = r_param, code = symbol - (3 << r_param);
+  while (code >= (1 << length)) { code -= 1 << length; length++; }
+  return 3 + length + 1 - r_param + length;
+}
+/* Bits of one transform block's residual syntax; with `update`, *c moves as the coder's contexts do.  sign data hiding, transform skip and
+ * encryption are off in this configuration (cfg.c:485-512).  type: 0 luma, 2 chroma; scan_mode: 0 diagonal, 1 horizontal, 2 vertical */
+static double encode_coeff_nxn(const kvz_hip_intra_cost_model *m, ctxs_t *c, int update, const int16_t *coeff, int width, int type, int scan_mode)
+{
+  int log2_size = 2;
+  while ((1 << log2_size) < width) log2_size++;
+  const int num_blk_side = width >> 2;
+  const uint32_t *scan = kvz_oracle_scan_table(scan_mode, log2_size);
+  /* g_sig_last_scan_cg (tables.h:84-89): the order of the 4x4 groups.  16x16 and 32x32 blocks are always scanned diagonally; the
+   * 8x8 grid of a 32x32 block in plain up-right diagonal order (the 8x8 coefficient scan is hierarchical, not this) */
+  static const uint32_t one_cg[1] = { 0 };
+  uint32_t diag8[64];
+  const uint32_t *scan_cg = log2_size == 2 ? one_cg : kvz_oracle_scan_table(log2_size == 3 ? scan_mode : 0, log2_size - 2);
+  if (log2_size == 5) {
+    int n = 0;
+    for (int d = 0; d < 15; d++) for (int x = 0; x <= d; x++) if (x < 8 && d - x < 8) diag8[n++] = (uint32_t)((d - x) * 8 + x);
+    scan_cg = diag8;
+  }
+  uint8_t sig_cg[64] = { 0 };
+  double bits = 0;
+  for (int cy = 0; cy < num_blk_side; cy++)
+    for (int cx = 0; cx < num_blk_side; cx++)
+      for (int i = 0; i < 16; i++) if (coeff[(cy * 4 + (i >> 2)) * width + cx * 4 + (i & 3)]) { sig_cg[cy * num_blk_side + cx] = 1; break; }
+  int scan_cg_last = num_blk_side * num_blk_side - 1;
+  while (!sig_cg[scan_cg[scan_cg_last]]) scan_cg_last--;
+  int scan_pos_last = scan_cg_last * 16 + 15;
+  while (!coeff[scan[scan_pos_last]]) scan_pos_last--;
+  const int pos_last = (int)scan[scan_pos_last];
+  bits += last_xy_cost(m, c, update, pos_last & (width - 1), pos_last >> log2_size, width, type, scan_mode);
+  const int base_sig = type == 0 ? CX_SIG_LUMA : CX_SIG_CHROMA;
+  int scan_pos_sig = scan_pos_last, c1 = 1;
+  for (int i = scan_cg_last; i >= 0; i--) {
+    const int sub_pos = i << 4, cg_blk_pos = (int)scan_cg[i], cg_pos_y = cg_blk_pos / num_blk_side, cg_pos_x = cg_blk_pos - cg_pos_y * num_blk_side;
+    int abs_coeff[16], num_non_zero = 0, go_rice = 0;
+    if (scan_pos_sig == scan_pos_last) { abs_coeff[0] = abs(coeff[pos_last]); num_non_zero = 1; scan_pos_sig--; }
+    const int right = cg_pos_x < num_blk_side - 1 && sig_cg[cg_pos_y * num_blk_side + cg_pos_x + 1];
+    const int lower = cg_pos_y < num_blk_side - 1 && sig_cg[(cg_pos_y + 1) * num_blk_side + cg_pos_x];
+    if (i == scan_cg_last || i == 0) sig_cg[cg_blk_pos] = 1;
+    else bits += bin_cost(m, c, update, CX_SIG_CG + type + (right || lower), sig_cg[cg_blk_pos]);  /* context.c:315-327 */
+    if (sig_cg[cg_blk_pos]) {
+      const int pattern = width == 4 ? -1 : right + (lower << 1);  /* context.c:339-351 */
+      for (; scan_pos_sig >= sub_pos; scan_pos_sig--) {
+        const int blk_pos = (int)scan[scan_pos_sig], pos_y = blk_pos >> log2_size, pos_x = blk_pos - (pos_y << log2_size), sig = coeff[blk_pos] != 0;
+        if (scan_pos_sig > sub_pos || i == 0 || num_non_zero) bits += bin_cost(m, c, update, base_sig + sig_ctx_inc(pattern, scan_mode, pos_x, pos_y, log2_size, type), sig);
+        if (sig) abs_coeff[num_non_zero++] = abs(coeff[blk_pos]);
+      }
+    } else scan_pos_sig = sub_pos - 1;
+    if (num_non_zero > 0) {
+      int ctx_set = (i > 0 && type == 0) ? 2 : 0;
+      if (c1 == 0) ctx_set++;
+      c1 = 1;
+      const int base_one = (type == 0 ? CX_ONE_LUMA : CX_ONE_CHROMA) + 4 * ctx_set, num_c1 = num_non_zero < 8 ? num_non_zero : 8;
+      int first_c2 = -1;
+      for (int idx = 0; idx < num_c1; idx++) {
+        const int symbol = abs_coeff[idx] > 1;
+        bits += bin_cost(m, c, update, base_one + c1, symbol);
+        if (symbol) { c1 = 0; if (first_c2 == -1) first_c2 = idx; }
+        else if (c1 < 3 && c1 > 0) c1++;
+      }
+      if (c1 == 0 && first_c2 != -1) bits += bin_cost(m, c, update, (type == 0 ? CX_ABS_LUMA : CX_ABS_CHROMA) + ctx_set, abs_coeff[first_c2] > 2);
+      bits += num_non_zero;  /* signs */
+      if (c1 == 0 || num_non_zero > 8) {
+        int first_coeff2 = 1;
+        for (int idx = 0; idx < num_non_zero; idx++) {
+          const int base_level = idx < 8 ? 2 + first_coeff2 : 1;
+          if (abs_coeff[idx] >= base_level) {
+            bits += coeff_remain_bits(abs_coeff[idx] - base_level, go_rice);
+            if (abs_coeff[idx] > 3 * (1 << go_rice)) go_rice = go_rice + 1 < 4 ? go_rice + 1 : 4;
+          }
+          if (abs_coeff[idx] >= 2) first_coeff2 = 0;
+        }
+      }
+    }
+  }
+  return bits;
+}
 
 /* ---- cbf bit helpers (cu.h:510-569: 5 depth bits per plane, is_set tests levels >= depth) ---- */
 static const uint16_t cbf_masks[5] = { 0x1f, 0x0f, 0x07, 0x03, 0x1 };
@@ -387,6 +524,43 @@ static void recon_cu(ctu_t *t, level_t *lv, int x, int y, int depth, int mode, i
   }
 }
 
+/* Test hook: the residual coder's bit count on caller-supplied states of the residual contexts (KVZ_HIP_CX_SIG_CG .. KVZ_HIP_CX_COUNT - 1,
+ * updated in place when `update`), against the reference's kvz_encode_coeff_nxn (tests/test_oracle_vs_ref.py) */
+double kvz_oracle_coeff_cabac_bits(const float entropy_fbits[128], const int16_t *coeff, int width, int type, int scan_mode, int update, uint8_t *ctx)
+{
+  kvz_hip_intra_cost_model m;
+  ctxs_t c;
+  build_transitions();
+  memset(&m, 0, sizeof m);
+  memset(&c, 0, sizeof c);
+  memcpy(m.entropy_fbits, entropy_fbits, sizeof m.entropy_fbits);
+  memcpy(&c.s[CX_SIG_CG], ctx, CX_COUNT - CX_SIG_CG);
+  const double bits = encode_coeff_nxn(&m, &c, update, coeff, width, type, scan_mode);
+  memcpy(ctx, &c.s[CX_SIG_CG], CX_COUNT - CX_SIG_CG);
+  return bits;
+}
+
+/* encoderstate.c:1761-1775 kvz_get_scan_order for an intra CU (the chroma mode is the luma mode here) */
+static int scan_order(int intra_mode, int depth)
+{
+  if (depth >= 3) {
+    if (intra_mode >= 6 && intra_mode <= 14) return 2;   /* SCAN_VER */
+    if (intra_mode >= 22 && intra_mode <= 30) return 1;  /* SCAN_HOR */
+  }
+  return 0;
+}
+/* rdo.c:311-340 kvz_get_coeff_cost: the fast estimate below fast_residual_cost_limit, else get_coeff_cabac_cost (rdo.c:220-263): the
+ * residual coder runs in counting mode on a copy of the search contexts -- `update` flag included, so the states move (and
+ * are copied back) only while the search has updates switched on; otherwise every bin is priced at the entry state */
+static double coeff_cost(ctu_t *t, const int16_t *coeff, int width, int type, int scan_mode, int update)
+{
+  if (!t->m->coeff_cabac) return kvz_oracle_fast_coeff_cost(coeff, width, t->m->coeff_weights);
+  int found = 0;
+  for (int i = 0; i < width * width; i++) if (coeff[i]) { found = 1; break; }
+  if (!found) return 0;
+  return encode_coeff_nxn(t->m, &t->cab, update && t->m->adaptive, coeff, width, type, scan_mode);
+}
+
 /* search.c:425-541 cu_rd_cost_tr_split_accurate (intra CU, fast coefficient cost rdo.c:311-326) */
 static double rd_cost(ctu_t *t, level_t *lv, int xl, int yl, int depth, const cu_t *pred_cu, int update)
 {
@@ -396,7 +570,6 @@ static double rd_cost(ctu_t *t, level_t *lv, int xl, int yl, int depth, const cu
   double coeff_bits = 0, tr_tree_bits = 0;
   const int tr_depth = tr_cu->tr_depth - depth;
   const int cb_u = cbf_is_set(tr_cu->cbf, depth, 1), cb_v = cbf_is_set(tr_cu->cbf, depth, 2);
-  (void)pred_cu;
   /* transform_tree split flag: never coded with tr_depth_intra = 0 (search.c:451-464) */
   if (tr_cu->depth == depth || cbf_is_set(tr_cu->cbf, depth - 1, 1)) tr_tree_bits += ctx_price(t, CX_CBF_CHROMA + depth - tr_cu->depth, cb_u, update, m->cbf_chroma[depth - tr_cu->depth][cb_u]);
   if (tr_cu->depth == depth || cbf_is_set(tr_cu->cbf, depth - 1, 2)) tr_tree_bits += ctx_price(t, CX_CBF_CHROMA + depth - tr_cu->depth, cb_v, update, m->cbf_chroma[depth - tr_cu->depth][cb_v]);
@@ -413,14 +586,14 @@ static double rd_cost(ctu_t *t, level_t *lv, int xl, int yl, int depth, const cu
   const int is_tr_split = depth - tr_cu->depth;
   tr_tree_bits += ctx_price(t, CX_CBF_LUMA + !is_tr_split, cb_y, update, m->cbf_luma[!is_tr_split][cb_y]);
   unsigned luma_ssd = kvz_oracle_pixels_calc_ssd(&t->org[0][yl * LCU + xl], &lv->rec[0][yl * LCU + xl], LCU, LCU, width);
-  if (cb_y) coeff_bits += kvz_oracle_fast_coeff_cost(&lv->coeff[0][zorder(xl, yl)], width, m->coeff_weights);
+  if (cb_y) coeff_bits += coeff_cost(t, &lv->coeff[0][zorder(xl, yl)], width, 0, scan_order(pred_cu->mode, depth), update);
   unsigned chroma_ssd = 0;
   if (xl % 8 == 0 && yl % 8 == 0) {
     const int cw = depth <= 3 ? LCU >> (depth + 1) : LCU >> depth, i = (yl / 2) * 32 + xl / 2;
     chroma_ssd = kvz_oracle_pixels_calc_ssd(&t->org[1][i], &lv->rec[1][i], 32, 32, cw) + kvz_oracle_pixels_calc_ssd(&t->org[2][i], &lv->rec[2][i], 32, 32, cw);
     const unsigned zi = zorder(xl / 2, yl / 2);
-    if (cb_u) coeff_bits += kvz_oracle_fast_coeff_cost(&lv->coeff[1][zi], cw, m->coeff_weights);
-    if (cb_v) coeff_bits += kvz_oracle_fast_coeff_cost(&lv->coeff[2][zi], cw, m->coeff_weights);
+    if (cb_u) coeff_bits += coeff_cost(t, &lv->coeff[1][zi], cw, 2, scan_order(pred_cu->mode, depth), update);
+    if (cb_v) coeff_bits += coeff_cost(t, &lv->coeff[2][zi], cw, 2, scan_order(pred_cu->mode, depth), update);
   }
   const double bits = tr_tree_bits + coeff_bits;
   return luma_ssd * 0.8 + chroma_ssd * 1.5 + bits * m->lambda; /* KVZ_LUMA_MULT / KVZ_CHROMA_MULT search.h:50-56 */
@@ -611,6 +784,12 @@ static void code_transform_tree(ctu_t *t, ctxs_t *c, int xl, int yl, int depth, 
     return;
   }
   ctx_code(c, CX_CBF_LUMA + !tr_depth, cb_y);  /* always present for intra (encode_coding_tree.c:276-279) */
+  if (t->m->coeff_cabac) {  /* encode_transform_unit (encode_coding_tree.c:117-190): the residual moves its own contexts */
+    const int w = LCU >> depth, cw = LCU >> (depth + 1), scan = scan_order(cu->mode, depth);
+    if (cb_y) encode_coeff_nxn(t->m, c, 1, &t->lv[0].coeff[0][zorder(xl, yl)], w, 0, scan);
+    if (cb_u) encode_coeff_nxn(t->m, c, 1, &t->lv[0].coeff[1][zorder(xl / 2, yl / 2)], cw, 2, scan);
+    if (cb_v) encode_coeff_nxn(t->m, c, 1, &t->lv[0].coeff[2][zorder(xl / 2, yl / 2)], cw, 2, scan);
+  }
 }
 static void code_coding_tree(ctu_t *t, ctxs_t *c, int x, int y, int depth)
 {
@@ -694,9 +873,30 @@ void kvz_oracle_intra_cost_model(int qp, const float entropy_fbits[128], uint64_
   m->lambda_sqrt = sqrt(m->lambda);
   m->coeff_weights = coeff_weights;
   {
-    const uint8_t inits[CX_COUNT] = { init_split[0], init_split[1], init_split[2], init_part, init_intra, init_chroma, init_cbf_luma[0], init_cbf_luma[1],
-                                      init_cbf_chroma[0], init_cbf_chroma[1] };
+    /* I-slice rows of context.c:142-193 (HEVC spec tables 9-4 ff.): coded_sub_block_flag, sig_coeff_flag (27 luma + 15 chroma),
+     * last_sig_coeff prefix (15 luma + 15 chroma, of which 3 are used; x and y share the values), greater1 (16 + 8), greater2 (4 + 2) */
+    static const uint8_t init_sig_cg[4] = { 91, 171, 134, 141 };
+    static const uint8_t init_sig[42] = { 111, 111, 125, 110, 110, 94, 124, 108, 124, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125,
+                                          140, 139, 182, 182, 152, 136, 152, 136, 153, 136, 139, 111, 136, 139, 111 };
+    static const uint8_t init_last[30] = { 110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63,
+                                           154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154 };  /* CNU = 154 */
+    static const uint8_t init_one[24] = { 140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166, 182, 140, 227, 122, 197 };
+    static const uint8_t init_abs[6] = { 138, 153, 136, 167, 152, 152 };
+    uint8_t inits[CX_COUNT] = { init_split[0], init_split[1], init_split[2], init_part, init_intra, init_chroma, init_cbf_luma[0], init_cbf_luma[1],
+                                init_cbf_chroma[0], init_cbf_chroma[1] };
+    for (int i = 0; i < 4; i++) inits[CX_SIG_CG + i] = init_sig_cg[i];
+    for (int i = 0; i < 27; i++) inits[CX_SIG_LUMA + i] = init_sig[i];
+    for (int i = 0; i < 15; i++) {
+      inits[CX_SIG_CHROMA + i] = init_sig[27 + i];
+      inits[CX_LAST_Y_LUMA + i] = inits[CX_LAST_X_LUMA + i] = init_last[i];
+      inits[CX_LAST_Y_CHROMA + i] = inits[CX_LAST_X_CHROMA + i] = init_last[15 + i];
+    }
+    for (int i = 0; i < 16; i++) inits[CX_ONE_LUMA + i] = init_one[i];
+    for (int i = 0; i < 8; i++) inits[CX_ONE_CHROMA + i] = init_one[16 + i];
+    for (int i = 0; i < 4; i++) inits[CX_ABS_LUMA + i] = init_abs[i];
+    for (int i = 0; i < 2; i++) inits[CX_ABS_CHROMA + i] = init_abs[4 + i];
     for (int i = 0; i < CX_COUNT; i++) m->ctx_init[i] = (uint8_t)ctx_state(qp, inits[i]);
+    m->coeff_cabac = qp >= 28;  /* `ultrafast`: fast-residual-cost 28 (cfg.c:485-512); MAX_FAST_COEFF_COST_QP = 50 lies above */
     memcpy(m->entropy_fbits, entropy_fbits, sizeof m->entropy_fbits);
     m->adaptive = 1;  /* kvazaar's behaviour; 0 freezes every context at its slice-start state */
   }

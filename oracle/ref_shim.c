@@ -314,3 +314,31 @@ void kvz_ref_sao_frame(int width, int height, const uint8_t *in, uint8_t *out, c
   kvz_image_free(src);
   g_state.tile = NULL;
 }
+
+/* ---- kvz_encode_coeff_nxn in counting mode (what get_coeff_cabac_cost runs, rdo.c:220-263) on caller-supplied context states:
+ * ctx[] = the residual-coding contexts in the KVZ_HIP_CX_* order from KVZ_HIP_CX_SIG_CG on (uc_state each), updated in place when
+ * `update` is set.  Returns the bits. ---- */
+#include "cabac.h"
+#include "context.h"
+double kvz_ref_coeff_cabac_bits(const int16_t *coeff, int width, int type, int scan_mode, int update, uint8_t *ctx)
+{
+  cabac_data_t cabac;
+  memset(&cabac, 0, sizeof cabac);
+  cabac.only_count = 1;
+  cabac.update = update ? 1 : 0;
+  cabac.range = 510; cabac.bits_left = 23;
+  uint8_t *p = ctx;
+#define KVZ_REF_LOAD(arr, n) for (int i = 0; i < (n); i++) cabac.ctx.arr[i].uc_state = *p++;
+  KVZ_REF_LOAD(cu_sig_coeff_group_model, 4) KVZ_REF_LOAD(cu_sig_model_luma, 27) KVZ_REF_LOAD(cu_sig_model_chroma, 15)
+  KVZ_REF_LOAD(cu_ctx_last_y_luma, 15) KVZ_REF_LOAD(cu_ctx_last_y_chroma, 15) KVZ_REF_LOAD(cu_ctx_last_x_luma, 15) KVZ_REF_LOAD(cu_ctx_last_x_chroma, 15)
+  KVZ_REF_LOAD(cu_one_model_luma, 16) KVZ_REF_LOAD(cu_one_model_chroma, 8) KVZ_REF_LOAD(cu_abs_model_luma, 4) KVZ_REF_LOAD(cu_abs_model_chroma, 2)
+  g_ctrl.cfg.signhide_enable = 0; g_ctrl.cfg.trskip_enable = 0; g_ctrl.cfg.lossless = 0; g_ctrl.cfg.crypto_features = 0;
+  double bits = 0;
+  kvz_encode_coeff_nxn(&g_state, &cabac, coeff, (uint8_t)width, (uint8_t)type, (int8_t)scan_mode, 0, &bits);
+  p = ctx;
+#define KVZ_REF_STORE(arr, n) for (int i = 0; i < (n); i++) *p++ = cabac.ctx.arr[i].uc_state;
+  KVZ_REF_STORE(cu_sig_coeff_group_model, 4) KVZ_REF_STORE(cu_sig_model_luma, 27) KVZ_REF_STORE(cu_sig_model_chroma, 15)
+  KVZ_REF_STORE(cu_ctx_last_y_luma, 15) KVZ_REF_STORE(cu_ctx_last_y_chroma, 15) KVZ_REF_STORE(cu_ctx_last_x_luma, 15) KVZ_REF_STORE(cu_ctx_last_x_chroma, 15)
+  KVZ_REF_STORE(cu_one_model_luma, 16) KVZ_REF_STORE(cu_one_model_chroma, 8) KVZ_REF_STORE(cu_abs_model_luma, 4) KVZ_REF_STORE(cu_abs_model_chroma, 2)
+  return bits;
+}

@@ -79,10 +79,12 @@ def sao_digests(func):
     return out
 
 
-# (width, height, frames, seed, kind, qp): sizes with partial CTUs, several QPs below fast_residual_cost_limit (28: above it
-# ultrafast prices coefficients with the full CABAC model, cfg.c / rdo.c:311-326, which the batched pass does not cover yet)
-ENCODER_CLIPS = [(64, 64, 2, 9, "small", 22), (72, 88, 2, 1, "small", 12), (200, 136, 2, 3, "small", 27), (416, 240, 3, 1234, "small", 22),
-                 (416, 240, 2, 99, "small", 17), (832, 480, 1, 5, "large", 22), (1920, 1080, 1, 1, "large", 22)]
+# (width, height, frames, seed, kind, qp): sizes with partial CTUs; QPs on both sides of fast_residual_cost_limit (28 in `ultrafast`,
+# cfg.c:485-512): below it coefficients are priced with the fast estimate, from it on with the CABAC model (rdo.c:311-340)
+ENCODER_CLIPS = [(64, 64, 2, 9, "small", 22), (72, 88, 2, 1, "small", 12), (200, 136, 2, 3, "small", 27), (64, 64, 2, 9, "small", 30),
+                 (200, 136, 2, 3, "small", 37), (416, 240, 3, 1234, "small", 22), (416, 240, 2, 99, "small", 17), (416, 240, 2, 7, "small", 32),
+                 (192, 136, 2, 5, "small", 45), (832, 480, 1, 5, "large", 22), (832, 480, 1, 5, "large", 28), (1920, 1080, 1, 1, "large", 22),
+                 (1920, 1080, 1, 1, "large", 32)]
 
 
 def clip_key(w, h, n, seed, kind, qp, deblock):

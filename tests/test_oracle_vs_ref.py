@@ -110,3 +110,33 @@ def test_sao_frame_matches_reference(oracle, reflib, size):
         b = sc.run_cpu(reflib.lib.kvz_ref_sao_frame, w, h, frame, luma, chroma)
         assert np.array_equal(a, b), np.flatnonzero(a != b)[:8]
         assert not np.array_equal(a, frame)
+
+
+def test_residual_coder_bits_match_reference(oracle, reflib):
+    """the oracle's restatement of kvz_encode_coeff_nxn in counting mode (what get_coeff_cabac_cost runs, rdo.c:220-263) against
+    the reference function on random blocks, random context states, all scans, with and without context updates: same bits,
+    same states afterwards"""
+    import ctypes as C
+    fb = (C.c_float * 128)(*[reflib.lib.kvz_ref_entropy_fbits(i) for i in range(128)])
+    reflib.lib.kvz_ref_coeff_cabac_bits.restype = C.c_double
+    oracle.lib.kvz_oracle_coeff_cabac_bits.restype = C.c_double
+    rng = np.random.default_rng(1)
+    for trial in range(1500):
+        typ = int(rng.choice([0, 2]))
+        w = int(rng.choice([4, 8, 16, 32] if typ == 0 else [4, 8, 16]))
+        scan = int(rng.choice([0, 1, 2])) if w <= 8 else 0
+        dens, mag = rng.choice([0.02, 0.1, 0.4, 0.9]), int(rng.choice([1, 2, 4, 40, 3000]))
+        blk = (rng.random(w * w) < dens) * rng.integers(-mag, mag + 1, w * w)
+        if rng.random() < 0.5:
+            yy, xx = np.divmod(np.arange(w * w), w)
+            blk = blk * ((yy + xx) < w // 2 + 1)
+        blk = blk.astype(np.int16)
+        if not blk.any():
+            blk[int(rng.integers(0, w * w))] = 1
+        upd = int(rng.integers(0, 2))
+        ctx = rng.integers(0, 126, 136, dtype=np.uint8)
+        a, b = ctx.copy(), ctx.copy()
+        ra = reflib.lib.kvz_ref_coeff_cabac_bits(blk.ctypes.data_as(C.c_void_p), w, typ, scan, upd, a.ctypes.data_as(C.c_void_p))
+        rb = oracle.lib.kvz_oracle_coeff_cabac_bits(fb, blk.ctypes.data_as(C.c_void_p), w, typ, scan, upd, b.ctypes.data_as(C.c_void_p))
+        assert ra == rb and np.array_equal(a, b), (trial, w, typ, scan, upd, ra, rb)
+        assert upd or np.array_equal(a, ctx)
