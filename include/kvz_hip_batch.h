@@ -13,7 +13,7 @@
  * frame of the batch.
  *
  * Decisions use kvazaar's own cost formulas, in double precision with the reference's operation order, on CABAC contexts
- * that evolve as kvazaar's do (kvz_hip_intra_cost_model): for QP < 28 the reconstruction, CU quadtree, modes and coefficients
+ * that evolve as kvazaar's do (kvz_hip_intra_cost_model): the reconstruction, CU quadtree, modes and coefficients
  * are those of `kvazaar --preset ultrafast -p 1`, picture for picture (tests/test_encoder_parity.py checks the pass against
  * digests of the reference CLI's --debug output).  The checker for every intermediate is oracle/kvz_oracle_ctu.c.
  */

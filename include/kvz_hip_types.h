@@ -67,8 +67,8 @@ typedef struct kvz_hip_epol_params {
  * CU the search evaluates, with the save / restore points of search_cu (search.c:655-1060), then by the real syntax of the
  * finished CTU in coding order (encode_coding_tree.c:745), and handed from CTU to CTU along a row and from the second CTU of a
  * row to the first of the row below (WPP, encoderstate.c:763-771) -- the reconstruction is then kvazaar's own, picture for
- * picture (tests/test_encoder_parity.py), for QP < fast_residual_cost_limit (cfg.c: 28 in `ultrafast`; above it kvazaar
- * prices coefficients with the full CABAC model, which the pass does not cover).  adaptive == 0 keeps every context at its
+ * picture (tests/test_encoder_parity.py), at every QP: below fast_residual_cost_limit (cfg.c: 28 in `ultrafast`) with the fast
+ * coefficient cost, from it on with the residual coder in counting mode (coeff_cabac).  adaptive == 0 keeps every context at its
  * slice-start state: CTUs then depend on each other through pixels and CU info only; a valid encode, not kvazaar's. */
 /* Index of each context in kvz_hip_intra_cost_model::ctx_init (cabac.h:63-100): CU / transform-tree syntax, then the residual-coding
  * contexts, which only matter when coefficients are priced with the CABAC model (coeff_cabac). */

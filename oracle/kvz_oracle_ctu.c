@@ -27,8 +27,9 @@
  * (code_coding_tree below), WPP seeding of the next row from a row's second CTU (encoderstate.c:763-771).  The mock encode's
  * left-neighbour lookup at the LCU's left edge is followed as well (intra_mode_syntax_bits).  PINNED END TO END: the pass
  * (+ kvz_oracle_deblock_frame) reproduces the reconstruction `kvazaar --preset ultrafast -p 1 --debug` writes, picture for
- * picture, for QP < 28 (tests/test_encoder_parity.py, tests/golden/encoder_recon.json).  At QP >= 28 `ultrafast` switches to
- * the full CABAC coefficient cost (fast_residual_cost_limit, rdo.c:311-326), which is not restated here.
+ * picture, for QP 12..45 (tests/test_encoder_parity.py, tests/golden/encoder_recon.json).  From QP 28 on `ultrafast` prices
+ * coefficients by running the residual coder in counting mode (fast_residual_cost_limit, rdo.c:311-340): encode_coeff_nxn() below,
+ * pinned against the reference's kvz_encode_coeff_nxn on random blocks and context states (tests/test_oracle_vs_ref.py).
  * adaptive == 0 freezes every context at its slice-start state (CTUs then interact through pixels and CU info only).
  */
 #include <math.h>
