@@ -13,7 +13,8 @@ Fixtures (small, committed; the GPU box and any machine without the reference tr
                         returns them: the cost-model inputs of tests that run without the reference tree
   encoder_recon.json    the reference ENCODER end to end: sha256 of the reconstruction `kvazaar --preset ultrafast -p 1 -q QP` (the CLI
                         built from /root/reference, all-intra, deblocking on / off) writes with --debug for seeded clips -- what the
-                        batched CTU pass (+ deblocking) must reproduce picture for picture
+                        batched CTU pass (+ deblocking) must reproduce picture for picture; ".../cu" entries: digests of the CU depth
+                        and intra mode maps of the encoder's cu_array behind it (recorded with the oracle/ref_cudump.c interposer)
 (the bitstream md5s of the reference encoder are asserted by tests/test_e2e_dropin.py)
 tests/test_oracle_golden.py holds the known answers of the reference's own unit tests; this file adds outputs of the
 compiled reference for the functions those tests do not pin."""
@@ -91,8 +92,10 @@ def clip_key(w, h, n, seed, kind, qp, deblock):
     return f"{w}x{h}/n{n}/seed{seed}/{kind}/qp{qp}/{'deblock' if deblock else 'nodeblock'}"
 
 
-def reference_encoder_recon(w, h, frames, qp, deblock, workdir):
-    """runs the reference CLI (oracle/_ref/kvazaar_ref) on the clip; returns its --debug reconstruction, one array per frame"""
+def reference_encoder_recon(w, h, frames, qp, deblock, workdir, cu_maps=None):
+    """runs the reference CLI (oracle/_ref/kvazaar_ref) on the clip; returns its --debug reconstruction, one array per frame.
+    cu_maps: a list that receives, per frame, the (depth, intra mode) maps per 8x8 cell the encoder's search left in its cu_array
+    (recorded through the oracle/ref_cudump.c interposer; single-threaded so that LCUs arrive frame by frame)"""
     exe = os.path.join(flatapi.ROOT, "oracle", "_ref", "kvazaar_ref")
     src, rec = os.path.join(workdir, "in.yuv"), os.path.join(workdir, "rec.yuv")
     with open(src, "wb") as f:
@@ -100,7 +103,22 @@ def reference_encoder_recon(w, h, frames, qp, deblock, workdir):
     cmd = [exe, "-i", src, "--input-res", f"{w}x{h}", "--preset", "ultrafast", "-p", "1", "-q", str(qp), "--debug", rec, "-o", os.path.join(workdir, "out.hevc")]
     if not deblock:
         cmd.append("--no-deblock")
-    subprocess.run(cmd, check=True, capture_output=True)
+    env = dict(os.environ)
+    dump = os.path.join(workdir, "cu.txt")
+    if cu_maps is not None:
+        if os.path.exists(dump):
+            os.remove(dump)
+        cmd += ["--threads", "0", "--owf", "0"]
+        env.update(LD_PRELOAD=os.path.join(flatapi.ROOT, "oracle", "_ref", "libkvz_cudump.so"), KVZ_CUDUMP=dump)
+    subprocess.run(cmd, check=True, capture_output=True, env=env)
+    if cu_maps is not None:
+        cells = (w // 8) * (h // 8)
+        rows = np.loadtxt(dump, dtype=np.int64).reshape(len(frames), cells, 5)
+        for fr in rows:
+            depth, mode = np.zeros((h // 8, w // 8), np.uint8), np.zeros((h // 8, w // 8), np.uint8)
+            depth[fr[:, 1] // 8, fr[:, 0] // 8] = fr[:, 2]
+            mode[fr[:, 1] // 8, fr[:, 0] // 8] = fr[:, 3]
+            cu_maps.append((depth, mode))
     return list(np.fromfile(rec, dtype=np.uint8).reshape(len(frames), -1))
 
 
@@ -110,9 +128,16 @@ def encoder_digests(workdir):
     for (w, h, n, seed, kind, qp) in ENCODER_CLIPS:
         frames = cc.yuv_frames(w, h, n, seed, kind)
         for deblock in (0, 1):
-            recs = reference_encoder_recon(w, h, frames, qp, deblock, workdir)
+            maps = [] if deblock == 0 else None
+            recs = reference_encoder_recon(w, h, frames, qp, deblock, workdir, maps)
             out[clip_key(w, h, n, seed, kind, qp, deblock)] = [hashlib.sha256(r.tobytes()).hexdigest()[:24] for r in recs]
+            if maps is not None:  # the CU quadtree and the intra modes behind that reconstruction
+                out[clip_key(w, h, n, seed, kind, qp, deblock) + "/cu"] = [cu_digest(d, m) for d, m in maps]
     return out
+
+
+def cu_digest(depth, mode):
+    return hashlib.sha256(np.ascontiguousarray(depth, np.uint8).tobytes() + np.ascontiguousarray(mode, np.uint8).tobytes()).hexdigest()[:24]
 
 
 def main():

@@ -42,6 +42,10 @@ def oracle_model(oracle, qp):
     return m
 
 
+def _cu(o, w, h):
+    return mg.cu_digest(o["depth"].reshape(h // 8, w // 8), o["mode"].reshape(h // 8, w // 8))
+
+
 def _oracle_chain(oracle, model, w, h, frame, qp, deblock):
     o = cc.run_oracle(oracle, model, w, h, frame)
     if not deblock:
@@ -60,6 +64,8 @@ def test_oracle_chain_reproduces_reference_encoder(oracle, clip):
     for deblock in (0, 1):
         got = [_sha(_oracle_chain(oracle, model, w, h, f, qp, deblock)) for f in frames]
         assert got == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, deblock)], (clip, deblock)
+    # ... and the decisions behind the pixels: CU depth and intra mode of every 8x8 cell as the encoder's cu_array holds them
+    assert [_cu(cc.run_oracle(oracle, model, w, h, f), w, h) for f in frames] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0) + "/cu"]
 
 
 def test_frozen_contexts_do_not_reproduce_the_encoder(oracle):
@@ -81,8 +87,11 @@ def test_encoder_fixture_matches_reference_build(tmp_path):
     for (w, h, n, seed, kind, qp) in mg.ENCODER_CLIPS[:5]:
         frames = cc.yuv_frames(w, h, n, seed, kind)
         for deblock in (0, 1):
-            recs = mg.reference_encoder_recon(w, h, frames, qp, deblock, str(tmp_path))
+            maps = [] if deblock == 0 else None
+            recs = mg.reference_encoder_recon(w, h, frames, qp, deblock, str(tmp_path), maps)
             assert [_sha(r) for r in recs] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, deblock)]
+            if maps is not None:
+                assert [mg.cu_digest(d, m) for d, m in maps] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, deblock) + "/cu"]
 
 
 def test_entropy_fixture_matches_reference_build():
@@ -101,8 +110,9 @@ def test_hostsim_pass_reproduces_reference_encoder(oracle, hostsim, clip):
     w, h, n, seed, kind, qp = clip
     model = oracle_model(oracle, qp)
     frames = cc.yuv_frames(w, h, n, seed, kind)
-    got = [_sha(cc.run_hostsim(hs.lib, model, w, h, f)["rec"]) for f in frames]
-    assert got == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0)]
+    outs = [cc.run_hostsim(hs.lib, model, w, h, f) for f in frames]
+    assert [_sha(o["rec"]) for o in outs] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0)]
+    assert [_cu(o, w, h) for o in outs] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0) + "/cu"]
 
 
 @pytest.mark.gpu
@@ -120,7 +130,9 @@ def test_hip_batch_reproduces_reference_encoder(clip):
         for i, f in enumerate(frames):
             b.upload(i, f)
         b.run(model)
-        assert [_sha(b.download(i)["rec"]) for i in range(n)] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0)]
+        outs = [b.download(i) for i in range(n)]
+        assert [_sha(o["rec"]) for o in outs] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0)]
+        assert [_cu(o, w, h) for o in outs] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0) + "/cu"]
         b.deblock(qp)
         assert [_sha(b.download(i)["rec"]) for i in range(n)] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 1)]
     finally:
