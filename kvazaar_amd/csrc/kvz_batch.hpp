@@ -21,14 +21,14 @@ namespace kvz {
 #ifndef KVZ_CTU_WAVES_PER_EU
 #define KVZ_CTU_WAVES_PER_EU 4  /* 8 workgroups of 128 lanes per CU = 4 wavefronts per SIMD at 128 VGPRs (LDS 16.5 KB would allow 9, but 96 VGPRs cost more than the ninth workgroup gives: profiles/experiments/r01_ab13*) */
 #endif
-__global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) intra_ctu_wave_kernel(const CtuFrames F, const CtuModel model, const Tables *tb,
+template <bool CABAC> __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) intra_ctu_wave_kernel(const CtuFrames F, const CtuModel model, const Tables *tb,
                                                                         const int wave, const int y_min, const int n_diag)
 {
-  __shared__ CtuShared shared;
+  __shared__ CtuSharedT<CABAC> shared;
   __shared__ CtuModel m;  // scalars in LDS; its price table stays in HBM (kvz_hip_batch::d_entropy)
   if (threadIdx.x == 0) m = model;
   __syncthreads();
-  CtuProgram p;
+  CtuProgramT<CABAC> p;
   p.m = &m; p.tb = tb; p.F = F; p.s = &shared;
   p.frame = blockIdx.x / n_diag;
   const int y = y_min + (int)(blockIdx.x % n_diag);
@@ -64,10 +64,10 @@ __device__ __forceinline__ bool wait_done(unsigned *flag, unsigned epoch, unsign
   }
 }
 
-__global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) KVZ_CTU_VGPR_ATTR intra_ctu_ticket_kernel(const CtuFrames F, const CtuModel model, const Tables *tb,
+template <bool CABAC> __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) KVZ_CTU_VGPR_ATTR intra_ctu_ticket_kernel(const CtuFrames F, const CtuModel model, const Tables *tb,
                                                                         const CtuSched sched)
 {
-  __shared__ CtuShared shared;
+  __shared__ CtuSharedT<CABAC> shared;
   __shared__ CtuModel m;  // scalars in LDS; its price table stays in HBM (kvz_hip_batch::d_entropy)
   __shared__ unsigned s_ticket;
   if (threadIdx.x == 0) m = model;
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_p
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
-    CtuProgram p;
+    CtuProgramT<CABAC> p;
     p.m = &m; p.tb = tb; p.F = F; p.s = &shared;
     p.frame = frame; p.cx = x * 64; p.cy = y * 64;
     p.lane_rot = (t * 64) & (KVZ_CTU_THREADS - 1);
@@ -249,7 +249,7 @@ kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
     const char *e = getenv("KVZ_HIP_SCHED");  // "wave": one launch per anti-diagonal (the simpler schedule, kept for A/B)
     b->sched_ticket = !(e && e[0] == 'w') && n_frames < 65536 && F.wc < 256 && F.hc < 256;
     int per_cu = 0, dev = 0, cus = 0;
-    KVZ_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kvz::intra_ctu_ticket_kernel, KVZ_CTU_THREADS, 0));
+    KVZ_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kvz::intra_ctu_ticket_kernel<true>, KVZ_CTU_THREADS, 0));
     KVZ_HIP_CHECK(hipGetDevice(&dev));
     KVZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (per_cu < 1) per_cu = 1;
@@ -317,7 +317,9 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
     KVZ_HIP_CHECK(hipMemsetAsync(b->d_ticket, 0, 2 * sizeof(unsigned), b->stream));
     KVZ_HIP_CHECK(hipEventRecord(b->ev0, b->stream));
     kvz::CtuSched sc{ b->d_items, b->d_ticket, b->d_done, b->d_error, b->total_items, b->epoch };
-    hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);
+    // two instantiations: the one without the CABAC coefficient model carries none of its code, registers or context storage
+    if (cm.coeff_cabac) hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel<true>, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);
+    else hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel<false>, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);
     KVZ_HIP_CHECK(hipGetLastError());
     KVZ_HIP_CHECK(hipEventRecord(b->ev1, b->stream));
     return 1;
@@ -332,8 +334,10 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
     if (y_max > F.hc - 1) y_max = F.hc - 1;
     const int n_diag = y_max - y_min + 1;
     if (n_diag <= 0) continue;
-    hipLaunchKernelGGL(kvz::intra_ctu_wave_kernel, dim3(n_diag * b->n_frames), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), wave,
-                       y_min, n_diag);
+    if (cm.coeff_cabac) hipLaunchKernelGGL(kvz::intra_ctu_wave_kernel<true>, dim3(n_diag * b->n_frames), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), wave,
+                                           y_min, n_diag);
+    else hipLaunchKernelGGL(kvz::intra_ctu_wave_kernel<false>, dim3(n_diag * b->n_frames), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), wave,
+                            y_min, n_diag);
     launches++;
   }
   KVZ_HIP_CHECK(hipGetLastError());

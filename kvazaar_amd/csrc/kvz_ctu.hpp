@@ -132,7 +132,9 @@ struct CtuCu { u8 type : 1, depth : 2, tr_depth : 2; u8 mode; uint16_t cbf; };  
 // when coefficients are priced with the CABAC model (CtuModel::coeff_cabac)
 enum { KVZ_CX_SPLIT = KVZ_HIP_CX_SPLIT, KVZ_CX_PART = KVZ_HIP_CX_PART, KVZ_CX_INTRA = KVZ_HIP_CX_INTRA, KVZ_CX_CHROMA = KVZ_HIP_CX_CHROMA,
        KVZ_CX_CBF_LUMA = KVZ_HIP_CX_CBF_LUMA, KVZ_CX_CBF_CHROMA = KVZ_HIP_CX_CBF_CHROMA, KVZ_CX_SYNTAX_COUNT = KVZ_HIP_CX_SIG_CG, KVZ_CX_COUNT = KVZ_HIP_CX_COUNT };
-struct CtxSet { alignas(4) u8 s[148]; };
+// CABAC = false compiles a program that never prices coefficients with the CABAC model: the sets shrink to the syntax contexts and
+// everything guarded by cabac_on() folds away (the kernel the QP < 28 runs launch)
+template <bool CABAC> struct CtxSetT { alignas(4) u8 s[CABAC ? 148 : 12]; };
 
 // What the CTU program reads of kvz_hip_intra_cost_model, compact (the device keeps it in LDS; the 128-entry price table stays
 // behind a pointer: a copy in HBM on the device)
@@ -173,7 +175,7 @@ struct CtuFrames {
 };
 #define KVZ_BORDER_BYTES 512
 
-struct CtuShared {
+template <bool CABAC> struct CtuSharedT {
   alignas(8) u8 org[1536];   // source pixels of the 32x32 quadrant being searched: Y 32x32 | U 16x16 | V 16x16 (load_org())
   // Reconstruction.  kvazaar keeps one full lcu_t per depth (search.c:103-122); what those copies hold at any time is
   // (a) the pixels already decided, identical in every level that can see them, plus (b) one candidate per depth for the
@@ -238,18 +240,22 @@ struct CtuShared {
   // CABAC contexts (lane 0 only).  cab = state->search_cabac while the CTU is searched; pre[d] = its value when search_cu entered
   // depth d (search.c:655; pre[0] is the row's state->cabac the search started from, search.c:1211, and what the CTU's real syntax
   // is replayed on afterwards); post2 = after the 16x16 CU was evaluated (search.c:956)
-  CtxSet cab, pre[3], post2;
+  CtxSetT<CABAC> cab, pre[3], post2;
   float entropy_fbits[128];  // the model's price table and the LPS transitions of Tables::ctx_next, staged per CTU: every lookup sits on lane 0's critical path
-  u8 ctx_lps[64];            // state (without the MPS bit) after a less probable symbol
+  u8 ctx_lps[64];            // packed state after a less probable symbol, for MPS = 0 (xor the MPS bit in; state 0 flips it: entry 0 is 1)
 };
+
+using CtuShared = CtuSharedT<true>;
 
 static const int kPlaneOff[3] = { 0, 4096, 5120 };
 
-struct CtuProgram {
+template <bool CABAC> struct CtuProgramT {
+  using CtxSet = CtxSetT<CABAC>;
   const CtuModel *m;
   const Tables *tb;
   CtuFrames F;
-  CtuShared *s;
+  CtuSharedT<CABAC> *s;
+  KVZ_DEV bool cabac_on() const { return CABAC && m->coeff_cabac; }  // coefficients priced with the CABAC model (rdo.c:311-340)
   int frame, cx, cy;  // CTU origin (luma px)
   int a1x, a1y, a2x, a2y;  // CTU-local luma origin of the depth-1 / depth-2 CU whose candidates are live (uniform)
   int lane_rot = 0;        // see KVZ_FOR_THREADS
@@ -377,13 +383,13 @@ struct CtuProgram {
   // kvz_g_auc_next_state_mps / _lps (cabac.c:40-62) on the packed state
   KVZ_DEV int ctx_next(int st, int bin) const
   {
-    if (bin == (st & 1)) return st >= 124 ? st : st + 2;
-    return st < 2 ? st ^ 1 : ((int)s->ctx_lps[st >> 1] << 1) | (st & 1);
+    const int mps = st + ((st < 124) << 1), lps = (int)s->ctx_lps[st >> 1] ^ (st & 1);  // branch-free: both are a handful of ALU ops + one LDS byte
+    return bin == (st & 1) ? mps : lps;
   }
   // copy of a context set: the residual-coding part only matters (and only moves) when coefficients are priced with the CABAC model
   KVZ_DEV void ctx_copy(CtxSet *dst, const CtxSet *src) const
   {
-    const int n = m->coeff_cabac ? 37 : 3;
+    const int n = cabac_on() ? 37 : 3;
     for (int i = 0; i < n; i++) ((unsigned *)dst->s)[i] = ((const unsigned *)src->s)[i];
   }
   // lambda_sqrt * kvz_luma_mode_bits of the three possible outcomes at the current state of the intra-mode context; the rough
@@ -584,6 +590,125 @@ struct CtuProgram {
     }
     return bits;
   }
+#ifndef KVZ_HOSTSIM
+  // The same count by a whole wavefront (all 64 lanes call it, converged; every argument wavefront-uniform).  What is parallel:
+  // the group masks (one lane per 4x4 group, one ballot), and inside a coded group the sixteen scan positions -- level, context
+  // increment of its significance flag -- on sixteen lanes.  What stays serial is only what the standard makes serial: with
+  // `update` the chain of state changes (one table lookup per bin, operands fetched from the lanes with v_readlane); without it
+  // even the significance flags are priced by their lanes and summed with DPP.  Prices are accumulated in Q15 integers -- every
+  // table entry is a multiple of 2^-15 -- so the sum is exact and order-free, and equals the double sum of the one-lane version.
+  KVZ_DEV static int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+  KVZ_DEV unsigned bin_q15(CtxSet *c, bool update, int idx, int bin) const
+  {
+    const int st = uni(c->s[idx]);
+    const unsigned q = (unsigned)(s->entropy_fbits[st ^ bin] * 32768.0f);
+    if (update) c->s[idx] = (u8)ctx_next(st, bin);  // every lane stores the same byte
+    return q;
+  }
+  KVZ_DEV double coeff_cabac_bits_wave(CtxSet *c, bool update, const i16 *coeff, int log2w, int type, int scan) const
+  {
+    update = update && m->adaptive;
+    const int lane = threadIdx.x & 63;
+    const int w = 1 << log2w, side = w >> 2, ngroups = side * side;
+    bool any = false;
+    if (lane < ngroups) {
+      const int gy = lane >> (log2w - 2), gx = lane & (side - 1);
+      unsigned long long acc = 0;
+      for (int r = 0; r < 4; r++) { unsigned long long four; __builtin_memcpy(&four, coeff + ((gy * 4 + r) << log2w) + gx * 4, 8); acc |= four; }
+      any = acc != 0;
+    }
+    const unsigned long long sig = __ballot(any);  // bit g: group g (raster) holds a level
+    if (!sig) return 0;
+    const unsigned long long ord = __ballot(lane < ngroups && ((sig >> group_of(log2w, scan, lane < ngroups ? lane : 0)) & 1));  // the same in group order
+    const int last_group = 63 - __builtin_clzll(ord);
+    unsigned long long q15 = 0;
+    int c1 = 1;
+    for (int i = last_group; i >= 0; i--) {
+      const int g = uni(group_of(log2w, scan, i)), gy = g >> (log2w - 2), gx = g & (side - 1);
+      const i16 *base = coeff + ((gy * 4) << log2w) + gx * 4;
+      const bool right = gx < side - 1 && ((sig >> (g + 1)) & 1), lower = gy < side - 1 && ((sig >> (g + side)) & 1);
+      bool coded = (sig >> g) & 1;
+      if (i == last_group || i == 0) coded = true;
+      else q15 += bin_q15(c, update, KVZ_HIP_CX_SIG_CG + type + (right || lower), coded);
+      if (!coded) continue;
+      const int k = lane & 15, r = scan_in_group(scan, k), px = gx * 4 + (r & 3), py = gy * 4 + (r >> 2);
+      const int level = lane < 16 ? base[((r >> 2) << log2w) + (r & 3)] : 0;
+      const unsigned nzmask = (unsigned)__ballot(level != 0) & 0xffffu;
+      const int absval = iabs(level);
+      unsigned coded_mask;
+      if (i == last_group) {
+        // the last significant position and its coding (encode_coding_tree.c:63-115)
+        const int k_last = 31 - __builtin_clz(nzmask), rl = scan_in_group(scan, k_last);
+        int lx = gx * 4 + (rl & 3), ly = gy * 4 + (rl >> 2);
+        if (scan == 2) { const int tmp = lx; lx = ly; ly = tmp; }
+        const int index = log2w - 2, ctx_offset = type ? 0 : (index * 3 + (index + 1) / 4), shift = type ? index : (index + 3) / 4;
+        const int bx = (type ? KVZ_HIP_CX_LAST_X_CHROMA : KVZ_HIP_CX_LAST_X_LUMA) + ctx_offset, by = (type ? KVZ_HIP_CX_LAST_Y_CHROMA : KVZ_HIP_CX_LAST_Y_LUMA) + ctx_offset;
+        const unsigned long long gidx_lo = 0x7777666655443210ull;
+        const int gxi = lx < 16 ? (int)((gidx_lo >> (4 * lx)) & 15) : (lx < 24 ? 8 : 9), gyi = ly < 16 ? (int)((gidx_lo >> (4 * ly)) & 15) : (ly < 24 ? 8 : 9);
+        const int gmax = w - 1 < 16 ? (int)((gidx_lo >> (4 * (w - 1))) & 15) : 9;
+        for (int q = 0; q < gxi; q++) q15 += bin_q15(c, update, bx + (q >> shift), 1);
+        if (gxi < gmax) q15 += bin_q15(c, update, bx + (gxi >> shift), 0);
+        for (int q = 0; q < gyi; q++) q15 += bin_q15(c, update, by + (q >> shift), 1);
+        if (gyi < gmax) q15 += bin_q15(c, update, by + (gyi >> shift), 0);
+        if (gxi > 3) q15 += (unsigned long long)((gxi - 2) / 2) << 15;
+        if (gyi > 3) q15 += (unsigned long long)((gyi - 2) / 2) << 15;
+        coded_mask = (1u << k_last) - 1;  // the positions below it; position 0 included (a level has been seen)
+      } else {
+        coded_mask = 0xffffu;
+        if (i != 0 && !(nzmask & 0xfffeu)) coded_mask &= ~1u;  // position 0 of a coded group with no other level is inferred
+      }
+      const int pattern = log2w == 2 ? -1 : (int)right + ((int)lower << 1);
+      const int ctx = (type == 0 ? KVZ_HIP_CX_SIG_LUMA : KVZ_HIP_CX_SIG_CHROMA) + sig_ctx_inc(pattern, scan, px, py, log2w, type);
+      if (!update) {
+        int x = (lane < 16 && ((coded_mask >> k) & 1)) ? (int)(s->entropy_fbits[c->s[ctx] ^ (level != 0)] * 32768.0f) : 0;
+        x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+        q15 += (unsigned)__builtin_amdgcn_readlane(x, 15);
+      } else {
+        for (unsigned mk = coded_mask; mk;) {
+          const int kk = uni(31 - __builtin_clz(mk));
+          mk &= ~(1u << kk);
+          q15 += bin_q15(c, true, __builtin_amdgcn_readlane(ctx, kk), (nzmask >> kk) & 1);
+        }
+      }
+      const int num = __builtin_popcount(nzmask);
+      if (num > 0) {
+        int ctx_set = (i > 0 && type == 0) ? 2 : 0;
+        if (c1 == 0) ctx_set++;
+        c1 = 1;
+        const int base_one = (type == 0 ? KVZ_HIP_CX_ONE_LUMA : KVZ_HIP_CX_ONE_CHROMA) + 4 * ctx_set;
+        int first_c2_abs = -1, cnt = 0;
+        for (unsigned mk = nzmask; mk && cnt < 8; cnt++) {  // levels in coding order = from the highest scan position down
+          const int kk = uni(31 - __builtin_clz(mk));
+          mk &= ~(1u << kk);
+          const int a = __builtin_amdgcn_readlane(absval, kk), symbol = a > 1;
+          q15 += bin_q15(c, update, base_one + c1, symbol);
+          if (symbol) { c1 = 0; if (first_c2_abs < 0) first_c2_abs = a; }
+          else if (c1 < 3 && c1 > 0) c1++;
+        }
+        if (c1 == 0 && first_c2_abs >= 0) q15 += bin_q15(c, update, (type == 0 ? KVZ_HIP_CX_ABS_LUMA : KVZ_HIP_CX_ABS_CHROMA) + ctx_set, first_c2_abs > 2);
+        int bypass = num;  // signs
+        if (c1 == 0 || num > 8) {
+          int first_coeff2 = 1, go_rice = 0, q = 0;
+          for (unsigned mk = nzmask; mk; q++) {
+            const int kk = uni(31 - __builtin_clz(mk));
+            mk &= ~(1u << kk);
+            const int a = __builtin_amdgcn_readlane(absval, kk), base_level = q < 8 ? 2 + first_coeff2 : 1;
+            if (a >= base_level) {
+              bypass += coeff_remain_bits(a - base_level, go_rice);
+              if (a > 3 * (1 << go_rice)) go_rice = go_rice + 1 < 4 ? go_rice + 1 : 4;
+            }
+            if (a >= 2) first_coeff2 = 0;
+          }
+        }
+        q15 += (unsigned long long)bypass << 15;
+      }
+    }
+    return (double)q15 / 32768.0;
+  }
+#endif
   // encoderstate.c:1761-1775 kvz_get_scan_order for an intra CU (the chroma mode is the luma mode here)
   KVZ_DEV static int scan_order(int mode, int depth)
   {
@@ -1037,7 +1162,7 @@ struct CtuProgram {
         const QuantScalars qi = qf;
         i16 *cout = lv == 2 ? s->lv2_coeff + (c == 0 ? 0 : (c == 1 ? 256 : 320))
                   : lv == 1 ? s->lv1_coeff + (c == 0 ? 0 : (c == 1 ? 1024 : 1280)) : coeff_level(lv) + kPlaneOff[c] + zorder(xl >> sh, yl >> sh);
-        i16 *stage = (m->coeff_cabac && (lv == 3 || lv == 0)) ? levels_lds(lv, c) : nullptr;  // see levels_lds()
+        i16 *stage = (cabac_on() && (lv == 3 || lv == 0)) ? levels_lds(lv, c) : nullptr;  // see levels_lds()
         const i16 *src = tbuf(t, 0, c);
         i16 *dq = tbuf(t, 1, c);
         u32 wsum = 0, nz = 0;
@@ -1130,15 +1255,38 @@ struct CtuProgram {
     return q;
   }
 
-  // get_coeff_cabac_cost (rdo.c:220-263) of the planes of one transform unit that have levels, luma first (search.c:518-547)
+  // get_coeff_cabac_cost (rdo.c:220-263) of the planes of one transform unit that have levels, luma first (search.c:518-547).
+  // On the device the callers bring the whole wavefront that plays threads 0..63 (KVZ_UNIT_COEFF_BITS), in the host simulation thread 0.
   KVZ_DEV double unit_coeff_bits(CtxSet *c, bool update, int lv, int depth, int mode, int cb_y, int cb_u, int cb_v) const
   {
     const int lw = 6 - depth, lc = depth == 3 ? 2 : lw - 1, scan = scan_order(mode, depth);
     double bits = 0;
+#ifdef KVZ_HOSTSIM
     if (cb_y) bits += coeff_cabac_bits(c, update, levels_lds(lv, 0), lw, 0, scan);
     if (cb_u) bits += coeff_cabac_bits(c, update, levels_lds(lv, 1), lc, 2, scan);
     if (cb_v) bits += coeff_cabac_bits(c, update, levels_lds(lv, 2), lc, 2, scan);
+#else  // a whole wavefront is here (see the callers)
+    if (cb_y) bits += coeff_cabac_bits_wave(c, update, levels_lds(lv, 0), lw, 0, scan);
+    if (cb_u) bits += coeff_cabac_bits_wave(c, update, levels_lds(lv, 1), lc, 2, scan);
+    if (cb_v) bits += coeff_cabac_bits_wave(c, update, levels_lds(lv, 2), lc, 2, scan);
+#endif
     return bits;
+  }
+  // ... of the unit just reconstructed (levels in levels_lds(lv), non-zero counts in acc[6..8]) into *out, for thread 0 to pick up
+  // in a later phase (same wavefront: no barrier needed in between)
+#ifdef KVZ_HOSTSIM
+#define KVZ_UNIT_COEFF_BITS(tid) ((tid) == 0)
+#else
+#define KVZ_UNIT_COEFF_BITS(tid) ((tid) < 64)
+#endif
+  KVZ_DEV void price_unit_coeffs(CtxSet *c, bool update, int lv, int depth, int mode, double *out) const
+  {
+    KVZ_FOR_THREADS(tid) {
+      if (KVZ_UNIT_COEFF_BITS(tid)) {
+        const double b = unit_coeff_bits(c, update, lv, depth, mode, s->acc[6] != 0, s->acc[7] != 0, s->acc[8] != 0);
+        if (tid == 0) *out = b;
+      }
+    }
   }
   // search.c:425-541 cu_rd_cost_tr_split_accurate for one leaf TU group whose sums sit in s->acc (lane 0 only)
   // `known_coeff_bits`: the units of the 64x64 attempt had their coefficients priced when their levels were staged (try_merge)
@@ -1151,8 +1299,7 @@ struct CtuProgram {
     if (code_cbf_u) tr_tree_bits += ctx_price(c, KVZ_CX_CBF_CHROMA + depth - cu_depth, cb_u, update);
     if (code_cbf_v) tr_tree_bits += ctx_price(c, KVZ_CX_CBF_CHROMA + depth - cu_depth, cb_v, update);
     tr_tree_bits += ctx_price(c, KVZ_CX_CBF_LUMA + (depth == cu_depth ? 1 : 0), cb_y, update);
-    if (known_coeff_bits) coeff_bits += *known_coeff_bits;
-    else if (m->coeff_cabac) coeff_bits += unit_coeff_bits(c, update, lv, depth, tr_cu->mode, cb_y, cb_u, cb_v);
+    if (known_coeff_bits) coeff_bits += *known_coeff_bits;  // always the case with the CABAC model
     else {  // kvz_fast_coeff_cost (rdo.c:311-326): the weight sums of the quantisation stage
       if (cb_y) coeff_bits += (double)s->acc[3] / 256.0;
       if (cb_u) coeff_bits += (double)s->acc[4] / 256.0;
@@ -1243,11 +1390,12 @@ struct CtuProgram {
     // All three planes' references were built by rough_search.
     TuSet t{ x, y, log2w, depth == 3 ? 2 : log2w - 1 };
     recon_tus(lv, t, depth, mode, true);
+    if (cabac_on()) price_unit_coeffs(&s->cab, true, lv, depth, mode, &s->child_bits[0]);  // residual contexts; the syntax ones below are disjoint
     KVZ_FOR_THREADS(tid) {
       if (tid == 0) {
         const double bits = cu_bits(lv, x, y, depth, mode, s->preds);  // search.c:895-940: cabac->update = 1 around the mock encode ...
         double cost = bits * m->lambda;
-        cost += leaf_rd_cost(&s->cab, true, lv, xl, yl, depth, depth, true, true);  // ... and the transform tree's flags
+        cost += leaf_rd_cost(&s->cab, true, lv, xl, yl, depth, depth, true, true, cabac_on() ? &s->child_bits[0] : nullptr);  // ... and the transform tree's flags
         *out_cost = cost;
         const CtuCu *cu = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
         *out_cbf = cbf_is_set(cu->cbf, depth, 0) || cbf_is_set(cu->cbf, depth, 1) || cbf_is_set(cu->cbf, depth, 2);
@@ -1333,8 +1481,8 @@ struct CtuProgram {
       }
       if (v >= 128 && v < 136) s->qs[(v - 128) >> 1][v & 1] = quant_scalars_dev(2 + ((v - 128) >> 1), (v & 1) ? 2 : 0);
       if (v < 128) s->entropy_fbits[v] = m->entropy_fbits[v];
-      if (v < 64) s->ctx_lps[v] = (u8)(tb->ctx_next[1][2 * v] >> 1);
-      if (v < (m->coeff_cabac ? KVZ_CX_COUNT : KVZ_CX_SYNTAX_COUNT)) {  // the residual contexts are only looked at with the CABAC coefficient cost
+      if (v < 64) s->ctx_lps[v] = tb->ctx_next[1][2 * v];
+      if (v < (cabac_on() ? KVZ_CX_COUNT : KVZ_CX_SYNTAX_COUNT)) {  // the residual contexts are only looked at with the CABAC coefficient cost
         // the row's contexts: from the CTU to the left; a row's first CTU from the second CTU of the row above (WPP; rows of a
         // one-CTU-wide picture and the first row start from the slice-start state, encoderstate.c:1218)
         const int ctx = cx >> 6, cty = cy >> 6;
@@ -1451,7 +1599,7 @@ struct CtuProgram {
       }
       KVZ_SYNC();
       KVZ_FOR_THREADS(tid) {
-        if (tid == 0) {
+        if (KVZ_UNIT_COEFF_BITS(tid)) {  // the whole wavefront walks the quadrant's units (everything it branches on is uniform)
           CtxSet *c = &s->pre[0];
           int i = 16 * q;
           while (i < 16 * q + 16) {
@@ -1461,9 +1609,14 @@ struct CtuProgram {
             const int td = cu->depth < 1 ? 1 : cu->depth;  // a 64x64 CU codes four 32x32 units, each read at its own origin
             const int lw = 6 - td, lc = td == 3 ? 2 : lw - 1, scan = scan_order(cu->mode, td);
             const i16 *y = s->lv1_coeff + (zorder(xl, yl) - q * 1024), *u = s->lv1_coeff + 1024 + (zorder(xl >> 1, yl >> 1) - q * 256);
-            if (cbf_is_set(cu->cbf, td, 0)) coeff_cabac_bits(c, true, y, lw, 0, scan);
-            if (cbf_is_set(cu->cbf, td, 1)) coeff_cabac_bits(c, true, u, lc, 2, scan);
-            if (cbf_is_set(cu->cbf, td, 2)) coeff_cabac_bits(c, true, u + 256, lc, 2, scan);
+#ifdef KVZ_HOSTSIM
+#define KVZ_CODE_RESIDUAL coeff_cabac_bits
+#else
+#define KVZ_CODE_RESIDUAL coeff_cabac_bits_wave
+#endif
+            if (cbf_is_set(cu->cbf, td, 0)) KVZ_CODE_RESIDUAL(c, true, y, lw, 0, scan);
+            if (cbf_is_set(cu->cbf, td, 1)) KVZ_CODE_RESIDUAL(c, true, u, lc, 2, scan);
+            if (cbf_is_set(cu->cbf, td, 2)) KVZ_CODE_RESIDUAL(c, true, u + 256, lc, 2, scan);
             i += 1 << (2 * (3 - td));
           }
         }
@@ -1489,7 +1642,7 @@ struct CtuProgram {
         if (m->adaptive) code_ctu_syntax(&s->pre[0]);  // moves the syntax contexts only
         for (int i = 0; i < KVZ_CX_SYNTAX_COUNT; i++) r[288 + i] = s->pre[0].s[i];
       }
-      if (m->coeff_cabac)
+      if (cabac_on())
         for (int v = KVZ_CX_SYNTAX_COUNT + tid; v < KVZ_CX_COUNT; v += KVZ_CTU_THREADS) r[288 + v] = s->pre[0].s[v];  // residual contexts: final since code_ctu_residual()
       for (int v = tid; v < 32; v += KVZ_CTU_THREADS) {
         const int i = v & 7;
@@ -1523,6 +1676,7 @@ struct CtuProgram {
     if (depth == 1) {
       TuSet t{ x, y, 5, 4 };
       recon_tus(lv, t, 1, mode);
+      if (cabac_on()) price_unit_coeffs(&s->pre[1], false, 1, 1, mode, &s->child_bits[0]);
       KVZ_FOR_THREADS(tid) {
         if (tid == 0) {
           // search.c:1005-1041: priced from the contexts at entry; pre_search_cabac carries update == 0 (it was copied while the
@@ -1533,7 +1687,7 @@ struct CtuProgram {
           const double mode_bits = intra_mode_syntax_bits(pc, false, lv, x, y, mode, false) + bits;  // calc_mode_bits search.c:557-581
           double cost = 0;
           cost += mode_bits * m->lambda;
-          cost += leaf_rd_cost(pc, false, lv, xl, yl, 1, 1, true, true);
+          cost += leaf_rd_cost(pc, false, lv, xl, yl, 1, 1, true, true, cabac_on() ? &s->child_bits[0] : nullptr);
           s->cost[1] = cost;
         }
       }
@@ -1547,11 +1701,9 @@ struct CtuProgram {
       a1x = qx - cx; a1y = qy - cy;
       load_org();
       recon_tus(lv, t, 1, mode);
-      KVZ_FOR_THREADS(tid) {
-        if (tid < 9) s->child_acc[q][tid] = s->acc[tid];
-        // priced from the contexts at entry with updates off (search.c:1005-1041), so each unit's bits stand alone
-        if (tid == 0 && m->coeff_cabac) s->child_bits[q] = unit_coeff_bits(&s->pre[0], false, 0, 1, mode, s->acc[6] != 0, s->acc[7] != 0, s->acc[8] != 0);
-      }
+      // priced from the contexts at entry with updates off (search.c:1005-1041), so each unit's bits stand alone
+      if (cabac_on()) price_unit_coeffs(&s->pre[0], false, 0, 1, mode, &s->child_bits[q]);
+      KVZ_FOR_THREADS(tid) { if (tid < 9) s->child_acc[q][tid] = s->acc[tid]; }
       KVZ_SYNC();
     }
     KVZ_FOR_THREADS(tid) {
@@ -1578,7 +1730,7 @@ struct CtuProgram {
           const CtuCu *tr_cu = &s->cu[lv][(qyl >> 3) * 8 + (qxl >> 3)];
           for (int i = 0; i < 9; i++) s->acc[i] = s->child_acc[q][i];
           // search.c:466-471: child cbf_cb/cbf_cr are coded when the entry has any chroma bit at depth >= 0
-          sum += leaf_rd_cost(pc, false, lv, qxl, qyl, 1, 0, cbf_is_set(tr_cu->cbf, 0, 1), cbf_is_set(tr_cu->cbf, 0, 2), m->coeff_cabac ? &s->child_bits[q] : nullptr);
+          sum += leaf_rd_cost(pc, false, lv, qxl, qyl, 1, 0, cbf_is_set(tr_cu->cbf, 0, 1), cbf_is_set(tr_cu->cbf, 0, 2), cabac_on() ? &s->child_bits[q] : nullptr);
         }
         const double rd = sum + tr_tree_bits * m->lambda;
         double bits = 0;
@@ -1669,7 +1821,7 @@ struct CtuProgram {
       write_rec();
     }
     KVZ_PROF(KVZ_P_MISC);
-    if (m->adaptive && m->coeff_cabac) code_ctu_residual();
+    if (m->adaptive && cabac_on()) code_ctu_residual();
     finish_info();
     KVZ_PROF(KVZ_P_FINISH);
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
@@ -1677,5 +1829,6 @@ struct CtuProgram {
 #endif
   }
 };
+using CtuProgram = CtuProgramT<true>;
 
 }  // namespace kvz

@@ -21,7 +21,8 @@ def main():
     import ctu_common as cc
     import bench
     lib = C.CDLL(out)
-    model = cc.hip_cost_model(lib, 22)
+    qp = int(os.environ.get("KVZ_PROFILE_QP", "22"))
+    model = cc.hip_cost_model(lib, qp, cc.coeff_weights(qp))
     frames = bench.synth_frames(1920, 1080, 4, 1)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     b = cc.HipBatch(lib, 1920, 1080, n)
