@@ -1,0 +1,188 @@
+/*
+ * search_lcu_hip.c -- kvazaar-side binding of the BATCHED pass (include/kvz_hip_batch.h): what a kvazaar maintainer would put
+ * in front of kvz_search_lcu (search.c:1209) to let the device search and reconstruct whole pictures.
+ *
+ * kvz_search_lcu(state, x, y, ...) leaves three things behind for the rest of encoder_state_worker_encode_lcu_search
+ * (encoderstate.c:659-720: deblocking, SAO, kvz_encode_coding_tree): the LCU's cu_info in frame->cu_array, its reconstruction in
+ * frame->rec and its quantised coefficients in state->coeff (copy_lcu_to_cu_data / copy_coeffs, search.c:1180-1249).  For the
+ * configuration the batched pass implements -- I slices of an all-intra `ultrafast`-like setup, 8-bit 4:2:0, constant QP, WPP --
+ * this file fills exactly those from one kvz_hip_intra_frames() run per picture: the first LCU of a picture to get here runs the
+ * pass for the whole picture (one-frame batch; the throughput path batches many pictures, this binding is about correctness),
+ * every LCU then copies its part.  Everything else falls through to the original function.  The bitstream is the reference's,
+ * byte for byte (tests/test_e2e_dropin.py).
+ *
+ * In this repository the splice is done at link time (-Wl,--wrap=kvz_search_lcu, oracle/Makefile) because reference sources
+ * are not modified; enabled at run time by KVZ_HIP_BATCH_SEARCH=1.
+ */
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "global.h" // IWYU pragma: keep
+#include "cu.h"
+#include "encoder.h"
+#include "encoderstate.h"
+#include "fast_coeff_cost.h"
+#include "image.h"
+#include "videoframe.h"
+
+#include "kvz_hip_batch.h"
+
+void __real_kvz_search_lcu(encoder_state_t *const state, const int x, const int y, const yuv_t *const hor_buf, const yuv_t *const ver_buf);
+
+typedef struct {
+  const videoframe_t *frame;  /* key: the (tile) frame and the picture it holds */
+  int32_t num;
+  int width, height, qp;
+  uint8_t *rec, *depth, *mode; /* tight planes Y|U|V; one byte per 8x8 */
+  int16_t *coeff;              /* KVZ_HIP_CTU_COEFFS per LCU, raster LCU order */
+} picture_result;
+
+#define N_SLOTS 16
+static picture_result g_slots[N_SLOTS];
+static int g_next_slot;
+static kvz_hip_batch *g_batch;
+static int g_batch_w, g_batch_h;
+static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+
+/* 1 when the picture can be searched by the batched pass: every option below changes the search in a way the pass does not model */
+static int eligible(const encoder_state_t *state)
+{
+  static int enabled = -1;
+  if (enabled < 0) { const char *e = getenv("KVZ_HIP_BATCH_SEARCH"); enabled = e ? atoi(e) : 0; }
+  if (!enabled) return 0;
+  const encoder_control_t *ctrl = state->encoder_control;
+  const kvz_config *cfg = &ctrl->cfg;
+#define REQUIRE(cond) do { if (!(cond)) { if (enabled > 1) fprintf(stderr, "search_lcu_hip: not eligible: %s\n", #cond); return 0; } } while (0)
+  REQUIRE(state->frame->slicetype == KVZ_SLICE_I);
+  REQUIRE(ctrl->bitdepth == 8 && ctrl->chroma_format == KVZ_CSP_420);
+  REQUIRE(cfg->rdo == 0 && !cfg->rdoq_enable && !cfg->signhide_enable && !cfg->trskip_enable && cfg->tr_depth_intra == 0);
+  REQUIRE(!cfg->lossless && !cfg->implicit_rdpcm && cfg->scaling_list == KVZ_SCALING_LIST_OFF);
+  REQUIRE(!cfg->full_intra_search);
+  REQUIRE(cfg->pu_depth_intra.min[0] == 2 && cfg->pu_depth_intra.max[0] == 3);  /* all-intra: GOP layer 0 only */
+  REQUIRE(cfg->cu_split_termination == KVZ_CU_SPLIT_TERMINATION_ZERO && cfg->combine_intra_cus && cfg->wpp);
+  REQUIRE(cfg->target_bitrate <= 0 && !cfg->vaq && !cfg->roi.file_path && !cfg->set_qp_in_cu && state->frame->max_qp_delta_depth < 0);
+  REQUIRE(!cfg->ml_pu_depth_intra && !cfg->intra_bit_allocation);
+#undef REQUIRE
+  return 1;
+}
+
+/* the picture's results, computed on first request */
+static const picture_result *picture_of(const encoder_state_t *state)
+{
+  const videoframe_t *frame = state->tile->frame;
+  pthread_mutex_lock(&g_lock);
+  for (int i = 0; i < N_SLOTS; i++)
+    if (g_slots[i].frame == frame && g_slots[i].num == state->frame->num) { pthread_mutex_unlock(&g_lock); return &g_slots[i]; }
+  picture_result *r = &g_slots[g_next_slot];
+  g_next_slot = (g_next_slot + 1) % N_SLOTS;
+  const int w = frame->width, h = frame->height, wc = (w + 63) / 64, hc = (h + 63) / 64;
+  const size_t ys = (size_t)w * h, cs = ys / 4;
+  if (r->width != w || r->height != h) {
+    free(r->rec); free(r->depth); free(r->mode); free(r->coeff);
+    r->rec = malloc(ys + 2 * cs);
+    r->depth = malloc((size_t)(w / 8) * (h / 8));
+    r->mode = malloc((size_t)(w / 8) * (h / 8));
+    r->coeff = malloc((size_t)wc * hc * KVZ_HIP_CTU_COEFFS * sizeof(int16_t));
+    r->width = w; r->height = h;
+  }
+  if (!g_batch || g_batch_w != w || g_batch_h != h) {
+    if (g_batch) kvz_hip_batch_destroy(g_batch);
+    g_batch = kvz_hip_batch_create(w, h, 1);
+    g_batch_w = w; g_batch_h = h;
+    if (!g_batch) { fprintf(stderr, "search_lcu_hip: cannot create a %dx%d batch\n", w, h); abort(); }
+  }
+  /* kvz_picture planes carry a stride; the batch takes tight planes */
+  uint8_t *src = malloc(ys + 2 * cs);
+  const kvz_picture *pic = frame->source;
+  for (int row = 0; row < h; row++) memcpy(src + (size_t)row * w, pic->y + (size_t)row * pic->stride, w);
+  for (int row = 0; row < h / 2; row++) {
+    memcpy(src + ys + (size_t)row * (w / 2), pic->u + (size_t)row * (pic->stride / 2), w / 2);
+    memcpy(src + ys + cs + (size_t)row * (w / 2), pic->v + (size_t)row * (pic->stride / 2), w / 2);
+  }
+  kvz_hip_intra_cost_model model;
+  kvz_hip_intra_cost_model_init(state->qp, kvz_fast_coeff_get_weights(state), &model);
+  const kvz_config *cfg = &state->encoder_control->cfg;
+  model.coeff_cabac = !(state->qp < cfg->fast_residual_cost_limit && state->qp < MAX_FAST_COEFF_COST_QP);  /* rdo.c:311-340 */
+  kvz_hip_batch_upload(g_batch, 0, src, src + ys, src + ys + cs);
+  kvz_hip_intra_frames(g_batch, &model);
+  kvz_hip_batch_sync(g_batch);
+  kvz_hip_batch_download(g_batch, 0, r->rec, r->rec + ys, r->rec + ys + cs, r->coeff, r->depth, r->mode, NULL);
+  free(src);
+  r->frame = frame; r->num = state->frame->num; r->qp = state->qp;
+  {  /* KVZ_HIP_BATCH_TRACE=<file>: number of pictures searched on the device so far (tests check the path was taken) */
+    static int pictures;
+    const char *trace = getenv("KVZ_HIP_BATCH_TRACE");
+    pictures++;
+    if (trace) { FILE *f = fopen(trace, "w"); if (f) { fprintf(f, "%d\n", pictures); fclose(f); } }
+  }
+  pthread_mutex_unlock(&g_lock);
+  return r;
+}
+
+static int any_level(const int16_t *c, int n)
+{
+  for (int i = 0; i < n; i++) if (c[i]) return 1;
+  return 0;
+}
+static unsigned zorder16(int x, int y) /* cu.h:385-421 xy_to_zorder for 4-sample units, in coefficients */
+{
+  unsigned r = 0;
+  for (int b = 0; b < 4; b++) r |= (((unsigned)(x >> (2 + b)) & 1u) << (2 * b)) | (((unsigned)(y >> (2 + b)) & 1u) << (2 * b + 1));
+  return r * 16;
+}
+
+void __wrap_kvz_search_lcu(encoder_state_t *const state, const int x, const int y, const yuv_t *const hor_buf, const yuv_t *const ver_buf)
+{
+  if (!eligible(state)) { __real_kvz_search_lcu(state, x, y, hor_buf, ver_buf); return; }
+  const picture_result *r = picture_of(state);
+  videoframe_t *frame = state->tile->frame;
+  const int w = r->width, h = r->height, w8 = w / 8, wc = (w + 63) / 64;
+  const size_t ys = (size_t)w * h, cs = ys / 4;
+  const int16_t *coeff = r->coeff + (size_t)((y / 64) * wc + x / 64) * KVZ_HIP_CTU_COEFFS;
+  const int16_t *plane[3] = { coeff, coeff + 4096, coeff + 5120 };
+
+  /* CU info (kvz_cu_array_copy_from_lcu): one cu_info_t per 4x4, every unit of a CU alike; coded block flags per transform unit
+   * as kvz_intra_recon_cu leaves them (intra.c:623-696): the unit's bit at its depth, and for a 64x64 CU the depth-0 bit on its
+   * first unit when any of the four has the plane coded */
+  for (int yy = 0; yy < 64 && y + yy < h; yy += 8)
+    for (int xx = 0; xx < 64 && x + xx < w; xx += 8) {
+      const int depth = r->depth[((y + yy) / 8) * w8 + (x + xx) / 8], mode = r->mode[((y + yy) / 8) * w8 + (x + xx) / 8];
+      const int td = depth < 1 ? 1 : depth, tw = 64 >> td, tx = xx & ~(tw - 1), ty = yy & ~(tw - 1), cw = td == 3 ? 4 : tw / 2;
+      uint16_t cbf = 0;
+      for (int c = 0; c < 3; c++) {
+        const int n = c ? cw * cw : tw * tw;
+        const int16_t *lv = plane[c] + (c ? zorder16(tx / 2, ty / 2) : zorder16(tx, ty));
+        if (any_level(lv, n)) cbf_set(&cbf, td, (color_t)c);
+      }
+      if (depth == 0 && tx == 0 && ty == 0)
+        for (int c = 0; c < 3; c++) {
+          int any = 0;
+          for (int q = 0; q < 4; q++) any |= any_level(plane[c] + (c ? q * 256 : q * 1024), c ? 256 : 1024);
+          if (any) cbf_set(&cbf, 0, (color_t)c);
+        }
+      for (int sy = 0; sy < 8; sy += 4)
+        for (int sx = 0; sx < 8; sx += 4) {
+          cu_info_t *cu = kvz_cu_array_at(frame->cu_array, x + xx + sx, y + yy + sy);
+          memset(cu, 0, sizeof *cu);
+          cu->type = CU_INTRA; cu->depth = depth; cu->part_size = SIZE_2Nx2N; cu->tr_depth = depth > 0 ? depth : 1;
+          cu->cbf = cbf; cu->qp = (uint8_t)state->qp;
+          cu->intra.mode = (int8_t)mode; cu->intra.mode_chroma = (int8_t)mode;
+        }
+    }
+  /* reconstruction before deblocking (copy_lcu_to_cu_data) */
+  for (int row = 0; row < 64 && y + row < h; row++) {
+    const int n = x + 64 <= w ? 64 : w - x;
+    memcpy(&frame->rec->y[x + (size_t)(y + row) * frame->rec->stride], r->rec + (size_t)(y + row) * w + x, n);
+  }
+  for (int row = 0; row < 32 && y / 2 + row < h / 2; row++) {
+    const int n = x / 2 + 32 <= w / 2 ? 32 : w / 2 - x / 2;
+    memcpy(&frame->rec->u[x / 2 + (size_t)(y / 2 + row) * (frame->rec->stride / 2)], r->rec + ys + (size_t)(y / 2 + row) * (w / 2) + x / 2, n);
+    memcpy(&frame->rec->v[x / 2 + (size_t)(y / 2 + row) * (frame->rec->stride / 2)], r->rec + ys + cs + (size_t)(y / 2 + row) * (w / 2) + x / 2, n);
+  }
+  /* coefficients (copy_coeffs): lcu_t z-order, the layout the batch returns */
+  memcpy(state->coeff->y, plane[0], 4096 * sizeof(int16_t));
+  memcpy(state->coeff->u, plane[1], 1024 * sizeof(int16_t));
+  memcpy(state->coeff->v, plane[2], 1024 * sizeof(int16_t));
+}

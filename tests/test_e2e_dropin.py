@@ -54,3 +54,36 @@ def test_golden_md5_416x240(tmp_path):
     assert synth.write_yuv(yuv, 416, 240, 8, 1234, "small") == synth.MD5["416x240"]
     md5_hip, t, err = _encode("kvazaar_hip", yuv, str(tmp_path / "hip.hevc"), ["--preset", "ultrafast", "-p", "1", "--threads", "8"])
     assert md5_hip == GOLDEN_416x240_8F
+
+
+@pytest.mark.parametrize("frames,extra", [(3, ["-q", "22"]), (2, ["-q", "32"]), (2, ["-q", "27", "--no-deblock"]), (1, ["-q", "22", "--tiles", "2x2", "--wpp"])],
+                         ids=["qp22", "qp32-cabac-coeff-cost", "qp27-nodeblock", "tiles-wpp"])
+def test_batched_search_bitstream_identical(tmp_path, frames, extra):
+    """The BATCHED pass inside the real encoder: integration/kvazaar/search_lcu_hip.c stands in front of kvz_search_lcu and
+    fills cu_array / reconstruction / coefficients of every LCU from one kvz_hip_intra_frames() run per picture; deblocking and
+    the entropy coder are the reference's own.  The bitstream must be the reference encoder's, byte for byte -- i.e. every CU
+    depth, mode, coded block flag and coefficient the device decided is kvazaar's.  (The per-call strategies are switched off
+    here: this is about the batched path.)  Tiles: each tile is a picture of its own for the pass; kvazaar switches WPP off
+    when tiles are requested (cfg.c:925-978) and the pass models the WPP context hand-off, so the tile case asks for both."""
+    if not os.path.exists(os.path.join(REF, "kvazaar_hip")):
+        pytest.skip("oracle/_ref/kvazaar_hip not built")
+    yuv = str(tmp_path / "syn.yuv")
+    synth.write_yuv(yuv, 416, 240, frames, 1234, "small")
+    common = ["--preset", "ultrafast", "-p", "1", "--threads", "4"] + extra
+    md5_ref, _, _ = _encode("kvazaar_ref", yuv, str(tmp_path / "ref.hevc"), common)
+    md5_plain, _, _ = _encode("kvazaar_hip", yuv, str(tmp_path / "plain.hevc"), common, {"KVZ_HIP_DISABLE": "1"})
+    md5_batch, t, _ = _encode("kvazaar_hip", yuv, str(tmp_path / "batch.hevc"), common, {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1", "KVZ_HIP_BATCH_TRACE": str(tmp_path / "trace")})
+    assert md5_plain == md5_ref
+    assert md5_batch == md5_ref
+    assert int(open(str(tmp_path / "trace")).read()) >= frames, "the batched search was not used"
+
+
+def test_batched_search_golden_md5_416x240(tmp_path):
+    """the survey's recorded md5 for BASELINE config 1 (8 frames) reproduced with the device searching whole pictures"""
+    if not os.path.exists(os.path.join(REF, "kvazaar_hip")):
+        pytest.skip("oracle/_ref/kvazaar_hip not built")
+    yuv = str(tmp_path / "syn.yuv")
+    assert synth.write_yuv(yuv, 416, 240, 8, 1234, "small") == synth.MD5["416x240"]
+    md5, _, _ = _encode("kvazaar_hip", yuv, str(tmp_path / "b.hevc"), ["--preset", "ultrafast", "-p", "1", "--threads", "8"],
+                        {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1"})
+    assert md5 == GOLDEN_416x240_8F
