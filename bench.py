@@ -47,7 +47,7 @@ def pmc_traffic(args, launches):
         except (OSError, ValueError):
             continue
         w = d.get("workload", {})
-        if (w.get("width"), w.get("height"), w.get("frames")) == (args.width, args.height, args.frames) and \
+        if (w.get("width"), w.get("height"), w.get("frames"), w.get("qp", 22)) == (args.width, args.height, args.frames, args.qp) and \
                 (w.get("schedule") == "ticket") == (launches == 1):
             best = d
     return None if best is None else best["bytes_per_launch"]
@@ -79,7 +79,7 @@ def cpu_baseline(args, frames, model):
             tmp.flush()
             threads = os.cpu_count() or 1
             cmd = [ref_bin, "-i", tmp.name, "--input-res", f"{args.width}x{args.height}", "--preset", "ultrafast", "-p", "1",
-                   "--threads", str(threads), "-o", "/dev/null"]
+                   "-q", str(args.qp), "--threads", str(threads), "-o", "/dev/null"]
             times = []
             for _ in range(3):
                 t = time.time()
@@ -91,7 +91,7 @@ def cpu_baseline(args, frames, model):
                 # the reference's own CPU path is the headline baseline; the single-core port of exactly this pass rides along
                 port = dict(out)
                 out = {"value": nf * ((args.width + 63) // 64) * ((args.height + 63) // 64) / best, "unit": "CTUs/s", "cores": threads, "kind": "reference",
-                       "sample": f"oracle/_ref/kvazaar_ref (kvazaar's AVX2 strategies, whole encoder incl. CABAC + deblocking) --preset ultrafast -p 1 --threads {threads}, "
+                       "sample": f"oracle/_ref/kvazaar_ref (kvazaar's AVX2 strategies, whole encoder incl. CABAC + deblocking) --preset ultrafast -p 1 -q {args.qp} --threads {threads}, "
                                  f"{nf} frames of the benchmark's clip, median of 3, wall incl. file read",
                        "port": port}
     return out
