@@ -56,7 +56,7 @@ def test_hip_ctu_equals_oracle(oracle, hiplib, size):
 def test_hip_ctu_adversarial_and_qps(oracle, hiplib):
     w, h = 192, 136
     frames = list(cc.adversarial_frames(w, h).values())
-    for qp in (10, 22, 37):
+    for qp in (10, 22, 28, 37, 51):  # fast coefficient cost below 28, the residual coder in counting mode from 28 on
         model = _model(hiplib, oracle, qp)
         got = _run_batch(hiplib, model, w, h, frames)
         for i, f in enumerate(frames):

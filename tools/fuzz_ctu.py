@@ -44,7 +44,7 @@ def main():
     for i in range(cases):
         w, h = int(rng.integers(1, 26)) * 8, int(rng.integers(1, 20)) * 8
         qp = int(rng.choice([0, 7, 12, 17, 22, 27, 32, 37, 42, 47, 51]))
-        model = cc.hip_cost_model(lib, qp)
+        model = cc.hip_cost_model(lib, qp, cc.coeff_weights(qp))
         frames = [picture(rng, w, h, int(rng.integers(0, 6))) for _ in range(int(rng.integers(1, 4)))]
         b = cc.HipBatch(lib, w, h, len(frames))
         for k, f in enumerate(frames):
