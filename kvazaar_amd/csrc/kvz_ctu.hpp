@@ -765,12 +765,13 @@ template <bool CABAC> struct CtuProgramT {
     const int avail_top = tb->avail_top[(y & 63) >> 2][(x & 63) >> 2], avail_left = tb->avail_left[(y & 63) >> 2][(x & 63) >> 2];
     KVZ_FOR_THREADS(tid) {
       if (tid == 0) first();
-      for (int c = luma ? 0 : 1; c <= (chroma ? 2 : 0); c++) {
-        const int l2 = c ? log2w_c : log2w_y, n = 2 * (1 << l2) + 1;
-        for (int i = tid; i < 2 * n; i += KVZ_CTU_THREADS) {
-          const int side = i >= n, k = side ? i - n : i;
-          s->ref[c][side][k] = ref_sample(lv, l2, c, x, y, side, k, avail_top, avail_left);
-        }
+      // one index space over the samples of all listed planes (luma, then U, then V; top then left inside a plane): the loop body
+      // -- long and branchy -- then runs once or twice per CU instead of once per plane
+      const int ny = luma ? 2 * (2 * (1 << log2w_y) + 1) : 0, nc = chroma ? 2 * (2 * (1 << log2w_c) + 1) : 0;
+      for (int g = tid; g < ny + 2 * nc; g += KVZ_CTU_THREADS) {
+        const int c = g < ny ? 0 : (g < ny + nc ? 1 : 2), i = g - (c == 0 ? 0 : (c == 1 ? ny : ny + nc));
+        const int l2 = c ? log2w_c : log2w_y, n = 2 * (1 << l2) + 1, side = i >= n, k = side ? i - n : i;
+        s->ref[c][side][k] = ref_sample(lv, l2, c, x, y, side, k, avail_top, avail_left);
       }
     }
     KVZ_SYNC();
@@ -1106,11 +1107,126 @@ template <bool CABAC> struct CtuProgramT {
 
   // intra_recon_tb_leaf (intra.c:561-608) + kvz_quantize_residual (quant-generic.c:198-292) for the planes of `t`,
   // written into work-tree level lv.  Sets the cbf bits of the CU's info entry.  One barrier per stage.
+  // Per-plane sums of the fused 8x8-CU stages: lanes 0..63 carry luma, 64..79 U, 80..95 V (the rest contribute 0).  Device: DPP
+  // row reduction, then the luma wavefront adds its four row sums to acc3[0], the other one rows 0 / 1 to acc3[1] / acc3[2].
+  KVZ_DEV void plane_add(u32 *acc3, u32 v, int tid) const
+  {
+#ifdef KVZ_HOSTSIM
+    if (tid < 96) acc3[tid < 64 ? 0 : (tid < 80 ? 1 : 2)] += v;
+#else
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+    const u32 r0 = (u32)__builtin_amdgcn_readlane(x, 15), r1 = (u32)__builtin_amdgcn_readlane(x, 31), r2 = (u32)__builtin_amdgcn_readlane(x, 47), r3 = (u32)__builtin_amdgcn_readlane(x, 63);
+    if ((tid & 63) == 0) {  // one writer per slot and stage: the slots were zeroed in stage 1
+      if (tid < 64) acc3[0] += r0 + r1 + r2 + r3;
+      else { acc3[1] += r0; acc3[2] += r1; }
+    }
+#endif
+  }
+  // The 8x8 CU -- an 8x8 luma and two 4x4 chroma units, 96 samples -- with every stage of recon_tus() in ONE pass, one lane per
+  // sample of any plane: three quarters of the CUs the search evaluates are these, and a loop per plane runs each stage's code
+  // three times for a handful of lanes.  Wavefront-uniform by construction: the wavefront playing threads 0..63 is all luma
+  // (8-point), the other one all chroma (4-point).  Same arithmetic, same order of the integer operations per sample.
+  KVZ_DEV void recon_cu8(int lv, const TuSet &t, int depth, int mode)
+  {
+    const int xl = t.x - cx, yl = t.y - cy;
+    const CandView cv = cand_view(lv);
+#define KVZ_CU8_ROLE(tid)                                                                                               \
+    const bool on = (tid) < 96;                                                                                         \
+    const int c = (tid) < 64 ? 0 : ((tid) < 80 ? 1 : 2), e = (tid) - (c == 0 ? 0 : (c == 1 ? 64 : 80)), l2 = c ? 2 : 3, n = 1 << l2, sh = c ? 1 : 0; \
+    (void)sh; (void)n
+    KVZ_FOR_THREADS(tid) {
+      if (tid < 16) s->acc[tid] = 0;
+      KVZ_CU8_ROLE(tid);
+      if (on) {
+        const int px = e & (n - 1), py = e >> l2;
+        const u8 p = predict_pixel(l2, mode, c, px, py);
+        cv.at(c, (xl >> sh) + px, (yl >> sh) + py) = p;
+        tbuf(t, 0, c)[e] = (i16)((int)*org_at(c, (xl >> sh) + px, (yl >> sh) + py) - (int)p);
+      }
+    }
+    KVZ_SYNC();
+    KVZ_PROF(KVZ_P_RPRED);
+    for (int pass = 0; pass < 2; pass++) {  // forward transform (dct-generic.c:559-568)
+      KVZ_FOR_THREADS(tid) {
+        KVZ_CU8_ROLE(tid);
+        if (on) {
+          const int shift = pass == 0 ? l2 - 1 : l2 + 6, add = 1 << (shift - 1), k = e >> l2, j = e & (n - 1);
+          const i16 *src = tbuf(t, pass, c);
+          int a = 0;
+          for (int i = 0; i < n; i++) a += dct_at(l2, k, i) * (int)src[(j << l2) + i];
+          tbuf(t, pass ^ 1, c)[e] = (i16)((a + add) >> shift);
+        }
+      }
+      KVZ_SYNC();
+    }
+    KVZ_PROF(KVZ_P_FDCT);
+    KVZ_FOR_THREADS(tid) {  // quantise (quant-generic.c:57-81) -> coefficient store + cost sums; dequantise (:335-339)
+      KVZ_CU8_ROLE(tid);
+      u32 wsum = 0, nz = 0;
+      if (on) {
+        const QuantScalars q = s->qs[l2 - 2][c ? 1 : 0];
+        const int cf = tbuf(t, 0, c)[e];
+        int level = (int)(((u32)iabs(cf) * (u32)q.flat_q + (u32)q.add) >> q.q_bits);
+        if (cf < 0) level = -level;
+        level = iclip(-32768, 32767, level);
+        (coeff_level(lv) + kPlaneOff[c] + zorder(xl >> sh, yl >> sh))[e] = (i16)level;
+        if (cabac_on()) levels_lds(lv, c)[e] = (i16)level;
+        int a = iabs(level);
+        nz = a != 0;
+        if (a > 3) a = 3;
+        wsum = (u32)((m->coeff_weights >> (16 * a)) & 0xffff);
+        tbuf(t, 1, c)[e] = (i16)iclip(-32768, 32767, (level * q.dq_scale + (1 << (q.dq_shift - 1))) >> q.dq_shift);
+      }
+      plane_add(&s->acc[3], wsum, tid);
+      plane_add(&s->acc[6], nz, tid);
+    }
+    KVZ_SYNC();
+    KVZ_PROF(KVZ_P_QUANT);
+    for (int pass = 0; pass < 2; pass++) {  // inverse transform (dct-generic.c:570-579), only observable when the plane has coefficients
+      KVZ_FOR_THREADS(tid) {
+        KVZ_CU8_ROLE(tid);
+        if (on && s->acc[6 + c]) {
+          const int shift = pass == 0 ? 7 : 12, add = 1 << (shift - 1), j = e >> l2, i = e & (n - 1);
+          const i16 *src = tbuf(t, pass ^ 1, c);
+          int a = 0;
+          for (int k = 0; k < n; k++) a += dct_at(l2, k, i) * (int)src[(k << l2) + j];
+          tbuf(t, pass, c)[e] = (i16)iclip(-32768, 32767, (a + add) >> shift);
+        }
+      }
+      KVZ_SYNC();
+    }
+    KVZ_PROF(KVZ_P_IDCT);
+    KVZ_FOR_THREADS(tid) {  // reconstruction (quant-generic.c:266-277) + SSD against the source (search.c:500-505, 512-523)
+      KVZ_CU8_ROLE(tid);
+      u32 ssd = 0;
+      if (on) {
+        u8 *rp = &cv.at(c, (xl >> sh) + (e & (n - 1)), (yl >> sh) + (e >> l2));
+        int v = *rp;
+        if (s->acc[6 + c]) { v = iclip(0, 255, (int)(i16)(tbuf(t, 1, c)[e] + v)); *rp = (u8)v; }
+        const int d = (int)*org_at(c, (xl >> sh) + (e & (n - 1)), (yl >> sh) + (e >> l2)) - v;
+        ssd = (u32)(d * d);
+      }
+      plane_add(&s->acc[0], ssd, tid);
+      if (tid == 0) {  // cbf bits of the TU's top-left CU entry (transform.c:314, 409-411)
+        CtuCu *cu = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
+        for (int cc = 0; cc < 3; cc++) { cbf_clear(&cu->cbf, depth, cc); if (s->acc[6 + cc]) cbf_set(&cu->cbf, depth, cc); }
+      }
+    }
+    KVZ_SYNC();
+    KVZ_PROF(KVZ_P_RECON);
+#undef KVZ_CU8_ROLE
+  }
+
   KVZ_DEV void recon_tus(int lv, const TuSet &t, int depth, int mode, bool refs_ready = false)
   {
     const int xl = t.x - cx, yl = t.y - cy;
     const CandView cv = cand_view(lv);
     if (!refs_ready) build_refs(lv, t.x, t.y, t.lw, t.lc, t.lw != 0, t.lc != 0);
+    if (KVZ_CTU_THREADS == 128 && t.lw == 3 && t.lc == 2) { recon_cu8(lv, t, depth, mode); return; }
     // stage 1: prediction -> rec (as kvazaar blits it before quantising) and residual
     KVZ_FOR_THREADS(tid) {
       if (tid < 16) s->acc[tid] = 0;
