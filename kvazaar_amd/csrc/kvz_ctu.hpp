@@ -340,20 +340,24 @@ template <bool CABAC> struct CtuProgramT {
     out->type = 1; out->depth = s->nb_depth[side][i]; out->mode = s->nb_mode[side][i]; out->tr_depth = out->depth; out->cbf = 0;
     return true;
   }
+  // Reconstructed sample (px, py) of plane c (plane coordinates of the frame) as work-tree level lv sees it.  The four places it can
+  // live in -- decided picture, the 8x8 siblings' candidates, the left / top border of the neighbour CTUs -- are all in CtuShared,
+  // so the choice is made on the byte offset and ONE load follows: lanes of a reference row disagree about the place all the time,
+  // and as branches every lane would walk through every alternative.
   KVZ_DEV u8 rec_px(int lv, int c, int px, int py) const
   {
-    const int sh = c ? 1 : 0, w = 64 >> sh, ox = cx >> sh, oy = cy >> sh;
-    if (px >= ox && px < ox + w && py >= oy && py < oy + w) {
-      const int pxl = px - ox, pyl = py - oy;
-      if (lv == 0) return s->dec[kPlaneOff[c] + pyl * w + pxl];  // the 64x64 merge predicts its 32x32 units from each other
-      if (lv == 3) {  // an 8x8 CU sees its already-tried siblings inside the current 16x16, decided pixels elsewhere
-        const int rx = a2x >> sh, ry = a2y >> sh, rw = 16 >> sh;
-        if (pxl >= rx && pxl < rx + rw && pyl >= ry && pyl < ry + rw) return s->c3[(c == 0 ? 0 : (c == 1 ? 256 : 320)) + (pyl - ry) * rw + pxl - rx];
-      }
-      return s->dec[kPlaneOff[c] + pyl * w + pxl];  // depths 1 and 2 never look inside their own CU
-    }
-    // neighbour CTUs: left column (px == ox-1) or top row (py == oy-1), staged in LDS by init()
-    return px < ox ? s->bpx_left[c][py - oy + 1] : s->bpx_top[c][px - ox + 1];
+    const int sh = c ? 1 : 0, w = 64 >> sh, pxl = px - (cx >> sh), pyl = py - (cy >> sh);
+    const u8 *base = (const u8 *)s;
+    const int o_dec = (int)(s->dec - base) + kPlaneOff[c] + pyl * w + pxl;  // depths 0..2 never look inside their own CU; the 64x64 merge predicts its units from each other
+    // an 8x8 CU sees its already-tried siblings inside the current 16x16, decided pixels elsewhere
+    const int rx = a2x >> sh, ry = a2y >> sh, rw = 16 >> sh;
+    const bool in3 = lv == 3 && (unsigned)(pxl - rx) < (unsigned)rw && (unsigned)(pyl - ry) < (unsigned)rw;
+    const int o_c3 = (int)(s->c3 - base) + (c == 0 ? 0 : (c == 1 ? 256 : 320)) + (pyl - ry) * rw + pxl - rx;
+    // neighbour CTUs: left column (pxl == -1) or top row (pyl == -1), staged in LDS by init()
+    const int o_left = (int)(&s->bpx_left[0][0] - base) + c * 66 + pyl + 1, o_top = (int)(&s->bpx_top[0][0] - base) + c * 98 + pxl + 1;
+    const bool inside = (unsigned)pxl < (unsigned)w && (unsigned)pyl < (unsigned)w;
+    const int off = inside ? (in3 ? o_c3 : o_dec) : (pxl < 0 ? o_left : o_top);
+    return base[off];
   }
 
   // intra.c:84-126 kvz_intra_get_dir_luma_predictor
@@ -734,25 +738,22 @@ template <bool CABAC> struct CtuProgramT {
   KVZ_DEV u8 ref_sample(int lv, int log2w, int c, int lx, int ly, int side, int i, int avail_top, int avail_left) const
   {
     const int sh = c ? 1 : 0, w = 1 << log2w, px = lx >> sh, py = ly >> sh;
-    if (i == 0) {
-      if (lx > 0 && ly > 0) return rec_px(lv, c, px - 1, py - 1);
-      i = 1; side = 1;  // corner = left[1]
-    }
+    // where the sample comes from, as coordinates: one rec_px() for every lane whatever its side
+    const bool corner = i == 0 && lx > 0 && ly > 0;
+    if (i == 0 && !corner) { i = 1; side = 1; }  // corner = left[1]
     const int k = i - 1;
-    if (side == 1) {
-      if (lx > 0) {
-        int avail = avail_left >> sh;
-        avail = imin(avail, imin(2 * w, (F.H - ly) >> sh));
-        return rec_px(lv, c, px - 1, py + imin(k, avail - 1));
-      }
-      return ly > 0 ? rec_px(lv, c, px, py - 1) : 128;
+    const int al = imin(avail_left >> sh, imin(2 * w, (F.H - ly) >> sh)), at = imin(avail_top >> sh, imin(2 * w, (F.W - lx) >> sh));
+    int qx, qy;
+    if (side == 1) {  // left: the column to the left if there is one, else the sample above, else mid-grey
+      qx = lx > 0 ? px - 1 : px;
+      qy = lx > 0 ? py + imin(k, al - 1) : py - 1;
+    } else {          // top: the row above if there is one, else the sample to the left
+      qx = ly > 0 ? px + imin(k, at - 1) : px - 1;
+      qy = ly > 0 ? py - 1 : py;
     }
-    if (ly > 0) {
-      int avail = avail_top >> sh;
-      avail = imin(avail, imin(2 * w, (F.W - lx) >> sh));
-      return rec_px(lv, c, px + imin(k, avail - 1), py - 1);
-    }
-    return lx > 0 ? rec_px(lv, c, px - 1, py) : 128;
+    if (corner) { qx = px - 1; qy = py - 1; }
+    if (lx <= 0 && ly <= 0) return 128;
+    return rec_px(lv, c, qx, qy);
   }
 
   // Builds the unfiltered references of the listed planes; second phase: the [1 2 1]-filtered luma references
