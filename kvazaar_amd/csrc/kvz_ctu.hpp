@@ -602,11 +602,37 @@ template <bool CABAC> struct CtuProgramT {
   // even the significance flags are priced by their lanes and summed with DPP.  Prices are accumulated in Q15 integers -- every
   // table entry is a multiple of 2^-15 -- so the sum is exact and order-free, and equals the double sum of the one-lane version.
   KVZ_DEV static int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-  KVZ_DEV unsigned bin_q15(CtxSet *c, bool update, int idx, int bin) const
+  // The state machine of the residual contexts in REGISTERS for the duration of one block: lane L holds contexts L, L + 64 and
+  // L + 128 (one byte each) of the 136, entry L of the LPS transition table and entries L / L + 64 of the price table (as Q15
+  // integers).  A bin is then v_readlane with scalar lane selects, one predicated move and a few scalar ALU operations -- no LDS round
+  // trip on the chain from one bin's state to the next.
+  struct WaveCtx { int st, lps; unsigned ent_lo, ent_hi; };
+  KVZ_DEV WaveCtx wave_ctx_load(const CtxSet *c, int lane) const
   {
-    const int st = uni(c->s[idx]);
-    const unsigned q = (unsigned)(s->entropy_fbits[st ^ bin] * 32768.0f);
-    if (update) c->s[idx] = (u8)ctx_next(st, bin);  // every lane stores the same byte
+    WaveCtx w;
+    const u8 *r = c->s + KVZ_HIP_CX_SIG_CG;
+    w.st = (int)r[lane] | ((int)r[lane + 64] << 8) | (lane < 8 ? (int)r[lane + 128] << 16 : 0);
+    w.lps = s->ctx_lps[lane];
+    w.ent_lo = (unsigned)(s->entropy_fbits[lane] * 32768.0f);
+    w.ent_hi = (unsigned)(s->entropy_fbits[lane + 64] * 32768.0f);
+    return w;
+  }
+  KVZ_DEV void wave_ctx_store(CtxSet *c, const WaveCtx &w, int lane) const
+  {
+    u8 *r = c->s + KVZ_HIP_CX_SIG_CG;
+    r[lane] = (u8)w.st; r[lane + 64] = (u8)(w.st >> 8);
+    if (lane < 8) r[lane + 128] = (u8)(w.st >> 16);
+  }
+  KVZ_DEV static unsigned bin_q15(WaveCtx &w, bool update, int idx, int bin)
+  {
+    const int lane = threadIdx.x & 63;
+    const int r = uni(idx) - KVZ_HIP_CX_SIG_CG, ln = r & 63, sh = (r >> 6) * 8;
+    const int packed = __builtin_amdgcn_readlane(w.st, ln), st = (packed >> sh) & 0xff, e = st ^ bin;
+    const unsigned q = (unsigned)__builtin_amdgcn_readlane((int)((e & 64) ? w.ent_hi : w.ent_lo), e & 63);
+    if (update) {
+      const int nxt = bin == (st & 1) ? st + ((st < 124) << 1) : (__builtin_amdgcn_readlane(w.lps, st >> 1) ^ (st & 1));
+      if (lane == ln) w.st = (packed & ~(0xff << sh)) | (nxt << sh);
+    }
     return q;
   }
   KVZ_DEV double coeff_cabac_bits_wave(CtxSet *c, bool update, const i16 *coeff, int log2w, int type, int scan) const
@@ -623,6 +649,7 @@ template <bool CABAC> struct CtuProgramT {
     }
     const unsigned long long sig = __ballot(any);  // bit g: group g (raster) holds a level
     if (!sig) return 0;
+    WaveCtx wc = wave_ctx_load(c, lane);
     const unsigned long long ord = __ballot(lane < ngroups && ((sig >> group_of(log2w, scan, lane < ngroups ? lane : 0)) & 1));  // the same in group order
     const int last_group = 63 - __builtin_clzll(ord);
     unsigned long long q15 = 0;
@@ -633,7 +660,7 @@ template <bool CABAC> struct CtuProgramT {
       const bool right = gx < side - 1 && ((sig >> (g + 1)) & 1), lower = gy < side - 1 && ((sig >> (g + side)) & 1);
       bool coded = (sig >> g) & 1;
       if (i == last_group || i == 0) coded = true;
-      else q15 += bin_q15(c, update, KVZ_HIP_CX_SIG_CG + type + (right || lower), coded);
+      else q15 += bin_q15(wc, update, KVZ_HIP_CX_SIG_CG + type + (right || lower), coded);
       if (!coded) continue;
       const int k = lane & 15, r = scan_in_group(scan, k), px = gx * 4 + (r & 3), py = gy * 4 + (r >> 2);
       const int level = lane < 16 ? base[((r >> 2) << log2w) + (r & 3)] : 0;
@@ -650,10 +677,10 @@ template <bool CABAC> struct CtuProgramT {
         const unsigned long long gidx_lo = 0x7777666655443210ull;
         const int gxi = lx < 16 ? (int)((gidx_lo >> (4 * lx)) & 15) : (lx < 24 ? 8 : 9), gyi = ly < 16 ? (int)((gidx_lo >> (4 * ly)) & 15) : (ly < 24 ? 8 : 9);
         const int gmax = w - 1 < 16 ? (int)((gidx_lo >> (4 * (w - 1))) & 15) : 9;
-        for (int q = 0; q < gxi; q++) q15 += bin_q15(c, update, bx + (q >> shift), 1);
-        if (gxi < gmax) q15 += bin_q15(c, update, bx + (gxi >> shift), 0);
-        for (int q = 0; q < gyi; q++) q15 += bin_q15(c, update, by + (q >> shift), 1);
-        if (gyi < gmax) q15 += bin_q15(c, update, by + (gyi >> shift), 0);
+        for (int q = 0; q < gxi; q++) q15 += bin_q15(wc, update, bx + (q >> shift), 1);
+        if (gxi < gmax) q15 += bin_q15(wc, update, bx + (gxi >> shift), 0);
+        for (int q = 0; q < gyi; q++) q15 += bin_q15(wc, update, by + (q >> shift), 1);
+        if (gyi < gmax) q15 += bin_q15(wc, update, by + (gyi >> shift), 0);
         if (gxi > 3) q15 += (unsigned long long)((gxi - 2) / 2) << 15;
         if (gyi > 3) q15 += (unsigned long long)((gyi - 2) / 2) << 15;
         coded_mask = (1u << k_last) - 1;  // the positions below it; position 0 included (a level has been seen)
@@ -674,7 +701,7 @@ template <bool CABAC> struct CtuProgramT {
         for (unsigned mk = coded_mask; mk;) {
           const int kk = uni(31 - __builtin_clz(mk));
           mk &= ~(1u << kk);
-          q15 += bin_q15(c, true, __builtin_amdgcn_readlane(ctx, kk), (nzmask >> kk) & 1);
+          q15 += bin_q15(wc, true, __builtin_amdgcn_readlane(ctx, kk), (nzmask >> kk) & 1);
         }
       }
       const int num = __builtin_popcount(nzmask);
@@ -688,11 +715,11 @@ template <bool CABAC> struct CtuProgramT {
           const int kk = uni(31 - __builtin_clz(mk));
           mk &= ~(1u << kk);
           const int a = __builtin_amdgcn_readlane(absval, kk), symbol = a > 1;
-          q15 += bin_q15(c, update, base_one + c1, symbol);
+          q15 += bin_q15(wc, update, base_one + c1, symbol);
           if (symbol) { c1 = 0; if (first_c2_abs < 0) first_c2_abs = a; }
           else if (c1 < 3 && c1 > 0) c1++;
         }
-        if (c1 == 0 && first_c2_abs >= 0) q15 += bin_q15(c, update, (type == 0 ? KVZ_HIP_CX_ABS_LUMA : KVZ_HIP_CX_ABS_CHROMA) + ctx_set, first_c2_abs > 2);
+        if (c1 == 0 && first_c2_abs >= 0) q15 += bin_q15(wc, update, (type == 0 ? KVZ_HIP_CX_ABS_LUMA : KVZ_HIP_CX_ABS_CHROMA) + ctx_set, first_c2_abs > 2);
         int bypass = num;  // signs
         if (c1 == 0 || num > 8) {
           int first_coeff2 = 1, go_rice = 0, q = 0;
@@ -710,6 +737,7 @@ template <bool CABAC> struct CtuProgramT {
         q15 += (unsigned long long)bypass << 15;
       }
     }
+    if (update) wave_ctx_store(c, wc, lane);
     return (double)q15 / 32768.0;
   }
 #endif
