@@ -290,7 +290,8 @@ template <bool CABAC> struct CtuProgramT {
   struct CandView {
     u8 *buf;
     int bias[3], lw[3];
-    KVZ_DEV u8 &at(int c, int x, int y) const { return buf[bias[c] + (y << lw[c]) + x]; }
+    // selects, not array indexing: with a per-lane plane index the arrays would have to live in scratch memory
+    KVZ_DEV u8 &at(int c, int x, int y) const { return buf[(c == 0 ? bias[0] : (c == 1 ? bias[1] : bias[2])) + (y << (c == 0 ? lw[0] : lw[1])) + x]; }
   };
   KVZ_DEV CandView cand_view(int lv) const
   {
@@ -331,14 +332,22 @@ template <bool CABAC> struct CtuProgramT {
   KVZ_DEV static void cbf_clear(uint16_t *cbf, int depth, int plane) { *cbf &= ~((0x1f >> depth) << (5 * plane)); }
 
   // CU info at luma frame position (fx, fy) as seen from work-tree level lv; false = not available
-  KVZ_DEV bool neighbour_cu(int lv, int fx, int fy, CtuCu *out) const
+  // CU info at luma frame position (fx, fy) as seen from work-tree level lv, as a VALUE: -1 = not available, else
+  // type | depth << 1 | mode << 8 (KVZ_NB_*).  (Handing out a CtuCu through a pointer put the struct on the stack: every neighbour
+  // lookup of the thread-0 blocks went through scratch memory.)
+#define KVZ_NB_TYPE(v) ((v) & 1)
+#define KVZ_NB_DEPTH(v) (((v) >> 1) & 3)
+#define KVZ_NB_MODE(v) (((v) >> 8) & 0xff)
+  KVZ_DEV int neighbour_cu(int lv, int fx, int fy) const
   {
-    if (fx < 0 || fy < 0 || fx >= F.W || fy >= F.H) return false;
-    if (fx >= cx && fx < cx + 64 && fy >= cy && fy < cy + 64) { *out = s->cu[lv][((fy - cy) >> 3) * 8 + ((fx - cx) >> 3)]; return true; }
+    if (fx < 0 || fy < 0 || fx >= F.W || fy >= F.H) return -1;
+    if (fx >= cx && fx < cx + 64 && fy >= cy && fy < cy + 64) {
+      const CtuCu c = s->cu[lv][((fy - cy) >> 3) * 8 + ((fx - cx) >> 3)];
+      return (int)c.type | ((int)c.depth << 1) | ((int)c.mode << 8);
+    }
     // outside the CTU only the left column (fx == cx-1) and the top row (fy == cy-1) are ever asked for
     const int side = fx < cx ? 0 : 1, i = side == 0 ? (fy - cy) >> 3 : (fx - cx) >> 3;
-    out->type = 1; out->depth = s->nb_depth[side][i]; out->mode = s->nb_mode[side][i]; out->tr_depth = out->depth; out->cbf = 0;
-    return true;
+    return 1 | ((int)s->nb_depth[side][i] << 1) | ((int)s->nb_mode[side][i] << 8);
   }
   // Reconstructed sample (px, py) of plane c (plane coordinates of the frame) as work-tree level lv sees it.  The four places it can
   // live in -- decided picture, the 8x8 siblings' candidates, the left / top border of the neighbour CTUs -- are all in CtuShared,
@@ -361,11 +370,11 @@ template <bool CABAC> struct CtuProgramT {
   }
 
   // intra.c:84-126 kvz_intra_get_dir_luma_predictor
-  KVZ_DEV static void mpm_candidates(int y, const CtuCu *left, const CtuCu *above, int8_t preds[3])
+  KVZ_DEV static void mpm_candidates(int y, int left /* neighbour_cu() values */, int above, int8_t preds[3])
   {
     int l = 1, a = 1;
-    if (left && left->type == 1) l = left->mode;
-    if (above && above->type == 1 && (y & 63) != 0) a = above->mode;
+    if (left >= 0 && KVZ_NB_TYPE(left) == 1) l = KVZ_NB_MODE(left);
+    if (above >= 0 && KVZ_NB_TYPE(above) == 1 && (y & 63) != 0) a = KVZ_NB_MODE(above);
     if (l == a) {
       if (l > 1) { preds[0] = (int8_t)l; preds[1] = (int8_t)(((l + 29) % 32) + 2); preds[2] = (int8_t)(((l - 1) % 32) + 2); }
       else { preds[0] = 0; preds[1] = 1; preds[2] = 26; }
@@ -418,10 +427,9 @@ template <bool CABAC> struct CtuProgramT {
   }
   KVZ_DEV int split_model(int lv, int x, int y, int depth) const
   {
-    CtuCu n;
-    int model = 0;
-    if (x > 0 && neighbour_cu(lv, x - 1, y, &n) && n.depth > depth) model++;
-    if (y > 0 && neighbour_cu(lv, x, y - 1, &n) && n.depth > depth) model++;
+    int model = 0, n;
+    if (x > 0 && (n = neighbour_cu(lv, x - 1, y)) >= 0 && KVZ_NB_DEPTH(n) > depth) model++;
+    if (y > 0 && (n = neighbour_cu(lv, x, y - 1)) >= 0 && KVZ_NB_DEPTH(n) > depth) model++;
     return model;
   }
   // `known_preds`: the CU's most probable modes when the caller already has them (rough_search derives the same three from
@@ -435,9 +443,8 @@ template <bool CABAC> struct CtuProgramT {
     const bool no_left = mock && (x & 63) == 0;
     if (known_preds && !(no_left && x > 0)) { preds[0] = known_preds[0]; preds[1] = known_preds[1]; preds[2] = known_preds[2]; }
     else {
-      CtuCu lc, ac, *left = nullptr, *above = nullptr;
-      if (x > 0 && !no_left && neighbour_cu(lv, x - 1, y, &lc)) left = &lc;
-      if ((y & 63) > 0 && y > 0 && neighbour_cu(lv, x, y - 1, &ac)) above = &ac;
+      const int left = (x > 0 && !no_left) ? neighbour_cu(lv, x - 1, y) : -1;
+      const int above = ((y & 63) > 0 && y > 0) ? neighbour_cu(lv, x, y - 1) : -1;
       mpm_candidates(y, left, above, preds);
     }
     double bits = luma_mode_bits(c, mode, preds, update);
@@ -991,9 +998,7 @@ template <bool CABAC> struct CtuProgramT {
       }
       for (int v = tid; v < 2 * 4; v += KVZ_CTU_THREADS) s->satd_raw[v >> 2][v & 3] = 0;
       if (tid == KVZ_CTU_THREADS - 1) {
-        CtuCu lc, ac, *left = nullptr, *above = nullptr;
-        if (x >= 4 && neighbour_cu(lv, x - 1, y, &lc)) left = &lc;
-        if (y >= 4 && yl > 0 && neighbour_cu(lv, x, y - 1, &ac)) above = &ac;
+        const int left = x >= 4 ? neighbour_cu(lv, x - 1, y) : -1, above = (y >= 4 && yl > 0) ? neighbour_cu(lv, x, y - 1) : -1;
         mpm_candidates(y, left, above, s->preds);
       }
     }
@@ -1703,9 +1708,7 @@ template <bool CABAC> struct CtuProgramT {
       }
       if (d == 3) ctx_code(KVZ_CX_PART, 1);  // part_mode 2Nx2N at the minimum CU size
       {
-        CtuCu lc, ac, *left = nullptr, *above = nullptr;
-        if (x > 0 && neighbour_cu(0, x - 1, y, &lc)) left = &lc;
-        if ((y & 63) > 0 && neighbour_cu(0, x, y - 1, &ac)) above = &ac;
+        const int left = x > 0 ? neighbour_cu(0, x - 1, y) : -1, above = (y & 63) > 0 ? neighbour_cu(0, x, y - 1) : -1;
         int8_t preds[3];
         mpm_candidates(y, left, above, preds);
         ctx_code(KVZ_CX_INTRA, cu->mode == preds[0] || cu->mode == preds[1] || cu->mode == preds[2]);  // prev_intra_luma_pred_flag; mpm_idx / rem mode are bypass
