@@ -859,9 +859,10 @@ template <bool CABAC> struct CtuProgramT {
       if (sample_disp == 0) v = main_ref[px + 1];
       else {
         const int delta_pos = (py + 1) * sample_disp, di = delta_pos >> 5, df = delta_pos & 31, inv = s->mode_inv[mode];
-        const int r1 = angular_ref(main_ref, side_ref, px + di, inv);
-        if (!df) v = r1;
-        else v = ((32 - df) * r1 + df * angular_ref(main_ref, side_ref, px + di + 1, inv) + 16) >> 5;
+        // df == 0 leaves (32 r1 + 16) >> 5 = r1 (intra-generic.c:131-148 copies in that case), so no branch on the fraction; the
+        // extra sample read then lies inside the reference arrays
+        const int r1 = angular_ref(main_ref, side_ref, px + di, inv), r2 = angular_ref(main_ref, side_ref, px + di + 1, inv);
+        v = ((32 - df) * r1 + df * r2 + 16) >> 5;
       }
     }
     if (c == 0 && w < 32) {  // intra.c:207-219 intra_post_process_angular

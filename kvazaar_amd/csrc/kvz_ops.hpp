@@ -439,8 +439,9 @@ struct FindLastOp {
 // i >= -1 comes from the main reference, i <= -2 is projected from the side reference with the inverse angle.
 KVZ_DEV int angular_ref(const u8 *main_ref, const u8 *side_ref, int i, int inv)
 {
-  if (i >= -1) return main_ref[i + 1];
-  return side_ref[(128 + (-1 - i) * inv) >> 8];
+  // one load behind a pointer select: lanes of a row disagree about the side all the time
+  const u8 *p = i >= -1 ? main_ref + (i + 1) : side_ref + ((128 + (-1 - i) * inv) >> 8);
+  return *p;
 }
 
 // Value of angular mode `mode` at pixel (x, y) of a w x w block (intra-generic.c:49-155).
