@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-encoder", action="store_true")
+    ap.add_argument("--wpp", action="store_true", help="with --tiles: keep WPP on (kvazaar --tiles CxR --wpp); by default tiles imply --no-wpp as in kvazaar (cfg.c:925-978): "
+                                                       "one coder per tile in raster order, i.e. one serial CTU chain per tile")
+    ap.add_argument("--no-wpp", action="store_true", help="kvazaar --no-wpp: one serial CTU chain per picture (contexts run from the end of a row into the next)")
     ap.add_argument("--frozen-contexts", action="store_true", help="A/B only: freeze the CABAC contexts at slice start (not kvazaar's behaviour)")
     ap.add_argument("--tiles", default="", help="COLSxROWS: strong-scaling variant (BASELINE config 5): --frames pictures in total, cut into kvazaar's "
                                                 "uniform tiles, the tiles dealt to the ranks; every tile is an independent sub-picture (SURVEY.md 8e)")
@@ -135,6 +138,8 @@ def main():
     model = cc.hip_cost_model(lib, args.qp, cc.coeff_weights(args.qp))
     if args.frozen_contexts:
         model.adaptive = 0
+    if args.no_wpp or (args.tiles and not args.wpp):
+        model.no_wpp = 1
 
     from kvazaar_amd import sharding
     batches = []  # (HipBatch, CTUs per picture of that batch, pictures)
@@ -200,6 +205,7 @@ def main():
             "config": {"workload": f"{args.width}x{args.height} yuv420p 8-bit all-intra ultrafast CTU pass (kvz_hip_intra_frames), QP {args.qp}",
                        "frames_per_gpu_per_step": None if args.tiles else args.frames, "frames_per_step": args.frames if args.tiles else args.frames * world,
                        "ctus_per_frame": ctus_per_frame, "distinct_frames": len(distinct),
+                       "wpp": not bool(model.no_wpp),
                        "parallelism": (f"--tiles {args.tiles}: tiles sharded over {world} GPU(s), no data-path collective" if args.tiles
                                        else f"frames sharded over {world} GPU(s), no data-path collective")},
             "roofline": {"bound": "hbm", "kernel": "intra_ctu_ticket_kernel" if launches == 1 else "intra_ctu_wave_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -110,7 +110,11 @@ typedef struct kvz_hip_intra_cost_model {
   /* != 0: coefficients are priced by running the residual coder in counting mode (get_coeff_cabac_cost, rdo.c:220-263) instead of
    * the fast estimate (kvz_fast_coeff_cost); what kvazaar does for QP >= fast_residual_cost_limit (28 in `ultrafast`), rdo.c:311-340 */
   int32_t  coeff_cabac;
-  int32_t  reserved;
+  /* != 0: no wavefront parallel processing -- one coder runs through the picture in raster order, so the first CTU of a row takes its
+   * contexts from the last CTU of the row above instead of from its second one.  kvazaar's default is WPP on (0 here), except that it
+   * switches WPP off when tiles are requested (cfg.c:925-978).  Rows then form one serial chain per picture: the batch needs as many
+   * pictures (or tiles) in flight as the device has workgroup slots. */
+  int32_t  no_wpp;
   uint8_t  ctx_init[160];     /* uc_state at slice start (kvz_init_contexts, context.c:202-305) of the KVZ_HIP_CX_* contexts; the rest unused */
   float    entropy_fbits[128];/* kvz_f_entropy_bits (rdo.c:69-83) */
 } kvz_hip_intra_cost_model;

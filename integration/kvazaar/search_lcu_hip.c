@@ -5,7 +5,7 @@
  * kvz_search_lcu(state, x, y, ...) leaves three things behind for the rest of encoder_state_worker_encode_lcu_search
  * (encoderstate.c:659-720: deblocking, SAO, kvz_encode_coding_tree): the LCU's cu_info in frame->cu_array, its reconstruction in
  * frame->rec and its quantised coefficients in state->coeff (copy_lcu_to_cu_data / copy_coeffs, search.c:1180-1249).  For the
- * configuration the batched pass implements -- I slices of an all-intra `ultrafast`-like setup, 8-bit 4:2:0, constant QP, WPP --
+ * configuration the batched pass implements -- I slices of an all-intra `ultrafast`-like setup, 8-bit 4:2:0, constant QP, with or without WPP --
  * this file fills exactly those from one kvz_hip_intra_frames() run per picture: the first LCU of a picture to get here runs the
  * pass for the whole picture (one-frame batch; the throughput path batches many pictures, this binding is about correctness),
  * every LCU then copies its part.  Everything else falls through to the original function.  The bitstream is the reference's,
@@ -61,7 +61,7 @@ static int eligible(const encoder_state_t *state)
   REQUIRE(!cfg->lossless && !cfg->implicit_rdpcm && cfg->scaling_list == KVZ_SCALING_LIST_OFF);
   REQUIRE(!cfg->full_intra_search);
   REQUIRE(cfg->pu_depth_intra.min[0] == 2 && cfg->pu_depth_intra.max[0] == 3);  /* all-intra: GOP layer 0 only */
-  REQUIRE(cfg->cu_split_termination == KVZ_CU_SPLIT_TERMINATION_ZERO && cfg->combine_intra_cus && cfg->wpp);
+  REQUIRE(cfg->cu_split_termination == KVZ_CU_SPLIT_TERMINATION_ZERO && cfg->combine_intra_cus);
   REQUIRE(cfg->target_bitrate <= 0 && !cfg->vaq && !cfg->roi.file_path && !cfg->set_qp_in_cu && state->frame->max_qp_delta_depth < 0);
   REQUIRE(!cfg->ml_pu_depth_intra && !cfg->intra_bit_allocation);
 #undef REQUIRE
@@ -105,6 +105,7 @@ static const picture_result *picture_of(const encoder_state_t *state)
   kvz_hip_intra_cost_model_init(state->qp, kvz_fast_coeff_get_weights(state), &model);
   const kvz_config *cfg = &state->encoder_control->cfg;
   model.coeff_cabac = !(state->qp < cfg->fast_residual_cost_limit && state->qp < MAX_FAST_COEFF_COST_QP);  /* rdo.c:311-340 */
+  model.no_wpp = !cfg->wpp;  /* kvazaar switches WPP off when tiles are used (cfg.c:925-978) */
   kvz_hip_batch_upload(g_batch, 0, src, src + ys, src + ys + cs);
   kvz_hip_intra_frames(g_batch, &model);
   kvz_hip_batch_sync(g_batch);

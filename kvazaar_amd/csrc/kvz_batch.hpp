@@ -53,6 +53,7 @@ struct CtuSched {
   unsigned *done;         // [frames * ctus_per_frame]: epoch of the last call that completed the CTU
   unsigned *error;        // set when a wait exceeds its spin bound (never in a healthy run)
   unsigned total, epoch;
+  int no_wpp;             // items in raster order per picture; a row's first CTU also waits for the last CTU of the row above
 };
 
 __device__ __forceinline__ bool wait_done(unsigned *flag, unsigned epoch, unsigned *error)
@@ -84,6 +85,7 @@ template <bool CABAC> __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attri
       unsigned *done = sched.done + (long)frame * ctus;
       if (x > 0) wait_done(&done[y * F.wc + x - 1], sched.epoch, sched.error);
       if (y > 0) wait_done(&done[(y - 1) * F.wc + (x + 1 < F.wc ? x + 1 : x)], sched.epoch, sched.error);  // above-right implies above and above-left
+      if (sched.no_wpp && x == 0 && y > 0) wait_done(&done[(y - 1) * F.wc + F.wc - 1], sched.epoch, sched.error);  // its contexts come from there
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -115,7 +117,7 @@ struct kvz_hip_batch {
   uint8_t *d_border;
   unsigned long long *d_prof;
   float *d_entropy;  // the model's entropy_fbits [128 floats] followed by its ctx_init [160 bytes] of the run in flight
-  uint32_t *d_items;
+  uint32_t *d_items, *d_items_raster;  // ticket order with WPP (anti-diagonals) / without (raster order per picture)
   unsigned *d_ticket, *d_done, *d_error;
   unsigned total_items, epoch;
   int sched_ticket, grid_ticket;
@@ -241,6 +243,12 @@ kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
     b->epoch = 0;
     KVZ_HIP_CHECK(hipMalloc((void **)&b->d_items, items.size() * sizeof(uint32_t)));
     KVZ_HIP_CHECK(hipMemcpy(b->d_items, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    items.clear();  // without WPP every CTU depends on its raster predecessor: CTU i of every picture, then CTU i + 1 of every picture
+    for (int y = 0; y < F.hc; y++)
+      for (int x = 0; x < F.wc; x++)
+        for (int f = 0; f < n_frames; f++) items.push_back((uint32_t)f << 16 | (uint32_t)y << 8 | (uint32_t)x);
+    KVZ_HIP_CHECK(hipMalloc((void **)&b->d_items_raster, items.size() * sizeof(uint32_t)));
+    KVZ_HIP_CHECK(hipMemcpy(b->d_items_raster, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     KVZ_HIP_CHECK(hipMalloc((void **)&b->d_done, nctu * sizeof(unsigned)));
     KVZ_HIP_CHECK(hipMemsetAsync(b->d_done, 0, nctu * sizeof(unsigned), b->stream));
     KVZ_HIP_CHECK(hipMalloc((void **)&b->d_ticket, 2 * sizeof(unsigned)));
@@ -267,7 +275,7 @@ void kvz_hip_batch_destroy(kvz_hip_batch *b)
 {
   if (!b) return;
   (void)hipStreamSynchronize(b->stream);
-  (void)hipFree(b->d_border); (void)hipFree(b->d_items); (void)hipFree(b->d_done); (void)hipFree(b->d_ticket); (void)hipFree(b->d_prof); (void)hipFree(b->d_entropy);
+  (void)hipFree(b->d_border); (void)hipFree(b->d_items); (void)hipFree(b->d_items_raster); (void)hipFree(b->d_done); (void)hipFree(b->d_ticket); (void)hipFree(b->d_prof); (void)hipFree(b->d_entropy);
   (void)hipFree(b->d_src); (void)hipFree(b->d_rec); (void)hipFree(b->d_coeff); (void)hipFree(b->d_scratch); (void)hipFree(b->d_depth); (void)hipFree(b->d_mode); (void)hipFree(b->d_cost);
   (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1);
   (void)hipStreamDestroy(b->stream);
@@ -312,11 +320,12 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
   cm.ctx_init = (const uint8_t *)(b->d_entropy + 128);
   KVZ_HIP_CHECK(hipMemcpyAsync(b->d_entropy, model->entropy_fbits, 128 * sizeof(float), hipMemcpyHostToDevice, b->stream));
   KVZ_HIP_CHECK(hipMemcpyAsync(b->d_entropy + 128, model->ctx_init, sizeof model->ctx_init, hipMemcpyHostToDevice, b->stream));
+  if (!b->sched_ticket && cm.no_wpp) { fprintf(stderr, "kvz_hip_intra_frames: the one-launch-per-diagonal schedule (KVZ_HIP_SCHED=wave) needs WPP\n"); abort(); }
   if (b->sched_ticket) {
     b->epoch++;
     KVZ_HIP_CHECK(hipMemsetAsync(b->d_ticket, 0, 2 * sizeof(unsigned), b->stream));
     KVZ_HIP_CHECK(hipEventRecord(b->ev0, b->stream));
-    kvz::CtuSched sc{ b->d_items, b->d_ticket, b->d_done, b->d_error, b->total_items, b->epoch };
+    kvz::CtuSched sc{ cm.no_wpp ? b->d_items_raster : b->d_items, b->d_ticket, b->d_done, b->d_error, b->total_items, b->epoch, cm.no_wpp };
     // two instantiations: the one without the CABAC coefficient model carries none of its code, registers or context storage
     if (cm.coeff_cabac) hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel<true>, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);
     else hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel<false>, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);

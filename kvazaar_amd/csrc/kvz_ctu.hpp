@@ -141,14 +141,14 @@ template <bool CABAC> struct CtxSetT { alignas(4) u8 s[CABAC ? 148 : 12]; };
 struct CtuModel {
   double lambda, lambda_sqrt;
   uint64_t coeff_weights;
-  int qp, adaptive, coeff_cabac;
+  int qp, adaptive, coeff_cabac, no_wpp;
   const float *entropy_fbits;  // [128]
   const u8 *ctx_init;          // [KVZ_CX_COUNT]
 };
 KVZ_HD void ctu_model_from(const kvz_hip_intra_cost_model *src, CtuModel *dst)
 {
   dst->lambda = src->lambda; dst->lambda_sqrt = src->lambda_sqrt; dst->coeff_weights = src->coeff_weights; dst->qp = src->qp; dst->adaptive = src->adaptive;
-  dst->coeff_cabac = src->coeff_cabac;
+  dst->coeff_cabac = src->coeff_cabac; dst->no_wpp = src->no_wpp;
   dst->entropy_fbits = src->entropy_fbits;
   dst->ctx_init = src->ctx_init;
 }
@@ -1635,10 +1635,12 @@ template <bool CABAC> struct CtuProgramT {
       if (v < 64) s->ctx_lps[v] = tb->ctx_next[1][2 * v];
       if (v < (cabac_on() ? KVZ_CX_COUNT : KVZ_CX_SYNTAX_COUNT)) {  // the residual contexts are only looked at with the CABAC coefficient cost
         // the row's contexts: from the CTU to the left; a row's first CTU from the second CTU of the row above (WPP; rows of a
-        // one-CTU-wide picture and the first row start from the slice-start state, encoderstate.c:1218)
+        // one-CTU-wide picture and the first row start from the slice-start state, encoderstate.c:1218) -- or, without WPP, from
+        // the last CTU of the row above (one coder runs through the picture in raster order)
         const int ctx = cx >> 6, cty = cy >> 6;
         const u8 *base = F.border + (long)frame * F.wc * F.hc * KVZ_BORDER_BYTES;
-        const u8 *r = ctx > 0 ? base + (long)(cty * F.wc + ctx - 1) * KVZ_BORDER_BYTES : ((cty > 0 && F.wc > 1) ? base + (long)((cty - 1) * F.wc + 1) * KVZ_BORDER_BYTES : nullptr);
+        const int seed = m->no_wpp ? F.wc - 1 : (F.wc > 1 ? 1 : -1);
+        const u8 *r = ctx > 0 ? base + (long)(cty * F.wc + ctx - 1) * KVZ_BORDER_BYTES : ((cty > 0 && seed >= 0) ? base + (long)((cty - 1) * F.wc + seed) * KVZ_BORDER_BYTES : nullptr);
         const u8 st = (r && m->adaptive) ? load_shared_byte(r + 288 + v) : m->ctx_init[v];
         s->pre[0].s[v] = st; s->cab.s[v] = st;
       }

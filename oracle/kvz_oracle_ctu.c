@@ -850,11 +850,14 @@ void kvz_oracle_intra_frame(const kvz_hip_intra_cost_model *m, int width, int he
   for (int r = 0; r < hc; r++) for (int i = 0; i < CX_COUNT; i++) rows[r].s[i] = m->ctx_init[i];
   for (int cy = 0; cy < hc; cy++)
     for (int cx = 0; cx < wc; cx++) {
-      t->cab = rows[cy];  /* kvz_search_lcu: search_cabac = state->cabac (search.c:1211) */
+      /* with WPP every LCU row has its own coder; without it (kvazaar switches it off when tiles are used, cfg.c:925-978) one coder runs
+       * through the picture in raster order, so a row starts from where the previous one ended */
+      ctxs_t *row = m->no_wpp ? &rows[0] : &rows[cy];
+      t->cab = *row;  /* kvz_search_lcu: search_cabac = state->cabac (search.c:1211) */
       ctu_cost[cy * wc + cx] = encode_ctu(t, cx * 64, cy * 64, coeff + (size_t)(cy * wc + cx) * KVZ_HIP_CTU_COEFFS);
       if (m->adaptive) {
-        code_coding_tree(t, &rows[cy], cx * 64, cy * 64, 0);
-        if (cx == 1 && cy + 1 < hc) rows[cy + 1] = rows[cy];
+        code_coding_tree(t, row, cx * 64, cy * 64, 0);
+        if (!m->no_wpp && cx == 1 && cy + 1 < hc) rows[cy + 1] = rows[cy];
       }
     }
   free(rows);

@@ -88,11 +88,15 @@ ENCODER_CLIPS = [(64, 64, 2, 9, "small", 22), (72, 88, 2, 1, "small", 12), (200,
                  (1920, 1080, 1, 1, "large", 32)]
 
 
-def clip_key(w, h, n, seed, kind, qp, deblock):
-    return f"{w}x{h}/n{n}/seed{seed}/{kind}/qp{qp}/{'deblock' if deblock else 'nodeblock'}"
+# ... and without wavefront parallel processing (--no-wpp; also what --tiles implies, cfg.c:925-978): one coder through the picture
+ENCODER_CLIPS_NO_WPP = [(416, 240, 2, 1234, "small", 22), (200, 136, 2, 3, "small", 32), (64, 136, 1, 3, "small", 22)]
 
 
-def reference_encoder_recon(w, h, frames, qp, deblock, workdir, cu_maps=None):
+def clip_key(w, h, n, seed, kind, qp, deblock, no_wpp=False):
+    return f"{w}x{h}/n{n}/seed{seed}/{kind}/qp{qp}/{'deblock' if deblock else 'nodeblock'}" + ("/nowpp" if no_wpp else "")
+
+
+def reference_encoder_recon(w, h, frames, qp, deblock, workdir, cu_maps=None, no_wpp=False):
     """runs the reference CLI (oracle/_ref/kvazaar_ref) on the clip; returns its --debug reconstruction, one array per frame.
     cu_maps: a list that receives, per frame, the (depth, intra mode) maps per 8x8 cell the encoder's search left in its cu_array
     (recorded through the oracle/ref_cudump.c interposer; single-threaded so that LCUs arrive frame by frame)"""
@@ -103,6 +107,8 @@ def reference_encoder_recon(w, h, frames, qp, deblock, workdir, cu_maps=None):
     cmd = [exe, "-i", src, "--input-res", f"{w}x{h}", "--preset", "ultrafast", "-p", "1", "-q", str(qp), "--debug", rec, "-o", os.path.join(workdir, "out.hevc")]
     if not deblock:
         cmd.append("--no-deblock")
+    if no_wpp:
+        cmd.append("--no-wpp")
     env = dict(os.environ)
     dump = os.path.join(workdir, "cu.txt")
     if cu_maps is not None:
@@ -133,6 +139,10 @@ def encoder_digests(workdir):
             out[clip_key(w, h, n, seed, kind, qp, deblock)] = [hashlib.sha256(r.tobytes()).hexdigest()[:24] for r in recs]
             if maps is not None:  # the CU quadtree and the intra modes behind that reconstruction
                 out[clip_key(w, h, n, seed, kind, qp, deblock) + "/cu"] = [cu_digest(d, m) for d, m in maps]
+    for (w, h, n, seed, kind, qp) in ENCODER_CLIPS_NO_WPP:
+        frames = cc.yuv_frames(w, h, n, seed, kind)
+        recs = reference_encoder_recon(w, h, frames, qp, 0, workdir, None, True)
+        out[clip_key(w, h, n, seed, kind, qp, 0, True)] = [hashlib.sha256(r.tobytes()).hexdigest()[:24] for r in recs]
     return out
 
 

@@ -56,15 +56,15 @@ def test_golden_md5_416x240(tmp_path):
     assert md5_hip == GOLDEN_416x240_8F
 
 
-@pytest.mark.parametrize("frames,extra", [(3, ["-q", "22"]), (2, ["-q", "32"]), (2, ["-q", "27", "--no-deblock"]), (1, ["-q", "22", "--tiles", "2x2", "--wpp"])],
-                         ids=["qp22", "qp32-cabac-coeff-cost", "qp27-nodeblock", "tiles-wpp"])
+@pytest.mark.parametrize("frames,extra", [(3, ["-q", "22"]), (2, ["-q", "32"]), (2, ["-q", "27", "--no-deblock"]), (1, ["-q", "22", "--tiles", "2x2", "--wpp"]), (2, ["-q", "22", "--tiles", "2x2"]), (2, ["-q", "32", "--no-wpp"])],
+                         ids=["qp22", "qp32-cabac-coeff-cost", "qp27-nodeblock", "tiles-wpp", "tiles", "no-wpp"])
 def test_batched_search_bitstream_identical(tmp_path, frames, extra):
     """The BATCHED pass inside the real encoder: integration/kvazaar/search_lcu_hip.c stands in front of kvz_search_lcu and
     fills cu_array / reconstruction / coefficients of every LCU from one kvz_hip_intra_frames() run per picture; deblocking and
     the entropy coder are the reference's own.  The bitstream must be the reference encoder's, byte for byte -- i.e. every CU
     depth, mode, coded block flag and coefficient the device decided is kvazaar's.  (The per-call strategies are switched off
     here: this is about the batched path.)  Tiles: each tile is a picture of its own for the pass; kvazaar switches WPP off
-    when tiles are requested (cfg.c:925-978) and the pass models the WPP context hand-off, so the tile case asks for both."""
+    when tiles are requested (cfg.c:925-978), which the pass follows (kvz_hip_intra_cost_model::no_wpp)."""
     if not os.path.exists(os.path.join(REF, "kvazaar_hip")):
         pytest.skip("oracle/_ref/kvazaar_hip not built")
     yuv = str(tmp_path / "syn.yuv")

@@ -68,6 +68,38 @@ def test_oracle_chain_reproduces_reference_encoder(oracle, clip):
     assert [_cu(cc.run_oracle(oracle, model, w, h, f), w, h) for f in frames] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0) + "/cu"]
 
 
+@pytest.mark.parametrize("clip", mg.ENCODER_CLIPS_NO_WPP, ids=lambda c: f"{c[0]}x{c[1]}-qp{c[5]}")
+def test_no_wpp_context_flow_reproduces_reference_encoder(oracle, hostsim, clip):
+    """--no-wpp (what --tiles implies in kvazaar): one coder runs through the picture, a row starts from the contexts the row above
+    ended with.  Oracle and the device sources (host simulation) against the reference CLI's reconstruction."""
+    w, h, n, seed, kind, qp = clip
+    model = oracle_model(oracle, qp)
+    model.no_wpp = 1
+    frames = cc.yuv_frames(w, h, n, seed, kind)
+    want = GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0, True)]
+    assert [_sha(cc.run_oracle(oracle, model, w, h, f)["rec"]) for f in frames] == want
+    assert [_sha(cc.run_hostsim(hostsim.lib, model, w, h, f)["rec"]) for f in frames] == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip", mg.ENCODER_CLIPS_NO_WPP, ids=lambda c: f"{c[0]}x{c[1]}-qp{c[5]}")
+def test_hip_batch_no_wpp_reproduces_reference_encoder(clip):
+    import kvazaar_amd
+    lib = kvazaar_amd.load_library()
+    w, h, n, seed, kind, qp = clip
+    model = cc.hip_cost_model(lib, qp, cc.coeff_weights(qp))
+    model.no_wpp = 1
+    frames = cc.yuv_frames(w, h, n, seed, kind)
+    b = cc.HipBatch(lib, w, h, n)
+    try:
+        for i, f in enumerate(frames):
+            b.upload(i, f)
+        b.run(model)
+        assert [_sha(b.download(i)["rec"]) for i in range(n)] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0, True)]
+    finally:
+        b.close()
+
+
 def test_frozen_contexts_do_not_reproduce_the_encoder(oracle):
     """the adaptive contexts matter: with every context frozen at its slice-start state the pass is still a valid encode,
     but not kvazaar's"""
