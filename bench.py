@@ -53,6 +53,23 @@ def pmc_traffic(args, launches):
     return None if best is None else best["bytes_per_launch"]
 
 
+def pmc_valu_issue(args, launches):
+    """share of the SIMDs' VALU issue slots the dominant kernel used (committed SQ counters of this exact workload, else null): the
+    bound of this kernel -- it is neither a streaming nor a matrix kernel"""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_sq.json"))):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        w = d.get("workload", {})
+        if (w.get("width"), w.get("height"), w.get("frames"), w.get("qp", 22)) == (args.width, args.height, args.frames, args.qp) and launches == 1 and not args.tiles:
+            best = d
+    return None if best is None else {"frac": best["valu_issue_frac"], "valu_insts_per_launch": best["insts_valu"], "salu_insts_per_launch": best["insts_salu"],
+                                      "source": "profiles/*pmc_sq.json: rocprofv3 --pmc SQ_INSTS_VALU / SQ_BUSY_CYCLES; a wave64 VALU instruction holds its SIMD for 4 cycles"}
+
+
 def cpu_baseline(args, frames, model):
     """kvazaar's own AVX2 encoder (oracle/_ref, built from the reference sources) on all host cores over 64 of the benchmark's
     frames (kind "reference"), with the oracle's single-core restatement of exactly this pass nested as "port"; only the port when
@@ -209,10 +226,10 @@ def main():
                        "parallelism": (f"--tiles {args.tiles}: tiles sharded over {world} GPU(s), no data-path collective" if args.tiles
                                        else f"frames sharded over {world} GPU(s), no data-path collective")},
             "roofline": {"bound": "hbm", "kernel": "intra_ctu_ticket_kernel" if launches == 1 else "intra_ctu_wave_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, launches), "traffic_source": "profiles/*pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, raw counters x 1024) on this workload, else null",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, launches), "valu_issue": pmc_valu_issue(args, launches), "traffic_source": "profiles/*pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, raw counters x 1024) on this workload, else null",
                          "launches_per_step": launches,
                          "avg_launch_us": per_launch_s * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "instruction-issue / latency-bound CTU search, not a streaming kernel (DESIGN.md 5); per-kernel HBM and MFMA fractions of the streaming primitives: bench_kernels.py"},
+                         "note": "instruction-issue-bound CTU search (valu_issue.frac of the SIMDs' VALU slots), not a streaming kernel (DESIGN.md 5); per-kernel HBM and MFMA fractions of the streaming primitives: bench_kernels.py"},
         }
         # auxiliary: the per-picture chain an encoder needs from the device before entropy coding -- CTU pass, deblocking, picture
         # hash -- timed the same way on rank 0's batches (not the headline: BASELINE's metric is the CTU pass)
