@@ -1,29 +1,34 @@
-// kvz_ctu.hpp -- the batched all-intra CTU pass: one workgroup (256 threads) searches and reconstructs one 64x64
-// CTU entirely out of LDS.
+// kvz_ctu.hpp -- the batched all-intra CTU pass: one workgroup (128 lanes, two wavefronts) searches and reconstructs one
+// 64x64 CTU entirely out of LDS.
 //
 // What it computes: kvazaar's per-CTU flow for an I slice under `--preset ultrafast` (search.c:646 search_cu ->
 // search_intra.c:391 search_intra_rough -> intra.c:623 kvz_intra_recon_cu -> quant-generic.c:198
-// kvz_quantize_residual -> search.c:425 cu_rd_cost_tr_split_accurate), CU quadtree 64/32/16/8, with the CABAC
-// contexts frozen at slice-init state (kvz_hip_intra_cost_model; see oracle/kvz_oracle_ctu.c for the function-by-
-// function restatement this kernel is checked against, bit for bit: modes, depths, coefficients, reconstruction
-// and the double-precision RD costs).
+// kvz_quantize_residual -> search.c:425 cu_rd_cost_tr_split_accurate), CU quadtree 64/32/16/8, priced on CABAC contexts
+// that evolve as the encoder's do (kvz_hip_intra_cost_model; search-time updates with search_cu's save / restore points,
+// syntax replay of the finished CTU, hand-off along the row and to the next row with or without WPP) and, from QP 28 on, with
+// the residual coder in counting mode.  oracle/kvz_oracle_ctu.c is the function-by-function restatement this kernel is checked
+// against bit for bit (modes, depths, coefficients, reconstruction, the double-precision RD costs); both reproduce the
+// reference encoder's own reconstruction and CU tree (tests/test_encoder_parity.py).
 //
-// How it is laid out for CDNA4:
-//   * LDS holds the CTU's source pixels (6 KB), the four work-tree levels of reconstruction kvazaar keeps in
-//     lcu_t copies (4 x 6 KB, search.c:103-122), the 35 candidate predictions of the CU being searched (<= 9 KB)
-//     and the transform scratch (6 KB): ~50 KB per workgroup -> 3 workgroups per CU.
-//   * All 35 intra modes of a CU are predicted and SATD-scored at once (kvazaar tries 8..17 of them one pair at a
-//     time, search_intra.c:433-519); one lane then replays kvazaar's selection order on the cost table, which picks
-//     the same winner because every cost is a pure function of (references, source).
-//   * Y, U and V of a CU go through residual -> DCT -> quant -> dequant -> IDCT -> reconstruction together, one
-//     barrier per stage; SSD and coefficient-cost sums are LDS atomics.
-//   * CTUs only depend on their left / above / above-right neighbours' reconstructed border and CU info, read
-//     from HBM; the host launches one grid per anti-diagonal (x + 2y = const) over ALL frames of the batch, so no
-//     inter-workgroup synchronisation exists inside a launch.
+// How it is laid out for CDNA4 (DESIGN.md 3.2 has the table and the measurements):
+//   * LDS (exactly 20 480 B with the CABAC coefficient model, 19 792 B without: eight workgroups per CU): the source pixels of
+//     the 32x32 quadrant being searched, ONE decided picture plus one candidate per depth sized to its CU (kvazaar keeps four
+//     full lcu_t copies, search.c:103-122), a transform scratch that the small-CU search buffers share, the challenger levels
+//     of 16x16 / 32x32 CUs, five context sets, the neighbour CTUs' borders.
+//   * All 35 intra modes of a CU are scored at once (kvazaar tries 8..17 of them one pair at a time, search_intra.c:433-519):
+//     the 33 angular ones by one lane per (mode, 8x8 block) that predicts and Hadamard-transforms in registers (packed int16);
+//     one wavefront then replays kvazaar's selection order on the cost table, which picks the same winner because every cost is
+//     a pure function of (references, source).
+//   * Y, U and V of a CU go through residual -> DCT -> quant -> dequant -> IDCT -> reconstruction together, one barrier per
+//     stage; 16- and 32-point transforms on the matrix cores (kvz_mfma.hpp); an 8x8 CU with one lane per sample of any plane.
+//   * CTUs depend on their left and above-right neighbours' border records (reconstructed pixels, CU info, contexts) in HBM;
+//     one persistent launch draws CTUs from an in-order ticket list (kvz_batch.hpp).
+//   * The kernel is bound by VALU instruction issue (76 % of all slots): what counts is the number of instructions per CTU.
 //
 // The program is a sequence of phases `KVZ_FOR_THREADS(tid) { ... } KVZ_SYNC();` with uniform control flow in
 // between.  tests/hostsim compiles it with KVZ_HOSTSIM, where a phase is a loop over tid -- exact emulation as long
-// as threads of one phase do not communicate, which is the discipline followed here (LDS atomics are integer adds).
+// as threads of one phase do not communicate, which is the discipline followed here (LDS atomics are integer adds; the few
+// places that use cross-lane operations on the device have a plain form for the host next to them).
 #pragma once
 #include "../../include/kvz_hip_types.h"
 #include "kvz_ops.hpp"
@@ -164,7 +169,7 @@ struct CtuFrames {
   u8 *cu_depth, *cu_mode;    // [frames][(H/8)*(W/8)]
   double *ctu_cost;          // [frames][ctu]
   unsigned long long *prof;  // [KVZ_P_COUNT] cycle counters (KVZ_CTU_PROFILE builds only, else unused)
-  // What a CTU hands to its right / lower neighbours: KVZ_BORDER_BYTES per CTU = three 128-byte lines with ONE producer each
+  // What a CTU hands to its right / lower neighbours: KVZ_BORDER_BYTES per CTU = four 128-byte lines with ONE producer each
   //   [0..127]   bottom row   Y 64 | U 32 | V 32        [128..255] right column Y 64 | U 32 | V 32
   //   [256..287] CU info: depth of the bottom 8x8 row [8], mode [8], depth of the right 8x8 column [8], mode [8]
   //   [288..433] the row's CABAC contexts after this CTU's syntax (KVZ_CX_*): what the CTU to the right starts from, and -- from
