@@ -9,8 +9,9 @@
  *
  * Frame independence: with `-p 1` every frame is an IDR picture (encoderstate.c:1599-1620), so a batch of N frames
  * is N independent problems; inside a frame CTU (x, y) needs its left, above and above-right neighbours, i.e. the
- * WPP order of encoderstate.c:793-903.  One kernel launch processes the anti-diagonal x + 2y = const of EVERY
- * frame of the batch.
+ * WPP order of encoderstate.c:793-903.  One persistent kernel launch per call draws the CTUs of EVERY frame of the batch from a
+ * ticket list in that order (anti-diagonals x + 2y = const; raster order per picture when the model says no WPP) and workgroups
+ * hand results to each other through per-CTU border records.
  *
  * Decisions use kvazaar's own cost formulas, in double precision with the reference's operation order, on CABAC contexts
  * that evolve as kvazaar's do (kvz_hip_intra_cost_model): the reconstruction, CU quadtree, modes and coefficients
@@ -40,7 +41,8 @@ void kvz_hip_batch_download(kvz_hip_batch *b, int frame, uint8_t *rec_y, uint8_t
                             uint8_t *cu_depth, uint8_t *cu_mode, double *ctu_cost);
 
 /* The hot path: search + reconstruct every CTU of every frame in the batch.  Asynchronous on the batch's stream;
- * kvz_hip_batch_sync() waits.  Returns the number of kernel launches issued (one per CTU anti-diagonal). */
+ * kvz_hip_batch_sync() waits.  Returns the number of kernel launches issued (1; one per CTU anti-diagonal with the older
+ * schedule behind KVZ_HIP_SCHED=wave). */
 int  kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model);
 void kvz_hip_batch_sync(kvz_hip_batch *b);
 /* Device time of the launches of the last kvz_hip_intra_frames call, from HIP events recorded on the batch's own

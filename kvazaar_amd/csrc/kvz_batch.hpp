@@ -1,5 +1,5 @@
-// kvz_batch.hpp -- host side of the batched CTU pass: device buffers of a frame batch, the wave-front launch
-// schedule and the cost model.  Included by kvz_hip.hip only.
+// kvz_batch.hpp -- host side of the batched CTU pass: device buffers of a frame batch, the two kernels (persistent launch with an
+// in-order ticket list; one launch per anti-diagonal kept for A/B), the cost model.  Included by kvz_hip.hip only.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
