@@ -45,6 +45,8 @@ def main():
         w, h = int(rng.integers(1, 26)) * 8, int(rng.integers(1, 20)) * 8
         qp = int(rng.choice([0, 7, 12, 17, 22, 27, 32, 37, 42, 47, 51]))
         model = cc.hip_cost_model(lib, qp, cc.coeff_weights(qp))
+        model.no_wpp = int(rng.integers(0, 2))      # with / without wavefront parallel processing (context hand-off between rows)
+        model.adaptive = int(rng.integers(0, 8) > 0)  # mostly kvazaar's adaptive contexts, sometimes frozen ones
         frames = [picture(rng, w, h, int(rng.integers(0, 6))) for _ in range(int(rng.integers(1, 4)))]
         b = cc.HipBatch(lib, w, h, len(frames))
         for k, f in enumerate(frames):
@@ -54,7 +56,7 @@ def main():
             diff = cc.compare(b.download(k), cc.run_oracle(oracle, model, w, h, f))
             if diff:
                 bad += 1
-                print(f"case {i} frame {k}: {w}x{h} qp {qp} differs in {diff}", flush=True)
+                print(f"case {i} frame {k}: {w}x{h} qp {qp} no_wpp {model.no_wpp} adaptive {model.adaptive} differs in {diff}", flush=True)
         b.close()
     print(f"fuzz: {cases} cases, {bad} mismatching frames")
     return 1 if bad else 0
