@@ -208,7 +208,7 @@ template <bool CABAC> struct CtuSharedT {
       alignas(8) u8 org_t[256];  // the CU's source block transposed (horizontal modes are predicted and scored transposed)
       u8 c2[384];              // depth-2 candidate (16x16 CU):     Y 256 | U 64 | V 64
       u8 c3[384];              // depth-3 candidates (the four 8x8 CUs of the current 16x16)
-      alignas(8) u8 pred[2 * 256];  // planar and DC predictions of the CU being searched (<= 16x16)
+      alignas(8) u8 pred[3 * 256];  // planar, DC and -- for 16x16 CUs -- mode 34 (see rough_search); the rest: planar and DC predictions of the CU being searched (<= 16x16)
       // Rough search, the 15 angular modes with a negative displacement (11..25): the main reference with its projected
       // extension (intra-generic.c:97-123), already picked from the filtered / unfiltered, top / left arrays.  Entry
       // [mode - 11][KVZ_MREF_ORG + q] is ref_main[q], q in [-w, w + 1] -- all such a mode can touch.  The other modes read
@@ -906,7 +906,12 @@ template <bool CABAC> struct CtuProgramT {
   //    the Hadamard magnitudes of D^T are those of D;
   //  - butterfly stages commute, so the one stage that would pair the two halves of a packed register is done last and
   //    folded into the magnitude sum: |a + b| + |a - b| = 2 max(|a|, |b|).
-  KVZ_DEV u32 angular_block_satd(int log2w, int mode, int bx, int by, int xl, int yl) const
+  // PAIR: the block is shared by two neighbouring lanes, `half` 0 / 1 taking rows 0..3 / 4..7 (across the main reference): each
+  // predicts and row-transforms its four rows, the lanes swap them (DPP quad_perm) for the butterfly stage that pairs row r with
+  // row r + 4 -- the even lane keeps the sums, the odd one the differences --, finish their halves alone and add up.  Both lanes
+  // return the block's total.  Device only (the host simulation has no cross-lane operations and runs the one-lane form).
+  template <bool PAIR>
+  KVZ_DEV u32 angular_block_satd(int log2w, int mode, int bx, int by, int xl, int yl, int half) const
   {
     const int w = 1 << log2w;
     const bool vertical = mode >= 18;
@@ -923,8 +928,12 @@ template <bool CABAC> struct CtuProgramT {
     const int ostride = vertical ? 32 : w;
     const u8 *side = vertical ? s->ref[0][1] : s->ref[0][0];  // intra.c:207-219: modes 10 / 26 use the unfiltered references
     const bool edge = disp == 0 && p0 == 0;
-    Pk16 d[8][4];
-    for (int r = 0; r < 8; r++) {
+    constexpr int NR = PAIR ? 4 : 8;
+    const int r0 = PAIR ? 4 * half : 0;
+    Pk16 d[NR][4];
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+      const int r = r0 + i;
       const int qa = q0 + r + 1, delta = qa * disp, di = delta >> 5, df = delta & 31;
       const u8 *m = mr + di;
       // the eight source pixels of the row in one 8-byte load (block origins are multiples of 8 in 8-byte aligned arrays)
@@ -937,20 +946,42 @@ template <bool CABAC> struct CtuProgramT {
         a = b;
       }
       if (edge) v[0] = iclip(0, 255, v[0] + (((int)side[qa] - (int)side[0]) >> 1));
-      for (int j = 0; j < 4; j++) d[r][j] = pk_make(v[2 * j] - (int)((ow >> (16 * j)) & 0xff), v[2 * j + 1] - (int)((ow >> (16 * j + 8)) & 0xff));
+      for (int j = 0; j < 4; j++) d[i][j] = pk_make(v[2 * j] - (int)((ow >> (16 * j)) & 0xff), v[2 * j + 1] - (int)((ow >> (16 * j + 8)) & 0xff));
     }
-    for (int r = 0; r < 8; r++) {  // along the rows: columns k and k + 4, then k and k + 2 (k and k + 1 is the folded stage)
-      const Pk16 a0 = pk_add(d[r][0], d[r][2]), a1 = pk_add(d[r][1], d[r][3]), a2 = pk_sub(d[r][0], d[r][2]), a3 = pk_sub(d[r][1], d[r][3]);
-      d[r][0] = pk_add(a0, a1); d[r][1] = pk_sub(a0, a1); d[r][2] = pk_add(a2, a3); d[r][3] = pk_sub(a2, a3);
+#pragma unroll
+    for (int i = 0; i < NR; i++) {  // along the rows: columns k and k + 4, then k and k + 2 (k and k + 1 is the folded stage)
+      const Pk16 a0 = pk_add(d[i][0], d[i][2]), a1 = pk_add(d[i][1], d[i][3]), a2 = pk_sub(d[i][0], d[i][2]), a3 = pk_sub(d[i][1], d[i][3]);
+      d[i][0] = pk_add(a0, a1); d[i][1] = pk_sub(a0, a1); d[i][2] = pk_add(a2, a3); d[i][3] = pk_sub(a2, a3);
     }
     u32 sum = 0;
-    for (int j = 0; j < 4; j++) {  // down the columns, two columns per register
-      const Pk16 a0 = pk_add(d[0][j], d[4][j]), a1 = pk_add(d[1][j], d[5][j]), a2 = pk_add(d[2][j], d[6][j]), a3 = pk_add(d[3][j], d[7][j]);
-      const Pk16 a4 = pk_sub(d[0][j], d[4][j]), a5 = pk_sub(d[1][j], d[5][j]), a6 = pk_sub(d[2][j], d[6][j]), a7 = pk_sub(d[3][j], d[7][j]);
-      const Pk16 b0 = pk_add(a0, a2), b1 = pk_add(a1, a3), b2 = pk_sub(a0, a2), b3 = pk_sub(a1, a3);
-      const Pk16 b4 = pk_add(a4, a6), b5 = pk_add(a5, a7), b6 = pk_sub(a4, a6), b7 = pk_sub(a5, a7);
-      sum += pk_absmax(pk_add(b0, b1)) + pk_absmax(pk_sub(b0, b1)) + pk_absmax(pk_add(b2, b3)) + pk_absmax(pk_sub(b2, b3));
-      sum += pk_absmax(pk_add(b4, b5)) + pk_absmax(pk_sub(b4, b5)) + pk_absmax(pk_add(b6, b7)) + pk_absmax(pk_sub(b6, b7));
+    if constexpr (PAIR) {
+#ifndef KVZ_HOSTSIM
+#pragma unroll
+      for (int j = 0; j < 4; j++) {  // down the columns, two columns per register
+        Pk16 e[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {  // rows r and r + 4 live in the two lanes of the pair
+          int mine;
+          __builtin_memcpy(&mine, &d[i][j], 4);
+          const int theirs = __builtin_amdgcn_update_dpp(0, mine, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+          Pk16 o;
+          __builtin_memcpy(&o, &theirs, 4);
+          e[i] = half ? pk_sub(o, d[i][j]) : pk_add(d[i][j], o);
+        }
+        const Pk16 b0 = pk_add(e[0], e[2]), b1 = pk_add(e[1], e[3]), b2 = pk_sub(e[0], e[2]), b3 = pk_sub(e[1], e[3]);
+        sum += pk_absmax(pk_add(b0, b1)) + pk_absmax(pk_sub(b0, b1)) + pk_absmax(pk_add(b2, b3)) + pk_absmax(pk_sub(b2, b3));
+      }
+      sum += (u32)__builtin_amdgcn_update_dpp(0, (int)sum, 0xB1, 0xF, 0xF, true);
+#endif
+    } else {
+      for (int j = 0; j < 4; j++) {  // down the columns, two columns per register
+        const Pk16 a0 = pk_add(d[0][j], d[4 % NR][j]), a1 = pk_add(d[1][j], d[5 % NR][j]), a2 = pk_add(d[2][j], d[6 % NR][j]), a3 = pk_add(d[3][j], d[7 % NR][j]);
+        const Pk16 a4 = pk_sub(d[0][j], d[4 % NR][j]), a5 = pk_sub(d[1][j], d[5 % NR][j]), a6 = pk_sub(d[2][j], d[6 % NR][j]), a7 = pk_sub(d[3][j], d[7 % NR][j]);
+        const Pk16 b0 = pk_add(a0, a2), b1 = pk_add(a1, a3), b2 = pk_sub(a0, a2), b3 = pk_sub(a1, a3);
+        const Pk16 b4 = pk_add(a4, a6), b5 = pk_add(a5, a7), b6 = pk_sub(a4, a6), b7 = pk_sub(a5, a7);
+        sum += pk_absmax(pk_add(b0, b1)) + pk_absmax(pk_sub(b0, b1)) + pk_absmax(pk_add(b2, b3)) + pk_absmax(pk_sub(b2, b3));
+        sum += pk_absmax(pk_add(b4, b5)) + pk_absmax(pk_sub(b4, b5)) + pk_absmax(pk_add(b6, b7)) + pk_absmax(pk_sub(b6, b7));
+      }
     }
     return 2 * sum;
   }
@@ -998,11 +1029,14 @@ template <bool CABAC> struct CtuProgramT {
         const int ex = e >> log2w, ey = e & (w - 1);
         s->org_t[e] = *org_at(0, xl + ex, yl + ey);
       }
-      for (int i = tid; i < 2 * w * w; i += KVZ_CTU_THREADS) {  // planar and DC
-        const int mode = i >> (2 * log2w), e = i & (w * w - 1);
-        s->pred[mode * 256 + e] = predict_pixel(log2w, mode, 0, e & (w - 1), e >> log2w);
+      // planar and DC go through LDS + column SATD.  So does mode 34 of a 16x16 CU: 33 angular modes x 4 blocks are 132 lane tasks,
+      // four more than there are lanes, and a second round of the in-lane predict + SATD for those four costs every lane's issue slots
+      const int lds_modes = 3;
+      for (int i = tid; i < lds_modes * w * w; i += KVZ_CTU_THREADS) {
+        const int mi = i >> (2 * log2w), e = i & (w * w - 1);
+        s->pred[mi * 256 + e] = predict_pixel(log2w, mi == 2 ? 34 : mi, 0, e & (w - 1), e >> log2w);
       }
-      for (int v = tid; v < 2 * 4; v += KVZ_CTU_THREADS) s->satd_raw[v >> 2][v & 3] = 0;
+      for (int v = tid; v < 3 * 4; v += KVZ_CTU_THREADS) s->satd_raw[v < 8 ? v >> 2 : 34][v & 3] = 0;
       if (tid == KVZ_CTU_THREADS - 1) {
         const int left = x >= 4 ? neighbour_cu(lv, x - 1, y) : -1, above = (y >= 4 && yl > 0) ? neighbour_cu(lv, x, y - 1) : -1;
         mpm_candidates(y, left, above, s->preds);
@@ -1012,16 +1046,26 @@ template <bool CABAC> struct CtuProgramT {
     KVZ_PROF(KVZ_P_PRED35);
     KVZ_FOR_THREADS(tid) {
       const int lb = 2 * (log2w - 3);  // log2(nblk)
-      for (int t = tid; t < 33 * nblk; t += KVZ_CTU_THREADS) {  // angular: one lane per (mode, block)
+#ifdef KVZ_HOSTSIM
+      for (int t = tid; t < 32 * nblk; t += KVZ_CTU_THREADS) {  // angular modes 2..33: one thread per (mode, block)
         const int mode = 2 + (t >> lb), b = t & (nblk - 1), bx = (b & ((w >> 3) - 1)) * 8, by = (b >> (log2w - 3)) * 8;
-        s->satd_raw[mode][b] = angular_block_satd(log2w, mode, bx, by, xl, yl);
+        s->satd_raw[mode][b] = angular_block_satd<false>(log2w, mode, bx, by, xl, yl, 0);
       }
+#else
+      // angular modes 2..33: TWO lanes per (mode, block), rows 0..3 and 4..7 of the block (angular_block_satd<true>): 64 lane tasks
+      // for an 8x8 CU, 256 for a 16x16 one -- whole wavefronts, half the instructions per wavefront
+      for (int t = tid; t < 64 * nblk; t += KVZ_CTU_THREADS) {
+        const int p = t >> 1, mode = 2 + (p >> lb), b = p & (nblk - 1), bx = (b & ((w >> 3) - 1)) * 8, by = (b >> (log2w - 3)) * 8;
+        const u32 v = angular_block_satd<true>(log2w, mode, bx, by, xl, yl, t & 1);
+        if (!(t & 1)) s->satd_raw[mode][b] = v;
+      }
+#endif
       // planar and DC: one lane per (mode, block, Hadamard column), taken from the far end of the thread ids so that
       // they land on another wavefront than the angular lanes
-      for (int t = KVZ_CTU_THREADS - 1 - tid; t < 2 * nblk * 8; t += KVZ_CTU_THREADS) {
-        const int col = t & 7, mb = t >> 3, mode = mb >> lb, b = mb & (nblk - 1), bx = (b & ((w >> 3) - 1)) * 8, by = (b >> (log2w - 3)) * 8;
-        const u32 v = satd8_column(s->pred + mode * 256 + by * w + bx, w, org_at(0, xl + bx, yl + by), 32, col);
-        KVZ_LDS_ADD(&s->satd_raw[mode][b], v);
+      for (int t = KVZ_CTU_THREADS - 1 - tid; t < 3 * nblk * 8; t += KVZ_CTU_THREADS) {
+        const int col = t & 7, mb = t >> 3, mi = mb >> lb, b = mb & (nblk - 1), bx = (b & ((w >> 3) - 1)) * 8, by = (b >> (log2w - 3)) * 8;
+        const u32 v = satd8_column(s->pred + mi * 256 + by * w + bx, w, org_at(0, xl + bx, yl + by), 32, col);
+        KVZ_LDS_ADD(&s->satd_raw[mi == 2 ? 34 : mi][b], v);
       }
     }
     KVZ_SYNC();
