@@ -16,14 +16,15 @@
 //     full lcu_t copies, search.c:103-122), a transform scratch that the small-CU search buffers share, the challenger levels
 //     of 16x16 / 32x32 CUs, five context sets, the neighbour CTUs' borders.
 //   * All 35 intra modes of a CU are scored at once (kvazaar tries 8..17 of them one pair at a time, search_intra.c:433-519):
-//     the 33 angular ones by one lane per (mode, 8x8 block) that predicts and Hadamard-transforms in registers (packed int16);
+//     32 angular ones by two lanes per (mode, 8x8 block) that predict and Hadamard-transform in registers (packed int16, one DPP
+//     exchange), mode 34, planar and DC through LDS;
 //     one wavefront then replays kvazaar's selection order on the cost table, which picks the same winner because every cost is
 //     a pure function of (references, source).
 //   * Y, U and V of a CU go through residual -> DCT -> quant -> dequant -> IDCT -> reconstruction together, one barrier per
 //     stage; 16- and 32-point transforms on the matrix cores (kvz_mfma.hpp); an 8x8 CU with one lane per sample of any plane.
 //   * CTUs depend on their left and above-right neighbours' border records (reconstructed pixels, CU info, contexts) in HBM;
 //     one persistent launch draws CTUs from an in-order ticket list (kvz_batch.hpp).
-//   * The kernel is bound by VALU instruction issue (76 % of all slots): what counts is the number of instructions per CTU.
+//   * The kernel is bound by VALU instruction issue (74 % of all slots): what counts is the number of instructions per CTU.
 //
 // The program is a sequence of phases `KVZ_FOR_THREADS(tid) { ... } KVZ_SYNC();` with uniform control flow in
 // between.  tests/hostsim compiles it with KVZ_HOSTSIM, where a phase is a loop over tid -- exact emulation as long
