@@ -44,14 +44,21 @@ extern "C" void kvz_hostsim_intra_frame(const kvz_hip_intra_cost_model *m, int w
   F.border = border;
   int16_t *scratch = (int16_t *)calloc((size_t)F.wc * F.hc * 6144, sizeof(int16_t));
   F.coeff_scratch = scratch;
-  kvz::CtuShared *sh = (kvz::CtuShared *)calloc(1, sizeof(kvz::CtuShared));
+  // like the device, two instantiations of the program: with and without the CABAC coefficient model (kvz_batch.hpp picks by model)
+  void *sh = calloc(1, sizeof(kvz::CtuSharedT<true>) > sizeof(kvz::CtuSharedT<false>) ? sizeof(kvz::CtuSharedT<true>) : sizeof(kvz::CtuSharedT<false>));
+  kvz::CtuModel cm;
+  kvz::ctu_model_from(m, &cm);
   for (int cy = 0; cy < F.hc; cy++)
     for (int cx = 0; cx < F.wc; cx++) {
-      kvz::CtuProgram p;
-      kvz::CtuModel cm;
-      kvz::ctu_model_from(m, &cm);
-      p.m = &cm; p.tb = &tb; p.F = F; p.s = sh; p.frame = 0; p.cx = cx * 64; p.cy = cy * 64;
-      p.run();
+      if (m->coeff_cabac) {
+        kvz::CtuProgramT<true> p;
+        p.m = &cm; p.tb = &tb; p.F = F; p.s = (kvz::CtuSharedT<true> *)sh; p.frame = 0; p.cx = cx * 64; p.cy = cy * 64;
+        p.run();
+      } else {
+        kvz::CtuProgramT<false> p;
+        p.m = &cm; p.tb = &tb; p.F = F; p.s = (kvz::CtuSharedT<false> *)sh; p.frame = 0; p.cx = cx * 64; p.cy = cy * 64;
+        p.run();
+      }
     }
   free(sh);
   free(scratch);
