@@ -1235,63 +1235,75 @@ template <bool CABAC> struct CtuProgramT {
     }
     KVZ_SYNC();
     KVZ_PROF(KVZ_P_RPRED);
-    for (int pass = 0; pass < 2; pass++) {  // forward transform (dct-generic.c:559-568)
-      KVZ_FOR_THREADS(tid) {
-        KVZ_CU8_ROLE(tid);
-        if (on) {
-          const int shift = pass == 0 ? l2 - 1 : l2 + 6, add = 1 << (shift - 1), k = e >> l2, j = e & (n - 1);
-          const i16 *src = tbuf(t, pass, c);
-          int a = 0;
-          for (int i = 0; i < n; i++) a += dct_at(l2, k, i) * (int)src[(j << l2) + i];
-          tbuf(t, pass ^ 1, c)[e] = (i16)((a + add) >> shift);
-        }
+    KVZ_FOR_THREADS(tid) {  // forward transform (dct-generic.c:559-568), first pass
+      KVZ_CU8_ROLE(tid);
+      if (on) {
+        const int shift = l2 - 1, add = 1 << (shift - 1), k = e >> l2, j = e & (n - 1);
+        const i16 *src = tbuf(t, 0, c);
+        int a = 0;
+        for (int i = 0; i < n; i++) a += dct_at(l2, k, i) * (int)src[(j << l2) + i];
+        tbuf(t, 1, c)[e] = (i16)((a + add) >> shift);
       }
-      KVZ_SYNC();
     }
+    KVZ_SYNC();
     KVZ_PROF(KVZ_P_FDCT);
-    KVZ_FOR_THREADS(tid) {  // quantise (quant-generic.c:57-81) -> coefficient store + cost sums; dequantise (:335-339)
+    // second pass, and -- the coefficient a lane produces is the one it quantises -- straight on: quantise (quant-generic.c:57-81)
+    // -> coefficient store + cost sums; dequantise (:335-339)
+    KVZ_FOR_THREADS(tid) {
       KVZ_CU8_ROLE(tid);
       u32 wsum = 0, nz = 0;
       if (on) {
+        const int shift = l2 + 6, add = 1 << (shift - 1), k = e >> l2, j = e & (n - 1);
+        const i16 *src = tbuf(t, 1, c);
+        int a = 0;
+        for (int i = 0; i < n; i++) a += dct_at(l2, k, i) * (int)src[(j << l2) + i];
+        const int cf = (i16)((a + add) >> shift);
         const QuantScalars q = s->qs[l2 - 2][c ? 1 : 0];
-        const int cf = tbuf(t, 0, c)[e];
         int level = (int)(((u32)iabs(cf) * (u32)q.flat_q + (u32)q.add) >> q.q_bits);
         if (cf < 0) level = -level;
         level = iclip(-32768, 32767, level);
         (coeff_level(lv) + kPlaneOff[c] + zorder(xl >> sh, yl >> sh))[e] = (i16)level;
         if (cabac_on()) levels_lds(lv, c)[e] = (i16)level;
-        int a = iabs(level);
-        nz = a != 0;
-        if (a > 3) a = 3;
-        wsum = (u32)((m->coeff_weights >> (16 * a)) & 0xffff);
-        tbuf(t, 1, c)[e] = (i16)iclip(-32768, 32767, (level * q.dq_scale + (1 << (q.dq_shift - 1))) >> q.dq_shift);
+        int al = iabs(level);
+        nz = al != 0;
+        if (al > 3) al = 3;
+        wsum = (u32)((m->coeff_weights >> (16 * al)) & 0xffff);
+        tbuf(t, 0, c)[e] = (i16)iclip(-32768, 32767, (level * q.dq_scale + (1 << (q.dq_shift - 1))) >> q.dq_shift);
       }
       plane_add(&s->acc[3], wsum, tid);
       plane_add(&s->acc[6], nz, tid);
     }
     KVZ_SYNC();
     KVZ_PROF(KVZ_P_QUANT);
-    for (int pass = 0; pass < 2; pass++) {  // inverse transform (dct-generic.c:570-579), only observable when the plane has coefficients
-      KVZ_FOR_THREADS(tid) {
-        KVZ_CU8_ROLE(tid);
-        if (on && s->acc[6 + c]) {
-          const int shift = pass == 0 ? 7 : 12, add = 1 << (shift - 1), j = e >> l2, i = e & (n - 1);
-          const i16 *src = tbuf(t, pass ^ 1, c);
-          int a = 0;
-          for (int k = 0; k < n; k++) a += dct_at(l2, k, i) * (int)src[(k << l2) + j];
-          tbuf(t, pass, c)[e] = (i16)iclip(-32768, 32767, (a + add) >> shift);
-        }
+    KVZ_FOR_THREADS(tid) {  // inverse transform (dct-generic.c:570-579), first pass; only observable when the plane has coefficients
+      KVZ_CU8_ROLE(tid);
+      if (on && s->acc[6 + c]) {
+        const int shift = 7, add = 1 << (shift - 1), j = e >> l2, i = e & (n - 1);
+        const i16 *src = tbuf(t, 0, c);
+        int a = 0;
+        for (int k = 0; k < n; k++) a += dct_at(l2, k, i) * (int)src[(k << l2) + j];
+        tbuf(t, 1, c)[e] = (i16)iclip(-32768, 32767, (a + add) >> shift);
       }
-      KVZ_SYNC();
     }
+    KVZ_SYNC();
     KVZ_PROF(KVZ_P_IDCT);
-    KVZ_FOR_THREADS(tid) {  // reconstruction (quant-generic.c:266-277) + SSD against the source (search.c:500-505, 512-523)
+    // second pass, and straight on with the sample it produces: reconstruction (quant-generic.c:266-277) + SSD against the source
+    // (search.c:500-505, 512-523)
+    KVZ_FOR_THREADS(tid) {
       KVZ_CU8_ROLE(tid);
       u32 ssd = 0;
       if (on) {
         u8 *rp = &cv.at(c, (xl >> sh) + (e & (n - 1)), (yl >> sh) + (e >> l2));
         int v = *rp;
-        if (s->acc[6 + c]) { v = iclip(0, 255, (int)(i16)(tbuf(t, 1, c)[e] + v)); *rp = (u8)v; }
+        if (s->acc[6 + c]) {
+          const int shift = 12, add = 1 << (shift - 1), j = e >> l2, i = e & (n - 1);
+          const i16 *src = tbuf(t, 1, c);
+          int a = 0;
+          for (int k = 0; k < n; k++) a += dct_at(l2, k, i) * (int)src[(k << l2) + j];
+          const i16 res = (i16)iclip(-32768, 32767, (a + add) >> shift);
+          v = iclip(0, 255, (int)(i16)(res + v));
+          *rp = (u8)v;
+        }
         const int d = (int)*org_at(c, (xl >> sh) + (e & (n - 1)), (yl >> sh) + (e >> l2)) - v;
         ssd = (u32)(d * d);
       }
