@@ -1018,6 +1018,39 @@ template <bool CABAC> struct CtuProgramT {
   // search_intra.c:391-530 search_intra_rough: all 35 modes predicted + SATD-scored, then the reference's selection
   // order replayed on the cost table by one lane.  Leaves the winner in s->best_mode and the CU's info entries filled.
   // Also builds the chroma references of the CU (they only depend on neighbouring chroma reconstruction).
+#ifndef KVZ_HOSTSIM
+  // Wavefront minima by DPP row shifts (a lane without a source keeps its own value) + the four row results by lane index
+  KVZ_DEV static unsigned long long wave_min_u64(unsigned long long v)
+  {
+#define KVZ_MIN64_STEP(ctrl)                                                                                         \
+    {                                                                                                                \
+      const int lo_ = (int)(unsigned)v, hi_ = (int)(unsigned)(v >> 32);                                              \
+      const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp(lo_, lo_, ctrl, 0xF, 0xF, false);                    \
+      const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp(hi_, hi_, ctrl, 0xF, 0xF, false);                    \
+      const unsigned long long o = ((unsigned long long)ohi << 32) | olo;                                            \
+      v = o < v ? o : v;                                                                                             \
+    }
+    KVZ_MIN64_STEP(0x111) KVZ_MIN64_STEP(0x112) KVZ_MIN64_STEP(0x114) KVZ_MIN64_STEP(0x118)
+#undef KVZ_MIN64_STEP
+    unsigned long long r = ~0ull;
+    for (int row = 0; row < 4; row++) {
+      const unsigned long long o = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 16 * row + 15) << 32) |
+                                   (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 16 * row + 15);
+      r = o < r ? o : r;
+    }
+    return r;
+  }
+  KVZ_DEV static unsigned wave_min_u32(unsigned v)
+  {
+    int x = (int)v;
+#define KVZ_MIN32_STEP(ctrl) { const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(x, x, ctrl, 0xF, 0xF, false); x = (int)(o < (unsigned)x ? o : (unsigned)x); }
+    KVZ_MIN32_STEP(0x111) KVZ_MIN32_STEP(0x112) KVZ_MIN32_STEP(0x114) KVZ_MIN32_STEP(0x118)
+#undef KVZ_MIN32_STEP
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane(x, 15), b = (unsigned)__builtin_amdgcn_readlane(x, 31), c = (unsigned)__builtin_amdgcn_readlane(x, 47), d = (unsigned)__builtin_amdgcn_readlane(x, 63);
+    const unsigned ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+  }
+#endif
   template <class First>
   KVZ_DEV void rough_search(int lv, int x, int y, int depth, First first)
   {
@@ -1086,7 +1119,10 @@ template <bool CABAC> struct CtuProgramT {
         const double my_cost = (double)my_raw + s->mode_bits_cost[my_mode == s->preds[0] ? 1 : ((my_mode == s->preds[1] || my_mode == s->preds[2]) ? 2 : 0)];
         const int my_cost_lo = __double2loint(my_cost), my_cost_hi = __double2hiint(my_cost);
 #define KVZ_RAW(md) ((u32)__builtin_amdgcn_readlane((int)my_raw, __builtin_amdgcn_readfirstlane(md)))
-#define KVZ_COST(md, raw) __hiloint2double(__builtin_amdgcn_readlane(my_cost_hi, __builtin_amdgcn_readfirstlane(md)), __builtin_amdgcn_readlane(my_cost_lo, __builtin_amdgcn_readfirstlane(md)))
+        // On the device an append only records WHEN a mode was appended (in the lane that holds the mode); "first minimum in append
+        // order" is then one wavefront minimum of the costs -- non-negative doubles order like their bit patterns -- and one of
+        // the append positions among the lanes that reach it, instead of two v_readlane and a double compare per append.
+        int my_pos = 0, n_app = 0;
 #endif
         // The list kvazaar builds (modes[], costs[]) is only ever read back as "first minimum in append order", so it is
         // replayed with a visited mask and running minima instead of arrays.
@@ -1094,6 +1130,7 @@ template <bool CABAC> struct CtuProgramT {
         double final_cost = 0;
         int final_mode = -1;
         const int8_t p0 = s->preds[0], p1 = s->preds[1], p2 = s->preds[2];
+#ifdef KVZ_HOSTSIM
 #define KVZ_APPEND(md, raw)                                                                                         \
         {                                                                                                           \
           const int md_ = (md);                                                                                     \
@@ -1101,6 +1138,15 @@ template <bool CABAC> struct CtuProgramT {
           const double c_ = KVZ_COST(md_, raw);                                                                     \
           if (final_mode < 0 || c_ < final_cost) { final_cost = c_; final_mode = md_; }                             \
         }
+#else
+#define KVZ_APPEND(md, raw)                                                                                         \
+        {                                                                                                           \
+          const int md_ = __builtin_amdgcn_readfirstlane(md);                                                       \
+          visited |= 1ull << md_;                                                                                   \
+          if (tid == md_) my_pos = n_app;                                                                           \
+          n_app++;                                                                                                  \
+        }
+#endif
         int offset = log2w == 2 ? 2 : (log2w == 3 ? 4 : 8);
         int32_t min_cost = 0x7fffffff, max_cost = -0x7fffffff - 1;
         int best_mode = -1;
@@ -1130,7 +1176,17 @@ template <bool CABAC> struct CtuProgramT {
           if (!((visited >> add_modes[p]) & 1)) { const u32 raw = KVZ_RAW(add_modes[p]); KVZ_APPEND(add_modes[p], raw); }
 #undef KVZ_APPEND
 #undef KVZ_RAW
+#ifdef KVZ_HOSTSIM
 #undef KVZ_COST
+#else
+        {
+          const bool mine = tid < 35 && ((visited >> tid) & 1);
+          const unsigned long long key = mine ? (((unsigned long long)(unsigned)my_cost_hi << 32) | (unsigned)my_cost_lo) : ~0ull;
+          const unsigned long long kmin = wave_min_u64(key);
+          final_mode = (int)(wave_min_u32((mine && key == kmin) ? (unsigned)((my_pos << 6) | tid) : ~0u) & 63);
+          (void)final_cost;
+        }
+#endif
         (void)p0; (void)p1; (void)p2;
         if (tid == 0) s->best_mode = final_mode;
         // lcu_fill_cu_info (search.c:137-159) for the searched CU: at most 2x2 entries
