@@ -54,13 +54,15 @@ struct CtuSched {
   unsigned *error;        // set when a wait exceeds its spin bound (never in a healthy run)
   unsigned total, epoch;
   int no_wpp;             // items in raster order per picture; a row's first CTU also waits for the last CTU of the row above
+  unsigned spin_limit;    // bound of a wait, in polls: generous for WPP (a neighbour is at most a few CTUs away), scaled with the picture
+                          // without it (a picture is one serial chain: the workgroup holding its last CTU waits for all the others)
 };
 
-__device__ __forceinline__ bool wait_done(unsigned *flag, unsigned epoch, unsigned *error)
+__device__ __forceinline__ bool wait_done(unsigned *flag, unsigned epoch, unsigned *error, unsigned spin_limit)
 {
   for (unsigned spins = 0;; ++spins) {
     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
-    if (spins > (1u << 22)) { atomicExch(error, 1u); return false; }  // bounded: a lost hand-off must not hang the GPU
+    if (spins > spin_limit) { atomicExch(error, 1u); return false; }  // bounded: a lost hand-off must not hang the GPU
     __builtin_amdgcn_s_sleep(16);
   }
 }
@@ -83,9 +85,9 @@ template <bool CABAC> __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attri
     const int frame = item >> 16, y = (item >> 8) & 0xff, x = item & 0xff;
     if (threadIdx.x == 0) {
       unsigned *done = sched.done + (long)frame * ctus;
-      if (x > 0) wait_done(&done[y * F.wc + x - 1], sched.epoch, sched.error);
-      if (y > 0) wait_done(&done[(y - 1) * F.wc + (x + 1 < F.wc ? x + 1 : x)], sched.epoch, sched.error);  // above-right implies above and above-left
-      if (sched.no_wpp && x == 0 && y > 0) wait_done(&done[(y - 1) * F.wc + F.wc - 1], sched.epoch, sched.error);  // its contexts come from there
+      if (x > 0) wait_done(&done[y * F.wc + x - 1], sched.epoch, sched.error, sched.spin_limit);
+      if (y > 0) wait_done(&done[(y - 1) * F.wc + (x + 1 < F.wc ? x + 1 : x)], sched.epoch, sched.error, sched.spin_limit);  // above-right implies above and above-left
+      if (sched.no_wpp && x == 0 && y > 0) wait_done(&done[(y - 1) * F.wc + F.wc - 1], sched.epoch, sched.error, sched.spin_limit);  // its contexts come from there
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -325,7 +327,8 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
     b->epoch++;
     KVZ_HIP_CHECK(hipMemsetAsync(b->d_ticket, 0, 2 * sizeof(unsigned), b->stream));
     KVZ_HIP_CHECK(hipEventRecord(b->ev0, b->stream));
-    kvz::CtuSched sc{ cm.no_wpp ? b->d_items_raster : b->d_items, b->d_ticket, b->d_done, b->d_error, b->total_items, b->epoch, cm.no_wpp };
+    kvz::CtuSched sc{ cm.no_wpp ? b->d_items_raster : b->d_items, b->d_ticket, b->d_done, b->d_error, b->total_items, b->epoch, cm.no_wpp,
+                        cm.no_wpp ? (unsigned)((1u << 22) + (unsigned long long)F.wc * F.hc * 8192u > 0x7fffffffull ? 0x7fffffffu : (1u << 22) + (unsigned)(F.wc * F.hc) * 8192u) : (1u << 22) };
     // two instantiations: the one without the CABAC coefficient model carries none of its code, registers or context storage
     if (cm.coeff_cabac) hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel<true>, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);
     else hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel<false>, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);
