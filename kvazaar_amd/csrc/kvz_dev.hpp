@@ -237,7 +237,7 @@ dev_sad_surface_kernel(const u8 *cur, const u8 *ref, const int W, const int H, c
 // category from the sample and its two neighbours along the CTU's edge class, or from its band (sao-generic.c:84-124).
 // Neighbours always come from `in` (the deblocked picture); samples whose neighbour would lie outside the picture keep their
 // value (sao.c:324-349).  One lane per 4 samples of a plane row: dword load of the centre, byte loads of the six outer
-// neighbours it does not already hold, dword store.
+// neighbours it does not already hold, dword store; one workgroup per plane row.
 // Per (frame, CTU, plane) parameter record packed into 8 bytes for the sample kernel: type | class | band position | offsets[0..4]
 __global__ void __launch_bounds__(256) dev_sao_pack_kernel(const kvz_hip_sao_params *luma, const kvz_hip_sao_params *chroma, const long n_ctus, unsigned long long *packed)
 {
@@ -251,57 +251,59 @@ __global__ void __launch_bounds__(256) dev_sao_pack_kernel(const kvz_hip_sao_par
   for (int k = 0; k < 5; k++) v |= (unsigned long long)(u8)(int8_t)p->offsets[base + k] << (24 + 8 * k);
   packed[i] = v;
 }
-__global__ void __launch_bounds__(256) dev_sao_kernel(const u8 *in, u8 *out, const int W, const int H, const long dwords_per_frame, const long total,
-                                                      const unsigned long long *packed)
+// One workgroup per plane row (blockIdx.x = row of the frame's 2H plane rows: Y, then U, then V; blockIdx.y = frame), its lanes
+// striding over the row's dwords: no index arithmetic beyond a compare and a subtract per lane.
+__global__ void __launch_bounds__(256) dev_sao_kernel(const u8 *in, u8 *out, const int W, const int H, const unsigned long long *packed)
 {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const long frame = i / dwords_per_frame;
-  long r = i % dwords_per_frame;
-  const long yd = (long)(W >> 2) * H, cd = (long)(W >> 3) * (H >> 1);
-  const int color = r < yd ? 0 : (r < yd + cd ? 1 : 2);
-  r -= color == 0 ? 0 : (color == 1 ? yd : yd + cd);
+  const int frame = blockIdx.y, prow = blockIdx.x;
+  const int color = prow < H ? 0 : (prow < H + (H >> 1) ? 1 : 2);
+  const int y = prow - (color == 0 ? 0 : (color == 1 ? H : H + (H >> 1)));
   const int sh = color ? 1 : 0, fw = W >> sh, fh = H >> sh, wd = fw >> 2;
-  const int y = (int)(r / wd), x = 4 * (int)(r % wd);
-  const long plane = frame * ((long)W * H * 3 / 2) + (color == 0 ? 0 : (color == 1 ? (long)W * H : (long)W * H * 5 / 4));
+  const long plane = (long)frame * ((long)W * H * 3 / 2) + (color == 0 ? 0 : (color == 1 ? (long)W * H : (long)W * H * 5 / 4));
   const u8 *src = in + plane;
   const int wc = (W + 63) >> 6, lcu_shift = 6 - sh;
-  const unsigned long long rec = packed[(frame * wc * ((H + 63) >> 6) + (long)(y >> lcu_shift) * wc + (x >> lcu_shift)) * 3 + color];  // 4 | CTU width: one CTU per dword
-  const u32 centre = *reinterpret_cast<const u32 *>(src + (long)y * fw + x);
-  const int type = (int)(rec & 0xff);
-  u32 result = centre;
-  if (type == 1) {
-    const int bp = (int)((rec >> 16) & 0xff);
-    result = 0;
-    for (int k = 0; k < 4; k++) {
-      int v = (centre >> (8 * k)) & 0xff;
-      const int d = (v >> 3) - bp;
-      if (d >= 0 && d <= 3) v = iclip(0, 255, v + (int)(int8_t)(rec >> (24 + 8 * (d + 1))));
-      result |= (u32)v << (8 * k);
-    }
-  } else if (type == 2) {
-    // the 3 x 6 neighbourhood of the four samples: three dwords + the bytes left and right of them (clamped at the picture edge;
-    // samples whose neighbour is really outside keep their value below)
-    const int ym = y > 0 ? y - 1 : y, yp = y + 1 < fh ? y + 1 : y, xm = x > 0 ? x - 1 : x, xp = x + 4 < fw ? x + 4 : x + 3;
-    const u32 up = *reinterpret_cast<const u32 *>(src + (long)ym * fw + x), dn = *reinterpret_cast<const u32 *>(src + (long)yp * fw + x);
-    const unsigned long long row_u = ((unsigned long long)src[(long)ym * fw + xp] << 40) | ((unsigned long long)up << 8) | src[(long)ym * fw + xm];
-    const unsigned long long row_c = ((unsigned long long)src[(long)y * fw + xp] << 40) | ((unsigned long long)centre << 8) | src[(long)y * fw + xm];
-    const unsigned long long row_d = ((unsigned long long)src[(long)yp * fw + xp] << 40) | ((unsigned long long)dn << 8) | src[(long)yp * fw + xm];
-    int ax, ay, bx, by;
-    eo_offsets((int)((rec >> 8) & 0xff), ax, ay, bx, by);
-    const unsigned long long ra = ay < 0 ? row_u : (ay > 0 ? row_d : row_c), rb = by < 0 ? row_u : (by > 0 ? row_d : row_c);
-    result = 0;
-    for (int k = 0; k < 4; k++) {
-      int v = (centre >> (8 * k)) & 0xff;
-      const int xa = x + k + ax, ya = y + ay, xb = x + k + bx, yb = y + by;
-      if (xa >= 0 && xa < fw && ya >= 0 && ya < fh && xb >= 0 && xb < fw && yb >= 0 && yb < fh) {
-        const int a = (int)((ra >> (8 * (k + 1 + ax))) & 0xff), b = (int)((rb >> (8 * (k + 1 + bx))) & 0xff);
-        v = iclip(0, 255, v + (int)(int8_t)(rec >> (24 + 8 * eo_cat(a, b, v))));
+  const unsigned long long *recs = packed + ((long)frame * wc * ((H + 63) >> 6) + (long)(y >> lcu_shift) * wc) * 3 + color;
+  const int ym = y > 0 ? y - 1 : y, yp = y + 1 < fh ? y + 1 : y;
+  const u8 *row_c_ptr = src + (long)y * fw, *row_u_ptr = src + (long)ym * fw, *row_d_ptr = src + (long)yp * fw;
+  for (int xd = threadIdx.x; xd < wd; xd += 256) {
+    const int x = 4 * xd;
+    const unsigned long long rec = recs[(x >> lcu_shift) * 3];  // 4 | CTU width: one CTU per dword
+    const u32 centre = *reinterpret_cast<const u32 *>(row_c_ptr + x);
+    const int type = (int)(rec & 0xff);
+    u32 result = centre;
+    if (type == 1) {
+      const int bp = (int)((rec >> 16) & 0xff);
+      result = 0;
+      for (int k = 0; k < 4; k++) {
+        int v = (centre >> (8 * k)) & 0xff;
+        const int d = (v >> 3) - bp;
+        if (d >= 0 && d <= 3) v = iclip(0, 255, v + (int)(int8_t)(rec >> (24 + 8 * (d + 1))));
+        result |= (u32)v << (8 * k);
       }
-      result |= (u32)v << (8 * k);
+    } else if (type == 2) {
+      // the 3 x 6 neighbourhood of the four samples: three dwords + the bytes left and right of them (clamped at the picture edge;
+      // samples whose neighbour is really outside keep their value below)
+      const int xm = x > 0 ? x - 1 : x, xp = x + 4 < fw ? x + 4 : x + 3;
+      const u32 up = *reinterpret_cast<const u32 *>(row_u_ptr + x), dn = *reinterpret_cast<const u32 *>(row_d_ptr + x);
+      const unsigned long long row_u = ((unsigned long long)row_u_ptr[xp] << 40) | ((unsigned long long)up << 8) | row_u_ptr[xm];
+      const unsigned long long row_c = ((unsigned long long)row_c_ptr[xp] << 40) | ((unsigned long long)centre << 8) | row_c_ptr[xm];
+      const unsigned long long row_d = ((unsigned long long)row_d_ptr[xp] << 40) | ((unsigned long long)dn << 8) | row_d_ptr[xm];
+      int ax, ay, bx, by;
+      eo_offsets((int)((rec >> 8) & 0xff), ax, ay, bx, by);
+      const unsigned long long ra = ay < 0 ? row_u : (ay > 0 ? row_d : row_c), rb = by < 0 ? row_u : (by > 0 ? row_d : row_c);
+      result = 0;
+      for (int k = 0; k < 4; k++) {
+        int v = (centre >> (8 * k)) & 0xff;
+        const int xa = x + k + ax, ya = y + ay, xb = x + k + bx, yb = y + by;
+        if (xa >= 0 && xa < fw && ya >= 0 && ya < fh && xb >= 0 && xb < fw && yb >= 0 && yb < fh) {
+          const int a = (int)((ra >> (8 * (k + 1 + ax))) & 0xff), b = (int)((rb >> (8 * (k + 1 + bx))) & 0xff);
+          v = iclip(0, 255, v + (int)(int8_t)(rec >> (24 + 8 * eo_cat(a, b, v))));
+        }
+        result |= (u32)v << (8 * k);
+      }
     }
+    *reinterpret_cast<u32 *>(out + plane + (long)y * fw + x) = result;
   }
-  *reinterpret_cast<u32 *>(out + plane + (long)y * fw + x) = result;
 }
 
 struct DeblockGeom { int W, H, beta, tc, tc_c; long frame_bytes; const u8 *cu_depth; };
@@ -598,12 +600,12 @@ void kvz_hip_dev_sao_frames(const uint8_t *in, uint8_t *out, int width, int heig
                             const kvz_hip_sao_params *chroma)
 {
   if (n_frames <= 0) return;
-  const long per_frame = (long)(width >> 2) * height + 2L * (width >> 3) * (height >> 1), total = per_frame * n_frames;
   const long n_ctus = (long)n_frames * ((width + 63) >> 6) * ((height + 63) >> 6);
   unsigned long long *packed = nullptr;
   KVZ_HIP_CHECK(hipMallocAsync((void **)&packed, (size_t)n_ctus * 3 * sizeof(unsigned long long), be().stream));
   KVZ_DEV_LAUNCH(kvz::dev_sao_pack_kernel, 3 * n_ctus, luma, chroma, n_ctus, packed);
-  KVZ_DEV_LAUNCH(kvz::dev_sao_kernel, total, in, out, width, height, per_frame, total, packed);
+  hipLaunchKernelGGL(kvz::dev_sao_kernel, dim3((unsigned)(2 * height), (unsigned)n_frames), dim3(256), 0, be().stream, in, out, width, height, packed);
+  KVZ_HIP_CHECK(hipGetLastError());
   KVZ_HIP_CHECK(hipFreeAsync(packed, be().stream));
 }
 
