@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--frames", type=int, default=768, help="frames per GPU and step (the batch resident in HBM)")
+    ap.add_argument("--frames", type=int, default=1536, help="frames per GPU and step (the batch resident in HBM)")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames generated on the host; the batch cycles through them")
     ap.add_argument("--qp", type=int, default=22)
     ap.add_argument("--cpu-frames", type=int, default=8)

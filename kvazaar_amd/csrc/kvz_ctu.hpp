@@ -24,7 +24,7 @@
 //     stage; 16- and 32-point transforms on the matrix cores (kvz_mfma.hpp); an 8x8 CU with one lane per sample of any plane.
 //   * CTUs depend on their left and above-right neighbours' border records (reconstructed pixels, CU info, contexts) in HBM;
 //     one persistent launch draws CTUs from an in-order ticket list (kvz_batch.hpp).
-//   * The kernel is bound by VALU instruction issue (74 % of all slots): what counts is the number of instructions per CTU.
+//   * The kernel is bound by VALU instruction issue (77 % of all slots): what counts is the number of instructions per CTU.
 //
 // The program is a sequence of phases `KVZ_FOR_THREADS(tid) { ... } KVZ_SYNC();` with uniform control flow in
 // between.  tests/hostsim compiles it with KVZ_HOSTSIM, where a phase is a loop over tid -- exact emulation as long
