@@ -6,10 +6,15 @@ A "step" is one pass of the hot path (kvz_hip_intra_frames: search + reconstruct
 1080p frames that is already resident in HBM.  N GPUs = N processes (torch.distributed.run), each with its own batch
 (frames are independent pictures with -p 1: weak scaling, no data-path collective).
 
+After the timed region the batch is CHECKED: frames of the batch that hold the picture of tests/golden/encoder_recon.json
+(the reference encoder's own reconstruction of the first frame of the clip) are downloaded and hashed, and the device
+checksums of all frames of the batch must agree between copies of the same picture -> "verified" (false => exit code 1).
+
 Prints ONE JSON line on rank 0; see DESIGN.md "Measurement" for every field.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import subprocess
@@ -20,98 +25,207 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 BYTES_PER_CTU = 24576        # 6144 source + 6144 reconstruction + 12288 coefficient bytes per CTU
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
-COEFF_WEIGHTS_QP22 = 0x065403F0052C0004  # kvazaar's default fast-coeff-cost weights at QP 22 (fast_coeff_cost.h:48)
+GOLDEN = os.path.join(ROOT, "tests", "golden", "encoder_recon.json")
+
+
+def clip_seed(w, h):
+    """the 1080p clip is seed 1, the 2160p clip seed 2 (what the golden encoder digests were taken on)"""
+    return 2 if (w, h) == (3840, 2160) else 1
 
 
 def synth_frames(w, h, n, seed):
     """SURVEY.md App. C generator (1080p / 2160p branch), distinct frames"""
-    import synth
+    from kvazaar_amd import synth
     return [np.concatenate([p.reshape(-1) for p in planes]) for planes in synth.frames(w, h, n, seed, "large")]
 
 
-def pmc_traffic(args, launches):
-    """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE + WRITE_SIZE, collected with
-    rocprofv3 in separate passes and committed under profiles/): only reported when the committed measurement was taken
-    on this exact workload, otherwise null."""
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:24]
+
+
+def golden_digest(w, h, seed, qp, deblock, tiles=None, wpp=False, no_wpp=False):
+    """digest(s) of the reference encoder's reconstruction of frame 0 of the clip (tests/golden/make_golden.py clip_key), or None"""
+    try:
+        g = json.load(open(GOLDEN))
+    except (OSError, ValueError):
+        return None
+    key = (f"{w}x{h}/n1/seed{seed}/large/qp{qp}/{'deblock' if deblock else 'nodeblock'}" + ("/nowpp" if no_wpp else "")
+           + (f"/tiles{tiles}" + ("-wpp" if wpp else "") if tiles else ""))
+    if tiles:
+        v = g.get(key + "/per-tile")
+        return v[0] if v else None
+    v = g.get(key)
+    return v[0] if v else None
+
+
+def verify_batches(batches, distinct_n, golden_for):
+    """batches: [(HipBatch, slots)] with slots[i] = (distinct picture index, tile index or None) of batch frame i.
+    1. every frame's device checksum equals that of the first frame holding the same (picture, tile)  [whole batch]
+    2. three frames holding picture 0 (first / middle / last of the batch) are downloaded and hashed against the reference encoder's
+       reconstruction digest where the fixture has one  [golden]"""
+    consistent, checked, golden_ok, golden_n = True, 0, True, 0
+    for b, slots in batches:
+        sums = b.checksums()
+        first = {}
+        for i, s in enumerate(slots):
+            if s in first:
+                consistent &= bool((sums[i] == sums[first[s]]).all())
+            else:
+                first[s] = i
+            checked += 1
+        for tile in sorted({s[1] for s in slots}, key=lambda t: -1 if t is None else t):
+            want = golden_for(tile)
+            if want is None:
+                continue
+            idx = [i for i, s in enumerate(slots) if s == (0, tile)]
+            for i in sorted({idx[0], idx[len(idx) // 2], idx[-1]}):
+                golden_ok &= sha(b.download(i)["rec"]) == want
+                golden_n += 1
+    return {"frames_checksummed": checked, "copies_consistent": consistent, "golden_frames_hashed": golden_n,
+            "golden_ok": (golden_ok if golden_n else None)}
+
+
+def pmc_file(args, launches, pattern):
+    """the committed PMC measurement of this exact workload (profiles/<round>_*<pattern>), newest round first, else None"""
     import glob
     best = None
     if args.tiles:
         return None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
         try:
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
         w = d.get("workload", {})
         if (w.get("width"), w.get("height"), w.get("frames"), w.get("qp", 22)) == (args.width, args.height, args.frames, args.qp) and \
-                (w.get("schedule") == "ticket") == (launches == 1):
-            best = d
-    return None if best is None else best["bytes_per_launch"]
+                (w.get("schedule", "ticket") == "ticket") == (launches == 1):
+            best = (path, d)
+    return best
 
 
-def pmc_valu_issue(args, launches):
-    """share of the SIMDs' VALU issue slots the dominant kernel used (committed SQ counters of this exact workload, else null): the
-    bound of this kernel -- it is neither a streaming nor a matrix kernel"""
-    import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_sq.json"))):
-        try:
-            d = json.load(open(path))
-        except (OSError, ValueError):
-            continue
-        w = d.get("workload", {})
-        if (w.get("width"), w.get("height"), w.get("frames"), w.get("qp", 22)) == (args.width, args.height, args.frames, args.qp) and launches == 1 and not args.tiles:
-            best = d
-    return None if best is None else {"frac": best["valu_issue_frac"], "valu_insts_per_launch": best["insts_valu"], "salu_insts_per_launch": best["insts_salu"],
-                                      "source": "profiles/*pmc_sq.json: rocprofv3 --pmc SQ_INSTS_VALU / SQ_BUSY_CYCLES; a wave64 VALU instruction holds its SIMD for 4 cycles"}
+def limiter(args, launches):
+    """what actually bounds the CTU kernel (it is neither a streaming nor a matrix kernel): the share of the SIMDs' VALU issue
+    cycles it uses, from the committed SQ counters of this workload and the MEASURED cycles per wave64 VALU instruction
+    (tools/valu_issue_bench.hip -> profiles/*valu_issue.jsonl)"""
+    got = pmc_file(args, launches, "*pmc_sq.json")
+    if got is None:
+        return None
+    path, d = got
+    out = {"kind": "valu_issue", "source": os.path.relpath(path, ROOT)}
+    for k in ("valu_issue_frac", "cycles_per_valu_inst", "insts_valu", "insts_salu", "insts_lds", "lane_utilisation", "wave_issue_frac", "wave_wait_frac", "note"):
+        if k in d:
+            out[k] = d[k]
+    return out
+
+
+def run_encoder(ref_bin, yuv, w, h, qp, extra, n_frames):
+    """one reference encoder process -> (seconds, ok)"""
+    cmd = [ref_bin, "-i", yuv, "--input-res", f"{w}x{h}", "--preset", "ultrafast", "-p", "1", "-q", str(qp), "-n", str(n_frames), "-o", "/dev/null"] + extra
+    t = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    return time.time() - t, r.returncode == 0
 
 
 def cpu_baseline(args, frames, model):
-    """kvazaar's own AVX2 encoder (oracle/_ref, built from the reference sources) on all host cores over 64 of the benchmark's
-    frames (kind "reference"), with the oracle's single-core restatement of exactly this pass nested as "port"; only the port when
-    the prebuilt reference encoder is absent."""
-    import ctu_common as cc
+    """kvazaar's own encoder (oracle/_ref, built from the reference sources; whole encoder incl. CABAC + deblocking) on the GPU box's
+    host cores, SURVEY.md 8(d): (a) AVX2, one process with --threads = all host threads; (b) AVX2, saturated: nproc/16 concurrent
+    16-thread encoders on the same clip; (c) AVX2, 1 thread; (d) generic (--no-cpuid), 1 thread.  `value` = the best multi-core
+    figure.  The oracle's single-core restatement of exactly the CTU pass rides along as "port"."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctu_common as cc   # test infrastructure: the oracle runner, used for this leg only
     import flatapi
     out = {}
+    w, h = args.width, args.height
+    ctus_pf = ((w + 63) // 64) * ((h + 63) // 64)
     oracle = flatapi.load_oracle()
     n = max(1, min(len(frames), args.cpu_frames))
     t = time.time()
     for f in frames[:n]:
-        cc.run_oracle(oracle, model, args.width, args.height, f)
+        cc.run_oracle(oracle, model, w, h, f)
     dt = time.time() - t
-    ctus = n * ((args.width + 63) // 64) * ((args.height + 63) // 64)
-    out.update(value=ctus / dt, unit="CTUs/s", cores=1, kind="port",
-               sample=f"{n} of the benchmark's {args.width}x{args.height} frames through oracle/kvz_oracle_ctu.c (single thread, {dt:.1f} s)")
+    port = dict(value=n * ctus_pf / dt, unit="CTUs/s", cores=1, kind="port",
+                sample=f"{n} of the benchmark's {w}x{h} frames through oracle/kvz_oracle_ctu.c (single thread, {dt:.1f} s)")
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "kvazaar_ref")
-    if os.path.exists(ref_bin) and not args.no_ref_encoder:
-        import tempfile
-        nf = 64  # SURVEY.md 8(d): >= 60 frames for the reference timing; the benchmark's distinct frames, cycled
-        with tempfile.NamedTemporaryFile(suffix=".yuv", dir="/tmp") as tmp:
-            for i in range(nf):
-                tmp.write(frames[i % len(frames)].tobytes())
-            tmp.flush()
-            threads = os.cpu_count() or 1
-            cmd = [ref_bin, "-i", tmp.name, "--input-res", f"{args.width}x{args.height}", "--preset", "ultrafast", "-p", "1",
-                   "-q", str(args.qp), "--threads", str(threads), "-o", "/dev/null"]
-            times = []
-            for _ in range(3):
-                t = time.time()
-                r = subprocess.run(cmd, capture_output=True, text=True)
-                if r.returncode == 0:
-                    times.append(time.time() - t)
-            best = sorted(times)[len(times) // 2] if times else None
-            if best:
-                # the reference's own CPU path is the headline baseline; the single-core port of exactly this pass rides along
-                port = dict(out)
-                out = {"value": nf * ((args.width + 63) // 64) * ((args.height + 63) // 64) / best, "unit": "CTUs/s", "cores": threads, "kind": "reference",
-                       "sample": f"oracle/_ref/kvazaar_ref (kvazaar's AVX2 strategies, whole encoder incl. CABAC + deblocking) --preset ultrafast -p 1 -q {args.qp} --threads {threads}, "
-                                 f"{nf} frames of the benchmark's clip, median of 3, wall incl. file read",
-                       "port": port}
-    return out
+    if not os.path.exists(ref_bin) or args.no_ref_encoder:
+        return port
+    import tempfile
+    threads = os.cpu_count() or 1
+    with tempfile.NamedTemporaryFile(suffix=".yuv", dir="/tmp") as tmp:
+        nf = 128  # frames in the file: the benchmark's distinct frames, cycled
+        for i in range(nf):
+            tmp.write(frames[i % len(frames)].tobytes())
+        tmp.flush()
+
+        def median_of(extra, n_frames, reps):
+            ts = []
+            for _ in range(reps):
+                s, ok = run_encoder(ref_bin, tmp.name, w, h, args.qp, extra, n_frames)
+                if ok:
+                    ts.append(s)
+            return sorted(ts)[len(ts) // 2] if ts else None
+
+        legs = {}
+        s = median_of(["--threads", str(threads)], nf, 3)
+        if s:
+            legs["avx2_one_process_all_threads"] = {"value": nf * ctus_pf / s, "cores": threads, "sample": f"{nf} frames, --threads {threads}, median of 3, wall incl. start-up and file read ({s:.2f} s)"}
+        procs = max(1, threads // 16)
+        t = time.time()
+        ps = [subprocess.Popen([ref_bin, "-i", tmp.name, "--input-res", f"{w}x{h}", "--preset", "ultrafast", "-p", "1", "-q", str(args.qp), "-n", str(nf),
+                                "--threads", "16", "-o", "/dev/null"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for _ in range(procs)]
+        ok = all(p.wait() == 0 for p in ps)
+        s = time.time() - t
+        if ok:
+            legs["avx2_saturated"] = {"value": procs * nf * ctus_pf / s, "cores": threads,
+                                      "sample": f"{procs} concurrent encoders x --threads 16 x {nf} frames each, wall {s:.2f} s"}
+        n1 = 8 if w * h <= 1920 * 1080 else 2
+        s = median_of(["--threads", "0", "--owf", "0"], n1, 1)
+        if s:
+            legs["avx2_1_thread"] = {"value": n1 * ctus_pf / s, "cores": 1, "sample": f"{n1} frames, --threads 0 --owf 0 ({s:.2f} s)"}
+        s = median_of(["--no-cpuid", "--threads", "0", "--owf", "0"], n1, 1)
+        if s:
+            legs["generic_1_thread"] = {"value": n1 * ctus_pf / s, "cores": 1, "sample": f"{n1} frames, --no-cpuid --threads 0 --owf 0 ({s:.2f} s)"}
+    multi = [k for k in ("avx2_saturated", "avx2_one_process_all_threads") if k in legs]
+    if not multi:
+        return port
+    best = max(multi, key=lambda k: legs[k]["value"])
+    return {"value": legs[best]["value"], "unit": "CTUs/s", "cores": legs[best]["cores"], "kind": "reference",
+            "sample": f"oracle/_ref/kvazaar_ref (kvazaar's AVX2 strategies, whole encoder incl. CABAC + deblocking) --preset ultrafast -p 1 -q {args.qp}; best of the multi-core legs = "
+                      f"{best}: {legs[best]['sample']}", "legs": legs, "port": port}
+
+
+def build_batches(args, lib, rank, world, width, height, frames, tiles_arg, HipBatch):
+    """-> (batches [(HipBatch, slots)], distinct frames, CTUs per (whole) picture, job CTUs per step over all ranks)"""
+    from kvazaar_amd import sharding
+    seed = clip_seed(width, height)
+    batches = []
+    if tiles_arg:
+        cols, rows = (int(v) for v in tiles_arg.lower().split("x"))
+        tiles = sharding.tile_grid(width, height, cols, rows)
+        lo, hi = sharding.frames_for_rank(len(tiles), rank, world)
+        distinct = synth_frames(width, height, max(1, min(args.distinct, frames)), seed)  # every rank cuts the same clip
+        by_geometry = {}
+        for ti in range(lo, hi):
+            by_geometry.setdefault((tiles[ti][2], tiles[ti][3]), []).append(ti)
+        for (tw, th), tis in sorted(by_geometry.items()):
+            b = HipBatch(lib, tw, th, frames * len(tis))
+            subs = [[sharding.crop_tile(f, width, height, tiles[ti]) for f in distinct] for ti in tis]
+            slots = []
+            for i in range(frames):
+                for j, ti in enumerate(tis):
+                    b.upload(i * len(tis) + j, subs[j][i % len(distinct)])
+                    slots.append((i % len(distinct), ti))
+            batches.append((b, slots))
+        ctus_per_frame = sum(((t[2] + 63) // 64) * ((t[3] + 63) // 64) for t in tiles)
+        return batches, distinct, ctus_per_frame, frames * ctus_per_frame
+    distinct = synth_frames(width, height, max(1, min(args.distinct, frames)), seed + rank)
+    b = HipBatch(lib, width, height, frames)
+    for i in range(frames):
+        b.upload(i, distinct[i % len(distinct)])
+    batches.append((b, [(i % len(distinct), None) for i in range(frames)]))
+    return batches, distinct, b.ctus_per_frame, frames * b.ctus_per_frame * world
 
 
 def main():
@@ -127,6 +241,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-encoder", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the auxiliary legs (chain, chain_d2h, configs_extra); they only run at --gpus 1")
     ap.add_argument("--wpp", action="store_true", help="with --tiles: keep WPP on (kvazaar --tiles CxR --wpp); by default tiles imply --no-wpp as in kvazaar (cfg.c:925-978): "
                                                        "one coder per tile in raster order, i.e. one serial CTU chain per tile")
     ap.add_argument("--no-wpp", action="store_true", help="kvazaar --no-wpp: one serial CTU chain per picture (contexts run from the end of a row into the next)")
@@ -142,61 +257,38 @@ def main():
 
     import torch
     dist = None
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl")
-    else:
-        torch.cuda.set_device(local_rank)
 
-    import ctu_common as cc
     import kvazaar_amd
-    lib = kvazaar_amd.load_library()  # raises when libkvz_hip.so is missing: no fallback
-    model = cc.hip_cost_model(lib, args.qp, cc.coeff_weights(args.qp))
-    if args.frozen_contexts:
-        model.adaptive = 0
-    if args.no_wpp or (args.tiles and not args.wpp):
-        model.no_wpp = 1
-
     from kvazaar_amd import sharding
-    batches = []  # (HipBatch, CTUs per picture of that batch, pictures)
-    if args.tiles:
-        cols, rows = (int(v) for v in args.tiles.lower().split("x"))
-        tiles = sharding.tile_grid(args.width, args.height, cols, rows)
-        lo, hi = sharding.frames_for_rank(len(tiles), rank, world)
-        distinct = synth_frames(args.width, args.height, max(1, min(args.distinct, args.frames)), 1)  # every rank cuts the same clip
-        by_geometry = {}
-        for t in tiles[lo:hi]:
-            by_geometry.setdefault((t[2], t[3]), []).append(t)
-        for (tw, th), ts in sorted(by_geometry.items()):
-            b = cc.HipBatch(lib, tw, th, args.frames * len(ts))
-            subs = [[sharding.crop_tile(f, args.width, args.height, t) for f in distinct] for t in ts]
-            for i in range(args.frames):
-                for j in range(len(ts)):
-                    b.upload(i * len(ts) + j, subs[j][i % len(distinct)])
-            batches.append((b, lib.kvz_hip_batch_ctus_per_frame(C.c_void_p(b.handle)), args.frames * len(ts)))
-        ctus_per_frame = sum(((t[2] + 63) // 64) * ((t[3] + 63) // 64) for t in tiles)
-        job_ctus_per_step = args.frames * ctus_per_frame  # whole job, all ranks
-    else:
-        distinct = synth_frames(args.width, args.height, max(1, min(args.distinct, args.frames)), 1 + rank)
-        batch = cc.HipBatch(lib, args.width, args.height, args.frames)
-        for i in range(args.frames):
-            batch.upload(i, distinct[i % len(distinct)])
-        ctus_per_frame = lib.kvz_hip_batch_ctus_per_frame(C.c_void_p(batch.handle))
-        batches.append((batch, ctus_per_frame, args.frames))
-        job_ctus_per_step = args.frames * ctus_per_frame * world
+    from kvazaar_amd.batch import HipBatch, PinnedResults, cost_model
+    lib = kvazaar_amd.load_library()  # raises when libkvz_hip.so is missing: no fallback
+
+    def model_for(qp, tiles_arg=""):
+        m = cost_model(lib, qp)
+        if args.frozen_contexts:
+            m.adaptive = 0
+        if args.no_wpp or (tiles_arg and not args.wpp):
+            m.no_wpp = 1
+        return m
+
+    model = model_for(args.qp, args.tiles)
+    batches, distinct, ctus_per_frame, job_ctus_per_step = build_batches(args, lib, rank, world, args.width, args.height, args.frames, args.tiles, HipBatch)
 
     kernel_ms = []
     state = {"launches": 0}
 
     def step():
         n = 0
-        for b, _, _ in batches:  # asynchronous: batches of different geometry overlap on their own streams
-            n += lib.kvz_hip_intra_frames(b.handle, C.byref(model))
-        for b, _, _ in batches:
-            lib.kvz_hip_batch_sync(b.handle)
+        for b, _ in batches:  # asynchronous: batches of different geometry overlap on their own streams
+            n += b.launch(model)
+        for b, _ in batches:
+            b.sync()
         state["launches"] = n
-        kernel_ms.append(sum(b.kernel_ms() for b, _, _ in batches))
+        kernel_ms.append(sum(b.kernel_ms() for b, _ in batches))
 
     for _ in range(args.warmup):
         step()
@@ -206,52 +298,149 @@ def main():
     dt = sharding.timed_steps(step, args.steps, dist, torch.cuda.synchronize, "cuda")
     launches = state["launches"]
 
+    # ---- what was timed is checked (every rank; the verdicts are AND-ed) ----
+    seed0 = clip_seed(args.width, args.height)
+    golden_applies = rank == 0 or bool(args.tiles)  # frame-sharded ranks > 0 hold other clips (seed + rank): consistency check only
+    def golden_for(tile):
+        if not golden_applies or args.frozen_contexts:
+            return None
+        if tile is not None:  # per-tile digests of the tiled encode
+            per_tile = golden_digest(args.width, args.height, seed0, args.qp, 0, args.tiles, args.wpp)
+            return per_tile[tile] if per_tile else None
+        return golden_digest(args.width, args.height, seed0, args.qp, 0, None, False, bool(model.no_wpp))
+
+    verify = verify_batches(batches, len(distinct), golden_for)
+    ok_local = verify["copies_consistent"] and verify["golden_ok"] is not False
+    if dist is not None:
+        t = torch.tensor([1 if ok_local else 0, verify["golden_frames_hashed"]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok_all = bool(t[0].item())
+    else:
+        ok_all = ok_local
+
     if rank == 0:
         total_ctus = job_ctus_per_step * args.steps
         value = total_ctus / dt
         # dominant kernel = the CTU kernel: all launches of a step are that kernel; HIP events on the batch's own stream
         k_ms = float(np.mean(kernel_ms))  # rank 0's launches
         per_launch_s = k_ms / 1e3 / launches
-        bytes_per_launch = sum(c * n for _, c, n in batches) * BYTES_PER_CTU / launches
+        rank_ctus = sum(b.ctus_per_frame * b.n for b, _ in batches)
+        bytes_per_launch = rank_ctus * BYTES_PER_CTU / launches
         achieved = bytes_per_launch / per_launch_s / 1e9
+        traffic = pmc_file(args, launches, "*pmc_traffic.json")
         result = {
             "metric": "CTUs/s (all-intra ultrafast hot path)", "value": value, "unit": "CTUs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.tiles else "weak", "vs_baseline": None,
             "dtype": "u8/i16 (f64 RD costs)", "data": "synthetic",
             "fps": value / ctus_per_frame,
+            # golden_ok None = the fixture has no encoder digest for this workload (only the copy-consistency check ran)
+            "verified": bool(ok_all and (verify["golden_ok"] is True or verify["golden_ok"] is None)), "verify": verify,
             "config": {"workload": f"{args.width}x{args.height} yuv420p 8-bit all-intra ultrafast CTU pass (kvz_hip_intra_frames), QP {args.qp}",
                        "frames_per_gpu_per_step": None if args.tiles else args.frames, "frames_per_step": args.frames if args.tiles else args.frames * world,
                        "ctus_per_frame": ctus_per_frame, "distinct_frames": len(distinct),
                        "wpp": not bool(model.no_wpp),
                        "parallelism": (f"--tiles {args.tiles}: tiles sharded over {world} GPU(s), no data-path collective" if args.tiles
                                        else f"frames sharded over {world} GPU(s), no data-path collective")},
+            # "bound" names the roof the fraction is taken against (the task's enum: hbm | mfma); what limits this kernel is "limiter"
             "roofline": {"bound": "hbm", "kernel": "intra_ctu_ticket_kernel" if launches == 1 else "intra_ctu_wave_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args, launches), "valu_issue": pmc_valu_issue(args, launches), "traffic_source": "profiles/*pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, raw counters x 1024) on this workload, else null",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if traffic is None else traffic[1]["bytes_per_launch"],
+                         "traffic_source": None if traffic is None else os.path.relpath(traffic[0], ROOT) + ": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on this workload",
+                         "limiter": limiter(args, launches),
                          "launches_per_step": launches,
                          "avg_launch_us": per_launch_s * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "instruction-issue-bound CTU search (valu_issue.frac of the SIMDs' VALU slots), not a streaming kernel (DESIGN.md 5); per-kernel HBM and MFMA fractions of the streaming primitives: bench_kernels.py"},
+                         "note": "the CTU search is a latency x concurrency machine limited by VALU issue (limiter), not a streaming kernel (DESIGN.md 5); per-kernel HBM and MFMA fractions of the streaming primitives: bench_kernels.py"},
         }
-        # auxiliary: the per-picture chain an encoder needs from the device before entropy coding -- CTU pass, deblocking, picture
-        # hash -- timed the same way on rank 0's batches (not the headline: BASELINE's metric is the CTU pass)
-        lib.kvz_hip_batch_deblock.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
-        lib.kvz_hip_batch_checksums.argtypes = [C.c_void_p, C.c_void_p]
-        sums = [np.zeros((n, 3), np.uint32) for _, _, n in batches]
-        t0 = time.perf_counter()
-        for b, _, _ in batches:
-            lib.kvz_hip_intra_frames(b.handle, C.byref(model))
-            lib.kvz_hip_batch_deblock(b.handle, args.qp, 0, 0)
-        for (b, _, _), o in zip(batches, sums):
-            lib.kvz_hip_batch_checksums(b.handle, o.ctypes.data)
-        chain_s = time.perf_counter() - t0
-        result["chain"] = {"stages": "CTU pass + deblocking + picture-hash checksums (rank 0)", "value": sum(c * n for _, c, n in batches) / chain_s,
-                           "unit": "CTUs/s", "ms": chain_s * 1e3}
+        if world == 1 and not args.no_extra:
+            extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedResults)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, distinct, model)
         print(json.dumps(result))
-    for b, _, _ in batches:
+    for b, _ in batches:
         b.close()
     if dist is not None:
         dist.destroy_process_group()
+    if not ok_all:
+        sys.exit(1)
+
+
+def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedResults):
+    """auxiliary measurements at --gpus 1 (not the headline):
+    chain      CTU pass + deblocking + picture-hash checksums of the whole batch
+    chain_d2h  the same + download of everything the host entropy coder needs (coefficients, CU depth / mode, reconstruction of every
+               frame) into pinned host memory, two half-size batches alternating on their own streams so that one batch's D2H
+               overlaps the other's kernel: "frames an encoder can actually consume per second"
+    configs_extra  a short 3840x2160 run (the north-star size), verified against the reference encoder's 4K digest"""
+    rank_ctus = sum(b.ctus_per_frame * b.n for b, _ in batches)
+    t0 = time.perf_counter()
+    for b, _ in batches:
+        b.launch(model)
+        b.deblock(args.qp, wait=False)
+    for b, _ in batches:
+        b.checksums()
+    chain_s = time.perf_counter() - t0
+    result["chain"] = {"stages": "CTU pass + deblocking + picture-hash checksums", "value": rank_ctus / chain_s, "unit": "CTUs/s", "ms": chain_s * 1e3}
+    if args.tiles:
+        return
+    # ---- chain + D2H, double-buffered ----
+    main_batch = batches[0][0]
+    half = max(1, min(args.frames // 2, 384))
+    distinct = synth_frames(args.width, args.height, max(1, min(args.distinct, half)), clip_seed(args.width, args.height))
+    pair = []
+    for _ in range(2):
+        b = HipBatch(lib, args.width, args.height, half)
+        for i in range(half):
+            b.upload(i, distinct[i % len(distinct)])
+        pair.append((b, PinnedResults(b)))
+    reps = 3
+
+    def run(with_d2h):
+        for b, _ in pair:
+            b.sync()
+        t = time.perf_counter()
+        for _ in range(reps):
+            for b, pinned in pair:
+                b.sync()          # the host is done with this batch's previous results
+                b.launch(model)
+                b.deblock(args.qp, wait=False)
+                if with_d2h:
+                    pinned.download_async()
+        for b, _ in pair:
+            b.sync()
+        return time.perf_counter() - t
+
+    run(True)  # warm-up (first touch of the pinned pages)
+    s_plain, s_d2h = run(False), run(True)
+    ctus = 2 * reps * half * main_batch.ctus_per_frame
+    payload = pair[0][1].bytes / half
+    # the downloaded bytes are the device's: frame 0 of the pinned buffer == the golden picture (deblocked) where the fixture has it
+    want = golden_digest(args.width, args.height, clip_seed(args.width, args.height), args.qp, 1)
+    got = sha(pair[0][1].array("rec")[:args.width * args.height * 3 // 2])
+    result["chain_d2h"] = {"stages": "CTU pass + deblocking + D2H of coefficients, CU depth/mode and reconstruction of every frame into pinned host memory; two batches of "
+                                     f"{half} frames alternating on two streams", "value": ctus / s_d2h, "unit": "CTUs/s", "fps": ctus / s_d2h / main_batch.ctus_per_frame,
+                           "without_d2h": ctus / s_plain, "payload_bytes_per_frame": payload, "pcie_GBps": 2 * reps * half * payload / s_d2h / 1e9,
+                           "host_copy_verified": (got == want) if want else None}
+    for b, pinned in pair:
+        b.close()
+        pinned.close()
+    # ---- the north-star size ----
+    if (args.width, args.height) != (3840, 2160):
+        w, h, n4k = 3840, 2160, 384
+        m4 = model_for(args.qp)
+        d4 = synth_frames(w, h, 4, clip_seed(w, h))
+        b4 = HipBatch(lib, w, h, n4k)
+        for i in range(n4k):
+            b4.upload(i, d4[i % len(d4)])
+        b4.run(m4)
+        steps = 3
+        t = time.perf_counter()
+        for _ in range(steps):
+            b4.run(m4)
+        s = time.perf_counter() - t
+        v = verify_batches([(b4, [(i % len(d4), None) for i in range(n4k)])], len(d4), lambda tile: golden_digest(w, h, clip_seed(w, h), args.qp, 0))
+        result["configs_extra"] = [{"workload": f"{w}x{h} yuv420p 8-bit all-intra ultrafast CTU pass, QP {args.qp}, {n4k} frames resident, {steps} steps",
+                                    "value": steps * n4k * b4.ctus_per_frame / s, "unit": "CTUs/s", "fps": steps * n4k / s, "kernel_ms": b4.kernel_ms(),
+                                    "verified": bool(v["copies_consistent"] and v["golden_ok"] is not False), "verify": v}]
+        b4.close()
 
 
 if __name__ == "__main__":

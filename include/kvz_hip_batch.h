@@ -36,15 +36,29 @@ void           kvz_hip_batch_destroy(kvz_hip_batch *b);
 /* Host <-> HBM.  Planes are tightly packed (stride = width; chroma width/2 x height/2). */
 void kvz_hip_batch_upload(kvz_hip_batch *b, int frame, const uint8_t *y, const uint8_t *u, const uint8_t *v);
 /* Any output pointer may be NULL.  coeff: KVZ_HIP_CTU_COEFFS int16 per CTU (raster CTU order, lcu_t z-order inside);
- * cu_depth / cu_mode: one byte per 8x8 block (raster, stride width/8); ctu_cost: one double per CTU. */
-void kvz_hip_batch_download(kvz_hip_batch *b, int frame, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, int16_t *coeff,
+ * cu_depth / cu_mode: one byte per 8x8 block (raster, stride width/8); ctu_cost: one double per CTU.
+ * Returns 0, or -1 when the run that produced the data was invalid (see kvz_hip_batch_sync). */
+int  kvz_hip_batch_download(kvz_hip_batch *b, int frame, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, int16_t *coeff,
                             uint8_t *cu_depth, uint8_t *cu_mode, double *ctu_cost);
+
+/* Pinned host memory (hipHostMalloc) for the asynchronous transfers below; plain malloc'ed buffers work too but serialise. */
+void *kvz_hip_host_alloc(size_t bytes);
+void  kvz_hip_host_free(void *p);
+/* Queues the download of what the entropy coder needs of EVERY frame of the batch (encode_coding_tree.c:745 reads the coefficients,
+ * cu_info and -- for the next stages -- the reconstruction) on the batch's stream, behind whatever it holds: with pinned
+ * destinations the copies overlap the kernels of other batches' streams (two batches alternating = double buffering).
+ * Layouts as kvz_hip_batch_download, frames back to back; NULL skips a buffer.  kvz_hip_batch_sync() waits and validates. */
+void kvz_hip_batch_download_all_async(kvz_hip_batch *b, uint8_t *rec, int16_t *coeff, uint8_t *cu_depth, uint8_t *cu_mode);
 
 /* The hot path: search + reconstruct every CTU of every frame in the batch.  Asynchronous on the batch's stream;
  * kvz_hip_batch_sync() waits.  Returns the number of kernel launches issued (1; one per CTU anti-diagonal with the older
  * schedule behind KVZ_HIP_SCHED=wave). */
 int  kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model);
-void kvz_hip_batch_sync(kvz_hip_batch *b);
+/* Waits for the batch's stream.  Returns 0, or -1 when a CTU hand-off wait inside a pass timed out (workgroups wait for their
+ * neighbours' results with a wall-clock bound -- 30 s per wait, KVZ_HIP_WAIT_MS overrides -- so that a lost hand-off cannot hang
+ * the GPU): the batch's results are then invalid and every later sync / download / checksum call of the batch reports -1 too.
+ * HIP runtime failures (no device, out of memory, launch failure) stay fatal, as in the per-call path. */
+int  kvz_hip_batch_sync(kvz_hip_batch *b);
 /* Device time of the launches of the last kvz_hip_intra_frames call, from HIP events recorded on the batch's own
  * stream around the launch sequence (milliseconds); call after kvz_hip_batch_sync(). */
 float kvz_hip_batch_last_kernel_ms(kvz_hip_batch *b);
@@ -60,12 +74,15 @@ void kvz_hip_batch_deblock(kvz_hip_batch *b, int qp, int beta_offset_div2, int t
 
 /* Picture-hash checksums (nal.c:73-86 kvz_image_checksum) of every frame's current reconstruction: host_out[3 * f + plane].
  * Queued behind whatever the batch's stream holds (CTU pass, deblocking) and waited for. */
-void kvz_hip_batch_checksums(kvz_hip_batch *b, uint32_t *host_out);
+int  kvz_hip_batch_checksums(kvz_hip_batch *b, uint32_t *host_out);  /* 0 / -1 like kvz_hip_batch_sync */
 
 /* Cost model of an I slice at `qp` (kvz_hip_intra_cost_model, adaptive contexts): HEVC context init values
  * (context.c:96-134), kvz_ctx_init (context.c:202-213), the HM entropy table (rdo.c:69-80), lambda of
  * rate_control.c:678-691.  coeff_weights = kvz_fast_coeff_get_weights(state) of the encoder (fast_coeff_cost.c:84-88). */
 void kvz_hip_intra_cost_model_init(int qp, uint64_t coeff_weights, kvz_hip_intra_cost_model *model);
+/* kvz_fast_coeff_get_weights for kvazaar's built-in table (fast_coeff_cost.h:48-101 packed by fast_coeff_cost.c:39-52); 0 for
+ * QP >= MAX_FAST_COEFF_COST_QP (50), where kvazaar never uses the fast estimate (rdo.c:311-340). */
+uint64_t kvz_hip_default_coeff_weights(int qp);
 
 #ifdef __cplusplus
 }

@@ -37,11 +37,13 @@ typedef struct {
   int width, height, qp;
   uint8_t *rec, *depth, *mode; /* tight planes Y|U|V; one byte per 8x8 */
   int16_t *coeff;              /* KVZ_HIP_CTU_COEFFS per LCU, raster LCU order */
+  int outstanding;             /* LCUs of the picture that have not copied their part yet; the slot is only reused at 0 (under g_lock) */
 } picture_result;
 
-#define N_SLOTS 16
-static picture_result g_slots[N_SLOTS];
-static int g_next_slot;
+/* One slot per picture in flight: (owf + 1) x tiles of them at most, so the table grows on demand and a slot is never recycled
+ * while an LCU of its picture is still to come (every LCU of a picture passes through kvz_search_lcu exactly once). */
+static picture_result **g_slots;
+static int g_n_slots;
 static kvz_hip_batch *g_batch;
 static int g_batch_w, g_batch_h;
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -69,14 +71,19 @@ static int eligible(const encoder_state_t *state)
 }
 
 /* the picture's results, computed on first request */
-static const picture_result *picture_of(const encoder_state_t *state)
+static picture_result *picture_of(const encoder_state_t *state)
 {
   const videoframe_t *frame = state->tile->frame;
   pthread_mutex_lock(&g_lock);
-  for (int i = 0; i < N_SLOTS; i++)
-    if (g_slots[i].frame == frame && g_slots[i].num == state->frame->num) { pthread_mutex_unlock(&g_lock); return &g_slots[i]; }
-  picture_result *r = &g_slots[g_next_slot];
-  g_next_slot = (g_next_slot + 1) % N_SLOTS;
+  picture_result *r = NULL;
+  for (int i = 0; i < g_n_slots; i++)
+    if (g_slots[i]->outstanding > 0 && g_slots[i]->frame == frame && g_slots[i]->num == state->frame->num) { pthread_mutex_unlock(&g_lock); return g_slots[i]; }
+  for (int i = 0; i < g_n_slots && !r; i++)
+    if (g_slots[i]->outstanding == 0) r = g_slots[i];
+  if (!r) {
+    g_slots = realloc(g_slots, (size_t)(g_n_slots + 1) * sizeof *g_slots);
+    r = g_slots[g_n_slots++] = calloc(1, sizeof *r);
+  }
   const int w = frame->width, h = frame->height, wc = (w + 63) / 64, hc = (h + 63) / 64;
   const size_t ys = (size_t)w * h, cs = ys / 4;
   if (r->width != w || r->height != h) {
@@ -108,10 +115,16 @@ static const picture_result *picture_of(const encoder_state_t *state)
   model.no_wpp = !cfg->wpp;  /* kvazaar switches WPP off when tiles are used (cfg.c:925-978) */
   kvz_hip_batch_upload(g_batch, 0, src, src + ys, src + ys + cs);
   kvz_hip_intra_frames(g_batch, &model);
-  kvz_hip_batch_sync(g_batch);
-  kvz_hip_batch_download(g_batch, 0, r->rec, r->rec + ys, r->rec + ys + cs, r->coeff, r->depth, r->mode, NULL);
+  /* the library reports an invalid run instead of aborting; this binding has no other search to fall back to for a picture whose
+   * LCUs are already being handed out, so it stops the encoder */
+  if (kvz_hip_batch_sync(g_batch) != 0 ||
+      kvz_hip_batch_download(g_batch, 0, r->rec, r->rec + ys, r->rec + ys + cs, r->coeff, r->depth, r->mode, NULL) != 0) {
+    fprintf(stderr, "search_lcu_hip: the device pass failed for picture %d\n", (int)state->frame->num);
+    abort();
+  }
   free(src);
   r->frame = frame; r->num = state->frame->num; r->qp = state->qp;
+  r->outstanding = wc * hc;
   {  /* KVZ_HIP_BATCH_TRACE=<file>: number of pictures searched on the device so far (tests check the path was taken) */
     static int pictures;
     const char *trace = getenv("KVZ_HIP_BATCH_TRACE");
@@ -137,7 +150,7 @@ static unsigned zorder16(int x, int y) /* cu.h:385-421 xy_to_zorder for 4-sample
 void __wrap_kvz_search_lcu(encoder_state_t *const state, const int x, const int y, const yuv_t *const hor_buf, const yuv_t *const ver_buf)
 {
   if (!eligible(state)) { __real_kvz_search_lcu(state, x, y, hor_buf, ver_buf); return; }
-  const picture_result *r = picture_of(state);
+  picture_result *r = picture_of(state);
   videoframe_t *frame = state->tile->frame;
   const int w = r->width, h = r->height, w8 = w / 8, wc = (w + 63) / 64;
   const size_t ys = (size_t)w * h, cs = ys / 4;
@@ -186,4 +199,7 @@ void __wrap_kvz_search_lcu(encoder_state_t *const state, const int x, const int 
   memcpy(state->coeff->y, plane[0], 4096 * sizeof(int16_t));
   memcpy(state->coeff->u, plane[1], 1024 * sizeof(int16_t));
   memcpy(state->coeff->v, plane[2], 1024 * sizeof(int16_t));
+  pthread_mutex_lock(&g_lock);
+  r->outstanding--;  /* this LCU is done with the slot's buffers */
+  pthread_mutex_unlock(&g_lock);
 }

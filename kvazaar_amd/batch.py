@@ -1,0 +1,154 @@
+"""ctypes view of include/kvz_hip_batch.h: the batched, device-resident all-intra CTU pass (kvz_hip_intra_frames) and what follows
+it per picture (deblocking, picture hashes).  Used by bench.py, __graft_entry__.smoke(), tools/ and the GPU tests; no checker code
+in here (the oracle runners are in tests/ctu_common.py)."""
+import ctypes as C
+
+import numpy as np
+
+from .capi import i16p, ptr, u8p
+
+
+class CostModel(C.Structure):
+    """kvz_hip_intra_cost_model (include/kvz_hip_types.h)"""
+    _fields_ = [("lambda_", C.c_double), ("lambda_sqrt", C.c_double), ("split_flag", (C.c_float * 2) * 3),
+                ("part_size", C.c_float * 2), ("intra_mode", C.c_float * 2), ("chroma_mode", C.c_float * 2),
+                ("cbf_luma", (C.c_float * 2) * 2), ("cbf_chroma", (C.c_float * 2) * 2), ("coeff_weights", C.c_uint64),
+                ("qp", C.c_int32), ("adaptive", C.c_int32), ("coeff_cabac", C.c_int32), ("no_wpp", C.c_int32), ("ctx_init", C.c_uint8 * 160),
+                ("entropy_fbits", C.c_float * 128)]
+
+    def key(self):
+        return bytes(self)
+
+
+def default_coeff_weights(lib, qp):
+    """kvz_fast_coeff_get_weights of kvazaar's built-in table (kvz_hip_default_coeff_weights)"""
+    lib.kvz_hip_default_coeff_weights.restype = C.c_uint64
+    lib.kvz_hip_default_coeff_weights.argtypes = [C.c_int]
+    return int(lib.kvz_hip_default_coeff_weights(qp))
+
+
+def cost_model(lib, qp, weights=None):
+    """kvz_hip_intra_cost_model_init: the model of an I slice at `qp` as `kvazaar --preset ultrafast` sets it up"""
+    m = CostModel()
+    lib.kvz_hip_intra_cost_model_init.argtypes = [C.c_int, C.c_uint64, C.POINTER(CostModel)]
+    lib.kvz_hip_intra_cost_model_init.restype = None
+    lib.kvz_hip_intra_cost_model_init(qp, default_coeff_weights(lib, qp) if weights is None else weights, C.byref(m))
+    return m
+
+
+def outputs(width, height):
+    """host arrays of one picture's results: reconstruction Y|U|V, coefficients, CU depth / intra mode per 8x8, CTU costs"""
+    nctu = ((width + 63) // 64) * ((height + 63) // 64)
+    ncu = (width // 8) * (height // 8)
+    return dict(rec=np.zeros(width * height * 3 // 2, np.uint8), coeff=np.zeros(nctu * 6144, np.int16),
+                depth=np.zeros(ncu, np.uint8), mode=np.zeros(ncu, np.uint8), cost=np.zeros(nctu, np.float64))
+
+
+class BatchError(RuntimeError):
+    """a pass of the batch was invalid (kvz_hip_batch_sync returned -1)"""
+
+
+class HipBatch:
+    """kvz_hip_batch_* through ctypes"""
+
+    def __init__(self, lib, width, height, n_frames):
+        self.lib, self.w, self.h, self.n = lib, width, height, n_frames
+        vp, ci = C.c_void_p, C.c_int
+        lib.kvz_hip_batch_create.restype = vp
+        lib.kvz_hip_batch_create.argtypes = [ci, ci, ci]
+        lib.kvz_hip_batch_destroy.argtypes = [vp]
+        lib.kvz_hip_batch_destroy.restype = None
+        lib.kvz_hip_batch_upload.argtypes = [vp, ci, u8p, u8p, u8p]
+        lib.kvz_hip_batch_upload.restype = None
+        lib.kvz_hip_batch_download.argtypes = [vp, ci, u8p, u8p, u8p, i16p, u8p, u8p, C.POINTER(C.c_double)]
+        lib.kvz_hip_batch_download.restype = ci
+        lib.kvz_hip_intra_frames.argtypes = [vp, C.POINTER(CostModel)]
+        lib.kvz_hip_intra_frames.restype = ci
+        lib.kvz_hip_batch_sync.argtypes = [vp]
+        lib.kvz_hip_batch_sync.restype = ci
+        lib.kvz_hip_batch_last_kernel_ms.argtypes = [vp]
+        lib.kvz_hip_batch_last_kernel_ms.restype = C.c_float
+        lib.kvz_hip_batch_ctus_per_frame.argtypes = [vp]
+        lib.kvz_hip_batch_ctus_per_frame.restype = ci
+        lib.kvz_hip_batch_deblock.argtypes = [vp, ci, ci, ci]
+        lib.kvz_hip_batch_deblock.restype = None
+        lib.kvz_hip_batch_checksums.argtypes = [vp, vp]
+        lib.kvz_hip_batch_checksums.restype = ci
+        self.handle = lib.kvz_hip_batch_create(width, height, n_frames)
+        if not self.handle:
+            raise RuntimeError(f"kvz_hip_batch_create({width}, {height}, {n_frames}) failed")
+        self.ctus_per_frame = lib.kvz_hip_batch_ctus_per_frame(self.handle)
+
+    def upload(self, frame, yuv):
+        ys, cs = self.w * self.h, self.w * self.h // 4
+        self.lib.kvz_hip_batch_upload(self.handle, frame, ptr(yuv), ptr(yuv, offset=ys), ptr(yuv, offset=ys + cs))
+
+    def launch(self, model):
+        """asynchronous on the batch's stream; returns the number of kernel launches"""
+        return self.lib.kvz_hip_intra_frames(self.handle, C.byref(model))
+
+    def sync(self):
+        if self.lib.kvz_hip_batch_sync(self.handle) != 0:
+            raise BatchError("kvz_hip_batch_sync: a CTU hand-off wait timed out; results invalid")
+
+    def run(self, model):
+        n = self.launch(model)
+        self.sync()
+        return n
+
+    def deblock(self, qp, beta_offset_div2=0, tc_offset_div2=0, wait=True):
+        self.lib.kvz_hip_batch_deblock(self.handle, qp, beta_offset_div2, tc_offset_div2)
+        if wait:
+            self.sync()
+
+    def checksums(self):
+        out = np.zeros((self.n, 3), np.uint32)
+        if self.lib.kvz_hip_batch_checksums(self.handle, out.ctypes.data) != 0:
+            raise BatchError("kvz_hip_batch_checksums: the batch's last pass was invalid")
+        return out
+
+    def kernel_ms(self):
+        return self.lib.kvz_hip_batch_last_kernel_ms(self.handle)
+
+    def download(self, frame):
+        o = outputs(self.w, self.h)
+        ys, cs = self.w * self.h, self.w * self.h // 4
+        rc = self.lib.kvz_hip_batch_download(self.handle, frame, ptr(o["rec"]), ptr(o["rec"], offset=ys), ptr(o["rec"], offset=ys + cs),
+                                             ptr(o["coeff"]), ptr(o["depth"]), ptr(o["mode"]), o["cost"].ctypes.data_as(C.POINTER(C.c_double)))
+        if rc != 0:
+            raise BatchError("kvz_hip_batch_download: the batch's last pass was invalid")
+        return o
+
+    def close(self):
+        if self.handle:
+            self.lib.kvz_hip_batch_destroy(self.handle)
+            self.handle = None
+
+
+class PinnedResults:
+    """pinned host buffers for kvz_hip_batch_download_all_async: everything the host entropy coder needs of every frame of a batch"""
+
+    def __init__(self, batch):
+        lib, w, h, n = batch.lib, batch.w, batch.h, batch.n
+        lib.kvz_hip_host_alloc.restype = C.c_void_p
+        lib.kvz_hip_host_alloc.argtypes = [C.c_size_t]
+        lib.kvz_hip_host_free.restype = None
+        lib.kvz_hip_host_free.argtypes = [C.c_void_p]
+        lib.kvz_hip_batch_download_all_async.restype = None
+        lib.kvz_hip_batch_download_all_async.argtypes = [C.c_void_p] * 5
+        self.lib, self.batch = lib, batch
+        self.sizes = dict(rec=w * h * 3 // 2 * n, coeff=batch.ctus_per_frame * 6144 * 2 * n, depth=(w // 8) * (h // 8) * n, mode=(w // 8) * (h // 8) * n)
+        self.ptrs = {k: lib.kvz_hip_host_alloc(v) for k, v in self.sizes.items()}
+        self.bytes = sum(self.sizes.values())
+
+    def download_async(self):
+        self.lib.kvz_hip_batch_download_all_async(self.batch.handle, self.ptrs["rec"], self.ptrs["coeff"], self.ptrs["depth"], self.ptrs["mode"])
+
+    def array(self, name, dtype=np.uint8):
+        buf = (C.c_uint8 * self.sizes[name]).from_address(self.ptrs[name])
+        return np.frombuffer(buf, dtype=dtype)
+
+    def close(self):
+        for p in self.ptrs.values():
+            self.lib.kvz_hip_host_free(p)
+        self.ptrs = {}

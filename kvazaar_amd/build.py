@@ -31,3 +31,19 @@ def build_library(force=False, verbose=False):
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return LIB_PATH
+
+
+TOOLS = {"valu_issue_bench": os.path.join(os.path.dirname(PKG), "tools", "valu_issue_bench.hip")}
+
+
+def build_tools(force=False, verbose=False):
+    """Measurement helpers that run on the GPU box next to the library (kvazaar_amd/lib/<name>): tools/valu_issue_bench.hip."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    for name, src in TOOLS.items():
+        out = os.path.join(LIB_DIR, name)
+        if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
+            continue
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-o", out, src]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)

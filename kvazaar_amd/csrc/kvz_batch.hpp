@@ -54,15 +54,20 @@ struct CtuSched {
   unsigned *error;        // set when a wait exceeds its spin bound (never in a healthy run)
   unsigned total, epoch;
   int no_wpp;             // items in raster order per picture; a row's first CTU also waits for the last CTU of the row above
-  unsigned spin_limit;    // bound of a wait, in polls: generous for WPP (a neighbour is at most a few CTUs away), scaled with the picture
-                          // without it (a picture is one serial chain: the workgroup holding its last CTU waits for all the others)
+  unsigned long long wait_ticks;  // bound of one wait in ticks of the 100 MHz constant clock (s_memrealtime): wall-clock, so that counter
+                                  // serialisation under rocprof, time slicing or preemption cannot turn a healthy run into a timeout
 };
 
-__device__ __forceinline__ bool wait_done(unsigned *flag, unsigned epoch, unsigned *error, unsigned spin_limit)
+__device__ __forceinline__ bool wait_done(unsigned *flag, unsigned epoch, unsigned *error, unsigned long long wait_ticks)
 {
+  unsigned long long t0 = 0;
   for (unsigned spins = 0;; ++spins) {
     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
-    if (spins > spin_limit) { atomicExch(error, 1u); return false; }  // bounded: a lost hand-off must not hang the GPU
+    if ((spins & 1023u) == 1023u) {  // bounded: a lost hand-off must not hang the GPU
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (!t0) t0 = now;
+      else if (now - t0 > wait_ticks) { atomicExch(error, 1u); return false; }
+    }
     __builtin_amdgcn_s_sleep(16);
   }
 }
@@ -85,9 +90,9 @@ template <bool CABAC> __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attri
     const int frame = item >> 16, y = (item >> 8) & 0xff, x = item & 0xff;
     if (threadIdx.x == 0) {
       unsigned *done = sched.done + (long)frame * ctus;
-      if (x > 0) wait_done(&done[y * F.wc + x - 1], sched.epoch, sched.error, sched.spin_limit);
-      if (y > 0) wait_done(&done[(y - 1) * F.wc + (x + 1 < F.wc ? x + 1 : x)], sched.epoch, sched.error, sched.spin_limit);  // above-right implies above and above-left
-      if (sched.no_wpp && x == 0 && y > 0) wait_done(&done[(y - 1) * F.wc + F.wc - 1], sched.epoch, sched.error, sched.spin_limit);  // its contexts come from there
+      if (x > 0) wait_done(&done[y * F.wc + x - 1], sched.epoch, sched.error, sched.wait_ticks);
+      if (y > 0) wait_done(&done[(y - 1) * F.wc + (x + 1 < F.wc ? x + 1 : x)], sched.epoch, sched.error, sched.wait_ticks);  // above-right implies above and above-left
+      if (sched.no_wpp && x == 0 && y > 0) wait_done(&done[(y - 1) * F.wc + F.wc - 1], sched.epoch, sched.error, sched.wait_ticks);  // its contexts come from there
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
@@ -123,7 +128,29 @@ struct kvz_hip_batch {
   unsigned *d_ticket, *d_done, *d_error;
   unsigned total_items, epoch;
   int sched_ticket, grid_ticket;
+  int device;   // the batch's buffers and stream live here; every entry point binds the calling thread to it
+  int failed;   // sticky: a CTU hand-off wait of some run timed out, the results of that run are invalid
+  unsigned long long wait_ticks;
 };
+
+namespace kvz {
+// kvazaar worker threads other than the creating one call into a batch (search_lcu_hip.c): bind them to the batch's device
+inline void batch_enter(const kvz_hip_batch *b) { KVZ_HIP_CHECK(hipSetDevice(b->device)); }
+// after the stream has drained: did a hand-off wait time out?  0 ok, -1 invalid results (reported, never fatal: the embedding
+// encoder decides what to do)
+inline int batch_check(kvz_hip_batch *b)
+{
+  if (b->sched_ticket && !b->failed) {
+    unsigned err = 0;
+    KVZ_HIP_CHECK(hipMemcpy(&err, b->d_error, sizeof err, hipMemcpyDeviceToHost));
+    if (err) {
+      b->failed = 1;
+      fprintf(stderr, "kvz_hip: a CTU hand-off wait timed out (KVZ_HIP_WAIT_MS to raise the bound) -- the results of this batch are invalid\n");
+    }
+  }
+  return b->failed ? -1 : 0;
+}
+}  // namespace kvz
 
 namespace kvz {
 
@@ -138,6 +165,23 @@ static const uint32_t kEntropyBits[128] = {
   0x00bda, 0x200f9, 0x00b3c, 0x20a99, 0x00aa5, 0x21438, 0x00a17, 0x21dd8, 0x00990, 0x22778, 0x00911, 0x23118, 0x00898, 0x23ab8, 0x00826, 0x24458,
   0x007ba, 0x24df7, 0x00753, 0x25797, 0x006f2, 0x26137, 0x00696, 0x26ad7, 0x0063f, 0x27477, 0x005ed, 0x27e17, 0x0059f, 0x287b6, 0x00554, 0x29156,
   0x0050e, 0x29af6, 0x004cc, 0x2a497, 0x0048d, 0x2ae35, 0x00451, 0x2b7d6, 0x00418, 0x2c176, 0x003e2, 0x2cb15, 0x003af, 0x2d4b5, 0x0037f, 0x2de55
+};
+
+// kvazaar's default fast-coefficient-cost weights per QP (fast_coeff_cost.h:48-101: four doubles per QP for |level| = 0, 1, 2, >= 3),
+// packed as kvz_fast_coeff_use_default_table does (fast_coeff_cost.c:39-52, 76-82: Q8.8 each, |level| = 0 in the low word) --
+// what kvz_fast_coeff_get_weights(state) returns unless --fastrd-learning-outdir / a custom table is used.  QP < 50
+// (MAX_FAST_COEFF_COST_QP).  Constant data; tests/test_ctu_pipeline.py pins it against the reference build's values.
+static const uint64_t kDefaultCoeffWeights[50] = {
+  0x06f8038004200029ull, 0x06f8038004200029ull, 0x06f8038004200029ull, 0x06f8038004200029ull, 0x06f8038004200029ull,
+  0x06f8038004200029ull, 0x06f8038004200029ull, 0x06f8038004200029ull, 0x06f8038004200029ull, 0x06f8038004200029ull,
+  0x06f8038004200029ull, 0x06e5038f040a0028ull, 0x06f703eb044f0021ull, 0x06e603f2046c001cull, 0x06ce0429047b0018ull,
+  0x06b9040b04a10013ull, 0x068f040004f6000dull, 0x067903f40522000aull, 0x066b03ce052f0009ull, 0x065a03c905340007ull,
+  0x065903cc05510006ull, 0x065303d105390005ull, 0x065403f0052c0004ull, 0x064b042505170003ull, 0x0644043405040002ull,
+  0x0635044e04f50002ull, 0x062d046704ea0001ull, 0x0622046304e80001ull, 0x0627048604df0001ull, 0x0627049704dd0001ull,
+  0x0624049b04dd0001ull, 0x063b04cb04c60001ull, 0x064604ca04cb0000ull, 0x063c04ca04d80000ull, 0x064604ce04d90000ull,
+  0x065904de04d70000ull, 0x067304f804c60000ull, 0x06aa050d04be0000ull, 0x069a050904cd0000ull, 0x06be051404cc0000ull,
+  0x06df052504c80000ull, 0x073a053804ea0000ull, 0x0748052704f90000ull, 0x0696048305510000ull, 0x06c6048e054e0000ull,
+  0x06f604b105430000ull, 0x071a04bc05310000ull, 0x075704d5052e0000ull, 0x075704d4052f0000ull, 0x0744048505640000ull,
 };
 
 // context.c:202-213 kvz_ctx_init
@@ -200,6 +244,7 @@ inline void cost_model_init(int qp, uint64_t coeff_weights, kvz_hip_intra_cost_m
 extern "C" {
 
 void kvz_hip_intra_cost_model_init(int qp, uint64_t coeff_weights, kvz_hip_intra_cost_model *model) { kvz::cost_model_init(qp, coeff_weights, model); }
+uint64_t kvz_hip_default_coeff_weights(int qp) { return qp >= 0 && qp < 50 ? kvz::kDefaultCoeffWeights[qp] : 0; }
 
 kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
 {
@@ -209,6 +254,13 @@ kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
   }
   kvz::runtime_init(-1);
   kvz_hip_batch *b = new kvz_hip_batch();
+  b->device = kvz::runtime().device;
+  b->failed = 0;
+  {
+    const char *e = getenv("KVZ_HIP_WAIT_MS");  // bound of one hand-off wait (wall clock); a whole 4K picture without WPP is a 2.5 s chain
+    const double ms = e && atof(e) > 0 ? atof(e) : 30000.0;
+    b->wait_ticks = (unsigned long long)(ms * 1e5);
+  }
   kvz::CtuFrames &F = b->F;
   F.W = width; F.H = height; F.wc = (width + 63) / 64; F.hc = (height + 63) / 64;
   F.frame_px = (long)width * height * 3 / 2;
@@ -276,6 +328,7 @@ kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
 void kvz_hip_batch_destroy(kvz_hip_batch *b)
 {
   if (!b) return;
+  kvz::batch_enter(b);
   (void)hipStreamSynchronize(b->stream);
   (void)hipFree(b->d_border); (void)hipFree(b->d_items); (void)hipFree(b->d_items_raster); (void)hipFree(b->d_done); (void)hipFree(b->d_ticket); (void)hipFree(b->d_prof); (void)hipFree(b->d_entropy);
   (void)hipFree(b->d_src); (void)hipFree(b->d_rec); (void)hipFree(b->d_coeff); (void)hipFree(b->d_scratch); (void)hipFree(b->d_depth); (void)hipFree(b->d_mode); (void)hipFree(b->d_cost);
@@ -288,6 +341,7 @@ int kvz_hip_batch_ctus_per_frame(const kvz_hip_batch *b) { return b->F.wc * b->F
 
 void kvz_hip_batch_upload(kvz_hip_batch *b, int frame, const uint8_t *y, const uint8_t *u, const uint8_t *v)
 {
+  kvz::batch_enter(b);
   const long ys = (long)b->F.W * b->F.H, cs = ys / 4;
   uint8_t *dst = b->d_src + (long)frame * b->F.frame_px;
   KVZ_HIP_CHECK(hipMemcpyAsync(dst, y, ys, hipMemcpyHostToDevice, b->stream));
@@ -296,9 +350,10 @@ void kvz_hip_batch_upload(kvz_hip_batch *b, int frame, const uint8_t *y, const u
   KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
 }
 
-void kvz_hip_batch_download(kvz_hip_batch *b, int frame, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, int16_t *coeff, uint8_t *cu_depth,
-                            uint8_t *cu_mode, double *ctu_cost)
+int kvz_hip_batch_download(kvz_hip_batch *b, int frame, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, int16_t *coeff, uint8_t *cu_depth,
+                           uint8_t *cu_mode, double *ctu_cost)
 {
+  kvz::batch_enter(b);
   const kvz::CtuFrames &F = b->F;
   const long ys = (long)F.W * F.H, cs = ys / 4, nctu = (long)F.wc * F.hc, ncu = (long)(F.W / 8) * (F.H / 8);
   const uint8_t *src = b->d_rec + (long)frame * F.frame_px;
@@ -310,10 +365,32 @@ void kvz_hip_batch_download(kvz_hip_batch *b, int frame, uint8_t *rec_y, uint8_t
   if (cu_depth) KVZ_HIP_CHECK(hipMemcpy(cu_depth, b->d_depth + frame * ncu, ncu, hipMemcpyDeviceToHost));
   if (cu_mode) KVZ_HIP_CHECK(hipMemcpy(cu_mode, b->d_mode + frame * ncu, ncu, hipMemcpyDeviceToHost));
   if (ctu_cost) KVZ_HIP_CHECK(hipMemcpy(ctu_cost, b->d_cost + frame * nctu, nctu * sizeof(double), hipMemcpyDeviceToHost));
+  return kvz::batch_check(b);
+}
+
+void *kvz_hip_host_alloc(size_t bytes)
+{
+  kvz::runtime_init(-1);
+  void *p = nullptr;
+  KVZ_HIP_CHECK(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
+  return p;
+}
+void kvz_hip_host_free(void *p) { if (p) KVZ_HIP_CHECK(hipHostFree(p)); }
+
+void kvz_hip_batch_download_all_async(kvz_hip_batch *b, uint8_t *rec, int16_t *coeff, uint8_t *cu_depth, uint8_t *cu_mode)
+{
+  kvz::batch_enter(b);
+  const kvz::CtuFrames &F = b->F;
+  const size_t n = (size_t)b->n_frames, nctu = (size_t)F.wc * F.hc * n, ncu = (size_t)(F.W / 8) * (F.H / 8) * n;
+  if (rec) KVZ_HIP_CHECK(hipMemcpyAsync(rec, b->d_rec, (size_t)F.frame_px * n, hipMemcpyDeviceToHost, b->stream));
+  if (coeff) KVZ_HIP_CHECK(hipMemcpyAsync(coeff, b->d_coeff, nctu * 6144 * sizeof(int16_t), hipMemcpyDeviceToHost, b->stream));
+  if (cu_depth) KVZ_HIP_CHECK(hipMemcpyAsync(cu_depth, b->d_depth, ncu, hipMemcpyDeviceToHost, b->stream));
+  if (cu_mode) KVZ_HIP_CHECK(hipMemcpyAsync(cu_mode, b->d_mode, ncu, hipMemcpyDeviceToHost, b->stream));
 }
 
 int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model)
 {
+  kvz::batch_enter(b);
   const kvz::CtuFrames &F = b->F;
   int launches = 0;
   kvz::CtuModel cm;
@@ -325,10 +402,9 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
   if (!b->sched_ticket && cm.no_wpp) { fprintf(stderr, "kvz_hip_intra_frames: the one-launch-per-diagonal schedule (KVZ_HIP_SCHED=wave) needs WPP\n"); abort(); }
   if (b->sched_ticket) {
     b->epoch++;
-    KVZ_HIP_CHECK(hipMemsetAsync(b->d_ticket, 0, 2 * sizeof(unsigned), b->stream));
+    KVZ_HIP_CHECK(hipMemsetAsync(b->d_ticket, 0, sizeof(unsigned), b->stream));  // the error word behind it stays: sticky across runs
     KVZ_HIP_CHECK(hipEventRecord(b->ev0, b->stream));
-    kvz::CtuSched sc{ cm.no_wpp ? b->d_items_raster : b->d_items, b->d_ticket, b->d_done, b->d_error, b->total_items, b->epoch, cm.no_wpp,
-                        cm.no_wpp ? (unsigned)((1u << 22) + (unsigned long long)F.wc * F.hc * 8192u > 0x7fffffffull ? 0x7fffffffu : (1u << 22) + (unsigned)(F.wc * F.hc) * 8192u) : (1u << 22) };
+    kvz::CtuSched sc{ cm.no_wpp ? b->d_items_raster : b->d_items, b->d_ticket, b->d_done, b->d_error, b->total_items, b->epoch, cm.no_wpp, b->wait_ticks };
     // two instantiations: the one without the CABAC coefficient model carries none of its code, registers or context storage
     if (cm.coeff_cabac) hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel<true>, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);
     else hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel<false>, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);
@@ -357,19 +433,17 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
   return launches;
 }
 
-void kvz_hip_batch_sync(kvz_hip_batch *b)
+int kvz_hip_batch_sync(kvz_hip_batch *b)
 {
+  kvz::batch_enter(b);
   KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
-  if (b->sched_ticket) {
-    unsigned err = 0;
-    KVZ_HIP_CHECK(hipMemcpy(&err, b->d_error, sizeof err, hipMemcpyDeviceToHost));
-    if (err) { fprintf(stderr, "kvz_hip: CTU hand-off wait timed out -- results are invalid, aborting\n"); abort(); }
-  }
+  return kvz::batch_check(b);
 }
 
 /* cycle counters of a -DKVZ_CTU_PROFILE build (all zero otherwise); reading resets them */
 int kvz_hip_batch_profile(kvz_hip_batch *b, unsigned long long *out, int n)
 {
+  kvz::batch_enter(b);
   KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
   if (n > 2 * kvz::KVZ_P_COUNT) n = 2 * kvz::KVZ_P_COUNT;  // cycles per category, then marks per category
   KVZ_HIP_CHECK(hipMemcpy(out, b->d_prof, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -381,6 +455,7 @@ int kvz_hip_batch_profile(kvz_hip_batch *b, unsigned long long *out, int n)
 float kvz_hip_batch_last_kernel_ms(kvz_hip_batch *b)
 {
   float ms = 0;
+  kvz::batch_enter(b);
   KVZ_HIP_CHECK(hipEventSynchronize(b->ev1));
   KVZ_HIP_CHECK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
   return ms;

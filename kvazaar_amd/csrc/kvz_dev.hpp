@@ -619,13 +619,15 @@ void kvz_hip_dev_picture_checksums(const uint8_t *frames, int width, int height,
 
 void kvz_hip_batch_deblock(kvz_hip_batch *b, int qp, int beta_offset_div2, int tc_offset_div2)
 {
+  kvz::batch_enter(b);
   kvz::deblock_frames_on(b->stream, b->d_rec, b->F.W, b->F.H, b->n_frames, b->d_depth, qp, beta_offset_div2, tc_offset_div2);
 }
 
-void kvz_hip_batch_checksums(kvz_hip_batch *b, uint32_t *host_out)
+int kvz_hip_batch_checksums(kvz_hip_batch *b, uint32_t *host_out)
 {
+  kvz::batch_enter(b);
   const int n = b->n_frames;
-  if (n <= 0) return;
+  if (n <= 0) return 0;
   uint32_t *d = nullptr;
   KVZ_HIP_CHECK(hipMallocAsync((void **)&d, (size_t)n * 3 * sizeof(uint32_t), b->stream));
   KVZ_HIP_CHECK(hipMemsetAsync(d, 0, (size_t)n * 3 * sizeof(uint32_t), b->stream));
@@ -636,6 +638,7 @@ void kvz_hip_batch_checksums(kvz_hip_batch *b, uint32_t *host_out)
   KVZ_HIP_CHECK(hipMemcpyAsync(host_out, d, (size_t)n * 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
   KVZ_HIP_CHECK(hipFreeAsync(d, b->stream));
   KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+  return kvz::batch_check(b);
 }
 
 }  // extern "C"

@@ -384,10 +384,11 @@ struct AbsSumOp {
 // nal-generic.c:57-82 array_checksum (SEI decoded picture hash, method "checksum"): sum over the plane of sample ^ mask(x, y),
 // 32-bit wrap-around.  One item per row.
 struct PlaneChecksumOp {
-  const u8 *data; int width, stride; u32 *out;
-  KVZ_DEV void operator()(int y) const
+  const u8 *data; int width, stride, y0; u32 *out;  // rows y0.. of the plane, data pointing at row y0
+  KVZ_DEV void operator()(int r) const
   {
-    const u8 *row = data + (long)y * stride;
+    const u8 *row = data + (long)r * stride;
+    const int y = y0 + r;
     u32 sum = 0;
     for (int x = 0; x < width; x++) sum += (u32)(row[x] ^ (u8)((x & 0xff) ^ (y & 0xff) ^ (x >> 8) ^ (y >> 8)));
     KVZ_ATOMIC_ADD(out, sum);

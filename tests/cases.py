@@ -494,7 +494,8 @@ def cases_find_last_scanpos(scan_table):
 def cases_plane_checksum():
     """nal-generic.c:57-82: planes wider / taller than 256 exercise the x >> 8 / y >> 8 terms of the mask, strides > width the row step"""
     rng = _rng(120)
-    for (h, w, stride) in ((1, 1, 1), (8, 8, 8), (16, 24, 40), (120, 208, 208), (270, 300, 304), (64, 520, 520), (515, 64, 72)):
+    for (h, w, stride) in ((1, 1, 1), (8, 8, 8), (16, 24, 40), (120, 208, 208), (270, 300, 304), (64, 520, 520), (515, 64, 72),
+                           (1080, 1920, 1920), (544, 960, 1984), (2160, 3840, 3840)):  # whole luma planes: 2 MB / 8 MB through the per-call path (nal.c:79-84)
         d = A(rng.integers(0, 256, h * stride, dtype=np.uint8))
         yield (f"plane_checksum{w}x{h}s{stride}", lambda lib, d=d, h=h, w=w, stride=stride: (lib.plane_checksum(ptr(d), h, w, stride),))
     full = A(np.full(64 * 64, 255, np.uint8))

@@ -85,18 +85,28 @@ def sao_digests(func):
 ENCODER_CLIPS = [(64, 64, 2, 9, "small", 22), (72, 88, 2, 1, "small", 12), (200, 136, 2, 3, "small", 27), (64, 64, 2, 9, "small", 30),
                  (200, 136, 2, 3, "small", 37), (416, 240, 3, 1234, "small", 22), (416, 240, 2, 99, "small", 17), (416, 240, 2, 7, "small", 32),
                  (192, 136, 2, 5, "small", 45), (832, 480, 1, 5, "large", 22), (832, 480, 1, 5, "large", 28), (1920, 1080, 1, 1, "large", 22),
-                 (1920, 1080, 1, 1, "large", 32)]
+                 (1920, 1080, 1, 1, "large", 32),
+                 # BASELINE configs 3-5 geometry (3840x2160 = 60x34 CTUs, partial bottom row), the size the north-star target is stated on
+                 (3840, 2160, 1, 2, "large", 22), (3840, 2160, 1, 2, "large", 32)]
 
 
 # ... and without wavefront parallel processing (--no-wpp; also what --tiles implies, cfg.c:925-978): one coder through the picture
-ENCODER_CLIPS_NO_WPP = [(416, 240, 2, 1234, "small", 22), (200, 136, 2, 3, "small", 32), (64, 136, 1, 3, "small", 22)]
+ENCODER_CLIPS_NO_WPP = [(416, 240, 2, 1234, "small", 22), (200, 136, 2, 3, "small", 32), (64, 136, 1, 3, "small", 22),
+                        (1920, 1080, 1, 3, "large", 22), (3840, 2160, 1, 3, "large", 22)]  # the longest serial CTU chains the schedule sees
+
+# (width, height, frames, seed, kind, qp, tiles, wpp): kvazaar's uniform tile grid (encoder.c:383-404); tiles are independent sub-pictures
+# with their own coder (encoderstate.c:944-979), WPP off unless asked for (cfg.c:925-978).  The last two are BASELINE config 5's real
+# geometry: 8 tiles of 15x17 CTUs (960x1088 / 960x1072), chains of 255 CTUs without WPP.
+ENCODER_CLIPS_TILES = [(416, 240, 2, 1234, "small", 22, "2x2", False), (416, 240, 1, 1234, "small", 32, "2x2", True), (832, 480, 1, 5, "large", 22, "3x2", False),
+                       (3840, 2160, 1, 2, "large", 22, "4x2", False), (3840, 2160, 1, 2, "large", 22, "4x2", True)]
 
 
-def clip_key(w, h, n, seed, kind, qp, deblock, no_wpp=False):
-    return f"{w}x{h}/n{n}/seed{seed}/{kind}/qp{qp}/{'deblock' if deblock else 'nodeblock'}" + ("/nowpp" if no_wpp else "")
+def clip_key(w, h, n, seed, kind, qp, deblock, no_wpp=False, tiles=None, wpp=False):
+    return (f"{w}x{h}/n{n}/seed{seed}/{kind}/qp{qp}/{'deblock' if deblock else 'nodeblock'}" + ("/nowpp" if no_wpp else "")
+            + (f"/tiles{tiles}" + ("-wpp" if wpp else "") if tiles else ""))
 
 
-def reference_encoder_recon(w, h, frames, qp, deblock, workdir, cu_maps=None, no_wpp=False):
+def reference_encoder_recon(w, h, frames, qp, deblock, workdir, cu_maps=None, no_wpp=False, tiles=None, wpp=False):
     """runs the reference CLI (oracle/_ref/kvazaar_ref) on the clip; returns its --debug reconstruction, one array per frame.
     cu_maps: a list that receives, per frame, the (depth, intra mode) maps per 8x8 cell the encoder's search left in its cu_array
     (recorded through the oracle/ref_cudump.c interposer; single-threaded so that LCUs arrive frame by frame)"""
@@ -109,6 +119,8 @@ def reference_encoder_recon(w, h, frames, qp, deblock, workdir, cu_maps=None, no
         cmd.append("--no-deblock")
     if no_wpp:
         cmd.append("--no-wpp")
+    if tiles:
+        cmd += ["--tiles", tiles] + (["--wpp"] if wpp else [])
     env = dict(os.environ)
     dump = os.path.join(workdir, "cu.txt")
     if cu_maps is not None:
@@ -143,6 +155,16 @@ def encoder_digests(workdir):
         frames = cc.yuv_frames(w, h, n, seed, kind)
         recs = reference_encoder_recon(w, h, frames, qp, 0, workdir, None, True)
         out[clip_key(w, h, n, seed, kind, qp, 0, True)] = [hashlib.sha256(r.tobytes()).hexdigest()[:24] for r in recs]
+    for (w, h, n, seed, kind, qp, tiles, wpp) in ENCODER_CLIPS_TILES:
+        frames = cc.yuv_frames(w, h, n, seed, kind)
+        for deblock in (0, 1):
+            recs = reference_encoder_recon(w, h, frames, qp, deblock, workdir, None, False, tiles, wpp)
+            out[clip_key(w, h, n, seed, kind, qp, deblock, False, tiles, wpp)] = [hashlib.sha256(r.tobytes()).hexdigest()[:24] for r in recs]
+            # ... and tile by tile (raster tile order), so that a rank holding some of the tiles can check its share (bench.py --tiles)
+            from kvazaar_amd import sharding
+            grid = sharding.tile_grid(w, h, *(int(v) for v in tiles.split("x")))
+            out[clip_key(w, h, n, seed, kind, qp, deblock, False, tiles, wpp) + "/per-tile"] = [
+                [hashlib.sha256(sharding.crop_tile(r, w, h, t).tobytes()).hexdigest()[:24] for t in grid] for r in recs]
     return out
 
 

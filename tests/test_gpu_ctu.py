@@ -9,6 +9,7 @@ import pytest
 import ctu_common as cc
 import flatapi
 
+flatapi.sys.path.insert(0, flatapi.os.path.join(flatapi.ROOT, "tests", "golden"))
 pytestmark = pytest.mark.gpu
 
 
@@ -74,14 +75,20 @@ def test_hip_ctu_1080p_frame_equals_oracle(oracle, hiplib):
     assert not cc.compare(want, got[0]), cc.compare(want, got[0])
 
 
-def test_hip_ctu_full_size_properties(oracle, hiplib):
-    """4K (BASELINE configs 3-5 geometry), properties that need no oracle run: frames of a batch are independent
-    (a frame encodes identically alone and inside a batch), repeated runs are deterministic, and the reconstruction is
-    a plausible QP-22 encode (PSNR band) whose coefficients are consistent with the CU costs being finite."""
+def test_hip_ctu_4k_batch_independence(oracle, hiplib):
+    """4K (BASELINE configs 3-5 geometry): frame 0 is the picture of tests/golden/encoder_recon.json's 3840x2160 clip -- the reference
+    encoder's reconstruction and CU maps (test_encoder_parity.py checks the same digests and the deblocked picture) -- and frames of a
+    batch are independent: a frame encodes identically alone and inside a batch, repeated runs are deterministic."""
+    import hashlib
+    import json
+    import make_golden as mg
     w, h = 3840, 2160
     model = _model(hiplib, oracle, 22)
     frames = cc.yuv_frames(w, h, 2, 2, "large")
     batch = _run_batch(hiplib, model, w, h, frames)
+    golden = json.load(open(flatapi.os.path.join(flatapi.ROOT, "tests", "golden", "encoder_recon.json")))
+    assert hashlib.sha256(batch[0]["rec"].tobytes()).hexdigest()[:24] == golden[mg.clip_key(w, h, 1, 2, "large", 22, 0)][0]
+    assert mg.cu_digest(batch[0]["depth"].reshape(h // 8, w // 8), batch[0]["mode"].reshape(h // 8, w // 8)) == golden[mg.clip_key(w, h, 1, 2, "large", 22, 0) + "/cu"][0]
     again = _run_batch(hiplib, model, w, h, frames)
     alone = _run_batch(hiplib, model, w, h, frames[1:])
     for i in range(2):

@@ -4,11 +4,14 @@
 tag=$1; shift
 repo=$PWD
 cd /tmp && export TMPDIR=/tmp
-B="python $repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ref-encoder $*"
+B="python $repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-ref-encoder --no-extra $*"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS \
   --output-format csv -d $repo/gpurun_out/pmc_${tag}_a -- $B > $repo/gpurun_out/pmc_${tag}_a.log 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_BUSY_CYCLES \
   --output-format csv -d $repo/gpurun_out/pmc_${tag}_b -- $B > $repo/gpurun_out/pmc_${tag}_b.log 2>&1
+# lane utilisation: SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 64 lanes x 4 [quad-cycles]) = active lanes per issued VALU instruction
+rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAVES SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA \
+  --output-format csv -d $repo/gpurun_out/pmc_${tag}_c -- $B > $repo/gpurun_out/pmc_${tag}_c.log 2>&1
 cd $repo
 python - <<PY
 import csv, glob, collections

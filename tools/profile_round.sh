@@ -6,7 +6,7 @@ tag=$1
 repo=$PWD
 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 cd /tmp && export TMPDIR=/tmp
-B="python $repo/bench.py --no-cpu-baseline --no-ref-encoder"
+B="python $repo/bench.py --no-cpu-baseline --no-ref-encoder --no-extra"
 rocprofv3 --kernel-trace --stats --output-format csv -d $repo/gpurun_out/${tag}_stats -o ${tag} -- $B > $repo/gpurun_out/${tag}_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $repo/gpurun_out/${tag}_pmc_f -o ${tag}_f -- $B --steps 1 --warmup 1 > $repo/gpurun_out/${tag}_pmc_f.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $repo/gpurun_out/${tag}_pmc_w -o ${tag}_w -- $B --steps 1 --warmup 1 > $repo/gpurun_out/${tag}_pmc_w.log 2>&1
