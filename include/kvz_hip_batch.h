@@ -50,6 +50,14 @@ void  kvz_hip_host_free(void *p);
  * Layouts as kvz_hip_batch_download, frames back to back; NULL skips a buffer.  kvz_hip_batch_sync() waits and validates. */
 void kvz_hip_batch_download_all_async(kvz_hip_batch *b, uint8_t *rec, int16_t *coeff, uint8_t *cu_depth, uint8_t *cu_mode);
 
+/* Work queued on `b` from now on starts only after everything queued on `other` so far has finished (both on the same device).  The
+ * CTU pass is ONE persistent launch that takes every workgroup slot of the device until its tickets run out: a second batch's pass launched
+ * right behind it moves into the slots as they free up, and the first batch's small follow-up kernels (deblocking, SAO, checksums) then wait
+ * for the whole second pass -- and with them its download.  Double-buffered pipelines therefore order the next batch's pass after the
+ * previous batch's follow-up kernels, and queue the download behind that point (bench.py chain_d2h): the copy engines then run during
+ * the next pass. */
+void kvz_hip_batch_order_after(kvz_hip_batch *b, kvz_hip_batch *other);
+
 /* The hot path: search + reconstruct every CTU of every frame in the batch.  Asynchronous on the batch's stream;
  * kvz_hip_batch_sync() waits.  Returns the number of kernel launches issued (1; one per CTU anti-diagonal with the older
  * schedule behind KVZ_HIP_SCHED=wave). */

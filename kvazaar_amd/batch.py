@@ -87,6 +87,12 @@ class HipBatch:
         """asynchronous on the batch's stream; returns the number of kernel launches"""
         return self.lib.kvz_hip_intra_frames(self.handle, C.byref(model))
 
+    def order_after(self, other):
+        """later work of this batch starts after everything queued on `other` so far (kvz_hip_batch_order_after)"""
+        self.lib.kvz_hip_batch_order_after.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.kvz_hip_batch_order_after.restype = None
+        self.lib.kvz_hip_batch_order_after(self.handle, other.handle)
+
     def sync(self):
         if self.lib.kvz_hip_batch_sync(self.handle) != 0:
             raise BatchError("kvz_hip_batch_sync: a CTU hand-off wait timed out; results invalid")

@@ -388,6 +388,16 @@ void kvz_hip_batch_download_all_async(kvz_hip_batch *b, uint8_t *rec, int16_t *c
   if (cu_mode) KVZ_HIP_CHECK(hipMemcpyAsync(cu_mode, b->d_mode, ncu, hipMemcpyDeviceToHost, b->stream));
 }
 
+void kvz_hip_batch_order_after(kvz_hip_batch *b, kvz_hip_batch *other)
+{
+  kvz::batch_enter(b);
+  hipEvent_t ev;
+  KVZ_HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  KVZ_HIP_CHECK(hipEventRecord(ev, other->stream));
+  KVZ_HIP_CHECK(hipStreamWaitEvent(b->stream, ev, 0));
+  KVZ_HIP_CHECK(hipEventDestroy(ev));  // released once the wait has been satisfied
+}
+
 int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model)
 {
   kvz::batch_enter(b);
