@@ -115,7 +115,8 @@ def limiter(args, launches):
         return None
     path, d = got
     out = {"kind": "valu_issue", "source": os.path.relpath(path, ROOT)}
-    for k in ("valu_issue_frac", "cycles_per_valu_inst", "insts_valu", "insts_salu", "insts_lds", "lane_utilisation", "wave_issue_frac", "wave_wait_frac", "note"):
+    for k in ("valu_issue_frac", "valu_issue_frac_range", "simd_ns_per_valu_inst", "insts_valu", "insts_salu", "insts_lds", "lane_utilisation", "wave_issue_frac", "wave_wait_frac",
+              "wave_issue_stall_frac", "waves_per_simd", "note"):
         if k in d:
             out[k] = d[k]
     return out
@@ -382,6 +383,22 @@ def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedRes
     result["chain"] = {"stages": "CTU pass + deblocking + picture-hash checksums", "value": rank_ctus / chain_s, "unit": "CTUs/s", "ms": chain_s * 1e3}
     if args.tiles:
         return
+    # ... and with `--sao full` on top (deblocking, SAO parameter decision per LCU, SAO reconstruction): what presets from veryfast up run
+    b0 = batches[0][0]
+    b0.launch(model)
+    b0.loop_filters(model, deblock=True, sao=True)  # first use allocates the SAO buffers
+    t0 = time.perf_counter()
+    b0.launch(model)
+    b0.loop_filters(model, deblock=True, sao=True, wait=False)
+    b0.checksums()
+    sao_s = time.perf_counter() - t0
+    try:
+        want = json.load(open(GOLDEN)).get(f"{args.width}x{args.height}/n1/seed{clip_seed(args.width, args.height)}/large/qp{args.qp}/deblock/sao")
+    except (OSError, ValueError):
+        want = None
+    result["chain_sao"] = {"stages": "CTU pass + deblocking + SAO decision (kvz_sao_search_lcu of every LCU) + SAO reconstruction + picture-hash checksums",
+                           "value": b0.ctus_per_frame * b0.n / sao_s, "unit": "CTUs/s", "ms": sao_s * 1e3,
+                           "verified": (sha(b0.download(0)["rec"]) == want[0]) if want else None}
     # ---- chain + D2H, double-buffered ----
     main_batch = batches[0][0]
     half = max(1, min(args.frames // 2, 384))

@@ -80,6 +80,20 @@ int   kvz_hip_batch_profile(kvz_hip_batch *b, unsigned long long *out, int n);
  * deblocked picture.  The next kvz_hip_intra_frames() overwrites the reconstruction. */
 void kvz_hip_batch_deblock(kvz_hip_batch *b, int qp, int beta_offset_div2, int tc_offset_div2);
 
+/* Both in-loop filters the way the encoder runs them per LCU (encoderstate.c:669-682): deblocking (when `deblock`) and -- when `sao` --
+ * the SAO parameter decision kvz_sao_search_lcu (sao.c:671, `--sao full`: edge and band) on the partly deblocked picture each LCU sees at
+ * that moment, with the merge-left / merge-up choice and the bit costs on the two SAO contexts as the LCU's real syntax moves them
+ * (encoderstate.c:467-552), followed by kvz_sao_reconstruct (sao.c:302-361) of every LCU.  On the batch's stream; afterwards the batch's
+ * reconstruction is the final picture (what `kvazaar --debug` writes), the decided parameters are read with kvz_hip_batch_sao_params().
+ * model: the cost model of the CTU pass (lambda, entropy table, no_wpp, the SAO contexts' initial states in ctx_init).  With sao == 0 this
+ * is kvz_hip_batch_deblock.  Three statistic sets per LCU (4 edge classes x 5 categories, 32 bands: {sum, count}) are gathered by one
+ * workgroup per (LCU, plane); the decision chain -- serial per picture like the coder it follows -- runs one lane per picture. */
+void kvz_hip_batch_loop_filters(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int deblock, int beta_offset_div2, int tc_offset_div2, int sao);
+/* The SAO parameters of one frame as the last kvz_hip_batch_loop_filters(..., sao = 1) decided them: one record per LCU in raster order
+ * (chroma: U in offsets[0..4] / band_position[0], V in offsets[5..9] / band_position[1], like sao_info_t); merge: 0 none, 1 left, 2 up.
+ * LCUs whose type is 0 (none) carry zeros in the other fields.  Any pointer may be NULL.  0 / -1 like kvz_hip_batch_sync. */
+int  kvz_hip_batch_sao_params(kvz_hip_batch *b, int frame, kvz_hip_sao_params *luma, kvz_hip_sao_params *chroma, uint8_t *merge);
+
 /* Picture-hash checksums (nal.c:73-86 kvz_image_checksum) of every frame's current reconstruction: host_out[3 * f + plane].
  * Queued behind whatever the batch's stream holds (CTU pass, deblocking) and waited for. */
 int  kvz_hip_batch_checksums(kvz_hip_batch *b, uint32_t *host_out);  /* 0 / -1 like kvz_hip_batch_sync */

@@ -90,7 +90,10 @@ enum {
   KVZ_HIP_CX_ONE_CHROMA = 132,   /* cu_one_model_chroma[0..7] */
   KVZ_HIP_CX_ABS_LUMA = 140,     /* cu_abs_model_luma[0..3] */
   KVZ_HIP_CX_ABS_CHROMA = 144,   /* cu_abs_model_chroma[0..1] */
-  KVZ_HIP_CX_COUNT = 146
+  KVZ_HIP_CX_COUNT = 146,        /* contexts of the CTU pass */
+  /* the two contexts of the SAO syntax (encoderstate.c:467-552), used by the SAO parameter decision only */
+  KVZ_HIP_CX_SAO_MERGE = 146,    /* sao_merge_flag_model */
+  KVZ_HIP_CX_SAO_TYPE = 147      /* sao_type_idx_model */
 };
 
 typedef struct kvz_hip_intra_cost_model {

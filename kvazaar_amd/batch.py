@@ -107,6 +107,27 @@ class HipBatch:
         if wait:
             self.sync()
 
+    def loop_filters(self, model, deblock=True, sao=True, beta_offset_div2=0, tc_offset_div2=0, wait=True):
+        """kvz_hip_batch_loop_filters: deblocking + SAO decision + SAO reconstruction on the batch's stream"""
+        f = self.lib.kvz_hip_batch_loop_filters
+        f.argtypes = [C.c_void_p, C.POINTER(CostModel), C.c_int, C.c_int, C.c_int, C.c_int]
+        f.restype = None
+        f(self.handle, C.byref(model), int(deblock), beta_offset_div2, tc_offset_div2, int(sao))
+        if wait:
+            self.sync()
+
+    def sao_params(self, frame):
+        """-> (luma records, chroma records, merge flags) of one frame, one entry per LCU in raster order"""
+        from .capi import SaoParams
+        n = self.ctus_per_frame
+        luma, chroma, merge = (SaoParams * n)(), (SaoParams * n)(), np.zeros(n, np.uint8)
+        f = self.lib.kvz_hip_batch_sao_params
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        f.restype = C.c_int
+        if f(self.handle, frame, luma, chroma, merge.ctypes.data) != 0:
+            raise BatchError("kvz_hip_batch_sao_params failed")
+        return luma, chroma, merge
+
     def checksums(self):
         out = np.zeros((self.n, 3), np.uint32)
         if self.lib.kvz_hip_batch_checksums(self.handle, out.ctypes.data) != 0:

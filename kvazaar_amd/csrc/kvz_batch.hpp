@@ -128,6 +128,12 @@ struct kvz_hip_batch {
   unsigned *d_ticket, *d_done, *d_error;
   unsigned total_items, epoch;
   int sched_ticket, grid_ticket;
+  // SAO (kvz_hip_batch_loop_filters with sao != 0; allocated on first use): the picture after the vertical edges and after all edges,
+  // statistics / context-free candidates / packed parameter records per (LCU, plane), merge choice per LCU
+  uint8_t *d_ver, *d_dbk, *d_sao_merge;
+  void *d_sao_stats, *d_sao_cand;
+  unsigned long long *d_sao_recs;
+  float *d_sao_fbits;
   int device;   // the batch's buffers and stream live here; every entry point binds the calling thread to it
   int failed;   // sticky: a CTU hand-off wait of some run timed out, the results of that run are invalid
   unsigned long long wait_ticks;
@@ -235,6 +241,8 @@ inline void cost_model_init(int qp, uint64_t coeff_weights, kvz_hip_intra_cost_m
   put(KVZ_HIP_CX_ONE_CHROMA, init_one + 16, 8);
   put(KVZ_HIP_CX_ABS_LUMA, init_abs, 4);
   put(KVZ_HIP_CX_ABS_CHROMA, init_abs + 4, 2);
+  m->ctx_init[KVZ_HIP_CX_SAO_MERGE] = (uint8_t)ctx_state(qp, 153);  // context.c:38-39 INIT_SAO_MERGE_FLAG / INIT_SAO_TYPE_IDX, I slice
+  m->ctx_init[KVZ_HIP_CX_SAO_TYPE] = (uint8_t)ctx_state(qp, 200);
   m->adaptive = 1;
   m->coeff_cabac = qp >= 28;  // `ultrafast`: fast-residual-cost 28 (cfg.c:485-512), rdo.c:311-340
 }
@@ -330,6 +338,7 @@ void kvz_hip_batch_destroy(kvz_hip_batch *b)
   if (!b) return;
   kvz::batch_enter(b);
   (void)hipStreamSynchronize(b->stream);
+  (void)hipFree(b->d_ver); (void)hipFree(b->d_dbk); (void)hipFree(b->d_sao_merge); (void)hipFree(b->d_sao_stats); (void)hipFree(b->d_sao_cand); (void)hipFree(b->d_sao_recs); (void)hipFree(b->d_sao_fbits);
   (void)hipFree(b->d_border); (void)hipFree(b->d_items); (void)hipFree(b->d_items_raster); (void)hipFree(b->d_done); (void)hipFree(b->d_ticket); (void)hipFree(b->d_prof); (void)hipFree(b->d_entropy);
   (void)hipFree(b->d_src); (void)hipFree(b->d_rec); (void)hipFree(b->d_coeff); (void)hipFree(b->d_scratch); (void)hipFree(b->d_depth); (void)hipFree(b->d_mode); (void)hipFree(b->d_cost);
   (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1);

@@ -10,6 +10,7 @@
 #include "../../include/kvz_hip_dev.h"
 #include "kvz_mfma.hpp"
 #include "kvz_ops.hpp"
+#include "kvz_sao.hpp"
 
 namespace kvz {
 
@@ -407,7 +408,8 @@ template <bool VERTICAL> __global__ void __launch_bounds__(256) dev_deblock_chro
   }
 }
 
-inline void deblock_frames_on(hipStream_t stream, u8 *frames, int width, int height, int n_frames, const u8 *cu_depth, int qp, int beta_off, int tc_off)
+// passes: 1 = the vertical edges, 2 = the horizontal edges, 3 = both (in that order)
+inline void deblock_frames_on(hipStream_t stream, u8 *frames, int width, int height, int n_frames, const u8 *cu_depth, int qp, int beta_off, int tc_off, int passes = 3)
 {
   if (n_frames <= 0) return;
   DeblockGeom g;
@@ -419,10 +421,10 @@ inline void deblock_frames_on(hipStream_t stream, u8 *frames, int width, int hei
   const int cw = width >> 1, ch = height >> 1;
   const long cv = 2L * n_frames * ((cw + 7) >> 3) * (ch >> 2), chh = 2L * n_frames * (cw >> 2) * ((ch + 7) >> 3);
   auto grid = [](long n) { return dim3((unsigned)((n + 255) / 256)); };
-  if (lv) hipLaunchKernelGGL(dev_deblock_luma_kernel<true>, grid(lv), dim3(256), 0, stream, frames, g, lv);
-  if (cv) hipLaunchKernelGGL(dev_deblock_chroma_kernel<true>, grid(cv), dim3(256), 0, stream, frames, g, cv);
-  if (lh) hipLaunchKernelGGL(dev_deblock_luma_kernel<false>, grid(lh), dim3(256), 0, stream, frames, g, lh);
-  if (chh) hipLaunchKernelGGL(dev_deblock_chroma_kernel<false>, grid(chh), dim3(256), 0, stream, frames, g, chh);
+  if (lv && (passes & 1)) hipLaunchKernelGGL(dev_deblock_luma_kernel<true>, grid(lv), dim3(256), 0, stream, frames, g, lv);
+  if (cv && (passes & 1)) hipLaunchKernelGGL(dev_deblock_chroma_kernel<true>, grid(cv), dim3(256), 0, stream, frames, g, cv);
+  if (lh && (passes & 2)) hipLaunchKernelGGL(dev_deblock_luma_kernel<false>, grid(lh), dim3(256), 0, stream, frames, g, lh);
+  if (chh && (passes & 2)) hipLaunchKernelGGL(dev_deblock_chroma_kernel<false>, grid(chh), dim3(256), 0, stream, frames, g, chh);
   KVZ_HIP_CHECK(hipGetLastError());
 }
 
@@ -456,6 +458,63 @@ __global__ void __launch_bounds__(256) dev_checksum_kernel(const u8 *frames, int
   } else if (i < total) {
     atomicAdd(&out[frame * 3 + plane], v);
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// SAO parameter decision (kvz_sao.hpp): statistics + context-free candidates, one workgroup per (LCU, plane) ...
+struct SaoGeom { int W, H, wl, hl; long frame_bytes; };
+__global__ void __launch_bounds__(256) dev_sao_stats_kernel(const u8 *src, const u8 *R, const u8 *V, const u8 *D, const SaoGeom g, SaoStats *stats, SaoCand *cand)
+{
+  __shared__ SaoStats st;
+  __shared__ u8 s_rec[64 * 64], s_org[64 * 64];
+  const long item = blockIdx.x;  // (frame, lcu, plane)
+  const int color = (int)(item % 3);
+  const long lcu_all = item / 3;
+  const int lcus = g.wl * g.hl, lcu = (int)(lcu_all % lcus);
+  const long frame = lcu_all / lcus;
+  const int lx = lcu % g.wl, ly = lcu / g.wl, sh = color ? 1 : 0, n = 64 >> sh, fw = g.W >> sh, fh = g.H >> sh;
+  const long plane = frame * g.frame_bytes + (color == 0 ? 0 : (color == 1 ? (long)g.W * g.H : (long)g.W * g.H * 5 / 4));
+  const int bw = imin(n, fw - lx * n), bh = imin(n, fh - ly * n);  // sao.c:598-605, 645-650
+  SaoView view{ R + plane, V + plane, D + plane, fw, n, lx * n, ly * n, lx == g.wl - 1, ly == g.hl - 1, color ? 1 : 3 };
+  for (int i = threadIdx.x; i < (int)(sizeof(SaoStats) / sizeof(i32)); i += 256) reinterpret_cast<i32 *>(&st)[i] = 0;
+  for (int p = threadIdx.x; p < bw * bh; p += 256) {
+    const int x = p % bw, y = p / bw;
+    s_rec[p] = (u8)view.at(x, y);
+    s_org[p] = src[plane + (long)(ly * n + y) * fw + lx * n + x];
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < bw * bh; p += 256) {
+    const int x = p % bw, y = p / bw, c = s_rec[p], diff = (int)s_org[p] - c;
+    atomicAdd(&st.band_sum[c >> 3], diff);
+    atomicAdd(&st.band_cnt[c >> 3], 1);
+    if (x >= 1 && x < bw - 1 && y >= 1 && y < bh - 1) {  // sao-generic.c:68-69: the block's interior
+#pragma unroll
+      for (int ec = 0; ec < 4; ec++) {
+        int ax, ay, bx, by;
+        eo_offsets(ec, ax, ay, bx, by);
+        const int cat = eo_cat(s_rec[p + ay * bw + ax], s_rec[p + by * bw + bx], c);
+        atomicAdd(&st.edge_sum[ec][cat], diff);
+        atomicAdd(&st.edge_cnt[ec][cat], 1);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (int)(sizeof(SaoStats) / sizeof(i32)); i += 256) reinterpret_cast<i32 *>(&stats[item])[i] = reinterpret_cast<const i32 *>(&st)[i];
+  if (threadIdx.x == 0) {
+    SaoCand c;
+    sao_candidates(st, c);
+    cand[item] = c;
+  }
+}
+// ... and the chain over the LCUs of a picture: one lane per picture
+__global__ void __launch_bounds__(64) dev_sao_chain_kernel(const SaoStats *stats, const SaoCand *cand, const SaoGeom g, const int n_frames, const float *fbits, const Tables *tb,
+                                                           const double lambda, const int init_merge, const int init_type, const int no_wpp, SaoRec *recs, u8 *merge)
+{
+  const int f = blockIdx.x * 64 + threadIdx.x;
+  if (f >= n_frames) return;
+  const long base = (long)f * g.wl * g.hl;
+  sao_chain_picture(fbits, tb->ctx_next[0], tb->ctx_next[1], lambda, (u8)init_merge, (u8)init_type, no_wpp, g.wl, g.hl, stats + base * 3, cand + base * 3, recs + base * 3,
+                    merge + base);
 }
 
 struct DevTimer { hipEvent_t e0 = nullptr, e1 = nullptr; };
@@ -621,6 +680,62 @@ void kvz_hip_batch_deblock(kvz_hip_batch *b, int qp, int beta_offset_div2, int t
 {
   kvz::batch_enter(b);
   kvz::deblock_frames_on(b->stream, b->d_rec, b->F.W, b->F.H, b->n_frames, b->d_depth, qp, beta_offset_div2, tc_offset_div2);
+}
+
+void kvz_hip_batch_loop_filters(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int deblock, int beta_offset_div2, int tc_offset_div2, int sao)
+{
+  kvz::batch_enter(b);
+  const kvz::CtuFrames &F = b->F;
+  const int n = b->n_frames;
+  if (!sao) {
+    if (deblock) kvz::deblock_frames_on(b->stream, b->d_rec, F.W, F.H, n, b->d_depth, model->qp, beta_offset_div2, tc_offset_div2);
+    return;
+  }
+  const size_t pic_bytes = (size_t)F.frame_px * n, lcus = (size_t)F.wc * F.hc * n;
+  if (!b->d_ver) {  // first use: the two intermediate pictures and the decision's records
+    KVZ_HIP_CHECK(hipMalloc((void **)&b->d_ver, pic_bytes));
+    KVZ_HIP_CHECK(hipMalloc((void **)&b->d_dbk, pic_bytes));
+    KVZ_HIP_CHECK(hipMalloc((void **)&b->d_sao_stats, lcus * 3 * sizeof(kvz::SaoStats)));
+    KVZ_HIP_CHECK(hipMalloc((void **)&b->d_sao_cand, lcus * 3 * sizeof(kvz::SaoCand)));
+    KVZ_HIP_CHECK(hipMalloc((void **)&b->d_sao_recs, lcus * 3 * sizeof(kvz::SaoRec)));
+    KVZ_HIP_CHECK(hipMalloc((void **)&b->d_sao_merge, lcus));
+    KVZ_HIP_CHECK(hipMalloc((void **)&b->d_sao_fbits, 128 * sizeof(float)));
+  }
+  // R = d_rec (kept), V = d_ver, D = d_dbk
+  KVZ_HIP_CHECK(hipMemcpyAsync(b->d_ver, b->d_rec, pic_bytes, hipMemcpyDeviceToDevice, b->stream));
+  if (deblock) kvz::deblock_frames_on(b->stream, b->d_ver, F.W, F.H, n, b->d_depth, model->qp, beta_offset_div2, tc_offset_div2, 1);
+  KVZ_HIP_CHECK(hipMemcpyAsync(b->d_dbk, b->d_ver, pic_bytes, hipMemcpyDeviceToDevice, b->stream));
+  if (deblock) kvz::deblock_frames_on(b->stream, b->d_dbk, F.W, F.H, n, b->d_depth, model->qp, beta_offset_div2, tc_offset_div2, 2);
+  KVZ_HIP_CHECK(hipMemcpyAsync(b->d_sao_fbits, model->entropy_fbits, 128 * sizeof(float), hipMemcpyHostToDevice, b->stream));
+  const kvz::SaoGeom g{ F.W, F.H, F.wc, F.hc, F.frame_px };
+  hipLaunchKernelGGL(kvz::dev_sao_stats_kernel, dim3((unsigned)(lcus * 3)), dim3(256), 0, b->stream, b->d_src, b->d_rec, b->d_ver, b->d_dbk, g, (kvz::SaoStats *)b->d_sao_stats, (kvz::SaoCand *)b->d_sao_cand);
+  hipLaunchKernelGGL(kvz::dev_sao_chain_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, b->stream, (const kvz::SaoStats *)b->d_sao_stats, (const kvz::SaoCand *)b->d_sao_cand, g, n, b->d_sao_fbits, kvz::device_tables(),
+                     model->lambda, (int)model->ctx_init[KVZ_HIP_CX_SAO_MERGE], (int)model->ctx_init[KVZ_HIP_CX_SAO_TYPE], model->no_wpp, b->d_sao_recs, b->d_sao_merge);
+  // the SAO'd picture becomes the batch's reconstruction (R is not needed any more)
+  hipLaunchKernelGGL(kvz::dev_sao_kernel, dim3((unsigned)(2 * F.H), (unsigned)n), dim3(256), 0, b->stream, b->d_dbk, b->d_rec, F.W, F.H, b->d_sao_recs);
+  KVZ_HIP_CHECK(hipGetLastError());
+}
+
+int kvz_hip_batch_sao_params(kvz_hip_batch *b, int frame, kvz_hip_sao_params *luma, kvz_hip_sao_params *chroma, uint8_t *merge)
+{
+  kvz::batch_enter(b);
+  const size_t lcus = (size_t)b->F.wc * b->F.hc;
+  if (!b->d_sao_recs) { fprintf(stderr, "kvz_hip_batch_sao_params: kvz_hip_batch_loop_filters(..., sao = 1) has not run on this batch\n"); return -1; }
+  std::vector<kvz::SaoRec> recs(lcus * 3);
+  KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+  KVZ_HIP_CHECK(hipMemcpy(recs.data(), b->d_sao_recs + (size_t)frame * lcus * 3, lcus * 3 * sizeof(kvz::SaoRec), hipMemcpyDeviceToHost));
+  if (merge) KVZ_HIP_CHECK(hipMemcpy(merge, b->d_sao_merge + (size_t)frame * lcus, lcus, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < lcus; i++) {
+    auto unpack = [&](kvz_hip_sao_params *o, int plane, int slot) {
+      const kvz::SaoRec r = recs[i * 3 + plane];
+      if (slot == 0) { memset(o, 0, sizeof *o); o->bitdepth = 8; o->type = (int)(r & 0xff); o->eo_class = (int)((r >> 8) & 0xff); }
+      o->band_position[slot] = (int)((r >> 16) & 0xff);
+      for (int k = 0; k < 5; k++) o->offsets[5 * slot + k] = (int)(int8_t)(r >> (24 + 8 * k));
+    };
+    if (luma) unpack(&luma[i], 0, 0);
+    if (chroma) { unpack(&chroma[i], 1, 0); unpack(&chroma[i], 2, 1); }
+  }
+  return kvz::batch_check(b);
 }
 
 int kvz_hip_batch_checksums(kvz_hip_batch *b, uint32_t *host_out)

@@ -134,6 +134,18 @@ void kvz_oracle_intra_cost_model(int qp, const float entropy_fbits[128], uint64_
 double kvz_oracle_coeff_cabac_bits(const float entropy_fbits[128], const int16_t *coeff, int width, int type, int scan_mode, int update, uint8_t *ctx);
 const uint8_t *kvz_oracle_next_state_table(int lps);  /* cabac.c:40-62, regenerated from H.265 Table 9-41 */
 
+/* ---- SAO parameter decision of a whole picture in the encoder's LCU order (kvz_oracle_sao.c; sao.c:671 kvz_sao_search_lcu) ----
+ * src = the original picture, rec = the reconstruction BEFORE deblocking (Y|U|V tight), deblocked in place LCU by LCU when `deblock`
+ * (the statistics see the partly deblocked picture the encoder has at that moment); on return rec is the deblocked, pre-SAO picture.
+ * luma_out / chroma_out / merge_out: one record per LCU in raster order; merge: 0 none, 1 left, 2 up. */
+void kvz_oracle_sao_search_frame(const kvz_hip_intra_cost_model *m, int width, int height, const uint8_t *src, uint8_t *rec, const uint8_t *cu_depth,
+                                 int deblock, int beta_offset_div2, int tc_offset_div2, kvz_hip_sao_params *luma_out, kvz_hip_sao_params *chroma_out,
+                                 uint8_t *merge_out);
+void kvz_oracle_deblock_frame_passes(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,
+                                     const uint8_t *cu_depth, int passes);
+void kvz_oracle_deblock_lcu(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,
+                            const uint8_t *cu_depth, int x_px, int y_px);
+
 /* ---- deblocking of an all-intra, constant-QP picture in place (kvz_oracle_deblock.c; filter.c:783 kvz_filter_deblock_lcu over
  * every LCU).  Planes are tight (stride = width), cu_depth is the CU depth per 8x8 unit as the CTU pass returns it. ---- */
 void kvz_oracle_deblock_frame(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,

@@ -900,6 +900,8 @@ void kvz_oracle_intra_cost_model(int qp, const float entropy_fbits[128], uint64_
     for (int i = 0; i < 4; i++) inits[CX_ABS_LUMA + i] = init_abs[i];
     for (int i = 0; i < 2; i++) inits[CX_ABS_CHROMA + i] = init_abs[4 + i];
     for (int i = 0; i < CX_COUNT; i++) m->ctx_init[i] = (uint8_t)ctx_state(qp, inits[i]);
+    m->ctx_init[KVZ_HIP_CX_SAO_MERGE] = (uint8_t)ctx_state(qp, 153);  /* context.c:38-39, I slice (index 2) */
+    m->ctx_init[KVZ_HIP_CX_SAO_TYPE] = (uint8_t)ctx_state(qp, 200);
     m->coeff_cabac = qp >= 28;  /* `ultrafast`: fast-residual-cost 28 (cfg.c:485-512); MAX_FAST_COEFF_COST_QP = 50 lies above */
     memcpy(m->entropy_fbits, entropy_fbits, sizeof m->entropy_fbits);
     m->adaptive = 1;  /* kvazaar's behaviour; 0 freezes every context at its slice-start state */

@@ -93,12 +93,21 @@ static void chroma_part(uint8_t *px, int step_across, int step_along, int tc)
 void kvz_oracle_deblock_frame(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,
                               const uint8_t *cu_depth)
 {
+  kvz_oracle_deblock_frame_passes(width, height, qp, beta_offset_div2, tc_offset_div2, y, u, v, cu_depth, 3);
+}
+
+/* passes: 1 = every vertical edge, 2 = every horizontal edge, 3 = both in that order (the intermediate pictures the device's SAO
+ * statistics are assembled from, kvazaar_amd/csrc/kvz_sao.hpp) */
+void kvz_oracle_deblock_frame_passes(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,
+                                     const uint8_t *cu_depth, int passes)
+{
   const int w8 = width >> 3, cw = width >> 1, ch = height >> 1;
   const int beta = beta_prime(clip3(0, 51, qp + (beta_offset_div2 << 1)));
   const int tc = tc_prime(clip3(0, 53, qp + 2 * (2 - 1) + (tc_offset_div2 << 1)));                       /* filter.c:496-497, strength 2 */
   const int tc_c = tc_prime(clip3(0, 53, chroma_qp[qp] + 2 * (2 - 1) + (tc_offset_div2 << 1)));        /* filter.c:592-595 */
   for (int dir = 0; dir < 2; dir++) {  /* 0: vertical edges (filtering across x), 1: horizontal edges */
     const int vertical = dir == 0;
+    if (!(passes & (1 << dir))) continue;
     for (int ey = 0; ey < height; ey += 8)
       for (int ex = 0; ex < width; ex += 8) {
         if ((vertical ? ex : ey) == 0) continue;                        /* picture border, filter.c:648-649 */
@@ -116,4 +125,68 @@ void kvz_oracle_deblock_frame(int width, int height, int qp, int beta_offset_div
       }
   }
   (void)ch;
+}
+
+/* ---- the reference's own order: one LCU at a time (filter.c:783 kvz_filter_deblock_lcu) ---------------------------------
+ * Needed where the INTERMEDIATE picture matters: kvazaar searches an LCU's SAO parameters right after deblocking that LCU
+ * (encoderstate.c:669-682), i.e. on a picture whose right / lower neighbours have not been deblocked yet (oracle/kvz_oracle_sao.c).
+ * Statement for statement: vertical edges of the LCU (filter.c:699-714), the deferred rightmost 4 samples of the horizontal edges of the
+ * LCU to the left (filter.c:725-757), the horizontal edges of the LCU without their rightmost 4 samples unless the LCU ends the picture
+ * (filter.c:648-683). */
+typedef struct { int width, height, beta, tc, tc_c; uint8_t *y, *u, *v; const uint8_t *cu_depth; } dbk_t;
+
+static void edge_luma(const dbk_t *d, int x, int y, int length, int vertical)   /* filter.c:386-561 on `length` samples */
+{
+  for (int part = 0; part < length / 4; part++) {
+    uint8_t *p = d->y + (y + (vertical ? 4 * part : 0)) * d->width + x + (vertical ? 0 : 4 * part);
+    luma_part(p, vertical ? 1 : d->width, vertical ? d->width : 1, d->beta, d->tc);
+  }
+}
+static void edge_chroma(const dbk_t *d, int xc, int yc, int length, int vertical)  /* filter.c:567-624 */
+{
+  const int cw = d->width >> 1;
+  for (int part = 0; part < length / 4; part++) {
+    const int off = (yc + (vertical ? 4 * part : 0)) * cw + xc + (vertical ? 0 : 4 * part);
+    chroma_part(d->u + off, vertical ? 1 : cw, vertical ? cw : 1, d->tc_c);
+    chroma_part(d->v + off, vertical ? 1 : cw, vertical ? cw : 1, d->tc_c);
+  }
+}
+static void deblock_unit(const dbk_t *d, int x, int y, int vertical)  /* filter.c:638-683 with width = height = 8 */
+{
+  if (x == 0 && vertical) return;
+  if (y == 0 && !vertical) return;
+  int length = 8, length_c = 4;
+  if (!vertical) {
+    const int x_right = x + 8;
+    if (x_right % 64 == 0 && x_right != d->width) { length = 4; length_c = 0; }  /* deferred to the next LCU */
+  }
+  edge_luma(d, x, y, length, vertical);
+  const int xc = x >> 1, yc = y >> 1;
+  if (((vertical ? xc : yc) & 7) == 0) edge_chroma(d, xc, yc, length_c, vertical);
+}
+static void deblock_lcu_inside(const dbk_t *d, int x, int y, int vertical)  /* filter.c:699-714 */
+{
+  const int end_x = x + 64 < d->width ? x + 64 : d->width, end_y = y + 64 < d->height ? y + 64 : d->height;
+  for (int ey = y; ey < end_y; ey += 8)
+    for (int ex = x; ex < end_x; ex += 8)
+      if (edge_is_filtered(d->cu_depth, d->width >> 3, ex, ey, vertical)) deblock_unit(d, ex, ey, vertical);
+}
+static void deblock_lcu_rightmost(const dbk_t *d, int x_px, int y_px)  /* filter.c:725-757 */
+{
+  const int x = x_px - 4, end = y_px + 64 < d->height ? y_px + 64 : d->height;
+  for (int y = y_px; y < end; y += 8)
+    if (y > 0 && edge_is_filtered(d->cu_depth, d->width >> 3, x, y, 0)) edge_luma(d, x, y, 4, 0);
+  const int xc = (x_px >> 1) - 4, yc0 = y_px >> 1, end_c = yc0 + 32 < (d->height >> 1) ? yc0 + 32 : d->height >> 1;
+  for (int yc = yc0; yc < end_c; yc += 8)
+    if (yc > 0 && edge_is_filtered(d->cu_depth, d->width >> 3, xc << 1, yc << 1, 0)) edge_chroma(d, xc, yc, 4, 0);
+}
+
+void kvz_oracle_deblock_lcu(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,
+                            const uint8_t *cu_depth, int x_px, int y_px)
+{
+  dbk_t d = { width, height, beta_prime(clip3(0, 51, qp + (beta_offset_div2 << 1))), tc_prime(clip3(0, 53, qp + 2 + (tc_offset_div2 << 1))),
+              tc_prime(clip3(0, 53, chroma_qp[qp] + 2 + (tc_offset_div2 << 1))), y, u, v, cu_depth };
+  deblock_lcu_inside(&d, x_px, y_px, 1);
+  if (x_px > 0) deblock_lcu_rightmost(&d, x_px, y_px);
+  deblock_lcu_inside(&d, x_px, y_px, 0);
 }

@@ -52,6 +52,8 @@ def compare(a, b):
 
 
 def yuv_frames(width, height, n, seed, kind):
+    if kind == "adversarial":  # flat / noise / ramp / blocks (seed unused): the pictures that make band SAO, zero-coefficient CUs, big merges happen
+        return list(adversarial_frames(width, height).values())[:n]
     import synth
     return [np.concatenate([p.reshape(-1) for p in planes]) for planes in synth.frames(width, height, n, seed, kind)]
 

@@ -101,12 +101,20 @@ ENCODER_CLIPS_TILES = [(416, 240, 2, 1234, "small", 22, "2x2", False), (416, 240
                        (3840, 2160, 1, 2, "large", 22, "4x2", False), (3840, 2160, 1, 2, "large", 22, "4x2", True)]
 
 
+# (width, height, frames, seed, kind, qp, no_wpp): `--sao full` on top of the all-intra ultrafast configuration: the SAO parameter decision
+# (sao.c:671) runs per LCU right after that LCU's deblocking; the digest is the final (post-SAO) reconstruction
+ENCODER_CLIPS_SAO = [(64, 64, 2, 9, "small", 22, False), (200, 136, 2, 3, "small", 27, False), (416, 240, 2, 1234, "small", 22, False), (416, 240, 2, 7, "small", 32, False),
+                     (192, 136, 2, 5, "small", 45, False), (416, 240, 1, 1234, "small", 22, True), (832, 480, 1, 5, "large", 22, False), (1920, 1080, 1, 1, "large", 22, False),
+                     (1920, 1080, 1, 1, "large", 37, False),
+                     (192, 136, 4, 0, "adversarial", 32, False), (192, 136, 4, 0, "adversarial", 40, False)]  # band SAO is only chosen on these
+
+
 def clip_key(w, h, n, seed, kind, qp, deblock, no_wpp=False, tiles=None, wpp=False):
     return (f"{w}x{h}/n{n}/seed{seed}/{kind}/qp{qp}/{'deblock' if deblock else 'nodeblock'}" + ("/nowpp" if no_wpp else "")
             + (f"/tiles{tiles}" + ("-wpp" if wpp else "") if tiles else ""))
 
 
-def reference_encoder_recon(w, h, frames, qp, deblock, workdir, cu_maps=None, no_wpp=False, tiles=None, wpp=False):
+def reference_encoder_recon(w, h, frames, qp, deblock, workdir, cu_maps=None, no_wpp=False, tiles=None, wpp=False, sao=False):
     """runs the reference CLI (oracle/_ref/kvazaar_ref) on the clip; returns its --debug reconstruction, one array per frame.
     cu_maps: a list that receives, per frame, the (depth, intra mode) maps per 8x8 cell the encoder's search left in its cu_array
     (recorded through the oracle/ref_cudump.c interposer; single-threaded so that LCUs arrive frame by frame)"""
@@ -121,6 +129,8 @@ def reference_encoder_recon(w, h, frames, qp, deblock, workdir, cu_maps=None, no
         cmd.append("--no-wpp")
     if tiles:
         cmd += ["--tiles", tiles] + (["--wpp"] if wpp else [])
+    if sao:
+        cmd += ["--sao", "full"]
     env = dict(os.environ)
     dump = os.path.join(workdir, "cu.txt")
     if cu_maps is not None:
@@ -155,6 +165,10 @@ def encoder_digests(workdir):
         frames = cc.yuv_frames(w, h, n, seed, kind)
         recs = reference_encoder_recon(w, h, frames, qp, 0, workdir, None, True)
         out[clip_key(w, h, n, seed, kind, qp, 0, True)] = [hashlib.sha256(r.tobytes()).hexdigest()[:24] for r in recs]
+    for (w, h, n, seed, kind, qp, no_wpp) in ENCODER_CLIPS_SAO:
+        frames = cc.yuv_frames(w, h, n, seed, kind)
+        recs = reference_encoder_recon(w, h, frames, qp, 1, workdir, None, no_wpp, None, False, True)
+        out[clip_key(w, h, n, seed, kind, qp, 1, no_wpp) + "/sao"] = [hashlib.sha256(r.tobytes()).hexdigest()[:24] for r in recs]
     for (w, h, n, seed, kind, qp, tiles, wpp) in ENCODER_CLIPS_TILES:
         frames = cc.yuv_frames(w, h, n, seed, kind)
         for deblock in (0, 1):

@@ -66,6 +66,59 @@ extern "C" void kvz_hostsim_intra_frame(const kvz_hip_intra_cost_model *m, int w
 }
 extern "C" unsigned kvz_hostsim_ctu_shared_bytes(void) { return (unsigned)sizeof(kvz::CtuShared); }
 
+// ---- the SAO parameter decision (kvz_sao.hpp) on the host: statistics by plain loops over the view, then the device's own candidate and
+// chain code.  R / V / D: the reconstruction before deblocking, after the vertical edges, after all edges (Y|U|V tight). ----
+#include "../../kvazaar_amd/csrc/kvz_sao.hpp"
+#include <vector>
+extern "C" void kvz_hostsim_sao_decide(const kvz_hip_intra_cost_model *m, int width, int height, const uint8_t *src, const uint8_t *R, const uint8_t *V, const uint8_t *D,
+                                       kvz_hip_sao_params *luma, kvz_hip_sao_params *chroma, uint8_t *merge)
+{
+  using namespace kvz;
+  static Tables tb;
+  build_tables(&tb);
+  const int wl = (width + 63) / 64, hl = (height + 63) / 64;
+  std::vector<SaoStats> stats((size_t)wl * hl * 3);
+  std::vector<SaoCand> cand((size_t)wl * hl * 3);
+  std::vector<SaoRec> recs((size_t)wl * hl * 3);
+  for (int lcu = 0; lcu < wl * hl; lcu++)
+    for (int color = 0; color < 3; color++) {
+      const int lx = lcu % wl, ly = lcu / wl, sh = color ? 1 : 0, n = 64 >> sh, fw = width >> sh, fh = height >> sh;
+      const long plane = color == 0 ? 0 : (color == 1 ? (long)width * height : (long)width * height * 5 / 4);
+      const int bw = imin(n, fw - lx * n), bh = imin(n, fh - ly * n);
+      SaoView view{ R + plane, V + plane, D + plane, fw, n, lx * n, ly * n, lx == wl - 1, ly == hl - 1, color ? 1 : 3 };
+      SaoStats &st = stats[(size_t)lcu * 3 + color];
+      memset(&st, 0, sizeof st);
+      for (int y = 0; y < bh; y++)
+        for (int x = 0; x < bw; x++) {
+          const int c = view.at(x, y), diff = (int)src[plane + (long)(ly * n + y) * fw + lx * n + x] - c;
+          st.band_sum[c >> 3] += diff;
+          st.band_cnt[c >> 3]++;
+          if (x >= 1 && x < bw - 1 && y >= 1 && y < bh - 1)
+            for (int ec = 0; ec < 4; ec++) {
+              int ax, ay, bx, by;
+              eo_offsets(ec, ax, ay, bx, by);
+              const int cat = eo_cat(view.at(x + ax, y + ay), view.at(x + bx, y + by), c);
+              st.edge_sum[ec][cat] += diff;
+              st.edge_cnt[ec][cat]++;
+            }
+        }
+      sao_candidates(st, cand[(size_t)lcu * 3 + color]);
+    }
+  sao_chain_picture(m->entropy_fbits, tb.ctx_next[0], tb.ctx_next[1], m->lambda, m->ctx_init[KVZ_HIP_CX_SAO_MERGE], m->ctx_init[KVZ_HIP_CX_SAO_TYPE], m->no_wpp, wl, hl, stats.data(),
+                    cand.data(), recs.data(), merge);
+  for (int i = 0; i < wl * hl; i++) {
+    auto unpack = [&](kvz_hip_sao_params *o, int plane, int slot) {
+      const SaoRec r = recs[(size_t)i * 3 + plane];
+      if (slot == 0) { memset(o, 0, sizeof *o); o->bitdepth = 8; o->type = (int)(r & 0xff); o->eo_class = (int)((r >> 8) & 0xff); }
+      o->band_position[slot] = (int)((r >> 16) & 0xff);
+      for (int k = 0; k < 5; k++) o->offsets[5 * slot + k] = (int)(int8_t)(r >> (24 + 8 * k));
+    };
+    unpack(&luma[i], 0, 0);
+    unpack(&chroma[i], 1, 0);
+    unpack(&chroma[i], 2, 1);
+  }
+}
+
 #ifdef KVZ_HOSTSIM_COUNT_SYNCS
 extern "C" unsigned long long kvz_hostsim_syncs(void) { return g_kvz_syncs; }
 #endif
