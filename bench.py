@@ -198,6 +198,40 @@ def cpu_baseline(args, frames, model):
                       f"{best}: {legs[best]['sample']}", "legs": legs, "port": port}
 
 
+def exchange_leg(dist, torch, rank, world, reps=20):
+    """The sharded INTER configuration's one collective, measured on its own: per picture every rank contributes the final
+    reconstruction of its tiles of a 3840x2160 --tiles 4x2 picture and receives everybody else's (kvazaar_amd/sharding.py
+    allgather_reference_frame: all_gather_into_tensor over RCCL + paste into the full reference frame).  Tile contents are synthetic
+    device buffers here (the inter CTU pass that would produce them is not part of this round); checked by an all-reduced byte sum."""
+    from kvazaar_amd import sharding
+    w, h = 3840, 2160
+    plan = sharding.exchange_plan(w, h, 4, 2, world)
+    mine = sharding.tiles_of_rank(len(plan["tiles"]), rank, world)
+    g = torch.Generator(device="cuda").manual_seed(1000 + rank)
+    local = {ti: torch.randint(0, 256, (plan["tiles"][ti][2] * plan["tiles"][ti][3] * 3 // 2,), dtype=torch.uint8, device="cuda", generator=g) for ti in mine}
+    frame = torch.empty(w * h * 3 // 2, dtype=torch.uint8, device="cuda")
+    sharding.allgather_reference_frame(dist, plan, rank, world, local, w, h, frame)  # warm-up (RCCL channel setup)
+    own = torch.tensor([sum(int(t.sum(dtype=torch.int64)) for t in local.values())], dtype=torch.int64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(own)
+    ok = int(frame.sum(dtype=torch.int64)) == int(own.item())
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t = time.perf_counter()
+    for _ in range(reps):
+        sharding.allgather_reference_frame(dist, plan, rank, world, local, w, h, frame)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    s = (time.perf_counter() - t) / reps
+    recv = plan["recv_bytes_per_rank"]
+    return {"workload": "3840x2160 --tiles 4x2 reference-frame exchange: all_gather_into_tensor of the ranks' reconstructed tiles + paste (one per inter picture)",
+            "ms_per_picture": s * 1e3, "recv_bytes_per_rank": recv, "recv_GBps_per_rank": recv / s / 1e9, "frame_bytes": plan["frame_bytes"], "assembled_ok": ok,
+            "xgmi_expected_us": recv / 153e9 * 1e6 if world > 1 else 0.0,
+            "note": "expected = received bytes / 153 GB/s (one xGMI link, ring all-gather is per-link bound); measured includes the per-tile paste kernels and launch overhead"}
+
+
 def build_batches(args, lib, rank, world, width, height, frames, tiles_arg, HipBatch):
     """-> (batches [(HipBatch, slots)], distinct frames, CTUs per (whole) picture, job CTUs per step over all ranks)"""
     from kvazaar_amd import sharding
@@ -320,6 +354,13 @@ def main():
     else:
         ok_all = ok_local
 
+    exchange = None
+    if not args.no_extra:
+        try:
+            exchange = exchange_leg(dist, torch, rank, world)
+        except Exception as e:  # auxiliary: never take the headline down
+            exchange = {"error": repr(e)}
+
     if rank == 0:
         total_ctus = job_ctus_per_step * args.steps
         value = total_ctus / dt
@@ -352,6 +393,8 @@ def main():
                          "avg_launch_us": per_launch_s * 1e6, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "the CTU search is a latency x concurrency machine limited by VALU issue (limiter), not a streaming kernel (DESIGN.md 5); per-kernel HBM and MFMA fractions of the streaming primitives: bench_kernels.py"},
         }
+        if exchange is not None:
+            result["exchange"] = exchange
         if world == 1 and not args.no_extra:
             extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedResults)
         if not args.no_cpu_baseline:

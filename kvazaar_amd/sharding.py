@@ -76,3 +76,62 @@ def timed_steps(step_fn, steps, dist=None, device_sync=None, tensor_device="cpu"
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+# ---- the one data-path collective of the sharded INTER configuration -----------------------------------------------
+# With tiles dealt to ranks, motion vectors of the next picture may point into any tile of the reference picture
+# (search_inter.c:149-178: only --mv-constraint keeps them inside), so after a picture's loop filters every rank needs every tile's final
+# reconstruction: one all-gather per picture.  Tiles of a uniform grid differ in size by at most one CTU row / column, so each rank
+# contributes a fixed-size slot per tile (the largest tile's planar 4:2:0 bytes) and pastes the received slots into its full reference
+# frame.  Backend "nccl" = RCCL over xGMI on the GPUs (uint8 tensors on the device), "gloo" in the CPU tests.
+
+def tile_slot_bytes(tiles):
+    """bytes of one exchange slot: the largest tile's Y|U|V planar picture"""
+    return max(t[2] * t[3] * 3 // 2 for t in tiles)
+
+
+def tiles_of_rank(n_tiles, rank, world):
+    lo, hi = frames_for_rank(n_tiles, rank, world)
+    return list(range(lo, hi))
+
+
+def exchange_plan(width, height, cols, rows, world):
+    """static description of the exchange for a picture: tiles, slot size, slots per rank (ranks with fewer tiles send padding), and the
+    bytes a rank receives per picture -- what the bench line reports next to the measured time"""
+    tiles = tile_grid(width, height, cols, rows)
+    per_rank = max(len(tiles_of_rank(len(tiles), r, world)) for r in range(world))
+    slot = tile_slot_bytes(tiles)
+    return {"tiles": tiles, "slot_bytes": slot, "slots_per_rank": per_rank, "frame_bytes": width * height * 3 // 2,
+            "recv_bytes_per_rank": (world - 1) * per_rank * slot}
+
+
+def allgather_reference_frame(dist, plan, rank, world, local_tiles, width, height, out_frame=None):
+    """local_tiles: {tile index: 1-D uint8 torch tensor holding that tile's planar picture} for this rank's tiles (any device).
+    Returns the full planar reference frame (1-D uint8 tensor on the same device) assembled from every rank's tiles."""
+    import torch
+    tiles, slot, per_rank = plan["tiles"], plan["slot_bytes"], plan["slots_per_rank"]
+    mine = tiles_of_rank(len(tiles), rank, world)
+    device = next(iter(local_tiles.values())).device if local_tiles else torch.device("cpu")
+    send = torch.zeros(per_rank * slot, dtype=torch.uint8, device=device)
+    for k, ti in enumerate(mine):
+        t = local_tiles[ti]
+        send[k * slot:k * slot + t.numel()] = t
+    recv = torch.empty(world * per_rank * slot, dtype=torch.uint8, device=device)
+    if world > 1:
+        dist.all_gather_into_tensor(recv, send)
+    else:
+        recv.copy_(send)
+    frame = out_frame if out_frame is not None else torch.empty(width * height * 3 // 2, dtype=torch.uint8, device=device)
+    ys, cs = width * height, (width // 2) * (height // 2)
+    Y = frame[:ys].view(height, width)
+    U = frame[ys:ys + cs].view(height // 2, width // 2)
+    V = frame[ys + cs:ys + 2 * cs].view(height // 2, width // 2)
+    for r in range(world):
+        for k, ti in enumerate(tiles_of_rank(len(tiles), r, world)):
+            x, y, w, h = tiles[ti]
+            base = (r * per_rank + k) * slot
+            c = (w // 2) * (h // 2)
+            Y[y:y + h, x:x + w] = recv[base:base + w * h].view(h, w)
+            U[y // 2:(y + h) // 2, x // 2:(x + w) // 2] = recv[base + w * h:base + w * h + c].view(h // 2, w // 2)
+            V[y // 2:(y + h) // 2, x // 2:(x + w) // 2] = recv[base + w * h + c:base + w * h + 2 * c].view(h // 2, w // 2)
+    return frame

@@ -160,3 +160,47 @@ def test_two_rank_tile_sharding_equals_single_process(oracle):
     [p.join(timeout=60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert got == want.tobytes()
+
+
+def _exchange_worker(rank, world, port, out, geometry):
+    """the inter configuration's collective: every rank contributes its tiles' reconstruction, every rank ends up with the whole reference frame"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w, h, cols, rows = geometry
+    rng = np.random.default_rng(11)
+    frame = rng.integers(0, 256, w * h * 3 // 2, dtype=np.uint8)  # stands for the reconstructed picture; every rank knows it only to cut ITS tiles
+    plan = sharding.exchange_plan(w, h, cols, rows, world)
+    mine = sharding.tiles_of_rank(len(plan["tiles"]), rank, world)
+    local = {ti: torch.from_numpy(sharding.crop_tile(frame, w, h, plan["tiles"][ti])) for ti in mine}
+    got = sharding.allgather_reference_frame(dist, plan, rank, world, local, w, h)
+    out.put((rank, bool(np.array_equal(got.numpy(), frame)), plan["recv_bytes_per_rank"]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("geometry", [(416, 240, 2, 2), (832, 480, 3, 2), (3840, 2160, 4, 2)], ids=lambda g: f"{g[0]}x{g[1]}-tiles{g[2]}x{g[3]}")
+def test_two_rank_reference_frame_allgather(geometry):
+    """SURVEY.md 8e, sharded inter: all_gather_into_tensor of per-rank tiles into the full reference frame on every rank (gloo here, RCCL on the
+    GPUs) == the single-process frame; uneven tile sizes (960x1088 / 960x1072 at 4K) and an odd tile count (3x2 over 2 ranks) included"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q, geometry)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert [r[1] for r in res] == [True, True]
+    w, h, cols, rows = geometry
+    tiles = sharding.tile_grid(w, h, cols, rows)
+    assert res[0][2] == (len(tiles) + 1) // 2 * sharding.tile_slot_bytes(tiles)  # one peer's slots
+
+
+def test_single_process_exchange_is_identity():
+    w, h = 416, 240
+    plan = sharding.exchange_plan(w, h, 2, 2, 1)
+    frame = np.random.default_rng(3).integers(0, 256, w * h * 3 // 2, dtype=np.uint8)
+    local = {i: torch.from_numpy(sharding.crop_tile(frame, w, h, t)) for i, t in enumerate(plan["tiles"])}
+    assert np.array_equal(sharding.allgather_reference_frame(None, plan, 0, 1, local, w, h).numpy(), frame)
