@@ -50,7 +50,7 @@ def main():
     args = ap.parse_args()
 
     import kvazaar_amd
-    import devapi
+    from kvazaar_amd import dev as devapi
     dev = devapi.Dev(kvazaar_amd.load_library())
     results = []
 
@@ -147,6 +147,51 @@ def main():
             "abs_diffs_per_s": round(diffs), "valu_sad_frac": round(diffs / (256 * 4 * 16 * 4 * 2.4e9), 4),
             "note": "bound: v_sad_u8 issue (4 differences per lane per instruction, 256 CUs x 4 SIMDs x 16 lanes at 2.4 GHz); the window is read from HBM once"})
     dev.free(dc, dr, dxy, dout)
+
+    # fractional motion search: every 16x16 (and 32x32) PU of a 1080p picture, both half-pel steps (`veryfast`: fme_level 2) = 9 SATDs per PU;
+    # algorithmic bytes: the (w + 8)(h + 8) window + the w h source block read, 17 costs written
+    class FmePu(C.Structure):
+        _fields_ = [("x", C.c_int16), ("y", C.c_int16), ("w", C.c_int16), ("h", C.c_int16), ("mv_x", C.c_int16), ("mv_y", C.c_int16), ("hpel_x", C.c_int8), ("hpel_y", C.c_int8), ("r", C.c_int16)]
+
+    class McPu(C.Structure):
+        _fields_ = [("x", C.c_int16), ("y", C.c_int16), ("w", C.c_int16), ("h", C.c_int16), ("mv", (C.c_int16 * 2) * 2), ("use", C.c_int8 * 2), ("r", C.c_int16)]
+    dev.lib.kvz_hip_dev_fme_costs.restype = None
+    dev.lib.kvz_hip_dev_fme_costs.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    dev.lib.kvz_hip_dev_inter_pred.restype = None
+    dev.lib.kvz_hip_dev_inter_pred.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    nrep = 16  # PU lists of 16 pictures' worth per launch (the same picture pair: the window traffic is what it would be for distinct ones)
+    dc, dr = dev.put(cur), dev.put(ref)
+    for pw in (16, 32):
+        coords = [(x, y) for y in range(0, h - pw + 1, pw) for x in range(0, w - pw + 1, pw)] * nrep
+        arr = (FmePu * len(coords))(*[FmePu(x, y, pw, pw, int(rng.integers(-8, 9)), int(rng.integers(-8, 9)), 0, 0, 0) for (x, y) in coords])
+        dp, dout = dev.empty(C.sizeof(arr)), dev.empty(len(coords) * 17 * 4)
+        dev.lib.kvz_hip_dev_upload(dp, C.addressof(arr), C.sizeof(arr))
+        for steps, label in ((3, "hpel"), (15, "hpel+qpel")):
+            ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_fme_costs(dc, dr, w, h, dp, len(coords), pw, steps, dout), args.reps, args.warmup)
+            ncand = 1 + 4 * bin(steps).count("1")
+            report(f"fme_costs_{pw}x{pw}_{label}", pw, len(coords), ms, (pw + 8) ** 2 + pw * pw + 4 * 17,
+                   {"path": "one workgroup per PU: window in LDS, shared 14-bit horizontal intermediates, planes scored in LDS", "candidates_per_s": round(len(coords) * ncand / (ms * 1e-3)),
+                    "pictures_per_s": round(nrep / (ms * 1e-3), 1)})
+        dev.free(dp, dout)
+    # motion-compensated prediction: every 16x16 PU of a 1080p picture, quarter-pel vectors; uni- and bi-prediction.  Bytes per PU and list:
+    # (w + 7)(h + 7) + 2 (w/2 + 3)(h/2 + 3) read, 1.5 w h written once
+    yuv = np.concatenate([cur.reshape(-1), rng.integers(0, 256, w * h // 2, dtype=np.uint8)])
+    d0, d1, dpred = dev.put(yuv), dev.put(np.roll(yuv, 7)), dev.empty(yuv.nbytes)
+    for bi in (0, 1):
+        coords = [(x, y) for y in range(0, h - 15, 16) for x in range(0, w - 15, 16)] * nrep
+        arr = (McPu * len(coords))()
+        for i, (x, y) in enumerate(coords):
+            arr[i].x, arr[i].y, arr[i].w, arr[i].h = x, y, 16, 16
+            for l in range(2):
+                arr[i].mv[l][0], arr[i].mv[l][1] = int(rng.integers(-40, 41)), int(rng.integers(-40, 41))
+            arr[i].use[0], arr[i].use[1] = 1, bi
+        dp = dev.empty(C.sizeof(arr))
+        dev.lib.kvz_hip_dev_upload(dp, C.addressof(arr), C.sizeof(arr))
+        ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_inter_pred(d0, d1, dpred, w, h, dp, len(coords), 16), args.reps, args.warmup)
+        report("inter_pred_16x16_" + ("bi" if bi else "uni"), 16, len(coords), ms, (1 + bi) * (23 * 23 + 2 * 11 * 11) + 384,
+               {"path": "one workgroup per PU: 8-tap luma / 4-tap chroma through LDS, bipred average in LDS", "pictures_per_s": round(nrep / (ms * 1e-3), 1)})
+        dev.free(dp)
+    dev.free(dc, dr, d0, d1, dpred)
 
     print(json.dumps({"summary": "bench_kernels", "batch_ctus": args.batch_ctus, "reps": args.reps, "kernels": len(results)}))
 

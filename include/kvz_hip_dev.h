@@ -59,6 +59,37 @@ void kvz_hip_dev_deblock_frames(uint8_t *frames, int width, int height, int n_fr
 void kvz_hip_dev_sad_surface(const uint8_t *cur, const uint8_t *ref, int width, int height, int bw, int range, const int16_t *blk_xy, int count,
                              uint32_t *out);
 
+/* Fractional motion search, the arithmetic of search_frac (search_inter.c:974-1130) for `count` prediction units of one picture pair:
+ * for PU i -- the w x h block of `cur` at (x, y), w and h multiples of 8 up to 64 -- with integer-pel motion vector (mv_x, mv_y):
+ *   out[i][0]            = kvz_satd_any_size(w, h, source block, reference block at the integer position)   (search_inter.c:1059)
+ *   out[i][1 + 4 s + j]  = cost j of kvz_satd_any_size_quad over the four planes of step s                    (search_inter.c:1088-1118)
+ * for every step s set in the bit mask `steps`: 0 = kvz_filter_hpel_blocks_hor_ver_luma (left, right, top, bottom), 1 = ..._hpel_blocks_diag_luma
+ * (top-left, top-right, bottom-left, bottom-right), 2 / 3 = the quarter-pel functions around the half-pel offset (hpel_x, hpel_y) in
+ * {-1, 0, 1}^2 (search_frac's sample_off_x / _y).  The reference window is read with clamped addressing, which is what
+ * kvz_get_extended_block (ipol-generic.c:761-814) materialises.  Both pictures are width x height luma planes, stride = width.
+ * `veryfast` (fme_level 2) uses steps = 3 in one call; quarter-pel presets call again with steps = 12 after choosing the half-pel offset. */
+typedef struct kvz_hip_fme_pu {
+  int16_t x, y, w, h;
+  int16_t mv_x, mv_y;      /* integer-pel units (best_mv >> 2) */
+  int8_t  hpel_x, hpel_y;  /* only read by steps 2 and 3 */
+  int16_t reserved;
+} kvz_hip_fme_pu;
+#define KVZ_HIP_FME_COSTS 17
+void kvz_hip_dev_fme_costs(const uint8_t *cur, const uint8_t *ref, int width, int height, const kvz_hip_fme_pu *pus, int count, int max_pu_size, int steps, uint32_t *out);
+
+/* Motion-compensated prediction (inter.c:371-575 inter_recon_unipred / kvz_inter_recon_bipred -> kvz_sample_quarterpel_luma(_hi),
+ * kvz_sample_octpel_chroma(_hi), kvz_bipred_average): for PU i -- w x h luma samples at (x, y), multiples of 8 up to 64 -- the prediction
+ * from reference list 0 (use[0]) and / or list 1 (use[1]) with quarter-pel motion vectors mv[list] = {x, y}, written into the PU's samples of
+ * all three planes of `pred`.  ref0 / ref1 / pred: tight planar 4:2:0 pictures (Y | U | V) of width x height; references are read with
+ * clamped addressing (what kvz_get_extended_block / inter_cp_with_ext_border materialise at the picture edge). */
+typedef struct kvz_hip_mc_pu {
+  int16_t x, y, w, h;
+  int16_t mv[2][2];
+  int8_t  use[2];
+  int16_t reserved;
+} kvz_hip_mc_pu;
+void kvz_hip_dev_inter_pred(const uint8_t *ref0, const uint8_t *ref1, uint8_t *pred, int width, int height, const kvz_hip_mc_pu *pus, int count, int max_pu_size);
+
 /* SAO applied to whole pictures: kvz_sao_reconstruct (sao.c:302-361) for every CTU and plane of n_frames tight planar 4:2:0
  * frames.  in = the deblocked pictures, out = a different buffer of the same layout (SAO reads pre-SAO neighbours);
  * luma / chroma = n_frames x CTUs (raster order) parameter records, chroma carrying U in offsets[0..4] / band_position[0] and V

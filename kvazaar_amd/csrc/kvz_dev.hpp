@@ -517,6 +517,10 @@ __global__ void __launch_bounds__(64) dev_sao_chain_kernel(const SaoStats *stats
                     merge + base);
 }
 
+}  // namespace kvz
+#include "kvz_fme.hpp"
+namespace kvz {
+
 struct DevTimer { hipEvent_t e0 = nullptr, e1 = nullptr; };
 static DevTimer &dev_timer() { static thread_local DevTimer t; return t; }
 
@@ -652,6 +656,30 @@ void kvz_hip_dev_sad_surface(const uint8_t *cur, const uint8_t *ref, int width, 
   case 64: hipLaunchKernelGGL(kvz::dev_sad_surface_kernel<64>, grid, block, 0, be().stream, cur, ref, width, height, range, blk_xy, out); break;
   default: fprintf(stderr, "kvz_hip_dev_sad_surface: unsupported block width %d\n", bw); abort();
   }
+  KVZ_HIP_CHECK(hipGetLastError());
+}
+
+void kvz_hip_dev_fme_costs(const uint8_t *cur, const uint8_t *ref, int width, int height, const kvz_hip_fme_pu *pus, int count, int max_pu_size, int steps, uint32_t *out)
+{
+  if (count <= 0) return;
+  const dim3 grid((unsigned)count), block(256);
+  const kvz::Tables *tb = kvz::device_tables();
+  if (max_pu_size <= 16) hipLaunchKernelGGL(kvz::dev_fme_kernel<16>, grid, block, 0, be().stream, cur, ref, width, height, pus, steps, tb, out);
+  else if (max_pu_size <= 32) hipLaunchKernelGGL(kvz::dev_fme_kernel<32>, grid, block, 0, be().stream, cur, ref, width, height, pus, steps, tb, out);
+  else if (max_pu_size <= 64) hipLaunchKernelGGL(kvz::dev_fme_kernel<64>, grid, block, 0, be().stream, cur, ref, width, height, pus, steps, tb, out);
+  else { fprintf(stderr, "kvz_hip_dev_fme_costs: PUs larger than 64 samples do not exist\n"); abort(); }
+  KVZ_HIP_CHECK(hipGetLastError());
+}
+
+void kvz_hip_dev_inter_pred(const uint8_t *ref0, const uint8_t *ref1, uint8_t *pred, int width, int height, const kvz_hip_mc_pu *pus, int count, int max_pu_size)
+{
+  if (count <= 0) return;
+  const dim3 grid((unsigned)count), block(256);
+  const kvz::Tables *tb = kvz::device_tables();
+  if (max_pu_size <= 16) hipLaunchKernelGGL(kvz::dev_inter_pred_kernel<16>, grid, block, 0, be().stream, ref0, ref1, pred, width, height, pus, tb);
+  else if (max_pu_size <= 32) hipLaunchKernelGGL(kvz::dev_inter_pred_kernel<32>, grid, block, 0, be().stream, ref0, ref1, pred, width, height, pus, tb);
+  else if (max_pu_size <= 64) hipLaunchKernelGGL(kvz::dev_inter_pred_kernel<64>, grid, block, 0, be().stream, ref0, ref1, pred, width, height, pus, tb);
+  else { fprintf(stderr, "kvz_hip_dev_inter_pred: PUs larger than 64 samples do not exist\n"); abort(); }
   KVZ_HIP_CHECK(hipGetLastError());
 }
 

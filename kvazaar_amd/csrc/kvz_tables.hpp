@@ -197,7 +197,7 @@ inline int satd_tiles(int kind, int w, int h, SatdTile *out)
 //   which 1: hpel diag     tl = HV(f2,f2)(y, x)   tr = HV(f2,f2)(y, x+1)   bl = HV(f2,f2)(y+1, x)   br = HV(f2,f2)(y+1, x+1)
 //   which 2: qpel hor_ver  l = HV(hl, vl)(y+soy, x+ofl)   r = HV(hr, vl)(y+soy, x+ofr)   t = HV(hh, vt)(y+oft, x+sox)   b = HV(hh, vb)(y+ofb, x+sox)
 //   which 3: qpel diag     tl/tr/bl/br = HV(hl|hr, vt|vb)(y+oft|ofb, x+ofl|ofr)
-inline void fme_planes(int which, int ox, int oy, FmePlane pl[4])
+KVZ_HD void fme_planes(int which, int ox, int oy, FmePlane pl[4])
 {
   const int hl = ox != 0 ? 1 : 3, hr = ox != 0 ? 3 : 1, hh = ox != 0 ? 2 : 0;
   const int vl = oy != 0 ? 2 : 0, vt = oy != 0 ? 1 : 3, vb = oy != 0 ? 3 : 1;
