@@ -98,8 +98,11 @@ void kvz_hip_intra_pred_filtered_dc(const int_fast8_t log2_width, const uint8_t 
 
 /* ---- 1. typedef-exact: strategies-quant.h:60-62 -------------------------------------------------------------------- */
 /* array_checksum_func (strategies-nal.h:54-58): typedef-exact; writes the sum big-endian into checksum_out[0..3] */
+void     kvz_hip_array_md5(const uint8_t *data, const int height, const int width, const int stride, unsigned char checksum_out[16],
+                           const uint8_t bitdepth);  /* strategies-nal.h:54-58 "array_md5" (--hash md5) */
 void     kvz_hip_array_checksum(const uint8_t *data, const int height, const int width, const int stride, unsigned char checksum_out[16],
                                 const uint8_t bitdepth);
+void     kvz_hip_plane_md5(const uint8_t *data, int height, int width, int stride, uint8_t *out16);       /* nal-generic.c:41-55, the 16 digest bytes */
 uint32_t kvz_hip_plane_checksum(const uint8_t *data, int height, int width, int stride);            /* nal-generic.c:57-82, the 32-bit sum */
 uint32_t kvz_hip_coeff_abs_sum(const int16_t *coeffs, size_t length);                        /* quant-generic.c:342-349 */
 double   kvz_hip_fast_coeff_cost(const int16_t *coeff, int32_t width, uint64_t weights);     /* :359-375 */

@@ -98,6 +98,9 @@ int  kvz_hip_batch_sao_params(kvz_hip_batch *b, int frame, kvz_hip_sao_params *l
  * Queued behind whatever the batch's stream holds (CTU pass, deblocking) and waited for. */
 int  kvz_hip_batch_checksums(kvz_hip_batch *b, uint32_t *host_out);  /* 0 / -1 like kvz_hip_batch_sync */
 
+/* ... and the MD5 flavour of the picture hash (nal.c:88-101 kvz_image_md5, `--hash md5`): host_out[(3 f + plane) * 16 ..] = 16 digest bytes. */
+int  kvz_hip_batch_md5(kvz_hip_batch *b, uint8_t *host_out);
+
 /* Cost model of an I slice at `qp` (kvz_hip_intra_cost_model, adaptive contexts): HEVC context init values
  * (context.c:96-134), kvz_ctx_init (context.c:202-213), the HM entropy table (rdo.c:69-80), lambda of
  * rate_control.c:678-691.  coeff_weights = kvz_fast_coeff_get_weights(state) of the encoder (fast_coeff_cost.c:84-88). */

@@ -102,6 +102,10 @@ void kvz_hip_dev_sao_frames(const uint8_t *in, uint8_t *out, int width, int heig
  * (nal-generic.c:57-82) for n_frames tight planar 4:2:0 frames; width a multiple of 8.  1.5 w h bytes read per frame. */
 void kvz_hip_dev_picture_checksums(const uint8_t *frames, int width, int height, int n_frames, uint32_t *out);
 
+/* Picture-hash MD5 (nal.c:88-101 kvz_image_md5, `--hash md5`): out[(3 f + p) * 16 ..] = the 16 digest bytes of plane p of frame f
+ * (kvz_array_md5, nal-generic.c:41-55).  One serial chain per plane, one lane each: throughput comes from the number of planes in flight. */
+void kvz_hip_dev_picture_md5(const uint8_t *frames, int width, int height, int n_frames, uint8_t *out);
+
 #ifdef __cplusplus
 }
 #endif

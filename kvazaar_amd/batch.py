@@ -134,6 +134,15 @@ class HipBatch:
             raise BatchError("kvz_hip_batch_checksums: the batch's last pass was invalid")
         return out
 
+    def md5(self):
+        """-> uint8 array [frames][3][16]: kvz_image_md5 of every frame's current reconstruction (--hash md5)"""
+        out = np.zeros((self.n, 3, 16), np.uint8)
+        self.lib.kvz_hip_batch_md5.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.kvz_hip_batch_md5.restype = C.c_int
+        if self.lib.kvz_hip_batch_md5(self.handle, out.ctypes.data) != 0:
+            raise BatchError("kvz_hip_batch_md5: the batch's last pass was invalid")
+        return out
+
     def kernel_ms(self):
         return self.lib.kvz_hip_batch_last_kernel_ms(self.handle)
 

@@ -311,6 +311,34 @@ template <class B> struct Api {
     return total;
   }
 
+  // kvz_array_md5 (nal-generic.c:41-55): width * height contiguous bytes from `data` (the reference ignores the stride too); the message
+  // goes through the staging arena in chunks of whole 64-byte blocks, the chaining value stays on the device's side of the arena.
+  static void plane_md5(B &be, const u8 *data, int height, int width, u8 out[16])
+  {
+    const unsigned long long total = (unsigned long long)(width > 0 && height > 0 ? (long)width * height : 0);
+    const size_t room = (be.cap - 4096) & ~(size_t)63;
+    u32 state[4] = { 0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u };
+    unsigned long long done = 0;
+    for (;;) {
+      const unsigned long long left = total - done;
+      const int finish = left <= room;
+      const size_t n = finish ? (size_t)left : room;
+      be.begin();
+      const u8 *d = be.in(data + done, n ? n : 1);
+      u32 *st = be.template in_raw<u32>(4);
+      memcpy(be.host_rw(st), state, sizeof state);
+      be.mark_download_from(st);
+      be.dl_end = be.cur;
+      be.upload();
+      be.run(Md5Op{ d, (long)(n / 64), finish ? (int)(n % 64) : 0, finish, total, st }, 1);
+      be.download();
+      memcpy(state, be.host(st), sizeof state);
+      done += n;
+      if (finish) break;
+    }
+    for (int i = 0; i < 16; i++) out[i] = (u8)(state[i >> 2] >> (8 * (i & 3)));
+  }
+
   static double fast_coeff_cost(B &be, const i16 *coeff, int width, uint64_t weights)
   {
     be.begin();

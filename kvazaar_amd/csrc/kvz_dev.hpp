@@ -521,6 +521,22 @@ __global__ void __launch_bounds__(64) dev_sao_chain_kernel(const SaoStats *stats
 #include "kvz_fme.hpp"
 namespace kvz {
 
+// ---------------------------------------------------------------------------------------------------------------
+// Picture-hash MD5 (nal.c:88-101 kvz_image_md5 -> nal-generic.c:41-55 per plane): a serial chain of 64-byte blocks per plane, so the batch
+// brings the parallelism: one lane per (frame, plane).  Each lane streams its plane with 64-byte reads (one cache line per block).
+__global__ void __launch_bounds__(64) dev_md5_kernel(const u8 *frames, const int W, const int H, const long n_planes, u8 *out /* [n_planes][16] */)
+{
+  const long i = (long)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n_planes) return;
+  const long frame = i / 3;
+  const int plane = (int)(i % 3);
+  const long bytes = plane ? (long)(W >> 1) * (H >> 1) : (long)W * H;
+  const u8 *p = frames + frame * ((long)W * H * 3 / 2) + (plane == 0 ? 0 : (plane == 1 ? (long)W * H : (long)W * H * 5 / 4));
+  u32 st[4] = { 0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u };
+  md5_run(st, p, bytes / 64, (int)(bytes % 64), 1, (unsigned long long)bytes);
+  for (int k = 0; k < 16; k++) out[i * 16 + k] = (u8)(st[k >> 2] >> (8 * (k & 3)));
+}
+
 struct DevTimer { hipEvent_t e0 = nullptr, e1 = nullptr; };
 static DevTimer &dev_timer() { static thread_local DevTimer t; return t; }
 
@@ -763,6 +779,29 @@ int kvz_hip_batch_sao_params(kvz_hip_batch *b, int frame, kvz_hip_sao_params *lu
     if (luma) unpack(&luma[i], 0, 0);
     if (chroma) { unpack(&chroma[i], 1, 0); unpack(&chroma[i], 2, 1); }
   }
+  return kvz::batch_check(b);
+}
+
+void kvz_hip_dev_picture_md5(const uint8_t *frames, int width, int height, int n_frames, uint8_t *out)
+{
+  if (n_frames <= 0) return;
+  const long n = 3L * n_frames;
+  hipLaunchKernelGGL(kvz::dev_md5_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, be().stream, frames, width, height, n, out);
+  KVZ_HIP_CHECK(hipGetLastError());
+}
+
+int kvz_hip_batch_md5(kvz_hip_batch *b, uint8_t *host_out)
+{
+  kvz::batch_enter(b);
+  const long n = 3L * b->n_frames;
+  if (n <= 0) return 0;
+  uint8_t *d = nullptr;
+  KVZ_HIP_CHECK(hipMallocAsync((void **)&d, (size_t)n * 16, b->stream));
+  hipLaunchKernelGGL(kvz::dev_md5_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, b->stream, b->d_rec, b->F.W, b->F.H, n, d);
+  KVZ_HIP_CHECK(hipGetLastError());
+  KVZ_HIP_CHECK(hipMemcpyAsync(host_out, d, (size_t)n * 16, hipMemcpyDeviceToHost, b->stream));
+  KVZ_HIP_CHECK(hipFreeAsync(d, b->stream));
+  KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
   return kvz::batch_check(b);
 }
 

@@ -107,6 +107,12 @@ void kvz_hip_array_checksum(const uint8_t *data, const int height, const int wid
   checksum_out[2] = (unsigned char)(v >> 8); checksum_out[3] = (unsigned char)v;
 }
 
+void kvz_hip_array_md5(const uint8_t *data, const int height, const int width, const int stride, unsigned char checksum_out[16], const uint8_t bitdepth)
+{
+  (void)bitdepth;
+  kvz_hip_plane_md5(data, height, width, stride, checksum_out);
+}
+
 // get_optimized_sad (strategies-picture.h:128): the widths kvazaar's PUs can have (square, SMP and AMP partitions)
 #define KVZ_OPT_SAD(w) \
   static uint32_t opt_sad_##w(const uint8_t *pic, const uint8_t *ref, int32_t height, uint32_t s1, uint32_t s2) { return kvz_hip_reg_sad(pic, ref, w, height, s1, s2); }

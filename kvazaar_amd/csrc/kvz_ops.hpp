@@ -395,6 +395,67 @@ struct PlaneChecksumOp {
   }
 };
 
+// nal-generic.c:41-55 array_md5_generic: MD5 (RFC 1321, extras/libmd5.c) of the plane's width * height bytes.  A hash is a serial chain over
+// 64-byte blocks, so one item = one whole message (or one chunk of it: the chaining value goes in and out through `state`); batches of
+// planes run one chain per lane.  K[i] = floor(2^32 |sin(i + 1)|) and the per-round rotations are the RFC's tables.
+KVZ_DEV u32 md5_rotl(u32 x, int c) { return (x << c) | (x >> (32 - c)); }
+KVZ_DEV void md5_block(u32 st[4], const u32 m[16])
+{
+  const u32 K[64] = { 0xd76aa478, 0xe8c7b756, 0x242070db, 0xc1bdceee, 0xf57c0faf, 0x4787c62a, 0xa8304613, 0xfd469501, 0x698098d8, 0x8b44f7af, 0xffff5bb1, 0x895cd7be, 0x6b901122,
+                      0xfd987193, 0xa679438e, 0x49b40821, 0xf61e2562, 0xc040b340, 0x265e5a51, 0xe9b6c7aa, 0xd62f105d, 0x02441453, 0xd8a1e681, 0xe7d3fbc8, 0x21e1cde6, 0xc33707d6,
+                      0xf4d50d87, 0x455a14ed, 0xa9e3e905, 0xfcefa3f8, 0x676f02d9, 0x8d2a4c8a, 0xfffa3942, 0x8771f681, 0x6d9d6122, 0xfde5380c, 0xa4beea44, 0x4bdecfa9, 0xf6bb4b60,
+                      0xbebfbc70, 0x289b7ec6, 0xeaa127fa, 0xd4ef3085, 0x04881d05, 0xd9d4d039, 0xe6db99e5, 0x1fa27cf8, 0xc4ac5665, 0xf4292244, 0x432aff97, 0xab9423a7, 0xfc93a039,
+                      0x655b59c3, 0x8f0ccc92, 0xffeff47d, 0x85845dd1, 0x6fa87e4f, 0xfe2ce6e0, 0xa3014314, 0x4e0811a1, 0xf7537e82, 0xbd3af235, 0x2ad7d2bb, 0xeb86d391 };
+  const int R[4][4] = { { 7, 12, 17, 22 }, { 5, 9, 14, 20 }, { 4, 11, 16, 23 }, { 6, 10, 15, 21 } };
+  u32 a = st[0], b = st[1], c = st[2], d = st[3];
+  for (int i = 0; i < 64; i++) {
+    u32 f;
+    int g;
+    if (i < 16) { f = (b & c) | (~b & d); g = i; }
+    else if (i < 32) { f = (d & b) | (~d & c); g = (5 * i + 1) & 15; }
+    else if (i < 48) { f = b ^ c ^ d; g = (3 * i + 5) & 15; }
+    else { f = c ^ (b | ~d); g = (7 * i) & 15; }
+    const u32 t = d;
+    d = c;
+    c = b;
+    b = b + md5_rotl(a + f + K[i] + m[g], R[i >> 4][i & 3]);
+    a = t;
+  }
+  st[0] += a; st[1] += b; st[2] += c; st[3] += d;
+}
+// `blocks` whole 64-byte blocks from p (4-byte aligned), then -- when finish -- the tail bytes, the 0x80 / zero padding and the bit length of
+// the whole message (total_bytes); digest = the state words little-endian.
+KVZ_DEV void md5_run(u32 st[4], const u8 *p, long blocks, int tail, int finish, unsigned long long total_bytes)
+{
+  for (long b = 0; b < blocks; b++) {
+    u32 m[16];
+    const u32 *w = reinterpret_cast<const u32 *>(p + b * 64);
+    for (int i = 0; i < 16; i++) m[i] = w[i];
+    md5_block(st, m);
+  }
+  if (!finish) return;
+  u8 buf[128];
+  const u8 *t = p + blocks * 64;
+  for (int i = 0; i < 128; i++) buf[i] = i < tail ? t[i] : (i == tail ? 0x80 : 0);
+  const int last = tail < 56 ? 1 : 2;
+  const unsigned long long bits = total_bytes * 8;
+  for (int i = 0; i < 8; i++) buf[last * 64 - 8 + i] = (u8)(bits >> (8 * i));
+  for (int k = 0; k < last; k++) {
+    u32 m[16];
+    for (int i = 0; i < 16; i++) m[i] = (u32)buf[k * 64 + 4 * i] | ((u32)buf[k * 64 + 4 * i + 1] << 8) | ((u32)buf[k * 64 + 4 * i + 2] << 16) | ((u32)buf[k * 64 + 4 * i + 3] << 24);
+    md5_block(st, m);
+  }
+}
+struct Md5Op {  // one item: a chunk of one message
+  const u8 *data; long blocks; int tail, finish; unsigned long long total; u32 *state /* [4] in/out */;
+  KVZ_DEV void operator()(int) const
+  {
+    u32 st[4] = { state[0], state[1], state[2], state[3] };
+    md5_run(st, data, blocks, tail, finish, total);
+    for (int i = 0; i < 4; i++) state[i] = st[i];
+  }
+};
+
 // quant-generic.c:351-375: sum of Q8.8 weights[min(|c|,3)]; the /256.0 happens on the host (exact)
 struct FastCoeffCostOp {
   const i16 *c; uint64_t weights; u32 *out;

@@ -11,6 +11,7 @@
 #include "kvz_oracle.h"
 
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 
 #define ORC_MIN(a, b) ((a) < (b) ? (a) : (b))
@@ -514,6 +515,41 @@ int kvz_oracle_quantize_residual(const kvz_hip_quant_params *p, int width, int c
 /* quant-generic.c:342-349 */
 /* nal-generic.c:57-82 array_checksum_generic: the picture-hash SEI's per-plane checksum (returned as the 32-bit value the
  * reference then stores big-endian in checksum_out[0..3]) */
+/* nal-generic.c:41-55 array_md5_generic: MD5 (RFC 1321; the reference uses extras/libmd5.c) of width * height contiguous bytes.  Restated
+ * from the RFC: four rounds of 16 steps with T[i] = floor(2^32 |sin(i + 1)|), message words little-endian, length appended in bits. */
+void kvz_oracle_plane_md5(const uint8_t *data, int height, int width, int stride, uint8_t *out16)
+{
+  static const uint8_t S[64] = { 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 7, 12, 17, 22, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20, 5, 9, 14, 20,
+                                 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 4, 11, 16, 23, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21, 6, 10, 15, 21 };
+  uint32_t T[64], h[4] = { 0x67452301u, 0xefcdab89u, 0x98badcfeu, 0x10325476u };
+  for (int i = 0; i < 64; i++) T[i] = (uint32_t)(uint64_t)floor(fabs(sin((double)(i + 1))) * 4294967296.0);
+  (void)stride;
+  const uint64_t len = (uint64_t)width * height, padded = ((len + 8) / 64 + 1) * 64;
+  for (uint64_t off = 0; off < padded; off += 64) {
+    uint8_t blk[64];
+    for (int i = 0; i < 64; i++) {
+      const uint64_t p = off + i;
+      blk[i] = p < len ? data[p] : (p == len ? 0x80 : (p >= padded - 8 ? (uint8_t)((len * 8) >> (8 * (p - (padded - 8)))) : 0));
+    }
+    uint32_t M[16], a = h[0], b = h[1], c = h[2], d = h[3];
+    for (int i = 0; i < 16; i++) M[i] = (uint32_t)blk[4 * i] | ((uint32_t)blk[4 * i + 1] << 8) | ((uint32_t)blk[4 * i + 2] << 16) | ((uint32_t)blk[4 * i + 3] << 24);
+    for (int i = 0; i < 64; i++) {
+      uint32_t f;
+      int g;
+      switch (i >> 4) {
+        case 0: f = (b & c) | (~b & d); g = i; break;
+        case 1: f = (d & b) | (~d & c); g = (5 * i + 1) % 16; break;
+        case 2: f = b ^ c ^ d; g = (3 * i + 5) % 16; break;
+        default: f = c ^ (b | ~d); g = (7 * i) % 16; break;
+      }
+      const uint32_t x = a + f + T[i] + M[g], tmp = d;
+      d = c; c = b; b = b + ((x << S[i]) | (x >> (32 - S[i]))); a = tmp;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d;
+  }
+  for (int i = 0; i < 16; i++) out16[i] = (uint8_t)(h[i >> 2] >> (8 * (i & 3)));
+}
+
 uint32_t kvz_oracle_plane_checksum(const uint8_t *data, int height, int width, int stride)
 {
   uint32_t sum = 0;

@@ -66,6 +66,7 @@ void kvz_oracle_dequant(const kvz_hip_quant_params *p, const int16_t *q_coef, in
 int  kvz_oracle_quantize_residual(const kvz_hip_quant_params *p, int width, int color, int scan_order,
                                   int use_trskip, int in_stride, int out_stride, const uint8_t *ref_in,
                                   const uint8_t *pred_in, uint8_t *rec_out, int16_t *coeff_out, int early_skip);
+void kvz_oracle_plane_md5(const uint8_t *data, int height, int width, int stride, uint8_t *out16);  /* nal-generic.c:41-55 (RFC 1321) */
 uint32_t kvz_oracle_plane_checksum(const uint8_t *data, int height, int width, int stride);  /* nal-generic.c:57-82 */
 uint32_t kvz_oracle_coeff_abs_sum(const int16_t *coeffs, size_t length);
 double   kvz_oracle_fast_coeff_cost(const int16_t *coeff, int32_t width, uint64_t weights);

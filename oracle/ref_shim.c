@@ -147,6 +147,13 @@ int kvz_ref_quantize_residual(const kvz_hip_quant_params *p, int width, int colo
 }
 uint32_t kvz_ref_coeff_abs_sum(const int16_t *coeffs, size_t length) { return kvz_coeff_abs_sum(coeffs, length); }
 #include "strategies/strategies-nal.h"
+void kvz_ref_plane_md5(const uint8_t *data, int height, int width, int stride, uint8_t *out16)
+{
+  unsigned char out[SEI_HASH_MAX_LENGTH];
+  kvz_array_md5(data, height, width, stride, out, 8);
+  memcpy(out16, out, 16);
+}
+
 uint32_t kvz_ref_plane_checksum(const uint8_t *data, int height, int width, int stride)
 {
   unsigned char out[SEI_HASH_MAX_LENGTH] = { 0 };

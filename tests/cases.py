@@ -500,6 +500,15 @@ def cases_plane_checksum():
         yield (f"plane_checksum{w}x{h}s{stride}", lambda lib, d=d, h=h, w=w, stride=stride: (lib.plane_checksum(ptr(d), h, w, stride),))
     full = A(np.full(64 * 64, 255, np.uint8))
     yield ("plane_checksum-ff", lambda lib: (lib.plane_checksum(ptr(full), 64, 64, 64),))
+    # nal-generic.c:41-55 array_md5: message lengths around the 56 / 64-byte padding boundaries, a picture-sized plane (chunked staging)
+    for (h, w) in ((1, 1), (1, 55), (1, 56), (7, 9), (8, 8), (1, 119), (3, 40), (120, 208), (1080, 1920), (1089, 961)):
+        d = A(rng.integers(0, 256, h * w, dtype=np.uint8))
+
+        def md5(lib, d=d, h=h, w=w):
+            out = A(np.zeros(16, np.uint8))
+            lib.plane_md5(ptr(d), h, w, w, ptr(out))
+            return (out.tobytes(),)
+        yield (f"plane_md5-{w}x{h}", md5)
 
 
 ALL_GENERATORS = [cases_plane_checksum, cases_sad_satd_nxn, cases_dual, cases_reg_sad, cases_any_size, cases_ssd_versad_horsad_var,

@@ -83,6 +83,22 @@ def test_batched_search_bitstream_identical(tmp_path, frames, extra):
     assert int(open(str(tmp_path / "trace")).read()) >= frames, "the batched search was not used"
 
 
+@pytest.mark.parametrize("preset,extra", [("superfast", ["-q", "22"]), ("veryfast", ["-q", "32"]), ("faster", ["-q", "22"]), ("faster", ["-q", "37", "--no-wpp"])],
+                         ids=["superfast-qp22", "veryfast-qp32", "faster-qp22", "faster-qp37-nowpp"])
+def test_batched_search_other_all_intra_presets(tmp_path, preset, extra):
+    """All-intra superfast / veryfast (= the ultrafast search + `--sao full`) and faster (fast-residual-cost 0: coefficients priced with the
+    CABAC model at every QP) with the device searching whole pictures: the reference's SAO decision then runs on the host on the device's
+    reconstruction, and the bitstream must still be the reference encoder's, byte for byte."""
+    _need_hip_encoder()
+    yuv = str(tmp_path / "syn.yuv")
+    synth.write_yuv(yuv, 416, 240, 2, 1234, "small")
+    common = ["--preset", preset, "-p", "1", "--threads", "4"] + extra
+    md5_ref, _, _ = _encode("kvazaar_ref", yuv, str(tmp_path / "ref.hevc"), common)
+    md5_batch, t, _ = _encode("kvazaar_hip", yuv, str(tmp_path / "batch.hevc"), common, {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1", "KVZ_HIP_BATCH_TRACE": str(tmp_path / "trace")})
+    assert md5_batch == md5_ref
+    assert int(open(str(tmp_path / "trace")).read()) >= 2, "the batched search was not used"
+
+
 def test_batched_search_golden_md5_416x240(tmp_path):
     """the survey's recorded md5 for BASELINE config 1 (8 frames) reproduced with the device searching whole pictures"""
     _need_hip_encoder()

@@ -147,6 +147,10 @@ def test_batch_deblock_after_ctu_pass(oracle, hiplib):
         sums = [oracle.plane_checksum(flatapi.ptr(want), h, w, w), oracle.plane_checksum(flatapi.ptr(want, offset=ys), h // 2, w // 2, w // 2),
                 oracle.plane_checksum(flatapi.ptr(want, offset=ys + cs), h // 2, w // 2, w // 2)]
         assert list(batch.checksums()[i]) == sums
+        # --hash md5 (nal.c:88-101): per plane the RFC 1321 digest of the plane's bytes (python's hashlib as the independent known answer)
+        import hashlib
+        planes = (want[:ys], want[ys:ys + cs], want[ys + cs:])
+        assert [bytes(batch.md5()[i][p]).hex() for p in range(3)] == [hashlib.md5(pl.tobytes()).hexdigest() for pl in planes]
     batch.close()
 
 

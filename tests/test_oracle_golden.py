@@ -95,3 +95,22 @@ def test_coeff_abs_sum_series(oracle):
     """tests/coeff_sum_tests.c:39-62: INT16_MIN .. step 16, closed form."""
     c = np.arange(-32768, 32768, 16).astype(np.int16)
     assert oracle.coeff_abs_sum(ptr(c), len(c)) == int(np.abs(c.astype(np.int64)).sum())
+
+
+def test_oracle_md5_known_answers(oracle):
+    """RFC 1321 appendix A.5 test suite + python's hashlib on plane-sized messages: pins kvz_oracle_plane_md5 (nal-generic.c:41-55)"""
+    import hashlib
+    import numpy as np
+    from flatapi import A, ptr
+    known = {b"": "d41d8cd98f00b204e9800998ecf8427e", b"a": "0cc175b9c0f1b6a831c399e269772661", b"abc": "900150983cd24fb0d6963f7d28e17f72",
+             b"message digest": "f96b697d7cb7938d525a2f31aaf161d0", b"abcdefghijklmnopqrstuvwxyz": "c3fcd3d76192e4007dfb496cca67e13b",
+             b"12345678901234567890123456789012345678901234567890123456789012345678901234567890": "57edf4a22be3c955ac49da2e2107b67a"}
+    rng = np.random.default_rng(2)
+    msgs = list(known) + [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (55, 56, 64, 416 * 240, 960 * 540)]
+    for m in msgs:
+        d = A(np.frombuffer(m or b"\0", np.uint8).copy())
+        out = A(np.zeros(16, np.uint8))
+        oracle.plane_md5(ptr(d), 1, len(m), len(m), ptr(out))
+        assert out.tobytes().hex() == hashlib.md5(m).hexdigest()
+        if m in known:
+            assert out.tobytes().hex() == known[m]
