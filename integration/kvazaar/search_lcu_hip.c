@@ -20,6 +20,7 @@
 #include <string.h>
 
 #include "global.h" // IWYU pragma: keep
+#include "cabac.h"
 #include "cu.h"
 #include "encoder.h"
 #include "encoderstate.h"
@@ -150,6 +151,11 @@ static unsigned zorder16(int x, int y) /* cu.h:385-421 xy_to_zorder for 4-sample
 void __wrap_kvz_search_lcu(encoder_state_t *const state, const int x, const int y, const yuv_t *const hor_buf, const yuv_t *const ver_buf)
 {
   if (!eligible(state)) { __real_kvz_search_lcu(state, x, y, hor_buf, ver_buf); return; }
+  /* what kvz_search_lcu leaves in state->search_cabac for the stages after it: a counting-mode copy of the row's contexts taken at the start of
+   * the LCU (search.c:1211-1212), update flag off as search_cu leaves it -- kvz_sao_search_lcu prices its mode bits on it (sao.c:52-177) */
+  memcpy(&state->search_cabac, &state->cabac, sizeof(cabac_data_t));
+  state->search_cabac.only_count = 1;
+  state->search_cabac.update = 0;
   picture_result *r = picture_of(state);
   videoframe_t *frame = state->tile->frame;
   const int w = r->width, h = r->height, w8 = w / 8, wc = (w + 63) / 64;
