@@ -102,6 +102,13 @@ void     kvz_hip_array_md5(const uint8_t *data, const int height, const int widt
                            const uint8_t bitdepth);  /* strategies-nal.h:54-58 "array_md5" (--hash md5) */
 void     kvz_hip_array_checksum(const uint8_t *data, const int height, const int width, const int stride, unsigned char checksum_out[16],
                                 const uint8_t bitdepth);
+/* kvz_rdoq (rdo.c:661-1000; not a strategy pointer in the reference: quant-generic.c:234-244 calls it directly when --rdoq is on) for intra
+ * blocks, flat scaling lists, sign hiding off: ctx_states = uc_state of state->cabac's contexts in KVZ_HIP_CX_* order (kvz_hip_types.h), lambda =
+ * state->lambda, type 0 luma / 2 chroma, tr_depth as passed to kvz_rdoq.  dest is read and written (positions above the last significant
+ * coefficient are zeroed, a block without any keeps the rest of the caller's values, as the reference does).  The 4th argument is unused (the
+ * library prices with kvz_entropy_bits, rdo.c:69-80); it keeps the signature of the test checkers.  _blocks: `count` blocks of one shape back to back. */
+void     kvz_hip_rdoq(int qp, double lambda, const uint8_t *ctx_states, const float *unused, const int16_t *coef, int16_t *dest, int width, int type, int scan_mode, int tr_depth);
+void     kvz_hip_rdoq_blocks(int qp, double lambda, const uint8_t *ctx_states, const int16_t *coef, int16_t *dest, int width, int type, int scan_mode, int tr_depth, int count);
 void     kvz_hip_plane_md5(const uint8_t *data, int height, int width, int stride, uint8_t *out16);       /* nal-generic.c:41-55, the 16 digest bytes */
 uint32_t kvz_hip_plane_checksum(const uint8_t *data, int height, int width, int stride);            /* nal-generic.c:57-82, the 32-bit sum */
 uint32_t kvz_hip_coeff_abs_sum(const int16_t *coeffs, size_t length);                        /* quant-generic.c:342-349 */

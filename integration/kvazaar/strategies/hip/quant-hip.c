@@ -2,6 +2,10 @@
  * on the host; the device never sees a kvazaar struct. */
 #include "strategies/hip/hip-common.h"
 
+#include <stdlib.h>
+#include <string.h>
+
+#include "cabac.h"
 #include "cu.h"
 #include "encoder.h"
 #include "encoderstate.h"
@@ -45,9 +49,31 @@ static void dequant_hip(const encoder_state_t *const state, coeff_t *q_coef, coe
   kvz_hip_dequant(&p, q_coef, coef, width, height, type, block_type);
 }
 
-/* quant_residual_func.  rdoq off: one fused device call.  rdoq on: kvz_rdoq is host code in the reference (rdo.c:661, double
- * precision, CABAC-context driven), so the steps are chained through the strategy pointers exactly as
- * quant-generic.c:198-292 does -- transform / dequant / inverse transform still run on the device. */
+/* The context states kvz_rdoq prices with (state->cabac, rdo.c:664-730) in the order of kvz_hip_types.h's KVZ_HIP_CX_* indices */
+static void gather_rdoq_contexts(const encoder_state_t *state, uint8_t ctx[160])
+{
+  const cabac_data_t *cb = &state->cabac;
+  memset(ctx, 0, 160);
+#define PUT(at, src, n) for (int i_ = 0; i_ < (n); i_++) ctx[(at) + i_] = (src)[i_].uc_state
+  PUT(KVZ_HIP_CX_CBF_LUMA, cb->ctx.qt_cbf_model_luma, 2);
+  PUT(KVZ_HIP_CX_CBF_CHROMA, cb->ctx.qt_cbf_model_chroma, 2);
+  PUT(KVZ_HIP_CX_SIG_CG, cb->ctx.cu_sig_coeff_group_model, 4);
+  PUT(KVZ_HIP_CX_SIG_LUMA, cb->ctx.cu_sig_model_luma, 27);
+  PUT(KVZ_HIP_CX_SIG_CHROMA, cb->ctx.cu_sig_model_chroma, 15);
+  PUT(KVZ_HIP_CX_LAST_Y_LUMA, cb->ctx.cu_ctx_last_y_luma, 15);
+  PUT(KVZ_HIP_CX_LAST_Y_CHROMA, cb->ctx.cu_ctx_last_y_chroma, 15);
+  PUT(KVZ_HIP_CX_LAST_X_LUMA, cb->ctx.cu_ctx_last_x_luma, 15);
+  PUT(KVZ_HIP_CX_LAST_X_CHROMA, cb->ctx.cu_ctx_last_x_chroma, 15);
+  PUT(KVZ_HIP_CX_ONE_LUMA, cb->ctx.cu_one_model_luma, 16);
+  PUT(KVZ_HIP_CX_ONE_CHROMA, cb->ctx.cu_one_model_chroma, 8);
+  PUT(KVZ_HIP_CX_ABS_LUMA, cb->ctx.cu_abs_model_luma, 4);
+  PUT(KVZ_HIP_CX_ABS_CHROMA, cb->ctx.cu_abs_model_chroma, 2);
+#undef PUT
+}
+
+/* quant_residual_func.  rdoq off: one fused device call.  rdoq on: the steps are chained exactly as quant-generic.c:198-292 does, all of
+ * them on the device -- transform, kvz_rdoq (rdo.c:661: not a strategy pointer in the reference; the library's restatement for intra
+ * blocks with flat lists and sign hiding off, kvz_hip_rdoq, is called in its place, otherwise the host function), dequant, inverse. */
 static int quantize_residual_hip(encoder_state_t *const state, const cu_info_t *const cur_cu, const int width, const color_t color,
                                  const coeff_scan_order_t scan_order, const int use_trskip, const int in_stride, const int out_stride,
                                  const kvz_pixel *const ref_in, const kvz_pixel *const pred_in, kvz_pixel *rec_out, coeff_t *coeff_out,
@@ -78,7 +104,15 @@ static int quantize_residual_hip(encoder_state_t *const state, const cu_info_t *
   {
     int8_t tr_depth = cur_cu->tr_depth - cur_cu->depth;
     tr_depth += (cur_cu->part_size == SIZE_NxN ? 1 : 0);
-    kvz_rdoq(state, coeff, coeff_out, width, width, (color == COLOR_Y ? 0 : 2), scan_order, cur_cu->type, tr_depth);
+    static int host_rdoq = -1;
+    if (host_rdoq < 0) { const char *e = getenv("KVZ_HIP_RDOQ_HOST"); host_rdoq = e && e[0] == '1'; }
+    if (!host_rdoq && cur_cu->type == CU_INTRA && !enc->scaling_list.enable && !enc->cfg.signhide_enable && enc->bitdepth == 8) {
+      uint8_t ctx[160];
+      gather_rdoq_contexts(state, ctx);
+      kvz_hip_rdoq(state->qp, state->lambda, ctx, NULL, coeff, coeff_out, width, (color == COLOR_Y ? 0 : 2), scan_order, tr_depth);
+    } else {
+      kvz_rdoq(state, coeff, coeff_out, width, width, (color == COLOR_Y ? 0 : 2), scan_order, cur_cu->type, tr_depth);
+    }
   }
   for (int i = 0; i < width * width; ++i) if (coeff_out[i] != 0) { has_coeffs = 1; break; }
   if (has_coeffs && !early_skip) {

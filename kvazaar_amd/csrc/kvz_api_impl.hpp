@@ -17,6 +17,7 @@
 
 #include "../../include/kvz_hip_types.h"
 #include "kvz_ops.hpp"
+#include "kvz_rdoq.hpp"
 #include "kvz_tables.hpp"
 
 namespace kvz {
@@ -337,6 +338,27 @@ template <class B> struct Api {
       if (finish) break;
     }
     for (int i = 0; i < 16; i++) out[i] = (u8)(state[i >> 2] >> (8 * (i & 3)));
+  }
+
+  // kvz_rdoq (rdo.c:661-1000) for `count` intra blocks of one shape: what kvz_quantize_residual runs instead of kvz_quant with --rdoq
+  // (quant-generic.c:234-244).  Serial per block: one item each.
+  static void rdoq(B &be, int qp, double lambda, const u8 *ctx_states, const i16 *coef, i16 *dest, int width, int type, int scan_mode, int tr_depth, int count)
+  {
+    const int n = width * width;
+    be.begin();
+    const i16 *c = be.in(coef, (size_t)n * count);
+    const u8 *cx = be.in(ctx_states, 160);
+    i16 *d = be.template in_raw<i16>((size_t)n * count);  // uploaded: blocks without a significant level keep the caller's values, as in the reference
+    memcpy(be.host_rw(d), dest, (size_t)n * count * sizeof(i16));
+    be.mark_download_from(d);
+    be.dl_end = be.cur;
+    double *tmp = be.template scratch<double>((size_t)3 * n * count);
+    be.upload();
+    int log2w = 2;
+    while ((1 << log2w) < width) log2w++;
+    be.run(RdoqOp{ be.tables(), cx, lambda, qp, c, d, log2w, type, scan_mode, tr_depth, tmp }, count);
+    be.download();
+    memcpy(dest, be.host(d), (size_t)n * count * sizeof(i16));
   }
 
   static double fast_coeff_cost(B &be, const i16 *coeff, int width, uint64_t weights)

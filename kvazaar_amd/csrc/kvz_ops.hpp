@@ -62,6 +62,7 @@ struct Tables {
   // [0] after coding the more probable symbol, [1] after the less probable one
   u8 ctx_next[2][128];
   u8 diag8[64];  // up-right diagonal order of an 8x8 grid: the coefficient groups of a 32x32 block (tables.h:66-79 g_sig_last_scan_32x32)
+  u32 entropy_bits[128];       // kvz_entropy_bits (rdo.c:69-80): Q15 price of a bin, index = context state ^ bin
   int8_t luma_filter[4][8];    // filter.c:66-72
   int8_t chroma_filter[8][4];  // filter.c:74-84
 };

@@ -135,6 +135,11 @@ void kvz_oracle_intra_cost_model(int qp, const float entropy_fbits[128], uint64_
 double kvz_oracle_coeff_cabac_bits(const float entropy_fbits[128], const int16_t *coeff, int width, int type, int scan_mode, int update, uint8_t *ctx);
 const uint8_t *kvz_oracle_next_state_table(int lps);  /* cabac.c:40-62, regenerated from H.265 Table 9-41 */
 
+/* ---- rate-distortion optimised quantisation of one intra transform block (kvz_oracle_rdoq.c; rdo.c:661 kvz_rdoq) ----
+ * ctx_states: uc_state of the contexts in KVZ_HIP_CX_* order (state->cabac.ctx of the encoder); entropy_fbits: kvz_f_entropy_bits; type 0 luma / 2 chroma */
+void kvz_oracle_rdoq(int qp, double lambda, const uint8_t *ctx_states, const float *entropy_fbits, const int16_t *coef, int16_t *dest, int width, int type,
+                     int scan_mode, int tr_depth);
+
 /* ---- SAO parameter decision of a whole picture in the encoder's LCU order (kvz_oracle_sao.c; sao.c:671 kvz_sao_search_lcu) ----
  * src = the original picture, rec = the reconstruction BEFORE deblocking (Y|U|V tight), deblocked in place LCU by LCU when `deblock`
  * (the statistics see the partly deblocked picture the encoder has at that moment); on return rec is the deblocked, pre-SAO picture.

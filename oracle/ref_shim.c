@@ -145,6 +145,33 @@ int kvz_ref_quantize_residual(const kvz_hip_quant_params *p, int width, int colo
   return kvz_quantize_residual(&g_state, &cu, width, (color_t)color, (coeff_scan_order_t)scan_order, use_trskip,
                                in_stride, out_stride, ref_in, pred_in, rec_out, coeff_out, early_skip);
 }
+/* kvz_rdoq (rdo.c:661) on an intra block with the given context states (KVZ_HIP_CX_* order) in state->cabac */
+void kvz_ref_rdoq(int qp, double lambda, const uint8_t *ctx, const float *entropy_fbits_unused, const int16_t *coef, int16_t *dest, int width, int type, int scan_mode,
+                  int tr_depth)
+{
+  (void)entropy_fbits_unused;
+  cabac_data_t *cb = &g_state.cabac;
+  g_state.qp = (int8_t)qp;
+  g_state.lambda = lambda;
+  g_ctrl.cfg.signhide_enable = 0;
+  g_frame.slicetype = KVZ_SLICE_I;
+#define SETCTX(dst, from, n) for (int i_ = 0; i_ < (n); i_++) (dst)[i_].uc_state = ctx[(from) + i_]
+  SETCTX(cb->ctx.qt_cbf_model_luma, KVZ_HIP_CX_CBF_LUMA, 2);
+  SETCTX(cb->ctx.qt_cbf_model_chroma, KVZ_HIP_CX_CBF_CHROMA, 2);
+  SETCTX(cb->ctx.cu_sig_coeff_group_model, KVZ_HIP_CX_SIG_CG, 4);
+  SETCTX(cb->ctx.cu_sig_model_luma, KVZ_HIP_CX_SIG_LUMA, 27);
+  SETCTX(cb->ctx.cu_sig_model_chroma, KVZ_HIP_CX_SIG_CHROMA, 15);
+  SETCTX(cb->ctx.cu_ctx_last_y_luma, KVZ_HIP_CX_LAST_Y_LUMA, 15);
+  SETCTX(cb->ctx.cu_ctx_last_y_chroma, KVZ_HIP_CX_LAST_Y_CHROMA, 15);
+  SETCTX(cb->ctx.cu_ctx_last_x_luma, KVZ_HIP_CX_LAST_X_LUMA, 15);
+  SETCTX(cb->ctx.cu_ctx_last_x_chroma, KVZ_HIP_CX_LAST_X_CHROMA, 15);
+  SETCTX(cb->ctx.cu_one_model_luma, KVZ_HIP_CX_ONE_LUMA, 16);
+  SETCTX(cb->ctx.cu_one_model_chroma, KVZ_HIP_CX_ONE_CHROMA, 8);
+  SETCTX(cb->ctx.cu_abs_model_luma, KVZ_HIP_CX_ABS_LUMA, 4);
+  SETCTX(cb->ctx.cu_abs_model_chroma, KVZ_HIP_CX_ABS_CHROMA, 2);
+#undef SETCTX
+  kvz_rdoq(&g_state, (coeff_t *)coef, dest, width, width, (int8_t)type, (int8_t)scan_mode, CU_INTRA, (int8_t)tr_depth);
+}
 uint32_t kvz_ref_coeff_abs_sum(const int16_t *coeffs, size_t length) { return kvz_coeff_abs_sum(coeffs, length); }
 #include "strategies/strategies-nal.h"
 void kvz_ref_plane_md5(const uint8_t *data, int height, int width, int stride, uint8_t *out16)

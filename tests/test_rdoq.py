@@ -1,0 +1,102 @@
+"""Rate-distortion optimised quantisation (kvz_rdoq, rdo.c:661-1000): the oracle restatement against the compiled reference's own function on
+random transform blocks x context states (CPU, where oracle/_ref exists); the device sources on the host (hostsim) against the oracle; and
+under -m gpu the per-call / batched device entry points against the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import ctu_common as cc
+import flatapi
+from flatapi import A, ptr
+from test_hostsim import hostsim  # noqa: F401  (fixture)
+
+RDOQ_ARGS = [C.c_int, C.c_double, flatapi.u8p, C.POINTER(C.c_float), flatapi.i16p, flatapi.i16p, C.c_int, C.c_int, C.c_int, C.c_int]
+
+
+def rdoq_cases(n_per_shape=14):
+    """(qp, lambda, ctx states, coefficients, width, type, scan_mode, tr_depth): the shapes kvazaar produces for intra blocks -- 4x4 / 8x8 luma with the three scans,
+    16x16 / 32x32 diagonal, chroma 4..16 -- on coefficient statistics from sparse to dense, context states from slice start to heavily adapted"""
+    rng = np.random.default_rng(4242)
+    out = []
+    for (w, typ, scans) in ((4, 0, (0, 1, 2)), (8, 0, (0, 1, 2)), (16, 0, (0,)), (32, 0, (0,)), (4, 2, (0, 1, 2)), (8, 2, (0,)), (16, 2, (0,))):
+        for scan in scans:
+            for k in range(n_per_shape):
+                qp = int(rng.choice([12, 22, 27, 32, 37, 45]))
+                lam = 0.57 * 2 ** ((qp - 12) / 3.0) * float(rng.choice([1.0, 0.7, 1.6]))
+                ctx = rng.integers(0, 126, 160).astype(np.uint8) if k % 3 else np.full(160, int(rng.integers(0, 126)), np.uint8)
+                scale = float(rng.choice([4, 30, 200, 1500]))
+                decay = np.exp(-np.add.outer(np.arange(w), np.arange(w)) / float(rng.choice([1.5, 4, 12, 100])))
+                coef = np.clip(rng.laplace(0, scale, (w, w)) * decay, -32000, 32000).astype(np.int16)
+                if k == 0:
+                    coef[:] = 0
+                if k == 1:
+                    coef[:] = 0
+                    coef[w - 1, w - 1] = 900
+                out.append((qp, lam, A(ctx), A(coef.reshape(-1)), w, typ, scan, int(rng.integers(0, 2))))
+    return out
+
+
+def run_rdoq(fn, fbits, case):
+    qp, lam, ctx, coef, w, typ, scan, trd = case
+    dest = A(np.full(w * w, 77, np.int16))  # the function leaves positions past the last significant one untouched only when nothing is coded
+    fn(qp, lam, ptr(ctx), fbits, ptr(coef), ptr(dest), w, typ, scan, trd)
+    return dest.tobytes()
+
+
+def _fbits():
+    return (C.c_float * 128)(*cc.model_constants()["entropy_fbits"])
+
+
+def test_oracle_rdoq_equals_compiled_reference(oracle):
+    if not os.path.exists(flatapi.refshim_path()):
+        pytest.skip("oracle/_ref not built")
+    ref = flatapi.load_ref(0)
+    fo, fr = oracle.lib.kvz_oracle_rdoq, ref.lib.kvz_ref_rdoq
+    fo.restype = fr.restype = None
+    fo.argtypes = fr.argtypes = RDOQ_ARGS
+    fb = _fbits()
+    cases = rdoq_cases()
+    bad = [i for i, c in enumerate(cases) if run_rdoq(fo, fb, c) != run_rdoq(fr, fb, c)]
+    assert not bad, f"{len(bad)}/{len(cases)} blocks differ: {[(cases[i][0], cases[i][4], cases[i][5], cases[i][6]) for i in bad[:8]]}"
+    changed = sum(1 for c in cases if np.frombuffer(run_rdoq(fo, fb, c), np.int16).any())
+    assert changed > len(cases) // 3  # the rest quantise to nothing at their QP
+
+
+def test_hostsim_rdoq_equals_oracle(oracle, hostsim):
+    """the device sources (kvz_rdoq.hpp through the per-call sequence) on the host == the oracle, block by block"""
+    fo, fh = oracle.lib.kvz_oracle_rdoq, hostsim.lib.kvz_hostsim_rdoq
+    fo.restype = fh.restype = None
+    fo.argtypes = fh.argtypes = RDOQ_ARGS
+    fb = _fbits()
+    cases = rdoq_cases()
+    bad = [i for i, c in enumerate(cases) if run_rdoq(fo, fb, c) != run_rdoq(fh, fb, c)]
+    assert not bad, f"{len(bad)}/{len(cases)} blocks differ: {[(cases[i][0], cases[i][4], cases[i][5], cases[i][6]) for i in bad[:8]]}"
+
+
+@pytest.mark.gpu
+def test_hip_rdoq_equals_oracle(oracle):
+    """on the MI355X: one block per call, and the same blocks grouped by shape through the batched entry point"""
+    import kvazaar_amd
+    lib = kvazaar_amd.load_library()
+    fo, fh = oracle.lib.kvz_oracle_rdoq, lib.kvz_hip_rdoq
+    fo.restype = fh.restype = None
+    fo.argtypes = fh.argtypes = RDOQ_ARGS
+    fb = _fbits()
+    cases = rdoq_cases(6)
+    want = [run_rdoq(fo, fb, c) for c in cases]
+    assert [run_rdoq(fh, fb, c) for c in cases] == want
+    lib.kvz_hip_rdoq_blocks.restype = None
+    lib.kvz_hip_rdoq_blocks.argtypes = [C.c_int, C.c_double, flatapi.u8p, flatapi.i16p, flatapi.i16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    # batches share qp / lambda / contexts / shape: re-run groups of cases with the first member's parameters
+    by_shape = {}
+    for c in cases:
+        by_shape.setdefault((c[4], c[5], c[6]), []).append(c)
+    for (w, typ, scan), group in by_shape.items():
+        qp, lam, ctx, _, _, _, _, trd = group[0]
+        coef = A(np.concatenate([g[3] for g in group]))
+        dest = A(np.full(coef.size, 77, np.int16))
+        lib.kvz_hip_rdoq_blocks(qp, lam, ptr(ctx), ptr(coef), ptr(dest), w, typ, scan, trd, len(group))
+        exp = b"".join(run_rdoq(fo, fb, (qp, lam, ctx, g[3], w, typ, scan, trd)) for g in group)
+        assert dest.tobytes() == exp, (w, typ, scan)
