@@ -51,6 +51,23 @@ void kvz_hip_dev_angular_pred(int log2_width, int mode, const uint8_t *ref_above
 void kvz_hip_dev_deblock_frames(uint8_t *frames, int width, int height, int n_frames, const uint8_t *cu_depth, int qp, int beta_offset_div2,
                                 int tc_offset_div2);
 
+/* Deblocking of pictures that contain inter CUs (P / B slices): as kvz_hip_dev_deblock_frames, with the boundary strengths of filter.c:405-493
+ * -- 2 next to an intra CU, 1 on a transform edge with coded luma coefficients or across different motion (vectors >= 1 sample apart, other reference
+ * pictures, the B-slice list permutations), 0 otherwise -- from one record per 4x4 unit (raster, stride width / 4, frames back to back): what the
+ * filter reads of cu_info_t.  Edges are the transform-unit edges (64 >> tr_depth) and the prediction-unit edges of part_size on the 8x8 grid
+ * (filter.c:202-257); chroma is only filtered at strength 2 (filter.c:610).  slice_is_b: the extra B-slice rules (filter.c:428-489). */
+typedef struct kvz_hip_cu_dbk {
+  uint8_t type;        /* cu_info_t::type: 1 = CU_INTRA, 2 = CU_INTER */
+  uint8_t depth, tr_depth, part_size;
+  uint8_t cbf_y;       /* cbf_is_set(cu->cbf, cu->tr_depth, COLOR_Y) */
+  uint8_t mv_dir;      /* inter.mv_dir: 1 = L0, 2 = L1, 3 = both */
+  int8_t  mv_ref[2];   /* inter.mv_ref: index into the reference lists */
+  int16_t ref_id[2];   /* state->frame->ref_LX[list][mv_ref[list]]: which picture that is (only compared for equality) */
+  int16_t mv[2][2];    /* inter.mv[list] = {x, y}, quarter samples */
+} kvz_hip_cu_dbk;
+void kvz_hip_dev_deblock_frames_inter(uint8_t *frames, int width, int height, int n_frames, const kvz_hip_cu_dbk *info, int qp, int beta_offset_div2,
+                                      int tc_offset_div2, int slice_is_b);
+
 /* Integer-pel motion cost surface (the candidate scoring of the inter search, search_inter.c:1000-1005 -> kvz_image_calc_sad,
  * image.c:407): for block b = the bw x bw block of `cur` at (blk_xy[2b], blk_xy[2b+1]) and every displacement (dx, dy) in
  * [-range, range]^2,   out[b * side^2 + (dy + range) * side + dx + range] = kvz_image_calc_sad(cur, ref, x, y, x + dx, y + dy, bw, bw)

@@ -307,13 +307,55 @@ __global__ void __launch_bounds__(256) dev_sao_kernel(const u8 *in, u8 *out, con
   }
 }
 
-struct DeblockGeom { int W, H, beta, tc, tc_c; long frame_bytes; const u8 *cu_depth; };
+struct DeblockGeom { int W, H, beta, tc, tc_c; long frame_bytes; const u8 *cu_depth; const kvz_hip_cu_dbk *info; int slice_b, tc1; /* inter pictures: per-4x4 records, tc at strength 1 */ };
 
 __device__ __forceinline__ bool deblock_edge_on(const DeblockGeom &g, long frame, int x, int y, bool vertical)  // filter.c:202-216
 {
   const int w8 = g.W >> 3, d = g.cu_depth[frame * (long)w8 * (g.H >> 3) + (long)(y >> 3) * w8 + (x >> 3)];
   const int tu_w = 64 >> (d ? d : 1);
   return ((vertical ? x : y) & (tu_w - 1)) == 0;
+}
+// Inter pictures: is the 8x8 unit at (ux, uy) on a transform or prediction edge (filter.c:202-257), and how strong is the 4-sample part whose first
+// sample on the q side is (x, y) (filter.c:405-493)?  One record per 4x4 unit.
+__device__ __forceinline__ const kvz_hip_cu_dbk *dbk_unit(const DeblockGeom &g, long frame, int x, int y)
+{
+  return g.info + frame * ((long)(g.W >> 2) * (g.H >> 2)) + (long)(y >> 2) * (g.W >> 2) + (x >> 2);
+}
+__device__ __forceinline__ bool dbk_edge_on_inter(const DeblockGeom &g, long frame, int ux, int uy, bool vertical)
+{
+  const kvz_hip_cu_dbk *u = dbk_unit(g, frame, ux, uy);
+  const int pos = vertical ? ux : uy;
+  if ((pos & ((64 >> u->tr_depth) - 1)) == 0) return true;  // transform edge
+  const int cu_w = 64 >> u->depth, rel = pos & (cu_w - 1);  // prediction edges of the CU's partitioning, in quarters of the CU (cu.c:63-72)
+  if (rel == 0) return true;
+  const int ps = u->part_size;
+  int q = -1;  // the second partition's offset along this axis, if it has one
+  if (vertical) q = (ps == 2 || ps == 3) ? 2 : (ps == 6 ? 1 : (ps == 7 ? 3 : -1));
+  else q = (ps == 1 || ps == 3) ? 2 : (ps == 4 ? 1 : (ps == 5 ? 3 : -1));
+  return q >= 0 && rel == q * cu_w / 4;
+}
+__device__ __forceinline__ int dbk_strength(const DeblockGeom &g, long frame, int x, int y, bool vertical, bool tu_boundary)
+{
+  const kvz_hip_cu_dbk *q = dbk_unit(g, frame, x, y), *p = dbk_unit(g, frame, vertical ? x - 1 : x, vertical ? y : y - 1);
+  if (q->type == 1 || p->type == 1) return 2;
+  if (tu_boundary && (q->cbf_y || p->cbf_y)) return 1;
+  auto far = [](int a, int b) { return iabs(a - b) >= 4; };
+  if (p->mv_dir != 3 && q->mv_dir != 3) {
+    const int lq = q->mv_dir - 1, lp = p->mv_dir - 1;
+    if (far(q->mv[lq][0], p->mv[lp][0]) || far(q->mv[lq][1], p->mv[lp][1])) return 1;
+    if (q->mv_ref[lq] != p->mv_ref[lp]) return 1;
+  }
+  if (!g.slice_b) return 0;
+  // B slices (filter.c:428-489): undefined vectors count as zero, references compared as pictures
+  const int rp0 = (p->mv_dir & 1) ? p->ref_id[0] : -1, rp1 = (p->mv_dir & 2) ? p->ref_id[1] : -1;
+  const int rq0 = (q->mv_dir & 1) ? q->ref_id[0] : -1, rq1 = (q->mv_dir & 2) ? q->ref_id[1] : -1;
+  const int q0x = (q->mv_dir & 1) ? q->mv[0][0] : 0, q0y = (q->mv_dir & 1) ? q->mv[0][1] : 0, q1x = (q->mv_dir & 2) ? q->mv[1][0] : 0, q1y = (q->mv_dir & 2) ? q->mv[1][1] : 0;
+  const int p0x = (p->mv_dir & 1) ? p->mv[0][0] : 0, p0y = (p->mv_dir & 1) ? p->mv[0][1] : 0, p1x = (p->mv_dir & 2) ? p->mv[1][0] : 0, p1y = (p->mv_dir & 2) ? p->mv[1][1] : 0;
+  if (!((rp0 == rq0 && rp1 == rq1) || (rp0 == rq1 && rp1 == rq0))) return 1;
+  const bool straight = far(q0x, p0x) || far(q0y, p0y) || far(q1x, p1x) || far(q1y, p1y);
+  const bool crossed = far(q1x, p0x) || far(q1y, p0y) || far(q0x, p1x) || far(q0y, p1y);
+  if (rp0 != rp1) return (rp0 == rq0 ? straight : crossed) ? 1 : 0;
+  return (straight && crossed) ? 1 : 0;
 }
 // b[i][k]: sample k (edge between 3 and 4) of line i (filter.c:386-561)
 __device__ __forceinline__ void deblock_luma_lines(int b[4][8], int beta, int tc)
@@ -359,7 +401,16 @@ template <bool VERTICAL> __global__ void __launch_bounds__(256) dev_deblock_luma
   const long frame = p / ((long)nx * ny);
   const int r = (int)(p % ((long)nx * ny)), ix = r % nx, iy = r / nx;
   const int x = VERTICAL ? 8 * ix : 4 * ix, y = VERTICAL ? 4 * iy : 8 * iy;
-  if ((VERTICAL ? x : y) == 0 || !deblock_edge_on(g, frame, x, y, VERTICAL)) return;
+  if ((VERTICAL ? x : y) == 0) return;
+  int tc = g.tc;
+  if (g.info) {  // inter picture: edge test on the 8x8 unit, strength per 4-sample part
+    const int ux = x & ~7, uy = y & ~7;
+    if (!dbk_edge_on_inter(g, frame, ux, uy, VERTICAL)) return;
+    const kvz_hip_cu_dbk *u = dbk_unit(g, frame, ux, uy);
+    const int strength = dbk_strength(g, frame, x, y, VERTICAL, (((VERTICAL ? ux : uy)) & ((64 >> u->tr_depth) - 1)) == 0);
+    if (!strength) return;
+    if (strength == 1) tc = g.tc1;
+  } else if (!deblock_edge_on(g, frame, x, y, VERTICAL)) return;
   u8 *Y = frames + frame * g.frame_bytes;
   int b[4][8];
   if (VERTICAL) {
@@ -374,7 +425,7 @@ template <bool VERTICAL> __global__ void __launch_bounds__(256) dev_deblock_luma
       for (int i = 0; i < 4; i++) b[i][k] = (v >> (8 * i)) & 0xff;
     }
   }
-  deblock_luma_lines(b, g.beta, g.tc);
+  deblock_luma_lines(b, g.beta, tc);
   if (VERTICAL) {
     for (int i = 0; i < 4; i++) {
       u32 *row = reinterpret_cast<u32 *>(Y + (long)(y + i) * g.W + x - 4);
@@ -396,7 +447,12 @@ template <bool VERTICAL> __global__ void __launch_bounds__(256) dev_deblock_chro
   const long per_frame = 2L * nx * ny, frame = p / per_frame;
   const int r = (int)(p % per_frame), plane = r / (nx * ny), q = r % (nx * ny), ix = q % nx, iy = q / nx;
   const int xc = VERTICAL ? 8 * ix : 4 * ix, yc = VERTICAL ? 4 * iy : 8 * iy;
-  if ((VERTICAL ? xc : yc) == 0 || !deblock_edge_on(g, frame, 2 * xc, 2 * yc, VERTICAL)) return;
+  if ((VERTICAL ? xc : yc) == 0) return;
+  if (g.info) {  // filter.c:567-632: the unit's edge test, then only next to an intra CU (strength 2)
+    if (!dbk_edge_on_inter(g, frame, 2 * xc, 2 * yc, VERTICAL)) return;
+    const kvz_hip_cu_dbk *q = dbk_unit(g, frame, 2 * xc, 2 * yc), *pp = dbk_unit(g, frame, VERTICAL ? 2 * xc - 2 : 2 * xc, VERTICAL ? 2 * yc : 2 * yc - 2);
+    if (q->type != 1 && pp->type != 1) return;
+  } else if (!deblock_edge_on(g, frame, 2 * xc, 2 * yc, VERTICAL)) return;
   u8 *P = frames + frame * g.frame_bytes + (long)g.W * g.H + (long)plane * cw * ch;
   const int across = VERTICAL ? 1 : cw, along = VERTICAL ? cw : 1;
   for (int i = 0; i < 4; i++) {
@@ -409,11 +465,14 @@ template <bool VERTICAL> __global__ void __launch_bounds__(256) dev_deblock_chro
 }
 
 // passes: 1 = the vertical edges, 2 = the horizontal edges, 3 = both (in that order)
-inline void deblock_frames_on(hipStream_t stream, u8 *frames, int width, int height, int n_frames, const u8 *cu_depth, int qp, int beta_off, int tc_off, int passes = 3)
+inline void deblock_frames_on(hipStream_t stream, u8 *frames, int width, int height, int n_frames, const u8 *cu_depth, int qp, int beta_off, int tc_off, int passes = 3,
+                              const kvz_hip_cu_dbk *info = nullptr, int slice_b = 0)
 {
   if (n_frames <= 0) return;
   DeblockGeom g;
   g.W = width; g.H = height; g.cu_depth = cu_depth; g.frame_bytes = (long)width * height * 3 / 2;
+  g.info = info; g.slice_b = slice_b;
+  g.tc1 = deblock_tc(iclip(0, 53, qp + 2 * tc_off));  // filter.c:496-497 with strength 1
   g.beta = deblock_beta(iclip(0, 51, qp + 2 * beta_off));
   g.tc = deblock_tc(iclip(0, 53, qp + 2 + 2 * tc_off));                  // filter.c:496-497 with strength 2
   g.tc_c = deblock_tc(iclip(0, 53, chroma_qp_of(qp) + 2 + 2 * tc_off));  // filter.c:592-595
@@ -667,6 +726,12 @@ void kvz_hip_dev_deblock_frames(uint8_t *frames, int width, int height, int n_fr
                                 int tc_offset_div2)
 {
   kvz::deblock_frames_on(be().stream, frames, width, height, n_frames, cu_depth, qp, beta_offset_div2, tc_offset_div2);
+}
+
+void kvz_hip_dev_deblock_frames_inter(uint8_t *frames, int width, int height, int n_frames, const kvz_hip_cu_dbk *info, int qp, int beta_offset_div2, int tc_offset_div2,
+                                      int slice_is_b)
+{
+  kvz::deblock_frames_on(be().stream, frames, width, height, n_frames, nullptr, qp, beta_offset_div2, tc_offset_div2, 3, info, slice_is_b);
 }
 
 void kvz_hip_dev_sad_surface(const uint8_t *cur, const uint8_t *ref, int width, int height, int bw, int range, const int16_t *blk_xy, int count,

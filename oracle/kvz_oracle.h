@@ -149,6 +149,9 @@ void kvz_oracle_sao_search_frame(const kvz_hip_intra_cost_model *m, int width, i
                                  uint8_t *merge_out);
 void kvz_oracle_deblock_frame_passes(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,
                                      const uint8_t *cu_depth, int passes);
+#include "../include/kvz_hip_dev.h" /* kvz_hip_cu_dbk */
+void kvz_oracle_deblock_frame_inter(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,
+                                    const kvz_hip_cu_dbk *info, int slice_is_b);  /* filter.c:405-493 boundary strengths from motion data */
 void kvz_oracle_deblock_lcu(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,
                             const uint8_t *cu_depth, int x_px, int y_px);
 

@@ -190,3 +190,75 @@ void kvz_oracle_deblock_lcu(int width, int height, int qp, int beta_offset_div2,
   if (x_px > 0) deblock_lcu_rightmost(&d, x_px, y_px);
   deblock_lcu_inside(&d, x_px, y_px, 0);
 }
+
+/* ---- pictures with inter CUs: boundary strengths from motion data (filter.c:405-493), prediction-unit edges (filter.c:225-257) -----------
+ * info: one kvz_hip_cu_dbk per 4x4 unit.  Picture-level order as above (all vertical edges, then all horizontal ones); the edge grid, the
+ * 4-sample parts and the filters are those of the intra case, only the per-part strength (and with it tc, or no filtering at all) differs. */
+static const kvz_hip_cu_dbk *unit_at(const kvz_hip_cu_dbk *info, int width, int x, int y) { return info + (size_t)(y >> 2) * (width >> 2) + (x >> 2); }
+
+static int inter_edge_on(const kvz_hip_cu_dbk *info, int width, int x, int y, int vertical, int *tu_boundary)
+{
+  static const int8_t second_x[8] = { -1, -1, 2, 2, -1, -1, 1, 3 }, second_y[8] = { -1, 2, -1, 2, 1, 3, -1, -1 };  /* cu.c:63-72, second partition's offset in CU quarters */
+  const kvz_hip_cu_dbk *u = unit_at(info, width, x, y);
+  const int pos = vertical ? x : y, cu_w = 64 >> u->depth, rel = pos & (cu_w - 1);
+  *tu_boundary = (pos & ((64 >> u->tr_depth) - 1)) == 0;
+  if (*tu_boundary || rel == 0) return 1;
+  const int q = vertical ? second_x[u->part_size] : second_y[u->part_size];
+  return q >= 0 && rel == q * cu_w / 4;
+}
+
+static int far4(int a, int b) { return abs(a - b) >= 4; }
+
+static int inter_strength(const kvz_hip_cu_dbk *q, const kvz_hip_cu_dbk *p, int tu_boundary, int slice_b)
+{
+  if (q->type == 1 || p->type == 1) return 2;
+  if (tu_boundary && (q->cbf_y || p->cbf_y)) return 1;
+  if (p->mv_dir != 3 && q->mv_dir != 3) {
+    if (far4(q->mv[q->mv_dir - 1][0], p->mv[p->mv_dir - 1][0]) || far4(q->mv[q->mv_dir - 1][1], p->mv[p->mv_dir - 1][1])) return 1;
+    if (q->mv_ref[q->mv_dir - 1] != p->mv_ref[p->mv_dir - 1]) return 1;
+  }
+  if (!slice_b) return 0;
+  int16_t mq[2][2], mp[2][2];
+  for (int l = 0; l < 2; l++) for (int k = 0; k < 2; k++) { mq[l][k] = (q->mv_dir & (1 << l)) ? q->mv[l][k] : 0; mp[l][k] = (p->mv_dir & (1 << l)) ? p->mv[l][k] : 0; }
+  const int rp0 = (p->mv_dir & 1) ? p->ref_id[0] : -1, rp1 = (p->mv_dir & 2) ? p->ref_id[1] : -1;
+  const int rq0 = (q->mv_dir & 1) ? q->ref_id[0] : -1, rq1 = (q->mv_dir & 2) ? q->ref_id[1] : -1;
+  if ((rp0 == rq0 && rp1 == rq1) || (rp0 == rq1 && rp1 == rq0)) {
+    const int straight = far4(mq[0][0], mp[0][0]) || far4(mq[0][1], mp[0][1]) || far4(mq[1][0], mp[1][0]) || far4(mq[1][1], mp[1][1]);
+    const int crossed = far4(mq[1][0], mp[0][0]) || far4(mq[1][1], mp[0][1]) || far4(mq[0][0], mp[1][0]) || far4(mq[0][1], mp[1][1]);
+    if (rp0 != rp1) return (rp0 == rq0) ? straight : crossed;
+    return straight && crossed;
+  }
+  return 1;
+}
+
+void kvz_oracle_deblock_frame_inter(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,
+                                    const kvz_hip_cu_dbk *info, int slice_is_b)
+{
+  const int cw = width >> 1;
+  const int beta = beta_prime(clip3(0, 51, qp + (beta_offset_div2 << 1)));
+  const int tc_c = tc_prime(clip3(0, 53, chroma_qp[qp] + 2 + (tc_offset_div2 << 1)));
+  for (int dir = 0; dir < 2; dir++) {
+    const int vertical = dir == 0;
+    for (int ey = 0; ey < height; ey += 8)
+      for (int ex = 0; ex < width; ex += 8) {
+        int tu_boundary;
+        if ((vertical ? ex : ey) == 0) continue;
+        if (!inter_edge_on(info, width, ex, ey, vertical, &tu_boundary)) continue;
+        for (int part = 0; part < 2; part++) {
+          const int px = ex + (vertical ? 0 : 4 * part), py = ey + (vertical ? 4 * part : 0);
+          const int s = inter_strength(unit_at(info, width, px, py), unit_at(info, width, vertical ? px - 1 : px, vertical ? py : py - 1), tu_boundary, slice_is_b);
+          if (!s) continue;
+          const int tc = tc_prime(clip3(0, 53, qp + 2 * (s - 1) + (tc_offset_div2 << 1)));
+          luma_part(y + py * width + px, vertical ? 1 : width, vertical ? width : 1, beta, tc);
+        }
+        const int xc = ex >> 1, yc = ey >> 1;
+        if (((vertical ? xc : yc) & 7) == 0) {  /* filter.c:680, then :610: only next to an intra CU */
+          const kvz_hip_cu_dbk *q = unit_at(info, width, ex, ey), *p = unit_at(info, width, vertical ? ex - 1 : ex, vertical ? ey : ey - 1);
+          if (q->type == 1 || p->type == 1) {
+            chroma_part(u + yc * cw + xc, vertical ? 1 : cw, vertical ? cw : 1, tc_c);
+            chroma_part(v + yc * cw + xc, vertical ? 1 : cw, vertical ? cw : 1, tc_c);
+          }
+        }
+      }
+  }
+}

@@ -303,6 +303,60 @@ void kvz_ref_deblock_frame(int width, int height, int qp, int beta_offset_div2, 
   g_state.tile = NULL;
 }
 
+/* ... and for pictures with inter CUs: the cu_array is filled from one record per 4x4 unit (include/kvz_hip_dev.h kvz_hip_cu_dbk) */
+#include "../include/kvz_hip_dev.h"
+void kvz_ref_deblock_frame_inter(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,
+                                 const kvz_hip_cu_dbk *info, int slice_is_b)
+{
+  encoder_state_config_tile_t tile;
+  videoframe_t frame;
+  memset(&tile, 0, sizeof tile);
+  memset(&frame, 0, sizeof frame);
+  frame.width = width; frame.height = height;
+  frame.width_in_lcu = (width + LCU_WIDTH - 1) / LCU_WIDTH; frame.height_in_lcu = (height + LCU_WIDTH - 1) / LCU_WIDTH;
+  frame.rec = kvz_image_alloc(KVZ_CSP_420, width, height);
+  frame.cu_array = kvz_cu_array_alloc(width, height);
+  for (int r = 0; r < height; r++) memcpy(frame.rec->y + r * frame.rec->stride, y + r * width, width);
+  for (int r = 0; r < height / 2; r++) {
+    memcpy(frame.rec->u + r * (frame.rec->stride / 2), u + r * (width / 2), width / 2);
+    memcpy(frame.rec->v + r * (frame.rec->stride / 2), v + r * (width / 2), width / 2);
+  }
+  for (int py = 0; py < height; py += 4)
+    for (int px = 0; px < width; px += 4) {
+      cu_info_t *cu = kvz_cu_array_at(frame.cu_array, px, py);
+      const kvz_hip_cu_dbk *d = &info[(size_t)(py >> 2) * (width >> 2) + (px >> 2)];
+      memset(cu, 0, sizeof *cu);
+      cu->type = d->type; cu->depth = d->depth; cu->tr_depth = d->tr_depth; cu->part_size = d->part_size; cu->qp = (int8_t)qp;
+      if (d->cbf_y) cbf_set(&cu->cbf, d->tr_depth, COLOR_Y);
+      if (d->type == CU_INTER) {
+        cu->inter.mv_dir = d->mv_dir;
+        for (int l = 0; l < 2; l++) {
+          cu->inter.mv[l][0] = d->mv[l][0]; cu->inter.mv[l][1] = d->mv[l][1]; cu->inter.mv_ref[l] = d->mv_ref[l];
+          if (d->mv_dir & (1 << l)) g_frame.ref_LX[l][d->mv_ref[l]] = (uint8_t)d->ref_id[l];  /* the caller keeps (list, index) -> picture consistent */
+        }
+      }
+    }
+  tile.frame = &frame;
+  g_state.tile = &tile;
+  g_state.qp = (int8_t)qp;
+  g_frame.max_qp_delta_depth = -1;
+  g_frame.slicetype = slice_is_b ? KVZ_SLICE_B : KVZ_SLICE_P;
+  g_frame.QP = (int8_t)qp;
+  g_ctrl.cfg.deblock_beta = beta_offset_div2; g_ctrl.cfg.deblock_tc = tc_offset_div2;
+  g_ctrl.cfg.lossless = 0;
+  g_ctrl.chroma_format = KVZ_CSP_420;
+  for (int ly = 0; ly < height; ly += LCU_WIDTH)
+    for (int lx = 0; lx < width; lx += LCU_WIDTH) kvz_filter_deblock_lcu(&g_state, lx, ly);
+  for (int r = 0; r < height; r++) memcpy(y + r * width, frame.rec->y + r * frame.rec->stride, width);
+  for (int r = 0; r < height / 2; r++) {
+    memcpy(u + r * (width / 2), frame.rec->u + r * (frame.rec->stride / 2), width / 2);
+    memcpy(v + r * (width / 2), frame.rec->v + r * (frame.rec->stride / 2), width / 2);
+  }
+  kvz_image_free(frame.rec);
+  kvz_cu_array_free(&frame.cu_array);
+  g_state.tile = NULL;
+}
+
 /* ---- SAO applied to a whole picture with the reference's own border logic: kvz_sao_reconstruct (sao.c:302-361) per CTU and
  * plane, input = a separate copy of the deblocked picture (neighbours are pre-SAO samples), output = frame->rec ---- */
 void kvz_ref_sao_frame(int width, int height, const uint8_t *in, uint8_t *out, const kvz_hip_sao_params *luma, const kvz_hip_sao_params *chroma)
