@@ -630,11 +630,20 @@ template <bool CABAC> struct CtuProgramT {
     w.ent_hi = (unsigned)(s->entropy_fbits[lane + 64] * 32768.0f);
     return w;
   }
-  KVZ_DEV void wave_ctx_store(CtxSet *c, const WaveCtx &w, int lane) const
+  // Only the contexts of the block's own class -- luma (type 0) or chroma -- are written back: a block never moves the other class
+  // (cabac.h:63-100: every residual context exists once per class), so a luma block on one wavefront and the chroma blocks of the same
+  // unit on the other can price and update the same set concurrently.
+  KVZ_DEV static bool ctx_is_chroma(int r)  // r = index - KVZ_HIP_CX_SIG_CG
+  {
+    return (r >= 2 && r < 4) || (r >= 31 && r < 46) || (r >= 61 && r < 76) || (r >= 91 && r < 106) || (r >= 122 && r < 130) || r >= 134;
+  }
+  KVZ_DEV void wave_ctx_store(CtxSet *c, const WaveCtx &w, int lane, int type) const
   {
     u8 *r = c->s + KVZ_HIP_CX_SIG_CG;
-    r[lane] = (u8)w.st; r[lane + 64] = (u8)(w.st >> 8);
-    if (lane < 8) r[lane + 128] = (u8)(w.st >> 16);
+    const bool chroma = type != 0;
+    if (ctx_is_chroma(lane) == chroma) r[lane] = (u8)w.st;
+    if (ctx_is_chroma(lane + 64) == chroma) r[lane + 64] = (u8)(w.st >> 8);
+    if (lane < 8 && ctx_is_chroma(lane + 128) == chroma) r[lane + 128] = (u8)(w.st >> 16);
   }
   KVZ_DEV static unsigned bin_q15(WaveCtx &w, bool update, int idx, int bin)
   {
@@ -750,7 +759,7 @@ template <bool CABAC> struct CtuProgramT {
         q15 += (unsigned long long)bypass << 15;
       }
     }
-    if (update) wave_ctx_store(c, wc, lane);
+    if (update) wave_ctx_store(c, wc, lane, type);
     return (double)q15 / 32768.0;
   }
 #endif
@@ -1526,18 +1535,23 @@ template <bool CABAC> struct CtuProgramT {
 
   // get_coeff_cabac_cost (rdo.c:220-263) of the planes of one transform unit that have levels, luma first (search.c:518-547).
   // On the device the callers bring the whole wavefront that plays threads 0..63 (KVZ_UNIT_COEFF_BITS), in the host simulation thread 0.
-  KVZ_DEV double unit_coeff_bits(CtxSet *c, bool update, int lv, int depth, int mode, int cb_y, int cb_u, int cb_v) const
+  KVZ_DEV double unit_coeff_bits(CtxSet *c, bool update, int lv, int depth, int mode, int cb_y, int cb_u, int cb_v, int tid) const
   {
     const int lw = 6 - depth, lc = depth == 3 ? 2 : lw - 1, scan = scan_order(mode, depth);
     double bits = 0;
 #ifdef KVZ_HOSTSIM
+    (void)tid;
     if (cb_y) bits += coeff_cabac_bits(c, update, levels_lds(lv, 0), lw, 0, scan);
     if (cb_u) bits += coeff_cabac_bits(c, update, levels_lds(lv, 1), lc, 2, scan);
     if (cb_v) bits += coeff_cabac_bits(c, update, levels_lds(lv, 2), lc, 2, scan);
-#else  // a whole wavefront is here (see the callers)
-    if (cb_y) bits += coeff_cabac_bits_wave(c, update, levels_lds(lv, 0), lw, 0, scan);
-    if (cb_u) bits += coeff_cabac_bits_wave(c, update, levels_lds(lv, 1), lc, 2, scan);
-    if (cb_v) bits += coeff_cabac_bits_wave(c, update, levels_lds(lv, 2), lc, 2, scan);
+#else  // both wavefronts are here: the one playing threads 0..63 takes the luma block, the other one the two chroma blocks -- luma and
+       // chroma contexts are disjoint, so the two chains (Y | U -> V) are independent even with updates on
+    if (tid < 64) {
+      if (cb_y) bits += coeff_cabac_bits_wave(c, update, levels_lds(lv, 0), lw, 0, scan);
+    } else {
+      if (cb_u) bits += coeff_cabac_bits_wave(c, update, levels_lds(lv, 1), lc, 2, scan);
+      if (cb_v) bits += coeff_cabac_bits_wave(c, update, levels_lds(lv, 2), lc, 2, scan);
+    }
 #endif
     return bits;
   }
@@ -1550,12 +1564,23 @@ template <bool CABAC> struct CtuProgramT {
 #endif
   KVZ_DEV void price_unit_coeffs(CtxSet *c, bool update, int lv, int depth, int mode, double *out) const
   {
+#ifdef KVZ_HOSTSIM
     KVZ_FOR_THREADS(tid) {
-      if (KVZ_UNIT_COEFF_BITS(tid)) {
-        const double b = unit_coeff_bits(c, update, lv, depth, mode, s->acc[6] != 0, s->acc[7] != 0, s->acc[8] != 0);
-        if (tid == 0) *out = b;
-      }
+      if (tid == 0) *out = unit_coeff_bits(c, update, lv, depth, mode, s->acc[6] != 0, s->acc[7] != 0, s->acc[8] != 0, tid);
     }
+#else
+    // the two wavefronts' shares meet in two doubles that alias child_acc[3][1..4]: dead here -- it is only written after the fourth
+    // unit of the 64x64 attempt has been priced, and read right after that loop (try_merge)
+    double *part = reinterpret_cast<double *>(&s->child_acc[3][1]);
+    KVZ_FOR_THREADS(tid) {
+      const double b = unit_coeff_bits(c, update, lv, depth, mode, s->acc[6] != 0, s->acc[7] != 0, s->acc[8] != 0, tid);
+      if ((tid & 63) == 0) part[tid >> 6] = b;
+    }
+    KVZ_SYNC();
+    KVZ_FOR_THREADS(tid) {
+      if (tid == 0) *out = part[0] + part[1];  // multiples of 2^-15 far below 2^38: the sum is exact in any order
+    }
+#endif
   }
   // search.c:425-541 cu_rd_cost_tr_split_accurate for one leaf TU group whose sums sit in s->acc (lane 0 only)
   // `known_coeff_bits`: the units of the 64x64 attempt had their coefficients priced when their levels were staged (try_merge)
@@ -1868,7 +1893,13 @@ template <bool CABAC> struct CtuProgramT {
       }
       KVZ_SYNC();
       KVZ_FOR_THREADS(tid) {
-        if (KVZ_UNIT_COEFF_BITS(tid)) {  // the whole wavefront walks the quadrant's units (everything it branches on is uniform)
+#ifdef KVZ_HOSTSIM
+        const bool luma_role = true, chroma_role = true;
+        if (tid == 0) {
+#else
+        const bool luma_role = tid < 64, chroma_role = !luma_role;  // two independent chains: luma blocks on one wavefront, chroma blocks on the other
+        {  // both wavefronts walk the quadrant's units (everything they branch on is wavefront-uniform)
+#endif
           CtxSet *c = &s->pre[0];
           int i = 16 * q;
           while (i < 16 * q + 16) {
@@ -1883,9 +1914,9 @@ template <bool CABAC> struct CtuProgramT {
 #else
 #define KVZ_CODE_RESIDUAL coeff_cabac_bits_wave
 #endif
-            if (cbf_is_set(cu->cbf, td, 0)) KVZ_CODE_RESIDUAL(c, true, y, lw, 0, scan);
-            if (cbf_is_set(cu->cbf, td, 1)) KVZ_CODE_RESIDUAL(c, true, u, lc, 2, scan);
-            if (cbf_is_set(cu->cbf, td, 2)) KVZ_CODE_RESIDUAL(c, true, u + 256, lc, 2, scan);
+            if (luma_role && cbf_is_set(cu->cbf, td, 0)) KVZ_CODE_RESIDUAL(c, true, y, lw, 0, scan);
+            if (chroma_role && cbf_is_set(cu->cbf, td, 1)) KVZ_CODE_RESIDUAL(c, true, u, lc, 2, scan);
+            if (chroma_role && cbf_is_set(cu->cbf, td, 2)) KVZ_CODE_RESIDUAL(c, true, u + 256, lc, 2, scan);
             i += 1 << (2 * (3 - td));
           }
         }

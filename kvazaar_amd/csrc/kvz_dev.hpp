@@ -126,12 +126,28 @@ __global__ void __launch_bounds__(256) dev_satd4_kernel(const u8 *a, const u8 *b
 // the next product and, read as A, the transposed matrix, so the first result feeds the second product directly.
 // Exactness: 16-bit operands are split x = 256 (x >> 8) + (x & 255); every operand is then an integer binary16 holds
 // exactly, products are exact in binary32 and all partial sums stay below 32 * 90 * 255 < 2^24.
+// Memory side: a wavefront moves its block between HBM and LDS with 16-byte accesses (2 KB per 32x32 block = two dwordx4 per lane) and feeds the
+// matrix cores from LDS -- the operand layouts want 2-byte column gathers (inverse input) and 2-byte row scatters (every output), which cost
+// 16 narrow global accesses per lane when done against HBM directly.
 template <int N> __global__ void __launch_bounds__(256) dev_transform_mfma_kernel(const i16 *in, i16 *out, const int count, const int inverse, const Tables *tb)
 {
-  const long blk = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (blk >= count) return;  // wavefront-uniform
-  constexpr int L2 = N == 16 ? 4 : 5;
-  mfma_transform_block<N>(in + blk * (N * N), out + blk * (N * N), inverse != 0, tb->dct_h[L2 - 4][0], tb->dct_h[L2 - 4][1], threadIdx.x & 63);
+  __shared__ alignas(16) i16 s_blk[4][N * N];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long blk = (long)blockIdx.x * 4 + wave;
+  const bool have = blk < count;  // wavefront-uniform
+  constexpr int L2 = N == 16 ? 4 : 5, VEC = N * N / 8 / 64;  // uint4 (8 coefficients) per lane: 2 for 32x32; 16x16 blocks: half a uint4 -> uint2
+  i16 *sb = s_blk[wave];
+  if (have) {
+    if (N == 32) { const uint4 *src = reinterpret_cast<const uint4 *>(in + blk * (N * N)); for (int k = 0; k < (VEC ? VEC : 1); k++) reinterpret_cast<uint4 *>(sb)[k * 64 + lane] = src[k * 64 + lane]; }
+    else reinterpret_cast<uint2 *>(sb)[lane] = reinterpret_cast<const uint2 *>(in + blk * (N * N))[lane];
+  }
+  __syncthreads();
+  if (have) mfma_transform_block<N>(sb, sb, inverse != 0, tb->dct_h[L2 - 4][0], tb->dct_h[L2 - 4][1], lane);
+  __syncthreads();
+  if (have) {
+    if (N == 32) { uint4 *dst = reinterpret_cast<uint4 *>(out + blk * (N * N)); for (int k = 0; k < (VEC ? VEC : 1); k++) dst[k * 64 + lane] = reinterpret_cast<const uint4 *>(sb)[k * 64 + lane]; }
+    else reinterpret_cast<uint2 *>(out + blk * (N * N))[lane] = reinterpret_cast<const uint2 *>(sb)[lane];
+  }
 }
 
 // 4- and 8-point transforms (and the 4x4 DST): 16 / n blocks sit on the diagonal of one 16x16 problem, the matrix is the
