@@ -118,6 +118,11 @@ typedef struct kvz_hip_intra_cost_model {
    * switches WPP off when tiles are requested (cfg.c:925-978).  Rows then form one serial chain per picture: the batch needs as many
    * pictures (or tiles) in flight as the device has workgroup slots. */
   int32_t  no_wpp;
+  /* != 0: CUs of 32x32 are searched like the 16x16 and 8x8 ones (kvazaar's --pu-depth-intra 1-3, preset `fast`): rough search + reconstruction of the
+   * 32x32 CU first, then -- unless it has no coefficients (cu-split-termination zero, search.c:975-984) -- its four 16x16 children with early termination.
+   * 0: --pu-depth-intra 2-3 (ultrafast ... faster): 32x32 CUs only arise by merging four 16x16 CUs under the top-left one's mode (search.c:996-1044). */
+  int32_t  search_32x32;
+  int32_t  reserved_;
   uint8_t  ctx_init[160];     /* uc_state at slice start (kvz_init_contexts, context.c:202-305) of the KVZ_HIP_CX_* contexts; the rest unused */
   float    entropy_fbits[128];/* kvz_f_entropy_bits (rdo.c:69-83) */
 } kvz_hip_intra_cost_model;

@@ -63,7 +63,7 @@ static int eligible(const encoder_state_t *state)
   REQUIRE(cfg->rdo == 0 && !cfg->rdoq_enable && !cfg->signhide_enable && !cfg->trskip_enable && cfg->tr_depth_intra == 0);
   REQUIRE(!cfg->lossless && !cfg->implicit_rdpcm && cfg->scaling_list == KVZ_SCALING_LIST_OFF);
   REQUIRE(!cfg->full_intra_search);
-  REQUIRE(cfg->pu_depth_intra.min[0] == 2 && cfg->pu_depth_intra.max[0] == 3);  /* all-intra: GOP layer 0 only */
+  REQUIRE((cfg->pu_depth_intra.min[0] == 2 || cfg->pu_depth_intra.min[0] == 1) && cfg->pu_depth_intra.max[0] == 3);  /* all-intra: GOP layer 0 only; 1-3 = preset `fast` */
   REQUIRE(cfg->cu_split_termination == KVZ_CU_SPLIT_TERMINATION_ZERO && cfg->combine_intra_cus);
   REQUIRE(cfg->target_bitrate <= 0 && !cfg->vaq && !cfg->roi.file_path && !cfg->set_qp_in_cu && state->frame->max_qp_delta_depth < 0);
   REQUIRE(!cfg->ml_pu_depth_intra && !cfg->intra_bit_allocation);
@@ -113,6 +113,7 @@ static picture_result *picture_of(const encoder_state_t *state)
   kvz_hip_intra_cost_model_init(state->qp, kvz_fast_coeff_get_weights(state), &model);
   const kvz_config *cfg = &state->encoder_control->cfg;
   model.coeff_cabac = !(state->qp < cfg->fast_residual_cost_limit && state->qp < MAX_FAST_COEFF_COST_QP);  /* rdo.c:311-340 */
+  model.search_32x32 = cfg->pu_depth_intra.min[0] == 1;  /* 32x32 CUs are searched, not only merged (search.c:794) */
   model.no_wpp = !cfg->wpp;  /* kvazaar switches WPP off when tiles are used (cfg.c:925-978) */
   kvz_hip_batch_upload(g_batch, 0, src, src + ys, src + ys + cs);
   kvz_hip_intra_frames(g_batch, &model);

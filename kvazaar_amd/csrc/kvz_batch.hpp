@@ -72,7 +72,7 @@ __device__ __forceinline__ bool wait_done(unsigned *flag, unsigned epoch, unsign
   }
 }
 
-template <bool CABAC> __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) KVZ_CTU_VGPR_ATTR intra_ctu_ticket_kernel(const CtuFrames F, const CtuModel model, const Tables *tb,
+template <bool CABAC, bool S32 = false> __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) KVZ_CTU_VGPR_ATTR intra_ctu_ticket_kernel(const CtuFrames F, const CtuModel model, const Tables *tb,
                                                                         const CtuSched sched)
 {
   __shared__ CtuSharedT<CABAC> shared;
@@ -96,7 +96,7 @@ template <bool CABAC> __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attri
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
-    CtuProgramT<CABAC> p;
+    CtuProgramT<CABAC, S32> p;
     p.m = &m; p.tb = tb; p.F = F; p.s = &shared;
     p.frame = frame; p.cx = x * 64; p.cy = y * 64;
     p.lane_rot = (t * 64) & (KVZ_CTU_THREADS - 1);
@@ -406,6 +406,7 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
   cm.ctx_init = (const uint8_t *)(b->d_entropy + 128);
   KVZ_HIP_CHECK(hipMemcpyAsync(b->d_entropy, model->entropy_fbits, 128 * sizeof(float), hipMemcpyHostToDevice, b->stream));
   KVZ_HIP_CHECK(hipMemcpyAsync(b->d_entropy + 128, model->ctx_init, sizeof model->ctx_init, hipMemcpyHostToDevice, b->stream));
+  if (!b->sched_ticket && cm.search_32x32) { fprintf(stderr, "kvz_hip_intra_frames: search_32x32 needs the ticket schedule\n"); abort(); }
   if (!b->sched_ticket && cm.no_wpp) { fprintf(stderr, "kvz_hip_intra_frames: the one-launch-per-diagonal schedule (KVZ_HIP_SCHED=wave) needs WPP\n"); abort(); }
   if (b->sched_ticket) {
     b->epoch++;
@@ -413,7 +414,11 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
     KVZ_HIP_CHECK(hipEventRecord(b->ev0, b->stream));
     kvz::CtuSched sc{ cm.no_wpp ? b->d_items_raster : b->d_items, b->d_ticket, b->d_done, b->d_error, b->total_items, b->epoch, cm.no_wpp, b->wait_ticks };
     // two instantiations: the one without the CABAC coefficient model carries none of its code, registers or context storage
-    if (cm.coeff_cabac) hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel<true>, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);
+    // (the instantiations that search 32x32 CUs, --pu-depth-intra 1-3, are separate ones too: the others stay as they were)
+    if (cm.search_32x32) {
+      if (cm.coeff_cabac) hipLaunchKernelGGL((kvz::intra_ctu_ticket_kernel<true, true>), dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);
+      else hipLaunchKernelGGL((kvz::intra_ctu_ticket_kernel<false, true>), dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);
+    } else if (cm.coeff_cabac) hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel<true>, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);
     else hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel<false>, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);
     KVZ_HIP_CHECK(hipGetLastError());
     KVZ_HIP_CHECK(hipEventRecord(b->ev1, b->stream));

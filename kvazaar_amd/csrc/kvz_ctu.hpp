@@ -147,14 +147,14 @@ template <bool CABAC> struct CtxSetT { alignas(4) u8 s[CABAC ? 148 : 12]; };
 struct CtuModel {
   double lambda, lambda_sqrt;
   uint64_t coeff_weights;
-  int qp, adaptive, coeff_cabac, no_wpp;
+  int qp, adaptive, coeff_cabac, no_wpp, search_32x32;
   const float *entropy_fbits;  // [128]
   const u8 *ctx_init;          // [KVZ_CX_COUNT]
 };
 KVZ_HD void ctu_model_from(const kvz_hip_intra_cost_model *src, CtuModel *dst)
 {
   dst->lambda = src->lambda; dst->lambda_sqrt = src->lambda_sqrt; dst->coeff_weights = src->coeff_weights; dst->qp = src->qp; dst->adaptive = src->adaptive;
-  dst->coeff_cabac = src->coeff_cabac; dst->no_wpp = src->no_wpp;
+  dst->coeff_cabac = src->coeff_cabac; dst->no_wpp = src->no_wpp; dst->search_32x32 = src->search_32x32;
   dst->entropy_fbits = src->entropy_fbits;
   dst->ctx_init = src->ctx_init;
 }
@@ -255,7 +255,8 @@ using CtuShared = CtuSharedT<true>;
 
 static const int kPlaneOff[3] = { 0, 4096, 5120 };
 
-template <bool CABAC> struct CtuProgramT {
+// S32: the instantiation that can also SEARCH 32x32 CUs (kvz_hip_intra_cost_model::search_32x32, --pu-depth-intra 1-3); the others carry none of its code
+template <bool CABAC, bool S32 = false> struct CtuProgramT {
   using CtxSet = CtxSetT<CABAC>;
   const CtuModel *m;
   const Tables *tb;
@@ -410,6 +411,11 @@ template <bool CABAC> struct CtuProgramT {
   {
     const int n = cabac_on() ? 37 : 3;
     for (int i = 0; i < n; i++) ((unsigned *)dst->s)[i] = ((const unsigned *)src->s)[i];
+  }
+  KVZ_DEV void ctx_swap(CtxSet *a, CtxSet *b) const
+  {
+    const int n = cabac_on() ? 37 : 3;
+    for (int i = 0; i < n; i++) { const unsigned t = ((unsigned *)a->s)[i]; ((unsigned *)a->s)[i] = ((unsigned *)b->s)[i]; ((unsigned *)b->s)[i] = t; }
   }
   // lambda_sqrt * kvz_luma_mode_bits of the three possible outcomes at the current state of the intra-mode context; the rough
   // search prices with it without touching the context (search_intra.c:524: search_cabac.update == 0 there).  One lane.
@@ -1019,6 +1025,7 @@ template <bool CABAC> struct CtuProgramT {
 
   KVZ_DEV u32 mode_satd(int mode, int nblk) const  // SATD_NxN: sum of (block sum + 2) >> 2 (strategies-picture.h:53-69)
   {
+    if (S32 && nblk == 16) return s->satd_raw[mode][0];  // a 32x32 CU's sum over its sixteen blocks, already rounded per block (rough_search)
     u32 v = 0;
     for (int b = 0; b < nblk; b++) v += (s->satd_raw[mode][b] + 2) >> 2;
     return v;
@@ -1065,6 +1072,34 @@ template <bool CABAC> struct CtuProgramT {
   {
     const int log2w = 6 - depth, w = 1 << log2w, xl = x - cx, yl = y - cy, nblk = (w >> 3) * (w >> 3);
     build_refs(lv, x, y, log2w, depth == 3 ? 2 : log2w - 1, true, true, first);
+    if (S32 && log2w == 5) {
+      // 32x32 CU (first version, generic): mode by mode the whole prediction into LDS (the 32-point transform scratch is free until the
+      // reconstruction), then one thread per (8x8 block, Hadamard column) -- 16 x 8 = the workgroup -- and the per-block rounding
+      // (strategies-picture.h:53-69: SATD_32x32 = sum of sixteen 8x8 SATDs) into the mode's total
+      u8 *scratch = reinterpret_cast<u8 *>(s->tb_big);
+      KVZ_FOR_THREADS(tid) {
+        for (int v = tid; v < 35; v += KVZ_CTU_THREADS) s->satd_raw[v][0] = 0;
+        if (tid < 16) s->acc[tid] = 0;
+        if (tid == KVZ_CTU_THREADS - 1) {
+          const int left = x >= 4 ? neighbour_cu(lv, x - 1, y) : -1, above = (y >= 4 && yl > 0) ? neighbour_cu(lv, x, y - 1) : -1;
+          mpm_candidates(y, left, above, s->preds);
+        }
+      }
+      KVZ_SYNC();
+      for (int mode = 0; mode < 35; mode++) {
+        KVZ_FOR_THREADS(tid) {
+          if (tid < 16) { KVZ_LDS_ADD(&s->satd_raw[mode > 0 ? mode - 1 : 0][0], mode > 0 ? (s->acc[tid] + 2) >> 2 : 0u); s->acc[tid] = 0; }  // the previous mode's blocks
+          for (int e = tid; e < 1024; e += KVZ_CTU_THREADS) scratch[e] = predict_pixel(5, mode, 0, e & 31, e >> 5);
+        }
+        KVZ_SYNC();
+        KVZ_FOR_THREADS(tid) {
+          const int tile = tid >> 3, col = tid & 7, bx = (tile & 3) * 8, by = (tile >> 2) * 8;
+          KVZ_LDS_ADD(&s->acc[tile], satd8_column(scratch + by * 32 + bx, 32, org_at(0, xl + bx, yl + by), 32, col));
+        }
+        KVZ_SYNC();
+      }
+      KVZ_FOR_THREADS(tid) { if (tid < 16) { KVZ_LDS_ADD(&s->satd_raw[34][0], (s->acc[tid] + 2) >> 2); s->acc[tid] = 0; } }
+    } else {
     KVZ_FOR_THREADS(tid) {
       // extended main reference per angular mode
       if (log2w == 3) build_mref<3>(tid); else build_mref<4>(tid);
@@ -1110,6 +1145,7 @@ template <bool CABAC> struct CtuProgramT {
         const u32 v = satd8_column(s->pred + mi * 256 + by * w + bx, w, org_at(0, xl + bx, yl + by), 32, col);
         KVZ_LDS_ADD(&s->satd_raw[mi == 2 ? 34 : mi][b], v);
       }
+    }
     }
     KVZ_SYNC();
     KVZ_PROF(KVZ_P_SATD);
@@ -2085,6 +2121,48 @@ template <bool CABAC> struct CtuProgramT {
     }
   }
 
+  // search_cu for depth 1 when 32x32 CUs are searched (--pu-depth-intra 1-3; search.c:646-1063 one level above search_d2): the 32x32 CU is
+  // evaluated first, its four 16x16 children only if it has coefficients (cu-split-termination zero) and while the running split cost stays
+  // below its cost.  Differences to the merge flow of the other presets: the 32x32 candidate exists BEFORE the children are searched, and the
+  // children's search buffers share storage with its pixels (CtuShared's union) -- so the candidate's 1 536 bytes wait in the CTU's
+  // scratch block in HBM (free until the 64x64 attempt at the very end) and come back if the 32x32 CU wins; its levels stay in lv1_coeff,
+  // which the children do not use.  The contexts after the 32x32 CU (search.c:956-959 post_search_cabac) are kept by SWAPPING them with the
+  // entry state in pre[1]: nothing reads this depth's entry state again, and commit() restores from pre[1] when the CU stays unsplit.
+  KVZ_DEV void search_d1(int x1, int y1)
+  {
+    const int xl = x1 - cx, yl = y1 - cy;
+    const bool inside = x1 + 32 <= F.W && y1 + 32 <= F.H;
+    int *cbf1 = reinterpret_cast<int *>(&s->child_acc[0][0]);  // "the 32x32 CU has coefficients": a scalar of its own (cbf_any is reused by the children); child_acc is dead until the 64x64 attempt
+    auto d1_first = [&]() { *cbf1 = 0; price_modes(); };
+    auto d1_last = [&]() {
+      ctx_swap(&s->cab, &s->pre[1]);
+      double sc = split_flag_cost(1, x1, y1, 1);
+      if (inside && !*cbf1) sc = 2147483647;  // search.c:975-984
+      s->split_cost[1] = sc;
+    };
+    if (inside) eval_cu(1, x1, y1, 1, &s->cost[1], cbf1, d1_first, d1_last);
+    else {
+      KVZ_FOR_THREADS(tid) { if (tid == 0) { d1_first(); d1_last(); } }
+      KVZ_SYNC();
+    }
+    const bool descend = !inside || *cbf1;
+    if (!descend) return;
+    u8 *stash = reinterpret_cast<u8 *>(coeff_level(0));
+    if (inside) {
+      KVZ_FOR_THREADS(tid) { for (int e = tid; e < 1536 / 4; e += KVZ_CTU_THREADS) reinterpret_cast<u32 *>(stash)[e] = reinterpret_cast<const u32 *>(s->c1)[e]; }
+      KVZ_SYNC();
+    }
+    for (int q2 = 0; q2 < 4; q2++) {
+      if (!(s->split_cost[1] < s->cost[1])) break;  // uniform: LDS scalars that only change inside commit(), which ends with a barrier
+      search_d2(x1 + (q2 & 1) * 16, y1 + (q2 >> 1) * 16);
+    }
+    if (inside && !(s->split_cost[1] < s->cost[1])) {  // the 32x32 CU wins: its pixels back into the candidate buffer for commit()
+      KVZ_SYNC();
+      KVZ_FOR_THREADS(tid) { for (int e = tid; e < 1536 / 4; e += KVZ_CTU_THREADS) reinterpret_cast<u32 *>(s->c1)[e] = reinterpret_cast<const u32 *>(stash)[e]; }
+      KVZ_SYNC();
+    }
+  }
+
   KVZ_DEV void run()
   {
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
@@ -2101,9 +2179,13 @@ template <bool CABAC> struct CtuProgramT {
       const int x1 = cx + (q1 & 1) * 32, y1 = cy + (q1 >> 1) * 32;
       if (x1 >= F.W || y1 >= F.H) continue;  // search_cu returns 0 outside the picture
       a1x = x1 - cx; a1y = y1 - cy;
-      load_org([&]() { cu_header(1, x1 - cx, y1 - cy, 1); s->cost[1] = 1.7e+308; ctx_copy(&s->pre[1], &s->cab); s->split_cost[1] = split_flag_cost(1, x1, y1, 1); });
-      for (int q2 = 0; q2 < 4; q2++) search_d2(x1 + (q2 & 1) * 16, y1 + (q2 >> 1) * 16);
-      if (x1 + 32 <= F.W && y1 + 32 <= F.H) try_merge(x1, y1, 1);
+      const bool search32 = S32 && m->search_32x32;
+      load_org([&]() { cu_header(1, x1 - cx, y1 - cy, 1); s->cost[1] = 1.7e+308; ctx_copy(&s->pre[1], &s->cab); if (!search32) s->split_cost[1] = split_flag_cost(1, x1, y1, 1); });
+      if (search32) search_d1(x1, y1);
+      else {
+        for (int q2 = 0; q2 < 4; q2++) search_d2(x1 + (q2 & 1) * 16, y1 + (q2 >> 1) * 16);
+        if (x1 + 32 <= F.W && y1 + 32 <= F.H) try_merge(x1, y1, 1);
+      }
       const bool split_wins1 = s->split_cost[1] < s->cost[1];  // operands stay put until the barrier that ends commit()
       if (split_wins1) commit(2, 1, 1, -1, false, x1 - cx, y1 - cy, 32, 1, true);
       else commit(1, 2, 3, 1, true, x1 - cx, y1 - cy, 32, 1, false);  // the 32x32 merge wins

@@ -671,7 +671,7 @@ static double search_cu(ctu_t *t, int x, int y, int depth)
   cur->tr_depth = (uint8_t)(depth > 0 ? depth : 1);
   cur->type = 0;
   const int inside = x + w <= t->W && y + w <= t->H;
-  if (inside && depth >= 2 && depth <= 3) {
+  if (inside && depth >= (m->search_32x32 ? 1 : 2) && depth <= 3) {  /* pu_depth_intra.min .. max (search.c:794) */
     const int mode = search_cu_intra(t, lv, x, y, depth);
     cur->type = 1; cur->mode = (uint8_t)mode;
     fill_cu(lv, xl, yl, w, cur);

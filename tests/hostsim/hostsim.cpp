@@ -50,7 +50,17 @@ extern "C" void kvz_hostsim_intra_frame(const kvz_hip_intra_cost_model *m, int w
   kvz::ctu_model_from(m, &cm);
   for (int cy = 0; cy < F.hc; cy++)
     for (int cx = 0; cx < F.wc; cx++) {
-      if (m->coeff_cabac) {
+      if (m->search_32x32) {  // the instantiations that search 32x32 CUs
+        if (m->coeff_cabac) {
+          kvz::CtuProgramT<true, true> p;
+          p.m = &cm; p.tb = &tb; p.F = F; p.s = (kvz::CtuSharedT<true> *)sh; p.frame = 0; p.cx = cx * 64; p.cy = cy * 64;
+          p.run();
+        } else {
+          kvz::CtuProgramT<false, true> p;
+          p.m = &cm; p.tb = &tb; p.F = F; p.s = (kvz::CtuSharedT<false> *)sh; p.frame = 0; p.cx = cx * 64; p.cy = cy * 64;
+          p.run();
+        }
+      } else if (m->coeff_cabac) {
         kvz::CtuProgramT<true> p;
         p.m = &cm; p.tb = &tb; p.F = F; p.s = (kvz::CtuSharedT<true> *)sh; p.frame = 0; p.cx = cx * 64; p.cy = cy * 64;
         p.run();

@@ -245,3 +245,56 @@ def test_hip_batch_reproduces_reference_encoder(clip):
         assert [_sha(b.download(i)["rec"]) for i in range(n)] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 1)]
     finally:
         b.close()
+
+
+# ---- preset `fast`: 32x32 CUs searched (--pu-depth-intra 1-3), CABAC coefficient cost at every QP ------------------------------------------
+def _fast_model(model):
+    model.search_32x32 = 1
+    model.coeff_cabac = 1
+    return model
+
+
+@pytest.mark.parametrize("clip", mg.ENCODER_CLIPS_FAST, ids=lambda c: f"{c[0]}x{c[1]}-{c[4]}-qp{c[5]}")
+def test_oracle_fast_preset_reproduces_reference_encoder(oracle, clip):
+    w, h, n, seed, kind, qp = clip
+    model = _fast_model(oracle_model(oracle, qp))
+    frames = cc.yuv_frames(w, h, n, seed, kind)
+    raw, _, deb = _oracle_outputs(oracle, model, w, h, frames, qp)
+    assert raw == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0) + "/fast"]
+    assert deb == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 1) + "/fast"]
+
+
+@pytest.mark.parametrize("clip", [c for c in mg.ENCODER_CLIPS_FAST if c[0] * c[1] <= 416 * 240], ids=lambda c: f"{c[0]}x{c[1]}-{c[4]}-qp{c[5]}")
+def test_hostsim_fast_preset_equals_oracle(oracle, hostsim, clip):
+    """the device sources with the 32x32 search (CtuProgramT<.., true>) on the host: every output equals the oracle's, costs included"""
+    w, h, n, seed, kind, qp = clip
+    for cab in (1, 0):  # 0: --pu-depth-intra 1-3 on top of the fast coefficient estimate (not a preset, but a legal configuration)
+        model = oracle_model(oracle, qp)
+        model.search_32x32, model.coeff_cabac = 1, cab
+        for f in cc.yuv_frames(w, h, n, seed, kind):
+            assert not cc.compare(cc.run_oracle(oracle, model, w, h, f), cc.run_hostsim(hostsim.lib, model, w, h, f)), (clip, cab)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip", mg.ENCODER_CLIPS_FAST, ids=lambda c: f"{c[0]}x{c[1]}-{c[4]}-qp{c[5]}")
+def test_hip_fast_preset_reproduces_reference_encoder(oracle, clip):
+    """the product on the MI355X with search_32x32: CTU pass, deblocking, SAO == `kvazaar --preset fast -p 1`, stage by stage; first frame also output by output against the oracle"""
+    import kvazaar_amd
+    from kvazaar_amd.batch import HipBatch, cost_model
+    lib = kvazaar_amd.load_library()
+    w, h, n, seed, kind, qp = clip
+    model = _fast_model(cost_model(lib, qp))
+    frames = cc.yuv_frames(w, h, n, seed, kind)
+    b = HipBatch(lib, w, h, n)
+    try:
+        for i, f in enumerate(frames):
+            b.upload(i, f)
+        b.run(model)
+        outs = [b.download(i) for i in range(n)]
+        assert [_sha(o["rec"]) for o in outs] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0) + "/fast"]
+        if w * h <= 832 * 480:
+            assert not cc.compare(cc.run_oracle(oracle, _fast_model(oracle_model(oracle, qp)), w, h, frames[0]), outs[0])
+        b.loop_filters(model, deblock=True, sao=True)
+        assert [_sha(b.download(i)["rec"]) for i in range(n)] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 1) + "/fast/sao"]
+    finally:
+        b.close()
