@@ -15,6 +15,7 @@
  * are not modified; enabled at run time by KVZ_HIP_BATCH_SEARCH=1.
  */
 #include <pthread.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -36,18 +37,32 @@ typedef struct {
   const videoframe_t *frame;  /* key: the (tile) frame and the picture it holds */
   int32_t num;
   int width, height, qp;
-  uint8_t *rec, *depth, *mode; /* tight planes Y|U|V; one byte per 8x8 */
+  uint8_t *src;                /* the source picture as tight planes Y|U|V (pinned), filled by the thread that registered the picture */
+  uint8_t *rec, *depth, *mode; /* tight planes Y|U|V; one byte per 8x8 (pinned) */
   int16_t *coeff;              /* KVZ_HIP_CTU_COEFFS per LCU, raster LCU order */
+  kvz_hip_intra_cost_model model;
+  int state;                   /* FREE -> PENDING (registered, waiting for a pass) -> COMPUTING (in the leader's batch) -> READY */
   int outstanding;             /* LCUs of the picture that have not copied their part yet; the slot is only reused at 0 (under g_lock) */
 } picture_result;
+enum { SLOT_FREE = 0, SLOT_PENDING, SLOT_COMPUTING, SLOT_READY };
 
 /* One slot per picture in flight: (owf + 1) x tiles of them at most, so the table grows on demand and a slot is never recycled
- * while an LCU of its picture is still to come (every LCU of a picture passes through kvz_search_lcu exactly once). */
+ * while an LCU of its picture is still to come (every LCU of a picture passes through kvz_search_lcu exactly once).
+ *
+ * Frame batching.  With --owf N kvazaar has N + 1 pictures in flight, and the first LCU of each of them asks for its picture's results at about
+ * the same time.  The device pass is a latency machine (a lone 1080p picture takes ~75 ms, sixty-four of them ~100 ms), so pictures are
+ * gathered: the thread that finds no pass running becomes the leader, waits a short window (KVZ_HIP_BATCH_WINDOW_US, default 3000) for the
+ * other pictures to register, runs ONE kvz_hip_intra_frames over everything pending with the same geometry and model (up to
+ * KVZ_HIP_BATCH_MAX, default 64), and wakes the rest.  Pictures that register while a pass runs form the next batch. */
 static picture_result **g_slots;
 static int g_n_slots;
-static kvz_hip_batch *g_batch;
-static int g_batch_w, g_batch_h;
 static pthread_mutex_t g_lock = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_cond = PTHREAD_COND_INITIALIZER;
+static int g_leader_active;
+#define N_BATCH_SIZES 4
+static const int g_batch_sizes[N_BATCH_SIZES] = { 1, 4, 16, 64 };
+static kvz_hip_batch *g_batches[N_BATCH_SIZES];  /* one batch per capacity, created on first use; all of the geometry g_batch_w x g_batch_h */
+static int g_batch_w, g_batch_h;
 
 /* 1 when the picture can be searched by the batched pass: every option below changes the search in a way the pass does not model */
 static int eligible(const encoder_state_t *state)
@@ -71,67 +86,117 @@ static int eligible(const encoder_state_t *state)
   return 1;
 }
 
-/* the picture's results, computed on first request */
+static int env_int(const char *name, int dflt)
+{
+  const char *e = getenv(name);
+  return e && atoi(e) > 0 ? atoi(e) : dflt;
+}
+
+/* the leader's work: one pass over `n` gathered pictures (same geometry and model) */
+static void run_pictures(picture_result **list, int n)
+{
+  const int w = list[0]->width, h = list[0]->height;
+  const size_t ys = (size_t)w * h, cs = ys / 4;
+  if (g_batch_w != w || g_batch_h != h) {
+    for (int i = 0; i < N_BATCH_SIZES; i++) if (g_batches[i]) { kvz_hip_batch_destroy(g_batches[i]); g_batches[i] = NULL; }
+    g_batch_w = w; g_batch_h = h;
+  }
+  int bi = 0;
+  while (g_batch_sizes[bi] < n) bi++;
+  if (!g_batches[bi]) {
+    g_batches[bi] = kvz_hip_batch_create(w, h, g_batch_sizes[bi]);
+    if (!g_batches[bi]) { fprintf(stderr, "search_lcu_hip: cannot create a %dx%d batch of %d pictures\n", w, h, g_batch_sizes[bi]); abort(); }
+  }
+  kvz_hip_batch *b = g_batches[bi];
+  /* slots beyond n keep whatever picture they held last: searched again, never read */
+  for (int i = 0; i < n; i++) kvz_hip_batch_upload(b, i, list[i]->src, list[i]->src + ys, list[i]->src + ys + cs);
+  kvz_hip_intra_frames(b, &list[0]->model);
+  /* the library reports an invalid run instead of aborting; this binding has no other search to fall back to for pictures whose
+   * LCUs are already being handed out, so it stops the encoder */
+  int bad = kvz_hip_batch_sync(b) != 0;
+  for (int i = 0; i < n && !bad; i++)
+    bad = kvz_hip_batch_download(b, i, list[i]->rec, list[i]->rec + ys, list[i]->rec + ys + cs, list[i]->coeff, list[i]->depth, list[i]->mode, NULL) != 0;
+  if (bad) { fprintf(stderr, "search_lcu_hip: the device pass failed\n"); abort(); }
+  {  /* KVZ_HIP_BATCH_TRACE=<file>: "pictures passes largest-batch" so far (tests check the path was taken, and that pictures were gathered) */
+    static int pictures, passes, largest;
+    const char *trace = getenv("KVZ_HIP_BATCH_TRACE");
+    pictures += n; passes++;
+    if (n > largest) largest = n;
+    if (trace) { FILE *f = fopen(trace, "w"); if (f) { fprintf(f, "%d %d %d\n", pictures, passes, largest); fclose(f); } }
+  }
+}
+
+/* the picture's results: registered on first request, computed with whatever else is pending */
 static picture_result *picture_of(const encoder_state_t *state)
 {
   const videoframe_t *frame = state->tile->frame;
   pthread_mutex_lock(&g_lock);
   picture_result *r = NULL;
-  for (int i = 0; i < g_n_slots; i++)
-    if (g_slots[i]->outstanding > 0 && g_slots[i]->frame == frame && g_slots[i]->num == state->frame->num) { pthread_mutex_unlock(&g_lock); return g_slots[i]; }
   for (int i = 0; i < g_n_slots && !r; i++)
-    if (g_slots[i]->outstanding == 0) r = g_slots[i];
+    if (g_slots[i]->outstanding > 0 && g_slots[i]->frame == frame && g_slots[i]->num == state->frame->num) r = g_slots[i];
   if (!r) {
-    g_slots = realloc(g_slots, (size_t)(g_n_slots + 1) * sizeof *g_slots);
-    r = g_slots[g_n_slots++] = calloc(1, sizeof *r);
+    for (int i = 0; i < g_n_slots && !r; i++)
+      if (g_slots[i]->outstanding == 0) r = g_slots[i];
+    if (!r) {
+      g_slots = realloc(g_slots, (size_t)(g_n_slots + 1) * sizeof *g_slots);
+      r = g_slots[g_n_slots++] = calloc(1, sizeof *r);
+    }
+    const int w = frame->width, h = frame->height, wc = (w + 63) / 64, hc = (h + 63) / 64;
+    const size_t ys = (size_t)w * h, cs = ys / 4;
+    if (r->width != w || r->height != h) {  /* pinned: the transfers of a 64-picture batch are 800 MB */
+      kvz_hip_host_free(r->src); kvz_hip_host_free(r->rec); kvz_hip_host_free(r->depth); kvz_hip_host_free(r->mode); kvz_hip_host_free(r->coeff);
+      r->src = kvz_hip_host_alloc(ys + 2 * cs);
+      r->rec = kvz_hip_host_alloc(ys + 2 * cs);
+      r->depth = kvz_hip_host_alloc((size_t)(w / 8) * (h / 8));
+      r->mode = kvz_hip_host_alloc((size_t)(w / 8) * (h / 8));
+      r->coeff = kvz_hip_host_alloc((size_t)wc * hc * KVZ_HIP_CTU_COEFFS * sizeof(int16_t));
+      r->width = w; r->height = h;
+    }
+    r->frame = frame; r->num = state->frame->num; r->qp = state->qp;
+    r->outstanding = wc * hc;
+    r->state = SLOT_PENDING;
+    const kvz_config *cfg = &state->encoder_control->cfg;
+    kvz_hip_intra_cost_model_init(state->qp, kvz_fast_coeff_get_weights(state), &r->model);
+    r->model.coeff_cabac = !(state->qp < cfg->fast_residual_cost_limit && state->qp < MAX_FAST_COEFF_COST_QP);  /* rdo.c:311-340 */
+    r->model.search_32x32 = cfg->pu_depth_intra.min[0] == 1;  /* 32x32 CUs are searched, not only merged (search.c:794) */
+    r->model.no_wpp = !cfg->wpp;  /* kvazaar switches WPP off when tiles are used (cfg.c:925-978) */
+    /* kvz_picture planes carry a stride; the batch takes tight planes.  (Outside the lock: only this thread knows the slot is being filled --
+     * nobody gathers a slot before it is PENDING ... so mark it pending only afterwards.) */
+    r->state = SLOT_FREE;
+    pthread_mutex_unlock(&g_lock);
+    const kvz_picture *pic = frame->source;
+    for (int row = 0; row < h; row++) memcpy(r->src + (size_t)row * w, pic->y + (size_t)row * pic->stride, w);
+    for (int row = 0; row < h / 2; row++) {
+      memcpy(r->src + ys + (size_t)row * (w / 2), pic->u + (size_t)row * (pic->stride / 2), w / 2);
+      memcpy(r->src + ys + cs + (size_t)row * (w / 2), pic->v + (size_t)row * (pic->stride / 2), w / 2);
+    }
+    pthread_mutex_lock(&g_lock);
+    r->state = SLOT_PENDING;
   }
-  const int w = frame->width, h = frame->height, wc = (w + 63) / 64, hc = (h + 63) / 64;
-  const size_t ys = (size_t)w * h, cs = ys / 4;
-  if (r->width != w || r->height != h) {
-    free(r->rec); free(r->depth); free(r->mode); free(r->coeff);
-    r->rec = malloc(ys + 2 * cs);
-    r->depth = malloc((size_t)(w / 8) * (h / 8));
-    r->mode = malloc((size_t)(w / 8) * (h / 8));
-    r->coeff = malloc((size_t)wc * hc * KVZ_HIP_CTU_COEFFS * sizeof(int16_t));
-    r->width = w; r->height = h;
-  }
-  if (!g_batch || g_batch_w != w || g_batch_h != h) {
-    if (g_batch) kvz_hip_batch_destroy(g_batch);
-    g_batch = kvz_hip_batch_create(w, h, 1);
-    g_batch_w = w; g_batch_h = h;
-    if (!g_batch) { fprintf(stderr, "search_lcu_hip: cannot create a %dx%d batch\n", w, h); abort(); }
-  }
-  /* kvz_picture planes carry a stride; the batch takes tight planes */
-  uint8_t *src = malloc(ys + 2 * cs);
-  const kvz_picture *pic = frame->source;
-  for (int row = 0; row < h; row++) memcpy(src + (size_t)row * w, pic->y + (size_t)row * pic->stride, w);
-  for (int row = 0; row < h / 2; row++) {
-    memcpy(src + ys + (size_t)row * (w / 2), pic->u + (size_t)row * (pic->stride / 2), w / 2);
-    memcpy(src + ys + cs + (size_t)row * (w / 2), pic->v + (size_t)row * (pic->stride / 2), w / 2);
-  }
-  kvz_hip_intra_cost_model model;
-  kvz_hip_intra_cost_model_init(state->qp, kvz_fast_coeff_get_weights(state), &model);
-  const kvz_config *cfg = &state->encoder_control->cfg;
-  model.coeff_cabac = !(state->qp < cfg->fast_residual_cost_limit && state->qp < MAX_FAST_COEFF_COST_QP);  /* rdo.c:311-340 */
-  model.search_32x32 = cfg->pu_depth_intra.min[0] == 1;  /* 32x32 CUs are searched, not only merged (search.c:794) */
-  model.no_wpp = !cfg->wpp;  /* kvazaar switches WPP off when tiles are used (cfg.c:925-978) */
-  kvz_hip_batch_upload(g_batch, 0, src, src + ys, src + ys + cs);
-  kvz_hip_intra_frames(g_batch, &model);
-  /* the library reports an invalid run instead of aborting; this binding has no other search to fall back to for a picture whose
-   * LCUs are already being handed out, so it stops the encoder */
-  if (kvz_hip_batch_sync(g_batch) != 0 ||
-      kvz_hip_batch_download(g_batch, 0, r->rec, r->rec + ys, r->rec + ys + cs, r->coeff, r->depth, r->mode, NULL) != 0) {
-    fprintf(stderr, "search_lcu_hip: the device pass failed for picture %d\n", (int)state->frame->num);
-    abort();
-  }
-  free(src);
-  r->frame = frame; r->num = state->frame->num; r->qp = state->qp;
-  r->outstanding = wc * hc;
-  {  /* KVZ_HIP_BATCH_TRACE=<file>: number of pictures searched on the device so far (tests check the path was taken) */
-    static int pictures;
-    const char *trace = getenv("KVZ_HIP_BATCH_TRACE");
-    pictures++;
-    if (trace) { FILE *f = fopen(trace, "w"); if (f) { fprintf(f, "%d\n", pictures); fclose(f); } }
+  while (r->state != SLOT_READY) {
+    if (r->state == SLOT_PENDING && !g_leader_active) {
+      g_leader_active = 1;
+      pthread_mutex_unlock(&g_lock);
+      usleep((useconds_t)env_int("KVZ_HIP_BATCH_WINDOW_US", 3000));  /* the gather window */
+      pthread_mutex_lock(&g_lock);
+      const int max_n = env_int("KVZ_HIP_BATCH_MAX", 64) < 64 ? env_int("KVZ_HIP_BATCH_MAX", 64) : 64;
+      picture_result *list[64];
+      int n = 0;
+      list[n++] = r;
+      r->state = SLOT_COMPUTING;
+      for (int i = 0; i < g_n_slots && n < max_n; i++) {
+        picture_result *o = g_slots[i];
+        if (o->state == SLOT_PENDING && o->width == r->width && o->height == r->height && memcmp(&o->model, &r->model, sizeof o->model) == 0) { o->state = SLOT_COMPUTING; list[n++] = o; }
+      }
+      pthread_mutex_unlock(&g_lock);
+      run_pictures(list, n);
+      pthread_mutex_lock(&g_lock);
+      for (int i = 0; i < n; i++) list[i]->state = SLOT_READY;
+      g_leader_active = 0;
+      pthread_cond_broadcast(&g_cond);
+    } else {
+      pthread_cond_wait(&g_cond, &g_lock);
+    }
   }
   pthread_mutex_unlock(&g_lock);
   return r;

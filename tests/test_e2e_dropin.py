@@ -80,7 +80,7 @@ def test_batched_search_bitstream_identical(tmp_path, frames, extra):
     md5_batch, t, _ = _encode("kvazaar_hip", yuv, str(tmp_path / "batch.hevc"), common, {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1", "KVZ_HIP_BATCH_TRACE": str(tmp_path / "trace")})
     assert md5_plain == md5_ref
     assert md5_batch == md5_ref
-    assert int(open(str(tmp_path / "trace")).read()) >= frames, "the batched search was not used"
+    assert int(open(str(tmp_path / "trace")).read().split()[0]) >= frames, "the batched search was not used"
 
 
 @pytest.mark.parametrize("preset,extra", [("superfast", ["-q", "22"]), ("veryfast", ["-q", "32"]), ("faster", ["-q", "22"]), ("faster", ["-q", "37", "--no-wpp"]),
@@ -97,7 +97,22 @@ def test_batched_search_other_all_intra_presets(tmp_path, preset, extra):
     md5_ref, _, _ = _encode("kvazaar_ref", yuv, str(tmp_path / "ref.hevc"), common)
     md5_batch, t, _ = _encode("kvazaar_hip", yuv, str(tmp_path / "batch.hevc"), common, {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1", "KVZ_HIP_BATCH_TRACE": str(tmp_path / "trace")})
     assert md5_batch == md5_ref
-    assert int(open(str(tmp_path / "trace")).read()) >= 2, "the batched search was not used"
+    assert int(open(str(tmp_path / "trace")).read().split()[0]) >= 2, "the batched search was not used"
+
+
+def test_batched_search_gathers_pictures_in_flight(tmp_path):
+    """--owf 7: eight pictures in flight ask for their results at about the same time; the binding gathers them into ONE device pass per group
+    (search_lcu_hip.c "frame batching") and the bitstream is still the reference's"""
+    _need_hip_encoder()
+    yuv = str(tmp_path / "syn.yuv")
+    synth.write_yuv(yuv, 416, 240, 16, 1234, "small")
+    common = ["--preset", "ultrafast", "-p", "1", "--threads", "8", "--owf", "7"]
+    md5_ref, _, _ = _encode("kvazaar_ref", yuv, str(tmp_path / "ref.hevc"), common)
+    md5_batch, _, _ = _encode("kvazaar_hip", yuv, str(tmp_path / "batch.hevc"), common,
+                              {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1", "KVZ_HIP_BATCH_TRACE": str(tmp_path / "trace"), "KVZ_HIP_BATCH_WINDOW_US": "20000"})
+    assert md5_batch == md5_ref
+    pictures, passes, largest = (int(v) for v in open(str(tmp_path / "trace")).read().split())
+    assert pictures == 16 and passes < 16 and largest > 1, (pictures, passes, largest)
 
 
 def test_batched_search_golden_md5_416x240(tmp_path):

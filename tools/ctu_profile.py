@@ -13,9 +13,11 @@ NAMES = ["init", "refs", "pred35", "satd", "select", "recon_pred", "fdct", "quan
 
 
 def main():
-    out = os.path.join(ROOT, "gpurun_out", "libkvz_hip_prof.so")
+    out = os.path.join(ROOT, "kvazaar_amd", "lib", "variants", "libkvz_hip_prof.so")  # built ahead (cross-compiles without a GPU) or on the box
     os.makedirs(os.path.dirname(out), exist_ok=True)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+    srcs = [os.path.join(ROOT, "kvazaar_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "kvazaar_amd", "csrc"))]
+    if not os.path.exists(out) or any(os.path.getmtime(f) > os.path.getmtime(out) for f in srcs):
+      subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                            "-DKVZ_CTU_PROFILE", *os.environ.get("KVZ_PROFILE_FLAGS", "").split(), "-o", out, os.path.join(ROOT, "kvazaar_amd", "csrc", "kvz_hip.hip")])
     import numpy as np
     import ctu_common as cc
@@ -23,6 +25,10 @@ def main():
     lib = C.CDLL(out)
     qp = int(os.environ.get("KVZ_PROFILE_QP", "22"))
     model = cc.hip_cost_model(lib, qp, cc.coeff_weights(qp))
+    if os.environ.get("KVZ_PROFILE_CABAC"):   # fast-residual-cost 0 (presets faster and up)
+        model.coeff_cabac = 1
+    if os.environ.get("KVZ_PROFILE_S32"):     # --pu-depth-intra 1-3 (preset fast)
+        model.search_32x32 = 1
     frames = bench.synth_frames(1920, 1080, 4, 1)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     b = cc.HipBatch(lib, 1920, 1080, n)
