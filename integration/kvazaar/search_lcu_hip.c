@@ -51,8 +51,8 @@ enum { SLOT_FREE = 0, SLOT_PENDING, SLOT_COMPUTING, SLOT_READY };
  *
  * Frame batching.  With --owf N kvazaar has N + 1 pictures in flight, and the first LCU of each of them asks for its picture's results at about
  * the same time.  The device pass is a latency machine (a lone 1080p picture takes ~75 ms, sixty-four of them ~100 ms), so pictures are
- * gathered: the thread that finds no pass running becomes the leader, waits a short window (KVZ_HIP_BATCH_WINDOW_US, default 3000) for the
- * other pictures to register, runs ONE kvz_hip_intra_frames over everything pending with the same geometry and model (up to
+ * gathered: the thread that finds no pass running becomes the leader, waits until half of the pictures in flight have registered (at most
+ * KVZ_HIP_BATCH_WINDOW_US, default 40 ms), runs ONE kvz_hip_intra_frames over everything pending with the same geometry and model (up to
  * KVZ_HIP_BATCH_MAX, default 64), and wakes the rest.  Pictures that register while a pass runs form the next batch. */
 static picture_result **g_slots;
 static int g_n_slots;
@@ -177,9 +177,19 @@ static picture_result *picture_of(const encoder_state_t *state)
     if (r->state == SLOT_PENDING && !g_leader_active) {
       g_leader_active = 1;
       pthread_mutex_unlock(&g_lock);
-      usleep((useconds_t)env_int("KVZ_HIP_BATCH_WINDOW_US", 3000));  /* the gather window */
-      pthread_mutex_lock(&g_lock);
+      /* the gather window: until half of the pictures kvazaar keeps in flight (--owf + 1) are pending -- the other half is then being entropy-coded
+       * on the host while this pass runs -- but never longer than KVZ_HIP_BATCH_WINDOW_US (default 40 ms, half a lone picture's pass) */
       const int max_n = env_int("KVZ_HIP_BATCH_MAX", 64) < 64 ? env_int("KVZ_HIP_BATCH_MAX", 64) : 64;
+      const int in_flight = state->encoder_control->cfg.owf + 1, want = in_flight / 2 < max_n ? (in_flight / 2 > 0 ? in_flight / 2 : 1) : max_n;
+      const int window_us = env_int("KVZ_HIP_BATCH_WINDOW_US", 40000);
+      for (int waited = 0;; waited += 500) {
+        pthread_mutex_lock(&g_lock);
+        int pending = 0;
+        for (int i = 0; i < g_n_slots; i++) pending += g_slots[i]->state == SLOT_PENDING;
+        if (pending >= want || waited >= window_us) break;  /* leaves with the lock held */
+        pthread_mutex_unlock(&g_lock);
+        usleep(500);
+      }
       picture_result *list[64];
       int n = 0;
       list[n++] = r;

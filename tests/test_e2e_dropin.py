@@ -109,7 +109,7 @@ def test_batched_search_gathers_pictures_in_flight(tmp_path):
     common = ["--preset", "ultrafast", "-p", "1", "--threads", "8", "--owf", "7"]
     md5_ref, _, _ = _encode("kvazaar_ref", yuv, str(tmp_path / "ref.hevc"), common)
     md5_batch, _, _ = _encode("kvazaar_hip", yuv, str(tmp_path / "batch.hevc"), common,
-                              {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1", "KVZ_HIP_BATCH_TRACE": str(tmp_path / "trace"), "KVZ_HIP_BATCH_WINDOW_US": "20000"})
+                              {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1", "KVZ_HIP_BATCH_TRACE": str(tmp_path / "trace"), "KVZ_HIP_BATCH_WINDOW_US": "40000"})
     assert md5_batch == md5_ref
     pictures, passes, largest = (int(v) for v in open(str(tmp_path / "trace")).read().split())
     assert pictures == 16 and passes < 16 and largest > 1, (pictures, passes, largest)
