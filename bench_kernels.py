@@ -98,7 +98,10 @@ def main():
         refs = rng.integers(0, 256, (2, count, 2 * w + 1), dtype=np.uint8)
         da, dl, do = dev.put(refs[0]), dev.put(refs[1]), dev.empty(count * w * w)
         ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_angular_pred(log2w, 7, da, dl, count, do), args.reps, args.warmup)
-        report(f"angular_{w}x{w}", w, count, ms, (4 * w + 2) + w * w)
+        report(f"angular_{w}x{w}", w, count, ms, (4 * w + 2) + w * w, {"mode": 7, "path": "horizontal (transposed on the way out), positive angle"})
+        for mode, path in ((30, "vertical, positive angle"), (22, "vertical, negative angle (projected side reference)"), (14, "horizontal, negative angle")):
+            ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_angular_pred(log2w, mode, da, dl, count, do), args.reps, args.warmup)
+            report(f"angular_{w}x{w}_mode{mode}", w, count, ms, (4 * w + 2) + w * w, {"mode": mode, "path": path})
         dev.free(da, dl, do)
 
     # deblocking of whole 1080p frames (kvz_hip_dev_deblock_frames): every sample is read and (for the filtered ones) written once
@@ -128,8 +131,18 @@ def main():
     dev.lib.kvz_hip_dev_sao_frames.restype = None
     dev.lib.kvz_hip_dev_sao_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_sao_frames(din, dout2, w, h, nfr, dl, dch), args.reps, args.warmup)
-    report("sao_1080p_frame", 0, nfr, ms, 2 * (w * h * 3 // 2), {"path": "one lane per 4 samples, per-CTU parameter records", "fps": round(nfr / (ms * 1e-3))})
-    dev.free(dl, dch, din, dout2)
+    report("sao_1080p_frame", 0, nfr, ms, 2 * (w * h * 3 // 2), {"path": "one workgroup per CTU, 4 samples per lane in packed 16-bit halves; random per-CTU parameters (1/4 none, 1/4 band, 1/2 edge)", "fps": round(nfr / (ms * 1e-3))})
+    dev.free(dl, dch)
+    for name, typ, cls in (("none", 0, 0), ("band", 1, 0), ("edge_class0", 2, 0), ("edge_class1", 2, 1), ("edge_class2", 2, 2)):
+        for arr in (lum, chr_):
+            for q in arr:
+                q.type, q.eo_class = typ, cls
+        dl = dev.put(np.tile(np.frombuffer(bytes(lum), dtype=np.uint8), nfr))
+        dch = dev.put(np.tile(np.frombuffer(bytes(chr_), dtype=np.uint8), nfr))
+        ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_sao_frames(din, dout2, w, h, nfr, dl, dch), args.reps, args.warmup)
+        report(f"sao_1080p_frame_{name}", 0, nfr, ms, 2 * (w * h * 3 // 2), {"path": f"every CTU {name}", "fps": round(nfr / (ms * 1e-3))})
+        dev.free(dl, dch)
+    dev.free(din, dout2)
 
     # motion cost surface: every 16x16 block of a 1080p picture, +-16 full search (1089 candidates per block)
     bw, rng_ = 16, 16

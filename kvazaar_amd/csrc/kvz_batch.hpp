@@ -77,14 +77,16 @@ template <bool CABAC, bool S32 = false> __global__ void __launch_bounds__(KVZ_CT
 {
   __shared__ CtuSharedT<CABAC> shared;
   __shared__ CtuModel m;  // scalars in LDS; its price table stays in HBM (kvz_hip_batch::d_entropy)
-  __shared__ unsigned s_ticket;
+  // The ticket is broadcast through a field of `shared` that is dead between two CTUs: with the CABAC contexts the block is exactly 20 480 B,
+  // and one more word would cost the eighth workgroup per CU (160 KB of LDS).
+  static_assert(sizeof(CtuSharedT<CABAC>) + sizeof(CtuModel) <= 20480, "eight workgroups per CU");
   if (threadIdx.x == 0) m = model;
   const int ctus = F.wc * F.hc;
   for (;;) {
     __syncthreads();  // previous item fully retired (and m visible on the first trip)
-    if (threadIdx.x == 0) s_ticket = atomicAdd(sched.ticket, 1u);
+    if (threadIdx.x == 0) shared.best_mode = (int)atomicAdd(sched.ticket, 1u);
     __syncthreads();
-    const unsigned t = s_ticket;
+    const unsigned t = (unsigned)shared.best_mode;
     if (t >= sched.total) break;
     const uint32_t item = sched.items[t];
     const int frame = item >> 16, y = (item >> 8) & 0xff, x = item & 0xff;

@@ -236,7 +236,7 @@ template <bool CABAC> struct CtuSharedT {
 #ifdef KVZ_HOSTSIM
   i16 dct32[32 * 32];        // HEVC core transform matrix; the 16/8/4-point matrices are its rows 2k/4k/8k (dct-generic.c:46-120)
 #else
-  i16 dct_small[64 + 16];    // the 8- and 4-point matrices: larger transforms run on the matrix cores from Tables::dct_h
+  i16 dct_small[64 + 16];    // the 8- and 4-point matrices: larger transforms run on the matrix cores from Tables::dct_i8
 #endif
   u8 dcval[3];               // DC value of the current references per plane
   int8_t mode_disp[35];      // angular parameters per mode (intra-generic.c:59-60, 70-76): signed sample displacement,
@@ -1271,8 +1271,8 @@ template <bool CABAC, bool S32 = false> struct CtuProgramT {
   {
 #ifndef KVZ_HOSTSIM
     if ((tid >> 6) != c % (KVZ_CTU_THREADS / 64)) return;
-    if (l2 == 5) mfma_transform_block<32>(x, x, inverse, tb->dct_h[1][0], tb->dct_h[1][1], tid & 63);
-    else mfma_transform_block<16>(x, x, inverse, tb->dct_h[0][0], tb->dct_h[0][1], tid & 63);
+    if (l2 == 5) mfma_transform_block<32>(x, x, inverse, tb, tid & 63);
+    else mfma_transform_block<16>(x, x, inverse, tb, tid & 63);
 #else
     if (tid != 0) return;
     const int n = 1 << l2;

@@ -119,13 +119,12 @@ __global__ void __launch_bounds__(256) dev_satd4_kernel(const u8 *a, const u8 *b
 
 // ---------------------------------------------------------------------------------------------------------------
 // 16- and 32-point DCT / IDCT on the matrix cores: one wavefront per block, both passes chained through registers.
-// With T the transform matrix (Tables::dct_h, exact in binary16) and X the n x n input:
+// With T the transform matrix (Tables::dct_i8, signed bytes) and X the n x n input:
 //   forward: D0^T = X T^T, K = T D0^T   -> out = K       (dct-generic.c partial_butterfly_*, intermediate wraps to int16)
 //   inverse: U = X^T T,    O = U^T T    -> out = O       (partial_butterfly_inverse_*, both stages clip to int16)
 // The accumulator layout of v_mfma (lane = column, registers = 4 consecutive rows per k-step) is the B operand layout of
 // the next product and, read as A, the transposed matrix, so the first result feeds the second product directly.
-// Exactness: 16-bit operands are split x = 256 (x >> 8) + (x & 255); every operand is then an integer binary16 holds
-// exactly, products are exact in binary32 and all partial sums stay below 32 * 90 * 255 < 2^24.
+// Exactness: int8 operands, int32 accumulators (kvz_mfma.hpp): 16-bit values go in as a signed high and a biased low byte plane.
 // Memory side: a wavefront moves its block between HBM and LDS with 16-byte accesses (2 KB per 32x32 block = two dwordx4 per lane) and feeds the
 // matrix cores from LDS -- the operand layouts want 2-byte column gathers (inverse input) and 2-byte row scatters (every output), which cost
 // 16 narrow global accesses per lane when done against HBM directly.
@@ -142,7 +141,7 @@ template <int N> __global__ void __launch_bounds__(256) dev_transform_mfma_kerne
     else reinterpret_cast<uint2 *>(sb)[lane] = reinterpret_cast<const uint2 *>(in + blk * (N * N))[lane];
   }
   __syncthreads();
-  if (have) mfma_transform_block<N>(sb, sb, inverse != 0, tb->dct_h[L2 - 4][0], tb->dct_h[L2 - 4][1], lane);
+  if (have) mfma_transform_block<N>(sb, sb, inverse != 0, tb, lane);
   __syncthreads();
   if (have) {
     if (N == 32) { uint4 *dst = reinterpret_cast<uint4 *>(out + blk * (N * N)); for (int k = 0; k < (VEC ? VEC : 1); k++) dst[k * 64 + lane] = reinterpret_cast<const uint4 *>(sb)[k * 64 + lane]; }
@@ -151,9 +150,9 @@ template <int N> __global__ void __launch_bounds__(256) dev_transform_mfma_kerne
 }
 
 // 4- and 8-point transforms (and the 4x4 DST): 16 / n blocks sit on the diagonal of one 16x16 problem, the matrix is the
-// matching block-diagonal one (Tables::bd_h), everything else as above.  Off-diagonal results are exact zeros and never stored.
+// matching block-diagonal one (Tables::bd_i8), everything else as above.  Off-diagonal results are exact zeros and never stored.
 template <int NB /* block size: 4 or 8 */> __global__ void __launch_bounds__(256)
-dev_transform_small_mfma_kernel(const i16 *in, i16 *out, const int count, const int inverse, const u16 *T, const u16 *Tt)
+dev_transform_small_mfma_kernel(const i16 *in, i16 *out, const int count, const int inverse, const int8_t *T, const int8_t *Tt, const i32 *sT, const i32 *sTt)
 {
   typedef DevMma<16> M;
   constexpr int L2 = NB == 4 ? 2 : 3, G = 16 / NB;
@@ -171,15 +170,15 @@ dev_transform_small_mfma_kernel(const i16 *in, i16 *out, const int count, const 
     v[i] = (have && diag) ? (int)(inverse ? x[kk * NB + cc] : x[cc * NB + kk]) : 0;
   }
   if (!inverse) {
-    dev_product<16>(v, T, false, lane, t);
-    { const int shift = L2 - 1, add = 1 << (shift - 1); for (int r = 0; r < 4; r++) v[r] = (int)(i16)((t[r] + add) >> shift); }
-    dev_product<16>(v, T, true, lane, t);
-    { const int shift = L2 + 6, add = 1 << (shift - 1); for (int r = 0; r < 4; r++) v[r] = (int)(i16)((t[r] + add) >> shift); }
+    dev_product<16>(v, T, sT, false, lane, 1 << (L2 - 2), t);
+    for (int r = 0; r < 4; r++) v[r] = t[r] >> (L2 - 1);
+    dev_product<16>(v, T, sT, true, lane, 1 << (L2 + 5), t);
+    for (int r = 0; r < 4; r++) v[r] = t[r] >> (L2 + 6);
   } else {
-    dev_product<16>(v, Tt, false, lane, t);
-    for (int r = 0; r < 4; r++) v[r] = iclip(-32768, 32767, (t[r] + 64) >> 7);
-    dev_product<16>(v, Tt, false, lane, t);
-    for (int r = 0; r < 4; r++) v[r] = iclip(-32768, 32767, (t[r] + 2048) >> 12);
+    dev_product<16>(v, Tt, sTt, false, lane, 64, t);
+    for (int r = 0; r < 4; r++) v[r] = iclip(-32768, 32767, t[r] >> 7);
+    dev_product<16>(v, Tt, sTt, false, lane, 2048, t);
+    for (int r = 0; r < 4; r++) v[r] = iclip(-32768, 32767, t[r] >> 12);
   }
   for (int r = 0; r < 4; r++) {
     const int row = M::row(lane, r);
@@ -188,24 +187,87 @@ dev_transform_small_mfma_kernel(const i16 *in, i16 *out, const int count, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Angular prediction of a batch of blocks with one mode (intra-generic.c:49-155): a workgroup stages the reference rows of its
-// blocks in LDS (they are re-read by every lane of the block), then one lane produces four horizontally adjacent samples and
-// stores them as one dword, lane-contiguous in the output.
+// Angular prediction of a batch of blocks with one mode (intra-generic.c:49-155), row-wise: a lane produces groups of 4 horizontally
+// adjacent samples of the *vertical* problem -- for modes >= 18 that is the block itself, for modes < 18 the block with the references
+// swapped and the result transposed.  Along a row the displacement (delta_int, delta_fract) is one number, so a group needs 5 consecutive
+// bytes of the main reference: two aligned LDS dwords funnel-shifted into place, then the two-tap interpolation on two samples per 32-bit
+// multiply (the 16-bit halves cannot carry: (32 - f) a + f b + 16 <= 8176).  Horizontal modes: the four lanes of a quad hold the same four
+// columns of four consecutive rows; they exchange their dwords by DPP (quad_perm broadcasts), each picks one byte column (v_perm_b32) and
+// holds four horizontally adjacent samples of the transposed block, which go through an LDS tile as dwords to be stored lane-contiguously.
+// A workgroup stages the references of its blocks (one contiguous byte range per side, copied as dwords whatever its alignment); modes with
+// a negative angle first build each block's extended main reference ext[k + W] = ref_main[k], k = -W .. W, the negative indices projected
+// from the side reference (intra-generic.c:82-104); the others read the staged bytes directly.
+// Bytes per block: 2 (2 W + 1) read, W^2 written.
+constexpr int kAngularGroupsPerLane = 8;  // 2048 groups = 8 KB of output per workgroup: enough bytes in flight per barrier phase to cover the load latency
 template <int L2> __global__ void __launch_bounds__(256) dev_angular_kernel(const u8 *above, const u8 *left, const int count, const int mode, u8 *out)
 {
-  constexpr int W = 1 << L2, LANES = W * W / 4, BLOCKS = 256 / LANES, RS = 2 * W + 1, RP = (RS + 3) & ~3;
-  __shared__ u8 refs[BLOCKS][2][RP];
+  constexpr int W = 1 << L2, NG = kAngularGroupsPerLane, GPB = W * W / 4, BLOCKS = 256 * NG / GPB, RS = 2 * W + 1, ES = (2 * W + 1 + 8 + 3) & ~3;
+  constexpr int RAW = (BLOCKS * RS + 3 + 3) / 4 + 2;
+  __shared__ u32 s_raw[2][RAW];
+  __shared__ alignas(8) u8 s_ext[BLOCKS][ES];
+  __shared__ u32 s_tile[BLOCKS * W * W / 4];
+  const int disp_tab[9] = { 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+  const int inv_tab[9] = { 0, 4096, 1638, 910, 630, 482, 390, 315, 256 };
+  const bool vertical = mode >= 18;
+  const int mode_disp = vertical ? mode - 26 : 10 - mode, ad = iabs(mode_disp);
+  const int disp = mode_disp < 0 ? -disp_tab[ad] : disp_tab[ad], inv = inv_tab[ad];
   const long blk0 = (long)blockIdx.x * BLOCKS;
-  for (int i = threadIdx.x; i < BLOCKS * 2 * RS; i += 256) {
-    const int b = i / (2 * RS), r = i % (2 * RS), side = r / RS, k = r % RS;
-    if (blk0 + b < count) refs[b][side][k] = (side ? left : above)[(blk0 + b) * RS + k];
+  const int nblk = (int)(count - blk0 < BLOCKS ? count - blk0 : BLOCKS);
+  const long g0 = blk0 * RS;
+  const int mis = (int)(g0 & 3), ndw = (mis + nblk * RS + 3) >> 2;
+  const u8 *main_g = vertical ? above : left, *side_g = vertical ? left : above;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < ndw; i += 256) {
+    s_raw[0][i] = reinterpret_cast<const u32 *>(main_g + g0 - mis)[i];
+    if (disp < 0) s_raw[1][i] = reinterpret_cast<const u32 *>(side_g + g0 - mis)[i];
   }
   __syncthreads();
-  const int b = threadIdx.x / LANES, e = threadIdx.x % LANES, y = e / (W / 4), x = 4 * (e % (W / 4));
-  if (blk0 + b >= count) return;
-  u32 v = 0;
-  for (int k = 0; k < 4; k++) v |= (u32)angular_pixel(mode, x + k, y, refs[b][0], refs[b][1]) << (8 * k);
-  reinterpret_cast<u32 *>(out + (blk0 + b) * (W * W))[e] = v;
+  if (disp < 0) {
+    const int lowest = (W * disp) >> 5, span = W + 1 - lowest;  // indices lowest .. W in use
+    const u8 *rm = reinterpret_cast<const u8 *>(s_raw[0]) + mis, *rs = reinterpret_cast<const u8 *>(s_raw[1]) + mis;
+    for (int i = tid; i < nblk * span; i += 256) {
+      const int bb = i / span, k = i - bb * span + lowest;
+      s_ext[bb][k + W] = k >= -1 ? rm[bb * RS + k + 1] : rs[bb * RS + ((128 + (-1 - k) * inv) >> 8)];
+    }
+    __syncthreads();
+  }
+  u32 *out32 = reinterpret_cast<u32 *>(out + blk0 * (W * W));
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    const int vl = tid + 256 * g, b = vl / GPB, q = vl % GPB;
+    const int py = vertical ? q / (W / 4) : q % W, px = 4 * (vertical ? q % (W / 4) : q / W);
+    // ref_main[k] = base[bo + k], base 4-byte aligned
+    const u8 *base = disp < 0 ? &s_ext[b][0] : reinterpret_cast<const u8 *>(s_raw[0]);
+    const int bo = disp < 0 ? W : mis + b * RS + 1;
+    const int delta = (py + 1) * disp, di = delta >> 5;
+    const u32 f = (u32)(delta & 31), c = 32 - f;
+    const int j0 = bo + px + di, o = j0 & 3;
+    const u32 *src = reinterpret_cast<const u32 *>(base + (j0 & ~3));
+    const unsigned long long w = (((unsigned long long)src[1] << 32) | src[0]) >> (8 * o);
+    const u32 A = (u32)w, B = (u32)(w >> 8);  // samples k and k + 1
+    const u32 ev = (((A & 0x00ff00ffu) * c + (B & 0x00ff00ffu) * f + 0x00100010u) >> 5) & 0x00ff00ffu;
+    const u32 od = ((((A >> 8) & 0x00ff00ffu) * c + ((B >> 8) & 0x00ff00ffu) * f + 0x00100010u) >> 5) & 0x00ff00ffu;
+    const u32 res = ev | (od << 8);
+    if (vertical) {
+      if (b < nblk) out32[vl] = res;
+    } else {
+      // res = samples (px .. px + 3, py) of the vertical problem = out(x = py, y = px .. px + 3); the quad holds py & ~3 .. + 3
+      const int r = (int)res, i = tid & 3;
+      const u32 r0 = (u32)__builtin_amdgcn_update_dpp(0, r, 0x00, 0xf, 0xf, false), r1 = (u32)__builtin_amdgcn_update_dpp(0, r, 0x55, 0xf, 0xf, false);
+      const u32 r2 = (u32)__builtin_amdgcn_update_dpp(0, r, 0xaa, 0xf, 0xf, false), r3 = (u32)__builtin_amdgcn_update_dpp(0, r, 0xff, 0xf, 0xf, false);
+      const u32 sel = 0x0400u + (u32)i * 0x0101u;  // byte i of the low operand, byte i of the high one
+      const u32 t01 = __builtin_amdgcn_perm(r1, r0, sel), t23 = __builtin_amdgcn_perm(r3, r2, sel);
+      s_tile[(b * (W * W) + (px + i) * W + (py & ~3)) >> 2] = __builtin_amdgcn_perm(t23, t01, 0x05040100u);  // out(y = px + i, x = py & ~3 .. + 3)
+    }
+  }
+  if (!vertical) {
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+      const int vl = tid + 256 * g;
+      if (vl / GPB < nblk) out32[vl] = s_tile[vl];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -255,71 +317,105 @@ dev_sad_surface_kernel(const u8 *cur, const u8 *ref, const int W, const int H, c
 // Neighbours always come from `in` (the deblocked picture); samples whose neighbour would lie outside the picture keep their
 // value (sao.c:324-349).  One lane per 4 samples of a plane row: dword load of the centre, byte loads of the six outer
 // neighbours it does not already hold, dword store; one workgroup per plane row.
-// Per (frame, CTU, plane) parameter record packed into 8 bytes for the sample kernel: type | class | band position | offsets[0..4]
-__global__ void __launch_bounds__(256) dev_sao_pack_kernel(const kvz_hip_sao_params *luma, const kvz_hip_sao_params *chroma, const long n_ctus, unsigned long long *packed)
+// Per (frame, CTU, plane) parameter record in 8 bytes: type | class | band position | offsets[0..4]
+// One workgroup per CTU (blockIdx = CTU column | CTU row | frame), 16 (luma) or 8 (chroma) lanes across a block row.
+// Four samples per lane, two per 32-bit operation: the bytes of the centre dword and of the two neighbour
+// dwords (unaligned loads at the class's displacement) are spread over 16-bit halves (even / odd bytes), sign(c - n) + 1 = clamp(c + 1 - n, 0, 2)
+// is three packed instructions per neighbour and pair, and the category -> offset table of the CTU's record is applied to all four samples by
+// two v_perm_b32 (byte look-ups); band offsets use the same look-up on clamp(band - position + 1, 0, 5).
+__device__ __forceinline__ u32 load_u32_any(const u8 *p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }  // any byte alignment
+__device__ __forceinline__ u32 sao_add_offsets(u32 c4, u32 off4)  // clip(c + (int8)off) on four bytes
 {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= 3 * n_ctus) return;
-  const long ctu = i / 3;
-  const int color = (int)(i % 3), base = color == 2 ? 5 : 0;
-  const kvz_hip_sao_params *p = color ? &chroma[ctu] : &luma[ctu];
-  unsigned long long v = (unsigned long long)(p->type & 0xff) | ((unsigned long long)(p->eo_class & 0xff) << 8) |
-                         ((unsigned long long)(p->band_position[color == 2 ? 1 : 0] & 0xff) << 16);
-  for (int k = 0; k < 5; k++) v |= (unsigned long long)(u8)(int8_t)p->offsets[base + k] << (24 + 8 * k);
-  packed[i] = v;
+  const dev_pk16 ce = __builtin_bit_cast(dev_pk16, c4 & 0x00ff00ffu), co = __builtin_bit_cast(dev_pk16, (c4 >> 8) & 0x00ff00ffu);
+  const dev_pk16 oe = __builtin_bit_cast(dev_pk16, off4 << 8) >> 8, oo = __builtin_bit_cast(dev_pk16, off4) >> 8;  // sign-extended int8 per half (even: the cross-half bits shifted in are shifted out again)
+  const dev_pk16 lo = { 0, 0 }, hi = { 255, 255 };
+  const dev_pk16 re = __builtin_elementwise_min(__builtin_elementwise_max(ce + oe, lo), hi), ro = __builtin_elementwise_min(__builtin_elementwise_max(co + oo, lo), hi);
+  return __builtin_bit_cast(u32, re) | (__builtin_bit_cast(u32, ro) << 8);
 }
-// One workgroup per plane row (blockIdx.x = row of the frame's 2H plane rows: Y, then U, then V; blockIdx.y = frame), its lanes
-// striding over the row's dwords: no index arithmetic beyond a compare and a subtract per lane.
-__global__ void __launch_bounds__(256) dev_sao_kernel(const u8 *in, u8 *out, const int W, const int H, const unsigned long long *packed)
+__device__ __forceinline__ u32 sao_sign_idx(u32 c4, u32 a4, u32 b4)  // per byte: 2 + sign(c - a) + sign(c - b)
 {
-  const int frame = blockIdx.y, prow = blockIdx.x;
-  const int color = prow < H ? 0 : (prow < H + (H >> 1) ? 1 : 2);
-  const int y = prow - (color == 0 ? 0 : (color == 1 ? H : H + (H >> 1)));
-  const int sh = color ? 1 : 0, fw = W >> sh, fh = H >> sh, wd = fw >> 2;
-  const long plane = (long)frame * ((long)W * H * 3 / 2) + (color == 0 ? 0 : (color == 1 ? (long)W * H : (long)W * H * 5 / 4));
-  const u8 *src = in + plane;
-  const int wc = (W + 63) >> 6, lcu_shift = 6 - sh;
-  const unsigned long long *recs = packed + ((long)frame * wc * ((H + 63) >> 6) + (long)(y >> lcu_shift) * wc) * 3 + color;
-  const int ym = y > 0 ? y - 1 : y, yp = y + 1 < fh ? y + 1 : y;
-  const u8 *row_c_ptr = src + (long)y * fw, *row_u_ptr = src + (long)ym * fw, *row_d_ptr = src + (long)yp * fw;
-  for (int xd = threadIdx.x; xd < wd; xd += 256) {
-    const int x = 4 * xd;
-    const unsigned long long rec = recs[(x >> lcu_shift) * 3];  // 4 | CTU width: one CTU per dword
-    const u32 centre = *reinterpret_cast<const u32 *>(row_c_ptr + x);
-    const int type = (int)(rec & 0xff);
-    u32 result = centre;
-    if (type == 1) {
-      const int bp = (int)((rec >> 16) & 0xff);
-      result = 0;
-      for (int k = 0; k < 4; k++) {
-        int v = (centre >> (8 * k)) & 0xff;
-        const int d = (v >> 3) - bp;
-        if (d >= 0 && d <= 3) v = iclip(0, 255, v + (int)(int8_t)(rec >> (24 + 8 * (d + 1))));
-        result |= (u32)v << (8 * k);
-      }
-    } else if (type == 2) {
-      // the 3 x 6 neighbourhood of the four samples: three dwords + the bytes left and right of them (clamped at the picture edge;
-      // samples whose neighbour is really outside keep their value below)
-      const int xm = x > 0 ? x - 1 : x, xp = x + 4 < fw ? x + 4 : x + 3;
-      const u32 up = *reinterpret_cast<const u32 *>(row_u_ptr + x), dn = *reinterpret_cast<const u32 *>(row_d_ptr + x);
-      const unsigned long long row_u = ((unsigned long long)row_u_ptr[xp] << 40) | ((unsigned long long)up << 8) | row_u_ptr[xm];
-      const unsigned long long row_c = ((unsigned long long)row_c_ptr[xp] << 40) | ((unsigned long long)centre << 8) | row_c_ptr[xm];
-      const unsigned long long row_d = ((unsigned long long)row_d_ptr[xp] << 40) | ((unsigned long long)dn << 8) | row_d_ptr[xm];
-      int ax, ay, bx, by;
-      eo_offsets((int)((rec >> 8) & 0xff), ax, ay, bx, by);
-      const unsigned long long ra = ay < 0 ? row_u : (ay > 0 ? row_d : row_c), rb = by < 0 ? row_u : (by > 0 ? row_d : row_c);
-      result = 0;
-      for (int k = 0; k < 4; k++) {
-        int v = (centre >> (8 * k)) & 0xff;
-        const int xa = x + k + ax, ya = y + ay, xb = x + k + bx, yb = y + by;
-        if (xa >= 0 && xa < fw && ya >= 0 && ya < fh && xb >= 0 && xb < fw && yb >= 0 && yb < fh) {
-          const int a = (int)((ra >> (8 * (k + 1 + ax))) & 0xff), b = (int)((rb >> (8 * (k + 1 + bx))) & 0xff);
-          v = iclip(0, 255, v + (int)(int8_t)(rec >> (24 + 8 * eo_cat(a, b, v))));
-        }
-        result |= (u32)v << (8 * k);
+  const dev_pk16 one = { 1, 1 }, lo = { 0, 0 }, two = { 2, 2 };
+  const dev_pk16 ce = __builtin_bit_cast(dev_pk16, c4 & 0x00ff00ffu) + one, co = __builtin_bit_cast(dev_pk16, (c4 >> 8) & 0x00ff00ffu) + one;
+  auto sg = [&](dev_pk16 c1, u32 n) { return __builtin_elementwise_min(__builtin_elementwise_max(c1 - __builtin_bit_cast(dev_pk16, n), lo), two); };
+  const dev_pk16 ie = sg(ce, a4 & 0x00ff00ffu) + sg(ce, b4 & 0x00ff00ffu), io = sg(co, (a4 >> 8) & 0x00ff00ffu) + sg(co, (b4 >> 8) & 0x00ff00ffu);
+  return __builtin_bit_cast(u32, ie) | (__builtin_bit_cast(u32, io) << 8);
+}
+__global__ void __launch_bounds__(256) dev_sao_kernel(const u8 *in, u8 *out, const int W, const int H, const unsigned long long *packed, const kvz_hip_sao_params *luma,
+                                                      const kvz_hip_sao_params *chroma)
+{
+  // One workgroup per CTU, six passes of 256 dwords: luma rows 0-15, 16-31, 32-47, 48-63 (16 lanes across), U, V (8 lanes across, 32 rows).  The
+  // parameter record of a pass -- type, class, offsets -- is uniform, so no lane ever runs another CTU's branch; all loads of all passes are
+  // issued before the first result is computed (a pass alone has too few bytes in flight to cover the memory latency).
+  const int cxi = blockIdx.x, cyi = blockIdx.y, frame = blockIdx.z, tid = threadIdx.x;
+  const int wc = (W + 63) >> 6, hc = (H + 63) >> 6;
+  const long frame_off = (long)frame * ((long)W * H * 3 / 2);
+  // The records: packed by the SAO decision kernels of the batch (kvz_sao.hpp SaoRec), or built here from the caller's parameter structures
+  const long ctu = (long)frame * wc * hc + (long)cyi * wc + cxi;
+  unsigned long long rec3[3];
+  for (int c = 0; c < 3; c++) {
+    if (packed) rec3[c] = packed[ctu * 3 + c];
+    else {
+      const kvz_hip_sao_params *q = c ? &chroma[ctu] : &luma[ctu];
+      const int base = c == 2 ? 5 : 0;
+      unsigned long long v = (unsigned long long)(q->type & 0xff) | ((unsigned long long)(q->eo_class & 0xff) << 8) | ((unsigned long long)(q->band_position[c == 2 ? 1 : 0] & 0xff) << 16);
+      for (int k = 0; k < 5; k++) v |= (unsigned long long)(u8)(int8_t)q->offsets[base + k] << (24 + 8 * k);
+      rec3[c] = v;
+    }
+  }
+  u32 c4[6], a4[6], b4[6], keep[6];
+  long at[6];  // byte index of the pass's dword, -1: outside the picture
+#pragma unroll
+  for (int p = 0; p < 6; p++) {
+    const int color = p < 4 ? 0 : p - 3, sh = color ? 1 : 0, fw = W >> sh, fh = H >> sh, bw = 64 >> sh;
+    const long plane = frame_off + (color == 0 ? 0 : (color == 1 ? (long)W * H : (long)W * H * 5 / 4));
+    const u32 rlo = (u32)rec3[color];
+    const int type = (int)(rlo & 0xff), cls = (int)((rlo >> 8) & 0xff);
+    const int x = cxi * bw + 4 * (color ? tid & 7 : tid & 15), y = cyi * bw + (color ? tid >> 3 : (tid >> 4) + 16 * p);
+    at[p] = -1; c4[p] = a4[p] = b4[p] = 0; keep[p] = 0xffffffffu;
+    if (x < fw && y < fh) {
+      const u8 *row = in + plane + (long)y * fw;
+      at[p] = plane + (long)y * fw + x;
+      c4[p] = *reinterpret_cast<const u32 *>(row + x);
+      if (type == 2) {
+        const int dx = cls == 1 ? 0 : (cls == 3 ? 1 : -1);           // a = (dx, -1 or 0), b = (-dx, +1 or 0)  (sao.h:71-76)
+        // clamped rows: samples whose neighbour row is outside keep their value
+        const int ra = (cls == 0 || y == 0) ? 0 : -fw, rb = (cls == 0 || y + 1 == fh) ? 0 : fw;
+        // neighbour dwords; at the ends of the row the load is moved inside the row and the bytes shifted into place (the byte that falls
+        // off belongs to a sample that keeps its value)
+        const int adj_a = (x + dx < 0) ? 1 : ((x + dx + 4 > fw) ? -1 : 0), adj_b = (x - dx < 0) ? 1 : ((x - dx + 4 > fw) ? -1 : 0);
+        a4[p] = load_u32_any(row + ra + x + dx + adj_a); b4[p] = load_u32_any(row + rb + x - dx + adj_b);
+        a4[p] = adj_a > 0 ? a4[p] << 8 : (adj_a < 0 ? a4[p] >> 8 : a4[p]);
+        b4[p] = adj_b > 0 ? b4[p] << 8 : (adj_b < 0 ? b4[p] >> 8 : b4[p]);
+        // samples with a neighbour outside the picture keep their value (sao.c:324-349)
+        if (cls != 0 && (y == 0 || y + 1 == fh)) keep[p] = 0;
+        if (cls != 1) { if (x == 0) keep[p] &= 0xffffff00u; if (x + 4 == fw) keep[p] &= 0x00ffffffu; }
       }
     }
-    *reinterpret_cast<u32 *>(out + plane + (long)y * fw + x) = result;
+  }
+#pragma unroll
+  for (int p = 0; p < 6; p++) {
+    const int color = p < 4 ? 0 : p - 3;
+    const unsigned long long rec = rec3[color];
+    const u32 rlo = (u32)rec, rhi = (u32)(rec >> 32);             // bytes: type, class, band position, offsets[0] | offsets[1..4]
+    const int type = (int)(rlo & 0xff);
+    if (at[p] < 0) continue;
+    u32 result = c4[p];
+    if (type == 1) {
+      const u32 bh = (1u - ((rlo >> 16) & 0xff)) & 0xffffu;
+      const dev_pk16 bias = __builtin_bit_cast(dev_pk16, bh | (bh << 16));  // + 1 - band position in both halves
+      const u32 band = (c4[p] >> 3) & 0x1f1f1f1fu;
+      const dev_pk16 lo = { 0, 0 }, five = { 5, 5 };
+      const dev_pk16 te = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(dev_pk16, band & 0x00ff00ffu) + bias, lo), five);
+      const dev_pk16 to = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(dev_pk16, (band >> 8) & 0x00ff00ffu) + bias, lo), five);
+      const u32 t4 = __builtin_bit_cast(u32, te) | (__builtin_bit_cast(u32, to) << 8);
+      const u32 sel = __builtin_amdgcn_perm(0x00000c07u, 0x0605040cu, t4);  // 0 -> zero, 1..4 -> offsets[1..4], 5 -> zero
+      result = sao_add_offsets(c4[p], __builtin_amdgcn_perm(rhi, rlo, sel));
+    } else if (type == 2) {
+      const u32 idx4 = sao_sign_idx(c4[p], a4[p], b4[p]);
+      const u32 sel = __builtin_amdgcn_perm(0x00000007u, 0x06030504u, idx4);  // {1,2,0,3,4}[idx] as byte positions of the record
+      result = sao_add_offsets(c4[p], __builtin_amdgcn_perm(rhi, rlo, sel) & keep[p]);
+    }
+    *reinterpret_cast<u32 *>(out + at[p]) = result;
   }
 }
 
@@ -716,8 +812,8 @@ void kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *o
     const kvz::Tables *tb = kvz::device_tables();
     const int kind_bd = idx == 4 ? 2 : (n == 8 ? 1 : 0), per_wave = 16 / n;
     const long threads = ((long)count + 4 * per_wave - 1) / (4 * per_wave) * 256;
-    if (n == 4) KVZ_DEV_LAUNCH(kvz::dev_transform_small_mfma_kernel<4>, threads, in, out, count, inverse, tb->bd_h[kind_bd][0], tb->bd_h[kind_bd][1]);
-    else KVZ_DEV_LAUNCH(kvz::dev_transform_small_mfma_kernel<8>, threads, in, out, count, inverse, tb->bd_h[kind_bd][0], tb->bd_h[kind_bd][1]);
+    if (n == 4) KVZ_DEV_LAUNCH(kvz::dev_transform_small_mfma_kernel<4>, threads, in, out, count, inverse, tb->bd_i8[kind_bd][0], tb->bd_i8[kind_bd][1], tb->bd_sum[kind_bd][0], tb->bd_sum[kind_bd][1]);
+    else KVZ_DEV_LAUNCH(kvz::dev_transform_small_mfma_kernel<8>, threads, in, out, count, inverse, tb->bd_i8[kind_bd][0], tb->bd_i8[kind_bd][1], tb->bd_sum[kind_bd][0], tb->bd_sum[kind_bd][1]);
     return;
   }
   if (!tmp) { fprintf(stderr, "kvz_hip_dev_transform: the scalar path needs tmp\n"); abort(); }
@@ -727,7 +823,7 @@ void kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *o
 void kvz_hip_dev_angular_pred(int log2_width, int mode, const uint8_t *ref_above, const uint8_t *ref_left, int count, uint8_t *out)
 {
   if (count <= 0) return;
-  const int lanes = (1 << (2 * log2_width)) / 4, blocks_per_wg = 256 / lanes;
+  const int blocks_per_wg = 256 * kvz::kAngularGroupsPerLane / ((1 << (2 * log2_width)) / 4);
   const long threads = ((long)count + blocks_per_wg - 1) / blocks_per_wg * 256;
   switch (log2_width) {
   case 2: KVZ_DEV_LAUNCH(kvz::dev_angular_kernel<2>, threads, ref_above, ref_left, count, mode, out); break;
@@ -794,13 +890,8 @@ void kvz_hip_dev_sao_frames(const uint8_t *in, uint8_t *out, int width, int heig
                             const kvz_hip_sao_params *chroma)
 {
   if (n_frames <= 0) return;
-  const long n_ctus = (long)n_frames * ((width + 63) >> 6) * ((height + 63) >> 6);
-  unsigned long long *packed = nullptr;
-  KVZ_HIP_CHECK(hipMallocAsync((void **)&packed, (size_t)n_ctus * 3 * sizeof(unsigned long long), be().stream));
-  KVZ_DEV_LAUNCH(kvz::dev_sao_pack_kernel, 3 * n_ctus, luma, chroma, n_ctus, packed);
-  hipLaunchKernelGGL(kvz::dev_sao_kernel, dim3((unsigned)(2 * height), (unsigned)n_frames), dim3(256), 0, be().stream, in, out, width, height, packed);
+  hipLaunchKernelGGL(kvz::dev_sao_kernel, dim3((unsigned)((width + 63) >> 6), (unsigned)((height + 63) >> 6), (unsigned)n_frames), dim3(256), 0, be().stream, in, out, width, height, (const unsigned long long *)nullptr, luma, chroma);
   KVZ_HIP_CHECK(hipGetLastError());
-  KVZ_HIP_CHECK(hipFreeAsync(packed, be().stream));
 }
 
 void kvz_hip_dev_picture_checksums(const uint8_t *frames, int width, int height, int n_frames, uint32_t *out)
@@ -847,7 +938,7 @@ void kvz_hip_batch_loop_filters(kvz_hip_batch *b, const kvz_hip_intra_cost_model
   hipLaunchKernelGGL(kvz::dev_sao_chain_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, b->stream, (const kvz::SaoStats *)b->d_sao_stats, (const kvz::SaoCand *)b->d_sao_cand, g, n, b->d_sao_fbits, kvz::device_tables(),
                      model->lambda, (int)model->ctx_init[KVZ_HIP_CX_SAO_MERGE], (int)model->ctx_init[KVZ_HIP_CX_SAO_TYPE], model->no_wpp, b->d_sao_recs, b->d_sao_merge);
   // the SAO'd picture becomes the batch's reconstruction (R is not needed any more)
-  hipLaunchKernelGGL(kvz::dev_sao_kernel, dim3((unsigned)(2 * F.H), (unsigned)n), dim3(256), 0, b->stream, b->d_dbk, b->d_rec, F.W, F.H, b->d_sao_recs);
+  hipLaunchKernelGGL(kvz::dev_sao_kernel, dim3((unsigned)F.wc, (unsigned)F.hc, (unsigned)n), dim3(256), 0, b->stream, b->d_dbk, b->d_rec, F.W, F.H, b->d_sao_recs, (const kvz_hip_sao_params *)nullptr, (const kvz_hip_sao_params *)nullptr);
   KVZ_HIP_CHECK(hipGetLastError());
 }
 

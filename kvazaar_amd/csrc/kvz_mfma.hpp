@@ -1,11 +1,17 @@
 // kvz_mfma.hpp -- exact integer matrix products on the matrix cores, shared by the CTU kernel (kvz_ctu.hpp) and the batch
 // transform kernels (kvz_dev.hpp).  Device code only.
 //
-// The accumulator layout of v_mfma (lane = column, registers = 4 consecutive rows per k-step) is the B operand layout of the
-// next product and, read as A, the transposed matrix, so a result can feed the next product without leaving registers.
-// Exactness: 16-bit operands are split x = 256 (x >> 8) + (x & 255); every operand is then an integer binary16 holds exactly
-// (as is every entry of the transform matrices, |v| <= 90), products are exact in binary32 and all partial sums stay below
-// 32 * 90 * 255 < 2^24 -- the binary32 accumulators hold exact integers whatever the summation order.
+// int8 MFMA with int32 accumulators (v_mfma_i32_32x32x32_i8 / v_mfma_i32_16x16x32_i8): every entry of the transform matrices fits a
+// signed byte (|v| <= 90); a 16-bit operand x is split x = 256 h + l into its signed high byte h and its unsigned low byte l, and
+// because the instruction wants signed bytes the low part goes in as l - 128 (= l ^ 0x80) with 128 * (sum of the matrix entries it meets)
+// preloaded into the accumulator -- together with the rounding constant of the stage.  Everything is exact integer arithmetic
+// (|sums| <= 32 * 90 * 128), so results are bit-identical to dct-generic.c whatever the order of summation.
+// Splitting four values into byte planes is four v_perm_b32; there are no conversions on either side of the product.
+//
+// The accumulator layout (lane = column, registers = rows) is the B operand layout of the next product and, read as A, the transposed
+// matrix, so a result can feed the next product without leaving registers: the contraction index k only has to sit in the same
+// (lane group, byte) slot on both operands, and which k that is is free.  Slot i of a lane carries k = row(lane, i), the row its
+// accumulator register i holds; the table operands are stored in that order (Tables::dct_i8, kvz_tables.hpp).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -13,53 +19,89 @@
 
 namespace kvz {
 
-typedef _Float16 dev_half4 __attribute__((ext_vector_type(4)));
-typedef float dev_float4 __attribute__((ext_vector_type(4)));
-typedef float dev_float16 __attribute__((ext_vector_type(16)));
+typedef int dev_int4 __attribute__((ext_vector_type(4)));
+typedef int dev_int16 __attribute__((ext_vector_type(16)));
 
-template <int N> struct DevMma;
-template <> struct DevMma<16> {  // v_mfma_f32_16x16x16_f16
-  typedef dev_float4 Acc;
-  static constexpr int NREG = 4, STEPS = 1;
-  static __device__ __forceinline__ int idx(int lane) { return lane & 15; }
-  static __device__ __forceinline__ int k0(int lane, int) { return 4 * (lane >> 4); }
-  static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
-  static __device__ __forceinline__ Acc mma(dev_half4 a, dev_half4 b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
-};
-template <> struct DevMma<32> {  // v_mfma_f32_32x32x8_f16
-  typedef dev_float16 Acc;
-  static constexpr int NREG = 16, STEPS = 4;
-  static __device__ __forceinline__ int idx(int lane) { return lane & 31; }
-  static __device__ __forceinline__ int k0(int lane, int step) { return 8 * step + 4 * (lane >> 5); }
-  static __device__ __forceinline__ int row(int lane, int r) { return 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3); }
-  static __device__ __forceinline__ Acc mma(dev_half4 a, dev_half4 b, Acc c) { return __builtin_amdgcn_mfma_f32_32x32x8f16(a, b, c, 0, 0, 0); }
-};
-
-// out[] = (register matrix v, accumulator layout) x (table) when table_is_a == false, (table) x (register matrix) otherwise
-template <int N> __device__ __forceinline__ void dev_product(const int *v, const u16 *table, bool table_is_a, int lane, int *out)
+// byte planes of four 16-bit values (the low halves of v0..v3): lo = (l0 l1 l2 l3) ^ 0x80808080, hi = (h0 h1 h2 h3)
+__device__ __forceinline__ void dev_byte_planes(int v0, int v1, int v2, int v3, u32 &lo, u32 &hi)
 {
-  typedef DevMma<N> M;
-  typename M::Acc lo = { 0 }, hi = { 0 };
-  for (int st = 0; st < M::STEPS; st++) {
-    const dev_half4 tv = *reinterpret_cast<const dev_half4 *>(table + M::idx(lane) * N + M::k0(lane, st));
-    dev_half4 dl, dh;
-    for (int i = 0; i < 4; i++) { const int x = v[4 * st + i]; dh[i] = (_Float16)(x >> 8); dl[i] = (_Float16)(x & 255); }
-    if (table_is_a) { lo = M::mma(tv, dl, lo); hi = M::mma(tv, dh, hi); }
-    else { lo = M::mma(dl, tv, lo); hi = M::mma(dh, tv, hi); }
-  }
-  for (int r = 0; r < M::NREG; r++) out[r] = (int)hi[r] * 256 + (int)lo[r];
+  const u32 t01 = __builtin_amdgcn_perm((u32)v1, (u32)v0, 0x05010400u), t23 = __builtin_amdgcn_perm((u32)v3, (u32)v2, 0x05010400u);
+  lo = __builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u;
+  hi = __builtin_amdgcn_perm(t23, t01, 0x07060302u);
 }
 
+template <int N> struct DevMma;
+template <> struct DevMma<16> {  // v_mfma_i32_16x16x32_i8, the upper half of the k slots left at zero
+  static constexpr int NREG = 4;
+  static __device__ __forceinline__ int idx(int lane) { return lane & 15; }
+  static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
+  static __device__ __forceinline__ int k0(int lane, int) { return 4 * (lane >> 4); }  // first of the 4 consecutive k of step 0
+  static constexpr int STEPS = 1;
+};
+template <> struct DevMma<32> {  // v_mfma_i32_32x32x32_i8
+  static constexpr int NREG = 16;
+  static __device__ __forceinline__ int idx(int lane) { return lane & 31; }
+  static __device__ __forceinline__ int row(int lane, int r) { return 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3); }
+  static __device__ __forceinline__ int k0(int lane, int step) { return 8 * step + 4 * (lane >> 5); }  // slots 4 step .. 4 step + 3
+  static constexpr int STEPS = 4;
+};
+
+// out[] = (register matrix v, accumulator layout) x (table) when table_is_a == false, (table) x (register matrix) otherwise, + add.
+// tab: the table's rows in slot order (16 or 32 signed bytes per row), sums: the row sums of the table.
+template <int N> __device__ __forceinline__ void dev_product(const int *v, const int8_t *tab, const i32 *sums, bool table_is_a, int lane, int add, int *out)
+{
+  typedef DevMma<N> M;
+  if constexpr (N == 32) {
+    dev_int4 lo, hi;
+    for (int q = 0; q < 4; q++) { u32 l, h; dev_byte_planes(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3], l, h); lo[q] = (int)l; hi[q] = (int)h; }
+    const dev_int4 tv = *reinterpret_cast<const dev_int4 *>(tab + M::idx(lane) * 32 + (lane >> 5) * 16);
+    dev_int16 al, ah;
+    for (int r = 0; r < 16; r++) ah[r] = 0;
+    if (table_is_a) {
+      for (int q = 0; q < 4; q++) {
+        const dev_int4 s4 = *reinterpret_cast<const dev_int4 *>(sums + M::row(lane, 4 * q));
+        for (int i = 0; i < 4; i++) al[4 * q + i] = 128 * s4[i] + add;
+      }
+      al = __builtin_amdgcn_mfma_i32_32x32x32_i8(tv, lo, al, 0, 0, 0);
+      ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(tv, hi, ah, 0, 0, 0);
+    } else {
+      const int c = 128 * sums[M::idx(lane)] + add;
+      for (int r = 0; r < 16; r++) al[r] = c;
+      al = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, tv, al, 0, 0, 0);
+      ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, tv, ah, 0, 0, 0);
+    }
+    for (int r = 0; r < 16; r++) out[r] = ah[r] * 256 + al[r];
+  } else {
+    u32 l, h;
+    dev_byte_planes(v[0], v[1], v[2], v[3], l, h);
+    const long lo = (long)(unsigned long long)l, hi = (long)(unsigned long long)h;
+    const long tv = (long)(unsigned long long)*reinterpret_cast<const u32 *>(tab + M::idx(lane) * 16 + 4 * (lane >> 4));
+    dev_int4 al, ah = { 0, 0, 0, 0 };
+    if (table_is_a) {
+      const dev_int4 s4 = *reinterpret_cast<const dev_int4 *>(sums + M::row(lane, 0));
+      for (int i = 0; i < 4; i++) al[i] = 128 * s4[i] + add;
+      al = __builtin_amdgcn_mfma_i32_16x16x32_i8(tv, lo, al, 0, 0, 0);
+      ah = __builtin_amdgcn_mfma_i32_16x16x32_i8(tv, hi, ah, 0, 0, 0);
+    } else {
+      const int c = 128 * sums[M::idx(lane)] + add;
+      for (int i = 0; i < 4; i++) al[i] = c;
+      al = __builtin_amdgcn_mfma_i32_16x16x32_i8(lo, tv, al, 0, 0, 0);
+      ah = __builtin_amdgcn_mfma_i32_16x16x32_i8(hi, tv, ah, 0, 0, 0);
+    }
+    for (int r = 0; r < 4; r++) out[r] = ah[r] * 256 + al[r];
+  }
+}
 
 // Both passes of a 16- or 32-point DCT / IDCT of one N x N int16 block, chained through registers; `x` and `o` may be the same
-// block (every load precedes every store: the stores depend on products that consumed all loads).  T / Tt = the transform
-// matrix / its transpose as halves, rows contiguous (Tables::dct_h).
-//   forward: D0^T = X T^T, K = T D0^T  (dct-generic.c partial_butterfly_*: the intermediate wraps to int16)
+// block (every load precedes every store: the stores depend on products that consumed all loads).
+//   forward: D0^T = X T^T, K = T D0^T  (dct-generic.c partial_butterfly_*: the intermediate wraps to int16 -- only its two low bytes are used)
 //   inverse: U = X^T T,    O = U^T T   (partial_butterfly_inverse_*: both stages clip to int16)
-template <int N> __device__ __forceinline__ void mfma_transform_block(const i16 *x, i16 *o, bool inverse, const u16 *T, const u16 *Tt, int lane)
+template <int N> __device__ __forceinline__ void mfma_transform_block(const i16 *x, i16 *o, bool inverse, const Tables *tb, int lane)
 {
   typedef DevMma<N> M;
   constexpr int L2 = N == 16 ? 4 : 5;
+  const int8_t *T = tb->dct_i8[L2 - 4][0], *Tt = tb->dct_i8[L2 - 4][1];
+  const i32 *sT = tb->dct_sum[L2 - 4][0], *sTt = tb->dct_sum[L2 - 4][1];
   const int col = M::idx(lane);
   int v[M::NREG], t[M::NREG];
   if (!inverse) {
@@ -67,17 +109,17 @@ template <int N> __device__ __forceinline__ void mfma_transform_block(const i16 
       const short4 q = *reinterpret_cast<const short4 *>(x + col * N + M::k0(lane, st));
       v[4 * st] = q.x; v[4 * st + 1] = q.y; v[4 * st + 2] = q.z; v[4 * st + 3] = q.w;
     }
-    dev_product<N>(v, T, false, lane, t);
-    { const int shift = L2 - 1, add = 1 << (shift - 1); for (int r = 0; r < M::NREG; r++) v[r] = (int)(i16)((t[r] + add) >> shift); }
-    dev_product<N>(v, T, true, lane, t);
-    { const int shift = L2 + 6, add = 1 << (shift - 1); for (int r = 0; r < M::NREG; r++) o[M::row(lane, r) * N + col] = (i16)((t[r] + add) >> shift); }
+    dev_product<N>(v, T, sT, false, lane, 1 << (L2 - 2), t);
+    for (int r = 0; r < M::NREG; r++) v[r] = t[r] >> (L2 - 1);
+    dev_product<N>(v, T, sT, true, lane, 1 << (L2 + 5), t);
+    for (int r = 0; r < M::NREG; r++) o[M::row(lane, r) * N + col] = (i16)(t[r] >> (L2 + 6));
   } else {
     for (int st = 0; st < M::STEPS; st++)    // A operand = rows of X^T: lane <-> column of X, four consecutive rows per step
       for (int i = 0; i < 4; i++) v[4 * st + i] = x[(M::k0(lane, st) + i) * N + col];
-    dev_product<N>(v, Tt, false, lane, t);
-    for (int r = 0; r < M::NREG; r++) v[r] = iclip(-32768, 32767, (t[r] + 64) >> 7);
-    dev_product<N>(v, Tt, false, lane, t);   // the accumulator read as A is U^T
-    for (int r = 0; r < M::NREG; r++) o[M::row(lane, r) * N + col] = (i16)iclip(-32768, 32767, (t[r] + 2048) >> 12);
+    dev_product<N>(v, Tt, sTt, false, lane, 64, t);
+    for (int r = 0; r < M::NREG; r++) v[r] = iclip(-32768, 32767, t[r] >> 7);
+    dev_product<N>(v, Tt, sTt, false, lane, 2048, t);   // the accumulator read as A is U^T
+    for (int r = 0; r < M::NREG; r++) o[M::row(lane, r) * N + col] = (i16)iclip(-32768, 32767, t[r] >> 12);
   }
 }
 

@@ -48,12 +48,15 @@ KVZ_DEV u8 clip_pixel(int v) { return (u8)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 struct Tables {
   i16 dct[4][32 * 32];   // [log2n-2] row-major n*n (dct-generic.c:46-120)
   i16 dst4[16];          // dct-generic.c:38-44
-  // The 16- and 32-point matrices again as IEEE half bit patterns (every entry is an integer of magnitude <= 90, exact
-  // in half): [0: n = 16, 1: n = 32][0: C row-major, 1: C transposed], the table operand of the MFMA transforms.
-  alignas(16) u16 dct_h[2][2][32 * 32];
-  // ... and 16 x 16 block-diagonal matrices for the small transforms, so that one 16x16x16 MFMA carries several blocks:
+  // The 16- and 32-point matrices again as signed bytes (|v| <= 90), the table operand of the MFMA transforms (kvz_mfma.hpp):
+  // [0: n = 16, 1: n = 32][0: C row-major, 1: C transposed]; rows of n bytes in the k-slot order of the instruction -- natural for
+  // n = 16, and for n = 32 byte 16 h + j of a row = entry 8 (j >> 2) + 4 h + (j & 3).  dct_sum: the row sums.
+  alignas(16) int8_t dct_i8[2][2][32 * 32];
+  alignas(16) i32 dct_sum[2][2][32];
+  // ... and 16 x 16 block-diagonal matrices for the small transforms, so that one 16 x 16 product carries several blocks:
   // [0: diag(C4 x4), 1: diag(C8 x2), 2: diag(DST4 x4)][0: T, 1: T transposed]
-  alignas(16) u16 bd_h[3][2][16 * 16];
+  alignas(16) int8_t bd_i8[3][2][16 * 16];
+  alignas(16) i32 bd_sum[3][2][16];
   u32 scan[3][4][1024];  // [scan_idx][log2-2] (tables.c kvz_g_sig_last_scan), sizes 4..32
   // intra.c:47-82 num_ref_pixels_top / num_ref_pixels_left: reference samples available above-right / below-left of the 4x4
   // unit at [y / 4][x / 4] of a CTU, regenerated from the z-order of the units (kvz_tables.hpp)

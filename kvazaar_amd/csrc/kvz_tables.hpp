@@ -89,10 +89,16 @@ inline void build_tables(Tables *t)
   }
   for (int l = 2; l < 4; l++) {
     const int n = 4 << l;
-    for (int k = 0; k < n; k++)
-      for (int j = 0; j < n; j++) {
-        t->dct_h[l - 2][0][k * n + j] = half_bits_of_int(t->dct[l][k * n + j]);
-        t->dct_h[l - 2][1][j * n + k] = half_bits_of_int(t->dct[l][k * n + j]);
+    for (int which = 0; which < 2; which++)
+      for (int r = 0; r < n; r++) {
+        int sum = 0;
+        for (int slot = 0; slot < n; slot++) {
+          const int h = slot >> 4, j = slot & 15, k = n == 32 ? 8 * (j >> 2) + 4 * h + (j & 3) : slot;  // kvz_mfma.hpp DevMma<32>::row
+          const int v = which == 0 ? t->dct[l][r * n + k] : t->dct[l][k * n + r];
+          t->dct_i8[l - 2][which][r * n + slot] = (int8_t)v;
+          sum += v;
+        }
+        t->dct_sum[l - 2][which][r] = sum;
       }
   }
   {  // a unit to the above-right / below-left is usable iff it comes earlier in z-order (cu.h:385-421) than the unit itself
@@ -128,8 +134,10 @@ inline void build_tables(Tables *t)
     for (int g = 0; g < 16 / n; g++)
       for (int k = 0; k < n; k++)
         for (int j = 0; j < n; j++) {
-          t->bd_h[kind][0][(g * n + k) * 16 + g * n + j] = half_bits_of_int(m[k * n + j]);
-          t->bd_h[kind][1][(g * n + j) * 16 + g * n + k] = half_bits_of_int(m[k * n + j]);
+          t->bd_i8[kind][0][(g * n + k) * 16 + g * n + j] = (int8_t)m[k * n + j];
+          t->bd_i8[kind][1][(g * n + j) * 16 + g * n + k] = (int8_t)m[k * n + j];
+          t->bd_sum[kind][0][g * n + k] += m[k * n + j];
+          t->bd_sum[kind][1][g * n + j] += m[k * n + j];
         }
   }
   for (int type = 0; type < 3; type++)

@@ -83,11 +83,11 @@ def test_dev_transform(oracle, dev, name, mfma):
 @pytest.mark.parametrize("log2w", [2, 3, 4, 5])
 def test_dev_angular(oracle, dev, log2w):
     rng = np.random.default_rng(log2w)
-    w, count = 1 << log2w, 50
+    w, count = 1 << log2w, 203
     above = rng.integers(0, 256, (count, 2 * w + 1), dtype=np.uint8)
     left = rng.integers(0, 256, (count, 2 * w + 1), dtype=np.uint8)
     left[:, 0] = above[:, 0]
-    for mode in (2, 7, 10, 18, 26, 34):
+    for mode in range(2, 35):
         da, dl, do = dev.put(above), dev.put(left), dev.empty(count * w * w)
         dev.lib.kvz_hip_dev_angular_pred(log2w, mode, da, dl, count, do)
         got = dev.get(do, (count, w * w), np.uint8)
