@@ -5,8 +5,8 @@ Shapes follow the reference's tests/speed_tests.c (N x N cost functions and tran
 BATCH_CTUS CTUs' worth of blocks that are resident in HBM before the timed region.  For every kernel one JSON line:
   achieved GB/s = algorithmic bytes (2 N^2 per SAD/SATD block, 4 N^2 per transform block, (4N+2)+N^2 per angular
   block) / mean launch time measured with HIP events on the launch stream; frac = achieved / 8000 GB/s (MI355X HBM3E peak);
-  16/32-point transforms additionally report matrix-core utilisation = blocks/s * 4 N^3 / 2.5e15 (dense f16 peak; the kernels
-  issue twice that many MFMA operations because 16-bit operands are split in bytes -- stated as mfma_issued_frac).
+  matrix-core transforms additionally report utilisation = blocks/s * 4 N^3 / 5e15 (dense int8 peak) and what they actually issue
+  (byte planes, zero padding: mfma_issued_frac).
 bench.py remains the headline (CTUs/s); this file is the per-kernel view."""
 import argparse
 import json
@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0
-F16_DENSE_PEAK = 2.5e15
+I8_DENSE_PEAK = 5.0e15  # int8 MFMA, dense: twice the bf16 / f16 rate (MI355X_MICROARCH.md)
 
 
 def gradient_blocks(n, count, seed):
@@ -82,13 +82,24 @@ def main():
         rng = np.random.default_rng(kind)
         x = np.tile(rng.integers(-255, 256, (min(count, 2048), n * n)).astype(np.int16), ((count + 2047) // 2048, 1))[:count]
         di, dt, do = dev.put(x), dev.empty(x.nbytes), dev.empty(x.nbytes)
-        for mfma in (0, 1):
+        for mfma in (0, 1, 2):
             ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_transform(kind, di, dt, do, count, mfma), args.reps, args.warmup)
-            extra = {"path": "matrix cores (v_mfma_f32_*_f16)" if mfma else "scalar item kernel, two passes through HBM"}
-            if mfma:
-                ops = count * 4 * n ** 3 / (ms * 1e-3)
-                extra.update({"mfma_algorithmic_frac": round(ops / F16_DENSE_PEAK, 5), "mfma_issued_frac": round(2 * ops / F16_DENSE_PEAK, 5)})
-            report(f"{name}" + ("_mfma" if mfma else "_scalar"), n, count, ms, 4 * n * n, extra)
+            if mfma == 0:
+                suffix, extra = "_scalar", {"path": "one lane per coefficient, two passes through HBM"}
+            elif mfma == 1 and n <= 8:
+                suffix, extra = "_rows", {"path": "vector ALU, one lane per block row: v_dot2_i32_i16 on packed pairs, transposes through LDS"}
+            else:
+                if mfma == 2 and n >= 16:
+                    continue                                                       # same kernel as mfma == 1
+                suffix = "_mfma"
+                per_issue = 32 if n == 32 else 16                                  # edge of the product the blocks ride on
+                blocks_per_issue = 1 if n >= 16 else 16 // n
+                k_issued = 32                                                      # K of both int8 instructions (16 x 16 x 32 runs half empty for 16-point rows)
+                ops = count * 4 * n ** 3 / (ms * 1e-3)                             # 2 products x 2 n^3 multiply-adds' worth of operations
+                issued = count / blocks_per_issue * 2 * 2 * 2 * per_issue * per_issue * k_issued / (ms * 1e-3)  # 2 products x 2 byte planes
+                extra = {"path": "matrix cores, v_mfma_i32_*_i8 on byte planes" + ("" if n >= 16 else " (small blocks on a block diagonal; A/B path)"),
+                         "mfma_algorithmic_frac": round(ops / I8_DENSE_PEAK, 5), "mfma_issued_frac": round(issued / I8_DENSE_PEAK, 5)}
+            report(f"{name}{suffix}", n, count, ms, 4 * n * n, extra)
         dev.free(di, dt, do)
 
     for log2w in (2, 3, 4, 5):
@@ -142,6 +153,11 @@ def main():
         ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_sao_frames(din, dout2, w, h, nfr, dl, dch), args.reps, args.warmup)
         report(f"sao_1080p_frame_{name}", 0, nfr, ms, 2 * (w * h * 3 // 2), {"path": f"every CTU {name}", "fps": round(nfr / (ms * 1e-3))})
         dev.free(dl, dch)
+    # the read + write streaming reference: the runtime's own device-to-device copy of the same 128 pictures
+    dev.lib.kvz_hip_dev_copy.restype = None
+    dev.lib.kvz_hip_dev_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_copy(dout2, din, nfr * frame.nbytes), args.reps, args.warmup)
+    report("copy_d2d_1080p_frame", 0, nfr, ms, 2 * (w * h * 3 // 2), {"path": "hipMemcpyAsync device to device: what a kernel that reads and writes every byte once can reach"})
     dev.free(din, dout2)
 
     # motion cost surface: every 16x16 block of a 1080p picture, +-16 full search (1089 candidates per block)

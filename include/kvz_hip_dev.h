@@ -25,6 +25,8 @@ void  kvz_hip_dev_free(void *p);
 void  kvz_hip_dev_upload(void *dev_dst, const void *host_src, size_t bytes);
 void  kvz_hip_dev_download(void *host_dst, const void *dev_src, size_t bytes);
 void  kvz_hip_dev_sync(void);
+/* device-to-device copy on the same stream (the read + write streaming reference of bench_kernels.py) */
+void  kvz_hip_dev_copy(void *dev_dst, const void *dev_src, size_t bytes);
 /* Event pair on the calling thread's stream: milliseconds the device spent between start and stop. */
 void  kvz_hip_dev_timer_start(void);
 float kvz_hip_dev_timer_stop(void);
@@ -35,8 +37,10 @@ void kvz_hip_dev_sad_nxn(int n, const uint8_t *a, const uint8_t *b, int count, u
 void kvz_hip_dev_satd_nxn(int n, const uint8_t *a, const uint8_t *b, int count, uint32_t *out);
 
 /* kvz_dct_NxN / kvz_idct_NxN / 4x4 DST (dct-generic.c:559-630), 8-bit: `kind` = enum kvz_hip_transform_kind.
- * All of them run on the matrix cores (v_mfma_f32_*_f16, exact integer arithmetic; 4- and 8-point blocks ride 4 / 2 at a time on
- * the diagonal of a 16x16 product) unless use_matrix_cores == 0; `tmp` is count * n^2 int16 of scratch for the scalar path (may be NULL with matrix cores). */
+ * use_matrix_cores == 1 (the product path): 16- and 32-point blocks on the matrix cores (v_mfma_i32_*_i8 on byte planes, exact integer
+ * arithmetic, one block per wavefront), 4- and 8-point blocks on the vector ALU, one lane per block row (v_dot2_i32_i16, transposes through LDS).
+ * == 2: the small sizes on the matrix cores as well, 4 or 2 blocks on the diagonal of a 16 x 16 product (kept for A/B).
+ * == 0: one lane per coefficient, two launches through `tmp` (count * n^2 int16 of scratch; may be NULL otherwise). */
 void kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *out, int count, int use_matrix_cores);
 
 /* kvz_angular_pred (intra-generic.c:49-155): block i is predicted from ref_above + i * (2w+1) and ref_left + i * (2w+1)

@@ -79,7 +79,9 @@ template <bool CABAC, bool S32 = false> __global__ void __launch_bounds__(KVZ_CT
   __shared__ CtuModel m;  // scalars in LDS; its price table stays in HBM (kvz_hip_batch::d_entropy)
   // The ticket is broadcast through a field of `shared` that is dead between two CTUs: with the CABAC contexts the block is exactly 20 480 B,
   // and one more word would cost the eighth workgroup per CU (160 KB of LDS).
+#ifndef KVZ_CTU_PROFILE
   static_assert(sizeof(CtuSharedT<CABAC>) + sizeof(CtuModel) <= 20480, "eight workgroups per CU");
+#endif
   if (threadIdx.x == 0) m = model;
   const int ctus = F.wc * F.hc;
   for (;;) {

@@ -111,11 +111,13 @@ namespace kvz {
 // Optional in-kernel timeline (build with -DKVZ_CTU_PROFILE): lane 0 of every workgroup adds the shader-clock cycles
 // spent since the previous mark to a per-category counter in HBM.  Categories are the KVZ_P_* constants.
 enum { KVZ_P_INIT = 0, KVZ_P_REFS, KVZ_P_PRED35, KVZ_P_SATD, KVZ_P_SELECT, KVZ_P_RPRED, KVZ_P_FDCT, KVZ_P_QUANT, KVZ_P_IDCT, KVZ_P_RECON,
-       KVZ_P_COST, KVZ_P_COPY, KVZ_P_FINISH, KVZ_P_MISC, KVZ_P_COUNT };
+       KVZ_P_COST, KVZ_P_COPY, KVZ_P_FINISH, KVZ_P_MISC, KVZ_P_COEFFBITS, KVZ_P_COUNT };
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
 #define KVZ_PROF(cat) prof_mark(cat)
+#define KVZ_PROF_SYNC(cat) do { KVZ_SYNC(); prof_mark(cat); } while (0)  /* a mark where the program has no barrier of its own */
 #else
 #define KVZ_PROF(cat)
+#define KVZ_PROF_SYNC(cat)
 #endif
 
 // One byte of another workgroup's border record.  On the device the containing dword is read with an agent-scope
@@ -1720,7 +1722,7 @@ template <bool CABAC, bool S32 = false> struct CtuProgramT {
     // All three planes' references were built by rough_search.
     TuSet t{ x, y, log2w, depth == 3 ? 2 : log2w - 1 };
     recon_tus(lv, t, depth, mode, true);
-    if (cabac_on()) price_unit_coeffs(&s->cab, true, lv, depth, mode, &s->child_bits[0]);  // residual contexts; the syntax ones below are disjoint
+    if (cabac_on()) { KVZ_PROF_SYNC(KVZ_P_RECON); price_unit_coeffs(&s->cab, true, lv, depth, mode, &s->child_bits[0]); KVZ_PROF_SYNC(KVZ_P_COEFFBITS); }  // residual contexts; the syntax ones below are disjoint
     KVZ_FOR_THREADS(tid) {
       if (tid == 0) {
         const double bits = cu_bits(lv, x, y, depth, mode, s->preds);  // search.c:895-940: cabac->update = 1 around the mock encode ...
@@ -2203,7 +2205,7 @@ template <bool CABAC, bool S32 = false> struct CtuProgramT {
       write_rec();
     }
     KVZ_PROF(KVZ_P_MISC);
-    if (m->adaptive && cabac_on()) code_ctu_residual();
+    if (m->adaptive && cabac_on()) { code_ctu_residual(); KVZ_PROF_SYNC(KVZ_P_PRED35); }  // category reused: the residual replay
     finish_info();
     KVZ_PROF(KVZ_P_FINISH);
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)

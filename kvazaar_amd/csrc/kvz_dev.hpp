@@ -149,6 +149,91 @@ template <int N> __global__ void __launch_bounds__(256) dev_transform_mfma_kerne
   }
 }
 
+// 4- and 8-point transforms (and the 4x4 DST) on the vector ALU, one lane per block ROW: a row of int16 arrives as packed pairs (one 8- or
+// 16-byte load, lane-contiguous), an output is NB / 2 v_dot2_i32_i16 against pairs of matrix entries held in scalar registers with the
+// rounding constant as the initial accumulator; the transposition between (and after / before) the two passes goes through a padded LDS tile:
+// NB 2-byte writes, one 8- or 16-byte read per row.  forward (dct-generic.c:559-579): pass, transpose, pass, transpose; inverse: transpose, pass,
+// transpose, pass.  Four rows per lane (loads of all four in flight at once), 1024 rows per workgroup.
+template <int NB> __global__ void __launch_bounds__(256) dev_transform_rows_kernel(const i16 *in, i16 *out, const long rows_total, const int inverse, const u32 *pairs /* [2][8][4] */)
+{
+  constexpr int R = 4, PW = NB / 2, BS = NB * NB + (NB == 8 ? 8 : 4), BLOCKS = R * 256 / NB, L2 = NB == 4 ? 2 : 3;
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  __shared__ alignas(16) i16 s_t[BLOCKS * BS];
+  const int tid = threadIdx.x;
+  u32 cp[NB][PW];
+  for (int k = 0; k < NB; k++) for (int i = 0; i < PW; i++) cp[k][i] = pairs[(inverse ? 32 : 0) + k * 4 + i];
+  u32 p[R][PW];
+  long row[R];
+  int base[R];  // element offset of the row's block in the tile
+  const int r = tid % NB;  // the row's index in its block (256 is a multiple of NB: the same for all four)
+#pragma unroll
+  for (int q = 0; q < R; q++) {
+    row[q] = ((long)blockIdx.x * R + q) * 256 + tid;
+    base[q] = ((q * 256 + tid) / NB) * BS;
+    for (int i = 0; i < PW; i++) p[q][i] = 0;
+    if (row[q] < rows_total) {
+      if (NB == 8) { const uint4 v = reinterpret_cast<const uint4 *>(in)[row[q]]; p[q][0] = v.x; p[q][1] = v.y; p[q][PW - 2] = v.z; p[q][PW - 1] = v.w; }
+      else { const uint2 v = reinterpret_cast<const uint2 *>(in)[row[q]]; p[q][0] = v.x; p[q][1] = v.y; }
+    }
+  }
+  auto pass = [&](const u32 *x, int shift, bool clip, int *y) {
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+      int acc = 1 << (shift - 1);
+#pragma unroll
+      for (int i = 0; i < PW; i++) acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, x[i]), __builtin_bit_cast(s16x2, cp[k][i]), acc, false);
+      acc >>= shift;
+      y[k] = clip ? iclip(-32768, 32767, acc) : acc;
+    }
+  };
+  auto put = [&](int q, const int *y) {  // element e of the lane's row -> [e][row]
+#pragma unroll
+    for (int e = 0; e < NB; e++) s_t[base[q] + e * NB + r] = (i16)y[e];
+  };
+  auto get = [&](int q, u32 *x) {    // the lane's row of the tile
+    const i16 *src = &s_t[base[q] + r * NB];
+    if (NB == 8) { const uint4 v = *reinterpret_cast<const uint4 *>(src); x[0] = v.x; x[1] = v.y; x[PW - 2] = v.z; x[PW - 1] = v.w; }
+    else { const uint2 v = *reinterpret_cast<const uint2 *>(src); x[0] = v.x; x[1] = v.y; }
+  };
+  int y[NB];
+  if (!inverse) {
+#pragma unroll
+    for (int q = 0; q < R; q++) { pass(p[q], L2 - 1, false, y); put(q, y); }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < R; q++) get(q, p[q]);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < R; q++) { pass(p[q], L2 + 6, false, y); put(q, y); }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < R; q++) get(q, p[q]);
+  } else {
+#pragma unroll
+    for (int q = 0; q < R; q++) { for (int e = 0; e < NB; e++) y[e] = (int)(i16)(p[q][e >> 1] >> (16 * (e & 1))); put(q, y); }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < R; q++) get(q, p[q]);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < R; q++) { pass(p[q], 7, true, y); put(q, y); }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      u32 x[PW];
+      get(q, x);
+      pass(x, 12, true, y);
+      for (int i = 0; i < PW; i++) p[q][i] = __builtin_amdgcn_perm((u32)y[2 * i + 1], (u32)y[2 * i], 0x05040100u);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < R; q++)
+    if (row[q] < rows_total) {
+      if (NB == 8) reinterpret_cast<uint4 *>(out)[row[q]] = make_uint4(p[q][0], p[q][1], p[q][PW - 2], p[q][PW - 1]);
+      else reinterpret_cast<uint2 *>(out)[row[q]] = make_uint2(p[q][0], p[q][1]);
+    }
+}
+
 // 4- and 8-point transforms (and the 4x4 DST): 16 / n blocks sit on the diagonal of one 16x16 problem, the matrix is the
 // matching block-diagonal one (Tables::bd_i8), everything else as above.  Off-diagonal results are exact zeros and never stored.
 template <int NB /* block size: 4 or 8 */> __global__ void __launch_bounds__(256)
@@ -318,8 +403,7 @@ dev_sad_surface_kernel(const u8 *cur, const u8 *ref, const int W, const int H, c
 // value (sao.c:324-349).  One lane per 4 samples of a plane row: dword load of the centre, byte loads of the six outer
 // neighbours it does not already hold, dword store; one workgroup per plane row.
 // Per (frame, CTU, plane) parameter record in 8 bytes: type | class | band position | offsets[0..4]
-// One workgroup per CTU (blockIdx = CTU column | CTU row | frame), 16 (luma) or 8 (chroma) lanes across a block row.
-// Four samples per lane, two per 32-bit operation: the bytes of the centre dword and of the two neighbour
+// One wavefront per CTU (blockIdx = group of four CTU columns | CTU row | frame).  Sixteen samples per lane, two per 32-bit operation: the bytes of the centre dword and of the two neighbour
 // dwords (unaligned loads at the class's displacement) are spread over 16-bit halves (even / odd bytes), sign(c - n) + 1 = clamp(c + 1 - n, 0, 2)
 // is three packed instructions per neighbour and pair, and the category -> offset table of the CTU's record is applied to all four samples by
 // two v_perm_b32 (byte look-ups); band offsets use the same look-up on clamp(band - position + 1, 0, 5).
@@ -340,14 +424,27 @@ __device__ __forceinline__ u32 sao_sign_idx(u32 c4, u32 a4, u32 b4)  // per byte
   const dev_pk16 ie = sg(ce, a4 & 0x00ff00ffu) + sg(ce, b4 & 0x00ff00ffu), io = sg(co, (a4 >> 8) & 0x00ff00ffu) + sg(co, (b4 >> 8) & 0x00ff00ffu);
   return __builtin_bit_cast(u32, ie) | (__builtin_bit_cast(u32, io) << 8);
 }
-__global__ void __launch_bounds__(256) dev_sao_kernel(const u8 *in, u8 *out, const int W, const int H, const unsigned long long *packed, const kvz_hip_sao_params *luma,
-                                                      const kvz_hip_sao_params *chroma)
+// 128-bit helpers: four dwords = sixteen samples
+__device__ __forceinline__ uint4 load_u128_any(const u8 *p) { uint4 v; __builtin_memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ uint4 shl8_u128(uint4 v)  // byte k <- byte k - 1
 {
-  // One workgroup per CTU, six passes of 256 dwords: luma rows 0-15, 16-31, 32-47, 48-63 (16 lanes across), U, V (8 lanes across, 32 rows).  The
-  // parameter record of a pass -- type, class, offsets -- is uniform, so no lane ever runs another CTU's branch; all loads of all passes are
-  // issued before the first result is computed (a pass alone has too few bytes in flight to cover the memory latency).
-  const int cxi = blockIdx.x, cyi = blockIdx.y, frame = blockIdx.z, tid = threadIdx.x;
+  return make_uint4(v.x << 8, __builtin_amdgcn_alignbyte(v.y, v.x, 3), __builtin_amdgcn_alignbyte(v.z, v.y, 3), __builtin_amdgcn_alignbyte(v.w, v.z, 3));
+}
+__device__ __forceinline__ uint4 shr8_u128(uint4 v)  // byte k <- byte k + 1
+{
+  return make_uint4(__builtin_amdgcn_alignbyte(v.y, v.x, 1), __builtin_amdgcn_alignbyte(v.z, v.y, 1), __builtin_amdgcn_alignbyte(v.w, v.z, 1), v.w >> 8);
+}
+// TAIL: plane widths that are not multiples of 16 (the last lane of a row then holds 4, 8 or 12 samples, moved as single dwords)
+template <bool TAIL> __global__ void __launch_bounds__(256) dev_sao_kernel(const u8 *in, u8 *out, const int W, const int H, const unsigned long long *packed, const kvz_hip_sao_params *luma,
+                                                                          const kvz_hip_sao_params *chroma)
+{
+  // One wavefront per CTU, four horizontally adjacent CTUs per workgroup (their rows share 128-byte lines), sixteen samples per lane and
+  // pass: luma in four passes of 16 rows (4 lanes across a row), U and V in one pass each (2 lanes across, 32 rows).  The parameter record
+  // of a pass -- type, class, offsets -- is uniform over the wavefront, so no lane ever runs another CTU's branch.  Phase 1 only issues the
+  // loads of all six passes (nothing in it consumes a loaded value), phase 2 computes and stores.
+  const int lane = threadIdx.x & 63, cxi = blockIdx.x * 4 + (threadIdx.x >> 6), cyi = blockIdx.y, frame = blockIdx.z;
   const int wc = (W + 63) >> 6, hc = (H + 63) >> 6;
+  if (cxi >= wc) return;
   const long frame_off = (long)frame * ((long)W * H * 3 / 2);
   // The records: packed by the SAO decision kernels of the batch (kvz_sao.hpp SaoRec), or built here from the caller's parameter structures
   const long ctu = (long)frame * wc * hc + (long)cyi * wc + cxi;
@@ -362,33 +459,38 @@ __global__ void __launch_bounds__(256) dev_sao_kernel(const u8 *in, u8 *out, con
       rec3[c] = v;
     }
   }
-  u32 c4[6], a4[6], b4[6], keep[6];
-  long at[6];  // byte index of the pass's dword, -1: outside the picture
+  uint4 c16[6], a16[6], b16[6];
+  long at[6];      // byte index of the pass's first sample, -1: outside the picture
+  int geo[6];      // nvalid (dwords inside the picture) | (adj_a + 1) << 4 | (adj_b + 1) << 8 | first-sample-at-x0 << 12 | last-sample-at-row-end << 13 | row-at-picture-edge << 14
 #pragma unroll
   for (int p = 0; p < 6; p++) {
     const int color = p < 4 ? 0 : p - 3, sh = color ? 1 : 0, fw = W >> sh, fh = H >> sh, bw = 64 >> sh;
     const long plane = frame_off + (color == 0 ? 0 : (color == 1 ? (long)W * H : (long)W * H * 5 / 4));
     const u32 rlo = (u32)rec3[color];
     const int type = (int)(rlo & 0xff), cls = (int)((rlo >> 8) & 0xff);
-    const int x = cxi * bw + 4 * (color ? tid & 7 : tid & 15), y = cyi * bw + (color ? tid >> 3 : (tid >> 4) + 16 * p);
-    at[p] = -1; c4[p] = a4[p] = b4[p] = 0; keep[p] = 0xffffffffu;
+    const int x = cxi * bw + 16 * (color ? lane & 1 : lane & 3), y = cyi * bw + (color ? lane >> 1 : (lane >> 2) + 16 * p);
+    at[p] = -1; geo[p] = 0;
+    c16[p] = a16[p] = b16[p] = make_uint4(0, 0, 0, 0);
     if (x < fw && y < fh) {
       const u8 *row = in + plane + (long)y * fw;
+      const int nvalid = (!TAIL || fw - x >= 16) ? 4 : (fw - x) >> 2;
       at[p] = plane + (long)y * fw + x;
-      c4[p] = *reinterpret_cast<const u32 *>(row + x);
-      if (type == 2) {
-        const int dx = cls == 1 ? 0 : (cls == 3 ? 1 : -1);           // a = (dx, -1 or 0), b = (-dx, +1 or 0)  (sao.h:71-76)
-        // clamped rows: samples whose neighbour row is outside keep their value
-        const int ra = (cls == 0 || y == 0) ? 0 : -fw, rb = (cls == 0 || y + 1 == fh) ? 0 : fw;
-        // neighbour dwords; at the ends of the row the load is moved inside the row and the bytes shifted into place (the byte that falls
-        // off belongs to a sample that keeps its value)
-        const int adj_a = (x + dx < 0) ? 1 : ((x + dx + 4 > fw) ? -1 : 0), adj_b = (x - dx < 0) ? 1 : ((x - dx + 4 > fw) ? -1 : 0);
-        a4[p] = load_u32_any(row + ra + x + dx + adj_a); b4[p] = load_u32_any(row + rb + x - dx + adj_b);
-        a4[p] = adj_a > 0 ? a4[p] << 8 : (adj_a < 0 ? a4[p] >> 8 : a4[p]);
-        b4[p] = adj_b > 0 ? b4[p] << 8 : (adj_b < 0 ? b4[p] >> 8 : b4[p]);
-        // samples with a neighbour outside the picture keep their value (sao.c:324-349)
-        if (cls != 0 && (y == 0 || y + 1 == fh)) keep[p] = 0;
-        if (cls != 1) { if (x == 0) keep[p] &= 0xffffff00u; if (x + 4 == fw) keep[p] &= 0x00ffffffu; }
+      const int dx = cls == 1 ? 0 : (cls == 3 ? 1 : -1);           // a = (dx, -1 or 0), b = (-dx, +1 or 0)  (sao.h:71-76)
+      // clamped rows: samples whose neighbour row is outside keep their value
+      const int ra = (cls == 0 || y == 0) ? 0 : -fw, rb = (cls == 0 || y + 1 == fh) ? 0 : fw;
+      // neighbour samples; at the ends of the row the load is moved inside the row and the bytes shifted into place in phase 2 (the byte
+      // that falls off belongs to a sample that keeps its value)
+      const int last = x + 4 * nvalid;  // one past the last valid sample of this lane
+      const int adj_a = (x + dx < 0) ? 1 : ((last + dx > fw) ? -1 : 0), adj_b = (x - dx < 0) ? 1 : ((last - dx > fw) ? -1 : 0);
+      geo[p] = nvalid | ((adj_a + 1) << 4) | ((adj_b + 1) << 8) | ((x == 0) << 12) | ((last == fw) << 13) | ((y == 0 || y + 1 == fh) << 14);
+      const u8 *pa = row + ra + x + dx + adj_a, *pb = row + rb + x - dx + adj_b;
+      if (!TAIL || nvalid == 4) {
+        c16[p] = *reinterpret_cast<const uint4 *>(row + x);
+        if (type == 2) { a16[p] = load_u128_any(pa); b16[p] = load_u128_any(pb); }
+      } else {
+        if (nvalid > 0) { c16[p].x = *reinterpret_cast<const u32 *>(row + x); if (type == 2) { a16[p].x = load_u32_any(pa); b16[p].x = load_u32_any(pb); } }
+        if (nvalid > 1) { c16[p].y = *reinterpret_cast<const u32 *>(row + x + 4); if (type == 2) { a16[p].y = load_u32_any(pa + 4); b16[p].y = load_u32_any(pb + 4); } }
+        if (nvalid > 2) { c16[p].z = *reinterpret_cast<const u32 *>(row + x + 8); if (type == 2) { a16[p].z = load_u32_any(pa + 8); b16[p].z = load_u32_any(pb + 8); } }
       }
     }
   }
@@ -397,26 +499,56 @@ __global__ void __launch_bounds__(256) dev_sao_kernel(const u8 *in, u8 *out, con
     const int color = p < 4 ? 0 : p - 3;
     const unsigned long long rec = rec3[color];
     const u32 rlo = (u32)rec, rhi = (u32)(rec >> 32);             // bytes: type, class, band position, offsets[0] | offsets[1..4]
-    const int type = (int)(rlo & 0xff);
+    const int type = (int)(rlo & 0xff), cls = (int)((rlo >> 8) & 0xff);
     if (at[p] < 0) continue;
-    u32 result = c4[p];
-    if (type == 1) {
-      const u32 bh = (1u - ((rlo >> 16) & 0xff)) & 0xffffu;
-      const dev_pk16 bias = __builtin_bit_cast(dev_pk16, bh | (bh << 16));  // + 1 - band position in both halves
-      const u32 band = (c4[p] >> 3) & 0x1f1f1f1fu;
-      const dev_pk16 lo = { 0, 0 }, five = { 5, 5 };
-      const dev_pk16 te = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(dev_pk16, band & 0x00ff00ffu) + bias, lo), five);
-      const dev_pk16 to = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(dev_pk16, (band >> 8) & 0x00ff00ffu) + bias, lo), five);
-      const u32 t4 = __builtin_bit_cast(u32, te) | (__builtin_bit_cast(u32, to) << 8);
-      const u32 sel = __builtin_amdgcn_perm(0x00000c07u, 0x0605040cu, t4);  // 0 -> zero, 1..4 -> offsets[1..4], 5 -> zero
-      result = sao_add_offsets(c4[p], __builtin_amdgcn_perm(rhi, rlo, sel));
-    } else if (type == 2) {
-      const u32 idx4 = sao_sign_idx(c4[p], a4[p], b4[p]);
-      const u32 sel = __builtin_amdgcn_perm(0x00000007u, 0x06030504u, idx4);  // {1,2,0,3,4}[idx] as byte positions of the record
-      result = sao_add_offsets(c4[p], __builtin_amdgcn_perm(rhi, rlo, sel) & keep[p]);
+    const int nvalid = geo[p] & 15, adj_a = ((geo[p] >> 4) & 3) - 1, adj_b = ((geo[p] >> 8) & 3) - 1;
+    u32 res[4];
+    uint4 a = a16[p], b = b16[p];
+    u32 keep_first = 0xffffffffu, keep_last = 0xffffffffu, whole = 0xffffffffu;
+    if (type == 2) {
+      if (adj_a > 0) a = shl8_u128(a); else if (adj_a < 0) a = shr8_u128(a);
+      if (adj_b > 0) b = shl8_u128(b); else if (adj_b < 0) b = shr8_u128(b);
+      // samples with a neighbour outside the picture keep their value (sao.c:324-349)
+      if (cls != 0 && ((geo[p] >> 14) & 1)) whole = 0;
+      if (cls != 1) { if ((geo[p] >> 12) & 1) keep_first = 0xffffff00u; if ((geo[p] >> 13) & 1) keep_last = 0x00ffffffu; }
     }
-    *reinterpret_cast<u32 *>(out + at[p]) = result;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const u32 c4 = i == 0 ? c16[p].x : (i == 1 ? c16[p].y : (i == 2 ? c16[p].z : c16[p].w));
+      const u32 a4 = i == 0 ? a.x : (i == 1 ? a.y : (i == 2 ? a.z : a.w)), b4 = i == 0 ? b.x : (i == 1 ? b.y : (i == 2 ? b.z : b.w));
+      res[i] = c4;
+      if (type == 1) {
+        const u32 bh = (1u - ((rlo >> 16) & 0xff)) & 0xffffu;
+        const dev_pk16 bias = __builtin_bit_cast(dev_pk16, bh | (bh << 16));  // + 1 - band position in both halves
+        const u32 band = (c4 >> 3) & 0x1f1f1f1fu;
+        const dev_pk16 lo = { 0, 0 }, five = { 5, 5 };
+        const dev_pk16 te = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(dev_pk16, band & 0x00ff00ffu) + bias, lo), five);
+        const dev_pk16 to = __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(dev_pk16, (band >> 8) & 0x00ff00ffu) + bias, lo), five);
+        const u32 t4 = __builtin_bit_cast(u32, te) | (__builtin_bit_cast(u32, to) << 8);
+        const u32 sel = __builtin_amdgcn_perm(0x00000c07u, 0x0605040cu, t4);  // 0 -> zero, 1..4 -> offsets[1..4], 5 -> zero
+        res[i] = sao_add_offsets(c4, __builtin_amdgcn_perm(rhi, rlo, sel));
+      } else if (type == 2) {
+        const u32 idx4 = sao_sign_idx(c4, a4, b4);
+        const u32 sel = __builtin_amdgcn_perm(0x00000007u, 0x06030504u, idx4);  // {1,2,0,3,4}[idx] as byte positions of the record
+        u32 keep = whole;
+        if (i == 0) keep &= keep_first;
+        if (i == nvalid - 1) keep &= keep_last;
+        res[i] = sao_add_offsets(c4, __builtin_amdgcn_perm(rhi, rlo, sel) & keep);
+      }
+    }
+    if (!TAIL || nvalid == 4) *reinterpret_cast<uint4 *>(out + at[p]) = make_uint4(res[0], res[1], res[2], res[3]);
+    else {
+      if (nvalid > 0) *reinterpret_cast<u32 *>(out + at[p]) = res[0];
+      if (nvalid > 1) *reinterpret_cast<u32 *>(out + at[p] + 4) = res[1];
+      if (nvalid > 2) *reinterpret_cast<u32 *>(out + at[p] + 8) = res[2];
+    }
   }
+}
+inline void launch_sao(hipStream_t stream, const u8 *in, u8 *out, int W, int H, int n_frames, const unsigned long long *packed, const kvz_hip_sao_params *luma, const kvz_hip_sao_params *chroma)
+{
+  const dim3 grid((unsigned)((((W + 63) >> 6) + 3) >> 2), (unsigned)((H + 63) >> 6), (unsigned)n_frames);
+  if ((W >> 1) % 16 == 0) hipLaunchKernelGGL(dev_sao_kernel<false>, grid, dim3(256), 0, stream, in, out, W, H, packed, luma, chroma);
+  else hipLaunchKernelGGL(dev_sao_kernel<true>, grid, dim3(256), 0, stream, in, out, W, H, packed, luma, chroma);
 }
 
 struct DeblockGeom { int W, H, beta, tc, tc_c; long frame_bytes; const u8 *cu_depth; const kvz_hip_cu_dbk *info; int slice_b, tc1; /* inter pictures: per-4x4 records, tc at strength 1 */ };
@@ -744,6 +876,7 @@ void kvz_hip_dev_download(void *h, const void *d, size_t n)
   KVZ_HIP_CHECK(hipStreamSynchronize(be().stream));
 }
 void kvz_hip_dev_sync(void) { KVZ_HIP_CHECK(hipStreamSynchronize(be().stream)); }
+void kvz_hip_dev_copy(void *d, const void *s, size_t n) { KVZ_HIP_CHECK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, be().stream)); }
 void kvz_hip_dev_timer_start(void)
 {
   kvz::DevTimer &t = kvz::dev_timer();
@@ -806,6 +939,14 @@ void kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *o
     const long threads = ((long)count + 3) / 4 * 256;
     if (n == 16) KVZ_DEV_LAUNCH(kvz::dev_transform_mfma_kernel<16>, threads, in, out, count, inverse, kvz::device_tables());
     else KVZ_DEV_LAUNCH(kvz::dev_transform_mfma_kernel<32>, threads, in, out, count, inverse, kvz::device_tables());
+    return;
+  }
+  if (use_matrix_cores == 1) {  // the small sizes run on the vector ALU (v_dot2_i32_i16); use_matrix_cores == 2 keeps the block-diagonal MFMA form for A/B
+    const kvz::Tables *tb = kvz::device_tables();
+    const int kind_sp = idx == 4 ? 2 : (n == 8 ? 1 : 0);
+    const long rows = (long)count * n, threads = (rows + 1023) / 1024 * 256;
+    if (n == 4) KVZ_DEV_LAUNCH(kvz::dev_transform_rows_kernel<4>, threads, in, out, rows, inverse, &tb->small_pairs[kind_sp][0][0][0]);
+    else KVZ_DEV_LAUNCH(kvz::dev_transform_rows_kernel<8>, threads, in, out, rows, inverse, &tb->small_pairs[kind_sp][0][0][0]);
     return;
   }
   if (use_matrix_cores) {
@@ -890,7 +1031,7 @@ void kvz_hip_dev_sao_frames(const uint8_t *in, uint8_t *out, int width, int heig
                             const kvz_hip_sao_params *chroma)
 {
   if (n_frames <= 0) return;
-  hipLaunchKernelGGL(kvz::dev_sao_kernel, dim3((unsigned)((width + 63) >> 6), (unsigned)((height + 63) >> 6), (unsigned)n_frames), dim3(256), 0, be().stream, in, out, width, height, (const unsigned long long *)nullptr, luma, chroma);
+  kvz::launch_sao(be().stream, in, out, width, height, n_frames, nullptr, luma, chroma);
   KVZ_HIP_CHECK(hipGetLastError());
 }
 
@@ -938,7 +1079,7 @@ void kvz_hip_batch_loop_filters(kvz_hip_batch *b, const kvz_hip_intra_cost_model
   hipLaunchKernelGGL(kvz::dev_sao_chain_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, b->stream, (const kvz::SaoStats *)b->d_sao_stats, (const kvz::SaoCand *)b->d_sao_cand, g, n, b->d_sao_fbits, kvz::device_tables(),
                      model->lambda, (int)model->ctx_init[KVZ_HIP_CX_SAO_MERGE], (int)model->ctx_init[KVZ_HIP_CX_SAO_TYPE], model->no_wpp, b->d_sao_recs, b->d_sao_merge);
   // the SAO'd picture becomes the batch's reconstruction (R is not needed any more)
-  hipLaunchKernelGGL(kvz::dev_sao_kernel, dim3((unsigned)F.wc, (unsigned)F.hc, (unsigned)n), dim3(256), 0, b->stream, b->d_dbk, b->d_rec, F.W, F.H, b->d_sao_recs, (const kvz_hip_sao_params *)nullptr, (const kvz_hip_sao_params *)nullptr);
+  kvz::launch_sao(b->stream, b->d_dbk, b->d_rec, F.W, F.H, n, b->d_sao_recs, nullptr, nullptr);
   KVZ_HIP_CHECK(hipGetLastError());
 }
 

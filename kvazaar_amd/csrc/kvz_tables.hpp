@@ -140,6 +140,15 @@ inline void build_tables(Tables *t)
           t->bd_sum[kind][1][g * n + j] += m[k * n + j];
         }
   }
+  for (int kind = 0; kind < 3; kind++) {
+    const int n = kind == 1 ? 8 : 4;
+    const i16 *m = kind == 2 ? t->dst4 : t->dct[kind == 1 ? 1 : 0];
+    for (int k = 0; k < n; k++)
+      for (int i = 0; i < n / 2; i++) {
+        t->small_pairs[kind][0][k][i] = (u32)(u16)m[k * n + 2 * i] | ((u32)(u16)m[k * n + 2 * i + 1] << 16);
+        t->small_pairs[kind][1][k][i] = (u32)(u16)m[(2 * i) * n + k] | ((u32)(u16)m[(2 * i + 1) * n + k] << 16);
+      }
+  }
   for (int type = 0; type < 3; type++)
     for (int l2 = 2; l2 <= 5; l2++) {
       const int size = 1 << l2, cgs = size / 4;

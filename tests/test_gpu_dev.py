@@ -60,7 +60,7 @@ def test_dev_empty_batch(dev):
 
 
 @pytest.mark.parametrize("name", sorted(devapi.TRANSFORM_KINDS))
-@pytest.mark.parametrize("mfma", [0, 1])
+@pytest.mark.parametrize("mfma", [0, 1, 2])
 def test_dev_transform(oracle, dev, name, mfma):
     kind = devapi.TRANSFORM_KINDS[name]
     n = devapi.TRANSFORM_SIZE[kind]
