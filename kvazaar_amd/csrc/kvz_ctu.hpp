@@ -409,15 +409,21 @@ template <bool CABAC, bool S32 = false> struct CtuProgramT {
     return bin == (st & 1) ? mps : lps;
   }
   // copy of a context set: the residual-coding part only matters (and only moves) when coefficients are priced with the CABAC model
+  // (all words are read before the first one is written: one lane does this, and with stores in between the compiler has to assume that the
+  // two sets overlap and waits for every LDS round trip)
   KVZ_DEV void ctx_copy(CtxSet *dst, const CtxSet *src) const
   {
-    const int n = cabac_on() ? 37 : 3;
-    for (int i = 0; i < n; i++) ((unsigned *)dst->s)[i] = ((const unsigned *)src->s)[i];
+    constexpr int n = CABAC ? 37 : 3;
+    unsigned t[n];
+    for (int i = 0; i < n; i++) t[i] = ((const unsigned *)src->s)[i];
+    for (int i = 0; i < n; i++) ((unsigned *)dst->s)[i] = t[i];
   }
   KVZ_DEV void ctx_swap(CtxSet *a, CtxSet *b) const
   {
-    const int n = cabac_on() ? 37 : 3;
-    for (int i = 0; i < n; i++) { const unsigned t = ((unsigned *)a->s)[i]; ((unsigned *)a->s)[i] = ((unsigned *)b->s)[i]; ((unsigned *)b->s)[i] = t; }
+    constexpr int n = CABAC ? 37 : 3;
+    unsigned ta[n], tb2[n];
+    for (int i = 0; i < n; i++) { ta[i] = ((const unsigned *)a->s)[i]; tb2[i] = ((const unsigned *)b->s)[i]; }
+    for (int i = 0; i < n; i++) { ((unsigned *)a->s)[i] = tb2[i]; ((unsigned *)b->s)[i] = ta[i]; }
   }
   // lambda_sqrt * kvz_luma_mode_bits of the three possible outcomes at the current state of the intra-mode context; the rough
   // search prices with it without touching the context (search_intra.c:524: search_cabac.update == 0 there).  One lane.
