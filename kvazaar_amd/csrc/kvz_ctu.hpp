@@ -629,16 +629,26 @@ template <bool CABAC, bool S32 = false> struct CtuProgramT {
   // even the significance flags are priced by their lanes and summed with DPP.  Prices are accumulated in Q15 integers -- every
   // table entry is a multiple of 2^-15 -- so the sum is exact and order-free, and equals the double sum of the one-lane version.
   KVZ_DEV static int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-  // The state machine of the residual contexts in REGISTERS for the duration of one block: lane L holds contexts L, L + 64 and
-  // L + 128 (one byte each) of the 136, entry L of the LPS transition table and entries L / L + 64 of the price table (as Q15
-  // integers).  A bin is then v_readlane with scalar lane selects, one predicated move and a few scalar ALU operations -- no LDS round
-  // trip on the chain from one bin's state to the next.
-  struct WaveCtx { int st, lps; unsigned ent_lo, ent_hi; };
+  // The state machine of the residual contexts in REGISTERS for the duration of one block, one context per lane and register so that a bin is
+  // v_readlane / v_writelane with a scalar lane number and a handful of scalar operations -- no LDS round trip, no byte insertion on the chain
+  // from one bin's state to the next.  Three registers, every class of contexts inside one of them (r = index - KVZ_HIP_CX_SIG_CG):
+  //   a: lanes 0..45 = r 0..45 (coded-group flags, significance luma / chroma), 46..51 = r 130..135 (greater-2 luma / chroma),
+  //      52..59 = r 122..129 (greater-1 chroma);   b: lanes 0..59 = r 46..105 (last position y / x, luma / chroma);   c: lanes 0..15 = r 106..121 (greater-1 luma)
+  // plus entry L of the LPS transition table and entries L / L + 64 of the price table (as Q15 integers).
+  struct WaveCtx { int a, b, c, lps; unsigned ent_lo, ent_hi; };
+  enum { KVZ_WREG_A = 0, KVZ_WREG_B = 1, KVZ_WREG_C = 2 };
+  KVZ_DEV static int wave_r_of(int reg, int lane)  // the context a lane of a register holds, -1: none
+  {
+    if (reg == KVZ_WREG_A) return lane < 46 ? lane : (lane < 52 ? 130 + (lane - 46) : (lane < 60 ? 122 + (lane - 52) : -1));
+    if (reg == KVZ_WREG_B) return lane < 60 ? 46 + lane : -1;
+    return lane < 16 ? 106 + lane : -1;
+  }
   KVZ_DEV WaveCtx wave_ctx_load(const CtxSet *c, int lane) const
   {
     WaveCtx w;
     const u8 *r = c->s + KVZ_HIP_CX_SIG_CG;
-    w.st = (int)r[lane] | ((int)r[lane + 64] << 8) | (lane < 8 ? (int)r[lane + 128] << 16 : 0);
+    const int ra = wave_r_of(KVZ_WREG_A, lane), rb = wave_r_of(KVZ_WREG_B, lane), rc = wave_r_of(KVZ_WREG_C, lane);
+    w.a = ra >= 0 ? (int)r[ra] : 0; w.b = rb >= 0 ? (int)r[rb] : 0; w.c = rc >= 0 ? (int)r[rc] : 0;
     w.lps = s->ctx_lps[lane];
     w.ent_lo = (unsigned)(s->entropy_fbits[lane] * 32768.0f);
     w.ent_hi = (unsigned)(s->entropy_fbits[lane + 64] * 32768.0f);
@@ -655,22 +665,28 @@ template <bool CABAC, bool S32 = false> struct CtuProgramT {
   {
     u8 *r = c->s + KVZ_HIP_CX_SIG_CG;
     const bool chroma = type != 0;
-    if (ctx_is_chroma(lane) == chroma) r[lane] = (u8)w.st;
-    if (ctx_is_chroma(lane + 64) == chroma) r[lane + 64] = (u8)(w.st >> 8);
-    if (lane < 8 && ctx_is_chroma(lane + 128) == chroma) r[lane + 128] = (u8)(w.st >> 16);
+    const int ra = wave_r_of(KVZ_WREG_A, lane), rb = wave_r_of(KVZ_WREG_B, lane), rc = wave_r_of(KVZ_WREG_C, lane);
+    if (ra >= 0 && ctx_is_chroma(ra) == chroma) r[ra] = (u8)w.a;
+    if (rb >= 0 && ctx_is_chroma(rb) == chroma) r[rb] = (u8)w.b;
+    if (rc >= 0 && !chroma) r[rc] = (u8)w.c;
   }
-  KVZ_DEV static unsigned bin_q15(WaveCtx &w, bool update, int idx, int bin)
+  // One bin on the context in lane `ln` of register REG: its Q15 price at the current state, and (update) the state transition
+  template <int REG> KVZ_DEV static unsigned bin_q15(WaveCtx &w, bool update, int ln, int bin)
   {
-    const int lane = threadIdx.x & 63;
-    const int r = uni(idx) - KVZ_HIP_CX_SIG_CG, ln = r & 63, sh = (r >> 6) * 8;
-    const int packed = __builtin_amdgcn_readlane(w.st, ln), st = (packed >> sh) & 0xff, e = st ^ bin;
-    const unsigned q = (unsigned)__builtin_amdgcn_readlane((int)((e & 64) ? w.ent_hi : w.ent_lo), e & 63);
+    int &reg = REG == KVZ_WREG_A ? w.a : (REG == KVZ_WREG_B ? w.b : w.c);
+    ln = uni(ln);
+    const int st = __builtin_amdgcn_readlane(reg, ln), e = st ^ bin;
+    const unsigned qlo = (unsigned)__builtin_amdgcn_readlane((int)w.ent_lo, e & 63), qhi = (unsigned)__builtin_amdgcn_readlane((int)w.ent_hi, e & 63);
     if (update) {
-      const int nxt = bin == (st & 1) ? st + ((st < 124) << 1) : (__builtin_amdgcn_readlane(w.lps, st >> 1) ^ (st & 1));
-      if (lane == ln) w.st = (packed & ~(0xff << sh)) | (nxt << sh);
+      const int lps = __builtin_amdgcn_readlane(w.lps, st >> 1) ^ (st & 1), mps = st + ((st < 124) << 1);
+      const int nxt = uni(bin == (st & 1) ? mps : lps);
+      reg = ((int)(threadIdx.x & 63) != ln) ? reg : nxt;  // a compare and a select with a scalar operand (v_writelane_b32 would need m0 here: two scalar registers exceed the constant bus)
     }
-    return q;
+    return (e & 64) ? qhi : qlo;
   }
+  // lanes of the classes (see WaveCtx): significance flags and coded-group flags sit at their r in register a
+  KVZ_DEV static int wlane_sig(int idx) { return idx - KVZ_HIP_CX_SIG_CG; }
+  KVZ_DEV static int wlane_last(int idx) { return idx - KVZ_HIP_CX_SIG_CG - 46; }
   KVZ_DEV double coeff_cabac_bits_wave(CtxSet *c, bool update, const i16 *coeff, int log2w, int type, int scan) const
   {
     update = update && m->adaptive;
@@ -696,7 +712,7 @@ template <bool CABAC, bool S32 = false> struct CtuProgramT {
       const bool right = gx < side - 1 && ((sig >> (g + 1)) & 1), lower = gy < side - 1 && ((sig >> (g + side)) & 1);
       bool coded = (sig >> g) & 1;
       if (i == last_group || i == 0) coded = true;
-      else q15 += bin_q15(wc, update, KVZ_HIP_CX_SIG_CG + type + (right || lower), coded);
+      else q15 += bin_q15<KVZ_WREG_A>(wc, update, type + (right || lower), coded);
       if (!coded) continue;
       const int k = lane & 15, r = scan_in_group(scan, k), px = gx * 4 + (r & 3), py = gy * 4 + (r >> 2);
       const int level = lane < 16 ? base[((r >> 2) << log2w) + (r & 3)] : 0;
@@ -713,10 +729,10 @@ template <bool CABAC, bool S32 = false> struct CtuProgramT {
         const unsigned long long gidx_lo = 0x7777666655443210ull;
         const int gxi = lx < 16 ? (int)((gidx_lo >> (4 * lx)) & 15) : (lx < 24 ? 8 : 9), gyi = ly < 16 ? (int)((gidx_lo >> (4 * ly)) & 15) : (ly < 24 ? 8 : 9);
         const int gmax = w - 1 < 16 ? (int)((gidx_lo >> (4 * (w - 1))) & 15) : 9;
-        for (int q = 0; q < gxi; q++) q15 += bin_q15(wc, update, bx + (q >> shift), 1);
-        if (gxi < gmax) q15 += bin_q15(wc, update, bx + (gxi >> shift), 0);
-        for (int q = 0; q < gyi; q++) q15 += bin_q15(wc, update, by + (q >> shift), 1);
-        if (gyi < gmax) q15 += bin_q15(wc, update, by + (gyi >> shift), 0);
+        for (int q = 0; q < gxi; q++) q15 += bin_q15<KVZ_WREG_B>(wc, update, wlane_last(bx) + (q >> shift), 1);
+        if (gxi < gmax) q15 += bin_q15<KVZ_WREG_B>(wc, update, wlane_last(bx) + (gxi >> shift), 0);
+        for (int q = 0; q < gyi; q++) q15 += bin_q15<KVZ_WREG_B>(wc, update, wlane_last(by) + (q >> shift), 1);
+        if (gyi < gmax) q15 += bin_q15<KVZ_WREG_B>(wc, update, wlane_last(by) + (gyi >> shift), 0);
         if (gxi > 3) q15 += (unsigned long long)((gxi - 2) / 2) << 15;
         if (gyi > 3) q15 += (unsigned long long)((gyi - 2) / 2) << 15;
         coded_mask = (1u << k_last) - 1;  // the positions below it; position 0 included (a level has been seen)
@@ -737,7 +753,7 @@ template <bool CABAC, bool S32 = false> struct CtuProgramT {
         for (unsigned mk = coded_mask; mk;) {
           const int kk = uni(31 - __builtin_clz(mk));
           mk &= ~(1u << kk);
-          q15 += bin_q15(wc, true, __builtin_amdgcn_readlane(ctx, kk), (nzmask >> kk) & 1);
+          q15 += bin_q15<KVZ_WREG_A>(wc, true, wlane_sig(__builtin_amdgcn_readlane(ctx, kk)), (nzmask >> kk) & 1);
         }
       }
       const int num = __builtin_popcount(nzmask);
@@ -745,17 +761,16 @@ template <bool CABAC, bool S32 = false> struct CtuProgramT {
         int ctx_set = (i > 0 && type == 0) ? 2 : 0;
         if (c1 == 0) ctx_set++;
         c1 = 1;
-        const int base_one = (type == 0 ? KVZ_HIP_CX_ONE_LUMA : KVZ_HIP_CX_ONE_CHROMA) + 4 * ctx_set;
         int first_c2_abs = -1, cnt = 0;
         for (unsigned mk = nzmask; mk && cnt < 8; cnt++) {  // levels in coding order = from the highest scan position down
           const int kk = uni(31 - __builtin_clz(mk));
           mk &= ~(1u << kk);
           const int a = __builtin_amdgcn_readlane(absval, kk), symbol = a > 1;
-          q15 += bin_q15(wc, update, base_one + c1, symbol);
+          q15 += type == 0 ? bin_q15<KVZ_WREG_C>(wc, update, 4 * ctx_set + c1, symbol) : bin_q15<KVZ_WREG_A>(wc, update, 52 + 4 * ctx_set + c1, symbol);
           if (symbol) { c1 = 0; if (first_c2_abs < 0) first_c2_abs = a; }
           else if (c1 < 3 && c1 > 0) c1++;
         }
-        if (c1 == 0 && first_c2_abs >= 0) q15 += bin_q15(wc, update, (type == 0 ? KVZ_HIP_CX_ABS_LUMA : KVZ_HIP_CX_ABS_CHROMA) + ctx_set, first_c2_abs > 2);
+        if (c1 == 0 && first_c2_abs >= 0) q15 += bin_q15<KVZ_WREG_A>(wc, update, (type == 0 ? 46 : 50) + ctx_set, first_c2_abs > 2);
         int bypass = num;  // signs
         if (c1 == 0 || num > 8) {
           int first_coeff2 = 1, go_rice = 0, q = 0;
