@@ -687,9 +687,125 @@ template <bool CABAC, bool S32 = false> struct CtuProgramT {
   // lanes of the classes (see WaveCtx): significance flags and coded-group flags sit at their r in register a
   KVZ_DEV static int wlane_sig(int idx) { return idx - KVZ_HIP_CX_SIG_CG; }
   KVZ_DEV static int wlane_last(int idx) { return idx - KVZ_HIP_CX_SIG_CG - 46; }
+  // The count with updates off (merge attempts: every bin is priced at the entry state, search.c:1005-1041): no bin depends on another, so
+  // nothing is serial.  Per coded group the sixteen lanes of the scan positions price their own significance and greater-1 flags (the
+  // greater-1 context of the q-th level is 0 once an earlier level exceeded 1, else min(q + 1, 3)), the prefix bins of the last position sit
+  // on lanes 0.. / 16.., and every lane keeps its own Q15 sum -- one wavefront reduction per block.  Only a group with a level above 3 among
+  // its escape-coded levels (the Rice parameter then moves) falls back to the serial bypass count.
+  KVZ_DEV double coeff_cabac_bits_frozen(const CtxSet *c, const i16 *coeff, int log2w, int type, int scan) const
+  {
+    const int lane = threadIdx.x & 63;
+    const int w = 1 << log2w, side = w >> 2, ngroups = side * side;
+    bool any = false;
+    if (lane < ngroups) {
+      const int gy = lane >> (log2w - 2), gx = lane & (side - 1);
+      unsigned long long acc4 = 0;
+      for (int r = 0; r < 4; r++) { unsigned long long four; __builtin_memcpy(&four, coeff + ((gy * 4 + r) << log2w) + gx * 4, 8); acc4 |= four; }
+      any = acc4 != 0;
+    }
+    const unsigned long long sig = __ballot(any);
+    if (!sig) return 0;
+    const unsigned long long ord = __ballot(lane < ngroups && ((sig >> group_of(log2w, scan, lane < ngroups ? lane : 0)) & 1));
+    const int last_group = 63 - __builtin_clzll(ord);
+    auto price = [&](int ctx, int bin) -> unsigned { return (unsigned)(s->entropy_fbits[c->s[ctx] ^ bin] * 32768.0f); };
+    unsigned acc = 0, byp = 0;        // per lane: Q15 price sum, bypass bins
+    unsigned long long bypass = 0;    // wavefront-uniform bypass bins
+    int prev_c1_zero = 0;
+    const int k = lane & 15;
+    for (int i = last_group; i >= 0; i--) {
+      const int g = uni(group_of(log2w, scan, i)), gy = g >> (log2w - 2), gx = g & (side - 1);
+      const i16 *base = coeff + ((gy * 4) << log2w) + gx * 4;
+      const bool right = gx < side - 1 && ((sig >> (g + 1)) & 1), lower = gy < side - 1 && ((sig >> (g + side)) & 1);
+      bool coded = (sig >> g) & 1;
+      if (i == last_group || i == 0) coded = true;
+      else if (lane == 0) acc += price(KVZ_HIP_CX_SIG_CG + type + (right || lower), coded);
+      if (!coded) continue;
+      const int r = scan_in_group(scan, k), px = gx * 4 + (r & 3), py = gy * 4 + (r >> 2);
+      const int level = lane < 16 ? base[((r >> 2) << log2w) + (r & 3)] : 0;
+      const unsigned nzmask = (unsigned)__ballot(level != 0) & 0xffffu;
+      const int absval = iabs(level);
+      unsigned coded_mask;
+      if (i == last_group) {
+        const int k_last = 31 - __builtin_clz(nzmask), rl = scan_in_group(scan, k_last);
+        int lx = gx * 4 + (rl & 3), ly = gy * 4 + (rl >> 2);
+        if (scan == 2) { const int tmp = lx; lx = ly; ly = tmp; }
+        const int index = log2w - 2, ctx_offset = type ? 0 : (index * 3 + (index + 1) / 4), shift = type ? index : (index + 3) / 4;
+        const int bx = (type ? KVZ_HIP_CX_LAST_X_CHROMA : KVZ_HIP_CX_LAST_X_LUMA) + ctx_offset, by = (type ? KVZ_HIP_CX_LAST_Y_CHROMA : KVZ_HIP_CX_LAST_Y_LUMA) + ctx_offset;
+        const unsigned long long gidx_lo = 0x7777666655443210ull;
+        const int gxi = lx < 16 ? (int)((gidx_lo >> (4 * lx)) & 15) : (lx < 24 ? 8 : 9), gyi = ly < 16 ? (int)((gidx_lo >> (4 * ly)) & 15) : (ly < 24 ? 8 : 9);
+        const int gmax = w - 1 < 16 ? (int)((gidx_lo >> (4 * (w - 1))) & 15) : 9;
+        if (lane < gxi || (lane == gxi && gxi < gmax)) acc += price(bx + (lane >> shift), lane < gxi);
+        { const int l2 = lane - 16; if (l2 >= 0 && (l2 < gyi || (l2 == gyi && gyi < gmax))) acc += price(by + (l2 >> shift), l2 < gyi); }
+        if (gxi > 3) bypass += (unsigned long long)((gxi - 2) / 2);
+        if (gyi > 3) bypass += (unsigned long long)((gyi - 2) / 2);
+        coded_mask = (1u << k_last) - 1;
+      } else {
+        coded_mask = 0xffffu;
+        if (i != 0 && !(nzmask & 0xfffeu)) coded_mask &= ~1u;
+      }
+      const int pattern = log2w == 2 ? -1 : (int)right + ((int)lower << 1);
+      if (lane < 16 && ((coded_mask >> k) & 1))
+        acc += price((type == 0 ? KVZ_HIP_CX_SIG_LUMA : KVZ_HIP_CX_SIG_CHROMA) + sig_ctx_inc(pattern, scan, px, py, log2w, type), level != 0);
+      const int num = __builtin_popcount(nzmask);
+      if (num > 0) {
+        const int ctx_set = ((i > 0 && type == 0) ? 2 : 0) + prev_c1_zero;
+        const int base_one = (type == 0 ? KVZ_HIP_CX_ONE_LUMA : KVZ_HIP_CX_ONE_CHROMA) + 4 * ctx_set;
+        const int q = __builtin_popcount(nzmask >> (k + 1));                     // levels coded before this one (higher scan positions)
+        const bool mine = lane < 16 && level != 0;
+        const unsigned first8 = (unsigned)__ballot(mine && q < 8) & 0xffffu;     // the levels that carry a greater-1 flag
+        const unsigned gt1 = (unsigned)__ballot(mine && q < 8 && absval > 1) & 0xffffu;
+        if (mine && q < 8) acc += price(base_one + ((gt1 >> (k + 1)) ? 0 : (q + 1 < 3 ? q + 1 : 3)), absval > 1);
+        (void)first8;
+        if (gt1) {  // the first level above 1 carries the greater-2 flag
+          const int kk = 31 - __builtin_clz(gt1);
+          if (lane == kk) acc += price((type == 0 ? KVZ_HIP_CX_ABS_LUMA : KVZ_HIP_CX_ABS_CHROMA) + ctx_set, absval > 2);
+        }
+        bypass += (unsigned long long)num;  // signs
+        if (gt1 || num > 8) {
+          const unsigned ge2 = (unsigned)__ballot(mine && absval >= 2) & 0xffffu;
+          if (!__ballot(mine && absval > 3)) {  // the Rice parameter stays 0: escape lengths are independent
+            const int base_level = q < 8 ? ((ge2 >> (k + 1)) ? 2 : 3) : 1;
+            if (mine && absval >= base_level) byp += (unsigned)(absval - base_level + 1);  // coeff_remain_bits(symbol <= 2, 0) = symbol + 1
+          } else {
+            int first_coeff2 = 1, go_rice = 0, qq = 0;
+            for (unsigned mk = nzmask; mk; qq++) {
+              const int kk = uni(31 - __builtin_clz(mk));
+              mk &= ~(1u << kk);
+              const int a = __builtin_amdgcn_readlane(absval, kk), base_level = qq < 8 ? 2 + first_coeff2 : 1;
+              if (a >= base_level) {
+                bypass += (unsigned long long)coeff_remain_bits(a - base_level, go_rice);
+                if (a > 3 * (1 << go_rice)) go_rice = go_rice + 1 < 4 ? go_rice + 1 : 4;
+              }
+              if (a >= 2) first_coeff2 = 0;
+            }
+          }
+        }
+        prev_c1_zero = gt1 ? 1 : 0;
+      }
+    }
+    // rows of 16 lanes first (each row's sum fits 32 bits), then the four row totals
+    unsigned x = acc;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+    unsigned y = byp;
+    y += __builtin_amdgcn_update_dpp(0, y, 0x118, 0xF, 0xF, true);
+    y += __builtin_amdgcn_update_dpp(0, y, 0x114, 0xF, 0xF, true);
+    y += __builtin_amdgcn_update_dpp(0, y, 0x112, 0xF, 0xF, true);
+    y += __builtin_amdgcn_update_dpp(0, y, 0x111, 0xF, 0xF, true);
+    unsigned long long q15 = 0;
+    for (int row = 0; row < 4; row++) {
+      q15 += (unsigned)__builtin_amdgcn_readlane((int)x, 16 * row + 15);
+      bypass += (unsigned)__builtin_amdgcn_readlane((int)y, 16 * row + 15);
+    }
+    q15 += bypass << 15;
+    return (double)q15 / 32768.0;
+  }
   KVZ_DEV double coeff_cabac_bits_wave(CtxSet *c, bool update, const i16 *coeff, int log2w, int type, int scan) const
   {
     update = update && m->adaptive;
+    if (!update) return coeff_cabac_bits_frozen(c, coeff, log2w, type, scan);
     const int lane = threadIdx.x & 63;
     const int w = 1 << log2w, side = w >> 2, ngroups = side * side;
     bool any = false;

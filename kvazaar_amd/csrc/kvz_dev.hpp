@@ -310,10 +310,12 @@ template <int L2> __global__ void __launch_bounds__(256) dev_angular_kernel(cons
   if (disp < 0) {
     const int lowest = (W * disp) >> 5, span = W + 1 - lowest;  // indices lowest .. W in use
     const u8 *rm = reinterpret_cast<const u8 *>(s_raw[0]) + mis, *rs = reinterpret_cast<const u8 *>(s_raw[1]) + mis;
-    for (int i = tid; i < nblk * span; i += 256) {
-      const int bb = i / span, k = i - bb * span + lowest;
-      s_ext[bb][k + W] = k >= -1 ? rm[bb * RS + k + 1] : rs[bb * RS + ((128 + (-1 - k) * inv) >> 8)];
-    }
+    constexpr int LPB = BLOCKS >= 256 ? 1 : 256 / BLOCKS;  // lanes per block (no division by the run-time span)
+    for (int bb = tid / LPB; bb < nblk; bb += 256 / LPB)
+      for (int j = tid % LPB; j < span; j += LPB) {
+        const int k = j + lowest;
+        s_ext[bb][k + W] = k >= -1 ? rm[bb * RS + k + 1] : rs[bb * RS + ((128 + (-1 - k) * inv) >> 8)];
+      }
     __syncthreads();
   }
   u32 *out32 = reinterpret_cast<u32 *>(out + blk0 * (W * W));
