@@ -603,37 +603,53 @@ __device__ __forceinline__ int dbk_strength(const DeblockGeom &g, long frame, in
   if (rp0 != rp1) return (rp0 == rq0 ? straight : crossed) ? 1 : 0;
   return (straight && crossed) ? 1 : 0;
 }
-// b[i][k]: sample k (edge between 3 and 4) of line i (filter.c:386-561)
-__device__ __forceinline__ void deblock_luma_lines(int b[4][8], int beta, int tc)
+// Luma filter of one 4-line part (filter.c:386-561): sample k of a line, the edge between k = 3 and k = 4.
+// Two lines per operation: P[p][k] = sample k of lines 2 p (low half) and 2 p + 1 (high half) as int16.  Every intermediate fits
+// 16 bits (|9 (m4 - m3) - 3 (m5 - m2) + 8| <= 3068, sums of up to 8 samples + 4 <= 2044); per-line conditions become 0 / -1 half masks.
+__device__ __forceinline__ dev_pk16 pk_splat(int v) { const dev_pk16 r = { (short)v, (short)v }; return r; }
+__device__ __forceinline__ dev_pk16 pk_abs(dev_pk16 a) { return __builtin_elementwise_max(a, -a); }
+__device__ __forceinline__ dev_pk16 pk_clip(dev_pk16 lo, dev_pk16 hi, dev_pk16 v) { return __builtin_elementwise_min(__builtin_elementwise_max(v, lo), hi); }
+__device__ __forceinline__ dev_pk16 pk_select(dev_pk16 mask, dev_pk16 a, dev_pk16 b)  // mask halves 0 / -1: a where set, else b
 {
-  const int dp0 = iabs(b[0][1] - 2 * b[0][2] + b[0][3]), dq0 = iabs(b[0][4] - 2 * b[0][5] + b[0][6]);
-  const int dp3 = iabs(b[3][1] - 2 * b[3][2] + b[3][3]), dq3 = iabs(b[3][4] - 2 * b[3][5] + b[3][6]);
+  const u32 m = __builtin_bit_cast(u32, mask);
+  return __builtin_bit_cast(dev_pk16, (__builtin_bit_cast(u32, a) & m) | (__builtin_bit_cast(u32, b) & ~m));
+}
+__device__ __forceinline__ void deblock_luma_lines_pk(dev_pk16 P[2][8], int beta, int tc)
+{
+  // decisions on lines 0 and 3 (filter.c:386-561): second differences of every line, then the two that count
+  const dev_pk16 dpA = pk_abs(P[0][1] - P[0][2] - P[0][2] + P[0][3]), dqA = pk_abs(P[0][4] - P[0][5] - P[0][5] + P[0][6]);
+  const dev_pk16 dpB = pk_abs(P[1][1] - P[1][2] - P[1][2] + P[1][3]), dqB = pk_abs(P[1][4] - P[1][5] - P[1][5] + P[1][6]);
+  const int dp0 = dpA.x, dq0 = dqA.x, dp3 = dpB.y, dq3 = dqB.y;
   const int dp = dp0 + dp3, dq = dq0 + dq3;
   if (dp + dq >= beta) return;
+  const int p00 = P[0][0].x, p03 = P[0][3].x, p04 = P[0][4].x, p07 = P[0][7].x, p30 = P[1][0].y, p33 = P[1][3].y, p34 = P[1][4].y, p37 = P[1][7].y;
   const bool strong = 2 * (dp0 + dq0) < (beta >> 2) && 2 * (dp3 + dq3) < (beta >> 2) &&
-                      iabs(b[0][3] - b[0][4]) < ((5 * tc + 1) >> 1) && iabs(b[3][3] - b[3][4]) < ((5 * tc + 1) >> 1) &&
-                      iabs(b[0][0] - b[0][3]) + iabs(b[0][4] - b[0][7]) < (beta >> 3) && iabs(b[3][0] - b[3][3]) + iabs(b[3][4] - b[3][7]) < (beta >> 3);
+                      iabs(p03 - p04) < ((5 * tc + 1) >> 1) && iabs(p33 - p34) < ((5 * tc + 1) >> 1) &&
+                      iabs(p00 - p03) + iabs(p04 - p07) < (beta >> 3) && iabs(p30 - p33) + iabs(p34 - p37) < (beta >> 3);
   const int side = (beta + (beta >> 1)) >> 3;
+  const dev_pk16 zero = pk_splat(0), maxv = pk_splat(255);
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int m0 = b[i][0], m1 = b[i][1], m2 = b[i][2], m3 = b[i][3], m4 = b[i][4], m5 = b[i][5], m6 = b[i][6], m7 = b[i][7];
+  for (int p = 0; p < 2; p++) {
+    const dev_pk16 m0 = P[p][0], m1 = P[p][1], m2 = P[p][2], m3 = P[p][3], m4 = P[p][4], m5 = P[p][5], m6 = P[p][6], m7 = P[p][7];
     if (strong) {
-      b[i][1] = iclip(m1 - 2 * tc, m1 + 2 * tc, (2 * m0 + 3 * m1 + m2 + m3 + m4 + 4) >> 3);
-      b[i][2] = iclip(m2 - 2 * tc, m2 + 2 * tc, (m1 + m2 + m3 + m4 + 2) >> 2);
-      b[i][3] = iclip(m3 - 2 * tc, m3 + 2 * tc, (m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4) >> 3);
-      b[i][4] = iclip(m4 - 2 * tc, m4 + 2 * tc, (m2 + 2 * m3 + 2 * m4 + 2 * m5 + m6 + 4) >> 3);
-      b[i][5] = iclip(m5 - 2 * tc, m5 + 2 * tc, (m3 + m4 + m5 + m6 + 2) >> 2);
-      b[i][6] = iclip(m6 - 2 * tc, m6 + 2 * tc, (m3 + m4 + m5 + 3 * m6 + 2 * m7 + 4) >> 3);
+      const dev_pk16 t2 = pk_splat(2 * tc), c2 = pk_splat(2), c4 = pk_splat(4);
+      const dev_pk16 s34 = m3 + m4;
+      P[p][1] = pk_clip(m1 - t2, m1 + t2, (m0 + m0 + m1 + m1 + m1 + m2 + s34 + c4) >> 3);
+      P[p][2] = pk_clip(m2 - t2, m2 + t2, (m1 + m2 + s34 + c2) >> 2);
+      P[p][3] = pk_clip(m3 - t2, m3 + t2, (m1 + m2 + m2 + s34 + s34 + m5 + c4) >> 3);
+      P[p][4] = pk_clip(m4 - t2, m4 + t2, (m2 + s34 + s34 + m5 + m5 + m6 + c4) >> 3);
+      P[p][5] = pk_clip(m5 - t2, m5 + t2, (s34 + m5 + m6 + c2) >> 2);
+      P[p][6] = pk_clip(m6 - t2, m6 + t2, (s34 + m5 + m6 + m6 + m6 + m7 + m7 + c4) >> 3);
     } else {
-      int delta = (9 * (m4 - m3) - 3 * (m5 - m2) + 8) >> 4;
-      if (iabs(delta) < tc * 10) {
-        const int tc2 = tc >> 1;
-        delta = iclip(-tc, tc, delta);
-        b[i][3] = iclip(0, 255, m3 + delta);
-        b[i][4] = iclip(0, 255, m4 - delta);
-        if (dp < side) b[i][2] = iclip(0, 255, m2 + iclip(-tc2, tc2, (((m1 + m3 + 1) >> 1) - m2 + delta) >> 1));
-        if (dq < side) b[i][5] = iclip(0, 255, m5 + iclip(-tc2, tc2, (((m6 + m4 + 1) >> 1) - m5 - delta) >> 1));
-      }
+      const dev_pk16 d43 = m4 - m3, d52 = m5 - m2;
+      dev_pk16 delta = ((d43 << 3) + d43 - d52 - d52 - d52 + pk_splat(8)) >> 4;
+      const dev_pk16 on = (pk_abs(delta) - pk_splat(tc * 10)) >> 15;  // -1 where |delta| < 10 tc
+      const dev_pk16 tcv = pk_splat(tc), tc2 = pk_splat(tc >> 1), one = pk_splat(1);
+      delta = pk_clip(-tcv, tcv, delta);
+      P[p][3] = pk_select(on, pk_clip(zero, maxv, m3 + delta), m3);
+      P[p][4] = pk_select(on, pk_clip(zero, maxv, m4 - delta), m4);
+      if (dp < side) P[p][2] = pk_select(on, pk_clip(zero, maxv, m2 + pk_clip(-tc2, tc2, ((((m1 + m3 + one) >> 1) - m2 + delta) >> 1))), m2);
+      if (dq < side) P[p][5] = pk_select(on, pk_clip(zero, maxv, m5 + pk_clip(-tc2, tc2, ((((m6 + m4 + one) >> 1) - m5 - delta) >> 1))), m5);
     }
   }
 }
@@ -658,29 +674,39 @@ template <bool VERTICAL> __global__ void __launch_bounds__(256) dev_deblock_luma
     if (strength == 1) tc = g.tc1;
   } else if (!deblock_edge_on(g, frame, x, y, VERTICAL)) return;
   u8 *Y = frames + frame * g.frame_bytes;
-  int b[4][8];
+  dev_pk16 P[2][8];
   if (VERTICAL) {
+    u32 lo[4], hi[4];
     for (int i = 0; i < 4; i++) {
       const u32 *row = reinterpret_cast<const u32 *>(Y + (long)(y + i) * g.W + x - 4);
-      const u32 lo = row[0], hi = row[1];
-      for (int k = 0; k < 4; k++) { b[i][k] = (lo >> (8 * k)) & 0xff; b[i][4 + k] = (hi >> (8 * k)) & 0xff; }
+      lo[i] = row[0]; hi[i] = row[1];
     }
+    for (int p = 0; p < 2; p++)
+      for (int k = 0; k < 4; k++) {  // byte k of line 2 p -> low half, of line 2 p + 1 -> high half
+        const u32 sel = 0x0c000c00u | (u32)k | ((u32)(4 + k) << 16);
+        P[p][k] = __builtin_bit_cast(dev_pk16, __builtin_amdgcn_perm(lo[2 * p + 1], lo[2 * p], sel));
+        P[p][4 + k] = __builtin_bit_cast(dev_pk16, __builtin_amdgcn_perm(hi[2 * p + 1], hi[2 * p], sel));
+      }
   } else {
     for (int k = 0; k < 8; k++) {
       const u32 v = *reinterpret_cast<const u32 *>(Y + (long)(y - 4 + k) * g.W + x);
-      for (int i = 0; i < 4; i++) b[i][k] = (v >> (8 * i)) & 0xff;
+      P[0][k] = __builtin_bit_cast(dev_pk16, __builtin_amdgcn_perm(v, v, 0x0c010c00u));
+      P[1][k] = __builtin_bit_cast(dev_pk16, __builtin_amdgcn_perm(v, v, 0x0c030c02u));
     }
   }
-  deblock_luma_lines(b, g.beta, tc);
+  deblock_luma_lines_pk(P, g.beta, tc);
   if (VERTICAL) {
-    for (int i = 0; i < 4; i++) {
-      u32 *row = reinterpret_cast<u32 *>(Y + (long)(y + i) * g.W + x - 4);
-      row[0] = (u32)b[i][0] | ((u32)b[i][1] << 8) | ((u32)b[i][2] << 16) | ((u32)b[i][3] << 24);
-      row[1] = (u32)b[i][4] | ((u32)b[i][5] << 8) | ((u32)b[i][6] << 16) | ((u32)b[i][7] << 24);
+    for (int p = 0; p < 2; p++) {
+      // halves (k0 | k1 << 8) and (k2 | k3 << 8) of both lines, then one dword per line
+      const u32 a01 = __builtin_bit_cast(u32, P[p][0]) | (__builtin_bit_cast(u32, P[p][1]) << 8), a23 = __builtin_bit_cast(u32, P[p][2]) | (__builtin_bit_cast(u32, P[p][3]) << 8);
+      const u32 a45 = __builtin_bit_cast(u32, P[p][4]) | (__builtin_bit_cast(u32, P[p][5]) << 8), a67 = __builtin_bit_cast(u32, P[p][6]) | (__builtin_bit_cast(u32, P[p][7]) << 8);
+      u32 *r0 = reinterpret_cast<u32 *>(Y + (long)(y + 2 * p) * g.W + x - 4), *r1 = reinterpret_cast<u32 *>(Y + (long)(y + 2 * p + 1) * g.W + x - 4);
+      r0[0] = __builtin_amdgcn_perm(a23, a01, 0x05040100u); r0[1] = __builtin_amdgcn_perm(a67, a45, 0x05040100u);
+      r1[0] = __builtin_amdgcn_perm(a23, a01, 0x07060302u); r1[1] = __builtin_amdgcn_perm(a67, a45, 0x07060302u);
     }
   } else {
     for (int k = 1; k < 7; k++)
-      *reinterpret_cast<u32 *>(Y + (long)(y - 4 + k) * g.W + x) = (u32)b[0][k] | ((u32)b[1][k] << 8) | ((u32)b[2][k] << 16) | ((u32)b[3][k] << 24);
+      *reinterpret_cast<u32 *>(Y + (long)(y - 4 + k) * g.W + x) = __builtin_amdgcn_perm(__builtin_bit_cast(u32, P[1][k]), __builtin_bit_cast(u32, P[0][k]), 0x06040200u);
   }
 }
 // Chroma (filter.c:567-632, 170-190): edges on the 8x8 chroma grid, 4 samples per part, both planes (part index carries the plane)
@@ -722,10 +748,10 @@ inline void deblock_frames_on(hipStream_t stream, u8 *frames, int width, int hei
   g.beta = deblock_beta(iclip(0, 51, qp + 2 * beta_off));
   g.tc = deblock_tc(iclip(0, 53, qp + 2 + 2 * tc_off));                  // filter.c:496-497 with strength 2
   g.tc_c = deblock_tc(iclip(0, 53, chroma_qp_of(qp) + 2 + 2 * tc_off));  // filter.c:592-595
-  const long lv = (long)n_frames * (width >> 3) * (height >> 2), lh = (long)n_frames * (width >> 2) * (height >> 3);
   const int cw = width >> 1, ch = height >> 1;
-  const long cv = 2L * n_frames * ((cw + 7) >> 3) * (ch >> 2), chh = 2L * n_frames * (cw >> 2) * ((ch + 7) >> 3);
   auto grid = [](long n) { return dim3((unsigned)((n + 255) / 256)); };
+  const long lv = (long)n_frames * (width >> 3) * (height >> 2), lh = (long)n_frames * (width >> 2) * (height >> 3);
+  const long cv = 2L * n_frames * ((cw + 7) >> 3) * (ch >> 2), chh = 2L * n_frames * (cw >> 2) * ((ch + 7) >> 3);
   if (lv && (passes & 1)) hipLaunchKernelGGL(dev_deblock_luma_kernel<true>, grid(lv), dim3(256), 0, stream, frames, g, lv);
   if (cv && (passes & 1)) hipLaunchKernelGGL(dev_deblock_chroma_kernel<true>, grid(cv), dim3(256), 0, stream, frames, g, cv);
   if (lh && (passes & 2)) hipLaunchKernelGGL(dev_deblock_luma_kernel<false>, grid(lh), dim3(256), 0, stream, frames, g, lh);

@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-NAMES = ["init", "refs", "replay", "satd", "select", "recon_pred", "fdct", "quant", "idct", "recon", "cost", "copy", "finish", "misc", "coeffbits"]
+NAMES = ["init", "refs", "pred35+replay", "satd", "select", "recon_pred", "fdct", "quant", "idct", "recon", "cost", "copy", "finish", "misc", "coeffbits"]
 
 
 def main():

@@ -13,3 +13,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $repo/gpurun_ou
 cd $repo
 cat gpurun_out/${tag}_bench.json
 find gpurun_out/${tag}_stats gpurun_out/${tag}_pmc_f gpurun_out/${tag}_pmc_w -name "*.csv" | head -20
+# per-kernel view: bench_kernels.py lines and the rocprofv3 kernel stats of the same command
+python bench_kernels.py > gpurun_out/${tag}_micro_kernels.jsonl 2> gpurun_out/${tag}_micro.err
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $repo/gpurun_out/${tag}_micro_stats -o ${tag}_micro -- python $repo/bench_kernels.py --reps 5 > $repo/gpurun_out/${tag}_micro_stats.log 2>&1
+cd $repo
