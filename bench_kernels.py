@@ -172,9 +172,9 @@ def main():
     ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_sad_surface(dc, dr, w, h, bw, rng_, dxy, len(xy), dout), args.reps, args.warmup)
     diffs = len(xy) * side * side * bw * bw / (ms * 1e-3)
     report("sad_surface_16x16_r16", bw, len(xy), ms, bw * bw + (bw + 2 * rng_) ** 2 + 4 * side * side,
-           {"path": "LDS-staged window, v_alignbyte + v_sad_u8", "candidates_per_s": round(len(xy) * side * side / (ms * 1e-3)),
-            "abs_diffs_per_s": round(diffs), "valu_sad_frac": round(diffs / (256 * 4 * 16 * 4 * 2.4e9), 4),
-            "note": "bound: v_sad_u8 issue (4 differences per lane per instruction, 256 CUs x 4 SIMDs x 16 lanes at 2.4 GHz); the window is read from HBM once"})
+           {"path": "LDS-staged window, v_qsad_pk_u16_u8: four candidates x four samples per instruction", "candidates_per_s": round(len(xy) * side * side / (ms * 1e-3)),
+            "abs_diffs_per_s": round(diffs), "qsad_issue_frac": round(diffs / (1024 * 64 * 16 / 1.79e-9), 4),
+            "note": "roof of the arithmetic: 16 differences per lane and v_qsad_pk_u16_u8, one VOP3 wave64 instruction per 1.79 ns and SIMD (profiles/r02_c_valu_issue.jsonl), 1024 SIMDs; the window is read from HBM once"})
     dev.free(dc, dr, dxy, dout)
 
     # fractional motion search: every 16x16 (and 32x32) PU of a 1080p picture, both half-pel steps (`veryfast`: fme_level 2) = 9 SATDs per PU;

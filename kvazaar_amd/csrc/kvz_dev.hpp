@@ -15,6 +15,7 @@
 namespace kvz {
 
 // Sum over aligned groups of G consecutive lanes (G a power of two <= 64); the result is valid in the group's first lane.
+__device__ __forceinline__ u32 load_u32_any(const u8 *p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }  // any byte alignment
 template <int G> __device__ __forceinline__ u32 group_sum(u32 v)
 {
   for (int off = G / 2; off > 0; off >>= 1) v += __shfl_down(v, off, G);
@@ -361,40 +362,57 @@ template <int L2> __global__ void __launch_bounds__(256) dev_angular_kernel(cons
 // Integer-pel motion cost surface: SAD of one BW x BW block of the current picture against the reference at every
 // displacement of a (2 range + 1)^2 window -- kvz_image_calc_sad (image.c:407) per candidate, i.e. the reference is
 // edge-replicated outside the frame (image.c:279-397).  One workgroup per block: the block and the (BW + 2 range)^2 window are
-// staged in LDS once (clamped addressing does the replication), then every lane scores whole candidates: per row it walks
-// aligned dwords of the window, funnel-shifts them to the candidate's column (v_alignbyte_b32) and accumulates v_sad_u8
-// against the block's dwords (a broadcast read).  Window re-use between candidates never touches HBM again.
-template <int BW> __global__ void __launch_bounds__(256)
+// staged in LDS once (clamped addressing does the replication), then a lane scores FOUR horizontally adjacent candidates at a time with
+// v_qsad_pk_u16_u8: one instruction takes 8 window bytes and 4 block bytes and adds the SADs at byte offsets 0, 1, 2, 3 to four packed
+// 16-bit sums -- 16 absolute differences per instruction, and the candidate's column needs no shifting into place.  The 16-bit sums are
+// flushed into 32-bit ones every 256 / BW rows (256 / BW * BW * 255 < 65 536).  Window re-use between candidates never touches HBM again.
+constexpr int kSadSurfaceLanes = 320;  // five wavefronts: the 33 x 9 = 297 groups of a +-16 search fit one round
+template <int BW> __global__ void __launch_bounds__(kSadSurfaceLanes)
 dev_sad_surface_kernel(const u8 *cur, const u8 *ref, const int W, const int H, const int range, const i16 *blk_xy, u32 *out)
 {
-  constexpr int MAXR = 32, WD = (BW + 2 * MAXR + 4) / 4;  // dwords per staged window row
+  constexpr int MAXR = 32, WD = (BW + 2 * MAXR + 8) / 4;  // dwords per staged window row (+ the bytes a partial last group of four reads)
+  constexpr int FL = 256 / BW >= BW ? BW : 256 / BW;       // rows per flush of the 16-bit sums
+  constexpr int NT = kSadSurfaceLanes;
   __shared__ u32 s_cur[BW * BW / 4];
-  __shared__ u32 s_win[(BW + 2 * MAXR) * WD];
+  __shared__ alignas(8) u32 s_win[(BW + 2 * MAXR) * WD];
   const int b = blockIdx.x, bx = blk_xy[2 * b], by = blk_xy[2 * b + 1], side = 2 * range + 1, wrows = BW + 2 * range, wcols = BW + 2 * range;
-  u8 *cur8 = reinterpret_cast<u8 *>(s_cur), *win8 = reinterpret_cast<u8 *>(s_win);
-  for (int i = threadIdx.x; i < BW * BW; i += 256) cur8[i] = cur[(long)(by + i / BW) * W + bx + i % BW];
-  for (int i = threadIdx.x; i < wrows * wcols; i += 256) {
-    const int r = i / wcols, c = i % wcols;
-    const int y = iclip(0, H - 1, by - range + r), x = iclip(0, W - 1, bx - range + c);
-    win8[r * (WD * 4) + c] = ref[(long)y * W + x];
+  u8 *win8 = reinterpret_cast<u8 *>(s_win);
+  for (int i = threadIdx.x; i < BW * BW / 4; i += NT) s_cur[i] = load_u32_any(cur + (long)(by + i / (BW / 4)) * W + bx + 4 * (i % (BW / 4)));
+  const int wdw = (wcols + 3) >> 2;  // dwords of a window row that hold samples
+  if (bx - range >= 0 && bx - range + 4 * wdw <= W && by - range >= 0 && by - range + wrows <= H) {  // the window lies inside the picture: dword copies
+    for (int i = threadIdx.x; i < wrows * wdw; i += NT) {
+      const int r = i / wdw, c = i - r * wdw;
+      s_win[r * WD + c] = load_u32_any(ref + (long)(by - range + r) * W + bx - range + 4 * c);
+    }
+  } else {
+    for (int i = threadIdx.x; i < wrows * wcols; i += NT) {
+      const int r = i / wcols, c = i % wcols;
+      const int y = iclip(0, H - 1, by - range + r), x = iclip(0, W - 1, bx - range + c);
+      win8[r * (WD * 4) + c] = ref[(long)y * W + x];
+    }
   }
   __syncthreads();
-  for (int cand = threadIdx.x; cand < side * side; cand += 256) {
-    const int dy = cand / side, dx = cand % side;  // window-relative displacement: column dx, row dy
-    const int d0 = dx >> 2;
-    const u32 sh = (u32)(dx & 3);
-    u32 sad = 0;
-    for (int r = 0; r < BW; r++) {
-      const u32 *wr = s_win + (dy + r) * WD + d0;
-      u32 lo = wr[0];
+  const int groups = (side + 3) >> 2;  // groups of four candidates along x
+  for (int t = threadIdx.x; t < side * groups; t += NT) {
+    const int dy = t / groups, d0 = t - dy * groups;  // window-relative displacement: row dy, columns 4 d0 .. 4 d0 + 3
+    u32 sad[4] = { 0, 0, 0, 0 };
+    for (int r0 = 0; r0 < BW; r0 += FL) {
+      unsigned long long acc = 0;
+#pragma unroll 4
+      for (int r = r0; r < r0 + FL; r++) {
+        const u32 *wr = s_win + (dy + r) * WD + d0;
+        u32 lo = wr[0];
 #pragma unroll
-      for (int k = 0; k < BW / 4; k++) {
-        const u32 hi = wr[k + 1];
-        sad = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(hi, lo, sh), s_cur[r * (BW / 4) + k], sad);
-        lo = hi;
+        for (int k = 0; k < BW / 4; k++) {
+          const u32 hi = wr[k + 1];
+          acc = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)hi << 32) | lo, s_cur[r * (BW / 4) + k], acc);
+          lo = hi;
+        }
       }
+      for (int i = 0; i < 4; i++) sad[i] += (u32)(acc >> (16 * i)) & 0xffffu;
     }
-    out[(long)b * side * side + cand] = sad;
+    for (int i = 0; i < 4; i++)
+      if (4 * d0 + i < side) out[(long)b * side * side + dy * side + 4 * d0 + i] = sad[i];
   }
 }
 
@@ -409,7 +427,6 @@ dev_sad_surface_kernel(const u8 *cur, const u8 *ref, const int W, const int H, c
 // dwords (unaligned loads at the class's displacement) are spread over 16-bit halves (even / odd bytes), sign(c - n) + 1 = clamp(c + 1 - n, 0, 2)
 // is three packed instructions per neighbour and pair, and the category -> offset table of the CTU's record is applied to all four samples by
 // two v_perm_b32 (byte look-ups); band offsets use the same look-up on clamp(band - position + 1, 0, 5).
-__device__ __forceinline__ u32 load_u32_any(const u8 *p) { u32 v; __builtin_memcpy(&v, p, 4); return v; }  // any byte alignment
 __device__ __forceinline__ u32 sao_add_offsets(u32 c4, u32 off4)  // clip(c + (int8)off) on four bytes
 {
   const dev_pk16 ce = __builtin_bit_cast(dev_pk16, c4 & 0x00ff00ffu), co = __builtin_bit_cast(dev_pk16, (c4 >> 8) & 0x00ff00ffu);
@@ -1020,7 +1037,7 @@ void kvz_hip_dev_sad_surface(const uint8_t *cur, const uint8_t *ref, int width, 
 {
   if (count <= 0) return;
   if (range < 0 || range > 32) { fprintf(stderr, "kvz_hip_dev_sad_surface: range %d not in [0, 32]\n", range); abort(); }
-  const dim3 grid((unsigned)count), block(256);
+  const dim3 grid((unsigned)count), block(kvz::kSadSurfaceLanes);
   switch (bw) {
   case 8: hipLaunchKernelGGL(kvz::dev_sad_surface_kernel<8>, grid, block, 0, be().stream, cur, ref, width, height, range, blk_xy, out); break;
   case 16: hipLaunchKernelGGL(kvz::dev_sad_surface_kernel<16>, grid, block, 0, be().stream, cur, ref, width, height, range, blk_xy, out); break;
