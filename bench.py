@@ -46,7 +46,11 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:24]
 
 
-def golden_digest(w, h, seed, qp, deblock, tiles=None, wpp=False, no_wpp=False):
+# preset -> (coeff_cabac or None = by QP, search_32x32, rdoq, suffix of the golden key)
+PRESETS = {"ultrafast": (None, 0, 0, ""), "faster": (1, 0, 0, None), "fast": (1, 1, 0, "/fast"), "medium-pu13": (1, 1, 1, "/medium-pu13")}
+
+
+def golden_digest(w, h, seed, qp, deblock, tiles=None, wpp=False, no_wpp=False, suffix=""):
     """digest(s) of the reference encoder's reconstruction of frame 0 of the clip (tests/golden/make_golden.py clip_key), or None"""
     try:
         g = json.load(open(GOLDEN))
@@ -57,7 +61,9 @@ def golden_digest(w, h, seed, qp, deblock, tiles=None, wpp=False, no_wpp=False):
     if tiles:
         v = g.get(key + "/per-tile")
         return v[0] if v else None
-    v = g.get(key)
+    if suffix is None:
+        return None
+    v = g.get(key + suffix)
     return v[0] if v else None
 
 
@@ -274,6 +280,8 @@ def main():
     ap.add_argument("--frames", type=int, default=1536, help="frames per GPU and step (the batch resident in HBM)")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames generated on the host; the batch cycles through them")
     ap.add_argument("--qp", type=int, default=22)
+    ap.add_argument("--preset", default="ultrafast", choices=sorted(PRESETS), help="which of kvazaar's all-intra searches the pass runs (the headline metric is ultrafast): "
+                    "faster = CABAC coefficient cost at every QP; fast = + 32x32 CUs searched; medium-pu13 = + RDOQ (`--preset medium --pu-depth-intra 1-3`)")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-encoder", action="store_true")
@@ -309,6 +317,10 @@ def main():
             m.adaptive = 0
         if args.no_wpp or (tiles_arg and not args.wpp):
             m.no_wpp = 1
+        cab, s32, rdoq, _ = PRESETS[args.preset]
+        if cab is not None:
+            m.coeff_cabac = cab
+        m.search_32x32, m.rdoq = s32, rdoq
         return m
 
     model = model_for(args.qp, args.tiles)
@@ -343,7 +355,7 @@ def main():
         if tile is not None:  # per-tile digests of the tiled encode
             per_tile = golden_digest(args.width, args.height, seed0, args.qp, 0, args.tiles, args.wpp)
             return per_tile[tile] if per_tile else None
-        return golden_digest(args.width, args.height, seed0, args.qp, 0, None, False, bool(model.no_wpp))
+        return golden_digest(args.width, args.height, seed0, args.qp, 0, None, False, bool(model.no_wpp), PRESETS[args.preset][3])
 
     verify = verify_batches(batches, len(distinct), golden_for)
     ok_local = verify["copies_consistent"] and verify["golden_ok"] is not False
@@ -378,7 +390,7 @@ def main():
             "fps": value / ctus_per_frame,
             # golden_ok None = the fixture has no encoder digest for this workload (only the copy-consistency check ran)
             "verified": bool(ok_all and (verify["golden_ok"] is True or verify["golden_ok"] is None)), "verify": verify,
-            "config": {"workload": f"{args.width}x{args.height} yuv420p 8-bit all-intra ultrafast CTU pass (kvz_hip_intra_frames), QP {args.qp}",
+            "config": {"workload": f"{args.width}x{args.height} yuv420p 8-bit all-intra {args.preset} CTU pass (kvz_hip_intra_frames), QP {args.qp}",
                        "frames_per_gpu_per_step": None if args.tiles else args.frames, "frames_per_step": args.frames if args.tiles else args.frames * world,
                        "ctus_per_frame": ctus_per_frame, "distinct_frames": len(distinct),
                        "wpp": not bool(model.no_wpp),
@@ -395,7 +407,7 @@ def main():
         }
         if exchange is not None:
             result["exchange"] = exchange
-        if world == 1 and not args.no_extra:
+        if world == 1 and not args.no_extra and args.preset == "ultrafast":  # the auxiliary legs verify against the ultrafast digests
             extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedResults)
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, distinct, model)

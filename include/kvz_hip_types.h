@@ -122,7 +122,10 @@ typedef struct kvz_hip_intra_cost_model {
    * 32x32 CU first, then -- unless it has no coefficients (cu-split-termination zero, search.c:975-984) -- its four 16x16 children with early termination.
    * 0: --pu-depth-intra 2-3 (ultrafast ... faster): 32x32 CUs only arise by merging four 16x16 CUs under the top-left one's mode (search.c:996-1044). */
   int32_t  search_32x32;
-  int32_t  reserved_;
+  /* != 0: every transform block is quantised by rate-distortion optimised quantisation (kvazaar's --rdoq with --rdoq-skip 0 and --signhide 0, preset `medium`;
+   * kvz_rdoq, rdo.c:661-1000, on the contexts of the row's real coder as they stand when the CTU's search begins: state->cabac) instead of kvz_quant.  Needs
+   * coeff_cabac (the presets that switch RDOQ on have --fast-residual-cost 0) and search_32x32 is independent of it. */
+  int32_t  rdoq;
   uint8_t  ctx_init[160];     /* uc_state at slice start (kvz_init_contexts, context.c:202-305) of the KVZ_HIP_CX_* contexts; the rest unused */
   float    entropy_fbits[128];/* kvz_f_entropy_bits (rdo.c:69-83) */
 } kvz_hip_intra_cost_model;

@@ -75,7 +75,9 @@ static int eligible(const encoder_state_t *state)
 #define REQUIRE(cond) do { if (!(cond)) { if (enabled > 1) fprintf(stderr, "search_lcu_hip: not eligible: %s\n", #cond); return 0; } } while (0)
   REQUIRE(state->frame->slicetype == KVZ_SLICE_I);
   REQUIRE(ctrl->bitdepth == 8 && ctrl->chroma_format == KVZ_CSP_420);
-  REQUIRE(cfg->rdo == 0 && !cfg->rdoq_enable && !cfg->signhide_enable && !cfg->trskip_enable && cfg->tr_depth_intra == 0);
+  REQUIRE(cfg->rdo == 0 && !cfg->signhide_enable && !cfg->trskip_enable && cfg->tr_depth_intra == 0);
+  /* --rdoq (preset medium): kvz_rdoq in every quantisation (rdoq-skip 0), priced on the CABAC model (fast-residual-cost 0) */
+  REQUIRE(!cfg->rdoq_enable || (!cfg->rdoq_skip && !(state->qp < cfg->fast_residual_cost_limit && state->qp < MAX_FAST_COEFF_COST_QP)));
   REQUIRE(!cfg->lossless && !cfg->implicit_rdpcm && cfg->scaling_list == KVZ_SCALING_LIST_OFF);
   REQUIRE(!cfg->full_intra_search);
   REQUIRE((cfg->pu_depth_intra.min[0] == 2 || cfg->pu_depth_intra.min[0] == 1) && cfg->pu_depth_intra.max[0] == 3);  /* all-intra: GOP layer 0 only; 1-3 = preset `fast` */
@@ -159,6 +161,7 @@ static picture_result *picture_of(const encoder_state_t *state)
     kvz_hip_intra_cost_model_init(state->qp, kvz_fast_coeff_get_weights(state), &r->model);
     r->model.coeff_cabac = !(state->qp < cfg->fast_residual_cost_limit && state->qp < MAX_FAST_COEFF_COST_QP);  /* rdo.c:311-340 */
     r->model.search_32x32 = cfg->pu_depth_intra.min[0] == 1;  /* 32x32 CUs are searched, not only merged (search.c:794) */
+    r->model.rdoq = cfg->rdoq_enable != 0;
     r->model.no_wpp = !cfg->wpp;  /* kvazaar switches WPP off when tiles are used (cfg.c:925-978) */
     /* kvz_picture planes carry a stride; the batch takes tight planes.  (Outside the lock: only this thread knows the slot is being filled --
      * nobody gathers a slot before it is PENDING ... so mark it pending only afterwards.) */

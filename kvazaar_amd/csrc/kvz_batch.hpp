@@ -72,8 +72,8 @@ __device__ __forceinline__ bool wait_done(unsigned *flag, unsigned epoch, unsign
   }
 }
 
-template <bool CABAC, bool S32 = false> __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) KVZ_CTU_VGPR_ATTR intra_ctu_ticket_kernel(const CtuFrames F, const CtuModel model, const Tables *tb,
-                                                                        const CtuSched sched)
+// The persistent loop of the ticket schedule; the kernels below differ in their register budget only.
+template <bool CABAC, bool S32, bool RDOQ> __device__ __forceinline__ void ticket_loop(const CtuFrames &F, const CtuModel &model, const Tables *tb, const CtuSched &sched)
 {
   __shared__ CtuSharedT<CABAC> shared;
   __shared__ CtuModel m;  // scalars in LDS; its price table stays in HBM (kvz_hip_batch::d_entropy)
@@ -100,7 +100,7 @@ template <bool CABAC, bool S32 = false> __global__ void __launch_bounds__(KVZ_CT
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
-    CtuProgramT<CABAC, S32> p;
+    CtuProgramT<CABAC, S32, RDOQ> p;
     p.m = &m; p.tb = tb; p.F = F; p.s = &shared;
     p.frame = frame; p.cx = x * 64; p.cy = y * 64;
     p.lane_rot = (t * 64) & (KVZ_CTU_THREADS - 1);
@@ -115,6 +115,18 @@ template <bool CABAC, bool S32 = false> __global__ void __launch_bounds__(KVZ_CT
   }
 }
 
+template <bool CABAC, bool S32 = false, bool RDOQ = false> __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) KVZ_CTU_VGPR_ATTR intra_ctu_ticket_kernel(const CtuFrames F, const CtuModel model, const Tables *tb,
+                                                                        const CtuSched sched)
+{
+  ticket_loop<CABAC, S32, RDOQ>(F, model, tb, sched);
+}
+// --rdoq: kvz_rdoq is a long double-precision routine run by one lane per plane; at 128 VGPRs its many inlined copies spill by the thousand, so this
+// instantiation trades occupancy (2 wavefronts per SIMD = 4 workgroups per CU) for registers
+__global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2))) intra_ctu_ticket_kernel_rdoq(const CtuFrames F, const CtuModel model, const Tables *tb, const CtuSched sched)
+{
+  ticket_loop<true, true, true>(F, model, tb, sched);
+}
+
 }  // namespace kvz
 
 struct kvz_hip_batch {
@@ -127,6 +139,7 @@ struct kvz_hip_batch {
   double *d_cost;
   uint8_t *d_border;
   unsigned long long *d_prof;
+  double *d_rdoq;    // kvz_rdoq's cost arrays, 72 KB per workgroup of the persistent launch (allocated with the first model that has rdoq set)
   float *d_entropy;  // the model's entropy_fbits [128 floats] followed by its ctx_init [160 bytes] of the run in flight
   uint32_t *d_items, *d_items_raster;  // ticket order with WPP (anti-diagonals) / without (raster order per picture)
   unsigned *d_ticket, *d_done, *d_error;
@@ -284,6 +297,7 @@ kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_border, nctu * KVZ_BORDER_BYTES));
   KVZ_HIP_CHECK(hipMemsetAsync(b->d_border, 0, nctu * KVZ_BORDER_BYTES, b->stream));
   F.border = b->d_border;
+  F.rdoq_scratch = nullptr;
   {  // ticket schedule: items in dependency order (anti-diagonal, frame, row)
     std::vector<uint32_t> items;
     items.reserve(nctu);
@@ -331,7 +345,7 @@ void kvz_hip_batch_destroy(kvz_hip_batch *b)
   kvz::batch_enter(b);
   (void)hipStreamSynchronize(b->stream);
   (void)hipFree(b->d_ver); (void)hipFree(b->d_dbk); (void)hipFree(b->d_sao_merge); (void)hipFree(b->d_sao_stats); (void)hipFree(b->d_sao_cand); (void)hipFree(b->d_sao_recs); (void)hipFree(b->d_sao_fbits);
-  (void)hipFree(b->d_border); (void)hipFree(b->d_items); (void)hipFree(b->d_items_raster); (void)hipFree(b->d_done); (void)hipFree(b->d_ticket); (void)hipFree(b->d_prof); (void)hipFree(b->d_entropy);
+  (void)hipFree(b->d_border); (void)hipFree(b->d_items); (void)hipFree(b->d_items_raster); (void)hipFree(b->d_done); (void)hipFree(b->d_ticket); (void)hipFree(b->d_prof); (void)hipFree(b->d_entropy); (void)hipFree(b->d_rdoq);
   (void)hipFree(b->d_src); (void)hipFree(b->d_rec); (void)hipFree(b->d_coeff); (void)hipFree(b->d_scratch); (void)hipFree(b->d_depth); (void)hipFree(b->d_mode); (void)hipFree(b->d_cost);
   (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1);
   (void)hipStreamDestroy(b->stream);
@@ -410,7 +424,7 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
   cm.ctx_init = (const uint8_t *)(b->d_entropy + 128);
   KVZ_HIP_CHECK(hipMemcpyAsync(b->d_entropy, model->entropy_fbits, 128 * sizeof(float), hipMemcpyHostToDevice, b->stream));
   KVZ_HIP_CHECK(hipMemcpyAsync(b->d_entropy + 128, model->ctx_init, sizeof model->ctx_init, hipMemcpyHostToDevice, b->stream));
-  if (!b->sched_ticket && cm.search_32x32) { fprintf(stderr, "kvz_hip_intra_frames: search_32x32 needs the ticket schedule\n"); abort(); }
+  if (!b->sched_ticket && (cm.search_32x32 || cm.rdoq)) { fprintf(stderr, "kvz_hip_intra_frames: search_32x32 / rdoq need the ticket schedule\n"); abort(); }
   if (!b->sched_ticket && cm.no_wpp) { fprintf(stderr, "kvz_hip_intra_frames: the one-launch-per-diagonal schedule (KVZ_HIP_SCHED=wave) needs WPP\n"); abort(); }
   if (b->sched_ticket) {
     b->epoch++;
@@ -419,7 +433,13 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
     kvz::CtuSched sc{ cm.no_wpp ? b->d_items_raster : b->d_items, b->d_ticket, b->d_done, b->d_error, b->total_items, b->epoch, cm.no_wpp, b->wait_ticks };
     // two instantiations: the one without the CABAC coefficient model carries none of its code, registers or context storage
     // (the instantiations that search 32x32 CUs, --pu-depth-intra 1-3, are separate ones too: the others stay as they were)
-    if (cm.search_32x32) {
+    if (cm.rdoq) {  // --rdoq (preset `medium`): its own instantiation (CABAC cost model, 32x32 search compiled in and switched by the model)
+      if (!cm.coeff_cabac) { fprintf(stderr, "kvz_hip_intra_frames: rdoq needs coeff_cabac (kvazaar's presets with --rdoq have --fast-residual-cost 0)\n"); abort(); }
+      if (!b->d_rdoq) KVZ_HIP_CHECK(hipMalloc((void **)&b->d_rdoq, (size_t)b->grid_ticket * 3 * 3 * 1024 * sizeof(double)));
+      kvz::CtuFrames Fr = F;
+      Fr.rdoq_scratch = b->d_rdoq;
+      hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel_rdoq, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, Fr, cm, kvz::device_tables(), sc);
+    } else if (cm.search_32x32) {
       if (cm.coeff_cabac) hipLaunchKernelGGL((kvz::intra_ctu_ticket_kernel<true, true>), dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);
       else hipLaunchKernelGGL((kvz::intra_ctu_ticket_kernel<false, true>), dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);
     } else if (cm.coeff_cabac) hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel<true>, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);

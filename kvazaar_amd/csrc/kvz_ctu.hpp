@@ -33,6 +33,7 @@
 #pragma once
 #include "../../include/kvz_hip_types.h"
 #include "kvz_ops.hpp"
+#include "kvz_rdoq.hpp"
 
 namespace kvz {
 
@@ -149,14 +150,14 @@ template <bool CABAC> struct CtxSetT { alignas(4) u8 s[CABAC ? 148 : 12]; };
 struct CtuModel {
   double lambda, lambda_sqrt;
   uint64_t coeff_weights;
-  int qp, adaptive, coeff_cabac, no_wpp, search_32x32;
+  int qp, adaptive, coeff_cabac, no_wpp, search_32x32, rdoq;
   const float *entropy_fbits;  // [128]
   const u8 *ctx_init;          // [KVZ_CX_COUNT]
 };
 KVZ_HD void ctu_model_from(const kvz_hip_intra_cost_model *src, CtuModel *dst)
 {
   dst->lambda = src->lambda; dst->lambda_sqrt = src->lambda_sqrt; dst->coeff_weights = src->coeff_weights; dst->qp = src->qp; dst->adaptive = src->adaptive;
-  dst->coeff_cabac = src->coeff_cabac; dst->no_wpp = src->no_wpp; dst->search_32x32 = src->search_32x32;
+  dst->coeff_cabac = src->coeff_cabac; dst->no_wpp = src->no_wpp; dst->search_32x32 = src->search_32x32; dst->rdoq = src->rdoq;
   dst->entropy_fbits = src->entropy_fbits;
   dst->ctx_init = src->ctx_init;
 }
@@ -180,6 +181,7 @@ struct CtuFrames {
   // Neighbour data is exchanged ONLY through these records: the frame-level rec / cu arrays share cache lines between CTUs
   // produced on different XCDs, and a line that is dirty in the reader's L2 cannot be invalidated by its acquire.
   u8 *border;                // [frames][ctu][KVZ_BORDER_BYTES]
+  double *rdoq_scratch;      // [workgroup][plane][3 * 1024]: the per-position cost arrays of kvz_rdoq (RDOQ instantiation only, else unused)
 };
 #define KVZ_BORDER_BYTES 512
 
@@ -257,8 +259,9 @@ using CtuShared = CtuSharedT<true>;
 
 static const int kPlaneOff[3] = { 0, 4096, 5120 };
 
+// RDOQ: the instantiation that quantises with kvz_rdoq (kvz_hip_intra_cost_model::rdoq, preset `medium`); the others carry none of its code
 // S32: the instantiation that can also SEARCH 32x32 CUs (kvz_hip_intra_cost_model::search_32x32, --pu-depth-intra 1-3); the others carry none of its code
-template <bool CABAC, bool S32 = false> struct CtuProgramT {
+template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   using CtxSet = CtxSetT<CABAC>;
   const CtuModel *m;
   const Tables *tb;
@@ -1393,6 +1396,15 @@ template <bool CABAC, bool S32 = false> struct CtuProgramT {
     if (t.lw == 5) return s->tb_big + (c == 0 ? 0 : (c == 1 ? 1024 : 1280));  // one buffer, every stage in place
     return s->tb_small + p * 384 + (c == 0 ? 0 : (c == 1 ? 256 : 320));
   }
+  // kvz_rdoq's three per-position cost arrays for plane c of this workgroup (HBM: 24 KB per plane at 32x32)
+  KVZ_DEV double *rdoq_scratch(int c) const
+  {
+#ifdef KVZ_HOSTSIM
+    return F.rdoq_scratch + (long)c * 3 * 1024;
+#else
+    return F.rdoq_scratch + ((long)blockIdx.x * 3 + c) * 3 * 1024;
+#endif
+  }
   // Entry (k, i) of the 2^l2-point transform matrix
   KVZ_DEV int dct_at(int l2, int k, int i) const
   {
@@ -1563,7 +1575,7 @@ template <bool CABAC, bool S32 = false> struct CtuProgramT {
     const int xl = t.x - cx, yl = t.y - cy;
     const CandView cv = cand_view(lv);
     if (!refs_ready) build_refs(lv, t.x, t.y, t.lw, t.lc, t.lw != 0, t.lc != 0);
-    if (KVZ_CTU_THREADS == 128 && t.lw == 3 && t.lc == 2) { recon_cu8(lv, t, depth, mode); return; }
+    if (!RDOQ && KVZ_CTU_THREADS == 128 && t.lw == 3 && t.lc == 2) { recon_cu8(lv, t, depth, mode); return; }
     // stage 1: prediction -> rec (as kvazaar blits it before quantising) and residual
     KVZ_FOR_THREADS(tid) {
       if (tid < 16) s->acc[tid] = 0;
@@ -1606,6 +1618,25 @@ template <bool CABAC, bool S32 = false> struct CtuProgramT {
     }
     KVZ_PROF(KVZ_P_FDCT);
     // stage 4: quantise (quant-generic.c:57-81) -> coefficient store + cost sums; dequantise (:335-339) -> tb[1]
+    // With RDOQ (quant-generic.c:234-244) the levels come from kvz_rdoq instead: serial per block, so one lane per plane runs it -- luma on the
+    // first wavefront, U and V on two lanes of the other -- on the contexts of the row's coder as they stood when this CTU began (pre[0] =
+    // state->cabac, rdo.c:665), and the loop below takes the levels from where it left them.
+    if (RDOQ && m->rdoq) {
+      KVZ_FOR_THREADS(tid) {
+        const int c = tid == 0 ? 0 : (tid == KVZ_CTU_THREADS - 64 ? 1 : (tid == KVZ_CTU_THREADS - 63 ? 2 : -1));
+        const int l2 = c < 0 ? 0 : tu_log2(t, c);
+        if (l2) {
+          const int sh = c ? 1 : 0, scan_mode = scan_order(mode, depth);
+          i16 *cout = lv == 2 ? s->lv2_coeff + (c == 0 ? 0 : (c == 1 ? 256 : 320))
+                    : lv == 1 ? s->lv1_coeff + (c == 0 ? 0 : (c == 1 ? 1024 : 1280)) : coeff_level(lv) + kPlaneOff[c] + zorder(xl >> sh, yl >> sh);
+          RdoqCtx rc{ s->pre[0].s, tb->entropy_bits, m->lambda };
+          rc.fbits = s->entropy_fbits;  // the price table's copy in LDS
+          // tr_depth = cu->tr_depth - cu->depth: 1 for the 32x32 units of the 64x64 attempt (level 0), 0 otherwise
+          rdoq_block(rc, m->qp, tbuf(t, 0, c), cout, l2, c ? 2 : 0, scan_mode, lv == 0 ? 1 : 0, tb->diag8, rdoq_scratch(c));
+        }
+      }
+      KVZ_SYNC();
+    }
     KVZ_FOR_THREADS(tid) {
       for (int c = 0; c < 3; c++) {
         const int l2 = tu_log2(t, c);
@@ -1622,10 +1653,14 @@ template <bool CABAC, bool S32 = false> struct CtuProgramT {
         for (int e = tid; e < n2; e += KVZ_CTU_THREADS) {
           const int cf = src[e];
           // |cf| * q + add < 2^31 for 8-bit flat lists (32767 * 26214 + (171 << 18)), so 32-bit arithmetic is exact
-          int level = (int)(((u32)iabs(cf) * (u32)qf.flat_q + (u32)qf.add) >> qf.q_bits);
-          if (cf < 0) level = -level;
-          level = iclip(-32768, 32767, level);
-          cout[e] = (i16)level;
+          int level;
+          if (RDOQ && m->rdoq) level = cout[e];
+          else {
+            level = (int)(((u32)iabs(cf) * (u32)qf.flat_q + (u32)qf.add) >> qf.q_bits);
+            if (cf < 0) level = -level;
+            level = iclip(-32768, 32767, level);
+            cout[e] = (i16)level;
+          }
           if (stage) stage[e] = (i16)level;
           int a = iabs(level);
           nz += a != 0;

@@ -16,7 +16,32 @@ struct RdoqCtx {
   const u8 *ctx;        // uc_state of the contexts in KVZ_HIP_CX_* order (include/kvz_hip_types.h)
   const u32 *bits;      // kvz_entropy_bits (rdo.c:69-80): Q15 price of coding `bin` in state s = bits[s ^ bin]
   double lambda;
-  KVZ_DEV i32 price(int idx, int bin) const { return (i32)bits[ctx[idx] ^ bin]; }
+  const float *fbits = nullptr;  // the same prices as multiples of 2^-15 in floats (the CTU kernel's copy in LDS); used instead of `bits` when set
+  KVZ_DEV i32 price(int idx, int bin) const { return fbits ? (i32)(fbits[ctx[idx] ^ bin] * 32768.0f) : (i32)bits[ctx[idx] ^ bin]; }
+};
+
+// The coefficient scans by arithmetic (HEVC scans are hierarchical: 4x4 groups in group order, sixteen positions inside a group): no table in memory on the
+// chain from one coefficient to the next.  diag8: the up-right diagonal order of an 8x8 grid (Tables::diag8), the group order of a 32x32 block.
+struct RdoqScan {
+  int log2w, mode;
+  const u8 *diag8;
+  KVZ_DEV static u32 in_group(int scan, int k)  // raster index inside the 4x4 group of its k-th position (tables.c kvz_g_sig_last_scan, 4x4 entries)
+  {
+    const unsigned long long pat = scan == 0 ? 0xfbe7ad369c258140ull : (scan == 1 ? 0xfedcba9876543210ull : 0xfb73ea62d951c840ull);
+    return (u32)((pat >> (4 * k)) & 15);
+  }
+  KVZ_DEV u32 cg(int i) const  // raster index of the i-th group in group order (tables.h:45-89 g_sig_last_scan_cg)
+  {
+    if (log2w == 2) return 0;
+    if (log2w == 3) return mode == 1 ? (u32)i : (u32)((0x3120 >> (4 * i)) & 3);
+    if (log2w == 4) return in_group(0, i);
+    return diag8[i];
+  }
+  KVZ_DEV u32 pos(int scanpos) const  // raster index of a scan position in the block
+  {
+    const u32 g = cg(scanpos >> 4), r = in_group(mode, scanpos & 15), side = 1u << (log2w - 2);
+    return ((((g >> (log2w - 2)) << 2) + (r >> 2)) << log2w) + ((g & (side - 1)) << 2) + (r & 3);
+  }
 };
 
 // rdo.c:345-392 kvz_get_ic_rate
@@ -118,10 +143,8 @@ KVZ_DEV int rdoq_sig_ctx_inc(int pattern, int scan_idx, int pos_x, int pos_y, in
   return ((type == 0 && ((pos_x >> 2) + (pos_y >> 2)) > 0) ? 3 : 0) + offset + cnt;
 }
 
-// The block.  coef: transform coefficients (row-major w x w); dest: quantised levels (out); scan / scan_cg: kvz_g_sig_last_scan[scan_mode][log2w - 1]
-// and g_sig_last_scan_cg[log2w - 2][scan_mode] as raster indices per scan position; cost3: 3 * w * w doubles of scratch.
-KVZ_DEV void rdoq_block(const RdoqCtx &c, int qp, const i16 *coef, i16 *dest, int log2w, int type /* 0 luma, 2 chroma */, int scan_mode, int tr_depth, const u32 *scan,
-                        const u32 *scan_cg, double *cost3)
+// The block.  coef: transform coefficients (row-major w x w); dest: quantised levels (out); diag8: Tables::diag8; cost3: 3 * w * w doubles of scratch.
+KVZ_DEV void rdoq_block(const RdoqCtx &c, int qp, const i16 *coef, i16 *dest, int log2w, int type /* 0 luma, 2 chroma */, int scan_mode, int tr_depth, const u8 *diag8, double *cost3)
 {
   const int width = 1 << log2w, n = width * width;
   const int transform_shift = 15 - 8 - log2w;
@@ -136,8 +159,8 @@ KVZ_DEV void rdoq_block(const RdoqCtx &c, int qp, const i16 *coef, i16 *dest, in
   double *cost_coeff = cost3, *cost_sig = cost3 + n, *cost_coeff0 = cost3 + 2 * n;
   const int num_blk_side = width >> 2, cg_num = n >> 4;
   double cost_coeffgroup_sig[64];
-  u32 sig_coeffgroup_flag[64];
-  for (int i = 0; i < cg_num; i++) sig_coeffgroup_flag[i] = 0;
+  const RdoqScan sc{ log2w, scan_mode, diag8 };
+  unsigned long long sig_groups = 0;  // sig_coeffgroup_flag, bit = raster index of the group
   int ctx_set = 0, c1 = 1, c2 = 0, go_rice = 0;
   double base_cost = 0, block_uncoded_cost = 0;
   u32 c1_idx = 0, c2_idx = 0;
@@ -146,7 +169,7 @@ KVZ_DEV void rdoq_block(const RdoqCtx &c, int qp, const i16 *coef, i16 *dest, in
   for (cg_scanpos = cg_num - 1; cg_scanpos >= 0 && last_scanpos < 0; cg_scanpos--) {
     for (int in_cg = 15; in_cg >= 0; in_cg--) {
       const int scanpos = cg_scanpos * 16 + in_cg;
-      const u32 blkpos = scan[scanpos];
+      const u32 blkpos = sc.pos(scanpos);
       i32 level_double = coef[blkpos];
       level_double = imin(iabs(level_double) * q, 0x7fffffff - (1 << (q_bits - 1)));
       if (((level_double + (1 << (q_bits - 1))) >> q_bits) > 0) {
@@ -182,37 +205,37 @@ KVZ_DEV void rdoq_block(const RdoqCtx &c, int qp, const i16 *coef, i16 *dest, in
   }
   const int cg0 = KVZ_HIP_CX_SIG_CG + type;
   for (int cgs = cg_last_scanpos; cgs >= 0; cgs--) {
-    const u32 cg_blkpos = scan_cg[cgs], cg_pos_y = cg_blkpos / num_blk_side, cg_pos_x = cg_blkpos - cg_pos_y * num_blk_side;
+    const u32 cg_blkpos = sc.cg(cgs), cg_pos_y = cg_blkpos / num_blk_side, cg_pos_x = cg_blkpos - cg_pos_y * num_blk_side;
     // context.c:339-351 / 315-327
     u32 right = 0, lower = 0;
-    if ((int)cg_pos_x < num_blk_side - 1) right = sig_coeffgroup_flag[cg_pos_y * num_blk_side + cg_pos_x + 1] != 0;
-    if ((int)cg_pos_y < num_blk_side - 1) lower = sig_coeffgroup_flag[(cg_pos_y + 1) * num_blk_side + cg_pos_x] != 0;
+    if ((int)cg_pos_x < num_blk_side - 1) right = (sig_groups >> (cg_pos_y * num_blk_side + cg_pos_x + 1)) & 1;
+    if ((int)cg_pos_y < num_blk_side - 1) lower = (sig_groups >> ((cg_pos_y + 1) * num_blk_side + cg_pos_x)) & 1;
     const int pattern_sig_ctx = width == 4 ? -1 : (int)(right + (lower << 1));
     double rd_coded_level_and_dist = 0, rd_uncoded_dist = 0, rd_sig_cost = 0, rd_sig_cost_0 = 0;
     int rd_nnz_before_pos0 = 0;
     for (int in_cg = 15; in_cg >= 0; in_cg--) {
       const int scanpos = cgs * 16 + in_cg;
       if (scanpos > last_scanpos) continue;
-      const u32 blkpos = scan[scanpos];
+      const u32 blkpos = sc.pos(scanpos);
       i32 level_double = coef[blkpos];
       level_double = imin(iabs(level_double) * q, 0x7fffffff - (1 << (q_bits - 1)));
       const u32 max_abs_level = (u32)((level_double + (1 << (q_bits - 1))) >> q_bits);
       const double err = (double)level_double;
-      cost_coeff0[scanpos] = err * err * temp;
-      block_uncoded_cost += cost_coeff0[scanpos];
+      // the position's three costs stay in registers while they are used here; the arrays are only written (the later passes read them back)
+      double c0v = err * err * temp, ccv, csv = 0;
+      block_uncoded_cost += c0v;
       const int one_ctx = 4 * ctx_set + c1, abs_ctx = ctx_set + c2;
       i32 level;
       if (scanpos == last_scanpos) {
-        level = (i32)rdoq_coded_level(c, &cost_coeff[scanpos], &cost_coeff0[scanpos], &cost_sig[scanpos], level_double, max_abs_level, 0, one_ctx, abs_ctx, go_rice, c1_idx, c2_idx,
-                                      q_bits, temp, true, type);
+        level = (i32)rdoq_coded_level(c, &ccv, &c0v, &csv, level_double, max_abs_level, 0, one_ctx, abs_ctx, go_rice, c1_idx, c2_idx, q_bits, temp, true, type);
       } else {
         const u32 pos_y = blkpos >> log2w, pos_x = blkpos - (pos_y << log2w);
         const int ctx_sig = rdoq_sig_ctx_inc(pattern_sig_ctx, scan_mode, (int)pos_x, (int)pos_y, log2w, type);
-        level = (i32)rdoq_coded_level(c, &cost_coeff[scanpos], &cost_coeff0[scanpos], &cost_sig[scanpos], level_double, max_abs_level, ctx_sig, one_ctx, abs_ctx, go_rice, c1_idx,
-                                      c2_idx, q_bits, temp, false, type);
+        level = (i32)rdoq_coded_level(c, &ccv, &c0v, &csv, level_double, max_abs_level, ctx_sig, one_ctx, abs_ctx, go_rice, c1_idx, c2_idx, q_bits, temp, false, type);
       }
+      cost_coeff[scanpos] = ccv; cost_coeff0[scanpos] = c0v; cost_sig[scanpos] = csv;
       dest[blkpos] = (i16)level;
-      base_cost += cost_coeff[scanpos];
+      base_cost += ccv;
       const i32 base_level = c1_idx < 8 ? (2 + (c2_idx < 1)) : 1;
       if (level >= base_level && level > 3 * (1 << go_rice)) go_rice = imin(go_rice + 1, 4);
       if (level >= 1) c1_idx++;
@@ -232,19 +255,19 @@ KVZ_DEV void rdoq_block(const RdoqCtx &c, int qp, const i16 *coef, i16 *dest, in
         if (c1 == 0) ctx_set++;
         c1 = 1;
       }
-      rd_sig_cost += cost_sig[scanpos];
-      if (in_cg == 0) rd_sig_cost_0 = cost_sig[scanpos];
-      if (dest[blkpos]) {
-        sig_coeffgroup_flag[cg_blkpos] = 1;
-        rd_coded_level_and_dist += cost_coeff[scanpos] - cost_sig[scanpos];
-        rd_uncoded_dist += cost_coeff0[scanpos];
+      rd_sig_cost += csv;
+      if (in_cg == 0) rd_sig_cost_0 = csv;
+      if (level) {
+        sig_groups |= 1ull << cg_blkpos;
+        rd_coded_level_and_dist += ccv - csv;
+        rd_uncoded_dist += c0v;
         if (in_cg != 0) rd_nnz_before_pos0++;
       }
     }
     if (cgs) {
       // the flags may have changed inside the loop above only for this group: right / lower are those of the groups coded before
       const int ctx_sig = (int)(right || lower);
-      if (sig_coeffgroup_flag[cg_blkpos] == 0) {
+      if (((sig_groups >> cg_blkpos) & 1) == 0) {
         cost_coeffgroup_sig[cgs] = c.lambda * c.price(cg0 + ctx_sig, 0);
         base_cost += cost_coeffgroup_sig[cgs] - rd_sig_cost;
       } else if (cgs < cg_last_scanpos) {
@@ -260,12 +283,12 @@ KVZ_DEV void rdoq_block(const RdoqCtx &c, int qp, const i16 *coef, i16 *dest, in
         cost_zero_cg -= rd_coded_level_and_dist;
         cost_zero_cg -= rd_sig_cost;
         if (cost_zero_cg < base_cost) {
-          sig_coeffgroup_flag[cg_blkpos] = 0;
+          sig_groups &= ~(1ull << cg_blkpos);
           base_cost = cost_zero_cg;
           cost_coeffgroup_sig[cgs] = c.lambda * c.price(cg0 + ctx_sig, 0);
           for (int in_cg = 15; in_cg >= 0; in_cg--) {
             const int scanpos = cgs * 16 + in_cg;
-            const u32 blkpos = scan[scanpos];
+            const u32 blkpos = sc.pos(scanpos);
             if (dest[blkpos]) {
               dest[blkpos] = 0;
               cost_coeff[scanpos] = cost_coeff0[scanpos];
@@ -275,7 +298,7 @@ KVZ_DEV void rdoq_block(const RdoqCtx &c, int qp, const i16 *coef, i16 *dest, in
         }
       }
     } else {
-      sig_coeffgroup_flag[cg_blkpos] = 1;
+      sig_groups |= 1ull << cg_blkpos;
     }
   }
   // ---- the last position (rdo.c:903-957), intra block: coded block flag of the transform unit
@@ -288,13 +311,13 @@ KVZ_DEV void rdoq_block(const RdoqCtx &c, int qp, const i16 *coef, i16 *dest, in
     base_cost += c.lambda * c.price(cbf0 + ctx_cbf, 1);
   }
   for (int cgs = cg_last_scanpos; cgs >= 0; cgs--) {
-    const u32 cg_blkpos = scan_cg[cgs];
+    const u32 cg_blkpos = sc.cg(cgs);
     base_cost -= cost_coeffgroup_sig[cgs];
-    if (sig_coeffgroup_flag[cg_blkpos]) {
+    if ((sig_groups >> cg_blkpos) & 1) {
       for (int in_cg = 15; in_cg >= 0; in_cg--) {
         const int scanpos = cgs * 16 + in_cg;
         if (scanpos > last_scanpos) continue;
-        const u32 blkpos = scan[scanpos];
+        const u32 blkpos = sc.pos(scanpos);
         if (dest[blkpos]) {
           const u32 pos_y = blkpos >> log2w, pos_x = blkpos - (pos_y << log2w);
           const u32 px = scan_mode == 2 ? pos_y : pos_x, py = scan_mode == 2 ? pos_x : pos_y;  // SCAN_VER swaps (rdo.c:934)
@@ -320,11 +343,11 @@ KVZ_DEV void rdoq_block(const RdoqCtx &c, int qp, const i16 *coef, i16 *dest, in
     }
   }
   for (int scanpos = 0; scanpos < best_last_idx_p1; scanpos++) {
-    const u32 blkpos = scan[scanpos];
+    const u32 blkpos = sc.pos(scanpos);
     const i32 level = dest[blkpos];
     dest[blkpos] = (i16)(coef[blkpos] < 0 ? -level : level);
   }
-  for (int scanpos = best_last_idx_p1; scanpos <= last_scanpos; scanpos++) dest[scan[scanpos]] = 0;
+  for (int scanpos = best_last_idx_p1; scanpos <= last_scanpos; scanpos++) dest[sc.pos(scanpos)] = 0;
 }
 
 // one item = one block of a batch of equally shaped blocks
@@ -332,12 +355,9 @@ struct RdoqOp {
   const Tables *tb; const u8 *ctx; double lambda; int qp; const i16 *coef; i16 *dest; int log2w, type, scan_mode, tr_depth; double *tmp;
   KVZ_DEV void operator()(int item) const
   {
-    const int n = 1 << (2 * log2w), side = 1 << (log2w - 2);
-    const u32 *scan = tb->scan[scan_mode][log2w - 2];
-    u32 scan_cg[64];  // g_sig_last_scan_cg (tables.h:45-89) = the order in which the block's own coefficient scan visits its 4x4 groups
-    for (int i = 0; i < side * side; i++) { const u32 p = scan[16 * i]; scan_cg[i] = ((p >> log2w) >> 2) * side + ((p & ((1u << log2w) - 1)) >> 2); }
+    const int n = 1 << (2 * log2w);
     const RdoqCtx c{ ctx, tb->entropy_bits, lambda };
-    rdoq_block(c, qp, coef + (long)item * n, dest + (long)item * n, log2w, type, scan_mode, tr_depth, scan, scan_cg, tmp + (long)item * 3 * n);
+    rdoq_block(c, qp, coef + (long)item * n, dest + (long)item * n, log2w, type, scan_mode, tr_depth, tb->diag8, tmp + (long)item * 3 * n);
   }
 };
 

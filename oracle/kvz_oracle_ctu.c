@@ -74,6 +74,7 @@ static void build_transitions(void)
 }
 const uint8_t *kvz_oracle_next_state_table(int lps) { build_transitions(); return lps ? g_next_lps : g_next_mps; }
 
+#define ORC_CLIP(lo, hi, v) ((v) < (lo) ? (lo) : ((v) > (hi) ? (hi) : (v)))
 #define LCU 64
 #define NLEVELS 5
 #define MAX_COST 1.7e+308 /* global.h:293 MAX_DOUBLE */
@@ -97,6 +98,7 @@ typedef struct {
   level_t lv[NLEVELS];
   uint8_t tbl_top[16][16], tbl_left[16][16];
   ctxs_t cab;                /* state->search_cabac's contexts (adaptive mode) */
+  ctxs_t coder;              /* state->cabac's contexts while this CTU is searched: what kvz_rdoq prices on (rdo.c:665) */
 } ctu_t;
 
 /* CABAC_FBITS_UPDATE (cabac.h:133-139) on context idx of t->cab: the price of `bin`, then -- if `update` -- the state change
@@ -473,8 +475,42 @@ static int search_cu_intra(ctu_t *t, level_t *lv, int x, int y, int depth)
   return modes[bi];
 }
 
-/* One leaf TU: intra_recon_tb_leaf (intra.c:561-608) + quantize_tr_residual (transform.c:294-412).  Returns has_coeffs. */
-static int recon_tu(ctu_t *t, level_t *lv, int c, int x, int y /* luma frame coords */, int log2w, int mode)
+/* kvz_get_scan_order for an intra block (encoderstate.c:1761-1775); the chroma mode is the luma mode here */
+static int tu_scan_order(int mode, int depth)
+{
+  if (depth >= 3) {
+    if (mode >= 6 && mode <= 14) return 2;
+    if (mode >= 22 && mode <= 30) return 1;
+  }
+  return 0;
+}
+
+/* kvz_quantize_residual's rdoq leg (quant-generic.c:198-292 with cfg.rdoq_enable, rdoq_skip 0): transform, kvz_rdoq on state->cabac's contexts, then as usual */
+static int quantize_residual_rdoq(const ctu_t *t, int width, int color, int scan_order, int tr_depth, int stride, const uint8_t *ref_in, uint8_t *rec, int16_t *coeff_out)
+{
+  int16_t residual[32 * 32], coeff[32 * 32];
+  kvz_hip_quant_params p;
+  memset(&p, 0, sizeof p);
+  p.qp = t->m->qp; p.bitdepth = 8; p.slice_is_intra = 1; p.cu_is_intra = 1;
+  for (int y = 0; y < width; y++)
+    for (int x = 0; x < width; x++) residual[x + y * width] = (int16_t)(ref_in[x + y * stride] - rec[x + y * stride]);
+  const int idx = width == 4 ? (color == 0 ? 4 : 0) : width == 8 ? 1 : width == 16 ? 2 : 3;
+  kvz_oracle_transform(idx, 8, residual, coeff);
+  kvz_oracle_rdoq(t->m->qp, t->m->lambda, t->coder.s, t->m->entropy_fbits, coeff, coeff_out, width, color == 0 ? 0 : 2, scan_order, tr_depth);
+  int has_coeffs = 0;
+  for (int i = 0; i < width * width; i++) if (coeff_out[i] != 0) { has_coeffs = 1; break; }
+  if (has_coeffs) {
+    kvz_oracle_dequant(&p, coeff_out, coeff, width, width, color == 0 ? 0 : (color == 1 ? 2 : 3), 1);
+    kvz_oracle_transform(KVZ_HIP_IDCT_4 + idx, 8, coeff, residual);
+    for (int y = 0; y < width; y++)
+      for (int x = 0; x < width; x++) rec[x + y * stride] = (uint8_t)ORC_CLIP(0, 255, (int16_t)(residual[x + y * width] + rec[x + y * stride]));
+  }
+  return has_coeffs;
+}
+
+/* One leaf TU: intra_recon_tb_leaf (intra.c:561-608) + quantize_tr_residual (transform.c:294-412).  Returns has_coeffs.
+ * depth: the transform unit's depth; tr_rel: cu->tr_depth - cu->depth (1 for the 32x32 units of a 64x64 CU) */
+static int recon_tu(ctu_t *t, level_t *lv, int c, int x, int y /* luma frame coords */, int log2w, int mode, int depth, int tr_rel)
 {
   const int sh = c ? 1 : 0, w = 1 << log2w, lw = LCU >> sh;
   const int xl = (x - t->cx) >> sh, yl = (y - t->cy) >> sh;
@@ -483,16 +519,17 @@ static int recon_tu(ctu_t *t, level_t *lv, int c, int x, int y /* luma frame coo
   intra_predict(log2w, mode, c, top, lft, pred);
   uint8_t *rec = &lv->rec[c][yl * lw + xl];
   for (int r = 0; r < w; r++) memcpy(rec + r * lw, pred + r * w, w);
+  int16_t *coeff = &lv->coeff[c][zorder(xl, yl)];
+  if (t->m->rdoq) return quantize_residual_rdoq(t, w, c, tu_scan_order(mode, depth), tr_rel, lw, &t->org[c][yl * lw + xl], rec, coeff);
   kvz_hip_quant_params p;
   memset(&p, 0, sizeof p);
   p.qp = t->m->qp; p.bitdepth = 8; p.slice_is_intra = 1; p.cu_is_intra = 1;
-  int16_t *coeff = &lv->coeff[c][zorder(xl, yl)];
   return kvz_oracle_quantize_residual(&p, w, c, 0, 0, lw, lw, &t->org[c][yl * lw + xl], rec, rec, coeff, 0);
 }
 
 /* intra.c:623-717 kvz_intra_recon_cu: depth 0 splits into four 32x32 transform units (tr_depth = 1), every other
  * depth is one luma TU (+ chroma TUs of half the size, 4x4 for 8x8 CUs; transform.c:322-328). */
-static void recon_cu(ctu_t *t, level_t *lv, int x, int y, int depth, int mode, int do_luma, int do_chroma)
+static void recon_cu_rel(ctu_t *t, level_t *lv, int x, int y, int depth, int mode, int do_luma, int do_chroma, int tr_rel)
 {
   const int w = LCU >> depth;
   cu_t *cu = cu_at(lv, x - t->cx, y - t->cy);
@@ -500,10 +537,10 @@ static void recon_cu(ctu_t *t, level_t *lv, int x, int y, int depth, int mode, i
   if (do_chroma) { cbf_clear(&cu->cbf, depth, 1); cbf_clear(&cu->cbf, depth, 2); }
   if (depth == 0) {
     const int o = w / 2;
-    recon_cu(t, lv, x, y, 1, mode, do_luma, do_chroma);
-    recon_cu(t, lv, x + o, y, 1, mode, do_luma, do_chroma);
-    recon_cu(t, lv, x, y + o, 1, mode, do_luma, do_chroma);
-    recon_cu(t, lv, x + o, y + o, 1, mode, do_luma, do_chroma);
+    recon_cu_rel(t, lv, x, y, 1, mode, do_luma, do_chroma, 1);  /* cu->tr_depth - cu->depth = 1 for these units */
+    recon_cu_rel(t, lv, x + o, y, 1, mode, do_luma, do_chroma, 1);
+    recon_cu_rel(t, lv, x, y + o, 1, mode, do_luma, do_chroma, 1);
+    recon_cu_rel(t, lv, x + o, y + o, 1, mode, do_luma, do_chroma, 1);
     const uint16_t ch[3] = { cu_at(lv, x - t->cx + o, y - t->cy)->cbf, cu_at(lv, x - t->cx, y - t->cy + o)->cbf, cu_at(lv, x - t->cx + o, y - t->cy + o)->cbf };
     for (int c = 0; c < 3; c++) {
       if ((c == 0 && !do_luma) || (c > 0 && !do_chroma)) continue;
@@ -514,16 +551,17 @@ static void recon_cu(ctu_t *t, level_t *lv, int x, int y, int depth, int mode, i
   const int log2w = 6 - depth;
   if (do_luma) {
     cbf_clear(&cu->cbf, depth, 0);
-    if (recon_tu(t, lv, 0, x, y, log2w, mode)) cbf_set(&cu->cbf, depth, 0);
+    if (recon_tu(t, lv, 0, x, y, log2w, mode, depth, tr_rel)) cbf_set(&cu->cbf, depth, 0);
   }
   if (do_chroma && x % 8 == 0 && y % 8 == 0) {
     const int cl2 = depth == 3 ? 2 : log2w - 1; /* transform.c:326-327 */
     for (int c = 1; c <= 2; c++) {
       cbf_clear(&cu->cbf, depth, c);
-      if (recon_tu(t, lv, c, x, y, cl2, mode)) cbf_set(&cu->cbf, depth, c);
+      if (recon_tu(t, lv, c, x, y, cl2, mode, depth, tr_rel)) cbf_set(&cu->cbf, depth, c);
     }
   }
 }
+static void recon_cu(ctu_t *t, level_t *lv, int x, int y, int depth, int mode, int do_luma, int do_chroma) { recon_cu_rel(t, lv, x, y, depth, mode, do_luma, do_chroma, 0); }
 
 /* Test hook: the residual coder's bit count on caller-supplied states of the residual contexts (KVZ_HIP_CX_SIG_CG .. KVZ_HIP_CX_COUNT - 1,
  * updated in place when `update`), against the reference's kvz_encode_coeff_nxn (tests/test_oracle_vs_ref.py) */
@@ -854,6 +892,7 @@ void kvz_oracle_intra_frame(const kvz_hip_intra_cost_model *m, int width, int he
        * through the picture in raster order, so a row starts from where the previous one ended */
       ctxs_t *row = m->no_wpp ? &rows[0] : &rows[cy];
       t->cab = *row;  /* kvz_search_lcu: search_cabac = state->cabac (search.c:1211) */
+      t->coder = *row;
       ctu_cost[cy * wc + cx] = encode_ctu(t, cx * 64, cy * 64, coeff + (size_t)(cy * wc + cx) * KVZ_HIP_CTU_COEFFS);
       if (m->adaptive) {
         code_coding_tree(t, row, cx * 64, cy * 64, 0);

@@ -115,12 +115,18 @@ ENCODER_CLIPS_FAST = [(64, 64, 2, 9, "small", 22), (72, 88, 2, 1, "small", 12), 
                       (192, 136, 4, 0, "adversarial", 32), (832, 480, 1, 5, "large", 22), (1920, 1080, 1, 1, "large", 22), (1920, 1080, 1, 1, "large", 37)]
 
 
+# (width, height, frames, seed, kind, qp): `--preset medium --pu-depth-intra 1-3 -p 1` = preset `fast` + --rdoq (kvz_rdoq in every quantisation; `medium` itself also
+# searches the 4x4 NxN partitions, pu-depth-intra 1-4, which the pass does not have yet); the same three stages as ENCODER_CLIPS_FAST
+ENCODER_CLIPS_RDOQ = [(64, 64, 2, 9, "small", 22), (72, 88, 2, 1, "small", 12), (200, 136, 2, 3, "small", 27), (416, 240, 2, 1234, "small", 22), (416, 240, 1, 7, "small", 32),
+                      (192, 136, 4, 0, "adversarial", 32), (832, 480, 1, 5, "large", 22), (1920, 1080, 1, 1, "large", 27)]
+
+
 def clip_key(w, h, n, seed, kind, qp, deblock, no_wpp=False, tiles=None, wpp=False):
     return (f"{w}x{h}/n{n}/seed{seed}/{kind}/qp{qp}/{'deblock' if deblock else 'nodeblock'}" + ("/nowpp" if no_wpp else "")
             + (f"/tiles{tiles}" + ("-wpp" if wpp else "") if tiles else ""))
 
 
-def reference_encoder_recon(w, h, frames, qp, deblock, workdir, cu_maps=None, no_wpp=False, tiles=None, wpp=False, sao=False, preset="ultrafast"):
+def reference_encoder_recon(w, h, frames, qp, deblock, workdir, cu_maps=None, no_wpp=False, tiles=None, wpp=False, sao=False, preset="ultrafast", extra=()):
     """runs the reference CLI (oracle/_ref/kvazaar_ref) on the clip; returns its --debug reconstruction, one array per frame.
     cu_maps: a list that receives, per frame, the (depth, intra mode) maps per 8x8 cell the encoder's search left in its cu_array
     (recorded through the oracle/ref_cudump.c interposer; single-threaded so that LCUs arrive frame by frame)"""
@@ -128,7 +134,7 @@ def reference_encoder_recon(w, h, frames, qp, deblock, workdir, cu_maps=None, no
     src, rec = os.path.join(workdir, "in.yuv"), os.path.join(workdir, "rec.yuv")
     with open(src, "wb") as f:
         f.write(b"".join(fr.tobytes() for fr in frames))
-    cmd = [exe, "-i", src, "--input-res", f"{w}x{h}", "--preset", preset, "-p", "1", "-q", str(qp), "--debug", rec, "-o", os.path.join(workdir, "out.hevc")]
+    cmd = [exe, "-i", src, "--input-res", f"{w}x{h}", "--preset", preset, "-p", "1", "-q", str(qp), "--debug", rec, "-o", os.path.join(workdir, "out.hevc")] + list(extra)
     if not deblock:
         cmd.append("--no-deblock")
     if no_wpp:
@@ -182,6 +188,11 @@ def encoder_digests(workdir):
         for stage, (deblock, sao) in (("nodeblock", (0, False)), ("deblock", (1, False)), ("sao", (1, True))):
             recs = reference_encoder_recon(w, h, frames, qp, deblock, workdir, None, False, None, False, sao, "fast")
             out[clip_key(w, h, n, seed, kind, qp, deblock) + "/fast" + ("/sao" if sao else "")] = [hashlib.sha256(r.tobytes()).hexdigest()[:24] for r in recs]
+    for (w, h, n, seed, kind, qp) in ENCODER_CLIPS_RDOQ:
+        frames = cc.yuv_frames(w, h, n, seed, kind)
+        for stage, (deblock, sao) in (("nodeblock", (0, False)), ("deblock", (1, False)), ("sao", (1, True))):
+            recs = reference_encoder_recon(w, h, frames, qp, deblock, workdir, None, False, None, False, sao, "medium", ("--pu-depth-intra", "1-3"))
+            out[clip_key(w, h, n, seed, kind, qp, deblock) + "/medium-pu13" + ("/sao" if sao else "")] = [hashlib.sha256(r.tobytes()).hexdigest()[:24] for r in recs]
     for (w, h, n, seed, kind, qp, tiles, wpp) in ENCODER_CLIPS_TILES:
         frames = cc.yuv_frames(w, h, n, seed, kind)
         for deblock in (0, 1):

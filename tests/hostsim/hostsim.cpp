@@ -44,13 +44,19 @@ extern "C" void kvz_hostsim_intra_frame(const kvz_hip_intra_cost_model *m, int w
   F.border = border;
   int16_t *scratch = (int16_t *)calloc((size_t)F.wc * F.hc * 6144, sizeof(int16_t));
   F.coeff_scratch = scratch;
+  double *rdoq_scratch = (double *)calloc((size_t)3 * 3 * 1024, sizeof(double));
+  F.rdoq_scratch = rdoq_scratch;
   // like the device, two instantiations of the program: with and without the CABAC coefficient model (kvz_batch.hpp picks by model)
   void *sh = calloc(1, sizeof(kvz::CtuSharedT<true>) > sizeof(kvz::CtuSharedT<false>) ? sizeof(kvz::CtuSharedT<true>) : sizeof(kvz::CtuSharedT<false>));
   kvz::CtuModel cm;
   kvz::ctu_model_from(m, &cm);
   for (int cy = 0; cy < F.hc; cy++)
     for (int cx = 0; cx < F.wc; cx++) {
-      if (m->search_32x32) {  // the instantiations that search 32x32 CUs
+      if (m->rdoq) {  // --rdoq: the instantiation with kvz_rdoq in the quantisation stage (CABAC cost model; 32x32 search switched by the model)
+        kvz::CtuProgramT<true, true, true> p;
+        p.m = &cm; p.tb = &tb; p.F = F; p.s = (kvz::CtuSharedT<true> *)sh; p.frame = 0; p.cx = cx * 64; p.cy = cy * 64;
+        p.run();
+      } else if (m->search_32x32) {  // the instantiations that search 32x32 CUs
         if (m->coeff_cabac) {
           kvz::CtuProgramT<true, true> p;
           p.m = &cm; p.tb = &tb; p.F = F; p.s = (kvz::CtuSharedT<true> *)sh; p.frame = 0; p.cx = cx * 64; p.cy = cy * 64;
@@ -72,6 +78,7 @@ extern "C" void kvz_hostsim_intra_frame(const kvz_hip_intra_cost_model *m, int w
     }
   free(sh);
   free(scratch);
+  free(rdoq_scratch);
   free(border);
 }
 extern "C" unsigned kvz_hostsim_ctu_shared_bytes(void) { return (unsigned)sizeof(kvz::CtuShared); }

@@ -84,11 +84,12 @@ def test_batched_search_bitstream_identical(tmp_path, frames, extra):
 
 
 @pytest.mark.parametrize("preset,extra", [("superfast", ["-q", "22"]), ("veryfast", ["-q", "32"]), ("faster", ["-q", "22"]), ("faster", ["-q", "37", "--no-wpp"]),
-                                          ("fast", ["-q", "22"]), ("fast", ["-q", "32", "--tiles", "2x2"])],
-                         ids=["superfast-qp22", "veryfast-qp32", "faster-qp22", "faster-qp37-nowpp", "fast-qp22", "fast-qp32-tiles"])
+                                          ("fast", ["-q", "22"]), ("fast", ["-q", "32", "--tiles", "2x2"]), ("medium", ["-q", "27", "--pu-depth-intra", "1-3"])],
+                         ids=["superfast-qp22", "veryfast-qp32", "faster-qp22", "faster-qp37-nowpp", "fast-qp22", "fast-qp32-tiles", "medium-pu13-qp27"])
 def test_batched_search_other_all_intra_presets(tmp_path, preset, extra):
     """All-intra superfast / veryfast (= the ultrafast search + `--sao full`), faster (fast-residual-cost 0: coefficients priced with the
-    CABAC model at every QP) and fast (--pu-depth-intra 1-3 on top: 32x32 CUs searched) with the device searching whole pictures: the reference's SAO decision then runs on the host on the device's
+    CABAC model at every QP), fast (--pu-depth-intra 1-3 on top: 32x32 CUs searched) and medium without its NxN partitions (--rdoq on top: kvz_rdoq in every
+    quantisation of the device's search) with the device searching whole pictures: the reference's SAO decision then runs on the host on the device's
     reconstruction, and the bitstream must still be the reference encoder's, byte for byte."""
     _need_hip_encoder()
     yuv = str(tmp_path / "syn.yuv")

@@ -298,3 +298,58 @@ def test_hip_fast_preset_reproduces_reference_encoder(oracle, clip):
         assert [_sha(b.download(i)["rec"]) for i in range(n)] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 1) + "/fast/sao"]
     finally:
         b.close()
+
+
+# ---- `--rdoq` (preset `medium` without its NxN partitions: --preset medium --pu-depth-intra 1-3): kvz_rdoq in every quantisation of the CTU pass ----------
+def _rdoq_model(model):
+    model.search_32x32 = 1
+    model.coeff_cabac = 1
+    model.rdoq = 1
+    return model
+
+
+@pytest.mark.parametrize("clip", mg.ENCODER_CLIPS_RDOQ, ids=lambda c: f"{c[0]}x{c[1]}-{c[4]}-qp{c[5]}")
+def test_oracle_rdoq_reproduces_reference_encoder(oracle, clip):
+    w, h, n, seed, kind, qp = clip
+    model = _rdoq_model(oracle_model(oracle, qp))
+    frames = cc.yuv_frames(w, h, n, seed, kind)
+    raw, _, deb = _oracle_outputs(oracle, model, w, h, frames, qp)
+    assert raw == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0) + "/medium-pu13"]
+    assert deb == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 1) + "/medium-pu13"]
+
+
+@pytest.mark.parametrize("clip", [c for c in mg.ENCODER_CLIPS_RDOQ if c[0] * c[1] <= 416 * 240], ids=lambda c: f"{c[0]}x{c[1]}-{c[4]}-qp{c[5]}")
+def test_hostsim_rdoq_equals_oracle(oracle, hostsim, clip):
+    """the device sources with kvz_rdoq in the quantisation stage (CtuProgramT<true, true, true>) on the host: every output equals the oracle's, costs included;
+    also without the 32x32 search (--rdoq on top of `faster`)"""
+    w, h, n, seed, kind, qp = clip
+    for s32 in (1, 0):
+        model = _rdoq_model(oracle_model(oracle, qp))
+        model.search_32x32 = s32
+        for f in cc.yuv_frames(w, h, n, seed, kind)[:1 if s32 == 0 else n]:
+            assert not cc.compare(cc.run_oracle(oracle, model, w, h, f), cc.run_hostsim(hostsim.lib, model, w, h, f)), (clip, s32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip", mg.ENCODER_CLIPS_RDOQ, ids=lambda c: f"{c[0]}x{c[1]}-{c[4]}-qp{c[5]}")
+def test_hip_rdoq_reproduces_reference_encoder(oracle, clip):
+    """the product on the MI355X with kvz_rdoq in the CTU pass: CTU pass, deblocking, SAO == `kvazaar --preset medium --pu-depth-intra 1-3 -p 1`, stage by stage"""
+    import kvazaar_amd
+    from kvazaar_amd.batch import HipBatch, cost_model
+    lib = kvazaar_amd.load_library()
+    w, h, n, seed, kind, qp = clip
+    model = _rdoq_model(cost_model(lib, qp))
+    frames = cc.yuv_frames(w, h, n, seed, kind)
+    b = HipBatch(lib, w, h, n)
+    try:
+        for i, f in enumerate(frames):
+            b.upload(i, f)
+        b.run(model)
+        outs = [b.download(i) for i in range(n)]
+        assert [_sha(o["rec"]) for o in outs] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0) + "/medium-pu13"]
+        if w * h <= 416 * 240:
+            assert not cc.compare(cc.run_oracle(oracle, _rdoq_model(oracle_model(oracle, qp)), w, h, frames[0]), outs[0])
+        b.loop_filters(model, deblock=True, sao=True)
+        assert [_sha(b.download(i)["rec"]) for i in range(n)] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 1) + "/medium-pu13/sao"]
+    finally:
+        b.close()

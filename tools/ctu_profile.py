@@ -29,6 +29,8 @@ def main():
         model.coeff_cabac = 1
     if os.environ.get("KVZ_PROFILE_S32"):     # --pu-depth-intra 1-3 (preset fast)
         model.search_32x32 = 1
+    if os.environ.get("KVZ_PROFILE_RDOQ"):    # --rdoq (preset medium without NxN)
+        model.coeff_cabac = model.search_32x32 = model.rdoq = 1
     frames = bench.synth_frames(1920, 1080, 4, 1)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     b = cc.HipBatch(lib, 1920, 1080, n)
