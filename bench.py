@@ -48,6 +48,9 @@ def sha(a):
 
 # preset -> (coeff_cabac or None = by QP, search_32x32, rdoq, suffix of the golden key)
 PRESETS = {"ultrafast": (None, 0, 0, ""), "faster": (1, 0, 0, None), "fast": (1, 1, 0, "/fast"), "medium-pu13": (1, 1, 1, "/medium-pu13")}
+# ... and what the reference CLI is given for the CPU baseline of that search (loop filters off where the preset has SAO: the pass timed here is the search)
+PRESET_CLI = {"ultrafast": ["--preset", "ultrafast"], "faster": ["--preset", "faster", "--sao", "off"], "fast": ["--preset", "fast", "--sao", "off"],
+              "medium-pu13": ["--preset", "medium", "--pu-depth-intra", "1-3", "--sao", "off"]}
 
 
 def golden_digest(w, h, seed, qp, deblock, tiles=None, wpp=False, no_wpp=False, suffix=""):
@@ -128,9 +131,9 @@ def limiter(args, launches):
     return out
 
 
-def run_encoder(ref_bin, yuv, w, h, qp, extra, n_frames):
+def run_encoder(ref_bin, yuv, w, h, qp, extra, n_frames, preset="ultrafast"):
     """one reference encoder process -> (seconds, ok)"""
-    cmd = [ref_bin, "-i", yuv, "--input-res", f"{w}x{h}", "--preset", "ultrafast", "-p", "1", "-q", str(qp), "-n", str(n_frames), "-o", "/dev/null"] + extra
+    cmd = [ref_bin, "-i", yuv, "--input-res", f"{w}x{h}"] + PRESET_CLI[preset] + ["-p", "1", "-q", str(qp), "-n", str(n_frames), "-o", "/dev/null"] + extra
     t = time.time()
     r = subprocess.run(cmd, capture_output=True, text=True)
     return time.time() - t, r.returncode == 0
@@ -169,7 +172,7 @@ def cpu_baseline(args, frames, model):
         def median_of(extra, n_frames, reps):
             ts = []
             for _ in range(reps):
-                s, ok = run_encoder(ref_bin, tmp.name, w, h, args.qp, extra, n_frames)
+                s, ok = run_encoder(ref_bin, tmp.name, w, h, args.qp, extra, n_frames, args.preset)
                 if ok:
                     ts.append(s)
             return sorted(ts)[len(ts) // 2] if ts else None
@@ -181,7 +184,7 @@ def cpu_baseline(args, frames, model):
         procs = max(1, threads // 16)
         nsat = nf // 2  # ~10 s of host time on a 256-thread box
         t = time.time()
-        ps = [subprocess.Popen([ref_bin, "-i", tmp.name, "--input-res", f"{w}x{h}", "--preset", "ultrafast", "-p", "1", "-q", str(args.qp), "-n", str(nsat),
+        ps = [subprocess.Popen([ref_bin, "-i", tmp.name, "--input-res", f"{w}x{h}"] + PRESET_CLI[args.preset] + ["-p", "1", "-q", str(args.qp), "-n", str(nsat),
                                 "--threads", "16", "-o", "/dev/null"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for _ in range(procs)]
         ok = all(p.wait() == 0 for p in ps)
         s = time.time() - t
@@ -200,7 +203,7 @@ def cpu_baseline(args, frames, model):
         return port
     best = max(multi, key=lambda k: legs[k]["value"])
     return {"value": legs[best]["value"], "unit": "CTUs/s", "cores": legs[best]["cores"], "kind": "reference",
-            "sample": f"oracle/_ref/kvazaar_ref (kvazaar's AVX2 strategies, whole encoder incl. CABAC + deblocking) --preset ultrafast -p 1 -q {args.qp}; best of the multi-core legs = "
+            "sample": f"oracle/_ref/kvazaar_ref (kvazaar's AVX2 strategies, whole encoder incl. CABAC + deblocking) {' '.join(PRESET_CLI[args.preset])} -p 1 -q {args.qp}; best of the multi-core legs = "
                       f"{best}: {legs[best]['sample']}", "legs": legs, "port": port}
 
 
