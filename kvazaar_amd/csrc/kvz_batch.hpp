@@ -102,6 +102,7 @@ template <bool CABAC, bool S32, bool RDOQ> __device__ __forceinline__ void ticke
     __syncthreads();
     CtuProgramT<CABAC, S32, RDOQ> p;
     p.m = &m; p.tb = tb; p.F = F; p.s = &shared;
+    if constexpr (RDOQ) { __shared__ RdoqLds rdoq_lds; p.rl = &rdoq_lds; }
     p.frame = frame; p.cx = x * 64; p.cy = y * 64;
     p.lane_rot = (t * 64) & (KVZ_CTU_THREADS - 1);
     p.run();
@@ -121,8 +122,11 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> __global__ void __lau
   ticket_loop<CABAC, S32, RDOQ>(F, model, tb, sched);
 }
 // --rdoq: kvz_rdoq is a long double-precision routine run by one lane per plane; at 128 VGPRs its many inlined copies spill by the thousand, so this
-// instantiation trades occupancy (2 wavefronts per SIMD = 4 workgroups per CU) for registers
-__global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(1, 2))) intra_ctu_ticket_kernel_rdoq(const CtuFrames F, const CtuModel model, const Tables *tb, const CtuSched sched)
+// instantiation trades occupancy for registers (KVZ_RDOQ_WAVES_PER_EU wavefronts per SIMD: 3 = 168 VGPRs, 6 workgroups per CU)
+#ifndef KVZ_RDOQ_WAVES_PER_EU
+#define KVZ_RDOQ_WAVES_PER_EU 3
+#endif
+__global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(1, KVZ_RDOQ_WAVES_PER_EU))) intra_ctu_ticket_kernel_rdoq(const CtuFrames F, const CtuModel model, const Tables *tb, const CtuSched sched)
 {
   ticket_loop<true, true, true>(F, model, tb, sched);
 }

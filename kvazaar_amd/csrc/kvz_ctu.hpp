@@ -259,6 +259,12 @@ using CtuShared = CtuSharedT<true>;
 
 static const int kPlaneOff[3] = { 0, 4096, 5120 };
 
+// What the RDOQ instantiation keeps in LDS on top of CtuSharedT: the price of both bins of every context at the row coder's states, fixed for the CTU.
+// (kvz_rdoq's per-position cost arrays were tried here too, for blocks up to 16x16: no gain -- the routine is bound by its own serial instruction stream --
+// and 12 KB less LDS means more CTUs in flight.)
+struct RdoqLds {
+  i32 ptab[2 * 148];
+};
 // RDOQ: the instantiation that quantises with kvz_rdoq (kvz_hip_intra_cost_model::rdoq, preset `medium`); the others carry none of its code
 // S32: the instantiation that can also SEARCH 32x32 CUs (kvz_hip_intra_cost_model::search_32x32, --pu-depth-intra 1-3); the others carry none of its code
 template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
@@ -267,6 +273,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   const Tables *tb;
   CtuFrames F;
   CtuSharedT<CABAC> *s;
+  RdoqLds *rl = nullptr;  // RDOQ instantiation only
   KVZ_DEV bool cabac_on() const { return CABAC && m->coeff_cabac; }  // coefficients priced with the CABAC model (rdo.c:311-340)
   int frame, cx, cy;  // CTU origin (luma px)
   int a1x, a1y, a2x, a2y;  // CTU-local luma origin of the depth-1 / depth-2 CU whose candidates are live (uniform)
@@ -1630,7 +1637,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
           i16 *cout = lv == 2 ? s->lv2_coeff + (c == 0 ? 0 : (c == 1 ? 256 : 320))
                     : lv == 1 ? s->lv1_coeff + (c == 0 ? 0 : (c == 1 ? 1024 : 1280)) : coeff_level(lv) + kPlaneOff[c] + zorder(xl >> sh, yl >> sh);
           RdoqCtx rc{ s->pre[0].s, tb->entropy_bits, m->lambda };
-          rc.fbits = s->entropy_fbits;  // the price table's copy in LDS
+          rc.ptab = rl->ptab;
           // tr_depth = cu->tr_depth - cu->depth: 1 for the 32x32 units of the 64x64 attempt (level 0), 0 otherwise
           rdoq_block(rc, m->qp, tbuf(t, 0, c), cout, l2, c ? 2 : 0, scan_mode, lv == 0 ? 1 : 0, tb->diag8, rdoq_scratch(c));
         }
@@ -2344,6 +2351,12 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     t_last = __builtin_amdgcn_s_memtime();
 #endif
     init();
+    if (RDOQ && m->rdoq) {  // kvz_rdoq prices on state->cabac's contexts as they stand now (pre[0]): both bins of every context, once per CTU
+      KVZ_FOR_THREADS(tid) {
+        for (int v = tid; v < 2 * KVZ_CX_COUNT; v += KVZ_CTU_THREADS) rl->ptab[v] = (i32)(s->entropy_fbits[s->pre[0].s[v >> 1] ^ (v & 1)] * 32768.0f);
+      }
+      KVZ_SYNC();
+    }
     KVZ_PROF(KVZ_P_INIT);
     KVZ_FOR_THREADS(tid) {
       if (tid == 0) { cu_header(0, 0, 0, 0); s->cost[0] = 1.7e+308; s->split_cost[0] = split_flag_cost(0, cx, cy, 0); }

@@ -16,8 +16,9 @@ struct RdoqCtx {
   const u8 *ctx;        // uc_state of the contexts in KVZ_HIP_CX_* order (include/kvz_hip_types.h)
   const u32 *bits;      // kvz_entropy_bits (rdo.c:69-80): Q15 price of coding `bin` in state s = bits[s ^ bin]
   double lambda;
-  const float *fbits = nullptr;  // the same prices as multiples of 2^-15 in floats (the CTU kernel's copy in LDS); used instead of `bits` when set
-  KVZ_DEV i32 price(int idx, int bin) const { return fbits ? (i32)(fbits[ctx[idx] ^ bin] * 32768.0f) : (i32)bits[ctx[idx] ^ bin]; }
+  const i32 *ptab = nullptr;     // prices of both bins of every context at the caller's states, [2 * idx + bin] (the CTU kernel builds it once per CTU in LDS:
+                                 // the states do not move while a CTU is searched); used instead of ctx / bits when set
+  KVZ_DEV i32 price(int idx, int bin) const { return ptab ? ptab[2 * idx + bin] : (i32)bits[ctx[idx] ^ bin]; }
 };
 
 // The coefficient scans by arithmetic (HEVC scans are hierarchical: 4x4 groups in group order, sixteen positions inside a group): no table in memory on the

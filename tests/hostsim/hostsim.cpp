@@ -53,7 +53,9 @@ extern "C" void kvz_hostsim_intra_frame(const kvz_hip_intra_cost_model *m, int w
   for (int cy = 0; cy < F.hc; cy++)
     for (int cx = 0; cx < F.wc; cx++) {
       if (m->rdoq) {  // --rdoq: the instantiation with kvz_rdoq in the quantisation stage (CABAC cost model; 32x32 search switched by the model)
+        static kvz::RdoqLds rdoq_lds;
         kvz::CtuProgramT<true, true, true> p;
+        p.rl = &rdoq_lds;
         p.m = &cm; p.tb = &tb; p.F = F; p.s = (kvz::CtuSharedT<true> *)sh; p.frame = 0; p.cx = cx * 64; p.cy = cy * 64;
         p.run();
       } else if (m->search_32x32) {  // the instantiations that search 32x32 CUs
