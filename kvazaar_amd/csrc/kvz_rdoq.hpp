@@ -145,7 +145,14 @@ KVZ_DEV int rdoq_sig_ctx_inc(int pattern, int scan_idx, int pos_x, int pos_y, in
 }
 
 // The block.  coef: transform coefficients (row-major w x w); dest: quantised levels (out); diag8: Tables::diag8; cost3: 3 * w * w doubles of scratch.
-KVZ_DEV void rdoq_block(const RdoqCtx &c, int qp, const i16 *coef, i16 *dest, int log2w, int type /* 0 luma, 2 chroma */, int scan_mode, int tr_depth, const u8 *diag8, double *cost3)
+// -DKVZ_RDOQ_CALL: a real function call on the device instead of a dozen inlined copies in the CTU program (A/B: 20.2 k vs 22.4 k CTUs/s -- the callee's 256+
+// registers leave one wavefront per SIMD; the instruction cache is not what limits the pass).
+#if defined(KVZ_RDOQ_CALL) && !defined(KVZ_HOSTSIM)
+#define KVZ_RDOQ_NOINLINE __attribute__((noinline))
+#else
+#define KVZ_RDOQ_NOINLINE
+#endif
+KVZ_DEV KVZ_RDOQ_NOINLINE void rdoq_block(const RdoqCtx &c, int qp, const i16 *coef, i16 *dest, int log2w, int type /* 0 luma, 2 chroma */, int scan_mode, int tr_depth, const u8 *diag8, double *cost3)
 {
   const int width = 1 << log2w, n = width * width;
   const int transform_shift = 15 - 8 - log2w;
