@@ -122,11 +122,13 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> __global__ void __lau
   ticket_loop<CABAC, S32, RDOQ>(F, model, tb, sched);
 }
 // --rdoq: kvz_rdoq is a long double-precision routine run by one lane per plane; at 128 VGPRs its many inlined copies spill by the thousand, so this
-// instantiation trades occupancy for registers (KVZ_RDOQ_WAVES_PER_EU wavefronts per SIMD: 3 = 168 VGPRs, 6 workgroups per CU)
+// instantiation trades occupancy for registers: exactly KVZ_RDOQ_WAVES_PER_EU wavefronts per SIMD (3 = 168 VGPRs, 6 workgroups per CU).  Measured at 1080p QP 27
+// (the pass waits on LDS / memory three quarters of the time, so residency counts until spills take over): 1 wavefront per SIMD (512 registers) 22.5 k CTUs/s,
+// 2 (256) 41.0 k, 3 (168) 54.3 k, 4 (128, thousands of spills) 17.5 k
 #ifndef KVZ_RDOQ_WAVES_PER_EU
 #define KVZ_RDOQ_WAVES_PER_EU 3
 #endif
-__global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(1, KVZ_RDOQ_WAVES_PER_EU))) intra_ctu_ticket_kernel_rdoq(const CtuFrames F, const CtuModel model, const Tables *tb, const CtuSched sched)
+__global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_RDOQ_WAVES_PER_EU, KVZ_RDOQ_WAVES_PER_EU))) intra_ctu_ticket_kernel_rdoq(const CtuFrames F, const CtuModel model, const Tables *tb, const CtuSched sched)
 {
   ticket_loop<true, true, true>(F, model, tb, sched);
 }
