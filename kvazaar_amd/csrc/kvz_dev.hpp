@@ -777,35 +777,49 @@ inline void deblock_frames_on(hipStream_t stream, u8 *frames, int width, int hei
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Picture-hash checksums of whole frames (nal.c:73-86 kvz_image_checksum -> nal-generic.c:57-82 per plane): one lane per dword
-// of a plane row, the four masks of a dword are c ^ {0, 1, 2, 3} for the lane's c = (x & 255) ^ (y & 255) ^ (x >> 8) ^ (y >> 8),
-// v_sad_u8 against zero adds the four bytes, then a wavefront sum and one atomic per wavefront.  out[frame][plane].
-__global__ void __launch_bounds__(256) dev_checksum_kernel(const u8 *frames, int W, int H, long frame_bytes, long dwords_per_frame, long total, u32 *out)
+// The "checksum" picture hash (nal-generic.c:57-82 array_checksum) of a batch: per plane the 32-bit wrap-around sum of sample ^ mask(x, y),
+// mask = (x & 0xff) ^ (y & 0xff) ^ (x >> 8) ^ (y >> 8).  One workgroup per (plane, group of rows): a lane takes 16 samples of a row per step -- inside an
+// aligned group of 16 the mask is one byte xor the position in the group, so four v_sad_u8 against 0 sum them -- and walks down the group's rows; the
+// workgroup's sum goes out with one atomic add.  No divisions by run-time values (the first version spent its time in 64-bit index arithmetic: 160 GB/s).
+__global__ void __launch_bounds__(256) dev_checksum_kernel(const u8 *frames, const int W, const int H, const long frame_bytes, const int rows_per_wg, u32 *out)
 {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  __shared__ u32 s_sum[4];
+  const int fp = blockIdx.y, frame = fp / 3, plane = fp - 3 * frame;
+  const int pw = plane ? W >> 1 : W, ph = plane ? H >> 1 : H;
+  const u8 *base = frames + frame * frame_bytes + (plane == 0 ? 0 : (plane == 1 ? (long)W * H : (long)W * H * 5 / 4));
+  const int y0 = blockIdx.x * rows_per_wg, y1 = y0 + rows_per_wg < ph ? y0 + rows_per_wg : ph;
   u32 v = 0;
-  long frame = 0;
-  int plane = 0;
-  if (i < total) {
-    frame = i / dwords_per_frame;
-    long r = i % dwords_per_frame;
-    const long yd = (long)(W >> 2) * H, cd = (long)(W >> 3) * (H >> 1);
-    plane = r < yd ? 0 : (r < yd + cd ? 1 : 2);
-    r -= plane == 0 ? 0 : (plane == 1 ? yd : yd + cd);
-    const int wd = plane ? W >> 3 : W >> 2;  // dwords per row of the plane
-    const int y = (int)(r / wd), x = 4 * (int)(r % wd);
-    const u32 w = reinterpret_cast<const u32 *>(frames + frame * frame_bytes + (plane == 0 ? 0 : (plane == 1 ? (long)W * H : (long)W * H * 5 / 4)))[r];
-    const u32 c = ((x & 0xff) ^ (y & 0xff) ^ (x >> 8) ^ (y >> 8)) & 0xff;
-    v = __builtin_amdgcn_sad_u8(w ^ (c * 0x01010101u) ^ 0x03020100u, 0u, 0u);
+  if (y0 < ph) {
+    if ((pw & 15) == 0) {
+      const int units = pw >> 4;  // 16-sample units per row
+      for (int i = threadIdx.x; i < units * (y1 - y0); i += 256) {
+        const int ry = i / units, u = i - ry * units, y = y0 + ry, x = 16 * u;
+        const uint4 w4 = *reinterpret_cast<const uint4 *>(base + (long)y * pw + x);
+        const u32 c = (((x & 0xff) ^ (y & 0xff) ^ (x >> 8) ^ (y >> 8)) & 0xff) * 0x01010101u;
+        v = __builtin_amdgcn_sad_u8(w4.x ^ c ^ 0x03020100u, 0u, v);
+        v = __builtin_amdgcn_sad_u8(w4.y ^ c ^ 0x07060504u, 0u, v);
+        v = __builtin_amdgcn_sad_u8(w4.z ^ c ^ 0x0b0a0908u, 0u, v);
+        v = __builtin_amdgcn_sad_u8(w4.w ^ c ^ 0x0f0e0d0cu, 0u, v);
+      }
+    } else {  // widths that are multiples of 4 only: dword by dword
+      const int units = pw >> 2;
+      for (int i = threadIdx.x; i < units * (y1 - y0); i += 256) {
+        const int ry = i / units, u = i - ry * units, y = y0 + ry, x = 4 * u;
+        const u32 w = *reinterpret_cast<const u32 *>(base + (long)y * pw + x);
+        const u32 c = (((x & 0xff) ^ (y & 0xff) ^ (x >> 8) ^ (y >> 8)) & 0xff) * 0x01010101u;
+        v = __builtin_amdgcn_sad_u8(w ^ c ^ 0x03020100u, 0u, v);
+      }
+    }
   }
-  // a wavefront may straddle a plane / frame boundary: lanes add into their own (frame, plane) slot, wavefront-summed when uniform
-  const long first = __shfl(i < total ? frame * 3 + plane : -1, 0), last = __shfl(i < total ? frame * 3 + plane : -1, 63);
-  if (first == last && first >= 0) {
-    const u32 s = group_sum<64>(v);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&out[first], s);
-  } else if (i < total) {
-    atomicAdd(&out[frame * 3 + plane], v);
-  }
+  v = group_sum<64>(v);
+  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0 && y0 < ph) atomicAdd(&out[fp], s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+}
+inline void launch_checksums(hipStream_t stream, const u8 *frames, int W, int H, int n_frames, u32 *out)
+{
+  const int rows = 32;  // 60 KB of a 1080p luma plane per workgroup
+  hipLaunchKernelGGL(dev_checksum_kernel, dim3((unsigned)((H + rows - 1) / rows), (unsigned)(3 * n_frames)), dim3(256), 0, stream, frames, W, H, (long)W * H * 3 / 2, rows, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1083,9 +1097,9 @@ void kvz_hip_dev_sao_frames(const uint8_t *in, uint8_t *out, int width, int heig
 void kvz_hip_dev_picture_checksums(const uint8_t *frames, int width, int height, int n_frames, uint32_t *out)
 {
   if (n_frames <= 0) return;
-  const long per_frame = (long)(width >> 2) * height + 2L * (width >> 3) * (height >> 1), total = per_frame * n_frames;
   KVZ_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)n_frames * 3 * sizeof(uint32_t), be().stream));
-  KVZ_DEV_LAUNCH(kvz::dev_checksum_kernel, total, frames, width, height, (long)width * height * 3 / 2, per_frame, total, out);
+  kvz::launch_checksums(be().stream, frames, width, height, n_frames, out);
+  KVZ_HIP_CHECK(hipGetLastError());
 }
 
 void kvz_hip_batch_deblock(kvz_hip_batch *b, int qp, int beta_offset_div2, int tc_offset_div2)
@@ -1181,9 +1195,7 @@ int kvz_hip_batch_checksums(kvz_hip_batch *b, uint32_t *host_out)
   uint32_t *d = nullptr;
   KVZ_HIP_CHECK(hipMallocAsync((void **)&d, (size_t)n * 3 * sizeof(uint32_t), b->stream));
   KVZ_HIP_CHECK(hipMemsetAsync(d, 0, (size_t)n * 3 * sizeof(uint32_t), b->stream));
-  const long per_frame = (long)(b->F.W >> 2) * b->F.H + 2L * (b->F.W >> 3) * (b->F.H >> 1), total = per_frame * n;
-  hipLaunchKernelGGL(kvz::dev_checksum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, b->stream, b->d_rec, b->F.W, b->F.H,
-                     (long)b->F.W * b->F.H * 3 / 2, per_frame, total, d);
+  kvz::launch_checksums(b->stream, b->d_rec, b->F.W, b->F.H, n, d);
   KVZ_HIP_CHECK(hipGetLastError());
   KVZ_HIP_CHECK(hipMemcpyAsync(host_out, d, (size_t)n * 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
   KVZ_HIP_CHECK(hipFreeAsync(d, b->stream));
