@@ -830,7 +830,10 @@ __global__ void __launch_bounds__(256) dev_sao_stats_kernel(const u8 *src, const
   // accumulators: {sum, count} of a statistic packed into one 64-bit LDS word (sum in the high half, count in the low half: one ds_add_u64 per
   // sample and statistic; the count never carries into the sum -- at most 4096 samples).  Category 0 of the edge classes is never read by the
   // decision (its offset is 0 by definition, sao.c:417-418), so samples of category 0 -- the majority -- touch the band histogram only.
-  __shared__ unsigned long long acc[4 * 5 + 32];
+  // Sixteen private copies of the 52 accumulators, interleaved so that copy c lives in LDS banks 2 c, 2 c + 1: the lanes of a wavefront that hit the same
+  // statistic no longer serialise on one address (one atomic per cycle and CU was the whole kernel: 34 ms per 1 536 pictures).
+  constexpr int NACC = 4 * 5 + 32, COPIES = 16;
+  __shared__ unsigned long long acc[NACC * COPIES];
   __shared__ SaoStats st;
   __shared__ u8 s_rec[64 * 64], s_org[64 * 64];
   const long item = blockIdx.x;  // (frame, lcu, plane)
@@ -842,7 +845,8 @@ __global__ void __launch_bounds__(256) dev_sao_stats_kernel(const u8 *src, const
   const long plane = frame * g.frame_bytes + (color == 0 ? 0 : (color == 1 ? (long)g.W * g.H : (long)g.W * g.H * 5 / 4));
   const int bw = imin(n, fw - lx * n), bh = imin(n, fh - ly * n);  // sao.c:598-605, 645-650
   SaoView view{ R + plane, V + plane, D + plane, fw, n, lx * n, ly * n, lx == g.wl - 1, ly == g.hl - 1, color ? 1 : 3 };
-  if (threadIdx.x < 4 * 5 + 32) acc[threadIdx.x] = 0;
+  for (int i = threadIdx.x; i < NACC * COPIES; i += 256) acc[i] = 0;
+  const int copy = threadIdx.x & (COPIES - 1);
   for (int p = threadIdx.x; p < bw * bh; p += 256) {
     const int x = p % bw, y = p / bw;
     s_rec[p] = (u8)view.at(x, y);
@@ -852,20 +856,21 @@ __global__ void __launch_bounds__(256) dev_sao_stats_kernel(const u8 *src, const
   for (int p = threadIdx.x; p < bw * bh; p += 256) {
     const int x = p % bw, y = p / bw, c = s_rec[p], diff = (int)s_org[p] - c;
     const unsigned long long add = ((unsigned long long)(long long)diff << 32) + 1ull;  // sum += diff (two's complement in the high half), count += 1
-    atomicAdd(&acc[20 + (c >> 3)], add);
+    atomicAdd(&acc[(20 + (c >> 3)) * COPIES + copy], add);
     if (x >= 1 && x < bw - 1 && y >= 1 && y < bh - 1) {  // sao-generic.c:68-69: the block's interior
 #pragma unroll
       for (int ec = 0; ec < 4; ec++) {
         int ax, ay, bx, by;
         eo_offsets(ec, ax, ay, bx, by);
         const int cat = eo_cat(s_rec[p + ay * bw + ax], s_rec[p + by * bw + bx], c);
-        if (cat) atomicAdd(&acc[ec * 5 + cat], add);
+        if (cat) atomicAdd(&acc[(ec * 5 + cat) * COPIES + copy], add);
       }
     }
   }
   __syncthreads();
   if (threadIdx.x < 4 * 5 + 32) {  // unpack: the low half's carries never reach bit 32 (counts <= 4096), the high half is the signed sum
-    const unsigned long long v = acc[threadIdx.x];
+    unsigned long long v = 0;
+    for (int k = 0; k < COPIES; k++) v += acc[threadIdx.x * COPIES + k];
     const i32 sum = (i32)(v >> 32), cnt = (i32)(v & 0xffffffffu);
     if (threadIdx.x < 20) { st.edge_sum[threadIdx.x / 5][threadIdx.x % 5] = sum; st.edge_cnt[threadIdx.x / 5][threadIdx.x % 5] = cnt; }
     else { st.band_sum[threadIdx.x - 20] = sum; st.band_cnt[threadIdx.x - 20] = cnt; }
