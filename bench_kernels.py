@@ -86,10 +86,10 @@ def main():
             ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_transform(kind, di, dt, do, count, mfma), args.reps, args.warmup)
             if mfma == 0:
                 suffix, extra = "_scalar", {"path": "one lane per coefficient, two passes through HBM"}
-            elif mfma == 1 and n <= 8:
+            elif mfma == 1 and n <= 16:
                 suffix, extra = "_rows", {"path": "vector ALU, one lane per block row: v_dot2_i32_i16 on packed pairs, transposes through LDS"}
             else:
-                if mfma == 2 and n >= 16:
+                if mfma == 2 and n == 32:
                     continue                                                       # same kernel as mfma == 1
                 suffix = "_mfma"
                 per_issue = 32 if n == 32 else 16                                  # edge of the product the blocks ride on

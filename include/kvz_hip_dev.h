@@ -37,9 +37,9 @@ void kvz_hip_dev_sad_nxn(int n, const uint8_t *a, const uint8_t *b, int count, u
 void kvz_hip_dev_satd_nxn(int n, const uint8_t *a, const uint8_t *b, int count, uint32_t *out);
 
 /* kvz_dct_NxN / kvz_idct_NxN / 4x4 DST (dct-generic.c:559-630), 8-bit: `kind` = enum kvz_hip_transform_kind.
- * use_matrix_cores == 1 (the product path): 16- and 32-point blocks on the matrix cores (v_mfma_i32_*_i8 on byte planes, exact integer
- * arithmetic, one block per wavefront), 4- and 8-point blocks on the vector ALU, one lane per block row (v_dot2_i32_i16, transposes through LDS).
- * == 2: the small sizes on the matrix cores as well, 4 or 2 blocks on the diagonal of a 16 x 16 product (kept for A/B).
+ * use_matrix_cores == 1 (the product path): 32-point blocks on the matrix cores (v_mfma_i32_32x32x32_i8 on byte planes, exact integer arithmetic, one block per
+ * wavefront), 4-, 8- and 16-point blocks on the vector ALU, one lane per block row (v_dot2_i32_i16, transposes through LDS).
+ * == 2: every size on the matrix cores, the small ones 4 or 2 blocks on the diagonal of a 16 x 16 product (kept for A/B).
  * == 0: one lane per coefficient, two launches through `tmp` (count * n^2 int16 of scratch; may be NULL otherwise). */
 void kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *out, int count, int use_matrix_cores);
 

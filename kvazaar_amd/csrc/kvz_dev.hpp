@@ -155,34 +155,38 @@ template <int N> __global__ void __launch_bounds__(256) dev_transform_mfma_kerne
 // rounding constant as the initial accumulator; the transposition between (and after / before) the two passes goes through a padded LDS tile:
 // NB 2-byte writes, one 8- or 16-byte read per row.  forward (dct-generic.c:559-579): pass, transpose, pass, transpose; inverse: transpose, pass,
 // transpose, pass.  Four rows per lane (loads of all four in flight at once), 1024 rows per workgroup.
-template <int NB> __global__ void __launch_bounds__(256) dev_transform_rows_kernel(const i16 *in, i16 *out, const long rows_total, const int inverse, const u32 *pairs /* [2][8][4] */)
+template <int NB> __global__ void __launch_bounds__(256) dev_transform_rows_kernel(const i16 *in, i16 *out, const long rows_total, const int inverse, const u32 *pairs /* [2][NB][NB / 2], rows padded to 4 pairs for NB = 4 */)
 {
-  constexpr int R = 4, PW = NB / 2, BS = NB * NB + (NB == 8 ? 8 : 4), BLOCKS = R * 256 / NB, L2 = NB == 4 ? 2 : 3;
+  constexpr int R = NB == 16 ? 2 : 4, PW = NB / 2, KS = NB == 16 ? 8 : 4, WS = NB == 16 ? 128 : 32, BS = NB * NB + (NB == 4 ? 4 : 8), BLOCKS = R * 256 / NB, L2 = NB == 4 ? 2 : (NB == 8 ? 3 : 4);
   typedef short s16x2 __attribute__((ext_vector_type(2)));
   __shared__ alignas(16) i16 s_t[BLOCKS * BS];
   const int tid = threadIdx.x;
-  u32 cp[NB][PW];
-  for (int k = 0; k < NB; k++) for (int i = 0; i < PW; i++) cp[k][i] = pairs[(inverse ? 32 : 0) + k * 4 + i];
+  const u32 *cp = pairs + (inverse ? WS : 0);  // uniform: the matrix pairs come through the scalar cache (this table is never rewritten)
   u32 p[R][PW];
   long row[R];
   int base[R];  // element offset of the row's block in the tile
-  const int r = tid % NB;  // the row's index in its block (256 is a multiple of NB: the same for all four)
+  const int r = tid % NB;  // the row's index in its block (256 is a multiple of NB: the same for every row of the lane)
+  auto rd = [&](const i16 *ptr, u32 *x) {  // one row = PW dwords
+    if (NB == 4) { const uint2 v = *reinterpret_cast<const uint2 *>(ptr); x[0] = v.x; x[1] = v.y; }
+    else for (int h = 0; h < PW / 4; h++) { const uint4 v = reinterpret_cast<const uint4 *>(ptr)[h]; x[4 * h] = v.x; x[4 * h + 1] = v.y; x[4 * h + 2] = v.z; x[4 * h + 3] = v.w; }
+  };
+  auto wr = [&](i16 *ptr, const u32 *x) {
+    if (NB == 4) *reinterpret_cast<uint2 *>(ptr) = make_uint2(x[0], x[1]);
+    else for (int h = 0; h < PW / 4; h++) reinterpret_cast<uint4 *>(ptr)[h] = make_uint4(x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]);
+  };
 #pragma unroll
   for (int q = 0; q < R; q++) {
     row[q] = ((long)blockIdx.x * R + q) * 256 + tid;
     base[q] = ((q * 256 + tid) / NB) * BS;
     for (int i = 0; i < PW; i++) p[q][i] = 0;
-    if (row[q] < rows_total) {
-      if (NB == 8) { const uint4 v = reinterpret_cast<const uint4 *>(in)[row[q]]; p[q][0] = v.x; p[q][1] = v.y; p[q][PW - 2] = v.z; p[q][PW - 1] = v.w; }
-      else { const uint2 v = reinterpret_cast<const uint2 *>(in)[row[q]]; p[q][0] = v.x; p[q][1] = v.y; }
-    }
+    if (row[q] < rows_total) rd(in + row[q] * NB, p[q]);
   }
   auto pass = [&](const u32 *x, int shift, bool clip, int *y) {
 #pragma unroll
     for (int k = 0; k < NB; k++) {
       int acc = 1 << (shift - 1);
 #pragma unroll
-      for (int i = 0; i < PW; i++) acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, x[i]), __builtin_bit_cast(s16x2, cp[k][i]), acc, false);
+      for (int i = 0; i < PW; i++) acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, x[i]), __builtin_bit_cast(s16x2, cp[k * KS + i]), acc, false);
       acc >>= shift;
       y[k] = clip ? iclip(-32768, 32767, acc) : acc;
     }
@@ -191,11 +195,7 @@ template <int NB> __global__ void __launch_bounds__(256) dev_transform_rows_kern
 #pragma unroll
     for (int e = 0; e < NB; e++) s_t[base[q] + e * NB + r] = (i16)y[e];
   };
-  auto get = [&](int q, u32 *x) {    // the lane's row of the tile
-    const i16 *src = &s_t[base[q] + r * NB];
-    if (NB == 8) { const uint4 v = *reinterpret_cast<const uint4 *>(src); x[0] = v.x; x[1] = v.y; x[PW - 2] = v.z; x[PW - 1] = v.w; }
-    else { const uint2 v = *reinterpret_cast<const uint2 *>(src); x[0] = v.x; x[1] = v.y; }
-  };
+  auto get = [&](int q, u32 *x) { rd(&s_t[base[q] + r * NB], x); };  // the lane's row of the tile
   int y[NB];
   if (!inverse) {
 #pragma unroll
@@ -229,10 +229,7 @@ template <int NB> __global__ void __launch_bounds__(256) dev_transform_rows_kern
   }
 #pragma unroll
   for (int q = 0; q < R; q++)
-    if (row[q] < rows_total) {
-      if (NB == 8) reinterpret_cast<uint4 *>(out)[row[q]] = make_uint4(p[q][0], p[q][1], p[q][PW - 2], p[q][PW - 1]);
-      else reinterpret_cast<uint2 *>(out)[row[q]] = make_uint2(p[q][0], p[q][1]);
-    }
+    if (row[q] < rows_total) wr(out + row[q] * NB, p[q]);
 }
 
 // 4- and 8-point transforms (and the 4x4 DST): 16 / n blocks sit on the diagonal of one 16x16 problem, the matrix is the
@@ -999,6 +996,11 @@ void kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *o
 {
   static const int sizes[5] = { 4, 8, 16, 32, 4 };
   const int inverse = kind >= KVZ_HIP_IDCT_4, idx = inverse ? kind - KVZ_HIP_IDCT_4 : kind, n = sizes[idx];
+  if (use_matrix_cores == 1 && n == 16) {  // 16-point blocks: one lane per row on v_dot2_i32_i16 as well (5 TB/s against 3.4 TB/s on the matrix cores, which use_matrix_cores == 2 keeps)
+    const long rows = (long)count * 16;
+    KVZ_DEV_LAUNCH(kvz::dev_transform_rows_kernel<16>, (rows + 511) / 512 * 256, in, out, rows, inverse, &kvz::device_tables()->pairs16[0][0][0]);
+    return;
+  }
   if (use_matrix_cores && (n == 16 || n == 32) && idx != 4) {
     const long threads = ((long)count + 3) / 4 * 256;
     if (n == 16) KVZ_DEV_LAUNCH(kvz::dev_transform_mfma_kernel<16>, threads, in, out, count, inverse, kvz::device_tables());

@@ -60,6 +60,7 @@ struct Tables {
   // The small matrices as int16 pairs for v_dot2_i32_i16 (kvz_dev.hpp dev_transform_rows_kernel): [0: C4, 1: C8, 2: DST4][0: rows of M, 1: rows of M^T]
   // [output][pair] = M[k][2 i] | M[k][2 i + 1] << 16
   u32 small_pairs[3][2][8][4];
+  u32 pairs16[2][16][8];  // the same for C16
   u32 scan[3][4][1024];  // [scan_idx][log2-2] (tables.c kvz_g_sig_last_scan), sizes 4..32
   // intra.c:47-82 num_ref_pixels_top / num_ref_pixels_left: reference samples available above-right / below-left of the 4x4
   // unit at [y / 4][x / 4] of a CTU, regenerated from the z-order of the units (kvz_tables.hpp)

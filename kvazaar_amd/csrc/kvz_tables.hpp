@@ -149,6 +149,12 @@ inline void build_tables(Tables *t)
         t->small_pairs[kind][1][k][i] = (u32)(u16)m[(2 * i) * n + k] | ((u32)(u16)m[(2 * i + 1) * n + k] << 16);
       }
   }
+  for (int k = 0; k < 16; k++)
+    for (int i = 0; i < 8; i++) {
+      const i16 *m = t->dct[2];
+      t->pairs16[0][k][i] = (u32)(u16)m[k * 16 + 2 * i] | ((u32)(u16)m[k * 16 + 2 * i + 1] << 16);
+      t->pairs16[1][k][i] = (u32)(u16)m[(2 * i) * 16 + k] | ((u32)(u16)m[(2 * i + 1) * 16 + k] << 16);
+    }
   for (int type = 0; type < 3; type++)
     for (int l2 = 2; l2 <= 5; l2++) {
       const int size = 1 << l2, cgs = size / 4;
