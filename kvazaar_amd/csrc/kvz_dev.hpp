@@ -562,9 +562,15 @@ template <bool TAIL> __global__ void __launch_bounds__(256) dev_sao_kernel(const
 }
 inline void launch_sao(hipStream_t stream, const u8 *in, u8 *out, int W, int H, int n_frames, const unsigned long long *packed, const kvz_hip_sao_params *luma, const kvz_hip_sao_params *chroma)
 {
-  const dim3 grid((unsigned)((((W + 63) >> 6) + 3) >> 2), (unsigned)((H + 63) >> 6), (unsigned)n_frames);
-  if ((W >> 1) % 16 == 0) hipLaunchKernelGGL(dev_sao_kernel<false>, grid, dim3(256), 0, stream, in, out, W, H, packed, luma, chroma);
-  else hipLaunchKernelGGL(dev_sao_kernel<true>, grid, dim3(256), 0, stream, in, out, W, H, packed, luma, chroma);
+  const long fb = (long)W * H * 3 / 2, lcus = (long)((W + 63) >> 6) * ((H + 63) >> 6);
+  for (int f0 = 0; f0 < n_frames; f0 += 32768) {  // gridDim.z <= 65535
+    const int nf = n_frames - f0 < 32768 ? n_frames - f0 : 32768;
+    const dim3 grid((unsigned)((((W + 63) >> 6) + 3) >> 2), (unsigned)((H + 63) >> 6), (unsigned)nf);
+    const unsigned long long *pk = packed ? packed + 3 * lcus * f0 : nullptr;
+    const kvz_hip_sao_params *lu = luma ? luma + lcus * f0 : nullptr, *ch = chroma ? chroma + lcus * f0 : nullptr;
+    if ((W >> 1) % 16 == 0) hipLaunchKernelGGL(dev_sao_kernel<false>, grid, dim3(256), 0, stream, in + f0 * fb, out + f0 * fb, W, H, pk, lu, ch);
+    else hipLaunchKernelGGL(dev_sao_kernel<true>, grid, dim3(256), 0, stream, in + f0 * fb, out + f0 * fb, W, H, pk, lu, ch);
+  }
 }
 
 struct DeblockGeom { int W, H, beta, tc, tc_c; long frame_bytes; const u8 *cu_depth; const kvz_hip_cu_dbk *info; int slice_b, tc1; /* inter pictures: per-4x4 records, tc at strength 1 */ };
@@ -816,7 +822,11 @@ __global__ void __launch_bounds__(256) dev_checksum_kernel(const u8 *frames, con
 inline void launch_checksums(hipStream_t stream, const u8 *frames, int W, int H, int n_frames, u32 *out)
 {
   const int rows = 32;  // 60 KB of a 1080p luma plane per workgroup
-  hipLaunchKernelGGL(dev_checksum_kernel, dim3((unsigned)((H + rows - 1) / rows), (unsigned)(3 * n_frames)), dim3(256), 0, stream, frames, W, H, (long)W * H * 3 / 2, rows, out);
+  const long fb = (long)W * H * 3 / 2;
+  for (int f0 = 0; f0 < n_frames; f0 += 16384) {  // gridDim.y <= 65535
+    const int nf = n_frames - f0 < 16384 ? n_frames - f0 : 16384;
+    hipLaunchKernelGGL(dev_checksum_kernel, dim3((unsigned)((H + rows - 1) / rows), (unsigned)(3 * nf)), dim3(256), 0, stream, frames + (long)f0 * fb, W, H, fb, rows, out + 3L * f0);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
