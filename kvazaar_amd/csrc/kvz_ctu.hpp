@@ -831,22 +831,30 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     const unsigned long long ord = __ballot(lane < ngroups && ((sig >> group_of(log2w, scan, lane < ngroups ? lane : 0)) & 1));  // the same in group order
     const int last_group = 63 - __builtin_clzll(ord);
     unsigned long long q15 = 0;
-    int c1 = 1;
+    unsigned acc_par = 0;  // per lane: Q15 prices of the bins counted one context per lane
+    // One bin on this lane's own context: the price goes to the lane's sum (off the state chain), the state moves on
+    auto step = [&](int &st, int bin) {
+      const int lps = (int)s->ctx_lps[st >> 1] ^ (st & 1);
+      acc_par += (unsigned)(s->entropy_fbits[st ^ bin] * 32768.0f);
+      st = bin == (st & 1) ? st + ((st < 124) << 1) : lps;
+    };
+    bool prev_gt1 = false;  // the previous group with levels held one above 1 (c1 == 0 at its end)
     for (int i = last_group; i >= 0; i--) {
       const int g = uni(group_of(log2w, scan, i)), gy = g >> (log2w - 2), gx = g & (side - 1);
       const i16 *base = coeff + ((gy * 4) << log2w) + gx * 4;
       const bool right = gx < side - 1 && ((sig >> (g + 1)) & 1), lower = gy < side - 1 && ((sig >> (g + side)) & 1);
       bool coded = (sig >> g) & 1;
-      if (i == last_group || i == 0) coded = true;
-      else q15 += bin_q15<KVZ_WREG_A>(wc, update, type + (right || lower), coded);
-      if (!coded) continue;
+      const bool group_flag = i != last_group && i != 0;
+      if (!group_flag) coded = true;
+      if (!coded) { q15 += bin_q15<KVZ_WREG_A>(wc, true, type + (right || lower), 0); continue; }
       const int k = lane & 15, r = scan_in_group(scan, k), px = gx * 4 + (r & 3), py = gy * 4 + (r >> 2);
       const int level = lane < 16 ? base[((r >> 2) << log2w) + (r & 3)] : 0;
       const unsigned nzmask = (unsigned)__ballot(level != 0) & 0xffffu;
       const int absval = iabs(level);
       unsigned coded_mask;
       if (i == last_group) {
-        // the last significant position and its coding (encode_coding_tree.c:63-115)
+        // the last significant position and its coding (encode_coding_tree.c:63-115): the prefix bins of one context are a run of ones
+        // and at most one zero, on the context's own lane of register b; the x and the y contexts run side by side
         const int k_last = 31 - __builtin_clz(nzmask), rl = scan_in_group(scan, k_last);
         int lx = gx * 4 + (rl & 3), ly = gy * 4 + (rl >> 2);
         if (scan == 2) { const int tmp = lx; lx = ly; ly = tmp; }
@@ -855,10 +863,17 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         const unsigned long long gidx_lo = 0x7777666655443210ull;
         const int gxi = lx < 16 ? (int)((gidx_lo >> (4 * lx)) & 15) : (lx < 24 ? 8 : 9), gyi = ly < 16 ? (int)((gidx_lo >> (4 * ly)) & 15) : (ly < 24 ? 8 : 9);
         const int gmax = w - 1 < 16 ? (int)((gidx_lo >> (4 * (w - 1))) & 15) : 9;
-        for (int q = 0; q < gxi; q++) q15 += bin_q15<KVZ_WREG_B>(wc, update, wlane_last(bx) + (q >> shift), 1);
-        if (gxi < gmax) q15 += bin_q15<KVZ_WREG_B>(wc, update, wlane_last(bx) + (gxi >> shift), 0);
-        for (int q = 0; q < gyi; q++) q15 += bin_q15<KVZ_WREG_B>(wc, update, wlane_last(by) + (q >> shift), 1);
-        if (gyi < gmax) q15 += bin_q15<KVZ_WREG_B>(wc, update, wlane_last(by) + (gyi >> shift), 0);
+        const int jx = lane - wlane_last(bx), jy = lane - wlane_last(by);
+        int ones = 0;
+        bool zero = false;
+        if (jx >= 0) { ones = imax(0, imin(gxi - (jx << shift), 1 << shift)); zero = gxi < gmax && (gxi >> shift) == jx; }
+        else if (jy >= 0) { ones = imax(0, imin(gyi - (jy << shift), 1 << shift)); zero = gyi < gmax && (gyi >> shift) == jy; }
+        int st = wc.b;
+        while (__ballot(ones > 0 || zero)) {
+          if (ones > 0) { step(st, 1); ones--; }
+          else if (zero) { step(st, 0); zero = false; }
+        }
+        wc.b = st;
         if (gxi > 3) q15 += (unsigned long long)((gxi - 2) / 2) << 15;
         if (gyi > 3) q15 += (unsigned long long)((gyi - 2) / 2) << 15;
         coded_mask = (1u << k_last) - 1;  // the positions below it; position 0 included (a level has been seen)
@@ -867,43 +882,54 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         if (i != 0 && !(nzmask & 0xfffeu)) coded_mask &= ~1u;  // position 0 of a coded group with no other level is inferred
       }
       const int pattern = log2w == 2 ? -1 : (int)right + ((int)lower << 1);
-      const int ctx = (type == 0 ? KVZ_HIP_CX_SIG_LUMA : KVZ_HIP_CX_SIG_CHROMA) + sig_ctx_inc(pattern, scan, px, py, log2w, type);
-      if (!update) {
-        int x = (lane < 16 && ((coded_mask >> k) & 1)) ? (int)(s->entropy_fbits[c->s[ctx] ^ (level != 0)] * 32768.0f) : 0;
-        x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
-        x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
-        x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
-        x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
-        q15 += (unsigned)__builtin_amdgcn_readlane(x, 15);
-      } else {
-        for (unsigned mk = coded_mask; mk;) {
-          const int kk = uni(31 - __builtin_clz(mk));
-          mk &= ~(1u << kk);
-          q15 += bin_q15<KVZ_WREG_A>(wc, true, wlane_sig(__builtin_amdgcn_readlane(ctx, kk)), (nzmask >> kk) & 1);
-        }
+      const int ctxl = wlane_sig((type == 0 ? KVZ_HIP_CX_SIG_LUMA : KVZ_HIP_CX_SIG_CHROMA) + sig_ctx_inc(pattern, scan, px, py, log2w, type));
+      // Every context-coded bin of the group, one context per lane: lane r of a register IS a context (WaveCtx), so the bins of one
+      // context are a serial chain on their own lane and the chains of different contexts run side by side -- the trip count is the
+      // longest chain of the group, not the number of bins.  `mine_*`: the scan positions whose bin uses this lane's context (their order
+      // is the coding order, from the highest position down; bit 16 = the group's own flag), `src_*`: the bin values by position.
+      // Classes never share a context, so the order between classes is free.
+      unsigned mine_a = 0, mine_c = 0;
+      for (unsigned rem = coded_mask; rem;) {  // significance flags: one pass per distinct context of the group
+        const int cc = __builtin_amdgcn_readlane(ctxl, uni(__builtin_ctz(rem)));
+        const unsigned same = (unsigned)__ballot(lane < 16 && ctxl == cc) & coded_mask;
+        mine_a = lane == cc ? same : mine_a;
+        rem &= ~same;
       }
+      if (group_flag && lane == type + (right || lower)) mine_a = 1u << 16;
       const int num = __builtin_popcount(nzmask);
+      const int ctx_set = ((i > 0 && type == 0) ? 2 : 0) + (prev_gt1 ? 1 : 0);
+      // greater-1 flags of the first eight levels: context 0 once an earlier level exceeded 1, else min(levels before + 1, 3)
+      const int q = __builtin_popcount(nzmask >> (k + 1));
+      const bool has1 = lane < 16 && level != 0 && q < 8;
+      const unsigned gt1 = (unsigned)__ballot(has1 && absval > 1) & 0xffffu;
+      const unsigned gt2 = (unsigned)__ballot(lane < 16 && absval > 2) & 0xffffu;
       if (num > 0) {
-        int ctx_set = (i > 0 && type == 0) ? 2 : 0;
-        if (c1 == 0) ctx_set++;
-        c1 = 1;
-        int first_c2_abs = -1, cnt = 0;
-        for (unsigned mk = nzmask; mk && cnt < 8; cnt++) {  // levels in coding order = from the highest scan position down
-          const int kk = uni(31 - __builtin_clz(mk));
-          mk &= ~(1u << kk);
-          const int a = __builtin_amdgcn_readlane(absval, kk), symbol = a > 1;
-          q15 += type == 0 ? bin_q15<KVZ_WREG_C>(wc, update, 4 * ctx_set + c1, symbol) : bin_q15<KVZ_WREG_A>(wc, update, 52 + 4 * ctx_set + c1, symbol);
-          if (symbol) { c1 = 0; if (first_c2_abs < 0) first_c2_abs = a; }
-          else if (c1 < 3 && c1 > 0) c1++;
+        const int c1v = (gt1 >> (k + 1)) ? 0 : (q + 1 < 3 ? q + 1 : 3);
+        const int lane1 = (type == 0 ? 0 : 52) + 4 * ctx_set;
+        for (int cv = 0; cv < 4; cv++) {
+          const unsigned mk = (unsigned)__ballot(has1 && c1v == cv) & 0xffffu;
+          if (type == 0) mine_c = lane == lane1 + cv ? mk : mine_c;
+          else mine_a = lane == lane1 + cv ? mk : mine_a;
         }
-        if (c1 == 0 && first_c2_abs >= 0) q15 += bin_q15<KVZ_WREG_A>(wc, update, (type == 0 ? 46 : 50) + ctx_set, first_c2_abs > 2);
+        if (gt1 && lane == (type == 0 ? 46 : 50) + ctx_set) mine_a = 1u << (31 - __builtin_clz(gt1));  // the first level above 1 carries the greater-2 flag
+      }
+      {
+        const unsigned src_a = lane < 46 ? (nzmask | 0x10000u) : (lane < 52 ? gt2 : gt1);
+        int st_a = wc.a, st_c = wc.c;
+        while (__ballot((mine_a | mine_c) != 0)) {
+          if (mine_a) { const int kk = 31 - __builtin_clz(mine_a); mine_a &= ~(1u << kk); step(st_a, (src_a >> kk) & 1); }
+          if (mine_c) { const int kk = 31 - __builtin_clz(mine_c); mine_c &= ~(1u << kk); step(st_c, (gt1 >> kk) & 1); }
+        }
+        wc.a = st_a; wc.c = st_c;
+      }
+      if (num > 0) {
         int bypass = num;  // signs
-        if (c1 == 0 || num > 8) {
-          int first_coeff2 = 1, go_rice = 0, q = 0;
-          for (unsigned mk = nzmask; mk; q++) {
+        if (gt1 || num > 8) {
+          int first_coeff2 = 1, go_rice = 0, qq = 0;
+          for (unsigned mk = nzmask; mk; qq++) {
             const int kk = uni(31 - __builtin_clz(mk));
             mk &= ~(1u << kk);
-            const int a = __builtin_amdgcn_readlane(absval, kk), base_level = q < 8 ? 2 + first_coeff2 : 1;
+            const int a = __builtin_amdgcn_readlane(absval, kk), base_level = qq < 8 ? 2 + first_coeff2 : 1;
             if (a >= base_level) {
               bypass += coeff_remain_bits(a - base_level, go_rice);
               if (a > 3 * (1 << go_rice)) go_rice = go_rice + 1 < 4 ? go_rice + 1 : 4;
@@ -912,9 +938,18 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
           }
         }
         q15 += (unsigned long long)bypass << 15;
+        prev_gt1 = gt1 != 0;
       }
     }
-    if (update) wave_ctx_store(c, wc, lane, type);
+    {  // rows of 16 lanes first (each row's sum fits 32 bits), then the four row totals
+      unsigned x = acc_par;
+      x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+      x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+      x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+      x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+      for (int row = 0; row < 4; row++) q15 += (unsigned)__builtin_amdgcn_readlane((int)x, 16 * row + 15);
+    }
+    wave_ctx_store(c, wc, lane, type);
     return (double)q15 / 32768.0;
   }
 #endif
