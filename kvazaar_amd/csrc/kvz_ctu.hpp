@@ -82,6 +82,8 @@ KVZ_DEV void block_add(u32 *dst, u32 v)
 
 #define KVZ_MREF_STRIDE 36  // q in [-16, 17] for a 16x16 CU (odd number of dwords: modes fall in different banks)
 #define KVZ_MREF_ORG 16
+#define KVZ_MREF32_STRIDE 68  // the same for a 32x32 CU (S32 instantiations; lives in the idle 32-point transform scratch): q in [-32, 33]
+#define KVZ_MREF32_ORG 32
 
 // Two int16 lanes in one register (v_pk_add_i16 / v_pk_sub_i16 / v_pk_max_i16 on the device).  The 8x8 Hadamard of 9-bit
 // differences stays within 15 bits + sign, so nothing here can wrap.
@@ -1114,20 +1116,22 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   KVZ_DEV u32 angular_block_satd(int log2w, int mode, int bx, int by, int xl, int yl, int half) const
   {
     const int w = 1 << log2w;
-    const bool vertical = mode >= 18;
+    const bool big = S32 && log2w == 5;  // a 32x32 CU: no edge filters (intra.c:207-219), and planar / DC are scored here too (below)
+    const bool flat = big && mode < 2;
+    const bool vertical = mode >= 18 || flat;
     const int disp = s->mode_disp[mode];
     const int p0 = vertical ? bx : by, q0 = vertical ? by : bx;  // block origin along / across the main reference
     const u8 *mr;
-    if (disp < 0) mr = s->mref[mode - 11] + KVZ_MREF_ORG;
+    if (disp < 0) mr = big ? mref32() + (mode - 11) * KVZ_MREF32_STRIDE + KVZ_MREF32_ORG : s->mref[mode - 11] + KVZ_MREF_ORG;
     else {
-      const bool filt = imin(iabs(mode - 26), iabs(mode - 10)) > (log2w == 3 ? 7 : 1);
+      const bool filt = imin(iabs(mode - 26), iabs(mode - 10)) > (log2w == 3 ? 7 : (log2w == 4 ? 1 : 0));
       mr = filt ? s->fref[vertical ? 0 : 1] : s->ref[0][vertical ? 0 : 1];
     }
     mr += p0 + 1;
-    const u8 *org = vertical ? org_at(0, xl + bx, yl + by) : s->org_t + bx * w + by;
+    const u8 *org = vertical ? org_at(0, xl + bx, yl + by) : (big ? org_t32() : s->org_t) + bx * w + by;
     const int ostride = vertical ? 32 : w;
     const u8 *side = vertical ? s->ref[0][1] : s->ref[0][0];  // intra.c:207-219: modes 10 / 26 use the unfiltered references
-    const bool edge = disp == 0 && p0 == 0;
+    const bool edge = !big && disp == 0 && p0 == 0;
     constexpr int NR = PAIR ? 4 : 8;
     const int r0 = PAIR ? 4 * half : 0;
     Pk16 d[NR][4];
@@ -1139,11 +1143,22 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       // the eight source pixels of the row in one 8-byte load (block origins are multiples of 8 in 8-byte aligned arrays)
       unsigned long long ow;
       __builtin_memcpy(&ow, __builtin_assume_aligned(org + r * ostride, 8), 8);
-      int v[8], a = m[0];
-      for (int k = 0; k < 8; k++) {
-        const int b = m[k + 1];
-        v[k] = ((32 - df) * a + df * b + 16) >> 5;
-        a = b;
+      int v[8];
+      if (flat) {
+        // planar (intra-generic.c:190-228, on the filtered references) and DC (a 32x32 block has no DC edge filter) of a 32x32 CU
+        if (mode == 1) { for (int k = 0; k < 8; k++) v[k] = s->dcval[0]; }
+        else {
+          const u8 *top = s->fref[0], *left = s->fref[1];
+          const int y = by + r, ly = left[y + 1], tr = top[33], bl = left[33];
+          for (int k = 0; k < 8; k++) { const int x = bx + k; v[k] = ((31 - x) * ly + (x + 1) * tr + (31 - y) * top[x + 1] + (y + 1) * bl + 32) >> 6; }
+        }
+      } else {
+        int a = m[0];
+        for (int k = 0; k < 8; k++) {
+          const int b = m[k + 1];
+          v[k] = ((32 - df) * a + df * b + 16) >> 5;
+          a = b;
+        }
       }
       if (edge) v[0] = iclip(0, 255, v[0] + (((int)side[qa] - (int)side[0]) >> 1));
       for (int j = 0; j < 4; j++) d[i][j] = pk_make(v[2 * j] - (int)((ow >> (16 * j)) & 0xff), v[2 * j + 1] - (int)((ow >> (16 * j + 8)) & 0xff));
@@ -1191,7 +1206,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   template <int L2>
   KVZ_DEV void build_mref(int tid)
   {
-    constexpr int W = 1 << L2, NQ = 2 * W + 2, THRES = L2 == 3 ? 7 : 1, N = (15 * NQ + KVZ_CTU_THREADS - 1) / KVZ_CTU_THREADS;
+    constexpr int W = 1 << L2, NQ = 2 * W + 2, THRES = L2 == 3 ? 7 : (L2 == 4 ? 1 : 0), N = (15 * NQ + KVZ_CTU_THREADS - 1) / KVZ_CTU_THREADS;
     u8 vals[N];
     for (int k = 0; k < N; k++) {
       const int i = imin(tid + k * KVZ_CTU_THREADS, 15 * NQ - 1), mode = 11 + i / NQ, q = i % NQ - W;
@@ -1203,9 +1218,15 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     }
     for (int k = 0; k < N; k++) {
       const int i = tid + k * KVZ_CTU_THREADS;
-      if (i < 15 * NQ) s->mref[i / NQ][KVZ_MREF_ORG + i % NQ - W] = vals[k];
+      if (i < 15 * NQ) {
+        if (L2 == 5) mref32()[(i / NQ) * KVZ_MREF32_STRIDE + KVZ_MREF32_ORG + i % NQ - W] = vals[k];
+        else s->mref[i / NQ][KVZ_MREF_ORG + i % NQ - W] = vals[k];
+      }
     }
   }
+  // 32x32 rough search (S32): the transposed source block and the extended references sit in the 32-point transform scratch, idle until the reconstruction
+  KVZ_DEV u8 *org_t32() const { return reinterpret_cast<u8 *>(s->tb_big); }
+  KVZ_DEV u8 *mref32() const { return reinterpret_cast<u8 *>(s->tb_big) + 1024; }
 
   KVZ_DEV u32 mode_satd(int mode, int nblk) const  // SATD_NxN: sum of (block sum + 2) >> 2 (strategies-picture.h:53-69)
   {
@@ -1257,32 +1278,35 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     const int log2w = 6 - depth, w = 1 << log2w, xl = x - cx, yl = y - cy, nblk = (w >> 3) * (w >> 3);
     build_refs(lv, x, y, log2w, depth == 3 ? 2 : log2w - 1, true, true, first);
     if (S32 && log2w == 5) {
-      // 32x32 CU (first version, generic): mode by mode the whole prediction into LDS (the 32-point transform scratch is free until the
-      // reconstruction), then one thread per (8x8 block, Hadamard column) -- 16 x 8 = the workgroup -- and the per-block rounding
-      // (strategies-picture.h:53-69: SATD_32x32 = sum of sixteen 8x8 SATDs) into the mode's total
-      u8 *scratch = reinterpret_cast<u8 *>(s->tb_big);
+      // 32x32 CU: all 35 modes x 16 blocks predicted and Hadamard-scored in registers like the angular modes of the smaller CUs
+      // (angular_block_satd; planar and DC have their own row generator there), each block's SATD rounded on its own
+      // (strategies-picture.h:53-69: SATD_32x32 = sum of sixteen 8x8 SATDs) and added to the mode's total
       KVZ_FOR_THREADS(tid) {
+        if constexpr (S32) build_mref<5>(tid);
+        u8 *ot = org_t32();
+        for (int e = tid; e < 1024; e += KVZ_CTU_THREADS) ot[e] = *org_at(0, xl + (e >> 5), yl + (e & 31));
         for (int v = tid; v < 35; v += KVZ_CTU_THREADS) s->satd_raw[v][0] = 0;
-        if (tid < 16) s->acc[tid] = 0;
         if (tid == KVZ_CTU_THREADS - 1) {
           const int left = x >= 4 ? neighbour_cu(lv, x - 1, y) : -1, above = (y >= 4 && yl > 0) ? neighbour_cu(lv, x, y - 1) : -1;
           mpm_candidates(y, left, above, s->preds);
         }
       }
       KVZ_SYNC();
-      for (int mode = 0; mode < 35; mode++) {
-        KVZ_FOR_THREADS(tid) {
-          if (tid < 16) { KVZ_LDS_ADD(&s->satd_raw[mode > 0 ? mode - 1 : 0][0], mode > 0 ? (s->acc[tid] + 2) >> 2 : 0u); s->acc[tid] = 0; }  // the previous mode's blocks
-          for (int e = tid; e < 1024; e += KVZ_CTU_THREADS) scratch[e] = predict_pixel(5, mode, 0, e & 31, e >> 5);
+      KVZ_PROF(KVZ_P_PRED35);
+      KVZ_FOR_THREADS(tid) {
+#ifdef KVZ_HOSTSIM
+        for (int t = tid; t < 35 * 16; t += KVZ_CTU_THREADS) {
+          const int mode = t >> 4, b = t & 15;
+          KVZ_LDS_ADD(&s->satd_raw[mode][0], (angular_block_satd<false>(5, mode, (b & 3) * 8, (b >> 2) * 8, xl, yl, 0) + 2) >> 2);
         }
-        KVZ_SYNC();
-        KVZ_FOR_THREADS(tid) {
-          const int tile = tid >> 3, col = tid & 7, bx = (tile & 3) * 8, by = (tile >> 2) * 8;
-          KVZ_LDS_ADD(&s->acc[tile], satd8_column(scratch + by * 32 + bx, 32, org_at(0, xl + bx, yl + by), 32, col));
+#else
+        for (int t = tid; t < 35 * 32; t += KVZ_CTU_THREADS) {  // two lanes per (mode, block); modes 0 and 1 fill one wavefront
+          const int p = t >> 1, mode = p >> 4, b = p & 15;
+          const u32 v = angular_block_satd<true>(5, mode, (b & 3) * 8, (b >> 2) * 8, xl, yl, t & 1);
+          if (!(t & 1)) KVZ_LDS_ADD(&s->satd_raw[mode][0], (v + 2) >> 2);
         }
-        KVZ_SYNC();
+#endif
       }
-      KVZ_FOR_THREADS(tid) { if (tid < 16) { KVZ_LDS_ADD(&s->satd_raw[34][0], (s->acc[tid] + 2) >> 2); s->acc[tid] = 0; } }
     } else {
     KVZ_FOR_THREADS(tid) {
       // extended main reference per angular mode
