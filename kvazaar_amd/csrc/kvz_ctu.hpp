@@ -536,6 +536,32 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     while (code >= (1 << length)) { code -= 1 << length; length++; }
     return 3 + length + 1 - r_param + length;
   }
+#ifndef KVZ_HOSTSIM
+  // The same count without the loop: the escape length L satisfies 2^L <= symbol - 2 * 2^r < 2^(L + 1)
+  KVZ_DEV static int coeff_remain_bits_flat(int symbol, int r_param)
+  {
+    const int length = 31 - __builtin_clz((unsigned)imax(symbol - (2 << r_param), 1));
+    return symbol < (3 << r_param) ? (symbol >> r_param) + 1 + r_param : 4 + 2 * length - r_param;
+  }
+  // Escape codes of one coded group, every level on its own lane (k = scan position = lane < 16, q = levels coded before it): the Rice
+  // parameter only ever moves up, by one after an escape-coded level above 3 << parameter (encode_coding_tree.c:224-246), so the up to
+  // four positions where it moves are the first level above 3, the first one above 6 after that, ... -- four ballots and a few scalar
+  // steps -- and each lane's parameter is the number of those positions coded before it.  Returns this lane's bypass bins.
+  KVZ_DEV static unsigned escape_bins_lane(bool mine, int k, int q, int absval)
+  {
+    const unsigned ge2 = (unsigned)__ballot(mine && absval >= 2) & 0xffffu;
+    const int base_level = q < 8 ? ((ge2 >> (k + 1)) ? 2 : 3) : 1;
+    const bool esc = mine && absval >= base_level;
+    int p = 16, rice = 0;
+#pragma unroll
+    for (int step = 0; step < 4; step++) {
+      const unsigned above = (unsigned)__ballot(esc && absval > (3 << step)) & ((1u << p) - 1);
+      p = above ? 31 - __builtin_clz(above) : 0;  // p == 0: nothing is coded after position 0, so it moves no lane's parameter
+      rice += k < p ? 1 : 0;
+    }
+    return esc ? (unsigned)coeff_remain_bits_flat(absval - base_level, rice) : 0u;
+  }
+#endif
   KVZ_DEV static int sig_ctx_inc(int pattern, int scan, int px, int py, int log2w, int type)  // context.c:366-399 kvz_context_get_sig_ctx_inc
   {
     if (px + py == 0) return 0;
@@ -647,57 +673,39 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   //   a: lanes 0..45 = r 0..45 (coded-group flags, significance luma / chroma), 46..51 = r 130..135 (greater-2 luma / chroma),
   //      52..59 = r 122..129 (greater-1 chroma);   b: lanes 0..59 = r 46..105 (last position y / x, luma / chroma);   c: lanes 0..15 = r 106..121 (greater-1 luma)
   // plus entry L of the LPS transition table and entries L / L + 64 of the price table (as Q15 integers).
-  struct WaveCtx { int a, b, c, lps; unsigned ent_lo, ent_hi; };
-  enum { KVZ_WREG_A = 0, KVZ_WREG_B = 1, KVZ_WREG_C = 2 };
-  KVZ_DEV static int wave_r_of(int reg, int lane)  // the context a lane of a register holds, -1: none
+  // The residual contexts of one block's class, one context per lane, in two registers: `a` the class's own contexts -- luma: coded-group
+  // flags 0..1, significance 2..28, greater-1 29..44, greater-2 45..48; chroma: 0..1, 2..16, 17..24, 25..26 -- and `b` the last-position
+  // prefixes of both classes (context r = 46 + lane, r = index - KVZ_HIP_CX_SIG_CG).
+  struct WaveCtx { int a, b; };
+  enum { KVZ_WL_SIG = 2, KVZ_WL_ONE_LUMA = 29, KVZ_WL_ABS_LUMA = 45, KVZ_WL_ONE_CHROMA = 17, KVZ_WL_ABS_CHROMA = 25 };
+  KVZ_DEV static int wave_r_class(int type, int lane)  // the context a lane of register a holds, -1: none
   {
-    if (reg == KVZ_WREG_A) return lane < 46 ? lane : (lane < 52 ? 130 + (lane - 46) : (lane < 60 ? 122 + (lane - 52) : -1));
-    if (reg == KVZ_WREG_B) return lane < 60 ? 46 + lane : -1;
-    return lane < 16 ? 106 + lane : -1;
+    if (type == 0) return lane < 2 ? lane : (lane < 29 ? lane + 2 : (lane < 45 ? 106 + lane - 29 : (lane < 49 ? 130 + lane - 45 : -1)));
+    return lane < 2 ? 2 + lane : (lane < 17 ? 31 + lane - 2 : (lane < 25 ? 122 + lane - 17 : (lane < 27 ? 134 + lane - 25 : -1)));
   }
-  KVZ_DEV WaveCtx wave_ctx_load(const CtxSet *c, int lane) const
+  KVZ_DEV static bool ctx_is_chroma(int r)  // r = index - KVZ_HIP_CX_SIG_CG
+  {
+    return (r >= 2 && r < 4) || (r >= 31 && r < 46) || (r >= 61 && r < 76) || (r >= 91 && r < 106) || (r >= 122 && r < 130) || r >= 134;
+  }
+  KVZ_DEV WaveCtx wave_ctx_load(const CtxSet *c, int lane, int type) const
   {
     WaveCtx w;
     const u8 *r = c->s + KVZ_HIP_CX_SIG_CG;
-    const int ra = wave_r_of(KVZ_WREG_A, lane), rb = wave_r_of(KVZ_WREG_B, lane), rc = wave_r_of(KVZ_WREG_C, lane);
-    w.a = ra >= 0 ? (int)r[ra] : 0; w.b = rb >= 0 ? (int)r[rb] : 0; w.c = rc >= 0 ? (int)r[rc] : 0;
-    w.lps = s->ctx_lps[lane];
-    w.ent_lo = (unsigned)(s->entropy_fbits[lane] * 32768.0f);
-    w.ent_hi = (unsigned)(s->entropy_fbits[lane + 64] * 32768.0f);
+    const int ra = wave_r_class(type, lane);
+    w.a = ra >= 0 ? (int)r[ra] : 0;
+    w.b = lane < 60 ? (int)r[46 + lane] : 0;
     return w;
   }
   // Only the contexts of the block's own class -- luma (type 0) or chroma -- are written back: a block never moves the other class
   // (cabac.h:63-100: every residual context exists once per class), so a luma block on one wavefront and the chroma blocks of the same
   // unit on the other can price and update the same set concurrently.
-  KVZ_DEV static bool ctx_is_chroma(int r)  // r = index - KVZ_HIP_CX_SIG_CG
-  {
-    return (r >= 2 && r < 4) || (r >= 31 && r < 46) || (r >= 61 && r < 76) || (r >= 91 && r < 106) || (r >= 122 && r < 130) || r >= 134;
-  }
   KVZ_DEV void wave_ctx_store(CtxSet *c, const WaveCtx &w, int lane, int type) const
   {
     u8 *r = c->s + KVZ_HIP_CX_SIG_CG;
-    const bool chroma = type != 0;
-    const int ra = wave_r_of(KVZ_WREG_A, lane), rb = wave_r_of(KVZ_WREG_B, lane), rc = wave_r_of(KVZ_WREG_C, lane);
-    if (ra >= 0 && ctx_is_chroma(ra) == chroma) r[ra] = (u8)w.a;
-    if (rb >= 0 && ctx_is_chroma(rb) == chroma) r[rb] = (u8)w.b;
-    if (rc >= 0 && !chroma) r[rc] = (u8)w.c;
+    const int ra = wave_r_class(type, lane);
+    if (ra >= 0) r[ra] = (u8)w.a;
+    if (lane < 60 && ctx_is_chroma(46 + lane) == (type != 0)) r[46 + lane] = (u8)w.b;
   }
-  // One bin on the context in lane `ln` of register REG: its Q15 price at the current state, and (update) the state transition
-  template <int REG> KVZ_DEV static unsigned bin_q15(WaveCtx &w, bool update, int ln, int bin)
-  {
-    int &reg = REG == KVZ_WREG_A ? w.a : (REG == KVZ_WREG_B ? w.b : w.c);
-    ln = uni(ln);
-    const int st = __builtin_amdgcn_readlane(reg, ln), e = st ^ bin;
-    const unsigned qlo = (unsigned)__builtin_amdgcn_readlane((int)w.ent_lo, e & 63), qhi = (unsigned)__builtin_amdgcn_readlane((int)w.ent_hi, e & 63);
-    if (update) {
-      const int lps = __builtin_amdgcn_readlane(w.lps, st >> 1) ^ (st & 1), mps = st + ((st < 124) << 1);
-      const int nxt = uni(bin == (st & 1) ? mps : lps);
-      reg = ((int)(threadIdx.x & 63) != ln) ? reg : nxt;  // a compare and a select with a scalar operand (v_writelane_b32 would need m0 here: two scalar registers exceed the constant bus)
-    }
-    return (e & 64) ? qhi : qlo;
-  }
-  // lanes of the classes (see WaveCtx): significance flags and coded-group flags sit at their r in register a
-  KVZ_DEV static int wlane_sig(int idx) { return idx - KVZ_HIP_CX_SIG_CG; }
   KVZ_DEV static int wlane_last(int idx) { return idx - KVZ_HIP_CX_SIG_CG - 46; }
   // The count with updates off (merge attempts: every bin is priced at the entry state, search.c:1005-1041): no bin depends on another, so
   // nothing is serial.  Per coded group the sixteen lanes of the scan positions price their own significance and greater-1 flags (the
@@ -773,25 +781,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
           if (lane == kk) acc += price((type == 0 ? KVZ_HIP_CX_ABS_LUMA : KVZ_HIP_CX_ABS_CHROMA) + ctx_set, absval > 2);
         }
         bypass += (unsigned long long)num;  // signs
-        if (gt1 || num > 8) {
-          const unsigned ge2 = (unsigned)__ballot(mine && absval >= 2) & 0xffffu;
-          if (!__ballot(mine && absval > 3)) {  // the Rice parameter stays 0: escape lengths are independent
-            const int base_level = q < 8 ? ((ge2 >> (k + 1)) ? 2 : 3) : 1;
-            if (mine && absval >= base_level) byp += (unsigned)(absval - base_level + 1);  // coeff_remain_bits(symbol <= 2, 0) = symbol + 1
-          } else {
-            int first_coeff2 = 1, go_rice = 0, qq = 0;
-            for (unsigned mk = nzmask; mk; qq++) {
-              const int kk = uni(31 - __builtin_clz(mk));
-              mk &= ~(1u << kk);
-              const int a = __builtin_amdgcn_readlane(absval, kk), base_level = qq < 8 ? 2 + first_coeff2 : 1;
-              if (a >= base_level) {
-                bypass += (unsigned long long)coeff_remain_bits(a - base_level, go_rice);
-                if (a > 3 * (1 << go_rice)) go_rice = go_rice + 1 < 4 ? go_rice + 1 : 4;
-              }
-              if (a >= 2) first_coeff2 = 0;
-            }
-          }
-        }
+        if (gt1 || num > 8) byp += escape_bins_lane(mine, k, q, absval);
         prev_c1_zero = gt1 ? 1 : 0;
       }
     }
@@ -829,11 +819,12 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     }
     const unsigned long long sig = __ballot(any);  // bit g: group g (raster) holds a level
     if (!sig) return 0;
-    WaveCtx wc = wave_ctx_load(c, lane);
+    WaveCtx wc = wave_ctx_load(c, lane, type);
     const unsigned long long ord = __ballot(lane < ngroups && ((sig >> group_of(log2w, scan, lane < ngroups ? lane : 0)) & 1));  // the same in group order
     const int last_group = 63 - __builtin_clzll(ord);
     unsigned long long q15 = 0;
     unsigned acc_par = 0;  // per lane: Q15 prices of the bins counted one context per lane
+    unsigned byp_par = 0;  // per lane: bypass bins of the escape codes
     // One bin on this lane's own context: the price goes to the lane's sum (off the state chain), the state moves on
     auto step = [&](int &st, int bin) {
       const int lps = (int)s->ctx_lps[st >> 1] ^ (st & 1);
@@ -848,7 +839,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       bool coded = (sig >> g) & 1;
       const bool group_flag = i != last_group && i != 0;
       if (!group_flag) coded = true;
-      if (!coded) { q15 += bin_q15<KVZ_WREG_A>(wc, true, type + (right || lower), 0); continue; }
+      if (!coded) { if (lane == (int)(right || lower)) step(wc.a, 0); continue; }  // the flag of a group without levels
       const int k = lane & 15, r = scan_in_group(scan, k), px = gx * 4 + (r & 3), py = gy * 4 + (r >> 2);
       const int level = lane < 16 ? base[((r >> 2) << log2w) + (r & 3)] : 0;
       const unsigned nzmask = (unsigned)__ballot(level != 0) & 0xffffu;
@@ -884,62 +875,52 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         if (i != 0 && !(nzmask & 0xfffeu)) coded_mask &= ~1u;  // position 0 of a coded group with no other level is inferred
       }
       const int pattern = log2w == 2 ? -1 : (int)right + ((int)lower << 1);
-      const int ctxl = wlane_sig((type == 0 ? KVZ_HIP_CX_SIG_LUMA : KVZ_HIP_CX_SIG_CHROMA) + sig_ctx_inc(pattern, scan, px, py, log2w, type));
-      // Every context-coded bin of the group, one context per lane: lane r of a register IS a context (WaveCtx), so the bins of one
-      // context are a serial chain on their own lane and the chains of different contexts run side by side -- the trip count is the
-      // longest chain of the group, not the number of bins.  `mine_*`: the scan positions whose bin uses this lane's context (their order
-      // is the coding order, from the highest position down; bit 16 = the group's own flag), `src_*`: the bin values by position.
-      // Classes never share a context, so the order between classes is free.
-      unsigned mine_a = 0, mine_c = 0;
+      const int ctxl = KVZ_WL_SIG + sig_ctx_inc(pattern, scan, px, py, log2w, type);
+      // Every context-coded bin of the group, one context per lane: lane r of the class register IS a context (WaveCtx), so the bins of
+      // one context are a serial chain on their own lane and the chains of different contexts run side by side -- the trip count is the
+      // longest chain of the group, not the number of bins.  `mine`: the scan positions whose bin uses this lane's context (their order
+      // is the coding order, from the highest position down; bit 16 = the group's own flag), `src`: the bin values by position.
+      // Classes of bins never share a context, so the order between classes is free.
+      unsigned mine = 0;
       for (unsigned rem = coded_mask; rem;) {  // significance flags: one pass per distinct context of the group
         const int cc = __builtin_amdgcn_readlane(ctxl, uni(__builtin_ctz(rem)));
         const unsigned same = (unsigned)__ballot(lane < 16 && ctxl == cc) & coded_mask;
-        mine_a = lane == cc ? same : mine_a;
+        mine = lane == cc ? same : mine;
         rem &= ~same;
       }
-      if (group_flag && lane == type + (right || lower)) mine_a = 1u << 16;
+      if (group_flag && lane == (int)(right || lower)) mine = 1u << 16;
       const int num = __builtin_popcount(nzmask);
       const int ctx_set = ((i > 0 && type == 0) ? 2 : 0) + (prev_gt1 ? 1 : 0);
       // greater-1 flags of the first eight levels: context 0 once an earlier level exceeded 1, else min(levels before + 1, 3)
       const int q = __builtin_popcount(nzmask >> (k + 1));
       const bool has1 = lane < 16 && level != 0 && q < 8;
       const unsigned gt1 = (unsigned)__ballot(has1 && absval > 1) & 0xffffu;
-      const unsigned gt2 = (unsigned)__ballot(lane < 16 && absval > 2) & 0xffffu;
+      const int lane_one = type == 0 ? KVZ_WL_ONE_LUMA : KVZ_WL_ONE_CHROMA, lane_abs = type == 0 ? KVZ_WL_ABS_LUMA : KVZ_WL_ABS_CHROMA;
+      unsigned src = nzmask | 0x10000u;
       if (num > 0) {
         const int c1v = (gt1 >> (k + 1)) ? 0 : (q + 1 < 3 ? q + 1 : 3);
-        const int lane1 = (type == 0 ? 0 : 52) + 4 * ctx_set;
         for (int cv = 0; cv < 4; cv++) {
           const unsigned mk = (unsigned)__ballot(has1 && c1v == cv) & 0xffffu;
-          if (type == 0) mine_c = lane == lane1 + cv ? mk : mine_c;
-          else mine_a = lane == lane1 + cv ? mk : mine_a;
+          mine = lane == lane_one + 4 * ctx_set + cv ? mk : mine;
         }
-        if (gt1 && lane == (type == 0 ? 46 : 50) + ctx_set) mine_a = 1u << (31 - __builtin_clz(gt1));  // the first level above 1 carries the greater-2 flag
+        if (gt1) {  // the first level above 1 carries the greater-2 flag
+          const int kk = 31 - __builtin_clz(gt1);
+          const unsigned gt2 = __builtin_amdgcn_readlane(absval, kk) > 2 ? 1u << kk : 0u;
+          mine = lane == lane_abs + ctx_set ? 1u << kk : mine;
+          src = lane >= lane_abs ? gt2 : src;
+        }
+        src = lane >= lane_one && lane < lane_abs ? gt1 : src;
       }
       {
-        const unsigned src_a = lane < 46 ? (nzmask | 0x10000u) : (lane < 52 ? gt2 : gt1);
-        int st_a = wc.a, st_c = wc.c;
-        while (__ballot((mine_a | mine_c) != 0)) {
-          if (mine_a) { const int kk = 31 - __builtin_clz(mine_a); mine_a &= ~(1u << kk); step(st_a, (src_a >> kk) & 1); }
-          if (mine_c) { const int kk = 31 - __builtin_clz(mine_c); mine_c &= ~(1u << kk); step(st_c, (gt1 >> kk) & 1); }
+        int st = wc.a;
+        while (__ballot(mine != 0)) {
+          if (mine) { const int kk = 31 - __builtin_clz(mine); mine &= ~(1u << kk); step(st, (src >> kk) & 1); }
         }
-        wc.a = st_a; wc.c = st_c;
+        wc.a = st;
       }
       if (num > 0) {
-        int bypass = num;  // signs
-        if (gt1 || num > 8) {
-          int first_coeff2 = 1, go_rice = 0, qq = 0;
-          for (unsigned mk = nzmask; mk; qq++) {
-            const int kk = uni(31 - __builtin_clz(mk));
-            mk &= ~(1u << kk);
-            const int a = __builtin_amdgcn_readlane(absval, kk), base_level = qq < 8 ? 2 + first_coeff2 : 1;
-            if (a >= base_level) {
-              bypass += coeff_remain_bits(a - base_level, go_rice);
-              if (a > 3 * (1 << go_rice)) go_rice = go_rice + 1 < 4 ? go_rice + 1 : 4;
-            }
-            if (a >= 2) first_coeff2 = 0;
-          }
-        }
-        q15 += (unsigned long long)bypass << 15;
+        q15 += (unsigned long long)num << 15;  // signs
+        if (gt1 || num > 8) byp_par += escape_bins_lane(lane < 16 && level != 0, k, q, absval);
         prev_gt1 = gt1 != 0;
       }
     }
@@ -950,6 +931,12 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
       x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
       for (int row = 0; row < 4; row++) q15 += (unsigned)__builtin_amdgcn_readlane((int)x, 16 * row + 15);
+      unsigned y = byp_par;  // lanes 0..15 only
+      y += __builtin_amdgcn_update_dpp(0, y, 0x118, 0xF, 0xF, true);
+      y += __builtin_amdgcn_update_dpp(0, y, 0x114, 0xF, 0xF, true);
+      y += __builtin_amdgcn_update_dpp(0, y, 0x112, 0xF, 0xF, true);
+      y += __builtin_amdgcn_update_dpp(0, y, 0x111, 0xF, 0xF, true);
+      q15 += (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)y, 15) << 15;
     }
     wave_ctx_store(c, wc, lane, type);
     return (double)q15 / 32768.0;
