@@ -699,12 +699,14 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   // Only the contexts of the block's own class -- luma (type 0) or chroma -- are written back: a block never moves the other class
   // (cabac.h:63-100: every residual context exists once per class), so a luma block on one wavefront and the chroma blocks of the same
   // unit on the other can price and update the same set concurrently.
-  KVZ_DEV void wave_ctx_store(CtxSet *c, const WaveCtx &w, int lane, int type) const
+  // part (coeff_cabac_bits_wave): 1 = only the coded-group and significance contexts moved, 2 = only the others
+  KVZ_DEV void wave_ctx_store(CtxSet *c, const WaveCtx &w, int lane, int type, int part) const
   {
     u8 *r = c->s + KVZ_HIP_CX_SIG_CG;
     const int ra = wave_r_class(type, lane);
-    if (ra >= 0) r[ra] = (u8)w.a;
-    if (lane < 60 && ctx_is_chroma(46 + lane) == (type != 0)) r[46 + lane] = (u8)w.b;
+    const bool sig_half = lane < (type == 0 ? KVZ_WL_ONE_LUMA : KVZ_WL_ONE_CHROMA);
+    if (ra >= 0 && (part == 0 || (part == 1) == sig_half)) r[ra] = (u8)w.a;
+    if (part != 1 && lane < 60 && ctx_is_chroma(46 + lane) == (type != 0)) r[46 + lane] = (u8)w.b;
   }
   KVZ_DEV static int wlane_last(int idx) { return idx - KVZ_HIP_CX_SIG_CG - 46; }
   // The count with updates off (merge attempts: every bin is priced at the entry state, search.c:1005-1041): no bin depends on another, so
@@ -804,10 +806,13 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     q15 += bypass << 15;
     return (double)q15 / 32768.0;
   }
-  KVZ_DEV double coeff_cabac_bits_wave(CtxSet *c, bool update, const i16 *coeff, int log2w, int type, int scan) const
+  // part: the bins of a block fall into classes with disjoint contexts, so a block can be shared by two wavefronts -- 1: the coded-group
+  // and significance flags (the longest chains), 2: last position, greater-1 / greater-2 flags, signs and escape codes; 0: everything.
+  // The two shares add up to the block's bits, and each share writes back only the contexts it moved.
+  KVZ_DEV double coeff_cabac_bits_wave(CtxSet *c, bool update, const i16 *coeff, int log2w, int type, int scan, int part = 0) const
   {
     update = update && m->adaptive;
-    if (!update) return coeff_cabac_bits_frozen(c, coeff, log2w, type, scan);
+    if (!update) return part == 2 ? 0.0 : coeff_cabac_bits_frozen(c, coeff, log2w, type, scan);
     const int lane = threadIdx.x & 63;
     const int w = 1 << log2w, side = w >> 2, ngroups = side * side;
     bool any = false;
@@ -839,7 +844,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       bool coded = (sig >> g) & 1;
       const bool group_flag = i != last_group && i != 0;
       if (!group_flag) coded = true;
-      if (!coded) { if (lane == (int)(right || lower)) step(wc.a, 0); continue; }  // the flag of a group without levels
+      if (!coded) { if (part != 2 && lane == (int)(right || lower)) step(wc.a, 0); continue; }  // the flag of a group without levels
       const int k = lane & 15, r = scan_in_group(scan, k), px = gx * 4 + (r & 3), py = gy * 4 + (r >> 2);
       const int level = lane < 16 ? base[((r >> 2) << log2w) + (r & 3)] : 0;
       const unsigned nzmask = (unsigned)__ballot(level != 0) & 0xffffu;
@@ -859,7 +864,8 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         const int jx = lane - wlane_last(bx), jy = lane - wlane_last(by);
         int ones = 0;
         bool zero = false;
-        if (jx >= 0) { ones = imax(0, imin(gxi - (jx << shift), 1 << shift)); zero = gxi < gmax && (gxi >> shift) == jx; }
+        if (part == 1) {}
+        else if (jx >= 0) { ones = imax(0, imin(gxi - (jx << shift), 1 << shift)); zero = gxi < gmax && (gxi >> shift) == jx; }
         else if (jy >= 0) { ones = imax(0, imin(gyi - (jy << shift), 1 << shift)); zero = gyi < gmax && (gyi >> shift) == jy; }
         int st = wc.b;
         while (__ballot(ones > 0 || zero)) {
@@ -867,8 +873,8 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
           else if (zero) { step(st, 0); zero = false; }
         }
         wc.b = st;
-        if (gxi > 3) q15 += (unsigned long long)((gxi - 2) / 2) << 15;
-        if (gyi > 3) q15 += (unsigned long long)((gyi - 2) / 2) << 15;
+        if (part != 1 && gxi > 3) q15 += (unsigned long long)((gxi - 2) / 2) << 15;
+        if (part != 1 && gyi > 3) q15 += (unsigned long long)((gyi - 2) / 2) << 15;
         coded_mask = (1u << k_last) - 1;  // the positions below it; position 0 included (a level has been seen)
       } else {
         coded_mask = 0xffffu;
@@ -882,13 +888,13 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       // is the coding order, from the highest position down; bit 16 = the group's own flag), `src`: the bin values by position.
       // Classes of bins never share a context, so the order between classes is free.
       unsigned mine = 0;
-      for (unsigned rem = coded_mask; rem;) {  // significance flags: one pass per distinct context of the group
+      for (unsigned rem = part == 2 ? 0u : coded_mask; rem;) {  // significance flags: one pass per distinct context of the group
         const int cc = __builtin_amdgcn_readlane(ctxl, uni(__builtin_ctz(rem)));
         const unsigned same = (unsigned)__ballot(lane < 16 && ctxl == cc) & coded_mask;
         mine = lane == cc ? same : mine;
         rem &= ~same;
       }
-      if (group_flag && lane == (int)(right || lower)) mine = 1u << 16;
+      if (part != 2 && group_flag && lane == (int)(right || lower)) mine = 1u << 16;
       const int num = __builtin_popcount(nzmask);
       const int ctx_set = ((i > 0 && type == 0) ? 2 : 0) + (prev_gt1 ? 1 : 0);
       // greater-1 flags of the first eight levels: context 0 once an earlier level exceeded 1, else min(levels before + 1, 3)
@@ -897,7 +903,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       const unsigned gt1 = (unsigned)__ballot(has1 && absval > 1) & 0xffffu;
       const int lane_one = type == 0 ? KVZ_WL_ONE_LUMA : KVZ_WL_ONE_CHROMA, lane_abs = type == 0 ? KVZ_WL_ABS_LUMA : KVZ_WL_ABS_CHROMA;
       unsigned src = nzmask | 0x10000u;
-      if (num > 0) {
+      if (part != 1 && num > 0) {
         const int c1v = (gt1 >> (k + 1)) ? 0 : (q + 1 < 3 ? q + 1 : 3);
         for (int cv = 0; cv < 4; cv++) {
           const unsigned mk = (unsigned)__ballot(has1 && c1v == cv) & 0xffffu;
@@ -918,10 +924,10 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         }
         wc.a = st;
       }
-      if (num > 0) {
+      if (num > 0) prev_gt1 = gt1 != 0;
+      if (part != 1 && num > 0) {
         q15 += (unsigned long long)num << 15;  // signs
         if (gt1 || num > 8) byp_par += escape_bins_lane(lane < 16 && level != 0, k, q, absval);
-        prev_gt1 = gt1 != 0;
       }
     }
     {  // rows of 16 lanes first (each row's sum fits 32 bits), then the four row totals
@@ -938,7 +944,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       y += __builtin_amdgcn_update_dpp(0, y, 0x111, 0xF, 0xF, true);
       q15 += (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)y, 15) << 15;
     }
-    wave_ctx_store(c, wc, lane, type);
+    wave_ctx_store(c, wc, lane, type, part);
     return (double)q15 / 32768.0;
   }
 #endif
@@ -1809,11 +1815,14 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     if (cb_v) bits += coeff_cabac_bits(c, update, levels_lds(lv, 2), lc, 2, scan);
 #else  // both wavefronts are here: the one playing threads 0..63 takes the luma block, the other one the two chroma blocks -- luma and
        // chroma contexts are disjoint, so the two chains (Y | U -> V) are independent even with updates on
+    // ... and the luma block's own bins split again: its significance flags (the longest chains) stay on the first wavefront, the second one
+    // takes the luma block's other classes after the chroma blocks
     if (tid < 64) {
-      if (cb_y) bits += coeff_cabac_bits_wave(c, update, levels_lds(lv, 0), lw, 0, scan);
+      if (cb_y) bits += coeff_cabac_bits_wave(c, update, levels_lds(lv, 0), lw, 0, scan, 1);
     } else {
       if (cb_u) bits += coeff_cabac_bits_wave(c, update, levels_lds(lv, 1), lc, 2, scan);
       if (cb_v) bits += coeff_cabac_bits_wave(c, update, levels_lds(lv, 2), lc, 2, scan);
+      if (cb_y) bits += coeff_cabac_bits_wave(c, update, levels_lds(lv, 0), lw, 0, scan, 2);
     }
 #endif
     return bits;
@@ -2173,13 +2182,15 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
             const int lw = 6 - td, lc = td == 3 ? 2 : lw - 1, scan = scan_order(cu->mode, td);
             const i16 *y = s->lv1_coeff + (zorder(xl, yl) - q * 1024), *u = s->lv1_coeff + 1024 + (zorder(xl >> 1, yl >> 1) - q * 256);
 #ifdef KVZ_HOSTSIM
-#define KVZ_CODE_RESIDUAL coeff_cabac_bits
+            if (cbf_is_set(cu->cbf, td, 0)) coeff_cabac_bits(c, true, y, lw, 0, scan);
+            if (cbf_is_set(cu->cbf, td, 1)) coeff_cabac_bits(c, true, u, lc, 2, scan);
+            if (cbf_is_set(cu->cbf, td, 2)) coeff_cabac_bits(c, true, u + 256, lc, 2, scan);
 #else
-#define KVZ_CODE_RESIDUAL coeff_cabac_bits_wave
+            if (luma_role && cbf_is_set(cu->cbf, td, 0)) coeff_cabac_bits_wave(c, true, y, lw, 0, scan, 1);
+            if (chroma_role && cbf_is_set(cu->cbf, td, 1)) coeff_cabac_bits_wave(c, true, u, lc, 2, scan);
+            if (chroma_role && cbf_is_set(cu->cbf, td, 2)) coeff_cabac_bits_wave(c, true, u + 256, lc, 2, scan);
+            if (chroma_role && cbf_is_set(cu->cbf, td, 0)) coeff_cabac_bits_wave(c, true, y, lw, 0, scan, 2);
 #endif
-            if (luma_role && cbf_is_set(cu->cbf, td, 0)) KVZ_CODE_RESIDUAL(c, true, y, lw, 0, scan);
-            if (chroma_role && cbf_is_set(cu->cbf, td, 1)) KVZ_CODE_RESIDUAL(c, true, u, lc, 2, scan);
-            if (chroma_role && cbf_is_set(cu->cbf, td, 2)) KVZ_CODE_RESIDUAL(c, true, u + 256, lc, 2, scan);
             i += 1 << (2 * (3 - td));
           }
         }
