@@ -65,6 +65,22 @@ def test_hip_ctu_adversarial_and_qps(oracle, hiplib):
             assert not cc.compare(want, got[i]), (qp, i, cc.compare(want, got[i]))
 
 
+@pytest.mark.parametrize("qp", [4, 12, 22])
+def test_hip_ctu_residual_coder_large_levels(oracle, hiplib, qp):
+    """The residual coder in counting mode where it is busiest: CABAC coefficient cost and the 32x32 search forced on (presets `faster` /
+    `fast`) at QPs whose levels run into the escape codes with a moving Rice parameter (encode_coding_tree.c:224-246) -- adversarial and
+    noise pictures, every output bit-exact against the oracle."""
+    w, h = 192, 136
+    frames = list(cc.adversarial_frames(w, h).values()) + cc.yuv_frames(w, h, 2, 77 + qp, "small")
+    model = _model(hiplib, oracle, qp)
+    model.coeff_cabac = 1
+    model.search_32x32 = 1
+    got = _run_batch(hiplib, model, w, h, frames)
+    for i, f in enumerate(frames):
+        want = cc.run_oracle(oracle, model, w, h, f)
+        assert not cc.compare(want, got[i]), (qp, i, cc.compare(want, got[i]))
+
+
 def test_hip_ctu_1080p_frame_equals_oracle(oracle, hiplib):
     """BASELINE config 2 geometry (1920x1080: 30x17 CTUs, partial bottom row), one frame against the oracle"""
     w, h = 1920, 1080
