@@ -430,6 +430,19 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     for (int i = 0; i < n; i++) t[i] = ((const unsigned *)src->s)[i];
     for (int i = 0; i < n; i++) ((unsigned *)dst->s)[i] = t[i];
   }
+  // The same by the lanes that play threads 0..36 (one wavefront: thread ids rotate by whole wavefronts), a word each.  Callers bring every
+  // thread; what thread 0 wrote into a set just before (same wavefront, program order) is seen.
+  KVZ_DEV void ctx_copy_lanes(CtxSet *dst, const CtxSet *src, int tid) const
+  {
+    if (tid < (CABAC ? 37 : 3)) ((unsigned *)dst->s)[tid] = ((const unsigned *)src->s)[tid];
+  }
+  KVZ_DEV void ctx_swap_lanes(CtxSet *a, CtxSet *b, int tid) const
+  {
+    if (tid < (CABAC ? 37 : 3)) {
+      const unsigned ta = ((const unsigned *)a->s)[tid], tb2 = ((const unsigned *)b->s)[tid];
+      ((unsigned *)a->s)[tid] = tb2; ((unsigned *)b->s)[tid] = ta;
+    }
+  }
   KVZ_DEV void ctx_swap(CtxSet *a, CtxSet *b) const
   {
     constexpr int n = CABAC ? 37 : 3;
@@ -993,14 +1006,14 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
 
   // Builds the unfiltered references of the listed planes; second phase: the [1 2 1]-filtered luma references
   // (intra.c:176-204) and the DC value of every plane (intra-generic.c:219-225).
-  struct NoHook { KVZ_DEV void operator()() const {} };
-  // `first` runs on thread 0 inside the first phase: bookkeeping of the caller that no lane reads before the next barrier
+  struct NoHook { KVZ_DEV void operator()(int) const {} };
+  // `first` runs inside the first phase (every thread calls it with its id; scalars are thread 0's business): bookkeeping of the caller that no lane reads before the next barrier
   template <class First = NoHook>
   KVZ_DEV void build_refs(int lv, int x, int y, int log2w_y, int log2w_c, bool luma, bool chroma, First first = First())
   {
     const int avail_top = tb->avail_top[(y & 63) >> 2][(x & 63) >> 2], avail_left = tb->avail_left[(y & 63) >> 2][(x & 63) >> 2];
     KVZ_FOR_THREADS(tid) {
-      if (tid == 0) first();
+      first(tid);
       // one index space over the samples of all listed planes (luma, then U, then V; top then left inside a plane): the loop body
       // -- long and branchy -- then runs once or twice per CU instead of once per plane
       const int ny = luma ? 2 * (2 * (1 << log2w_y) + 1) : 0, nc = chroma ? 2 * (2 * (1 << log2w_c) + 1) : 0;
@@ -1903,9 +1916,9 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         if (res_depth > 0) s->split_cost[res_depth - 1] += r;  // the parent's running sum (search.c:1005-1010)
         // search.c:1051: an unsplit CU below depth 0 continues from the contexts as they were after it was priced -- for a merge
         // those at entry, since the merge is priced with updates off (search.c:1005-1041)
-        if (!split_won && res_depth == 2) ctx_copy(&s->cab, &s->post2);
-        if (!split_won && res_depth == 1) ctx_copy(&s->cab, &s->pre[1]);
       }
+      if (!split_won && res_depth == 2) ctx_copy_lanes(&s->cab, &s->post2, tid);
+      if (!split_won && res_depth == 1) ctx_copy_lanes(&s->cab, &s->pre[1], tid);
       const int n = w >> 3, lw = w == 16 ? 4 : (w == 32 ? 5 : 6), ln = lw - 3, cw = w >> 1;
       if (tid < n * n) {
         const int i = ((yl >> 3) + (tid >> ln)) * 8 + (xl >> 3) + (tid & (n - 1));
@@ -1965,8 +1978,8 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         *out_cost = cost;
         const CtuCu *cu = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
         *out_cbf = cbf_is_set(cu->cbf, depth, 0) || cbf_is_set(cu->cbf, depth, 1) || cbf_is_set(cu->cbf, depth, 2);
-        last();
       }
+      last(tid);
     }
     KVZ_SYNC();
     KVZ_PROF(KVZ_P_COST);
@@ -1979,7 +1992,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   KVZ_DEV void load_org(First first = First())
   {
     KVZ_FOR_THREADS(tid) {
-      if (tid == 0) first();
+      first(tid);
       for (int c = 0; c < 3; c++) {
         const int sh = c ? 1 : 0, l2 = 5 - sh, qw = 1 << l2, fw = F.W >> sh, fh = F.H >> sh, ox = (cx + a1x) >> sh, oy = (cy + a1y) >> sh;
         const u8 *src = frame_src(c);
@@ -2327,17 +2340,22 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     a2x = xl; a2y = yl;
     const bool inside = x + 16 <= F.W && y + 16 <= F.H;
     // thread-0 bookkeeping around the 16x16 CU: header + cost initialisation before, split cost after
-    auto d2_first = [&]() { cu_header(2, xl, yl, 2); s->cost[2] = 1.7e+308; s->cbf_any = 0; ctx_copy(&s->pre[2], &s->cab); price_modes(); };
-    auto d2_last = [&]() {
-      ctx_copy(&s->post2, &s->cab);  // search.c:956-959: the split alternative starts again from the contexts at entry
-      ctx_copy(&s->cab, &s->pre[2]);
-      double sc = split_flag_cost(2, x, y, 2);
-      if (inside && !s->cbf_any) sc = 2147483647;  // cu_split_termination = zero (search.c:975-984)
-      s->split_cost[2] = sc;
+    auto d2_first = [&](int tid) {
+      if (tid == 0) { cu_header(2, xl, yl, 2); s->cost[2] = 1.7e+308; s->cbf_any = 0; price_modes(); }
+      ctx_copy_lanes(&s->pre[2], &s->cab, tid);
+    };
+    auto d2_last = [&](int tid) {
+      ctx_copy_lanes(&s->post2, &s->cab, tid);  // search.c:956-959: the split alternative starts again from the contexts at entry
+      ctx_copy_lanes(&s->cab, &s->pre[2], tid);
+      if (tid == 0) {  // prices the split flag on the contexts at entry: after the copy above (same wavefront, program order)
+        double sc = split_flag_cost(2, x, y, 2);
+        if (inside && !s->cbf_any) sc = 2147483647;  // cu_split_termination = zero (search.c:975-984)
+        s->split_cost[2] = sc;
+      }
     };
     if (inside) eval_cu(2, x, y, 2, &s->cost[2], &s->cbf_any, d2_first, d2_last);
     else {
-      KVZ_FOR_THREADS(tid) { if (tid == 0) { d2_first(); d2_last(); } }
+      KVZ_FOR_THREADS(tid) { d2_first(tid); d2_last(tid); }
       KVZ_SYNC();
     }
     if (!inside || s->cbf_any) {
@@ -2345,7 +2363,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         if (!(s->split_cost[2] < s->cost[2])) break;  // uniform: both are LDS scalars
         const int qx = x + (q & 1) * 8, qy = y + (q >> 1) * 8;
         if (qx >= F.W || qy >= F.H) continue;  // child outside the picture costs 0
-        eval_cu(3, qx, qy, 3, &s->cost[3], &s->cbf_any, [&]() { cu_header(3, qx - cx, qy - cy, 3); price_modes(); }, [&]() { s->split_cost[2] += s->cost[3]; });
+        eval_cu(3, qx, qy, 3, &s->cost[3], &s->cbf_any, [&](int tid) { if (tid == 0) { cu_header(3, qx - cx, qy - cy, 3); price_modes(); } }, [&](int tid) { if (tid == 0) s->split_cost[2] += s->cost[3]; });
       }
     }
     // Every lane reads the verdict here; thread 0 only touches its operands again after the barrier that ends commit()
@@ -2371,16 +2389,18 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     const int xl = x1 - cx, yl = y1 - cy;
     const bool inside = x1 + 32 <= F.W && y1 + 32 <= F.H;
     int *cbf1 = reinterpret_cast<int *>(&s->child_acc[0][0]);  // "the 32x32 CU has coefficients": a scalar of its own (cbf_any is reused by the children); child_acc is dead until the 64x64 attempt
-    auto d1_first = [&]() { *cbf1 = 0; price_modes(); };
-    auto d1_last = [&]() {
-      ctx_swap(&s->cab, &s->pre[1]);
-      double sc = split_flag_cost(1, x1, y1, 1);
-      if (inside && !*cbf1) sc = 2147483647;  // search.c:975-984
-      s->split_cost[1] = sc;
+    auto d1_first = [&](int tid) { if (tid == 0) { *cbf1 = 0; price_modes(); } };
+    auto d1_last = [&](int tid) {
+      ctx_swap_lanes(&s->cab, &s->pre[1], tid);
+      if (tid == 0) {
+        double sc = split_flag_cost(1, x1, y1, 1);
+        if (inside && !*cbf1) sc = 2147483647;  // search.c:975-984
+        s->split_cost[1] = sc;
+      }
     };
     if (inside) eval_cu(1, x1, y1, 1, &s->cost[1], cbf1, d1_first, d1_last);
     else {
-      KVZ_FOR_THREADS(tid) { if (tid == 0) { d1_first(); d1_last(); } }
+      KVZ_FOR_THREADS(tid) { d1_first(tid); d1_last(tid); }
       KVZ_SYNC();
     }
     const bool descend = !inside || *cbf1;
@@ -2424,7 +2444,10 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       if (x1 >= F.W || y1 >= F.H) continue;  // search_cu returns 0 outside the picture
       a1x = x1 - cx; a1y = y1 - cy;
       const bool search32 = S32 && m->search_32x32;
-      load_org([&]() { cu_header(1, x1 - cx, y1 - cy, 1); s->cost[1] = 1.7e+308; ctx_copy(&s->pre[1], &s->cab); if (!search32) s->split_cost[1] = split_flag_cost(1, x1, y1, 1); });
+      load_org([&](int tid) {
+        ctx_copy_lanes(&s->pre[1], &s->cab, tid);  // before the split flag below is priced (it moves its context)
+        if (tid == 0) { cu_header(1, x1 - cx, y1 - cy, 1); s->cost[1] = 1.7e+308; if (!search32) s->split_cost[1] = split_flag_cost(1, x1, y1, 1); }
+      });
       if (search32) search_d1(x1, y1);
       else {
         for (int q2 = 0; q2 < 4; q2++) search_d2(x1 + (q2 & 1) * 16, y1 + (q2 >> 1) * 16);
