@@ -1889,6 +1889,65 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     return luma_ssd * 0.8 + chroma_ssd * 1.5 + bits * m->lambda;
   }
 
+  // cu_bits() * lambda + leaf_rd_cost() of the CU just evaluated at its own depth (eval_cu: search.c:895-940 + 425-541), bin for bin the same
+  // prices and transitions on the search contexts -- but the six bins sit on five different contexts (only U's and V's coded-block flags share
+  // one), so all states are read first, all prices and successors looked up next, and everything is written back at the end: three LDS round
+  // trips on thread 0's critical path instead of one read-price-write chain per bin.  The sums of prices are exact in any order (multiples
+  // of 2^-15 below 2^10), the cost expressions are the callees' own.
+  KVZ_DEV double cu_cost_batched(int lv, int x, int y, int depth, int mode, const int8_t *known_preds, const double *known_coeff_bits) const
+  {
+    const int xl = x - cx, yl = y - cy, w = 64 >> depth;
+    u8 *cs = s->cab.s;
+    const bool adaptive = m->adaptive != 0;
+    // which contexts, which bins
+    const bool has_sp = depth == 3 || !(F.W < x + w || F.H < y + w);
+    const int i_sp = depth == 3 ? KVZ_CX_PART : KVZ_CX_SPLIT + (has_sp ? split_model(lv, x, y, depth) : 0), b_sp = depth == 3 ? 1 : 0;
+    int8_t preds[3];
+    const bool no_left = (x & 63) == 0;  // the mock encode's left neighbour (intra_mode_syntax_bits)
+    if (known_preds && !(no_left && x > 0)) { preds[0] = known_preds[0]; preds[1] = known_preds[1]; preds[2] = known_preds[2]; }
+    else {
+      const int left = (x > 0 && !no_left) ? neighbour_cu(lv, x - 1, y) : -1;
+      const int above = ((y & 63) > 0 && y > 0) ? neighbour_cu(lv, x, y - 1) : -1;
+      mpm_candidates(y, left, above, preds);
+    }
+    const int b_in = (mode == preds[0] || mode == preds[1] || mode == preds[2]) ? 1 : 0;
+    const CtuCu *tr_cu = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
+    const int cb_u = cbf_is_set(tr_cu->cbf, depth, 1), cb_v = cbf_is_set(tr_cu->cbf, depth, 2), cb_y = cbf_is_set(tr_cu->cbf, depth, 0);
+    const int i_cc = KVZ_CX_CBF_CHROMA, i_cl = KVZ_CX_CBF_LUMA + 1;
+    // states, then prices and successors, then the second bin on the chroma flag's context
+    const int s_sp = cs[i_sp], s_in = cs[KVZ_CX_INTRA], s_ch = cs[KVZ_CX_CHROMA], s_cu = cs[i_cc], s_cl = cs[i_cl];
+    const float f_sp = s->entropy_fbits[s_sp ^ b_sp], f_in = s->entropy_fbits[s_in ^ b_in], f_ch = s->entropy_fbits[s_ch ^ 0];
+    const float f_cu = s->entropy_fbits[s_cu ^ cb_u], f_cl = s->entropy_fbits[s_cl ^ cb_y];
+    const int n_sp = ctx_next(s_sp, b_sp), n_in = ctx_next(s_in, b_in), n_ch = ctx_next(s_ch, 0), n_cu = ctx_next(s_cu, cb_u), n_cl = ctx_next(s_cl, cb_y);
+    const int s_cv = adaptive ? n_cu : s_cu;
+    const float f_cv = s->entropy_fbits[s_cv ^ cb_v];
+    const int n_cv = ctx_next(s_cv, cb_v);
+    if (adaptive) {
+      if (has_sp) cs[i_sp] = (u8)n_sp;
+      cs[KVZ_CX_INTRA] = (u8)n_in; cs[KVZ_CX_CHROMA] = (u8)n_ch; cs[i_cc] = (u8)n_cv; cs[i_cl] = (u8)n_cl;
+    }
+    // cu_bits
+    double bits = 0;
+    if (has_sp) bits += (double)f_sp;
+    bits += ((double)f_in + (b_in ? ((mode == preds[0]) ? 1 : 2) : 5)) + (double)f_ch;
+    double cost = bits * m->lambda;
+    // leaf_rd_cost
+    double tr_tree_bits = 0, coeff_bits = 0;
+    tr_tree_bits += (double)f_cu;
+    tr_tree_bits += (double)f_cv;
+    tr_tree_bits += (double)f_cl;
+    if (known_coeff_bits) coeff_bits += *known_coeff_bits;
+    else {
+      if (cb_y) coeff_bits += (double)s->acc[3] / 256.0;
+      if (cb_u) coeff_bits += (double)s->acc[4] / 256.0;
+      if (cb_v) coeff_bits += (double)s->acc[5] / 256.0;
+    }
+    const unsigned luma_ssd = s->acc[0], chroma_ssd = s->acc[1] + s->acc[2];
+    const double lbits = tr_tree_bits + coeff_bits;
+    cost += luma_ssd * 0.8 + chroma_ssd * 1.5 + lbits * m->lambda;
+    return cost;
+  }
+
   KVZ_DEV void fill_cu(int lv, int xl, int yl, int w, int type, int depth, int mode, int tr_depth)
   {
     KVZ_FOR_THREADS(tid) {
@@ -1972,10 +2031,8 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     if (cabac_on()) { KVZ_PROF_SYNC(KVZ_P_RECON); price_unit_coeffs(&s->cab, true, lv, depth, mode, &s->child_bits[0]); KVZ_PROF_SYNC(KVZ_P_COEFFBITS); }  // residual contexts; the syntax ones below are disjoint
     KVZ_FOR_THREADS(tid) {
       if (tid == 0) {
-        const double bits = cu_bits(lv, x, y, depth, mode, s->preds);  // search.c:895-940: cabac->update = 1 around the mock encode ...
-        double cost = bits * m->lambda;
-        cost += leaf_rd_cost(&s->cab, true, lv, xl, yl, depth, depth, true, true, cabac_on() ? &s->child_bits[0] : nullptr);  // ... and the transform tree's flags
-        *out_cost = cost;
+        // search.c:895-940: cabac->update = 1 around the mock encode and the transform tree's flags (= cu_bits() * lambda + leaf_rd_cost())
+        *out_cost = cu_cost_batched(lv, x, y, depth, mode, s->preds, cabac_on() ? &s->child_bits[0] : nullptr);
         const CtuCu *cu = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
         *out_cbf = cbf_is_set(cu->cbf, depth, 0) || cbf_is_set(cu->cbf, depth, 1) || cbf_is_set(cu->cbf, depth, 2);
       }
