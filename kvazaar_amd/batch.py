@@ -13,7 +13,7 @@ class CostModel(C.Structure):
     _fields_ = [("lambda_", C.c_double), ("lambda_sqrt", C.c_double), ("split_flag", (C.c_float * 2) * 3),
                 ("part_size", C.c_float * 2), ("intra_mode", C.c_float * 2), ("chroma_mode", C.c_float * 2),
                 ("cbf_luma", (C.c_float * 2) * 2), ("cbf_chroma", (C.c_float * 2) * 2), ("coeff_weights", C.c_uint64),
-                ("qp", C.c_int32), ("adaptive", C.c_int32), ("coeff_cabac", C.c_int32), ("no_wpp", C.c_int32), ("search_32x32", C.c_int32), ("rdoq", C.c_int32), ("ctx_init", C.c_uint8 * 160),
+                ("qp", C.c_int32), ("adaptive", C.c_int32), ("coeff_cabac", C.c_int32), ("no_wpp", C.c_int32), ("search_32x32", C.c_int32), ("rdoq", C.c_int32), ("search_nxn", C.c_int32), ("ctx_init", C.c_uint8 * 160),
                 ("entropy_fbits", C.c_float * 128)]
 
     def key(self):

@@ -131,6 +131,9 @@ int  kvz_oracle_sao_band_ddistortion(int bitdepth, const uint8_t *orig, const ui
 void kvz_oracle_intra_frame(const kvz_hip_intra_cost_model *m, int width, int height, const uint8_t *src_y, const uint8_t *src_u,
                             const uint8_t *src_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, int16_t *coeff, uint8_t *cu_depth,
                             uint8_t *cu_mode, double *ctu_cost);
+void kvz_oracle_intra_frame_nxn(const kvz_hip_intra_cost_model *m, int width, int height, const uint8_t *src_y, const uint8_t *src_u,
+                            const uint8_t *src_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, int16_t *coeff, uint8_t *cu_depth,
+                            uint8_t *cu_mode, double *ctu_cost, uint8_t *cu_part, uint8_t *cu_mode4);
 void kvz_oracle_intra_cost_model(int qp, const float entropy_fbits[128], uint64_t coeff_weights, kvz_hip_intra_cost_model *m);
 double kvz_oracle_coeff_cabac_bits(const float entropy_fbits[128], const int16_t *coeff, int width, int type, int scan_mode, int update, uint8_t *ctx);
 const uint8_t *kvz_oracle_next_state_table(int lps);  /* cabac.c:40-62, regenerated from H.265 Table 9-41 */

@@ -31,6 +31,12 @@
  * coefficients by running the residual coder in counting mode (fast_residual_cost_limit, rdo.c:311-340): encode_coeff_nxn() below,
  * pinned against the reference's kvz_encode_coeff_nxn on random blocks and context states (tests/test_oracle_vs_ref.py).
  * adaptive == 0 freezes every context at its slice-start state (CTUs then interact through pixels and CU info only).
+ *
+ * The other presets are the same flow with more switched on (kvz_hip_intra_cost_model): coeff_cabac at every QP (`faster`), search_32x32 (`fast`: pu-depth-intra
+ * 1-3), rdoq (`medium`: kvz_rdoq in every quantisation, kvz_oracle_rdoq.c) and search_nxn (`medium`: pu-depth-intra 1-4 -- depth 4 of search_cu, the four 4x4 PUs
+ * of an 8x8 CU: search.c:691, 794, 906-913, 970-974; intra.c:573-577 and transform.c:306-328 for the 4x4 chroma blocks done with the first PU;
+ * quant-generic.c:237-238 for kvz_rdoq's tr_depth; encode_coding_tree.c:148-163, 205-225, 505-560 for the coded syntax).  Each is pinned the same way: the
+ * reconstruction of `kvazaar --preset <p> -p 1 --debug` before the loop filters, after deblocking and after SAO (tests/test_encoder_parity.py).
  */
 #include <math.h>
 #include <stdlib.h>
@@ -93,6 +99,7 @@ typedef struct {
   const uint8_t *src[3];     /* source planes, stride W (luma) / W/2 */
   uint8_t *frec[3];          /* frame reconstruction */
   uint8_t *fdepth, *fmode;   /* frame CU info per 8x8 (stride W/8) */
+  uint8_t *fmode4, *fnxn;    /* search_nxn: luma mode per 4x4 PU (stride W/4) and "part_size == NxN" per 8x8 CU (stride W/8); owned by kvz_oracle_intra_frame */
   int cx, cy;                /* luma origin of the current CTU */
   uint8_t org[3][LCU * LCU]; /* lcu->ref, zero outside the picture (search.c:1084 FILL) */
   level_t lv[NLEVELS];
@@ -281,7 +288,7 @@ static int neighbour_cu(ctu_t *t, level_t *lv, int fx, int fy, cu_t *out)
   if (fx < 0 || fy < 0 || fx >= t->W || fy >= t->H) return 0;
   if (fx >= t->cx && fx < t->cx + LCU && fy >= t->cy && fy < t->cy + LCU) { *out = *cu_at(lv, fx - t->cx, fy - t->cy); return 1; }
   const int i = (fy >> 3) * (t->W >> 3) + (fx >> 3);
-  out->type = 1; out->depth = t->fdepth[i]; out->mode = t->fmode[i]; out->tr_depth = out->depth; out->cbf = 0;
+  out->type = 1; out->depth = t->fdepth[i]; out->mode = t->fmode4[(fy >> 2) * (t->W >> 2) + (fx >> 2)]; out->tr_depth = out->depth; out->cbf = 0;
   return 1;
 }
 
@@ -554,14 +561,16 @@ static void recon_cu_rel(ctu_t *t, level_t *lv, int x, int y, int depth, int mod
     if (recon_tu(t, lv, 0, x, y, log2w, mode, depth, tr_rel)) cbf_set(&cu->cbf, depth, 0);
   }
   if (do_chroma && x % 8 == 0 && y % 8 == 0) {
-    const int cl2 = depth == 3 ? 2 : log2w - 1; /* transform.c:326-327 */
+    const int cl2 = depth >= 3 ? 2 : log2w - 1; /* transform.c:326-327; depth 4 (NxN): the 4x4 chroma blocks of the 8x8 CU, done with its first PU (transform.c:306-312) */
     for (int c = 1; c <= 2; c++) {
       cbf_clear(&cu->cbf, depth, c);
       if (recon_tu(t, lv, c, x, y, cl2, mode, depth, tr_rel)) cbf_set(&cu->cbf, depth, c);
     }
   }
 }
-static void recon_cu(ctu_t *t, level_t *lv, int x, int y, int depth, int mode, int do_luma, int do_chroma) { recon_cu_rel(t, lv, x, y, depth, mode, do_luma, do_chroma, 0); }
+/* tr_rel: what kvz_rdoq gets as tr_depth = cu->tr_depth - cu->depth, plus one for an NxN CU (quant-generic.c:237-238): 2 for the blocks of its four PUs
+ * (depth 4: cu->depth stays 3, search.c:691) */
+static void recon_cu(ctu_t *t, level_t *lv, int x, int y, int depth, int mode, int do_luma, int do_chroma) { recon_cu_rel(t, lv, x, y, depth, mode, do_luma, do_chroma, depth == 4 ? 2 : 0); }
 
 /* Test hook: the residual coder's bit count on caller-supplied states of the residual contexts (KVZ_HIP_CX_SIG_CG .. KVZ_HIP_CX_COUNT - 1,
  * updated in place when `update`), against the reference's kvz_encode_coeff_nxn (tests/test_oracle_vs_ref.py) */
@@ -709,7 +718,8 @@ static double search_cu(ctu_t *t, int x, int y, int depth)
   cur->tr_depth = (uint8_t)(depth > 0 ? depth : 1);
   cur->type = 0;
   const int inside = x + w <= t->W && y + w <= t->H;
-  if (inside && depth >= (m->search_32x32 ? 1 : 2) && depth <= 3) {  /* pu_depth_intra.min .. max (search.c:794) */
+  const int max_depth = m->search_nxn ? 4 : 3;  /* pu_depth_intra.max: 4 = the NxN partition of an 8x8 CU, one more level of this recursion (search.c:691, 794) */
+  if (inside && depth >= (m->search_32x32 ? 1 : 2) && depth <= max_depth) {  /* pu_depth_intra.min .. max (search.c:794) */
     const int mode = search_cu_intra(t, lv, x, y, depth);
     cur->type = 1; cur->mode = (uint8_t)mode;
     fill_cu(lv, xl, yl, w, cur);
@@ -717,11 +727,12 @@ static double search_cu(ctu_t *t, int x, int y, int depth)
     if (x % 8 == 0 && y % 8 == 0) recon_cu(t, lv, x, y, depth, mode, 0, 1);
   }
   if (cur->type == 1) {
-    const double bits = cu_bits(t, lv, x, y, depth, cur->mode, 1);  /* search.c:895-940: cabac->update = 1 around the mock encode ... */
+    /* search.c:895-940: cabac->update = 1 around the mock encode (a PU of an NxN CU: calc_mode_bits instead, search.c:906-913) ... */
+    const double bits = depth == 4 ? intra_mode_syntax_bits(t, lv, x, y, cur->mode, x % 8 == 0 && y % 8 == 0, 1, 0) : cu_bits(t, lv, x, y, depth, cur->mode, 1);
     cost = bits * m->lambda;
     cost += rd_cost(t, lv, xl, yl, depth, cur, 1);                  /* ... and the transform-tree flags */
   }
-  const int can_split = cur->type == 0 || depth < 3;
+  const int can_split = cur->type == 0 || depth < max_depth;
   if (can_split) {
     const int half = w / 2;
     double split_cost = 0.0;
@@ -730,6 +741,7 @@ static double search_cu(ctu_t *t, int x, int y, int depth)
     t->cab = pre_search;
     double split_bits = 0;
     if (depth < 3) { const int sm = split_model(t, lv, x, y, depth); split_bits += ctx_price(t, CX_SPLIT + sm, 1, 1, m->split_flag[sm][1]); }
+    if (cur->type == 1 && depth == 3) split_bits += ctx_price(t, CX_PART, 0, 1, m->part_size[0]);  /* search.c:970-974: part_size NxN */
     split_cost += split_bits * m->lambda;
     if (cur->type == 0 || cbf) {
       if (split_cost < cost) split_cost += search_cu(t, x, y, depth + 1);
@@ -793,6 +805,8 @@ static double encode_ctu(ctu_t *t, int cx, int cy, int16_t *coeff_out)
       const int i = ((cy + yy) >> 3) * (t->W >> 3) + ((cx + xx) >> 3);
       t->fdepth[i] = cu_at(l0, xx, yy)->depth;
       t->fmode[i] = cu_at(l0, xx, yy)->mode;
+      t->fnxn[i] = cu_at(l0, xx, yy)->tr_depth == 4;
+      for (int j = 0; j < 4; j++) t->fmode4[((cy + yy) / 4 + (j >> 1)) * (t->W >> 2) + (cx + xx) / 4 + (j & 1)] = cu_at(l0, xx + 4 * (j & 1), yy + 4 * (j >> 1))->mode;
     }
   memcpy(coeff_out, l0->coeff[0], 4096 * sizeof(int16_t));
   memcpy(coeff_out + 4096, l0->coeff[1], 1024 * sizeof(int16_t));
@@ -806,9 +820,9 @@ static double encode_ctu(ctu_t *t, int cx, int cy, int16_t *coeff_out)
  * CTUs) and, for the coded block flags, level 0 of the CTU just searched. */
 static void code_transform_tree(ctu_t *t, ctxs_t *c, int xl, int yl, int depth, int tr_depth, int parent_u, int parent_v)
 {
-  const cu_t *cu = cu_at(&t->lv[0], xl, yl);
-  const int split = cu->tr_depth > depth;
-  const int cb_y = cbf_is_set(cu->cbf, depth, 0), cb_u = cbf_is_set(cu->cbf, depth, 1), cb_v = cbf_is_set(cu->cbf, depth, 2);
+  const cu_t *cu = cu_at(&t->lv[0], xl, yl), *cu8 = cu_at(&t->lv[0], xl & ~7, yl & ~7);  /* cur_pu / cur_cu of encode_transform_coeff (encode_coding_tree.c:205-210) */
+  const int split = cu8->tr_depth > depth;
+  const int cb_y = cbf_is_set(cu->cbf, depth, 0), cb_u = cbf_is_set(cu8->cbf, depth, 1), cb_v = cbf_is_set(cu8->cbf, depth, 2);
   /* split_transform_flag is never coded: tr_depth_intra = 0, and the 64x64 split is inferred (encode_coding_tree.c:236-243) */
   if (depth < 4) {
     if (tr_depth == 0 || parent_u) ctx_code(c, CX_CBF_CHROMA + tr_depth, cb_u);
@@ -824,10 +838,13 @@ static void code_transform_tree(ctu_t *t, ctxs_t *c, int xl, int yl, int depth, 
   }
   ctx_code(c, CX_CBF_LUMA + !tr_depth, cb_y);  /* always present for intra (encode_coding_tree.c:276-279) */
   if (t->m->coeff_cabac) {  /* encode_transform_unit (encode_coding_tree.c:117-190): the residual moves its own contexts */
-    const int w = LCU >> depth, cw = LCU >> (depth + 1), scan = scan_order(cu->mode, depth);
-    if (cb_y) encode_coeff_nxn(t->m, c, 1, &t->lv[0].coeff[0][zorder(xl, yl)], w, 0, scan);
-    if (cb_u) encode_coeff_nxn(t->m, c, 1, &t->lv[0].coeff[1][zorder(xl / 2, yl / 2)], cw, 2, scan);
-    if (cb_v) encode_coeff_nxn(t->m, c, 1, &t->lv[0].coeff[2][zorder(xl / 2, yl / 2)], cw, 2, scan);
+    const int w = LCU >> depth, cw = depth == 4 ? w : LCU >> (depth + 1);
+    if (cb_y) encode_coeff_nxn(t->m, c, 1, &t->lv[0].coeff[0][zorder(xl, yl)], w, 0, scan_order(cu->mode, depth));
+    /* 4x4 luma blocks: the 4x4 chroma blocks of the 8x8 CU follow the last of them, under the first PU's mode (encode_coding_tree.c:148-163) */
+    if (depth == 4 && (xl % 8 == 0 || yl % 8 == 0)) return;
+    const int cscan = scan_order(cu8->mode, depth), cxl = (xl & ~7) / 2, cyl = (yl & ~7) / 2;
+    if (cb_u) encode_coeff_nxn(t->m, c, 1, &t->lv[0].coeff[1][zorder(cxl, cyl)], cw, 2, cscan);
+    if (cb_v) encode_coeff_nxn(t->m, c, 1, &t->lv[0].coeff[2][zorder(cxl, cyl)], cw, 2, cscan);
   }
 }
 static void code_coding_tree(ctu_t *t, ctxs_t *c, int x, int y, int depth)
@@ -852,16 +869,23 @@ static void code_coding_tree(ctu_t *t, ctxs_t *c, int x, int y, int depth)
       return;
     }
   }
-  if (depth == 3) ctx_code(c, CX_PART, 1);  /* part_mode 2Nx2N at the minimum CU size */
+  const int nxn = depth == 3 && t->fnxn[(y >> 3) * w8 + (x >> 3)];
+  if (depth == 3) ctx_code(c, CX_PART, !nxn);  /* part_mode at the minimum CU size: 2Nx2N = 1, NxN = 0 */
   {
-    cu_t lc = { 1, 0, 0, 0, 0 }, ac = { 1, 0, 0, 0, 0 }, *left = NULL, *above = NULL;
-    const int mode = t->fmode[(y >> 3) * w8 + (x >> 3)];
-    if (x > 0) { lc.mode = t->fmode[(y >> 3) * w8 + ((x - 1) >> 3)]; left = &lc; }
-    if (y % LCU > 0 && y > 0) { ac.mode = t->fmode[((y - 1) >> 3) * w8 + (x >> 3)]; above = &ac; }
-    int8_t preds[3];
-    mpm_candidates(y, left, above, preds);
-    ctx_code(c, CX_INTRA, mode == preds[0] || mode == preds[1] || mode == preds[2]);  /* prev_intra_luma_pred_flag; mpm_idx / rem mode are bypass */
-    ctx_code(c, CX_CHROMA, 0);                                                         /* intra_chroma_pred_mode: derived from luma */
+    /* encode_intra_coding_unit (encode_coding_tree.c:467-652): the prev_intra_luma_pred_flags of all PUs first, each against the most probable modes
+     * at its own position (4x4-granular CU info); mpm_idx / rem_intra_luma_pred_mode are bypass bins; chroma mode derived from the first PU's */
+    const int w4 = t->W >> 2;
+    for (int j = 0; j < (nxn ? 4 : 1); j++) {
+      const int px = x + 4 * (j & 1), py = y + 4 * (j >> 1);
+      cu_t lc = { 1, 0, 0, 0, 0 }, ac = { 1, 0, 0, 0, 0 }, *left = NULL, *above = NULL;
+      const int mode = t->fmode4[(py >> 2) * w4 + (px >> 2)];
+      if (px > 0) { lc.mode = t->fmode4[(py >> 2) * w4 + ((px - 1) >> 2)]; left = &lc; }
+      if (py % LCU > 0 && py > 0) { ac.mode = t->fmode4[((py - 1) >> 2) * w4 + (px >> 2)]; above = &ac; }
+      int8_t preds[3];
+      mpm_candidates(py, left, above, preds);
+      ctx_code(c, CX_INTRA, mode == preds[0] || mode == preds[1] || mode == preds[2]);
+    }
+    ctx_code(c, CX_CHROMA, 0);
   }
   code_transform_tree(t, c, x - t->cx, y - t->cy, depth, 0, 0, 0);
 }
@@ -870,15 +894,19 @@ static void code_coding_tree(ctu_t *t, ctxs_t *c, int x, int y, int depth)
  * must be multiples of 8 (kvazaar pads its input to that, encoder.c).  Outputs: rec planes, KVZ_HIP_CTU_COEFFS
  * coefficients per CTU (raster CTU order), CU depth and luma mode per 8x8 block (raster, stride width/8), and the
  * RD cost of every CTU. */
-void kvz_oracle_intra_frame(const kvz_hip_intra_cost_model *m, int width, int height, const uint8_t *src_y, const uint8_t *src_u,
-                            const uint8_t *src_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, int16_t *coeff, uint8_t *cu_depth,
-                            uint8_t *cu_mode, double *ctu_cost)
+/* ... + (model.search_nxn) cu_part: 1 per 8x8 block that is an NxN CU; cu_mode4: luma mode per 4x4 block (stride width/4); cu_mode then holds the first PU's.
+ * Both may be NULL. */
+void kvz_oracle_intra_frame_nxn(const kvz_hip_intra_cost_model *m, int width, int height, const uint8_t *src_y, const uint8_t *src_u,
+                                const uint8_t *src_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, int16_t *coeff, uint8_t *cu_depth,
+                                uint8_t *cu_mode, double *ctu_cost, uint8_t *cu_part, uint8_t *cu_mode4)
 {
   ctu_t *t = (ctu_t *)calloc(1, sizeof(ctu_t));
   t->m = m; t->W = width; t->H = height;
   t->src[0] = src_y; t->src[1] = src_u; t->src[2] = src_v;
   t->frec[0] = rec_y; t->frec[1] = rec_u; t->frec[2] = rec_v;
   t->fdepth = cu_depth; t->fmode = cu_mode;
+  t->fmode4 = (uint8_t *)calloc((size_t)(width / 4) * (height / 4), 1);
+  t->fnxn = (uint8_t *)calloc((size_t)(width / 8) * (height / 8), 1);
   build_avail_tables(t);
   build_transitions();
   const int wc = (width + 63) / 64, hc = (height + 63) / 64;
@@ -899,8 +927,17 @@ void kvz_oracle_intra_frame(const kvz_hip_intra_cost_model *m, int width, int he
         if (!m->no_wpp && cx == 1 && cy + 1 < hc) rows[cy + 1] = rows[cy];
       }
     }
+  if (cu_part) memcpy(cu_part, t->fnxn, (size_t)(width / 8) * (height / 8));
+  if (cu_mode4) memcpy(cu_mode4, t->fmode4, (size_t)(width / 4) * (height / 4));
+  free(t->fmode4); free(t->fnxn);
   free(rows);
   free(t);
+}
+void kvz_oracle_intra_frame(const kvz_hip_intra_cost_model *m, int width, int height, const uint8_t *src_y, const uint8_t *src_u,
+                            const uint8_t *src_v, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, int16_t *coeff, uint8_t *cu_depth,
+                            uint8_t *cu_mode, double *ctu_cost)
+{
+  kvz_oracle_intra_frame_nxn(m, width, height, src_y, src_u, src_v, rec_y, rec_u, rec_v, coeff, cu_depth, cu_mode, ctu_cost, NULL, NULL);
 }
 
 /* The cost model for QP `qp` of an I slice (kvz_hip_intra_cost_model): context init values of the

@@ -121,6 +121,12 @@ ENCODER_CLIPS_RDOQ = [(64, 64, 2, 9, "small", 22), (72, 88, 2, 1, "small", 12), 
                       (192, 136, 4, 0, "adversarial", 32), (832, 480, 1, 5, "large", 22), (1920, 1080, 1, 1, "large", 27)]
 
 
+# (width, height, frames, seed, kind, qp): `--preset medium -p 1` as it is -- pu-depth-intra 1-4: 8x8 CUs are also tried as four 4x4 PUs (part_size NxN) -- on clips
+# where that partition is taken (noise at QP 12: every CU; the synthetic scenes at QP 12-27: a few per cent of the 8x8 CUs); the same three stages
+ENCODER_CLIPS_MEDIUM = [(64, 64, 2, 9, "small", 22), (72, 88, 2, 1, "small", 12), (200, 136, 2, 3, "small", 27), (416, 240, 2, 1234, "small", 22),
+                        (192, 136, 4, 0, "adversarial", 12), (192, 136, 4, 0, "adversarial", 32), (832, 480, 1, 5, "large", 17), (1920, 1080, 1, 1, "large", 27)]
+
+
 def clip_key(w, h, n, seed, kind, qp, deblock, no_wpp=False, tiles=None, wpp=False):
     return (f"{w}x{h}/n{n}/seed{seed}/{kind}/qp{qp}/{'deblock' if deblock else 'nodeblock'}" + ("/nowpp" if no_wpp else "")
             + (f"/tiles{tiles}" + ("-wpp" if wpp else "") if tiles else ""))
@@ -193,6 +199,7 @@ def encoder_digests(workdir):
         for stage, (deblock, sao) in (("nodeblock", (0, False)), ("deblock", (1, False)), ("sao", (1, True))):
             recs = reference_encoder_recon(w, h, frames, qp, deblock, workdir, None, False, None, False, sao, "medium", ("--pu-depth-intra", "1-3"))
             out[clip_key(w, h, n, seed, kind, qp, deblock) + "/medium-pu13" + ("/sao" if sao else "")] = [hashlib.sha256(r.tobytes()).hexdigest()[:24] for r in recs]
+    out.update(medium_digests(workdir))
     for (w, h, n, seed, kind, qp, tiles, wpp) in ENCODER_CLIPS_TILES:
         frames = cc.yuv_frames(w, h, n, seed, kind)
         for deblock in (0, 1):
@@ -204,6 +211,30 @@ def encoder_digests(workdir):
             out[clip_key(w, h, n, seed, kind, qp, deblock, False, tiles, wpp) + "/per-tile"] = [
                 [hashlib.sha256(sharding.crop_tile(r, w, h, t).tobytes()).hexdigest()[:24] for t in grid] for r in recs]
     return out
+
+
+def medium_digests(workdir):
+    """the ENCODER_CLIPS_MEDIUM entries of encoder_recon.json (callable on its own: `python -c "import make_golden as m; m.update_medium()"`)"""
+    import ctu_common as cc
+    out = {}
+    for (w, h, n, seed, kind, qp) in ENCODER_CLIPS_MEDIUM:
+        frames = cc.yuv_frames(w, h, n, seed, kind)
+        for stage, (deblock, sao) in (("nodeblock", (0, False)), ("deblock", (1, False)), ("sao", (1, True))):
+            maps = [] if stage == "nodeblock" else None
+            recs = reference_encoder_recon(w, h, frames, qp, deblock, workdir, maps, False, None, False, sao, "medium")
+            out[clip_key(w, h, n, seed, kind, qp, deblock) + "/medium" + ("/sao" if sao else "")] = [hashlib.sha256(r.tobytes()).hexdigest()[:24] for r in recs]
+            if maps is not None:  # CU depth and the first PU's intra mode per 8x8 cell
+                out[clip_key(w, h, n, seed, kind, qp, deblock) + "/medium/cu"] = [cu_digest(d, m) for d, m in maps]
+    return out
+
+
+def update_medium():
+    import tempfile
+    path = os.path.join(HERE, "encoder_recon.json")
+    data = json.load(open(path))
+    with tempfile.TemporaryDirectory() as d:
+        data.update(medium_digests(d))
+    json.dump(data, open(path, "w"), indent=0, sort_keys=True)
 
 
 def cu_digest(depth, mode):

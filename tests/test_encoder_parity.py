@@ -318,6 +318,49 @@ def test_oracle_rdoq_reproduces_reference_encoder(oracle, clip):
     assert deb == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 1) + "/medium-pu13"]
 
 
+# ---- `--preset medium` itself: the above + the 4x4 NxN partitions of 8x8 CUs (pu-depth-intra 1-4).  ORACLE ONLY so far (model.search_nxn): the next row of the
+# device pass starts from a pinned restatement ----------
+def _medium_model(model):
+    model = _rdoq_model(model)
+    model.search_nxn = 1
+    return model
+
+
+@pytest.mark.parametrize("clip", mg.ENCODER_CLIPS_MEDIUM, ids=lambda c: f"{c[0]}x{c[1]}-{c[4]}-qp{c[5]}")
+def test_oracle_medium_reproduces_reference_encoder(oracle, clip):
+    """`kvazaar --preset medium -p 1 --debug`, picture for picture: before the loop filters, the CU depth / first-PU mode maps behind it, after deblocking and
+    after SAO (`--sao full`, the preset's own) -- with the NxN partition taken by every CU (noise at QP 12) down to a few per cent of the 8x8 CUs"""
+    from test_sao_decision import oracle_sao_chain
+    w, h, n, seed, kind, qp = clip
+    model = _medium_model(oracle_model(oracle, qp))
+    frames = cc.yuv_frames(w, h, n, seed, kind)
+    raw, cu, deb = _oracle_outputs(oracle, model, w, h, frames, qp)
+    assert raw == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0) + "/medium"]
+    assert cu == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0) + "/medium/cu"]
+    assert deb == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 1) + "/medium"]
+    if w * h <= 832 * 480:
+        assert [_sha(oracle_sao_chain(oracle, model, w, h, f)[0]) for f in frames] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 1) + "/medium/sao"]
+
+
+def test_oracle_medium_takes_the_nxn_partition(oracle):
+    """the fixture exercises what it is for: the noise picture at QP 12 codes every 8x8 CU as four 4x4 PUs with modes of their own"""
+    import ctypes as C
+    w, h, qp = 192, 136, 12
+    f = cc.yuv_frames(w, h, 4, 0, "adversarial")[1]
+    model = _medium_model(oracle_model(oracle, qp))
+    o = cc.outputs(w, h)
+    part, mode4 = np.zeros((h // 8) * (w // 8), np.uint8), np.zeros((h // 4) * (w // 4), np.uint8)
+    ys, cs = w * h, w * h // 4
+    fn = oracle.lib.kvz_oracle_intra_frame_nxn
+    fn.restype = None
+    fn(C.byref(model), w, h, cc.ptr(f[:ys]), cc.ptr(f[ys:ys + cs]), cc.ptr(f[ys + cs:]), cc.ptr(o["rec"]), cc.ptr(o["rec"], offset=ys), cc.ptr(o["rec"], offset=ys + cs),
+       cc.ptr(o["coeff"]), cc.ptr(o["depth"]), cc.ptr(o["mode"]), o["cost"].ctypes.data_as(C.POINTER(C.c_double)), cc.ptr(part), cc.ptr(mode4))
+    assert part.sum() > 0.9 * part.size and (o["depth"][part == 1] == 3).all()
+    m4 = mode4.reshape(h // 4, w // 4)
+    assert np.array_equal(m4[::2, ::2].reshape(-1), o["mode"])          # cu_mode holds the first PU's mode
+    assert (m4[::2, ::2] != m4[1::2, 1::2]).mean() > 0.5                # ... and the PUs of a CU choose their own
+
+
 @pytest.mark.parametrize("clip", [c for c in mg.ENCODER_CLIPS_RDOQ if c[0] * c[1] <= 416 * 240], ids=lambda c: f"{c[0]}x{c[1]}-{c[4]}-qp{c[5]}")
 def test_hostsim_rdoq_equals_oracle(oracle, hostsim, clip):
     """the device sources with kvz_rdoq in the quantisation stage (CtuProgramT<true, true, true>) on the host: every output equals the oracle's, costs included;
