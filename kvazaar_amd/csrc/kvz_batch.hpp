@@ -430,7 +430,7 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
   cm.ctx_init = (const uint8_t *)(b->d_entropy + 128);
   KVZ_HIP_CHECK(hipMemcpyAsync(b->d_entropy, model->entropy_fbits, 128 * sizeof(float), hipMemcpyHostToDevice, b->stream));
   KVZ_HIP_CHECK(hipMemcpyAsync(b->d_entropy + 128, model->ctx_init, sizeof model->ctx_init, hipMemcpyHostToDevice, b->stream));
-  if (cm.search_nxn) { fprintf(stderr, "kvz_hip_intra_frames: search_nxn (4x4 NxN partitions, --pu-depth-intra ..-4) is not on the device yet\n"); abort(); }
+  if (model->search_nxn) { fprintf(stderr, "kvz_hip_intra_frames: search_nxn (4x4 NxN partitions, --pu-depth-intra ..-4) is not on the device yet\n"); abort(); }
   if (!b->sched_ticket && (cm.search_32x32 || cm.rdoq)) { fprintf(stderr, "kvz_hip_intra_frames: search_32x32 / rdoq need the ticket schedule\n"); abort(); }
   if (!b->sched_ticket && cm.no_wpp) { fprintf(stderr, "kvz_hip_intra_frames: the one-launch-per-diagonal schedule (KVZ_HIP_SCHED=wave) needs WPP\n"); abort(); }
   if (b->sched_ticket) {
