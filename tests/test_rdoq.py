@@ -38,6 +38,21 @@ def rdoq_cases(n_per_shape=14):
     return out
 
 
+def rdoq_cases_nxn(n=40):
+    """the 4x4 blocks of an NxN CU: kvz_rdoq gets tr_depth 2 for them (quant-generic.c:237-238), and a chroma block then prices its coded-block flag on
+    qt_cbf_model_chroma[2], which still has its slice-start state"""
+    rng = np.random.default_rng(77)
+    out = []
+    for k in range(n):
+        typ = 2 if k % 2 else 0
+        qp = int(rng.choice([12, 17, 22, 27, 32, 37]))
+        lam = 0.57 * 2 ** ((qp - 12) / 3.0)
+        ctx = rng.integers(0, 126, 160).astype(np.uint8)
+        coef = np.clip(rng.laplace(0, float(rng.choice([4, 30, 200, 1500])), (4, 4)), -32000, 32000).astype(np.int16)
+        out.append((qp, lam, A(ctx), A(coef.reshape(-1)), 4, typ, int(rng.integers(0, 3)), 2))
+    return out
+
+
 def run_rdoq(fn, fbits, case):
     qp, lam, ctx, coef, w, typ, scan, trd = case
     dest = A(np.full(w * w, 77, np.int16))  # the function leaves positions past the last significant one untouched only when nothing is coded
@@ -62,6 +77,31 @@ def test_oracle_rdoq_equals_compiled_reference(oracle):
     assert not bad, f"{len(bad)}/{len(cases)} blocks differ: {[(cases[i][0], cases[i][4], cases[i][5], cases[i][6]) for i in bad[:8]]}"
     changed = sum(1 for c in cases if np.frombuffer(run_rdoq(fo, fb, c), np.int16).any())
     assert changed > len(cases) // 3  # the rest quantise to nothing at their QP
+
+
+def test_oracle_rdoq_nxn_blocks_equal_compiled_reference(oracle):
+    if not os.path.exists(flatapi.refshim_path()):
+        pytest.skip("oracle/_ref not built")
+    ref = flatapi.load_ref(0)
+    fo, fr = oracle.lib.kvz_oracle_rdoq, ref.lib.kvz_ref_rdoq
+    fo.restype = fr.restype = None
+    fo.argtypes = fr.argtypes = RDOQ_ARGS
+    fb = _fbits()
+    cases = rdoq_cases_nxn()
+    bad = [i for i, c in enumerate(cases) if run_rdoq(fo, fb, c) != run_rdoq(fr, fb, c)]
+    assert not bad, f"{len(bad)}/{len(cases)} blocks differ: {[(cases[i][0], cases[i][5], cases[i][6]) for i in bad[:8]]}"
+    # ... and the deep context matters: with tr_depth 1 some of the chroma blocks quantise differently
+    rng = np.random.default_rng(5)
+    found = 0
+    for _ in range(3000):  # blocks around the code-it-or-not threshold: a single small coefficient
+        qp = int(rng.choice([22, 27, 32, 37]))
+        coef = np.zeros(16, np.int16)
+        coef[int(rng.integers(0, 16))] = int(rng.integers(4, 400))
+        c = (qp, 0.57 * 2 ** ((qp - 12) / 3.0), A(rng.integers(0, 126, 160).astype(np.uint8)), A(coef), 4, 2, 0, 2)
+        a = run_rdoq(fo, fb, c)
+        assert a == run_rdoq(fr, fb, c)
+        found += a != run_rdoq(fo, fb, c[:7] + (1,))
+    assert found > 0
 
 
 def test_hostsim_rdoq_equals_oracle(oracle, hostsim):
