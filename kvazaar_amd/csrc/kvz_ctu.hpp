@@ -420,18 +420,9 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     const int mps = st + ((st < 124) << 1), lps = (int)s->ctx_lps[st >> 1] ^ (st & 1);  // branch-free: both are a handful of ALU ops + one LDS byte
     return bin == (st & 1) ? mps : lps;
   }
-  // copy of a context set: the residual-coding part only matters (and only moves) when coefficients are priced with the CABAC model
-  // (all words are read before the first one is written: one lane does this, and with stores in between the compiler has to assume that the
-  // two sets overlap and waits for every LDS round trip)
-  KVZ_DEV void ctx_copy(CtxSet *dst, const CtxSet *src) const
-  {
-    constexpr int n = CABAC ? 37 : 3;
-    unsigned t[n];
-    for (int i = 0; i < n; i++) t[i] = ((const unsigned *)src->s)[i];
-    for (int i = 0; i < n; i++) ((unsigned *)dst->s)[i] = t[i];
-  }
-  // The same by the lanes that play threads 0..36 (one wavefront: thread ids rotate by whole wavefronts), a word each.  Callers bring every
-  // thread; what thread 0 wrote into a set just before (same wavefront, program order) is seen.
+  // Copy / exchange of context sets (search.c:655, 956-959, 1051): the residual-coding part only matters (and only moves) when coefficients are priced
+  // with the CABAC model.  By the lanes that play threads 0..36 (one wavefront: thread ids rotate by whole wavefronts), a word each -- one lane doing
+  // it was 74 LDS operations in a row.  Callers bring every thread; what thread 0 wrote into a set just before (same wavefront, program order) is seen.
   KVZ_DEV void ctx_copy_lanes(CtxSet *dst, const CtxSet *src, int tid) const
   {
     if (tid < (CABAC ? 37 : 3)) ((unsigned *)dst->s)[tid] = ((const unsigned *)src->s)[tid];
@@ -442,13 +433,6 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       const unsigned ta = ((const unsigned *)a->s)[tid], tb2 = ((const unsigned *)b->s)[tid];
       ((unsigned *)a->s)[tid] = tb2; ((unsigned *)b->s)[tid] = ta;
     }
-  }
-  KVZ_DEV void ctx_swap(CtxSet *a, CtxSet *b) const
-  {
-    constexpr int n = CABAC ? 37 : 3;
-    unsigned ta[n], tb2[n];
-    for (int i = 0; i < n; i++) { ta[i] = ((const unsigned *)a->s)[i]; tb2[i] = ((const unsigned *)b->s)[i]; }
-    for (int i = 0; i < n; i++) { ((unsigned *)a->s)[i] = tb2[i]; ((unsigned *)b->s)[i] = ta[i]; }
   }
   // lambda_sqrt * kvz_luma_mode_bits of the three possible outcomes at the current state of the intra-mode context; the rough
   // search prices with it without touching the context (search_intra.c:524: search_cabac.update == 0 there).  One lane.
