@@ -2220,10 +2220,11 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       KVZ_SYNC();
       KVZ_FOR_THREADS(tid) {
 #ifdef KVZ_HOSTSIM
-        const bool luma_role = true, chroma_role = true;
         if (tid == 0) {
 #else
-        const bool luma_role = tid < 64, chroma_role = !luma_role;  // two independent chains: luma blocks on one wavefront, chroma blocks on the other
+        // independent chains on the two wavefronts: the significance flags of the luma blocks on one, the chroma blocks and the luma blocks' other
+        // classes on the other (coeff_cabac_bits_wave's `part`)
+        const bool luma_role = tid < 64, chroma_role = !luma_role;
         {  // both wavefronts walk the quadrant's units (everything they branch on is wavefront-uniform)
 #endif
           CtxSet *c = &s->pre[0];
