@@ -78,7 +78,7 @@ enum {
   KVZ_HIP_CX_INTRA = 4,          /* intra_mode_model */
   KVZ_HIP_CX_CHROMA = 5,         /* chroma_pred_model[0] */
   KVZ_HIP_CX_CBF_LUMA = 6,       /* qt_cbf_model_luma[0..1] */
-  KVZ_HIP_CX_CBF_CHROMA = 8,     /* qt_cbf_model_chroma[0..1] */
+  KVZ_HIP_CX_CBF_CHROMA = 8,     /* qt_cbf_model_chroma[0..1]; [2..3] are KVZ_HIP_CX_CBF_CHROMA_DEEP below */
   KVZ_HIP_CX_SIG_CG = 10,        /* cu_sig_coeff_group_model[0..3] */
   KVZ_HIP_CX_SIG_LUMA = 14,      /* cu_sig_model_luma[0..26] */
   KVZ_HIP_CX_SIG_CHROMA = 41,    /* cu_sig_model_chroma[0..14] */
@@ -90,10 +90,13 @@ enum {
   KVZ_HIP_CX_ONE_CHROMA = 132,   /* cu_one_model_chroma[0..7] */
   KVZ_HIP_CX_ABS_LUMA = 140,     /* cu_abs_model_luma[0..3] */
   KVZ_HIP_CX_ABS_CHROMA = 144,   /* cu_abs_model_chroma[0..1] */
-  KVZ_HIP_CX_COUNT = 146,        /* contexts of the CTU pass */
+  /* qt_cbf_model_chroma[2..3] (cabac.h:75): nothing in these configurations ever CODES a chroma coded-block flag at transform depth 2 or 3, but kvz_rdoq PRICES
+   * the flag of a chroma block on qt_cbf_model_chroma[tr_depth] (rdo.c:907-915), and the blocks of an NxN CU arrive with tr_depth 2 (quant-generic.c:237-238) */
+  KVZ_HIP_CX_CBF_CHROMA_DEEP = 146,
+  KVZ_HIP_CX_COUNT = 148,        /* contexts of the CTU pass */
   /* the two contexts of the SAO syntax (encoderstate.c:467-552), used by the SAO parameter decision only */
-  KVZ_HIP_CX_SAO_MERGE = 146,    /* sao_merge_flag_model */
-  KVZ_HIP_CX_SAO_TYPE = 147      /* sao_type_idx_model */
+  KVZ_HIP_CX_SAO_MERGE = 148,    /* sao_merge_flag_model */
+  KVZ_HIP_CX_SAO_TYPE = 149      /* sao_type_idx_model */
 };
 
 typedef struct kvz_hip_intra_cost_model {

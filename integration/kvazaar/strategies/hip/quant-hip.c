@@ -57,6 +57,7 @@ static void gather_rdoq_contexts(const encoder_state_t *state, uint8_t ctx[160])
 #define PUT(at, src, n) for (int i_ = 0; i_ < (n); i_++) ctx[(at) + i_] = (src)[i_].uc_state
   PUT(KVZ_HIP_CX_CBF_LUMA, cb->ctx.qt_cbf_model_luma, 2);
   PUT(KVZ_HIP_CX_CBF_CHROMA, cb->ctx.qt_cbf_model_chroma, 2);
+  PUT(KVZ_HIP_CX_CBF_CHROMA_DEEP, cb->ctx.qt_cbf_model_chroma + 2, 2);  /* tr_depth 2 / 3: the chroma blocks of an NxN CU (quant-generic.c:237-238), --tr-depth-intra */
   PUT(KVZ_HIP_CX_SIG_CG, cb->ctx.cu_sig_coeff_group_model, 4);
   PUT(KVZ_HIP_CX_SIG_LUMA, cb->ctx.cu_sig_model_luma, 27);
   PUT(KVZ_HIP_CX_SIG_CHROMA, cb->ctx.cu_sig_model_chroma, 15);

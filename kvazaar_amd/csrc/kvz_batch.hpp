@@ -252,6 +252,10 @@ inline void cost_model_init(int qp, uint64_t coeff_weights, kvz_hip_intra_cost_m
   put(KVZ_HIP_CX_ONE_CHROMA, init_one + 16, 8);
   put(KVZ_HIP_CX_ABS_LUMA, init_abs, 4);
   put(KVZ_HIP_CX_ABS_CHROMA, init_abs + 4, 2);
+  {
+    static const uint8_t init_cbf_chroma_deep[2] = { 182, 154 };  // INIT_QT_CBF[2][6..7] (context.c:130-134)
+    put(KVZ_HIP_CX_CBF_CHROMA_DEEP, init_cbf_chroma_deep, 2);
+  }
   m->ctx_init[KVZ_HIP_CX_SAO_MERGE] = (uint8_t)ctx_state(qp, 153);  // context.c:38-39 INIT_SAO_MERGE_FLAG / INIT_SAO_TYPE_IDX, I slice
   m->ctx_init[KVZ_HIP_CX_SAO_TYPE] = (uint8_t)ctx_state(qp, 200);
   m->adaptive = 1;

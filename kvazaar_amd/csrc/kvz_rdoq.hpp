@@ -314,9 +314,11 @@ KVZ_DEV KVZ_RDOQ_NOINLINE void rdoq_block(const RdoqCtx &c, int qp, const i16 *c
   int best_last_idx_p1 = 0;
   bool found_last = false;
   {
-    const int cbf0 = type ? KVZ_HIP_CX_CBF_CHROMA : KVZ_HIP_CX_CBF_LUMA, ctx_cbf = type ? tr_depth : !tr_depth;
-    best_cost = block_uncoded_cost + c.lambda * c.price(cbf0 + ctx_cbf, 0);
-    base_cost += c.lambda * c.price(cbf0 + ctx_cbf, 1);
+    // luma: qt_cbf_model_luma[!tr_depth]; chroma: qt_cbf_model_chroma[tr_depth] (rdo.c:907-915) -- entries 2..3 of the latter (the blocks of an NxN CU come
+    // with tr_depth 2, quant-generic.c:237-238) sit behind the other contexts in the KVZ_HIP_CX_* layout
+    const int ctx_cbf = type == 0 ? KVZ_HIP_CX_CBF_LUMA + !tr_depth : (tr_depth < 2 ? KVZ_HIP_CX_CBF_CHROMA + tr_depth : KVZ_HIP_CX_CBF_CHROMA_DEEP + imin(tr_depth, 3) - 2);
+    best_cost = block_uncoded_cost + c.lambda * c.price(ctx_cbf, 0);
+    base_cost += c.lambda * c.price(ctx_cbf, 1);
   }
   for (int cgs = cg_last_scanpos; cgs >= 0; cgs--) {
     const u32 cg_blkpos = sc.cg(cgs);

@@ -572,7 +572,7 @@ static void recon_cu_rel(ctu_t *t, level_t *lv, int x, int y, int depth, int mod
  * (depth 4: cu->depth stays 3, search.c:691) */
 static void recon_cu(ctu_t *t, level_t *lv, int x, int y, int depth, int mode, int do_luma, int do_chroma) { recon_cu_rel(t, lv, x, y, depth, mode, do_luma, do_chroma, depth == 4 ? 2 : 0); }
 
-/* Test hook: the residual coder's bit count on caller-supplied states of the residual contexts (KVZ_HIP_CX_SIG_CG .. KVZ_HIP_CX_COUNT - 1,
+/* Test hook: the residual coder's bit count on caller-supplied states of the residual contexts (KVZ_HIP_CX_SIG_CG .. KVZ_HIP_CX_CBF_CHROMA_DEEP - 1,
  * updated in place when `update`), against the reference's kvz_encode_coeff_nxn (tests/test_oracle_vs_ref.py) */
 double kvz_oracle_coeff_cabac_bits(const float entropy_fbits[128], const int16_t *coeff, int width, int type, int scan_mode, int update, uint8_t *ctx)
 {
@@ -582,9 +582,9 @@ double kvz_oracle_coeff_cabac_bits(const float entropy_fbits[128], const int16_t
   memset(&m, 0, sizeof m);
   memset(&c, 0, sizeof c);
   memcpy(m.entropy_fbits, entropy_fbits, sizeof m.entropy_fbits);
-  memcpy(&c.s[CX_SIG_CG], ctx, CX_COUNT - CX_SIG_CG);
+  memcpy(&c.s[CX_SIG_CG], ctx, KVZ_HIP_CX_CBF_CHROMA_DEEP - CX_SIG_CG);
   const double bits = encode_coeff_nxn(&m, &c, update, coeff, width, type, scan_mode);
-  memcpy(ctx, &c.s[CX_SIG_CG], CX_COUNT - CX_SIG_CG);
+  memcpy(ctx, &c.s[CX_SIG_CG], KVZ_HIP_CX_CBF_CHROMA_DEEP - CX_SIG_CG);
   return bits;
 }
 
@@ -975,6 +975,7 @@ void kvz_oracle_intra_cost_model(int qp, const float entropy_fbits[128], uint64_
     for (int i = 0; i < 8; i++) inits[CX_ONE_CHROMA + i] = init_one[16 + i];
     for (int i = 0; i < 4; i++) inits[CX_ABS_LUMA + i] = init_abs[i];
     for (int i = 0; i < 2; i++) inits[CX_ABS_CHROMA + i] = init_abs[4 + i];
+    inits[KVZ_HIP_CX_CBF_CHROMA_DEEP] = 182; inits[KVZ_HIP_CX_CBF_CHROMA_DEEP + 1] = 154;  /* INIT_QT_CBF[2][6..7], context.c:130-134: qt_cbf_model_chroma[2..3] */
     for (int i = 0; i < CX_COUNT; i++) m->ctx_init[i] = (uint8_t)ctx_state(qp, inits[i]);
     m->ctx_init[KVZ_HIP_CX_SAO_MERGE] = (uint8_t)ctx_state(qp, 153);  /* context.c:38-39, I slice (index 2) */
     m->ctx_init[KVZ_HIP_CX_SAO_TYPE] = (uint8_t)ctx_state(qp, 200);

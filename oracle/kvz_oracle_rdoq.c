@@ -11,7 +11,7 @@
 
 #define ORC_MIN(a, b) ((a) < (b) ? (a) : (b))
 
-typedef struct { const uint8_t *ctx; const uint32_t *bits; double lambda; int cbf_chroma_deep; } rdoq_ctx;
+typedef struct { const uint8_t *ctx; const uint32_t *bits; double lambda; } rdoq_ctx;
 static int32_t price(const rdoq_ctx *c, int idx, int bin) { return (int32_t)c->bits[c->ctx[idx] ^ bin]; }
 
 // rdo.c:345-392 kvz_get_ic_rate
@@ -278,12 +278,11 @@ static void rdoq_block(const rdoq_ctx *c, int qp, const int16_t *coef, int16_t *
   int best_last_idx_p1 = 0;
   int found_last = 0;
   {
-    const int cbf0 = type ? KVZ_HIP_CX_CBF_CHROMA : KVZ_HIP_CX_CBF_LUMA, ctx_cbf = type ? tr_depth : !tr_depth;
-    // The chroma blocks of an NxN CU arrive with tr_depth 2 (quant-generic.c:237-238 adds one for the partition): qt_cbf_model_chroma[2], a context no
-    // syntax of this configuration ever codes, so it still has its slice-start state (c->cbf_chroma_deep)
-    const int deep = type && tr_depth >= 2;
-    best_cost = block_uncoded_cost + c->lambda * (deep ? (int32_t)c->bits[c->cbf_chroma_deep ^ 0] : price(c, cbf0 + ctx_cbf, 0));
-    base_cost += c->lambda * (deep ? (int32_t)c->bits[c->cbf_chroma_deep ^ 1] : price(c, cbf0 + ctx_cbf, 1));
+    /* rdo.c:907-915: qt_cbf_model_luma[!tr_depth] / qt_cbf_model_chroma[tr_depth].  The chroma blocks of an NxN CU arrive with tr_depth 2 (quant-generic.c:237-238
+     * adds one for the partition): qt_cbf_model_chroma[2..3] are KVZ_HIP_CX_CBF_CHROMA_DEEP in the context layout */
+    const int ctx_cbf = type == 0 ? KVZ_HIP_CX_CBF_LUMA + !tr_depth : (tr_depth < 2 ? KVZ_HIP_CX_CBF_CHROMA + tr_depth : KVZ_HIP_CX_CBF_CHROMA_DEEP + (tr_depth > 3 ? 3 : tr_depth) - 2);
+    best_cost = block_uncoded_cost + c->lambda * price(c, ctx_cbf, 0);
+    base_cost += c->lambda * price(c, ctx_cbf, 1);
   }
   for (int cgs = cg_last_scanpos; cgs >= 0; cgs--) {
     const uint32_t cg_blkpos = scan_cg[cgs];
@@ -327,21 +326,13 @@ static void rdoq_block(const rdoq_ctx *c, int qp, const int16_t *coef, int16_t *
 
 
 /* context.c:202-213 kvz_ctx_init: init value + QP -> uc_state */
-static int rdoq_init_state(int qp, int init_value)
-{
-  int slope = (init_value >> 4) * 5 - 45, offset = ((init_value & 15) << 3) - 16;
-  int st = ((slope * qp) >> 4) + offset;
-  st = st < 1 ? 1 : st > 126 ? 126 : st;
-  return st >= 64 ? ((st - 64) << 1) + 1 : (63 - st) << 1;
-}
-
 /* Q15 entropy table (rdo.c:69-80 kvz_entropy_bits), regenerated from the float table the model carries: entropy_fbits[i] * 32768 is exact */
 void kvz_oracle_rdoq(int qp, double lambda, const uint8_t *ctx_states, const float *entropy_fbits, const int16_t *coef, int16_t *dest, int width, int type,
                      int scan_mode, int tr_depth)
 {
   uint32_t bits[128];
   for (int i = 0; i < 128; i++) bits[i] = (uint32_t)(entropy_fbits[i] * 32768.0f);
-  rdoq_ctx c = { ctx_states, bits, lambda, rdoq_init_state(qp, tr_depth >= 3 ? 154 : 182) /* INIT_QT_CBF[2][6..7], context.c:130-134 */ };
+  rdoq_ctx c = { ctx_states, bits, lambda };
   int log2w = 2;
   while ((1 << log2w) < width) log2w++;
   double *cost3 = malloc(sizeof(double) * 3 * width * width);

@@ -158,8 +158,7 @@ void kvz_ref_rdoq(int qp, double lambda, const uint8_t *ctx, const float *entrop
 #define SETCTX(dst, from, n) for (int i_ = 0; i_ < (n); i_++) (dst)[i_].uc_state = ctx[(from) + i_]
   SETCTX(cb->ctx.qt_cbf_model_luma, KVZ_HIP_CX_CBF_LUMA, 2);
   SETCTX(cb->ctx.qt_cbf_model_chroma, KVZ_HIP_CX_CBF_CHROMA, 2);
-  kvz_ctx_init(&cb->ctx.qt_cbf_model_chroma[2], qp, 182);  /* never coded in these configurations: slice-start state (context.c:130-134, I slice); read by the blocks of an NxN CU (tr_depth 2) */
-  kvz_ctx_init(&cb->ctx.qt_cbf_model_chroma[3], qp, 154);
+  SETCTX(&cb->ctx.qt_cbf_model_chroma[2], KVZ_HIP_CX_CBF_CHROMA_DEEP, 2);  /* read by the blocks of an NxN CU (tr_depth 2) */
   SETCTX(cb->ctx.cu_sig_coeff_group_model, KVZ_HIP_CX_SIG_CG, 4);
   SETCTX(cb->ctx.cu_sig_model_luma, KVZ_HIP_CX_SIG_LUMA, 27);
   SETCTX(cb->ctx.cu_sig_model_chroma, KVZ_HIP_CX_SIG_CHROMA, 15);

@@ -110,7 +110,7 @@ def test_hostsim_rdoq_equals_oracle(oracle, hostsim):
     fo.restype = fh.restype = None
     fo.argtypes = fh.argtypes = RDOQ_ARGS
     fb = _fbits()
-    cases = rdoq_cases()
+    cases = rdoq_cases() + rdoq_cases_nxn()  # the latter: tr_depth 2, chroma coded-block flag priced on qt_cbf_model_chroma[2]
     bad = [i for i, c in enumerate(cases) if run_rdoq(fo, fb, c) != run_rdoq(fh, fb, c)]
     assert not bad, f"{len(bad)}/{len(cases)} blocks differ: {[(cases[i][0], cases[i][4], cases[i][5], cases[i][6]) for i in bad[:8]]}"
 
@@ -124,7 +124,7 @@ def test_hip_rdoq_equals_oracle(oracle):
     fo.restype = fh.restype = None
     fo.argtypes = fh.argtypes = RDOQ_ARGS
     fb = _fbits()
-    cases = rdoq_cases(6)
+    cases = rdoq_cases(6) + rdoq_cases_nxn(24)
     want = [run_rdoq(fo, fb, c) for c in cases]
     assert [run_rdoq(fh, fb, c) for c in cases] == want
     lib.kvz_hip_rdoq_blocks.restype = None
@@ -132,8 +132,8 @@ def test_hip_rdoq_equals_oracle(oracle):
     # batches share qp / lambda / contexts / shape: re-run groups of cases with the first member's parameters
     by_shape = {}
     for c in cases:
-        by_shape.setdefault((c[4], c[5], c[6]), []).append(c)
-    for (w, typ, scan), group in by_shape.items():
+        by_shape.setdefault((c[4], c[5], c[6], c[7] >= 2), []).append(c)
+    for (w, typ, scan, _), group in by_shape.items():
         qp, lam, ctx, _, _, _, _, trd = group[0]
         coef = A(np.concatenate([g[3] for g in group]))
         dest = A(np.full(coef.size, 77, np.int16))
