@@ -162,9 +162,10 @@ def cpu_baseline(args, frames, model):
     if not os.path.exists(ref_bin) or args.no_ref_encoder:
         return port
     import tempfile
-    threads = os.cpu_count() or 1
+    host = host_cpu_facts()
+    threads = host["schedulable_cpus"]
     with tempfile.NamedTemporaryFile(suffix=".yuv", dir="/tmp") as tmp:
-        nf = 128  # frames in the file: the benchmark's distinct frames, cycled
+        nf = 128  # frames in the file: the benchmark's distinct frames, cycled (the long legs re-read it with --loop-input)
         for i in range(nf):
             tmp.write(frames[i % len(frames)].tobytes())
         tmp.flush()
@@ -178,33 +179,82 @@ def cpu_baseline(args, frames, model):
             return sorted(ts)[len(ts) // 2] if ts else None
 
         legs = {}
-        s = median_of(["--threads", str(threads)], nf, 3)
-        if s:
-            legs["avx2_one_process_all_threads"] = {"value": nf * ctus_pf / s, "cores": threads, "sample": f"{nf} frames, --threads {threads}, median of 3, wall incl. start-up and file read ({s:.2f} s)"}
-        procs = max(1, threads // 16)
-        nsat = nf // 2  # ~10 s of host time on a 256-thread box
-        t = time.time()
-        ps = [subprocess.Popen([ref_bin, "-i", tmp.name, "--input-res", f"{w}x{h}"] + PRESET_CLI[args.preset] + ["-p", "1", "-q", str(args.qp), "-n", str(nsat),
-                                "--threads", "16", "-o", "/dev/null"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for _ in range(procs)]
-        ok = all(p.wait() == 0 for p in ps)
-        s = time.time() - t
-        if ok:
-            legs["avx2_saturated"] = {"value": procs * nsat * ctus_pf / s, "cores": threads,
-                                      "sample": f"{procs} concurrent encoders x --threads 16 x {nsat} frames each, wall {s:.2f} s"}
         n1 = 8 if w * h <= 1920 * 1080 else 2
-        s = median_of(["--threads", "0", "--owf", "0"], n1, 1)
-        if s:
-            legs["avx2_1_thread"] = {"value": n1 * ctus_pf / s, "cores": 1, "sample": f"{n1} frames, --threads 0 --owf 0 ({s:.2f} s)"}
+        s1 = median_of(["--threads", "0", "--owf", "0"], n1, 1)
+        if s1:
+            legs["avx2_1_thread"] = {"value": n1 * ctus_pf / s1, "cores": 1, "sample": f"{n1} frames, --threads 0 --owf 0 ({s1:.2f} s)"}
         s = median_of(["--no-cpuid", "--threads", "0", "--owf", "0"], n1, 1)
         if s:
             legs["generic_1_thread"] = {"value": n1 * ctus_pf / s, "cores": 1, "sample": f"{n1} frames, --no-cpuid --threads 0 --owf 0 ({s:.2f} s)"}
-    multi = [k for k in ("avx2_saturated", "avx2_one_process_all_threads") if k in legs]
+        # one process on every schedulable CPU: long enough (>= 600 frames at 1080p) that start-up and the first file read are a few per cent
+        n_long = max(nf, min(640, int(640 * (1920 * 1080) / (w * h))))
+        s = median_of(["--threads", str(threads), "--loop-input"], n_long, 1 if n_long > 256 else 3)
+        if s:
+            legs["avx2_one_process_all_threads"] = {"value": n_long * ctus_pf / s, "cores": threads,
+                                                    "sample": f"{n_long} frames (--loop-input over the {nf}-frame file), --threads {threads}, wall incl. start-up and file read ({s:.2f} s)"}
+        # N independent single-thread encoders, N = schedulable CPUs: no thread queue, no output-order coupling -- what the host's cores can do at best
+        # (frames per encoder bounded so that the leg takes ~15 s even if the box turns out to schedule far fewer CPUs than it lists)
+        fps_known = max([legs[k]["value"] / ctus_pf for k in legs] or [1.0])
+        n_ind = max(4, min(32, int(15.0 * 1.5 * fps_known / threads)))
+        t = time.time()
+        ps = [subprocess.Popen([ref_bin, "-i", tmp.name, "--input-res", f"{w}x{h}"] + PRESET_CLI[args.preset] + ["-p", "1", "-q", str(args.qp), "-n", str(n_ind),
+                                "--threads", "0", "--owf", "0", "-o", "/dev/null"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for _ in range(threads)]
+        ok = all(p.wait() == 0 for p in ps)
+        s = time.time() - t
+        if ok:
+            legs["avx2_independent_1thread_xN"] = {"value": threads * n_ind * ctus_pf / s, "cores": threads,
+                                                   "sample": f"{threads} concurrent encoders x --threads 0 --owf 0 x {n_ind} frames each, wall of the slowest {s:.2f} s"}
+        if threads >= 32:
+            procs = threads // 16
+            nsat = nf // 2
+            t = time.time()
+            ps = [subprocess.Popen([ref_bin, "-i", tmp.name, "--input-res", f"{w}x{h}"] + PRESET_CLI[args.preset] + ["-p", "1", "-q", str(args.qp), "-n", str(nsat),
+                                    "--threads", "16", "-o", "/dev/null"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for _ in range(procs)]
+            ok = all(p.wait() == 0 for p in ps)
+            s = time.time() - t
+            if ok:
+                legs["avx2_saturated"] = {"value": procs * nsat * ctus_pf / s, "cores": threads,
+                                          "sample": f"{procs} concurrent encoders x --threads 16 x {nsat} frames each, wall {s:.2f} s"}
+    multi = [k for k in ("avx2_independent_1thread_xN", "avx2_saturated", "avx2_one_process_all_threads") if k in legs]
     if not multi:
         return port
     best = max(multi, key=lambda k: legs[k]["value"])
+    eff = None
+    if "avx2_1_thread" in legs:
+        eff = legs[best]["value"] / legs["avx2_1_thread"]["value"]  # how many single-thread encoders' worth the best multi-core leg reaches
     return {"value": legs[best]["value"], "unit": "CTUs/s", "cores": legs[best]["cores"], "kind": "reference",
             "sample": f"oracle/_ref/kvazaar_ref (kvazaar's AVX2 strategies, whole encoder incl. CABAC + deblocking) {' '.join(PRESET_CLI[args.preset])} -p 1 -q {args.qp}; best of the multi-core legs = "
-                      f"{best}: {legs[best]['sample']}", "legs": legs, "port": port}
+                      f"{best}: {legs[best]['sample']}", "legs": legs, "port": port, "host": host, "single_thread_equivalents": eff}
+
+
+def host_cpu_facts():
+    """what this process may actually run on: the affinity mask, the cgroup CPU quota, the load when the baseline starts -- `cores` of the
+    baseline legs is the schedulable count, not os.cpu_count()"""
+    facts = {"os_cpu_count": os.cpu_count(), "sched_getaffinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+        except OSError:
+            continue
+        facts["cgroup_" + os.path.basename(path)] = " ".join(txt)
+        if path.endswith("cpu.max") and txt and txt[0] != "max":
+            quota = float(txt[0]) / float(txt[1])
+        elif path.endswith("cfs_quota_us") and txt and int(txt[0]) > 0:
+            try:
+                quota = int(txt[0]) / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            except (OSError, ValueError):
+                pass
+    facts["cgroup_cpu_quota"] = quota
+    try:
+        facts["loadavg_1min"] = os.getloadavg()[0]
+    except OSError:
+        pass
+    n = facts["sched_getaffinity"] or facts["os_cpu_count"] or 1
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    facts["schedulable_cpus"] = n
+    return facts
 
 
 def exchange_leg(dist, torch, rank, world, reps=20):

@@ -41,6 +41,11 @@ void kvz_hip_batch_upload(kvz_hip_batch *b, int frame, const uint8_t *y, const u
 int  kvz_hip_batch_download(kvz_hip_batch *b, int frame, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, int16_t *coeff,
                             uint8_t *cu_depth, uint8_t *cu_mode, double *ctu_cost);
 
+/* After a pass with model.search_nxn: cu_part, one byte per 8x8 block (raster, stride width/8): 1 = the CU is coded as four 4x4 prediction units (part_size NxN);
+ * cu_mode4, the luma mode of every 4x4 unit (raster, stride width/4; four equal entries for a 2Nx2N CU -- cu_mode of kvz_hip_batch_download holds the first PU's).
+ * Either may be NULL.  Returns 0, or -1 when the run was invalid or no such pass has run on the batch. */
+int  kvz_hip_batch_download_partitions(kvz_hip_batch *b, int frame, uint8_t *cu_part, uint8_t *cu_mode4);
+
 /* Pinned host memory (hipHostMalloc) for the asynchronous transfers below; plain malloc'ed buffers work too but serialise. */
 void *kvz_hip_host_alloc(size_t bytes);
 void  kvz_hip_host_free(void *p);
@@ -60,7 +65,8 @@ void kvz_hip_batch_order_after(kvz_hip_batch *b, kvz_hip_batch *other);
 
 /* The hot path: search + reconstruct every CTU of every frame in the batch.  Asynchronous on the batch's stream;
  * kvz_hip_batch_sync() waits.  Returns the number of kernel launches issued (1; one per CTU anti-diagonal with the older
- * schedule behind KVZ_HIP_SCHED=wave). */
+ * schedule behind KVZ_HIP_SCHED=wave), or -1 -- with a message on stderr and nothing launched -- for a model the batch cannot run (rdoq without coeff_cabac;
+ * search_32x32 / rdoq / search_nxn / no_wpp under KVZ_HIP_SCHED=wave). */
 int  kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model);
 /* Waits for the batch's stream.  Returns 0, or -1 when a CTU hand-off wait inside a pass timed out (workgroups wait for their
  * neighbours' results with a wall-clock bound -- 30 s per wait, KVZ_HIP_WAIT_MS overrides -- so that a lost hand-off cannot hang

@@ -131,7 +131,7 @@ typedef struct kvz_hip_intra_cost_model {
   int32_t  rdoq;
   /* != 0: 8x8 CUs are also tried as four 4x4 prediction units (part_size NxN: kvazaar's --pu-depth-intra ..-4, preset `medium`) -- one more level of search_cu's
    * recursion (search.c:691, 794, 970-974): each PU with its own rough search, DST, reconstruction and most probable modes at 4x4 granularity, chroma once per CU
-   * under the first PU's mode.  ORACLE ONLY so far (oracle/kvz_oracle_ctu.c, pinned against `kvazaar --preset medium`): the device pass rejects a model with it set. */
+   * under the first PU's mode.  Results: kvz_hip_batch_download_partitions (cu_mode keeps the first PU's mode). */
   int32_t  search_nxn;
   uint8_t  ctx_init[160];     /* uc_state at slice start (kvz_init_contexts, context.c:202-305) of the KVZ_HIP_CX_* contexts; the rest unused */
   float    entropy_fbits[128];/* kvz_f_entropy_bits (rdo.c:69-83) */

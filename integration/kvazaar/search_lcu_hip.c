@@ -39,6 +39,7 @@ typedef struct {
   int width, height, qp;
   uint8_t *src;                /* the source picture as tight planes Y|U|V (pinned), filled by the thread that registered the picture */
   uint8_t *rec, *depth, *mode; /* tight planes Y|U|V; one byte per 8x8 (pinned) */
+  uint8_t *part, *mode4;       /* model.search_nxn: NxN flag per 8x8 CU, luma mode per 4x4 unit */
   int16_t *coeff;              /* KVZ_HIP_CTU_COEFFS per LCU, raster LCU order */
   kvz_hip_intra_cost_model model;
   int state;                   /* FREE -> PENDING (registered, waiting for a pass) -> COMPUTING (in the leader's batch) -> READY */
@@ -80,7 +81,8 @@ static int eligible(const encoder_state_t *state)
   REQUIRE(!cfg->rdoq_enable || (!cfg->rdoq_skip && !(state->qp < cfg->fast_residual_cost_limit && state->qp < MAX_FAST_COEFF_COST_QP)));
   REQUIRE(!cfg->lossless && !cfg->implicit_rdpcm && cfg->scaling_list == KVZ_SCALING_LIST_OFF);
   REQUIRE(!cfg->full_intra_search);
-  REQUIRE((cfg->pu_depth_intra.min[0] == 2 || cfg->pu_depth_intra.min[0] == 1) && cfg->pu_depth_intra.max[0] == 3);  /* all-intra: GOP layer 0 only; 1-3 = preset `fast` */
+  /* all-intra: GOP layer 0 only; 1-3 = preset `fast`, 1-4 = `medium` (8x8 CUs also tried as four 4x4 PUs) */
+  REQUIRE((cfg->pu_depth_intra.min[0] == 2 || cfg->pu_depth_intra.min[0] == 1) && (cfg->pu_depth_intra.max[0] == 3 || cfg->pu_depth_intra.max[0] == 4));
   REQUIRE(cfg->cu_split_termination == KVZ_CU_SPLIT_TERMINATION_ZERO && cfg->combine_intra_cus);
   REQUIRE(cfg->target_bitrate <= 0 && !cfg->vaq && !cfg->roi.file_path && !cfg->set_qp_in_cu && state->frame->max_qp_delta_depth < 0);
   REQUIRE(!cfg->ml_pu_depth_intra && !cfg->intra_bit_allocation);
@@ -112,12 +114,13 @@ static void run_pictures(picture_result **list, int n)
   kvz_hip_batch *b = g_batches[bi];
   /* slots beyond n keep whatever picture they held last: searched again, never read */
   for (int i = 0; i < n; i++) kvz_hip_batch_upload(b, i, list[i]->src, list[i]->src + ys, list[i]->src + ys + cs);
-  kvz_hip_intra_frames(b, &list[0]->model);
+  if (kvz_hip_intra_frames(b, &list[0]->model) < 0) { fprintf(stderr, "search_lcu_hip: the library cannot run this model\n"); abort(); }
   /* the library reports an invalid run instead of aborting; this binding has no other search to fall back to for pictures whose
    * LCUs are already being handed out, so it stops the encoder */
   int bad = kvz_hip_batch_sync(b) != 0;
   for (int i = 0; i < n && !bad; i++)
     bad = kvz_hip_batch_download(b, i, list[i]->rec, list[i]->rec + ys, list[i]->rec + ys + cs, list[i]->coeff, list[i]->depth, list[i]->mode, NULL) != 0;
+  for (int i = 0; i < n && !bad && list[0]->model.search_nxn; i++) bad = kvz_hip_batch_download_partitions(b, i, list[i]->part, list[i]->mode4) != 0;
   if (bad) { fprintf(stderr, "search_lcu_hip: the device pass failed\n"); abort(); }
   {  /* KVZ_HIP_BATCH_TRACE=<file>: "pictures passes largest-batch" so far (tests check the path was taken, and that pictures were gathered) */
     static int pictures, passes, largest;
@@ -140,13 +143,19 @@ static picture_result *picture_of(const encoder_state_t *state)
     for (int i = 0; i < g_n_slots && !r; i++)
       if (g_slots[i]->outstanding == 0) r = g_slots[i];
     if (!r) {
-      g_slots = realloc(g_slots, (size_t)(g_n_slots + 1) * sizeof *g_slots);
-      r = g_slots[g_n_slots++] = calloc(1, sizeof *r);
+      picture_result **grown = realloc(g_slots, (size_t)(g_n_slots + 1) * sizeof *g_slots);
+      r = grown ? calloc(1, sizeof *r) : NULL;
+      if (!r) { fprintf(stderr, "search_lcu_hip: out of memory\n"); abort(); }
+      g_slots = grown;
+      g_slots[g_n_slots++] = r;
     }
     const int w = frame->width, h = frame->height, wc = (w + 63) / 64, hc = (h + 63) / 64;
     const size_t ys = (size_t)w * h, cs = ys / 4;
     if (r->width != w || r->height != h) {  /* pinned: the transfers of a 64-picture batch are 800 MB */
       kvz_hip_host_free(r->src); kvz_hip_host_free(r->rec); kvz_hip_host_free(r->depth); kvz_hip_host_free(r->mode); kvz_hip_host_free(r->coeff);
+      kvz_hip_host_free(r->part); kvz_hip_host_free(r->mode4);
+      r->part = kvz_hip_host_alloc((size_t)(w / 8) * (h / 8));
+      r->mode4 = kvz_hip_host_alloc((size_t)(w / 4) * (h / 4));
       r->src = kvz_hip_host_alloc(ys + 2 * cs);
       r->rec = kvz_hip_host_alloc(ys + 2 * cs);
       r->depth = kvz_hip_host_alloc((size_t)(w / 8) * (h / 8));
@@ -162,6 +171,7 @@ static picture_result *picture_of(const encoder_state_t *state)
     r->model.coeff_cabac = !(state->qp < cfg->fast_residual_cost_limit && state->qp < MAX_FAST_COEFF_COST_QP);  /* rdo.c:311-340 */
     r->model.search_32x32 = cfg->pu_depth_intra.min[0] == 1;  /* 32x32 CUs are searched, not only merged (search.c:794) */
     r->model.rdoq = cfg->rdoq_enable != 0;
+    r->model.search_nxn = cfg->pu_depth_intra.max[0] == 4;  /* depth 4 of search_cu: the NxN partition of 8x8 CUs (search.c:691, 794) */
     r->model.no_wpp = !cfg->wpp;  /* kvazaar switches WPP off when tiles are used (cfg.c:925-978) */
     /* kvz_picture planes carry a stride; the batch takes tight planes.  (Outside the lock: only this thread knows the slot is being filled --
      * nobody gathers a slot before it is PENDING ... so mark it pending only afterwards.) */
@@ -248,6 +258,23 @@ void __wrap_kvz_search_lcu(encoder_state_t *const state, const int x, const int 
   for (int yy = 0; yy < 64 && y + yy < h; yy += 8)
     for (int xx = 0; xx < 64 && x + xx < w; xx += 8) {
       const int depth = r->depth[((y + yy) / 8) * w8 + (x + xx) / 8], mode = r->mode[((y + yy) / 8) * w8 + (x + xx) / 8];
+      if (r->model.search_nxn && r->part[((y + yy) / 8) * w8 + (x + xx) / 8]) {
+        /* an NxN CU (search.c:691-700, 794-800): four 4x4 PUs with a mode and a luma transform block each (tr_depth 4), the 4x4 chroma blocks with the first
+         * PU (transform.c:306-312); coded block flags at depth 4 on the unit that owns the block */
+        for (int j = 0; j < 4; j++) {
+          const int sx = 4 * (j & 1), sy = 4 * (j >> 1), pm = r->mode4[((y + yy + sy) / 4) * (w / 4) + (x + xx + sx) / 4];
+          cu_info_t *cu = kvz_cu_array_at(frame->cu_array, x + xx + sx, y + yy + sy);
+          memset(cu, 0, sizeof *cu);
+          cu->type = CU_INTRA; cu->depth = 3; cu->part_size = SIZE_NxN; cu->tr_depth = 4; cu->qp = (uint8_t)state->qp;
+          cu->intra.mode = (int8_t)pm; cu->intra.mode_chroma = (int8_t)pm;
+          if (any_level(plane[0] + zorder16(xx + sx, yy + sy), 16)) cbf_set(&cu->cbf, 4, COLOR_Y);
+          if (j == 0) {
+            if (any_level(plane[1] + zorder16(xx / 2, yy / 2), 16)) cbf_set(&cu->cbf, 4, COLOR_U);
+            if (any_level(plane[2] + zorder16(xx / 2, yy / 2), 16)) cbf_set(&cu->cbf, 4, COLOR_V);
+          }
+        }
+        continue;
+      }
       const int td = depth < 1 ? 1 : depth, tw = 64 >> td, tx = xx & ~(tw - 1), ty = yy & ~(tw - 1), cw = td == 3 ? 4 : tw / 2;
       uint16_t cbf = 0;
       for (int c = 0; c < 3; c++) {

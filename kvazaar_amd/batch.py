@@ -99,6 +99,8 @@ class HipBatch:
 
     def run(self, model):
         n = self.launch(model)
+        if n < 0:
+            raise BatchError("kvz_hip_intra_frames: the batch cannot run this model (see stderr)")
         self.sync()
         return n
 
@@ -154,6 +156,15 @@ class HipBatch:
         if rc != 0:
             raise BatchError("kvz_hip_batch_download: the batch's last pass was invalid")
         return o
+
+    def download_partitions(self, frame):
+        """after a pass with model.search_nxn: (NxN flag per 8x8 CU, luma mode per 4x4 unit)"""
+        part, mode4 = np.zeros((self.h // 8) * (self.w // 8), np.uint8), np.zeros((self.h // 4) * (self.w // 4), np.uint8)
+        self.lib.kvz_hip_batch_download_partitions.argtypes = [C.c_void_p, C.c_int, u8p, u8p]
+        self.lib.kvz_hip_batch_download_partitions.restype = C.c_int
+        if self.lib.kvz_hip_batch_download_partitions(self.handle, frame, ptr(part), ptr(mode4)) != 0:
+            raise BatchError("kvz_hip_batch_download_partitions: invalid pass, or no pass with search_nxn has run")
+        return part, mode4
 
     def close(self):
         if self.handle:

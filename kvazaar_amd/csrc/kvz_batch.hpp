@@ -141,6 +141,7 @@ struct kvz_hip_batch {
   hipStream_t stream;
   hipEvent_t ev0, ev1;
   uint8_t *d_src, *d_rec, *d_depth, *d_mode;
+  uint8_t *d_part, *d_mode4;  // search_nxn: NxN flag per 8x8 CU, luma mode per 4x4 unit (allocated with the first model that has it set)
   int16_t *d_coeff, *d_scratch;
   double *d_cost;
   uint8_t *d_border;
@@ -356,7 +357,7 @@ void kvz_hip_batch_destroy(kvz_hip_batch *b)
   (void)hipStreamSynchronize(b->stream);
   (void)hipFree(b->d_ver); (void)hipFree(b->d_dbk); (void)hipFree(b->d_sao_merge); (void)hipFree(b->d_sao_stats); (void)hipFree(b->d_sao_cand); (void)hipFree(b->d_sao_recs); (void)hipFree(b->d_sao_fbits);
   (void)hipFree(b->d_border); (void)hipFree(b->d_items); (void)hipFree(b->d_items_raster); (void)hipFree(b->d_done); (void)hipFree(b->d_ticket); (void)hipFree(b->d_prof); (void)hipFree(b->d_entropy); (void)hipFree(b->d_rdoq);
-  (void)hipFree(b->d_src); (void)hipFree(b->d_rec); (void)hipFree(b->d_coeff); (void)hipFree(b->d_scratch); (void)hipFree(b->d_depth); (void)hipFree(b->d_mode); (void)hipFree(b->d_cost);
+  (void)hipFree(b->d_src); (void)hipFree(b->d_rec); (void)hipFree(b->d_coeff); (void)hipFree(b->d_scratch); (void)hipFree(b->d_depth); (void)hipFree(b->d_mode); (void)hipFree(b->d_cost); (void)hipFree(b->d_part); (void)hipFree(b->d_mode4);
   (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1);
   (void)hipStreamDestroy(b->stream);
   delete b;
@@ -390,6 +391,18 @@ int kvz_hip_batch_download(kvz_hip_batch *b, int frame, uint8_t *rec_y, uint8_t 
   if (cu_depth) KVZ_HIP_CHECK(hipMemcpy(cu_depth, b->d_depth + frame * ncu, ncu, hipMemcpyDeviceToHost));
   if (cu_mode) KVZ_HIP_CHECK(hipMemcpy(cu_mode, b->d_mode + frame * ncu, ncu, hipMemcpyDeviceToHost));
   if (ctu_cost) KVZ_HIP_CHECK(hipMemcpy(ctu_cost, b->d_cost + frame * nctu, nctu * sizeof(double), hipMemcpyDeviceToHost));
+  return kvz::batch_check(b);
+}
+
+int kvz_hip_batch_download_partitions(kvz_hip_batch *b, int frame, uint8_t *cu_part, uint8_t *cu_mode4)
+{
+  kvz::batch_enter(b);
+  const kvz::CtuFrames &F = b->F;
+  const long ncu = (long)(F.W / 8) * (F.H / 8), n4 = (long)(F.W / 4) * (F.H / 4);
+  KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+  if (!b->d_part) { fprintf(stderr, "kvz_hip_batch_download_partitions: no pass with model.search_nxn has run on this batch\n"); return -1; }
+  if (cu_part) KVZ_HIP_CHECK(hipMemcpy(cu_part, b->d_part + frame * ncu, ncu, hipMemcpyDeviceToHost));
+  if (cu_mode4) KVZ_HIP_CHECK(hipMemcpy(cu_mode4, b->d_mode4 + frame * n4, n4, hipMemcpyDeviceToHost));
   return kvz::batch_check(b);
 }
 
@@ -434,9 +447,10 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
   cm.ctx_init = (const uint8_t *)(b->d_entropy + 128);
   KVZ_HIP_CHECK(hipMemcpyAsync(b->d_entropy, model->entropy_fbits, 128 * sizeof(float), hipMemcpyHostToDevice, b->stream));
   KVZ_HIP_CHECK(hipMemcpyAsync(b->d_entropy + 128, model->ctx_init, sizeof model->ctx_init, hipMemcpyHostToDevice, b->stream));
-  if (model->search_nxn) { fprintf(stderr, "kvz_hip_intra_frames: search_nxn (4x4 NxN partitions, --pu-depth-intra ..-4) is not on the device yet\n"); abort(); }
-  if (!b->sched_ticket && (cm.search_32x32 || cm.rdoq)) { fprintf(stderr, "kvz_hip_intra_frames: search_32x32 / rdoq need the ticket schedule\n"); abort(); }
-  if (!b->sched_ticket && cm.no_wpp) { fprintf(stderr, "kvz_hip_intra_frames: the one-launch-per-diagonal schedule (KVZ_HIP_SCHED=wave) needs WPP\n"); abort(); }
+  // argument errors are reported, not fatal (a HIP failure still aborts: there is no error channel for it and no CPU path to fall back to)
+  if (!b->sched_ticket && (cm.search_32x32 || cm.rdoq || cm.search_nxn)) { fprintf(stderr, "kvz_hip_intra_frames: search_32x32 / rdoq / search_nxn need the ticket schedule\n"); return -1; }
+  if (!b->sched_ticket && cm.no_wpp) { fprintf(stderr, "kvz_hip_intra_frames: the one-launch-per-diagonal schedule (KVZ_HIP_SCHED=wave) needs WPP\n"); return -1; }
+  if (cm.rdoq && !cm.coeff_cabac) { fprintf(stderr, "kvz_hip_intra_frames: rdoq needs coeff_cabac (kvazaar's presets with --rdoq have --fast-residual-cost 0)\n"); return -1; }
   if (b->sched_ticket) {
     b->epoch++;
     KVZ_HIP_CHECK(hipMemsetAsync(b->d_ticket, 0, sizeof(unsigned), b->stream));  // the error word behind it stays: sticky across runs
@@ -444,11 +458,15 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
     kvz::CtuSched sc{ cm.no_wpp ? b->d_items_raster : b->d_items, b->d_ticket, b->d_done, b->d_error, b->total_items, b->epoch, cm.no_wpp, b->wait_ticks };
     // two instantiations: the one without the CABAC coefficient model carries none of its code, registers or context storage
     // (the instantiations that search 32x32 CUs, --pu-depth-intra 1-3, are separate ones too: the others stay as they were)
-    if (cm.rdoq) {  // --rdoq (preset `medium`): its own instantiation (CABAC cost model, 32x32 search compiled in and switched by the model)
-      if (!cm.coeff_cabac) { fprintf(stderr, "kvz_hip_intra_frames: rdoq needs coeff_cabac (kvazaar's presets with --rdoq have --fast-residual-cost 0)\n"); abort(); }
-      if (!b->d_rdoq) KVZ_HIP_CHECK(hipMalloc((void **)&b->d_rdoq, (size_t)b->grid_ticket * 3 * 3 * 1024 * sizeof(double)));
+    if (cm.rdoq || cm.search_nxn) {  // --rdoq and / or NxN partitions (preset `medium`): their own instantiation (32x32 search and the coefficient cost model switched by the model)
+      if (cm.rdoq && !b->d_rdoq) KVZ_HIP_CHECK(hipMalloc((void **)&b->d_rdoq, (size_t)b->grid_ticket * 3 * 3 * 1024 * sizeof(double)));
+      if (cm.search_nxn && !b->d_part) {
+        KVZ_HIP_CHECK(hipMalloc((void **)&b->d_part, (size_t)(F.W / 8) * (F.H / 8) * b->n_frames));
+        KVZ_HIP_CHECK(hipMalloc((void **)&b->d_mode4, (size_t)(F.W / 4) * (F.H / 4) * b->n_frames));
+      }
       kvz::CtuFrames Fr = F;
       Fr.rdoq_scratch = b->d_rdoq;
+      Fr.cu_part = b->d_part; Fr.cu_mode4 = b->d_mode4;
       hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel_rdoq, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, Fr, cm, kvz::device_tables(), sc);
     } else if (cm.search_32x32) {
       if (cm.coeff_cabac) hipLaunchKernelGGL((kvz::intra_ctu_ticket_kernel<true, true>), dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);

@@ -136,7 +136,9 @@ KVZ_DEV u8 load_shared_byte(const u8 *p)
 #endif
 }
 
-struct CtuCu { u8 type : 1, depth : 2, tr_depth : 2; u8 mode; uint16_t cbf; };  // one per 8x8 (min CU), 4 bytes: 4 levels x 64 of them live in LDS
+// One per 8x8 (min CU), 4 bytes: 4 levels x 64 of them live in LDS.  tr_depth 4 marks an NxN CU (four 4x4 PUs, search.c:691): `mode` is then its first PU's,
+// all four are in NxnLds::mode4, and `cbf` holds bits of its own: bit j (0..3) = PU j has luma levels, bits 5 / 10 = the 4x4 U / V block has (see nxn_attempt()).
+struct CtuCu { u8 type : 1, depth : 2, tr_depth : 3; u8 mode; uint16_t cbf; };
 
 // The CABAC contexts the all-intra search prices syntax with (cabac.h:63-100; indices: KVZ_HIP_CX_* of kvz_hip_types.h), each as
 // kvazaar's uc_state = state << 1 | MPS: ten for the CU / transform-tree syntax, then the residual-coding ones, which only move
@@ -152,14 +154,15 @@ template <bool CABAC> struct CtxSetT { alignas(4) u8 s[CABAC ? 148 : 12]; };
 struct CtuModel {
   double lambda, lambda_sqrt;
   uint64_t coeff_weights;
-  int qp, adaptive, coeff_cabac, no_wpp, search_32x32, rdoq;
+  int qp;
+  u8 adaptive, coeff_cabac, no_wpp, search_32x32, rdoq, search_nxn;  // switches (bytes: the struct lives in LDS next to a block that is sized to the last word)
   const float *entropy_fbits;  // [128]
   const u8 *ctx_init;          // [KVZ_CX_COUNT]
 };
 KVZ_HD void ctu_model_from(const kvz_hip_intra_cost_model *src, CtuModel *dst)
 {
-  dst->lambda = src->lambda; dst->lambda_sqrt = src->lambda_sqrt; dst->coeff_weights = src->coeff_weights; dst->qp = src->qp; dst->adaptive = src->adaptive;
-  dst->coeff_cabac = src->coeff_cabac; dst->no_wpp = src->no_wpp; dst->search_32x32 = src->search_32x32; dst->rdoq = src->rdoq;
+  dst->lambda = src->lambda; dst->lambda_sqrt = src->lambda_sqrt; dst->coeff_weights = src->coeff_weights; dst->qp = src->qp; dst->adaptive = src->adaptive != 0;
+  dst->coeff_cabac = src->coeff_cabac != 0; dst->no_wpp = src->no_wpp != 0; dst->search_32x32 = src->search_32x32 != 0; dst->rdoq = src->rdoq != 0; dst->search_nxn = src->search_nxn != 0;
   dst->entropy_fbits = src->entropy_fbits;
   dst->ctx_init = src->ctx_init;
 }
@@ -173,13 +176,16 @@ struct CtuFrames {
   i16 *coeff;                // [frames][ctu][6144]
   i16 *coeff_scratch;        // [frames][ctu][3 levels][6144]  (work-tree levels 1..3)
   u8 *cu_depth, *cu_mode;    // [frames][(H/8)*(W/8)]
+  u8 *cu_part = nullptr;     // [frames][(H/8)*(W/8)]: 1 = the 8x8 CU is coded as four 4x4 PUs (model.search_nxn; may be null)
+  u8 *cu_mode4 = nullptr;    // [frames][(H/4)*(W/4)]: luma mode per 4x4 (model.search_nxn; may be null); cu_mode keeps the first PU's
   double *ctu_cost;          // [frames][ctu]
   unsigned long long *prof;  // [KVZ_P_COUNT] cycle counters (KVZ_CTU_PROFILE builds only, else unused)
   // What a CTU hands to its right / lower neighbours: KVZ_BORDER_BYTES per CTU = four 128-byte lines with ONE producer each
   //   [0..127]   bottom row   Y 64 | U 32 | V 32        [128..255] right column Y 64 | U 32 | V 32
   //   [256..287] CU info: depth of the bottom 8x8 row [8], mode [8], depth of the right 8x8 column [8], mode [8]
-  //   [288..433] the row's CABAC contexts after this CTU's syntax (KVZ_CX_*): what the CTU to the right starts from, and -- from
+  //   [288..435] the row's CABAC contexts after this CTU's syntax (KVZ_CX_*): what the CTU to the right starts from, and -- from
   //              the second CTU of a row -- the first CTU of the row below (WPP, encoderstate.c:763-771)
+  //   [448..463] (search_nxn) luma mode of the sixteen 4x4 units of the right column: most probable modes are 4x4-granular once CUs can be NxN
   // Neighbour data is exchanged ONLY through these records: the frame-level rec / cu arrays share cache lines between CTUs
   // produced on different XCDs, and a line that is dirty in the reader's L2 cannot be invalidated by its acquire.
   u8 *border;                // [frames][ctu][KVZ_BORDER_BYTES]
@@ -266,8 +272,21 @@ static const int kPlaneOff[3] = { 0, 4096, 5120 };
 // and 12 KB less LDS means more CTUs in flight.)
 struct RdoqLds {
   i32 ptab[2 * 148];
+  // ---- the NxN partition of 8x8 CUs (kvz_hip_intra_cost_model::search_nxn, kvazaar's --pu-depth-intra ..-4): depth 4 of search_cu's recursion (search.c:691, 794,
+  // 970-974).  kvazaar gives it a fifth lcu_t; here it is what that level can differ in: the candidate of the one 8x8 CU being tried, its levels, four modes and
+  // coded-block flags.  CU info becomes 4x4-granular in one respect only -- the luma mode, which the most probable modes of a neighbour look at.
+  u8 mode4[4][64][4];             // [work-tree level][8x8 cell][PU]: luma mode per 4x4 unit (four equal entries for a 2Nx2N CU)
+  u8 nb_mode4_left[16];           // ... of the left CTU's right column (the row above is never asked: intra.c:107 takes DC across an LCU row boundary)
+  u8 c4[96];                      // candidate pixels of the NxN attempt: Y 8x8 | U 4x4 | V 4x4
+  alignas(8) i16 lv4_coeff[96];   // its levels: the four luma blocks in z-order (16 each), U, V
+  u8 pu_mode[4], pu_cbf[4];       // per PU: mode, luma coded-block flag
+  int pu_cbf_c[2];                // the CU's 4x4 U / V blocks (done with the first PU, transform.c:306-312)
+  int a3x, a3y, n_pu;             // CTU-local origin of the 8x8 CU being tried as NxN; PUs evaluated so far (-1: no attempt running)
+  double split_cost3;
+  CtxSetT<true> pre3, post3;      // search contexts when search_cu entered the 8x8 CU / after its 2Nx2N evaluation (search.c:655, 956-959)
 };
-// RDOQ: the instantiation that quantises with kvz_rdoq (kvz_hip_intra_cost_model::rdoq, preset `medium`); the others carry none of its code
+// RDOQ: the instantiation that quantises with kvz_rdoq (kvz_hip_intra_cost_model::rdoq, preset `medium`) and / or tries NxN partitions (search_nxn); the
+// others carry none of that code
 // S32: the instantiation that can also SEARCH 32x32 CUs (kvz_hip_intra_cost_model::search_32x32, --pu-depth-intra 1-3); the others carry none of its code
 template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   using CtxSet = CtxSetT<CABAC>;
@@ -276,6 +295,8 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   CtuFrames F;
   CtuSharedT<CABAC> *s;
   RdoqLds *rl = nullptr;  // RDOQ instantiation only
+  static constexpr bool NXN = RDOQ;
+  KVZ_DEV bool nxn_on() const { return NXN && m->search_nxn; }
   KVZ_DEV bool cabac_on() const { return CABAC && m->coeff_cabac; }  // coefficients priced with the CABAC model (rdo.c:311-340)
   int frame, cx, cy;  // CTU origin (luma px)
   int a1x, a1y, a2x, a2y;  // CTU-local luma origin of the depth-1 / depth-2 CU whose candidates are live (uniform)
@@ -317,7 +338,13 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   KVZ_DEV CandView cand_view(int lv) const
   {
     CandView v;
-    if (lv == 0) {
+    if (NXN && lv == 4) {  // the 8x8 CU being tried as four 4x4 PUs
+      v.buf = rl->c4;
+      v.lw[0] = 3; v.lw[1] = v.lw[2] = 2;
+      v.bias[0] = -(rl->a3y * 8 + rl->a3x);
+      v.bias[1] = 64 - ((rl->a3y >> 1) * 4 + (rl->a3x >> 1));
+      v.bias[2] = v.bias[1] + 16;
+    } else if (lv == 0) {
       v.buf = s->dec;  // see CtuShared::dec
       v.lw[0] = 6; v.lw[1] = v.lw[2] = 5;
       v.bias[0] = 0; v.bias[1] = 4096; v.bias[2] = 5120;
@@ -351,6 +378,11 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   KVZ_DEV static int cbf_is_set(uint16_t cbf, int depth, int plane) { return (cbf & ((0x1f >> depth) << (5 * plane))) != 0; }
   KVZ_DEV static void cbf_set(uint16_t *cbf, int depth, int plane) { *cbf |= (0x10 >> depth) << (5 * plane); }
   KVZ_DEV static void cbf_clear(uint16_t *cbf, int depth, int plane) { *cbf &= ~((0x1f >> depth) << (5 * plane)); }
+  // search_nxn: the 4x4-granular luma modes of cell `cell` at level lv, all four = mode (a 2Nx2N CU)
+  KVZ_DEV void set_mode4(int lv, int cell, int mode) const
+  {
+    if constexpr (NXN) { if (m->search_nxn) { const u32 v = (u32)mode * 0x01010101u; __builtin_memcpy(rl->mode4[lv][cell], &v, 4); } }
+  }
 
   // CU info at luma frame position (fx, fy) as seen from work-tree level lv; false = not available
   // CU info at luma frame position (fx, fy) as seen from work-tree level lv, as a VALUE: -1 = not available, else
@@ -362,13 +394,23 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   KVZ_DEV int neighbour_cu(int lv, int fx, int fy) const
   {
     if (fx < 0 || fy < 0 || fx >= F.W || fy >= F.H) return -1;
+    const int pu = ((fy >> 2) & 1) * 2 + ((fx >> 2) & 1);  // which 4x4 unit of its 8x8 cell (search_nxn: modes are 4x4-granular)
     if (fx >= cx && fx < cx + 64 && fy >= cy && fy < cy + 64) {
-      const CtuCu c = s->cu[lv][((fy - cy) >> 3) * 8 + ((fx - cx) >> 3)];
-      return (int)c.type | ((int)c.depth << 1) | ((int)c.mode << 8);
+      const int cell = ((fy - cy) >> 3) * 8 + ((fx - cx) >> 3);
+      if (NXN && lv == 4) {
+        // level 4 of the work tree equals level 3 except inside the 8x8 CU being tried as NxN: there, the PUs evaluated so far (an untouched
+        // cell of kvazaar's level is CU_NOTSET)
+        if (cell == (rl->a3y >> 3) * 8 + (rl->a3x >> 3)) return pu < rl->n_pu ? (1 | (3 << 1) | ((int)rl->pu_mode[pu] << 8)) : 0;
+        lv = 3;
+      }
+      const CtuCu c = s->cu[lv][cell];
+      const int mode = nxn_on() ? (int)rl->mode4[lv][cell][pu] : (int)c.mode;
+      return (int)c.type | ((int)c.depth << 1) | (mode << 8);
     }
     // outside the CTU only the left column (fx == cx-1) and the top row (fy == cy-1) are ever asked for
     const int side = fx < cx ? 0 : 1, i = side == 0 ? (fy - cy) >> 3 : (fx - cx) >> 3;
-    return 1 | ((int)s->nb_depth[side][i] << 1) | ((int)s->nb_mode[side][i] << 8);
+    const int mode = (nxn_on() && side == 0) ? (int)rl->nb_mode4_left[(fy - cy) >> 2] : (int)s->nb_mode[side][i];
+    return 1 | ((int)s->nb_depth[side][i] << 1) | (mode << 8);
   }
   // Reconstructed sample (px, py) of plane c (plane coordinates of the frame) as work-tree level lv sees it.  The four places it can
   // live in -- decided picture, the 8x8 siblings' candidates, the left / top border of the neighbour CTUs -- are all in CtuShared,
@@ -376,17 +418,27 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   // and as branches every lane would walk through every alternative.
   KVZ_DEV u8 rec_px(int lv, int c, int px, int py) const
   {
+#ifdef KVZ_HOSTSIM
+    typedef long lds_off;  // the host build's "LDS" objects are ordinary allocations, any distance apart
+#else
+    typedef int lds_off;
+#endif
     const int sh = c ? 1 : 0, w = 64 >> sh, pxl = px - (cx >> sh), pyl = py - (cy >> sh);
     const u8 *base = (const u8 *)s;
-    const int o_dec = (int)(s->dec - base) + kPlaneOff[c] + pyl * w + pxl;  // depths 0..2 never look inside their own CU; the 64x64 merge predicts its units from each other
+    const lds_off o_dec = (lds_off)(s->dec - base) + kPlaneOff[c] + pyl * w + pxl;  // depths 0..2 never look inside their own CU; the 64x64 merge predicts its units from each other
     // an 8x8 CU sees its already-tried siblings inside the current 16x16, decided pixels elsewhere
     const int rx = a2x >> sh, ry = a2y >> sh, rw = 16 >> sh;
-    const bool in3 = lv == 3 && (unsigned)(pxl - rx) < (unsigned)rw && (unsigned)(pyl - ry) < (unsigned)rw;
-    const int o_c3 = (int)(s->c3 - base) + (c == 0 ? 0 : (c == 1 ? 256 : 320)) + (pyl - ry) * rw + pxl - rx;
+    const bool in3 = lv >= 3 && (unsigned)(pxl - rx) < (unsigned)rw && (unsigned)(pyl - ry) < (unsigned)rw;
+    const lds_off o_c3 = (lds_off)(s->c3 - base) + (c == 0 ? 0 : (c == 1 ? 256 : 320)) + (pyl - ry) * rw + pxl - rx;
     // neighbour CTUs: left column (pxl == -1) or top row (pyl == -1), staged in LDS by init()
-    const int o_left = (int)(&s->bpx_left[0][0] - base) + c * 66 + pyl + 1, o_top = (int)(&s->bpx_top[0][0] - base) + c * 98 + pxl + 1;
+    const lds_off o_left = (lds_off)(&s->bpx_left[0][0] - base) + c * 66 + pyl + 1, o_top = (lds_off)(&s->bpx_top[0][0] - base) + c * 98 + pxl + 1;
     const bool inside = (unsigned)pxl < (unsigned)w && (unsigned)pyl < (unsigned)w;
-    const int off = inside ? (in3 ? o_c3 : o_dec) : (pxl < 0 ? o_left : o_top);
+    lds_off off = inside ? (in3 ? o_c3 : o_dec) : (pxl < 0 ? o_left : o_top);
+    if (NXN && lv == 4) {  // a 4x4 PU also sees the PUs of its own CU that came before it
+      const int qx = rl->a3x >> sh, qy = rl->a3y >> sh, qw = 8 >> sh;
+      if ((unsigned)(pxl - qx) < (unsigned)qw && (unsigned)(pyl - qy) < (unsigned)qw)
+        off = (lds_off)(rl->c4 - base) + (c == 0 ? 0 : (c == 1 ? 64 : 80)) + (pyl - qy) * qw + pxl - qx;
+    }
     return base[off];
   }
 
@@ -959,6 +1011,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   // attempt in lv1_coeff (recon_tus stage 4)
   KVZ_DEV i16 *levels_lds(int lv, int c) const
   {
+    if (NXN && lv == 4) return rl->lv4_coeff + (c == 0 ? 16 * rl->n_pu : (c == 1 ? 64 : 80));  // the PU being evaluated (n_pu counts the finished ones)
     if (lv == 3) return (i16 *)s->pred + (c == 0 ? 0 : (c == 1 ? 64 : 80));
     if (lv == 2) return s->lv2_coeff + (c == 0 ? 0 : (c == 1 ? 256 : 320));
     return s->lv1_coeff + (c == 0 ? 0 : (c == 1 ? 1024 : 1280));
@@ -1221,6 +1274,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   KVZ_DEV u32 mode_satd(int mode, int nblk) const  // SATD_NxN: sum of (block sum + 2) >> 2 (strategies-picture.h:53-69)
   {
     if (S32 && nblk == 16) return s->satd_raw[mode][0];  // a 32x32 CU's sum over its sixteen blocks, already rounded per block (rough_search)
+    if (NXN && nblk == 0) return s->satd_raw[mode][0];   // a 4x4 PU: the finished 4x4 SATD (eval_pu)
     u32 v = 0;
     for (int b = 0; b < nblk; b++) v += (s->satd_raw[mode][b] + 2) >> 2;
     return v;
@@ -1262,6 +1316,99 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     return ab < cd ? ab : cd;
   }
 #endif
+  // The selection order of search_intra_rough (search_intra.c:433-530) replayed on the cost table of all 35 modes (s->satd_raw; nblk 8x8 blocks per mode, 0: a 4x4
+  // PU whose entry is the finished SATD).  Returns the winner on the lanes that ran the replay -- the host build: thread 0; the device: the wavefront playing
+  // threads 0..63, all its lanes together -- and -1 on the others.
+  KVZ_DEV int replay_selection(int tid, int log2w, int nblk) const
+  {
+    // The replay below is serial and uniform.  On the device the first wavefront's worth of thread ids runs it together:
+    // lane m first works out mode m's SATD and cost, the replay then picks values out of those registers by lane index
+    // (v_readlane) instead of recomputing them from LDS.  The host build computes them on demand -- same formulas.
+#ifdef KVZ_HOSTSIM
+      if (tid != 0) return -1;
+      {
+#define KVZ_RAW(md) mode_satd((md), nblk)
+#define KVZ_COST(md, raw) ((double)(raw) + s->mode_bits_cost[(md) == p0 ? 1 : (((md) == p1 || (md) == p2) ? 2 : 0)])
+#else
+      if (tid >= 64) return -1;
+      {
+        const int my_mode = tid < 35 ? tid : 0;
+        const u32 my_raw = mode_satd(my_mode, nblk);
+        const double my_cost = (double)my_raw + s->mode_bits_cost[my_mode == s->preds[0] ? 1 : ((my_mode == s->preds[1] || my_mode == s->preds[2]) ? 2 : 0)];
+        const int my_cost_lo = __double2loint(my_cost), my_cost_hi = __double2hiint(my_cost);
+#define KVZ_RAW(md) ((u32)__builtin_amdgcn_readlane((int)my_raw, __builtin_amdgcn_readfirstlane(md)))
+        // On the device an append only records WHEN a mode was appended (in the lane that holds the mode); "first minimum in append
+        // order" is then one wavefront minimum of the costs -- non-negative doubles order like their bit patterns -- and one of
+        // the append positions among the lanes that reach it, instead of two v_readlane and a double compare per append.
+        int my_pos = 0, n_app = 0;
+#endif
+        // The list kvazaar builds (modes[], costs[]) is only ever read back as "first minimum in append order", so it is
+        // replayed with a visited mask and running minima instead of arrays.
+        unsigned long long visited = 0;
+        double final_cost = 0;
+        int final_mode = -1;
+        const int8_t p0 = s->preds[0], p1 = s->preds[1], p2 = s->preds[2];
+#ifdef KVZ_HOSTSIM
+#define KVZ_APPEND(md, raw)                                                                                         \
+        {                                                                                                           \
+          const int md_ = (md);                                                                                     \
+          visited |= 1ull << md_;                                                                                   \
+          const double c_ = KVZ_COST(md_, raw);                                                                     \
+          if (final_mode < 0 || c_ < final_cost) { final_cost = c_; final_mode = md_; }                             \
+        }
+#else
+#define KVZ_APPEND(md, raw)                                                                                         \
+        {                                                                                                           \
+          const int md_ = __builtin_amdgcn_readfirstlane(md);                                                       \
+          visited |= 1ull << md_;                                                                                   \
+          if (tid == md_) my_pos = n_app;                                                                           \
+          n_app++;                                                                                                  \
+        }
+#endif
+        int offset = log2w == 2 ? 2 : (log2w == 3 ? 4 : 8);
+        int32_t min_cost = 0x7fffffff, max_cost = -0x7fffffff - 1;
+        int best_mode = -1;
+        u32 first_min = 0;
+        for (int mode = 2; mode <= 34; mode += 2 * offset)
+          for (int i = 0; i < 2; i++) if (mode + i * offset <= 34) {
+            const u32 raw = KVZ_RAW(mode + i * offset);
+            KVZ_APPEND(mode + i * offset, raw);
+            if ((int32_t)raw < min_cost) min_cost = (int32_t)raw;
+            if ((int32_t)raw > max_cost) max_cost = (int32_t)raw;
+            if (best_mode < 0 || raw < first_min) { first_min = raw; best_mode = mode + i * offset; }
+          }
+        double best_cost = min_cost;
+        if (min_cost != max_cost) {
+          while (offset > 1) {
+            offset >>= 1;
+            const int tm[2] = { best_mode - offset, best_mode + offset };
+            for (int i = 0; i < 2; i++) if (tm[i] >= 2 && tm[i] <= 34) {
+              const u32 raw = KVZ_RAW(tm[i]);
+              KVZ_APPEND(tm[i], raw);
+              if ((double)raw < best_cost) { best_cost = (double)raw; best_mode = tm[i]; }
+            }
+          }
+        }
+        const int add_modes[5] = { p0, p1, p2, 0, 1 };
+        for (int p = 0; p < 5; p++)
+          if (!((visited >> add_modes[p]) & 1)) { const u32 raw = KVZ_RAW(add_modes[p]); KVZ_APPEND(add_modes[p], raw); }
+#undef KVZ_APPEND
+#undef KVZ_RAW
+#ifdef KVZ_HOSTSIM
+#undef KVZ_COST
+#else
+        {
+          const bool mine = tid < 35 && ((visited >> tid) & 1);
+          const unsigned long long key = mine ? (((unsigned long long)(unsigned)my_cost_hi << 32) | (unsigned)my_cost_lo) : ~0ull;
+          const unsigned long long kmin = wave_min_u64(key);
+          final_mode = (int)(wave_min_u32((mine && key == kmin) ? (unsigned)((my_pos << 6) | tid) : ~0u) & 63);
+          (void)final_cost;
+        }
+#endif
+        (void)p0; (void)p1; (void)p2;
+        return final_mode;
+      }
+  }
   template <class First>
   KVZ_DEV void rough_search(int lv, int x, int y, int depth, First first)
   {
@@ -1348,94 +1495,15 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     KVZ_SYNC();
     KVZ_PROF(KVZ_P_SATD);
     KVZ_FOR_THREADS(tid) {
-      // The replay below is serial and uniform.  On the device the first wavefront's worth of thread ids runs it together:
-      // lane m first works out mode m's SATD and cost, the replay then picks values out of those registers by lane index
-      // (v_readlane) instead of recomputing them from LDS.  The host build computes them on demand -- same formulas.
-#ifdef KVZ_HOSTSIM
-      if (tid == 0) {
-#define KVZ_RAW(md) mode_satd((md), nblk)
-#define KVZ_COST(md, raw) ((double)(raw) + s->mode_bits_cost[(md) == p0 ? 1 : (((md) == p1 || (md) == p2) ? 2 : 0)])
-#else
-      if (tid < 64) {
-        const int my_mode = tid < 35 ? tid : 0;
-        const u32 my_raw = mode_satd(my_mode, nblk);
-        const double my_cost = (double)my_raw + s->mode_bits_cost[my_mode == s->preds[0] ? 1 : ((my_mode == s->preds[1] || my_mode == s->preds[2]) ? 2 : 0)];
-        const int my_cost_lo = __double2loint(my_cost), my_cost_hi = __double2hiint(my_cost);
-#define KVZ_RAW(md) ((u32)__builtin_amdgcn_readlane((int)my_raw, __builtin_amdgcn_readfirstlane(md)))
-        // On the device an append only records WHEN a mode was appended (in the lane that holds the mode); "first minimum in append
-        // order" is then one wavefront minimum of the costs -- non-negative doubles order like their bit patterns -- and one of
-        // the append positions among the lanes that reach it, instead of two v_readlane and a double compare per append.
-        int my_pos = 0, n_app = 0;
-#endif
-        // The list kvazaar builds (modes[], costs[]) is only ever read back as "first minimum in append order", so it is
-        // replayed with a visited mask and running minima instead of arrays.
-        unsigned long long visited = 0;
-        double final_cost = 0;
-        int final_mode = -1;
-        const int8_t p0 = s->preds[0], p1 = s->preds[1], p2 = s->preds[2];
-#ifdef KVZ_HOSTSIM
-#define KVZ_APPEND(md, raw)                                                                                         \
-        {                                                                                                           \
-          const int md_ = (md);                                                                                     \
-          visited |= 1ull << md_;                                                                                   \
-          const double c_ = KVZ_COST(md_, raw);                                                                     \
-          if (final_mode < 0 || c_ < final_cost) { final_cost = c_; final_mode = md_; }                             \
-        }
-#else
-#define KVZ_APPEND(md, raw)                                                                                         \
-        {                                                                                                           \
-          const int md_ = __builtin_amdgcn_readfirstlane(md);                                                       \
-          visited |= 1ull << md_;                                                                                   \
-          if (tid == md_) my_pos = n_app;                                                                           \
-          n_app++;                                                                                                  \
-        }
-#endif
-        int offset = log2w == 2 ? 2 : (log2w == 3 ? 4 : 8);
-        int32_t min_cost = 0x7fffffff, max_cost = -0x7fffffff - 1;
-        int best_mode = -1;
-        u32 first_min = 0;
-        for (int mode = 2; mode <= 34; mode += 2 * offset)
-          for (int i = 0; i < 2; i++) if (mode + i * offset <= 34) {
-            const u32 raw = KVZ_RAW(mode + i * offset);
-            KVZ_APPEND(mode + i * offset, raw);
-            if ((int32_t)raw < min_cost) min_cost = (int32_t)raw;
-            if ((int32_t)raw > max_cost) max_cost = (int32_t)raw;
-            if (best_mode < 0 || raw < first_min) { first_min = raw; best_mode = mode + i * offset; }
-          }
-        double best_cost = min_cost;
-        if (min_cost != max_cost) {
-          while (offset > 1) {
-            offset >>= 1;
-            const int tm[2] = { best_mode - offset, best_mode + offset };
-            for (int i = 0; i < 2; i++) if (tm[i] >= 2 && tm[i] <= 34) {
-              const u32 raw = KVZ_RAW(tm[i]);
-              KVZ_APPEND(tm[i], raw);
-              if ((double)raw < best_cost) { best_cost = (double)raw; best_mode = tm[i]; }
-            }
-          }
-        }
-        const int add_modes[5] = { p0, p1, p2, 0, 1 };
-        for (int p = 0; p < 5; p++)
-          if (!((visited >> add_modes[p]) & 1)) { const u32 raw = KVZ_RAW(add_modes[p]); KVZ_APPEND(add_modes[p], raw); }
-#undef KVZ_APPEND
-#undef KVZ_RAW
-#ifdef KVZ_HOSTSIM
-#undef KVZ_COST
-#else
-        {
-          const bool mine = tid < 35 && ((visited >> tid) & 1);
-          const unsigned long long key = mine ? (((unsigned long long)(unsigned)my_cost_hi << 32) | (unsigned)my_cost_lo) : ~0ull;
-          const unsigned long long kmin = wave_min_u64(key);
-          final_mode = (int)(wave_min_u32((mine && key == kmin) ? (unsigned)((my_pos << 6) | tid) : ~0u) & 63);
-          (void)final_cost;
-        }
-#endif
-        (void)p0; (void)p1; (void)p2;
+      const int final_mode = replay_selection(tid, log2w, nblk);
+      if (final_mode >= 0) {
         if (tid == 0) s->best_mode = final_mode;
         // lcu_fill_cu_info (search.c:137-159) for the searched CU: at most 2x2 entries
         for (int i = 0; tid == 0 && i < (w >> 3) * (w >> 3); i++) {
-          CtuCu *cu = &s->cu[lv][((yl >> 3) + i / (w >> 3)) * 8 + (xl >> 3) + i % (w >> 3)];
+          const int cell = ((yl >> 3) + i / (w >> 3)) * 8 + (xl >> 3) + i % (w >> 3);
+          CtuCu *cu = &s->cu[lv][cell];
           cu->type = 1; cu->depth = (u8)depth; cu->mode = (u8)final_mode; cu->tr_depth = (u8)depth;
+          set_mode4(lv, cell, final_mode);
         }
       }
     }
@@ -1626,6 +1694,22 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
 #undef KVZ_CU8_ROLE
   }
 
+  // Where the quantised levels of plane c of a transform unit at (xl, yl) go when work-tree level lv evaluates it (see coeff_level())
+  KVZ_DEV i16 *coeff_dst(int lv, int c, int xl, int yl) const
+  {
+    const int sh = c ? 1 : 0;
+    if (NXN && lv == 4) return levels_lds(4, c);
+    return lv == 2 ? s->lv2_coeff + (c == 0 ? 0 : (c == 1 ? 256 : 320))
+         : lv == 1 ? s->lv1_coeff + (c == 0 ? 0 : (c == 1 ? 1024 : 1280)) : coeff_level(lv) + kPlaneOff[c] + zorder(xl >> sh, yl >> sh);
+  }
+  // Entry (k, i) of the transform of a 2^l2 block of plane c: the DCT, except 4x4 intra luma (strategies-dct.c:82-86, 111-115: the DST), which only the PUs of
+  // an NxN CU have
+  KVZ_DEV int tmat(int l2, int c, int k, int i) const
+  {
+    if (NXN && l2 == 2 && c == 0) return tb->dst4[4 * k + i];
+    return dct_at(l2, k, i);
+  }
+
   KVZ_DEV void recon_tus(int lv, const TuSet &t, int depth, int mode, bool refs_ready = false)
   {
     const int xl = t.x - cx, yl = t.y - cy;
@@ -1665,7 +1749,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
           for (int e = tid; e < n * n; e += KVZ_CTU_THREADS) {
             const int k = e >> l2, j = e & (n - 1);
             int a = 0;
-            for (int i = 0; i < n; i++) a += dct_at(l2, k, i) * (int)src[(j << l2) + i];
+            for (int i = 0; i < n; i++) a += tmat(l2, c, k, i) * (int)src[(j << l2) + i];
             dst[e] = (i16)((a + add) >> shift);
           }
         }
@@ -1682,13 +1766,13 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         const int c = tid == 0 ? 0 : (tid == KVZ_CTU_THREADS - 64 ? 1 : (tid == KVZ_CTU_THREADS - 63 ? 2 : -1));
         const int l2 = c < 0 ? 0 : tu_log2(t, c);
         if (l2) {
-          const int sh = c ? 1 : 0, scan_mode = scan_order(mode, depth);
-          i16 *cout = lv == 2 ? s->lv2_coeff + (c == 0 ? 0 : (c == 1 ? 256 : 320))
-                    : lv == 1 ? s->lv1_coeff + (c == 0 ? 0 : (c == 1 ? 1024 : 1280)) : coeff_level(lv) + kPlaneOff[c] + zorder(xl >> sh, yl >> sh);
+          const int scan_mode = scan_order(mode, depth);
+          i16 *cout = coeff_dst(lv, c, xl, yl);
           RdoqCtx rc{ s->pre[0].s, tb->entropy_bits, m->lambda };
           rc.ptab = rl->ptab;
-          // tr_depth = cu->tr_depth - cu->depth: 1 for the 32x32 units of the 64x64 attempt (level 0), 0 otherwise
-          rdoq_block(rc, m->qp, tbuf(t, 0, c), cout, l2, c ? 2 : 0, scan_mode, lv == 0 ? 1 : 0, tb->diag8, rdoq_scratch(c));
+          // tr_depth = cu->tr_depth - cu->depth: 1 for the 32x32 units of the 64x64 attempt (level 0), 0 otherwise -- plus one for an NxN CU
+          // (quant-generic.c:237-238): 2 for the blocks of its PUs (level 4)
+          rdoq_block(rc, m->qp, tbuf(t, 0, c), cout, l2, c ? 2 : 0, scan_mode, lv == 4 ? 2 : (lv == 0 ? 1 : 0), tb->diag8, rdoq_scratch(c));
         }
       }
       KVZ_SYNC();
@@ -1697,11 +1781,10 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       for (int c = 0; c < 3; c++) {
         const int l2 = tu_log2(t, c);
         if (!l2) continue;
-        const int n2 = 1 << (2 * l2), sh = c ? 1 : 0;
+        const int n2 = 1 << (2 * l2);
         const QuantScalars qf = s->qs[l2 - 2][c ? 1 : 0];  // forward and inverse share the plane's scaled QP (U and V alike)
         const QuantScalars qi = qf;
-        i16 *cout = lv == 2 ? s->lv2_coeff + (c == 0 ? 0 : (c == 1 ? 256 : 320))
-                  : lv == 1 ? s->lv1_coeff + (c == 0 ? 0 : (c == 1 ? 1024 : 1280)) : coeff_level(lv) + kPlaneOff[c] + zorder(xl >> sh, yl >> sh);
+        i16 *cout = coeff_dst(lv, c, xl, yl);
         i16 *stage = (cabac_on() && (lv == 3 || lv == 0)) ? levels_lds(lv, c) : nullptr;  // see levels_lds()
         const i16 *src = tbuf(t, 0, c);
         i16 *dq = tbuf(t, 1, c);
@@ -1746,7 +1829,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
           for (int e = tid; e < n * n; e += KVZ_CTU_THREADS) {
             const int j = e >> l2, i = e & (n - 1);
             int a = 0;
-            for (int k = 0; k < n; k++) a += dct_at(l2, k, i) * (int)src[(k << l2) + j];
+            for (int k = 0; k < n; k++) a += tmat(l2, c, k, i) * (int)src[(k << l2) + j];
             dst[e] = (i16)iclip(-32768, 32767, (a + add) >> shift);
           }
         }
@@ -1772,8 +1855,13 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         block_add(&s->acc[c], ssd);
       }
       if (tid == 0) {  // cbf bits of the TU's top-left CU entry (transform.c:314, 409-411)
-        CtuCu *cu = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
-        for (int c = 0; c < 3; c++) if (tu_log2(t, c)) { cbf_clear(&cu->cbf, depth, c); if (s->acc[6 + c]) cbf_set(&cu->cbf, depth, c); }
+        if (NXN && lv == 4) {  // a PU of the NxN attempt: its flags wait in RdoqLds until the partition wins (nxn_attempt)
+          rl->pu_cbf[rl->n_pu] = s->acc[6] != 0;
+          if (t.lc) { rl->pu_cbf_c[0] = s->acc[7] != 0; rl->pu_cbf_c[1] = s->acc[8] != 0; }
+        } else {
+          CtuCu *cu = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
+          for (int c = 0; c < 3; c++) if (tu_log2(t, c)) { cbf_clear(&cu->cbf, depth, c); if (s->acc[6 + c]) cbf_set(&cu->cbf, depth, c); }
+        }
       }
     }
     KVZ_SYNC();
@@ -1803,7 +1891,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   // On the device the callers bring the whole wavefront that plays threads 0..63 (KVZ_UNIT_COEFF_BITS), in the host simulation thread 0.
   KVZ_DEV double unit_coeff_bits(CtxSet *c, bool update, int lv, int depth, int mode, int cb_y, int cb_u, int cb_v, int tid) const
   {
-    const int lw = 6 - depth, lc = depth == 3 ? 2 : lw - 1, scan = scan_order(mode, depth);
+    const int lw = 6 - depth, lc = depth >= 3 ? 2 : lw - 1, scan = scan_order(mode, depth);
     double bits = 0;
 #ifdef KVZ_HOSTSIM
     (void)tid;
@@ -1937,8 +2025,10 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     KVZ_FOR_THREADS(tid) {
       const int n = w >> 3, ln = w == 8 ? 0 : (w == 16 ? 1 : (w == 32 ? 2 : 3));
       if (tid < n * n) {
-        CtuCu *c = &s->cu[lv][((yl >> 3) + (tid >> ln)) * 8 + (xl >> 3) + (tid & (n - 1))];
+        const int cell = ((yl >> 3) + (tid >> ln)) * 8 + (xl >> 3) + (tid & (n - 1));
+        CtuCu *c = &s->cu[lv][cell];
         c->type = (u8)type; c->depth = (u8)depth; c->mode = (u8)mode; c->tr_depth = (u8)tr_depth;
+        set_mode4(lv, cell, mode);
       }
     }
     KVZ_SYNC();
@@ -1965,7 +2055,10 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       const int n = w >> 3, lw = w == 16 ? 4 : (w == 32 ? 5 : 6), ln = lw - 3, cw = w >> 1;
       if (tid < n * n) {
         const int i = ((yl >> 3) + (tid >> ln)) * 8 + (xl >> 3) + (tid & (n - 1));
-        for (int to = cu_to_lo; to <= cu_to_hi; to++) s->cu[to][i] = s->cu[cu_from][i];
+        for (int to = cu_to_lo; to <= cu_to_hi; to++) {
+          s->cu[to][i] = s->cu[cu_from][i];
+          if constexpr (NXN) { if (m->search_nxn) __builtin_memcpy(rl->mode4[to][i], rl->mode4[cu_from][i], 4); }
+        }
       }
       if (pix_lv >= 0) {
         for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) {
@@ -2024,6 +2117,122 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     }
     KVZ_SYNC();
     KVZ_PROF(KVZ_P_COST);
+  }
+
+  // ---------------------------------------------------------------- the NxN partition of an 8x8 CU (search_nxn)
+  // SATD of mode `mode` on the 4x4 PU at CTU-local (xl, yl): prediction (intra.c:252-301 at width 4: unfiltered references, DC edge filter, the mode
+  // 10 / 26 post-filter) minus source, 4x4 Hadamard, (sum + 1) >> 1 (picture-generic.c:117-208).  One lane, everything in registers.
+  KVZ_DEV u32 pu_mode_satd(int mode, int xl, int yl) const
+  {
+    int t[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const u8 *o = org_at(0, xl, yl + r);
+      const int d0 = (int)predict_pixel(2, mode, 0, 0, r) - o[0], d1 = (int)predict_pixel(2, mode, 0, 1, r) - o[1];
+      const int d2 = (int)predict_pixel(2, mode, 0, 2, r) - o[2], d3 = (int)predict_pixel(2, mode, 0, 3, r) - o[3];
+      t[r][0] = d0 + d1 + d2 + d3; t[r][1] = d0 - d1 + d2 - d3; t[r][2] = d0 + d1 - d2 - d3; t[r][3] = d0 - d1 - d2 + d3;
+    }
+    int sum = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int p = t[0][c], q = t[1][c], r = t[2][c], v = t[3][c];
+      sum += iabs(p + q + r + v) + iabs(p - q + r - v) + iabs(p + q - r - v) + iabs(p - q - r + v);
+    }
+    return (u32)((sum + 1) >> 1);
+  }
+  // calc_mode_bits (search.c:557-581, updates on: search.c:906-913) + cu_rd_cost_tr_split_accurate at depth 4 (search.c:425-541) of the PU just
+  // reconstructed; sums in s->acc, its most probable modes in s->preds.  One lane.
+  KVZ_DEV double pu_cost(int j, int mode, const double *known_coeff_bits) const
+  {
+    CtxSet *c = &s->cab;
+    double bits = luma_mode_bits(c, mode, s->preds, true);
+    if (j == 0) bits += ctx_price(c, KVZ_CX_CHROMA, 0, true);  // the chroma mode is the CU's, coded once (with the PU at the CU's origin)
+    double cost = bits * m->lambda;
+    const int cb_y = s->acc[6] != 0, cb_u = j == 0 && s->acc[7] != 0, cb_v = j == 0 && s->acc[8] != 0;
+    double tr_tree_bits = 0, coeff_bits = 0;
+    // search.c:463-470 codes a chroma flag at this depth when the parent's is set, and reads the parent's from the same entry: cbf_is_set(cbf, depth - 1)
+    // covers the bit the 4x4 block itself set.  So the flag is priced exactly when it is 1 -- on the depth-1 context (depth 4 - cu depth 3).
+    if (cb_u) tr_tree_bits += ctx_price(c, KVZ_CX_CBF_CHROMA + 1, 1, true);
+    if (cb_v) tr_tree_bits += ctx_price(c, KVZ_CX_CBF_CHROMA + 1, 1, true);
+    tr_tree_bits += ctx_price(c, KVZ_CX_CBF_LUMA, cb_y, true);  // is_tr_split = depth - cu depth = 1 -> qt_cbf_model_luma[0]
+    if (known_coeff_bits) coeff_bits += *known_coeff_bits;
+    else {
+      if (cb_y) coeff_bits += (double)s->acc[3] / 256.0;
+      if (cb_u) coeff_bits += (double)s->acc[4] / 256.0;
+      if (cb_v) coeff_bits += (double)s->acc[5] / 256.0;
+    }
+    const unsigned luma_ssd = s->acc[0], chroma_ssd = j == 0 ? s->acc[1] + s->acc[2] : 0u;
+    const double tbits = tr_tree_bits + coeff_bits;
+    cost += luma_ssd * 0.8 + chroma_ssd * 1.5 + tbits * m->lambda;
+    return cost;
+  }
+  // search_cu at depth 4 (search.c:646-1063 with depth > MAX_DEPTH: cu depth stays 3, search.c:691): PU j of the 8x8 CU at (rl->a3x, rl->a3y)
+  KVZ_DEV void eval_pu(int j)
+  {
+    lane_rot = (lane_rot + 64) & (KVZ_CTU_THREADS - 1);
+    const int xl = rl->a3x + 4 * (j & 1), yl = rl->a3y + 4 * (j >> 1), x = cx + xl, y = cy + yl;
+    // references of the 4x4 luma block from level 4's view; with the first PU the CU's 4x4 chroma blocks (transform.c:306-312)
+    build_refs(4, x, y, 2, 2, true, j == 0, [&](int tid) { if (tid == 0) price_modes(); });
+    KVZ_FOR_THREADS(tid) {
+      if (tid < 35) s->satd_raw[tid][0] = pu_mode_satd(tid, xl, yl);
+      if (tid == KVZ_CTU_THREADS - 1) {
+        const int left = x >= 4 ? neighbour_cu(4, x - 1, y) : -1, above = (y >= 4 && yl > 0) ? neighbour_cu(4, x, y - 1) : -1;
+        mpm_candidates(y, left, above, s->preds);
+      }
+    }
+    KVZ_SYNC();
+    KVZ_FOR_THREADS(tid) {
+      const int final_mode = replay_selection(tid, 2, 0);
+      if (tid == 0) { s->best_mode = final_mode; rl->pu_mode[j] = (u8)final_mode; }
+    }
+    KVZ_SYNC();
+    const int mode = s->best_mode;
+    TuSet t{ x, y, 2, j == 0 ? 2 : 0 };
+    recon_tus(4, t, 4, mode, true);
+    if (cabac_on()) price_unit_coeffs(&s->cab, true, 4, 4, mode, &s->child_bits[0]);
+    KVZ_FOR_THREADS(tid) {
+      if (tid == 0) {
+        rl->split_cost3 += pu_cost(j, mode, cabac_on() ? &s->child_bits[0] : nullptr);
+        rl->n_pu = j + 1;
+      }
+    }
+    KVZ_SYNC();
+  }
+  // The split alternative of an 8x8 CU (search.c:943-1063 at depth 3 with pu_depth_intra.max = 4).  On entry the CU has been evaluated as 2Nx2N at level 3
+  // (cost in s->cost[3]; d3_last has saved the contexts after it, gone back to those at entry and priced part_size NxN into rl->split_cost3); on exit the cheaper
+  // alternative is what level 3 holds and its cost has been added to the 16x16 CU's running split cost.
+  KVZ_DEV void nxn_attempt(int x, int y)
+  {
+    const int xl = x - cx, yl = y - cy, cell = (yl >> 3) * 8 + (xl >> 3);
+    for (int j = 0; j < 4; j++) {
+      if (!(rl->split_cost3 < s->cost[3])) break;  // uniform: LDS scalars that only change in phases that end with a barrier
+      eval_pu(j);
+    }
+    // every lane reads the verdict here; thread 0 does not touch its operands below (see search_d2)
+    const bool nxn_wins = rl->split_cost3 < s->cost[3];
+    const CandView c3v = cand_view(3), c4v = cand_view(4);
+    KVZ_FOR_THREADS(tid) {
+      if (nxn_wins) {  // work_tree_copy_up from level 4: pixels, levels, CU info
+        if (tid < 96) {
+          const int c = tid < 64 ? 0 : (tid < 80 ? 1 : 2), e = tid - (c == 0 ? 0 : (c == 1 ? 64 : 80)), sh = c ? 1 : 0, l2 = 3 - sh;
+          const int px = (xl >> sh) + (e & ((1 << l2) - 1)), py = (yl >> sh) + (e >> l2);
+          c3v.at(c, px, py) = c4v.at(c, px, py);
+          i16 *dst = coeff_level(3) + kPlaneOff[c] + zorder(xl >> sh, yl >> sh);
+          dst[e] = rl->lv4_coeff[tid];
+        }
+        if (tid == 0) {
+          CtuCu *cu = &s->cu[3][cell];
+          cu->type = 1; cu->depth = 3; cu->tr_depth = 4; cu->mode = rl->pu_mode[0];
+          cu->cbf = (uint16_t)(rl->pu_cbf[0] | (rl->pu_cbf[1] << 1) | (rl->pu_cbf[2] << 2) | (rl->pu_cbf[3] << 3) | (rl->pu_cbf_c[0] << 5) | (rl->pu_cbf_c[1] << 10));
+          for (int k = 0; k < 4; k++) rl->mode4[3][cell][k] = rl->pu_mode[k];
+        }
+      } else ctx_copy_lanes(&s->cab, &rl->post3, tid);  // search.c:1051: the 2Nx2N CU stands; go on from the contexts after it
+      if (tid == 0) {
+        s->split_cost[2] += nxn_wins ? rl->split_cost3 : s->cost[3];
+        rl->n_pu = -1;
+      }
+    }
+    KVZ_SYNC();
   }
 
   // ---------------------------------------------------------------- CTU driver
@@ -2090,6 +2299,13 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
           const u8 *r = side == 0 ? r_left : r_top;
           s->nb_depth[side][i] = r ? load_shared_byte(r + 256 + (side == 0 ? 16 : 0) + i) : 0;
           s->nb_mode[side][i] = r ? load_shared_byte(r + 256 + (side == 0 ? 24 : 8) + i) : 0;
+        }
+        if constexpr (NXN) {
+          if (m->search_nxn) {
+            if (tid < 16) rl->nb_mode4_left[tid] = r_left ? load_shared_byte(r_left + 448 + tid) : 0;
+            for (int e = tid; e < 4 * 64; e += KVZ_CTU_THREADS) reinterpret_cast<u32 *>(rl->mode4)[e] = 0;
+            if (tid == 0) rl->n_pu = -1;
+          }
         }
       }
       for (int v = tid; v < 256; v += KVZ_CTU_THREADS) {
@@ -2178,7 +2394,26 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         }
         break;
       }
-      if (d == 3) ctx_code(KVZ_CX_PART, 1);  // part_mode 2Nx2N at the minimum CU size
+      const bool nxn = NXN && d == 3 && cu->tr_depth == 4;
+      if (d == 3) ctx_code(KVZ_CX_PART, !nxn);  // part_mode at the minimum CU size: 2Nx2N = 1, NxN = 0
+      if (nxn) {
+        // encode_intra_coding_unit (encode_coding_tree.c:505-560): the prev_intra_luma_pred_flags of the four PUs first, each against the most probable modes at
+        // its own position; then the chroma mode; the transform tree below codes cbf_cb / cbf_cr once (from the first PU's entry) and four luma flags on the
+        // split-unit context (encode_coding_tree.c:148-163, 205-225)
+        for (int j = 0; j < 4; j++) {
+          const int px = x + 4 * (j & 1), py = y + 4 * (j >> 1), pm = rl->mode4[0][(yl >> 3) * 8 + (xl >> 3)][j];
+          const int left = px > 0 ? neighbour_cu(0, px - 1, py) : -1, above = (py & 63) > 0 ? neighbour_cu(0, px, py - 1) : -1;
+          int8_t preds[3];
+          mpm_candidates(py, left, above, preds);
+          ctx_code(KVZ_CX_INTRA, pm == preds[0] || pm == preds[1] || pm == preds[2]);
+        }
+        ctx_code(KVZ_CX_CHROMA, 0);
+        ctx_code(KVZ_CX_CBF_CHROMA, (cu->cbf >> 5) & 1);
+        ctx_code(KVZ_CX_CBF_CHROMA, (cu->cbf >> 10) & 1);
+        for (int j = 0; j < 4; j++) ctx_code(KVZ_CX_CBF_LUMA, (cu->cbf >> j) & 1);
+        i += 1;
+        continue;
+      }
       {
         const int left = x > 0 ? neighbour_cu(0, x - 1, y) : -1, above = (y & 63) > 0 ? neighbour_cu(0, x, y - 1) : -1;
         int8_t preds[3];
@@ -2233,6 +2468,24 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
             const int xl = ((i & 1) | ((i >> 1) & 2) | ((i >> 2) & 4)) * 8, yl = (((i >> 1) & 1) | ((i >> 2) & 2) | ((i >> 3) & 4)) * 8;
             if (cx + xl >= F.W || cy + yl >= F.H) { i++; continue; }
             const CtuCu *cu = &s->cu[0][(yl >> 3) * 8 + (xl >> 3)];
+            if (NXN && cu->tr_depth == 4) {
+              // four 4x4 luma blocks, each scanned by its own PU's mode, then the 4x4 chroma blocks under the first PU's (encode_coding_tree.c:148-163)
+              const u8 *pm = rl->mode4[0][(yl >> 3) * 8 + (xl >> 3)];
+              const i16 *y4 = s->lv1_coeff + (zorder(xl, yl) - q * 1024), *u4 = s->lv1_coeff + 1024 + (zorder(xl >> 1, yl >> 1) - q * 256);
+              const int cscan = scan_order(pm[0], 4);
+#ifdef KVZ_HOSTSIM
+              for (int j = 0; j < 4; j++) if ((cu->cbf >> j) & 1) coeff_cabac_bits(c, true, y4 + 16 * j, 2, 0, scan_order(pm[j], 4));
+              if ((cu->cbf >> 5) & 1) coeff_cabac_bits(c, true, u4, 2, 2, cscan);
+              if ((cu->cbf >> 10) & 1) coeff_cabac_bits(c, true, u4 + 256, 2, 2, cscan);
+#else
+              for (int j = 0; j < 4; j++) if (luma_role && ((cu->cbf >> j) & 1)) coeff_cabac_bits_wave(c, true, y4 + 16 * j, 2, 0, scan_order(pm[j], 4), 1);
+              if (chroma_role && ((cu->cbf >> 5) & 1)) coeff_cabac_bits_wave(c, true, u4, 2, 2, cscan);
+              if (chroma_role && ((cu->cbf >> 10) & 1)) coeff_cabac_bits_wave(c, true, u4 + 256, 2, 2, cscan);
+              for (int j = 0; j < 4; j++) if (chroma_role && ((cu->cbf >> j) & 1)) coeff_cabac_bits_wave(c, true, y4 + 16 * j, 2, 0, scan_order(pm[j], 4), 2);
+#endif
+              i += 1;
+              continue;
+            }
             const int td = cu->depth < 1 ? 1 : cu->depth;  // a 64x64 CU codes four 32x32 units, each read at its own origin
             const int lw = 6 - td, lc = td == 3 ? 2 : lw - 1, scan = scan_order(cu->mode, td);
             const i16 *y = s->lv1_coeff + (zorder(xl, yl) - q * 1024), *u = s->lv1_coeff + 1024 + (zorder(xl >> 1, yl >> 1) - q * 256);
@@ -2277,6 +2530,21 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         const int i = v & 7;
         const CtuCu *cu = &s->cu[0][v < 16 ? 56 + i : i * 8 + 7];
         r[256 + v] = ((v >> 3) & 1) ? cu->mode : cu->depth;
+      }
+      if constexpr (NXN) {
+        if (m->search_nxn) {
+          if (tid < 16) r[448 + tid] = rl->mode4[0][(tid >> 1) * 8 + 7][(tid & 1) * 2 + 1];  // right column, 4x4 unit `tid` from the top
+          if (tid < 64) {
+            const int fx = cx + (tid & 7) * 8, fy = cy + (tid >> 3) * 8;
+            if (fx < F.W && fy < F.H) {
+              if (F.cu_part) F.cu_part[(long)frame * (F.H >> 3) * (F.W >> 3) + (long)(fy >> 3) * (F.W >> 3) + (fx >> 3)] = s->cu[0][tid].tr_depth == 4;
+              if (F.cu_mode4) {
+                u8 *m4 = F.cu_mode4 + (long)frame * (F.H >> 2) * (F.W >> 2) + (long)(fy >> 2) * (F.W >> 2) + (fx >> 2);
+                m4[0] = rl->mode4[0][tid][0]; m4[1] = rl->mode4[0][tid][1]; m4[F.W >> 2] = rl->mode4[0][tid][2]; m4[(F.W >> 2) + 1] = rl->mode4[0][tid][3];
+              }
+            }
+          }
+        }
       }
     }
     KVZ_SYNC();
@@ -2405,6 +2673,30 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         if (!(s->split_cost[2] < s->cost[2])) break;  // uniform: both are LDS scalars
         const int qx = x + (q & 1) * 8, qy = y + (q >> 1) * 8;
         if (qx >= F.W || qy >= F.H) continue;  // child outside the picture costs 0
+        if (nxn_on()) {
+          if constexpr (NXN) {
+            // search_cu at depth 3 with pu_depth_intra.max = 4: the 8x8 CU as 2Nx2N, then -- if it has coefficients (cu-split-termination zero, search.c:975-984)
+            // -- as four 4x4 PUs starting again from the contexts at entry with part_size NxN priced (search.c:956-974)
+            eval_cu(3, qx, qy, 3, &s->cost[3], &s->cbf_any,
+                    [&](int tid) {
+                      if (tid == 0) { cu_header(3, qx - cx, qy - cy, 3); price_modes(); rl->a3x = qx - cx; rl->a3y = qy - cy; rl->n_pu = 0; }
+                      ctx_copy_lanes(&rl->pre3, &s->cab, tid);
+                    },
+                    [&](int tid) {
+                      ctx_copy_lanes(&rl->post3, &s->cab, tid);
+                      ctx_copy_lanes(&s->cab, &rl->pre3, tid);
+                      if (tid == 0) {  // after the copy above (same wavefront, program order)
+                        double sb = 0;
+                        sb += ctx_price(&s->cab, KVZ_CX_PART, 0, true);
+                        double sc = 0.0;
+                        sc += sb * m->lambda;
+                        if (!s->cbf_any) sc = 2147483647;
+                        rl->split_cost3 = sc;
+                      }
+                    });
+            nxn_attempt(qx, qy);
+          }
+        } else
         eval_cu(3, qx, qy, 3, &s->cost[3], &s->cbf_any, [&](int tid) { if (tid == 0) { cu_header(3, qx - cx, qy - cy, 3); price_modes(); } }, [&](int tid) { if (tid == 0) s->split_cost[2] += s->cost[3]; });
       }
     }

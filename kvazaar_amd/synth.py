@@ -3,7 +3,8 @@ import hashlib
 
 import numpy as np
 
-MD5 = {"416x240": "c87920652c571cde553cb44f0d039522"}  # 8 frames, seed 1234
+# md5 of the files SURVEY.md App. C records: 416x240 x 8 frames (seed 1234, "small"), 1920x1080 x 8 (seed 1, "large"), 3840x2160 x 4 (seed 2, "large")
+MD5 = {"416x240": "c87920652c571cde553cb44f0d039522", "1920x1080": "4aa32ffcf953b3bcb14fd67659b963b1", "3840x2160": "7379f169ab620d1bbbef3255acb1ccb1"}
 
 
 def frames(w, h, n, seed, kind):

@@ -1,0 +1,79 @@
+/* batch_sim.c -- TEST INFRASTRUCTURE ONLY.  The subset of include/kvz_hip_batch.h that integration/kvazaar/search_lcu_hip.c calls, served by the ORACLE's
+ * CTU pass (oracle/kvz_oracle_ctu.c) on the host.  oracle/Makefile links it into oracle/_ref/kvazaar_hipsim, a copy of the integrated encoder in which these
+ * definitions shadow libkvz_hip.so's: it lets the CPU test suite check the BINDING's own logic (picture gathering, CU-array / coded-block-flag rebuild, tile views,
+ * NxN partitions) against the reference encoder's bitstream on machines without a GPU.  It is never linked into, loaded by or shipped with the product; no -m gpu
+ * test, bench leg or smoke() uses it -- those run oracle/_ref/kvazaar_hip, where the same calls reach the device. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/kvz_hip_batch.h"
+#include "kvz_oracle.h"
+
+struct kvz_hip_batch {
+  int w, h, n;
+  uint8_t *src, *rec, *depth, *mode, *part, *mode4;
+  int16_t *coeff;
+  double *cost;
+  int has_parts;
+};
+
+kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
+{
+  kvz_hip_batch *b = calloc(1, sizeof *b);
+  const size_t px = (size_t)width * height * 3 / 2, nctu = (size_t)((width + 63) / 64) * ((height + 63) / 64);
+  b->w = width; b->h = height; b->n = n_frames;
+  b->src = calloc(px, n_frames); b->rec = calloc(px, n_frames);
+  b->depth = calloc((size_t)(width / 8) * (height / 8), n_frames); b->mode = calloc((size_t)(width / 8) * (height / 8), n_frames);
+  b->part = calloc((size_t)(width / 8) * (height / 8), n_frames); b->mode4 = calloc((size_t)(width / 4) * (height / 4), n_frames);
+  b->coeff = calloc(nctu * KVZ_HIP_CTU_COEFFS * sizeof(int16_t), n_frames);
+  b->cost = calloc(nctu * sizeof(double), n_frames);
+  return b;
+}
+void kvz_hip_batch_destroy(kvz_hip_batch *b)
+{
+  if (!b) return;
+  free(b->src); free(b->rec); free(b->depth); free(b->mode); free(b->part); free(b->mode4); free(b->coeff); free(b->cost); free(b);
+}
+int kvz_hip_batch_ctus_per_frame(const kvz_hip_batch *b) { return ((b->w + 63) / 64) * ((b->h + 63) / 64); }
+void kvz_hip_batch_upload(kvz_hip_batch *b, int frame, const uint8_t *y, const uint8_t *u, const uint8_t *v)
+{
+  const size_t ys = (size_t)b->w * b->h, cs = ys / 4;
+  uint8_t *dst = b->src + (size_t)frame * (ys + 2 * cs);
+  memcpy(dst, y, ys); memcpy(dst + ys, u, cs); memcpy(dst + ys + cs, v, cs);
+}
+int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model)
+{
+  const size_t ys = (size_t)b->w * b->h, cs = ys / 4, px = ys + 2 * cs, ncu = (size_t)(b->w / 8) * (b->h / 8), nctu = (size_t)kvz_hip_batch_ctus_per_frame(b);
+  for (int f = 0; f < b->n; f++) {
+    const uint8_t *s = b->src + f * px;
+    uint8_t *r = b->rec + f * px;
+    kvz_oracle_intra_frame_nxn(model, b->w, b->h, s, s + ys, s + ys + cs, r, r + ys, r + ys + cs, b->coeff + f * nctu * KVZ_HIP_CTU_COEFFS, b->depth + f * ncu, b->mode + f * ncu,
+                               b->cost + f * nctu, b->part + f * ncu, b->mode4 + f * ncu * 4);
+  }
+  b->has_parts = model->search_nxn != 0;
+  return 1;
+}
+int kvz_hip_batch_sync(kvz_hip_batch *b) { (void)b; return 0; }
+int kvz_hip_batch_download(kvz_hip_batch *b, int frame, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, int16_t *coeff, uint8_t *cu_depth, uint8_t *cu_mode, double *ctu_cost)
+{
+  const size_t ys = (size_t)b->w * b->h, cs = ys / 4, px = ys + 2 * cs, ncu = (size_t)(b->w / 8) * (b->h / 8), nctu = (size_t)kvz_hip_batch_ctus_per_frame(b);
+  if (rec_y) memcpy(rec_y, b->rec + frame * px, ys);
+  if (rec_u) memcpy(rec_u, b->rec + frame * px + ys, cs);
+  if (rec_v) memcpy(rec_v, b->rec + frame * px + ys + cs, cs);
+  if (coeff) memcpy(coeff, b->coeff + frame * nctu * KVZ_HIP_CTU_COEFFS, nctu * KVZ_HIP_CTU_COEFFS * sizeof(int16_t));
+  if (cu_depth) memcpy(cu_depth, b->depth + frame * ncu, ncu);
+  if (cu_mode) memcpy(cu_mode, b->mode + frame * ncu, ncu);
+  if (ctu_cost) memcpy(ctu_cost, b->cost + frame * nctu, nctu * sizeof(double));
+  return 0;
+}
+int kvz_hip_batch_download_partitions(kvz_hip_batch *b, int frame, uint8_t *cu_part, uint8_t *cu_mode4)
+{
+  const size_t ncu = (size_t)(b->w / 8) * (b->h / 8);
+  if (!b->has_parts) return -1;
+  if (cu_part) memcpy(cu_part, b->part + frame * ncu, ncu);
+  if (cu_mode4) memcpy(cu_mode4, b->mode4 + frame * ncu * 4, ncu * 4);
+  return 0;
+}
+void *kvz_hip_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+void kvz_hip_host_free(void *p) { free(p); }

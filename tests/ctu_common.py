@@ -46,15 +46,40 @@ def run_hostsim(lib, model, width, height, yuv):
     return o
 
 
+def _partition_outputs(o, width, height):
+    o["part"], o["mode4"] = np.zeros((height // 8) * (width // 8), np.uint8), np.zeros((height // 4) * (width // 4), np.uint8)
+    return o
+
+
+def run_oracle_nxn(oracle, model, width, height, yuv):
+    """kvz_oracle_intra_frame_nxn: the pass + the NxN flag per 8x8 CU ("part") and the luma mode per 4x4 unit ("mode4")"""
+    o = _partition_outputs(outputs(width, height), width, height)
+    ys, cs = width * height, width * height // 4
+    f = oracle.lib.kvz_oracle_intra_frame_nxn
+    f.restype = None
+    f(C.byref(model), width, height, ptr(yuv[:ys]), ptr(yuv[ys:ys + cs]), ptr(yuv[ys + cs:]), ptr(o["rec"]), ptr(o["rec"], offset=ys), ptr(o["rec"], offset=ys + cs),
+      ptr(o["coeff"]), ptr(o["depth"]), ptr(o["mode"]), o["cost"].ctypes.data_as(C.POINTER(C.c_double)), ptr(o["part"]), ptr(o["mode4"]))
+    return o
+
+
+def run_hostsim_nxn(lib, model, width, height, yuv):
+    o = _partition_outputs(outputs(width, height), width, height)
+    f = lib.kvz_hostsim_intra_frame_nxn
+    f.restype = None
+    f(C.byref(model), width, height, ptr(yuv), ptr(o["rec"]), ptr(o["coeff"]), ptr(o["depth"]), ptr(o["mode"]),
+      o["cost"].ctypes.data_as(C.POINTER(C.c_double)), ptr(o["part"]), ptr(o["mode4"]))
+    return o
+
+
 def compare(a, b):
     """names of the outputs that differ (bit-exact comparison, doubles included)"""
-    return [k for k in ("rec", "coeff", "depth", "mode", "cost") if a[k].tobytes() != b[k].tobytes()]
+    return [k for k in ("rec", "coeff", "depth", "mode", "cost", "part", "mode4") if k in a and k in b and a[k].tobytes() != b[k].tobytes()]
 
 
 def yuv_frames(width, height, n, seed, kind):
     if kind == "adversarial":  # flat / noise / ramp / blocks (seed unused): the pictures that make band SAO, zero-coefficient CUs, big merges happen
         return list(adversarial_frames(width, height).values())[:n]
-    import synth
+    from kvazaar_amd import synth
     return [np.concatenate([p.reshape(-1) for p in planes]) for planes in synth.frames(width, height, n, seed, kind)]
 
 

@@ -1,0 +1,59 @@
+"""The kvazaar-side binding of the batched pass (integration/kvazaar/search_lcu_hip.c) checked WITHOUT a GPU: oracle/_ref/kvazaar_hipsim is the integrated
+encoder with the kvz_hip_batch_* calls served by the oracle's CTU pass (oracle/batch_sim.c, test infrastructure) instead of the device.  What is under test is the
+binding's own logic -- eligibility, picture gathering, CU-array / coded-block-flag rebuild incl. NxN CUs, tile views, coefficient hand-over: the bitstream must be the
+reference encoder's, byte for byte.  The same cases run against the device under -m gpu (tests/test_e2e_dropin.py, oracle/_ref/kvazaar_hip)."""
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+import ctu_common as cc
+import flatapi
+from kvazaar_amd import synth
+
+REF = os.path.join(flatapi.ROOT, "oracle", "_ref")
+
+
+def _encode(binary, yuv, res, out, extra, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([os.path.join(REF, binary), "-i", yuv, "--input-res", res, "-o", out] + extra, env=e, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return hashlib.md5(open(out, "rb").read()).hexdigest()
+
+
+CASES = [("416x240", 2, 1234, "small", ["--preset", "medium", "-p", "1"]),                           # BASELINE config 3's preset as it is: rdoq, NxN, SAO
+         ("416x240", 2, 1234, "small", ["--preset", "medium", "-p", "1", "-q", "12"]),               # ... where a sixth of the 8x8 CUs go NxN
+         ("192x136", 4, 0, "adversarial", ["--preset", "medium", "-p", "1", "-q", "12"]),            # the noise picture: every CU NxN
+         ("416x240", 2, 1234, "small", ["--preset", "ultrafast", "-p", "1", "--pu-depth-intra", "2-4"]),
+         ("416x240", 2, 1234, "small", ["--preset", "medium", "-p", "1", "-q", "32", "--tiles", "2x2"]),
+         ("416x240", 3, 1234, "small", ["--preset", "ultrafast", "-p", "1", "-q", "32", "--no-wpp"])]
+
+
+@pytest.mark.parametrize("res,frames,seed,kind,opts", CASES, ids=[" ".join(c[4][1:2] + c[4][4:]).replace(" ", "_") + "_" + c[0] for c in CASES])
+def test_binding_writes_the_reference_bitstream(tmp_path, res, frames, seed, kind, opts):
+    if not os.path.exists(os.path.join(REF, "kvazaar_hipsim")):
+        pytest.skip("oracle/_ref/kvazaar_hipsim not built (oracle/Makefile, where /root/reference exists)")
+    w, h = (int(v) for v in res.split("x"))
+    yuv = str(tmp_path / "syn.yuv")
+    if kind == "adversarial":
+        open(yuv, "wb").write(b"".join(f.tobytes() for f in cc.yuv_frames(w, h, frames, seed, kind)))
+    else:
+        synth.write_yuv(yuv, w, h, frames, seed, kind)
+    want = _encode("kvazaar_ref", yuv, res, str(tmp_path / "ref.hevc"), opts + ["--threads", "4"])
+    got = _encode("kvazaar_hipsim", yuv, res, str(tmp_path / "sim.hevc"), opts + ["--threads", "4"],
+                  {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1", "KVZ_HIP_BATCH_TRACE": str(tmp_path / "trace")})
+    assert got == want
+    assert int(open(str(tmp_path / "trace")).read().split()[0]) >= frames, "the batched search was not used"
+
+
+def test_binding_reproduces_the_survey_md5_at_1080p(tmp_path):
+    """1920x1080 x 8 frames --preset ultrafast -p 1 (BASELINE config 2's geometry through the binding's slot table and cbf rebuild)"""
+    if not os.path.exists(os.path.join(REF, "kvazaar_hipsim")):
+        pytest.skip("oracle/_ref/kvazaar_hipsim not built")
+    yuv = str(tmp_path / "syn.yuv")
+    assert synth.write_yuv(yuv, 1920, 1080, 8, 1, "large") == synth.MD5["1920x1080"]
+    got = _encode("kvazaar_hipsim", yuv, "1920x1080", str(tmp_path / "sim.hevc"), ["--preset", "ultrafast", "-p", "1", "--threads", "8"],
+                  {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1"})
+    assert got == "dce84d2200dc0e54e2e029425d1682e1"

@@ -10,7 +10,7 @@ import time
 import pytest
 
 import flatapi
-import synth
+from kvazaar_amd import synth
 
 pytestmark = pytest.mark.gpu
 REF = os.path.join(flatapi.ROOT, "oracle", "_ref")
@@ -25,11 +25,11 @@ def _need_hip_encoder():
                     "/root/reference exists (the built files ship with the snapshot)")
 
 
-def _encode(binary, yuv, out, extra, env=None):
+def _encode(binary, yuv, out, extra, env=None, res="416x240"):
     e = dict(os.environ)
     e.update(env or {})
     t = time.time()
-    r = subprocess.run([os.path.join(REF, binary), "-i", yuv, "--input-res", "416x240", "-o", out] + extra,
+    r = subprocess.run([os.path.join(REF, binary), "-i", yuv, "--input-res", res, "-o", out] + extra,
                        env=e, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     return hashlib.md5(open(out, "rb").read()).hexdigest(), time.time() - t, r.stderr
@@ -84,12 +84,14 @@ def test_batched_search_bitstream_identical(tmp_path, frames, extra):
 
 
 @pytest.mark.parametrize("preset,extra", [("superfast", ["-q", "22"]), ("veryfast", ["-q", "32"]), ("faster", ["-q", "22"]), ("faster", ["-q", "37", "--no-wpp"]),
-                                          ("fast", ["-q", "22"]), ("fast", ["-q", "32", "--tiles", "2x2"]), ("medium", ["-q", "27", "--pu-depth-intra", "1-3"])],
-                         ids=["superfast-qp22", "veryfast-qp32", "faster-qp22", "faster-qp37-nowpp", "fast-qp22", "fast-qp32-tiles", "medium-pu13-qp27"])
+                                          ("fast", ["-q", "22"]), ("fast", ["-q", "32", "--tiles", "2x2"]), ("medium", ["-q", "27", "--pu-depth-intra", "1-3"]),
+                                          ("medium", ["-q", "22"]), ("medium", ["-q", "12"]), ("ultrafast", ["-q", "22", "--pu-depth-intra", "2-4"])],
+                         ids=["superfast-qp22", "veryfast-qp32", "faster-qp22", "faster-qp37-nowpp", "fast-qp22", "fast-qp32-tiles", "medium-pu13-qp27",
+                              "medium-qp22", "medium-qp12-nxn", "ultrafast-pu24-nxn"])
 def test_batched_search_other_all_intra_presets(tmp_path, preset, extra):
     """All-intra superfast / veryfast (= the ultrafast search + `--sao full`), faster (fast-residual-cost 0: coefficients priced with the
-    CABAC model at every QP), fast (--pu-depth-intra 1-3 on top: 32x32 CUs searched) and medium without its NxN partitions (--rdoq on top: kvz_rdoq in every
-    quantisation of the device's search) with the device searching whole pictures: the reference's SAO decision then runs on the host on the device's
+    CABAC model at every QP), fast (--pu-depth-intra 1-3 on top: 32x32 CUs searched), medium without its NxN partitions (--rdoq on top: kvz_rdoq in every
+    quantisation of the device's search) and medium as it is (BASELINE config 3's preset: + 8x8 CUs tried as four 4x4 PUs) with the device searching whole pictures: the reference's SAO decision then runs on the host on the device's
     reconstruction, and the bitstream must still be the reference encoder's, byte for byte."""
     _need_hip_encoder()
     yuv = str(tmp_path / "syn.yuv")
@@ -124,3 +126,22 @@ def test_batched_search_golden_md5_416x240(tmp_path):
     md5, _, _ = _encode("kvazaar_hip", yuv, str(tmp_path / "b.hevc"), ["--preset", "ultrafast", "-p", "1", "--threads", "8"],
                         {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1"})
     assert md5 == GOLDEN_416x240_8F
+
+
+# the bitstream md5s of the reference encoder at BASELINE's own picture sizes (identical for generic and AVX2)
+GOLDEN_AT_SIZE = [("1920x1080", 8, 1, ["--preset", "ultrafast", "-p", "1"], "dce84d2200dc0e54e2e029425d1682e1"),
+                  ("3840x2160", 4, 2, ["--preset", "ultrafast", "-p", "1", "--tiles", "4x2"], "3de25813427ad6fc374bb50351d48dd9")]
+
+
+@pytest.mark.parametrize("res,frames,seed,opts,md5", GOLDEN_AT_SIZE, ids=["1080p-x8-ultrafast", "2160p-x4-tiles4x2"])
+def test_batched_search_golden_md5_at_baseline_sizes(tmp_path, res, frames, seed, opts, md5):
+    """BASELINE configs 2 and 5 at their real geometry through the binding (integration/kvazaar/search_lcu_hip.c: slot table, cbf rebuild, tile views of
+    960x1088 / 960x1072 luma): the device searches every picture / tile, the reference's entropy coder writes the survey's bitstream byte for byte"""
+    _need_hip_encoder()
+    w, h = (int(v) for v in res.split("x"))
+    yuv = str(tmp_path / "syn.yuv")
+    assert synth.write_yuv(yuv, w, h, frames, seed, "large") == synth.MD5[res]
+    got, t, _ = _encode("kvazaar_hip", yuv, str(tmp_path / "b.hevc"), opts + ["--threads", "16"],
+                        {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1", "KVZ_HIP_BATCH_TRACE": str(tmp_path / "trace")}, res=res)
+    assert got == md5
+    assert int(open(str(tmp_path / "trace")).read().split()[0]) >= frames, "the batched search was not used"

@@ -318,8 +318,7 @@ def test_oracle_rdoq_reproduces_reference_encoder(oracle, clip):
     assert deb == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 1) + "/medium-pu13"]
 
 
-# ---- `--preset medium` itself: the above + the 4x4 NxN partitions of 8x8 CUs (pu-depth-intra 1-4).  ORACLE ONLY so far (model.search_nxn): the next row of the
-# device pass starts from a pinned restatement ----------
+# ---- `--preset medium` itself: the above + the 4x4 NxN partitions of 8x8 CUs (pu-depth-intra 1-4; model.search_nxn) ----------
 def _medium_model(model):
     model = _rdoq_model(model)
     model.search_nxn = 1
@@ -359,6 +358,56 @@ def test_oracle_medium_takes_the_nxn_partition(oracle):
     m4 = mode4.reshape(h // 4, w // 4)
     assert np.array_equal(m4[::2, ::2].reshape(-1), o["mode"])          # cu_mode holds the first PU's mode
     assert (m4[::2, ::2] != m4[1::2, 1::2]).mean() > 0.5                # ... and the PUs of a CU choose their own
+
+
+@pytest.mark.parametrize("clip", [c for c in mg.ENCODER_CLIPS_MEDIUM if c[0] * c[1] <= 416 * 240], ids=lambda c: f"{c[0]}x{c[1]}-{c[4]}-qp{c[5]}")
+def test_hostsim_medium_equals_oracle(oracle, hostsim, clip):
+    """the device sources with depth 4 of the search (the NxN partition of 8x8 CUs, CtuProgramT<true, true, true> with model.search_nxn) on the host: every output
+    equals the oracle's -- pictures, levels, costs, the NxN flags and the 4x4-granular modes -- for `medium` itself and for the partition on top of the `ultrafast`
+    search (no RDOQ, fast coefficient cost below QP 28: the instantiation's other switch positions)"""
+    w, h, n, seed, kind, qp = clip
+    frames = cc.yuv_frames(w, h, n, seed, kind)
+    for variant in ("medium", "nxn-only"):
+        model = oracle_model(oracle, qp)
+        if variant == "medium":
+            model = _medium_model(model)
+        else:
+            model.search_nxn = 1
+        for f in (frames if variant == "medium" else frames[:2]):
+            o = cc.run_oracle_nxn(oracle, model, w, h, f)
+            assert not cc.compare(o, cc.run_hostsim_nxn(hostsim.lib, model, w, h, f)), (clip, variant)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip", mg.ENCODER_CLIPS_MEDIUM, ids=lambda c: f"{c[0]}x{c[1]}-{c[4]}-qp{c[5]}")
+def test_hip_medium_reproduces_reference_encoder(oracle, clip):
+    """the product on the MI355X with the whole of `medium` in the CTU pass (32x32 search, RDOQ, NxN partitions): CTU pass, CU maps, deblocking, SAO ==
+    `kvazaar --preset medium -p 1 --debug`, stage by stage; on the smaller clips every output also equals the oracle's (levels, costs, partitions, 4x4 modes)"""
+    import kvazaar_amd
+    from kvazaar_amd.batch import HipBatch, cost_model
+    lib = kvazaar_amd.load_library()
+    w, h, n, seed, kind, qp = clip
+    model = _medium_model(cost_model(lib, qp))
+    frames = cc.yuv_frames(w, h, n, seed, kind)
+    b = HipBatch(lib, w, h, n)
+    try:
+        for i, f in enumerate(frames):
+            b.upload(i, f)
+        b.run(model)
+        outs = [b.download(i) for i in range(n)]
+        assert [_sha(o["rec"]) for o in outs] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0) + "/medium"]
+        assert [_cu(o, w, h) for o in outs] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0) + "/medium/cu"]
+        if w * h <= 416 * 240:
+            for i in range(n):
+                outs[i]["part"], outs[i]["mode4"] = b.download_partitions(i)
+                assert not cc.compare(cc.run_oracle_nxn(oracle, _medium_model(oracle_model(oracle, qp)), w, h, frames[i]), outs[i]), (clip, i)
+        b.loop_filters(model, deblock=True, sao=False)
+        assert [_sha(b.download(i)["rec"]) for i in range(n)] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 1) + "/medium"]
+        b.run(model)
+        b.loop_filters(model, deblock=True, sao=True)
+        assert [_sha(b.download(i)["rec"]) for i in range(n)] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 1) + "/medium/sao"]
+    finally:
+        b.close()
 
 
 @pytest.mark.parametrize("clip", [c for c in mg.ENCODER_CLIPS_RDOQ if c[0] * c[1] <= 416 * 240], ids=lambda c: f"{c[0]}x{c[1]}-{c[4]}-qp{c[5]}")

@@ -4,7 +4,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-import devapi
+from kvazaar_amd import dev as devapi
 import flatapi
 
 pytestmark = pytest.mark.gpu
