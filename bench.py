@@ -46,11 +46,12 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:24]
 
 
-# preset -> (coeff_cabac or None = by QP, search_32x32, rdoq, suffix of the golden key)
-PRESETS = {"ultrafast": (None, 0, 0, ""), "faster": (1, 0, 0, None), "fast": (1, 1, 0, "/fast"), "medium-pu13": (1, 1, 1, "/medium-pu13")}
+# preset -> (coeff_cabac or None = by QP, search_32x32, rdoq, suffix of the golden key, search_nxn)
+PRESETS = {"ultrafast": (None, 0, 0, "", 0), "faster": (1, 0, 0, None, 0), "fast": (1, 1, 0, "/fast", 0), "medium-pu13": (1, 1, 1, "/medium-pu13", 0),
+           "medium": (1, 1, 1, "/medium", 1)}
 # ... and what the reference CLI is given for the CPU baseline of that search (loop filters off where the preset has SAO: the pass timed here is the search)
 PRESET_CLI = {"ultrafast": ["--preset", "ultrafast"], "faster": ["--preset", "faster", "--sao", "off"], "fast": ["--preset", "fast", "--sao", "off"],
-              "medium-pu13": ["--preset", "medium", "--pu-depth-intra", "1-3", "--sao", "off"]}
+              "medium-pu13": ["--preset", "medium", "--pu-depth-intra", "1-3", "--sao", "off"], "medium": ["--preset", "medium", "--sao", "off"]}
 
 
 def golden_digest(w, h, seed, qp, deblock, tiles=None, wpp=False, no_wpp=False, suffix=""):
@@ -334,7 +335,8 @@ def main():
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames generated on the host; the batch cycles through them")
     ap.add_argument("--qp", type=int, default=22)
     ap.add_argument("--preset", default="ultrafast", choices=sorted(PRESETS), help="which of kvazaar's all-intra searches the pass runs (the headline metric is ultrafast): "
-                    "faster = CABAC coefficient cost at every QP; fast = + 32x32 CUs searched; medium-pu13 = + RDOQ (`--preset medium --pu-depth-intra 1-3`)")
+                    "faster = CABAC coefficient cost at every QP; fast = + 32x32 CUs searched; medium-pu13 = + RDOQ (`--preset medium --pu-depth-intra 1-3`); "
+                    "medium = + 8x8 CUs tried as four 4x4 PUs: BASELINE config 3's preset as it is")
     ap.add_argument("--cpu-frames", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-encoder", action="store_true")
@@ -370,10 +372,10 @@ def main():
             m.adaptive = 0
         if args.no_wpp or (tiles_arg and not args.wpp):
             m.no_wpp = 1
-        cab, s32, rdoq, _ = PRESETS[args.preset]
+        cab, s32, rdoq, _, nxn = PRESETS[args.preset]
         if cab is not None:
             m.coeff_cabac = cab
-        m.search_32x32, m.rdoq = s32, rdoq
+        m.search_32x32, m.rdoq, m.search_nxn = s32, rdoq, nxn
         return m
 
     model = model_for(args.qp, args.tiles)

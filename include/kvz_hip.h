@@ -108,6 +108,11 @@ void     kvz_hip_array_checksum(const uint8_t *data, const int height, const int
  * coefficient are zeroed, a block without any keeps the rest of the caller's values, as the reference does).  The 4th argument is unused (the
  * library prices with kvz_entropy_bits, rdo.c:69-80); it keeps the signature of the test checkers.  _blocks: `count` blocks of one shape back to back. */
 void     kvz_hip_rdoq(int qp, double lambda, const uint8_t *ctx_states, const float *unused, const int16_t *coef, int16_t *dest, int width, int type, int scan_mode, int tr_depth);
+/* kvz_quantize_residual (quant-generic.c:198-292) WITH rdoq (:234-244) for an intra block -- flat lists, no sign hiding, no transform skip, not lossless: residual,
+ * forward transform, kvz_rdoq on the caller's context states (as kvz_hip_rdoq), dequantisation, inverse transform and reconstruction in one device round trip.
+ * Arguments as kvz_hip_quantize_residual plus state->lambda, the contexts and kvz_rdoq's tr_depth. */
+int      kvz_hip_quantize_residual_rdoq(const kvz_hip_quant_params *p, double lambda, const uint8_t *ctx_states, int tr_depth, int width, int color, int scan_order,
+                                        int in_stride, int out_stride, const uint8_t *ref_in, const uint8_t *pred_in, uint8_t *rec_out, int16_t *coeff_out, int early_skip);
 void     kvz_hip_rdoq_blocks(int qp, double lambda, const uint8_t *ctx_states, const int16_t *coef, int16_t *dest, int width, int type, int scan_mode, int tr_depth, int count);
 void     kvz_hip_plane_md5(const uint8_t *data, int height, int width, int stride, uint8_t *out16);       /* nal-generic.c:41-55, the 16 digest bytes */
 uint32_t kvz_hip_plane_checksum(const uint8_t *data, int height, int width, int stride);            /* nal-generic.c:57-82, the 32-bit sum */

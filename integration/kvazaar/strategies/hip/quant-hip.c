@@ -11,6 +11,7 @@
 #include "encoderstate.h"
 #include "rdo.h"
 #include "scalinglist.h"
+#include "strategies/generic/quant-generic.h"
 #include "strategies/strategies-quant.h"
 #include "strategyselector.h"
 #include "tables.h"
@@ -72,17 +73,18 @@ static void gather_rdoq_contexts(const encoder_state_t *state, uint8_t ctx[160])
 #undef PUT
 }
 
-/* quant_residual_func.  rdoq off: one fused device call.  rdoq on: the steps are chained exactly as quant-generic.c:198-292 does, all of
- * them on the device -- transform, kvz_rdoq (rdo.c:661: not a strategy pointer in the reference; the library's restatement for intra
- * blocks with flat lists and sign hiding off, kvz_hip_rdoq, is called in its place, otherwise the host function), dequant, inverse. */
+/* quant_residual_func.  rdoq off: one fused device call.  rdoq on, intra block with flat lists / no sign hiding / no transform skip (what the all-intra presets
+ * with --rdoq produce): one fused device call as well -- kvz_rdoq is host code in the reference (rdo.c:661, called directly by quant-generic.c:234-244), the library
+ * carries it for these blocks (kvz_hip_quantize_residual_rdoq).  Everything else with rdoq on (inter blocks, scaling lists, sign hiding, lossless) goes to the
+ * reference's own kvz_quantize_residual_generic, whose transform / quant / dequant steps come back here through the strategy pointers. */
 static int quantize_residual_hip(encoder_state_t *const state, const cu_info_t *const cur_cu, const int width, const color_t color,
                                  const coeff_scan_order_t scan_order, const int use_trskip, const int in_stride, const int out_stride,
                                  const kvz_pixel *const ref_in, const kvz_pixel *const pred_in, kvz_pixel *rec_out, coeff_t *coeff_out,
                                  bool early_skip)
 {
   const encoder_control_t *enc = state->encoder_control;
+  kvz_hip_quant_params p;
   if (!(enc->cfg.rdoq_enable && (width > 4 || !enc->cfg.rdoq_skip)) && !enc->cfg.lossless) {
-    kvz_hip_quant_params p;
     fill_params(state, width, color == COLOR_Y ? 0 : 2, cur_cu->type, &p);
     if (enc->scaling_list.enable) {
       /* the inverse pass of a V block uses list type 3 (quant-generic.c:263) */
@@ -94,42 +96,17 @@ static int quantize_residual_hip(encoder_state_t *const state, const cu_info_t *
     return kvz_hip_quantize_residual(&p, width, color, scan_order, use_trskip, in_stride, out_stride, ref_in, pred_in, rec_out,
                                      coeff_out, early_skip);
   }
-
-  ALIGNED(64) int16_t residual[TR_MAX_WIDTH * TR_MAX_WIDTH];
-  ALIGNED(64) coeff_t coeff[TR_MAX_WIDTH * TR_MAX_WIDTH];
-  int has_coeffs = 0;
-  for (int y = 0; y < width; ++y)
-    for (int x = 0; x < width; ++x) residual[x + y * width] = (int16_t)(ref_in[x + y * in_stride] - pred_in[x + y * in_stride]);
-  if (use_trskip) kvz_transformskip(enc, residual, coeff, width);
-  else kvz_transform2d(enc, residual, coeff, width, color, cur_cu->type);
-  {
-    int8_t tr_depth = cur_cu->tr_depth - cur_cu->depth;
-    tr_depth += (cur_cu->part_size == SIZE_NxN ? 1 : 0);
-    static int host_rdoq = -1;
-    if (host_rdoq < 0) { const char *e = getenv("KVZ_HIP_RDOQ_HOST"); host_rdoq = e && e[0] == '1'; }
-    if (!host_rdoq && cur_cu->type == CU_INTRA && !enc->scaling_list.enable && !enc->cfg.signhide_enable && enc->bitdepth == 8) {
-      uint8_t ctx[160];
-      gather_rdoq_contexts(state, ctx);
-      kvz_hip_rdoq(state->qp, state->lambda, ctx, NULL, coeff, coeff_out, width, (color == COLOR_Y ? 0 : 2), scan_order, tr_depth);
-    } else {
-      kvz_rdoq(state, coeff, coeff_out, width, width, (color == COLOR_Y ? 0 : 2), scan_order, cur_cu->type, tr_depth);
-    }
+  static int host_rdoq = -1;  /* KVZ_HIP_RDOQ_HOST=1: always the reference's chain with its host kvz_rdoq (A/B) */
+  if (host_rdoq < 0) { const char *e = getenv("KVZ_HIP_RDOQ_HOST"); host_rdoq = e && e[0] == '1'; }
+  if (!host_rdoq && cur_cu->type == CU_INTRA && !enc->scaling_list.enable && !enc->cfg.signhide_enable && !enc->cfg.lossless && !use_trskip && enc->bitdepth == 8) {
+    uint8_t ctx[160];
+    /* kvz_rdoq's tr_depth argument (quant-generic.c:237-238) */
+    const int tr_depth = cur_cu->tr_depth - cur_cu->depth + (cur_cu->part_size == SIZE_NxN ? 1 : 0);
+    gather_rdoq_contexts(state, ctx);
+    fill_params(state, width, color == COLOR_Y ? 0 : 2, cur_cu->type, &p);
+    return kvz_hip_quantize_residual_rdoq(&p, state->lambda, ctx, tr_depth, width, color, scan_order, in_stride, out_stride, ref_in, pred_in, rec_out, coeff_out, early_skip);
   }
-  for (int i = 0; i < width * width; ++i) if (coeff_out[i] != 0) { has_coeffs = 1; break; }
-  if (has_coeffs && !early_skip) {
-    kvz_dequant(state, coeff_out, coeff, width, width, (color == COLOR_Y ? 0 : (color == COLOR_U ? 2 : 3)), cur_cu->type);
-    if (use_trskip) kvz_itransformskip(enc, residual, coeff, width);
-    else kvz_itransform2d(enc, residual, coeff, width, color, cur_cu->type);
-    for (int y = 0; y < width; ++y)
-      for (int x = 0; x < width; ++x) {
-        int16_t val = residual[x + y * width] + pred_in[x + y * in_stride];
-        rec_out[x + y * out_stride] = (kvz_pixel)CLIP(0, PIXEL_MAX, val);
-      }
-  } else if (rec_out != pred_in) {
-    for (int y = 0; y < width; ++y)
-      for (int x = 0; x < width; ++x) rec_out[x + y * out_stride] = pred_in[x + y * in_stride];
-  }
-  return has_coeffs;
+  return kvz_quantize_residual_generic(state, cur_cu, width, color, scan_order, use_trskip, in_stride, out_stride, ref_in, pred_in, rec_out, coeff_out, early_skip);
 }
 
 static void find_last_scanpos_hip(coeff_t *coef, coeff_t *dest_coeff, int8_t type, int32_t q_bits, const coeff_t *quant_coeff,

@@ -1,34 +1,66 @@
-"""Builds libkvz_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Builds libkvz_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+The library is seven translation units compiled in parallel: kvz_hip.hip (C ABI, per-call ops, streaming kernels, host side of the batch; with
+-DKVZ_CTU_SEPARATE_TUS it only declares the CTU kernels) and kvz_ctu_tu.hip six times, one CTU kernel instantiation each (-DKVZ_CTU_KERNEL_TU=0..5,
+csrc/kvz_ctu_kernels.hpp).  Objects are rebuilt when one of the files they include (hipcc -MD) is newer."""
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
 LIB_PATH = os.environ.get("KVZ_HIP_LIB") or os.path.join(LIB_DIR, "libkvz_hip.so")  # KVZ_HIP_LIB: developer override (kernel variants)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["kvz_hip.hip"]
 # -ffp-contract=off: pixel_var / cost arithmetic must not be contracted into FMAs (bit-exact double results)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
+# (object name, source, extra defines)
+UNITS = [("kvz_hip", "kvz_hip.hip", ["-DKVZ_CTU_SEPARATE_TUS"])] + [(f"kvz_ctu_tu{k}", "kvz_ctu_tu.hip", [f"-DKVZ_CTU_KERNEL_TU={k}"]) for k in range(6)]
+
+
+def _deps(dfile):
+    try:
+        txt = open(dfile).read().replace("\\\n", " ")
+    except OSError:
+        return None
+    return [t for t in txt.split(":", 1)[1].split() if t] if ":" in txt else None
+
+
+def _unit_stale(name):
+    obj, dfile = os.path.join(OBJ_DIR, name + ".o"), os.path.join(OBJ_DIR, name + ".d")
+    deps = _deps(dfile)
+    if not os.path.exists(obj) or deps is None:
+        return True
+    t = os.path.getmtime(obj)
+    return any((not os.path.exists(p)) or os.path.getmtime(p) > t for p in deps) or os.path.getmtime(os.path.abspath(__file__)) > t
 
 
 def _stale():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    inc = os.path.join(os.path.dirname(PKG), "include")
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(inc, f) for f in os.listdir(inc)]
-    return any(os.path.getmtime(p) > t for p in deps)
+    return not os.path.exists(LIB_PATH) or any(_unit_stale(n) or os.path.getmtime(os.path.join(OBJ_DIR, n + ".o")) > os.path.getmtime(LIB_PATH) for n, _, _ in UNITS)
 
 
 def build_library(force=False, verbose=False):
     """Compile every HIP source into kvazaar_amd/lib/libkvz_hip.so.  Returns the library path."""
     if os.environ.get("KVZ_HIP_LIB") or (not force and not _stale()):
         return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+
+    def compile_unit(unit):
+        name, src, defs = unit
+        if not force and not _unit_stale(name):
+            return
+        obj = os.path.join(OBJ_DIR, name + ".o")
+        cmd = [HIPCC] + FLAGS + defs + ["-c", "-MD", "-MF", os.path.join(OBJ_DIR, name + ".d"), "-o", obj, os.path.join(CSRC, src)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(len(UNITS), os.cpu_count() or 1)) as pool:
+        list(pool.map(compile_unit, UNITS))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + [os.path.join(OBJ_DIR, n + ".o") for n, _, _ in UNITS]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB_PATH
 

@@ -279,6 +279,38 @@ template <class B> struct Api {
     return has;
   }
 
+  // ... and with rdoq on (quant-generic.c:234-244: kvz_rdoq in place of kvz_quant) for an intra block, flat lists, sign hiding and transform skip off: the
+  // whole function in ONE round trip -- residual, transform, kvz_rdoq on the caller's context states, dequantisation, inverse transform, reconstruction
+  static int quantize_residual_rdoq(B &be, const kvz_hip_quant_params *p, double lambda, const u8 *ctx_states, int tr_depth, int width, int color, int scan_order, int in_stride,
+                                    int out_stride, const u8 *ref_in, const u8 *pred_in, u8 *rec_out, i16 *coeff_out, int early_skip)
+  {
+    const int n = width * width, l2 = ilog2(width);
+    const int idx = width == 4 ? ((color == 0 && p->cu_is_intra) ? 4 : 0) : l2 - 2;
+    const QuantScalars qi = quant_scalars(p->qp, p->bitdepth, p->slice_is_intra, 0, width, color == 0 ? 0 : (color == 1 ? 2 : 3));
+    be.begin();
+    const u8 *ref = be.in_rows(ref_in, width, width, in_stride), *pred = be.in_rows(pred_in, width, width, in_stride);
+    const u8 *cx = be.in(ctx_states, 160);
+    u32 *acc = be.template zeroed<u32>(2);  // [1] non-zero count
+    i16 *co = be.template out<i16>(n);
+    u8 *rec = be.template out<u8>(n);
+    i16 *resid = be.template scratch<i16>(n), *coeff = be.template scratch<i16>(n), *tmp = be.template scratch<i16>(n);
+    double *cost3 = be.template scratch<double>((size_t)3 * n);
+    be.upload();
+    be.run(ResidualOp{ ref, pred, width, width, resid }, n);
+    transform_dev(be, idx, p->bitdepth, resid, tmp, coeff, 1);
+    be.run(RdoqOp{ be.tables(), cx, lambda, p->qp, coeff, co, l2, color == 0 ? 0 : 2, scan_order, tr_depth, cost3 }, 1);  // writes every level of the block
+    be.run(AnyNonzeroOp{ co, acc + 1 }, n);
+    be.run(DequantOp{ qi, co, nullptr, coeff, n }, n);
+    transform_dev(be, KVZ_HIP_IDCT_4 + idx, p->bitdepth, coeff, tmp, resid, 1);
+    be.run(ReconOp{ resid, pred, width, rec, width, width, acc + 1, early_skip }, n);
+    be.download();
+    const int has = be.host(acc)[1] != 0;
+    memcpy(coeff_out, be.host(co), n * sizeof(i16));
+    if ((has && !early_skip) || rec_out != pred_in)
+      for (int y = 0; y < width; y++) memcpy(rec_out + (long)y * out_stride, be.host(rec) + y * width, width);
+    return has;
+  }
+
   static u32 coeff_abs_sum(B &be, const i16 *coeffs, size_t length)
   {
     be.begin();

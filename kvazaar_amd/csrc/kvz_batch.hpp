@@ -1,5 +1,5 @@
-// kvz_batch.hpp -- host side of the batched CTU pass: device buffers of a frame batch, the two kernels (persistent launch with an
-// in-order ticket list; one launch per anti-diagonal kept for A/B), the cost model.  Included by kvz_hip.hip only.
+// kvz_batch.hpp -- host side of the batched CTU pass: device buffers of a frame batch, the launches of the CTU kernels (kvz_ctu_kernels.hpp: persistent launch
+// with an in-order ticket list; one launch per anti-diagonal kept for A/B), the cost model.  Included by kvz_hip.hip only.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -10,130 +10,7 @@
 #include "kvz_ctu.hpp"
 #include "kvz_runtime.hpp"
 
-namespace kvz {
-
-// One workgroup per CTU of the anti-diagonal `wave` (x + 2y == wave) of every frame.
-#ifdef KVZ_CTU_NUM_VGPR  /* register-cap experiments */
-#define KVZ_CTU_VGPR_ATTR __attribute__((amdgpu_num_vgpr(KVZ_CTU_NUM_VGPR)))
-#else
-#define KVZ_CTU_VGPR_ATTR
-#endif
-#ifndef KVZ_CTU_WAVES_PER_EU
-#define KVZ_CTU_WAVES_PER_EU 4  /* 8 workgroups of 128 lanes per CU = 4 wavefronts per SIMD at 128 VGPRs (LDS 16.5 KB would allow 9, but 96 VGPRs cost more than the ninth workgroup gives: profiles/experiments/r01_ab13*) */
-#endif
-template <bool CABAC> __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) intra_ctu_wave_kernel(const CtuFrames F, const CtuModel model, const Tables *tb,
-                                                                        const int wave, const int y_min, const int n_diag)
-{
-  __shared__ CtuSharedT<CABAC> shared;
-  __shared__ CtuModel m;  // scalars in LDS; its price table stays in HBM (kvz_hip_batch::d_entropy)
-  if (threadIdx.x == 0) m = model;
-  __syncthreads();
-  CtuProgramT<CABAC> p;
-  p.m = &m; p.tb = tb; p.F = F; p.s = &shared;
-  p.frame = blockIdx.x / n_diag;
-  const int y = y_min + (int)(blockIdx.x % n_diag);
-  p.cx = (wave - 2 * y) * 64;
-  p.cy = y * 64;
-  p.run();
-}
-
-// ---- single-launch schedule: in-order tickets --------------------------------------------------------------------
-// Work items (one CTU each) are listed in an order in which every CTU comes after the CTUs it depends on (anti-diagonal
-// x + 2y ascending, all frames interleaved).  Workgroups draw tickets from an atomic counter and process the item behind
-// the ticket; before touching neighbour data they wait for the `done` flags of the left and the above-right CTU.
-// Deadlock-free for ANY number of resident workgroups: an item only ever waits for items with smaller tickets, and every
-// smaller ticket has been drawn by a workgroup that is running (induction over the ticket order) -- no co-residency of
-// the whole grid is assumed.  Hand-off follows the agent-scope release/acquire recipe of the CDNA guide (G16): producer
-// drains its stores, one lane releases at agent scope and stores the flag; consumer polls relaxed, one lane acquires,
-// then the workgroup barrier.  Compared with one launch per diagonal this removes the per-launch tail (a diagonal of
-// n CTUs x F frames rarely is a multiple of the resident workgroup count) and 61 of 62 launches.
-struct CtuSched {
-  const uint32_t *items;  // [total]: frame << 16 | y << 8 | x  (CTU coordinates)
-  unsigned *ticket;       // atomic ticket counter, zeroed before every launch
-  unsigned *done;         // [frames * ctus_per_frame]: epoch of the last call that completed the CTU
-  unsigned *error;        // set when a wait exceeds its spin bound (never in a healthy run)
-  unsigned total, epoch;
-  int no_wpp;             // items in raster order per picture; a row's first CTU also waits for the last CTU of the row above
-  unsigned long long wait_ticks;  // bound of one wait in ticks of the 100 MHz constant clock (s_memrealtime): wall-clock, so that counter
-                                  // serialisation under rocprof, time slicing or preemption cannot turn a healthy run into a timeout
-};
-
-__device__ __forceinline__ bool wait_done(unsigned *flag, unsigned epoch, unsigned *error, unsigned long long wait_ticks)
-{
-  unsigned long long t0 = 0;
-  for (unsigned spins = 0;; ++spins) {
-    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
-    if ((spins & 1023u) == 1023u) {  // bounded: a lost hand-off must not hang the GPU
-      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
-      if (!t0) t0 = now;
-      else if (now - t0 > wait_ticks) { atomicExch(error, 1u); return false; }
-    }
-    __builtin_amdgcn_s_sleep(16);
-  }
-}
-
-// The persistent loop of the ticket schedule; the kernels below differ in their register budget only.
-template <bool CABAC, bool S32, bool RDOQ> __device__ __forceinline__ void ticket_loop(const CtuFrames &F, const CtuModel &model, const Tables *tb, const CtuSched &sched)
-{
-  __shared__ CtuSharedT<CABAC> shared;
-  __shared__ CtuModel m;  // scalars in LDS; its price table stays in HBM (kvz_hip_batch::d_entropy)
-  // The ticket is broadcast through a field of `shared` that is dead between two CTUs: with the CABAC contexts the block is exactly 20 480 B,
-  // and one more word would cost the eighth workgroup per CU (160 KB of LDS).
-#ifndef KVZ_CTU_PROFILE
-  static_assert(sizeof(CtuSharedT<CABAC>) + sizeof(CtuModel) <= 20480, "eight workgroups per CU");
-#endif
-  if (threadIdx.x == 0) m = model;
-  const int ctus = F.wc * F.hc;
-  for (;;) {
-    __syncthreads();  // previous item fully retired (and m visible on the first trip)
-    if (threadIdx.x == 0) shared.best_mode = (int)atomicAdd(sched.ticket, 1u);
-    __syncthreads();
-    const unsigned t = (unsigned)shared.best_mode;
-    if (t >= sched.total) break;
-    const uint32_t item = sched.items[t];
-    const int frame = item >> 16, y = (item >> 8) & 0xff, x = item & 0xff;
-    if (threadIdx.x == 0) {
-      unsigned *done = sched.done + (long)frame * ctus;
-      if (x > 0) wait_done(&done[y * F.wc + x - 1], sched.epoch, sched.error, sched.wait_ticks);
-      if (y > 0) wait_done(&done[(y - 1) * F.wc + (x + 1 < F.wc ? x + 1 : x)], sched.epoch, sched.error, sched.wait_ticks);  // above-right implies above and above-left
-      if (sched.no_wpp && x == 0 && y > 0) wait_done(&done[(y - 1) * F.wc + F.wc - 1], sched.epoch, sched.error, sched.wait_ticks);  // its contexts come from there
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    CtuProgramT<CABAC, S32, RDOQ> p;
-    p.m = &m; p.tb = tb; p.F = F; p.s = &shared;
-    if constexpr (RDOQ) { __shared__ RdoqLds rdoq_lds; p.rl = &rdoq_lds; }
-    p.frame = frame; p.cx = x * 64; p.cy = y * 64;
-    p.lane_rot = (t * 64) & (KVZ_CTU_THREADS - 1);
-    p.run();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its stores (reconstruction, CU info, coefficients)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&sched.done[(long)frame * ctus + y * F.wc + x], sched.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
-template <bool CABAC, bool S32 = false, bool RDOQ = false> __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_CTU_WAVES_PER_EU))) KVZ_CTU_VGPR_ATTR intra_ctu_ticket_kernel(const CtuFrames F, const CtuModel model, const Tables *tb,
-                                                                        const CtuSched sched)
-{
-  ticket_loop<CABAC, S32, RDOQ>(F, model, tb, sched);
-}
-// --rdoq: kvz_rdoq is a long double-precision routine run by one lane per plane; at 128 VGPRs its many inlined copies spill by the thousand, so this
-// instantiation trades occupancy for registers: exactly KVZ_RDOQ_WAVES_PER_EU wavefronts per SIMD (3 = 168 VGPRs, 6 workgroups per CU).  Measured at 1080p QP 27
-// (the pass waits on LDS / memory three quarters of the time, so residency counts until spills take over): 1 wavefront per SIMD (512 registers) 22.5 k CTUs/s,
-// 2 (256) 41.0 k, 3 (168) 54.3 k, 4 (128, thousands of spills) 17.5 k
-#ifndef KVZ_RDOQ_WAVES_PER_EU
-#define KVZ_RDOQ_WAVES_PER_EU 3
-#endif
-__global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_RDOQ_WAVES_PER_EU, KVZ_RDOQ_WAVES_PER_EU))) intra_ctu_ticket_kernel_rdoq(const CtuFrames F, const CtuModel model, const Tables *tb, const CtuSched sched)
-{
-  ticket_loop<true, true, true>(F, model, tb, sched);
-}
-
-}  // namespace kvz
+#include "kvz_ctu_kernels.hpp"
 
 struct kvz_hip_batch {
   kvz::CtuFrames F;
@@ -459,7 +336,7 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
     // two instantiations: the one without the CABAC coefficient model carries none of its code, registers or context storage
     // (the instantiations that search 32x32 CUs, --pu-depth-intra 1-3, are separate ones too: the others stay as they were)
     if (cm.rdoq || cm.search_nxn) {  // --rdoq and / or NxN partitions (preset `medium`): their own instantiation (32x32 search and the coefficient cost model switched by the model)
-      if (cm.rdoq && !b->d_rdoq) KVZ_HIP_CHECK(hipMalloc((void **)&b->d_rdoq, (size_t)b->grid_ticket * 3 * 3 * 1024 * sizeof(double)));
+      if (cm.rdoq && !b->d_rdoq) KVZ_HIP_CHECK(hipMalloc((void **)&b->d_rdoq, (size_t)b->grid_ticket * 3 * KVZ_RDOQ_SCRATCH_DOUBLES * sizeof(double)));
       if (cm.search_nxn && !b->d_part) {
         KVZ_HIP_CHECK(hipMalloc((void **)&b->d_part, (size_t)(F.W / 8) * (F.H / 8) * b->n_frames));
         KVZ_HIP_CHECK(hipMalloc((void **)&b->d_mode4, (size_t)(F.W / 4) * (F.H / 4) * b->n_frames));

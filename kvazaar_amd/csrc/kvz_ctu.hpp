@@ -189,7 +189,7 @@ struct CtuFrames {
   // Neighbour data is exchanged ONLY through these records: the frame-level rec / cu arrays share cache lines between CTUs
   // produced on different XCDs, and a line that is dirty in the reader's L2 cannot be invalidated by its acquire.
   u8 *border;                // [frames][ctu][KVZ_BORDER_BYTES]
-  double *rdoq_scratch;      // [workgroup][plane][3 * 1024]: the per-position cost arrays of kvz_rdoq (RDOQ instantiation only, else unused)
+  double *rdoq_scratch;      // [workgroup][plane][KVZ_RDOQ_SCRATCH_DOUBLES]: the per-position cost arrays of kvz_rdoq (RDOQ instantiation only, else unused)
 };
 #define KVZ_BORDER_BYTES 512
 
@@ -272,6 +272,7 @@ static const int kPlaneOff[3] = { 0, 4096, 5120 };
 // and 12 KB less LDS means more CTUs in flight.)
 struct RdoqLds {
   i32 ptab[2 * 148];
+  RdoqWaveLds wave[2];            // rdoq_block_wave's hand-over block of the two wavefronts that quantise (luma | U then V)
   // ---- the NxN partition of 8x8 CUs (kvz_hip_intra_cost_model::search_nxn, kvazaar's --pu-depth-intra ..-4): depth 4 of search_cu's recursion (search.c:691, 794,
   // 970-974).  kvazaar gives it a fifth lcu_t; here it is what that level can differ in: the candidate of the one 8x8 CU being tried, its levels, four modes and
   // coded-block flags.  CU info becomes 4x4-granular in one respect only -- the luma mode, which the most probable modes of a neighbour look at.
@@ -1520,13 +1521,14 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     if (t.lw == 5) return s->tb_big + (c == 0 ? 0 : (c == 1 ? 1024 : 1280));  // one buffer, every stage in place
     return s->tb_small + p * 384 + (c == 0 ? 0 : (c == 1 ? 256 : 320));
   }
-  // kvz_rdoq's three per-position cost arrays for plane c of this workgroup (HBM: 24 KB per plane at 32x32)
+  // kvz_rdoq's three per-position cost arrays + one entry per 4x4 group for plane c of this workgroup (HBM: 24.5 KB per plane at 32x32)
+#define KVZ_RDOQ_SCRATCH_DOUBLES (3 * 1024 + 64)
   KVZ_DEV double *rdoq_scratch(int c) const
   {
 #ifdef KVZ_HOSTSIM
-    return F.rdoq_scratch + (long)c * 3 * 1024;
+    return F.rdoq_scratch + (long)c * KVZ_RDOQ_SCRATCH_DOUBLES;
 #else
-    return F.rdoq_scratch + ((long)blockIdx.x * 3 + c) * 3 * 1024;
+    return F.rdoq_scratch + ((long)blockIdx.x * 3 + c) * KVZ_RDOQ_SCRATCH_DOUBLES;
 #endif
   }
   // Entry (k, i) of the 2^l2-point transform matrix
@@ -1763,16 +1765,22 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     // state->cabac, rdo.c:665), and the loop below takes the levels from where it left them.
     if (RDOQ && m->rdoq) {
       KVZ_FOR_THREADS(tid) {
-        const int c = tid == 0 ? 0 : (tid == KVZ_CTU_THREADS - 64 ? 1 : (tid == KVZ_CTU_THREADS - 63 ? 2 : -1));
-        const int l2 = c < 0 ? 0 : tu_log2(t, c);
-        if (l2) {
+        // one wavefront per block (rdoq_block_wave): the one playing threads 0..63 takes the luma block, the next one U then V
+#ifdef KVZ_HOSTSIM
+        const int wv = tid == 0 ? 0 : (tid == 64 ? 1 : -1), lane = 0;
+#else
+        const int wv = tid >> 6, lane = tid & 63;
+#endif
+        for (int c = 0; c < 3; c++) {
+          const int l2 = tu_log2(t, c);
+          if (!l2 || wv != (c ? 1 : 0)) continue;
           const int scan_mode = scan_order(mode, depth);
           i16 *cout = coeff_dst(lv, c, xl, yl);
           RdoqCtx rc{ s->pre[0].s, tb->entropy_bits, m->lambda };
           rc.ptab = rl->ptab;
           // tr_depth = cu->tr_depth - cu->depth: 1 for the 32x32 units of the 64x64 attempt (level 0), 0 otherwise -- plus one for an NxN CU
           // (quant-generic.c:237-238): 2 for the blocks of its PUs (level 4)
-          rdoq_block(rc, m->qp, tbuf(t, 0, c), cout, l2, c ? 2 : 0, scan_mode, lv == 4 ? 2 : (lv == 0 ? 1 : 0), tb->diag8, rdoq_scratch(c));
+          rdoq_block_wave(rc, m->qp, tbuf(t, 0, c), cout, l2, c ? 2 : 0, scan_mode, lv == 4 ? 2 : (lv == 0 ? 1 : 0), tb->diag8, rdoq_scratch(c), &rl->wave[wv], lane);
         }
       }
       KVZ_SYNC();

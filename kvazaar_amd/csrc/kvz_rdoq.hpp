@@ -360,6 +360,292 @@ KVZ_DEV KVZ_RDOQ_NOINLINE void rdoq_block(const RdoqCtx &c, int qp, const i16 *c
   for (int scanpos = best_last_idx_p1; scanpos <= last_scanpos; scanpos++) dest[sc.pos(scanpos)] = 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// The same block by a whole WAVEFRONT (the CTU pass, kvz_ctu.hpp recon_tus).  kvz_rdoq is a chain of decisions, but most of what it computes per coefficient does not
+// depend on the chain at all.  What is serial, and stays on one lane in the reference's order:
+//   * the (c1, c2, go_rice, c1_idx, c2_idx) state inside a 4x4 group, which only positions that can quantise to a non-zero level move or read;
+//   * the double-precision running sums (base_cost, block_uncoded_cost, the group sums): floating-point addition is not associative, so they are added one term at a
+//     time in scan order -- an addition per position, not the ~270 dependent instructions per position of the one-lane routine above;
+//   * the zero-the-group and best-last-position decisions, which compare those sums.
+// What is per-position and goes to sixteen lanes, one 4x4 group at a time (the group's pattern_sig_ctx is known by then): scan position -> block position, level_double,
+// max_abs_level, err^2 * temp, the distortion of the two candidate levels, the significance context and lambda times the price of both its bins, the cost of
+// coding a zero (coded_cost0 + cost of the zero flag) -- for a position whose max_abs_level is 0, the common case, that IS the position's result.  The per-position
+// arrays of the later passes (cost_coeff, cost_coeff0, cost_sig in the caller's scratch) are written and read back sixteen positions at a time; the last-position
+// pass gets its per-position rate terms the same way.  Values travel between the sixteen lanes and the chain lane through a small LDS block per wavefront
+// (RdoqWaveLds): one wavefront's LDS operations execute in order, so no barrier is involved.
+//
+// The host simulation runs the same source: a "lane loop" is a plain loop there (KVZ_WAVE_LANES), the chain runs once.
+struct RdoqWaveLds {
+  double c0v[16], ccv0[16], sig0[16], sig1[16], dhi[16], dlo[16];  // per position of the group in flight: see rdoq_block_wave
+  double ccv[16], csv[16];                                           // what the chain decided for it: coded cost and the significance part of it
+  i32 max_abs[16];
+  i32 lx_bits[32], ly_bits[32];                                      // calc_last_bits (rdo.c:480-509)
+  i16 blkpos[16], level[16];
+  unsigned long long sig_groups;                                     // sig_coeffgroup_flag, bit = raster index of the group (the chain lane writes, everybody reads)
+  int last_scanpos, zeroed, found_last, best_last_idx_p1;
+};
+
+#ifdef KVZ_HOSTSIM
+#define KVZ_WAVE_LANES(l, n) for (int l = 0; l < (n); l++)
+#define KVZ_WAVE_STRIDE(i, n) for (int i = 0; i < (n); i++)
+#define KVZ_WAVE_CHAIN() if (true)
+#define KVZ_WAVE_ORDER()
+#else
+#define KVZ_WAVE_LANES(l, n) for (int l = lane, once_ = 1; once_ && l < (n); once_ = 0)
+#define KVZ_WAVE_STRIDE(i, n) for (int i = lane; i < (n); i += 64)
+#define KVZ_WAVE_CHAIN() if (lane == 0)
+// LDS traffic of one wavefront is executed in program order; this only keeps the compiler from moving accesses across the hand-over points
+#define KVZ_WAVE_ORDER() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+
+// cost3: 3 * w * w + 64 doubles of scratch (cost_coeff | cost_sig | cost_coeff0 | cost_coeffgroup_sig).  Device: every lane of the wavefront calls it, converged, with
+// wavefront-uniform arguments; lane = its index in the wavefront.  Host: one call (lane 0).
+KVZ_DEV void rdoq_block_wave(const RdoqCtx &c, int qp, const i16 *coef, i16 *dest, int log2w, int type /* 0 luma, 2 chroma */, int scan_mode, int tr_depth, const u8 *diag8, double *cost3,
+                             RdoqWaveLds *W, int lane)
+{
+  (void)lane;
+  const int width = 1 << log2w, n = width * width;
+  const int transform_shift = 15 - 8 - log2w;
+  const int qp_scaled = rdoq_scaled_qp(type, qp);
+  const i32 q_bits = 14 + qp_scaled / 6 + transform_shift;
+  const i32 q = rdoq_quant_scale(qp_scaled % 6);
+  double scale = 32768.0;  // scalinglist.c:349-367: err_scale = 2^15 * 2^(-2 transform_shift) / q / q
+  for (int i = 0; i < 2 * transform_shift; i++) scale = scale * 0.5;
+  for (int i = 0; i > 2 * transform_shift; i--) scale = scale * 2.0;
+  const double temp = scale / (double)q / (double)q;
+  double *cost_coeff = cost3, *cost_sig = cost3 + n, *cost_coeff0 = cost3 + 2 * n, *cost_cg_sig = cost3 + 3 * n;
+  const int num_blk_side = width >> 2, cg_num = n >> 4;
+  const RdoqScan sc{ log2w, scan_mode, diag8 };
+  const i32 round = 1 << (q_bits - 1);
+  // ---- quant-generic.c:379-399 find_last_scanpos: the highest scan position that does not quantise to zero; everything above it is zero in dest
+  int my_last = -1;
+  KVZ_WAVE_STRIDE(sp, n) {
+    const u32 blkpos = sc.pos(sp);
+    const i32 ld = imin(iabs((i32)coef[blkpos]) * q, 0x7fffffff - round);
+    if (((ld + round) >> q_bits) > 0) my_last = imax(my_last, sp);
+  }
+#ifndef KVZ_HOSTSIM
+  {  // wavefront maximum (values >= -1)
+    int x = my_last + 1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x = imax(x, __shfl_xor(x, off));
+    my_last = x - 1;
+  }
+#endif
+  const int last_scanpos = my_last;
+  KVZ_WAVE_STRIDE(sp, n) { if (sp > last_scanpos) dest[sc.pos(sp)] = 0; }
+  if (last_scanpos < 0) return;
+  const int cg_last_scanpos = last_scanpos >> 4;
+  // rdo.c:480-509 calc_last_bits: prefix-sum of the "one more" bins; lanes 0 / 1 walk the x / y contexts
+  {
+    const int cb = log2w - 2;
+    const int off = type ? 0 : (cb * 3 + ((cb + 1) >> 2)), shift = type ? cb : ((cb + 3) >> 2);
+    const int bx = (type ? KVZ_HIP_CX_LAST_X_CHROMA : KVZ_HIP_CX_LAST_X_LUMA) + off, by = (type ? KVZ_HIP_CX_LAST_Y_CHROMA : KVZ_HIP_CX_LAST_Y_LUMA) + off;
+    KVZ_WAVE_LANES(l, 2) {
+      i32 *dst = l == 0 ? W->lx_bits : W->ly_bits;
+      const int b0 = l == 0 ? bx : by;
+      i32 bits = 0;
+      int k;
+      for (k = 0; k < rdoq_group_idx(width - 1); k++) {
+        dst[k] = bits + c.price(b0 + (k >> shift), 0);
+        bits += c.price(b0 + (k >> shift), 1);
+      }
+      dst[k] = bits;
+    }
+    KVZ_WAVE_CHAIN() { W->sig_groups = 0; W->found_last = 0; W->best_last_idx_p1 = 0; }
+  }
+  KVZ_WAVE_ORDER();
+  const int cg0 = KVZ_HIP_CX_SIG_CG + type;
+  const int sig_base = type ? KVZ_HIP_CX_SIG_CHROMA : KVZ_HIP_CX_SIG_LUMA;
+  // the chain's state: meaningful on the chain lane only
+  int ctx_set = (last_scanpos > 0 && type == 0) ? 2 : 0, c1 = 1, c2 = 0, go_rice = 0;
+  u32 c1_idx = 0, c2_idx = 0;
+  double base_cost = 0, block_uncoded_cost = 0;
+  for (int cgs = cg_last_scanpos; cgs >= 0; cgs--) {
+    const u32 cg_blkpos = sc.cg(cgs), cg_pos_y = cg_blkpos / num_blk_side, cg_pos_x = cg_blkpos - cg_pos_y * num_blk_side;
+    const unsigned long long sig_groups_in = W->sig_groups;
+    u32 right = 0, lower = 0;  // context.c:339-351 / 315-327
+    if ((int)cg_pos_x < num_blk_side - 1) right = (u32)(sig_groups_in >> (cg_pos_y * num_blk_side + cg_pos_x + 1)) & 1;
+    if ((int)cg_pos_y < num_blk_side - 1) lower = (u32)(sig_groups_in >> ((cg_pos_y + 1) * num_blk_side + cg_pos_x)) & 1;
+    const int pattern_sig_ctx = width == 4 ? -1 : (int)(right + (lower << 1));
+    // ---- per position, sixteen lanes
+    KVZ_WAVE_LANES(k, 16) {
+      const int scanpos = cgs * 16 + k;
+      const u32 blkpos = sc.pos(scanpos);
+      const i32 ld = imin(iabs((i32)coef[blkpos]) * q, 0x7fffffff - round);
+      const i32 max_abs = scanpos > last_scanpos ? -1 : (ld + round) >> q_bits;  // -1: beyond the last position, not part of the block's chain
+      const double err = (double)ld;
+      const double c0 = err * err * temp;
+      const u32 pos_y = blkpos >> log2w, pos_x = blkpos - (pos_y << log2w);
+      const int ctx_sig = scanpos == last_scanpos ? 0 : rdoq_sig_ctx_inc(pattern_sig_ctx, scan_mode, (int)pos_x, (int)pos_y, log2w, type);
+      const double s0 = c.lambda * c.price(sig_base + ctx_sig, 0), s1 = c.lambda * c.price(sig_base + ctx_sig, 1);
+      const double e_hi = (double)(ld - (max_abs * (1 << q_bits))), e_lo = (double)(ld - ((max_abs - 1) * (1 << q_bits)));
+      W->blkpos[k] = (i16)blkpos; W->max_abs[k] = max_abs;
+      W->c0v[k] = c0; W->sig0[k] = s0; W->sig1[k] = s1; W->ccv0[k] = c0 + s0;
+      W->dhi[k] = e_hi * e_hi * temp; W->dlo[k] = e_lo * e_lo * temp;
+    }
+    KVZ_WAVE_ORDER();
+    // ---- the chain: rdo.c:760-840 for this group, then its coded-group decision (rdo.c:842-900)
+    KVZ_WAVE_CHAIN() {
+      double rd_coded_level_and_dist = 0, rd_uncoded_dist = 0, rd_sig_cost = 0, rd_sig_cost_0 = 0;
+      int rd_nnz_before_pos0 = 0;
+      bool any_level = false;
+      for (int k = 15; k >= 0; k--) {
+        const int scanpos = cgs * 16 + k;
+        const i32 max_abs = W->max_abs[k];
+        if (max_abs < 0) continue;
+        const double c0v = W->c0v[k];
+        double ccv, csv;
+        i32 level = 0;
+        block_uncoded_cost += c0v;
+        if (max_abs == 0) { ccv = W->ccv0[k]; csv = W->sig0[k]; }  // kvz_get_coded_level: nothing but zero can be coded here (never the last position)
+        else {
+          // rdo.c:413-459 kvz_get_coded_level on the precomputed pieces
+          const bool last = scanpos == last_scanpos;
+          const int one_ctx = 4 * ctx_set + c1, abs_ctx = ctx_set + c2;
+          double cur_cost_sig = 0;
+          csv = 0;
+          if (!last && max_abs < 3) { csv = W->sig0[k]; ccv = W->ccv0[k]; }
+          else ccv = 1.7e+308;
+          if (!last) cur_cost_sig = W->sig1[k];
+          const i32 min_abs = max_abs > 1 ? max_abs - 1 : 1;
+          for (i32 a = max_abs; a >= min_abs; a--) {
+            double cur = (a == max_abs ? W->dhi[k] : W->dlo[k]) + c.lambda * rdoq_ic_rate(c, (u32)a, one_ctx, abs_ctx, go_rice, c1_idx, c2_idx, type);
+            cur += cur_cost_sig;
+            if (cur < ccv) { level = a; ccv = cur; csv = cur_cost_sig; }
+          }
+          const i32 base_level = c1_idx < 8 ? (2 + (c2_idx < 1)) : 1;
+          if (level >= base_level && level > 3 * (1 << go_rice)) go_rice = imin(go_rice + 1, 4);
+          if (level >= 1) c1_idx++;
+          if (level > 1) { c1 = 0; c2 += (c2 < 2); c2_idx++; }
+          else if (c1 < 3 && c1 > 0 && level) c1++;
+        }
+        W->ccv[k] = ccv; W->csv[k] = csv; W->level[k] = (i16)level;
+        base_cost += ccv;
+        if ((scanpos % 16 == 0) && scanpos > 0) {
+          c2 = 0; go_rice = 0; c1_idx = 0; c2_idx = 0;
+          ctx_set = (scanpos == 16 || type != 0) ? 0 : 2;
+          if (c1 == 0) ctx_set++;
+          c1 = 1;
+        }
+        rd_sig_cost += csv;
+        if (k == 0) rd_sig_cost_0 = csv;
+        if (level) {
+          any_level = true;
+          rd_coded_level_and_dist += ccv - csv;
+          rd_uncoded_dist += c0v;
+          if (k != 0) rd_nnz_before_pos0++;
+        }
+      }
+      unsigned long long sg = sig_groups_in;
+      if (any_level) sg |= 1ull << cg_blkpos;
+      int zeroed = 0;
+      double cg_cost = 0;
+      if (cgs) {
+        const int ctx_sig = (int)(right || lower);
+        if (!any_level) {
+          cg_cost = c.lambda * c.price(cg0 + ctx_sig, 0);
+          base_cost += cg_cost - rd_sig_cost;
+        } else if (cgs < cg_last_scanpos) {
+          if (rd_nnz_before_pos0 == 0) { base_cost -= rd_sig_cost_0; rd_sig_cost -= rd_sig_cost_0; }
+          double cost_zero_cg = base_cost;
+          cg_cost = c.lambda * c.price(cg0 + ctx_sig, 1);
+          base_cost += cg_cost;
+          cost_zero_cg += c.lambda * c.price(cg0 + ctx_sig, 0);
+          cost_zero_cg += rd_uncoded_dist;
+          cost_zero_cg -= rd_coded_level_and_dist;
+          cost_zero_cg -= rd_sig_cost;
+          if (cost_zero_cg < base_cost) {
+            sg &= ~(1ull << cg_blkpos);
+            base_cost = cost_zero_cg;
+            cg_cost = c.lambda * c.price(cg0 + ctx_sig, 0);
+            zeroed = 1;
+          }
+        }
+      } else sg |= 1ull << cg_blkpos;
+      cost_cg_sig[cgs] = cg_cost;  // every group's entry is written here, by the lane that reads it back in the last pass (0 for the first and the last group, rdo.c:729)
+      W->sig_groups = sg;
+      W->zeroed = zeroed;
+    }
+    KVZ_WAVE_ORDER();
+    // ---- the group's entries of the per-position arrays and its levels, sixteen lanes
+    {
+      const int zeroed = W->zeroed;
+      KVZ_WAVE_LANES(k, 16) {
+        const int scanpos = cgs * 16 + k;
+        if (W->max_abs[k] >= 0) {
+          i32 level = W->level[k];
+          double ccv = W->ccv[k], csv = W->csv[k];
+          if (zeroed && level) { level = 0; ccv = W->c0v[k]; csv = 0; }  // rdo.c:888-897: the group is cheaper uncoded
+          cost_coeff[scanpos] = ccv; cost_sig[scanpos] = csv; cost_coeff0[scanpos] = W->c0v[k];
+          dest[W->blkpos[k]] = (i16)level;
+        }
+      }
+    }
+    KVZ_WAVE_ORDER();
+  }
+  // ---- the last position (rdo.c:903-957), intra block: coded block flag of the transform unit
+  double best_cost = 0;
+  KVZ_WAVE_CHAIN() {
+    const int ctx_cbf = type == 0 ? KVZ_HIP_CX_CBF_LUMA + !tr_depth : (tr_depth < 2 ? KVZ_HIP_CX_CBF_CHROMA + tr_depth : KVZ_HIP_CX_CBF_CHROMA_DEEP + imin(tr_depth, 3) - 2);
+    best_cost = block_uncoded_cost + c.lambda * c.price(ctx_cbf, 0);
+    base_cost += c.lambda * c.price(ctx_cbf, 1);
+  }
+  const unsigned long long sig_groups = W->sig_groups;
+  for (int cgs = cg_last_scanpos; cgs >= 0; cgs--) {
+    const u32 cg_blkpos = sc.cg(cgs);
+    const bool coded = (sig_groups >> cg_blkpos) & 1;
+    if (coded) {
+      // per position: the level, the three costs, and for a level lambda times the rate of ending the block there (rdo.c:465-478 get_rate_last)
+      KVZ_WAVE_LANES(k, 16) {
+        const int scanpos = cgs * 16 + k;
+        i32 level = -1;
+        if (scanpos <= last_scanpos) {
+          const u32 blkpos = sc.pos(scanpos);
+          level = dest[blkpos];
+          W->ccv[k] = cost_coeff[scanpos]; W->csv[k] = cost_sig[scanpos]; W->c0v[k] = cost_coeff0[scanpos];
+          if (level) {
+            const u32 pos_y = blkpos >> log2w, pos_x = blkpos - (pos_y << log2w);
+            const u32 px = scan_mode == 2 ? pos_y : pos_x, py = scan_mode == 2 ? pos_x : pos_y;  // SCAN_VER swaps (rdo.c:934)
+            const int gx = rdoq_group_idx((int)px), gy = rdoq_group_idx((int)py);
+            double ui_cost = W->lx_bits[gx] + W->ly_bits[gy];
+            if (gx > 3) ui_cost += (double)((1 << 15) * ((gx - 2) >> 1));
+            if (gy > 3) ui_cost += (double)((1 << 15) * ((gy - 2) >> 1));
+            W->dhi[k] = c.lambda * ui_cost;
+          }
+        }
+        W->max_abs[k] = level;
+      }
+    }
+    KVZ_WAVE_ORDER();
+    KVZ_WAVE_CHAIN() {
+      base_cost -= cost_cg_sig[cgs];
+      if (coded) {
+        for (int k = 15; k >= 0; k--) {
+          const i32 level = W->max_abs[k];
+          if (level < 0) continue;
+          if (level) {
+            const double total = base_cost + W->dhi[k] - W->csv[k];
+            if (total < best_cost) { W->best_last_idx_p1 = cgs * 16 + k + 1; best_cost = total; }
+            if (level > 1) { W->found_last = 1; break; }
+            base_cost -= W->ccv[k];
+            base_cost += W->c0v[k];
+          } else base_cost -= W->csv[k];
+        }
+      }
+    }
+    KVZ_WAVE_ORDER();
+    if (W->found_last) break;
+  }
+  const int best_last_idx_p1 = W->best_last_idx_p1;
+  KVZ_WAVE_STRIDE(sp, last_scanpos + 1) {
+    const u32 blkpos = sc.pos(sp);
+    if (sp < best_last_idx_p1) { const i32 level = dest[blkpos]; dest[blkpos] = (i16)(coef[blkpos] < 0 ? -level : level); }
+    else dest[blkpos] = 0;
+  }
+  KVZ_WAVE_ORDER();
+}
+
 // one item = one block of a batch of equally shaped blocks
 struct RdoqOp {
   const Tables *tb; const u8 *ctx; double lambda; int qp; const i16 *coef; i16 *dest; int log2w, type, scan_mode, tr_depth; double *tmp;

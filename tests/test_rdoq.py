@@ -140,3 +140,71 @@ def test_hip_rdoq_equals_oracle(oracle):
         lib.kvz_hip_rdoq_blocks(qp, lam, ptr(ctx), ptr(coef), ptr(dest), w, typ, scan, trd, len(group))
         exp = b"".join(run_rdoq(fo, fb, (qp, lam, ctx, g[3], w, typ, scan, trd)) for g in group)
         assert dest.tobytes() == exp, (w, typ, scan)
+
+
+QR_RDOQ_ARGS = [C.POINTER(flatapi.QuantParams), C.c_double, flatapi.u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, flatapi.u8p, flatapi.u8p, flatapi.u8p, flatapi.i16p, C.c_int]
+
+
+def _fused_cases(n=36):
+    """(qp, lambda, ctx, width, color, scan, tr_depth, ref block, pred block with stride, early_skip)"""
+    rng = np.random.default_rng(99)
+    out = []
+    for k in range(n):
+        color = int(rng.integers(0, 3))
+        w = int(rng.choice([4, 8, 16, 32] if color == 0 else [4, 8, 16]))
+        qp = int(rng.choice([17, 22, 27, 32, 37]))
+        stride = w + int(rng.choice([0, 8, 24]))
+        pred = rng.integers(0, 256, (w, stride)).astype(np.uint8)
+        noise = rng.normal(0, float(rng.choice([1.5, 6, 25])), (w, stride))
+        ref = np.clip(pred.astype(np.float64) + noise + (8 if k % 5 == 0 else 0), 0, 255).astype(np.uint8)
+        scan = int(rng.integers(0, 3)) if w <= 8 else 0
+        trd = 2 if (w == 4 and k % 2) else int(rng.integers(0, 2))
+        out.append((qp, 0.57 * 2 ** ((qp - 12) / 3.0), A(rng.integers(0, 126, 160).astype(np.uint8)), w, color, scan, trd, A(ref.reshape(-1)), A(pred.reshape(-1)), stride, int(k % 7 == 3)))
+    return out
+
+
+def _fused_expected(oracle, fb, case):
+    """quant-generic.c:198-292 with the rdoq leg, from the oracle's pieces: residual, transform, kvz_oracle_rdoq, dequant, inverse, reconstruction"""
+    qp, lam, ctx, w, color, scan, trd, ref, pred, stride, early_skip = case
+    r2, p2 = ref.reshape(w, stride)[:, :w].astype(np.int16), pred.reshape(w, stride)[:, :w].astype(np.int16)
+    resid = A((r2 - p2).reshape(-1))
+    idx = (4 if color == 0 else 0) if w == 4 else {8: 1, 16: 2, 32: 3}[w]
+    coeff, levels = A(np.zeros(w * w, np.int16)), A(np.full(w * w, 77, np.int16))
+    oracle.transform(idx, 8, ptr(resid), ptr(coeff))
+    fo = oracle.lib.kvz_oracle_rdoq
+    fo.restype, fo.argtypes = None, RDOQ_ARGS
+    fo(qp, lam, ptr(ctx), fb, ptr(coeff), ptr(levels), w, 0 if color == 0 else 2, scan, trd)
+    rec = p2.astype(np.uint8).copy()
+    has = bool(levels.any())
+    if has and not early_skip:
+        qpar = flatapi.QuantParams(qp=qp, bitdepth=8, slice_is_intra=1, cu_is_intra=1)
+        deq, res2 = A(np.zeros(w * w, np.int16)), A(np.zeros(w * w, np.int16))
+        oracle.dequant(C.byref(qpar), ptr(levels), ptr(deq), w, w, 0 if color == 0 else (2 if color == 1 else 3), 1)
+        oracle.transform(5 + idx, 8, ptr(deq), ptr(res2))
+        rec = np.clip((res2.reshape(w, w) + p2).astype(np.int16), 0, 255).astype(np.uint8)
+    return int(has), levels.tobytes(), rec.tobytes()
+
+
+def _run_fused(fn, case):
+    qp, lam, ctx, w, color, scan, trd, ref, pred, stride, early_skip = case
+    qpar = flatapi.QuantParams(qp=qp, bitdepth=8, slice_is_intra=1, cu_is_intra=1)
+    rec, levels = A(np.zeros(w * stride, np.uint8)), A(np.zeros(w * w, np.int16))
+    fn.restype, fn.argtypes = C.c_int, QR_RDOQ_ARGS
+    has = fn(C.byref(qpar), lam, ptr(ctx), trd, w, color, scan, stride, stride, ptr(ref), ptr(pred), ptr(rec), ptr(levels), early_skip)
+    return int(has), levels.tobytes(), rec.reshape(w, stride)[:, :w].tobytes()
+
+
+def test_hostsim_fused_quantize_residual_rdoq(oracle, hostsim):
+    fb = _fbits()
+    for case in _fused_cases():
+        assert _run_fused(hostsim.lib.kvz_hostsim_quantize_residual_rdoq, case) == _fused_expected(oracle, fb, case), case[:7]
+
+
+@pytest.mark.gpu
+def test_hip_fused_quantize_residual_rdoq(oracle):
+    """kvz_hip_quantize_residual_rdoq (what the drop-in's quantize_residual calls with --rdoq): one round trip == the oracle's chain of the same steps"""
+    import kvazaar_amd
+    lib = kvazaar_amd.load_library()
+    fb = _fbits()
+    for case in _fused_cases():
+        assert _run_fused(lib.kvz_hip_quantize_residual_rdoq, case) == _fused_expected(oracle, fb, case), case[:7]
