@@ -40,29 +40,41 @@ def _stale():
     return not os.path.exists(LIB_PATH) or any(_unit_stale(n) or os.path.getmtime(os.path.join(OBJ_DIR, n + ".o")) > os.path.getmtime(LIB_PATH) for n, _, _ in UNITS)
 
 
-def build_library(force=False, verbose=False):
-    """Compile every HIP source into kvazaar_amd/lib/libkvz_hip.so.  Returns the library path."""
-    if os.environ.get("KVZ_HIP_LIB") or (not force and not _stale()):
-        return LIB_PATH
-    os.makedirs(OBJ_DIR, exist_ok=True)
+def _compile_and_link(obj_dir, lib_path, extra_flags, only_stale, verbose):
+    os.makedirs(obj_dir, exist_ok=True)
 
     def compile_unit(unit):
         name, src, defs = unit
-        if not force and not _unit_stale(name):
+        if only_stale and not _unit_stale(name):
             return
-        obj = os.path.join(OBJ_DIR, name + ".o")
-        cmd = [HIPCC] + FLAGS + defs + ["-c", "-MD", "-MF", os.path.join(OBJ_DIR, name + ".d"), "-o", obj, os.path.join(CSRC, src)]
+        obj = os.path.join(obj_dir, name + ".o")
+        cmd = [HIPCC] + FLAGS + defs + list(extra_flags) + ["-c", "-MD", "-MF", os.path.join(obj_dir, name + ".d"), "-o", obj, os.path.join(CSRC, src)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
 
     with ThreadPoolExecutor(max_workers=min(len(UNITS), os.cpu_count() or 1)) as pool:
         list(pool.map(compile_unit, UNITS))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + [os.path.join(OBJ_DIR, n + ".o") for n, _, _ in UNITS]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + [os.path.join(obj_dir, n + ".o") for n, _, _ in UNITS]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return lib_path
+
+
+def build_library(force=False, verbose=False):
+    """Compile every HIP source into kvazaar_amd/lib/libkvz_hip.so.  Returns the library path."""
+    if os.environ.get("KVZ_HIP_LIB") or (not force and not _stale()):
+        return LIB_PATH
+    return _compile_and_link(OBJ_DIR, LIB_PATH, [], not force, verbose)
+
+
+def build_variant(name, extra_flags, verbose=False):
+    """Developer builds with extra compiler flags (-DKVZ_CTU_PROFILE, occupancy experiments ...): kvazaar_amd/lib/variants/libkvz_hip_<name>.so, always rebuilt.
+    Use with KVZ_HIP_LIB=<path> (bench.py, tools/)."""
+    vdir = os.path.join(LIB_DIR, "variants")
+    os.makedirs(vdir, exist_ok=True)
+    return _compile_and_link(os.path.join(vdir, "obj_" + name), os.path.join(vdir, f"libkvz_hip_{name}.so"), extra_flags, False, verbose)
 
 
 TOOLS = {"valu_issue_bench": os.path.join(os.path.dirname(PKG), "tools", "valu_issue_bench.hip")}

@@ -114,7 +114,7 @@ namespace kvz {
 // Optional in-kernel timeline (build with -DKVZ_CTU_PROFILE): lane 0 of every workgroup adds the shader-clock cycles
 // spent since the previous mark to a per-category counter in HBM.  Categories are the KVZ_P_* constants.
 enum { KVZ_P_INIT = 0, KVZ_P_REFS, KVZ_P_PRED35, KVZ_P_SATD, KVZ_P_SELECT, KVZ_P_RPRED, KVZ_P_FDCT, KVZ_P_QUANT, KVZ_P_IDCT, KVZ_P_RECON,
-       KVZ_P_COST, KVZ_P_COPY, KVZ_P_FINISH, KVZ_P_MISC, KVZ_P_COEFFBITS, KVZ_P_COUNT };
+       KVZ_P_COST, KVZ_P_COPY, KVZ_P_FINISH, KVZ_P_MISC, KVZ_P_COEFFBITS, KVZ_P_RDOQ, KVZ_P_COUNT };
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
 #define KVZ_PROF(cat) prof_mark(cat)
 #define KVZ_PROF_SYNC(cat) do { KVZ_SYNC(); prof_mark(cat); } while (0)  /* a mark where the program has no barrier of its own */
@@ -272,7 +272,7 @@ static const int kPlaneOff[3] = { 0, 4096, 5120 };
 // and 12 KB less LDS means more CTUs in flight.)
 struct RdoqLds {
   i32 ptab[2 * 148];
-  RdoqWaveLds wave[2];            // rdoq_block_wave's hand-over block of the two wavefronts that quantise (luma | U then V)
+  u8 diag8[64];                   // Tables::diag8 (the group order of a 32x32 block) next to the lanes that index it per position
   // ---- the NxN partition of 8x8 CUs (kvz_hip_intra_cost_model::search_nxn, kvazaar's --pu-depth-intra ..-4): depth 4 of search_cu's recursion (search.c:691, 794,
   // 970-974).  kvazaar gives it a fifth lcu_t; here it is what that level can differ in: the candidate of the one 8x8 CU being tried, its levels, four modes and
   // coded-block flags.  CU info becomes 4x4-granular in one respect only -- the luma mode, which the most probable modes of a neighbour look at.
@@ -1774,16 +1774,24 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         for (int c = 0; c < 3; c++) {
           const int l2 = tu_log2(t, c);
           if (!l2 || wv != (c ? 1 : 0)) continue;
-          const int scan_mode = scan_order(mode, depth);
-          i16 *cout = coeff_dst(lv, c, xl, yl);
-          RdoqCtx rc{ s->pre[0].s, tb->entropy_bits, m->lambda };
-          rc.ptab = rl->ptab;
+          // the levels go to LDS whatever the work-tree level: CUs whose levels live in HBM (8x8 CUs, the units of the 64x64 attempt) have a staging copy
+          // for the coefficient cost anyway (levels_lds); the loop below moves them on
+          i16 *cout = (lv == 3 || lv == 0) ? levels_lds(lv, c) : coeff_dst(lv, c, xl, yl);
+          RdoqWaveArgs ra;
+          ra.ptab = (KVZ_LDS_PTR(const i32))rl->ptab; ra.coef = (KVZ_LDS_PTR(const i16))tbuf(t, 0, c); ra.dest = (KVZ_LDS_PTR(i16))cout;
+          ra.diag8 = (KVZ_LDS_PTR(const u8))rl->diag8; ra.cost3 = rdoq_scratch(c); ra.lambda = m->lambda; ra.qp = m->qp; ra.log2w = l2; ra.type = c ? 2 : 0;
+          ra.scan_mode = scan_order(mode, depth);
           // tr_depth = cu->tr_depth - cu->depth: 1 for the 32x32 units of the 64x64 attempt (level 0), 0 otherwise -- plus one for an NxN CU
           // (quant-generic.c:237-238): 2 for the blocks of its PUs (level 4)
-          rdoq_block_wave(rc, m->qp, tbuf(t, 0, c), cout, l2, c ? 2 : 0, scan_mode, lv == 4 ? 2 : (lv == 0 ? 1 : 0), tb->diag8, rdoq_scratch(c), &rl->wave[wv], lane);
+          ra.tr_depth = lv == 4 ? 2 : (lv == 0 ? 1 : 0);
+#if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
+          ra.prof = F.prof + 2 * KVZ_P_COUNT;
+#endif
+          rdoq_block_wave(ra, lane);
         }
       }
       KVZ_SYNC();
+      KVZ_PROF(KVZ_P_RDOQ);
     }
     KVZ_FOR_THREADS(tid) {
       for (int c = 0; c < 3; c++) {
@@ -1801,14 +1809,14 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
           const int cf = src[e];
           // |cf| * q + add < 2^31 for 8-bit flat lists (32767 * 26214 + (171 << 18)), so 32-bit arithmetic is exact
           int level;
-          if (RDOQ && m->rdoq) level = cout[e];
+          if (RDOQ && m->rdoq) { level = (stage ? stage : cout)[e]; if (stage) cout[e] = (i16)level; }  // kvz_rdoq left them in LDS (above)
           else {
             level = (int)(((u32)iabs(cf) * (u32)qf.flat_q + (u32)qf.add) >> qf.q_bits);
             if (cf < 0) level = -level;
             level = iclip(-32768, 32767, level);
             cout[e] = (i16)level;
           }
-          if (stage) stage[e] = (i16)level;
+          if (stage && !(RDOQ && m->rdoq)) stage[e] = (i16)level;
           int a = iabs(level);
           nz += a != 0;
           if (a > 3) a = 3;
@@ -2773,6 +2781,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     if (RDOQ && m->rdoq) {  // kvz_rdoq prices on state->cabac's contexts as they stand now (pre[0]): both bins of every context, once per CTU
       KVZ_FOR_THREADS(tid) {
         for (int v = tid; v < 2 * KVZ_CX_COUNT; v += KVZ_CTU_THREADS) rl->ptab[v] = (i32)(s->entropy_fbits[s->pre[0].s[v >> 1] ^ (v & 1)] * 32768.0f);
+        if (tid < 64) rl->diag8[tid] = tb->diag8[tid];
       }
       KVZ_SYNC();
     }

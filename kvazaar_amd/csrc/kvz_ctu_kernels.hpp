@@ -136,12 +136,12 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> __global__ void __lau
   ticket_loop<CABAC, S32, RDOQ>(F, model, tb, sched);
 }
 #endif
-// --rdoq: kvz_rdoq is a long double-precision routine run by one lane per plane; at 128 VGPRs its many inlined copies spill by the thousand, so this
-// instantiation trades occupancy for registers: exactly KVZ_RDOQ_WAVES_PER_EU wavefronts per SIMD (3 = 168 VGPRs, 6 workgroups per CU).  Measured at 1080p QP 27
-// (the pass waits on LDS / memory three quarters of the time, so residency counts until spills take over): 1 wavefront per SIMD (512 registers) 22.5 k CTUs/s,
-// 2 (256) 41.0 k, 3 (168) 54.3 k, 4 (128, thousands of spills) 17.5 k
+// --rdoq / NxN partitions: its own register budget.  Round 3: kvz_rdoq runs as ONE out-of-line wavefront-cooperative routine (kvz_rdoq.hpp rdoq_block_wave), so the
+// instantiation no longer needs the 168 registers the inlined one-lane routine did: 128 registers = 4 wavefronts per SIMD, and with 23.4 KB of LDS seven workgroups
+// per CU.  Measured at 1080p QP 27 `medium-pu13`: 3 wavefronts per SIMD 130.4 k CTUs/s, 4: 135.4 k (141.4 k with 320 pictures in flight) -- the pass is still partly
+// latency-bound (profiles/r03_*).  (Round 2, one lane per block: 1 wavefront per SIMD 22.5 k, 2: 41.0 k, 3: 54.3 k, 4 with thousands of spills: 17.5 k.)
 #ifndef KVZ_RDOQ_WAVES_PER_EU
-#define KVZ_RDOQ_WAVES_PER_EU 3
+#define KVZ_RDOQ_WAVES_PER_EU 4
 #endif
 __global__ void __launch_bounds__(KVZ_CTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_RDOQ_WAVES_PER_EU, KVZ_RDOQ_WAVES_PER_EU))) intra_ctu_ticket_kernel_rdoq(const CtuFrames F, const CtuModel model, const Tables *tb, const CtuSched sched)
 #if !KVZ_CTU_KERNEL_BODIES || (defined(KVZ_CTU_KERNEL_TU) && KVZ_CTU_KERNEL_TU != 5)

@@ -9,16 +9,18 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-NAMES = ["init", "refs", "pred35+replay", "satd", "select", "recon_pred", "fdct", "quant", "idct", "recon", "cost", "copy", "finish", "misc", "coeffbits"]
+NAMES = ["init", "refs", "pred35+replay", "satd", "select", "recon_pred", "fdct", "quant", "idct", "recon", "cost", "copy", "finish", "misc", "coeffbits", "rdoq"]
+
+RDOQ_SECTIONS = ["setup / last position / final", "64 positions (pass 1)", "group: flag prices", "group: chain", "group: decision", "group: levels out", "64 positions (last pass)", "last-position walk"]
 
 
 def main():
-    out = os.path.join(ROOT, "kvazaar_amd", "lib", "variants", "libkvz_hip_prof.so")  # built ahead (cross-compiles without a GPU) or on the box
-    os.makedirs(os.path.dirname(out), exist_ok=True)
-    srcs = [os.path.join(ROOT, "kvazaar_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "kvazaar_amd", "csrc"))]
-    if not os.path.exists(out) or any(os.path.getmtime(f) > os.path.getmtime(out) for f in srcs):
-      subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                           "-DKVZ_CTU_PROFILE", *os.environ.get("KVZ_PROFILE_FLAGS", "").split(), "-o", out, os.path.join(ROOT, "kvazaar_amd", "csrc", "kvz_hip.hip")])
+    out = os.path.join(ROOT, "kvazaar_amd", "lib", "variants", "libkvz_hip_prof.so")  # built ahead (cross-compiles without a GPU): python tools/ctu_profile.py --build
+    if "--build" in sys.argv or not os.path.exists(out):
+        from kvazaar_amd import build
+        build.build_variant("prof", ["-DKVZ_CTU_PROFILE"] + os.environ.get("KVZ_PROFILE_FLAGS", "").split())
+        if "--build" in sys.argv:
+            return
     import numpy as np
     import ctu_common as cc
     import bench
@@ -31,23 +33,32 @@ def main():
         model.search_32x32 = 1
     if os.environ.get("KVZ_PROFILE_RDOQ"):    # --rdoq (preset medium without NxN)
         model.coeff_cabac = model.search_32x32 = model.rdoq = 1
+    if os.environ.get("KVZ_PROFILE_NXN"):     # + the NxN partition: preset medium
+        model.search_nxn = 1
     frames = bench.synth_frames(1920, 1080, 4, 1)
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     b = cc.HipBatch(lib, 1920, 1080, n)
     for i in range(n):
         b.upload(i, frames[i % len(frames)])
     b.run(model)
-    buf = (C.c_ulonglong * 32)()
+    buf = (C.c_ulonglong * 40)()
+    n_cat = len(NAMES)
     lib.kvz_hip_batch_profile.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
-    lib.kvz_hip_batch_profile(b.handle, buf, 32)
+    lib.kvz_hip_batch_profile(b.handle, buf, 40)
     b.run(model)
-    lib.kvz_hip_batch_profile(b.handle, buf, 32)
+    lib.kvz_hip_batch_profile(b.handle, buf, 40)
     tot = sum(buf[:len(NAMES)])
     nctu = n * 510
     print(f"kernel_ms {b.kernel_ms():.2f}  cycles/CTU {tot / nctu:.0f}")
     for i, nm in enumerate(NAMES):
         print(f"{nm:11s} {buf[i] / nctu:10.0f} cyc/CTU  {100.0 * buf[i] / tot:5.1f}%  {buf[len(NAMES) + i] / nctu:7.1f} marks/CTU")
+    rq = [buf[2 * len(NAMES) + i] for i in range(8)]
+    if sum(rq):
+        print("rdoq_block_wave, luma blocks (cycles of the wavefront's own clock per CTU):")
+        for i, nm in enumerate(RDOQ_SECTIONS):
+            print(f"  {nm:28s} {rq[i] / nctu:10.0f}  {100.0 * rq[i] / sum(rq):5.1f}%")
 
 
 if __name__ == "__main__":
     main()
+
