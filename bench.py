@@ -258,20 +258,23 @@ def host_cpu_facts():
     return facts
 
 
-def exchange_leg(dist, torch, rank, world, reps=20):
+def exchange_leg(dist, torch, rank, world, lib, reps=50):
     """The sharded INTER configuration's one collective, measured on its own: per picture every rank contributes the final
-    reconstruction of its tiles of a 3840x2160 --tiles 4x2 picture and receives everybody else's (kvazaar_amd/sharding.py
-    allgather_reference_frame: all_gather_into_tensor over RCCL + paste into the full reference frame).  Tile contents are synthetic
-    device buffers here (the inter CTU pass that would produce them is not part of this round); checked by an all-reduced byte sum."""
+    reconstruction of its tiles of a 3840x2160 --tiles 4x2 picture and receives everybody else's (kvazaar_amd/sharding.py ReferenceExchange:
+    persistent buffers, all_gather_into_tensor over RCCL, ONE paste launch into the full reference frame).  Tile contents are synthetic
+    device buffers written into the send slots (the inter CTU pass that would produce them is not part of this round); checked by an all-reduced byte sum."""
     from kvazaar_amd import sharding
     w, h = 3840, 2160
     plan = sharding.exchange_plan(w, h, 4, 2, world)
-    mine = sharding.tiles_of_rank(len(plan["tiles"]), rank, world)
+    ex = sharding.ReferenceExchange(dist, plan, rank, world, w, h, torch.device("cuda"), lib)
     g = torch.Generator(device="cuda").manual_seed(1000 + rank)
-    local = {ti: torch.randint(0, 256, (plan["tiles"][ti][2] * plan["tiles"][ti][3] * 3 // 2,), dtype=torch.uint8, device="cuda", generator=g) for ti in mine}
-    frame = torch.empty(w * h * 3 // 2, dtype=torch.uint8, device="cuda")
-    sharding.allgather_reference_frame(dist, plan, rank, world, local, w, h, frame)  # warm-up (RCCL channel setup)
-    own = torch.tensor([sum(int(t.sum(dtype=torch.int64)) for t in local.values())], dtype=torch.int64, device="cuda")
+    own_sum = 0
+    for k in range(len(ex.mine)):
+        slot = ex.send_slot(k)
+        slot.copy_(torch.randint(0, 256, (slot.numel(),), dtype=torch.uint8, device="cuda", generator=g))
+        own_sum += int(slot.sum(dtype=torch.int64))
+    frame = ex.exchange()  # warm-up (RCCL channel setup)
+    own = torch.tensor([own_sum], dtype=torch.int64, device="cuda")
     if dist is not None:
         dist.all_reduce(own)
     ok = int(frame.sum(dtype=torch.int64)) == int(own.item())
@@ -280,16 +283,17 @@ def exchange_leg(dist, torch, rank, world, reps=20):
         dist.barrier()
     t = time.perf_counter()
     for _ in range(reps):
-        sharding.allgather_reference_frame(dist, plan, rank, world, local, w, h, frame)
+        ex.exchange()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     s = (time.perf_counter() - t) / reps
     recv = plan["recv_bytes_per_rank"]
-    return {"workload": "3840x2160 --tiles 4x2 reference-frame exchange: all_gather_into_tensor of the ranks' reconstructed tiles + paste (one per inter picture)",
+    return {"workload": "3840x2160 --tiles 4x2 reference-frame exchange: all_gather_into_tensor of the ranks' reconstructed tiles + one paste launch (one per inter picture)",
             "ms_per_picture": s * 1e3, "recv_bytes_per_rank": recv, "recv_GBps_per_rank": recv / s / 1e9, "frame_bytes": plan["frame_bytes"], "assembled_ok": ok,
             "xgmi_expected_us": recv / 153e9 * 1e6 if world > 1 else 0.0,
-            "note": "expected = received bytes / 153 GB/s (one xGMI link, ring all-gather is per-link bound); measured includes the per-tile paste kernels and launch overhead"}
+            "note": "expected = received bytes / 153 GB/s (one xGMI link, ring all-gather is per-link bound); measured = the collective + the paste kernel (12.4 MB written "
+                    "per picture) + two launches; at world = 1 nothing is received: the figure is the paste alone"}
 
 
 def build_batches(args, lib, rank, world, width, height, frames, tiles_arg, HipBatch):
@@ -331,7 +335,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--frames", type=int, default=1536, help="frames per GPU and step (the batch resident in HBM)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU and step (the batch resident in HBM); default 1536, with --tiles: pictures of the whole job -- "
+                    "3072 (every GPU of an 8-GPU node then still holds 3072 serial tile chains, what saturates it; 231 GB at one GPU) or 384 with --wpp")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames generated on the host; the batch cycles through them")
     ap.add_argument("--qp", type=int, default=22)
     ap.add_argument("--preset", default="ultrafast", choices=sorted(PRESETS), help="which of kvazaar's all-intra searches the pass runs (the headline metric is ultrafast): "
@@ -348,6 +353,8 @@ def main():
     ap.add_argument("--tiles", default="", help="COLSxROWS: strong-scaling variant (BASELINE config 5): --frames pictures in total, cut into kvazaar's "
                                                 "uniform tiles, the tiles dealt to the ranks; every tile is an independent sub-picture (SURVEY.md 8e)")
     args = ap.parse_args()
+    if args.frames is None:
+        args.frames = 1536 if not args.tiles else (384 if args.wpp else 3072)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -379,6 +386,16 @@ def main():
         return m
 
     model = model_for(args.qp, args.tiles)
+    # HBM the batch needs on this rank: source + reconstruction (1.5 B / pixel each) + two coefficient blocks (3 B / pixel each) + borders and CU maps
+    per_picture = args.width * args.height * 9.3
+    pictures_here = args.frames if not args.tiles else -(-args.frames // world)
+    free_b, _total_b = torch.cuda.mem_get_info()
+    frames_asked = args.frames
+    if pictures_here * per_picture > 0.9 * free_b:
+        fit = int(0.9 * free_b / per_picture)
+        args.frames = fit if not args.tiles else fit * world
+        if rank == 0:
+            print(f"bench: {frames_asked} pictures need {pictures_here * per_picture / 1e9:.0f} GB per GPU, {free_b / 1e9:.0f} GB free: running {args.frames}", file=sys.stderr)
     batches, distinct, ctus_per_frame, job_ctus_per_step = build_batches(args, lib, rank, world, args.width, args.height, args.frames, args.tiles, HipBatch)
 
     kernel_ms = []
@@ -424,7 +441,7 @@ def main():
     exchange = None
     if not args.no_extra:
         try:
-            exchange = exchange_leg(dist, torch, rank, world)
+            exchange = exchange_leg(dist, torch, rank, world, lib)
         except Exception as e:  # auxiliary: never take the headline down
             exchange = {"error": repr(e)}
 

@@ -73,6 +73,10 @@ int  kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *mode
  * the GPU): the batch's results are then invalid and every later sync / download / checksum call of the batch reports -1 too.
  * HIP runtime failures (no device, out of memory, launch failure) stay fatal, as in the per-call path. */
 int  kvz_hip_batch_sync(kvz_hip_batch *b);
+/* After a pass reported -1: once a hand-off wait has timed out the rest of that pass only drains its tickets (no CTU is searched on stale neighbour data, nothing
+ * waits again) and the batch stays invalid -- sticky, so that no later call can mistake its contents for results -- until this call clears the condition.  The
+ * pictures uploaded to the batch are untouched: the caller may simply run the pass again.  Returns 0. */
+int  kvz_hip_batch_reset(kvz_hip_batch *b);
 /* Device time of the launches of the last kvz_hip_intra_frames call, from HIP events recorded on the batch's own
  * stream around the launch sequence (milliseconds); call after kvz_hip_batch_sync(). */
 float kvz_hip_batch_last_kernel_ms(kvz_hip_batch *b);

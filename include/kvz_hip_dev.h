@@ -127,6 +127,11 @@ void kvz_hip_dev_picture_checksums(const uint8_t *frames, int width, int height,
  * (kvz_array_md5, nal-generic.c:41-55).  One serial chain per plane, one lane each: throughput comes from the number of planes in flight. */
 void kvz_hip_dev_picture_md5(const uint8_t *frames, int width, int height, int n_frames, uint8_t *out);
 
+/* Assembles a planar 4:2:0 picture from tile pictures: `tiles` (HOST memory) holds n records (x, y, w, h, slot); tile i's planar Y|U|V picture of w x h lies at
+ * slots + slot * slot_bytes (device memory) and is pasted at (x, y) of the width x height frame (device memory).  One launch on `stream` (a hipStream_t; NULL = the
+ * calling thread's stream of this library).  n <= 64.  Used by the reference-frame exchange of the tile-sharded inter configuration (kvazaar_amd/sharding.py). */
+int kvz_hip_dev_paste_tiles(uint8_t *frame, int width, int height, const uint8_t *slots, long slot_bytes, const int32_t *tiles, int n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -193,13 +193,23 @@ static picture_result *picture_of(const encoder_state_t *state)
       /* the gather window: until half of the pictures kvazaar keeps in flight (--owf + 1) are pending -- the other half is then being entropy-coded
        * on the host while this pass runs -- but never longer than KVZ_HIP_BATCH_WINDOW_US (default 40 ms, half a lone picture's pass) */
       const int max_n = env_int("KVZ_HIP_BATCH_MAX", 64) < 64 ? env_int("KVZ_HIP_BATCH_MAX", 64) : 64;
-      const int in_flight = state->encoder_control->cfg.owf + 1, want = in_flight / 2 < max_n ? (in_flight / 2 > 0 ? in_flight / 2 : 1) : max_n;
+      /* ... and never for more pictures than can register at all: every picture in the window is brought here by a worker thread that then blocks on the
+       * condition variable below, so with few workers (--threads 1 / 2) the others cannot arrive; tiles are pictures of their own.  The wait also ends as
+       * soon as nothing new has registered for 1 ms: a full window is only paid while pictures keep arriving. */
+      const kvz_config *cfg = &state->encoder_control->cfg;
+      const int tiles = cfg->tiles_width_count * cfg->tiles_height_count, in_flight = (cfg->owf + 1) * (tiles > 0 ? tiles : 1);
+      const int workers = cfg->threads > 0 ? cfg->threads : 1;
+      int want = in_flight / 2 > 0 ? in_flight / 2 : 1;
+      if (want > workers) want = workers;
+      if (want > max_n) want = max_n;
       const int window_us = env_int("KVZ_HIP_BATCH_WINDOW_US", 40000);
-      for (int waited = 0;; waited += 500) {
+      for (int waited = 0, last_pending = -1, quiet_us = 0;; waited += 500) {
         pthread_mutex_lock(&g_lock);
         int pending = 0;
         for (int i = 0; i < g_n_slots; i++) pending += g_slots[i]->state == SLOT_PENDING;
-        if (pending >= want || waited >= window_us) break;  /* leaves with the lock held */
+        quiet_us = pending == last_pending ? quiet_us + 500 : 0;
+        last_pending = pending;
+        if (pending >= want || waited >= window_us || quiet_us >= 1000) break;  /* leaves with the lock held */
         pthread_mutex_unlock(&g_lock);
         usleep(500);
       }

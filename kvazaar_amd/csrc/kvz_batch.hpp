@@ -382,6 +382,15 @@ int kvz_hip_batch_sync(kvz_hip_batch *b)
   return kvz::batch_check(b);
 }
 
+int kvz_hip_batch_reset(kvz_hip_batch *b)
+{
+  kvz::batch_enter(b);
+  KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+  KVZ_HIP_CHECK(hipMemset(b->d_error, 0, sizeof(unsigned)));
+  b->failed = 0;
+  return 0;
+}
+
 /* cycle counters of a -DKVZ_CTU_PROFILE build (all zero otherwise); reading resets them */
 int kvz_hip_batch_profile(kvz_hip_batch *b, unsigned long long *out, int n)
 {

@@ -103,18 +103,25 @@ template <bool CABAC, bool S32, bool RDOQ> __device__ __forceinline__ void ticke
     const int frame = item >> 16, y = (item >> 8) & 0xff, x = item & 0xff;
     if (threadIdx.x == 0) {
       unsigned *done = sched.done + (long)frame * ctus;
-      if (x > 0) wait_done(&done[y * F.wc + x - 1], sched.epoch, sched.error, sched.wait_ticks);
-      if (y > 0) wait_done(&done[(y - 1) * F.wc + (x + 1 < F.wc ? x + 1 : x)], sched.epoch, sched.error, sched.wait_ticks);  // above-right implies above and above-left
-      if (sched.no_wpp && x == 0 && y > 0) wait_done(&done[(y - 1) * F.wc + F.wc - 1], sched.epoch, sched.error, sched.wait_ticks);  // its contexts come from there
+      // a hand-off that timed out anywhere (this launch or an earlier one: the word is sticky until kvz_hip_batch_reset) poisons the pass: from then on
+      // tickets are only drained -- no search on stale neighbour data, no further 30-second waits -- and every CTU still publishes its flag
+      bool ok = __hip_atomic_load(sched.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+      if (ok && x > 0) ok = wait_done(&done[y * F.wc + x - 1], sched.epoch, sched.error, sched.wait_ticks);
+      if (ok && y > 0) ok = wait_done(&done[(y - 1) * F.wc + (x + 1 < F.wc ? x + 1 : x)], sched.epoch, sched.error, sched.wait_ticks);  // above-right implies above and above-left
+      if (ok && sched.no_wpp && x == 0 && y > 0) ok = wait_done(&done[(y - 1) * F.wc + F.wc - 1], sched.epoch, sched.error, sched.wait_ticks);  // its contexts come from there
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      shared.best_mode = ok ? 1 : 0;
     }
     __syncthreads();
-    CtuProgramT<CABAC, S32, RDOQ> p;
-    p.m = &m; p.tb = tb; p.F = F; p.s = &shared;
-    if constexpr (RDOQ) { __shared__ RdoqLds rdoq_lds; p.rl = &rdoq_lds; }
-    p.frame = frame; p.cx = x * 64; p.cy = y * 64;
-    p.lane_rot = (t * 64) & (KVZ_CTU_THREADS - 1);
-    p.run();
+    const bool run_it = shared.best_mode != 0;  // uniform.  (run() first writes the field behind several barriers of its own: no lane can still be reading it here)
+    if (run_it) {
+      CtuProgramT<CABAC, S32, RDOQ> p;
+      p.m = &m; p.tb = tb; p.F = F; p.s = &shared;
+      if constexpr (RDOQ) { __shared__ RdoqLds rdoq_lds; p.rl = &rdoq_lds; }
+      p.frame = frame; p.cx = x * 64; p.cy = y * 64;
+      p.lane_rot = (t * 64) & (KVZ_CTU_THREADS - 1);
+      p.run();
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its stores (reconstruction, CU info, coefficients)
     __syncthreads();
     if (threadIdx.x == 0) {

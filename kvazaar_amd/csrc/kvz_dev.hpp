@@ -926,6 +926,30 @@ static DevTimer &dev_timer() { static thread_local DevTimer t; return t; }
 
 }  // namespace kvz
 
+// ---- assembling a picture from tile pictures (the receive side of the sharded inter configuration's exchange, kvazaar_amd/sharding.py) ----
+// Every tile arrives as its own planar Y|U|V picture in a fixed-size slot; one launch pastes all of them into the full planar frame.  One workgroup per
+// (tile, row of any plane): a row is w or w/2 contiguous bytes on both sides, copied sixteen bytes per lane where both ends are 16-byte aligned.
+namespace kvz {
+struct PasteTable { int n; int x[64], y[64], w[64], h[64], slot[64]; };
+__global__ void __launch_bounds__(256) dev_paste_tiles_kernel(u8 *frame, const int W, const int H, const u8 *slots, const long slot_bytes, const PasteTable tb)
+{
+  const int ti = blockIdx.y;
+  const int x = tb.x[ti], y = tb.y[ti], w = tb.w[ti], h = tb.h[ti];
+  const u8 *src0 = slots + (long)tb.slot[ti] * slot_bytes;
+  for (int row = blockIdx.x; row < 2 * h; row += gridDim.x) {  // h luma rows, then h/2 of U, h/2 of V
+    const int plane = row < h ? 0 : (row < h + h / 2 ? 1 : 2), r = plane == 0 ? row : (plane == 1 ? row - h : row - h - h / 2);
+    const int pw = plane ? w >> 1 : w, fw = plane ? W >> 1 : W;
+    const u8 *src = src0 + (plane == 0 ? 0 : (plane == 1 ? (long)w * h : (long)w * h + (long)(w >> 1) * (h >> 1))) + (long)r * pw;
+    u8 *dst = frame + (plane == 0 ? 0 : (plane == 1 ? (long)W * H : (long)W * H + (long)(W >> 1) * (H >> 1))) + (long)((plane ? y >> 1 : y) + r) * fw + (plane ? x >> 1 : x);
+    if ((((unsigned long long)src | (unsigned long long)dst | (unsigned)pw) & 15) == 0) {
+      for (int i = threadIdx.x * 16; i < pw; i += 256 * 16) *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(src + i);
+    } else {
+      for (int i = threadIdx.x; i < pw; i += 256) dst[i] = src[i];
+    }
+  }
+}
+}  // namespace kvz
+
 extern "C" {
 
 void *kvz_hip_dev_alloc(size_t bytes)
@@ -1109,6 +1133,22 @@ void kvz_hip_dev_sao_frames(const uint8_t *in, uint8_t *out, int width, int heig
   if (n_frames <= 0) return;
   kvz::launch_sao(be().stream, in, out, width, height, n_frames, nullptr, luma, chroma);
   KVZ_HIP_CHECK(hipGetLastError());
+}
+
+int kvz_hip_dev_paste_tiles(uint8_t *frame, int width, int height, const uint8_t *slots, long slot_bytes, const int32_t *tiles /* host: n x (x, y, w, h, slot) */, int n, void *stream)
+{
+  if (n < 0 || n > 64) { fprintf(stderr, "kvz_hip_dev_paste_tiles: at most 64 tiles per launch\n"); return -1; }
+  if (n == 0) return 0;
+  kvz::PasteTable tb;
+  tb.n = n;
+  int hmax = 0;
+  for (int i = 0; i < n; i++) {
+    tb.x[i] = tiles[5 * i]; tb.y[i] = tiles[5 * i + 1]; tb.w[i] = tiles[5 * i + 2]; tb.h[i] = tiles[5 * i + 3]; tb.slot[i] = tiles[5 * i + 4];
+    if (tb.h[i] > hmax) hmax = tb.h[i];
+  }
+  hipLaunchKernelGGL(kvz::dev_paste_tiles_kernel, dim3(2 * hmax < 512 ? 2 * hmax : 512, n), dim3(256), 0, stream ? (hipStream_t)stream : be().stream, frame, width, height, slots, slot_bytes, tb);
+  KVZ_HIP_CHECK(hipGetLastError());
+  return 0;
 }
 
 void kvz_hip_dev_picture_checksums(const uint8_t *frames, int width, int height, int n_frames, uint32_t *out)

@@ -105,33 +105,74 @@ def exchange_plan(width, height, cols, rows, world):
             "recv_bytes_per_rank": (world - 1) * per_rank * slot}
 
 
-def allgather_reference_frame(dist, plan, rank, world, local_tiles, width, height, out_frame=None):
+class ReferenceExchange:
+    """The per-picture exchange with everything that does not change between pictures set up ONCE: the send / receive buffers (a rank's tile pictures are
+    produced straight into its send slots: send_slot(k)), the paste table, and -- on the GPU -- ONE paste launch of the library (kvz_hip_dev_paste_tiles) on
+    torch's current stream instead of 3 x tiles strided torch copies.  exchange() = all_gather_into_tensor + paste."""
+
+    def __init__(self, dist, plan, rank, world, width, height, device, lib=None):
+        import numpy as np
+        import torch
+        self.dist, self.plan, self.rank, self.world, self.w, self.h, self.lib = dist, plan, rank, world, width, height, lib
+        tiles, self.slot, self.per_rank = plan["tiles"], plan["slot_bytes"], plan["slots_per_rank"]
+        self.mine = tiles_of_rank(len(tiles), rank, world)
+        self.send = torch.zeros(self.per_rank * self.slot, dtype=torch.uint8, device=device)
+        self.recv = torch.empty(world * self.per_rank * self.slot, dtype=torch.uint8, device=device)
+        self.frame = torch.empty(width * height * 3 // 2, dtype=torch.uint8, device=device)
+        table = []
+        for r in range(world):
+            for k, ti in enumerate(tiles_of_rank(len(tiles), r, world)):
+                table.append(tuple(tiles[ti]) + (r * self.per_rank + k,))
+        self.table = table
+        self.table_np = np.ascontiguousarray(np.array(table, np.int32).reshape(-1))
+        self.on_gpu = self.send.is_cuda and lib is not None
+        if self.on_gpu:
+            import ctypes as C
+            lib.kvz_hip_dev_paste_tiles.restype = C.c_int
+            lib.kvz_hip_dev_paste_tiles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p]
+
+    def send_slot(self, k):
+        """the k-th of this rank's tile pictures (a view into the send buffer: write the tile's planar bytes here)"""
+        ti = self.mine[k]
+        n = self.plan["tiles"][ti][2] * self.plan["tiles"][ti][3] * 3 // 2
+        return self.send[k * self.slot:k * self.slot + n]
+
+    def exchange(self):
+        import torch
+        if self.world > 1:
+            self.dist.all_gather_into_tensor(self.recv, self.send)
+            src = self.recv
+        else:
+            src = self.send  # one rank holds every tile: nothing moves
+        if self.on_gpu:
+            rc = self.lib.kvz_hip_dev_paste_tiles(self.frame.data_ptr(), self.w, self.h, src.data_ptr(), self.slot, self.table_np.ctypes.data, len(self.table),
+                                                  torch.cuda.current_stream().cuda_stream)
+            if rc != 0:
+                raise RuntimeError("kvz_hip_dev_paste_tiles failed")
+            return self.frame
+        ys, cs = self.w * self.h, (self.w // 2) * (self.h // 2)
+        Y, U, V = self.frame[:ys].view(self.h, self.w), self.frame[ys:ys + cs].view(self.h // 2, self.w // 2), self.frame[ys + cs:ys + 2 * cs].view(self.h // 2, self.w // 2)
+        for (x, y, w, h, slot_i) in self.table:
+            base, c = slot_i * self.slot, (w // 2) * (h // 2)
+            Y[y:y + h, x:x + w] = src[base:base + w * h].view(h, w)
+            U[y // 2:(y + h) // 2, x // 2:(x + w) // 2] = src[base + w * h:base + w * h + c].view(h // 2, w // 2)
+            V[y // 2:(y + h) // 2, x // 2:(x + w) // 2] = src[base + w * h + c:base + w * h + 2 * c].view(h // 2, w // 2)
+        return self.frame
+
+
+def allgather_reference_frame(dist, plan, rank, world, local_tiles, width, height, out_frame=None, state=None, lib=None):
     """local_tiles: {tile index: 1-D uint8 torch tensor holding that tile's planar picture} for this rank's tiles (any device).
-    Returns the full planar reference frame (1-D uint8 tensor on the same device) assembled from every rank's tiles."""
+    Returns the full planar reference frame (1-D uint8 tensor on the same device) assembled from every rank's tiles.  One-shot convenience around
+    ReferenceExchange (pass `state` to reuse its buffers between pictures; producers that write into state.send_slot() skip the packing copy)."""
     import torch
-    tiles, slot, per_rank = plan["tiles"], plan["slot_bytes"], plan["slots_per_rank"]
-    mine = tiles_of_rank(len(tiles), rank, world)
     device = next(iter(local_tiles.values())).device if local_tiles else torch.device("cpu")
-    send = torch.zeros(per_rank * slot, dtype=torch.uint8, device=device)
-    for k, ti in enumerate(mine):
+    if state is None:
+        state = ReferenceExchange(dist, plan, rank, world, width, height, device, lib)
+    for k, ti in enumerate(state.mine):
         t = local_tiles[ti]
-        send[k * slot:k * slot + t.numel()] = t
-    recv = torch.empty(world * per_rank * slot, dtype=torch.uint8, device=device)
-    if world > 1:
-        dist.all_gather_into_tensor(recv, send)
-    else:
-        recv.copy_(send)
-    frame = out_frame if out_frame is not None else torch.empty(width * height * 3 // 2, dtype=torch.uint8, device=device)
-    ys, cs = width * height, (width // 2) * (height // 2)
-    Y = frame[:ys].view(height, width)
-    U = frame[ys:ys + cs].view(height // 2, width // 2)
-    V = frame[ys + cs:ys + 2 * cs].view(height // 2, width // 2)
-    for r in range(world):
-        for k, ti in enumerate(tiles_of_rank(len(tiles), r, world)):
-            x, y, w, h = tiles[ti]
-            base = (r * per_rank + k) * slot
-            c = (w // 2) * (h // 2)
-            Y[y:y + h, x:x + w] = recv[base:base + w * h].view(h, w)
-            U[y // 2:(y + h) // 2, x // 2:(x + w) // 2] = recv[base + w * h:base + w * h + c].view(h // 2, w // 2)
-            V[y // 2:(y + h) // 2, x // 2:(x + w) // 2] = recv[base + w * h + c:base + w * h + 2 * c].view(h // 2, w // 2)
+        state.send_slot(k).copy_(t)
+    frame = state.exchange()
+    if out_frame is not None:
+        out_frame.copy_(frame)
+        return out_frame
     return frame

@@ -192,3 +192,33 @@ def test_dev_sao_frames(oracle, dev, size):
     for f in range(nf):
         want = sc.run_cpu(oracle.lib.kvz_oracle_sao_frame, w, h, frames[f], lumas[f], chromas[f])
         assert np.array_equal(got[f], want), (f, np.flatnonzero(got[f] != want)[:8])
+
+
+def test_dev_paste_tiles_assembles_the_reference_frame(dev):
+    """kvz_hip_dev_paste_tiles (the receive side of the tile-sharded inter configuration's exchange): every tile's planar picture, one slot each, pasted into the
+    full frame by ONE launch == the numpy paste of kvazaar_amd/sharding.py, for BASELINE config 5's geometry (960x1088 / 960x1072 tiles) and a ragged small one"""
+    import ctypes as C
+    from kvazaar_amd import sharding
+    lib = dev.lib
+    lib.kvz_hip_dev_paste_tiles.restype = C.c_int
+    lib.kvz_hip_dev_paste_tiles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(3)
+    for (w, h, cols, rows) in ((3840, 2160, 4, 2), (200, 136, 3, 2)):
+        tiles = sharding.tile_grid(w, h, cols, rows)
+        slot = sharding.tile_slot_bytes(tiles)
+        order = rng.permutation(len(tiles))  # slot index of every tile: any order
+        slots = np.zeros(len(tiles) * slot, np.uint8)
+        want = np.zeros(w * h * 3 // 2, np.uint8)
+        table = []
+        for ti, t in enumerate(tiles):
+            sub = rng.integers(0, 256, t[2] * t[3] * 3 // 2, dtype=np.uint8)
+            slots[order[ti] * slot:order[ti] * slot + sub.size] = sub
+            sharding.paste_tile(want, w, h, t, sub)
+            table += [t[0], t[1], t[2], t[3], int(order[ti])]
+        table = np.ascontiguousarray(np.array(table, np.int32))
+        d_slots, d_frame = dev.put(slots), dev.empty(want.size)
+        assert lib.kvz_hip_dev_paste_tiles(d_frame, w, h, d_slots, slot, table.ctypes.data, len(tiles), None) == 0
+        lib.kvz_hip_dev_sync()
+        got = dev.get(d_frame, want.shape, np.uint8)
+        dev.free(d_slots, d_frame)
+        assert np.array_equal(got, want), (w, h, cols, rows)

@@ -18,7 +18,7 @@ def main():
     out = os.path.join(ROOT, "kvazaar_amd", "lib", "variants", "libkvz_hip_prof.so")  # built ahead (cross-compiles without a GPU): python tools/ctu_profile.py --build
     if "--build" in sys.argv or not os.path.exists(out):
         from kvazaar_amd import build
-        build.build_variant("prof", ["-DKVZ_CTU_PROFILE"] + os.environ.get("KVZ_PROFILE_FLAGS", "").split())
+        build.build_variant("prof", ["-DKVZ_CTU_PROFILE", "-DKVZ_RDOQ_WAVES_PER_EU=3"] + os.environ.get("KVZ_PROFILE_FLAGS", "").split())  # the timers cost registers: 3 wavefronts per SIMD there
         if "--build" in sys.argv:
             return
     import numpy as np
