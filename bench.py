@@ -54,13 +54,22 @@ PRESET_CLI = {"ultrafast": ["--preset", "ultrafast"], "faster": ["--preset", "fa
               "medium-pu13": ["--preset", "medium", "--pu-depth-intra", "1-3", "--sao", "off"], "medium": ["--preset", "medium", "--sao", "off"]}
 
 
-def golden_digest(w, h, seed, qp, deblock, tiles=None, wpp=False, no_wpp=False, suffix=""):
-    """digest(s) of the reference encoder's reconstruction of frame 0 of the clip (tests/golden/make_golden.py clip_key), or None"""
+def golden_digest(w, h, seed, qp, deblock, tiles=None, wpp=False, no_wpp=False, suffix="", picture=0):
+    """digest(s) of the reference encoder's reconstruction of frame `picture` of the clip (tests/golden/make_golden.py clip_key), or None.  Picture 0 has
+    one-frame fixtures for every configuration; the plain ultrafast pass also has all 8 (1080p) / 4 (4K) pictures of the bench clip (ENCODER_CLIPS_BENCH)."""
     try:
         g = json.load(open(GOLDEN))
     except (OSError, ValueError):
         return None
-    key = (f"{w}x{h}/n1/seed{seed}/large/qp{qp}/{'deblock' if deblock else 'nodeblock'}" + ("/nowpp" if no_wpp else "")
+    stage = 'deblock' if deblock else 'nodeblock'
+    if not tiles and not no_wpp and suffix == "":
+        for n in (8, 4):
+            v = g.get(f"{w}x{h}/n{n}/seed{seed}/large/qp{qp}/{stage}")
+            if v and picture < len(v):
+                return v[picture]
+    if picture != 0:
+        return None
+    key = (f"{w}x{h}/n1/seed{seed}/large/qp{qp}/{stage}" + ("/nowpp" if no_wpp else "")
            + (f"/tiles{tiles}" + ("-wpp" if wpp else "") if tiles else ""))
     if tiles:
         v = g.get(key + "/per-tile")
@@ -74,9 +83,9 @@ def golden_digest(w, h, seed, qp, deblock, tiles=None, wpp=False, no_wpp=False, 
 def verify_batches(batches, distinct_n, golden_for):
     """batches: [(HipBatch, slots)] with slots[i] = (distinct picture index, tile index or None) of batch frame i.
     1. every frame's device checksum equals that of the first frame holding the same (picture, tile)  [whole batch]
-    2. three frames holding picture 0 (first / middle / last of the batch) are downloaded and hashed against the reference encoder's
-       reconstruction digest where the fixture has one  [golden]"""
-    consistent, checked, golden_ok, golden_n = True, 0, True, 0
+    2. frames are downloaded and hashed against the reference encoder's reconstruction digest where the fixture has one: three copies of picture 0
+       (first / middle / last of the batch) and one copy of every other distinct picture  [golden; golden_for(tile, picture) -> digest or None]"""
+    consistent, checked, golden_ok, golden_n, pictures_hashed = True, 0, True, 0, set()
     for b, slots in batches:
         sums = b.checksums()
         first = {}
@@ -87,14 +96,16 @@ def verify_batches(batches, distinct_n, golden_for):
                 first[s] = i
             checked += 1
         for tile in sorted({s[1] for s in slots}, key=lambda t: -1 if t is None else t):
-            want = golden_for(tile)
-            if want is None:
-                continue
-            idx = [i for i, s in enumerate(slots) if s == (0, tile)]
-            for i in sorted({idx[0], idx[len(idx) // 2], idx[-1]}):
-                golden_ok &= sha(b.download(i)["rec"]) == want
-                golden_n += 1
-    return {"frames_checksummed": checked, "copies_consistent": consistent, "golden_frames_hashed": golden_n,
+            for pic in sorted({s[0] for s in slots}):
+                want = golden_for(tile, pic)
+                if want is None:
+                    continue
+                idx = [i for i, s in enumerate(slots) if s == (pic, tile)]
+                for i in sorted({idx[0], idx[len(idx) // 2], idx[-1]} if pic == 0 else {idx[0]}):
+                    golden_ok &= sha(b.download(i)["rec"]) == want
+                    golden_n += 1
+                pictures_hashed.add(pic)
+    return {"frames_checksummed": checked, "copies_consistent": consistent, "golden_frames_hashed": golden_n, "distinct_pictures_hashed": len(pictures_hashed),
             "golden_ok": (golden_ok if golden_n else None)}
 
 
@@ -421,13 +432,15 @@ def main():
     # ---- what was timed is checked (every rank; the verdicts are AND-ed) ----
     seed0 = clip_seed(args.width, args.height)
     golden_applies = rank == 0 or bool(args.tiles)  # frame-sharded ranks > 0 hold other clips (seed + rank): consistency check only
-    def golden_for(tile):
+    def golden_for(tile, picture=0):
         if not golden_applies or args.frozen_contexts:
             return None
         if tile is not None:  # per-tile digests of the tiled encode
+            if picture != 0:
+                return None
             per_tile = golden_digest(args.width, args.height, seed0, args.qp, 0, args.tiles, args.wpp)
             return per_tile[tile] if per_tile else None
-        return golden_digest(args.width, args.height, seed0, args.qp, 0, None, False, bool(model.no_wpp), PRESETS[args.preset][3])
+        return golden_digest(args.width, args.height, seed0, args.qp, 0, None, False, bool(model.no_wpp), PRESETS[args.preset][3], picture)
 
     verify = verify_batches(batches, len(distinct), golden_for)
     ok_local = verify["copies_consistent"] and verify["golden_ok"] is not False
@@ -582,7 +595,7 @@ def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedRes
         for _ in range(steps):
             b4.run(m4)
         s = time.perf_counter() - t
-        v = verify_batches([(b4, [(i % len(d4), None) for i in range(n4k)])], len(d4), lambda tile: golden_digest(w, h, clip_seed(w, h), args.qp, 0))
+        v = verify_batches([(b4, [(i % len(d4), None) for i in range(n4k)])], len(d4), lambda tile, picture=0: golden_digest(w, h, clip_seed(w, h), args.qp, 0, picture=picture))
         result["configs_extra"] = [{"workload": f"{w}x{h} yuv420p 8-bit all-intra ultrafast CTU pass, QP {args.qp}, {n4k} frames resident, {steps} steps",
                                     "value": steps * n4k * b4.ctus_per_frame / s, "unit": "CTUs/s", "fps": steps * n4k / s, "kernel_ms": b4.kernel_ms(),
                                     "verified": bool(v["copies_consistent"] and v["golden_ok"] is not False), "verify": v}]

@@ -127,6 +127,11 @@ ENCODER_CLIPS_MEDIUM = [(64, 64, 2, 9, "small", 22), (72, 88, 2, 1, "small", 12)
                         (192, 136, 4, 0, "adversarial", 12), (192, 136, 4, 0, "adversarial", 32), (832, 480, 1, 5, "large", 17), (1920, 1080, 1, 1, "large", 27)]
 
 
+# (width, height, frames, seed, kind, qp): the pictures bench.py keeps resident -- the first 8 (1080p) / 4 (4K) frames of SURVEY.md App. C's clips, ALL of them: the bench
+# hashes one copy of every distinct picture of its batch against these (reconstruction before the loop filters, and deblocked)
+ENCODER_CLIPS_BENCH = [(1920, 1080, 8, 1, "large", 22), (3840, 2160, 4, 2, "large", 22)]
+
+
 def clip_key(w, h, n, seed, kind, qp, deblock, no_wpp=False, tiles=None, wpp=False):
     return (f"{w}x{h}/n{n}/seed{seed}/{kind}/qp{qp}/{'deblock' if deblock else 'nodeblock'}" + ("/nowpp" if no_wpp else "")
             + (f"/tiles{tiles}" + ("-wpp" if wpp else "") if tiles else ""))
@@ -200,6 +205,7 @@ def encoder_digests(workdir):
             recs = reference_encoder_recon(w, h, frames, qp, deblock, workdir, None, False, None, False, sao, "medium", ("--pu-depth-intra", "1-3"))
             out[clip_key(w, h, n, seed, kind, qp, deblock) + "/medium-pu13" + ("/sao" if sao else "")] = [hashlib.sha256(r.tobytes()).hexdigest()[:24] for r in recs]
     out.update(medium_digests(workdir))
+    out.update(bench_digests(workdir))
     for (w, h, n, seed, kind, qp, tiles, wpp) in ENCODER_CLIPS_TILES:
         frames = cc.yuv_frames(w, h, n, seed, kind)
         for deblock in (0, 1):
@@ -211,6 +217,27 @@ def encoder_digests(workdir):
             out[clip_key(w, h, n, seed, kind, qp, deblock, False, tiles, wpp) + "/per-tile"] = [
                 [hashlib.sha256(sharding.crop_tile(r, w, h, t).tobytes()).hexdigest()[:24] for t in grid] for r in recs]
     return out
+
+
+def bench_digests(workdir):
+    """the ENCODER_CLIPS_BENCH entries of encoder_recon.json (callable on its own: `python -c "import make_golden as m; m.update_bench()"`)"""
+    import ctu_common as cc
+    out = {}
+    for (w, h, n, seed, kind, qp) in ENCODER_CLIPS_BENCH:
+        frames = cc.yuv_frames(w, h, n, seed, kind)
+        for deblock in (0, 1):
+            recs = reference_encoder_recon(w, h, frames, qp, deblock, workdir)
+            out[clip_key(w, h, n, seed, kind, qp, deblock)] = [hashlib.sha256(r.tobytes()).hexdigest()[:24] for r in recs]
+    return out
+
+
+def update_bench():
+    import tempfile
+    path = os.path.join(HERE, "encoder_recon.json")
+    data = json.load(open(path))
+    with tempfile.TemporaryDirectory() as d:
+        data.update(bench_digests(d))
+    json.dump(data, open(path, "w"), indent=0, sort_keys=True)
 
 
 def medium_digests(workdir):

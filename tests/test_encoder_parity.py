@@ -445,3 +445,33 @@ def test_hip_rdoq_reproduces_reference_encoder(oracle, clip):
         assert [_sha(b.download(i)["rec"]) for i in range(n)] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 1) + "/medium-pu13/sao"]
     finally:
         b.close()
+
+
+# ---- the pictures bench.py keeps resident, ALL of them (the first 8 frames of the 1080p clip, the first 4 of the 4K one): bench.py hashes one copy of each ----------
+def test_oracle_reproduces_every_bench_picture_1080p(oracle):
+    w, h, n, seed, kind, qp = mg.ENCODER_CLIPS_BENCH[0]
+    model = oracle_model(oracle, qp)
+    frames = cc.yuv_frames(w, h, n, seed, kind)
+    assert [_sha(cc.run_oracle(oracle, model, w, h, f)["rec"]) for f in frames] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip", mg.ENCODER_CLIPS_BENCH, ids=lambda c: f"{c[0]}x{c[1]}-n{c[2]}")
+def test_hip_reproduces_every_bench_picture(clip):
+    """CTU pass and deblocking of all 8 / 4 distinct pictures of the bench batches == the reference encoder's reconstructions"""
+    import kvazaar_amd
+    from kvazaar_amd.batch import HipBatch, cost_model
+    lib = kvazaar_amd.load_library()
+    w, h, n, seed, kind, qp = clip
+    model = cost_model(lib, qp, cc.coeff_weights(qp))
+    frames = cc.yuv_frames(w, h, n, seed, kind)
+    b = HipBatch(lib, w, h, n)
+    try:
+        for i, f in enumerate(frames):
+            b.upload(i, f)
+        b.run(model)
+        assert [_sha(b.download(i)["rec"]) for i in range(n)] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0)]
+        b.deblock(qp)
+        assert [_sha(b.download(i)["rec"]) for i in range(n)] == GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 1)]
+    finally:
+        b.close()
