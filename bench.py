@@ -600,6 +600,49 @@ def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedRes
                                     "value": steps * n4k * b4.ctus_per_frame / s, "unit": "CTUs/s", "fps": steps * n4k / s, "kernel_ms": b4.kernel_ms(),
                                     "verified": bool(v["copies_consistent"] and v["golden_ok"] is not False), "verify": v}]
         b4.close()
+        # ---- BASELINE config 5 at one GPU: the same 4K pictures cut into kvazaar's --tiles 4x2 (8 tiles of 15x17 CTUs, no WPP inside a tile: 3 072 serial chains) ----
+        import types
+        from kvazaar_amd import sharding
+        mt = model_for(args.qp, "4x2")
+        targs = types.SimpleNamespace(distinct=4)
+        tb, _, ctus_pf, _ = build_batches(targs, lib, 0, 1, w, h, n4k, "4x2", HipBatch)
+
+        def tile_step():
+            for b, _ in tb:
+                b.launch(mt)
+            for b, _ in tb:
+                b.sync()
+        tile_step()
+        t = time.perf_counter()
+        for _ in range(steps):
+            tile_step()
+        s = time.perf_counter() - t
+        per_tile = golden_digest(w, h, clip_seed(w, h), args.qp, 0, "4x2", False)
+        v = verify_batches(tb, 4, lambda tile, picture=0: (per_tile[tile] if per_tile and picture == 0 else None))
+        result["configs_extra"].append({"workload": f"{w}x{h} --tiles 4x2 (BASELINE config 5 on ONE GPU; tiles imply --no-wpp as in kvazaar) all-intra ultrafast CTU pass, QP {args.qp}, "
+                                                    f"{n4k} pictures = {8 * n4k} tile chains resident, {steps} steps", "value": steps * n4k * ctus_pf / s, "unit": "CTUs/s",
+                                        "fps": steps * n4k / s, "verified": bool(v["copies_consistent"] and v["golden_ok"] is not False), "verify": v})
+        for b, _ in tb:
+            b.close()
+        # ---- BASELINE config 3: `--preset medium` (32x32 search, RDOQ, NxN partitions) at 3840x2160 ----
+        n_med = 96
+        mm = model_for(args.qp)
+        mm.coeff_cabac, mm.search_32x32, mm.rdoq, mm.search_nxn = 1, 1, 1, 1
+        bm = HipBatch(lib, w, h, n_med)
+        for i in range(n_med):
+            bm.upload(i, d4[i % len(d4)])
+        bm.run(mm)
+        t = time.perf_counter()
+        bm.run(mm)
+        s = time.perf_counter() - t
+        vm = verify_batches([(bm, [(i % len(d4), None) for i in range(n_med)])], len(d4),
+                            lambda tile, picture=0: golden_digest(w, h, clip_seed(w, h), args.qp, 0, suffix="/medium") if picture == 0 else None)
+        result["configs_extra"].append({"workload": f"{w}x{h} yuv420p 8-bit all-intra `--preset medium` CTU pass (32x32 CUs searched, kvz_rdoq in every quantisation, 8x8 CUs also "
+                                                    f"as four 4x4 PUs), QP {args.qp}, {n_med} frames resident, 1 step", "value": n_med * bm.ctus_per_frame / s, "unit": "CTUs/s",
+                                        "fps": n_med / s, "kernel_ms": bm.kernel_ms(), "verified": bool(vm["copies_consistent"] and vm["golden_ok"] is not False), "verify": vm,
+                                        "matrix_cores": "every 16- and 32-point transform of this pass runs on v_mfma_i32_*_i8 (kvz_mfma.hpp); their share of the pass and the MFMA "
+                                                        "rate of the transform kernels alone: DESIGN.md 5, bench_kernels.py"})
+        bm.close()
 
 
 if __name__ == "__main__":

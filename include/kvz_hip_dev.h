@@ -7,7 +7,8 @@
  * reference's: blocks are the contiguous n*n arrays kvz_sad_NxN / kvz_satd_NxN / kvz_dct_NxN take
  * (strategies-picture.h:115-131, strategies-dct.h:44), `count` of them back to back.
  *
- * All work is queued on the calling thread's stream; kvz_hip_dev_sync() waits for it.  Results are bit-exact with the
+ * All work is queued on the calling thread's stream; kvz_hip_dev_sync() waits for it.  Entry points that take a shape argument return 0, or -1 -- with a
+ * message on stderr and nothing queued -- for a shape they do not have (HIP failures stay fatal, as everywhere in the library).  Results are bit-exact with the
  * per-call entry points (tests/test_gpu_dev.py compares against the oracle).
  */
 #ifndef KVZ_HIP_DEV_H_
@@ -33,19 +34,19 @@ float kvz_hip_dev_timer_stop(void);
 
 /* kvz_sad_NxN / kvz_satd_NxN (picture-generic.c:475-501, 252-340 + strategies-picture.h:53-69), n in {4 (satd only), 8, 16, 32, 64}:
  * out[i] = cost of blocks a[i], b[i].  2 n^2 bytes read per block, 4 written. */
-void kvz_hip_dev_sad_nxn(int n, const uint8_t *a, const uint8_t *b, int count, uint32_t *out);
-void kvz_hip_dev_satd_nxn(int n, const uint8_t *a, const uint8_t *b, int count, uint32_t *out);
+int  kvz_hip_dev_sad_nxn(int n, const uint8_t *a, const uint8_t *b, int count, uint32_t *out);
+int  kvz_hip_dev_satd_nxn(int n, const uint8_t *a, const uint8_t *b, int count, uint32_t *out);
 
 /* kvz_dct_NxN / kvz_idct_NxN / 4x4 DST (dct-generic.c:559-630), 8-bit: `kind` = enum kvz_hip_transform_kind.
  * use_matrix_cores == 1 (the product path): 32-point blocks on the matrix cores (v_mfma_i32_32x32x32_i8 on byte planes, exact integer arithmetic, one block per
  * wavefront), 4-, 8- and 16-point blocks on the vector ALU, one lane per block row (v_dot2_i32_i16, transposes through LDS).
  * == 2: every size on the matrix cores, the small ones 4 or 2 blocks on the diagonal of a 16 x 16 product (kept for A/B).
  * == 0: one lane per coefficient, two launches through `tmp` (count * n^2 int16 of scratch; may be NULL otherwise). */
-void kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *out, int count, int use_matrix_cores);
+int  kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *out, int count, int use_matrix_cores);
 
 /* kvz_angular_pred (intra-generic.c:49-155): block i is predicted from ref_above + i * (2w+1) and ref_left + i * (2w+1)
  * into out + i * w * w.  (4w + 2) + w^2 bytes per block. */
-void kvz_hip_dev_angular_pred(int log2_width, int mode, const uint8_t *ref_above, const uint8_t *ref_left, int count, uint8_t *out);
+int  kvz_hip_dev_angular_pred(int log2_width, int mode, const uint8_t *ref_above, const uint8_t *ref_left, int count, uint8_t *out);
 
 /* Deblocking of all-intra, constant-QP pictures in place: kvz_filter_deblock_lcu (filter.c:783) over every LCU of every
  * frame.  frames = n_frames x [Y | U | V] tight planar 4:2:0 (the batch layout), cu_depth = n_frames x [H/8][W/8] CU depths
@@ -77,7 +78,7 @@ void kvz_hip_dev_deblock_frames_inter(uint8_t *frames, int width, int height, in
  * [-range, range]^2,   out[b * side^2 + (dy + range) * side + dx + range] = kvz_image_calc_sad(cur, ref, x, y, x + dx, y + dy, bw, bw)
  * with side = 2 range + 1 -- the reference picture is edge-replicated outside the frame as image.c:279-397 does.  Both
  * pictures are width x height luma planes (stride = width); bw in {8, 16, 32, 64}, range <= 32, blocks inside the picture. */
-void kvz_hip_dev_sad_surface(const uint8_t *cur, const uint8_t *ref, int width, int height, int bw, int range, const int16_t *blk_xy, int count,
+int  kvz_hip_dev_sad_surface(const uint8_t *cur, const uint8_t *ref, int width, int height, int bw, int range, const int16_t *blk_xy, int count,
                              uint32_t *out);
 
 /* Fractional motion search, the arithmetic of search_frac (search_inter.c:974-1130) for `count` prediction units of one picture pair:
@@ -96,7 +97,7 @@ typedef struct kvz_hip_fme_pu {
   int16_t reserved;
 } kvz_hip_fme_pu;
 #define KVZ_HIP_FME_COSTS 17
-void kvz_hip_dev_fme_costs(const uint8_t *cur, const uint8_t *ref, int width, int height, const kvz_hip_fme_pu *pus, int count, int max_pu_size, int steps, uint32_t *out);
+int  kvz_hip_dev_fme_costs(const uint8_t *cur, const uint8_t *ref, int width, int height, const kvz_hip_fme_pu *pus, int count, int max_pu_size, int steps, uint32_t *out);
 
 /* Motion-compensated prediction (inter.c:371-575 inter_recon_unipred / kvz_inter_recon_bipred -> kvz_sample_quarterpel_luma(_hi),
  * kvz_sample_octpel_chroma(_hi), kvz_bipred_average): for PU i -- w x h luma samples at (x, y), multiples of 8 up to 64 -- the prediction
@@ -109,7 +110,7 @@ typedef struct kvz_hip_mc_pu {
   int8_t  use[2];
   int16_t reserved;
 } kvz_hip_mc_pu;
-void kvz_hip_dev_inter_pred(const uint8_t *ref0, const uint8_t *ref1, uint8_t *pred, int width, int height, const kvz_hip_mc_pu *pus, int count, int max_pu_size);
+int  kvz_hip_dev_inter_pred(const uint8_t *ref0, const uint8_t *ref1, uint8_t *pred, int width, int height, const kvz_hip_mc_pu *pus, int count, int max_pu_size);
 
 /* SAO applied to whole pictures: kvz_sao_reconstruct (sao.c:302-361) for every CTU and plane of n_frames tight planar 4:2:0
  * frames.  in = the deblocked pictures, out = a different buffer of the same layout (SAO reads pre-SAO neighbours);

@@ -997,7 +997,7 @@ float kvz_hip_dev_timer_stop(void)
     }                                                                                                             \
   } while (0)
 
-void kvz_hip_dev_sad_nxn(int n, const uint8_t *a, const uint8_t *b, int count, uint32_t *out)
+int kvz_hip_dev_sad_nxn(int n, const uint8_t *a, const uint8_t *b, int count, uint32_t *out)
 {
   const long chunks = (long)count * n * n / 16;
   const uint4 *pa = reinterpret_cast<const uint4 *>(a), *pb = reinterpret_cast<const uint4 *>(b);
@@ -1009,11 +1009,12 @@ void kvz_hip_dev_sad_nxn(int n, const uint8_t *a, const uint8_t *b, int count, u
     KVZ_HIP_CHECK(hipMemsetAsync(out, 0, (size_t)count * sizeof(uint32_t), be().stream));
     KVZ_DEV_LAUNCH(kvz::dev_sad_kernel<64>, chunks, pa, pb, chunks, out);
     break;
-  default: fprintf(stderr, "kvz_hip_dev_sad_nxn: unsupported n=%d\n", n); abort();
+  default: fprintf(stderr, "kvz_hip_dev_sad_nxn: unsupported n=%d\n", n); return -1;
   }
+  return 0;
 }
 
-void kvz_hip_dev_satd_nxn(int n, const uint8_t *a, const uint8_t *b, int count, uint32_t *out)
+int kvz_hip_dev_satd_nxn(int n, const uint8_t *a, const uint8_t *b, int count, uint32_t *out)
 {
   const long tiles = n >= 8 ? (long)count * (n / 8) * (n / 8) : count;
   switch (n) {
@@ -1022,24 +1023,25 @@ void kvz_hip_dev_satd_nxn(int n, const uint8_t *a, const uint8_t *b, int count, 
   case 16: KVZ_DEV_LAUNCH(kvz::dev_satd_kernel<16>, tiles, a, b, tiles, out); break;
   case 32: KVZ_DEV_LAUNCH(kvz::dev_satd_kernel<32>, tiles, a, b, tiles, out); break;
   case 64: KVZ_DEV_LAUNCH(kvz::dev_satd_kernel<64>, tiles, a, b, tiles, out); break;
-  default: fprintf(stderr, "kvz_hip_dev_satd_nxn: unsupported n=%d\n", n); abort();
+  default: fprintf(stderr, "kvz_hip_dev_satd_nxn: unsupported n=%d\n", n); return -1;
   }
+  return 0;
 }
 
-void kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *out, int count, int use_matrix_cores)
+int kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *out, int count, int use_matrix_cores)
 {
   static const int sizes[5] = { 4, 8, 16, 32, 4 };
   const int inverse = kind >= KVZ_HIP_IDCT_4, idx = inverse ? kind - KVZ_HIP_IDCT_4 : kind, n = sizes[idx];
   if (use_matrix_cores == 1 && n == 16) {  // 16-point blocks: one lane per row on v_dot2_i32_i16 as well (5 TB/s against 3.4 TB/s on the matrix cores, which use_matrix_cores == 2 keeps)
     const long rows = (long)count * 16;
     KVZ_DEV_LAUNCH(kvz::dev_transform_rows_kernel<16>, (rows + 511) / 512 * 256, in, out, rows, inverse, &kvz::device_tables()->pairs16[0][0][0]);
-    return;
+    return 0;
   }
   if (use_matrix_cores && (n == 16 || n == 32) && idx != 4) {
     const long threads = ((long)count + 3) / 4 * 256;
     if (n == 16) KVZ_DEV_LAUNCH(kvz::dev_transform_mfma_kernel<16>, threads, in, out, count, inverse, kvz::device_tables());
     else KVZ_DEV_LAUNCH(kvz::dev_transform_mfma_kernel<32>, threads, in, out, count, inverse, kvz::device_tables());
-    return;
+    return 0;
   }
   if (use_matrix_cores == 1) {  // the small sizes run on the vector ALU (v_dot2_i32_i16); use_matrix_cores == 2 keeps the block-diagonal MFMA form for A/B
     const kvz::Tables *tb = kvz::device_tables();
@@ -1047,7 +1049,7 @@ void kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *o
     const long rows = (long)count * n, threads = (rows + 1023) / 1024 * 256;
     if (n == 4) KVZ_DEV_LAUNCH(kvz::dev_transform_rows_kernel<4>, threads, in, out, rows, inverse, &tb->small_pairs[kind_sp][0][0][0]);
     else KVZ_DEV_LAUNCH(kvz::dev_transform_rows_kernel<8>, threads, in, out, rows, inverse, &tb->small_pairs[kind_sp][0][0][0]);
-    return;
+    return 0;
   }
   if (use_matrix_cores) {
     const kvz::Tables *tb = kvz::device_tables();
@@ -1055,15 +1057,16 @@ void kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *o
     const long threads = ((long)count + 4 * per_wave - 1) / (4 * per_wave) * 256;
     if (n == 4) KVZ_DEV_LAUNCH(kvz::dev_transform_small_mfma_kernel<4>, threads, in, out, count, inverse, tb->bd_i8[kind_bd][0], tb->bd_i8[kind_bd][1], tb->bd_sum[kind_bd][0], tb->bd_sum[kind_bd][1]);
     else KVZ_DEV_LAUNCH(kvz::dev_transform_small_mfma_kernel<8>, threads, in, out, count, inverse, tb->bd_i8[kind_bd][0], tb->bd_i8[kind_bd][1], tb->bd_sum[kind_bd][0], tb->bd_sum[kind_bd][1]);
-    return;
+    return 0;
   }
-  if (!tmp) { fprintf(stderr, "kvz_hip_dev_transform: the scalar path needs tmp\n"); abort(); }
+  if (!tmp) { fprintf(stderr, "kvz_hip_dev_transform: the scalar path needs tmp\n"); return -1; }
   A::transform_dev(be(), kind, 8, in, tmp, out, count);
+  return 0;
 }
 
-void kvz_hip_dev_angular_pred(int log2_width, int mode, const uint8_t *ref_above, const uint8_t *ref_left, int count, uint8_t *out)
+int kvz_hip_dev_angular_pred(int log2_width, int mode, const uint8_t *ref_above, const uint8_t *ref_left, int count, uint8_t *out)
 {
-  if (count <= 0) return;
+  if (count <= 0) return 0;
   const int blocks_per_wg = 256 * kvz::kAngularGroupsPerLane / ((1 << (2 * log2_width)) / 4);
   const long threads = ((long)count + blocks_per_wg - 1) / blocks_per_wg * 256;
   switch (log2_width) {
@@ -1071,8 +1074,9 @@ void kvz_hip_dev_angular_pred(int log2_width, int mode, const uint8_t *ref_above
   case 3: KVZ_DEV_LAUNCH(kvz::dev_angular_kernel<3>, threads, ref_above, ref_left, count, mode, out); break;
   case 4: KVZ_DEV_LAUNCH(kvz::dev_angular_kernel<4>, threads, ref_above, ref_left, count, mode, out); break;
   case 5: KVZ_DEV_LAUNCH(kvz::dev_angular_kernel<5>, threads, ref_above, ref_left, count, mode, out); break;
-  default: fprintf(stderr, "kvz_hip_dev_angular_pred: unsupported log2_width=%d\n", log2_width); abort();
+  default: fprintf(stderr, "kvz_hip_dev_angular_pred: unsupported log2_width=%d\n", log2_width); return -1;
   }
+  return 0;
 }
 
 void kvz_hip_dev_deblock_frames(uint8_t *frames, int width, int height, int n_frames, const uint8_t *cu_depth, int qp, int beta_offset_div2,
@@ -1087,44 +1091,50 @@ void kvz_hip_dev_deblock_frames_inter(uint8_t *frames, int width, int height, in
   kvz::deblock_frames_on(be().stream, frames, width, height, n_frames, nullptr, qp, beta_offset_div2, tc_offset_div2, 3, info, slice_is_b);
 }
 
-void kvz_hip_dev_sad_surface(const uint8_t *cur, const uint8_t *ref, int width, int height, int bw, int range, const int16_t *blk_xy, int count,
+int kvz_hip_dev_sad_surface(const uint8_t *cur, const uint8_t *ref, int width, int height, int bw, int range, const int16_t *blk_xy, int count,
                              uint32_t *out)
 {
-  if (count <= 0) return;
-  if (range < 0 || range > 32) { fprintf(stderr, "kvz_hip_dev_sad_surface: range %d not in [0, 32]\n", range); abort(); }
+  if (count <= 0) return 0;
+  if (range < 0 || range > 32) { fprintf(stderr, "kvz_hip_dev_sad_surface: range %d not in [0, 32]\n", range); return -1; }
   const dim3 grid((unsigned)count), block(kvz::kSadSurfaceLanes);
   switch (bw) {
   case 8: hipLaunchKernelGGL(kvz::dev_sad_surface_kernel<8>, grid, block, 0, be().stream, cur, ref, width, height, range, blk_xy, out); break;
   case 16: hipLaunchKernelGGL(kvz::dev_sad_surface_kernel<16>, grid, block, 0, be().stream, cur, ref, width, height, range, blk_xy, out); break;
   case 32: hipLaunchKernelGGL(kvz::dev_sad_surface_kernel<32>, grid, block, 0, be().stream, cur, ref, width, height, range, blk_xy, out); break;
   case 64: hipLaunchKernelGGL(kvz::dev_sad_surface_kernel<64>, grid, block, 0, be().stream, cur, ref, width, height, range, blk_xy, out); break;
-  default: fprintf(stderr, "kvz_hip_dev_sad_surface: unsupported block width %d\n", bw); abort();
+  default: fprintf(stderr, "kvz_hip_dev_sad_surface: unsupported block width %d\n", bw); return -1;
   }
   KVZ_HIP_CHECK(hipGetLastError());
+  return 0;
 }
 
-void kvz_hip_dev_fme_costs(const uint8_t *cur, const uint8_t *ref, int width, int height, const kvz_hip_fme_pu *pus, int count, int max_pu_size, int steps, uint32_t *out)
+int kvz_hip_dev_fme_costs(const uint8_t *cur, const uint8_t *ref, int width, int height, const kvz_hip_fme_pu *pus, int count, int max_pu_size, int steps, uint32_t *out)
 {
-  if (count <= 0) return;
+  if (count <= 0) return 0;
   const dim3 grid((unsigned)count), block(256);
   const kvz::Tables *tb = kvz::device_tables();
   if (max_pu_size <= 16) hipLaunchKernelGGL(kvz::dev_fme_kernel<16>, grid, block, 0, be().stream, cur, ref, width, height, pus, steps, tb, out);
   else if (max_pu_size <= 32) hipLaunchKernelGGL(kvz::dev_fme_kernel<32>, grid, block, 0, be().stream, cur, ref, width, height, pus, steps, tb, out);
   else if (max_pu_size <= 64) hipLaunchKernelGGL(kvz::dev_fme_kernel<64>, grid, block, 0, be().stream, cur, ref, width, height, pus, steps, tb, out);
-  else { fprintf(stderr, "kvz_hip_dev_fme_costs: PUs larger than 64 samples do not exist\n"); abort(); }
+  else { fprintf(stderr, "kvz_hip_dev_fme_costs: PUs larger than 64 samples do not exist\n"); return -1; }
   KVZ_HIP_CHECK(hipGetLastError());
+  return 0;
 }
 
-void kvz_hip_dev_inter_pred(const uint8_t *ref0, const uint8_t *ref1, uint8_t *pred, int width, int height, const kvz_hip_mc_pu *pus, int count, int max_pu_size)
+int kvz_hip_dev_inter_pred(const uint8_t *ref0, const uint8_t *ref1, uint8_t *pred, int width, int height, const kvz_hip_mc_pu *pus, int count, int max_pu_size)
 {
-  if (count <= 0) return;
+  if (count <= 0) return 0;
   const dim3 grid((unsigned)count), block(256);
   const kvz::Tables *tb = kvz::device_tables();
-  if (max_pu_size <= 16) hipLaunchKernelGGL(kvz::dev_inter_pred_kernel<16>, grid, block, 0, be().stream, ref0, ref1, pred, width, height, pus, tb);
+  // PUs up to 16x16 with a picture width that is a multiple of 8 (all of kvazaar's): one wavefront per PU
+  if (max_pu_size <= 16 && (width & 7) == 0 && !getenv("KVZ_HIP_MC_WORKGROUP_PER_PU"))
+    hipLaunchKernelGGL(kvz::dev_inter_pred_wave_kernel, dim3((unsigned)((count + 3) / 4)), block, 0, be().stream, ref0, ref1, pred, width, height, pus, count, tb);
+  else if (max_pu_size <= 16) hipLaunchKernelGGL(kvz::dev_inter_pred_kernel<16>, grid, block, 0, be().stream, ref0, ref1, pred, width, height, pus, tb);
   else if (max_pu_size <= 32) hipLaunchKernelGGL(kvz::dev_inter_pred_kernel<32>, grid, block, 0, be().stream, ref0, ref1, pred, width, height, pus, tb);
   else if (max_pu_size <= 64) hipLaunchKernelGGL(kvz::dev_inter_pred_kernel<64>, grid, block, 0, be().stream, ref0, ref1, pred, width, height, pus, tb);
-  else { fprintf(stderr, "kvz_hip_dev_inter_pred: PUs larger than 64 samples do not exist\n"); abort(); }
+  else { fprintf(stderr, "kvz_hip_dev_inter_pred: PUs larger than 64 samples do not exist\n"); return -1; }
   KVZ_HIP_CHECK(hipGetLastError());
+  return 0;
 }
 
 void kvz_hip_dev_sao_frames(const uint8_t *in, uint8_t *out, int width, int height, int n_frames, const kvz_hip_sao_params *luma,

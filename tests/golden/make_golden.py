@@ -124,7 +124,8 @@ ENCODER_CLIPS_RDOQ = [(64, 64, 2, 9, "small", 22), (72, 88, 2, 1, "small", 12), 
 # (width, height, frames, seed, kind, qp): `--preset medium -p 1` as it is -- pu-depth-intra 1-4: 8x8 CUs are also tried as four 4x4 PUs (part_size NxN) -- on clips
 # where that partition is taken (noise at QP 12: every CU; the synthetic scenes at QP 12-27: a few per cent of the 8x8 CUs); the same three stages
 ENCODER_CLIPS_MEDIUM = [(64, 64, 2, 9, "small", 22), (72, 88, 2, 1, "small", 12), (200, 136, 2, 3, "small", 27), (416, 240, 2, 1234, "small", 22),
-                        (192, 136, 4, 0, "adversarial", 12), (192, 136, 4, 0, "adversarial", 32), (832, 480, 1, 5, "large", 17), (1920, 1080, 1, 1, "large", 27)]
+                        (192, 136, 4, 0, "adversarial", 12), (192, 136, 4, 0, "adversarial", 32), (832, 480, 1, 5, "large", 17), (1920, 1080, 1, 1, "large", 27),
+                        (3840, 2160, 1, 2, "large", 22)]  # BASELINE config 3 at its own size (checked on the GPU; the oracle needs minutes for it)
 
 
 # (width, height, frames, seed, kind, qp): the pictures bench.py keeps resident -- the first 8 (1080p) / 4 (4K) frames of SURVEY.md App. C's clips, ALL of them: the bench
