@@ -157,6 +157,32 @@ void kvz_oracle_deblock_frame_inter(int width, int height, int qp, int beta_offs
                                     const kvz_hip_cu_dbk *info, int slice_is_b);  /* filter.c:405-493 boundary strengths from motion data */
 void kvz_oracle_deblock_lcu(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,
                             const uint8_t *cu_depth, int x_px, int y_px);
+void kvz_oracle_deblock_lcu_inter(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,
+                                  const kvz_hip_cu_dbk *info, int slice_is_b, int x_px, int y_px);
+void kvz_oracle_sao_search_frame_inter(const kvz_hip_intra_cost_model *m, int width, int height, const uint8_t *src, uint8_t *rec, const kvz_hip_cu_dbk *info,
+                                       int slice_is_b, int deblock, int beta_offset_div2, int tc_offset_div2, kvz_hip_sao_params *luma_out,
+                                       kvz_hip_sao_params *chroma_out, uint8_t *merge_out);
+
+/* ---- sequences with inter prediction (kvz_oracle_inter.inc, part of kvz_oracle_ctu.c): an I picture followed by B pictures that each reference the previous
+ * one in both lists -- `--gop lp-g<gop_len>d<gop_depth>t1` with the `veryfast` or `ultrafast` preset (BASELINE config 4) ---- */
+typedef struct kvz_oracle_cu {  /* cu_info_t (cu.h:130-170) of one 4x4 unit */
+  uint8_t type /* 0 not set, 1 intra, 2 inter */, depth, mode /* intra */, tr_depth; uint16_t cbf;
+  uint8_t skipped, merged, merge_idx, mv_dir, mv_ref[2], mv_cand[2];  /* motion fields of a list mv_dir does not use: 0 / 255 */
+  int16_t mv[2][2];
+} kvz_oracle_cu;
+typedef struct kvz_oracle_lowdelay_cfg {
+  int32_t qp;                  /* --qp */
+  int32_t gop_len, gop_depth;  /* lp-g<len>d<depth>t1 */
+  int32_t intra_period;        /* --period (64) */
+  int32_t fme_level;           /* --subme: 2 `veryfast`, 0 `ultrafast` */
+  int32_t pu_depth_inter_max;  /* 3 `veryfast`, 2 `ultrafast` */
+  int32_t sao, deblock;        /* --sao full / off, --deblock / --no-deblock */
+  int32_t mv_constraint;       /* cfg.owf && cfg.wpp (search_inter.c:85) */
+  int32_t no_wpp;
+} kvz_oracle_lowdelay_cfg;
+int  kvz_oracle_lowdelay_qp(int qp, int gop_len, int gop_depth, int frame, int intra_period);
+void kvz_oracle_lowdelay_encode(const kvz_oracle_lowdelay_cfg *cfg, const float entropy_fbits[128], const uint64_t coeff_weights[52], int width, int height,
+                                int n_frames, const uint8_t *src, uint8_t *rec_search, uint8_t *rec_final, kvz_oracle_cu *cu_out, int32_t *frame_qp);
 
 /* ---- deblocking of an all-intra, constant-QP picture in place (kvz_oracle_deblock.c; filter.c:783 kvz_filter_deblock_lcu over
  * every LCU).  Planes are tight (stride = width), cu_depth is the CU depth per 8x8 unit as the CTU pass returns it. ---- */

@@ -44,6 +44,8 @@
 
 #include "kvz_oracle.h"
 
+struct inter_seq;
+
 /* context.c:202-213 kvz_ctx_init: init value + QP -> uc_state */
 static int ctx_state(int qp, int init_value)
 {
@@ -63,7 +65,10 @@ enum { CX_SPLIT = KVZ_HIP_CX_SPLIT /* ..2 */, CX_PART = KVZ_HIP_CX_PART, CX_INTR
        CX_LAST_X_LUMA = KVZ_HIP_CX_LAST_X_LUMA /* 15 */, CX_LAST_X_CHROMA = KVZ_HIP_CX_LAST_X_CHROMA /* 15 */,
        CX_ONE_LUMA = KVZ_HIP_CX_ONE_LUMA /* 16 */, CX_ONE_CHROMA = KVZ_HIP_CX_ONE_CHROMA /* 8 */, CX_ABS_LUMA = KVZ_HIP_CX_ABS_LUMA /* 4 */,
        CX_ABS_CHROMA = KVZ_HIP_CX_ABS_CHROMA /* 2 */, CX_COUNT = KVZ_HIP_CX_COUNT };
-typedef struct { uint8_t s[CX_COUNT]; } ctxs_t;
+/* the contexts only P / B slices use (kvz_oracle_inter.inc; cabac.h:63-77) live behind the device-visible ones (and the two SAO contexts at 148 / 149) */
+enum { CXB_SKIP = 150 /* ..152 */, CXB_MERGE_FLAG = 153, CXB_MERGE_IDX = 154, CXB_PRED_MODE = 155, CXB_MVD = 156 /* ..157 */, CXB_MVP_IDX = 158 /* ..159 */,
+       CXB_INTER_DIR = 160 /* ..164 */, CXB_ROOT_CBF = 165, CXB_TRANS_SUBDIV = 166 /* ..168 */, CXB_REF_PIC = 169 /* ..170 */, CX_ALL = 172 };
+typedef struct { uint8_t s[CX_ALL]; } ctxs_t;
 
 /* H.265 Table 9-41 state transitions in kvazaar's packing (cabac.c:40-62 kvz_g_auc_next_state_mps / _lps) */
 static uint8_t g_next_mps[128], g_next_lps[128];
@@ -85,7 +90,9 @@ const uint8_t *kvz_oracle_next_state_table(int lps) { build_transitions(); retur
 #define NLEVELS 5
 #define MAX_COST 1.7e+308 /* global.h:293 MAX_DOUBLE */
 
-typedef struct { uint8_t type /* 0 not set, 1 intra */, depth, mode, tr_depth; uint16_t cbf; } cu_t;
+/* kvz_oracle_cu (kvz_oracle.h): type 0 not set, 1 intra, 2 inter (cu.h:72-77).  Motion fields of a list mv_dir does not use are kept at 0 / 255: the reference
+ * leaves them undefined and clears them whenever a neighbour is taken as a candidate (inter.c:669-677 inter_clear_cu_unused); nothing else reads them */
+typedef kvz_oracle_cu cu_t;
 
 typedef struct {
   uint8_t rec[3][LCU * LCU];
@@ -106,6 +113,11 @@ typedef struct {
   uint8_t tbl_top[16][16], tbl_left[16][16];
   ctxs_t cab;                /* state->search_cabac's contexts (adaptive mode) */
   ctxs_t coder;              /* state->cabac's contexts while this CTU is searched: what kvz_rdoq prices on (rdo.c:665) */
+  /* sequences with inter pictures (kvz_oracle_inter.inc): the frame's cu_array per 4x4 unit (neighbours outside the CTU come from it when it is set),
+   * the slice type and what the inter search reads of the reference picture */
+  cu_t *fcu;
+  int slice_b;
+  const struct inter_seq *in;
 } ctu_t;
 
 /* CABAC_FBITS_UPDATE (cabac.h:133-139) on context idx of t->cab: the price of `bin`, then -- if `update` -- the state change
@@ -287,7 +299,9 @@ static int neighbour_cu(ctu_t *t, level_t *lv, int fx, int fy, cu_t *out)
 {
   if (fx < 0 || fy < 0 || fx >= t->W || fy >= t->H) return 0;
   if (fx >= t->cx && fx < t->cx + LCU && fy >= t->cy && fy < t->cy + LCU) { *out = *cu_at(lv, fx - t->cx, fy - t->cy); return 1; }
+  if (t->fcu) { *out = t->fcu[(fy >> 2) * (t->W >> 2) + (fx >> 2)]; return 1; }
   const int i = (fy >> 3) * (t->W >> 3) + (fx >> 3);
+  memset(out, 0, sizeof *out);
   out->type = 1; out->depth = t->fdepth[i]; out->mode = t->fmode4[(fy >> 2) * (t->W >> 2) + (fx >> 2)]; out->tr_depth = out->depth; out->cbf = 0;
   return 1;
 }
@@ -464,7 +478,7 @@ static int rough_search(ctu_t *t, int log2w, const uint8_t *orig /* contiguous *
 }
 
 /* search_intra.c:812-900 kvz_search_cu_intra (rd=0: rough search only) */
-static int search_cu_intra(ctu_t *t, level_t *lv, int x, int y, int depth)
+static int search_cu_intra_cost(ctu_t *t, level_t *lv, int x, int y, int depth, double *cost_out)
 {
   const int log2w = 6 - depth, w = 1 << log2w, xl = x - t->cx, yl = y - t->cy;
   cu_t lc, ac, *left = NULL, *above = NULL;
@@ -479,8 +493,10 @@ static int search_cu_intra(ctu_t *t, level_t *lv, int x, int y, int depth)
   const int n = rough_search(t, log2w, orig, top, lft, preds, modes, costs);
   int bi = 0;
   for (int i = 1; i < n; i++) if (costs[i] < costs[bi]) bi = i;
+  if (cost_out) *cost_out = costs[bi];
   return modes[bi];
 }
+static int search_cu_intra(ctu_t *t, level_t *lv, int x, int y, int depth) { return search_cu_intra_cost(t, lv, x, y, depth, NULL); }
 
 /* kvz_get_scan_order for an intra block (encoderstate.c:1761-1775); the chroma mode is the luma mode here */
 static int tu_scan_order(int mode, int depth)
@@ -498,7 +514,7 @@ static int quantize_residual_rdoq(const ctu_t *t, int width, int color, int scan
   int16_t residual[32 * 32], coeff[32 * 32];
   kvz_hip_quant_params p;
   memset(&p, 0, sizeof p);
-  p.qp = t->m->qp; p.bitdepth = 8; p.slice_is_intra = 1; p.cu_is_intra = 1;
+  p.qp = t->m->qp; p.bitdepth = 8; p.slice_is_intra = !t->slice_b; p.cu_is_intra = 1;
   for (int y = 0; y < width; y++)
     for (int x = 0; x < width; x++) residual[x + y * width] = (int16_t)(ref_in[x + y * stride] - rec[x + y * stride]);
   const int idx = width == 4 ? (color == 0 ? 4 : 0) : width == 8 ? 1 : width == 16 ? 2 : 3;
@@ -530,7 +546,7 @@ static int recon_tu(ctu_t *t, level_t *lv, int c, int x, int y /* luma frame coo
   if (t->m->rdoq) return quantize_residual_rdoq(t, w, c, tu_scan_order(mode, depth), tr_rel, lw, &t->org[c][yl * lw + xl], rec, coeff);
   kvz_hip_quant_params p;
   memset(&p, 0, sizeof p);
-  p.qp = t->m->qp; p.bitdepth = 8; p.slice_is_intra = 1; p.cu_is_intra = 1;
+  p.qp = t->m->qp; p.bitdepth = 8; p.slice_is_intra = !t->slice_b; p.cu_is_intra = 1;
   return kvz_oracle_quantize_residual(&p, w, c, 0, 0, lw, lw, &t->org[c][yl * lw + xl], rec, rec, coeff, 0);
 }
 
@@ -991,3 +1007,5 @@ void kvz_oracle_intra_cost_model(int qp, const float entropy_fbits[128], uint64_
   FILL2(m->chroma_mode, init_chroma);
   for (int i = 0; i < 2; i++) { FILL2(m->cbf_luma[i], init_cbf_luma[i]); FILL2(m->cbf_chroma[i], init_cbf_chroma[i]); }
 }
+
+#include "kvz_oracle_inter.inc"

@@ -133,13 +133,33 @@ void kvz_oracle_deblock_frame_passes(int width, int height, int qp, int beta_off
  * Statement for statement: vertical edges of the LCU (filter.c:699-714), the deferred rightmost 4 samples of the horizontal edges of the
  * LCU to the left (filter.c:725-757), the horizontal edges of the LCU without their rightmost 4 samples unless the LCU ends the picture
  * (filter.c:648-683). */
-typedef struct { int width, height, beta, tc, tc_c; uint8_t *y, *u, *v; const uint8_t *cu_depth; } dbk_t;
+typedef struct {
+  int width, height, beta, tc, tc_c; uint8_t *y, *u, *v; const uint8_t *cu_depth;
+  /* pictures with inter CUs (kvz_oracle_deblock_lcu_inter): per-part boundary strengths from `info` instead of the constant 2 */
+  const kvz_hip_cu_dbk *info; int slice_b, qp, tc_offset_div2;
+} dbk_t;
+static const kvz_hip_cu_dbk *unit_at(const kvz_hip_cu_dbk *info, int width, int x, int y);
+static int inter_edge_on(const kvz_hip_cu_dbk *info, int width, int x, int y, int vertical, int *tu_boundary);
+static int inter_strength(const kvz_hip_cu_dbk *q, const kvz_hip_cu_dbk *p, int tu_boundary, int slice_b);
+static int unit_edge(const dbk_t *d, int x, int y, int vertical, int *tu_boundary)
+{
+  if (d->info) return inter_edge_on(d->info, d->width, x, y, vertical, tu_boundary);
+  *tu_boundary = 1;
+  return edge_is_filtered(d->cu_depth, d->width >> 3, x, y, vertical);
+}
 
-static void edge_luma(const dbk_t *d, int x, int y, int length, int vertical)   /* filter.c:386-561 on `length` samples */
+static void edge_luma(const dbk_t *d, int x, int y, int length, int vertical, int tu_boundary)   /* filter.c:386-561 on `length` samples */
 {
   for (int part = 0; part < length / 4; part++) {
-    uint8_t *p = d->y + (y + (vertical ? 4 * part : 0)) * d->width + x + (vertical ? 0 : 4 * part);
-    luma_part(p, vertical ? 1 : d->width, vertical ? d->width : 1, d->beta, d->tc);
+    const int px = x + (vertical ? 0 : 4 * part), py = y + (vertical ? 4 * part : 0);
+    int tc = d->tc;
+    if (d->info) {  /* filter.c:405-497: the strength of this 4-sample part */
+      const int s = inter_strength(unit_at(d->info, d->width, px, py), unit_at(d->info, d->width, vertical ? px - 1 : px, vertical ? py : py - 1), tu_boundary, d->slice_b);
+      if (!s) continue;
+      tc = tc_prime(clip3(0, 53, d->qp + 2 * (s - 1) + (d->tc_offset_div2 << 1)));
+    }
+    uint8_t *p = d->y + py * d->width + px;
+    luma_part(p, vertical ? 1 : d->width, vertical ? d->width : 1, d->beta, tc);
   }
 }
 static void edge_chroma(const dbk_t *d, int xc, int yc, int length, int vertical)  /* filter.c:567-624 */
@@ -147,11 +167,15 @@ static void edge_chroma(const dbk_t *d, int xc, int yc, int length, int vertical
   const int cw = d->width >> 1;
   for (int part = 0; part < length / 4; part++) {
     const int off = (yc + (vertical ? 4 * part : 0)) * cw + xc + (vertical ? 0 : 4 * part);
+    if (d->info) {  /* filter.c:610: chroma only at strength 2, i.e. next to an intra CU */
+      const int lx = 2 * (xc + (vertical ? 0 : 4 * part)), ly = 2 * (yc + (vertical ? 4 * part : 0));
+      if (unit_at(d->info, d->width, lx, ly)->type != 1 && unit_at(d->info, d->width, vertical ? lx - 1 : lx, vertical ? ly : ly - 1)->type != 1) continue;
+    }
     chroma_part(d->u + off, vertical ? 1 : cw, vertical ? cw : 1, d->tc_c);
     chroma_part(d->v + off, vertical ? 1 : cw, vertical ? cw : 1, d->tc_c);
   }
 }
-static void deblock_unit(const dbk_t *d, int x, int y, int vertical)  /* filter.c:638-683 with width = height = 8 */
+static void deblock_unit(const dbk_t *d, int x, int y, int vertical, int tu_boundary)  /* filter.c:638-683 with width = height = 8 */
 {
   if (x == 0 && vertical) return;
   if (y == 0 && !vertical) return;
@@ -160,7 +184,7 @@ static void deblock_unit(const dbk_t *d, int x, int y, int vertical)  /* filter.
     const int x_right = x + 8;
     if (x_right % 64 == 0 && x_right != d->width) { length = 4; length_c = 0; }  /* deferred to the next LCU */
   }
-  edge_luma(d, x, y, length, vertical);
+  edge_luma(d, x, y, length, vertical, tu_boundary);
   const int xc = x >> 1, yc = y >> 1;
   if (((vertical ? xc : yc) & 7) == 0) edge_chroma(d, xc, yc, length_c, vertical);
 }
@@ -168,24 +192,37 @@ static void deblock_lcu_inside(const dbk_t *d, int x, int y, int vertical)  /* f
 {
   const int end_x = x + 64 < d->width ? x + 64 : d->width, end_y = y + 64 < d->height ? y + 64 : d->height;
   for (int ey = y; ey < end_y; ey += 8)
-    for (int ex = x; ex < end_x; ex += 8)
-      if (edge_is_filtered(d->cu_depth, d->width >> 3, ex, ey, vertical)) deblock_unit(d, ex, ey, vertical);
+    for (int ex = x; ex < end_x; ex += 8) {
+      int tu_boundary;
+      if (unit_edge(d, ex, ey, vertical, &tu_boundary)) deblock_unit(d, ex, ey, vertical, tu_boundary);
+    }
 }
 static void deblock_lcu_rightmost(const dbk_t *d, int x_px, int y_px)  /* filter.c:725-757 */
 {
   const int x = x_px - 4, end = y_px + 64 < d->height ? y_px + 64 : d->height;
+  int tu_boundary;
   for (int y = y_px; y < end; y += 8)
-    if (y > 0 && edge_is_filtered(d->cu_depth, d->width >> 3, x, y, 0)) edge_luma(d, x, y, 4, 0);
+    if (y > 0 && unit_edge(d, x, y, 0, &tu_boundary)) edge_luma(d, x, y, 4, 0, tu_boundary);
   const int xc = (x_px >> 1) - 4, yc0 = y_px >> 1, end_c = yc0 + 32 < (d->height >> 1) ? yc0 + 32 : d->height >> 1;
   for (int yc = yc0; yc < end_c; yc += 8)
-    if (yc > 0 && edge_is_filtered(d->cu_depth, d->width >> 3, xc << 1, yc << 1, 0)) edge_chroma(d, xc, yc, 4, 0);
+    if (yc > 0 && unit_edge(d, xc << 1, yc << 1, 0, &tu_boundary)) edge_chroma(d, xc, yc, 4, 0);
 }
 
 void kvz_oracle_deblock_lcu(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,
                             const uint8_t *cu_depth, int x_px, int y_px)
 {
   dbk_t d = { width, height, beta_prime(clip3(0, 51, qp + (beta_offset_div2 << 1))), tc_prime(clip3(0, 53, qp + 2 + (tc_offset_div2 << 1))),
-              tc_prime(clip3(0, 53, chroma_qp[qp] + 2 + (tc_offset_div2 << 1))), y, u, v, cu_depth };
+              tc_prime(clip3(0, 53, chroma_qp[qp] + 2 + (tc_offset_div2 << 1))), y, u, v, cu_depth, NULL, 0, qp, tc_offset_div2 };
+  deblock_lcu_inside(&d, x_px, y_px, 1);
+  if (x_px > 0) deblock_lcu_rightmost(&d, x_px, y_px);
+  deblock_lcu_inside(&d, x_px, y_px, 0);
+}
+/* the same LCU step on a picture with inter CUs: edges and per-part strengths from one kvz_hip_cu_dbk per 4x4 unit */
+void kvz_oracle_deblock_lcu_inter(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,
+                                  const kvz_hip_cu_dbk *info, int slice_is_b, int x_px, int y_px)
+{
+  dbk_t d = { width, height, beta_prime(clip3(0, 51, qp + (beta_offset_div2 << 1))), tc_prime(clip3(0, 53, qp + 2 + (tc_offset_div2 << 1))),
+              tc_prime(clip3(0, 53, chroma_qp[qp] + 2 + (tc_offset_div2 << 1))), y, u, v, NULL, info, slice_is_b, qp, tc_offset_div2 };
   deblock_lcu_inside(&d, x_px, y_px, 1);
   if (x_px > 0) deblock_lcu_rightmost(&d, x_px, y_px);
   deblock_lcu_inside(&d, x_px, y_px, 0);

@@ -247,8 +247,24 @@ static void export_params(const sao_t *s, kvz_hip_sao_params *o, int planes)
   o->bitdepth = 8;
 }
 
+static void sao_search_frame(const kvz_hip_intra_cost_model *m, int width, int height, const uint8_t *src, uint8_t *rec, const uint8_t *cu_depth,
+                             const kvz_hip_cu_dbk *info, int slice_is_b, int deblock, int beta_offset_div2, int tc_offset_div2, kvz_hip_sao_params *luma_out,
+                             kvz_hip_sao_params *chroma_out, uint8_t *merge_out);
 void kvz_oracle_sao_search_frame(const kvz_hip_intra_cost_model *m, int width, int height, const uint8_t *src, uint8_t *rec, const uint8_t *cu_depth,
                                  int deblock, int beta_offset_div2, int tc_offset_div2, kvz_hip_sao_params *luma_out, kvz_hip_sao_params *chroma_out, uint8_t *merge_out)
+{
+  sao_search_frame(m, width, height, src, rec, cu_depth, NULL, 0, deblock, beta_offset_div2, tc_offset_div2, luma_out, chroma_out, merge_out);
+}
+/* the same on a picture of a sequence with inter prediction: the deblocking step takes its edges and strengths from `info` (one record per 4x4 unit) */
+void kvz_oracle_sao_search_frame_inter(const kvz_hip_intra_cost_model *m, int width, int height, const uint8_t *src, uint8_t *rec, const kvz_hip_cu_dbk *info,
+                                       int slice_is_b, int deblock, int beta_offset_div2, int tc_offset_div2, kvz_hip_sao_params *luma_out,
+                                       kvz_hip_sao_params *chroma_out, uint8_t *merge_out)
+{
+  sao_search_frame(m, width, height, src, rec, NULL, info, slice_is_b, deblock, beta_offset_div2, tc_offset_div2, luma_out, chroma_out, merge_out);
+}
+static void sao_search_frame(const kvz_hip_intra_cost_model *m, int width, int height, const uint8_t *src, uint8_t *rec, const uint8_t *cu_depth,
+                             const kvz_hip_cu_dbk *info, int slice_is_b, int deblock, int beta_offset_div2, int tc_offset_div2, kvz_hip_sao_params *luma_out,
+                             kvz_hip_sao_params *chroma_out, uint8_t *merge_out)
 {
   const int wl = (width + 63) / 64, hl = (height + 63) / 64, cw = width / 2, ch = height / 2;
   const size_t ys = (size_t)width * height, cs = ys / 4;
@@ -260,7 +276,8 @@ void kvz_oracle_sao_search_frame(const kvz_hip_intra_cost_model *m, int width, i
      * LCU wide: lcu->index == 1 never happens and the row keeps its slice-start state); without WPP the coder simply runs on */
     if (!m->no_wpp) cab = ly == 0 ? row_start : next_row;
     for (int lx = 0; lx < wl; lx++) {
-      if (deblock) kvz_oracle_deblock_lcu(width, height, m->qp, beta_offset_div2, tc_offset_div2, ry, ru, rv, cu_depth, lx * 64, ly * 64);
+      if (deblock && info) kvz_oracle_deblock_lcu_inter(width, height, m->qp, beta_offset_div2, tc_offset_div2, ry, ru, rv, info, slice_is_b, lx * 64, ly * 64);
+      else if (deblock) kvz_oracle_deblock_lcu(width, height, m->qp, beta_offset_div2, tc_offset_div2, ry, ru, rv, cu_depth, lx * 64, ly * 64);
       sao_t *sl = &luma[ly * wl + lx], *sc = &chroma[ly * wl + lx];
       const sao_t *top_l = ly ? &luma[(ly - 1) * wl + lx] : NULL, *left_l = lx ? &luma[ly * wl + lx - 1] : NULL;
       const sao_t *top_c = ly ? &chroma[(ly - 1) * wl + lx] : NULL, *left_c = lx ? &chroma[ly * wl + lx - 1] : NULL;

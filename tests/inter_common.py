@@ -1,0 +1,142 @@
+"""Shared by the inter-oracle tests and tests/golden/make_golden.py --inter: synthetic clips with real motion, the low-delay sequence oracle
+(oracle/kvz_oracle_inter.inc through ctypes) and the compiled reference encoder run on the same clip (oracle/_ref/kvazaar_ref with the
+oracle/ref_cudump.c interposer recording the CU decisions).  TEST INFRASTRUCTURE -- never imported by the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import ctu_common as cc
+import flatapi
+
+CU_DTYPE = np.dtype([("type", "u1"), ("depth", "u1"), ("mode", "u1"), ("tr_depth", "u1"), ("cbf", "<u2"), ("skipped", "u1"), ("merged", "u1"), ("merge_idx", "u1"),
+                     ("mv_dir", "u1"), ("mv_ref", "u1", (2,)), ("mv_cand", "u1", (2,)), ("mv", "<i2", (2, 2))], align=True)
+assert CU_DTYPE.itemsize == 22
+
+
+class LowdelayCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("qp", "gop_len", "gop_depth", "intra_period", "fme_level", "pu_depth_inter_max", "sao", "deblock", "mv_constraint", "no_wpp")]
+
+
+PRESETS = {"veryfast": dict(fme_level=2, pu_depth_inter_max=3, sao=1), "ultrafast": dict(fme_level=0, pu_depth_inter_max=2, sao=0)}
+
+
+def clip(w, h, n, seed, noise=1.5):
+    """n frames (Y|U|V bytes each) of a textured background under a global sub-pel pan, rectangles moving on their own, one object that appears in
+    frame 2 (nothing to predict it from) and sensor noise: skipped, merged, AMVP and intra CUs all occur"""
+    rng = np.random.default_rng(seed)
+    H2, W2 = h + 64, w + 64
+    yy, xx = np.mgrid[0:H2, 0:W2].astype(np.float64)
+    base = 128 + 45 * np.sin(xx / 9.0) * np.cos(yy / 13.0) + 30 * np.sin((xx + 2 * yy) / 31.0) + 12 * rng.standard_normal((H2, W2)).cumsum(axis=1) / 6
+    cb = 128 + 40 * np.sin(xx[::2, ::2] / 27.0) + 20 * np.cos(yy[::2, ::2] / 19.0)
+    cr = 128 + 40 * np.cos((xx[::2, ::2] - yy[::2, ::2]) / 33.0)
+    rects = [(int(rng.integers(0, w - 40)), int(rng.integers(0, h - 40)), int(rng.integers(16, 40)), int(rng.integers(16, 40)), float(rng.uniform(-3, 3)), float(rng.uniform(-2, 2)),
+              int(rng.integers(40, 220))) for _ in range(4)]
+    out = []
+
+    def shift(p, dx, dy):  # bilinear sub-pel shift of a padded plane
+        ix, iy = int(np.floor(dx)), int(np.floor(dy))
+        fx, fy = dx - ix, dy - iy
+        q = np.roll(p, (-iy, -ix), (0, 1))
+        q = (1 - fx) * q + fx * np.roll(q, -1, 1)
+        return (1 - fy) * q + fy * np.roll(q, -1, 0)
+
+    for i in range(n):
+        dx, dy = 1.25 * i, -0.5 * i
+        Y = shift(base, dx, dy)[32:32 + h, 32:32 + w].copy()
+        U = shift(cb, dx / 2, dy / 2)[16:16 + h // 2, 16:16 + w // 2].copy()
+        V = shift(cr, dx / 2, dy / 2)[16:16 + h // 2, 16:16 + w // 2].copy()
+        for (rx, ry, rw, rh, vx, vy, lum) in rects:
+            x0, y0 = int(round(rx + vx * i)) % max(1, w - rw), int(round(ry + vy * i)) % max(1, h - rh)
+            Y[y0:y0 + rh, x0:x0 + rw] = lum + 10 * np.sin(np.arange(rw) / 3.0)[None, :]
+            U[y0 // 2:(y0 + rh) // 2, x0 // 2:(x0 + rw) // 2] = 90
+        if i >= 2:
+            Y[h // 3:h // 3 + 24, w // 2:w // 2 + 24] = 30 + 8 * ((np.arange(24)[:, None] + np.arange(24)[None, :]) % 5)
+            V[h // 6:h // 6 + 12, w // 4:w // 4 + 12] = 200
+        Y = Y + rng.normal(0, noise, Y.shape)
+        out.append(np.concatenate([np.clip(np.rint(p), 0, 255).astype(np.uint8).reshape(-1) for p in (Y, U, V)]))
+    return out
+
+
+def oracle_encode(oracle, w, h, frames, qp, preset="veryfast", deblock=True, sao=None, mv_constraint=False, gop=(4, 3), no_wpp=False):
+    """-> (rec_search [n, fs], rec_final [n, fs], cu [n, h/4, w/4] of CU_DTYPE, qps)"""
+    p = dict(PRESETS[preset])
+    if sao is not None:
+        p["sao"] = int(sao)
+    cfg = LowdelayCfg(qp=qp, gop_len=gop[0], gop_depth=gop[1], intra_period=64, deblock=int(deblock), mv_constraint=int(mv_constraint), no_wpp=int(no_wpp), **p)
+    mc = cc.model_constants()
+    fb = (C.c_float * 128)(*mc["entropy_fbits"])
+    wts = (C.c_uint64 * 52)(*[int(mc["coeff_weights"][str(q)]) for q in range(52)])
+    n, fs = len(frames), w * h * 3 // 2
+    src = np.ascontiguousarray(np.concatenate(frames))
+    rs, rf = np.zeros(n * fs, np.uint8), np.zeros(n * fs, np.uint8)
+    cu = np.zeros(n * (w // 4) * (h // 4), CU_DTYPE)
+    qps = np.zeros(n, np.int32)
+    f = oracle.lib.kvz_oracle_lowdelay_encode
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 5
+    f(C.addressof(cfg), C.addressof(fb), C.addressof(wts), w, h, n, src.ctypes.data, rs.ctypes.data, rf.ctypes.data, cu.ctypes.data, qps.ctypes.data)
+    return rs.reshape(n, fs), rf.reshape(n, fs), cu.reshape(n, h // 4, w // 4), qps
+
+
+def reference_encode(w, h, frames, qp, workdir, preset="veryfast", deblock=True, sao=None, owf=0, threads=0, gop="lp-g4d3t1", cu=True, extra=()):
+    """oracle/_ref/kvazaar_ref on the clip -> (--debug reconstruction [n, fs], cu [n, h/4, w/4] of CU_DTYPE or None).  The CU records are only taken with
+    threads == 0 (LCUs then reach kvz_encode_coding_tree picture by picture, in raster order)"""
+    exe = os.path.join(flatapi.ROOT, "oracle", "_ref", "kvazaar_ref")
+    src, rec, dump = os.path.join(workdir, "in.yuv"), os.path.join(workdir, "rec.yuv"), os.path.join(workdir, "cu.txt")
+    with open(src, "wb") as f:
+        f.write(b"".join(fr.tobytes() for fr in frames))
+    cmd = [exe, "-i", src, "--input-res", f"{w}x{h}", "--preset", preset, "--gop", gop, "-q", str(qp), "--debug", rec, "-o", os.path.join(workdir, "out.hevc"),
+           "--threads", str(threads), "--owf", str(owf)] + list(extra)
+    if not deblock:
+        cmd.append("--no-deblock")
+    if sao is not None:
+        cmd += ["--sao", "full" if sao else "off"]
+    env = dict(os.environ)
+    if cu:
+        assert threads == 0
+        if os.path.exists(dump):
+            os.remove(dump)
+        env.update(LD_PRELOAD=os.path.join(flatapi.ROOT, "oracle", "_ref", "libkvz_cudump.so"), KVZ_CUDUMP=dump, KVZ_CUDUMP_INTER="1")
+    subprocess.run(cmd, check=True, capture_output=True, env=env)
+    n, fs = len(frames), w * h * 3 // 2
+    recon = np.fromfile(rec, dtype=np.uint8).reshape(n, fs)
+    if not cu:
+        return recon, None
+    rows = np.loadtxt(dump, dtype=np.int64).reshape(n, -1, 20)
+    out = np.zeros((n, h // 4, w // 4), CU_DTYPE)
+    for f in range(n):
+        r = rows[f]
+        yy, xx = r[:, 1] // 4, r[:, 0] // 4
+        for k, name in ((2, "type"), (3, "depth"), (5, "tr_depth"), (6, "skipped"), (7, "merged"), (8, "merge_idx"), (9, "cbf"), (10, "mode"), (11, "mv_dir")):
+            out[name][f, yy, xx] = r[:, k]
+        out["mv"][f, yy, xx, 0, 0], out["mv"][f, yy, xx, 0, 1], out["mv"][f, yy, xx, 1, 0], out["mv"][f, yy, xx, 1, 1] = r[:, 12], r[:, 13], r[:, 14], r[:, 15]
+        out["mv_ref"][f, yy, xx, 0], out["mv_ref"][f, yy, xx, 1] = r[:, 16], r[:, 17]
+        out["mv_cand"][f, yy, xx, 0], out["mv_cand"][f, yy, xx, 1] = r[:, 18], r[:, 19]
+    return recon, out
+
+
+def first_difference(a, b, fields=("type", "depth", "skipped", "merged", "merge_idx", "mv_dir", "mv", "mv_ref", "mv_cand", "mode")):
+    """the first CU (picture, then raster order of the 4x4 units inside LCUs in coding order) where two CU maps differ, or None"""
+    n, h4, w4 = a.shape
+    for f in range(n):
+        for ly in range(0, h4, 16):
+            for lx in range(0, w4, 16):
+                for name in fields:
+                    x, y = a[name][f, ly:ly + 16, lx:lx + 16], b[name][f, ly:ly + 16, lx:lx + 16]
+                    if name == "mode":
+                        m = (a["type"][f, ly:ly + 16, lx:lx + 16] == 1)
+                        x, y = np.where(m, x, 0), np.where(m, y, 0)
+                    if name in ("mv_dir", "mv", "mv_ref", "mv_cand", "skipped", "merged"):
+                        m = (a["type"][f, ly:ly + 16, lx:lx + 16] == 2)
+                        m = m.reshape(m.shape + (1,) * (x.ndim - 2))
+                        x, y = np.where(m, x, 0), np.where(m, y, 0)
+                    if name in ("merge_idx",):
+                        m = (a["merged"][f, ly:ly + 16, lx:lx + 16] | a["skipped"][f, ly:ly + 16, lx:lx + 16]) > 0
+                        x, y = np.where(m, x, 0), np.where(m, y, 0)
+                    if not np.array_equal(x, y):
+                        d = np.argwhere((x != y).reshape(x.shape[0], x.shape[1], -1).any(axis=2))
+                        yy, xx = d[0]
+                        return dict(frame=f, lcu=(lx // 16, ly // 16), field=name, x=4 * (lx + xx), y=4 * (ly + yy), ours=a[f, ly + yy, lx + xx], ref=b[f, ly + yy, lx + xx])
+    return None
