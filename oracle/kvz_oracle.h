@@ -179,8 +179,9 @@ typedef struct kvz_oracle_lowdelay_cfg {
   int32_t sao, deblock;        /* --sao full / off, --deblock / --no-deblock */
   int32_t mv_constraint;       /* cfg.owf && cfg.wpp (search_inter.c:85) */
   int32_t no_wpp;
+  int32_t ra8_qp_model;        /* a --preset came before --gop lp-...: the QP model fields of kvz_gop_ra8 stay in the GOP entries (kvz_oracle_lowdelay_qp) */
 } kvz_oracle_lowdelay_cfg;
-int  kvz_oracle_lowdelay_qp(int qp, int gop_len, int gop_depth, int frame, int intra_period);
+int  kvz_oracle_lowdelay_qp(int qp, int gop_len, int gop_depth, int frame, int intra_period, int ra8_model);
 void kvz_oracle_lowdelay_encode(const kvz_oracle_lowdelay_cfg *cfg, const float entropy_fbits[128], const uint64_t coeff_weights[52], int width, int height,
                                 int n_frames, const uint8_t *src, uint8_t *rec_search, uint8_t *rec_final, kvz_oracle_cu *cu_out, int32_t *frame_qp);
 

@@ -269,7 +269,27 @@ def cu_digest(depth, mode):
     return hashlib.sha256(np.ascontiguousarray(depth, np.uint8).tobytes() + np.ascontiguousarray(mode, np.uint8).tobytes()).hexdigest()[:24]
 
 
+def update_inter():
+    """tests/golden/inter_recon.json: the reference encoder (oracle/_ref/kvazaar_ref, --preset ... --gop lp-g4d3t1, --threads 0 so that the ref_cudump.c
+    interposer sees the LCUs in order) on the clips of tests/inter_common.py CASES: digest of every picture's --debug reconstruction and of its CU decisions,
+    md5 of the bitstream"""
+    import tempfile
+    import inter_common as ic
+    out = {}
+    for case in ic.CASES:
+        name, w, h, n, qp, preset, dbk, sao, owf, src = case
+        frames = ic.case_frames(case)
+        with tempfile.TemporaryDirectory() as d:
+            rec, cu = ic.reference_encode(w, h, frames, qp, d, preset=preset, deblock=bool(dbk), sao=bool(sao), owf=owf)
+            out[name] = dict(ic.digests(rec, cu), bitstream_md5=hashlib.md5(open(os.path.join(d, "out.hevc"), "rb").read()).hexdigest(),
+                             clip_md5=hashlib.md5(b"".join(f.tobytes() for f in frames)).hexdigest())
+        print(name, out[name]["bitstream_md5"], flush=True)
+    json.dump(out, open(os.path.join(HERE, "inter_recon.json"), "w"), indent=0, sort_keys=True)
+
+
 def main():
+    if "--inter" in sys.argv:
+        return update_inter()
     ref = flatapi.load_ref(0)  # generic strategies
     oracle = flatapi.load_oracle()
 

@@ -16,17 +16,17 @@ assert CU_DTYPE.itemsize == 22
 
 
 class LowdelayCfg(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("qp", "gop_len", "gop_depth", "intra_period", "fme_level", "pu_depth_inter_max", "sao", "deblock", "mv_constraint", "no_wpp")]
+    _fields_ = [(n, C.c_int32) for n in ("qp", "gop_len", "gop_depth", "intra_period", "fme_level", "pu_depth_inter_max", "sao", "deblock", "mv_constraint", "no_wpp", "ra8_qp_model")]
 
 
 PRESETS = {"veryfast": dict(fme_level=2, pu_depth_inter_max=3, sao=1), "ultrafast": dict(fme_level=0, pu_depth_inter_max=2, sao=0)}
 
 
-def clip(w, h, n, seed, noise=1.5):
+def clip(w, h, n, seed, noise=1.5, pan=(1.25, -0.5)):
     """n frames (Y|U|V bytes each) of a textured background under a global sub-pel pan, rectangles moving on their own, one object that appears in
     frame 2 (nothing to predict it from) and sensor noise: skipped, merged, AMVP and intra CUs all occur"""
     rng = np.random.default_rng(seed)
-    H2, W2 = h + 64, w + 64
+    H2, W2 = h + 64, w + 64  # the pan wraps around (np.roll): large pans bring in unrelated content, which is fine
     yy, xx = np.mgrid[0:H2, 0:W2].astype(np.float64)
     base = 128 + 45 * np.sin(xx / 9.0) * np.cos(yy / 13.0) + 30 * np.sin((xx + 2 * yy) / 31.0) + 12 * rng.standard_normal((H2, W2)).cumsum(axis=1) / 6
     cb = 128 + 40 * np.sin(xx[::2, ::2] / 27.0) + 20 * np.cos(yy[::2, ::2] / 19.0)
@@ -43,7 +43,7 @@ def clip(w, h, n, seed, noise=1.5):
         return (1 - fy) * q + fy * np.roll(q, -1, 0)
 
     for i in range(n):
-        dx, dy = 1.25 * i, -0.5 * i
+        dx, dy = pan[0] * i, pan[1] * i
         Y = shift(base, dx, dy)[32:32 + h, 32:32 + w].copy()
         U = shift(cb, dx / 2, dy / 2)[16:16 + h // 2, 16:16 + w // 2].copy()
         V = shift(cr, dx / 2, dy / 2)[16:16 + h // 2, 16:16 + w // 2].copy()
@@ -64,7 +64,7 @@ def oracle_encode(oracle, w, h, frames, qp, preset="veryfast", deblock=True, sao
     p = dict(PRESETS[preset])
     if sao is not None:
         p["sao"] = int(sao)
-    cfg = LowdelayCfg(qp=qp, gop_len=gop[0], gop_depth=gop[1], intra_period=64, deblock=int(deblock), mv_constraint=int(mv_constraint), no_wpp=int(no_wpp), **p)
+    cfg = LowdelayCfg(qp=qp, gop_len=gop[0], gop_depth=gop[1], intra_period=64, deblock=int(deblock), mv_constraint=int(mv_constraint), no_wpp=int(no_wpp), ra8_qp_model=1, **p)
     mc = cc.model_constants()
     fb = (C.c_float * 128)(*mc["entropy_fbits"])
     wts = (C.c_uint64 * 52)(*[int(mc["coeff_weights"][str(q)]) for q in range(52)])
@@ -140,3 +140,48 @@ def first_difference(a, b, fields=("type", "depth", "skipped", "merged", "merge_
                         yy, xx = d[0]
                         return dict(frame=f, lcu=(lx // 16, ly // 16), field=name, x=4 * (lx + xx), y=4 * (ly + yy), ours=a[f, ly + yy, lx + xx], ref=b[f, ly + yy, lx + xx])
     return None
+
+
+# (name, width, height, frames, qp, preset, deblock, sao, owf, clip) -- clip = ("motion", seed, noise, pan) of clip() above or ("synth", seed, kind) of kvazaar_amd/synth.py.
+# tests/golden/inter_recon.json holds, per case, the REFERENCE encoder's digests (reconstruction per picture, CU decisions per picture, its bitstream's md5)
+CASES = [
+    ("pan", 200, 136, 4, 22, "veryfast", 1, 1, 0, ("motion", 5, 1.5, (1.25, -0.5))),
+    ("noisy-qp27", 200, 136, 4, 27, "veryfast", 1, 1, 0, ("motion", 6, 3.0, (-2.0, 1.75))),
+    ("cabac-coeff-cost-qp32", 264, 200, 4, 32, "veryfast", 1, 1, 0, ("motion", 7, 1.0, (0.5, 0.25))),
+    ("fast-pan-owf-qp37", 264, 200, 4, 37, "veryfast", 1, 1, 2, ("motion", 8, 2.0, (4.0, 9.0))),
+    ("ultrafast", 416, 240, 5, 22, "ultrafast", 1, 0, 0, ("motion", 9, 1.5, (1.25, -0.5))),
+    ("ultrafast-fast-pan-owf-qp30", 416, 240, 5, 30, "ultrafast", 1, 0, 2, ("motion", 10, 1.5, (-6.0, 13.0))),
+    ("vertical-pan-owf", 320, 320, 5, 22, "veryfast", 1, 1, 2, ("motion", 11, 0.5, (3.0, 21.0))),
+    ("static-qp17", 320, 320, 5, 17, "veryfast", 1, 1, 0, ("motion", 12, 0.0, (0.0, 0.0))),
+    ("two-gops", 128, 64, 9, 24, "veryfast", 1, 1, 0, ("motion", 13, 1.0, (-1.0, 0.5))),
+    ("no-loop-filters", 416, 240, 4, 22, "veryfast", 0, 0, 0, ("motion", 3, 1.5, (1.25, -0.5))),
+    ("deblock-only", 416, 240, 4, 22, "veryfast", 1, 0, 0, ("motion", 3, 1.5, (1.25, -0.5))),
+    ("survey-416x240", 416, 240, 8, 22, "veryfast", 1, 1, 2, ("synth", 1234, "small")),    # bitstream md5 1e7a8165...
+    ("survey-1080p", 1920, 1080, 4, 22, "veryfast", 1, 1, 2, ("synth", 1, "large")),
+    ("baseline-c4-2160p", 3840, 2160, 4, 22, "veryfast", 1, 1, 2, ("synth", 2, "large")),    # BASELINE config 4 at its own size
+]
+
+
+def case_frames(case):
+    name, w, h, n, qp, preset, dbk, sao, owf, src = case
+    if src[0] == "motion":
+        return clip(w, h, n, src[1], src[2], src[3])
+    import kvazaar_amd.synth as synth
+    return [np.concatenate([p.reshape(-1) for p in f]) for f in synth.frames(w, h, n, src[1], src[2])]
+
+
+def cu_bytes(cu):
+    """the decisions of one picture as bytes, motion and flags only where they mean something"""
+    inter = cu["type"] == 2
+    coded = inter & (cu["merged"] == 0) & (cu["skipped"] == 0)
+    parts = [cu["type"], cu["depth"], np.where(cu["type"] == 1, cu["mode"], 0), np.where(inter, cu["skipped"], 0), np.where(inter, cu["merged"], 0),
+             np.where(inter & ((cu["merged"] | cu["skipped"]) > 0), cu["merge_idx"], 0), np.where(inter, cu["mv_dir"], 0)]
+    for l in range(2):
+        used = inter & ((cu["mv_dir"] >> l) & 1 > 0)
+        parts += [np.where(used, cu["mv"][..., l, 0], 0).astype("<i2"), np.where(used, cu["mv"][..., l, 1], 0).astype("<i2"), np.where(coded & used, cu["mv_cand"][..., l], 0)]
+    return b"".join(np.ascontiguousarray(p).tobytes() for p in parts)
+
+
+def digests(rec, cu):
+    import hashlib
+    return {"rec": [hashlib.sha256(r.tobytes()).hexdigest()[:24] for r in rec], "cu": [hashlib.sha256(cu_bytes(c)).hexdigest()[:24] for c in cu]}
