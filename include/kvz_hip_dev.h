@@ -112,6 +112,45 @@ typedef struct kvz_hip_mc_pu {
 } kvz_hip_mc_pu;
 int  kvz_hip_dev_inter_pred(const uint8_t *ref0, const uint8_t *ref1, uint8_t *pred, int width, int height, const kvz_hip_mc_pu *pus, int count, int max_pu_size);
 
+/* The motion search of one reference picture for `count` prediction units, whole -- search_pu_inter_ref (search_inter.c:1237-1435) and the fractional
+ * refinement of its result (search_inter.c:1866-1917 -> search_frac :974-1130) with every decision the reference takes on the way:
+ *   the starting point (select_starting_point :285-312: the best of (0,0), the co-located motion of the previous picture and the single-list merge candidates),
+ *   the early termination (early_terminate :425-486, `sensitive`: two rounds of a small cross, stop when a round gains less than 5 %),
+ *   the hexagon search (hexagon_search :712-800, unlimited steps) -- every probe = check_mv_cost (:180-232): edge-replicated SAD (image.c:407), then the MVD
+ *   bit cost of the cheaper AMVP predictor (calc_mvd_cost :381-423 / get_mvd_coding_cost :328-341) times lambda_sqrt, against the best so far with the
+ *   reference's 0.001 guard --, for fme_level 0 the SATD re-pricing of the result (:1381-1393),
+ *   for fme_level 2 the two half-pel steps (hor / ver neighbours, diagonal neighbours) with the truncation of the reference's `unsigned` cost accumulator,
+ *   and throughout the motion-vector restriction of overlapped pictures (fracmv_within_tile :75-152 with mv-constraint none: cfg.owf && cfg.wpp).
+ * What the caller supplies per PU is what depends on the neighbourhood: the two AMVP predictors (kvz_inter_get_mv_cand), the merge candidates' motion
+ * (kvz_inter_get_merge_cand; only candidates that use one list take part) and the co-located CU's motion.  cur / ref: width x height luma planes, stride = width.
+ * One workgroup per PU; PUs are squares of 8, 16, 32 or 64 samples inside the picture. */
+typedef struct kvz_hip_me_pu {
+  int16_t x, y, w, h;
+  int16_t mv_cand[2][2];   /* AMVP predictors, quarter samples */
+  int16_t start_mv[2];     /* motion of the co-located CU of the reference picture (search_inter.c:1286-1339), quarter samples; read when has_start */
+  uint8_t has_start;
+  uint8_t num_merge;       /* merge candidates, in list order */
+  uint8_t merge_dir[5];    /* inter_merge_cand_t::dir: 1 = L0, 2 = L1, 3 = both (ignored by the search) */
+  uint8_t reserved;
+  int16_t merge_mv[5][2];  /* motion of the candidate's list (dir 1 or 2), quarter samples */
+} kvz_hip_me_pu;
+typedef struct kvz_hip_me_params {
+  double  lambda_sqrt;     /* state->lambda_sqrt of the picture */
+  int32_t mv_constraint;   /* cfg.owf && cfg.wpp */
+  int32_t sao, deblock;    /* cfg.sao_type != 0, cfg.deblock_enable: the margin of that restriction */
+  int32_t fme_level;       /* 0 (`ultrafast`) or 2 (`veryfast`) */
+} kvz_hip_me_params;
+typedef struct kvz_hip_me_result {
+  int32_t mv[2];           /* after the integer search, quarter samples */
+  int32_t mvp, valid;      /* select_mv_cand of that vector; valid = it becomes an AMVP candidate (vector allowed and a cost was found, :1404-1405) */
+  double  cost, bits;
+  int32_t frac_mv[2];      /* after search_frac; frac_valid 0: not refined (fme_level 0, no quarter-sample step possible, or the result not allowed) -- the integer result stands */
+  int32_t frac_mvp, frac_valid;
+  double  frac_cost, frac_bits;
+} kvz_hip_me_result;
+int  kvz_hip_dev_pu_search(const uint8_t *cur, const uint8_t *ref, int width, int height, const kvz_hip_me_pu *pus, int count, const kvz_hip_me_params *params,
+                           kvz_hip_me_result *out);
+
 /* SAO applied to whole pictures: kvz_sao_reconstruct (sao.c:302-361) for every CTU and plane of n_frames tight planar 4:2:0
  * frames.  in = the deblocked pictures, out = a different buffer of the same layout (SAO reads pre-SAO neighbours);
  * luma / chroma = n_frames x CTUs (raster order) parameter records, chroma carrying U in offsets[0..4] / band_position[0] and V

@@ -181,6 +181,12 @@ typedef struct kvz_oracle_lowdelay_cfg {
   int32_t no_wpp;
   int32_t ra8_qp_model;        /* a --preset came before --gop lp-...: the QP model fields of kvz_gop_ra8 stay in the GOP entries (kvz_oracle_lowdelay_qp) */
 } kvz_oracle_lowdelay_cfg;
+/* the motion search of single PUs on caller-supplied candidates (the contract of kvz_hip_dev_pu_search, include/kvz_hip_dev.h), and a recorder of every such
+ * search the sequence encoder runs: inputs, results and the picture they belong to */
+void kvz_oracle_pu_motion_search(const uint8_t *cur, const uint8_t *ref, int width, int height, const kvz_hip_me_pu *pus, int count, const kvz_hip_me_params *prm,
+                                 kvz_hip_me_result *out);
+void kvz_oracle_me_trace(kvz_hip_me_pu *pus, kvz_hip_me_result *res, int32_t *poc, int capacity);
+int  kvz_oracle_me_trace_count(void);
 int  kvz_oracle_lowdelay_qp(int qp, int gop_len, int gop_depth, int frame, int intra_period, int ra8_model);
 void kvz_oracle_lowdelay_encode(const kvz_oracle_lowdelay_cfg *cfg, const float entropy_fbits[128], const uint64_t coeff_weights[52], int width, int height,
                                 int n_frames, const uint8_t *src, uint8_t *rec_search, uint8_t *rec_final, kvz_oracle_cu *cu_out, int32_t *frame_qp);

@@ -185,3 +185,57 @@ def cu_bytes(cu):
 def digests(rec, cu):
     import hashlib
     return {"rec": [hashlib.sha256(r.tobytes()).hexdigest()[:24] for r in rec], "cu": [hashlib.sha256(cu_bytes(c)).hexdigest()[:24] for c in cu]}
+
+
+# ---- the motion search of single PUs (kvz_hip_dev_pu_search's contract, include/kvz_hip_dev.h) ----
+ME_PU = np.dtype([("x", "<i2"), ("y", "<i2"), ("w", "<i2"), ("h", "<i2"), ("mv_cand", "<i2", (2, 2)), ("start_mv", "<i2", (2,)), ("has_start", "u1"), ("num_merge", "u1"),
+                  ("merge_dir", "u1", (5,)), ("reserved", "u1"), ("merge_mv", "<i2", (5, 2))], align=True)
+ME_RESULT = np.dtype([("mv", "<i4", (2,)), ("mvp", "<i4"), ("valid", "<i4"), ("cost", "<f8"), ("bits", "<f8"), ("frac_mv", "<i4", (2,)), ("frac_mvp", "<i4"), ("frac_valid", "<i4"),
+                      ("frac_cost", "<f8"), ("frac_bits", "<f8")], align=True)
+assert ME_PU.itemsize == 48 and ME_RESULT.itemsize == 64
+
+
+class MeParams(C.Structure):
+    _fields_ = [("lambda_sqrt", C.c_double), ("mv_constraint", C.c_int32), ("sao", C.c_int32), ("deblock", C.c_int32), ("fme_level", C.c_int32)]
+
+
+def lambda_sqrt(qp):
+    return float(np.sqrt(0.57 * 2.0 ** ((qp - 12) / 3.0)))
+
+
+def oracle_pu_search(oracle, cur, ref, w, h, pus, params):
+    out = np.zeros(len(pus), ME_RESULT)
+    f = oracle.lib.kvz_oracle_pu_motion_search
+    f.restype = None
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    cur, ref, pus = np.ascontiguousarray(cur), np.ascontiguousarray(ref), np.ascontiguousarray(pus)
+    f(cur.ctypes.data, ref.ctypes.data, w, h, pus.ctypes.data, len(pus), C.addressof(params), out.ctypes.data)
+    return out
+
+
+def traced_encode(oracle, case, capacity=400000):
+    """the sequence oracle on a CASES entry with the motion-search recorder on -> (frames, rec_final, qps, pus, results, poc) of every search it ran"""
+    name, w, h, n, qp, preset, dbk, sao, owf, src = case
+    frames = case_frames(case)
+    pus, res, poc = np.zeros(capacity, ME_PU), np.zeros(capacity, ME_RESULT), np.zeros(capacity, np.int32)
+    tr = oracle.lib.kvz_oracle_me_trace
+    tr.restype = None
+    tr.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    tr(pus.ctypes.data, res.ctypes.data, poc.ctypes.data, capacity)
+    try:
+        rs, rf, cu, qps = oracle_encode(oracle, w, h, frames, qp, preset=preset, deblock=bool(dbk), sao=bool(sao), mv_constraint=owf > 0)
+        cnt = oracle.lib.kvz_oracle_me_trace_count()
+    finally:
+        tr(None, None, None, 0)
+    assert cnt < capacity
+    return frames, rf, qps, pus[:cnt].copy(), res[:cnt].copy(), poc[:cnt].copy()
+
+
+def me_results_differ(a, b, fme_level):
+    """indices where two ME_RESULT arrays differ in a field that is defined"""
+    bad = (a["mv"] != b["mv"]).any(axis=1) | (a["valid"] != b["valid"]) | (a["mvp"] != b["mvp"]) | (a["cost"] != b["cost"]) | (a["bits"] != b["bits"])
+    if fme_level:
+        bad |= a["frac_valid"] != b["frac_valid"]
+        both = (a["frac_valid"] != 0) & (b["frac_valid"] != 0)
+        bad |= both & ((a["frac_mv"] != b["frac_mv"]).any(axis=1) | (a["frac_mvp"] != b["frac_mvp"]) | (a["frac_cost"] != b["frac_cost"]) | (a["frac_bits"] != b["frac_bits"]))
+    return np.flatnonzero(bad)
