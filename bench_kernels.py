@@ -218,9 +218,52 @@ def main():
         dev.lib.kvz_hip_dev_upload(dp, C.addressof(arr), C.sizeof(arr))
         ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_inter_pred(d0, d1, dpred, w, h, dp, len(coords), 16), args.reps, args.warmup)
         report("inter_pred_16x16_" + ("bi" if bi else "uni"), 16, len(coords), ms, (1 + bi) * (23 * 23 + 2 * 11 * 11) + 384,
-               {"path": "one workgroup per PU: 8-tap luma / 4-tap chroma through LDS, bipred average in LDS", "pictures_per_s": round(nrep / (ms * 1e-3), 1)})
+               {"path": "one wavefront per PU (four per workgroup): dword window in LDS, v_dot4 horizontal / v_dot2 vertical 8-tap, 4-tap chroma, bipred average", "pictures_per_s": round(nrep / (ms * 1e-3), 1)})
         dev.free(dp)
     dev.free(dc, dr, d0, d1, dpred)
+
+    # the motion search of a PU, whole (kvz_hip_dev_pu_search: starting points, early termination, hexagon search, the two half-pel steps or the SATD re-pricing):
+    # every 8x8 / 16x16 / 32x32 PU of a 1080p picture on smooth moving content (a search has a gradient to follow), AMVP predictors and merge candidates near
+    # the true motion, the co-located motion one sample off.  Algorithmic bytes per PU (SURVEY.md 8d's accounting: what must be read once): the source block,
+    # the (w + 8)^2 window around the result, 64 B result; the ~25-35 probes re-read reference samples that sit in L2
+    class MePu(C.Structure):
+        _fields_ = [("x", C.c_int16), ("y", C.c_int16), ("w", C.c_int16), ("h", C.c_int16), ("mv_cand", (C.c_int16 * 2) * 2), ("start_mv", C.c_int16 * 2), ("has_start", C.c_uint8),
+                    ("num_merge", C.c_uint8), ("merge_dir", C.c_uint8 * 5), ("r", C.c_uint8), ("merge_mv", (C.c_int16 * 2) * 5)]
+
+    class MeParams(C.Structure):
+        _fields_ = [("lambda_sqrt", C.c_double), ("mv_constraint", C.c_int32), ("sao", C.c_int32), ("deblock", C.c_int32), ("fme_level", C.c_int32)]
+    dev.lib.kvz_hip_dev_pu_search.restype = C.c_int
+    dev.lib.kvz_hip_dev_pu_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    tex = 128 + 45 * np.sin(xx / 9.0) * np.cos(yy / 13.0) + 30 * np.sin((xx + 2 * yy) / 31.0)
+    cur2 = np.clip(tex + rng.normal(0, 2, (h, w)), 0, 255).astype(np.uint8)
+    ref2 = np.clip(np.roll(tex, (3, -5), (0, 1)) + rng.normal(0, 2, (h, w)), 0, 255).astype(np.uint8)   # true motion (-5, 3) integer samples
+    dc, dr = dev.put(cur2), dev.put(ref2)
+    for pw in (8, 16, 32):
+        coords = [(x, y) for y in range(0, h - pw + 1, pw) for x in range(0, w - pw + 1, pw)] * (4 if pw == 8 else nrep)
+        arr = (MePu * len(coords))()
+        for i, (x, y) in enumerate(coords):
+            a = arr[i]
+            a.x, a.y, a.w, a.h = x, y, pw, pw
+            for k in range(2):
+                a.mv_cand[k][0], a.mv_cand[k][1] = -20 + int(rng.integers(-6, 7)), 12 + int(rng.integers(-6, 7))
+            a.start_mv[0], a.start_mv[1], a.has_start = -16, 8, 1
+            a.num_merge = 3
+            for k in range(3):
+                a.merge_dir[k] = (1, 3, 2)[k]
+                a.merge_mv[k][0], a.merge_mv[k][1] = -20 + int(rng.integers(-9, 10)), 12 + int(rng.integers(-9, 10))
+        dp, dres = dev.empty(C.sizeof(arr)), dev.empty(len(coords) * 64)
+        dev.lib.kvz_hip_dev_upload(dp, C.addressof(arr), C.sizeof(arr))
+        for fme_level, label in ((2, "hexbs+hpel"), (0, "hexbs+satd")):
+            prm = MeParams(lambda_sqrt=float(np.sqrt(0.57 * 2.0 ** ((25 - 12) / 3.0))), mv_constraint=1, sao=1, deblock=1, fme_level=fme_level)
+            ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_pu_search(dc, dr, w, h, dp, len(coords), pw, C.addressof(prm), dres), args.reps, args.warmup)
+            resv = dev.get(dres, (len(coords), 16), np.int32)
+            found = float(np.mean((resv[:, 0] == -20) & (resv[:, 1] == 12)))
+            report(f"pu_search_{pw}x{pw}_{label}", pw, len(coords), ms, pw * pw + (pw + 8) ** 2 + 64,
+                   {"path": "one workgroup per PU: rounds of probes in parallel (SAD through L2, clamped), the reference's decisions replayed; fused half-pel pipeline in LDS",
+                    "pictures_per_s": round(len(coords) / ((w // pw) * (h // pw)) / (ms * 1e-3), 1), "searches_ending_on_the_true_motion": round(found, 3)})
+        dev.free(dp, dres)
+    dev.free(dc, dr)
 
     print(json.dumps({"summary": "bench_kernels", "batch_ctus": args.batch_ctus, "reps": args.reps, "kernels": len(results)}))
 

@@ -123,7 +123,7 @@ int  kvz_hip_dev_inter_pred(const uint8_t *ref0, const uint8_t *ref1, uint8_t *p
  *   and throughout the motion-vector restriction of overlapped pictures (fracmv_within_tile :75-152 with mv-constraint none: cfg.owf && cfg.wpp).
  * What the caller supplies per PU is what depends on the neighbourhood: the two AMVP predictors (kvz_inter_get_mv_cand), the merge candidates' motion
  * (kvz_inter_get_merge_cand; only candidates that use one list take part) and the co-located CU's motion.  cur / ref: width x height luma planes, stride = width.
- * One workgroup per PU; PUs are squares of 8, 16, 32 or 64 samples inside the picture. */
+ * One workgroup per PU; PUs are squares of 8, 16, 32 or 64 samples inside the picture, none larger than max_pu_size.  Returns -1 on a bad argument. */
 typedef struct kvz_hip_me_pu {
   int16_t x, y, w, h;
   int16_t mv_cand[2][2];   /* AMVP predictors, quarter samples */
@@ -148,8 +148,8 @@ typedef struct kvz_hip_me_result {
   int32_t frac_mvp, frac_valid;
   double  frac_cost, frac_bits;
 } kvz_hip_me_result;
-int  kvz_hip_dev_pu_search(const uint8_t *cur, const uint8_t *ref, int width, int height, const kvz_hip_me_pu *pus, int count, const kvz_hip_me_params *params,
-                           kvz_hip_me_result *out);
+int  kvz_hip_dev_pu_search(const uint8_t *cur, const uint8_t *ref, int width, int height, const kvz_hip_me_pu *pus, int count, int max_pu_size,
+                           const kvz_hip_me_params *params, kvz_hip_me_result *out);
 
 /* SAO applied to whole pictures: kvz_sao_reconstruct (sao.c:302-361) for every CTU and plane of n_frames tight planar 4:2:0
  * frames.  in = the deblocked pictures, out = a different buffer of the same layout (SAO reads pre-SAO neighbours);

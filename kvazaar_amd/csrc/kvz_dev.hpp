@@ -1122,18 +1122,17 @@ int kvz_hip_dev_fme_costs(const uint8_t *cur, const uint8_t *ref, int width, int
   return 0;
 }
 
-int kvz_hip_dev_pu_search(const uint8_t *cur, const uint8_t *ref, int width, int height, const kvz_hip_me_pu *pus, int count, const kvz_hip_me_params *params,
-                          kvz_hip_me_result *out)
+int kvz_hip_dev_pu_search(const uint8_t *cur, const uint8_t *ref, int width, int height, const kvz_hip_me_pu *pus, int count, int max_pu_size,
+                          const kvz_hip_me_params *params, kvz_hip_me_result *out)
 {
   if (count <= 0) return 0;
   if (!params || (params->fme_level != 0 && params->fme_level != 2)) { fprintf(stderr, "kvz_hip_dev_pu_search: fme_level must be 0 or 2\n"); return -1; }
   const dim3 grid((unsigned)count), block(256);
   const kvz::Tables *tb = kvz::device_tables();
-  // PU sizes are mixed within a picture's list: one instantiation sized for the largest inter PU (32) serves them all; 64x64 PUs (not reachable with
-  // pu-depth-inter 1-3) go through the large one
-  const int big = getenv("KVZ_HIP_ME_MAX64") != nullptr;
-  if (!big) hipLaunchKernelGGL(kvz::dev_pu_search_kernel<32>, grid, block, 0, be().stream, cur, ref, width, height, pus, *params, tb, out);
-  else hipLaunchKernelGGL(kvz::dev_pu_search_kernel<64>, grid, block, 0, be().stream, cur, ref, width, height, pus, *params, tb, out);
+  // PU sizes are mixed within a picture's list: the instantiation is sized for the largest one (pu-depth-inter 1-3: 32)
+  if (max_pu_size <= 32) hipLaunchKernelGGL(kvz::dev_pu_search_kernel<32>, grid, block, 0, be().stream, cur, ref, width, height, pus, *params, tb, out);
+  else if (max_pu_size <= 64) hipLaunchKernelGGL(kvz::dev_pu_search_kernel<64>, grid, block, 0, be().stream, cur, ref, width, height, pus, *params, tb, out);
+  else { fprintf(stderr, "kvz_hip_dev_pu_search: PUs larger than 64 samples do not exist\n"); return -1; }
   KVZ_HIP_CHECK(hipGetLastError());
   return 0;
 }

@@ -5,9 +5,11 @@
 // One workgroup of four wavefronts per PU.  The search is a chain of ROUNDS -- the starting points (up to 7 probes), the two rounds of the early-termination
 // cross (4 + 3), the hexagon's first ring (6), its steps (3 each) and the final square (8) -- and inside a round the probes' SADs do not depend on one
 // another: only the reference's accept / reject sequence (check_mv_cost, search_inter.c:180-232: each probe against the best so far, the MVD bits only when
-// the SAD alone does not rule it out) is order-dependent.  So a round computes all its SADs in parallel (8x8 PUs: one wavefront per probe; larger ones: the
-// workgroup per probe, wavefront-reduced), then every thread replays the decisions on those numbers -- uniformly, so that no broadcast is needed.  Probes read
-// the reference picture through L2 with clamped addressing (= image.c:279-397's edge replication); the source block sits in LDS.  The fractional part is the
+// the SAD alone does not rule it out) is order-dependent.  So a round computes all its SADs in parallel -- one wavefront per probe, a run of w h / 64 samples
+// per lane, v_sad_u8 on dwords, a DPP wave sum --, then every thread replays the decisions on those numbers, uniformly, so that no broadcast is needed and a
+// round costs one barrier.  After the starting points a (w + 16)^2 search window around the best of them is staged in LDS (clamped addressing = image.c:279-397's
+// edge replication) and follows the search: it is reloaded around the current centre when a probe of the coming round would leave it; probes outside it (the
+// starting points themselves) read the reference picture through L2.  The source block sits in LDS.  The fractional part is the
 // fused pipeline of kvz_fme.hpp (window -> shared 14-bit horizontal intermediates -> four planes per step -> 8x8 Hadamard), followed by search_frac's own
 // bookkeeping including its `unsigned` cost accumulator.
 // Algorithmic bytes per PU: w h source + ~30 probes x w h reference samples (L2 hits after the first touch) + the (w + 8)^2 window; 64 B result.
@@ -49,7 +51,7 @@ template <int MAXN> __global__ void __launch_bounds__(256) dev_pu_search_kernel(
   __shared__ alignas(8) u8 s_cur[MAXN * MAXN];
   __shared__ alignas(8) u8 s_pred[4][MAXN * MAXN];
   __shared__ u32 s_cost[4];
-  __shared__ u32 s_sad[8];
+  __shared__ u32 s_sad[2][8];
   const kvz_hip_me_pu pu = pus[blockIdx.x];
   const int w = pu.w, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wh = w * w, l2w = 31 - __builtin_clz((unsigned)w);
   if (w > MAXN || pu.h != w) return;  // routed to a larger instantiation by the host; only square PUs
@@ -76,49 +78,79 @@ template <int MAXN> __global__ void __launch_bounds__(256) dev_pu_search_kernel(
     return me_mvd_bits(x - pu.mv_cand[1][0], y - pu.mv_cand[1][1]) < me_mvd_bits(x - pu.mv_cand[0][0], y - pu.mv_cand[0][1]) ? 1 : 0;
   };
 
-  // one round: the SADs of n <= 8 integer displacements (px[k], py[k]) into s_sad[0..n)
+  // One round: the SADs of n <= 8 integer displacements (px[k], py[k]) into s_sad[buf][0..n).  One wavefront per probe (probes wave, wave + 4), every lane a run
+  // of w h / 64 samples; reference samples from the search window in LDS (wx0, wy0: its origin in the picture; (w + 16)^2 samples around the search centre, aliased
+  // on the prediction planes the fractional part uses later) when the probe lies inside it, through L2 with clamped addressing otherwise.  s_sad is double
+  // buffered, so a round costs one barrier.
+  constexpr int R = 8, WW = MAXN + 2 * R;
+  u8 *s_sw = &s_pred[0][0];
   int px[8], py[8];
+  int wx0 = 0, wy0 = 0, buf = 0;
+  bool have_window = false;
+  const int per = wh >> 6, run = lane * per, ryy = run >> l2w, rxx = run & (w - 1), ww = w + 2 * R;
+  auto load_window = [&](int mx, int my) {  // centred on the integer displacement (mx, my)
+    wx0 = pu.x + mx - R; wy0 = pu.y + my - R;
+    __syncthreads();  // earlier probes are done with the old window
+    for (int i = tid; i < ww * ww; i += 256) {
+      const int r = i / ww, c = i - r * ww;
+      s_sw[r * WW + c] = ref[(long)iclip(0, H - 1, wy0 + r) * W + iclip(0, W - 1, wx0 + c)];
+    }
+    have_window = true;
+    __syncthreads();
+  };
   auto probe = [&](int n) {
-    __syncthreads();
-    if (tid < 8) s_sad[tid] = 0;
-    __syncthreads();
-    if (wh == 64) {  // one wavefront per probe, one sample per lane
-      const int yy = lane >> 3, xx = lane & 7, c = s_cur[lane];
+    buf ^= 1;
 #pragma unroll
-      for (int k0 = 0; k0 < 8; k0 += 4) {
-        const int k = k0 + wave;
-        if (k < n) {
-          const int kx = k0 == 0 ? (wave == 0 ? px[0] : wave == 1 ? px[1] : wave == 2 ? px[2] : px[3]) : (wave == 0 ? px[4] : wave == 1 ? px[5] : wave == 2 ? px[6] : px[7]);
-          const int ky = k0 == 0 ? (wave == 0 ? py[0] : wave == 1 ? py[1] : wave == 2 ? py[2] : py[3]) : (wave == 0 ? py[4] : wave == 1 ? py[5] : wave == 2 ? py[6] : py[7]);
-          const int r = ref[(long)iclip(0, H - 1, pu.y + ky + yy) * W + iclip(0, W - 1, pu.x + kx + xx)];
-          u32 v = (u32)(c > r ? c - r : r - c);
-          for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-          if (lane == 0) s_sad[k] = v;
-        }
-      }
-    } else {  // the workgroup per probe: runs of four samples per thread
+    for (int k0 = 0; k0 < 8; k0 += 4) {
+      const int k = k0 + wave;
+      if (k < n) {
+        int kx = 0, ky = 0;
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        if (k >= n) break;
-        const int X = pu.x + px[k], Y = pu.y + py[k];
-        const bool inside = X >= 0 && X + w <= W && Y >= 0 && Y + w <= H;
+        for (int j = 0; j < 4; j++) if (j == wave) { kx = px[k0 + j]; ky = py[k0 + j]; }
+        const int X = pu.x + kx, Y = pu.y + ky;
         u32 part = 0;
-        for (int i = tid * 4; i < wh; i += 1024) {
-          const int yy = i >> l2w, xx = i & (w - 1);
-          const u32 c4 = *reinterpret_cast<const u32 *>(&s_cur[i]);
-          u32 r4;
-          if (inside) { __builtin_memcpy(&r4, ref + (long)(Y + yy) * W + X + xx, 4); }
+        if (have_window && X >= wx0 && X + w <= wx0 + ww && Y >= wy0 && Y + w <= wy0 + ww) {
+          const u8 *p = s_sw + (Y - wy0 + ryy) * WW + (X - wx0 + rxx);
+          if (per == 1) { const int c = s_cur[run], r = p[0]; part = (u32)(c > r ? c - r : r - c); }
           else {
-            const u8 *row = ref + (long)iclip(0, H - 1, Y + yy) * W;
-            r4 = (u32)row[iclip(0, W - 1, X + xx)] | ((u32)row[iclip(0, W - 1, X + xx + 1)] << 8) | ((u32)row[iclip(0, W - 1, X + xx + 2)] << 16) | ((u32)row[iclip(0, W - 1, X + xx + 3)] << 24);
+            const int sh = (X - wx0) & 3;  // rxx is a multiple of four and rows start aligned: the misalignment is the same for every lane
+            const u32 *q = reinterpret_cast<const u32 *>(p - sh);
+            u32 lo = q[0];
+            for (int j = 0; j < per / 4; j++) {
+              const u32 hi = q[j + 1];
+              const u32 r4 = sh == 0 ? lo : (u32)(((unsigned long long)hi << 32 | lo) >> (8 * sh));
+              part = __builtin_amdgcn_sad_u8(*reinterpret_cast<const u32 *>(&s_cur[run + 4 * j]), r4, part);
+              lo = hi;
+            }
           }
-          part = __builtin_amdgcn_sad_u8(c4, r4, part);
+        } else if (per == 1) {
+          const int c = s_cur[run], r = ref[(long)iclip(0, H - 1, Y + ryy) * W + iclip(0, W - 1, X + rxx)];
+          part = (u32)(c > r ? c - r : r - c);
+        } else if (X >= 0 && X + w <= W && Y >= 0 && Y + w <= H) {
+          const u8 *row = ref + (long)(Y + ryy) * W + X + rxx;
+          for (int j = 0; j < per / 4; j++) { u32 r4; __builtin_memcpy(&r4, row + 4 * j, 4); part = __builtin_amdgcn_sad_u8(*reinterpret_cast<const u32 *>(&s_cur[run + 4 * j]), r4, part); }
+        } else {
+          const u8 *row = ref + (long)iclip(0, H - 1, Y + ryy) * W;
+          for (int j = 0; j < per; j++) { const int c = s_cur[run + j], r = row[iclip(0, W - 1, X + rxx + j)]; part += (u32)(c > r ? c - r : r - c); }
         }
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
-        if (lane == 0) atomicAdd(&s_sad[k], part);
+        int x = (int)part;  // wave64 sum: row_shr 8 / 4 / 2 / 1 inside rows of 16 lanes, then the four row totals
+        x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+        const u32 total = (u32)(__builtin_amdgcn_readlane(x, 15) + __builtin_amdgcn_readlane(x, 31) + __builtin_amdgcn_readlane(x, 47) + __builtin_amdgcn_readlane(x, 63));
+        if (lane == 0) s_sad[buf][k] = total;
       }
     }
     __syncthreads();
+  };
+  // the window follows the search: reloaded around (mx, my) when a probe of the coming round would leave it
+  auto keep_window = [&](int n, int mx, int my) {
+    bool inside = have_window;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if (j < n) inside = inside && pu.x + px[j] >= wx0 && pu.x + px[j] + w <= wx0 + ww && pu.y + py[j] >= wy0 && pu.y + py[j] + w <= wy0 + ww;
+    if (!inside) load_window(mx, my);
   };
 
   MeState best;
@@ -126,7 +158,7 @@ template <int MAXN> __global__ void __launch_bounds__(256) dev_pu_search_kernel(
   // check_mv_cost on the SAD of probe k (search_inter.c:180-232)
   auto consider = [&](int k, int x, int y) -> bool {
     if (!allowed(x * 4, y * 4)) return false;
-    double cost = (double)s_sad[k];
+    double cost = (double)s_sad[buf][k];
     if (cost + 0.001 >= best.cost) return false;
     const double bits = (double)mvd_bits(x * 4, y * 4);
     cost += bits * prm.lambda_sqrt;
@@ -142,22 +174,30 @@ template <int MAXN> __global__ void __launch_bounds__(256) dev_pu_search_kernel(
   ex >>= 2; ey >>= 2;
   {
     int n = 0;
-    px[n] = 0; py[n] = 0; n++;
+    auto push = [&](int x, int y) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) if (j == n) { px[j] = x; py[j] = y; }
+      n++;
+    };
+#pragma unroll
+    for (int j = 0; j < 8; j++) { px[j] = 0; py[j] = 0; }
+    push(0, 0);
     bool extra = ex != 0 || ey != 0;
     if (extra)
       for (int i = 0; i < pu.num_merge; i++)
         if (pu.merge_dir[i] != 3 && ((pu.merge_mv[i][0] + 2) >> 2) == ex && ((pu.merge_mv[i][1] + 2) >> 2) == ey) { extra = false; break; }
-    if (extra) { px[n] = ex; py[n] = ey; n++; }
+    if (extra) push(ex, ey);
     for (int i = 0; i < pu.num_merge; i++) {
       if (pu.merge_dir[i] == 3) continue;
       const int x = (pu.merge_mv[i][0] + 2) >> 2, y = (pu.merge_mv[i][1] + 2) >> 2;
       if (x == 0 && y == 0) continue;
-      px[n] = x; py[n] = y; n++;
+      push(x, y);
     }
-    for (int i = n; i < 8; i++) { px[i] = 0; py[i] = 0; }
+    __syncthreads();  // s_cur is complete
     probe(n);
 #pragma unroll
     for (int k = 0; k < 8; k++) if (k < n) consider(k, px[k], py[k]);
+    load_window(best.mvx >> 2, best.mvy >> 2);
   }
 
   // ---- early_terminate (search_inter.c:425-486), me-early-termination sensitive ----
@@ -171,6 +211,7 @@ template <int MAXN> __global__ void __launch_bounds__(256) dev_pu_search_kernel(
 #pragma unroll
       for (int j = 0; j < 4; j++) { const int i = first + j <= last ? first + j : 6; px[j] = mx + hx[i]; py[j] = my + hy[i]; }
       for (int j = 4; j < 8; j++) { px[j] = 0; py[j] = 0; }
+      keep_window(last - first + 1, mx, my);
       probe(last - first + 1);
 #pragma unroll
       for (int j = 0; j < 4; j++) if (first + j <= last && consider(j, px[j], py[j])) best_index = first + j;
@@ -189,6 +230,7 @@ template <int MAXN> __global__ void __launch_bounds__(256) dev_pu_search_kernel(
 #pragma unroll
     for (int j = 0; j < 6; j++) { px[j] = mx + lx[j + 1]; py[j] = my + ly[j + 1]; }
     px[6] = px[7] = 0; py[6] = py[7] = 0;
+    keep_window(6, mx, my);
     probe(6);
 #pragma unroll
     for (int j = 0; j < 6; j++) if (consider(j, px[j], py[j])) best_index = j + 1;
@@ -198,12 +240,14 @@ template <int MAXN> __global__ void __launch_bounds__(256) dev_pu_search_kernel(
       best_index = 0;
 #pragma unroll
       for (int j = 0; j < 3; j++) { px[j] = mx + lx[start + j]; py[j] = my + ly[start + j]; }
+      keep_window(3, mx, my);
       probe(3);
 #pragma unroll
       for (int j = 0; j < 3; j++) if (consider(j, px[j], py[j])) best_index = start + j;
     }
 #pragma unroll
     for (int j = 0; j < 8; j++) { px[j] = mx + sx[j + 1]; py[j] = my + sy[j + 1]; }
+    keep_window(8, mx, my);
     probe(8);
 #pragma unroll
     for (int j = 0; j < 8; j++) consider(j, px[j], py[j]);
