@@ -112,6 +112,15 @@ typedef struct kvz_hip_mc_pu {
 } kvz_hip_mc_pu;
 int  kvz_hip_dev_inter_pred(const uint8_t *ref0, const uint8_t *ref1, uint8_t *pred, int width, int height, const kvz_hip_mc_pu *pus, int count, int max_pu_size);
 
+/* cu_info_t (cu.h:130-170) of one 4x4 unit as the inter CTU pass reads and writes it: type 0 not set / 1 intra / 2 inter, the CU's depth, the intra mode,
+ * tr_depth, the coded block flags in kvazaar's packing (cu.h:262-300: 5 depth bits per plane), the inter flags and motion.  Motion fields of a list mv_dir does
+ * not use are 0 / 255. */
+typedef struct kvz_hip_cu_info {
+  uint8_t type, depth, mode, tr_depth; uint16_t cbf;
+  uint8_t skipped, merged, merge_idx, mv_dir, mv_ref[2], mv_cand[2];
+  int16_t mv[2][2];
+} kvz_hip_cu_info;
+
 /* The motion search of one reference picture for `count` prediction units, whole -- search_pu_inter_ref (search_inter.c:1237-1435) and the fractional
  * refinement of its result (search_inter.c:1866-1917 -> search_frac :974-1130) with every decision the reference takes on the way:
  *   the starting point (select_starting_point :285-312: the best of (0,0), the co-located motion of the previous picture and the single-list merge candidates),

@@ -1,0 +1,160 @@
+// kvz_inter_ctu.hpp -- the CTU pass of pictures with inter prediction (BASELINE config 4: `--preset veryfast --gop lp-g4d3t1`, B slices whose two lists hold the
+// previous picture): one workgroup searches and reconstructs one 64x64 CTU -- search_cu of a P / B slice (search.c:646-1063) with everything below it:
+// kvz_search_cu_inter (search_inter.c:2202: merge candidates, early skip, the motion search of kvz_me.hpp's shape, half-pel refinement), the intra alternative
+// (search_intra.c:812, rd 0), motion compensation (inter.c:374-660), the transform tree of either CU type, zero-coefficient RDO, kvz_mock_encode_coding_unit and
+// cu_rd_cost_tr_split_accurate on CABAC contexts that live as the encoder's do, the recursion with its work-tree copies, and the finished CTU's syntax for the
+// next CTU's contexts.  oracle/kvz_oracle_inter.inc is the function-by-function CPU restatement it is checked against (itself equal to the reference encoder CU
+// for CU, tests/test_inter_oracle.py); function names below are the oracle's, which cites the reference lines.
+//
+// FIRST VERSION, written for correctness: the program is the reference's own control flow executed uniformly by all lanes of the workgroup -- every lane holds
+// the scalar state (the CU being evaluated, candidate lists, costs, contexts) in registers / private memory and takes the same decisions --, and every loop over
+// samples is a phase `IC_FOR(tid) { ... } IC_SYNC();` spread over the lanes: probes of the motion search, interpolation, SATD / SSD, residual -> DCT -> quantisation
+// -> reconstruction (the item-parallel ops of kvz_ops.hpp, which the per-call strategy API already runs and checks), intra prediction.  The work tree (lcu_t x 5:
+// reconstruction, coefficients, CU info of every depth) is a slab in HBM per resident workgroup; LDS holds the sample buffers of the stage at hand.  CTUs of a
+// picture run in WPP order under the ticket schedule of kvz_ctu_kernels.hpp; pictures of one sequence are launches in order, the launch carries picture k of many
+// independent sequences.  tests/hostsim compiles this file for the host (a phase = a loop over tid), which is how it was brought up against the oracle without a GPU.
+// Restrictions of this version: coefficients priced with kvz_fast_coeff_cost only (every picture QP below fast-residual-cost 28), square PUs, one reference picture.
+#pragma once
+#include "../../include/kvz_hip_types.h"
+#include "../../include/kvz_hip_dev.h"
+#include "kvz_ops.hpp"
+
+namespace kvz {
+
+#define KVZ_ICTU_THREADS 256
+#ifdef KVZ_HOSTSIM
+#define IC_FOR(tid) for (int tid = 0; tid < KVZ_ICTU_THREADS; ++tid)
+#define IC_SYNC()
+#define IC_LDS_ADD(p, v) (*(p) += (v))
+#else
+#define IC_FOR(tid) for (int tid = threadIdx.x, once_ = 1; once_; once_ = 0)
+#define IC_SYNC() __syncthreads()
+#define IC_LDS_ADD(p, v) atomicAdd((p), (v))
+#endif
+#define IC_RUN(op, n) do { IC_FOR(tid) { for (int i_ = tid; i_ < (n); i_ += KVZ_ICTU_THREADS) (op)(i_); } IC_SYNC(); } while (0)
+
+typedef kvz_hip_cu_info CuInfo;  // one 4x4 unit of the frame's CU info (include/kvz_hip_dev.h)
+
+// compact context numbering of a B slice priced with the fast coefficient cost (cabac.h:63-100)
+enum { IX_SPLIT = 0 /* 3 */, IX_SKIP = 3 /* 3 */, IX_MERGE_FLAG = 6, IX_MERGE_IDX = 7, IX_PRED_MODE = 8, IX_PART = 9, IX_INTRA = 10, IX_CHROMA = 11, IX_CBF_LUMA = 12 /* 2 */,
+       IX_CBF_CHROMA = 14 /* 2 */, IX_MVD = 16 /* 2 */, IX_MVP_IDX = 18, IX_INTER_DIR = 19 /* 5 */, IX_ROOT_CBF = 24, IX_COUNT = 32 };
+struct ICtx { u8 s[IX_COUNT]; };
+
+struct InterModel {  // per picture
+  double lambda, lambda_sqrt;
+  uint64_t coeff_weights;
+  int qp, poc, mv_constraint, sao, deblock, fme_level, pu_depth_inter_max, no_wpp;
+  u8 ctx_init[IX_COUNT];
+  QuantScalars qf[2][4], qi[2][4];  // forward / inverse scalars, [luma, chroma][log2 size - 2]
+  float fbits[128];                 // kvz_f_entropy_bits
+};
+
+struct InterSlab {  // the work tree of one CTU in flight: lcu_t x 5 (search.c:1220-1225)
+  u8 rec[5][64 * 64 + 2 * 32 * 32];
+  i16 coeff[5][64 * 64 + 2 * 32 * 32];
+  CuInfo cu[5][256];
+  u8 org[64 * 64 + 2 * 32 * 32];
+};
+
+struct InterFrames {
+  int W, H, wc, hc;
+  long frame_px, cells;  // bytes of a picture (Y|U|V), CU records of a picture
+  const u8 *src;         // [n] pictures to encode
+  const u8 *ref;         // [n] their reference pictures (the previous picture of each sequence after its loop filters)
+  const CuInfo *ref_cu;  // [n] the reference pictures' CU info
+  u8 *rec;               // [n] out: reconstruction before the loop filters
+  CuInfo *cu;            // [n] out: CU info
+  i16 *coeff;            // [n] out: KVZ_HIP_CTU_COEFFS per CTU (raster CTU order), z-order inside as lcu_coeff_t
+  ICtx *ctx_out;         // [n][CTUs]: the row coder's contexts after each CTU
+  InterSlab *slabs;      // one per resident workgroup
+};
+
+struct InterLds {
+  alignas(8) u8 win[40 * 40];      // clamped reference window (motion compensation, fractional search), stride 40
+  i16 g[40 * 33];                  // 14-bit horizontal intermediates, stride 33
+  alignas(8) u8 cur[32 * 32];      // the PU's source block, contiguous
+  alignas(8) u8 pred[4][32 * 32];  // the candidate planes of a fractional step / intra predictions
+  i16 im[2][32 * 32];              // 14-bit predictions of the two lists
+  i16 resid[32 * 32], coefa[32 * 32], tmpb[32 * 32];
+  u32 acc[16];
+  u32 sad[8];
+  u32 cost[4];
+  u8 top[65], left[65], ftop[65], fleft[65];
+  float fbits[128];
+};
+
+struct MCand { i16 mv[2][2]; u8 ref[2], dir; };                         // inter_merge_cand_t
+struct PuSearch { int x, y, w; i16 mv_cand[2][2]; MCand merge[5]; int num_merge; };
+struct UMap { CuInfo unit[5]; double cost[5], bits[5]; int8_t keys[5]; int size; };
+
+#define IC_MAX_COST 1.7e+308
+#define IC_MAX_INT 2147483647.0
+
+struct InterCtu {
+  InterFrames F;
+  const InterModel *M;
+  const Tables *tb;
+  InterLds *L;
+  InterSlab *S;
+  int frame, cx, cy;
+  ICtx cab;
+  int acc_slot;
+
+  // ---- small things ----
+  KVZ_DEV u8 *rec(int lv, int c) const { return S->rec[lv] + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)); }
+  KVZ_DEV i16 *coef(int lv, int c) const { return S->coeff[lv] + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)); }
+  KVZ_DEV u8 *org(int c) const { return S->org + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)); }
+  KVZ_DEV const u8 *refp(int c) const { return F.ref + frame * F.frame_px + (c == 0 ? 0 : (c == 1 ? (long)F.W * F.H : (long)F.W * F.H * 5 / 4)); }
+  KVZ_DEV const u8 *srcp(int c) const { return F.src + frame * F.frame_px + (c == 0 ? 0 : (c == 1 ? (long)F.W * F.H : (long)F.W * F.H * 5 / 4)); }
+  KVZ_DEV CuInfo *cell(int lv, int xl, int yl) const { return &S->cu[lv][(yl >> 2) * 16 + (xl >> 2)]; }
+  KVZ_DEV static unsigned zorder(int x, int y)
+  {
+    unsigned r = 0;
+    for (int b = 0; b < 4; b++) r |= (((unsigned)(x >> (2 + b)) & 1u) << (2 * b)) | (((unsigned)(y >> (2 + b)) & 1u) << (2 * b + 1));
+    return r * 16;
+  }
+  KVZ_DEV static bool cbf_is_set(unsigned cbf, int depth, int plane)
+  {
+    const unsigned masks[5] = { 0x1f, 0x0f, 0x07, 0x03, 0x1 };
+    return (cbf & (masks[depth] << (5 * plane))) != 0;
+  }
+  KVZ_DEV static bool cbf_any(unsigned cbf, int depth) { return cbf_is_set(cbf, depth, 0) || cbf_is_set(cbf, depth, 1) || cbf_is_set(cbf, depth, 2); }
+  KVZ_DEV static void cbf_set(uint16_t *cbf, int depth, int plane) { *cbf = (uint16_t)(*cbf | ((0x10 >> depth) << (5 * plane))); }
+  KVZ_DEV static void cbf_clear(uint16_t *cbf, int depth, int plane)
+  {
+    const unsigned masks[5] = { 0x1f, 0x0f, 0x07, 0x03, 0x1 };
+    *cbf = (uint16_t)(*cbf & ~(masks[depth] << (5 * plane)));
+  }
+
+  // sum over the workgroup of a per-lane value computed inside a phase: lanes add into a rotating LDS slot (a slot is only reused sixteen reductions later)
+  KVZ_DEV u32 *acc_begin()
+  {
+    acc_slot = (acc_slot + 1) & 15;
+    u32 *a = &L->acc[acc_slot];
+    IC_FOR(tid) { if (tid == 0) *a = 0; }
+    IC_SYNC();
+    return a;
+  }
+
+  // the CU info of luma position (fx, fy): inside this CTU from the work-tree level, else from the frame (finished CTUs)
+  KVZ_DEV CuInfo cell_at(int lv, int fx, int fy) const
+  {
+    if (fx >= cx && fx < cx + 64 && fy >= cy && fy < cy + 64) return *cell(lv, fx - cx, fy - cy);
+    return F.cu[frame * F.cells + (long)(fy >> 2) * (F.W >> 2) + (fx >> 2)];
+  }
+
+  // CABAC_FBITS_UPDATE on the search contexts (cabac.h:133-139)
+  KVZ_DEV double price(int idx, int bin, bool update)
+  {
+    const u8 st = cab.s[idx];
+    const double bits = L->fbits[st ^ bin];
+    if (update) cab.s[idx] = tb->ctx_next[bin != (st & 1)][st];
+    return bits;
+  }
+
+#include "kvz_inter_ctu_cand.inc"
+#include "kvz_inter_ctu_pix.inc"
+#include "kvz_inter_ctu_search.inc"
+};
+
+}  // namespace kvz

@@ -1,0 +1,47 @@
+// kvz_inter_host.hpp -- host side of the inter CTU pass (kvz_inter_ctu.hpp): the per-picture model (lambda, quantisation scalars, the B slice's context
+// initialisation, kvz_init_contexts context.c:202-305 with row 0 of the tables :36-193).
+#pragma once
+#include <math.h>
+#include <string.h>
+
+#include "kvz_inter_ctu.hpp"
+#include "kvz_tables.hpp"
+
+namespace kvz {
+
+inline int inter_ctx_state(int qp, int init_value)  // context.c:202-213 kvz_ctx_init
+{
+  const int slope = (init_value >> 4) * 5 - 45, offset = ((init_value & 15) << 3) - 16;
+  int st = ((slope * qp) >> 4) + offset;
+  st = st < 1 ? 1 : (st > 126 ? 126 : st);
+  return st >= 64 ? ((st - 64) << 1) + 1 : (63 - st) << 1;
+}
+
+inline void inter_model_init(InterModel *m, int qp, int poc, uint64_t coeff_weights, const float fbits[128], int mv_constraint, int sao, int deblock, int fme_level,
+                             int pu_depth_inter_max, int no_wpp)
+{
+  memset(m, 0, sizeof *m);
+  m->qp = qp; m->poc = poc;
+  m->lambda = 0.57 * pow(2.0, (qp - 12) / 3.0);  // rate_control.c:678-691
+  m->lambda_sqrt = sqrt(m->lambda);
+  m->coeff_weights = coeff_weights;
+  m->mv_constraint = mv_constraint; m->sao = sao; m->deblock = deblock; m->fme_level = fme_level; m->pu_depth_inter_max = pu_depth_inter_max; m->no_wpp = no_wpp;
+  uint8_t init[IX_COUNT];
+  memset(init, 154, sizeof init);
+  const uint8_t split[3] = { 107, 139, 126 }, skip[3] = { 197, 185, 201 }, inter_dir[5] = { 95, 79, 63, 31, 31 };
+  for (int i = 0; i < 3; i++) { init[IX_SPLIT + i] = split[i]; init[IX_SKIP + i] = skip[i]; }
+  init[IX_MERGE_FLAG] = 154; init[IX_MERGE_IDX] = 137; init[IX_PRED_MODE] = 134; init[IX_PART] = 154; init[IX_INTRA] = 183; init[IX_CHROMA] = 152;
+  init[IX_CBF_LUMA] = 153; init[IX_CBF_LUMA + 1] = 111; init[IX_CBF_CHROMA] = 149; init[IX_CBF_CHROMA + 1] = 92;
+  init[IX_MVD] = 169; init[IX_MVD + 1] = 198; init[IX_MVP_IDX] = 168;
+  for (int i = 0; i < 5; i++) init[IX_INTER_DIR + i] = inter_dir[i];
+  init[IX_ROOT_CBF] = 79;
+  for (int i = 0; i < IX_COUNT; i++) m->ctx_init[i] = (uint8_t)inter_ctx_state(qp, init[i]);
+  for (int l2 = 2; l2 <= 5; l2++)
+    for (int c = 0; c < 2; c++) {
+      m->qf[c][l2 - 2] = quant_scalars(qp, 8, 0 /* B slice: rounding 85 */, 0, 1 << l2, c ? 2 : 0);
+      m->qi[c][l2 - 2] = quant_scalars(qp, 8, 0, 0, 1 << l2, c ? 2 : 0);
+    }
+  memcpy(m->fbits, fbits, sizeof m->fbits);
+}
+
+}  // namespace kvz
