@@ -121,6 +121,31 @@ typedef struct kvz_hip_cu_info {
   int16_t mv[2][2];
 } kvz_hip_cu_info;
 
+/* The CTU pass of pictures with inter prediction -- search_cu of a B slice (search.c:646-1063) and everything below it, for picture k of n_pictures independent
+ * sequences at once (BASELINE config 4: `--preset veryfast --gop lp-g4d3t1`, each B picture predicting from the previous picture of its sequence in both lists):
+ *   src      [n] the pictures to encode, tight planar 4:2:0 (Y|U|V), width and height multiples of 8
+ *   ref      [n] their reference pictures (the previous picture of each sequence AFTER its loop filters), same layout
+ *   ref_cu   [n] the reference pictures' CU info, one record per 4x4 unit, raster order, stride width / 4 (temporal candidates, the motion search's starting point)
+ *   rec      [n] out: the reconstruction before the loop filters
+ *   cu       [n] out: CU info of the encoded pictures (what the next picture takes as ref_cu, and what deblocking reads)
+ *   coeff    [n] out or NULL: KVZ_HIP_CTU_COEFFS quantised coefficients per CTU (raster CTU order; inside a CTU as lcu_coeff_t: Y | U | V, z-order)
+ * All device pointers.  The pass is oracle/kvz_oracle_inter.inc's search_cu_b on the device, CTU for CTU identical to the reference encoder (tests/test_gpu_inter_ctu.py).
+ * This version prices coefficients with kvz_fast_coeff_cost only: every picture QP must lie below `fast-residual-cost` 28 (BASELINE's QP 22 runs its pictures at
+ * 21-25); returns -1 otherwise or on a bad argument, -2 when a CTU hand-off timed out. */
+typedef struct kvz_hip_inter_params {
+  int32_t qp;                  /* the picture's QP (state->frame->QP; kvz_oracle_lowdelay_qp states how kvazaar derives it from --qp and the GOP) */
+  int32_t poc;                 /* picture order count inside the intra period (> 0); temporal AMVP candidates need poc > 1 (inter.c:1290) */
+  int32_t mv_constraint;       /* cfg.owf && cfg.wpp */
+  int32_t sao, deblock;        /* cfg.sao_type != 0, cfg.deblock_enable (the margin of that restriction) */
+  int32_t fme_level;           /* 2 `veryfast`, 0 `ultrafast` */
+  int32_t pu_depth_inter_max;  /* 3 `veryfast`, 2 `ultrafast` */
+  int32_t no_wpp;              /* one coder runs through the picture in raster order (--no-wpp) */
+} kvz_hip_inter_params;
+int  kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz_hip_cu_info *ref_cu, uint8_t *rec, kvz_hip_cu_info *cu, int16_t *coeff, int width,
+                                int height, int n_pictures, const kvz_hip_inter_params *params);
+/* what the deblocking filter reads (kvz_hip_cu_dbk) of `count` CU records: type, depth, tr_depth, the luma coded block flag at tr_depth, motion */
+void kvz_hip_dev_cu_dbk_from_info(const kvz_hip_cu_info *cu, int count, kvz_hip_cu_dbk *out);
+
 /* The motion search of one reference picture for `count` prediction units, whole -- search_pu_inter_ref (search_inter.c:1237-1435) and the fractional
  * refinement of its result (search_inter.c:1866-1917 -> search_frac :974-1130) with every decision the reference takes on the way:
  *   the starting point (select_starting_point :285-312: the best of (0,0), the co-located motion of the previous picture and the single-list merge candidates),

@@ -1,6 +1,6 @@
 """Builds libkvz_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-The library is seven translation units compiled in parallel: kvz_hip.hip (C ABI, per-call ops, streaming kernels, host side of the batch; with
+The library is eight translation units compiled in parallel: kvz_hip.hip (C ABI, per-call ops, streaming kernels, host side of the batch; with
 -DKVZ_CTU_SEPARATE_TUS it only declares the CTU kernels) and kvz_ctu_tu.hip six times, one CTU kernel instantiation each (-DKVZ_CTU_KERNEL_TU=0..5,
 csrc/kvz_ctu_kernels.hpp).  Objects are rebuilt when one of the files they include (hipcc -MD) is newer."""
 import os
@@ -16,7 +16,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: pixel_var / cost arithmetic must not be contracted into FMAs (bit-exact double results)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 # (object name, source, extra defines)
-UNITS = [("kvz_hip", "kvz_hip.hip", ["-DKVZ_CTU_SEPARATE_TUS"])] + [(f"kvz_ctu_tu{k}", "kvz_ctu_tu.hip", [f"-DKVZ_CTU_KERNEL_TU={k}"]) for k in range(6)]
+UNITS = ([("kvz_hip", "kvz_hip.hip", ["-DKVZ_CTU_SEPARATE_TUS"])] + [(f"kvz_ctu_tu{k}", "kvz_ctu_tu.hip", [f"-DKVZ_CTU_KERNEL_TU={k}"]) for k in range(6)]
+         + [("kvz_inter_tu", "kvz_inter_tu.hip", [])])  # the inter CTU pass (csrc/kvz_inter_kernels.hpp)
 
 
 def _deps(dfile):

@@ -7,6 +7,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include "../../include/kvz_hip_dev.h"
 #include "kvz_mfma.hpp"
 #include "kvz_ops.hpp"
@@ -904,6 +906,35 @@ __global__ void __launch_bounds__(64) dev_sao_chain_kernel(const SaoStats *stats
 }  // namespace kvz
 #include "kvz_fme.hpp"
 #include "kvz_me.hpp"
+#include "kvz_inter_kernels.hpp"
+#include "kvz_inter_host.hpp"
+
+namespace kvz {
+__global__ void dev_cu_dbk_kernel(const kvz_hip_cu_info *cu, int count, kvz_hip_cu_dbk *out)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const kvz_hip_cu_info c = cu[i];
+  kvz_hip_cu_dbk o;
+  __builtin_memset(&o, 0, sizeof o);
+  const unsigned masks[5] = { 0x1f, 0x0f, 0x07, 0x03, 0x1 };
+  o.type = c.type; o.depth = c.depth; o.tr_depth = c.tr_depth; o.part_size = 0;
+  o.cbf_y = (uint8_t)((c.cbf & masks[c.tr_depth > 4 ? 4 : c.tr_depth]) != 0);
+  if (c.type == 2) {
+    o.mv_dir = c.mv_dir;
+    for (int l = 0; l < 2; l++) { o.mv_ref[l] = (int8_t)((c.mv_dir & (1 << l)) ? c.mv_ref[l] : 0); o.ref_id[l] = 0; o.mv[l][0] = c.mv[l][0]; o.mv[l][1] = c.mv[l][1]; }
+  }
+  out[i] = o;
+}
+// the device-side scratch of kvz_hip_dev_inter_ctu_pass, grown on demand and kept between calls
+struct InterScratch {
+  InterSlab *slabs = nullptr; int n_slabs = 0;
+  ICtx *ctx = nullptr; unsigned *done = nullptr; uint32_t *items = nullptr; long n_ctus = 0;
+  unsigned *ticket = nullptr;  // [0] ticket, [1] error
+  InterModel *model = nullptr;
+};
+inline InterScratch &inter_scratch() { static InterScratch s; return s; }
+}  // namespace kvz
 namespace kvz {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1120,6 +1151,76 @@ int kvz_hip_dev_fme_costs(const uint8_t *cur, const uint8_t *ref, int width, int
   else { fprintf(stderr, "kvz_hip_dev_fme_costs: PUs larger than 64 samples do not exist\n"); return -1; }
   KVZ_HIP_CHECK(hipGetLastError());
   return 0;
+}
+
+void kvz_hip_dev_cu_dbk_from_info(const kvz_hip_cu_info *cu, int count, kvz_hip_cu_dbk *out)
+{
+  if (count <= 0) return;
+  hipLaunchKernelGGL(kvz::dev_cu_dbk_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, be().stream, cu, count, out);
+  KVZ_HIP_CHECK(hipGetLastError());
+}
+
+int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz_hip_cu_info *ref_cu, uint8_t *rec, kvz_hip_cu_info *cu, int16_t *coeff, int width,
+                               int height, int n_pictures, const kvz_hip_inter_params *p)
+{
+  if (n_pictures <= 0) return 0;
+  if (!p || width <= 0 || height <= 0 || (width & 7) || (height & 7) || width > 64 * 255 || height > 64 * 255 || n_pictures > 65535) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: bad geometry\n"); return -1; }
+  if (p->qp < 0 || p->qp >= 28) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: picture QP %d: this version prices coefficients with kvz_fast_coeff_cost only (QP < 28)\n", p->qp); return -1; }
+  if ((p->fme_level != 0 && p->fme_level != 2) || p->pu_depth_inter_max < 1 || p->pu_depth_inter_max > 3 || p->poc < 1) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: unsupported parameters\n"); return -1; }
+  hipStream_t st = be().stream;
+  const int wc = (width + 63) / 64, hc = (height + 63) / 64, ctus = wc * hc;
+  const long total = (long)ctus * n_pictures;
+  kvz::InterScratch &sc = kvz::inter_scratch();
+  int dev_id = 0, n_cu = 256;
+  KVZ_HIP_CHECK(hipGetDevice(&dev_id));
+  KVZ_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id));
+  const char *env = getenv("KVZ_HIP_INTER_WG_PER_CU");
+  const int per_cu = env ? atoi(env) : 4;
+  int n_wg = n_cu * (per_cu > 0 ? per_cu : 4);
+  if ((long)n_wg > total) n_wg = (int)total;
+  if (n_wg > sc.n_slabs) {
+    if (sc.slabs) KVZ_HIP_CHECK(hipFree(sc.slabs));
+    KVZ_HIP_CHECK(hipMalloc((void **)&sc.slabs, (size_t)n_wg * sizeof(kvz::InterSlab)));
+    sc.n_slabs = n_wg;
+  }
+  if (total > sc.n_ctus) {
+    if (sc.ctx) { KVZ_HIP_CHECK(hipFree(sc.ctx)); KVZ_HIP_CHECK(hipFree(sc.done)); KVZ_HIP_CHECK(hipFree(sc.items)); }
+    KVZ_HIP_CHECK(hipMalloc((void **)&sc.ctx, (size_t)total * sizeof(kvz::ICtx)));
+    KVZ_HIP_CHECK(hipMalloc((void **)&sc.done, (size_t)total * sizeof(unsigned)));
+    KVZ_HIP_CHECK(hipMalloc((void **)&sc.items, (size_t)total * sizeof(uint32_t)));
+    sc.n_ctus = total;
+  }
+  if (!sc.ticket) { KVZ_HIP_CHECK(hipMalloc((void **)&sc.ticket, 2 * sizeof(unsigned))); KVZ_HIP_CHECK(hipMalloc((void **)&sc.model, sizeof(kvz::InterModel))); }
+  // the ticket list: anti-diagonals x + 2 y ascending (raster order per picture without WPP), pictures interleaved
+  std::vector<uint32_t> items;
+  items.reserve((size_t)total);
+  if (p->no_wpp) {
+    for (int y = 0; y < hc; y++) for (int x = 0; x < wc; x++) for (int f = 0; f < n_pictures; f++) items.push_back((uint32_t)f << 16 | (uint32_t)y << 8 | (uint32_t)x);
+  } else {
+    for (int d = 0; d <= (wc - 1) + 2 * (hc - 1); d++)
+      for (int y = 0; y < hc; y++) { const int x = d - 2 * y; if (x < 0 || x >= wc) continue; for (int f = 0; f < n_pictures; f++) items.push_back((uint32_t)f << 16 | (uint32_t)y << 8 | (uint32_t)x); }
+  }
+  kvz::InterModel m;
+  float fbits[128];
+  for (int i = 0; i < 128; i++) fbits[i] = (float)kvz::kEntropyBits[i] / 32768.0f;
+  kvz::inter_model_init(&m, p->qp, p->poc, kvz::kDefaultCoeffWeights[p->qp], fbits, p->mv_constraint, p->sao, p->deblock, p->fme_level, p->pu_depth_inter_max, p->no_wpp);
+  KVZ_HIP_CHECK(hipMemcpyAsync(sc.items, items.data(), (size_t)total * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  KVZ_HIP_CHECK(hipMemcpyAsync(sc.model, &m, sizeof m, hipMemcpyHostToDevice, st));
+  KVZ_HIP_CHECK(hipMemsetAsync(sc.done, 0, (size_t)total * sizeof(unsigned), st));
+  KVZ_HIP_CHECK(hipMemsetAsync(sc.ticket, 0, 2 * sizeof(unsigned), st));
+  KVZ_HIP_CHECK(hipStreamSynchronize(st));  // `items` and `m` are stack / heap objects of this call
+  kvz::InterFrames F;
+  F.W = width; F.H = height; F.wc = wc; F.hc = hc; F.frame_px = (long)width * height * 3 / 2; F.cells = (long)(width / 4) * (height / 4);
+  F.src = src; F.ref = ref; F.ref_cu = ref_cu; F.rec = rec; F.cu = cu; F.coeff = coeff; F.ctx_out = sc.ctx; F.slabs = sc.slabs;
+  kvz::InterSched sched;
+  sched.items = sc.items; sched.ticket = sc.ticket; sched.done = sc.done; sched.error = sc.ticket + 1; sched.total = (unsigned)total; sched.no_wpp = p->no_wpp;
+  sched.wait_ticks = 3000000000ull;  // 30 s of the 100 MHz clock
+  hipLaunchKernelGGL(kvz::inter_ctu_ticket_kernel, dim3((unsigned)n_wg), dim3(KVZ_ICTU_THREADS), 0, st, F, sc.model, kvz::device_tables(), sched);
+  KVZ_HIP_CHECK(hipGetLastError());
+  unsigned flags[2] = { 0, 0 };
+  KVZ_HIP_CHECK(hipMemcpyAsync(flags, sc.ticket, sizeof flags, hipMemcpyDeviceToHost, st));
+  KVZ_HIP_CHECK(hipStreamSynchronize(st));
+  return flags[1] ? -2 : 0;
 }
 
 int kvz_hip_dev_pu_search(const uint8_t *cur, const uint8_t *ref, int width, int height, const kvz_hip_me_pu *pus, int count, int max_pu_size,

@@ -18,6 +18,7 @@
 #include "../../include/kvz_hip_types.h"
 #include "../../include/kvz_hip_dev.h"
 #include "kvz_ops.hpp"
+#include "kvz_tables.hpp"
 
 namespace kvz {
 
@@ -30,6 +31,12 @@ namespace kvz {
 #define IC_FOR(tid) for (int tid = threadIdx.x, once_ = 1; once_; once_ = 0)
 #define IC_SYNC() __syncthreads()
 #define IC_LDS_ADD(p, v) atomicAdd((p), (v))
+#endif
+// IC_FN: the program's larger functions are real calls on the device (one copy each; inlined, the four depths of search_cu_b would each carry a copy of everything)
+#ifdef KVZ_HOSTSIM
+#define IC_FN inline
+#else
+#define IC_FN __device__ __noinline__
 #endif
 #define IC_RUN(op, n) do { IC_FOR(tid) { for (int i_ = tid; i_ < (n); i_ += KVZ_ICTU_THREADS) (op)(i_); } IC_SYNC(); } while (0)
 
@@ -137,7 +144,7 @@ struct InterCtu {
   }
 
   // the CU info of luma position (fx, fy): inside this CTU from the work-tree level, else from the frame (finished CTUs)
-  KVZ_DEV CuInfo cell_at(int lv, int fx, int fy) const
+  IC_FN CuInfo cell_at(int lv, int fx, int fy) const
   {
     if (fx >= cx && fx < cx + 64 && fy >= cy && fy < cy + 64) return *cell(lv, fx - cx, fy - cy);
     return F.cu[frame * F.cells + (long)(fy >> 2) * (F.W >> 2) + (fx >> 2)];

@@ -1,0 +1,129 @@
+"""kvz_hip_dev_inter_ctu_pass -- the CTU pass of B pictures on the MI355X (kvazaar_amd/csrc/kvz_inter_ctu.hpp) -- against the sequence oracle
+(oracle/kvz_oracle_inter.inc, equal to the reference encoder CU for CU: tests/test_inter_oracle.py): every B picture of a clip is searched on the device from the
+oracle's reference picture and reference CU info, and the device's reconstruction and every CU decision must equal the oracle's picture for picture; then the
+device chains its own pictures (its reconstruction deblocked on the device becomes the next picture's reference).  The host simulation of the same sources
+(tests/hostsim, CPU) is checked the same way without a GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ctu_common as cc
+import flatapi
+import inter_common as ic
+
+
+class InterParams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("qp", "poc", "mv_constraint", "sao", "deblock", "fme_level", "pu_depth_inter_max", "no_wpp")]
+
+
+FAST_COST_CASES = ["pan", "ultrafast", "vertical-pan-owf", "static-qp17", "no-loop-filters", "survey-416x240"]  # every picture QP below 28
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return flatapi.load_oracle()
+
+
+def params_of(case, qp, poc):
+    name, w, h, n, base_qp, preset, dbk, sao, owf, src = case
+    p = ic.PRESETS[preset]
+    return InterParams(qp=int(qp), poc=poc, mv_constraint=int(owf > 0), sao=int(sao), deblock=int(dbk), fme_level=p["fme_level"], pu_depth_inter_max=p["pu_depth_inter_max"], no_wpp=0)
+
+
+@pytest.fixture(scope="module")
+def hostsim_lib():
+    d = os.path.join(flatapi.ROOT, "tests", "hostsim")
+    so = os.path.join(d, "libkvz_hostsim.so")
+    srcs = [os.path.join(d, "hostsim.cpp")] + [os.path.join(flatapi.ROOT, "kvazaar_amd", "csrc", f) for f in os.listdir(os.path.join(flatapi.ROOT, "kvazaar_amd", "csrc"))]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, os.path.join(d, "hostsim.cpp")])
+    return C.CDLL(so)
+
+
+@pytest.mark.parametrize("name", ["pan", "ultrafast", "vertical-pan-owf", "no-loop-filters"])
+def test_host_simulation_of_the_device_program_equals_the_oracle(oracle, hostsim_lib, name):
+    case = [c for c in ic.CASES if c[0] == name][0]
+    _, w, h, n, qp, preset, dbk, sao, owf, src = case
+    frames = ic.case_frames(case)
+    rs, rf, cu, qps = ic.oracle_encode(oracle, w, h, frames, qp, preset=preset, deblock=bool(dbk), sao=bool(sao), mv_constraint=owf > 0)
+    mc = cc.model_constants()
+    fb = np.array(mc["entropy_fbits"], np.float32)
+    f = hostsim_lib.kvz_hostsim_inter_frame
+    f.restype = None
+    f.argtypes = [C.c_int] * 4 + [C.c_uint64, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 5
+    p = ic.PRESETS[preset]
+    for k in range(1, n):
+        rec = np.zeros(w * h * 3 // 2, np.uint8)
+        out = np.zeros((h // 4, w // 4), ic.CU_DTYPE)
+        f(w, h, int(qps[k]), k, int(mc["coeff_weights"][str(int(qps[k]))]), fb.ctypes.data, int(owf > 0), int(sao), int(dbk), p["fme_level"], p["pu_depth_inter_max"], 0,
+          np.ascontiguousarray(frames[k]).ctypes.data, np.ascontiguousarray(rf[k - 1]).ctypes.data, np.ascontiguousarray(cu[k - 1]).ctypes.data, rec.ctypes.data, out.ctypes.data)
+        assert ic.first_difference(out[None], cu[k][None]) is None, k
+        assert np.array_equal(rec, rs[k]), k
+
+
+def device_pass(lib, dev, w, h, srcs, refs, ref_cus, prm):
+    n = len(srcs)
+    lib.kvz_hip_dev_inter_ctu_pass.restype = C.c_int
+    lib.kvz_hip_dev_inter_ctu_pass.argtypes = [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_void_p]
+    fs, cells = w * h * 3 // 2, (w // 4) * (h // 4)
+    d_src, d_ref, d_rcu = dev.put(np.concatenate(srcs)), dev.put(np.concatenate(refs)), dev.put(np.concatenate([c.reshape(-1) for c in ref_cus]))
+    d_rec, d_cu = dev.empty(n * fs), dev.empty(n * cells * ic.CU_DTYPE.itemsize)
+    rc = lib.kvz_hip_dev_inter_ctu_pass(d_src, d_ref, d_rcu, d_rec, d_cu, None, w, h, n, C.addressof(prm))
+    assert rc == 0, rc
+    rec = dev.get(d_rec, (n, fs), np.uint8)
+    cu = dev.get(d_cu, (n, h // 4, w // 4), ic.CU_DTYPE)
+    dev.free(d_src, d_ref, d_rcu, d_rec, d_cu)
+    return rec, cu
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FAST_COST_CASES)
+def test_device_pass_equals_oracle_picture_by_picture(oracle, name):
+    import kvazaar_amd
+    from kvazaar_amd.dev import Dev
+    lib = kvazaar_amd.load_library()
+    dev = Dev(lib)
+    case = [c for c in ic.CASES if c[0] == name][0]
+    _, w, h, n, qp, preset, dbk, sao, owf, src = case
+    frames = ic.case_frames(case)
+    rs, rf, cu, qps = ic.oracle_encode(oracle, w, h, frames, qp, preset=preset, deblock=bool(dbk), sao=bool(sao), mv_constraint=owf > 0)
+    for k in range(1, n):
+        rec, got = device_pass(lib, dev, w, h, [frames[k]], [rf[k - 1]], [cu[k - 1]], params_of(case, qps[k], k))
+        d = ic.first_difference(got, cu[k][None])
+        assert d is None, (k, {a: (b if a not in ("ours", "ref") else b.tolist()) for a, b in d.items()})
+        assert np.array_equal(rec[0], rs[k]), k
+
+
+@pytest.mark.gpu
+def test_device_pass_on_several_sequences_at_once(oracle):
+    """picture k of three independent sequences in one launch (the ticket list interleaves their CTUs) == each of them alone"""
+    import kvazaar_amd
+    from kvazaar_amd.dev import Dev
+    lib = kvazaar_amd.load_library()
+    dev = Dev(lib)
+    w, h, n, qp = 264, 200, 3, 22
+    seqs = []
+    for seed in (31, 32, 33):
+        frames = ic.clip(w, h, n, seed, 1.5, (1.0 + seed % 3, -0.75))
+        seqs.append((frames,) + ic.oracle_encode(oracle, w, h, frames, qp, preset="veryfast", deblock=True, sao=True, mv_constraint=True))
+    case = ("x", w, h, n, qp, "veryfast", 1, 1, 2, None)
+    for k in range(1, n):
+        rec, got = device_pass(lib, dev, w, h, [s[0][k] for s in seqs], [s[2][k - 1] for s in seqs], [s[3][k - 1] for s in seqs], params_of(case, seqs[0][4][k], k))
+        for i, s in enumerate(seqs):
+            assert ic.first_difference(got[i][None], s[3][k][None]) is None, (k, i)
+            assert np.array_equal(rec[i], s[1][k]), (k, i)
+
+
+@pytest.mark.gpu
+def test_device_pass_rejects_what_it_does_not_cover():
+    import kvazaar_amd
+    lib = kvazaar_amd.load_library()
+    lib.kvz_hip_dev_inter_ctu_pass.restype = C.c_int
+    lib.kvz_hip_dev_inter_ctu_pass.argtypes = [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_void_p]
+    ok = InterParams(qp=25, poc=1, mv_constraint=0, sao=1, deblock=1, fme_level=2, pu_depth_inter_max=3, no_wpp=0)
+    for bad in (dict(qp=28), dict(fme_level=4), dict(poc=0), dict(pu_depth_inter_max=4)):
+        p = InterParams(**{**{n: getattr(ok, n) for n, _ in InterParams._fields_}, **bad})
+        assert lib.kvz_hip_dev_inter_ctu_pass(None, None, None, None, None, None, 64, 64, 1, C.addressof(p)) == -1
