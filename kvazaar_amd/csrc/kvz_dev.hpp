@@ -1175,8 +1175,8 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
   KVZ_HIP_CHECK(hipGetDevice(&dev_id));
   KVZ_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id));
   const char *env = getenv("KVZ_HIP_INTER_WG_PER_CU");
-  const int per_cu = env ? atoi(env) : 4;
-  int n_wg = n_cu * (per_cu > 0 ? per_cu : 4);
+  const int per_cu = env ? atoi(env) : 7;  // one wavefront per workgroup, 20.6 KB of LDS each: seven fit a CU's 160 KB (the register budget would allow eight)
+  int n_wg = n_cu * (per_cu > 0 ? per_cu : 7);
   if ((long)n_wg > total) n_wg = (int)total;
   if (n_wg > sc.n_slabs) {
     if (sc.slabs) KVZ_HIP_CHECK(hipFree(sc.slabs));
@@ -1212,6 +1212,13 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
   kvz::InterFrames F;
   F.W = width; F.H = height; F.wc = wc; F.hc = hc; F.frame_px = (long)width * height * 3 / 2; F.cells = (long)(width / 4) * (height / 4);
   F.src = src; F.ref = ref; F.ref_cu = ref_cu; F.rec = rec; F.cu = cu; F.coeff = coeff; F.ctx_out = sc.ctx; F.slabs = sc.slabs;
+  F.prof = nullptr;
+#ifdef KVZ_ICTU_PROFILE
+  static unsigned long long *d_prof = nullptr;
+  if (!d_prof) KVZ_HIP_CHECK(hipMalloc((void **)&d_prof, kvz::IP_COUNT * sizeof(unsigned long long)));
+  KVZ_HIP_CHECK(hipMemsetAsync(d_prof, 0, kvz::IP_COUNT * sizeof(unsigned long long), st));
+  F.prof = d_prof;
+#endif
   kvz::InterSched sched;
   sched.items = sc.items; sched.ticket = sc.ticket; sched.done = sc.done; sched.error = sc.ticket + 1; sched.total = (unsigned)total; sched.no_wpp = p->no_wpp;
   sched.wait_ticks = 3000000000ull;  // 30 s of the 100 MHz clock
@@ -1220,6 +1227,14 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
   unsigned flags[2] = { 0, 0 };
   KVZ_HIP_CHECK(hipMemcpyAsync(flags, sc.ticket, sizeof flags, hipMemcpyDeviceToHost, st));
   KVZ_HIP_CHECK(hipStreamSynchronize(st));
+#ifdef KVZ_ICTU_PROFILE
+  {
+    unsigned long long hp[kvz::IP_COUNT];
+    KVZ_HIP_CHECK(hipMemcpy(hp, d_prof, sizeof hp, hipMemcpyDeviceToHost));
+    static const char *names[kvz::IP_COUNT] = { "merge MC+SATD", "early skip", "integer ME", "fractional ME", "candidates", "intra search", "intra recon", "inter quant/recon", "mock+rd cost", "copies", "io", "total search" };
+    for (int i = 0; i < kvz::IP_COUNT; i++) fprintf(stderr, "ictu-profile %-18s %10.3f ms (sum over workgroups) %5.1f %%\n", names[i], hp[i] / 1e5, 100.0 * hp[i] / (double)hp[kvz::IP_TOTAL]);
+  }
+#endif
   return flags[1] ? -2 : 0;
 }
 

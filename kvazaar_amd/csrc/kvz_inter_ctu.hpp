@@ -22,7 +22,10 @@
 
 namespace kvz {
 
-#define KVZ_ICTU_THREADS 256
+#ifndef KVZ_ICTU_THREADS
+#define KVZ_ICTU_THREADS 64  // lanes per CTU, any multiple of 64.  Measured on the MI355X with 256 sequences in flight (416x240): 64 lanes 20.9 k CTUs/s, 128: 18.8 k, 256: 11.9 k
+                             // -- the program is a chain of short phases, and with one wavefront per CTU a barrier costs nothing and four CTUs share a CU
+#endif
 #ifdef KVZ_HOSTSIM
 #define IC_FOR(tid) for (int tid = 0; tid < KVZ_ICTU_THREADS; ++tid)
 #define IC_SYNC()
@@ -36,8 +39,18 @@ namespace kvz {
 #ifdef KVZ_HOSTSIM
 #define IC_FN inline
 #else
+#ifndef KVZ_ICTU_WAVES_PER_EU
+#define KVZ_ICTU_WAVES_PER_EU 2
+#endif
 #define IC_FN __device__ __noinline__
 #endif
+// stage profile (developer builds, -DKVZ_ICTU_PROFILE): ticks of the 100 MHz clock per category, lane 0 of every workgroup adds into F.prof[]
+#if defined(KVZ_ICTU_PROFILE) && !defined(KVZ_HOSTSIM)
+#define IC_PROF(cat, stmt) do { const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime(); stmt; if (threadIdx.x == 0 && F.prof) atomicAdd(&F.prof[cat], __builtin_amdgcn_s_memrealtime() - t0_); } while (0)
+#else
+#define IC_PROF(cat, stmt) do { stmt; } while (0)
+#endif
+enum { IP_MERGE = 0, IP_EARLY_SKIP, IP_ME, IP_FME, IP_CAND, IP_INTRA_SEARCH, IP_INTRA_RECON, IP_INTER_RECON, IP_COST, IP_COPY, IP_IO, IP_TOTAL, IP_COUNT };
 #define IC_RUN(op, n) do { IC_FOR(tid) { for (int i_ = tid; i_ < (n); i_ += KVZ_ICTU_THREADS) (op)(i_); } IC_SYNC(); } while (0)
 
 typedef kvz_hip_cu_info CuInfo;  // one 4x4 unit of the frame's CU info (include/kvz_hip_dev.h)
@@ -74,6 +87,7 @@ struct InterFrames {
   i16 *coeff;            // [n] out: KVZ_HIP_CTU_COEFFS per CTU (raster CTU order), z-order inside as lcu_coeff_t
   ICtx *ctx_out;         // [n][CTUs]: the row coder's contexts after each CTU
   InterSlab *slabs;      // one per resident workgroup
+  unsigned long long *prof;  // [IP_COUNT] or NULL (KVZ_ICTU_PROFILE)
 };
 
 struct InterLds {
@@ -86,6 +100,7 @@ struct InterLds {
   u32 acc[16];
   u32 sad[8];
   u32 cost[4];
+  u32 mcost[36];                   // SATD of every intra mode of the CU under evaluation
   u8 top[65], left[65], ftop[65], fleft[65];
   float fbits[128];
 };
@@ -133,7 +148,28 @@ struct InterCtu {
     *cbf = (uint16_t)(*cbf & ~(masks[depth] << (5 * plane)));
   }
 
-  // sum over the workgroup of a per-lane value computed inside a phase: lanes add into a rotating LDS slot (a slot is only reused sixteen reductions later)
+  // Sum over the lanes of a value accumulated inside a phase.  The idiom is
+  //   u32 part = 0;  IC_FOR(tid) { ... part += ...; }  const u32 total = lanes_sum(part);
+  // on the host the phase is a loop over tid around ONE `part`, which therefore already holds the total; on the device every lane has its own.
+  KVZ_DEV u32 lanes_sum(u32 part)
+  {
+#ifdef KVZ_HOSTSIM
+    return part;
+#else
+    int x = (int)part;  // wave64: row_shr 8 / 4 / 2 / 1 inside rows of 16 lanes, then the four row totals
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+    const u32 wave = (u32)(__builtin_amdgcn_readlane(x, 15) + __builtin_amdgcn_readlane(x, 31) + __builtin_amdgcn_readlane(x, 47) + __builtin_amdgcn_readlane(x, 63));
+    if (KVZ_ICTU_THREADS == 64) return wave;
+    u32 *a = acc_begin();
+    if ((threadIdx.x & 63) == 0) atomicAdd(a, wave);
+    __syncthreads();
+    return *a;
+#endif
+  }
+  // a zeroed LDS word for sums that lanes add into directly (a slot is only reused sixteen reductions later)
   KVZ_DEV u32 *acc_begin()
   {
     acc_slot = (acc_slot + 1) & 15;

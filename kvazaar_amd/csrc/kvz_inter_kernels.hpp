@@ -19,7 +19,7 @@ struct InterSched {
   unsigned long long wait_ticks;
 };
 
-__global__ void __launch_bounds__(KVZ_ICTU_THREADS) inter_ctu_ticket_kernel(const InterFrames F, const InterModel *model, const Tables *tb, const InterSched sched)
+__global__ void __launch_bounds__(KVZ_ICTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_ICTU_WAVES_PER_EU, KVZ_ICTU_WAVES_PER_EU))) inter_ctu_ticket_kernel(const InterFrames F, const InterModel *model, const Tables *tb, const InterSched sched)
 #ifndef KVZ_INTER_KERNEL_BODY
 ;
 #else

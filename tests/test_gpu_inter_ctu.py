@@ -4,6 +4,7 @@ oracle's reference picture and reference CU info, and the device's reconstructio
 device chains its own pictures (its reconstruction deblocked on the device becomes the next picture's reference).  The host simulation of the same sources
 (tests/hostsim, CPU) is checked the same way without a GPU."""
 import ctypes as C
+import json
 import os
 import subprocess
 
@@ -95,6 +96,61 @@ def test_device_pass_equals_oracle_picture_by_picture(oracle, name):
         d = ic.first_difference(got, cu[k][None])
         assert d is None, (k, {a: (b if a not in ("ours", "ref") else b.tolist()) for a, b in d.items()})
         assert np.array_equal(rec[0], rs[k]), k
+
+
+@pytest.mark.gpu
+def test_device_pass_on_baseline_config_4(oracle):
+    """3840x2160 `--preset veryfast --gop lp-g4d3t1 -q 22`, SURVEY's own clip: the three B pictures, each from the oracle's reference"""
+    import kvazaar_amd
+    from kvazaar_amd.dev import Dev
+    lib = kvazaar_amd.load_library()
+    dev = Dev(lib)
+    case = [c for c in ic.CASES if c[0] == "baseline-c4-2160p"][0]
+    _, w, h, n, qp, preset, dbk, sao, owf, src = case
+    frames = ic.case_frames(case)
+    rs, rf, cu, qps = ic.oracle_encode(oracle, w, h, frames, qp, preset=preset, deblock=bool(dbk), sao=bool(sao), mv_constraint=owf > 0)
+    assert ic.digests(rf, cu)["cu"] == json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inter_recon.json")))["baseline-c4-2160p"]["cu"]
+    for k in range(1, n):
+        rec, got = device_pass(lib, dev, w, h, [frames[k]], [rf[k - 1]], [cu[k - 1]], params_of(case, qps[k], k))
+        assert ic.first_difference(got, cu[k][None]) is None, k
+        assert np.array_equal(rec[0], rs[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["deblock-only", "ultrafast"])
+def test_device_chains_its_own_pictures(oracle, name):
+    """the I picture from the oracle, then every B picture on the device from the device's own previous picture: CTU pass -> deblocking with motion-based strengths
+    (kvz_hip_dev_deblock_frames_inter on records made by kvz_hip_dev_cu_dbk_from_info) -> reference of the next picture.  Configurations without SAO."""
+    import kvazaar_amd
+    from kvazaar_amd.dev import Dev
+    lib = kvazaar_amd.load_library()
+    dev = Dev(lib)
+    case = [c for c in ic.CASES if c[0] == name][0]
+    _, w, h, n, qp, preset, dbk, sao, owf, src = case
+    assert dbk and not sao
+    frames = ic.case_frames(case)
+    rs, rf, cu, qps = ic.oracle_encode(oracle, w, h, frames, qp, preset=preset, deblock=True, sao=False, mv_constraint=owf > 0)
+    lib.kvz_hip_dev_inter_ctu_pass.restype = C.c_int
+    lib.kvz_hip_dev_inter_ctu_pass.argtypes = [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_void_p]
+    lib.kvz_hip_dev_cu_dbk_from_info.restype = None
+    lib.kvz_hip_dev_cu_dbk_from_info.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.kvz_hip_dev_deblock_frames_inter.restype = None
+    lib.kvz_hip_dev_deblock_frames_inter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 4
+    fs, cells = w * h * 3 // 2, (w // 4) * (h // 4)
+    d_ref, d_rcu = dev.put(rf[0]), dev.put(cu[0].reshape(-1))
+    d_rec, d_cu, d_dbk = dev.empty(fs), dev.empty(cells * ic.CU_DTYPE.itemsize), dev.empty(cells * 20)
+    for k in range(1, n):
+        d_src = dev.put(frames[k])
+        prm = params_of(case, qps[k], k)
+        assert lib.kvz_hip_dev_inter_ctu_pass(d_src, d_ref, d_rcu, d_rec, d_cu, None, w, h, 1, C.addressof(prm)) == 0
+        lib.kvz_hip_dev_cu_dbk_from_info(d_cu, cells, d_dbk)
+        lib.kvz_hip_dev_deblock_frames_inter(d_rec, w, h, 1, d_dbk, int(qps[k]), 0, 0, 1)
+        assert np.array_equal(dev.get(d_rec, (fs,), np.uint8), rf[k]), k
+        assert ic.first_difference(dev.get(d_cu, (1, h // 4, w // 4), ic.CU_DTYPE), cu[k][None]) is None, k
+        d_ref, d_rec = d_rec, d_ref      # the filtered picture is the next reference
+        d_rcu, d_cu = d_cu, d_rcu
+        dev.free(d_src)
+    dev.free(d_ref, d_rcu, d_rec, d_cu, d_dbk)
 
 
 @pytest.mark.gpu
