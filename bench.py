@@ -505,6 +505,47 @@ def main():
         sys.exit(1)
 
 
+def inter_leg(args, lib, model_for, HipBatch, pictures, sequences=64):
+    """BASELINE config 4 (3840x2160 `--preset veryfast --gop lp-g4d3t1 -q 22`) on the device, as far as the inter CTU pass goes: the I picture through the batched
+    intra pass + deblocking + SAO (picture QP 21: intra_qp_offset -1), then the first B picture (picture QP 25: GOP layer 3) of `sequences` independent sequences in
+    one launch of kvz_hip_dev_inter_ctu_pass -- every sequence the same clip, so that one result can be checked against the reference encoder's CU decisions
+    (tests/golden/inter_recon.json) and the others against it.  value = CTUs of B pictures searched and reconstructed per second (loop filters not included)."""
+    from kvazaar_amd import inter
+    w, h = 3840, 2160
+    if args.qp != 22:
+        return {"workload": "3840x2160 --preset veryfast --gop lp-g4d3t1 (BASELINE config 4)", "skipped": "the fixture holds --qp 22"}
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "inter_recon.json")))["baseline-c4-2160p"]
+    mi = model_for(args.qp - 1)
+    bi = HipBatch(lib, w, h, 1)
+    bi.upload(0, pictures[0])
+    bi.launch(mi)
+    bi.loop_filters(mi, deblock=True, sao=True)
+    rec0 = bi.download(0)["rec"]
+    bi.close()
+    i_ok = hashlib.sha256(np.ascontiguousarray(rec0).tobytes()).hexdigest()[:24] == gold["rec"][0]
+    ip = inter.InterPictures(lib, w, h, sequences)
+    cu0 = inter.intra_picture_cu_info(w, h)
+    for i in range(sequences):
+        ip.upload(i, pictures[1], rec0, cu0)
+    prm = inter.veryfast_params(args.qp + 3, 1)
+    ip.run(prm)  # warm-up: allocates the work-tree slabs
+    t = time.perf_counter()
+    ip.run(prm)
+    s = time.perf_counter() - t
+    _, cu_first = ip.download(0)
+    _, cu_last = ip.download(sequences - 1)
+    ip.close()
+    cu_ok = inter.cu_digest(cu_first) == gold["cu"][1]
+    return {"workload": f"{w}x{h} --preset veryfast --gop lp-g4d3t1 -q {args.qp} (BASELINE config 4): CTU pass of the first B picture (QP {args.qp + 3}; merge / AMVP / temporal "
+                        f"candidates, hexbs + half-pel search, early skip, uni- and bi-prediction, the intra alternative, zero-coefficient RDO, CABAC-context life cycle) of "
+                        f"{sequences} independent sequences in one launch, from the I picture's reconstruction (intra pass + deblocking + SAO at QP {args.qp - 1}, on the device)",
+            "value": sequences * ip.ctus / s, "unit": "CTUs/s", "fps": sequences / s, "ms": s * 1e3,
+            "verified": bool(i_ok and cu_ok and np.array_equal(cu_first, cu_last)),
+            "verify": {"i_picture_reconstruction_equals_reference_encoder": bool(i_ok), "b_picture_cu_decisions_equal_reference_encoder": bool(cu_ok),
+                       "copies_consistent": bool(np.array_equal(cu_first, cu_last))},
+            "note": "first version of the pass (one wavefront per CTU, the reference's control flow in every lane): correctness first, see DESIGN.md 3.8"}
+
+
 def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedResults):
     """auxiliary measurements at --gpus 1 (not the headline):
     chain      CTU pass + deblocking + picture-hash checksums of the whole batch
@@ -624,6 +665,11 @@ def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedRes
                                         "fps": steps * n4k / s, "verified": bool(v["copies_consistent"] and v["golden_ok"] is not False), "verify": v})
         for b, _ in tb:
             b.close()
+        # ---- BASELINE config 4: `--preset veryfast --gop lp-g4d3t1` at 3840x2160: the first B picture of many independent sequences ----
+        try:
+            result["configs_extra"].append(inter_leg(args, lib, model_for, HipBatch, d4))
+        except Exception as e:  # auxiliary: never take the headline down
+            result["configs_extra"].append({"workload": "3840x2160 --preset veryfast --gop lp-g4d3t1 (BASELINE config 4)", "error": repr(e)})
         # ---- BASELINE config 3: `--preset medium` (32x32 search, RDOQ, NxN partitions) at 3840x2160 ----
         n_med = 96
         mm = model_for(args.qp)

@@ -1,0 +1,79 @@
+"""Host side of the inter CTU pass (include/kvz_hip_dev.h kvz_hip_dev_inter_ctu_pass): the CU record layout, the per-picture parameters and a thin wrapper that
+keeps the pictures of many independent sequences on the device.  The product path: no oracle, no CPU fallback -- the library call fails if the HIP kernels are missing."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+
+CU_DTYPE = np.dtype([("type", "u1"), ("depth", "u1"), ("mode", "u1"), ("tr_depth", "u1"), ("cbf", "<u2"), ("skipped", "u1"), ("merged", "u1"), ("merge_idx", "u1"),
+                     ("mv_dir", "u1"), ("mv_ref", "u1", (2,)), ("mv_cand", "u1", (2,)), ("mv", "<i2", (2, 2))], align=True)  # kvz_hip_cu_info
+assert CU_DTYPE.itemsize == 22
+
+
+class InterParams(C.Structure):  # kvz_hip_inter_params
+    _fields_ = [(n, C.c_int32) for n in ("qp", "poc", "mv_constraint", "sao", "deblock", "fme_level", "pu_depth_inter_max", "no_wpp")]
+
+
+def veryfast_params(qp, poc, mv_constraint=True):
+    """`--preset veryfast` (cfg.c:541-568) for a B picture of the low-delay GOP"""
+    return InterParams(qp=qp, poc=poc, mv_constraint=int(mv_constraint), sao=1, deblock=1, fme_level=2, pu_depth_inter_max=3, no_wpp=0)
+
+
+def intra_picture_cu_info(width, height):
+    """the CU info of an I picture as far as the next picture's search reads it (no motion: no temporal candidates, no co-located starting point)"""
+    cu = np.zeros((height // 4, width // 4), CU_DTYPE)
+    cu["type"] = 1
+    cu["mv_ref"] = 255
+    return cu
+
+
+def cu_decision_bytes(cu):
+    """the decisions of one picture as bytes, motion and flags only where they mean something (the digests of tests/golden/inter_recon.json are taken over these)"""
+    inter = cu["type"] == 2
+    coded = inter & (cu["merged"] == 0) & (cu["skipped"] == 0)
+    parts = [cu["type"], cu["depth"], np.where(cu["type"] == 1, cu["mode"], 0), np.where(inter, cu["skipped"], 0), np.where(inter, cu["merged"], 0),
+             np.where(inter & ((cu["merged"] | cu["skipped"]) > 0), cu["merge_idx"], 0), np.where(inter, cu["mv_dir"], 0)]
+    for l in range(2):
+        used = inter & ((cu["mv_dir"] >> l) & 1 > 0)
+        parts += [np.where(used, cu["mv"][..., l, 0], 0).astype("<i2"), np.where(used, cu["mv"][..., l, 1], 0).astype("<i2"), np.where(coded & used, cu["mv_cand"][..., l], 0)]
+    return b"".join(np.ascontiguousarray(p).tobytes() for p in parts)
+
+
+def cu_digest(cu):
+    return hashlib.sha256(cu_decision_bytes(cu)).hexdigest()[:24]
+
+
+class InterPictures:
+    """picture k of `n` independent sequences, resident on the device: sources, references (+ their CU info), and the pass's outputs"""
+
+    def __init__(self, lib, width, height, n):
+        from .dev import Dev
+        self.lib, self.dev, self.w, self.h, self.n = lib, Dev(lib), width, height, n
+        self.fs, self.cells = width * height * 3 // 2, (width // 4) * (height // 4)
+        lib.kvz_hip_dev_inter_ctu_pass.restype = C.c_int
+        lib.kvz_hip_dev_inter_ctu_pass.argtypes = [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_void_p]
+        e = self.dev.empty
+        self.d_src, self.d_ref, self.d_rec = e(n * self.fs), e(n * self.fs), e(n * self.fs)
+        self.d_ref_cu, self.d_cu = e(n * self.cells * CU_DTYPE.itemsize), e(n * self.cells * CU_DTYPE.itemsize)
+        self.ctus = ((width + 63) // 64) * ((height + 63) // 64)
+
+    def upload(self, i, src, ref, ref_cu):
+        up = self.lib.kvz_hip_dev_upload
+        for base, a, size in ((self.d_src, src, self.fs), (self.d_ref, ref, self.fs), (self.d_ref_cu, ref_cu, self.cells * CU_DTYPE.itemsize)):
+            a = np.ascontiguousarray(a)
+            assert a.nbytes == size
+            up(base + i * size, a.ctypes.data, size)
+
+    def run(self, params):
+        rc = self.lib.kvz_hip_dev_inter_ctu_pass(self.d_src, self.d_ref, self.d_ref_cu, self.d_rec, self.d_cu, None, self.w, self.h, self.n, C.addressof(params))
+        if rc != 0:
+            raise RuntimeError(f"kvz_hip_dev_inter_ctu_pass returned {rc}")
+
+    def download(self, i):
+        rec, cu = np.empty(self.fs, np.uint8), np.empty((self.h // 4, self.w // 4), CU_DTYPE)
+        self.lib.kvz_hip_dev_download(rec.ctypes.data, self.d_rec + i * self.fs, self.fs)
+        self.lib.kvz_hip_dev_download(cu.ctypes.data, self.d_cu + i * self.cells * CU_DTYPE.itemsize, cu.nbytes)
+        return rec, cu
+
+    def close(self):
+        self.dev.free(self.d_src, self.d_ref, self.d_rec, self.d_ref_cu, self.d_cu)
