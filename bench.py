@@ -505,7 +505,7 @@ def main():
         sys.exit(1)
 
 
-def inter_leg(args, lib, model_for, HipBatch, pictures, sequences=64):
+def inter_leg(args, lib, model_for, HipBatch, pictures, sequences=128):
     """BASELINE config 4 (3840x2160 `--preset veryfast --gop lp-g4d3t1 -q 22`) on the device, as far as the inter CTU pass goes: the I picture through the batched
     intra pass + deblocking + SAO (picture QP 21: intra_qp_offset -1), then the first B picture (picture QP 25: GOP layer 3) of `sequences` independent sequences in
     one launch of kvz_hip_dev_inter_ctu_pass -- every sequence the same clip, so that one result can be checked against the reference encoder's CU decisions

@@ -1175,8 +1175,8 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
   KVZ_HIP_CHECK(hipGetDevice(&dev_id));
   KVZ_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id));
   const char *env = getenv("KVZ_HIP_INTER_WG_PER_CU");
-  const int per_cu = env ? atoi(env) : 7;  // one wavefront per workgroup, 20.6 KB of LDS each: seven fit a CU's 160 KB (the register budget would allow eight)
-  int n_wg = n_cu * (per_cu > 0 ? per_cu : 7);
+  const int per_cu = env ? atoi(env) : 8;  // one wavefront per workgroup at up to 256 registers: two wavefronts per SIMD = eight workgroups per CU (15 KB of LDS each)
+  int n_wg = n_cu * (per_cu > 0 ? per_cu : 8);
   if ((long)n_wg > total) n_wg = (int)total;
   if (n_wg > sc.n_slabs) {
     if (sc.slabs) KVZ_HIP_CHECK(hipFree(sc.slabs));

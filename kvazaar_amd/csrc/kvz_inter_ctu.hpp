@@ -15,6 +15,8 @@
 // independent sequences.  tests/hostsim compiles this file for the host (a phase = a loop over tid), which is how it was brought up against the oracle without a GPU.
 // Restrictions of this version: coefficients priced with kvz_fast_coeff_cost only (every picture QP below fast-residual-cost 28), square PUs, one reference picture.
 #pragma once
+#include <stddef.h>
+
 #include "../../include/kvz_hip_types.h"
 #include "../../include/kvz_hip_dev.h"
 #include "kvz_ops.hpp"
@@ -94,11 +96,15 @@ struct InterLds {
   alignas(8) u8 win[40 * 40];      // clamped reference window (motion compensation, fractional search), stride 40
   i16 g[40 * 33];                  // 14-bit horizontal intermediates, stride 33
   alignas(8) u8 cur[32 * 32];      // the PU's source block, contiguous
-  alignas(8) u8 pred[4][32 * 32];  // the candidate planes of a fractional step / intra predictions
-  i16 im[2][32 * 32];              // 14-bit predictions of the two lists
-  i16 resid[32 * 32], coefa[32 * 32], tmpb[32 * 32];
+  union {                          // the sample buffers of stages that never overlap in time
+    struct {
+      alignas(8) u8 pred[4][32 * 32];  // the candidate planes of a fractional step
+      i16 im[2][32 * 32];              // 14-bit predictions of the two lists
+    };
+    struct { i16 resid[32 * 32], coefa[32 * 32], tmpb[32 * 32]; };  // the transform path
+    u8 planes[35 * 256];               // the 35 intra predictions of a 16x16 CU (intra_all_mode_costs)
+  };
   u32 acc[16];
-  u32 sad[8];
   u32 cost[4];
   u32 mcost[36];                   // SATD of every intra mode of the CU under evaluation
   u8 top[65], left[65], ftop[65], fleft[65];
