@@ -92,6 +92,11 @@ struct InterFrames {
   unsigned long long *prof;  // [IP_COUNT] or NULL (KVZ_ICTU_PROFILE)
 };
 
+struct MCand { i16 mv[2][2]; u8 ref[2], dir; };                         // inter_merge_cand_t
+struct PuSearch { int x, y, w; i16 mv_cand[2][2]; MCand merge[5]; int num_merge; };
+struct UMap { CuInfo unit[5]; double cost[5], bits[5]; int8_t keys[5]; int size; };
+struct Nbr { CuInfo a[2], b[3], c3, h; bool va[2], vb[3], vc3, vh; };  // merge_candidates_t
+
 struct InterLds {
   alignas(8) u8 win[40 * 40];      // clamped reference window (motion compensation, fractional search), stride 40
   i16 g[40 * 33];                  // 14-bit horizontal intermediates, stride 33
@@ -109,11 +114,22 @@ struct InterLds {
   u32 mcost[36];                   // SATD of every intra mode of the CU under evaluation
   u8 top[65], left[65], ftop[65], fleft[65];
   float fbits[128];
+  // Scalar work memory.  Every lane runs the same control flow on the same values, and with one wavefront per CTU the lanes are in lockstep: small arrays that are
+  // indexed at run time live here once instead of 64 times in private (scratch) memory, whose round trips were most of the decision code's time
+  UMap amvp[3], merge;
+  PuSearch pu;
+  Nbr nb;
+  double costs[36];
+  int8_t modes[36];
+  int px[8], py[8];
+  u32 sad[8];
+  ICtx ctx;  // state->search_cabac's contexts (indexed at run time on every priced bin)
+  ICtx pre[4], post[4];  // search_cu's copies of them, per depth (search.c:655, 956)
+  CuInfo cur_cu[4];      // the CU under evaluation at each depth of the recursion
+  struct { int mvx, mvy; double cost, bits; } best;  // check_mv_cost's best so far
 };
+static_assert(KVZ_ICTU_THREADS == 64, "the scalar work memory in LDS relies on one wavefront per CTU");
 
-struct MCand { i16 mv[2][2]; u8 ref[2], dir; };                         // inter_merge_cand_t
-struct PuSearch { int x, y, w; i16 mv_cand[2][2]; MCand merge[5]; int num_merge; };
-struct UMap { CuInfo unit[5]; double cost[5], bits[5]; int8_t keys[5]; int size; };
 
 #define IC_MAX_COST 1.7e+308
 #define IC_MAX_INT 2147483647.0
@@ -125,8 +141,8 @@ struct InterCtu {
   InterLds *L;
   InterSlab *S;
   int frame, cx, cy;
-  ICtx cab;
   int acc_slot;
+#define cab (L->ctx)  /* the search contexts */
 
   // ---- small things ----
   KVZ_DEV u8 *rec(int lv, int c) const { return S->rec[lv] + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)); }
@@ -186,7 +202,7 @@ struct InterCtu {
   }
 
   // the CU info of luma position (fx, fy): inside this CTU from the work-tree level, else from the frame (finished CTUs)
-  IC_FN CuInfo cell_at(int lv, int fx, int fy) const
+  KVZ_DEV CuInfo cell_at(int lv, int fx, int fy) const
   {
     if (fx >= cx && fx < cx + 64 && fy >= cy && fy < cy + 64) return *cell(lv, fx - cx, fy - cy);
     return F.cu[frame * F.cells + (long)(fy >> 2) * (F.W >> 2) + (fx >> 2)];
@@ -204,6 +220,7 @@ struct InterCtu {
 #include "kvz_inter_ctu_cand.inc"
 #include "kvz_inter_ctu_pix.inc"
 #include "kvz_inter_ctu_search.inc"
+#undef cab
 };
 
 }  // namespace kvz

@@ -25,6 +25,7 @@ __global__ void __launch_bounds__(KVZ_ICTU_THREADS) __attribute__((amdgpu_waves_
 #else
 {
   __shared__ InterLds lds;
+  __shared__ InterCtu prog;  // the program's own members (picture geometry, pointers, position): in LDS, not behind a private `this`
   __shared__ int s_ticket;
   const int ctus = F.wc * F.hc;
   for (;;) {
@@ -59,8 +60,9 @@ __global__ void __launch_bounds__(KVZ_ICTU_THREADS) __attribute__((amdgpu_waves_
     }
     __syncthreads();
     if (s_ticket != 0) {
-      InterCtu p;
+      InterCtu &p = prog;
       p.F = F; p.M = model; p.tb = tb; p.L = &lds; p.S = F.slabs + blockIdx.x; p.frame = frame; p.cx = x * 64; p.cy = y * 64;
+      __syncthreads();
       p.run();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
