@@ -505,7 +505,7 @@ def main():
         sys.exit(1)
 
 
-def inter_leg(args, lib, model_for, HipBatch, pictures, sequences=128):
+def inter_leg(args, lib, model_for, HipBatch, pictures, sequences=192):
     """BASELINE config 4 (3840x2160 `--preset veryfast --gop lp-g4d3t1 -q 22`) on the device, as far as the inter CTU pass goes: the I picture through the batched
     intra pass + deblocking + SAO (picture QP 21: intra_qp_offset -1), then the first B picture (picture QP 25: GOP layer 3) of `sequences` independent sequences in
     one launch of kvz_hip_dev_inter_ctu_pass -- every sequence the same clip, so that one result can be checked against the reference encoder's CU decisions
@@ -536,7 +536,38 @@ def inter_leg(args, lib, model_for, HipBatch, pictures, sequences=128):
     _, cu_last = ip.download(sequences - 1)
     ip.close()
     cu_ok = inter.cu_digest(cu_first) == gold["cu"][1]
-    return {"workload": f"{w}x{h} --preset veryfast --gop lp-g4d3t1 -q {args.qp} (BASELINE config 4): CTU pass of the first B picture (QP {args.qp + 3}; merge / AMVP / temporal "
+    # the reference encoder on the same clip and settings, on this box's host cores: (a) one thread, (b) its default threading, (c) as many independent one-thread encoders
+    # as the box grants CPUs.  Whole encoder (I picture, entropy coding, loop filters included): a reported baseline, bounded to a few seconds each
+    cpu = None
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "kvazaar_ref")
+    if os.path.exists(ref_bin) and not args.no_ref_encoder and not args.no_cpu_baseline:
+        import tempfile
+        with tempfile.NamedTemporaryFile(suffix=".yuv") as tmp:
+            nfr = 8
+            for i in range(nfr):
+                tmp.write(pictures[i % len(pictures)].tobytes())
+            tmp.flush()
+            base = [ref_bin, "-i", tmp.name, "--input-res", f"{w}x{h}", "--preset", "veryfast", "--gop", "lp-g4d3t1", "-q", str(args.qp), "-o", "/dev/null"]
+            def timed(cmds):
+                t0 = time.time()
+                ps = [subprocess.Popen(c, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for c in cmds]
+                ok = all(p.wait() == 0 for p in ps)
+                return time.time() - t0, ok
+            cpus = len(os.sched_getaffinity(0))
+            try:
+                quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+                if quota != "max":
+                    cpus = max(1, min(cpus, int(int(quota) / int(period))))
+            except (OSError, ValueError):
+                pass
+            s1, ok1 = timed([base + ["-n", "4", "--threads", "0", "--owf", "0"]])
+            sd, okd = timed([base + ["-n", str(nfr)]])
+            sn, okn = timed([base + ["-n", "4", "--threads", "0", "--owf", "0"] for _ in range(cpus)])
+            cpu = {"unit": "CTUs/s", "kind": "reference", "cpus": cpus,
+                   "one_thread": {"value": 4 * ip.ctus / s1 if ok1 else None, "sample": f"4 pictures, --threads 0 --owf 0 ({s1:.1f} s)"},
+                   "default_threading": {"value": nfr * ip.ctus / sd if okd else None, "sample": f"{nfr} pictures, threads / owf auto ({sd:.1f} s)"},
+                   "independent_one_thread_encoders": {"value": cpus * 4 * ip.ctus / sn if okn else None, "sample": f"{cpus} concurrent encoders x 4 pictures, --threads 0 ({sn:.1f} s)"}}
+    return {"cpu_reference": cpu, "workload": f"{w}x{h} --preset veryfast --gop lp-g4d3t1 -q {args.qp} (BASELINE config 4): CTU pass of the first B picture (QP {args.qp + 3}; merge / AMVP / temporal "
                         f"candidates, hexbs + half-pel search, early skip, uni- and bi-prediction, the intra alternative, zero-coefficient RDO, CABAC-context life cycle) of "
                         f"{sequences} independent sequences in one launch, from the I picture's reconstruction (intra pass + deblocking + SAO at QP {args.qp - 1}, on the device)",
             "value": sequences * ip.ctus / s, "unit": "CTUs/s", "fps": sequences / s, "ms": s * 1e3,

@@ -123,6 +123,9 @@ struct InterLds {
   int8_t modes[36];
   int px[8], py[8];
   u32 sad[8];
+#ifdef KVZ_ICTU_ORG_LDS
+  alignas(8) u8 org[64 * 64 + 2 * 32 * 32];  // the CTU's source samples
+#endif
   ICtx ctx;  // state->search_cabac's contexts (indexed at run time on every priced bin)
   ICtx pre[4], post[4];  // search_cu's copies of them, per depth (search.c:655, 956)
   CuInfo cur_cu[4];      // the CU under evaluation at each depth of the recursion
@@ -147,7 +150,11 @@ struct InterCtu {
   // ---- small things ----
   KVZ_DEV u8 *rec(int lv, int c) const { return S->rec[lv] + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)); }
   KVZ_DEV i16 *coef(int lv, int c) const { return S->coeff[lv] + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)); }
+#ifdef KVZ_ICTU_ORG_LDS
+  KVZ_DEV u8 *org(int c) const { return L->org + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)); }
+#else
   KVZ_DEV u8 *org(int c) const { return S->org + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)); }
+#endif
   KVZ_DEV const u8 *refp(int c) const { return F.ref + frame * F.frame_px + (c == 0 ? 0 : (c == 1 ? (long)F.W * F.H : (long)F.W * F.H * 5 / 4)); }
   KVZ_DEV const u8 *srcp(int c) const { return F.src + frame * F.frame_px + (c == 0 ? 0 : (c == 1 ? (long)F.W * F.H : (long)F.W * F.H * 5 / 4)); }
   KVZ_DEV CuInfo *cell(int lv, int xl, int yl) const { return &S->cu[lv][(yl >> 2) * 16 + (xl >> 2)]; }
