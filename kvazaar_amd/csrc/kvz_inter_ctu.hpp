@@ -121,6 +121,10 @@ struct InterLds {
   Nbr nb;
   double costs[36];
   int8_t modes[36];
+  int8_t todo[36];
+  int mvc_key[4];      // the PU and list L->mvc holds the AMVP predictors of ({x, y, w, list}; w = 0: none) -- the search asks for the same pair up to three times
+  i16 mvc[2][2];
+  int level_holds;     // after search_pu_inter: bit 0 / 1 = the level's luma / chroma samples are the prediction of the best merge candidate (merge.keys[0])
   int px[8], py[8];
   u32 sad[8];
 #ifdef KVZ_ICTU_ORG_LDS
