@@ -18,3 +18,8 @@ python bench_kernels.py > gpurun_out/${tag}_micro_kernels.jsonl 2> gpurun_out/${
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $repo/gpurun_out/${tag}_micro_stats -o ${tag}_micro -- python $repo/bench_kernels.py --reps 5 > $repo/gpurun_out/${tag}_micro_stats.log 2>&1
 cd $repo
+# the inter CTU pass (BASELINE config 4): rocprofv3 kernel stats of tools/inter_ctu_probe.py (1024 sequences of the 416x240 survey clip, every picture checked against the oracle)
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $repo/gpurun_out/${tag}_inter_stats -o ${tag}_inter -- python $repo/tools/inter_ctu_probe.py survey-416x240 1024 > $repo/gpurun_out/${tag}_inter_probe.log 2>&1
+cd $repo
+tail -8 gpurun_out/${tag}_inter_probe.log
