@@ -5,7 +5,8 @@
  * kvz_search_lcu(state, x, y, ...) leaves three things behind for the rest of encoder_state_worker_encode_lcu_search
  * (encoderstate.c:659-720: deblocking, SAO, kvz_encode_coding_tree): the LCU's cu_info in frame->cu_array, its reconstruction in
  * frame->rec and its quantised coefficients in state->coeff (copy_lcu_to_cu_data / copy_coeffs, search.c:1180-1249).  For the
- * configuration the batched pass implements -- I slices of an all-intra `ultrafast`-like setup, 8-bit 4:2:0, constant QP, with or without WPP --
+ * configuration the batched pass implements -- I slices of an `ultrafast` .. `medium`-like setup, 8-bit 4:2:0, constant QP, with or without WPP; since round 3 also
+ * the B pictures of a low-delay GOP (search_lcu_inter below: kvz_hip_dev_inter_ctu_pass) --
  * this file fills exactly those from one kvz_hip_intra_frames() run per picture: the first LCU of a picture to get here runs the
  * pass for the whole picture (one-frame batch; the throughput path batches many pictures, this binding is about correctness),
  * every LCU then copies its part.  Everything else falls through to the original function.  The bitstream is the reference's,
@@ -30,6 +31,7 @@
 #include "videoframe.h"
 
 #include "kvz_hip_batch.h"
+#include "kvz_hip_dev.h"
 
 void __real_kvz_search_lcu(encoder_state_t *const state, const int x, const int y, const yuv_t *const hor_buf, const yuv_t *const ver_buf);
 
@@ -74,7 +76,7 @@ static int eligible(const encoder_state_t *state)
   const encoder_control_t *ctrl = state->encoder_control;
   const kvz_config *cfg = &ctrl->cfg;
 #define REQUIRE(cond) do { if (!(cond)) { if (enabled > 1) fprintf(stderr, "search_lcu_hip: not eligible: %s\n", #cond); return 0; } } while (0)
-  REQUIRE(state->frame->slicetype == KVZ_SLICE_I);
+  REQUIRE(state->frame->slicetype == KVZ_SLICE_I || state->frame->slicetype == KVZ_SLICE_B);
   REQUIRE(ctrl->bitdepth == 8 && ctrl->chroma_format == KVZ_CSP_420);
   REQUIRE(cfg->rdo == 0 && !cfg->signhide_enable && !cfg->trskip_enable && cfg->tr_depth_intra == 0);
   /* --rdoq (preset medium): kvz_rdoq in every quantisation (rdoq-skip 0), priced on the CABAC model (fast-residual-cost 0) */
@@ -85,9 +87,25 @@ static int eligible(const encoder_state_t *state)
   REQUIRE((cfg->pu_depth_intra.min[0] == 2 || cfg->pu_depth_intra.min[0] == 1) && (cfg->pu_depth_intra.max[0] == 3 || cfg->pu_depth_intra.max[0] == 4));
   REQUIRE(cfg->cu_split_termination == KVZ_CU_SPLIT_TERMINATION_ZERO && cfg->combine_intra_cus);
   REQUIRE(cfg->target_bitrate <= 0 && !cfg->vaq && !cfg->roi.file_path && !cfg->set_qp_in_cu && state->frame->max_qp_delta_depth < 0);
-  REQUIRE(!cfg->ml_pu_depth_intra && !cfg->intra_bit_allocation);
+  REQUIRE(!cfg->ml_pu_depth_intra);  /* (intra_bit_allocation, which lp GOPs switch on, only acts under rate control: rate_control.c:352-705) */
+  if (state->frame->slicetype == KVZ_SLICE_I) return 1;
+  /* B pictures: the inter CTU pass (include/kvz_hip_dev.h kvz_hip_dev_inter_ctu_pass) is the search of `--preset veryfast|superfast|ultrafast --gop lp-gNd*t1`:
+   * one reference picture -- the previous one -- in both lists, hexagon search with the `sensitive` early termination, fme level 0 or 2, bi-prediction through
+   * merge candidates only, early skip, 2Nx2N PUs of 8..32 samples, coefficients priced by kvz_fast_coeff_cost (QP < 28).  --owf 0: the pass searches the whole
+   * picture when its first LCU arrives, so the reference picture has to be complete by then. */
+  const encoder_state_config_frame_t *fr = state->frame;
+  REQUIRE(cfg->owf == 0 && cfg->tiles_width_count * cfg->tiles_height_count <= 1 && cfg->slices == KVZ_SLICES_NONE);
+  REQUIRE(fr->ref->used_size == 1 && fr->ref_LX_size[0] == 1 && fr->ref_LX_size[1] == 1 && fr->ref->pocs[0] == fr->poc - 1);
+  REQUIRE(cfg->gop_len > 0 && cfg->gop_lowdelay && cfg->bipred && cfg->fast_bipred && cfg->tmvp_enable);
+  REQUIRE(cfg->ime_algorithm == KVZ_IME_HEXBS && cfg->me_early_termination == KVZ_ME_EARLY_TERMINATION_SENSITIVE && cfg->me_max_steps == (uint32_t)-1);
+  REQUIRE((cfg->fme_level == 0 || cfg->fme_level == 2) && !cfg->mv_rdo && cfg->mv_constraint == KVZ_MV_CONSTRAIN_NONE);
+  REQUIRE(cfg->early_skip && cfg->max_merge == 5 && cfg->zero_coeff_rdo && !cfg->smp_enable && !cfg->amp_enable && !cfg->rdoq_enable);
+  REQUIRE(cfg->pu_depth_inter.min[0] == 1 && (cfg->pu_depth_inter.max[0] == 2 || cfg->pu_depth_inter.max[0] == 3));
+  REQUIRE(cfg->pu_depth_intra.min[0] == 2 && cfg->pu_depth_intra.max[0] == 3);
+  REQUIRE(state->qp < cfg->fast_residual_cost_limit && state->qp < MAX_FAST_COEFF_COST_QP && !cfg->intra_rdo_et);
+  REQUIRE(state->tile->frame->width % 8 == 0 && state->tile->frame->height % 8 == 0);
 #undef REQUIRE
-  return 1;
+  return 2;
 }
 
 static int env_int(const char *name, int dflt)
@@ -247,14 +265,151 @@ static unsigned zorder16(int x, int y) /* cu.h:385-421 xy_to_zorder for 4-sample
   return r * 16;
 }
 
+/* ---- B pictures: one kvz_hip_dev_inter_ctu_pass per picture.  --owf 0 keeps one picture in flight, so a single set of buffers serves: the first LCU of a
+ * picture to get here uploads the source, the reference picture (after its loop filters) and the reference's CU array, runs the pass and downloads the
+ * reconstruction, CU records and coefficients; the other LCUs wait for it. */
+static struct {
+  int w, h, ready, busy;
+  int32_t num;
+  uint8_t *src, *ref, *rec;
+  kvz_hip_cu_info *ref_cu, *cu;
+  int16_t *coeff;
+  void *d_src, *d_ref, *d_rec, *d_ref_cu, *d_cu, *d_coeff;
+} g_inter = { .num = -1 };
+
+static void tight_planes(uint8_t *dst, const kvz_picture *pic, int w, int h)
+{
+  const size_t ys = (size_t)w * h, cs = ys / 4;
+  for (int row = 0; row < h; row++) memcpy(dst + (size_t)row * w, pic->y + (size_t)row * pic->stride, w);
+  for (int row = 0; row < h / 2; row++) {
+    memcpy(dst + ys + (size_t)row * (w / 2), pic->u + (size_t)row * (pic->stride / 2), w / 2);
+    memcpy(dst + ys + cs + (size_t)row * (w / 2), pic->v + (size_t)row * (pic->stride / 2), w / 2);
+  }
+}
+
+static void inter_picture(const encoder_state_t *state)
+{
+  const videoframe_t *frame = state->tile->frame;
+  const kvz_config *cfg = &state->encoder_control->cfg;
+  const int w = frame->width, h = frame->height, wc = (w + 63) / 64, hc = (h + 63) / 64;
+  const size_t bytes = (size_t)w * h * 3 / 2, cells = (size_t)(w / 4) * (h / 4), ncoeff = (size_t)wc * hc * KVZ_HIP_CTU_COEFFS;
+  if (g_inter.w != w || g_inter.h != h) {
+    kvz_hip_host_free(g_inter.src); kvz_hip_host_free(g_inter.ref); kvz_hip_host_free(g_inter.rec);
+    kvz_hip_host_free(g_inter.ref_cu); kvz_hip_host_free(g_inter.cu); kvz_hip_host_free(g_inter.coeff);
+    kvz_hip_dev_free(g_inter.d_src); kvz_hip_dev_free(g_inter.d_ref); kvz_hip_dev_free(g_inter.d_rec);
+    kvz_hip_dev_free(g_inter.d_ref_cu); kvz_hip_dev_free(g_inter.d_cu); kvz_hip_dev_free(g_inter.d_coeff);
+    g_inter.src = kvz_hip_host_alloc(bytes); g_inter.ref = kvz_hip_host_alloc(bytes); g_inter.rec = kvz_hip_host_alloc(bytes);
+    g_inter.ref_cu = kvz_hip_host_alloc(cells * sizeof(kvz_hip_cu_info)); g_inter.cu = kvz_hip_host_alloc(cells * sizeof(kvz_hip_cu_info));
+    g_inter.coeff = kvz_hip_host_alloc(ncoeff * sizeof(int16_t));
+    g_inter.d_src = kvz_hip_dev_alloc(bytes); g_inter.d_ref = kvz_hip_dev_alloc(bytes); g_inter.d_rec = kvz_hip_dev_alloc(bytes);
+    g_inter.d_ref_cu = kvz_hip_dev_alloc(cells * sizeof(kvz_hip_cu_info)); g_inter.d_cu = kvz_hip_dev_alloc(cells * sizeof(kvz_hip_cu_info));
+    g_inter.d_coeff = kvz_hip_dev_alloc(ncoeff * sizeof(int16_t));
+    if (!g_inter.src || !g_inter.ref || !g_inter.rec || !g_inter.ref_cu || !g_inter.cu || !g_inter.coeff || !g_inter.d_src || !g_inter.d_ref || !g_inter.d_rec ||
+        !g_inter.d_ref_cu || !g_inter.d_cu || !g_inter.d_coeff) { fprintf(stderr, "search_lcu_hip: out of memory\n"); abort(); }
+    g_inter.w = w; g_inter.h = h;
+  }
+  tight_planes(g_inter.src, frame->source, w, h);
+  tight_planes(g_inter.ref, state->frame->ref->images[0], w, h);
+  /* what the search reads of the reference picture's CUs (inter.c:1204-1260 temporal candidates, search_inter.c:1286-1339 the starting point): type and motion */
+  const cu_array_t *rca = state->frame->ref->cu_arrays[0];
+  for (int y = 0; y < h; y += 4)
+    for (int x = 0; x < w; x += 4) {
+      const cu_info_t *c = kvz_cu_array_at_const(rca, x, y);
+      kvz_hip_cu_info *o = &g_inter.ref_cu[(size_t)(y / 4) * (w / 4) + x / 4];
+      memset(o, 0, sizeof *o);
+      o->type = c->type; o->depth = c->depth; o->tr_depth = c->tr_depth; o->cbf = c->cbf;
+      if (c->type == CU_INTER) {
+        o->skipped = c->skipped; o->merged = c->merged; o->merge_idx = c->merge_idx; o->mv_dir = c->inter.mv_dir;
+        for (int l = 0; l < 2; l++) { o->mv_ref[l] = c->inter.mv_ref[l]; o->mv[l][0] = c->inter.mv[l][0]; o->mv[l][1] = c->inter.mv[l][1]; }
+      } else {
+        o->mode = (uint8_t)c->intra.mode;
+      }
+    }
+  kvz_hip_dev_upload(g_inter.d_src, g_inter.src, bytes);
+  kvz_hip_dev_upload(g_inter.d_ref, g_inter.ref, bytes);
+  kvz_hip_dev_upload(g_inter.d_ref_cu, g_inter.ref_cu, cells * sizeof(kvz_hip_cu_info));
+  kvz_hip_inter_params prm;
+  memset(&prm, 0, sizeof prm);
+  prm.qp = state->qp; prm.poc = state->frame->poc;
+  prm.mv_constraint = cfg->owf && cfg->wpp;  /* search_inter.c:75-152 */
+  prm.sao = cfg->sao_type != 0; prm.deblock = cfg->deblock_enable != 0;
+  prm.fme_level = cfg->fme_level; prm.pu_depth_inter_max = cfg->pu_depth_inter.max[0]; prm.no_wpp = !cfg->wpp;
+  const int rc = kvz_hip_dev_inter_ctu_pass(g_inter.d_src, g_inter.d_ref, g_inter.d_ref_cu, g_inter.d_rec, g_inter.d_cu, g_inter.d_coeff, w, h, 1, &prm);
+  if (rc != 0) { fprintf(stderr, "search_lcu_hip: the inter CTU pass failed (%d)\n", rc); abort(); }
+  kvz_hip_dev_download(g_inter.rec, g_inter.d_rec, bytes);
+  kvz_hip_dev_download(g_inter.cu, g_inter.d_cu, cells * sizeof(kvz_hip_cu_info));
+  kvz_hip_dev_download(g_inter.coeff, g_inter.d_coeff, ncoeff * sizeof(int16_t));
+  {  /* KVZ_HIP_INTER_TRACE=<file>: B pictures searched on the device so far */
+    static int pictures;
+    const char *trace = getenv("KVZ_HIP_INTER_TRACE");
+    pictures++;
+    if (trace) { FILE *f = fopen(trace, "w"); if (f) { fprintf(f, "%d\n", pictures); fclose(f); } }
+  }
+}
+
+static void copy_rec_and_coeff(encoder_state_t *state, int x, int y, int w, int h, const uint8_t *rec, const int16_t *coeff)
+{
+  videoframe_t *frame = state->tile->frame;
+  const size_t ys = (size_t)w * h, cs = ys / 4;
+  /* reconstruction before deblocking (copy_lcu_to_cu_data) */
+  for (int row = 0; row < 64 && y + row < h; row++) {
+    const int n = x + 64 <= w ? 64 : w - x;
+    memcpy(&frame->rec->y[x + (size_t)(y + row) * frame->rec->stride], rec + (size_t)(y + row) * w + x, n);
+  }
+  for (int row = 0; row < 32 && y / 2 + row < h / 2; row++) {
+    const int n = x / 2 + 32 <= w / 2 ? 32 : w / 2 - x / 2;
+    memcpy(&frame->rec->u[x / 2 + (size_t)(y / 2 + row) * (frame->rec->stride / 2)], rec + ys + (size_t)(y / 2 + row) * (w / 2) + x / 2, n);
+    memcpy(&frame->rec->v[x / 2 + (size_t)(y / 2 + row) * (frame->rec->stride / 2)], rec + ys + cs + (size_t)(y / 2 + row) * (w / 2) + x / 2, n);
+  }
+  /* coefficients (copy_coeffs): lcu_t z-order, the layout the library returns */
+  memcpy(state->coeff->y, coeff, 4096 * sizeof(int16_t));
+  memcpy(state->coeff->u, coeff + 4096, 1024 * sizeof(int16_t));
+  memcpy(state->coeff->v, coeff + 5120, 1024 * sizeof(int16_t));
+}
+
+static void search_lcu_inter(encoder_state_t *state, int x, int y)
+{
+  videoframe_t *frame = state->tile->frame;
+  pthread_mutex_lock(&g_lock);
+  while (g_inter.busy) pthread_cond_wait(&g_cond, &g_lock);
+  if (g_inter.num != state->frame->num || !g_inter.ready) {
+    g_inter.busy = 1; g_inter.ready = 0; g_inter.num = state->frame->num;
+    pthread_mutex_unlock(&g_lock);
+    inter_picture(state);
+    pthread_mutex_lock(&g_lock);
+    g_inter.busy = 0; g_inter.ready = 1;
+    pthread_cond_broadcast(&g_cond);
+  }
+  pthread_mutex_unlock(&g_lock);
+  const int w = g_inter.w, h = g_inter.h, wc = (w + 63) / 64;
+  /* CU info (kvz_cu_array_copy_from_lcu): one cu_info_t per 4x4 unit, as search_cu leaves them (search.c:1000-1063, lcu_fill_inter / lcu_fill_cbf) */
+  for (int yy = 0; yy < 64 && y + yy < h; yy += 4)
+    for (int xx = 0; xx < 64 && x + xx < w; xx += 4) {
+      const kvz_hip_cu_info *c = &g_inter.cu[(size_t)((y + yy) / 4) * (w / 4) + (x + xx) / 4];
+      cu_info_t *cu = kvz_cu_array_at(frame->cu_array, x + xx, y + yy);
+      memset(cu, 0, sizeof *cu);
+      cu->type = c->type; cu->depth = c->depth; cu->part_size = SIZE_2Nx2N; cu->tr_depth = c->tr_depth; cu->cbf = c->cbf; cu->qp = (uint8_t)state->qp;
+      if (c->type == CU_INTER) {
+        cu->skipped = c->skipped; cu->merged = c->merged; cu->merge_idx = c->merge_idx;
+        cu->inter.mv_dir = c->mv_dir; cu->inter.mv_cand0 = c->mv_cand[0]; cu->inter.mv_cand1 = c->mv_cand[1];
+        for (int l = 0; l < 2; l++) { cu->inter.mv_ref[l] = c->mv_ref[l]; cu->inter.mv[l][0] = c->mv[l][0]; cu->inter.mv[l][1] = c->mv[l][1]; }
+      } else {
+        cu->intra.mode = (int8_t)c->mode; cu->intra.mode_chroma = (int8_t)c->mode;
+      }
+    }
+  copy_rec_and_coeff(state, x, y, w, h, g_inter.rec, g_inter.coeff + (size_t)((y / 64) * wc + x / 64) * KVZ_HIP_CTU_COEFFS);
+}
+
 void __wrap_kvz_search_lcu(encoder_state_t *const state, const int x, const int y, const yuv_t *const hor_buf, const yuv_t *const ver_buf)
 {
-  if (!eligible(state)) { __real_kvz_search_lcu(state, x, y, hor_buf, ver_buf); return; }
+  const int path = eligible(state);
+  if (!path) { __real_kvz_search_lcu(state, x, y, hor_buf, ver_buf); return; }
   /* what kvz_search_lcu leaves in state->search_cabac for the stages after it: a counting-mode copy of the row's contexts taken at the start of
    * the LCU (search.c:1211-1212), update flag off as search_cu leaves it -- kvz_sao_search_lcu prices its mode bits on it (sao.c:52-177) */
   memcpy(&state->search_cabac, &state->cabac, sizeof(cabac_data_t));
   state->search_cabac.only_count = 1;
   state->search_cabac.update = 0;
+  if (path == 2) { search_lcu_inter(state, x, y); return; }
   picture_result *r = picture_of(state);
   videoframe_t *frame = state->tile->frame;
   const int w = r->width, h = r->height, w8 = w / 8, wc = (w + 63) / 64;
@@ -307,20 +462,7 @@ void __wrap_kvz_search_lcu(encoder_state_t *const state, const int x, const int 
           cu->intra.mode = (int8_t)mode; cu->intra.mode_chroma = (int8_t)mode;
         }
     }
-  /* reconstruction before deblocking (copy_lcu_to_cu_data) */
-  for (int row = 0; row < 64 && y + row < h; row++) {
-    const int n = x + 64 <= w ? 64 : w - x;
-    memcpy(&frame->rec->y[x + (size_t)(y + row) * frame->rec->stride], r->rec + (size_t)(y + row) * w + x, n);
-  }
-  for (int row = 0; row < 32 && y / 2 + row < h / 2; row++) {
-    const int n = x / 2 + 32 <= w / 2 ? 32 : w / 2 - x / 2;
-    memcpy(&frame->rec->u[x / 2 + (size_t)(y / 2 + row) * (frame->rec->stride / 2)], r->rec + ys + (size_t)(y / 2 + row) * (w / 2) + x / 2, n);
-    memcpy(&frame->rec->v[x / 2 + (size_t)(y / 2 + row) * (frame->rec->stride / 2)], r->rec + ys + cs + (size_t)(y / 2 + row) * (w / 2) + x / 2, n);
-  }
-  /* coefficients (copy_coeffs): lcu_t z-order, the layout the batch returns */
-  memcpy(state->coeff->y, plane[0], 4096 * sizeof(int16_t));
-  memcpy(state->coeff->u, plane[1], 1024 * sizeof(int16_t));
-  memcpy(state->coeff->v, plane[2], 1024 * sizeof(int16_t));
+  copy_rec_and_coeff(state, x, y, w, h, r->rec, coeff);
   pthread_mutex_lock(&g_lock);
   r->outstanding--;  /* this LCU is done with the slot's buffers */
   pthread_mutex_unlock(&g_lock);

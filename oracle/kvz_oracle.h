@@ -190,6 +190,10 @@ int  kvz_oracle_me_trace_count(void);
 int  kvz_oracle_lowdelay_qp(int qp, int gop_len, int gop_depth, int frame, int intra_period, int ra8_model);
 void kvz_oracle_lowdelay_encode(const kvz_oracle_lowdelay_cfg *cfg, const float entropy_fbits[128], const uint64_t coeff_weights[52], int width, int height,
                                 int n_frames, const uint8_t *src, uint8_t *rec_search, uint8_t *rec_final, kvz_oracle_cu *cu_out, int32_t *frame_qp);
+/* one B picture of such a sequence on its own, from its reference picture (after the loop filters) and that picture's CU records: qp / poc are the picture's;
+ * of cfg the search options are read (fme_level, pu_depth_inter_max, sao, deblock, mv_constraint, no_wpp).  coeff (or NULL): KVZ_HIP_CTU_COEFFS per CTU. */
+void kvz_oracle_inter_picture(int qp, int poc, const kvz_oracle_lowdelay_cfg *cfg, const float entropy_fbits[128], uint64_t coeff_weights, int width, int height,
+                              const uint8_t *src, const uint8_t *ref, const kvz_oracle_cu *ref_cu, uint8_t *rec, kvz_oracle_cu *cu, int16_t *coeff);
 
 /* ---- deblocking of an all-intra, constant-QP picture in place (kvz_oracle_deblock.c; filter.c:783 kvz_filter_deblock_lcu over
  * every LCU).  Planes are tight (stride = width), cu_depth is the CU depth per 8x8 unit as the CTU pass returns it. ---- */

@@ -57,3 +57,30 @@ def test_binding_reproduces_the_survey_md5_at_1080p(tmp_path):
     got = _encode("kvazaar_hipsim", yuv, "1920x1080", str(tmp_path / "sim.hevc"), ["--preset", "ultrafast", "-p", "1", "--threads", "8"],
                   {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1"})
     assert got == "dce84d2200dc0e54e2e029425d1682e1"
+
+
+# ---- B pictures: the binding's inter path (search_lcu_inter: reference picture and CU-array hand-over, cu_info_t rebuild incl. motion, coefficients) ----
+INTER_CASES = [("416x240", 8, ["--preset", "veryfast", "--gop", "lp-g4d3t1", "--owf", "0"], 7),                          # BASELINE config 4's options
+               ("416x240", 6, ["--preset", "ultrafast", "--gop", "lp-g4d3t1", "--owf", "0", "-q", "20"], 5),            # fme 0, PUs down to 16x16, no SAO
+               ("416x240", 5, ["--preset", "veryfast", "--gop", "lp-g4d3t1", "--owf", "0", "--no-wpp"], 4),             # one coder through the picture
+               ("416x240", 10, ["--preset", "veryfast", "--gop", "lp-g4d3t1", "--owf", "0", "--period", "8"], 8),       # a second I picture: the chain restarts
+               ("416x240", 6, ["--preset", "superfast", "--gop", "lp-g8d4t1", "--owf", "0", "--no-sao"], 5),            # another low-delay GOP: other picture QPs
+               ("416x240", 6, ["--preset", "ultrafast", "--gop", "lp-g4d3t1", "--owf", "0", "-q", "24"], 3)]            # pictures at QP 28 go to kvazaar's own search
+
+
+@pytest.mark.parametrize("res,frames,opts,device_pictures", INTER_CASES, ids=["veryfast", "ultrafast-qp20", "veryfast-no-wpp", "veryfast-period8", "superfast-g8-no-sao", "ultrafast-qp24-mixed"])
+def test_binding_inter_pictures_write_the_reference_bitstream(tmp_path, res, frames, opts, device_pictures):
+    """B pictures of a low-delay GOP through the binding: the reference picture (after kvazaar's own loop filters) and its cu_array go in, cu_info_t / reconstruction /
+    coefficients of every LCU come back; kvazaar's entropy coder must then write the reference encoder's bitstream"""
+    if not os.path.exists(os.path.join(REF, "kvazaar_hipsim")):
+        pytest.skip("oracle/_ref/kvazaar_hipsim not built (oracle/Makefile, where /root/reference exists)")
+    w, h = (int(v) for v in res.split("x"))
+    yuv = str(tmp_path / "syn.yuv")
+    synth.write_yuv(yuv, w, h, frames, 1234, "small")
+    want = _encode("kvazaar_ref", yuv, res, str(tmp_path / "ref.hevc"), opts + ["--threads", "4"])
+    got = _encode("kvazaar_hipsim", yuv, res, str(tmp_path / "sim.hevc"), opts + ["--threads", "4"],
+                  {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1", "KVZ_HIP_INTER_TRACE": str(tmp_path / "trace")})
+    assert got == want
+    assert int(open(str(tmp_path / "trace")).read()) >= device_pictures, "the inter pass was not used"
+    if opts[1] == "veryfast" and len(opts) == 6 and frames == 8:
+        assert got == "1e7a81653d1157ce05e9ffd85c7cd5cf"  # SURVEY.md 8c: 416x240 x 8 --preset veryfast --gop lp-g4d3t1

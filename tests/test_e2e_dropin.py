@@ -145,3 +145,34 @@ def test_batched_search_golden_md5_at_baseline_sizes(tmp_path, res, frames, seed
                         {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1", "KVZ_HIP_BATCH_TRACE": str(tmp_path / "trace")}, res=res)
     assert got == md5
     assert int(open(str(tmp_path / "trace")).read().split()[0]) >= frames, "the batched search was not used"
+
+
+# ---- BASELINE config 4: B pictures searched by the inter CTU pass on the device, inside the real encoder ----
+INTER_CASES = [("416x240", 8, 1234, "small", ["--preset", "veryfast", "--gop", "lp-g4d3t1", "--owf", "0"], 7),
+               ("416x240", 6, 1234, "small", ["--preset", "ultrafast", "--gop", "lp-g4d3t1", "--owf", "0", "-q", "20"], 5),
+               ("416x240", 5, 1234, "small", ["--preset", "veryfast", "--gop", "lp-g4d3t1", "--owf", "0", "--no-wpp"], 4),
+               ("416x240", 10, 1234, "small", ["--preset", "veryfast", "--gop", "lp-g4d3t1", "--owf", "0", "--period", "8"], 8),
+               ("1920x1080", 5, 1, "large", ["--preset", "veryfast", "--gop", "lp-g4d3t1", "--owf", "0"], 4),
+               ("3840x2160", 4, 2, "large", ["--preset", "veryfast", "--gop", "lp-g4d3t1", "--owf", "0"], 3)]
+
+
+@pytest.mark.parametrize("res,frames,seed,kind,opts,device_pictures", INTER_CASES,
+                         ids=["veryfast-416x240", "ultrafast-qp20", "veryfast-no-wpp", "veryfast-period8", "veryfast-1080p", "baseline-c4-2160p"])
+def test_inter_pass_inside_the_encoder_bitstream_identical(tmp_path, res, frames, seed, kind, opts, device_pictures):
+    """`--preset veryfast --gop lp-g4d3t1` with every picture searched on the device: the I picture by the batched intra pass, the B pictures by
+    kvz_hip_dev_inter_ctu_pass (integration/kvazaar/search_lcu_hip.c search_lcu_inter), each from kvazaar's own deblocked + SAO-filtered reference picture and its
+    cu_array.  kvazaar's loop filters and entropy coder then run on the device's CU records, reconstruction and coefficients, and the bitstream must be the
+    reference encoder's byte for byte -- every motion vector, merge index, skip flag, intra mode, coded block flag and coefficient of every CU.  (--owf 0: the pass
+    needs the complete reference picture when a picture's first LCU is searched.)"""
+    _need_hip_encoder()
+    w, h = (int(v) for v in res.split("x"))
+    yuv = str(tmp_path / "syn.yuv")
+    synth.write_yuv(yuv, w, h, frames, seed, kind)
+    common = opts + ["--threads", "8"]
+    md5_ref, _, _ = _encode("kvazaar_ref", yuv, str(tmp_path / "ref.hevc"), common, res=res)
+    md5_dev, t, _ = _encode("kvazaar_hip", yuv, str(tmp_path / "dev.hevc"), common,
+                            {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1", "KVZ_HIP_INTER_TRACE": str(tmp_path / "trace")}, res=res)
+    assert md5_dev == md5_ref
+    assert int(open(str(tmp_path / "trace")).read()) >= device_pictures, "the inter pass was not used"
+    if res == "416x240" and frames == 8:
+        assert md5_dev == "1e7a81653d1157ce05e9ffd85c7cd5cf"  # SURVEY.md 8c
