@@ -525,17 +525,50 @@ def inter_leg(args, lib, model_for, HipBatch, pictures, sequences=192):
     i_ok = hashlib.sha256(np.ascontiguousarray(rec0).tobytes()).hexdigest()[:24] == gold["rec"][0]
     ip = inter.InterPictures(lib, w, h, sequences)
     cu0 = inter.intra_picture_cu_info(w, h)
+    n_b = min(3, len(pictures) - 1)
     for i in range(sequences):
         ip.upload(i, pictures[1], rec0, cu0)
-    prm = inter.veryfast_params(args.qp + 3, 1)
-    ip.run(prm)  # warm-up: allocates the work-tree slabs
+    for k in range(2, n_b + 1):  # the later pictures' sources, resident before the clock starts
+        ip.new_source_set()
+        ip.use_source_set(k - 1)
+        for i in range(sequences):
+            ip.upload_source(i, pictures[k])
+    ip.use_source_set(0)
+    qps = [inter.lowdelay_picture_qp(args.qp, k) for k in range(n_b + 1)]
+    prm = inter.veryfast_params(qps[1], 1)
+    ip.run(prm)           # warm-up: allocates the work-tree slabs and the loop filters' scratch pictures; the timed run rewrites d_rec
+    ip.loop_filters(prm)
+    ip.sync()
     t = time.perf_counter()
     ip.run(prm)
     s = time.perf_counter() - t
     _, cu_first = ip.download(0)
     _, cu_last = ip.download(sequences - 1)
-    ip.close()
     cu_ok = inter.cu_digest(cu_first) == gold["cu"][1]
+    # ... and the sequence carried on: loop filters of picture 1, then pictures 2 and 3 from the device's own previous pictures (pass -> CU records for the filters ->
+    # deblocking + SAO decision + SAO -> reference of the next picture), everything resident
+    pass_s, filt_s, chain_ok, rec_ok = [s], [], [bool(cu_ok)], []
+    for k in range(1, n_b + 1):
+        prm = inter.veryfast_params(qps[k], k)
+        if k > 1:
+            ip.advance()
+            ip.use_source_set(k - 1)
+            t = time.perf_counter()
+            ip.run(prm)
+            pass_s.append(time.perf_counter() - t)
+            chain_ok.append(inter.cu_digest(ip.download(0)[1]) == gold["cu"][k] and np.array_equal(ip.download(0)[1], ip.download(sequences - 1)[1]))
+        t = time.perf_counter()
+        ip.loop_filters(prm)
+        ip.sync()
+        filt_s.append(time.perf_counter() - t)
+        rec_ok.append(hashlib.sha256(ip.download(0)[0].tobytes()).hexdigest()[:24] == gold["rec"][k] and np.array_equal(ip.download(0)[0], ip.download(sequences - 1)[0]))
+    chain_total = sum(pass_s) + sum(filt_s)
+    chain = {"stages": f"{n_b} B pictures of {sequences} sequences, each: CTU pass -> CU records for the filters -> deblocking + SAO decision + SAO -> the next picture's reference; all resident",
+             "value": n_b * sequences * ip.ctus / chain_total, "unit": "CTUs/s", "fps": n_b * sequences / chain_total, "picture_qps": qps,
+             "pass_ms": [round(x * 1e3, 1) for x in pass_s], "loop_filters_ms": [round(x * 1e3, 1) for x in filt_s],
+             "verified": bool(all(chain_ok) and all(rec_ok)),
+             "verify": {"cu_decisions_equal_reference_encoder_per_picture": [bool(v) for v in chain_ok], "final_pictures_equal_reference_encoder": [bool(v) for v in rec_ok]}}
+    ip.close()
     # the reference encoder on the same clip and settings, on this box's host cores: (a) one thread, (b) its default threading, (c) as many independent one-thread encoders
     # as the box grants CPUs.  Whole encoder (I picture, entropy coding, loop filters included): a reported baseline, bounded to a few seconds each
     cpu = None
@@ -574,7 +607,8 @@ def inter_leg(args, lib, model_for, HipBatch, pictures, sequences=192):
             "verified": bool(i_ok and cu_ok and np.array_equal(cu_first, cu_last)),
             "verify": {"i_picture_reconstruction_equals_reference_encoder": bool(i_ok), "b_picture_cu_decisions_equal_reference_encoder": bool(cu_ok),
                        "copies_consistent": bool(np.array_equal(cu_first, cu_last))},
-            "note": "first version of the pass (one wavefront per CTU, the reference's control flow in every lane): correctness first, see DESIGN.md 3.8"}
+            "chain": chain,
+            "note": "one wavefront per CTU, the reference's control flow in every lane (DESIGN.md 3.8); `chain` carries the sequence on through the loop filters and the next pictures"}
 
 
 def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedResults):

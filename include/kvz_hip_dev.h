@@ -73,6 +73,16 @@ typedef struct kvz_hip_cu_dbk {
 void kvz_hip_dev_deblock_frames_inter(uint8_t *frames, int width, int height, int n_frames, const kvz_hip_cu_dbk *info, int qp, int beta_offset_div2,
                                       int tc_offset_div2, int slice_is_b);
 
+/* Both loop filters of n pictures with inter prediction, in place -- what encoder_state_worker_encode_lcu_search runs after the search of every LCU (encoderstate.c:659-720:
+ * kvz_filter_deblock_lcu, kvz_sao_search_lcu) and what kvz_sao_reconstruct applies afterwards: `rec` goes in as the inter CTU pass returned it and comes out as the picture the next
+ * one predicts from.  src: the source pictures (the SAO decision measures against them); info: kvz_hip_dev_cu_dbk_from_info of the pass's CU records; qp: the picture QP (lambda and
+ * the SAO contexts' initial states follow from it and slice_is_b); deblock / sao: cfg.deblock_enable, cfg.sao_type != 0 (`full`); no_wpp: one coder per picture.  The decision is
+ * kvazaar's LCU by LCU: statistics on the partly deblocked picture exactly as the encoder sees it at that point, merge candidates, the SAO syntax priced on the evolving contexts of
+ * the picture's substreams.  luma / chroma / merge (HOST pointers or NULL): the decisions, n_pictures x LCUs in raster order, as kvz_hip_batch_sao_params returns them.
+ * Returns -1 on a bad argument. */
+int  kvz_hip_dev_loop_filters_inter(const uint8_t *src, uint8_t *rec, int width, int height, int n_pictures, const kvz_hip_cu_dbk *info, int qp, int slice_is_b, int deblock,
+                                    int beta_offset_div2, int tc_offset_div2, int sao, int no_wpp, kvz_hip_sao_params *luma, kvz_hip_sao_params *chroma, uint8_t *merge);
+
 /* Integer-pel motion cost surface (the candidate scoring of the inter search, search_inter.c:1000-1005 -> kvz_image_calc_sad,
  * image.c:407): for block b = the bw x bw block of `cur` at (blk_xy[2b], blk_xy[2b+1]) and every displacement (dx, dy) in
  * [-range, range]^2,   out[b * side^2 + (dy + range) * side + dx + range] = kvz_image_calc_sad(cur, ref, x, y, x + dx, y + dy, bw, bw)

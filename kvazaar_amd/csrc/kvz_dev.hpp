@@ -1123,6 +1123,83 @@ void kvz_hip_dev_deblock_frames_inter(uint8_t *frames, int width, int height, in
   kvz::deblock_frames_on(be().stream, frames, width, height, n_frames, nullptr, qp, beta_offset_div2, tc_offset_div2, 3, info, slice_is_b);
 }
 
+// The loop filters between two pictures of a device-resident chain with inter prediction: kvz_hip_batch_loop_filters' pipeline (three pictures R / V / D, the
+// statistics kernel, the decision chain, the SAO kernel) with the deblocking edges and strengths taken from kvz_hip_cu_dbk records.
+namespace kvz {
+struct LoopScratch {
+  u8 *ver = nullptr, *dbk = nullptr; size_t pic_bytes = 0;
+  SaoStats *stats = nullptr; SaoCand *cand = nullptr; SaoRec *recs = nullptr; u8 *merge = nullptr; size_t lcus = 0;
+  float *fbits = nullptr;
+};
+inline LoopScratch &loop_scratch() { static LoopScratch s; return s; }
+}  // namespace kvz
+int kvz_hip_dev_loop_filters_inter(const uint8_t *src, uint8_t *rec, int width, int height, int n_pictures, const kvz_hip_cu_dbk *info, int qp, int slice_is_b, int deblock,
+                                   int beta_offset_div2, int tc_offset_div2, int sao, int no_wpp, kvz_hip_sao_params *luma, kvz_hip_sao_params *chroma, uint8_t *merge)
+{
+  if (n_pictures <= 0) return 0;
+  if (!src || !rec || !info || width <= 0 || height <= 0 || (width & 7) || (height & 7) || qp < 0 || qp > 51) { fprintf(stderr, "kvz_hip_dev_loop_filters_inter: bad argument\n"); return -1; }
+  hipStream_t st = be().stream;
+  if (!sao) {
+    if (deblock) kvz::deblock_frames_on(st, rec, width, height, n_pictures, nullptr, qp, beta_offset_div2, tc_offset_div2, 3, info, slice_is_b);
+    return 0;
+  }
+  const int wc = (width + 63) >> 6, hc = (height + 63) >> 6;
+  const long frame_px = (long)width * height * 3 / 2;
+  const size_t pic_bytes = (size_t)frame_px * n_pictures, lcus = (size_t)wc * hc * n_pictures;
+  kvz::LoopScratch &sc = kvz::loop_scratch();
+  if (pic_bytes > sc.pic_bytes) {
+    if (sc.ver) { KVZ_HIP_CHECK(hipFree(sc.ver)); KVZ_HIP_CHECK(hipFree(sc.dbk)); }
+    KVZ_HIP_CHECK(hipMalloc((void **)&sc.ver, pic_bytes));
+    KVZ_HIP_CHECK(hipMalloc((void **)&sc.dbk, pic_bytes));
+    sc.pic_bytes = pic_bytes;
+  }
+  if (lcus > sc.lcus) {
+    if (sc.stats) { KVZ_HIP_CHECK(hipFree(sc.stats)); KVZ_HIP_CHECK(hipFree(sc.cand)); KVZ_HIP_CHECK(hipFree(sc.recs)); KVZ_HIP_CHECK(hipFree(sc.merge)); }
+    KVZ_HIP_CHECK(hipMalloc((void **)&sc.stats, lcus * 3 * sizeof(kvz::SaoStats)));
+    KVZ_HIP_CHECK(hipMalloc((void **)&sc.cand, lcus * 3 * sizeof(kvz::SaoCand)));
+    KVZ_HIP_CHECK(hipMalloc((void **)&sc.recs, lcus * 3 * sizeof(kvz::SaoRec)));
+    KVZ_HIP_CHECK(hipMalloc((void **)&sc.merge, lcus));
+    sc.lcus = lcus;
+  }
+  if (!sc.fbits) {
+    float fbits[128];
+    for (int i = 0; i < 128; i++) fbits[i] = (float)kvz::kEntropyBits[i] / 32768.0f;
+    KVZ_HIP_CHECK(hipMalloc((void **)&sc.fbits, sizeof fbits));
+    KVZ_HIP_CHECK(hipMemcpy(sc.fbits, fbits, sizeof fbits, hipMemcpyHostToDevice));
+  }
+  // R = rec (kept until the SAO kernel has read D), V = after the vertical edges, D = after all edges (sao.c:632-735 reads all three around an LCU's borders)
+  KVZ_HIP_CHECK(hipMemcpyAsync(sc.ver, rec, pic_bytes, hipMemcpyDeviceToDevice, st));
+  if (deblock) kvz::deblock_frames_on(st, sc.ver, width, height, n_pictures, nullptr, qp, beta_offset_div2, tc_offset_div2, 1, info, slice_is_b);
+  KVZ_HIP_CHECK(hipMemcpyAsync(sc.dbk, sc.ver, pic_bytes, hipMemcpyDeviceToDevice, st));
+  if (deblock) kvz::deblock_frames_on(st, sc.dbk, width, height, n_pictures, nullptr, qp, beta_offset_div2, tc_offset_div2, 2, info, slice_is_b);
+  const kvz::SaoGeom g{ width, height, wc, hc, frame_px };
+  const double lambda = 0.57 * pow(2.0, (qp - 12) / 3.0);  // rate_control.c:678-691 at the picture's QP
+  // context.c:38-39 INIT_SAO_MERGE_FLAG / INIT_SAO_TYPE_IDX of the slice type (B: 153 / 160, I: 153 / 200)
+  const int cx_merge = kvz::ctx_state(qp, 153), cx_type = kvz::ctx_state(qp, slice_is_b ? 160 : 200);
+  hipLaunchKernelGGL(kvz::dev_sao_stats_kernel, dim3((unsigned)(lcus * 3)), dim3(256), 0, st, src, rec, sc.ver, sc.dbk, g, sc.stats, sc.cand);
+  hipLaunchKernelGGL(kvz::dev_sao_chain_kernel, dim3((unsigned)((n_pictures + 63) / 64)), dim3(64), 0, st, (const kvz::SaoStats *)sc.stats, (const kvz::SaoCand *)sc.cand, g, n_pictures, sc.fbits,
+                     kvz::device_tables(), lambda, cx_merge, cx_type, no_wpp, sc.recs, sc.merge);
+  kvz::launch_sao(st, sc.dbk, rec, width, height, n_pictures, sc.recs, nullptr, nullptr);
+  KVZ_HIP_CHECK(hipGetLastError());
+  if (luma || chroma || merge) {  // host copies of the decisions (what the encoder writes as SAO syntax)
+    std::vector<kvz::SaoRec> recs(lcus * 3);
+    KVZ_HIP_CHECK(hipMemcpyAsync(recs.data(), sc.recs, lcus * 3 * sizeof(kvz::SaoRec), hipMemcpyDeviceToHost, st));
+    if (merge) KVZ_HIP_CHECK(hipMemcpyAsync(merge, sc.merge, lcus, hipMemcpyDeviceToHost, st));
+    KVZ_HIP_CHECK(hipStreamSynchronize(st));
+    for (size_t i = 0; i < lcus; i++) {
+      auto unpack = [&](kvz_hip_sao_params *o, int plane, int slot) {
+        const kvz::SaoRec r = recs[i * 3 + plane];
+        if (slot == 0) { memset(o, 0, sizeof *o); o->bitdepth = 8; o->type = (int)(r & 0xff); o->eo_class = (int)((r >> 8) & 0xff); }
+        o->band_position[slot] = (int)((r >> 16) & 0xff);
+        for (int k = 0; k < 5; k++) o->offsets[5 * slot + k] = (int)(int8_t)(r >> (24 + 8 * k));
+      };
+      if (luma) unpack(&luma[i], 0, 0);
+      if (chroma) { unpack(&chroma[i], 1, 0); unpack(&chroma[i], 2, 1); }
+    }
+  }
+  return 0;
+}
+
 int kvz_hip_dev_sad_surface(const uint8_t *cur, const uint8_t *ref, int width, int height, int bw, int range, const int16_t *blk_xy, int count,
                              uint32_t *out)
 {

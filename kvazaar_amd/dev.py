@@ -29,6 +29,10 @@ class Dev:
         self.lib.kvz_hip_dev_upload(p, a.ctypes.data, a.nbytes)
         return p
 
+    def copy_in(self, p, a):
+        a = np.ascontiguousarray(a)
+        self.lib.kvz_hip_dev_upload(p, a.ctypes.data, a.nbytes)
+
     def empty(self, nbytes):
         return self.lib.kvz_hip_dev_alloc(nbytes)
 

@@ -19,6 +19,35 @@ def veryfast_params(qp, poc, mv_constraint=True):
     return InterParams(qp=qp, poc=poc, mv_constraint=int(mv_constraint), sao=1, deblock=1, fme_level=2, pu_depth_inter_max=3, no_wpp=0)
 
 
+def lowdelay_picture_qp(qp, frame, gop_len=4, gop_depth=3, intra_period=0, preset_given=True):
+    """the picture QP kvazaar runs picture `frame` of `--gop lp-g<len>d<depth>t1 -q <qp>` at, without rate control: intra_qp_offset for the I picture
+    (encoder.c:180-183), the GOP layer for the others (cfg.c:1455-1463) plus -- when a preset was given, whose "gop 8" leaves the random-access GOP's QP model in
+    the entries kvz_config_process_lp_gop does not rewrite (cfg.c:485-760, gop.h:94-200) -- CLIP(0, 3, qp * scale + offset) of rate_control.c:1040-1056"""
+    ra8_offset = (0.0, -6.25, -6.25, -7.0, -7.0, -6.25, -7.0, -7.0)
+    ra8_scale = (0.0, 0.25, 0.25, 0.245, 0.245, 0.25, 0.245, 0.245)
+    pos = frame % intra_period if intra_period else frame
+    if pos == 0:
+        l2 = 0
+        while (1 << l2) < gop_len:
+            l2 += 1
+        q = qp + (max(-l2 + 1, -3) if gop_len > 1 else 0)
+    else:
+        k = (pos + gop_len - 1) % gop_len
+        g = k + 1
+        modulo = [0] * 8
+        for d in range(gop_depth):
+            modulo[gop_depth - 1 - d] = 1 << d
+        modulo[0] = gop_len
+        layer = 1
+        while layer < gop_depth and g % modulo[layer - 1]:
+            layer += 1
+        dq = float(qp + layer)
+        if preset_given and k < 8:
+            dq += min(3.0, max(0.0, dq * ra8_scale[k] + ra8_offset[k]))
+        q = int(dq + 0.5)
+    return min(51, max(0, q))
+
+
 def intra_picture_cu_info(width, height):
     """the CU info of an I picture as far as the next picture's search reads it (no motion: no temporal candidates, no co-located starting point)"""
     cu = np.zeros((height // 4, width // 4), CU_DTYPE)
@@ -52,6 +81,11 @@ class InterPictures:
         self.fs, self.cells = width * height * 3 // 2, (width // 4) * (height // 4)
         lib.kvz_hip_dev_inter_ctu_pass.restype = C.c_int
         lib.kvz_hip_dev_inter_ctu_pass.argtypes = [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_void_p]
+        lib.kvz_hip_dev_cu_dbk_from_info.restype = None
+        lib.kvz_hip_dev_cu_dbk_from_info.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.kvz_hip_dev_loop_filters_inter.restype = C.c_int
+        lib.kvz_hip_dev_loop_filters_inter.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p] * 3
+        self.d_dbk = None
         e = self.dev.empty
         self.d_src, self.d_ref, self.d_rec = e(n * self.fs), e(n * self.fs), e(n * self.fs)
         self.d_ref_cu, self.d_cu = e(n * self.cells * CU_DTYPE.itemsize), e(n * self.cells * CU_DTYPE.itemsize)
@@ -69,6 +103,39 @@ class InterPictures:
         if rc != 0:
             raise RuntimeError(f"kvz_hip_dev_inter_ctu_pass returned {rc}")
 
+    def upload_source(self, i, src):
+        a = np.ascontiguousarray(src)
+        assert a.nbytes == self.fs
+        self.lib.kvz_hip_dev_upload(self.d_src + i * self.fs, a.ctypes.data, self.fs)
+
+    def new_source_set(self):
+        """another resident set of n source pictures (the next picture of every sequence); returns the handle use_source_set() takes"""
+        self._source_sets = getattr(self, "_source_sets", [self.d_src])
+        self._source_sets.append(self.dev.empty(self.n * self.fs))
+        return len(self._source_sets) - 1
+
+    def use_source_set(self, k):
+        self._source_sets = getattr(self, "_source_sets", [self.d_src])
+        self.d_src = self._source_sets[k]
+
+    def loop_filters(self, params, slice_is_b=True):
+        """deblocking and SAO of the pictures the pass just produced, in place (kvz_hip_dev_loop_filters_inter): d_rec becomes what the next picture predicts from"""
+        if self.d_dbk is None:
+            self.d_dbk = self.dev.empty(self.n * self.cells * 20)  # kvz_hip_cu_dbk
+        self.lib.kvz_hip_dev_cu_dbk_from_info(self.d_cu, self.n * self.cells, self.d_dbk)
+        rc = self.lib.kvz_hip_dev_loop_filters_inter(self.d_src, self.d_rec, self.w, self.h, self.n, self.d_dbk, params.qp, int(slice_is_b), params.deblock, 0, 0, params.sao,
+                                                     params.no_wpp, None, None, None)
+        if rc != 0:
+            raise RuntimeError(f"kvz_hip_dev_loop_filters_inter returned {rc}")
+
+    def advance(self):
+        """the pictures just encoded (after their loop filters) and their CU records become the references of the next picture"""
+        self.d_ref, self.d_rec = self.d_rec, self.d_ref
+        self.d_ref_cu, self.d_cu = self.d_cu, self.d_ref_cu
+
+    def sync(self):
+        self.lib.kvz_hip_dev_sync()
+
     def download(self, i):
         rec, cu = np.empty(self.fs, np.uint8), np.empty((self.h // 4, self.w // 4), CU_DTYPE)
         self.lib.kvz_hip_dev_download(rec.ctypes.data, self.d_rec + i * self.fs, self.fs)
@@ -76,4 +143,6 @@ class InterPictures:
         return rec, cu
 
     def close(self):
-        self.dev.free(self.d_src, self.d_ref, self.d_rec, self.d_ref_cu, self.d_cu)
+        self.dev.free(self.d_ref, self.d_rec, self.d_ref_cu, self.d_cu, *getattr(self, "_source_sets", [self.d_src]))
+        if self.d_dbk is not None:
+            self.dev.free(self.d_dbk)

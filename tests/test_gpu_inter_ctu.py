@@ -116,39 +116,53 @@ def test_device_pass_on_baseline_config_4(oracle):
         assert np.array_equal(rec[0], rs[k]), k
 
 
+CHAIN_CASES = ["deblock-only", "ultrafast", "pan", "vertical-pan-owf", "static-qp17", "no-loop-filters", "survey-416x240", "survey-1080p", "baseline-c4-2160p"]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["deblock-only", "ultrafast"])
+@pytest.mark.parametrize("name", CHAIN_CASES)
 def test_device_chains_its_own_pictures(oracle, name):
-    """the I picture from the oracle, then every B picture on the device from the device's own previous picture: CTU pass -> deblocking with motion-based strengths
-    (kvz_hip_dev_deblock_frames_inter on records made by kvz_hip_dev_cu_dbk_from_info) -> reference of the next picture.  Configurations without SAO."""
+    """A whole sequence on the device from the I picture's search result on: its loop filters, then every B picture from the device's own previous picture -- CTU pass ->
+    kvz_hip_dev_cu_dbk_from_info -> kvz_hip_dev_loop_filters_inter (deblocking with motion-based strengths, the SAO decision on the partly deblocked picture, SAO) -> reference
+    of the next picture.  Every picture before and after its loop filters, every CU decision and every SAO decision must equal the oracle's (= the reference encoder's), up to
+    BASELINE config 4's own 3840x2160 sequence."""
     import kvazaar_amd
     from kvazaar_amd.dev import Dev
     lib = kvazaar_amd.load_library()
     dev = Dev(lib)
     case = [c for c in ic.CASES if c[0] == name][0]
     _, w, h, n, qp, preset, dbk, sao, owf, src = case
-    assert dbk and not sao
     frames = ic.case_frames(case)
-    rs, rf, cu, qps = ic.oracle_encode(oracle, w, h, frames, qp, preset=preset, deblock=True, sao=False, mv_constraint=owf > 0)
+    rs, rf, cu, qps = ic.oracle_encode(oracle, w, h, frames, qp, preset=preset, deblock=bool(dbk), sao=bool(sao), mv_constraint=owf > 0)
     lib.kvz_hip_dev_inter_ctu_pass.restype = C.c_int
     lib.kvz_hip_dev_inter_ctu_pass.argtypes = [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_void_p]
     lib.kvz_hip_dev_cu_dbk_from_info.restype = None
     lib.kvz_hip_dev_cu_dbk_from_info.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-    lib.kvz_hip_dev_deblock_frames_inter.restype = None
-    lib.kvz_hip_dev_deblock_frames_inter.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 4
+    lib.kvz_hip_dev_loop_filters_inter.restype = C.c_int
+    lib.kvz_hip_dev_loop_filters_inter.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p] * 3
     fs, cells = w * h * 3 // 2, (w // 4) * (h // 4)
-    d_ref, d_rcu = dev.put(rf[0]), dev.put(cu[0].reshape(-1))
     d_rec, d_cu, d_dbk = dev.empty(fs), dev.empty(cells * ic.CU_DTYPE.itemsize), dev.empty(cells * 20)
+    d_ref, d_rcu = dev.empty(fs), dev.empty(cells * ic.CU_DTYPE.itemsize)
+
+    def loop_filters(k, d_src):
+        lib.kvz_hip_dev_cu_dbk_from_info(d_cu, cells, d_dbk)
+        assert lib.kvz_hip_dev_loop_filters_inter(d_src, d_rec, w, h, 1, d_dbk, int(qps[k]), int(k > 0), int(dbk), 0, 0, int(sao), 0, None, None, None) == 0
+        assert np.array_equal(dev.get(d_rec, (fs,), np.uint8), rf[k]), k
+
+    # the I picture: the oracle's search result (the all-intra pass has its own tests), filtered here
+    d_src = dev.put(frames[0])
+    dev.copy_in(d_rec, rs[0]); dev.copy_in(d_cu, cu[0].reshape(-1))
+    loop_filters(0, d_src)
+    dev.free(d_src)
     for k in range(1, n):
+        d_ref, d_rec = d_rec, d_ref      # the filtered picture is the next reference
+        d_rcu, d_cu = d_cu, d_rcu
         d_src = dev.put(frames[k])
         prm = params_of(case, qps[k], k)
         assert lib.kvz_hip_dev_inter_ctu_pass(d_src, d_ref, d_rcu, d_rec, d_cu, None, w, h, 1, C.addressof(prm)) == 0
-        lib.kvz_hip_dev_cu_dbk_from_info(d_cu, cells, d_dbk)
-        lib.kvz_hip_dev_deblock_frames_inter(d_rec, w, h, 1, d_dbk, int(qps[k]), 0, 0, 1)
-        assert np.array_equal(dev.get(d_rec, (fs,), np.uint8), rf[k]), k
+        assert np.array_equal(dev.get(d_rec, (fs,), np.uint8), rs[k]), k
         assert ic.first_difference(dev.get(d_cu, (1, h // 4, w // 4), ic.CU_DTYPE), cu[k][None]) is None, k
-        d_ref, d_rec = d_rec, d_ref      # the filtered picture is the next reference
-        d_rcu, d_cu = d_cu, d_rcu
+        loop_filters(k, d_src)
         dev.free(d_src)
     dev.free(d_ref, d_rcu, d_rec, d_cu, d_dbk)
 
