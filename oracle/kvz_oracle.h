@@ -195,6 +195,13 @@ void kvz_oracle_lowdelay_encode(const kvz_oracle_lowdelay_cfg *cfg, const float 
 void kvz_oracle_inter_picture(int qp, int poc, const kvz_oracle_lowdelay_cfg *cfg, const float entropy_fbits[128], uint64_t coeff_weights, int width, int height,
                               const uint8_t *src, const uint8_t *ref, const kvz_oracle_cu *ref_cu, uint8_t *rec, kvz_oracle_cu *cu, int16_t *coeff);
 
+/* ---- the entropy coder in its real mode (kvz_oracle_entropy.inc): the slice data kvazaar writes for an I picture -- one substream per CTU row with WPP, one for the
+ * picture without -- from what the CTU pass returns: CU depth / luma mode per 8x8, NxN flags per 8x8 and PU modes per 4x4 (or NULL), KVZ_HIP_CTU_COEFFS levels per CTU,
+ * and the SAO decisions (or NULL: SAO off; merge 0 none / 1 left / 2 up).  m: qp, ctx_init, no_wpp.  Returns the total size; substream_bytes: one entry per substream. ---- */
+size_t kvz_oracle_entropy_intra_picture(const kvz_hip_intra_cost_model *m, int width, int height, const uint8_t *cu_depth, const uint8_t *cu_mode, const uint8_t *part,
+                                        const uint8_t *mode4, const int16_t *coeff, const kvz_hip_sao_params *sao_luma, const kvz_hip_sao_params *sao_chroma,
+                                        const uint8_t *sao_merge, uint8_t *out, size_t capacity, uint32_t *substream_bytes);
+
 /* ---- deblocking of an all-intra, constant-QP picture in place (kvz_oracle_deblock.c; filter.c:783 kvz_filter_deblock_lcu over
  * every LCU).  Planes are tight (stride = width), cu_depth is the CU depth per 8x8 unit as the CTU pass returns it. ---- */
 void kvz_oracle_deblock_frame(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,

@@ -1009,3 +1009,4 @@ void kvz_oracle_intra_cost_model(int qp, const float entropy_fbits[128], uint64_
 }
 
 #include "kvz_oracle_inter.inc"
+#include "kvz_oracle_entropy.inc"

@@ -15,6 +15,7 @@ Fixtures (small, committed; the GPU box and any machine without the reference tr
                         built from /root/reference, all-intra, deblocking on / off) writes with --debug for seeded clips -- what the
                         batched CTU pass (+ deblocking) must reproduce picture for picture; ".../cu" entries: digests of the CU depth
                         and intra mode maps of the encoder's cu_array behind it (recorded with the oracle/ref_cudump.c interposer)
+  entropy.json          (--entropy) the slice data of the reference encoder's bitstreams for tests/entropy_common.py CASES: digest and substream sizes per picture
 (the bitstream md5s of the reference encoder are asserted by tests/test_e2e_dropin.py)
 tests/test_oracle_golden.py holds the known answers of the reference's own unit tests; this file adds outputs of the
 compiled reference for the functions those tests do not pin."""
@@ -287,9 +288,34 @@ def update_inter():
     json.dump(out, open(os.path.join(HERE, "inter_recon.json"), "w"), indent=0, sort_keys=True)
 
 
+def update_entropy():
+    """tests/golden/entropy.json: the slice data of the reference encoder's bitstreams for tests/entropy_common.py CASES.  Per picture: sha256 of the slice NAL's payload
+    behind the slice header (the bytes are taken from the REFERENCE bitstream; where the header ends follows from the substream sizes, which the header's own entry
+    points must confirm -- asserted here), the substream sizes and the header bytes in front"""
+    import tempfile
+    import entropy_common as ec
+    oracle = flatapi.load_oracle()
+    out = {}
+    for case in ec.CASES:
+        with tempfile.TemporaryDirectory() as d:
+            payloads = ec.reference_slice_payloads(os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "kvazaar_ref"), case, d)
+        pictures = []
+        for payload, (data, sizes) in zip(payloads, ec.oracle_slice_data(oracle, case)):
+            total = sum(sizes)
+            ref_data, header = payload[len(payload) - total:], payload[:len(payload) - total]
+            assert ec.header_ends_with_entry_points(header, sizes, "--no-wpp" not in case[8]), (case[0], "the slice header's entry points are not these substream sizes")
+            assert ref_data == data, (case[0], "oracle/kvz_oracle_entropy.inc does not reproduce the reference's slice data")
+            pictures.append({"sha": hashlib.sha256(ref_data).hexdigest()[:24], "sizes": sizes, "header": header.hex()})
+        out[case[0]] = pictures
+        print(case[0], [p["sizes"] for p in pictures], flush=True)
+    json.dump(out, open(os.path.join(HERE, "entropy.json"), "w"), indent=0, sort_keys=True)
+
+
 def main():
     if "--inter" in sys.argv:
         return update_inter()
+    if "--entropy" in sys.argv:
+        return update_entropy()
     ref = flatapi.load_ref(0)  # generic strategies
     oracle = flatapi.load_oracle()
 

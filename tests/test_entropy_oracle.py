@@ -1,0 +1,50 @@
+"""oracle/kvz_oracle_entropy.inc -- kvazaar's entropy coder in its REAL mode (cabac.c, encode_coding_tree.c, encode_coding_tree-generic.c, the per-LCU bitstream worker
+of encoderstate.c) restated on the outputs of the CTU pass -- pinned against the reference encoder: the slice data of every picture of tests/entropy_common.py CASES
+(ultrafast at several QPs, --no-wpp, partial CTUs, a one-CTU-wide picture, noise / flat pictures, SAO syntax, `medium` with RDOQ levels and NxN CUs) must be the bytes
+kvazaar_ref wrote -- against tests/golden/entropy.json (made from the reference's bitstreams by tests/golden/make_golden.py --entropy) everywhere, and against live
+runs of the compiled reference where oracle/_ref exists."""
+import hashlib
+import json
+import os
+
+import pytest
+
+import entropy_common as ec
+import flatapi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = json.load(open(os.path.join(HERE, "golden", "entropy.json")))
+REF = os.path.join(flatapi.ROOT, "oracle", "_ref", "kvazaar_ref")
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return flatapi.load_oracle()
+
+
+@pytest.mark.parametrize("case", ec.CASES, ids=[c[0] for c in ec.CASES])
+def test_oracle_slice_data_equals_the_reference_encoders(oracle, case):
+    got = ec.oracle_slice_data(oracle, case)
+    want = GOLDEN[case[0]]
+    assert len(got) == len(want)
+    for (data, sizes), g in zip(got, want):
+        assert sizes == g["sizes"]
+        assert hashlib.sha256(data).hexdigest()[:24] == g["sha"]
+        assert ec.header_ends_with_entry_points(bytes.fromhex(g["header"]), sizes, "--no-wpp" not in case[8])
+
+
+@pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/kvazaar_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("case", [c for c in ec.CASES if c[0] in ("ultrafast-qp22", "veryfast-sao-noise", "medium-nxn-everywhere")], ids=lambda c: c[0])
+def test_oracle_slice_data_live_against_the_compiled_reference(oracle, case, tmp_path):
+    payloads = ec.reference_slice_payloads(REF, case, str(tmp_path))
+    for payload, (data, sizes) in zip(payloads, ec.oracle_slice_data(oracle, case)):
+        assert payload.endswith(data)
+        assert ec.header_ends_with_entry_points(payload[:len(payload) - len(data)], sizes, "--no-wpp" not in case[8])
+
+
+def test_byte_stream_splitter_removes_emulation_prevention():
+    stream = bytes([0, 0, 0, 1, 0x40, 1, 0xAA, 0, 0, 3, 1, 0xBB, 0, 0, 1, 0x26, 1, 0x11, 0, 0, 3, 0, 0, 3, 2])
+    units = ec.nal_units(stream)
+    assert units == [(32, bytes([0xAA, 0, 0, 1, 0xBB])), (19, bytes([0x11, 0, 0, 0, 0, 2]))]
+    assert ec.slice_payloads(stream) == [bytes([0x11, 0, 0, 0, 0, 2])]
+    assert ec.ue_bits(0) == "1" and ec.ue_bits(3) == "00100"
