@@ -117,6 +117,15 @@ int  kvz_hip_batch_md5(kvz_hip_batch *b, uint8_t *host_out);
 void kvz_hip_intra_cost_model_init(int qp, uint64_t coeff_weights, kvz_hip_intra_cost_model *model);
 /* kvz_fast_coeff_get_weights for kvazaar's built-in table (fast_coeff_cost.h:48-101 packed by fast_coeff_cost.c:39-52); 0 for
  * QP >= MAX_FAST_COEFF_COST_QP (50), where kvazaar never uses the fast estimate (rdo.c:311-340). */
+/* The entropy coder in its REAL mode -- what kvazaar's encoder_state_worker_encode_lcu_bitstream writes (encoderstate.c:676-745: SAO syntax, kvz_encode_coding_tree
+ * encode_coding_tree.c:745, kvz_encode_coeff_nxn strategies/generic/encode_coding_tree-generic.c:40, the arithmetic coder cabac.c:85-270, the per-substream flush and
+ * byte alignment) for every picture of the batch, on the device, from the results of the last kvz_hip_intra_frames (CU depths / modes / partitions, levels) and -- with
+ * sao != 0 -- of the last kvz_hip_batch_loop_filters(..., sao = 1): I slices of the configurations the pass covers.  model: the pass's (ctx_init = the slice's initial
+ * context states, no_wpp, search_nxn).  out (HOST, `capacity` bytes) receives the slice data: picture after picture, and inside a picture one substream per CTU row
+ * (WPP; the rows' contexts start from the row above after its second CTU, encoderstate.c:763-771) or one for the whole picture (no_wpp); substream_bytes (HOST) their sizes,
+ * n_frames x (CTU rows | 1) entries -- the entry points of the slice header (encoder_state-bitstream.c:935-954).  The bytes are what kvazaar puts behind the slice header,
+ * before emulation prevention.  Only these bytes cross PCIe instead of the levels (12 KB per CTU).  Returns the total size, -1 on failure. */
+long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, uint8_t *out, size_t capacity, uint32_t *substream_bytes);
 uint64_t kvz_hip_default_coeff_weights(int qp);
 
 #ifdef __cplusplus

@@ -13,6 +13,7 @@
 #include "kvz_mfma.hpp"
 #include "kvz_ops.hpp"
 #include "kvz_sao.hpp"
+#include "kvz_entropy.hpp"
 
 namespace kvz {
 
@@ -1438,6 +1439,88 @@ int kvz_hip_batch_sao_params(kvz_hip_batch *b, int frame, kvz_hip_sao_params *lu
     if (chroma) { unpack(&chroma[i], 1, 0); unpack(&chroma[i], 2, 1); }
   }
   return kvz::batch_check(b);
+}
+
+// The entropy coder in its real mode (kvz_entropy.hpp): the slice data of every picture of the batch, substream by substream, from the device-resident results of the
+// CTU pass (and of the loop filters' SAO decision).  Pictures are coded in chunks so that the bin records of a chunk fit a scratch budget (KVZ_HIP_ENTROPY_SCRATCH_MB,
+// default 6144); a CTU that produces more records than the chunk's capacity per CTU makes the chunk run again with the capacity it needs.
+long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, uint8_t *out, size_t capacity, uint32_t *substream_bytes)
+{
+  kvz::batch_enter(b);
+  const kvz::CtuFrames &F = b->F;
+  const int n = b->n_frames, ctus = F.wc * F.hc, rows = model->no_wpp ? 1 : F.hc;
+  if (sao && !b->d_sao_recs) { fprintf(stderr, "kvz_hip_batch_entropy_code: kvz_hip_batch_loop_filters(..., sao = 1) has not run on this batch\n"); return -1; }
+  if (model->search_nxn && !b->d_part) { fprintf(stderr, "kvz_hip_batch_entropy_code: the batch has no NxN partition maps\n"); return -1; }
+  KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+  if (kvz::batch_check(b) != 0) return -1;
+  size_t budget = 6144;
+  if (const char *e = getenv("KVZ_HIP_ENTROPY_SCRATCH_MB")) { const long v = atol(e); if (v > 0) budget = (size_t)v; }
+  budget <<= 20;
+  uint32_t cap = 12288;  // records per CTU to start with (QP 22 pictures need 4-6 k; noise at low QPs more)
+  if (const char *e = getenv("KVZ_HIP_ENTROPY_CAP")) { const long v = atol(e); if (v > 0) cap = (uint32_t)v; }
+  const long cells8 = (long)(F.H >> 3) * (F.W >> 3), cells4 = (long)(F.H >> 2) * (F.W >> 2);
+  size_t total = 0;
+  int f0 = 0;
+  std::vector<uint32_t> counts, sizes;
+  std::vector<unsigned long long> offsets;
+  while (f0 < n) {
+    int nf = (int)(budget / ((size_t)ctus * cap * sizeof(uint32_t)));
+    if (nf < 1) nf = 1;
+    if (nf > n - f0) nf = n - f0;
+    const long items = (long)nf * ctus, streams = (long)nf * rows;
+    uint32_t *d_bins = nullptr, *d_nbins = nullptr, *d_sizes = nullptr;
+    unsigned long long *d_offsets = nullptr;
+    uint8_t *d_rowctx = nullptr, *d_out = nullptr;
+    KVZ_HIP_CHECK(hipMalloc((void **)&d_bins, (size_t)items * cap * sizeof(uint32_t)));
+    KVZ_HIP_CHECK(hipMalloc((void **)&d_nbins, (size_t)items * sizeof(uint32_t)));
+    KVZ_HIP_CHECK(hipMalloc((void **)&d_sizes, (size_t)streams * sizeof(uint32_t)));
+    KVZ_HIP_CHECK(hipMalloc((void **)&d_offsets, (size_t)streams * sizeof(unsigned long long)));
+    KVZ_HIP_CHECK(hipMalloc((void **)&d_rowctx, (size_t)nf * F.hc * KVZ_ENTROPY_CTXS));
+    kvz::EntropyJob J;
+    memset(&J, 0, sizeof J);
+    J.W = F.W; J.H = F.H; J.wc = F.wc; J.hc = F.hc; J.n_frames = nf; J.no_wpp = model->no_wpp;
+    J.depth = b->d_depth + f0 * cells8; J.mode = b->d_mode + f0 * cells8;
+    J.part = model->search_nxn ? b->d_part + f0 * cells8 : nullptr; J.mode4 = model->search_nxn ? b->d_mode4 + f0 * cells4 : nullptr;
+    J.coeff = b->d_coeff + (size_t)f0 * ctus * KVZ_HIP_CTU_COEFFS;
+    J.sao = sao ? (const kvz::SaoRec *)b->d_sao_recs + (size_t)f0 * ctus * 3 : nullptr; J.sao_merge = sao ? b->d_sao_merge + (size_t)f0 * ctus : nullptr;
+    J.bins = d_bins; J.nbins = d_nbins; J.cap = cap; J.row_ctx = d_rowctx;
+    memcpy(J.ctx_init, model->ctx_init, sizeof model->ctx_init < sizeof J.ctx_init ? sizeof model->ctx_init : sizeof J.ctx_init);
+    hipLaunchKernelGGL(kvz::dev_entropy_bins_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, b->stream, J, kvz::device_tables(), items);
+    counts.resize((size_t)items);
+    KVZ_HIP_CHECK(hipMemcpyAsync(counts.data(), d_nbins, (size_t)items * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+    uint32_t most = 0;
+    for (uint32_t c : counts) most = c > most ? c : most;
+    bool again = most > cap;
+    if (!again) {
+      if (!model->no_wpp) hipLaunchKernelGGL(kvz::dev_entropy_row_ctx_kernel, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, b->stream, J, kvz::device_tables());
+      hipLaunchKernelGGL(kvz::dev_entropy_code_kernel, dim3((unsigned)((streams + 63) / 64)), dim3(64), 0, b->stream, J, kvz::device_tables(), streams, d_sizes, nullptr, nullptr);
+      sizes.resize((size_t)streams);
+      KVZ_HIP_CHECK(hipMemcpyAsync(sizes.data(), d_sizes, (size_t)streams * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+      KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+      offsets.resize((size_t)streams);
+      unsigned long long chunk_bytes = 0;
+      for (long i = 0; i < streams; i++) { offsets[(size_t)i] = chunk_bytes; chunk_bytes += sizes[(size_t)i]; }
+      if (total + chunk_bytes > capacity) {
+        fprintf(stderr, "kvz_hip_batch_entropy_code: the output buffer is too small (%zu bytes needed so far)\n", (size_t)(total + chunk_bytes));
+        KVZ_HIP_CHECK(hipFree(d_bins)); KVZ_HIP_CHECK(hipFree(d_nbins)); KVZ_HIP_CHECK(hipFree(d_sizes)); KVZ_HIP_CHECK(hipFree(d_offsets)); KVZ_HIP_CHECK(hipFree(d_rowctx));
+        return -1;
+      }
+      KVZ_HIP_CHECK(hipMalloc((void **)&d_out, chunk_bytes ? chunk_bytes : 1));
+      KVZ_HIP_CHECK(hipMemcpyAsync(d_offsets, offsets.data(), (size_t)streams * sizeof(unsigned long long), hipMemcpyHostToDevice, b->stream));
+      hipLaunchKernelGGL(kvz::dev_entropy_code_kernel, dim3((unsigned)((streams + 63) / 64)), dim3(64), 0, b->stream, J, kvz::device_tables(), streams, (uint32_t *)nullptr, d_offsets, d_out);
+      KVZ_HIP_CHECK(hipGetLastError());
+      KVZ_HIP_CHECK(hipMemcpyAsync(out + total, d_out, chunk_bytes, hipMemcpyDeviceToHost, b->stream));
+      KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+      memcpy(substream_bytes + (size_t)f0 * rows, sizes.data(), (size_t)streams * sizeof(uint32_t));
+      total += chunk_bytes;
+      KVZ_HIP_CHECK(hipFree(d_out));
+      f0 += nf;
+    }
+    KVZ_HIP_CHECK(hipFree(d_bins)); KVZ_HIP_CHECK(hipFree(d_nbins)); KVZ_HIP_CHECK(hipFree(d_sizes)); KVZ_HIP_CHECK(hipFree(d_offsets)); KVZ_HIP_CHECK(hipFree(d_rowctx));
+    if (again) cap = (most + 1023u) & ~1023u;  // this chunk again, with room for its largest CTU
+  }
+  return (long)total;
 }
 
 void kvz_hip_dev_picture_md5(const uint8_t *frames, int width, int height, int n_frames, uint8_t *out)

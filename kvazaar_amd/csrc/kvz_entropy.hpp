@@ -1,0 +1,535 @@
+// kvz_entropy.hpp -- kvazaar's entropy coder in its REAL mode on the device: the slice data of I pictures from what the CTU pass left in HBM.
+//
+// Reference: encoder_state_worker_encode_lcu_bitstream (encoderstate.c:676-745: SAO syntax :467-552, kvz_encode_coding_tree, end_of_slice_segment_flag,
+// end_of_subset_one_bit, kvz_cabac_finish + byte alignment per substream), kvz_encode_coding_tree of an I slice (encode_coding_tree.c:745-900, :467-652, :193-310,
+// :117-190, :63-115), kvz_encode_coeff_nxn (strategies/generic/encode_coding_tree-generic.c:40-283, cabac.c:275-301) and the arithmetic coder (cabac.c:85-270);
+// WPP: a row's contexts start from the row above after its second CTU (encoderstate.c:763-771).  oracle/kvz_oracle_entropy.inc is the CPU restatement, byte-identical
+// to the reference encoder's slice data.
+//
+// The coder is serial per substream, but its two halves are not equally serial, so the work is cut at the bin:
+//   1. entropy_ctu_bins      one lane per CTU, all CTUs of all pictures at once: walks the CTU's syntax and writes its BINS as 32-bit records -- a context-coded bin
+//                            (context index, value), a run of bypass bins, a terminating bin.  Which context a bin uses never depends on a context's state, so this
+//                            half has no dependency between CTUs at all (neighbour CU depths / modes come from the frame-level maps).
+//   2. entropy_row_contexts  one lane per picture: the context states each CTU row starts from -- the state machine run over the first two CTUs' context-coded bins
+//                            of every row, row after row (with --no-wpp there is nothing to do).
+//   3. entropy_code_row      one lane per substream (picture x CTU row; one per picture without WPP): the arithmetic coder proper over the row's records -- range
+//                            subdivision, renormalisation, carry propagation -- run twice: once counting bytes (the substream sizes, from which the host lays the
+//                            output out compactly) and once writing them.
+// The same functions compile for the host (tests/hostsim) where every lane is a loop iteration.
+#pragma once
+#include "kvz_ops.hpp"
+#include "kvz_sao.hpp"
+#include "../../include/kvz_hip_types.h"
+
+namespace kvz {
+
+struct EntropyJob {
+  int W, H, wc, hc, n_frames, no_wpp;
+  const u8 *depth, *mode;      // [frames][(H/8)*(W/8)]
+  const u8 *part, *mode4;      // [frames][(H/8)*(W/8)], [frames][(H/4)*(W/4)] or null (no NxN CUs)
+  const i16 *coeff;            // [frames][ctu][KVZ_HIP_CTU_COEFFS]
+  const SaoRec *sao;           // [frames][ctu][3] packed decisions or null (SAO off)
+  const u8 *sao_merge;         // [frames][ctu]: 0 none, 1 left, 2 up
+  u32 *bins;                   // [frames * ctus][cap] records
+  u32 *nbins;                  // [frames * ctus] records the CTU produced (may exceed cap: then the list is truncated and the host retries with a larger cap)
+  u32 cap;
+  u8 *row_ctx;                 // [frames][hc][KVZ_ENTROPY_CTXS] context states at the start of every row
+  u8 ctx_init[152];            // the slice's initial states (kvz_hip_intra_cost_model::ctx_init)
+};
+#define KVZ_ENTROPY_CTXS 152
+#define KVZ_EB_CTX(ctx, v) ((u32)(ctx) | ((u32)(v) << 8))
+#define KVZ_EB_EP(value, n) (0x40000000u | ((u32)(n) << 16) | ((u32)(value) & 0xffffu))
+#define KVZ_EB_TRM(v) (0x80000000u | (u32)(v))
+
+struct BinSink {
+  u32 *out; u32 n, cap;
+  KVZ_DEV void put(u32 r) { if (n < cap) out[n] = r; n++; }
+  KVZ_DEV void ctx(int c, int v) { put(KVZ_EB_CTX(c, v ? 1 : 0)); }
+  KVZ_DEV void ep(u32 value, int bits)  // kvz_cabac_encode_bins_ep: any split of a run into pieces codes the same bytes (the coder's interval arithmetic is exact)
+  {
+    while (bits > 16) { bits -= 16; put(KVZ_EB_EP(value >> bits, 16)); value &= (1u << bits) - 1; }
+    if (bits > 0) put(KVZ_EB_EP(value, bits));
+  }
+  KVZ_DEV void trm(int v) { put(KVZ_EB_TRM(v)); }
+};
+
+KVZ_DEV unsigned entropy_zorder(int x, int y)  // cu.h:385-421 with width 64: Morton index of the 4x4 block times 16
+{
+  unsigned r = 0;
+  for (int b = 0; b < 4; b++) r |= (((unsigned)(x >> (2 + b)) & 1u) << (2 * b)) | (((unsigned)(y >> (2 + b)) & 1u) << (2 * b + 1));
+  return r * 16;
+}
+KVZ_DEV bool entropy_any(const i16 *c, int n)
+{
+  // levels are stored as 16-bit values, blocks are 8-byte aligned (16 levels at least)
+  const unsigned long long *q = (const unsigned long long *)c;
+  for (int i = 0; i < n / 4; i++) if (q[i]) return true;
+  return false;
+}
+KVZ_DEV int entropy_scan_order(int mode, int depth)  // encoderstate.c:1761-1775 kvz_get_scan_order, intra
+{
+  if (depth >= 3) {
+    if (mode >= 6 && mode <= 14) return 2;
+    if (mode >= 22 && mode <= 30) return 1;
+  }
+  return 0;
+}
+KVZ_DEV int entropy_sig_ctx_inc(int pattern_sig_ctx, int scan_idx, int pos_x, int pos_y, int log2_size, int type)  // context.c:366-399
+{
+  if (pos_x + pos_y == 0) return 0;
+  if (log2_size == 2) { const unsigned long long map = 0x8877886654325410ull; return (int)((map >> (4 * (4 * pos_y + pos_x))) & 15); }  // ctx_ind_map
+  const int offset = log2_size == 3 ? (scan_idx == 0 ? 9 : 15) : (type == 0 ? 21 : 12);
+  const int xs = pos_x & 3, ys = pos_y & 3;
+  int cnt;
+  if (pattern_sig_ctx == 0) cnt = xs + ys <= 2 ? (xs + ys == 0 ? 2 : 1) : 0;
+  else if (pattern_sig_ctx == 1) cnt = ys <= 1 ? (ys == 0 ? 2 : 1) : 0;
+  else if (pattern_sig_ctx == 2) cnt = xs <= 1 ? (xs == 0 ? 2 : 1) : 0;
+  else cnt = 2;
+  return ((type == 0 && ((pos_x >> 2) + (pos_y >> 2)) > 0) ? 3 : 0) + offset + cnt;
+}
+KVZ_DEV int entropy_group_idx(int v)  // encoderstate.h:397 g_group_idx
+{
+  return v < 4 ? v : (v < 6 ? 4 : (v < 8 ? 5 : (v < 12 ? 6 : (v < 16 ? 7 : (v < 24 ? 8 : 9)))));
+}
+
+// kvz_encode_coeff_nxn_generic: the residual syntax of one transform block (sign hiding, transform skip, encryption off)
+KVZ_DEV void entropy_coeff_nxn(BinSink &s, const Tables *tb, const i16 *coeff, int log2_size, int type, int scan_mode)
+{
+  const int width = 1 << log2_size, nbs = width >> 2;
+  const u32 *scan = tb->scan[scan_mode][log2_size - 2];
+  unsigned long long sig_cg = 0;  // bit cy * nbs + cx
+  for (int cy = 0; cy < nbs; cy++)
+    for (int cx = 0; cx < nbs; cx++) {
+      bool any = false;
+      for (int r = 0; r < 4; r++) any |= *(const unsigned long long *)&coeff[(cy * 4 + r) * width + cx * 4] != 0;
+      if (any) sig_cg |= 1ull << (cy * nbs + cx);
+    }
+  auto cg_of = [&](int i) { const int p = (int)scan[i << 4]; return ((p >> log2_size) >> 2) * nbs + ((p & (width - 1)) >> 2); };  // g_sig_last_scan_cg: the scan is group-major
+  int scan_cg_last = nbs * nbs - 1;
+  while (!((sig_cg >> cg_of(scan_cg_last)) & 1)) scan_cg_last--;
+  int scan_pos_last = scan_cg_last * 16 + 15;
+  while (!coeff[scan[scan_pos_last]]) scan_pos_last--;
+  const int pos_last = (int)scan[scan_pos_last];
+  {  // kvz_encode_last_significant_xy (encode_coding_tree.c:63-115)
+    int lx = pos_last & (width - 1), ly = pos_last >> log2_size;
+    const int index = log2_size - 2;
+    const int ctx_offset = type ? 0 : (index * 3 + (index + 1) / 4), shift = type ? index : (index + 3) / 4;
+    const int base_x = type ? KVZ_HIP_CX_LAST_X_CHROMA : KVZ_HIP_CX_LAST_X_LUMA, base_y = type ? KVZ_HIP_CX_LAST_Y_CHROMA : KVZ_HIP_CX_LAST_Y_LUMA;
+    if (scan_mode == 2) { const int t = lx; lx = ly; ly = t; }
+    const int gx = entropy_group_idx(lx), gy = entropy_group_idx(ly), gmax = entropy_group_idx(width - 1);
+    for (int i = 0; i < gx; i++) s.ctx(base_x + ctx_offset + (i >> shift), 1);
+    if (gx < gmax) s.ctx(base_x + ctx_offset + (gx >> shift), 0);
+    for (int i = 0; i < gy; i++) s.ctx(base_y + ctx_offset + (i >> shift), 1);
+    if (gy < gmax) s.ctx(base_y + ctx_offset + (gy >> shift), 0);
+    const int min_in_group[10] = { 0, 1, 2, 3, 4, 6, 8, 12, 16, 24 };
+    if (gx > 3) s.ep((u32)(lx - min_in_group[gx]), (gx - 2) / 2);
+    if (gy > 3) s.ep((u32)(ly - min_in_group[gy]), (gy - 2) / 2);
+  }
+  const int base_sig = type == 0 ? KVZ_HIP_CX_SIG_LUMA : KVZ_HIP_CX_SIG_CHROMA;
+  int scan_pos_sig = scan_pos_last, c1 = 1;
+  for (int i = scan_cg_last; i >= 0; i--) {
+    const int sub_pos = i << 4, cg_blk_pos = cg_of(i), cg_pos_y = cg_blk_pos / nbs, cg_pos_x = cg_blk_pos - cg_pos_y * nbs;
+    int abs_coeff[16], num_non_zero = 0;
+    u32 coeff_signs = 0, go_rice = 0;
+    if (scan_pos_sig == scan_pos_last) { const int v = coeff[pos_last]; abs_coeff[0] = iabs(v); coeff_signs = v < 0; num_non_zero = 1; scan_pos_sig--; }
+    const int right = cg_pos_x < nbs - 1 && ((sig_cg >> (cg_pos_y * nbs + cg_pos_x + 1)) & 1);
+    const int lower = cg_pos_y < nbs - 1 && ((sig_cg >> ((cg_pos_y + 1) * nbs + cg_pos_x)) & 1);
+    if (i == scan_cg_last || i == 0) sig_cg |= 1ull << cg_blk_pos;
+    else s.ctx(KVZ_HIP_CX_SIG_CG + type + (right || lower), (int)((sig_cg >> cg_blk_pos) & 1));  // coded_sub_block_flag (context.c:315-327)
+    if ((sig_cg >> cg_blk_pos) & 1) {
+      const int pattern = width == 4 ? -1 : right + (lower << 1);  // context.c:339-351
+      for (; scan_pos_sig >= sub_pos; scan_pos_sig--) {
+        const int blk_pos = (int)scan[scan_pos_sig], pos_y = blk_pos >> log2_size, pos_x = blk_pos - (pos_y << log2_size), v = coeff[blk_pos];
+        if (scan_pos_sig > sub_pos || i == 0 || num_non_zero) s.ctx(base_sig + entropy_sig_ctx_inc(pattern, scan_mode, pos_x, pos_y, log2_size, type), v != 0);
+        if (v) { abs_coeff[num_non_zero++] = iabs(v); coeff_signs = 2 * coeff_signs + (v < 0); }
+      }
+    } else scan_pos_sig = sub_pos - 1;
+    if (num_non_zero > 0) {
+      int ctx_set = (i > 0 && type == 0) ? 2 : 0;
+      if (c1 == 0) ctx_set++;
+      c1 = 1;
+      const int base_one = (type == 0 ? KVZ_HIP_CX_ONE_LUMA : KVZ_HIP_CX_ONE_CHROMA) + 4 * ctx_set, num_c1 = num_non_zero < 8 ? num_non_zero : 8;
+      int first_c2 = -1;
+      for (int idx = 0; idx < num_c1; idx++) {
+        const int symbol = abs_coeff[idx] > 1;
+        s.ctx(base_one + c1, symbol);
+        if (symbol) { c1 = 0; if (first_c2 == -1) first_c2 = idx; }
+        else if (c1 < 3 && c1 > 0) c1++;
+      }
+      if (c1 == 0 && first_c2 != -1) s.ctx((type == 0 ? KVZ_HIP_CX_ABS_LUMA : KVZ_HIP_CX_ABS_CHROMA) + ctx_set, abs_coeff[first_c2] > 2);
+      s.ep(coeff_signs, num_non_zero);
+      if (c1 == 0 || num_non_zero > 8) {
+        int first_coeff2 = 1;
+        for (int idx = 0; idx < num_non_zero; idx++) {
+          const int base_level = idx < 8 ? 2 + first_coeff2 : 1;
+          if (abs_coeff[idx] >= base_level) {  // kvz_cabac_write_coeff_remain (cabac.c:275-301)
+            int code_number = abs_coeff[idx] - base_level;
+            if (code_number < (3 << go_rice)) {
+              const u32 length = (u32)code_number >> go_rice;
+              s.ep((1u << (length + 1)) - 2, (int)length + 1);
+              s.ep((u32)code_number & ((1u << go_rice) - 1), (int)go_rice);
+            } else {
+              u32 length = go_rice;
+              code_number -= 3 << go_rice;
+              while (code_number >= (1 << length)) { code_number -= 1 << length; ++length; }
+              s.ep((1u << (3 + length + 1 - go_rice)) - 2, (int)(3 + length + 1 - go_rice));
+              s.ep((u32)code_number, (int)length);
+            }
+            if (abs_coeff[idx] > 3 * (1 << go_rice)) go_rice = go_rice + 1 < 4 ? go_rice + 1 : 4;
+          }
+          if (abs_coeff[idx] >= 2) first_coeff2 = 0;
+        }
+      }
+    }
+  }
+}
+
+struct EntropyCtu {  // one CTU of one picture
+  const EntropyJob &J;
+  const Tables *tb;
+  const u8 *depth, *mode, *part, *mode4;
+  const i16 *ctu;
+  int w8, w4;
+  KVZ_DEV int mode_at(int x, int y) const
+  {
+    if (part && part[(y >> 3) * w8 + (x >> 3)]) return mode4[(y >> 2) * w4 + (x >> 2)];
+    return mode[(y >> 3) * w8 + (x >> 3)];
+  }
+  // cbf_is_set(cu->cbf, depth, plane) read off the levels (cu.h:510-569: the block or any block below it)
+  KVZ_DEV bool cbf(int c, int xl, int yl, int depth) const
+  {
+    const int w = 64 >> depth;
+    if (c == 0) return entropy_any(ctu + entropy_zorder(xl, yl), w * w);
+    const int cw = depth >= 3 ? 4 : w / 2;
+    return entropy_any(ctu + (c == 1 ? 4096 : 5120) + entropy_zorder((xl & ~7) / 2, (yl & ~7) / 2), cw * cw);
+  }
+  // encode_transform_unit (encode_coding_tree.c:117-190) of the block at (x, y), tree depth `depth`
+  KVZ_DEV void transform_unit(BinSink &s, int x, int y, int depth, bool cb_y, bool cu_u, bool cu_v) const
+  {
+    const int xl = x & 63, yl = y & 63, log2w = 6 - depth, log2c = depth == 4 ? 2 : log2w - 1;
+    if (cb_y) entropy_coeff_nxn(s, tb, ctu + entropy_zorder(xl, yl), log2w, 0, entropy_scan_order(mode_at(x, y), depth));
+    if (depth == 4 && (x % 8 == 0 || y % 8 == 0)) return;  // the 4x4 chroma blocks follow the last luma block, under the first PU's mode
+    const int cscan = entropy_scan_order(mode_at(x & ~7, y & ~7), depth), cxl = (xl & ~7) / 2, cyl = (yl & ~7) / 2;
+    if (cu_u) entropy_coeff_nxn(s, tb, ctu + 4096 + entropy_zorder(cxl, cyl), log2c, 2, cscan);
+    if (cu_v) entropy_coeff_nxn(s, tb, ctu + 5120 + entropy_zorder(cxl, cyl), log2c, 2, cscan);
+  }
+  // encode_transform_coeff (encode_coding_tree.c:193-310) of an intra CU: one level of implicit split at most (64x64 CUs, NxN CUs), no split_transform_flag is ever coded
+  KVZ_DEV void transform_tree(BinSink &s, int x, int y, int depth, bool nxn) const
+  {
+    const int xl = x & 63, yl = y & 63;
+    const bool cu_u = cbf(1, xl, yl, depth), cu_v = cbf(2, xl, yl, depth);
+    s.ctx(KVZ_HIP_CX_CBF_CHROMA, cu_u);
+    s.ctx(KVZ_HIP_CX_CBF_CHROMA, cu_v);
+    if (depth > 0 && !nxn) {  // one transform block
+      const bool cb_y = cbf(0, xl, yl, depth);
+      s.ctx(KVZ_HIP_CX_CBF_LUMA + 1, cb_y);
+      if (cb_y | cu_u | cu_v) transform_unit(s, x, y, depth, cb_y, cu_u, cu_v);
+      return;
+    }
+    const int o = 64 >> (depth + 1);
+    for (int q = 0; q < 4; q++) {
+      const int qx = x + (q & 1) * o, qy = y + (q >> 1) * o, d = depth + 1;
+      bool cb_u = cu_u, cb_v = cu_v;
+      if (d < 4) {  // chroma flags of the 32x32 units, when the CU's were set
+        cb_u = cu_u && cbf(1, qx & 63, qy & 63, d);
+        cb_v = cu_v && cbf(2, qx & 63, qy & 63, d);
+        if (cu_u) s.ctx(KVZ_HIP_CX_CBF_CHROMA + 1, cb_u);
+        if (cu_v) s.ctx(KVZ_HIP_CX_CBF_CHROMA + 1, cb_v);
+      }
+      const bool cb_y = cbf(0, qx & 63, qy & 63, d);
+      s.ctx(KVZ_HIP_CX_CBF_LUMA, cb_y);
+      if (cb_y | cb_u | cb_v) transform_unit(s, qx, qy, d, cb_y, cb_u, cb_v);
+    }
+  }
+  // intra.c:84-126 kvz_intra_get_dir_luma_predictor
+  KVZ_DEV static void mpm_candidates(int l, int a, int preds[3])
+  {
+    if (l == a) {
+      if (l > 1) { preds[0] = l; preds[1] = ((l + 29) % 32) + 2; preds[2] = ((l - 1) % 32) + 2; }
+      else { preds[0] = 0; preds[1] = 1; preds[2] = 26; }
+    } else {
+      preds[0] = l; preds[1] = a;
+      if (l && a) preds[2] = 0; else preds[2] = (l + a) < 2 ? 26 : 1;
+    }
+  }
+  // the leaf of kvz_encode_coding_tree: part_mode, encode_intra_coding_unit (encode_coding_tree.c:467-652), the transform tree
+  KVZ_DEV void coding_unit(BinSink &s, int x, int y, int depth) const
+  {
+    const bool nxn = depth == 3 && part && part[(y >> 3) * w8 + (x >> 3)];
+    if (depth == 3) s.ctx(KVZ_HIP_CX_PART, !nxn);
+    const int n_pu = nxn ? 4 : 1;
+    int preds[4][3], mpm[4], modes[4];
+    for (int j = 0; j < n_pu; j++) {
+      const int px = x + 4 * (j & 1), py = y + 4 * (j >> 1);
+      modes[j] = mode_at(px, py);
+      const int l = px > 0 ? mode_at(px - 1, py) : 1, a = (py % 64 > 0 && py > 0) ? mode_at(px, py - 1) : 1;
+      mpm_candidates(l, a, preds[j]);
+      mpm[j] = -1;
+      for (int i = 2; i >= 0; i--) if (preds[j][i] == modes[j]) mpm[j] = i;
+    }
+    for (int j = 0; j < n_pu; j++) s.ctx(KVZ_HIP_CX_INTRA, mpm[j] != -1);
+    for (int j = 0; j < n_pu; j++) {
+      if (mpm[j] != -1) {
+        s.ep(mpm[j] == 0 ? 0 : 1, 1);
+        if (mpm[j] != 0) s.ep(mpm[j] == 1 ? 0 : 1, 1);
+      } else {
+        int *q = preds[j], t;
+        if (q[0] > q[1]) { t = q[0]; q[0] = q[1]; q[1] = t; }
+        if (q[0] > q[2]) { t = q[0]; q[0] = q[2]; q[2] = t; }
+        if (q[1] > q[2]) { t = q[1]; q[1] = q[2]; q[2] = t; }
+        int rem = modes[j];
+        for (int i = 2; i >= 0; i--) rem = rem > q[i] ? rem - 1 : rem;
+        s.ep((u32)rem, 5);
+      }
+    }
+    s.ctx(KVZ_HIP_CX_CHROMA, 0);  // intra_chroma_pred_mode 4: the luma mode
+    transform_tree(s, x, y, depth, nxn);
+  }
+  // kvz_encode_coding_tree (encode_coding_tree.c:745-900) without recursion: a stack of (x, y, depth) nodes, children pushed in reverse coding order
+  KVZ_DEV void coding_tree(BinSink &s, int cx, int cy) const
+  {
+    int stack[16], sp = 0;
+    stack[sp++] = 0;  // node: x offset >> 3 in bits 0..3, y offset >> 3 in bits 4..7, depth in bits 8..9
+    while (sp > 0) {
+      const int node = stack[--sp], depth = node >> 8, x = cx + ((node & 15) << 3), y = cy + (((node >> 4) & 15) << 3);
+      const int w = 64 >> depth, half = w >> 1;
+      const int cur_depth = this->depth[(y >> 3) * w8 + (x >> 3)];
+      const bool split_flag = cur_depth > depth;
+      const bool border_x = J.W < x + w, border_y = J.H < y + w, border = border_x || border_y;
+      const bool border_split_x = J.W >= x + 8 + half, border_split_y = J.H >= y + 8 + half;
+      if (depth != 3) {
+        if (!border) {
+          int sm = 0;
+          if (x > 0 && this->depth[(y >> 3) * w8 + ((x - 1) >> 3)] > depth) sm++;
+          if (y > 0 && this->depth[((y - 1) >> 3) * w8 + (x >> 3)] > depth) sm++;
+          s.ctx(KVZ_HIP_CX_SPLIT + sm, split_flag);
+        }
+        if (split_flag || border) {
+          const int h8 = half >> 3, base = (node & 0xff) | ((depth + 1) << 8);
+          if (!border || (border_split_x && border_split_y)) stack[sp++] = base + h8 + (h8 << 4);
+          if (!border_y || border_split_y) stack[sp++] = base + (h8 << 4);
+          if (!border_x || border_split_x) stack[sp++] = base + h8;
+          stack[sp++] = base;
+          continue;
+        }
+      }
+      coding_unit(s, x, y, depth);
+    }
+  }
+  // encode_sao_color (encoderstate.c:467-517) from the packed decision records (kvz_sao.hpp SaoRec: type | class << 8 | band << 16 | five offsets from bit 24)
+  KVZ_DEV static void sao_color(BinSink &s, SaoRec first, SaoRec own, int color)
+  {
+    const int type = (int)(first & 0xff);
+    if (color != 2) {
+      s.ctx(KVZ_HIP_CX_SAO_TYPE, type != 0);
+      if (type == 1) s.ep(0, 1); else if (type == 2) s.ep(1, 1);
+    }
+    if (type == 0) return;
+    int off[5];
+    for (int k = 0; k < 5; k++) off[k] = (int)(int8_t)(own >> (24 + 8 * k));
+    for (int i = 1; i <= 4; i++) {  // kvz_cabac_write_unary_max_symbol_ep (cabac.c:526-551), max 7
+      const int symbol = iabs(off[i]);
+      if (!symbol) { s.ep(0, 1); continue; }
+      const int n = symbol + (symbol < 7);
+      s.ep(((1u << symbol) - 1) << (symbol < 7), n);
+    }
+    if (type == 1) {
+      for (int i = 1; i <= 4; i++) if (off[i] != 0) s.ep(off[i] < 0 ? 1 : 0, 1);
+      s.ep((u32)((own >> 16) & 0xff), 5);
+    } else if (color != 2) {
+      s.ep((u32)((first >> 8) & 0xff), 2);
+    }
+  }
+};
+
+// stage 1: the bins of CTU `item` (frame-major, raster CTU order inside a frame)
+KVZ_DEV void entropy_ctu_bins(const EntropyJob &J, const Tables *tb, long item)
+{
+  const int ctus = J.wc * J.hc, f = (int)(item / ctus), k = (int)(item - (long)f * ctus), lx = k % J.wc, ly = k / J.wc;
+  const long cells8 = (long)(J.H >> 3) * (J.W >> 3), cells4 = (long)(J.H >> 2) * (J.W >> 2);
+  EntropyCtu c{ J, tb, J.depth + f * cells8, J.mode + f * cells8, J.part ? J.part + f * cells8 : nullptr, J.mode4 ? J.mode4 + f * cells4 : nullptr,
+                J.coeff + item * KVZ_HIP_CTU_COEFFS, J.W >> 3, J.W >> 2 };
+  BinSink s{ J.bins + item * J.cap, 0, J.cap };
+  if (J.sao) {  // encode_sao (encoderstate.c:519-552)
+    const int merge = J.sao_merge[item];
+    if (lx > 0) s.ctx(KVZ_HIP_CX_SAO_MERGE, merge == 1);
+    if (ly > 0 && merge != 1) s.ctx(KVZ_HIP_CX_SAO_MERGE, merge == 2);
+    if (!merge) {
+      const SaoRec *r = J.sao + item * 3;
+      EntropyCtu::sao_color(s, r[0], r[0], 0);
+      EntropyCtu::sao_color(s, r[1], r[1], 1);
+      EntropyCtu::sao_color(s, r[1], r[2], 2);
+    }
+  }
+  c.coding_tree(s, lx * 64, ly * 64);
+  const bool last_col = lx == J.wc - 1, last_row = ly == J.hc - 1, end_of_slice = last_col && last_row;
+  s.trm(end_of_slice);                                          // end_of_slice_segment_flag (encoderstate.c:699-712)
+  if (!J.no_wpp && last_col && !end_of_slice) s.trm(1);         // end_of_subset_one_bit
+  J.nbins[item] = s.n;
+}
+
+// stage 2: the contexts every row of picture f starts from (WPP)
+KVZ_DEV void entropy_row_contexts(const EntropyJob &J, const Tables *tb, int f, u8 *ctx /* KVZ_ENTROPY_CTXS bytes of work memory */)
+{
+  const int ctus = J.wc * J.hc;
+  u8 *out = J.row_ctx + (long)f * J.hc * KVZ_ENTROPY_CTXS;
+  for (int i = 0; i < KVZ_ENTROPY_CTXS; i++) { ctx[i] = J.ctx_init[i]; out[i] = ctx[i]; }
+  for (int r = 0; r + 1 < J.hc; r++) {
+    if (J.wc >= 2) {  // a picture one CTU wide never reaches "lcu->index == 1": its rows keep the slice's initial states
+      for (int x = 0; x < 2; x++) {
+        const long item = (long)f * ctus + r * J.wc + x;
+        const u32 *b = J.bins + item * J.cap, n = J.nbins[item] < J.cap ? J.nbins[item] : J.cap;
+        for (u32 i = 0; i < n; i++) {
+          const u32 rec = b[i];
+          if (rec >> 30) continue;
+          const int c = (int)(rec & 0xff), bin = (int)((rec >> 8) & 1), st = ctx[c];
+          ctx[c] = tb->ctx_next[bin != (st & 1)][st];
+        }
+      }
+    } else {
+      for (int i = 0; i < KVZ_ENTROPY_CTXS; i++) ctx[i] = J.ctx_init[i];
+    }
+    for (int i = 0; i < KVZ_ENTROPY_CTXS; i++) out[(r + 1) * KVZ_ENTROPY_CTXS + i] = ctx[i];
+  }
+}
+
+// the arithmetic coder (cabac.c:85-270)
+struct ArithCoder {
+  u32 low, range, buffered_byte;
+  int bits_left, num_buffered_bytes;
+  u8 *out;   // null: count only
+  u32 n;
+  KVZ_DEV void start() { low = 0; range = 510; bits_left = 23; num_buffered_bytes = 0; buffered_byte = 0xff; }
+  KVZ_DEV void put_byte(u32 b) { if (out) out[n] = (u8)b; n++; }
+  KVZ_DEV void write()  // kvz_cabac_write
+  {
+    const u32 lead_byte = low >> (24 - bits_left);
+    bits_left += 8;
+    low &= 0xffffffffu >> bits_left;
+    if (lead_byte == 0xff) { num_buffered_bytes++; return; }
+    if (num_buffered_bytes > 0) {
+      const u32 carry = lead_byte >> 8;
+      put_byte(buffered_byte + carry);
+      buffered_byte = lead_byte & 0xff;
+      const u32 fill = (0xff + carry) & 0xff;
+      while (num_buffered_bytes > 1) { put_byte(fill); num_buffered_bytes--; }
+    } else {
+      num_buffered_bytes = 1;
+      buffered_byte = lead_byte;
+    }
+  }
+  KVZ_DEV void finish_and_align()  // kvz_cabac_finish, then the stop bit and the zero bits up to the byte boundary (encoderstate.c:726-732)
+  {
+    if (low >> (32 - bits_left)) {
+      put_byte(buffered_byte + 1);
+      while (num_buffered_bytes > 1) { put_byte(0); num_buffered_bytes--; }
+      low -= 1u << (32 - bits_left);
+    } else {
+      if (num_buffered_bytes > 0) put_byte(buffered_byte);
+      while (num_buffered_bytes > 1) { put_byte(0xff); num_buffered_bytes--; }
+    }
+    const int nb = 24 - bits_left;  // kvz_bitstream_put(stream, low >> 8, nb), then "1" and the alignment
+    unsigned long long w = (((unsigned long long)(low >> 8) & ((1ull << nb) - 1)) << 1) | 1ull;
+    int bits = nb + 1;
+    const int pad = (8 - (bits & 7)) & 7;
+    w <<= pad; bits += pad;
+    for (int sh = bits - 8; sh >= 0; sh -= 8) put_byte((u32)(w >> sh) & 0xff);
+  }
+};
+
+// Range of the less probable symbol, H.265 table 9-46 (cabac.c:66-82 kvz_g_auc_lpst_table), four bytes per state
+#ifdef KVZ_HOSTSIM
+static const u32 kLpsPacked[64] = {
+#else
+__device__ const u32 kLpsPacked[64] = {
+#endif
+  0xF0D0B080u, 0xE3C5A780u, 0xD8BB9E80u, 0xCDB2967Bu, 0xC3A98E74u, 0xB9A0876Fu, 0xAF988069u, 0xA6907A64u,
+  0x9E89745Fu, 0x96826E5Au, 0x8E7B6855u, 0x87756351u, 0x806F5E4Du, 0x7A695949u, 0x74645545u, 0x6E5F5042u,
+  0x685A4C3Eu, 0x6356483Bu, 0x5E514538u, 0x594D4135u, 0x55493E33u, 0x50453B30u, 0x4C42382Eu, 0x483F352Bu,
+  0x453B3229u, 0x41383027u, 0x3E362D25u, 0x3B332B23u, 0x38302921u, 0x352E2720u, 0x322B251Eu, 0x3029231Du,
+  0x2D27211Bu, 0x2B251F1Au, 0x29231E18u, 0x27211C17u, 0x25201B16u, 0x231E1A15u, 0x211D1814u, 0x1F1B1713u,
+  0x1E1A1612u, 0x1C191511u, 0x1B171410u, 0x1916130Fu, 0x1815120Eu, 0x1714110Eu, 0x1613100Du, 0x15120F0Cu,
+  0x14110E0Cu, 0x13100E0Bu, 0x120F0D0Bu, 0x110F0C0Au, 0x100E0C0Au, 0x0F0D0B09u, 0x0E0C0B09u, 0x0E0C0A08u,
+  0x0D0B0908u, 0x0C0B0907u, 0x0C0A0907u, 0x0B0A0807u, 0x0B090806u, 0x0A090706u, 0x09080706u, 0x02020202u };
+KVZ_DEV u32 entropy_lps_row(int state) { return kLpsPacked[state]; }
+
+// stage 3: the substream `item` -- (picture, CTU row) with WPP, the picture without; returns its size in bytes.  ctx: KVZ_ENTROPY_CTXS bytes of work memory
+KVZ_DEV u32 entropy_code_row(const EntropyJob &J, const Tables *tb, long item, u8 *ctx, u8 *out)
+{
+  const int ctus = J.wc * J.hc;
+  const int f = J.no_wpp ? (int)item : (int)(item / J.hc), row = J.no_wpp ? 0 : (int)(item - (long)f * J.hc);
+  const long first = (long)f * ctus + (long)row * J.wc, count = J.no_wpp ? ctus : J.wc;
+  const u8 *start = J.no_wpp ? J.ctx_init : J.row_ctx + ((long)f * J.hc + row) * KVZ_ENTROPY_CTXS;
+  for (int i = 0; i < KVZ_ENTROPY_CTXS; i++) ctx[i] = start[i];
+  ArithCoder a;
+  a.out = out; a.n = 0;
+  a.start();
+  for (long k = 0; k < count; k++) {
+    const u32 *b = J.bins + (first + k) * J.cap, n = J.nbins[first + k] < J.cap ? J.nbins[first + k] : J.cap;
+    for (u32 i = 0; i < n; i++) {
+      const u32 rec = b[i], kind = rec >> 30;
+      if (kind == 0) {  // kvz_cabac_encode_bin
+        const int c = (int)(rec & 0xff), bin = (int)((rec >> 8) & 1), st = ctx[c];
+        const u32 lps = (entropy_lps_row(st >> 1) >> (8 * ((a.range >> 6) & 3))) & 0xff;
+        a.range -= lps;
+        if (bin != (st & 1)) {
+          const int num_bits = lps < 8 ? 6 : (int)__builtin_clz(lps) - 23;  // kvz_g_auc_renorm_table[lps >> 3] (cabac.c:84-88): the shift that brings lps back to >= 256
+          a.low = (a.low + a.range) << num_bits;
+          a.range = lps << num_bits;
+          a.bits_left -= num_bits;
+          ctx[c] = tb->ctx_next[1][st];
+        } else {
+          ctx[c] = tb->ctx_next[0][st];
+          if (a.range >= 256) continue;
+          a.low <<= 1; a.range <<= 1; a.bits_left--;
+        }
+      } else if (kind == 1) {  // kvz_cabac_encode_bins_ep
+        int nb = (int)((rec >> 16) & 0x3f);
+        u32 v = rec & 0xffff;
+        if (nb > 8) {
+          nb -= 8;
+          const u32 pattern = v >> nb;
+          a.low = (a.low << 8) + a.range * pattern;
+          v -= pattern << nb;
+          a.bits_left -= 8;
+          if (a.bits_left < 12) a.write();
+        }
+        a.low = (a.low << nb) + a.range * v;
+        a.bits_left -= nb;
+      } else {  // kvz_cabac_encode_bin_trm
+        a.range -= 2;
+        if (rec & 1) { a.low += a.range; a.low <<= 7; a.range = 2 << 7; a.bits_left -= 7; }
+        else if (a.range >= 256) continue;
+        else { a.low <<= 1; a.range <<= 1; a.bits_left--; }
+      }
+      if (a.bits_left < 12) a.write();
+    }
+  }
+  a.finish_and_align();
+  return a.n;
+}
+
+#ifndef KVZ_HOSTSIM
+__global__ void __launch_bounds__(64) dev_entropy_bins_kernel(const EntropyJob J, const Tables *tb, long total)
+{
+  const long item = (long)blockIdx.x * 64 + threadIdx.x;
+  if (item < total) entropy_ctu_bins(J, tb, item);
+}
+__global__ void __launch_bounds__(64) dev_entropy_row_ctx_kernel(const EntropyJob J, const Tables *tb)
+{
+  __shared__ u8 ctx[64][KVZ_ENTROPY_CTXS];
+  const int f = blockIdx.x * 64 + threadIdx.x;
+  if (f < J.n_frames) entropy_row_contexts(J, tb, f, ctx[threadIdx.x]);
+}
+// sizes != null: count (out unused); else write every substream at out + offsets[item]
+__global__ void __launch_bounds__(64) dev_entropy_code_kernel(const EntropyJob J, const Tables *tb, long total, u32 *sizes, const unsigned long long *offsets, u8 *out)
+{
+  __shared__ u8 ctx[64][KVZ_ENTROPY_CTXS];
+  const long item = (long)blockIdx.x * 64 + threadIdx.x;
+  if (item >= total) return;
+  if (sizes) sizes[item] = entropy_code_row(J, tb, item, ctx[threadIdx.x], nullptr);
+  else entropy_code_row(J, tb, item, ctx[threadIdx.x], out + offsets[item]);
+}
+#endif
+
+}  // namespace kvz

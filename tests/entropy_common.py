@@ -146,3 +146,48 @@ def reference_slice_payloads(ref_binary, case, workdir):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-1500:]
     return slice_payloads(open(out, "rb").read())
+
+
+def pack_sao_records(luma, chroma, n_lcus):
+    """kvz_sao.hpp SaoRec per (LCU, plane) from kvz_hip_sao_params arrays (the layout the device's SAO decision writes and kvz_hip_batch_sao_params unpacks):
+    type | eo_class << 8 | band_position << 16 | five offsets as signed bytes from bit 24"""
+    lp = np.frombuffer(luma, np.int32).reshape(n_lcus, 15)   # type, eo_class, band_position[2], offsets[10], bitdepth
+    cp = np.frombuffer(chroma, np.int32).reshape(n_lcus, 15)
+    recs = np.zeros((n_lcus, 3), np.uint64)
+    for i in range(n_lcus):
+        for plane, (p, slot) in enumerate(((lp[i], 0), (cp[i], 0), (cp[i], 1))):
+            r = int(p[0]) | int(p[1]) << 8 | int(p[2 + slot]) << 16
+            for k in range(5):
+                r |= (int(p[4 + 5 * slot + k]) & 0xFF) << (24 + 8 * k)
+            recs[i, plane] = r
+    return recs
+
+
+def hostsim_slice_data(oracle, hostsim_cdll, case, cap=12288, retry=True):
+    """the device's entropy coder (kvazaar_amd/csrc/kvz_entropy.hpp) compiled for the host, on the oracle's CTU-pass outputs: [(slice data, substream sizes)] per picture"""
+    from test_sao_decision import oracle_sao_chain
+    name, w, h, n, seed, kind, qp, preset, extra = case
+    model = case_model(oracle, case)
+    f = hostsim_cdll.kvz_hostsim_entropy_code
+    f.restype = C.c_long
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7 + [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    wc, hc = (w + 63) // 64, (h + 63) // 64
+    out = []
+    for fr in cc.yuv_frames(w, h, n, seed, kind):
+        o = cc.run_oracle_nxn(oracle, model, w, h, fr) if preset == "medium" else cc.run_oracle(oracle, model, w, h, fr)
+        recs = merge = None
+        if preset != "ultrafast":
+            _, _, luma, chroma, merge, _ = oracle_sao_chain(oracle, model, w, h, fr, pre=o)
+            recs = pack_sao_records(luma, chroma, wc * hc)
+        part, mode4 = o.get("part"), o.get("mode4")
+        buf, sizes, most = np.zeros(w * h * 4 + 4096, np.uint8), np.zeros(hc, np.uint32), C.c_uint32(0)
+        def run(cap):
+            return f(C.addressof(model), w, h, 1, o["depth"].ctypes.data, o["mode"].ctypes.data, part.ctypes.data if part is not None else None,
+                     mode4.ctypes.data if mode4 is not None else None, o["coeff"].ctypes.data, recs.ctypes.data if recs is not None else None,
+                     merge.ctypes.data if merge is not None else None, cap, buf.ctypes.data, sizes.ctypes.data, C.byref(most))
+        total = run(cap)
+        if total == -1 and retry:  # a CTU's bin list did not fit: again with the capacity it needs (what kvz_hip_batch_entropy_code does)
+            total = run(most.value)
+        assert total >= 0, (total, most.value)
+        out.append((buf[:total].tobytes(), [int(v) for v in sizes[:1 if model.no_wpp else hc]]))
+    return out

@@ -174,3 +174,37 @@ extern "C" void kvz_hostsim_inter_frame(int width, int height, int qp, int poc, 
     }
   free(F.ctx_out); free(slab); free(lds);
 }
+
+// ---- the entropy coder's three stages (kvz_entropy.hpp) run on the host: every lane a loop iteration ----
+#include "../../kvazaar_amd/csrc/kvz_entropy.hpp"
+extern "C" long kvz_hostsim_entropy_code(const kvz_hip_intra_cost_model *m, int width, int height, int n_frames, const uint8_t *cu_depth, const uint8_t *cu_mode, const uint8_t *part,
+                                         const uint8_t *mode4, const int16_t *coeff, const unsigned long long *sao_recs, const uint8_t *sao_merge, uint32_t cap, uint8_t *out,
+                                         uint32_t *substream_bytes, uint32_t *most_records)
+{
+  static kvz::Tables tb;
+  kvz::build_tables(&tb);
+  kvz::EntropyJob J;
+  memset(&J, 0, sizeof J);
+  J.W = width; J.H = height; J.wc = (width + 63) / 64; J.hc = (height + 63) / 64; J.n_frames = n_frames; J.no_wpp = m->no_wpp;
+  J.depth = cu_depth; J.mode = cu_mode; J.part = part; J.mode4 = mode4; J.coeff = coeff; J.sao = sao_recs; J.sao_merge = sao_merge;
+  const long items = (long)n_frames * J.wc * J.hc, streams = (long)n_frames * (m->no_wpp ? 1 : J.hc);
+  J.bins = (uint32_t *)malloc((size_t)items * cap * sizeof(uint32_t)); J.nbins = (uint32_t *)malloc((size_t)items * sizeof(uint32_t)); J.cap = cap;
+  J.row_ctx = (uint8_t *)malloc((size_t)n_frames * J.hc * KVZ_ENTROPY_CTXS);
+  memcpy(J.ctx_init, m->ctx_init, sizeof m->ctx_init < sizeof J.ctx_init ? sizeof m->ctx_init : sizeof J.ctx_init);
+  uint8_t ctx[KVZ_ENTROPY_CTXS];
+  *most_records = 0;
+  for (long i = 0; i < items; i++) { kvz::entropy_ctu_bins(J, &tb, i); if (J.nbins[i] > *most_records) *most_records = J.nbins[i]; }
+  long total = -1;
+  if (*most_records <= cap) {
+    if (!m->no_wpp) for (int f = 0; f < n_frames; f++) kvz::entropy_row_contexts(J, &tb, f, ctx);
+    total = 0;
+    for (long i = 0; i < streams; i++) {
+      const uint32_t counted = kvz::entropy_code_row(J, &tb, i, ctx, nullptr);
+      substream_bytes[i] = kvz::entropy_code_row(J, &tb, i, ctx, out + total);
+      if (counted != substream_bytes[i]) { total = -2; break; }
+      total += substream_bytes[i];
+    }
+  }
+  free(J.bins); free(J.nbins); free(J.row_ctx);
+  return total;
+}

@@ -48,3 +48,30 @@ def test_byte_stream_splitter_removes_emulation_prevention():
     assert units == [(32, bytes([0xAA, 0, 0, 1, 0xBB])), (19, bytes([0x11, 0, 0, 0, 0, 2]))]
     assert ec.slice_payloads(stream) == [bytes([0x11, 0, 0, 0, 0, 2])]
     assert ec.ue_bits(0) == "1" and ec.ue_bits(3) == "00100"
+
+
+@pytest.fixture(scope="module")
+def hostsim_cdll():
+    import ctypes
+    import subprocess
+    d = os.path.join(flatapi.ROOT, "tests", "hostsim")
+    so = os.path.join(d, "libkvz_hostsim.so")
+    srcs = [os.path.join(d, "hostsim.cpp")] + [os.path.join(flatapi.ROOT, "kvazaar_amd", "csrc", f) for f in os.listdir(os.path.join(flatapi.ROOT, "kvazaar_amd", "csrc"))]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, os.path.join(d, "hostsim.cpp")])
+    return ctypes.CDLL(so)
+
+
+@pytest.mark.parametrize("case", ec.CASES, ids=[c[0] for c in ec.CASES])
+def test_host_simulation_of_the_device_coder_writes_the_reference_slice_data(oracle, hostsim_cdll, case):
+    """kvazaar_amd/csrc/kvz_entropy.hpp -- bin lists per CTU, row-start contexts, one arithmetic coder per substream -- compiled for the host: the bytes of every
+    picture are the reference encoder's (tests/golden/entropy.json), and the counting run of the coder agrees with the writing run"""
+    for (data, sizes), g in zip(ec.hostsim_slice_data(oracle, hostsim_cdll, case), GOLDEN[case[0]]):
+        assert sizes == g["sizes"]
+        assert hashlib.sha256(data).hexdigest()[:24] == g["sha"]
+
+
+def test_host_simulation_reports_a_bin_list_that_does_not_fit(oracle, hostsim_cdll):
+    case = [c for c in ec.CASES if c[0] == "noise-qp12"][0]
+    with pytest.raises(AssertionError):
+        ec.hostsim_slice_data(oracle, hostsim_cdll, case, cap=256, retry=False)

@@ -1,0 +1,104 @@
+"""kvz_hip_batch_entropy_code on the MI355X: kvazaar's entropy coder in its real mode (kvazaar_amd/csrc/kvz_entropy.hpp) on the device-resident results of the CTU pass.
+The bytes of every picture must be the slice data the REFERENCE ENCODER wrote (tests/golden/entropy.json, made from kvazaar_ref's bitstreams): ultrafast at several QPs,
+--no-wpp, partial CTUs, a one-CTU-wide picture, noise / flat pictures (a bin list that outgrows the first capacity), SAO syntax from the device's own SAO decision,
+`medium` with RDOQ levels and NxN CUs; then whole batches at BASELINE's picture sizes against the oracle's coder."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import ctu_common as cc
+import entropy_common as ec
+import flatapi
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = json.load(open(os.path.join(HERE, "golden", "entropy.json")))
+
+
+def device_model(lib, case):
+    from kvazaar_amd.batch import cost_model
+    name, w, h, n, seed, kind, qp, preset, extra = case
+    m = cost_model(lib, qp, cc.coeff_weights(qp))
+    if preset == "medium":
+        m.coeff_cabac, m.search_32x32, m.rdoq, m.search_nxn = 1, 1, 1, 1
+    if "--no-wpp" in extra:
+        m.no_wpp = 1
+    return m
+
+
+def split(data, sizes):
+    out, at = [], 0
+    for row in sizes:
+        total = int(row.sum())
+        out.append((bytes(data[at:at + total]), [int(v) for v in row]))
+        at += total
+    assert at == len(data)
+    return out
+
+
+@pytest.mark.parametrize("case", ec.CASES, ids=[c[0] for c in ec.CASES])
+def test_device_slice_data_equals_the_reference_encoders(case):
+    import kvazaar_amd
+    from kvazaar_amd.batch import HipBatch
+    lib = kvazaar_amd.load_library()
+    name, w, h, n, seed, kind, qp, preset, extra = case
+    frames = cc.yuv_frames(w, h, n, seed, kind)
+    model = device_model(lib, case)
+    b = HipBatch(lib, w, h, n)
+    for i, f in enumerate(frames):
+        b.upload(i, f)
+    b.run(model)
+    sao = preset != "ultrafast"
+    if sao:
+        b.loop_filters(model, deblock=True, sao=True)
+    data, sizes = b.entropy_code(model, sao=sao)
+    got = split(data, sizes)
+    b.close()
+    for (bytes_, row), g in zip(got, GOLDEN[name]):
+        assert row == g["sizes"]
+        assert hashlib.sha256(bytes_).hexdigest()[:24] == g["sha"]
+
+
+def test_model_matches_the_oracle_tests_model():
+    """the medium switches of device_model are those of tests/test_encoder_parity.py _medium_model (what entropy.json was made with)"""
+    import kvazaar_amd
+    from test_encoder_parity import _medium_model, oracle_model
+    oracle = flatapi.load_oracle()
+    case = [c for c in ec.CASES if c[0] == "medium"][0]
+    a, b = device_model(kvazaar_amd.load_library(), case), _medium_model(oracle_model(oracle, case[6]))
+    for field in ("coeff_cabac", "search_32x32", "rdoq", "search_nxn", "no_wpp", "qp"):
+        assert getattr(a, field) == getattr(b, field), field
+    assert bytes(a.ctx_init) == bytes(b.ctx_init)
+
+
+@pytest.mark.parametrize("w,h,n,seed,qp", [(1920, 1080, 8, 1, 22), (3840, 2160, 4, 2, 22)], ids=["1080p-x8", "2160p-x4"])
+def test_device_slice_data_at_baseline_sizes(w, h, n, seed, qp):
+    """BASELINE configs 2 and 5's pictures: every substream of every picture equals the oracle's coder run on the device's own CTU-pass results (which
+    tests/test_gpu_ctu_batch.py pins to the reference encoder), several pictures per launch, scratch budget small enough to force chunks"""
+    import kvazaar_amd
+    from kvazaar_amd.batch import HipBatch, cost_model
+    from test_encoder_parity import oracle_model
+    lib = kvazaar_amd.load_library()
+    oracle = flatapi.load_oracle()
+    frames = cc.yuv_frames(w, h, n, seed, "large")
+    model = cost_model(lib, qp, cc.coeff_weights(qp))
+    b = HipBatch(lib, w, h, n)
+    for i, f in enumerate(frames):
+        b.upload(i, f)
+    b.run(model)
+    os.environ["KVZ_HIP_ENTROPY_SCRATCH_MB"] = "160" if w == 1920 else "300"  # three / two pictures per chunk
+    try:
+        data, sizes = b.entropy_code(model)
+    finally:
+        del os.environ["KVZ_HIP_ENTROPY_SCRATCH_MB"]
+    got = split(data, sizes)
+    om = oracle_model(oracle, qp)
+    for i in range(n):
+        o = b.download(i)
+        want, want_sizes = ec.oracle_entropy(oracle, om, w, h, o)
+        assert got[i][1] == want_sizes, i
+        assert got[i][0] == want, i
+    b.close()
