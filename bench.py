@@ -645,6 +645,33 @@ def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedRes
     result["chain_sao"] = {"stages": "CTU pass + deblocking + SAO decision (kvz_sao_search_lcu of every LCU) + SAO reconstruction + picture-hash checksums",
                            "value": b0.ctus_per_frame * b0.n / sao_s, "unit": "CTUs/s", "ms": sao_s * 1e3,
                            "verified": (sha(b0.download(0)["rec"]) == want[0]) if want else None}
+    # ---- the entropy coder in its real mode on the device (kvz_hip_batch_entropy_code): slice data instead of levels over PCIe ----
+    try:
+        b0.launch(model)
+        b0.sync()
+        b0.entropy_code(model)  # first use: scratch allocations
+        t0 = time.perf_counter()
+        data, sizes = b0.entropy_code(model)
+        ent_s = time.perf_counter() - t0
+        ent_ok = None
+        try:
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "entropy.json"))).get("bench-1080p")
+        except (OSError, ValueError):
+            gold = None
+        if gold and (args.width, args.height, args.qp, args.preset) == (1920, 1080, 22, "ultrafast") and not args.no_wpp and not args.frozen_contexts:
+            ent_ok, at = True, 0
+            for i in range(min(b0.n, len(gold), args.distinct)):  # picture i of the batch is frame i of the clip
+                total = int(sizes[i].sum())
+                ent_ok = ent_ok and [int(v) for v in sizes[i]] == gold[i]["sizes"] and hashlib.sha256(bytes(data[at:at + total])).hexdigest()[:24] == gold[i]["sha"]
+                at += total
+            ent_ok = bool(ent_ok and all(np.array_equal(sizes[i], sizes[i % args.distinct]) for i in range(b0.n)))
+        result["entropy"] = {"stages": "kvz_encode_coding_tree + kvz_encode_coeff_nxn + CABAC of every picture's slice data on the device from the resident results of the CTU pass "
+                                       "(bins per CTU, row-start contexts, one arithmetic coder per WPP substream), substreams and entry points downloaded",
+                             "value": b0.n / ent_s, "unit": "pictures/s", "ctus_per_s": b0.ctus_per_frame * b0.n / ent_s, "ms": ent_s * 1e3,
+                             "slice_data_bytes_per_picture": len(data) / b0.n, "levels_bytes_per_picture": b0.ctus_per_frame * 12288,
+                             "verified": ent_ok, "verify": "slice data and entry points of the clip's pictures equal the reference encoder's bitstream (tests/golden/entropy.json)"}
+    except Exception as e:  # auxiliary: never take the headline down
+        result["entropy"] = {"error": repr(e)}
     # ---- chain + D2H, double-buffered ----
     main_batch = batches[0][0]
     half = max(1, min(args.frames // 2, 384))

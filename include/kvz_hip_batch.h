@@ -123,8 +123,9 @@ void kvz_hip_intra_cost_model_init(int qp, uint64_t coeff_weights, kvz_hip_intra
  * sao != 0 -- of the last kvz_hip_batch_loop_filters(..., sao = 1): I slices of the configurations the pass covers.  model: the pass's (ctx_init = the slice's initial
  * context states, no_wpp, search_nxn).  out (HOST, `capacity` bytes) receives the slice data: picture after picture, and inside a picture one substream per CTU row
  * (WPP; the rows' contexts start from the row above after its second CTU, encoderstate.c:763-771) or one for the whole picture (no_wpp); substream_bytes (HOST) their sizes,
- * n_frames x (CTU rows | 1) entries -- the entry points of the slice header (encoder_state-bitstream.c:935-954).  The bytes are what kvazaar puts behind the slice header,
- * before emulation prevention.  Only these bytes cross PCIe instead of the levels (12 KB per CTU).  Returns the total size, -1 on failure. */
+ * n_frames x (CTU rows | 1) entries -- the entry points of the slice header (encoder_state-bitstream.c:935-954).  The bytes are those of kvazaar's per-row bitstream_t
+ * objects, emulation prevention bytes included (bitstream.c:212-223): what follows the slice header in the NAL unit, verbatim.  Only these bytes cross PCIe instead of
+ * the levels (12 KB per CTU).  Returns the total size, -1 on failure. */
 long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, uint8_t *out, size_t capacity, uint32_t *substream_bytes);
 uint64_t kvz_hip_default_coeff_weights(int qp);
 

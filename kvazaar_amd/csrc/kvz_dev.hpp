@@ -1442,8 +1442,8 @@ int kvz_hip_batch_sao_params(kvz_hip_batch *b, int frame, kvz_hip_sao_params *lu
 }
 
 // The entropy coder in its real mode (kvz_entropy.hpp): the slice data of every picture of the batch, substream by substream, from the device-resident results of the
-// CTU pass (and of the loop filters' SAO decision).  Pictures are coded in chunks so that the bin records of a chunk fit a scratch budget (KVZ_HIP_ENTROPY_SCRATCH_MB,
-// default 6144); a CTU that produces more records than the chunk's capacity per CTU makes the chunk run again with the capacity it needs.
+// CTU pass (and of the loop filters' SAO decision).  Pictures are coded in chunks whose bin records fit a scratch budget (KVZ_HIP_ENTROPY_SCRATCH_MB, default 49152:
+// 25 MB per 1080p picture at the default capacity of 12 288 records per CTU); a CTU that produces more records than that makes its chunk run again with the room it needs.
 long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, uint8_t *out, size_t capacity, uint32_t *substream_bytes)
 {
   kvz::batch_enter(b);
@@ -1453,28 +1453,30 @@ long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model
   if (model->search_nxn && !b->d_part) { fprintf(stderr, "kvz_hip_batch_entropy_code: the batch has no NxN partition maps\n"); return -1; }
   KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
   if (kvz::batch_check(b) != 0) return -1;
-  size_t budget = 6144;
+  size_t budget = 49152;
   if (const char *e = getenv("KVZ_HIP_ENTROPY_SCRATCH_MB")) { const long v = atol(e); if (v > 0) budget = (size_t)v; }
   budget <<= 20;
-  uint32_t cap = 12288;  // records per CTU to start with (QP 22 pictures need 4-6 k; noise at low QPs more)
-  if (const char *e = getenv("KVZ_HIP_ENTROPY_CAP")) { const long v = atol(e); if (v > 0) cap = (uint32_t)v; }
+  uint32_t cap = 12288;
+  if (const char *e = getenv("KVZ_HIP_ENTROPY_CAP")) { const long v = atol(e); if (v > 0) cap = ((uint32_t)v + 15u) & ~15u; }
   const long cells8 = (long)(F.H >> 3) * (F.W >> 3), cells4 = (long)(F.H >> 2) * (F.W >> 2);
+  std::vector<uint32_t> counts, bound_bits, sizes;
+  std::vector<unsigned long long> offsets, bound_offsets;
   size_t total = 0;
-  int f0 = 0;
-  std::vector<uint32_t> counts, sizes;
-  std::vector<unsigned long long> offsets;
-  while (f0 < n) {
+  long rc = 0;
+  for (int f0 = 0; f0 < n && rc == 0;) {
     int nf = (int)(budget / ((size_t)ctus * cap * sizeof(uint32_t)));
     if (nf < 1) nf = 1;
     if (nf > n - f0) nf = n - f0;
     const long items = (long)nf * ctus, streams = (long)nf * rows;
-    uint32_t *d_bins = nullptr, *d_nbins = nullptr, *d_sizes = nullptr;
-    unsigned long long *d_offsets = nullptr;
-    uint8_t *d_rowctx = nullptr, *d_out = nullptr;
+    uint32_t *d_bins = nullptr, *d_nbins = nullptr, *d_nbits = nullptr, *d_sizes = nullptr;
+    unsigned long long *d_offsets = nullptr, *d_bound_offsets = nullptr;
+    uint8_t *d_rowctx = nullptr, *d_out = nullptr, *d_scratch = nullptr;
     KVZ_HIP_CHECK(hipMalloc((void **)&d_bins, (size_t)items * cap * sizeof(uint32_t)));
     KVZ_HIP_CHECK(hipMalloc((void **)&d_nbins, (size_t)items * sizeof(uint32_t)));
+    KVZ_HIP_CHECK(hipMalloc((void **)&d_nbits, (size_t)items * sizeof(uint32_t)));
     KVZ_HIP_CHECK(hipMalloc((void **)&d_sizes, (size_t)streams * sizeof(uint32_t)));
     KVZ_HIP_CHECK(hipMalloc((void **)&d_offsets, (size_t)streams * sizeof(unsigned long long)));
+    KVZ_HIP_CHECK(hipMalloc((void **)&d_bound_offsets, (size_t)streams * sizeof(unsigned long long)));
     KVZ_HIP_CHECK(hipMalloc((void **)&d_rowctx, (size_t)nf * F.hc * KVZ_ENTROPY_CTXS));
     kvz::EntropyJob J;
     memset(&J, 0, sizeof J);
@@ -1483,18 +1485,38 @@ long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model
     J.part = model->search_nxn ? b->d_part + f0 * cells8 : nullptr; J.mode4 = model->search_nxn ? b->d_mode4 + f0 * cells4 : nullptr;
     J.coeff = b->d_coeff + (size_t)f0 * ctus * KVZ_HIP_CTU_COEFFS;
     J.sao = sao ? (const kvz::SaoRec *)b->d_sao_recs + (size_t)f0 * ctus * 3 : nullptr; J.sao_merge = sao ? b->d_sao_merge + (size_t)f0 * ctus : nullptr;
-    J.bins = d_bins; J.nbins = d_nbins; J.cap = cap; J.row_ctx = d_rowctx;
+    J.bins = d_bins; J.nbins = d_nbins; J.nbits = d_nbits; J.cap = cap; J.row_ctx = d_rowctx;
     memcpy(J.ctx_init, model->ctx_init, sizeof model->ctx_init < sizeof J.ctx_init ? sizeof model->ctx_init : sizeof J.ctx_init);
     hipLaunchKernelGGL(kvz::dev_entropy_bins_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, b->stream, J, kvz::device_tables(), items);
-    counts.resize((size_t)items);
+    counts.resize((size_t)items); bound_bits.resize((size_t)items);
     KVZ_HIP_CHECK(hipMemcpyAsync(counts.data(), d_nbins, (size_t)items * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
+    KVZ_HIP_CHECK(hipMemcpyAsync(bound_bits.data(), d_nbits, (size_t)items * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
     KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
     uint32_t most = 0;
     for (uint32_t c : counts) most = c > most ? c : most;
-    bool again = most > cap;
+    const bool again = most > cap;
     if (!again) {
-      if (!model->no_wpp) hipLaunchKernelGGL(kvz::dev_entropy_row_ctx_kernel, dim3((unsigned)((nf + 63) / 64)), dim3(64), 0, b->stream, J, kvz::device_tables());
-      hipLaunchKernelGGL(kvz::dev_entropy_code_kernel, dim3((unsigned)((streams + 63) / 64)), dim3(64), 0, b->stream, J, kvz::device_tables(), streams, d_sizes, nullptr, nullptr);
+      // room per substream: the bound of its CTUs' bits, the coder's flush, and an emulation prevention byte after every two bytes at worst
+      bound_offsets.resize((size_t)streams);
+      unsigned long long scratch_bytes = 0;
+      const long per_stream = model->no_wpp ? ctus : F.wc;
+      for (long i = 0; i < streams; i++) {
+        unsigned long long bits = 0;
+        for (long k = 0; k < per_stream; k++) bits += bound_bits[(size_t)(i * per_stream + k)];
+        bound_offsets[(size_t)i] = scratch_bytes;
+        scratch_bytes += (((bits + 7) / 8 + 16) * 3 / 2 + 15) & ~15ull;
+      }
+      KVZ_HIP_CHECK(hipMalloc((void **)&d_scratch, scratch_bytes ? scratch_bytes : 16));
+      KVZ_HIP_CHECK(hipMemcpyAsync(d_bound_offsets, bound_offsets.data(), (size_t)streams * sizeof(unsigned long long), hipMemcpyHostToDevice, b->stream));
+      static const int lanes = [] { const char *e = getenv("KVZ_HIP_ENTROPY_LANES"); const int v = e ? atoi(e) : 16; return v == 64 || v == 32 || v == 8 ? v : 16; }();
+      if (!model->no_wpp) hipLaunchKernelGGL(kvz::dev_entropy_row_ctx_kernel<8>, dim3((unsigned)((nf + 7) / 8)), dim3(8), 0, b->stream, J, kvz::device_tables());
+      {
+        const dim3 grid((unsigned)((streams + lanes - 1) / lanes)), block((unsigned)lanes);
+        if (lanes == 64) hipLaunchKernelGGL(kvz::dev_entropy_code_kernel<64>, grid, block, 0, b->stream, J, kvz::device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
+        else if (lanes == 32) hipLaunchKernelGGL(kvz::dev_entropy_code_kernel<32>, grid, block, 0, b->stream, J, kvz::device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
+        else if (lanes == 8) hipLaunchKernelGGL(kvz::dev_entropy_code_kernel<8>, grid, block, 0, b->stream, J, kvz::device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
+        else hipLaunchKernelGGL(kvz::dev_entropy_code_kernel<16>, grid, block, 0, b->stream, J, kvz::device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
+      }
       sizes.resize((size_t)streams);
       KVZ_HIP_CHECK(hipMemcpyAsync(sizes.data(), d_sizes, (size_t)streams * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
       KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
@@ -1503,24 +1525,26 @@ long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model
       for (long i = 0; i < streams; i++) { offsets[(size_t)i] = chunk_bytes; chunk_bytes += sizes[(size_t)i]; }
       if (total + chunk_bytes > capacity) {
         fprintf(stderr, "kvz_hip_batch_entropy_code: the output buffer is too small (%zu bytes needed so far)\n", (size_t)(total + chunk_bytes));
-        KVZ_HIP_CHECK(hipFree(d_bins)); KVZ_HIP_CHECK(hipFree(d_nbins)); KVZ_HIP_CHECK(hipFree(d_sizes)); KVZ_HIP_CHECK(hipFree(d_offsets)); KVZ_HIP_CHECK(hipFree(d_rowctx));
-        return -1;
+        rc = -1;
+      } else {
+        KVZ_HIP_CHECK(hipMalloc((void **)&d_out, chunk_bytes ? chunk_bytes : 1));
+        KVZ_HIP_CHECK(hipMemcpyAsync(d_offsets, offsets.data(), (size_t)streams * sizeof(unsigned long long), hipMemcpyHostToDevice, b->stream));
+        hipLaunchKernelGGL(kvz::dev_entropy_compact_kernel, dim3((unsigned)streams), dim3(256), 0, b->stream, d_scratch, d_bound_offsets, d_sizes, d_offsets, d_out);
+        KVZ_HIP_CHECK(hipGetLastError());
+        KVZ_HIP_CHECK(hipMemcpyAsync(out + total, d_out, chunk_bytes, hipMemcpyDeviceToHost, b->stream));
+        KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+        memcpy(substream_bytes + (size_t)f0 * rows, sizes.data(), (size_t)streams * sizeof(uint32_t));
+        total += chunk_bytes;
+        KVZ_HIP_CHECK(hipFree(d_out));
+        f0 += nf;
       }
-      KVZ_HIP_CHECK(hipMalloc((void **)&d_out, chunk_bytes ? chunk_bytes : 1));
-      KVZ_HIP_CHECK(hipMemcpyAsync(d_offsets, offsets.data(), (size_t)streams * sizeof(unsigned long long), hipMemcpyHostToDevice, b->stream));
-      hipLaunchKernelGGL(kvz::dev_entropy_code_kernel, dim3((unsigned)((streams + 63) / 64)), dim3(64), 0, b->stream, J, kvz::device_tables(), streams, (uint32_t *)nullptr, d_offsets, d_out);
-      KVZ_HIP_CHECK(hipGetLastError());
-      KVZ_HIP_CHECK(hipMemcpyAsync(out + total, d_out, chunk_bytes, hipMemcpyDeviceToHost, b->stream));
-      KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
-      memcpy(substream_bytes + (size_t)f0 * rows, sizes.data(), (size_t)streams * sizeof(uint32_t));
-      total += chunk_bytes;
-      KVZ_HIP_CHECK(hipFree(d_out));
-      f0 += nf;
+      KVZ_HIP_CHECK(hipFree(d_scratch));
     }
-    KVZ_HIP_CHECK(hipFree(d_bins)); KVZ_HIP_CHECK(hipFree(d_nbins)); KVZ_HIP_CHECK(hipFree(d_sizes)); KVZ_HIP_CHECK(hipFree(d_offsets)); KVZ_HIP_CHECK(hipFree(d_rowctx));
+    KVZ_HIP_CHECK(hipFree(d_bins)); KVZ_HIP_CHECK(hipFree(d_nbins)); KVZ_HIP_CHECK(hipFree(d_nbits)); KVZ_HIP_CHECK(hipFree(d_sizes)); KVZ_HIP_CHECK(hipFree(d_offsets));
+    KVZ_HIP_CHECK(hipFree(d_bound_offsets)); KVZ_HIP_CHECK(hipFree(d_rowctx));
     if (again) cap = (most + 1023u) & ~1023u;  // this chunk again, with room for its largest CTU
   }
-  return (long)total;
+  return rc ? rc : (long)total;
 }
 
 void kvz_hip_dev_picture_md5(const uint8_t *frames, int width, int height, int n_frames, uint8_t *out)

@@ -9,12 +9,13 @@
 // The coder is serial per substream, but its two halves are not equally serial, so the work is cut at the bin:
 //   1. entropy_ctu_bins      one lane per CTU, all CTUs of all pictures at once: walks the CTU's syntax and writes its BINS as 32-bit records -- a context-coded bin
 //                            (context index, value), a run of bypass bins, a terminating bin.  Which context a bin uses never depends on a context's state, so this
-//                            half has no dependency between CTUs at all (neighbour CU depths / modes come from the frame-level maps).
+//                            half has no dependency between CTUs at all (neighbour CU depths / modes come from the frame-level maps).  A CTU's list has a fixed
+//                            capacity (6-9 k records at QP 22, 24 k for noise at QP 12); a list that outgrows it is reported and the host runs the chunk again.
 //   2. entropy_row_contexts  one lane per picture: the context states each CTU row starts from -- the state machine run over the first two CTUs' context-coded bins
 //                            of every row, row after row (with --no-wpp there is nothing to do).
 //   3. entropy_code_row      one lane per substream (picture x CTU row; one per picture without WPP): the arithmetic coder proper over the row's records -- range
-//                            subdivision, renormalisation, carry propagation -- run twice: once counting bytes (the substream sizes, from which the host lays the
-//                            output out compactly) and once writing them.
+//                            subdivision, renormalisation, carry propagation, emulation prevention -- into scratch sized by an upper bound stage 1 keeps
+//                            (6 bits per context-coded bin, 7 per terminating bin, the bypass bins); a copy kernel then packs the substreams back to back.
 // The same functions compile for the host (tests/hostsim) where every lane is a loop iteration.
 #pragma once
 #include "kvz_ops.hpp"
@@ -30,9 +31,10 @@ struct EntropyJob {
   const i16 *coeff;            // [frames][ctu][KVZ_HIP_CTU_COEFFS]
   const SaoRec *sao;           // [frames][ctu][3] packed decisions or null (SAO off)
   const u8 *sao_merge;         // [frames][ctu]: 0 none, 1 left, 2 up
-  u32 *bins;                   // [frames * ctus][cap] records
-  u32 *nbins;                  // [frames * ctus] records the CTU produced (may exceed cap: then the list is truncated and the host retries with a larger cap)
+  u32 *bins;                   // [frames * ctus][cap] records, cap a multiple of 16 (lists are read a 64-byte line at a time)
+  u32 *nbins;                  // [frames * ctus] records the CTU produced; above cap the list is truncated (still counted) and the host runs the chunk again with room
   u32 cap;
+  u32 *nbits;                  // [frames * ctus] upper bound of the bits the CTU's records make the coder emit (sizes the substreams' scratch)
   u8 *row_ctx;                 // [frames][hc][KVZ_ENTROPY_CTXS] context states at the start of every row
   u8 ctx_init[152];            // the slice's initial states (kvz_hip_intra_cost_model::ctx_init)
 };
@@ -43,14 +45,16 @@ struct EntropyJob {
 
 struct BinSink {
   u32 *out; u32 n, cap;
+  u32 bits;  // upper bound of the bits these records make the coder emit: 6 per context-coded bin (the longest renormalisation), 7 per terminating bin, bypass bins as they are
   KVZ_DEV void put(u32 r) { if (n < cap) out[n] = r; n++; }
-  KVZ_DEV void ctx(int c, int v) { put(KVZ_EB_CTX(c, v ? 1 : 0)); }
+  KVZ_DEV void ctx(int c, int v) { put(KVZ_EB_CTX(c, v ? 1 : 0)); bits += 6; }
   KVZ_DEV void ep(u32 value, int bits)  // kvz_cabac_encode_bins_ep: any split of a run into pieces codes the same bytes (the coder's interval arithmetic is exact)
   {
+    this->bits += (u32)bits;
     while (bits > 16) { bits -= 16; put(KVZ_EB_EP(value >> bits, 16)); value &= (1u << bits) - 1; }
     if (bits > 0) put(KVZ_EB_EP(value, bits));
   }
-  KVZ_DEV void trm(int v) { put(KVZ_EB_TRM(v)); }
+  KVZ_DEV void trm(int v) { put(KVZ_EB_TRM(v)); bits += 7; }
 };
 
 KVZ_DEV unsigned entropy_zorder(int x, int y)  // cu.h:385-421 with width 64: Morton index of the 4x4 block times 16
@@ -349,7 +353,7 @@ KVZ_DEV void entropy_ctu_bins(const EntropyJob &J, const Tables *tb, long item)
   const long cells8 = (long)(J.H >> 3) * (J.W >> 3), cells4 = (long)(J.H >> 2) * (J.W >> 2);
   EntropyCtu c{ J, tb, J.depth + f * cells8, J.mode + f * cells8, J.part ? J.part + f * cells8 : nullptr, J.mode4 ? J.mode4 + f * cells4 : nullptr,
                 J.coeff + item * KVZ_HIP_CTU_COEFFS, J.W >> 3, J.W >> 2 };
-  BinSink s{ J.bins + item * J.cap, 0, J.cap };
+  BinSink s{ J.bins + item * J.cap, 0, J.cap, 0 };
   if (J.sao) {  // encode_sao (encoderstate.c:519-552)
     const int merge = J.sao_merge[item];
     if (lx > 0) s.ctx(KVZ_HIP_CX_SAO_MERGE, merge == 1);
@@ -366,10 +370,35 @@ KVZ_DEV void entropy_ctu_bins(const EntropyJob &J, const Tables *tb, long item)
   s.trm(end_of_slice);                                          // end_of_slice_segment_flag (encoderstate.c:699-712)
   if (!J.no_wpp && last_col && !end_of_slice) s.trm(1);         // end_of_subset_one_bit
   J.nbins[item] = s.n;
+  J.nbits[item] = s.bits;
 }
 
+// Four records per load: a lane walks its own list, so what bounds it is the latency of its loads -- 16 bytes at a time, the next four requested before these are coded
+struct alignas(16) Rec4 { u32 v[4]; };
+struct Rec16 {  // one 64-byte line of a list, consumed front first: next() shifts the rest down (register moves; indexing the line with a variable would put it in scratch)
+  u32 w[16];
+  KVZ_DEV u32 next()
+  {
+    const u32 r = w[0];
+#pragma unroll
+    for (int k = 0; k < 15; k++) w[k] = w[k + 1];
+    return r;
+  }
+};
+KVZ_DEV Rec16 entropy_load16(const Rec4 *b, u32 block)
+{
+  Rec16 r;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { const Rec4 q = b[4 * block + k]; r.w[4 * k] = q.v[0]; r.w[4 * k + 1] = q.v[1]; r.w[4 * k + 2] = q.v[2]; r.w[4 * k + 3] = q.v[3]; }
+  return r;
+}
+struct EntropyTabs {       // where the coder's two tables live: LDS copies on the device, the originals on the host
+  const u8 *next;          // Tables::ctx_next as [2][128]
+  const u32 *lps;          // kLpsPacked
+};
+
 // stage 2: the contexts every row of picture f starts from (WPP)
-KVZ_DEV void entropy_row_contexts(const EntropyJob &J, const Tables *tb, int f, u8 *ctx /* KVZ_ENTROPY_CTXS bytes of work memory */)
+KVZ_DEV void entropy_row_contexts(const EntropyJob &J, const EntropyTabs T, int f, u8 *ctx /* KVZ_ENTROPY_CTXS bytes of work memory */)
 {
   const int ctus = J.wc * J.hc;
   u8 *out = J.row_ctx + (long)f * J.hc * KVZ_ENTROPY_CTXS;
@@ -378,12 +407,20 @@ KVZ_DEV void entropy_row_contexts(const EntropyJob &J, const Tables *tb, int f, 
     if (J.wc >= 2) {  // a picture one CTU wide never reaches "lcu->index == 1": its rows keep the slice's initial states
       for (int x = 0; x < 2; x++) {
         const long item = (long)f * ctus + r * J.wc + x;
-        const u32 *b = J.bins + item * J.cap, n = J.nbins[item] < J.cap ? J.nbins[item] : J.cap;
-        for (u32 i = 0; i < n; i++) {
-          const u32 rec = b[i];
-          if (rec >> 30) continue;
-          const int c = (int)(rec & 0xff), bin = (int)((rec >> 8) & 1), st = ctx[c];
-          ctx[c] = tb->ctx_next[bin != (st & 1)][st];
+        const Rec4 *b = (const Rec4 *)(J.bins + item * J.cap);
+        const u32 n = J.nbins[item] < J.cap ? J.nbins[item] : J.cap;
+        Rec16 cur = entropy_load16(b, 0);  // (capacities are multiples of 16 records: a whole line is always there to read)
+        for (u32 i0 = 0; i0 < n; i0 += 16) {
+          const Rec16 nxt = i0 + 16 < n ? entropy_load16(b, (i0 >> 4) + 1) : cur;
+          const u32 m = n - i0 < 16 ? n - i0 : 16;
+#pragma unroll
+          for (u32 k = 0; k < 16; k++) {  // unrolled: the line stays in registers under constant indices, and the body is three LDS accesses
+            const u32 rec = cur.w[k];
+            if (k >= m || (rec >> 30)) continue;
+            const int c = (int)(rec & 0xff), bin = (int)((rec >> 8) & 1), st = ctx[c];
+            ctx[c] = T.next[(bin != (st & 1) ? 128 : 0) + st];
+          }
+          cur = nxt;
         }
       }
     } else {
@@ -399,8 +436,16 @@ struct ArithCoder {
   int bits_left, num_buffered_bytes;
   u8 *out;   // null: count only
   u32 n;
-  KVZ_DEV void start() { low = 0; range = 510; bits_left = 23; num_buffered_bytes = 0; buffered_byte = 0xff; }
-  KVZ_DEV void put_byte(u32 b) { if (out) out[n] = (u8)b; n++; }
+  int zerocount;
+  KVZ_DEV void start() { low = 0; range = 510; bits_left = 23; num_buffered_bytes = 0; buffered_byte = 0xff; zerocount = 0; }
+  KVZ_DEV void raw_byte(u32 b) { if (out) out[n] = (u8)b; n++; }
+  KVZ_DEV void put_byte(u32 b)  // kvz_bitstream_put_byte (bitstream.c:212-223): emulation prevention as the substream is written
+  {
+    b &= 0xff;
+    if (zerocount == 2 && b < 4) { raw_byte(3); zerocount = 0; }
+    zerocount = b == 0 ? zerocount + 1 : 0;
+    raw_byte(b);
+  }
   KVZ_DEV void write()  // kvz_cabac_write
   {
     const u32 lead_byte = low >> (24 - bits_left);
@@ -453,8 +498,49 @@ __device__ const u32 kLpsPacked[64] = {
   0x0D0B0908u, 0x0C0B0907u, 0x0C0A0907u, 0x0B0A0807u, 0x0B090806u, 0x0A090706u, 0x09080706u, 0x02020202u };
 KVZ_DEV u32 entropy_lps_row(int state) { return kLpsPacked[state]; }
 
+// one record through the coder (cabac.c:104-133 kvz_cabac_encode_bin, :231-254 kvz_cabac_encode_bins_ep, :193-210 kvz_cabac_encode_bin_trm)
+KVZ_DEV void entropy_code_record(ArithCoder &a, u8 *ctx, const EntropyTabs T, u32 rec)
+{
+  const u32 kind = rec >> 30;
+  if (kind == 0) {
+    const int c = (int)(rec & 0xff), bin = (int)((rec >> 8) & 1), st = ctx[c];
+    const u32 lps = (T.lps[st >> 1] >> (8 * ((a.range >> 6) & 3))) & 0xff;
+    a.range -= lps;
+    if (bin != (st & 1)) {
+      const int num_bits = lps < 8 ? 6 : (int)__builtin_clz(lps) - 23;  // kvz_g_auc_renorm_table[lps >> 3] (cabac.c:84-88): the shift that brings lps back to >= 256
+      a.low = (a.low + a.range) << num_bits;
+      a.range = lps << num_bits;
+      a.bits_left -= num_bits;
+      ctx[c] = T.next[128 + st];
+    } else {
+      ctx[c] = T.next[st];
+      if (a.range >= 256) return;
+      a.low <<= 1; a.range <<= 1; a.bits_left--;
+    }
+  } else if (kind == 1) {
+    int nb = (int)((rec >> 16) & 0x3f);
+    u32 v = rec & 0xffff;
+    if (nb > 8) {
+      nb -= 8;
+      const u32 pattern = v >> nb;
+      a.low = (a.low << 8) + a.range * pattern;
+      v -= pattern << nb;
+      a.bits_left -= 8;
+      if (a.bits_left < 12) a.write();
+    }
+    a.low = (a.low << nb) + a.range * v;
+    a.bits_left -= nb;
+  } else {
+    a.range -= 2;
+    if (rec & 1) { a.low += a.range; a.low <<= 7; a.range = 2 << 7; a.bits_left -= 7; }
+    else if (a.range >= 256) return;
+    else { a.low <<= 1; a.range <<= 1; a.bits_left--; }
+  }
+  if (a.bits_left < 12) a.write();
+}
+
 // stage 3: the substream `item` -- (picture, CTU row) with WPP, the picture without; returns its size in bytes.  ctx: KVZ_ENTROPY_CTXS bytes of work memory
-KVZ_DEV u32 entropy_code_row(const EntropyJob &J, const Tables *tb, long item, u8 *ctx, u8 *out)
+KVZ_DEV u32 entropy_code_row(const EntropyJob &J, const EntropyTabs T, long item, u8 *ctx, u8 *out)
 {
   const int ctus = J.wc * J.hc;
   const int f = J.no_wpp ? (int)item : (int)(item / J.hc), row = J.no_wpp ? 0 : (int)(item - (long)f * J.hc);
@@ -465,44 +551,15 @@ KVZ_DEV u32 entropy_code_row(const EntropyJob &J, const Tables *tb, long item, u
   a.out = out; a.n = 0;
   a.start();
   for (long k = 0; k < count; k++) {
-    const u32 *b = J.bins + (first + k) * J.cap, n = J.nbins[first + k] < J.cap ? J.nbins[first + k] : J.cap;
-    for (u32 i = 0; i < n; i++) {
-      const u32 rec = b[i], kind = rec >> 30;
-      if (kind == 0) {  // kvz_cabac_encode_bin
-        const int c = (int)(rec & 0xff), bin = (int)((rec >> 8) & 1), st = ctx[c];
-        const u32 lps = (entropy_lps_row(st >> 1) >> (8 * ((a.range >> 6) & 3))) & 0xff;
-        a.range -= lps;
-        if (bin != (st & 1)) {
-          const int num_bits = lps < 8 ? 6 : (int)__builtin_clz(lps) - 23;  // kvz_g_auc_renorm_table[lps >> 3] (cabac.c:84-88): the shift that brings lps back to >= 256
-          a.low = (a.low + a.range) << num_bits;
-          a.range = lps << num_bits;
-          a.bits_left -= num_bits;
-          ctx[c] = tb->ctx_next[1][st];
-        } else {
-          ctx[c] = tb->ctx_next[0][st];
-          if (a.range >= 256) continue;
-          a.low <<= 1; a.range <<= 1; a.bits_left--;
-        }
-      } else if (kind == 1) {  // kvz_cabac_encode_bins_ep
-        int nb = (int)((rec >> 16) & 0x3f);
-        u32 v = rec & 0xffff;
-        if (nb > 8) {
-          nb -= 8;
-          const u32 pattern = v >> nb;
-          a.low = (a.low << 8) + a.range * pattern;
-          v -= pattern << nb;
-          a.bits_left -= 8;
-          if (a.bits_left < 12) a.write();
-        }
-        a.low = (a.low << nb) + a.range * v;
-        a.bits_left -= nb;
-      } else {  // kvz_cabac_encode_bin_trm
-        a.range -= 2;
-        if (rec & 1) { a.low += a.range; a.low <<= 7; a.range = 2 << 7; a.bits_left -= 7; }
-        else if (a.range >= 256) continue;
-        else { a.low <<= 1; a.range <<= 1; a.bits_left--; }
-      }
-      if (a.bits_left < 12) a.write();
+    const Rec4 *b = (const Rec4 *)(J.bins + (first + k) * J.cap);
+    const u32 n = J.nbins[first + k] < J.cap ? J.nbins[first + k] : J.cap;
+    Rec16 cur = entropy_load16(b, 0);
+    for (u32 i0 = 0; i0 < n; i0 += 16) {
+      const Rec16 nxt = i0 + 16 < n ? entropy_load16(b, (i0 >> 4) + 1) : cur;
+      const u32 m = n - i0 < 16 ? n - i0 : 16;
+#pragma unroll 1
+      for (u32 q = 0; q < m; q++) entropy_code_record(a, ctx, T, cur.next());
+      cur = nxt;
     }
   }
   a.finish_and_align();
@@ -515,20 +572,43 @@ __global__ void __launch_bounds__(64) dev_entropy_bins_kernel(const EntropyJob J
   const long item = (long)blockIdx.x * 64 + threadIdx.x;
   if (item < total) entropy_ctu_bins(J, tb, item);
 }
-__global__ void __launch_bounds__(64) dev_entropy_row_ctx_kernel(const EntropyJob J, const Tables *tb)
+// Lanes per workgroup of the two serial stages: every lane runs a long dependent chain of its own (its list's records, its coder's state), so what fills the chip is
+// the number of wavefronts, not their width -- 16 lanes per wavefront gives four times as many of them and a quarter of the divergence inside each
+template <int LANES> struct EntropyLds {
+  u8 ctx[LANES][KVZ_ENTROPY_CTXS];
+  u8 next[256];
+  u32 lps[64];
+};
+template <int LANES> KVZ_DEV EntropyTabs entropy_stage_tables(EntropyLds<LANES> *L, const Tables *tb)
 {
-  __shared__ u8 ctx[64][KVZ_ENTROPY_CTXS];
-  const int f = blockIdx.x * 64 + threadIdx.x;
-  if (f < J.n_frames) entropy_row_contexts(J, tb, f, ctx[threadIdx.x]);
+  for (int i = threadIdx.x; i < 256; i += LANES) L->next[i] = tb->ctx_next[i >> 7][i & 127];
+  for (int i = threadIdx.x; i < 64; i += LANES) L->lps[i] = kLpsPacked[i];
+  __syncthreads();
+  return EntropyTabs{ L->next, L->lps };
 }
-// sizes != null: count (out unused); else write every substream at out + offsets[item]
-__global__ void __launch_bounds__(64) dev_entropy_code_kernel(const EntropyJob J, const Tables *tb, long total, u32 *sizes, const unsigned long long *offsets, u8 *out)
+template <int LANES> __global__ void __launch_bounds__(LANES) dev_entropy_row_ctx_kernel(const EntropyJob J, const Tables *tb)
 {
-  __shared__ u8 ctx[64][KVZ_ENTROPY_CTXS];
-  const long item = (long)blockIdx.x * 64 + threadIdx.x;
+  __shared__ EntropyLds<LANES> L;
+  const EntropyTabs T = entropy_stage_tables(&L, tb);
+  const int f = blockIdx.x * LANES + threadIdx.x;
+  if (f < J.n_frames) entropy_row_contexts(J, T, f, L.ctx[threadIdx.x]);
+}
+// every substream coded once, at out + offsets[item] (room for its upper bound); sizes: what it came to
+template <int LANES> __global__ void __launch_bounds__(LANES) dev_entropy_code_kernel(const EntropyJob J, const Tables *tb, long total, u32 *sizes, const unsigned long long *offsets, u8 *out)
+{
+  __shared__ EntropyLds<LANES> L;
+  const EntropyTabs T = entropy_stage_tables(&L, tb);
+  const long item = (long)blockIdx.x * LANES + threadIdx.x;
   if (item >= total) return;
-  if (sizes) sizes[item] = entropy_code_row(J, tb, item, ctx[threadIdx.x], nullptr);
-  else entropy_code_row(J, tb, item, ctx[threadIdx.x], out + offsets[item]);
+  sizes[item] = entropy_code_row(J, T, item, L.ctx[threadIdx.x], out + offsets[item]);
+}
+// ... and moved back to back: one workgroup per substream
+__global__ void __launch_bounds__(256) dev_entropy_compact_kernel(const u8 *src, const unsigned long long *src_off, const u32 *sizes, const unsigned long long *dst_off, u8 *dst)
+{
+  const u8 *s = src + src_off[blockIdx.x];
+  u8 *d = dst + dst_off[blockIdx.x];
+  const u32 n = sizes[blockIdx.x];
+  for (u32 i = threadIdx.x; i < n; i += 256) d[i] = s[i];
 }
 #endif
 

@@ -296,7 +296,7 @@ def update_entropy():
     import entropy_common as ec
     oracle = flatapi.load_oracle()
     out = {}
-    for case in ec.CASES:
+    for case in ec.CASES + ec.BENCH_CASES:
         with tempfile.TemporaryDirectory() as d:
             payloads = ec.reference_slice_payloads(os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "kvazaar_ref"), case, d)
         pictures = []

@@ -188,23 +188,30 @@ extern "C" long kvz_hostsim_entropy_code(const kvz_hip_intra_cost_model *m, int 
   J.W = width; J.H = height; J.wc = (width + 63) / 64; J.hc = (height + 63) / 64; J.n_frames = n_frames; J.no_wpp = m->no_wpp;
   J.depth = cu_depth; J.mode = cu_mode; J.part = part; J.mode4 = mode4; J.coeff = coeff; J.sao = sao_recs; J.sao_merge = sao_merge;
   const long items = (long)n_frames * J.wc * J.hc, streams = (long)n_frames * (m->no_wpp ? 1 : J.hc);
-  J.bins = (uint32_t *)malloc((size_t)items * cap * sizeof(uint32_t)); J.nbins = (uint32_t *)malloc((size_t)items * sizeof(uint32_t)); J.cap = cap;
+  cap = (cap + 15u) & ~15u;
+  J.bins = (uint32_t *)aligned_alloc(64, (size_t)items * cap * sizeof(uint32_t)); J.nbins = (uint32_t *)malloc((size_t)items * sizeof(uint32_t)); J.nbits = (uint32_t *)malloc((size_t)items * sizeof(uint32_t)); J.cap = cap;
   J.row_ctx = (uint8_t *)malloc((size_t)n_frames * J.hc * KVZ_ENTROPY_CTXS);
   memcpy(J.ctx_init, m->ctx_init, sizeof m->ctx_init < sizeof J.ctx_init ? sizeof m->ctx_init : sizeof J.ctx_init);
+  const kvz::EntropyTabs T{ &tb.ctx_next[0][0], kvz::kLpsPacked };
   uint8_t ctx[KVZ_ENTROPY_CTXS];
   *most_records = 0;
   for (long i = 0; i < items; i++) { kvz::entropy_ctu_bins(J, &tb, i); if (J.nbins[i] > *most_records) *most_records = J.nbins[i]; }
   long total = -1;
   if (*most_records <= cap) {
-    if (!m->no_wpp) for (int f = 0; f < n_frames; f++) kvz::entropy_row_contexts(J, &tb, f, ctx);
+    if (!m->no_wpp) for (int f = 0; f < n_frames; f++) kvz::entropy_row_contexts(J, T, f, ctx);
     total = 0;
     for (long i = 0; i < streams; i++) {
-      const uint32_t counted = kvz::entropy_code_row(J, &tb, i, ctx, nullptr);
-      substream_bytes[i] = kvz::entropy_code_row(J, &tb, i, ctx, out + total);
+      const uint32_t counted = kvz::entropy_code_row(J, T, i, ctx, nullptr);
+      substream_bytes[i] = kvz::entropy_code_row(J, T, i, ctx, out + total);
+      // the bound the device sizes its scratch with (kvz_hip_batch_entropy_code) must hold
+      unsigned long long bits = 0;
+      const long per_stream = m->no_wpp ? (long)J.wc * J.hc : J.wc;
+      for (long k = 0; k < per_stream; k++) bits += J.nbits[i * per_stream + k];
       if (counted != substream_bytes[i]) { total = -2; break; }
+      if (substream_bytes[i] > ((bits + 7) / 8 + 16) * 3 / 2) { total = -3; break; }
       total += substream_bytes[i];
     }
   }
-  free(J.bins); free(J.nbins); free(J.row_ctx);
+  free(J.bins); free(J.nbins); free(J.nbits); free(J.row_ctx);
   return total;
 }

@@ -46,7 +46,7 @@ def test_byte_stream_splitter_removes_emulation_prevention():
     stream = bytes([0, 0, 0, 1, 0x40, 1, 0xAA, 0, 0, 3, 1, 0xBB, 0, 0, 1, 0x26, 1, 0x11, 0, 0, 3, 0, 0, 3, 2])
     units = ec.nal_units(stream)
     assert units == [(32, bytes([0xAA, 0, 0, 1, 0xBB])), (19, bytes([0x11, 0, 0, 0, 0, 2]))]
-    assert ec.slice_payloads(stream) == [bytes([0x11, 0, 0, 0, 0, 2])]
+    assert ec.slice_payloads(stream) == [bytes([0x11, 0, 0, 3, 0, 0, 3, 2])]
     assert ec.ue_bits(0) == "1" and ec.ue_bits(3) == "00100"
 
 

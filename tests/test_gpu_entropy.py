@@ -39,7 +39,7 @@ def split(data, sizes):
     return out
 
 
-@pytest.mark.parametrize("case", ec.CASES, ids=[c[0] for c in ec.CASES])
+@pytest.mark.parametrize("case", ec.CASES + ec.BENCH_CASES, ids=[c[0] for c in ec.CASES + ec.BENCH_CASES])
 def test_device_slice_data_equals_the_reference_encoders(case):
     import kvazaar_amd
     from kvazaar_amd.batch import HipBatch
