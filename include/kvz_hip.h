@@ -115,6 +115,12 @@ int      kvz_hip_quantize_residual_rdoq(const kvz_hip_quant_params *p, double la
                                         int in_stride, int out_stride, const uint8_t *ref_in, const uint8_t *pred_in, uint8_t *rec_out, int16_t *coeff_out, int early_skip);
 void     kvz_hip_rdoq_blocks(int qp, double lambda, const uint8_t *ctx_states, const int16_t *coef, int16_t *dest, int width, int type, int scan_mode, int tr_depth, int count);
 void     kvz_hip_plane_md5(const uint8_t *data, int height, int width, int stride, uint8_t *out16);       /* nal-generic.c:41-55, the 16 digest bytes */
+/* strategies-encode.h:49-65 kvz_encode_coeff_nxn (strategies/generic/encode_coding_tree-generic.c:40-283), the part that does not touch the coder's state: the residual
+ * syntax of one width x width block (type 0 luma / 2 chroma; scan_mode 0 diagonal, 1 horizontal, 2 vertical; sign hiding, transform skip and encryption off) as bin
+ * records -- context-coded bin: context index (KVZ_HIP_CX_* of kvz_hip_types.h) | value << 8; bypass run: 1 << 30 | bins << 16 | value (16 bins at most per record,
+ * most significant first); -- in coding order.  The caller drives its cabac_data_t with them (integration/kvazaar/strategies/hip/encode-hip.c).  Returns the number of
+ * records of the block; at most `capacity` are written. */
+int kvz_hip_coeff_nxn_bins(const int16_t *coeff, int width, int type, int scan_mode, uint32_t *records, int capacity);
 uint32_t kvz_hip_plane_checksum(const uint8_t *data, int height, int width, int stride);            /* nal-generic.c:57-82, the 32-bit sum */
 uint32_t kvz_hip_coeff_abs_sum(const int16_t *coeffs, size_t length);                        /* quant-generic.c:342-349 */
 double   kvz_hip_fast_coeff_cost(const int16_t *coeff, int32_t width, uint64_t weights);     /* :359-375 */

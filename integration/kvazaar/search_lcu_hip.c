@@ -27,6 +27,7 @@
 #include "encoder.h"
 #include "encoderstate.h"
 #include "fast_coeff_cost.h"
+#include "bitstream.h"
 #include "image.h"
 #include "videoframe.h"
 
@@ -34,7 +35,10 @@
 #include "kvz_hip_dev.h"
 
 void __real_kvz_search_lcu(encoder_state_t *const state, const int x, const int y, const yuv_t *const hor_buf, const yuv_t *const ver_buf);
+void __real_kvz_encode_coding_tree(encoder_state_t *const state, uint16_t x, uint16_t y, uint8_t depth);
+void __real_kvz_encoder_state_worker_write_bitstream(void *opaque);
 
+#define KVZ_HIP_MAX_LCU_ROWS 136  /* 8192 / 64 + a margin */
 typedef struct {
   const videoframe_t *frame;  /* key: the (tile) frame and the picture it holds */
   int32_t num;
@@ -43,11 +47,18 @@ typedef struct {
   uint8_t *rec, *depth, *mode; /* tight planes Y|U|V; one byte per 8x8 (pinned) */
   uint8_t *part, *mode4;       /* model.search_nxn: NxN flag per 8x8 CU, luma mode per 4x4 unit */
   int16_t *coeff;              /* KVZ_HIP_CTU_COEFFS per LCU, raster LCU order */
+  /* KVZ_HIP_BATCH_ENTROPY=1: the picture's slice data, coded on the device (kvz_hip_batch_entropy_code) -- one substream per LCU row (WPP) or one for the picture;
+   * then the levels stay on the device, kvz_encode_coding_tree is skipped and the row coders' streams are replaced by these bytes before the slice header is written */
+  uint8_t *ent; size_t ent_cap;
+  uint32_t ent_sizes[KVZ_HIP_MAX_LCU_ROWS];
+  int ent_ready;               /* this picture's slice data is in ent */
+  int ent_hold;                /* ... and has not been handed to the bitstream yet: the slot must not be reused */
   kvz_hip_intra_cost_model model;
   int state;                   /* FREE -> PENDING (registered, waiting for a pass) -> COMPUTING (in the leader's batch) -> READY */
   int outstanding;             /* LCUs of the picture that have not copied their part yet; the slot is only reused at 0 (under g_lock) */
 } picture_result;
 enum { SLOT_FREE = 0, SLOT_PENDING, SLOT_COMPUTING, SLOT_READY };
+static int g_entropy = -1;  /* KVZ_HIP_BATCH_ENTROPY */
 
 /* One slot per picture in flight: (owf + 1) x tiles of them at most, so the table grows on demand and a slot is never recycled
  * while an LCU of its picture is still to come (every LCU of a picture passes through kvz_search_lcu exactly once).
@@ -115,6 +126,8 @@ static int env_int(const char *name, int dflt)
 }
 
 /* the leader's work: one pass over `n` gathered pictures (same geometry and model) */
+static kvz_hip_batch *g_last_batch;  /* the batch object run_pictures used (the leader codes its pictures afterwards) */
+static int g_last_batch_capacity;
 static void run_pictures(picture_result **list, int n)
 {
   const int w = list[0]->width, h = list[0]->height;
@@ -130,14 +143,16 @@ static void run_pictures(picture_result **list, int n)
     if (!g_batches[bi]) { fprintf(stderr, "search_lcu_hip: cannot create a %dx%d batch of %d pictures\n", w, h, g_batch_sizes[bi]); abort(); }
   }
   kvz_hip_batch *b = g_batches[bi];
+  g_last_batch = b; g_last_batch_capacity = g_batch_sizes[bi];
   /* slots beyond n keep whatever picture they held last: searched again, never read */
   for (int i = 0; i < n; i++) kvz_hip_batch_upload(b, i, list[i]->src, list[i]->src + ys, list[i]->src + ys + cs);
   if (kvz_hip_intra_frames(b, &list[0]->model) < 0) { fprintf(stderr, "search_lcu_hip: the library cannot run this model\n"); abort(); }
   /* the library reports an invalid run instead of aborting; this binding has no other search to fall back to for pictures whose
    * LCUs are already being handed out, so it stops the encoder */
   int bad = kvz_hip_batch_sync(b) != 0;
+  const int entropy = g_entropy > 0 && list[0]->ent_hold;  /* (set with the slot: the configuration has no SAO syntax) */
   for (int i = 0; i < n && !bad; i++)
-    bad = kvz_hip_batch_download(b, i, list[i]->rec, list[i]->rec + ys, list[i]->rec + ys + cs, list[i]->coeff, list[i]->depth, list[i]->mode, NULL) != 0;
+    bad = kvz_hip_batch_download(b, i, list[i]->rec, list[i]->rec + ys, list[i]->rec + ys + cs, entropy ? NULL : list[i]->coeff, list[i]->depth, list[i]->mode, NULL) != 0;
   for (int i = 0; i < n && !bad && list[0]->model.search_nxn; i++) bad = kvz_hip_batch_download_partitions(b, i, list[i]->part, list[i]->mode4) != 0;
   if (bad) { fprintf(stderr, "search_lcu_hip: the device pass failed\n"); abort(); }
   {  /* KVZ_HIP_BATCH_TRACE=<file>: "pictures passes largest-batch" so far (tests check the path was taken, and that pictures were gathered) */
@@ -146,6 +161,36 @@ static void run_pictures(picture_result **list, int n)
     pictures += n; passes++;
     if (n > largest) largest = n;
     if (trace) { FILE *f = fopen(trace, "w"); if (f) { fprintf(f, "%d %d %d\n", pictures, passes, largest); fclose(f); } }
+  }
+}
+
+/* the leader, after the pictures' LCUs have been released to the workers: the slice data of the same pictures (nothing needs it before the frame's bitstream is written) */
+static void run_entropy(picture_result **list, int n)
+{
+  kvz_hip_batch *b = g_last_batch;
+  const int w = list[0]->width, h = list[0]->height;
+  /* every picture of the batch object is coded (slots beyond n hold older pictures); only the first n are read */
+  const int cap_n = g_last_batch_capacity, rows = list[0]->model.no_wpp ? 1 : (h + 63) / 64;
+  const size_t cap = (size_t)cap_n * ((size_t)w * h * 2 + 65536);
+  static uint8_t *all; static size_t all_cap; static uint32_t *sizes; static size_t sizes_cap;
+  if (all_cap < cap) { free(all); all = malloc(cap); all_cap = cap; }
+  if (sizes_cap < (size_t)cap_n * rows) { free(sizes); sizes = malloc((size_t)cap_n * rows * sizeof *sizes); sizes_cap = (size_t)cap_n * rows; }
+  if (!all || !sizes || rows > KVZ_HIP_MAX_LCU_ROWS) { fprintf(stderr, "search_lcu_hip: out of memory\n"); abort(); }
+  if (kvz_hip_batch_entropy_code(b, &list[0]->model, 0, all, cap, sizes) < 0) { fprintf(stderr, "search_lcu_hip: the device entropy coder failed\n"); abort(); }
+  size_t at = 0;
+  for (int i = 0; i < n; i++) {
+    size_t bytes = 0;
+    for (int r = 0; r < rows; r++) { list[i]->ent_sizes[r] = sizes[(size_t)i * rows + r]; bytes += sizes[(size_t)i * rows + r]; }
+    if (list[i]->ent_cap < bytes) { free(list[i]->ent); list[i]->ent = malloc(bytes); list[i]->ent_cap = bytes; }
+    if (!list[i]->ent) { fprintf(stderr, "search_lcu_hip: out of memory\n"); abort(); }
+    memcpy(list[i]->ent, all + at, bytes);
+    at += bytes;
+  }
+  {  /* KVZ_HIP_ENTROPY_TRACE=<file>: pictures whose slice data the device has written so far */
+    static int coded;
+    const char *trace = getenv("KVZ_HIP_ENTROPY_TRACE");
+    coded += n;
+    if (trace) { FILE *f = fopen(trace, "w"); if (f) { fprintf(f, "%d\n", coded); fclose(f); } }
   }
 }
 
@@ -159,7 +204,7 @@ static picture_result *picture_of(const encoder_state_t *state)
     if (g_slots[i]->outstanding > 0 && g_slots[i]->frame == frame && g_slots[i]->num == state->frame->num) r = g_slots[i];
   if (!r) {
     for (int i = 0; i < g_n_slots && !r; i++)
-      if (g_slots[i]->outstanding == 0) r = g_slots[i];
+      if (g_slots[i]->outstanding == 0 && !g_slots[i]->ent_hold) r = g_slots[i];
     if (!r) {
       picture_result **grown = realloc(g_slots, (size_t)(g_n_slots + 1) * sizeof *g_slots);
       r = grown ? calloc(1, sizeof *r) : NULL;
@@ -183,6 +228,12 @@ static picture_result *picture_of(const encoder_state_t *state)
     }
     r->frame = frame; r->num = state->frame->num; r->qp = state->qp;
     r->outstanding = wc * hc;
+    if (g_entropy < 0) { const char *e = getenv("KVZ_HIP_BATCH_ENTROPY"); g_entropy = e ? atoi(e) : 0; }
+    r->ent_ready = 0;
+    /* the device writes the slice data of configurations whose LCUs carry no SAO syntax (the SAO decision is made on the host here), with one slice per picture and
+     * no tiles (a tile that is not the slice's last ends in end_of_subset_one_bit instead of end_of_slice_segment_flag: kvz_hip_batch_entropy_code codes whole pictures) */
+    r->ent_hold = g_entropy > 0 && state->encoder_control->cfg.sao_type == 0 && state->encoder_control->cfg.slices == KVZ_SLICES_NONE &&
+                  state->encoder_control->cfg.tiles_width_count * state->encoder_control->cfg.tiles_height_count <= 1;
     r->state = SLOT_PENDING;
     const kvz_config *cfg = &state->encoder_control->cfg;
     kvz_hip_intra_cost_model_init(state->qp, kvz_fast_coeff_get_weights(state), &r->model);
@@ -243,6 +294,13 @@ static picture_result *picture_of(const encoder_state_t *state)
       run_pictures(list, n);
       pthread_mutex_lock(&g_lock);
       for (int i = 0; i < n; i++) list[i]->state = SLOT_READY;
+      pthread_cond_broadcast(&g_cond);
+      if (g_entropy > 0 && list[0]->ent_hold) {  /* the LCUs go out now; the device codes the pictures meanwhile, and the next pass waits for that */
+        pthread_mutex_unlock(&g_lock);
+        run_entropy(list, n);
+        pthread_mutex_lock(&g_lock);
+        for (int i = 0; i < n; i++) list[i]->ent_ready = 1;
+      }
       g_leader_active = 0;
       pthread_cond_broadcast(&g_cond);
     } else {
@@ -400,6 +458,90 @@ static void search_lcu_inter(encoder_state_t *state, int x, int y)
   copy_rec_and_coeff(state, x, y, w, h, g_inter.rec, g_inter.coeff + (size_t)((y / 64) * wc + x / 64) * KVZ_HIP_CTU_COEFFS);
 }
 
+/* The LCU's part of a picture whose slice data the device has written: CU info (depth, modes, partition) for the loop filters and for the neighbours' sake, the
+ * reconstruction -- no levels, no coded block flags: their only reader, kvz_encode_coding_tree, does not run for this picture (deblocking of intra CUs is strength 2
+ * whatever the flags, filter.c:405-431). */
+static void search_lcu_without_levels(encoder_state_t *state, picture_result *r, int x, int y)
+{
+  videoframe_t *frame = state->tile->frame;
+  const int w = r->width, h = r->height, w8 = w / 8;
+  for (int yy = 0; yy < 64 && y + yy < h; yy += 8)
+    for (int xx = 0; xx < 64 && x + xx < w; xx += 8) {
+      const int depth = r->depth[((y + yy) / 8) * w8 + (x + xx) / 8], mode = r->mode[((y + yy) / 8) * w8 + (x + xx) / 8];
+      const int nxn = r->model.search_nxn && r->part[((y + yy) / 8) * w8 + (x + xx) / 8];
+      for (int sy = 0; sy < 8; sy += 4)
+        for (int sx = 0; sx < 8; sx += 4) {
+          cu_info_t *cu = kvz_cu_array_at(frame->cu_array, x + xx + sx, y + yy + sy);
+          const int pm = nxn ? r->mode4[((y + yy + sy) / 4) * (w / 4) + (x + xx + sx) / 4] : mode;
+          memset(cu, 0, sizeof *cu);
+          cu->type = CU_INTRA; cu->depth = nxn ? 3 : depth; cu->part_size = nxn ? SIZE_NxN : SIZE_2Nx2N; cu->tr_depth = nxn ? 4 : (depth > 0 ? depth : 1);
+          cu->qp = (uint8_t)state->qp; cu->intra.mode = (int8_t)pm; cu->intra.mode_chroma = (int8_t)pm;
+        }
+    }
+  static const int16_t no_levels[KVZ_HIP_CTU_COEFFS];
+  copy_rec_and_coeff(state, x, y, w, h, r->rec, no_levels);
+  pthread_mutex_lock(&g_lock);
+  r->outstanding--;
+  pthread_mutex_unlock(&g_lock);
+}
+
+/* kvz_encode_coding_tree (encode_coding_tree.c:745) is what encoder_state_worker_encode_lcu_bitstream spends its time in; for pictures the device has coded it has
+ * nothing to do (the few bins the worker still writes around it -- end_of_slice_segment_flag, the substream's flush -- go into streams that are replaced below) */
+void __wrap_kvz_encode_coding_tree(encoder_state_t *const state, uint16_t x, uint16_t y, uint8_t depth)
+{
+  if (g_entropy > 0 && depth == 0) {
+    const videoframe_t *frame = state->tile->frame;
+    int coded = 0;
+    pthread_mutex_lock(&g_lock);
+    for (int i = 0; i < g_n_slots && !coded; i++) coded = g_slots[i]->ent_hold && g_slots[i]->frame == frame && g_slots[i]->num == state->frame->num;
+    pthread_mutex_unlock(&g_lock);
+    if (coded) return;
+  }
+  __real_kvz_encode_coding_tree(state, x, y, depth);
+}
+
+/* the leaves of a frame's encoder-state tree, in the order the bitstream takes them: replace what the host coders wrote by the device's substreams */
+static void replace_leaf_streams(encoder_state_t *state)
+{
+  if (!state->is_leaf) {
+    for (int i = 0; state->children[i].encoder_control; ++i) replace_leaf_streams(&state->children[i]);
+    return;
+  }
+  const videoframe_t *frame = state->tile->frame;
+  picture_result *r = NULL;
+  pthread_mutex_lock(&g_lock);
+  for (int i = 0; i < g_n_slots && !r; i++)
+    if (g_slots[i]->ent_hold && g_slots[i]->frame == frame && g_slots[i]->num == state->frame->num) r = g_slots[i];
+  while (r && !r->ent_ready) pthread_cond_wait(&g_cond, &g_lock);  /* the leader is still coding the batch this picture was in */
+  pthread_mutex_unlock(&g_lock);
+  if (!r) return;
+  const int row = (state->type == ENCODER_STATE_TYPE_WAVEFRONT_ROW && !r->model.no_wpp) ? state->wfrow->lcu_offset_y : 0;
+  size_t at = 0;
+  for (int k = 0; k < row; k++) at += r->ent_sizes[k];
+  kvz_bitstream_clear(&state->stream);
+  for (uint32_t k = 0; k < r->ent_sizes[row]; k++) kvz_bitstream_writebyte(&state->stream, r->ent[at + k]);  /* the bytes carry their emulation prevention already */
+}
+static void release_entropy_slots(encoder_state_t *state)
+{
+  if (!state->is_leaf) {
+    for (int i = 0; state->children[i].encoder_control; ++i) release_entropy_slots(&state->children[i]);
+    return;
+  }
+  pthread_mutex_lock(&g_lock);
+  for (int i = 0; i < g_n_slots; i++)
+    if (g_slots[i]->ent_hold && g_slots[i]->outstanding == 0 && g_slots[i]->frame == state->tile->frame && g_slots[i]->num == state->frame->num) { g_slots[i]->ent_hold = 0; g_slots[i]->ent_ready = 0; }
+  pthread_mutex_unlock(&g_lock);
+}
+/* kvz_encoder_state_worker_write_bitstream (encoder_state-bitstream.c:1138) runs once per frame when all its LCUs are through: the slice header it writes takes the entry
+ * points from the leaves' streams, so they are swapped first */
+void __wrap_kvz_encoder_state_worker_write_bitstream(void *opaque)
+{
+  encoder_state_t *state = (encoder_state_t *)opaque;
+  if (g_entropy > 0) replace_leaf_streams(state);
+  __real_kvz_encoder_state_worker_write_bitstream(opaque);
+  if (g_entropy > 0) release_entropy_slots(state);
+}
+
 void __wrap_kvz_search_lcu(encoder_state_t *const state, const int x, const int y, const yuv_t *const hor_buf, const yuv_t *const ver_buf)
 {
   const int path = eligible(state);
@@ -411,6 +553,7 @@ void __wrap_kvz_search_lcu(encoder_state_t *const state, const int x, const int 
   state->search_cabac.update = 0;
   if (path == 2) { search_lcu_inter(state, x, y); return; }
   picture_result *r = picture_of(state);
+  if (r->ent_hold) { search_lcu_without_levels(state, r, x, y); return; }
   videoframe_t *frame = state->tile->frame;
   const int w = r->width, h = r->height, w8 = w / 8, wc = (w + 63) / 64;
   const size_t ys = (size_t)w * h, cs = ys / 4;

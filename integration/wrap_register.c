@@ -23,3 +23,4 @@ WRAP(intra)
 WRAP(ipol)
 WRAP(sao)
 WRAP(nal)
+WRAP(encode)

@@ -59,6 +59,7 @@ SIGNATURES = {
     "quantize_residual": (C.c_int, [C.POINTER(QuantParams), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     u8p, u8p, u8p, i16p, C.c_int]),
     "plane_checksum": (C.c_uint32, [u8p, C.c_int, C.c_int, C.c_int]),
+    "coeff_nxn_bins": (C.c_int, [i16p, C.c_int, C.c_int, C.c_int, u32p, C.c_int]),
     "plane_md5": (None, [u8p, C.c_int, C.c_int, C.c_int, u8p]),
     "coeff_abs_sum": (C.c_uint32, [i16p, C.c_size_t]),
     "fast_coeff_cost": (C.c_double, [i16p, C.c_int32, C.c_uint64]),

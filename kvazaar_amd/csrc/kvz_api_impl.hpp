@@ -17,6 +17,7 @@
 
 #include "../../include/kvz_hip_types.h"
 #include "kvz_ops.hpp"
+#include "kvz_entropy.hpp"
 #include "kvz_rdoq.hpp"
 #include "kvz_tables.hpp"
 
@@ -320,6 +321,23 @@ template <class B> struct Api {
     be.run(AbsSumOp{ c, o }, (int)length);
     be.download();
     return *be.host(o);
+  }
+  // ---------------------------------------------------------------- encode
+  // kvz_encode_coeff_nxn (strategies-encode.h:49-65) as far as it is data-parallel-friendly per call: the block's syntax as bin records (kvz_entropy.hpp); the
+  // arithmetic coder state lives in the caller's cabac_data_t.  Returns the number of records the block has (more than `capacity`: the list is truncated).
+  static int coeff_nxn_bins(B &be, const i16 *coeff, int width, int type, int scan_mode, u32 *records, int capacity)
+  {
+    int log2 = 2;
+    while ((1 << log2) < width) log2++;
+    be.begin();
+    const i16 *c = be.in(coeff, (size_t)width * width);
+    u32 *o = be.template zeroed<u32>((size_t)capacity + 1);
+    be.upload();
+    be.run(CoeffBinsOp{ be.tables(), c, log2, type, scan_mode, o, (u32)capacity }, 1);
+    be.download();
+    const int n = (int)be.host(o)[0];
+    memcpy(records, be.host(o) + 1, (size_t)(n < capacity ? n : capacity) * sizeof(u32));
+    return n;
   }
   // ---------------------------------------------------------------- nal
   // kvz_array_checksum is called once per whole plane (nal.c:79-84; 2 MB of luma at 1080p, 8 MB at 4K): the plane goes through the

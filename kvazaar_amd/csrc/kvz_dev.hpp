@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <vector>
 
 #include "../../include/kvz_hip_dev.h"
@@ -1444,9 +1445,29 @@ int kvz_hip_batch_sao_params(kvz_hip_batch *b, int frame, kvz_hip_sao_params *lu
 // The entropy coder in its real mode (kvz_entropy.hpp): the slice data of every picture of the batch, substream by substream, from the device-resident results of the
 // CTU pass (and of the loop filters' SAO decision).  Pictures are coded in chunks whose bin records fit a scratch budget (KVZ_HIP_ENTROPY_SCRATCH_MB, default 49152:
 // 25 MB per 1080p picture at the default capacity of 12 288 records per CTU); a CTU that produces more records than that makes its chunk run again with the room it needs.
+namespace kvz {
+// scratch of the entropy coder, kept between calls (grow-only; hipMalloc / hipFree per call cost more than a small batch's kernels): one caller at a time
+struct EntropyScratch {
+  std::mutex lock;
+  struct Buf { void *p = nullptr; size_t bytes = 0; };
+  Buf bins, nbins, nbits, sizes, offsets, bound_offsets, rowctx, scratch, out;
+  static void *need(Buf &b, size_t bytes)
+  {
+    if (bytes > b.bytes) {
+      if (b.p) KVZ_HIP_CHECK(hipFree(b.p));
+      b.bytes = bytes + bytes / 8;
+      KVZ_HIP_CHECK(hipMalloc(&b.p, b.bytes));
+    }
+    return b.p;
+  }
+};
+inline EntropyScratch &entropy_scratch(int device) { static EntropyScratch s[64]; return s[device & 63]; }  // buffers live on the device they were allocated on
+}  // namespace kvz
 long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, uint8_t *out, size_t capacity, uint32_t *substream_bytes)
 {
   kvz::batch_enter(b);
+  kvz::EntropyScratch &S = kvz::entropy_scratch(b->device);
+  std::lock_guard<std::mutex> guard(S.lock);
   const kvz::CtuFrames &F = b->F;
   const int n = b->n_frames, ctus = F.wc * F.hc, rows = model->no_wpp ? 1 : F.hc;
   if (sao && !b->d_sao_recs) { fprintf(stderr, "kvz_hip_batch_entropy_code: kvz_hip_batch_loop_filters(..., sao = 1) has not run on this batch\n"); return -1; }
@@ -1468,16 +1489,11 @@ long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model
     if (nf < 1) nf = 1;
     if (nf > n - f0) nf = n - f0;
     const long items = (long)nf * ctus, streams = (long)nf * rows;
-    uint32_t *d_bins = nullptr, *d_nbins = nullptr, *d_nbits = nullptr, *d_sizes = nullptr;
-    unsigned long long *d_offsets = nullptr, *d_bound_offsets = nullptr;
-    uint8_t *d_rowctx = nullptr, *d_out = nullptr, *d_scratch = nullptr;
-    KVZ_HIP_CHECK(hipMalloc((void **)&d_bins, (size_t)items * cap * sizeof(uint32_t)));
-    KVZ_HIP_CHECK(hipMalloc((void **)&d_nbins, (size_t)items * sizeof(uint32_t)));
-    KVZ_HIP_CHECK(hipMalloc((void **)&d_nbits, (size_t)items * sizeof(uint32_t)));
-    KVZ_HIP_CHECK(hipMalloc((void **)&d_sizes, (size_t)streams * sizeof(uint32_t)));
-    KVZ_HIP_CHECK(hipMalloc((void **)&d_offsets, (size_t)streams * sizeof(unsigned long long)));
-    KVZ_HIP_CHECK(hipMalloc((void **)&d_bound_offsets, (size_t)streams * sizeof(unsigned long long)));
-    KVZ_HIP_CHECK(hipMalloc((void **)&d_rowctx, (size_t)nf * F.hc * KVZ_ENTROPY_CTXS));
+    uint32_t *d_bins = (uint32_t *)S.need(S.bins, (size_t)items * cap * sizeof(uint32_t)), *d_nbins = (uint32_t *)S.need(S.nbins, (size_t)items * sizeof(uint32_t));
+    uint32_t *d_nbits = (uint32_t *)S.need(S.nbits, (size_t)items * sizeof(uint32_t)), *d_sizes = (uint32_t *)S.need(S.sizes, (size_t)streams * sizeof(uint32_t));
+    unsigned long long *d_offsets = (unsigned long long *)S.need(S.offsets, (size_t)streams * sizeof(unsigned long long));
+    unsigned long long *d_bound_offsets = (unsigned long long *)S.need(S.bound_offsets, (size_t)streams * sizeof(unsigned long long));
+    uint8_t *d_rowctx = (uint8_t *)S.need(S.rowctx, (size_t)nf * F.hc * KVZ_ENTROPY_CTXS), *d_out = nullptr, *d_scratch = nullptr;
     kvz::EntropyJob J;
     memset(&J, 0, sizeof J);
     J.W = F.W; J.H = F.H; J.wc = F.wc; J.hc = F.hc; J.n_frames = nf; J.no_wpp = model->no_wpp;
@@ -1506,7 +1522,7 @@ long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model
         bound_offsets[(size_t)i] = scratch_bytes;
         scratch_bytes += (((bits + 7) / 8 + 16) * 3 / 2 + 15) & ~15ull;
       }
-      KVZ_HIP_CHECK(hipMalloc((void **)&d_scratch, scratch_bytes ? scratch_bytes : 16));
+      d_scratch = (uint8_t *)S.need(S.scratch, scratch_bytes ? scratch_bytes : 16);
       KVZ_HIP_CHECK(hipMemcpyAsync(d_bound_offsets, bound_offsets.data(), (size_t)streams * sizeof(unsigned long long), hipMemcpyHostToDevice, b->stream));
       static const int lanes = [] { const char *e = getenv("KVZ_HIP_ENTROPY_LANES"); const int v = e ? atoi(e) : 16; return v == 64 || v == 32 || v == 8 ? v : 16; }();
       if (!model->no_wpp) hipLaunchKernelGGL(kvz::dev_entropy_row_ctx_kernel<8>, dim3((unsigned)((nf + 7) / 8)), dim3(8), 0, b->stream, J, kvz::device_tables());
@@ -1527,7 +1543,7 @@ long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model
         fprintf(stderr, "kvz_hip_batch_entropy_code: the output buffer is too small (%zu bytes needed so far)\n", (size_t)(total + chunk_bytes));
         rc = -1;
       } else {
-        KVZ_HIP_CHECK(hipMalloc((void **)&d_out, chunk_bytes ? chunk_bytes : 1));
+        d_out = (uint8_t *)S.need(S.out, chunk_bytes ? chunk_bytes : 1);
         KVZ_HIP_CHECK(hipMemcpyAsync(d_offsets, offsets.data(), (size_t)streams * sizeof(unsigned long long), hipMemcpyHostToDevice, b->stream));
         hipLaunchKernelGGL(kvz::dev_entropy_compact_kernel, dim3((unsigned)streams), dim3(256), 0, b->stream, d_scratch, d_bound_offsets, d_sizes, d_offsets, d_out);
         KVZ_HIP_CHECK(hipGetLastError());
@@ -1535,13 +1551,9 @@ long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model
         KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
         memcpy(substream_bytes + (size_t)f0 * rows, sizes.data(), (size_t)streams * sizeof(uint32_t));
         total += chunk_bytes;
-        KVZ_HIP_CHECK(hipFree(d_out));
         f0 += nf;
       }
-      KVZ_HIP_CHECK(hipFree(d_scratch));
     }
-    KVZ_HIP_CHECK(hipFree(d_bins)); KVZ_HIP_CHECK(hipFree(d_nbins)); KVZ_HIP_CHECK(hipFree(d_nbits)); KVZ_HIP_CHECK(hipFree(d_sizes)); KVZ_HIP_CHECK(hipFree(d_offsets));
-    KVZ_HIP_CHECK(hipFree(d_bound_offsets)); KVZ_HIP_CHECK(hipFree(d_rowctx));
     if (again) cap = (most + 1023u) & ~1023u;  // this chunk again, with room for its largest CTU
   }
   return rc ? rc : (long)total;

@@ -188,6 +188,18 @@ KVZ_DEV void entropy_coeff_nxn(BinSink &s, const Tables *tb, const i16 *coeff, i
   }
 }
 
+// Per-call form (strategies-encode.h:49-65 kvz_encode_coeff_nxn): the bins of ONE transform block.  out[0] = number of records, out[1..] the records (as many as fit
+// `cap`); the caller -- integration/kvazaar/strategies/hip/encode-hip.c -- feeds them to the cabac_data_t it was handed.
+struct CoeffBinsOp {
+  const Tables *tb; const i16 *coeff; int log2_size, type, scan_mode; u32 *out; u32 cap;
+  KVZ_DEV void operator()(int) const
+  {
+    BinSink s{ out + 1, 0, cap, 0 };
+    entropy_coeff_nxn(s, tb, coeff, log2_size, type, scan_mode);
+    out[0] = s.n;
+  }
+};
+
 struct EntropyCtu {  // one CTU of one picture
   const EntropyJob &J;
   const Tables *tb;

@@ -202,6 +202,11 @@ size_t kvz_oracle_entropy_intra_picture(const kvz_hip_intra_cost_model *m, int w
                                         const uint8_t *mode4, const int16_t *coeff, const kvz_hip_sao_params *sao_luma, const kvz_hip_sao_params *sao_chroma,
                                         const uint8_t *sao_merge, uint8_t *out, size_t capacity, uint32_t *substream_bytes);
 
+/* the per-call form (strategies-encode.h:49-65): one block's residual syntax as bin records (include/kvz_hip.h kvz_hip_coeff_nxn_bins), and records through the
+ * arithmetic coder from given context states (KVZ_HIP_CX_* order; 150 of them) + flush + stop bit + alignment */
+int kvz_oracle_coeff_nxn_bins(const int16_t *coeff, int width, int type, int scan_mode, uint32_t *records, int capacity);
+int kvz_oracle_code_records(const uint8_t *ctx_states, const uint32_t *records, int n, uint8_t *out, int capacity);
+
 /* ---- deblocking of an all-intra, constant-QP picture in place (kvz_oracle_deblock.c; filter.c:783 kvz_filter_deblock_lcu over
  * every LCU).  Planes are tight (stride = width), cu_depth is the CU depth per 8x8 unit as the CTU pass returns it. ---- */
 void kvz_oracle_deblock_frame(int width, int height, int qp, int beta_offset_div2, int tc_offset_div2, uint8_t *y, uint8_t *u, uint8_t *v,

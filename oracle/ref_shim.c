@@ -431,3 +431,42 @@ double kvz_ref_coeff_cabac_bits(const int16_t *coeff, int width, int type, int s
   KVZ_REF_STORE(cu_one_model_luma, 16) KVZ_REF_STORE(cu_one_model_chroma, 8) KVZ_REF_STORE(cu_abs_model_luma, 4) KVZ_REF_STORE(cu_abs_model_chroma, 2)
   return bits;
 }
+
+/* kvz_encode_coeff_nxn (strategies-encode.h:49-65) in its REAL mode on a block, from the given context states (KVZ_HIP_CX_* order), then kvz_cabac_finish, a stop bit and
+ * the alignment (what ends a substream, encoderstate.c:726-732): the bytes the reference leaves in the stream.  Returns their number. */
+#include "bitstream.h"
+#include "strategies/strategies-encode.h"
+int kvz_ref_encode_coeff_nxn_bytes(const uint8_t *ctx, const int16_t *coeff, int width, int type, int scan_mode, uint8_t *out, int capacity)
+{
+  cabac_data_t *cb = &g_state.cabac;
+  bitstream_t stream;
+  kvz_bitstream_init(&stream);
+  g_ctrl.cfg.signhide_enable = 0; g_ctrl.cfg.trskip_enable = 0; g_ctrl.cfg.crypto_features = 0; g_ctrl.cfg.lossless = 0;
+  g_frame.slicetype = KVZ_SLICE_I;
+#define SETCTX(dst, from, n) for (int i_ = 0; i_ < (n); i_++) (dst)[i_].uc_state = ctx[(from) + i_]
+  SETCTX(cb->ctx.cu_sig_coeff_group_model, KVZ_HIP_CX_SIG_CG, 4);
+  SETCTX(cb->ctx.cu_sig_model_luma, KVZ_HIP_CX_SIG_LUMA, 27);
+  SETCTX(cb->ctx.cu_sig_model_chroma, KVZ_HIP_CX_SIG_CHROMA, 15);
+  SETCTX(cb->ctx.cu_ctx_last_y_luma, KVZ_HIP_CX_LAST_Y_LUMA, 15);
+  SETCTX(cb->ctx.cu_ctx_last_y_chroma, KVZ_HIP_CX_LAST_Y_CHROMA, 15);
+  SETCTX(cb->ctx.cu_ctx_last_x_luma, KVZ_HIP_CX_LAST_X_LUMA, 15);
+  SETCTX(cb->ctx.cu_ctx_last_x_chroma, KVZ_HIP_CX_LAST_X_CHROMA, 15);
+  SETCTX(cb->ctx.cu_one_model_luma, KVZ_HIP_CX_ONE_LUMA, 16);
+  SETCTX(cb->ctx.cu_one_model_chroma, KVZ_HIP_CX_ONE_CHROMA, 8);
+  SETCTX(cb->ctx.cu_abs_model_luma, KVZ_HIP_CX_ABS_LUMA, 4);
+  SETCTX(cb->ctx.cu_abs_model_chroma, KVZ_HIP_CX_ABS_CHROMA, 2);
+#undef SETCTX
+  kvz_cabac_start(cb);
+  cb->stream = &stream;
+  cb->only_count = 0;
+  cb->update = 1;  /* as encoder_state_worker_encode_lcu_bitstream sets it (encoderstate.c:686): CABAC_FBITS_UPDATE only codes a bin when it is on */
+  kvz_encode_coeff_nxn(&g_state, cb, (const coeff_t *)coeff, (uint8_t)width, (uint8_t)type, (int8_t)scan_mode, 0, NULL);
+  kvz_cabac_finish(cb);
+  kvz_bitstream_put(&stream, 1, 1);
+  kvz_bitstream_align_zero(&stream);
+  int n = 0;
+  for (kvz_data_chunk *c = stream.first; c; c = c->next)
+    for (uint32_t i = 0; i < c->len; i++) { if (n < capacity) out[n] = c->data[i]; n++; }
+  kvz_bitstream_finalize(&stream);
+  return n;
+}

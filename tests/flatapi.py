@@ -42,7 +42,7 @@ def load_ref(cpuid):
 
     The function pointers are process globals (kvazaar.c:94), so selecting rebinds them for every holder."""
     if "lib" not in _ref_cache:
-        lib = FlatLib(refshim_path(), "kvz_ref_")
+        lib = FlatLib(refshim_path(), "kvz_ref_", optional=("coeff_nxn_bins",))  # the reference has no record form: kvz_ref_encode_coeff_nxn_bytes checks the coded bytes
         lib.lib.kvz_ref_select.argtypes = [C.c_int]
         lib.lib.kvz_ref_dct_matrix.restype = i16p
         lib.lib.kvz_ref_dct_matrix.argtypes = [C.c_int]

@@ -84,3 +84,30 @@ def test_binding_inter_pictures_write_the_reference_bitstream(tmp_path, res, fra
     assert int(open(str(tmp_path / "trace")).read()) >= device_pictures, "the inter pass was not used"
     if opts[1] == "veryfast" and len(opts) == 6 and frames == 8:
         assert got == "1e7a81653d1157ce05e9ffd85c7cd5cf"  # 416x240 x 8 --preset veryfast --gop lp-g4d3t1
+
+
+# ---- the device's entropy coder behind the binding (KVZ_HIP_BATCH_ENTROPY=1): levels stay on the device, kvz_encode_coding_tree is skipped, the row coders' streams are
+# replaced by the device's substreams before the slice header takes its entry points from them ----
+ENTROPY_CASES = [(8, ["--preset", "ultrafast", "-p", "1"], True),                                  # BASELINE config 1: the survey's md5
+                 (8, ["--preset", "ultrafast", "-p", "1", "--owf", "7", "--threads", "8"], True),  # pictures gathered, several coded per call
+                 (3, ["--preset", "ultrafast", "-p", "1", "--no-wpp"], True),                       # one substream per picture
+                 (2, ["--preset", "ultrafast", "-p", "1", "-q", "32", "--pu-depth-intra", "2-4"], True),  # NxN CUs, levels priced with the CABAC model
+                 (2, ["--preset", "ultrafast", "-p", "1", "--tiles", "2x2"], False),                # tiles: the host codes (the binding says why)
+                 (2, ["--preset", "veryfast", "-p", "1"], False)]                                   # SAO syntax: the host codes
+
+
+@pytest.mark.parametrize("frames,opts,on_device", ENTROPY_CASES, ids=["ultrafast", "owf7", "no-wpp", "nxn-qp32", "tiles-fall-back", "sao-falls-back"])
+def test_binding_with_device_entropy_coding_writes_the_reference_bitstream(tmp_path, frames, opts, on_device):
+    if not os.path.exists(os.path.join(REF, "kvazaar_hipsim")):
+        pytest.skip("oracle/_ref/kvazaar_hipsim not built (oracle/Makefile, where /root/reference exists)")
+    yuv = str(tmp_path / "syn.yuv")
+    synth.write_yuv(yuv, 416, 240, frames, 1234, "small")
+    opts = opts + ([] if "--threads" in opts else ["--threads", "4"])
+    want = _encode("kvazaar_ref", yuv, "416x240", str(tmp_path / "ref.hevc"), opts)
+    got = _encode("kvazaar_hipsim", yuv, "416x240", str(tmp_path / "sim.hevc"), opts,
+                  {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1", "KVZ_HIP_BATCH_ENTROPY": "1", "KVZ_HIP_ENTROPY_TRACE": str(tmp_path / "trace")})
+    assert got == want
+    if frames == 8 and "--owf" not in opts:
+        assert got == "9aeb72382ab3092e285ce3f97f51d4ea"
+    coded = int(open(str(tmp_path / "trace")).read()) if os.path.exists(str(tmp_path / "trace")) else 0
+    assert (coded >= frames) if on_device else coded == 0

@@ -176,3 +176,29 @@ def test_inter_pass_inside_the_encoder_bitstream_identical(tmp_path, res, frames
     assert int(open(str(tmp_path / "trace")).read()) >= device_pictures, "the inter pass was not used"
     if res == "416x240" and frames == 8:
         assert md5_dev == "1e7a81653d1157ce05e9ffd85c7cd5cf"
+
+
+# ---- the device's entropy coder inside the real encoder (KVZ_HIP_BATCH_ENTROPY=1) ----
+@pytest.mark.parametrize("res,frames,seed,kind,opts", [("416x240", 8, 1234, "small", ["--preset", "ultrafast", "-p", "1"]),
+                                                        ("416x240", 3, 1234, "small", ["--preset", "ultrafast", "-p", "1", "--no-wpp"]),
+                                                        ("416x240", 2, 1234, "small", ["--preset", "ultrafast", "-p", "1", "-q", "32", "--pu-depth-intra", "2-4"]),
+                                                        ("1920x1080", 8, 1, "large", ["--preset", "ultrafast", "-p", "1", "--owf", "7"])],
+                         ids=["survey-416x240", "no-wpp", "nxn-qp32", "1080p-x8-owf7"])
+def test_device_entropy_coding_inside_the_encoder_bitstream_identical(tmp_path, res, frames, seed, kind, opts):
+    """The slice data of every picture written on the device (kvz_hip_batch_entropy_code behind integration/kvazaar/search_lcu_hip.c): the levels never leave the device,
+    kvz_encode_coding_tree does not run, the row coders' streams are replaced by the device's substreams before kvazaar writes the slice header (whose entry points are
+    their sizes), parameter sets, SEI and NAL framing.  The file must be the reference encoder's, byte for byte."""
+    _need_hip_encoder()
+    w, h = (int(v) for v in res.split("x"))
+    yuv = str(tmp_path / "syn.yuv")
+    synth.write_yuv(yuv, w, h, frames, seed, kind)
+    common = opts + ["--threads", "8"]
+    md5_ref, _, _ = _encode("kvazaar_ref", yuv, str(tmp_path / "ref.hevc"), common, res=res)
+    md5_dev, t, _ = _encode("kvazaar_hip", yuv, str(tmp_path / "dev.hevc"), common,
+                            {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1", "KVZ_HIP_BATCH_ENTROPY": "1", "KVZ_HIP_ENTROPY_TRACE": str(tmp_path / "trace")}, res=res)
+    assert md5_dev == md5_ref
+    assert int(open(str(tmp_path / "trace")).read()) >= frames, "the device entropy coder was not used"
+    if res == "416x240" and frames == 8:
+        assert md5_dev == GOLDEN_416x240_8F
+    if res == "1920x1080":
+        assert md5_dev == "dce84d2200dc0e54e2e029425d1682e1"  # SURVEY.md 8c

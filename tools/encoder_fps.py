@@ -21,7 +21,7 @@ distinct = [b"".join(p.tobytes() for p in planes) for planes in synth.frames(w, 
 with open(yuv, "wb") as f:
     for i in range(frames):
         f.write(distinct[i % 8])
-threads = os.cpu_count() or 8
+threads = len(os.sched_getaffinity(0))
 
 
 def run(binary, extra, env=None):
@@ -41,5 +41,11 @@ for owf in (15, 63):
     fps_ref, md5_ref = run("kvazaar_ref", opts)
     trace = "/tmp/enc_fps_trace"
     fps_hip, md5_hip = run("kvazaar_hip", opts, {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1", "KVZ_HIP_BATCH_TRACE": trace})
+    etrace = "/tmp/enc_fps_etrace"
+    if os.path.exists(etrace):
+        os.remove(etrace)
+    fps_ent, md5_ent = run("kvazaar_hip", opts, {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1", "KVZ_HIP_BATCH_ENTROPY": "1", "KVZ_HIP_ENTROPY_TRACE": etrace})
+    coded = open(etrace).read().strip() if os.path.exists(etrace) else "0"
     print(f"preset {preset} QP {qp} {frames} frames --threads {threads} --owf {owf}: AVX2 encoder {fps_ref:.1f} fps | device search {fps_hip:.1f} fps "
-          f"(pictures passes largest-batch: {open(trace).read().strip()}) | bitstreams identical: {md5_ref == md5_hip}", flush=True)
+          f"(pictures passes largest-batch: {open(trace).read().strip()}) | device search + device entropy coding {fps_ent:.1f} fps ({coded} pictures coded on the device) | "
+          f"bitstreams identical: {md5_ref == md5_hip and md5_ref == md5_ent}", flush=True)
