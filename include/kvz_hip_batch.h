@@ -127,6 +127,11 @@ void kvz_hip_intra_cost_model_init(int qp, uint64_t coeff_weights, kvz_hip_intra
  * objects, emulation prevention bytes included (bitstream.c:212-223): what follows the slice header in the NAL unit, verbatim.  Only these bytes cross PCIe instead of
  * the levels (12 KB per CTU).  Returns the total size, -1 on failure. */
 long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, uint8_t *out, size_t capacity, uint32_t *substream_bytes);
+/* ... when the batch's pictures are TILES of larger pictures (each tile a picture of its own for the pass, model.no_wpp as kvazaar codes tiles): not_last[f] != 0 (HOST,
+ * n_frames entries) marks a tile that is not the last of its slice -- its substream ends in end_of_subset_one_bit instead of end_of_slice_segment_flag
+ * (encoderstate.c:699-724).  not_last == NULL: every picture is a slice of its own (the function above). */
+long kvz_hip_batch_entropy_code_tiles(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, const uint8_t *not_last, uint8_t *out, size_t capacity,
+                                      uint32_t *substream_bytes);
 uint64_t kvz_hip_default_coeff_weights(int qp);
 
 #ifdef __cplusplus

@@ -53,6 +53,7 @@ typedef struct {
   uint32_t ent_sizes[KVZ_HIP_MAX_LCU_ROWS];
   int ent_ready;               /* this picture's slice data is in ent */
   int ent_hold;                /* ... and has not been handed to the bitstream yet: the slot must not be reused */
+  int ent_not_last;            /* the picture is a tile, and not its slice's last */
   kvz_hip_intra_cost_model model;
   int state;                   /* FREE -> PENDING (registered, waiting for a pass) -> COMPUTING (in the leader's batch) -> READY */
   int outstanding;             /* LCUs of the picture that have not copied their part yet; the slot is only reused at 0 (under g_lock) */
@@ -176,7 +177,9 @@ static void run_entropy(picture_result **list, int n)
   if (all_cap < cap) { free(all); all = malloc(cap); all_cap = cap; }
   if (sizes_cap < (size_t)cap_n * rows) { free(sizes); sizes = malloc((size_t)cap_n * rows * sizeof *sizes); sizes_cap = (size_t)cap_n * rows; }
   if (!all || !sizes || rows > KVZ_HIP_MAX_LCU_ROWS) { fprintf(stderr, "search_lcu_hip: out of memory\n"); abort(); }
-  if (kvz_hip_batch_entropy_code(b, &list[0]->model, 0, all, cap, sizes) < 0) { fprintf(stderr, "search_lcu_hip: the device entropy coder failed\n"); abort(); }
+  uint8_t not_last[64] = { 0 };
+  for (int i = 0; i < n; i++) not_last[i] = (uint8_t)list[i]->ent_not_last;
+  if (kvz_hip_batch_entropy_code_tiles(b, &list[0]->model, 0, not_last, all, cap, sizes) < 0) { fprintf(stderr, "search_lcu_hip: the device entropy coder failed\n"); abort(); }
   size_t at = 0;
   for (int i = 0; i < n; i++) {
     size_t bytes = 0;
@@ -230,10 +233,13 @@ static picture_result *picture_of(const encoder_state_t *state)
     r->outstanding = wc * hc;
     if (g_entropy < 0) { const char *e = getenv("KVZ_HIP_BATCH_ENTROPY"); g_entropy = e ? atoi(e) : 0; }
     r->ent_ready = 0;
-    /* the device writes the slice data of configurations whose LCUs carry no SAO syntax (the SAO decision is made on the host here), with one slice per picture and
-     * no tiles (a tile that is not the slice's last ends in end_of_subset_one_bit instead of end_of_slice_segment_flag: kvz_hip_batch_entropy_code codes whole pictures) */
-    r->ent_hold = g_entropy > 0 && state->encoder_control->cfg.sao_type == 0 && state->encoder_control->cfg.slices == KVZ_SLICES_NONE &&
-                  state->encoder_control->cfg.tiles_width_count * state->encoder_control->cfg.tiles_height_count <= 1;
+    /* the device writes the slice data of configurations whose LCUs carry no SAO syntax (the SAO decision is made on the host here) and one slice per picture; a
+     * tile that is not the picture's last ends in end_of_subset_one_bit instead of end_of_slice_segment_flag (encoderstate.c:699-724) */
+    r->ent_hold = g_entropy > 0 && state->encoder_control->cfg.sao_type == 0 && state->encoder_control->cfg.slices == KVZ_SLICES_NONE;
+    {
+      const int tiles = state->encoder_control->cfg.tiles_width_count * state->encoder_control->cfg.tiles_height_count;
+      r->ent_not_last = tiles > 1 && state->tile->id != tiles - 1;
+    }
     r->state = SLOT_PENDING;
     const kvz_config *cfg = &state->encoder_control->cfg;
     kvz_hip_intra_cost_model_init(state->qp, kvz_fast_coeff_get_weights(state), &r->model);

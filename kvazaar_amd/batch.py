@@ -118,18 +118,20 @@ class HipBatch:
         if wait:
             self.sync()
 
-    def entropy_code(self, model, sao=False, capacity=None):
+    def entropy_code(self, model, sao=False, capacity=None, not_last=None):
         """kvz_hip_batch_entropy_code: the slice data of every picture of the batch, coded on the device from the results of the last launch (and, with sao, of the
         last loop_filters(sao=True)).  -> (bytes of all substreams back to back, sizes as an array [frame][substream])"""
-        f = self.lib.kvz_hip_batch_entropy_code
-        f.argtypes = [C.c_void_p, C.POINTER(CostModel), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+        f = self.lib.kvz_hip_batch_entropy_code_tiles
+        f.argtypes = [C.c_void_p, C.POINTER(CostModel), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         f.restype = C.c_long
+        flags = None if not_last is None else np.ascontiguousarray(not_last, np.uint8)  # tiles: 1 = other tiles of the slice follow
+        assert flags is None or flags.size == self.n
         rows = 1 if model.no_wpp else (self.h + 63) // 64
         capacity = capacity or self.n * self.w * self.h * 2 + 65536
         if getattr(self, "_entropy_out", None) is None or self._entropy_out.nbytes < capacity:
             self._entropy_out = np.empty(capacity, np.uint8)
         sizes = np.zeros((self.n, rows), np.uint32)
-        total = f(self.handle, C.byref(model), int(sao), self._entropy_out.ctypes.data, capacity, sizes.ctypes.data)
+        total = f(self.handle, C.byref(model), int(sao), flags.ctypes.data if flags is not None else None, self._entropy_out.ctypes.data, capacity, sizes.ctypes.data)
         if total < 0:
             raise BatchError("kvz_hip_batch_entropy_code failed")
         return self._entropy_out[:total], sizes

@@ -1450,7 +1450,7 @@ namespace kvz {
 struct EntropyScratch {
   std::mutex lock;
   struct Buf { void *p = nullptr; size_t bytes = 0; };
-  Buf bins, nbins, nbits, sizes, offsets, bound_offsets, rowctx, scratch, out;
+  Buf bins, nbins, nbits, sizes, offsets, bound_offsets, rowctx, scratch, out, not_last;
   static void *need(Buf &b, size_t bytes)
   {
     if (bytes > b.bytes) {
@@ -1464,6 +1464,11 @@ struct EntropyScratch {
 inline EntropyScratch &entropy_scratch(int device) { static EntropyScratch s[64]; return s[device & 63]; }  // buffers live on the device they were allocated on
 }  // namespace kvz
 long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, uint8_t *out, size_t capacity, uint32_t *substream_bytes)
+{
+  return kvz_hip_batch_entropy_code_tiles(b, model, sao, nullptr, out, capacity, substream_bytes);
+}
+long kvz_hip_batch_entropy_code_tiles(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, const uint8_t *not_last, uint8_t *out, size_t capacity,
+                                      uint32_t *substream_bytes)
 {
   kvz::batch_enter(b);
   kvz::EntropyScratch &S = kvz::entropy_scratch(b->device);
@@ -1494,6 +1499,8 @@ long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model
     unsigned long long *d_offsets = (unsigned long long *)S.need(S.offsets, (size_t)streams * sizeof(unsigned long long));
     unsigned long long *d_bound_offsets = (unsigned long long *)S.need(S.bound_offsets, (size_t)streams * sizeof(unsigned long long));
     uint8_t *d_rowctx = (uint8_t *)S.need(S.rowctx, (size_t)nf * F.hc * KVZ_ENTROPY_CTXS), *d_out = nullptr, *d_scratch = nullptr;
+    uint8_t *d_not_last = not_last ? (uint8_t *)S.need(S.not_last, (size_t)nf) : nullptr;
+    if (not_last) KVZ_HIP_CHECK(hipMemcpyAsync(d_not_last, not_last + f0, (size_t)nf, hipMemcpyHostToDevice, b->stream));
     kvz::EntropyJob J;
     memset(&J, 0, sizeof J);
     J.W = F.W; J.H = F.H; J.wc = F.wc; J.hc = F.hc; J.n_frames = nf; J.no_wpp = model->no_wpp;
@@ -1501,7 +1508,7 @@ long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model
     J.part = model->search_nxn ? b->d_part + f0 * cells8 : nullptr; J.mode4 = model->search_nxn ? b->d_mode4 + f0 * cells4 : nullptr;
     J.coeff = b->d_coeff + (size_t)f0 * ctus * KVZ_HIP_CTU_COEFFS;
     J.sao = sao ? (const kvz::SaoRec *)b->d_sao_recs + (size_t)f0 * ctus * 3 : nullptr; J.sao_merge = sao ? b->d_sao_merge + (size_t)f0 * ctus : nullptr;
-    J.bins = d_bins; J.nbins = d_nbins; J.nbits = d_nbits; J.cap = cap; J.row_ctx = d_rowctx;
+    J.bins = d_bins; J.nbins = d_nbins; J.nbits = d_nbits; J.cap = cap; J.row_ctx = d_rowctx; J.not_last = d_not_last;
     memcpy(J.ctx_init, model->ctx_init, sizeof model->ctx_init < sizeof J.ctx_init ? sizeof model->ctx_init : sizeof J.ctx_init);
     hipLaunchKernelGGL(kvz::dev_entropy_bins_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, b->stream, J, kvz::device_tables(), items);
     counts.resize((size_t)items); bound_bits.resize((size_t)items);

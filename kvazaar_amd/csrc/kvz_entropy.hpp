@@ -31,6 +31,7 @@ struct EntropyJob {
   const i16 *coeff;            // [frames][ctu][KVZ_HIP_CTU_COEFFS]
   const SaoRec *sao;           // [frames][ctu][3] packed decisions or null (SAO off)
   const u8 *sao_merge;         // [frames][ctu]: 0 none, 1 left, 2 up
+  const u8 *not_last;          // [frames] or null: 1 = the picture is a tile that is not its slice's last: it ends in end_of_subset_one_bit, not end_of_slice_segment_flag
   u32 *bins;                   // [frames * ctus][cap] records, cap a multiple of 16 (lists are read a 64-byte line at a time)
   u32 *nbins;                  // [frames * ctus] records the CTU produced; above cap the list is truncated (still counted) and the host runs the chunk again with room
   u32 cap;
@@ -378,9 +379,10 @@ KVZ_DEV void entropy_ctu_bins(const EntropyJob &J, const Tables *tb, long item)
     }
   }
   c.coding_tree(s, lx * 64, ly * 64);
-  const bool last_col = lx == J.wc - 1, last_row = ly == J.hc - 1, end_of_slice = last_col && last_row;
-  s.trm(end_of_slice);                                          // end_of_slice_segment_flag (encoderstate.c:699-712)
-  if (!J.no_wpp && last_col && !end_of_slice) s.trm(1);         // end_of_subset_one_bit
+  const bool last_col = lx == J.wc - 1, last_row = ly == J.hc - 1, end_of_picture = last_col && last_row;
+  const bool end_of_slice = end_of_picture && !(J.not_last && J.not_last[f]);
+  s.trm(end_of_slice);                                                              // end_of_slice_segment_flag (encoderstate.c:699-712)
+  if ((end_of_picture || (!J.no_wpp && last_col)) && !end_of_slice) s.trm(1);       // end_of_subset_one_bit: the substream ends, the slice does not (:716-724)
   J.nbins[item] = s.n;
   J.nbits[item] = s.bits;
 }

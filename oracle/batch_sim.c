@@ -103,7 +103,14 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
 }
 
 /* ---- the entropy coder's real mode (include/kvz_hip_batch.h kvz_hip_batch_entropy_code), served by kvz_oracle_entropy_intra_picture ---- */
+long kvz_hip_batch_entropy_code_tiles(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, const uint8_t *not_last, uint8_t *out, size_t capacity,
+                                      uint32_t *substream_bytes);
 long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, uint8_t *out, size_t capacity, uint32_t *substream_bytes)
+{
+  return kvz_hip_batch_entropy_code_tiles(b, model, sao, NULL, out, capacity, substream_bytes);
+}
+long kvz_hip_batch_entropy_code_tiles(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, const uint8_t *not_last, uint8_t *out, size_t capacity,
+                                      uint32_t *substream_bytes)
 {
   if (sao) return -1;  /* the binding only asks for pictures without SAO syntax */
   const size_t ys = (size_t)b->w * b->h, ncu = (size_t)(b->w / 8) * (b->h / 8), nctu = (size_t)kvz_hip_batch_ctus_per_frame(b);
@@ -111,9 +118,9 @@ long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model
   size_t total = 0;
   (void)ys;
   for (int f = 0; f < b->n; f++) {
-    const size_t n = kvz_oracle_entropy_intra_picture(model, b->w, b->h, b->depth + f * ncu, b->mode + f * ncu, model->search_nxn ? b->part + f * ncu : NULL,
-                                                      model->search_nxn ? b->mode4 + f * ncu * 4 : NULL, b->coeff + f * nctu * KVZ_HIP_CTU_COEFFS, NULL, NULL, NULL,
-                                                      out + total, capacity - total, substream_bytes + (size_t)f * rows);
+    const size_t n = kvz_oracle_entropy_intra_tile(model, b->w, b->h, b->depth + f * ncu, b->mode + f * ncu, model->search_nxn ? b->part + f * ncu : NULL,
+                                                   model->search_nxn ? b->mode4 + f * ncu * 4 : NULL, b->coeff + f * nctu * KVZ_HIP_CTU_COEFFS, NULL, NULL, NULL,
+                                                   not_last ? not_last[f] : 0, out + total, capacity - total, substream_bytes + (size_t)f * rows);
     if (total + n > capacity) return -1;
     total += n;
   }

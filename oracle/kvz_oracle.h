@@ -201,6 +201,9 @@ void kvz_oracle_inter_picture(int qp, int poc, const kvz_oracle_lowdelay_cfg *cf
 size_t kvz_oracle_entropy_intra_picture(const kvz_hip_intra_cost_model *m, int width, int height, const uint8_t *cu_depth, const uint8_t *cu_mode, const uint8_t *part,
                                         const uint8_t *mode4, const int16_t *coeff, const kvz_hip_sao_params *sao_luma, const kvz_hip_sao_params *sao_chroma,
                                         const uint8_t *sao_merge, uint8_t *out, size_t capacity, uint32_t *substream_bytes);
+size_t kvz_oracle_entropy_intra_tile(const kvz_hip_intra_cost_model *m, int width, int height, const uint8_t *cu_depth, const uint8_t *cu_mode, const uint8_t *part,
+                                     const uint8_t *mode4, const int16_t *coeff, const kvz_hip_sao_params *sao_luma, const kvz_hip_sao_params *sao_chroma,
+                                     const uint8_t *sao_merge, int not_last, uint8_t *out, size_t capacity, uint32_t *substream_bytes);
 
 /* the per-call form (strategies-encode.h:49-65): one block's residual syntax as bin records (include/kvz_hip.h kvz_hip_coeff_nxn_bins), and records through the
  * arithmetic coder from given context states (KVZ_HIP_CX_* order; 150 of them) + flush + stop bit + alignment */

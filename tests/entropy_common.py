@@ -70,12 +70,12 @@ def header_ends_with_entry_points(header, sizes, wpp):
     return bits.endswith(tail.rstrip("0")) if tail.rstrip("0") else True
 
 
-def oracle_entropy(oracle, model, width, height, o, sao=None):
+def oracle_entropy(oracle, model, width, height, o, sao=None, not_last=0):
     """kvz_oracle_entropy_intra_picture on the outputs `o` of a CTU pass (rec / coeff / depth / mode [/ part / mode4]); sao = (luma, chroma, merge) arrays or None.
     Returns (bytes of all substreams, [substream sizes])"""
-    f = oracle.lib.kvz_oracle_entropy_intra_picture
+    f = oracle.lib.kvz_oracle_entropy_intra_tile
     f.restype = C.c_size_t
-    f.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_void_p, C.c_size_t, C.c_void_p]
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
     hc = (height + 63) // 64
     cap = width * height * 4 + 4096
     out = np.zeros(cap, np.uint8)
@@ -84,7 +84,7 @@ def oracle_entropy(oracle, model, width, height, o, sao=None):
     mode4 = o.get("mode4")
     n = f(C.addressof(model), width, height, o["depth"].ctypes.data, o["mode"].ctypes.data, part.ctypes.data if part is not None else None,
           mode4.ctypes.data if mode4 is not None else None, o["coeff"].ctypes.data, sao[0].ctypes.data if sao else None, sao[1].ctypes.data if sao else None,
-          sao[2].ctypes.data if sao else None, out.ctypes.data, cap, sizes.ctypes.data)
+          sao[2].ctypes.data if sao else None, int(not_last), out.ctypes.data, cap, sizes.ctypes.data)
     assert n <= cap
     k = 1 if model.no_wpp else hc
     return out[:n].tobytes(), [int(v) for v in sizes[:k]]

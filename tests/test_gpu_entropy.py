@@ -102,3 +102,31 @@ def test_device_slice_data_at_baseline_sizes(w, h, n, seed, qp):
         assert got[i][1] == want_sizes, i
         assert got[i][0] == want, i
     b.close()
+
+
+def test_device_slice_data_of_tiles():
+    """pictures that are tiles of a slice (kvz_hip_batch_entropy_code_tiles): all but the slice's last end in end_of_subset_one_bit -- against the oracle's tile coder;
+    the integrated encoder's --tiles bitstreams are checked in tests/test_e2e_dropin.py"""
+    import kvazaar_amd
+    from kvazaar_amd.batch import HipBatch, cost_model
+    from test_encoder_parity import oracle_model
+    lib = kvazaar_amd.load_library()
+    oracle = flatapi.load_oracle()
+    w, h, n, qp = 208, 120, 4, 22
+    frames = cc.yuv_frames(w, h, n, 7, "small")
+    model = cost_model(lib, qp, cc.coeff_weights(qp))
+    model.no_wpp = 1
+    b = HipBatch(lib, w, h, n)
+    for i, f in enumerate(frames):
+        b.upload(i, f)
+    b.run(model)
+    flags = [1, 1, 0, 1]
+    data, sizes = b.entropy_code(model, not_last=flags)
+    got = split(data, sizes)
+    om = oracle_model(oracle, qp)
+    om.no_wpp = 1
+    for i in range(n):
+        want, want_sizes = ec.oracle_entropy(oracle, om, w, h, b.download(i), not_last=flags[i])
+        assert got[i] == (want, want_sizes), i
+    assert got[2] != split(*b.entropy_code(model, not_last=[1, 1, 1, 1]))[2]
+    b.close()
