@@ -54,6 +54,7 @@ typedef struct {
   int ent_ready;               /* this picture's slice data is in ent */
   int ent_hold;                /* ... and has not been handed to the bitstream yet: the slot must not be reused */
   int ent_not_last;            /* the picture is a tile, and not its slice's last */
+  int ent_sao, ent_deblock, ent_beta, ent_tc;  /* SAO syntax to write: the device's own loop filters run first (their decisions are what gets coded) */
   kvz_hip_intra_cost_model model;
   int state;                   /* FREE -> PENDING (registered, waiting for a pass) -> COMPUTING (in the leader's batch) -> READY */
   int outstanding;             /* LCUs of the picture that have not copied their part yet; the slot is only reused at 0 (under g_lock) */
@@ -179,7 +180,9 @@ static void run_entropy(picture_result **list, int n)
   if (!all || !sizes || rows > KVZ_HIP_MAX_LCU_ROWS) { fprintf(stderr, "search_lcu_hip: out of memory\n"); abort(); }
   uint8_t not_last[64] = { 0 };
   for (int i = 0; i < n; i++) not_last[i] = (uint8_t)list[i]->ent_not_last;
-  if (kvz_hip_batch_entropy_code_tiles(b, &list[0]->model, 0, not_last, all, cap, sizes) < 0) { fprintf(stderr, "search_lcu_hip: the device entropy coder failed\n"); abort(); }
+  const int sao = list[0]->ent_sao;
+  if (sao) kvz_hip_batch_loop_filters(b, &list[0]->model, list[0]->ent_deblock, list[0]->ent_beta, list[0]->ent_tc, 1);  /* (the pictures before the filters are on the host already) */
+  if (kvz_hip_batch_entropy_code_tiles(b, &list[0]->model, sao, not_last, all, cap, sizes) < 0) { fprintf(stderr, "search_lcu_hip: the device entropy coder failed\n"); abort(); }
   size_t at = 0;
   for (int i = 0; i < n; i++) {
     size_t bytes = 0;
@@ -235,9 +238,14 @@ static picture_result *picture_of(const encoder_state_t *state)
     r->ent_ready = 0;
     /* the device writes the slice data of configurations whose LCUs carry no SAO syntax (the SAO decision is made on the host here) and one slice per picture; a
      * tile that is not the picture's last ends in end_of_subset_one_bit instead of end_of_slice_segment_flag (encoderstate.c:699-724) */
-    r->ent_hold = g_entropy > 0 && state->encoder_control->cfg.sao_type == 0 && state->encoder_control->cfg.slices == KVZ_SLICES_NONE;
     {
-      const int tiles = state->encoder_control->cfg.tiles_width_count * state->encoder_control->cfg.tiles_height_count;
+      const kvz_config *c = &state->encoder_control->cfg;
+      const int tiles = c->tiles_width_count * c->tiles_height_count;
+      /* SAO syntax: the device then makes the SAO decision of the pictures as well (kvz_hip_batch_loop_filters, the same decision kvz_sao_search_lcu makes on the host
+       * from the same pictures) -- `--sao full` without tiles (the loop filters of a tile read its neighbours) */
+      r->ent_sao = c->sao_type == KVZ_SAO_FULL && tiles <= 1;
+      r->ent_deblock = c->deblock_enable != 0; r->ent_beta = c->deblock_beta; r->ent_tc = c->deblock_tc;
+      r->ent_hold = g_entropy > 0 && (c->sao_type == KVZ_SAO_OFF || r->ent_sao) && c->slices == KVZ_SLICES_NONE;
       r->ent_not_last = tiles > 1 && state->tile->id != tiles - 1;
     }
     r->state = SLOT_PENDING;

@@ -16,6 +16,9 @@ struct kvz_hip_batch {
   int16_t *coeff;
   double *cost;
   int has_parts;
+  kvz_hip_sao_params *sao_luma, *sao_chroma;  /* the last kvz_hip_batch_loop_filters(..., sao = 1)'s decisions, one record per LCU and frame */
+  uint8_t *sao_merge;
+  int has_sao;
 };
 
 kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
@@ -28,12 +31,14 @@ kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
   b->part = calloc((size_t)(width / 8) * (height / 8), n_frames); b->mode4 = calloc((size_t)(width / 4) * (height / 4), n_frames);
   b->coeff = calloc(nctu * KVZ_HIP_CTU_COEFFS * sizeof(int16_t), n_frames);
   b->cost = calloc(nctu * sizeof(double), n_frames);
+  b->sao_luma = calloc(nctu * sizeof(kvz_hip_sao_params), n_frames); b->sao_chroma = calloc(nctu * sizeof(kvz_hip_sao_params), n_frames);
+  b->sao_merge = calloc(nctu, n_frames);
   return b;
 }
 void kvz_hip_batch_destroy(kvz_hip_batch *b)
 {
   if (!b) return;
-  free(b->src); free(b->rec); free(b->depth); free(b->mode); free(b->part); free(b->mode4); free(b->coeff); free(b->cost); free(b);
+  free(b->src); free(b->rec); free(b->depth); free(b->mode); free(b->part); free(b->mode4); free(b->coeff); free(b->cost); free(b->sao_luma); free(b->sao_chroma); free(b->sao_merge); free(b);
 }
 int kvz_hip_batch_ctus_per_frame(const kvz_hip_batch *b) { return ((b->w + 63) / 64) * ((b->h + 63) / 64); }
 void kvz_hip_batch_upload(kvz_hip_batch *b, int frame, const uint8_t *y, const uint8_t *u, const uint8_t *v)
@@ -112,17 +117,31 @@ long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model
 long kvz_hip_batch_entropy_code_tiles(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, const uint8_t *not_last, uint8_t *out, size_t capacity,
                                       uint32_t *substream_bytes)
 {
-  if (sao) return -1;  /* the binding only asks for pictures without SAO syntax */
+  if (sao && !b->has_sao) return -1;
   const size_t ys = (size_t)b->w * b->h, ncu = (size_t)(b->w / 8) * (b->h / 8), nctu = (size_t)kvz_hip_batch_ctus_per_frame(b);
   const int rows = model->no_wpp ? 1 : (b->h + 63) / 64;
   size_t total = 0;
   (void)ys;
   for (int f = 0; f < b->n; f++) {
     const size_t n = kvz_oracle_entropy_intra_tile(model, b->w, b->h, b->depth + f * ncu, b->mode + f * ncu, model->search_nxn ? b->part + f * ncu : NULL,
-                                                   model->search_nxn ? b->mode4 + f * ncu * 4 : NULL, b->coeff + f * nctu * KVZ_HIP_CTU_COEFFS, NULL, NULL, NULL,
+                                                   model->search_nxn ? b->mode4 + f * ncu * 4 : NULL, b->coeff + f * nctu * KVZ_HIP_CTU_COEFFS,
+                                                   sao ? b->sao_luma + f * nctu : NULL, sao ? b->sao_chroma + f * nctu : NULL, sao ? b->sao_merge + f * nctu : NULL,
                                                    not_last ? not_last[f] : 0, out + total, capacity - total, substream_bytes + (size_t)f * rows);
     if (total + n > capacity) return -1;
     total += n;
   }
   return (long)total;
+}
+
+/* kvz_hip_batch_loop_filters: deblocking + the SAO decision (+ SAO) of every picture, by the oracle; what the sim keeps of it are the decisions */
+void kvz_hip_batch_loop_filters(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int deblock, int beta_offset_div2, int tc_offset_div2, int sao)
+{
+  const size_t ys = (size_t)b->w * b->h, px = ys * 3 / 2, ncu = (size_t)(b->w / 8) * (b->h / 8), nctu = (size_t)kvz_hip_batch_ctus_per_frame(b);
+  for (int f = 0; f < b->n; f++) {
+    uint8_t *r = b->rec + f * px;
+    if (sao) kvz_oracle_sao_search_frame(model, b->w, b->h, b->src + f * px, r, b->depth + f * ncu, deblock, beta_offset_div2, tc_offset_div2, b->sao_luma + f * nctu,
+                                         b->sao_chroma + f * nctu, b->sao_merge + f * nctu);
+    else if (deblock) kvz_oracle_deblock_frame(b->w, b->h, model->qp, beta_offset_div2, tc_offset_div2, r, r + ys, r + ys + ys / 4, b->depth + f * ncu);
+  }
+  b->has_sao = sao != 0;
 }

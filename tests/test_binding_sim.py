@@ -93,10 +93,12 @@ ENTROPY_CASES = [(8, ["--preset", "ultrafast", "-p", "1"], True),               
                  (3, ["--preset", "ultrafast", "-p", "1", "--no-wpp"], True),                       # one substream per picture
                  (2, ["--preset", "ultrafast", "-p", "1", "-q", "32", "--pu-depth-intra", "2-4"], True),  # NxN CUs, levels priced with the CABAC model
                  (2, ["--preset", "ultrafast", "-p", "1", "--tiles", "2x2"], True),                 # tiles: every tile a substream, all but the last end in end_of_subset_one_bit
-                 (2, ["--preset", "veryfast", "-p", "1"], False)]                                   # SAO syntax: the host codes
+                 (2, ["--preset", "veryfast", "-p", "1"], True),                                    # SAO syntax from the device's own SAO decision
+                 (2, ["--preset", "medium", "-p", "1"], True),                                      # BASELINE config 3's preset: RDOQ levels, NxN CUs, SAO
+                 (2, ["--preset", "veryfast", "-p", "1", "--sao", "edge"], False)]                  # a SAO mode the device's decision does not model: the host codes
 
 
-@pytest.mark.parametrize("frames,opts,on_device", ENTROPY_CASES, ids=["ultrafast", "owf7", "no-wpp", "nxn-qp32", "tiles", "sao-falls-back"])
+@pytest.mark.parametrize("frames,opts,on_device", ENTROPY_CASES, ids=["ultrafast", "owf7", "no-wpp", "nxn-qp32", "tiles", "veryfast-sao", "medium", "sao-edge-falls-back"])
 def test_binding_with_device_entropy_coding_writes_the_reference_bitstream(tmp_path, frames, opts, on_device):
     if not os.path.exists(os.path.join(REF, "kvazaar_hipsim")):
         pytest.skip("oracle/_ref/kvazaar_hipsim not built (oracle/Makefile, where /root/reference exists)")

@@ -184,8 +184,11 @@ def test_inter_pass_inside_the_encoder_bitstream_identical(tmp_path, res, frames
                                                         ("416x240", 2, 1234, "small", ["--preset", "ultrafast", "-p", "1", "-q", "32", "--pu-depth-intra", "2-4"]),
                                                         ("1920x1080", 8, 1, "large", ["--preset", "ultrafast", "-p", "1", "--owf", "7"]),
                                                         ("416x240", 3, 1234, "small", ["--preset", "ultrafast", "-p", "1", "--tiles", "2x2"]),
+                                                        ("416x240", 3, 1234, "small", ["--preset", "veryfast", "-p", "1"]),
+                                                        ("416x240", 2, 1234, "small", ["--preset", "medium", "-p", "1"]),
+                                                        ("1920x1080", 4, 1, "large", ["--preset", "medium", "-p", "1", "--owf", "3"]),
                                                         ("3840x2160", 4, 2, "large", ["--preset", "ultrafast", "-p", "1", "--tiles", "4x2"])],
-                         ids=["survey-416x240", "no-wpp", "nxn-qp32", "1080p-x8-owf7", "tiles-2x2", "2160p-tiles-4x2"])
+                         ids=["survey-416x240", "no-wpp", "nxn-qp32", "1080p-x8-owf7", "tiles-2x2", "veryfast-sao", "medium", "medium-1080p", "2160p-tiles-4x2"])
 def test_device_entropy_coding_inside_the_encoder_bitstream_identical(tmp_path, res, frames, seed, kind, opts):
     """The slice data of every picture written on the device (kvz_hip_batch_entropy_code behind integration/kvazaar/search_lcu_hip.c): the levels never leave the device,
     kvz_encode_coding_tree does not run, the row coders' streams are replaced by the device's substreams before kvazaar writes the slice header (whose entry points are
@@ -204,5 +207,5 @@ def test_device_entropy_coding_inside_the_encoder_bitstream_identical(tmp_path, 
         assert md5_dev == "3de25813427ad6fc374bb50351d48dd9"  # BASELINE config 5
     if res == "416x240" and frames == 8:
         assert md5_dev == GOLDEN_416x240_8F
-    if res == "1920x1080":
+    if res == "1920x1080" and "ultrafast" in opts:
         assert md5_dev == "dce84d2200dc0e54e2e029425d1682e1"
