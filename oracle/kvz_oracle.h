@@ -190,6 +190,11 @@ int  kvz_oracle_me_trace_count(void);
 int  kvz_oracle_lowdelay_qp(int qp, int gop_len, int gop_depth, int frame, int intra_period, int ra8_model);
 void kvz_oracle_lowdelay_encode(const kvz_oracle_lowdelay_cfg *cfg, const float entropy_fbits[128], const uint64_t coeff_weights[52], int width, int height,
                                 int n_frames, const uint8_t *src, uint8_t *rec_search, uint8_t *rec_final, kvz_oracle_cu *cu_out, int32_t *frame_qp);
+/* ... and the slice data of every picture (kvz_oracle_entropy.inc): the substreams of all pictures back to back, their sizes (n_frames x (CTU rows | 1)), and where every
+ * picture's begin (n_frames + 1 offsets) */
+void kvz_oracle_lowdelay_encode_bits(const kvz_oracle_lowdelay_cfg *cfg, const float entropy_fbits[128], const uint64_t coeff_weights[52], int width, int height,
+                                     int n_frames, const uint8_t *src, uint8_t *rec_final, kvz_oracle_cu *cu_out, uint8_t *slice_data, size_t slice_capacity,
+                                     uint32_t *substream_bytes, uint64_t *picture_offsets);
 /* one B picture of such a sequence on its own, from its reference picture (after the loop filters) and that picture's CU records: qp / poc are the picture's;
  * of cfg the search options are read (fme_level, pu_depth_inter_max, sao, deblock, mv_constraint, no_wpp).  coeff (or NULL): KVZ_HIP_CTU_COEFFS per CTU. */
 void kvz_oracle_inter_picture(int qp, int poc, const kvz_oracle_lowdelay_cfg *cfg, const float entropy_fbits[128], uint64_t coeff_weights, int width, int height,

@@ -15,6 +15,7 @@ Fixtures (small, committed; the GPU box and any machine without the reference tr
                         built from /root/reference, all-intra, deblocking on / off) writes with --debug for seeded clips -- what the
                         batched CTU pass (+ deblocking) must reproduce picture for picture; ".../cu" entries: digests of the CU depth
                         and intra mode maps of the encoder's cu_array behind it (recorded with the oracle/ref_cudump.c interposer)
+  entropy_inter.json    (--entropy-inter) the same for low-delay sequences (I and B pictures) of tests/inter_common.py ENTROPY_CASES
   entropy.json          (--entropy) the slice data of the reference encoder's bitstreams for tests/entropy_common.py CASES: digest and substream sizes per picture
 (the bitstream md5s of the reference encoder are asserted by tests/test_e2e_dropin.py)
 tests/test_oracle_golden.py holds the known answers of the reference's own unit tests; this file adds outputs of the
@@ -311,7 +312,37 @@ def update_entropy():
     json.dump(out, open(os.path.join(HERE, "entropy.json"), "w"), indent=0, sort_keys=True)
 
 
+def update_entropy_inter():
+    """tests/golden/entropy_inter.json: the slice data of the reference encoder's low-delay bitstreams (I and B pictures) for the small cases of tests/inter_common.py;
+    taken from the reference's bytes, the split asserted as in update_entropy"""
+    import tempfile
+    import entropy_common as ec
+    import inter_common as ic
+    oracle = flatapi.load_oracle()
+    out = {}
+    for case in ic.CASES:
+        name, w, h, n, qp, preset, dbk, sao, owf, src = case
+        if name not in ic.ENTROPY_CASES:
+            continue
+        frames = ic.case_frames(case)
+        with tempfile.TemporaryDirectory() as d:
+            ic.reference_encode(w, h, frames, qp, d, preset=preset, deblock=bool(dbk), sao=bool(sao), owf=owf, cu=False)
+            payloads = ec.slice_payloads(open(os.path.join(d, "out.hevc"), "rb").read())
+        pictures = []
+        for payload, (data, sizes) in zip(payloads, ic.oracle_encode_bits(oracle, w, h, frames, qp, preset=preset, deblock=bool(dbk), sao=bool(sao), mv_constraint=owf > 0)):
+            total = sum(sizes)
+            ref_data, header = payload[len(payload) - total:], payload[:len(payload) - total]
+            assert ec.header_ends_with_entry_points(header, sizes, True), (name, "entry points")
+            assert ref_data == data, (name, "slice data")
+            pictures.append({"sha": hashlib.sha256(ref_data).hexdigest()[:24], "sizes": sizes})
+        out[name] = pictures
+        print(name, [sum(p["sizes"]) for p in pictures], flush=True)
+    json.dump(out, open(os.path.join(HERE, "entropy_inter.json"), "w"), indent=0, sort_keys=True)
+
+
 def main():
+    if "--entropy-inter" in sys.argv:
+        return update_entropy_inter()
     if "--inter" in sys.argv:
         return update_inter()
     if "--entropy" in sys.argv:

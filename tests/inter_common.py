@@ -162,6 +162,10 @@ CASES = [
 ]
 
 
+# the cases whose slice data is pinned (tests/golden/entropy_inter.json): every picture QP below 28 (the device's inter pass), SAO on / off, the wavefront MV restriction
+ENTROPY_CASES = ["pan", "ultrafast", "vertical-pan-owf", "static-qp17", "two-gops", "no-loop-filters", "deblock-only", "survey-416x240", "noisy-qp27", "cabac-coeff-cost-qp32"]
+
+
 def case_frames(case):
     name, w, h, n, qp, preset, dbk, sao, owf, src = case
     if src[0] == "motion":
@@ -239,3 +243,24 @@ def me_results_differ(a, b, fme_level):
         both = (a["frac_valid"] != 0) & (b["frac_valid"] != 0)
         bad |= both & ((a["frac_mv"] != b["frac_mv"]).any(axis=1) | (a["frac_mvp"] != b["frac_mvp"]) | (a["frac_cost"] != b["frac_cost"]) | (a["frac_bits"] != b["frac_bits"]))
     return np.flatnonzero(bad)
+
+
+def oracle_encode_bits(oracle, w, h, frames, qp, preset="veryfast", deblock=True, sao=None, mv_constraint=False, gop=(4, 3), no_wpp=False):
+    """kvz_oracle_lowdelay_encode_bits -> [(slice data of the picture, [substream sizes])] per picture"""
+    p = dict(PRESETS[preset])
+    if sao is not None:
+        p["sao"] = int(sao)
+    cfg = LowdelayCfg(qp=qp, gop_len=gop[0], gop_depth=gop[1], intra_period=64, deblock=int(deblock), mv_constraint=int(mv_constraint), no_wpp=int(no_wpp), ra8_qp_model=1, **p)
+    mc = cc.model_constants()
+    fb = (C.c_float * 128)(*mc["entropy_fbits"])
+    wts = (C.c_uint64 * 52)(*[int(mc["coeff_weights"][str(q)]) for q in range(52)])
+    n, fs = len(frames), w * h * 3 // 2
+    src = np.ascontiguousarray(np.concatenate(frames))
+    rows = 1 if no_wpp else (h + 63) // 64
+    cap = n * (w * h * 4 + 4096)
+    data, sizes, offs = np.zeros(cap, np.uint8), np.zeros((n, rows), np.uint32), np.zeros(n + 1, np.uint64)
+    f = oracle.lib.kvz_oracle_lowdelay_encode_bits
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p, C.c_void_p]
+    f(C.addressof(cfg), C.addressof(fb), C.addressof(wts), w, h, n, src.ctypes.data, None, None, data.ctypes.data, cap, sizes.ctypes.data, offs.ctypes.data)
+    return [(data[int(offs[k]):int(offs[k + 1])].tobytes(), [int(v) for v in sizes[k]]) for k in range(n)]

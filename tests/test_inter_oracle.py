@@ -107,3 +107,21 @@ def test_default_threading_gives_the_constrained_result():
         assert np.array_equal(np.fromfile(os.path.join(d, "rd.yuv"), np.uint8).reshape(n, -1), rrec)
         md5 = hashlib.md5(open(os.path.join(d, "o.hevc"), "rb").read()).hexdigest()
     assert md5 == GOLDEN["survey-416x240"]["bitstream_md5"] == "1e7a81653d1157ce05e9ffd85c7cd5cf"  # SURVEY.md App. C's inter stream
+
+
+import hashlib as _hashlib
+ENTROPY_GOLDEN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "entropy_inter.json")))
+
+
+@pytest.mark.parametrize("name", ic.ENTROPY_CASES)
+def test_oracle_slice_data_of_low_delay_sequences_equals_the_reference_encoders(oracle, name):
+    """oracle/kvz_oracle_entropy.inc e_b_picture -- kvz_encode_coding_tree with the inter syntax (skip / merge / inter_pred_idc / MVD / MVP index / rqt_root_cbf), in real mode --
+    and the I picture's coder inside a sequence (SAO decisions, picture QPs of the GOP): every picture's slice data and entry points are the reference encoder's
+    (tests/golden/entropy_inter.json, taken from kvazaar_ref's bitstreams by make_golden.py --entropy-inter)"""
+    case = [c for c in ic.CASES if c[0] == name][0]
+    _, w, h, n, qp, preset, dbk, sao, owf, src = case
+    got = ic.oracle_encode_bits(oracle, w, h, ic.case_frames(case), qp, preset=preset, deblock=bool(dbk), sao=bool(sao), mv_constraint=owf > 0)
+    assert len(got) == len(ENTROPY_GOLDEN[name])
+    for (data, sizes), g in zip(got, ENTROPY_GOLDEN[name]):
+        assert sizes == g["sizes"]
+        assert _hashlib.sha256(data).hexdigest()[:24] == g["sha"]
