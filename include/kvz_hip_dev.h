@@ -153,6 +153,14 @@ typedef struct kvz_hip_inter_params {
 } kvz_hip_inter_params;
 int  kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz_hip_cu_info *ref_cu, uint8_t *rec, kvz_hip_cu_info *cu, int16_t *coeff, int width,
                                 int height, int n_pictures, const kvz_hip_inter_params *params);
+/* The slice data of n B pictures -- kvz_encode_coding_tree with the inter syntax (encode_coding_tree.c:745-900, kvz_encode_inter_prediction_unit :311-421, kvz_encode_mvd
+ * :1062-1112), the residual coder and the arithmetic coder, as kvz_hip_batch_entropy_code does it for I pictures (kvz_hip_batch.h) -- from what the inter CTU pass left on
+ * the device: cu (its CU records), ref_cu (the reference pictures' records: the temporal MV predictor), coeff (its levels; the pass must have been given a coeff buffer).
+ * params: the pass's (qp, poc, no_wpp; sao != 0: the SAO syntax of the decisions the last kvz_hip_dev_loop_filters_inter(..., sao = 1) made on the same pictures).  The MV
+ * predictors the MVDs are coded against are derived again from the records (kvz_inter_get_mv_cand_cua, inter.c:1330-1352).  out (HOST) / substream_bytes (HOST, n_pictures x
+ * (CTU rows | 1)): as kvz_hip_batch_entropy_code.  Returns the total size, -1 on failure. */
+long kvz_hip_dev_entropy_code_inter(const kvz_hip_cu_info *cu, const kvz_hip_cu_info *ref_cu, const int16_t *coeff, int width, int height, int n_pictures,
+                                    const kvz_hip_inter_params *params, uint8_t *out, size_t capacity, uint32_t *substream_bytes);
 /* what the deblocking filter reads (kvz_hip_cu_dbk) of `count` CU records: type, depth, tr_depth, the luma coded block flag at tr_depth, motion */
 void kvz_hip_dev_cu_dbk_from_info(const kvz_hip_cu_info *cu, int count, kvz_hip_cu_dbk *out);
 

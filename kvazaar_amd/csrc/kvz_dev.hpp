@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <functional>
 #include <mutex>
 #include <vector>
 
@@ -1446,6 +1447,39 @@ int kvz_hip_batch_sao_params(kvz_hip_batch *b, int frame, kvz_hip_sao_params *lu
 // CTU pass (and of the loop filters' SAO decision).  Pictures are coded in chunks whose bin records fit a scratch budget (KVZ_HIP_ENTROPY_SCRATCH_MB, default 49152:
 // 25 MB per 1080p picture at the default capacity of 12 288 records per CTU); a CTU that produces more records than that makes its chunk run again with the room it needs.
 namespace kvz {
+// kvz_init_contexts for a B slice (context.c:36-193 row 0 of every table, :202-305) in the entropy coder's numbering: KVZ_HIP_CX_* then KVZ_EB_CX_* (kvz_entropy.hpp)
+inline void entropy_b_slice_contexts(int qp, uint8_t out[KVZ_ENTROPY_CTXS])
+{
+  static const uint8_t split[3] = { 107, 139, 126 }, skip[3] = { 197, 185, 201 }, mvd[2] = { 169, 198 }, inter_dir[5] = { 95, 79, 63, 31, 31 }, sig_cg[4] = { 121, 140, 61, 154 };
+  static const uint8_t sig[42] = { 170, 154, 139, 153, 139, 123, 123, 63, 124, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154,
+                                   170, 153, 138, 138, 122, 121, 122, 121, 167, 151, 183, 140, 151, 183, 140 };
+  static const uint8_t last[30] = { 125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79, 108, 123, 93, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154 };
+  static const uint8_t one[24] = { 154, 196, 167, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 122, 169, 208, 166, 167, 154, 152, 167, 182 };
+  static const uint8_t absf[6] = { 107, 167, 91, 107, 107, 167 };
+  uint8_t init[KVZ_ENTROPY_CTXS];
+  memset(init, 154, sizeof init);
+  for (int i = 0; i < 3; i++) { init[KVZ_HIP_CX_SPLIT + i] = split[i]; init[KVZ_EB_CX_SKIP + i] = skip[i]; }
+  init[KVZ_HIP_CX_PART] = 154; init[KVZ_HIP_CX_INTRA] = 183; init[KVZ_HIP_CX_CHROMA] = 152;
+  init[KVZ_HIP_CX_CBF_LUMA] = 153; init[KVZ_HIP_CX_CBF_LUMA + 1] = 111;
+  init[KVZ_HIP_CX_CBF_CHROMA] = 149; init[KVZ_HIP_CX_CBF_CHROMA + 1] = 92; init[KVZ_HIP_CX_CBF_CHROMA_DEEP] = 167; init[KVZ_HIP_CX_CBF_CHROMA_DEEP + 1] = 154;
+  for (int i = 0; i < 4; i++) init[KVZ_HIP_CX_SIG_CG + i] = sig_cg[i];
+  for (int i = 0; i < 27; i++) init[KVZ_HIP_CX_SIG_LUMA + i] = sig[i];
+  for (int i = 0; i < 15; i++) {
+    init[KVZ_HIP_CX_SIG_CHROMA + i] = sig[27 + i];
+    init[KVZ_HIP_CX_LAST_Y_LUMA + i] = init[KVZ_HIP_CX_LAST_X_LUMA + i] = last[i];
+    init[KVZ_HIP_CX_LAST_Y_CHROMA + i] = init[KVZ_HIP_CX_LAST_X_CHROMA + i] = last[15 + i];
+  }
+  for (int i = 0; i < 16; i++) init[KVZ_HIP_CX_ONE_LUMA + i] = one[i];
+  for (int i = 0; i < 8; i++) init[KVZ_HIP_CX_ONE_CHROMA + i] = one[16 + i];
+  for (int i = 0; i < 4; i++) init[KVZ_HIP_CX_ABS_LUMA + i] = absf[i];
+  for (int i = 0; i < 2; i++) init[KVZ_HIP_CX_ABS_CHROMA + i] = absf[4 + i];
+  init[KVZ_HIP_CX_SAO_MERGE] = 153; init[KVZ_HIP_CX_SAO_TYPE] = 160;
+  init[KVZ_EB_CX_MERGE_FLAG] = 154; init[KVZ_EB_CX_MERGE_IDX] = 137; init[KVZ_EB_CX_PRED_MODE] = 134;
+  init[KVZ_EB_CX_MVD] = mvd[0]; init[KVZ_EB_CX_MVD + 1] = mvd[1]; init[KVZ_EB_CX_MVP_IDX] = 168;
+  for (int i = 0; i < 5; i++) init[KVZ_EB_CX_INTER_DIR + i] = inter_dir[i];
+  init[KVZ_EB_CX_ROOT_CBF] = 79;
+  for (int i = 0; i < KVZ_ENTROPY_CTXS; i++) out[i] = (uint8_t)ctx_state(qp, init[i]);
+}
 // scratch of the entropy coder, kept between calls (grow-only; hipMalloc / hipFree per call cost more than a small batch's kernels): one caller at a time
 struct EntropyScratch {
   std::mutex lock;
@@ -1463,28 +1497,20 @@ struct EntropyScratch {
 };
 inline EntropyScratch &entropy_scratch(int device) { static EntropyScratch s[64]; return s[device & 63]; }  // buffers live on the device they were allocated on
 }  // namespace kvz
-long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, uint8_t *out, size_t capacity, uint32_t *substream_bytes)
+namespace kvz {
+// The stages of kvz_entropy.hpp over n_frames pictures, in chunks whose bin records fit the scratch budget.  job(f0, nf): the chunk's inputs (everything of EntropyJob but
+// the scratch pointers); not_last: host flags or null.
+inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc, int hc, int no_wpp, const uint8_t *not_last, const std::function<EntropyJob(int, int)> &job,
+                                  uint8_t *out, size_t capacity, uint32_t *substream_bytes)
 {
-  return kvz_hip_batch_entropy_code_tiles(b, model, sao, nullptr, out, capacity, substream_bytes);
-}
-long kvz_hip_batch_entropy_code_tiles(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, const uint8_t *not_last, uint8_t *out, size_t capacity,
-                                      uint32_t *substream_bytes)
-{
-  kvz::batch_enter(b);
-  kvz::EntropyScratch &S = kvz::entropy_scratch(b->device);
+  EntropyScratch &S = entropy_scratch(device);
   std::lock_guard<std::mutex> guard(S.lock);
-  const kvz::CtuFrames &F = b->F;
-  const int n = b->n_frames, ctus = F.wc * F.hc, rows = model->no_wpp ? 1 : F.hc;
-  if (sao && !b->d_sao_recs) { fprintf(stderr, "kvz_hip_batch_entropy_code: kvz_hip_batch_loop_filters(..., sao = 1) has not run on this batch\n"); return -1; }
-  if (model->search_nxn && !b->d_part) { fprintf(stderr, "kvz_hip_batch_entropy_code: the batch has no NxN partition maps\n"); return -1; }
-  KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
-  if (kvz::batch_check(b) != 0) return -1;
+  const int ctus = wc * hc, rows = no_wpp ? 1 : hc;
   size_t budget = 49152;
   if (const char *e = getenv("KVZ_HIP_ENTROPY_SCRATCH_MB")) { const long v = atol(e); if (v > 0) budget = (size_t)v; }
   budget <<= 20;
   uint32_t cap = 12288;
   if (const char *e = getenv("KVZ_HIP_ENTROPY_CAP")) { const long v = atol(e); if (v > 0) cap = ((uint32_t)v + 15u) & ~15u; }
-  const long cells8 = (long)(F.H >> 3) * (F.W >> 3), cells4 = (long)(F.H >> 2) * (F.W >> 2);
   std::vector<uint32_t> counts, bound_bits, sizes;
   std::vector<unsigned long long> offsets, bound_offsets;
   size_t total = 0;
@@ -1498,23 +1524,16 @@ long kvz_hip_batch_entropy_code_tiles(kvz_hip_batch *b, const kvz_hip_intra_cost
     uint32_t *d_nbits = (uint32_t *)S.need(S.nbits, (size_t)items * sizeof(uint32_t)), *d_sizes = (uint32_t *)S.need(S.sizes, (size_t)streams * sizeof(uint32_t));
     unsigned long long *d_offsets = (unsigned long long *)S.need(S.offsets, (size_t)streams * sizeof(unsigned long long));
     unsigned long long *d_bound_offsets = (unsigned long long *)S.need(S.bound_offsets, (size_t)streams * sizeof(unsigned long long));
-    uint8_t *d_rowctx = (uint8_t *)S.need(S.rowctx, (size_t)nf * F.hc * KVZ_ENTROPY_CTXS), *d_out = nullptr, *d_scratch = nullptr;
+    uint8_t *d_rowctx = (uint8_t *)S.need(S.rowctx, (size_t)nf * hc * KVZ_ENTROPY_CTXS), *d_out = nullptr, *d_scratch = nullptr;
     uint8_t *d_not_last = not_last ? (uint8_t *)S.need(S.not_last, (size_t)nf) : nullptr;
-    if (not_last) KVZ_HIP_CHECK(hipMemcpyAsync(d_not_last, not_last + f0, (size_t)nf, hipMemcpyHostToDevice, b->stream));
-    kvz::EntropyJob J;
-    memset(&J, 0, sizeof J);
-    J.W = F.W; J.H = F.H; J.wc = F.wc; J.hc = F.hc; J.n_frames = nf; J.no_wpp = model->no_wpp;
-    J.depth = b->d_depth + f0 * cells8; J.mode = b->d_mode + f0 * cells8;
-    J.part = model->search_nxn ? b->d_part + f0 * cells8 : nullptr; J.mode4 = model->search_nxn ? b->d_mode4 + f0 * cells4 : nullptr;
-    J.coeff = b->d_coeff + (size_t)f0 * ctus * KVZ_HIP_CTU_COEFFS;
-    J.sao = sao ? (const kvz::SaoRec *)b->d_sao_recs + (size_t)f0 * ctus * 3 : nullptr; J.sao_merge = sao ? b->d_sao_merge + (size_t)f0 * ctus : nullptr;
+    if (not_last) KVZ_HIP_CHECK(hipMemcpyAsync(d_not_last, not_last + f0, (size_t)nf, hipMemcpyHostToDevice, stream));
+    EntropyJob J = job(f0, nf);
     J.bins = d_bins; J.nbins = d_nbins; J.nbits = d_nbits; J.cap = cap; J.row_ctx = d_rowctx; J.not_last = d_not_last;
-    memcpy(J.ctx_init, model->ctx_init, sizeof model->ctx_init < sizeof J.ctx_init ? sizeof model->ctx_init : sizeof J.ctx_init);
-    hipLaunchKernelGGL(kvz::dev_entropy_bins_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, b->stream, J, kvz::device_tables(), items);
+    hipLaunchKernelGGL(dev_entropy_bins_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, stream, J, device_tables(), items);
     counts.resize((size_t)items); bound_bits.resize((size_t)items);
-    KVZ_HIP_CHECK(hipMemcpyAsync(counts.data(), d_nbins, (size_t)items * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
-    KVZ_HIP_CHECK(hipMemcpyAsync(bound_bits.data(), d_nbits, (size_t)items * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
-    KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+    KVZ_HIP_CHECK(hipMemcpyAsync(counts.data(), d_nbins, (size_t)items * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    KVZ_HIP_CHECK(hipMemcpyAsync(bound_bits.data(), d_nbits, (size_t)items * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    KVZ_HIP_CHECK(hipStreamSynchronize(stream));
     uint32_t most = 0;
     for (uint32_t c : counts) most = c > most ? c : most;
     const bool again = most > cap;
@@ -1522,7 +1541,7 @@ long kvz_hip_batch_entropy_code_tiles(kvz_hip_batch *b, const kvz_hip_intra_cost
       // room per substream: the bound of its CTUs' bits, the coder's flush, and an emulation prevention byte after every two bytes at worst
       bound_offsets.resize((size_t)streams);
       unsigned long long scratch_bytes = 0;
-      const long per_stream = model->no_wpp ? ctus : F.wc;
+      const long per_stream = no_wpp ? ctus : wc;
       for (long i = 0; i < streams; i++) {
         unsigned long long bits = 0;
         for (long k = 0; k < per_stream; k++) bits += bound_bits[(size_t)(i * per_stream + k)];
@@ -1530,19 +1549,19 @@ long kvz_hip_batch_entropy_code_tiles(kvz_hip_batch *b, const kvz_hip_intra_cost
         scratch_bytes += (((bits + 7) / 8 + 16) * 3 / 2 + 15) & ~15ull;
       }
       d_scratch = (uint8_t *)S.need(S.scratch, scratch_bytes ? scratch_bytes : 16);
-      KVZ_HIP_CHECK(hipMemcpyAsync(d_bound_offsets, bound_offsets.data(), (size_t)streams * sizeof(unsigned long long), hipMemcpyHostToDevice, b->stream));
+      KVZ_HIP_CHECK(hipMemcpyAsync(d_bound_offsets, bound_offsets.data(), (size_t)streams * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
       static const int lanes = [] { const char *e = getenv("KVZ_HIP_ENTROPY_LANES"); const int v = e ? atoi(e) : 16; return v == 64 || v == 32 || v == 8 ? v : 16; }();
-      if (!model->no_wpp) hipLaunchKernelGGL(kvz::dev_entropy_row_ctx_kernel<8>, dim3((unsigned)((nf + 7) / 8)), dim3(8), 0, b->stream, J, kvz::device_tables());
+      if (!no_wpp) hipLaunchKernelGGL(dev_entropy_row_ctx_kernel<8>, dim3((unsigned)((nf + 7) / 8)), dim3(8), 0, stream, J, device_tables());
       {
         const dim3 grid((unsigned)((streams + lanes - 1) / lanes)), block((unsigned)lanes);
-        if (lanes == 64) hipLaunchKernelGGL(kvz::dev_entropy_code_kernel<64>, grid, block, 0, b->stream, J, kvz::device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
-        else if (lanes == 32) hipLaunchKernelGGL(kvz::dev_entropy_code_kernel<32>, grid, block, 0, b->stream, J, kvz::device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
-        else if (lanes == 8) hipLaunchKernelGGL(kvz::dev_entropy_code_kernel<8>, grid, block, 0, b->stream, J, kvz::device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
-        else hipLaunchKernelGGL(kvz::dev_entropy_code_kernel<16>, grid, block, 0, b->stream, J, kvz::device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
+        if (lanes == 64) hipLaunchKernelGGL(dev_entropy_code_kernel<64>, grid, block, 0, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
+        else if (lanes == 32) hipLaunchKernelGGL(dev_entropy_code_kernel<32>, grid, block, 0, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
+        else if (lanes == 8) hipLaunchKernelGGL(dev_entropy_code_kernel<8>, grid, block, 0, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
+        else hipLaunchKernelGGL(dev_entropy_code_kernel<16>, grid, block, 0, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
       }
       sizes.resize((size_t)streams);
-      KVZ_HIP_CHECK(hipMemcpyAsync(sizes.data(), d_sizes, (size_t)streams * sizeof(uint32_t), hipMemcpyDeviceToHost, b->stream));
-      KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+      KVZ_HIP_CHECK(hipMemcpyAsync(sizes.data(), d_sizes, (size_t)streams * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      KVZ_HIP_CHECK(hipStreamSynchronize(stream));
       offsets.resize((size_t)streams);
       unsigned long long chunk_bytes = 0;
       for (long i = 0; i < streams; i++) { offsets[(size_t)i] = chunk_bytes; chunk_bytes += sizes[(size_t)i]; }
@@ -1551,11 +1570,11 @@ long kvz_hip_batch_entropy_code_tiles(kvz_hip_batch *b, const kvz_hip_intra_cost
         rc = -1;
       } else {
         d_out = (uint8_t *)S.need(S.out, chunk_bytes ? chunk_bytes : 1);
-        KVZ_HIP_CHECK(hipMemcpyAsync(d_offsets, offsets.data(), (size_t)streams * sizeof(unsigned long long), hipMemcpyHostToDevice, b->stream));
-        hipLaunchKernelGGL(kvz::dev_entropy_compact_kernel, dim3((unsigned)streams), dim3(256), 0, b->stream, d_scratch, d_bound_offsets, d_sizes, d_offsets, d_out);
+        KVZ_HIP_CHECK(hipMemcpyAsync(d_offsets, offsets.data(), (size_t)streams * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(dev_entropy_compact_kernel, dim3((unsigned)streams), dim3(256), 0, stream, d_scratch, d_bound_offsets, d_sizes, d_offsets, d_out);
         KVZ_HIP_CHECK(hipGetLastError());
-        KVZ_HIP_CHECK(hipMemcpyAsync(out + total, d_out, chunk_bytes, hipMemcpyDeviceToHost, b->stream));
-        KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+        KVZ_HIP_CHECK(hipMemcpyAsync(out + total, d_out, chunk_bytes, hipMemcpyDeviceToHost, stream));
+        KVZ_HIP_CHECK(hipStreamSynchronize(stream));
         memcpy(substream_bytes + (size_t)f0 * rows, sizes.data(), (size_t)streams * sizeof(uint32_t));
         total += chunk_bytes;
         f0 += nf;
@@ -1564,6 +1583,66 @@ long kvz_hip_batch_entropy_code_tiles(kvz_hip_batch *b, const kvz_hip_intra_cost
     if (again) cap = (most + 1023u) & ~1023u;  // this chunk again, with room for its largest CTU
   }
   return rc ? rc : (long)total;
+}
+}  // namespace kvz
+
+long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, uint8_t *out, size_t capacity, uint32_t *substream_bytes)
+{
+  return kvz_hip_batch_entropy_code_tiles(b, model, sao, nullptr, out, capacity, substream_bytes);
+}
+long kvz_hip_batch_entropy_code_tiles(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, const uint8_t *not_last, uint8_t *out, size_t capacity,
+                                      uint32_t *substream_bytes)
+{
+  kvz::batch_enter(b);
+  const kvz::CtuFrames &F = b->F;
+  const int ctus = F.wc * F.hc;
+  if (sao && !b->d_sao_recs) { fprintf(stderr, "kvz_hip_batch_entropy_code: kvz_hip_batch_loop_filters(..., sao = 1) has not run on this batch\n"); return -1; }
+  if (model->search_nxn && !b->d_part) { fprintf(stderr, "kvz_hip_batch_entropy_code: the batch has no NxN partition maps\n"); return -1; }
+  KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+  if (kvz::batch_check(b) != 0) return -1;
+  const long cells8 = (long)(F.H >> 3) * (F.W >> 3), cells4 = (long)(F.H >> 2) * (F.W >> 2);
+  auto job = [&](int f0, int nf) {
+    kvz::EntropyJob J;
+    memset(&J, 0, sizeof J);
+    J.W = F.W; J.H = F.H; J.wc = F.wc; J.hc = F.hc; J.n_frames = nf; J.no_wpp = model->no_wpp;
+    J.depth = b->d_depth + f0 * cells8; J.mode = b->d_mode + f0 * cells8;
+    J.part = model->search_nxn ? b->d_part + f0 * cells8 : nullptr; J.mode4 = model->search_nxn ? b->d_mode4 + f0 * cells4 : nullptr;
+    J.coeff = b->d_coeff + (size_t)f0 * ctus * KVZ_HIP_CTU_COEFFS;
+    J.sao = sao ? (const kvz::SaoRec *)b->d_sao_recs + (size_t)f0 * ctus * 3 : nullptr; J.sao_merge = sao ? b->d_sao_merge + (size_t)f0 * ctus : nullptr;
+    memcpy(J.ctx_init, model->ctx_init, sizeof model->ctx_init < sizeof J.ctx_init ? sizeof model->ctx_init : sizeof J.ctx_init);
+    return J;
+  };
+  return kvz::entropy_code_pictures(b->stream, b->device, b->n_frames, F.wc, F.hc, model->no_wpp, not_last, job, out, capacity, substream_bytes);
+}
+
+// ... of B pictures: the CU records, levels and (with sao) the SAO decisions of the last kvz_hip_dev_loop_filters_inter as the inter CTU pass / the loop filters left them
+long kvz_hip_dev_entropy_code_inter(const kvz_hip_cu_info *cu, const kvz_hip_cu_info *ref_cu, const int16_t *coeff, int width, int height, int n_pictures,
+                                    const kvz_hip_inter_params *params, uint8_t *out, size_t capacity, uint32_t *substream_bytes)
+{
+  if (n_pictures <= 0) return 0;
+  if (!cu || !ref_cu || !coeff || !params || width <= 0 || height <= 0 || (width & 7) || (height & 7) || params->qp < 0 || params->qp > 51 || params->poc < 1) {
+    fprintf(stderr, "kvz_hip_dev_entropy_code_inter: bad argument\n");
+    return -1;
+  }
+  const int wc = (width + 63) >> 6, hc = (height + 63) >> 6, ctus = wc * hc;
+  const long cells4 = (long)(height >> 2) * (width >> 2);
+  kvz::LoopScratch &ls = kvz::loop_scratch();
+  if (params->sao && (!ls.recs || ls.lcus < (size_t)ctus * n_pictures)) { fprintf(stderr, "kvz_hip_dev_entropy_code_inter: kvz_hip_dev_loop_filters_inter(..., sao = 1) has not run on these pictures\n"); return -1; }
+  uint8_t init[KVZ_ENTROPY_CTXS];
+  kvz::entropy_b_slice_contexts(params->qp, init);
+  int device = 0;
+  KVZ_HIP_CHECK(hipGetDevice(&device));
+  auto job = [&](int f0, int nf) {
+    kvz::EntropyJob J;
+    memset(&J, 0, sizeof J);
+    J.W = width; J.H = height; J.wc = wc; J.hc = hc; J.n_frames = nf; J.no_wpp = params->no_wpp;
+    J.cu = cu + f0 * cells4; J.ref_cu = ref_cu + f0 * cells4; J.poc = params->poc;
+    J.coeff = coeff + (size_t)f0 * ctus * KVZ_HIP_CTU_COEFFS;
+    J.sao = params->sao ? ls.recs + (size_t)f0 * ctus * 3 : nullptr; J.sao_merge = params->sao ? ls.merge + (size_t)f0 * ctus : nullptr;
+    memcpy(J.ctx_init, init, sizeof init);
+    return J;
+  };
+  return kvz::entropy_code_pictures(be().stream, device, n_pictures, wc, hc, params->no_wpp, nullptr, job, out, capacity, substream_bytes);
 }
 
 void kvz_hip_dev_picture_md5(const uint8_t *frames, int width, int height, int n_frames, uint8_t *out)

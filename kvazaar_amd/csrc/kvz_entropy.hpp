@@ -21,8 +21,15 @@
 #include "kvz_ops.hpp"
 #include "kvz_sao.hpp"
 #include "../../include/kvz_hip_types.h"
+#include "../../include/kvz_hip_dev.h"
 
 namespace kvz {
+
+#define KVZ_ENTROPY_CTXS 168
+// contexts of the inter syntax, behind the KVZ_HIP_CX_* ones (cabac.h:63-100: cu_skip_flag_model[3], cu_merge_flag_ext_model, cu_merge_idx_ext_model, cu_pred_mode_model,
+// cu_mvd_model[2], mvp_idx_model[2], inter_dir[5], cu_qt_root_cbf_model)
+enum { KVZ_EB_CX_SKIP = 150, KVZ_EB_CX_MERGE_FLAG = 153, KVZ_EB_CX_MERGE_IDX = 154, KVZ_EB_CX_PRED_MODE = 155, KVZ_EB_CX_MVD = 156, KVZ_EB_CX_MVP_IDX = 158,
+       KVZ_EB_CX_INTER_DIR = 160, KVZ_EB_CX_ROOT_CBF = 165 };
 
 struct EntropyJob {
   int W, H, wc, hc, n_frames, no_wpp;
@@ -37,9 +44,11 @@ struct EntropyJob {
   u32 cap;
   u32 *nbits;                  // [frames * ctus] upper bound of the bits the CTU's records make the coder emit (sizes the substreams' scratch)
   u8 *row_ctx;                 // [frames][hc][KVZ_ENTROPY_CTXS] context states at the start of every row
-  u8 ctx_init[152];            // the slice's initial states (kvz_hip_intra_cost_model::ctx_init)
+  // B pictures (kvz_hip_dev_entropy_code_inter): the CU records of the pictures and of their reference pictures, one per 4x4 unit; then depth / mode / part are unused
+  const kvz_hip_cu_info *cu, *ref_cu;  // [frames][(H/4)*(W/4)]
+  int poc;                     // temporal MV predictors need poc > 1 (inter.c:1290)
+  u8 ctx_init[KVZ_ENTROPY_CTXS];  // the slice's initial states: kvz_hip_intra_cost_model::ctx_init (KVZ_HIP_CX_* order); B slices: + the KVZ_EB_CX_* contexts
 };
-#define KVZ_ENTROPY_CTXS 152
 #define KVZ_EB_CTX(ctx, v) ((u32)(ctx) | ((u32)(v) << 8))
 #define KVZ_EB_EP(value, n) (0x40000000u | ((u32)(n) << 16) | ((u32)(value) & 0xffffu))
 #define KVZ_EB_TRM(v) (0x80000000u | (u32)(v))
@@ -359,13 +368,217 @@ struct EntropyCtu {  // one CTU of one picture
   }
 };
 
+// ---- B pictures: kvz_encode_coding_tree with the inter syntax, from the frame-level CU records of the inter CTU pass (kvz_hip_dev_inter_ctu_pass) ----
+// One reference picture per list, 2Nx2N CUs, max_merge 5 (BASELINE config 4's presets).  What the records do not hold are the MV predictors the MVDs are coded against:
+// kvz_inter_get_mv_cand_cua (inter.c:1330-1352) derived again here from the neighbours' records -- all of them final by now, availability is a matter of coding order.
+struct EntropyCtuB {
+  const EntropyJob &J;
+  const Tables *tb;
+  const kvz_hip_cu_info *cu, *ref_cu;  // the picture's, the reference picture's
+  const i16 *ctu;
+  int w4, cx, cy;
+  KVZ_DEV const kvz_hip_cu_info &at(int x, int y) const { return cu[(y >> 2) * w4 + (x >> 2)]; }
+  KVZ_DEV static bool a0_coded(int x, int y, int width, int height)  // inter.c:686-741 is_a0_cand_coded
+  {
+    int size = (width & -width) < (height & -height) ? (width & -width) : (height & -height);
+    if (height != size) y = y + height - size;
+    while (size < 64) {
+      const int parent = 2 * size, idx = (x % parent != 0) + 2 * (y % parent != 0);
+      if (idx == 0) return true;
+      if (idx == 1 || idx == 3) return false;
+      y -= size; size = parent;
+    }
+    return false;
+  }
+  KVZ_DEV static bool b0_coded(int x, int y, int width, int height)  // inter.c:743-798 is_b0_cand_coded
+  {
+    int size = (width & -width) < (height & -height) ? (width & -width) : (height & -height);
+    if (width != size) x = x + width - size;
+    while (size < 64) {
+      const int parent = 2 * size, idx = (x % parent != 0) + 2 * (y % parent != 0);
+      if (idx == 0 || idx == 2) return true;
+      if (idx == 3) return false;
+      x -= size; size = parent;
+    }
+    return true;
+  }
+  KVZ_DEV static bool add_mvp(const kvz_hip_cu_info &c, bool valid, int reflist, i16 out[2])  // inter.c:1121-1145 add_mvp_candidate, one reference picture
+  {
+    if (!valid) return false;
+    for (int i = 0; i < 2; i++) {
+      const int l = i == 0 ? reflist : !reflist;
+      if ((c.mv_dir & (1 << l)) == 0) continue;
+      out[0] = c.mv[l][0]; out[1] = c.mv[l][1];
+      return true;
+    }
+    return false;
+  }
+  KVZ_DEV void mv_candidates(int x, int y, int w, int h, int reflist, i16 mv_cand[2][2]) const  // inter.c:1147-1352
+  {
+    const int xl = x - cx, yl = y - cy;
+    kvz_hip_cu_info a[2], b[3], col;
+    bool va[2] = { false, false }, vb[3] = { false, false, false }, vcol = false;
+    if (x != 0) {
+      const kvz_hip_cu_info &a1 = at(x - 1, y + h - 1);
+      if (a1.type == 2) { a[1] = a1; va[1] = true; }
+      if (yl + h < 64 && y + h < J.H) { const kvz_hip_cu_info &a0 = at(x - 1, y + h); if (a0.type == 2 && a0_coded(x, y, w, h)) { a[0] = a0; va[0] = true; } }
+    }
+    if (y != 0) {
+      if (x + w < J.W && (xl + w < 64 || yl == 0)) { const kvz_hip_cu_info &b0 = at(x + w, y - 1); if (b0.type == 2 && b0_coded(x, y, w, h)) { b[0] = b0; vb[0] = true; } }
+      const kvz_hip_cu_info &b1 = at(x + w - 1, y - 1);
+      if (b1.type == 2) { b[1] = b1; vb[1] = true; }
+      if (x != 0) { const kvz_hip_cu_info &b2 = at(x - 1, y - 1); if (b2.type == 2) { b[2] = b2; vb[2] = true; } }
+    }
+    if (J.poc >= 1) {  // inter.c:1204-1260: H (below right, not across the CTU row) before C3 (centre), at 16-sample granularity in the reference picture
+      const int xbr = x + w, ybr = y + h, xc = x + w / 2, yc = y + h / 2;
+      bool vh = false;
+      if (xbr < J.W && ybr < J.H && ybr % 64 != 0) { const kvz_hip_cu_info &c = ref_cu[(((ybr >> 4) << 4) >> 2) * w4 + (((xbr >> 4) << 4) >> 2)]; if (c.type == 2) { col = c; vh = true; } }
+      vcol = vh;
+      if (!vh && xc < J.W && yc < J.H) { const kvz_hip_cu_info &c = ref_cu[(((yc >> 4) << 4) >> 2) * w4 + (((xc >> 4) << 4) >> 2)]; if (c.type == 2) { col = c; vcol = true; } }
+    }
+    int n = 0, nb_b = 0;
+    for (int i = 0; i < 2; i++) if (add_mvp(a[i], va[i], reflist, mv_cand[n])) { n++; break; }
+    if (n == 0) for (int i = 0; i < 2; i++) if (add_mvp(a[i], va[i], reflist, mv_cand[n])) { n++; break; }
+    for (int i = 0; i < 3; i++) if (add_mvp(b[i], vb[i], reflist, mv_cand[n < 2 ? n : 1])) { nb_b++; break; }
+    n += nb_b;
+    if (va[0] || va[1]) nb_b = 1; else if (n != 2) nb_b = 0;
+    if (!nb_b) for (int i = 0; i < 3; i++) if (add_mvp(b[i], vb[i], reflist, mv_cand[n < 2 ? n : 1])) { n++; break; }
+    if (n == 2 && mv_cand[0][0] == mv_cand[1][0] && mv_cand[0][1] == mv_cand[1][1]) n = 1;
+    if (J.poc > 1 && n < 2 && vcol) {
+      int col_list = reflist;
+      if ((col.mv_dir & (col_list + 1)) == 0) col_list = 1 - col_list;
+      mv_cand[n][0] = col.mv[col_list][0]; mv_cand[n][1] = col.mv[col_list][1];
+      n++;
+    }
+    while (n < 2) { mv_cand[n][0] = 0; mv_cand[n][1] = 0; n++; }
+  }
+  KVZ_DEV static void merge_idx(BinSink &s, int idx)  // encode_coding_tree.c:323-338
+  {
+    for (int ui = 0; ui < 4; ui++) {
+      const int symbol = ui != idx;
+      if (ui == 0) s.ctx(KVZ_EB_CX_MERGE_IDX, symbol); else s.ep((u32)symbol, 1);
+      if (!symbol) break;
+    }
+  }
+  KVZ_DEV static void ex_golomb(BinSink &s, u32 symbol, u32 count)  // cabac.c:556-586 kvz_cabac_write_ep_ex_golomb
+  {
+    u32 bins = 0;
+    int num_bins = 0;
+    while (symbol >= (1u << count)) { bins = 2 * bins + 1; ++num_bins; symbol -= 1u << count; ++count; }
+    bins = 2 * bins; ++num_bins;
+    bins = (bins << count) | symbol;
+    s.ep(bins, num_bins + (int)count);
+  }
+  KVZ_DEV static void mvd(BinSink &s, int hor, int ver)  // encode_coding_tree.c:1062-1112 kvz_encode_mvd
+  {
+    const u32 ah = (u32)iabs(hor), av = (u32)iabs(ver);
+    s.ctx(KVZ_EB_CX_MVD, hor != 0);
+    s.ctx(KVZ_EB_CX_MVD, ver != 0);
+    if (hor) s.ctx(KVZ_EB_CX_MVD + 1, ah > 1);
+    if (ver) s.ctx(KVZ_EB_CX_MVD + 1, av > 1);
+    if (hor) { if (ah > 1) ex_golomb(s, ah - 2, 1); s.ep(hor > 0 ? 0 : 1, 1); }
+    if (ver) { if (av > 1) ex_golomb(s, av - 2, 1); s.ep(ver > 0 ? 0 : 1, 1); }
+  }
+  KVZ_DEV static bool cbf_set(u32 cbf, int depth, int plane) { const u32 masks[5] = { 0x1f, 0x0f, 0x07, 0x03, 0x1 }; return (cbf & (masks[depth] << (5 * plane))) != 0; }  // cu.h:510-569
+  KVZ_DEV void coding_unit(BinSink &s, int x, int y, int depth) const
+  {
+    const kvz_hip_cu_info &cur = at(x, y);
+    const int w = 64 >> depth, xl = x - cx, yl = y - cy, log2w = 6 - depth, log2c = depth == 3 ? 2 : log2w - 1;
+    int skip_ctx = 0;
+    if (x) skip_ctx += at(x - 1, y).skipped;
+    if (y) skip_ctx += at(x, y - 1).skipped;
+    s.ctx(KVZ_EB_CX_SKIP + skip_ctx, cur.skipped);
+    if (cur.skipped) { merge_idx(s, cur.merge_idx); return; }
+    s.ctx(KVZ_EB_CX_PRED_MODE, cur.type == 1);
+    if (cur.type == 2 || depth == 3) s.ctx(KVZ_HIP_CX_PART, 1);  // 2Nx2N
+    const bool cb_y = cbf_set(cur.cbf, depth, 0), cb_u = cbf_set(cur.cbf, depth, 1), cb_v = cbf_set(cur.cbf, depth, 2);
+    int scan = 0;
+    if (cur.type == 2) {
+      s.ctx(KVZ_EB_CX_MERGE_FLAG, cur.merged);
+      if (cur.merged) merge_idx(s, cur.merge_idx);
+      else {
+        const int inter_dir = cur.mv_dir - 1;
+        s.ctx(KVZ_EB_CX_INTER_DIR + depth, inter_dir == 2);
+        if (inter_dir < 2) s.ctx(KVZ_EB_CX_INTER_DIR + 4, inter_dir);
+        for (int l = 0; l < 2; l++) {
+          if (!(cur.mv_dir & (1 << l))) continue;
+          i16 cand[2][2];
+          mv_candidates(x, y, w, w, l, cand);
+          const int k = cur.mv_cand[l];
+          mvd(s, cur.mv[l][0] - cand[k][0], cur.mv[l][1] - cand[k][1]);
+          s.ctx(KVZ_EB_CX_MVP_IDX, k);
+        }
+      }
+      const bool any = cb_y || cb_u || cb_v;
+      if (!cur.merged) s.ctx(KVZ_EB_CX_ROOT_CBF, any);
+      if (!any) return;
+      s.ctx(KVZ_HIP_CX_CBF_CHROMA, cb_u);
+      s.ctx(KVZ_HIP_CX_CBF_CHROMA, cb_v);
+      if (cb_u || cb_v) s.ctx(KVZ_HIP_CX_CBF_LUMA + 1, cb_y);
+    } else {
+      int l = 1, a = 1;
+      if (x > 0 && at(x - 1, y).type == 1) l = at(x - 1, y).mode;
+      if (y % 64 > 0 && y > 0 && at(x, y - 1).type == 1) a = at(x, y - 1).mode;
+      int preds[3], mpm = -1;
+      EntropyCtu::mpm_candidates(l, a, preds);
+      for (int i = 2; i >= 0; i--) if (preds[i] == cur.mode) mpm = i;
+      s.ctx(KVZ_HIP_CX_INTRA, mpm != -1);
+      if (mpm != -1) { s.ep(mpm == 0 ? 0 : 1, 1); if (mpm != 0) s.ep(mpm == 1 ? 0 : 1, 1); }
+      else {
+        int t;
+        if (preds[0] > preds[1]) { t = preds[0]; preds[0] = preds[1]; preds[1] = t; }
+        if (preds[0] > preds[2]) { t = preds[0]; preds[0] = preds[2]; preds[2] = t; }
+        if (preds[1] > preds[2]) { t = preds[1]; preds[1] = preds[2]; preds[2] = t; }
+        int rem = cur.mode;
+        for (int i = 2; i >= 0; i--) rem = rem > preds[i] ? rem - 1 : rem;
+        s.ep((u32)rem, 5);
+      }
+      s.ctx(KVZ_HIP_CX_CHROMA, 0);
+      s.ctx(KVZ_HIP_CX_CBF_CHROMA, cb_u);
+      s.ctx(KVZ_HIP_CX_CBF_CHROMA, cb_v);
+      s.ctx(KVZ_HIP_CX_CBF_LUMA + 1, cb_y);
+      scan = entropy_scan_order(cur.mode, depth);
+    }
+    if (cb_y) entropy_coeff_nxn(s, tb, ctu + entropy_zorder(xl, yl), log2w, 0, scan);
+    if (cb_u) entropy_coeff_nxn(s, tb, ctu + 4096 + entropy_zorder(xl / 2, yl / 2), log2c, 2, scan);
+    if (cb_v) entropy_coeff_nxn(s, tb, ctu + 5120 + entropy_zorder(xl / 2, yl / 2), log2c, 2, scan);
+  }
+  KVZ_DEV void coding_tree(BinSink &s) const
+  {
+    int stack[16], sp = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+      const int node = stack[--sp], depth = node >> 8, x = cx + ((node & 15) << 3), y = cy + (((node >> 4) & 15) << 3);
+      const int w = 64 >> depth, half = w >> 1;
+      const bool split_flag = at(x, y).depth > depth;
+      const bool border_x = J.W < x + w, border_y = J.H < y + w, border = border_x || border_y;
+      const bool border_split_x = J.W >= x + 8 + half, border_split_y = J.H >= y + 8 + half;
+      if (depth != 3) {
+        if (!border) {
+          int sm = 0;
+          if (x > 0 && at(x - 1, y).depth > depth) sm++;
+          if (y > 0 && at(x, y - 1).depth > depth) sm++;
+          s.ctx(KVZ_HIP_CX_SPLIT + sm, split_flag);
+        }
+        if (split_flag || border) {
+          const int h8 = half >> 3, base = (node & 0xff) | ((depth + 1) << 8);
+          if (!border || (border_split_x && border_split_y)) stack[sp++] = base + h8 + (h8 << 4);
+          if (!border_y || border_split_y) stack[sp++] = base + (h8 << 4);
+          if (!border_x || border_split_x) stack[sp++] = base + h8;
+          stack[sp++] = base;
+          continue;
+        }
+      }
+      coding_unit(s, x, y, depth);
+    }
+  }
+};
+
 // stage 1: the bins of CTU `item` (frame-major, raster CTU order inside a frame)
 KVZ_DEV void entropy_ctu_bins(const EntropyJob &J, const Tables *tb, long item)
 {
   const int ctus = J.wc * J.hc, f = (int)(item / ctus), k = (int)(item - (long)f * ctus), lx = k % J.wc, ly = k / J.wc;
   const long cells8 = (long)(J.H >> 3) * (J.W >> 3), cells4 = (long)(J.H >> 2) * (J.W >> 2);
-  EntropyCtu c{ J, tb, J.depth + f * cells8, J.mode + f * cells8, J.part ? J.part + f * cells8 : nullptr, J.mode4 ? J.mode4 + f * cells4 : nullptr,
-                J.coeff + item * KVZ_HIP_CTU_COEFFS, J.W >> 3, J.W >> 2 };
   BinSink s{ J.bins + item * J.cap, 0, J.cap, 0 };
   if (J.sao) {  // encode_sao (encoderstate.c:519-552)
     const int merge = J.sao_merge[item];
@@ -378,7 +591,14 @@ KVZ_DEV void entropy_ctu_bins(const EntropyJob &J, const Tables *tb, long item)
       EntropyCtu::sao_color(s, r[1], r[2], 2);
     }
   }
-  c.coding_tree(s, lx * 64, ly * 64);
+  if (J.cu) {  // a B picture: the inter syntax from the CU records
+    const EntropyCtuB cb{ J, tb, J.cu + f * cells4, J.ref_cu + f * cells4, J.coeff + item * KVZ_HIP_CTU_COEFFS, J.W >> 2, lx * 64, ly * 64 };
+    cb.coding_tree(s);
+  } else {
+    const EntropyCtu c{ J, tb, J.depth + f * cells8, J.mode + f * cells8, J.part ? J.part + f * cells8 : nullptr, J.mode4 ? J.mode4 + f * cells4 : nullptr,
+                        J.coeff + item * KVZ_HIP_CTU_COEFFS, J.W >> 3, J.W >> 2 };
+    c.coding_tree(s, lx * 64, ly * 64);
+  }
   const bool last_col = lx == J.wc - 1, last_row = ly == J.hc - 1, end_of_picture = last_col && last_row;
   const bool end_of_slice = end_of_picture && !(J.not_last && J.not_last[f]);
   s.trm(end_of_slice);                                                              // end_of_slice_segment_flag (encoderstate.c:699-712)

@@ -75,7 +75,7 @@ def cu_digest(cu):
 class InterPictures:
     """picture k of `n` independent sequences, resident on the device: sources, references (+ their CU info), and the pass's outputs"""
 
-    def __init__(self, lib, width, height, n):
+    def __init__(self, lib, width, height, n, with_levels=False):
         from .dev import Dev
         self.lib, self.dev, self.w, self.h, self.n = lib, Dev(lib), width, height, n
         self.fs, self.cells = width * height * 3 // 2, (width // 4) * (height // 4)
@@ -86,10 +86,14 @@ class InterPictures:
         lib.kvz_hip_dev_loop_filters_inter.restype = C.c_int
         lib.kvz_hip_dev_loop_filters_inter.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p] * 3
         self.d_dbk = None
+        lib.kvz_hip_dev_entropy_code_inter.restype = C.c_long
+        lib.kvz_hip_dev_entropy_code_inter.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         e = self.dev.empty
         self.d_src, self.d_ref, self.d_rec = e(n * self.fs), e(n * self.fs), e(n * self.fs)
         self.d_ref_cu, self.d_cu = e(n * self.cells * CU_DTYPE.itemsize), e(n * self.cells * CU_DTYPE.itemsize)
         self.ctus = ((width + 63) // 64) * ((height + 63) // 64)
+        self.d_coeff = e(n * self.ctus * 6144 * 2) if with_levels else None  # KVZ_HIP_CTU_COEFFS int16 per CTU: what the entropy coder reads
+        self._entropy_out = None
 
     def upload(self, i, src, ref, ref_cu):
         up = self.lib.kvz_hip_dev_upload
@@ -99,7 +103,7 @@ class InterPictures:
             up(base + i * size, a.ctypes.data, size)
 
     def run(self, params):
-        rc = self.lib.kvz_hip_dev_inter_ctu_pass(self.d_src, self.d_ref, self.d_ref_cu, self.d_rec, self.d_cu, None, self.w, self.h, self.n, C.addressof(params))
+        rc = self.lib.kvz_hip_dev_inter_ctu_pass(self.d_src, self.d_ref, self.d_ref_cu, self.d_rec, self.d_cu, self.d_coeff, self.w, self.h, self.n, C.addressof(params))
         if rc != 0:
             raise RuntimeError(f"kvz_hip_dev_inter_ctu_pass returned {rc}")
 
@@ -128,6 +132,22 @@ class InterPictures:
         if rc != 0:
             raise RuntimeError(f"kvz_hip_dev_loop_filters_inter returned {rc}")
 
+    def entropy_code(self, params):
+        """kvz_hip_dev_entropy_code_inter: the slice data of the pictures the pass just produced (after loop_filters when params.sao: their SAO decisions are coded).
+        -> (bytes of all substreams back to back, sizes [sequence][substream])"""
+        if self.d_coeff is None:
+            raise RuntimeError("InterPictures(..., with_levels=True) keeps the levels the entropy coder needs")
+        rows = 1 if params.no_wpp else (self.h + 63) // 64
+        capacity = self.n * self.w * self.h * 2 + 65536
+        if self._entropy_out is None:
+            self._entropy_out = np.empty(capacity, np.uint8)
+        sizes = np.zeros((self.n, rows), np.uint32)
+        total = self.lib.kvz_hip_dev_entropy_code_inter(self.d_cu, self.d_ref_cu, self.d_coeff, self.w, self.h, self.n, C.addressof(params), self._entropy_out.ctypes.data,
+                                                        capacity, sizes.ctypes.data)
+        if total < 0:
+            raise RuntimeError("kvz_hip_dev_entropy_code_inter failed")
+        return self._entropy_out[:total], sizes
+
     def advance(self):
         """the pictures just encoded (after their loop filters) and their CU records become the references of the next picture"""
         self.d_ref, self.d_rec = self.d_rec, self.d_ref
@@ -146,3 +166,5 @@ class InterPictures:
         self.dev.free(self.d_ref, self.d_rec, self.d_ref_cu, self.d_cu, *getattr(self, "_source_sets", [self.d_src]))
         if self.d_dbk is not None:
             self.dev.free(self.d_dbk)
+        if self.d_coeff is not None:
+            self.dev.free(self.d_coeff)

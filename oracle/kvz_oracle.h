@@ -195,6 +195,12 @@ void kvz_oracle_lowdelay_encode(const kvz_oracle_lowdelay_cfg *cfg, const float 
 void kvz_oracle_lowdelay_encode_bits(const kvz_oracle_lowdelay_cfg *cfg, const float entropy_fbits[128], const uint64_t coeff_weights[52], int width, int height,
                                      int n_frames, const uint8_t *src, uint8_t *rec_final, kvz_oracle_cu *cu_out, uint8_t *slice_data, size_t slice_capacity,
                                      uint32_t *substream_bytes, uint64_t *picture_offsets);
+/* ... what an entropy coder needs of every picture besides the CU records (levels of every CTU, SAO decisions), and the initial context states of a B slice (CX order:
+ * KVZ_HIP_CX_*, then skip[3] 150, merge flag 153, merge idx 154, pred mode 155, mvd[2] 156, mvp idx 158, inter dir[5] 160, root cbf 165) */
+void kvz_oracle_lowdelay_encode_parts(const kvz_oracle_lowdelay_cfg *cfg, const float entropy_fbits[128], const uint64_t coeff_weights[52], int width, int height,
+                                      int n_frames, const uint8_t *src, kvz_oracle_cu *cu_out, int16_t *coeff_out, kvz_hip_sao_params *sao_luma, kvz_hip_sao_params *sao_chroma,
+                                      uint8_t *sao_merge, int32_t *frame_qp);
+void kvz_oracle_b_slice_contexts(int qp, uint8_t out[172]);
 /* one B picture of such a sequence on its own, from its reference picture (after the loop filters) and that picture's CU records: qp / poc are the picture's;
  * of cfg the search options are read (fme_level, pu_depth_inter_max, sao, deblock, mv_constraint, no_wpp).  coeff (or NULL): KVZ_HIP_CTU_COEFFS per CTU. */
 void kvz_oracle_inter_picture(int qp, int poc, const kvz_oracle_lowdelay_cfg *cfg, const float entropy_fbits[128], uint64_t coeff_weights, int width, int height,

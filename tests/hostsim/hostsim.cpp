@@ -215,3 +215,32 @@ extern "C" long kvz_hostsim_entropy_code(const kvz_hip_intra_cost_model *m, int 
   free(J.bins); free(J.nbins); free(J.nbits); free(J.row_ctx);
   return total;
 }
+
+// ... and for B pictures: the CU records of a picture and of its reference picture, levels, packed SAO decisions
+extern "C" long kvz_hostsim_entropy_code_inter(const uint8_t *ctx_init /* KVZ_ENTROPY_CTXS states */, int width, int height, int poc, int no_wpp, const kvz_hip_cu_info *cu,
+                                               const kvz_hip_cu_info *ref_cu, const int16_t *coeff, const unsigned long long *sao_recs, const uint8_t *sao_merge, uint32_t cap,
+                                               uint8_t *out, uint32_t *substream_bytes)
+{
+  static kvz::Tables tb;
+  kvz::build_tables(&tb);
+  kvz::EntropyJob J;
+  memset(&J, 0, sizeof J);
+  J.W = width; J.H = height; J.wc = (width + 63) / 64; J.hc = (height + 63) / 64; J.n_frames = 1; J.no_wpp = no_wpp;
+  J.cu = cu; J.ref_cu = ref_cu; J.poc = poc; J.coeff = coeff; J.sao = sao_recs; J.sao_merge = sao_merge;
+  const long items = (long)J.wc * J.hc, streams = no_wpp ? 1 : J.hc;
+  cap = (cap + 15u) & ~15u;
+  J.bins = (uint32_t *)aligned_alloc(64, (size_t)items * cap * sizeof(uint32_t)); J.nbins = (uint32_t *)malloc((size_t)items * sizeof(uint32_t));
+  J.nbits = (uint32_t *)malloc((size_t)items * sizeof(uint32_t)); J.cap = cap;
+  J.row_ctx = (uint8_t *)malloc((size_t)J.hc * KVZ_ENTROPY_CTXS);
+  memcpy(J.ctx_init, ctx_init, KVZ_ENTROPY_CTXS);
+  const kvz::EntropyTabs T{ &tb.ctx_next[0][0], kvz::kLpsPacked };
+  uint8_t ctx[KVZ_ENTROPY_CTXS];
+  long total = 0;
+  for (long i = 0; i < items; i++) { kvz::entropy_ctu_bins(J, &tb, i); if (J.nbins[i] > cap) total = -1; }
+  if (total == 0) {
+    if (!no_wpp) kvz::entropy_row_contexts(J, T, 0, ctx);
+    for (long i = 0; i < streams; i++) { substream_bytes[i] = kvz::entropy_code_row(J, T, i, ctx, out + total); total += substream_bytes[i]; }
+  }
+  free(J.bins); free(J.nbins); free(J.nbits); free(J.row_ctx);
+  return total;
+}

@@ -264,3 +264,39 @@ def oracle_encode_bits(oracle, w, h, frames, qp, preset="veryfast", deblock=True
     f.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p, C.c_void_p]
     f(C.addressof(cfg), C.addressof(fb), C.addressof(wts), w, h, n, src.ctypes.data, None, None, data.ctypes.data, cap, sizes.ctypes.data, offs.ctypes.data)
     return [(data[int(offs[k]):int(offs[k + 1])].tobytes(), [int(v) for v in sizes[k]]) for k in range(n)]
+
+
+def b_slice_context_states(oracle, qp):
+    """the 168 initial context states of a B slice at `qp` in the device coder's numbering (kvz_entropy.hpp: KVZ_HIP_CX_* then KVZ_EB_CX_*) = the oracle's CX numbering"""
+    f = oracle.lib.kvz_oracle_b_slice_contexts
+    f.restype = None
+    f.argtypes = [C.c_int, C.c_void_p]
+    out = np.zeros(172, np.uint8)
+    f(int(qp), out.ctypes.data)
+    return out[:168].copy()
+
+
+def oracle_sequence_for_entropy(oracle, case):
+    """everything the device's B-picture coder needs of a sequence, from the oracle: per picture the final CU records, the levels of every CTU, the SAO decisions
+    (kvz_hip_sao_params arrays + merge) and the picture QPs"""
+    name, w, h, n, qp, preset, dbk, sao, owf, src = case
+    p = dict(PRESETS[preset])
+    p["sao"] = int(sao)
+    cfg = LowdelayCfg(qp=qp, gop_len=4, gop_depth=3, intra_period=64, deblock=int(dbk), mv_constraint=int(owf > 0), no_wpp=0, ra8_qp_model=1, **p)
+    mc = cc.model_constants()
+    fb = (C.c_float * 128)(*mc["entropy_fbits"])
+    wts = (C.c_uint64 * 52)(*[int(mc["coeff_weights"][str(q)]) for q in range(52)])
+    frames = case_frames(case)
+    fs, cells, ctus = w * h * 3 // 2, (w // 4) * (h // 4), ((w + 63) // 64) * ((h + 63) // 64)
+    src_all = np.ascontiguousarray(np.concatenate(frames))
+    cu = np.zeros(n * cells, CU_DTYPE)
+    coeff = np.zeros(n * ctus * 6144, np.int16)
+    sao_l, sao_c, merge = np.zeros(n * ctus * 15, np.int32), np.zeros(n * ctus * 15, np.int32), np.zeros(n * ctus, np.uint8)
+    qps = np.zeros(n, np.int32)
+    f = oracle.lib.kvz_oracle_lowdelay_encode_parts
+    f.restype = None
+    f.argtypes = [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 7
+    f(C.addressof(cfg), C.addressof(fb), C.addressof(wts), w, h, n, src_all.ctypes.data, cu.ctypes.data, coeff.ctypes.data, sao_l.ctypes.data, sao_c.ctypes.data,
+      merge.ctypes.data, qps.ctypes.data)
+    return dict(cu=cu.reshape(n, cells), coeff=coeff.reshape(n, ctus * 6144), sao_luma=sao_l.reshape(n, ctus, 15), sao_chroma=sao_c.reshape(n, ctus, 15),
+                merge=merge.reshape(n, ctus), qps=qps, ctus=ctus)

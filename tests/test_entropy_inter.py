@@ -1,0 +1,91 @@
+"""The device's entropy coder on B pictures (kvazaar_amd/csrc/kvz_entropy.hpp EntropyCtuB; include/kvz_hip_dev.h kvz_hip_dev_entropy_code_inter): kvz_encode_coding_tree
+with the inter syntax from the CU records of the inter CTU pass, MV predictors derived again from the records.  Inputs from the oracle's sequence encode (CU records, levels,
+SAO decisions of every picture); the bytes must be the reference encoder's (tests/golden/entropy_inter.json, taken from kvazaar_ref's bitstreams).  CPU: the host simulation of
+the device sources; -m gpu: the device, and the device's own chain pass -> loop filters -> coder."""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import entropy_common as ec
+import flatapi
+import inter_common as ic
+
+GOLDEN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "entropy_inter.json")))
+DEVICE_CASES = [c for c in ic.ENTROPY_CASES if c not in ("noisy-qp27", "cabac-coeff-cost-qp32", "two-gops")]  # every picture QP below 28 (the device's inter pass); the coder itself has no such limit
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return flatapi.load_oracle()
+
+
+@pytest.fixture(scope="module")
+def hostsim_cdll():
+    d = os.path.join(flatapi.ROOT, "tests", "hostsim")
+    so = os.path.join(d, "libkvz_hostsim.so")
+    srcs = [os.path.join(d, "hostsim.cpp")] + [os.path.join(flatapi.ROOT, "kvazaar_amd", "csrc", f) for f in os.listdir(os.path.join(flatapi.ROOT, "kvazaar_amd", "csrc"))]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", so, os.path.join(d, "hostsim.cpp")])
+    return C.CDLL(so)
+
+
+def sao_records(parts, k, sao):
+    if not sao:
+        return None, None
+    return ec.pack_sao_records(np.ascontiguousarray(parts["sao_luma"][k]), np.ascontiguousarray(parts["sao_chroma"][k]), parts["ctus"]), np.ascontiguousarray(parts["merge"][k])
+
+
+@pytest.mark.parametrize("name", ic.ENTROPY_CASES)
+def test_host_simulation_of_the_device_coder_on_b_pictures(oracle, hostsim_cdll, name):
+    case = [c for c in ic.CASES if c[0] == name][0]
+    _, w, h, n, qp, preset, dbk, sao, owf, src = case
+    parts = ic.oracle_sequence_for_entropy(oracle, case)
+    f = hostsim_cdll.kvz_hostsim_entropy_code_inter
+    f.restype = C.c_long
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_uint32, C.c_void_p, C.c_void_p]
+    hc = (h + 63) // 64
+    for k in range(1, n):  # picture 0 is the I picture (tests/test_entropy_oracle.py)
+        init = ic.b_slice_context_states(oracle, parts["qps"][k])
+        recs, merge = sao_records(parts, k, sao)
+        out, sizes = np.zeros(w * h * 4 + 4096, np.uint8), np.zeros(hc, np.uint32)
+        cu, ref_cu, coeff = np.ascontiguousarray(parts["cu"][k]), np.ascontiguousarray(parts["cu"][k - 1]), np.ascontiguousarray(parts["coeff"][k])
+        total = f(init.ctypes.data, w, h, k, 0, cu.ctypes.data, ref_cu.ctypes.data, coeff.ctypes.data, recs.ctypes.data if recs is not None else None,
+                  merge.ctypes.data if merge is not None else None, 49152, out.ctypes.data, sizes.ctypes.data)
+        assert total >= 0
+        g = GOLDEN[name][k]
+        assert [int(v) for v in sizes] == g["sizes"], k
+        assert hashlib.sha256(out[:total].tobytes()).hexdigest()[:24] == g["sha"], k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", DEVICE_CASES)
+def test_device_chain_pass_filters_coder_writes_the_reference_slice_data(oracle, name):
+    """A whole low-delay sequence on the device from the I picture's search result on: CTU pass (with levels) -> loop filters incl. the SAO decision -> entropy coder, picture
+    after picture from the device's own previous picture.  The slice data of every B picture is the reference encoder's."""
+    import kvazaar_amd
+    from kvazaar_amd import inter
+    lib = kvazaar_amd.load_library()
+    case = [c for c in ic.CASES if c[0] == name][0]
+    _, w, h, n, qp, preset, dbk, sao, owf, src = case
+    frames = ic.case_frames(case)
+    rs, rf, cu, qps = ic.oracle_encode(oracle, w, h, frames, qp, preset=preset, deblock=bool(dbk), sao=bool(sao), mv_constraint=owf > 0)
+    ip = inter.InterPictures(lib, w, h, 1, with_levels=True)
+    p = ic.PRESETS[preset]
+    ip.upload(0, frames[1], rf[0], cu[0].reshape(-1))  # the I picture after its loop filters, from the oracle (the all-intra chain has its own tests)
+    for k in range(1, n):
+        prm = inter.InterParams(qp=int(qps[k]), poc=k, mv_constraint=int(owf > 0), sao=int(sao), deblock=int(dbk), fme_level=p["fme_level"], pu_depth_inter_max=p["pu_depth_inter_max"], no_wpp=0)
+        if k > 1:
+            ip.advance()
+            ip.upload_source(0, frames[k])
+        ip.run(prm)
+        ip.loop_filters(prm)
+        data, sizes = ip.entropy_code(prm)
+        g = GOLDEN[name][k]
+        assert [int(v) for v in sizes[0]] == g["sizes"], k
+        assert hashlib.sha256(bytes(data)).hexdigest()[:24] == g["sha"], k
+    ip.close()
