@@ -523,8 +523,12 @@ def inter_leg(args, lib, model_for, HipBatch, pictures, sequences=192):
     rec0 = bi.download(0)["rec"]
     bi.close()
     i_ok = hashlib.sha256(np.ascontiguousarray(rec0).tobytes()).hexdigest()[:24] == gold["rec"][0]
-    ip = inter.InterPictures(lib, w, h, sequences)
+    ip = inter.InterPictures(lib, w, h, sequences, with_levels=True)
     cu0 = inter.intra_picture_cu_info(w, h)
+    try:
+        gold_bits = json.load(open(os.path.join(ROOT, "tests", "golden", "entropy_inter.json"))).get("baseline-c4-2160p")
+    except (OSError, ValueError):
+        gold_bits = None
     n_b = min(3, len(pictures) - 1)
     for i in range(sequences):
         ip.upload(i, pictures[1], rec0, cu0)
@@ -547,7 +551,7 @@ def inter_leg(args, lib, model_for, HipBatch, pictures, sequences=192):
     cu_ok = inter.cu_digest(cu_first) == gold["cu"][1]
     # ... and the sequence carried on: loop filters of picture 1, then pictures 2 and 3 from the device's own previous pictures (pass -> CU records for the filters ->
     # deblocking + SAO decision + SAO -> reference of the next picture), everything resident
-    pass_s, filt_s, chain_ok, rec_ok = [s], [], [bool(cu_ok)], []
+    pass_s, filt_s, ent_s, chain_ok, rec_ok, bits_ok, slice_bytes = [s], [], [], [bool(cu_ok)], [], [], []
     for k in range(1, n_b + 1):
         prm = inter.veryfast_params(qps[k], k)
         if k > 1:
@@ -562,12 +566,25 @@ def inter_leg(args, lib, model_for, HipBatch, pictures, sequences=192):
         ip.sync()
         filt_s.append(time.perf_counter() - t)
         rec_ok.append(hashlib.sha256(ip.download(0)[0].tobytes()).hexdigest()[:24] == gold["rec"][k] and np.array_equal(ip.download(0)[0], ip.download(sequences - 1)[0]))
-    chain_total = sum(pass_s) + sum(filt_s)
-    chain = {"stages": f"{n_b} B pictures of {sequences} sequences, each: CTU pass -> CU records for the filters -> deblocking + SAO decision + SAO -> the next picture's reference; all resident",
+        # the pictures' slice data, coded on the device from the CU records, the levels and the SAO decisions just made
+        if k == 1:
+            ip.entropy_code(prm)  # first use: scratch allocations
+        t = time.perf_counter()
+        data, sizes = ip.entropy_code(prm)
+        ent_s.append(time.perf_counter() - t)
+        first = int(sizes[0].sum())
+        slice_bytes.append(first)
+        bits_ok.append(bool(gold_bits and [int(v) for v in sizes[0]] == gold_bits[k]["sizes"] and hashlib.sha256(bytes(data[:first])).hexdigest()[:24] == gold_bits[k]["sha"]
+                            and np.array_equal(sizes[0], sizes[-1]) and bytes(data[:first]) == bytes(data[len(data) - first:])))
+    chain_total = sum(pass_s) + sum(filt_s) + sum(ent_s)
+    chain = {"stages": f"{n_b} B pictures of {sequences} sequences, each: CTU pass -> CU records for the filters -> deblocking + SAO decision + SAO -> slice data (entropy coder, "
+                       "downloaded) -> the next picture's reference; pictures, CU records and levels resident",
              "value": n_b * sequences * ip.ctus / chain_total, "unit": "CTUs/s", "fps": n_b * sequences / chain_total, "picture_qps": qps,
-             "pass_ms": [round(x * 1e3, 1) for x in pass_s], "loop_filters_ms": [round(x * 1e3, 1) for x in filt_s],
-             "verified": bool(all(chain_ok) and all(rec_ok)),
-             "verify": {"cu_decisions_equal_reference_encoder_per_picture": [bool(v) for v in chain_ok], "final_pictures_equal_reference_encoder": [bool(v) for v in rec_ok]}}
+             "pass_ms": [round(x * 1e3, 1) for x in pass_s], "loop_filters_ms": [round(x * 1e3, 1) for x in filt_s], "entropy_ms": [round(x * 1e3, 1) for x in ent_s],
+             "slice_data_bytes_per_picture": slice_bytes,
+             "verified": bool(all(chain_ok) and all(rec_ok) and all(bits_ok)),
+             "verify": {"cu_decisions_equal_reference_encoder_per_picture": [bool(v) for v in chain_ok], "final_pictures_equal_reference_encoder": [bool(v) for v in rec_ok],
+                        "slice_data_equals_reference_encoder_bitstream": [bool(v) for v in bits_ok]}}
     ip.close()
     # the reference encoder on the same clip and settings, on this box's host cores: (a) one thread, (b) its default threading, (c) as many independent one-thread encoders
     # as the box grants CPUs.  Whole encoder (I picture, entropy coding, loop filters included): a reported baseline, bounded to a few seconds each

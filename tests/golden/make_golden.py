@@ -322,7 +322,7 @@ def update_entropy_inter():
     out = {}
     for case in ic.CASES:
         name, w, h, n, qp, preset, dbk, sao, owf, src = case
-        if name not in ic.ENTROPY_CASES:
+        if name not in ic.ENTROPY_CASES + ic.ENTROPY_BENCH_CASES:
             continue
         frames = ic.case_frames(case)
         with tempfile.TemporaryDirectory() as d:

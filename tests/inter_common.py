@@ -165,6 +165,9 @@ CASES = [
 # the cases whose slice data is pinned (tests/golden/entropy_inter.json): every picture QP below 28 (the device's inter pass), SAO on / off, the wavefront MV restriction
 ENTROPY_CASES = ["pan", "ultrafast", "vertical-pan-owf", "static-qp17", "two-gops", "no-loop-filters", "deblock-only", "survey-416x240", "noisy-qp27", "cabac-coeff-cost-qp32"]
 
+# ... and BASELINE config 4 at its own size: fixture entry only (bench.py's leg and the GPU test check the device against it)
+ENTROPY_BENCH_CASES = ["baseline-c4-2160p"]
+
 
 def case_frames(case):
     name, w, h, n, qp, preset, dbk, sao, owf, src = case

@@ -63,7 +63,7 @@ def test_host_simulation_of_the_device_coder_on_b_pictures(oracle, hostsim_cdll,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", DEVICE_CASES)
+@pytest.mark.parametrize("name", DEVICE_CASES + ic.ENTROPY_BENCH_CASES)
 def test_device_chain_pass_filters_coder_writes_the_reference_slice_data(oracle, name):
     """A whole low-delay sequence on the device from the I picture's search result on: CTU pass (with levels) -> loop filters incl. the SAO decision -> entropy coder, picture
     after picture from the device's own previous picture.  The slice data of every B picture is the reference encoder's."""
