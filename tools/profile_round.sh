@@ -23,3 +23,11 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $repo/gpurun_out/${tag}_inter_stats -o ${tag}_inter -- python $repo/tools/inter_ctu_probe.py survey-416x240 1024 > $repo/gpurun_out/${tag}_inter_probe.log 2>&1
 cd $repo
 tail -8 gpurun_out/${tag}_inter_probe.log
+# the entropy coder (kvz_hip_batch_entropy_code) on the headline batch: rocprofv3 kernel stats of tools/entropy_probe.py, and the real encoder's frame rates (AVX2 / device
+# search / device search + device entropy coding) from tools/encoder_fps.py
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $repo/gpurun_out/${tag}_entropy_stats -o ${tag}_entropy -- python $repo/tools/entropy_probe.py 1536 22 > $repo/gpurun_out/${tag}_entropy_probe.log 2>&1
+cd $repo
+tail -3 gpurun_out/${tag}_entropy_probe.log
+python tools/encoder_fps.py 512 ultrafast 22 > gpurun_out/${tag}_encoder_fps.log 2>&1
+tail -3 gpurun_out/${tag}_encoder_fps.log
