@@ -77,7 +77,7 @@ def oracle_entropy(oracle, model, width, height, o, sao=None, not_last=0):
     f.restype = C.c_size_t
     f.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8 + [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
     hc = (height + 63) // 64
-    cap = width * height * 4 + 4096
+    cap = width * height * 12 + 65536  # dense blocks of 16-bit levels cost 5 bytes per sample and more
     out = np.zeros(cap, np.uint8)
     sizes = np.zeros(hc, np.uint32)
     part = o.get("part")

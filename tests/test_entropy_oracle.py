@@ -75,3 +75,12 @@ def test_host_simulation_reports_a_bin_list_that_does_not_fit(oracle, hostsim_cd
     case = [c for c in ec.CASES if c[0] == "noise-qp12"][0]
     with pytest.raises(AssertionError):
         ec.hostsim_slice_data(oracle, hostsim_cdll, case, cap=256, retry=False)
+
+
+def test_fuzz_of_the_device_sources_against_the_oracle(hostsim_cdll):
+    """tools/fuzz_entropy.py: random CU quadtrees with NxN CUs and all 35 modes, levels from sparse +-1 to dense +-32767, random SAO decisions, QPs 0..51, WPP / --no-wpp,
+    pictures that cut CTUs -- the host simulation of kvz_entropy.hpp writes the oracle's bytes, and every substream stays inside the scratch bound stage 1 computes for it"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(flatapi.ROOT, "tools", "fuzz_entropy.py"), "24", "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
