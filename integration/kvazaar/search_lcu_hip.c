@@ -104,7 +104,7 @@ static int eligible(const encoder_state_t *state)
   if (state->frame->slicetype == KVZ_SLICE_I) return 1;
   /* B pictures: the inter CTU pass (include/kvz_hip_dev.h kvz_hip_dev_inter_ctu_pass) is the search of `--preset veryfast|superfast|ultrafast --gop lp-gNd*t1`:
    * one reference picture -- the previous one -- in both lists, hexagon search with the `sensitive` early termination, fme level 0 or 2, bi-prediction through
-   * merge candidates only, early skip, 2Nx2N PUs of 8..32 samples, coefficients priced by kvz_fast_coeff_cost (QP < 28).  --owf 0: the pass searches the whole
+   * merge candidates only, early skip, 2Nx2N PUs of 8..32 samples, coefficients priced as kvz_get_coeff_cost does with fast-residual-cost 28.  --owf 0: the pass searches the whole
    * picture when its first LCU arrives, so the reference picture has to be complete by then. */
   const encoder_state_config_frame_t *fr = state->frame;
   REQUIRE(cfg->owf == 0 && cfg->tiles_width_count * cfg->tiles_height_count <= 1 && cfg->slices == KVZ_SLICES_NONE);
@@ -115,7 +115,8 @@ static int eligible(const encoder_state_t *state)
   REQUIRE(cfg->early_skip && cfg->max_merge == 5 && cfg->zero_coeff_rdo && !cfg->smp_enable && !cfg->amp_enable && !cfg->rdoq_enable);
   REQUIRE(cfg->pu_depth_inter.min[0] == 1 && (cfg->pu_depth_inter.max[0] == 2 || cfg->pu_depth_inter.max[0] == 3));
   REQUIRE(cfg->pu_depth_intra.min[0] == 2 && cfg->pu_depth_intra.max[0] == 3);
-  REQUIRE(state->qp < cfg->fast_residual_cost_limit && state->qp < MAX_FAST_COEFF_COST_QP && !cfg->intra_rdo_et);
+  /* the pass switches from kvz_fast_coeff_cost to the residual coder in counting mode at picture QP 28 (rdo.c:311-340 with these presets' fast-residual-cost) */
+  REQUIRE((state->qp < cfg->fast_residual_cost_limit && state->qp < MAX_FAST_COEFF_COST_QP) == (state->qp < 28) && !cfg->intra_rdo_et);
   REQUIRE(state->tile->frame->width % 8 == 0 && state->tile->frame->height % 8 == 0);
 #undef REQUIRE
   return 2;

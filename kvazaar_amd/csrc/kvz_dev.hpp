@@ -1245,7 +1245,7 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
 {
   if (n_pictures <= 0) return 0;
   if (!p || width <= 0 || height <= 0 || (width & 7) || (height & 7) || width > 64 * 255 || height > 64 * 255 || n_pictures > 65535) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: bad geometry\n"); return -1; }
-  if (p->qp < 0 || p->qp >= 28) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: picture QP %d: this version prices coefficients with kvz_fast_coeff_cost only (QP < 28)\n", p->qp); return -1; }
+  if (p->qp < 0 || p->qp > 51) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: picture QP %d outside 0..51\n", p->qp); return -1; }
   if ((p->fme_level != 0 && p->fme_level != 2) || p->pu_depth_inter_max < 1 || p->pu_depth_inter_max > 3 || p->poc < 1) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: unsupported parameters\n"); return -1; }
   hipStream_t st = be().stream;
   const int wc = (width + 63) / 64, hc = (height + 63) / 64, ctus = wc * hc;
@@ -1450,29 +1450,14 @@ namespace kvz {
 // kvz_init_contexts for a B slice (context.c:36-193 row 0 of every table, :202-305) in the entropy coder's numbering: KVZ_HIP_CX_* then KVZ_EB_CX_* (kvz_entropy.hpp)
 inline void entropy_b_slice_contexts(int qp, uint8_t out[KVZ_ENTROPY_CTXS])
 {
-  static const uint8_t split[3] = { 107, 139, 126 }, skip[3] = { 197, 185, 201 }, mvd[2] = { 169, 198 }, inter_dir[5] = { 95, 79, 63, 31, 31 }, sig_cg[4] = { 121, 140, 61, 154 };
-  static const uint8_t sig[42] = { 170, 154, 139, 153, 139, 123, 123, 63, 124, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154,
-                                   170, 153, 138, 138, 122, 121, 122, 121, 167, 151, 183, 140, 151, 183, 140 };
-  static const uint8_t last[30] = { 125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79, 108, 123, 93, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154, 154 };
-  static const uint8_t one[24] = { 154, 196, 167, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 122, 169, 208, 166, 167, 154, 152, 167, 182 };
-  static const uint8_t absf[6] = { 107, 167, 91, 107, 107, 167 };
+  static const uint8_t split[3] = { 107, 139, 126 }, skip[3] = { 197, 185, 201 }, mvd[2] = { 169, 198 }, inter_dir[5] = { 95, 79, 63, 31, 31 };
   uint8_t init[KVZ_ENTROPY_CTXS];
   memset(init, 154, sizeof init);
   for (int i = 0; i < 3; i++) { init[KVZ_HIP_CX_SPLIT + i] = split[i]; init[KVZ_EB_CX_SKIP + i] = skip[i]; }
   init[KVZ_HIP_CX_PART] = 154; init[KVZ_HIP_CX_INTRA] = 183; init[KVZ_HIP_CX_CHROMA] = 152;
   init[KVZ_HIP_CX_CBF_LUMA] = 153; init[KVZ_HIP_CX_CBF_LUMA + 1] = 111;
   init[KVZ_HIP_CX_CBF_CHROMA] = 149; init[KVZ_HIP_CX_CBF_CHROMA + 1] = 92; init[KVZ_HIP_CX_CBF_CHROMA_DEEP] = 167; init[KVZ_HIP_CX_CBF_CHROMA_DEEP + 1] = 154;
-  for (int i = 0; i < 4; i++) init[KVZ_HIP_CX_SIG_CG + i] = sig_cg[i];
-  for (int i = 0; i < 27; i++) init[KVZ_HIP_CX_SIG_LUMA + i] = sig[i];
-  for (int i = 0; i < 15; i++) {
-    init[KVZ_HIP_CX_SIG_CHROMA + i] = sig[27 + i];
-    init[KVZ_HIP_CX_LAST_Y_LUMA + i] = init[KVZ_HIP_CX_LAST_X_LUMA + i] = last[i];
-    init[KVZ_HIP_CX_LAST_Y_CHROMA + i] = init[KVZ_HIP_CX_LAST_X_CHROMA + i] = last[15 + i];
-  }
-  for (int i = 0; i < 16; i++) init[KVZ_HIP_CX_ONE_LUMA + i] = one[i];
-  for (int i = 0; i < 8; i++) init[KVZ_HIP_CX_ONE_CHROMA + i] = one[16 + i];
-  for (int i = 0; i < 4; i++) init[KVZ_HIP_CX_ABS_LUMA + i] = absf[i];
-  for (int i = 0; i < 2; i++) init[KVZ_HIP_CX_ABS_CHROMA + i] = absf[4 + i];
+  b_slice_residual_init_values(init + KVZ_HIP_CX_SIG_CG);  // kvz_inter_host.hpp: the tables' row 0
   init[KVZ_HIP_CX_SAO_MERGE] = 153; init[KVZ_HIP_CX_SAO_TYPE] = 160;
   init[KVZ_EB_CX_MERGE_FLAG] = 154; init[KVZ_EB_CX_MERGE_IDX] = 137; init[KVZ_EB_CX_PRED_MODE] = 134;
   init[KVZ_EB_CX_MVD] = mvd[0]; init[KVZ_EB_CX_MVD + 1] = mvd[1]; init[KVZ_EB_CX_MVP_IDX] = 168;

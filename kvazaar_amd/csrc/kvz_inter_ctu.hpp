@@ -13,7 +13,9 @@
 // reconstruction, coefficients, CU info of every depth) is a slab in HBM per resident workgroup; LDS holds the sample buffers of the stage at hand.  CTUs of a
 // picture run in WPP order under the ticket schedule of kvz_ctu_kernels.hpp; pictures of one sequence are launches in order, the launch carries picture k of many
 // independent sequences.  tests/hostsim compiles this file for the host (a phase = a loop over tid), which is how it was brought up against the oracle without a GPU.
-// Restrictions of this version: coefficients priced with kvz_fast_coeff_cost only (every picture QP below fast-residual-cost 28), square PUs, one reference picture.
+// Coefficients are priced as kvz_get_coeff_cost does (rdo.c:311-340): kvz_fast_coeff_cost while the picture QP lies below fast-residual-cost 28 (fused with the
+// quantisation), the residual coder in counting mode on the search contexts from there on (coeff_bits_cabac: kvz_residual.hpp's syntax walk into a price sink).
+// Restrictions of this version: square PUs, one reference picture.
 #pragma once
 #include <stddef.h>
 
@@ -21,6 +23,7 @@
 #include "../../include/kvz_hip_dev.h"
 #include "kvz_ops.hpp"
 #include "kvz_tables.hpp"
+#include "kvz_residual.hpp"
 
 namespace kvz {
 
@@ -57,16 +60,20 @@ enum { IP_MERGE = 0, IP_EARLY_SKIP, IP_ME, IP_FME, IP_CAND, IP_INTRA_SEARCH, IP_
 
 typedef kvz_hip_cu_info CuInfo;  // one 4x4 unit of the frame's CU info (include/kvz_hip_dev.h)
 
-// compact context numbering of a B slice priced with the fast coefficient cost (cabac.h:63-100)
+// compact context numbering of a B slice (cabac.h:63-100): the CU / transform-tree syntax in the first 32 bytes -- all that moves while coefficients are priced with the
+// fast estimate --, then the residual coder's contexts, KVZ_HIP_CX_SIG_CG .. KVZ_HIP_CX_ABS_CHROMA + 1 of include/kvz_hip_types.h in that order (picture QP >= 28)
 enum { IX_SPLIT = 0 /* 3 */, IX_SKIP = 3 /* 3 */, IX_MERGE_FLAG = 6, IX_MERGE_IDX = 7, IX_PRED_MODE = 8, IX_PART = 9, IX_INTRA = 10, IX_CHROMA = 11, IX_CBF_LUMA = 12 /* 2 */,
-       IX_CBF_CHROMA = 14 /* 2 */, IX_MVD = 16 /* 2 */, IX_MVP_IDX = 18, IX_INTER_DIR = 19 /* 5 */, IX_ROOT_CBF = 24, IX_COUNT = 32 };
-struct ICtx { u8 s[IX_COUNT]; };
+       IX_CBF_CHROMA = 14 /* 2 */, IX_MVD = 16 /* 2 */, IX_MVP_IDX = 18, IX_INTER_DIR = 19 /* 5 */, IX_ROOT_CBF = 24, IX_SYNTAX = 32,
+       IX_RES = 32 /* 136 */, IX_COUNT = IX_RES + (KVZ_HIP_CX_ABS_CHROMA + 2 - KVZ_HIP_CX_SIG_CG) };
+struct alignas(8) ICtx { u8 s[IX_COUNT]; };
+static_assert(IX_COUNT == 168 && sizeof(ICtx) == 168, "context sets are copied as 32-bit words");
 
 struct InterModel {  // per picture
   double lambda, lambda_sqrt;
   uint64_t coeff_weights;
   int qp, poc, mv_constraint, sao, deblock, fme_level, pu_depth_inter_max, no_wpp;
-  u8 ctx_init[IX_COUNT];
+  int coeff_cabac;  // qp >= fast-residual-cost (28 in the presets this pass covers, cfg.c:509-565): get_coeff_cabac_cost instead of kvz_fast_coeff_cost
+  alignas(8) u8 ctx_init[IX_COUNT];  // an ICtx: the slice's initial states
   QuantScalars qf[2][4], qi[2][4];  // forward / inverse scalars, [luma, chroma][log2 size - 2]
   float fbits[128];                 // kvz_f_entropy_bits
 };
@@ -132,6 +139,7 @@ struct InterLds {
 #endif
   ICtx ctx;  // state->search_cabac's contexts (indexed at run time on every priced bin)
   ICtx pre[4], post[4];  // search_cu's copies of them, per depth (search.c:655, 956)
+  ICtx row;              // the row coder's contexts at the start of the CTU (the finished CTU's syntax runs on them)
   CuInfo cur_cu[4];      // the CU under evaluation at each depth of the recursion
   struct { int mvx, mvy; double cost, bits; } best;  // check_mv_cost's best so far
 };
@@ -226,6 +234,34 @@ struct InterCtu {
     const double bits = L->fbits[st ^ bin];
     if (update) cab.s[idx] = tb->ctx_next[bin != (st & 1)][st];
     return bits;
+  }
+
+  // A context set copied by the lanes, a word each: the syntax contexts always, the residual coder's only when they can have moved
+  KVZ_DEV void ctx_copy(ICtx *dst, const ICtx *src)
+  {
+    const int words = M->coeff_cabac ? IX_COUNT / 4 : IX_SYNTAX / 4;
+    IC_FOR(tid) { for (int i = tid; i < words; i += KVZ_ICTU_THREADS) ((u32 *)dst->s)[i] = ((const u32 *)src->s)[i]; }
+    IC_SYNC();
+  }
+  // get_coeff_cabac_cost (rdo.c:220-263): kvz_encode_coeff_nxn in counting mode on the search contexts -- every context-coded bin at CABAC_FBITS_UPDATE's price
+  // (cabac.h:133-139; the state moves only while the search has updates on), every bypass bin one bit.  The prices are multiples of 2^-15 below 2^20, so their
+  // sum in a double does not depend on the order the reference adds them in.
+  struct PriceSink {
+    InterLds *L; const Tables *tb; bool update; double bits;
+    KVZ_DEV void ctx(int c, int v)
+    {
+      const int idx = IX_RES + c - KVZ_HIP_CX_SIG_CG;
+      const u8 st = L->ctx.s[idx];
+      bits += L->fbits[st ^ (v ? 1 : 0)];
+      if (update) L->ctx.s[idx] = tb->ctx_next[(v ? 1 : 0) != (st & 1)][st];
+    }
+    KVZ_DEV void ep(u32, int n) { bits += n; }
+  };
+  IC_FN double coeff_bits_cabac(const i16 *coeff, int width, int type, int scan_mode, bool update)
+  {
+    PriceSink s{ L, tb, update, 0.0 };
+    entropy_coeff_nxn(s, tb, coeff, ilog2i(width), type, scan_mode);
+    return s.bits;
   }
 
 #include "kvz_inter_ctu_cand.inc"

@@ -93,7 +93,7 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
                                int height, int n_pictures, const kvz_hip_inter_params *p)
 {
   _Static_assert(sizeof(kvz_hip_cu_info) == sizeof(kvz_oracle_cu), "the two CU records are one layout");
-  if (p->qp >= 28 || p->poc < 1 || width % 8 || height % 8) return -1;
+  if (p->qp < 0 || p->qp > 51 || p->poc < 1 || width % 8 || height % 8) return -1;
   const size_t px = (size_t)width * height * 3 / 2, cells = (size_t)(width / 4) * (height / 4), nctu = (size_t)((width + 63) / 64) * ((height + 63) / 64);
   kvz_hip_intra_cost_model m;  /* for kvz_f_entropy_bits and the coefficient weights of the QP only */
   kvz_hip_intra_cost_model_init(p->qp, kvz_hip_default_coeff_weights(p->qp), &m);

@@ -16,7 +16,7 @@ import flatapi
 import inter_common as ic
 
 GOLDEN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "entropy_inter.json")))
-DEVICE_CASES = [c for c in ic.ENTROPY_CASES if c not in ("noisy-qp27", "cabac-coeff-cost-qp32", "two-gops")]  # every picture QP below 28 (the device's inter pass); the coder itself has no such limit
+DEVICE_CASES = [c for c in ic.ENTROPY_CASES if c != "two-gops"]  # one I picture at the start (the chain's I pictures have their own tests); picture QPs on both sides of fast-residual-cost 28
 
 
 @pytest.fixture(scope="module")

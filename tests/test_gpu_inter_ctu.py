@@ -20,7 +20,8 @@ class InterParams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("qp", "poc", "mv_constraint", "sao", "deblock", "fme_level", "pu_depth_inter_max", "no_wpp")]
 
 
-FAST_COST_CASES = ["pan", "ultrafast", "vertical-pan-owf", "static-qp17", "no-loop-filters", "survey-416x240"]  # every picture QP below 28
+FAST_COST_CASES = ["pan", "ultrafast", "vertical-pan-owf", "static-qp17", "no-loop-filters", "survey-416x240"]  # every picture QP below 28: kvz_fast_coeff_cost
+CABAC_COST_CASES = ["noisy-qp27", "cabac-coeff-cost-qp32", "fast-pan-owf-qp37", "ultrafast-fast-pan-owf-qp30"]     # picture QPs from 28 on: the residual coder in counting mode
 
 
 @pytest.fixture(scope="module")
@@ -44,7 +45,7 @@ def hostsim_lib():
     return C.CDLL(so)
 
 
-@pytest.mark.parametrize("name", ["pan", "ultrafast", "vertical-pan-owf", "no-loop-filters"])
+@pytest.mark.parametrize("name", ["pan", "ultrafast", "vertical-pan-owf", "no-loop-filters", "noisy-qp27", "cabac-coeff-cost-qp32", "fast-pan-owf-qp37", "ultrafast-fast-pan-owf-qp30"])
 def test_host_simulation_of_the_device_program_equals_the_oracle(oracle, hostsim_lib, name):
     case = [c for c in ic.CASES if c[0] == name][0]
     _, w, h, n, qp, preset, dbk, sao, owf, src = case
@@ -81,7 +82,7 @@ def device_pass(lib, dev, w, h, srcs, refs, ref_cus, prm):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", FAST_COST_CASES)
+@pytest.mark.parametrize("name", FAST_COST_CASES + CABAC_COST_CASES + ["two-gops"])
 def test_device_pass_equals_oracle_picture_by_picture(oracle, name):
     import kvazaar_amd
     from kvazaar_amd.dev import Dev
@@ -116,7 +117,8 @@ def test_device_pass_on_baseline_config_4(oracle):
         assert np.array_equal(rec[0], rs[k]), k
 
 
-CHAIN_CASES = ["deblock-only", "ultrafast", "pan", "vertical-pan-owf", "static-qp17", "no-loop-filters", "survey-416x240", "survey-1080p", "baseline-c4-2160p"]
+CHAIN_CASES = ["deblock-only", "ultrafast", "pan", "vertical-pan-owf", "static-qp17", "no-loop-filters", "survey-416x240", "survey-1080p", "baseline-c4-2160p",
+               "noisy-qp27", "cabac-coeff-cost-qp32", "ultrafast-fast-pan-owf-qp30"]
 
 
 @pytest.mark.gpu
@@ -194,6 +196,6 @@ def test_device_pass_rejects_what_it_does_not_cover():
     lib.kvz_hip_dev_inter_ctu_pass.restype = C.c_int
     lib.kvz_hip_dev_inter_ctu_pass.argtypes = [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_void_p]
     ok = InterParams(qp=25, poc=1, mv_constraint=0, sao=1, deblock=1, fme_level=2, pu_depth_inter_max=3, no_wpp=0)
-    for bad in (dict(qp=28), dict(fme_level=4), dict(poc=0), dict(pu_depth_inter_max=4)):
+    for bad in (dict(qp=52), dict(qp=-1), dict(fme_level=4), dict(poc=0), dict(pu_depth_inter_max=4)):
         p = InterParams(**{**{n: getattr(ok, n) for n, _ in InterParams._fields_}, **bad})
         assert lib.kvz_hip_dev_inter_ctu_pass(None, None, None, None, None, None, 64, 64, 1, C.addressof(p)) == -1
