@@ -140,16 +140,18 @@ typedef struct kvz_hip_cu_info {
  *   cu       [n] out: CU info of the encoded pictures (what the next picture takes as ref_cu, and what deblocking reads)
  *   coeff    [n] out or NULL: KVZ_HIP_CTU_COEFFS quantised coefficients per CTU (raster CTU order; inside a CTU as lcu_coeff_t: Y | U | V, z-order)
  * All device pointers.  The pass is oracle/kvz_oracle_inter.inc's search_cu_b on the device, CTU for CTU identical to the reference encoder (tests/test_gpu_inter_ctu.py).
- * This version prices coefficients with kvz_fast_coeff_cost only: every picture QP must lie below `fast-residual-cost` 28 (BASELINE's QP 22 runs its pictures at
- * 21-25); returns -1 otherwise or on a bad argument, -2 when a CTU hand-off timed out. */
+ * Coefficients are priced as kvz_get_coeff_cost does (rdo.c:311-340): kvz_fast_coeff_cost while the picture QP lies below params->fast_residual_cost (28 in BASELINE
+ * config 4's preset, whose QP 22 runs its pictures at 21-25), the residual coder in counting mode on the search contexts from there on.  Returns -1 on a bad argument, -2 when a CTU
+ * hand-off timed out. */
 typedef struct kvz_hip_inter_params {
   int32_t qp;                  /* the picture's QP (state->frame->QP; kvz_oracle_lowdelay_qp states how kvazaar derives it from --qp and the GOP) */
   int32_t poc;                 /* picture order count inside the intra period (> 0); temporal AMVP candidates need poc > 1 (inter.c:1290) */
   int32_t mv_constraint;       /* cfg.owf && cfg.wpp */
   int32_t sao, deblock;        /* cfg.sao_type != 0, cfg.deblock_enable (the margin of that restriction) */
-  int32_t fme_level;           /* 2 `veryfast`, 0 `ultrafast` */
+  int32_t fme_level;           /* cfg.fme_level (--subme): 4 `faster`, 2 `veryfast`, 0 `ultrafast` */
   int32_t pu_depth_inter_max;  /* 3 `veryfast`, 2 `ultrafast` */
   int32_t no_wpp;              /* one coder runs through the picture in raster order (--no-wpp) */
+  int32_t fast_residual_cost;  /* cfg.fast_residual_cost_limit: 28 `ultrafast` .. `veryfast`, 0 `faster` -- below it (and below 50) coefficients are priced by kvz_fast_coeff_cost */
 } kvz_hip_inter_params;
 int  kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz_hip_cu_info *ref_cu, uint8_t *rec, kvz_hip_cu_info *cu, int16_t *coeff, int width,
                                 int height, int n_pictures, const kvz_hip_inter_params *params);

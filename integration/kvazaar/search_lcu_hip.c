@@ -102,21 +102,20 @@ static int eligible(const encoder_state_t *state)
   REQUIRE(cfg->target_bitrate <= 0 && !cfg->vaq && !cfg->roi.file_path && !cfg->set_qp_in_cu && state->frame->max_qp_delta_depth < 0);
   REQUIRE(!cfg->ml_pu_depth_intra);  /* (intra_bit_allocation, which lp GOPs switch on, only acts under rate control: rate_control.c:352-705) */
   if (state->frame->slicetype == KVZ_SLICE_I) return 1;
-  /* B pictures: the inter CTU pass (include/kvz_hip_dev.h kvz_hip_dev_inter_ctu_pass) is the search of `--preset veryfast|superfast|ultrafast --gop lp-gNd*t1`:
-   * one reference picture -- the previous one -- in both lists, hexagon search with the `sensitive` early termination, fme level 0 or 2, bi-prediction through
-   * merge candidates only, early skip, 2Nx2N PUs of 8..32 samples, coefficients priced as kvz_get_coeff_cost does with fast-residual-cost 28.  --owf 0: the pass searches the whole
+  /* B pictures: the inter CTU pass (include/kvz_hip_dev.h kvz_hip_dev_inter_ctu_pass) is the search of `--preset faster|veryfast|superfast|ultrafast --gop lp-gNd*t1`:
+   * one reference picture -- the previous one -- in both lists, hexagon search with the `sensitive` early termination, fme level 0, 2 or 4, bi-prediction through
+   * merge candidates only, early skip, 2Nx2N PUs of 8..32 samples, coefficients priced as kvz_get_coeff_cost does with the configuration's fast-residual-cost.  --owf 0: the pass searches the whole
    * picture when its first LCU arrives, so the reference picture has to be complete by then. */
   const encoder_state_config_frame_t *fr = state->frame;
   REQUIRE(cfg->owf == 0 && cfg->tiles_width_count * cfg->tiles_height_count <= 1 && cfg->slices == KVZ_SLICES_NONE);
   REQUIRE(fr->ref->used_size == 1 && fr->ref_LX_size[0] == 1 && fr->ref_LX_size[1] == 1 && fr->ref->pocs[0] == fr->poc - 1);
   REQUIRE(cfg->gop_len > 0 && cfg->gop_lowdelay && cfg->bipred && cfg->fast_bipred && cfg->tmvp_enable);
   REQUIRE(cfg->ime_algorithm == KVZ_IME_HEXBS && cfg->me_early_termination == KVZ_ME_EARLY_TERMINATION_SENSITIVE && cfg->me_max_steps == (uint32_t)-1);
-  REQUIRE((cfg->fme_level == 0 || cfg->fme_level == 2) && !cfg->mv_rdo && cfg->mv_constraint == KVZ_MV_CONSTRAIN_NONE);
+  REQUIRE((cfg->fme_level == 0 || cfg->fme_level == 2 || cfg->fme_level == 4) && !cfg->mv_rdo && cfg->mv_constraint == KVZ_MV_CONSTRAIN_NONE);
   REQUIRE(cfg->early_skip && cfg->max_merge == 5 && cfg->zero_coeff_rdo && !cfg->smp_enable && !cfg->amp_enable && !cfg->rdoq_enable);
   REQUIRE(cfg->pu_depth_inter.min[0] == 1 && (cfg->pu_depth_inter.max[0] == 2 || cfg->pu_depth_inter.max[0] == 3));
   REQUIRE(cfg->pu_depth_intra.min[0] == 2 && cfg->pu_depth_intra.max[0] == 3);
-  /* the pass switches from kvz_fast_coeff_cost to the residual coder in counting mode at picture QP 28 (rdo.c:311-340 with these presets' fast-residual-cost) */
-  REQUIRE((state->qp < cfg->fast_residual_cost_limit && state->qp < MAX_FAST_COEFF_COST_QP) == (state->qp < 28) && !cfg->intra_rdo_et);
+  REQUIRE(cfg->fast_residual_cost_limit >= 0 && cfg->fast_residual_cost_limit <= 51 && !cfg->intra_rdo_et);  /* the pass prices coefficients either way (rdo.c:311-340) */
   REQUIRE(state->tile->frame->width % 8 == 0 && state->tile->frame->height % 8 == 0);
 #undef REQUIRE
   return 2;
@@ -407,6 +406,7 @@ static void inter_picture(const encoder_state_t *state)
   prm.mv_constraint = cfg->owf && cfg->wpp;  /* search_inter.c:75-152 */
   prm.sao = cfg->sao_type != 0; prm.deblock = cfg->deblock_enable != 0;
   prm.fme_level = cfg->fme_level; prm.pu_depth_inter_max = cfg->pu_depth_inter.max[0]; prm.no_wpp = !cfg->wpp;
+  prm.fast_residual_cost = cfg->fast_residual_cost_limit;
   const int rc = kvz_hip_dev_inter_ctu_pass(g_inter.d_src, g_inter.d_ref, g_inter.d_ref_cu, g_inter.d_rec, g_inter.d_cu, g_inter.d_coeff, w, h, 1, &prm);
   if (rc != 0) { fprintf(stderr, "search_lcu_hip: the inter CTU pass failed (%d)\n", rc); abort(); }
   kvz_hip_dev_download(g_inter.rec, g_inter.d_rec, bytes);

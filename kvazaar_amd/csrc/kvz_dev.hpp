@@ -1246,7 +1246,7 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
   if (n_pictures <= 0) return 0;
   if (!p || width <= 0 || height <= 0 || (width & 7) || (height & 7) || width > 64 * 255 || height > 64 * 255 || n_pictures > 65535) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: bad geometry\n"); return -1; }
   if (p->qp < 0 || p->qp > 51) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: picture QP %d outside 0..51\n", p->qp); return -1; }
-  if ((p->fme_level != 0 && p->fme_level != 2) || p->pu_depth_inter_max < 1 || p->pu_depth_inter_max > 3 || p->poc < 1) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: unsupported parameters\n"); return -1; }
+  if ((p->fme_level != 0 && p->fme_level != 2 && p->fme_level != 4) || p->pu_depth_inter_max < 1 || p->pu_depth_inter_max > 3 || p->poc < 1 || p->fast_residual_cost < 0 || p->fast_residual_cost > 51) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: unsupported parameters\n"); return -1; }
   hipStream_t st = be().stream;
   const int wc = (width + 63) / 64, hc = (height + 63) / 64, ctus = wc * hc;
   const long total = (long)ctus * n_pictures;
@@ -1283,7 +1283,7 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
   kvz::InterModel m;
   float fbits[128];
   for (int i = 0; i < 128; i++) fbits[i] = (float)kvz::kEntropyBits[i] / 32768.0f;
-  kvz::inter_model_init(&m, p->qp, p->poc, kvz::kDefaultCoeffWeights[p->qp], fbits, p->mv_constraint, p->sao, p->deblock, p->fme_level, p->pu_depth_inter_max, p->no_wpp);
+  kvz::inter_model_init(&m, p->qp, p->poc, kvz::kDefaultCoeffWeights[p->qp], fbits, p->mv_constraint, p->sao, p->deblock, p->fme_level, p->pu_depth_inter_max, p->no_wpp, p->fast_residual_cost);
   KVZ_HIP_CHECK(hipMemcpyAsync(sc.items, items.data(), (size_t)total * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   KVZ_HIP_CHECK(hipMemcpyAsync(sc.model, &m, sizeof m, hipMemcpyHostToDevice, st));
   KVZ_HIP_CHECK(hipMemsetAsync(sc.done, 0, (size_t)total * sizeof(unsigned), st));

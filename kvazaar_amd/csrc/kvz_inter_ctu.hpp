@@ -1,5 +1,5 @@
 // kvz_inter_ctu.hpp -- the CTU pass of pictures with inter prediction (BASELINE config 4: `--preset veryfast --gop lp-g4d3t1`, B slices whose two lists hold the
-// previous picture): one workgroup searches and reconstructs one 64x64 CTU -- search_cu of a P / B slice (search.c:646-1063) with everything below it:
+// previous picture; `ultrafast` .. `faster` with that GOP): one workgroup searches and reconstructs one 64x64 CTU -- search_cu of a P / B slice (search.c:646-1063) with everything below it:
 // kvz_search_cu_inter (search_inter.c:2202: merge candidates, early skip, the motion search of kvz_me.hpp's shape, half-pel refinement), the intra alternative
 // (search_intra.c:812, rd 0), motion compensation (inter.c:374-660), the transform tree of either CU type, zero-coefficient RDO, kvz_mock_encode_coding_unit and
 // cu_rd_cost_tr_split_accurate on CABAC contexts that live as the encoder's do, the recursion with its work-tree copies, and the finished CTU's syntax for the
@@ -72,7 +72,7 @@ struct InterModel {  // per picture
   double lambda, lambda_sqrt;
   uint64_t coeff_weights;
   int qp, poc, mv_constraint, sao, deblock, fme_level, pu_depth_inter_max, no_wpp;
-  int coeff_cabac;  // qp >= fast-residual-cost (28 in the presets this pass covers, cfg.c:509-565): get_coeff_cabac_cost instead of kvz_fast_coeff_cost
+  int coeff_cabac;  // qp >= fast-residual-cost (28 `ultrafast` .. `veryfast`, 0 `faster`: cfg.c:509-593): get_coeff_cabac_cost instead of kvz_fast_coeff_cost
   alignas(8) u8 ctx_init[IX_COUNT];  // an ICtx: the slice's initial states
   QuantScalars qf[2][4], qi[2][4];  // forward / inverse scalars, [luma, chroma][log2 size - 2]
   float fbits[128];                 // kvz_f_entropy_bits

@@ -42,14 +42,14 @@ inline void b_slice_residual_init_values(uint8_t v[KVZ_HIP_CX_ABS_CHROMA + 2 - K
 }
 
 inline void inter_model_init(InterModel *m, int qp, int poc, uint64_t coeff_weights, const float fbits[128], int mv_constraint, int sao, int deblock, int fme_level,
-                             int pu_depth_inter_max, int no_wpp)
+                             int pu_depth_inter_max, int no_wpp, int fast_residual_cost)
 {
   memset(m, 0, sizeof *m);
   m->qp = qp; m->poc = poc;
   m->lambda = 0.57 * pow(2.0, (qp - 12) / 3.0);  // rate_control.c:678-691
   m->lambda_sqrt = sqrt(m->lambda);
   m->coeff_weights = coeff_weights;
-  m->coeff_cabac = qp >= 28;  // fast-residual-cost 28 of `ultrafast` .. `veryfast` (cfg.c:509-565); MAX_FAST_COEFF_COST_QP = 50 lies above
+  m->coeff_cabac = !(qp < fast_residual_cost && qp < 50);  // rdo.c:311-340: cfg.fast_residual_cost_limit (28 `ultrafast` .. `veryfast`, 0 `faster`), MAX_FAST_COEFF_COST_QP
   m->mv_constraint = mv_constraint; m->sao = sao; m->deblock = deblock; m->fme_level = fme_level; m->pu_depth_inter_max = pu_depth_inter_max; m->no_wpp = no_wpp;
   uint8_t init[IX_COUNT];
   memset(init, 154, sizeof init);

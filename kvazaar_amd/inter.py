@@ -11,12 +11,12 @@ assert CU_DTYPE.itemsize == 22
 
 
 class InterParams(C.Structure):  # kvz_hip_inter_params
-    _fields_ = [(n, C.c_int32) for n in ("qp", "poc", "mv_constraint", "sao", "deblock", "fme_level", "pu_depth_inter_max", "no_wpp")]
+    _fields_ = [(n, C.c_int32) for n in ("qp", "poc", "mv_constraint", "sao", "deblock", "fme_level", "pu_depth_inter_max", "no_wpp", "fast_residual_cost")]
 
 
 def veryfast_params(qp, poc, mv_constraint=True):
     """`--preset veryfast` (cfg.c:541-568) for a B picture of the low-delay GOP"""
-    return InterParams(qp=qp, poc=poc, mv_constraint=int(mv_constraint), sao=1, deblock=1, fme_level=2, pu_depth_inter_max=3, no_wpp=0)
+    return InterParams(qp=qp, poc=poc, mv_constraint=int(mv_constraint), sao=1, deblock=1, fme_level=2, pu_depth_inter_max=3, no_wpp=0, fast_residual_cost=28)
 
 
 def lowdelay_picture_qp(qp, frame, gop_len=4, gop_depth=3, intra_period=0, preset_given=True):

@@ -93,14 +93,14 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
                                int height, int n_pictures, const kvz_hip_inter_params *p)
 {
   _Static_assert(sizeof(kvz_hip_cu_info) == sizeof(kvz_oracle_cu), "the two CU records are one layout");
-  if (p->qp < 0 || p->qp > 51 || p->poc < 1 || width % 8 || height % 8) return -1;
+  if (p->qp < 0 || p->qp > 51 || p->fast_residual_cost < 0 || p->fast_residual_cost > 51 || p->poc < 1 || width % 8 || height % 8) return -1;
   const size_t px = (size_t)width * height * 3 / 2, cells = (size_t)(width / 4) * (height / 4), nctu = (size_t)((width + 63) / 64) * ((height + 63) / 64);
   kvz_hip_intra_cost_model m;  /* for kvz_f_entropy_bits and the coefficient weights of the QP only */
   kvz_hip_intra_cost_model_init(p->qp, kvz_hip_default_coeff_weights(p->qp), &m);
   kvz_oracle_lowdelay_cfg cfg;
   memset(&cfg, 0, sizeof cfg);
   cfg.fme_level = p->fme_level; cfg.pu_depth_inter_max = p->pu_depth_inter_max; cfg.sao = p->sao; cfg.deblock = p->deblock; cfg.mv_constraint = p->mv_constraint;
-  cfg.no_wpp = p->no_wpp;
+  cfg.no_wpp = p->no_wpp; cfg.fast_residual_cost = p->fast_residual_cost;
   for (int f = 0; f < n_pictures; f++)
     kvz_oracle_inter_picture(p->qp, p->poc, &cfg, m.entropy_fbits, kvz_hip_default_coeff_weights(p->qp), width, height, src + f * px, ref + f * px,
                              (const kvz_oracle_cu *)ref_cu + f * cells, rec + f * px, (kvz_oracle_cu *)cu + f * cells, coeff ? coeff + f * nctu * KVZ_HIP_CTU_COEFFS : NULL);

@@ -164,7 +164,7 @@ void kvz_oracle_sao_search_frame_inter(const kvz_hip_intra_cost_model *m, int wi
                                        kvz_hip_sao_params *chroma_out, uint8_t *merge_out);
 
 /* ---- sequences with inter prediction (kvz_oracle_inter.inc, part of kvz_oracle_ctu.c): an I picture followed by B pictures that each reference the previous
- * one in both lists -- `--gop lp-g<gop_len>d<gop_depth>t1` with the `veryfast` or `ultrafast` preset (BASELINE config 4) ---- */
+ * one in both lists -- `--gop lp-g<gop_len>d<gop_depth>t1` with the `ultrafast` .. `faster` presets (BASELINE config 4 is `veryfast`) ---- */
 typedef struct kvz_oracle_cu {  /* cu_info_t (cu.h:130-170) of one 4x4 unit */
   uint8_t type /* 0 not set, 1 intra, 2 inter */, depth, mode /* intra */, tr_depth; uint16_t cbf;
   uint8_t skipped, merged, merge_idx, mv_dir, mv_ref[2], mv_cand[2];  /* motion fields of a list mv_dir does not use: 0 / 255 */
@@ -174,12 +174,13 @@ typedef struct kvz_oracle_lowdelay_cfg {
   int32_t qp;                  /* --qp */
   int32_t gop_len, gop_depth;  /* lp-g<len>d<depth>t1 */
   int32_t intra_period;        /* --period (64) */
-  int32_t fme_level;           /* --subme: 2 `veryfast`, 0 `ultrafast` */
+  int32_t fme_level;           /* --subme: 4 `faster`, 2 `veryfast`, 0 `ultrafast` */
   int32_t pu_depth_inter_max;  /* 3 `veryfast`, 2 `ultrafast` */
   int32_t sao, deblock;        /* --sao full / off, --deblock / --no-deblock */
   int32_t mv_constraint;       /* cfg.owf && cfg.wpp (search_inter.c:85) */
   int32_t no_wpp;
   int32_t ra8_qp_model;        /* a --preset came before --gop lp-...: the QP model fields of kvz_gop_ra8 stay in the GOP entries (kvz_oracle_lowdelay_qp) */
+  int32_t fast_residual_cost;  /* --fast-residual-cost: 28 `ultrafast` .. `veryfast`, 0 `faster` (coefficients priced with the CABAC model at every QP; rdo.c:311-340) */
 } kvz_oracle_lowdelay_cfg;
 /* the motion search of single PUs on caller-supplied candidates (the contract of kvz_hip_dev_pu_search, include/kvz_hip_dev.h), and a recorder of every such
  * search the sequence encoder runs: inputs, results and the picture they belong to */

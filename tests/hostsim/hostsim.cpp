@@ -151,12 +151,13 @@ extern "C" unsigned long long kvz_hostsim_syncs(void) { return g_kvz_syncs; }
 // ---- the inter CTU pass (kvz_inter_ctu.hpp) run on the host: one B picture, CTUs in raster order, every phase a loop over its 256 "lanes" ----
 #include "../../kvazaar_amd/csrc/kvz_inter_host.hpp"
 extern "C" void kvz_hostsim_inter_frame(int width, int height, int qp, int poc, uint64_t coeff_weights, const float *fbits, int mv_constraint, int sao, int deblock, int fme_level,
-                                        int pu_depth_inter_max, int no_wpp, const uint8_t *src, const uint8_t *ref, const kvz_hip_cu_info *ref_cu, uint8_t *rec, kvz_hip_cu_info *cu)
+                                        int pu_depth_inter_max, int no_wpp, int fast_residual_cost, const uint8_t *src, const uint8_t *ref, const kvz_hip_cu_info *ref_cu, uint8_t *rec,
+                                        kvz_hip_cu_info *cu)
 {
   static kvz::Tables tb;
   kvz::build_tables(&tb);
   kvz::InterModel m;
-  kvz::inter_model_init(&m, qp, poc, coeff_weights, fbits, mv_constraint, sao, deblock, fme_level, pu_depth_inter_max, no_wpp);
+  kvz::inter_model_init(&m, qp, poc, coeff_weights, fbits, mv_constraint, sao, deblock, fme_level, pu_depth_inter_max, no_wpp, fast_residual_cost);
   kvz::InterFrames F;
   memset(&F, 0, sizeof F);
   F.W = width; F.H = height; F.wc = (width + 63) / 64; F.hc = (height + 63) / 64; F.frame_px = (long)width * height * 3 / 2; F.cells = (long)(width / 4) * (height / 4);

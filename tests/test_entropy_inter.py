@@ -78,7 +78,7 @@ def test_device_chain_pass_filters_coder_writes_the_reference_slice_data(oracle,
     p = ic.PRESETS[preset]
     ip.upload(0, frames[1], rf[0], cu[0].reshape(-1))  # the I picture after its loop filters, from the oracle (the all-intra chain has its own tests)
     for k in range(1, n):
-        prm = inter.InterParams(qp=int(qps[k]), poc=k, mv_constraint=int(owf > 0), sao=int(sao), deblock=int(dbk), fme_level=p["fme_level"], pu_depth_inter_max=p["pu_depth_inter_max"], no_wpp=0)
+        prm = inter.InterParams(qp=int(qps[k]), poc=k, mv_constraint=int(owf > 0), sao=int(sao), deblock=int(dbk), fme_level=p["fme_level"], pu_depth_inter_max=p["pu_depth_inter_max"], no_wpp=0, fast_residual_cost=p["fast_residual_cost"])
         if k > 1:
             ip.advance()
             ip.upload_source(0, frames[k])

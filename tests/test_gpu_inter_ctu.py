@@ -17,7 +17,7 @@ import inter_common as ic
 
 
 class InterParams(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("qp", "poc", "mv_constraint", "sao", "deblock", "fme_level", "pu_depth_inter_max", "no_wpp")]
+    _fields_ = [(n, C.c_int32) for n in ("qp", "poc", "mv_constraint", "sao", "deblock", "fme_level", "pu_depth_inter_max", "no_wpp", "fast_residual_cost")]
 
 
 FAST_COST_CASES = ["pan", "ultrafast", "vertical-pan-owf", "static-qp17", "no-loop-filters", "survey-416x240"]  # every picture QP below 28: kvz_fast_coeff_cost
@@ -32,7 +32,7 @@ def oracle():
 def params_of(case, qp, poc):
     name, w, h, n, base_qp, preset, dbk, sao, owf, src = case
     p = ic.PRESETS[preset]
-    return InterParams(qp=int(qp), poc=poc, mv_constraint=int(owf > 0), sao=int(sao), deblock=int(dbk), fme_level=p["fme_level"], pu_depth_inter_max=p["pu_depth_inter_max"], no_wpp=0)
+    return InterParams(qp=int(qp), poc=poc, mv_constraint=int(owf > 0), sao=int(sao), deblock=int(dbk), fme_level=p["fme_level"], pu_depth_inter_max=p["pu_depth_inter_max"], no_wpp=0, fast_residual_cost=p["fast_residual_cost"])
 
 
 @pytest.fixture(scope="module")
@@ -45,7 +45,8 @@ def hostsim_lib():
     return C.CDLL(so)
 
 
-@pytest.mark.parametrize("name", ["pan", "ultrafast", "vertical-pan-owf", "no-loop-filters", "noisy-qp27", "cabac-coeff-cost-qp32", "fast-pan-owf-qp37", "ultrafast-fast-pan-owf-qp30"])
+@pytest.mark.parametrize("name", ["pan", "ultrafast", "vertical-pan-owf", "no-loop-filters", "noisy-qp27", "cabac-coeff-cost-qp32", "fast-pan-owf-qp37", "ultrafast-fast-pan-owf-qp30",
+                                  "faster-pan", "faster-qp32", "faster-owf-qp27"])
 def test_host_simulation_of_the_device_program_equals_the_oracle(oracle, hostsim_lib, name):
     case = [c for c in ic.CASES if c[0] == name][0]
     _, w, h, n, qp, preset, dbk, sao, owf, src = case
@@ -55,12 +56,12 @@ def test_host_simulation_of_the_device_program_equals_the_oracle(oracle, hostsim
     fb = np.array(mc["entropy_fbits"], np.float32)
     f = hostsim_lib.kvz_hostsim_inter_frame
     f.restype = None
-    f.argtypes = [C.c_int] * 4 + [C.c_uint64, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 5
+    f.argtypes = [C.c_int] * 4 + [C.c_uint64, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p] * 5
     p = ic.PRESETS[preset]
     for k in range(1, n):
         rec = np.zeros(w * h * 3 // 2, np.uint8)
         out = np.zeros((h // 4, w // 4), ic.CU_DTYPE)
-        f(w, h, int(qps[k]), k, int(mc["coeff_weights"][str(int(qps[k]))]), fb.ctypes.data, int(owf > 0), int(sao), int(dbk), p["fme_level"], p["pu_depth_inter_max"], 0,
+        f(w, h, int(qps[k]), k, int(mc["coeff_weights"][str(int(qps[k]))]), fb.ctypes.data, int(owf > 0), int(sao), int(dbk), p["fme_level"], p["pu_depth_inter_max"], 0, p["fast_residual_cost"],
           np.ascontiguousarray(frames[k]).ctypes.data, np.ascontiguousarray(rf[k - 1]).ctypes.data, np.ascontiguousarray(cu[k - 1]).ctypes.data, rec.ctypes.data, out.ctypes.data)
         assert ic.first_difference(out[None], cu[k][None]) is None, k
         assert np.array_equal(rec, rs[k]), k
@@ -195,7 +196,7 @@ def test_device_pass_rejects_what_it_does_not_cover():
     lib = kvazaar_amd.load_library()
     lib.kvz_hip_dev_inter_ctu_pass.restype = C.c_int
     lib.kvz_hip_dev_inter_ctu_pass.argtypes = [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_void_p]
-    ok = InterParams(qp=25, poc=1, mv_constraint=0, sao=1, deblock=1, fme_level=2, pu_depth_inter_max=3, no_wpp=0)
-    for bad in (dict(qp=52), dict(qp=-1), dict(fme_level=4), dict(poc=0), dict(pu_depth_inter_max=4)):
+    ok = InterParams(qp=25, poc=1, mv_constraint=0, sao=1, deblock=1, fme_level=2, pu_depth_inter_max=3, no_wpp=0, fast_residual_cost=28)
+    for bad in (dict(qp=52), dict(qp=-1), dict(fme_level=3), dict(fast_residual_cost=52), dict(poc=0), dict(pu_depth_inter_max=4)):
         p = InterParams(**{**{n: getattr(ok, n) for n, _ in InterParams._fields_}, **bad})
         assert lib.kvz_hip_dev_inter_ctu_pass(None, None, None, None, None, None, 64, 64, 1, C.addressof(p)) == -1
