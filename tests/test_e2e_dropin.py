@@ -154,12 +154,13 @@ INTER_CASES = [("416x240", 8, 1234, "small", ["--preset", "veryfast", "--gop", "
                ("416x240", 10, 1234, "small", ["--preset", "veryfast", "--gop", "lp-g4d3t1", "--owf", "0", "--period", "8"], 8),
                ("416x240", 6, 1234, "small", ["--preset", "veryfast", "--gop", "lp-g4d3t1", "--owf", "0", "-q", "32"], 5),   # picture QPs 35-38: coefficients priced with the CABAC model
                ("416x240", 6, 1234, "small", ["--preset", "ultrafast", "--gop", "lp-g4d3t1", "--owf", "0", "-q", "24"], 5),  # picture QPs on both sides of fast-residual-cost 28
+               ("416x240", 6, 1234, "small", ["--preset", "faster", "--gop", "lp-g4d3t1", "--owf", "0"], 5),                 # subme 4 (quarter-sample search), fast-residual-cost 0
                ("1920x1080", 5, 1, "large", ["--preset", "veryfast", "--gop", "lp-g4d3t1", "--owf", "0"], 4),
                ("3840x2160", 4, 2, "large", ["--preset", "veryfast", "--gop", "lp-g4d3t1", "--owf", "0"], 3)]
 
 
 @pytest.mark.parametrize("res,frames,seed,kind,opts,device_pictures", INTER_CASES,
-                         ids=["veryfast-416x240", "ultrafast-qp20", "veryfast-no-wpp", "veryfast-period8", "veryfast-qp32", "ultrafast-qp24-mixed", "veryfast-1080p", "baseline-c4-2160p"])
+                         ids=["veryfast-416x240", "ultrafast-qp20", "veryfast-no-wpp", "veryfast-period8", "veryfast-qp32", "ultrafast-qp24-mixed", "faster", "veryfast-1080p", "baseline-c4-2160p"])
 def test_inter_pass_inside_the_encoder_bitstream_identical(tmp_path, res, frames, seed, kind, opts, device_pictures):
     """`--preset veryfast --gop lp-g4d3t1` with every picture searched on the device: the I picture by the batched intra pass, the B pictures by
     kvz_hip_dev_inter_ctu_pass (integration/kvazaar/search_lcu_hip.c search_lcu_inter), each from kvazaar's own deblocked + SAO-filtered reference picture and its

@@ -22,6 +22,7 @@ class InterParams(C.Structure):
 
 FAST_COST_CASES = ["pan", "ultrafast", "vertical-pan-owf", "static-qp17", "no-loop-filters", "survey-416x240"]  # every picture QP below 28: kvz_fast_coeff_cost
 CABAC_COST_CASES = ["noisy-qp27", "cabac-coeff-cost-qp32", "fast-pan-owf-qp37", "ultrafast-fast-pan-owf-qp30"]     # picture QPs from 28 on: the residual coder in counting mode
+FASTER_CASES = ["faster-pan", "faster-qp32", "faster-owf-qp27"]  # `--preset faster`: quarter-sample steps in the fractional search, CABAC coefficient cost at every QP
 
 
 @pytest.fixture(scope="module")
@@ -83,7 +84,7 @@ def device_pass(lib, dev, w, h, srcs, refs, ref_cus, prm):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", FAST_COST_CASES + CABAC_COST_CASES + ["two-gops"])
+@pytest.mark.parametrize("name", FAST_COST_CASES + CABAC_COST_CASES + FASTER_CASES + ["two-gops"])
 def test_device_pass_equals_oracle_picture_by_picture(oracle, name):
     import kvazaar_amd
     from kvazaar_amd.dev import Dev
@@ -119,7 +120,7 @@ def test_device_pass_on_baseline_config_4(oracle):
 
 
 CHAIN_CASES = ["deblock-only", "ultrafast", "pan", "vertical-pan-owf", "static-qp17", "no-loop-filters", "survey-416x240", "survey-1080p", "baseline-c4-2160p",
-               "noisy-qp27", "cabac-coeff-cost-qp32", "ultrafast-fast-pan-owf-qp30"]
+               "noisy-qp27", "cabac-coeff-cost-qp32", "ultrafast-fast-pan-owf-qp30", "faster-pan", "faster-qp32"]
 
 
 @pytest.mark.gpu
