@@ -99,13 +99,16 @@ struct InterFrames {
   unsigned long long *prof;  // [IP_COUNT] or NULL (KVZ_ICTU_PROFILE)
 };
 
+#define IC_WS 44  /* window stride: 3 bytes of alignment + up to 40 samples, rounded to dwords */
 struct MCand { i16 mv[2][2]; u8 ref[2], dir; };                         // inter_merge_cand_t
 struct PuSearch { int x, y, w; i16 mv_cand[2][2]; MCand merge[5]; int num_merge; };
 struct UMap { CuInfo unit[5]; double cost[5], bits[5]; int8_t keys[5]; int size; };
 struct Nbr { CuInfo a[2], b[3], c3, h; bool va[2], vb[3], vc3, vh; };  // merge_candidates_t
 
 struct InterLds {
-  alignas(8) u8 win[40 * 40];      // clamped reference window (motion compensation, fractional search), stride 40
+  alignas(8) u8 win[40 * IC_WS + 16];  // reference window (motion compensation, fractional search): rows staged from a dword-aligned column, sample (r, c) at
+                                       // win[r * IC_WS + win_xo + c]; 16 bytes of slack behind the last row for the horizontal pass's whole-dword reads
+  int win_xo;
   i16 g[40 * 33];                  // 14-bit horizontal intermediates, stride 33
   alignas(8) u8 cur[32 * 32];      // the PU's source block, contiguous
   union {                          // the sample buffers of stages that never overlap in time
@@ -219,6 +222,19 @@ struct InterCtu {
     IC_SYNC();
     return a;
   }
+
+  // byte-string helpers of the horizontal interpolation pass (v_alignbyte_b32, v_dot4_i32_i8; plain C++ for the host simulation)
+#ifdef KVZ_HOSTSIM
+  KVZ_DEV static u32 alignbyte(u32 hi, u32 lo, u32 n) { return (u32)(((((unsigned long long)hi) << 32) | lo) >> (8 * (n & 3))); }
+  KVZ_DEV static int dot4(u32 a, u32 b, int c)
+  {
+    for (int k = 0; k < 4; k++) c += (int)(int8_t)(a >> (8 * k)) * (int)(int8_t)(b >> (8 * k));
+    return c;
+  }
+#else
+  KVZ_DEV static u32 alignbyte(u32 hi, u32 lo, u32 n) { return __builtin_amdgcn_alignbyte(hi, lo, n); }
+  KVZ_DEV static int dot4(u32 a, u32 b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
+#endif
 
   // the CU info of luma position (fx, fy): inside this CTU from the work-tree level, else from the frame (finished CTUs)
   KVZ_DEV CuInfo cell_at(int lv, int fx, int fy) const
