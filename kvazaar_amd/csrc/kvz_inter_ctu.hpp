@@ -120,6 +120,7 @@ struct InterLds {
     u8 planes[35 * 256];               // the 35 intra predictions of a 16x16 CU (intra_all_mode_costs)
   };
   u32 acc[16];
+  u32 tsum[8];                     // satd_tiles: the eight tiles of a round
   u32 cost[4];
   u32 mcost[36];                   // SATD of every intra mode of the CU under evaluation
   u8 top[65], left[65], ftop[65], fleft[65];
