@@ -173,7 +173,8 @@ void kvz_hip_dev_cu_dbk_from_info(const kvz_hip_cu_info *cu, int count, kvz_hip_
  *   the hexagon search (hexagon_search :712-800, unlimited steps) -- every probe = check_mv_cost (:180-232): edge-replicated SAD (image.c:407), then the MVD
  *   bit cost of the cheaper AMVP predictor (calc_mvd_cost :381-423 / get_mvd_coding_cost :328-341) times lambda_sqrt, against the best so far with the
  *   reference's 0.001 guard --, for fme_level 0 the SATD re-pricing of the result (:1381-1393),
- *   for fme_level 2 the two half-pel steps (hor / ver neighbours, diagonal neighbours) with the truncation of the reference's `unsigned` cost accumulator,
+ *   for fme_level 2 the two half-pel steps (hor / ver neighbours, diagonal neighbours) with the truncation of the reference's `unsigned` cost accumulator, for
+ *   fme_level 4 the two quarter-pel steps around the best half-pel position as well,
  *   and throughout the motion-vector restriction of overlapped pictures (fracmv_within_tile :75-152 with mv-constraint none: cfg.owf && cfg.wpp).
  * What the caller supplies per PU is what depends on the neighbourhood: the two AMVP predictors (kvz_inter_get_mv_cand), the merge candidates' motion
  * (kvz_inter_get_merge_cand; only candidates that use one list take part) and the co-located CU's motion.  cur / ref: width x height luma planes, stride = width.
@@ -192,7 +193,7 @@ typedef struct kvz_hip_me_params {
   double  lambda_sqrt;     /* state->lambda_sqrt of the picture */
   int32_t mv_constraint;   /* cfg.owf && cfg.wpp */
   int32_t sao, deblock;    /* cfg.sao_type != 0, cfg.deblock_enable: the margin of that restriction */
-  int32_t fme_level;       /* 0 (`ultrafast`) or 2 (`veryfast`) */
+  int32_t fme_level;       /* 0 (`ultrafast`), 2 (`veryfast`) or 4 (`faster`) */
 } kvz_hip_me_params;
 typedef struct kvz_hip_me_result {
   int32_t mv[2];           /* after the integer search, quarter samples */

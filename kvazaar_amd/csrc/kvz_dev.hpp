@@ -1322,7 +1322,7 @@ int kvz_hip_dev_pu_search(const uint8_t *cur, const uint8_t *ref, int width, int
                           const kvz_hip_me_params *params, kvz_hip_me_result *out)
 {
   if (count <= 0) return 0;
-  if (!params || (params->fme_level != 0 && params->fme_level != 2)) { fprintf(stderr, "kvz_hip_dev_pu_search: fme_level must be 0 or 2\n"); return -1; }
+  if (!params || (params->fme_level != 0 && params->fme_level != 2 && params->fme_level != 4)) { fprintf(stderr, "kvz_hip_dev_pu_search: fme_level must be 0, 2 or 4\n"); return -1; }
   const dim3 grid((unsigned)count), block(256);
   const kvz::Tables *tb = kvz::device_tables();
   // PU sizes are mixed within a picture's list: the instantiation is sized for the largest one (pu-depth-inter 1-3: 32)

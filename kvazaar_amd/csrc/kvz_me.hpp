@@ -293,17 +293,20 @@ template <int MAXN> __global__ void __launch_bounds__(256) dev_pu_search_kernel(
   res.frac_mv[0] = res.frac_mv[1] = 0; res.frac_mvp = 0; res.frac_valid = 0; res.frac_cost = 0; res.frac_bits = 0;
 
   if (prm.fme_level > 0 && res.valid && (allowed(best.mvx + 3, best.mvy + 3) || allowed(best.mvx - 3, best.mvy - 3))) {
-    // search_frac (search_inter.c:974-1130) with fme_level 2: `costs` is unsigned there, the sums with the motion cost truncate
+    // search_frac (search_inter.c:974-1166): the two half-sample steps, with fme_level 4 the two quarter-sample steps around the best half-sample position as well;
+    // `costs` is unsigned there, the sums with the motion cost truncate
     const int sqx[9] = { 0, -1, 1, 0, 0, -1, 1, -1, 1 }, sqy[9] = { 0, 0, 0, -1, 1, -1, -1, 1, 1 };
     int mx = imx, my = imy;
     double bitcost = (double)mvd_bits(mx * 4, my * 4);
     u32 c0 = (u32)((double)s_cost[0] + bitcost * prm.lambda_sqrt);
     double cost = (double)c0;
     mx *= 2; my *= 2;
-    int best_index = 0, i0 = 1;
-    for (int step = 0; step < 2; step++) {
+    int best_index = 0, i0 = 1, off_x = 0, off_y = 0;
+    const int steps = prm.fme_level;
+    for (int step = 0; step < steps; step++) {
+      const int unit = step < 2 ? 2 : 1;  // quarter samples per step of this precision
       FmePlane pl[4];
-      fme_planes(step, 0, 0, pl);
+      fme_planes(step, off_x, off_y, pl);
       int done = 0;
       for (int first = 0; first < 4; first++) {
         if (done & (1 << first)) continue;
@@ -335,15 +338,17 @@ template <int MAXN> __global__ void __launch_bounds__(256) dev_pu_search_kernel(
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int cx = mx + sqx[i0 + j], cy = my + sqy[i0 + j];
-        if (!allowed(cx * 2, cy * 2)) continue;
-        const double b = (double)mvd_bits(cx * 2, cy * 2);
+        if (!allowed(cx * unit, cy * unit)) continue;
+        const double b = (double)mvd_bits(cx * unit, cy * unit);
         const u32 cj = (u32)((double)s_cost[j] + b * prm.lambda_sqrt);
         if ((double)cj < cost) { cost = (double)cj; bitcost = b; best_index = i0 + j; }
       }
       i0 += 4;
+      if (step == 1 || step == steps - 1) {  // search_inter.c:1146-1162
+        mx += sqx[best_index]; my += sqy[best_index];
+        if (step == (steps - 1 < 1 ? steps - 1 : 1)) { mx *= 2; my *= 2; off_x = sqx[best_index]; off_y = sqy[best_index]; best_index = 0; i0 = 1; }
+      }
     }
-    mx += sqx[best_index]; my += sqy[best_index];
-    mx *= 2; my *= 2;
     res.frac_mv[0] = mx; res.frac_mv[1] = my; res.frac_cost = cost; res.frac_bits = bitcost;
     res.frac_mvp = mvp_index(mx, my);
     res.frac_valid = allowed(mx, my);

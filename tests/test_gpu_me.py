@@ -56,7 +56,7 @@ def random_pus(rng, w, h, n):
 def test_contract_function_reproduces_every_traced_search(oracle):
     """CPU: kvz_oracle_pu_motion_search on the recorded inputs == what the sequence encoder computed (the recorder and the contract are the same code paths)"""
     total = 0
-    for name in ("fast-pan-owf-qp37", "ultrafast-fast-pan-owf-qp30", "two-gops"):
+    for name in ("fast-pan-owf-qp37", "ultrafast-fast-pan-owf-qp30", "two-gops", "faster-owf-qp27"):
         case = [c for c in ic.CASES if c[0] == name][0]
         _, w, h, n, qp, preset, dbk, sao, owf, src = case
         frames, rf, qps, pus, res, poc = ic.traced_encode(oracle, case)
@@ -70,7 +70,7 @@ def test_contract_function_reproduces_every_traced_search(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fme_level,constraint", [(2, 0), (2, 1), (0, 0), (0, 1)])
+@pytest.mark.parametrize("fme_level,constraint", [(2, 0), (2, 1), (0, 0), (0, 1), (4, 0), (4, 1)])
 def test_device_search_equals_oracle_on_random_pus(oracle, fme_level, constraint):
     import kvazaar_amd
     from kvazaar_amd.dev import Dev
@@ -91,7 +91,7 @@ def test_device_search_equals_oracle_on_random_pus(oracle, fme_level, constraint
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["fast-pan-owf-qp37", "ultrafast-fast-pan-owf-qp30", "vertical-pan-owf", "noisy-qp27", "survey-416x240", "baseline-c4-2160p"])
+@pytest.mark.parametrize("name", ["fast-pan-owf-qp37", "ultrafast-fast-pan-owf-qp30", "vertical-pan-owf", "noisy-qp27", "survey-416x240", "baseline-c4-2160p", "faster-owf-qp27", "faster-qp32"])
 def test_device_reproduces_every_search_of_an_encode(oracle, name):
     import kvazaar_amd
     from kvazaar_amd.dev import Dev
