@@ -20,7 +20,7 @@ class LowdelayCfg(C.Structure):
 
 
 PRESETS = {"faster": dict(fme_level=4, pu_depth_inter_max=3, sao=1, fast_residual_cost=0), "veryfast": dict(fme_level=2, pu_depth_inter_max=3, sao=1, fast_residual_cost=28),
-           "ultrafast": dict(fme_level=0, pu_depth_inter_max=2, sao=0, fast_residual_cost=28)}
+           "superfast": dict(fme_level=2, pu_depth_inter_max=2, sao=1, fast_residual_cost=28), "ultrafast": dict(fme_level=0, pu_depth_inter_max=2, sao=0, fast_residual_cost=28)}
 
 
 def clip(w, h, n, seed, noise=1.5, pan=(1.25, -0.5)):
@@ -160,6 +160,8 @@ CASES = [
     ("faster-pan", 200, 136, 4, 22, "faster", 1, 1, 0, ("motion", 5, 1.5, (1.25, -0.5))),            # `faster`: quarter-sample motion search, CABAC coefficient cost at every QP
     ("faster-qp32", 264, 200, 4, 32, "faster", 1, 1, 0, ("motion", 7, 1.0, (0.5, 0.25))),
     ("faster-owf-qp27", 416, 240, 5, 27, "faster", 1, 1, 2, ("motion", 9, 1.5, (1.25, -0.5))),
+    ("ultrafast-8mod16", 200, 136, 4, 25, "ultrafast", 1, 0, 2, ("motion", 14, 1.5, (2.5, -1.25))),  # width and height 8 mod 16: 8x8 CUs at the edges may be inter although pu-depth-inter stops at 16x16 (search.c:702-713)
+    ("superfast-8mod16-qp33", 136, 200, 3, 33, "superfast", 1, 1, 0, ("motion", 15, 1.0, (-1.5, 3.0))),
     ("survey-416x240", 416, 240, 8, 22, "veryfast", 1, 1, 2, ("synth", 1234, "small")),    # bitstream md5 1e7a8165...
     ("survey-1080p", 1920, 1080, 4, 22, "veryfast", 1, 1, 2, ("synth", 1, "large")),
     ("baseline-c4-2160p", 3840, 2160, 4, 22, "veryfast", 1, 1, 2, ("synth", 2, "large")),    # BASELINE config 4 at its own size
@@ -168,7 +170,7 @@ CASES = [
 
 # the cases whose slice data is pinned (tests/golden/entropy_inter.json): picture QPs on both sides of fast-residual-cost 28, SAO on / off, the wavefront MV restriction, `faster`
 ENTROPY_CASES = ["pan", "ultrafast", "vertical-pan-owf", "static-qp17", "two-gops", "no-loop-filters", "deblock-only", "survey-416x240", "noisy-qp27", "cabac-coeff-cost-qp32",
-                 "faster-pan", "faster-qp32"]
+                 "faster-pan", "faster-qp32", "ultrafast-8mod16"]
 
 # ... and BASELINE config 4 at its own size: fixture entry only (bench.py's leg and the GPU test check the device against it)
 ENTROPY_BENCH_CASES = ["baseline-c4-2160p"]

@@ -67,10 +67,11 @@ INTER_CASES = [("416x240", 8, ["--preset", "veryfast", "--gop", "lp-g4d3t1", "--
                ("416x240", 6, ["--preset", "superfast", "--gop", "lp-g8d4t1", "--owf", "0", "--no-sao"], 5),            # another low-delay GOP: other picture QPs
                ("416x240", 6, ["--preset", "ultrafast", "--gop", "lp-g4d3t1", "--owf", "0", "-q", "24"], 5),            # picture QPs on both sides of fast-residual-cost 28
                ("416x240", 6, ["--preset", "veryfast", "--gop", "lp-g4d3t1", "--owf", "0", "-q", "32"], 5),            # coefficients priced by the residual coder's counting mode
-               ("416x240", 6, ["--preset", "faster", "--gop", "lp-g4d3t1", "--owf", "0"], 5)]                        # subme 4, fast-residual-cost 0
+               ("416x240", 6, ["--preset", "faster", "--gop", "lp-g4d3t1", "--owf", "0"], 5),                        # subme 4, fast-residual-cost 0
+               ("200x136", 5, ["--preset", "ultrafast", "--gop", "lp-g4d3t1", "--owf", "0", "-q", "25"], 4)]        # 8 mod 16: 8x8 inter CUs where the edge forces the split (search.c:702-713)
 
 
-@pytest.mark.parametrize("res,frames,opts,device_pictures", INTER_CASES, ids=["veryfast", "ultrafast-qp20", "veryfast-no-wpp", "veryfast-period8", "superfast-g8-no-sao", "ultrafast-qp24-mixed", "veryfast-qp32", "faster"])
+@pytest.mark.parametrize("res,frames,opts,device_pictures", INTER_CASES, ids=["veryfast", "ultrafast-qp20", "veryfast-no-wpp", "veryfast-period8", "superfast-g8-no-sao", "ultrafast-qp24-mixed", "veryfast-qp32", "faster", "ultrafast-8mod16"])
 def test_binding_inter_pictures_write_the_reference_bitstream(tmp_path, res, frames, opts, device_pictures):
     """B pictures of a low-delay GOP through the binding: the reference picture (after kvazaar's own loop filters) and its cu_array go in, cu_info_t / reconstruction /
     coefficients of every LCU come back; kvazaar's entropy coder must then write the reference encoder's bitstream"""

@@ -22,6 +22,7 @@ class InterParams(C.Structure):
 
 FAST_COST_CASES = ["pan", "ultrafast", "vertical-pan-owf", "static-qp17", "no-loop-filters", "survey-416x240"]  # every picture QP below 28: kvz_fast_coeff_cost
 CABAC_COST_CASES = ["noisy-qp27", "cabac-coeff-cost-qp32", "fast-pan-owf-qp37", "ultrafast-fast-pan-owf-qp30"]     # picture QPs from 28 on: the residual coder in counting mode
+EDGE_CASES = ["ultrafast-8mod16", "superfast-8mod16-qp33"]  # 8x8 inter CUs where the picture edge forces the split below pu-depth-inter's 16x16 (search.c:702-713)
 FASTER_CASES = ["faster-pan", "faster-qp32", "faster-owf-qp27"]  # `--preset faster`: quarter-sample steps in the fractional search, CABAC coefficient cost at every QP
 
 
@@ -47,7 +48,7 @@ def hostsim_lib():
 
 
 @pytest.mark.parametrize("name", ["pan", "ultrafast", "vertical-pan-owf", "no-loop-filters", "noisy-qp27", "cabac-coeff-cost-qp32", "fast-pan-owf-qp37", "ultrafast-fast-pan-owf-qp30",
-                                  "faster-pan", "faster-qp32", "faster-owf-qp27"])
+                                  "faster-pan", "faster-qp32", "faster-owf-qp27", "ultrafast-8mod16", "superfast-8mod16-qp33"])
 def test_host_simulation_of_the_device_program_equals_the_oracle(oracle, hostsim_lib, name):
     case = [c for c in ic.CASES if c[0] == name][0]
     _, w, h, n, qp, preset, dbk, sao, owf, src = case
@@ -68,6 +69,15 @@ def test_host_simulation_of_the_device_program_equals_the_oracle(oracle, hostsim
         assert np.array_equal(rec, rs[k]), k
 
 
+def test_fuzz_of_the_device_program_against_the_oracle(hostsim_lib):
+    """tools/fuzz_inter.py: random clips, sizes that cut CTUs (incl. 8 mod 16), --qp 10..44, ultrafast / superfast / veryfast / faster, GOPs of 2 / 3 / 4 / 8, fast pans,
+    loop filters / motion restriction / WPP on and off -- the simulated device program must equal the oracle on every B picture"""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(flatapi.ROOT, "tools", "fuzz_inter.py"), "60", "9"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 of 60 rounds differ" in r.stdout
+
+
 def device_pass(lib, dev, w, h, srcs, refs, ref_cus, prm):
     n = len(srcs)
     lib.kvz_hip_dev_inter_ctu_pass.restype = C.c_int
@@ -84,7 +94,7 @@ def device_pass(lib, dev, w, h, srcs, refs, ref_cus, prm):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", FAST_COST_CASES + CABAC_COST_CASES + FASTER_CASES + ["two-gops"])
+@pytest.mark.parametrize("name", FAST_COST_CASES + CABAC_COST_CASES + FASTER_CASES + EDGE_CASES + ["two-gops"])
 def test_device_pass_equals_oracle_picture_by_picture(oracle, name):
     import kvazaar_amd
     from kvazaar_amd.dev import Dev

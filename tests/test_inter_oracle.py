@@ -89,6 +89,17 @@ def test_oracle_vs_compiled_reference_cu_by_cu(oracle, name):
     assert ic.digests(rrec, rcu) == {k: GOLDEN[name][k] for k in ("rec", "cu")}
 
 
+def test_fuzz_of_the_oracle_against_the_reference_encoder():
+    """tools/fuzz_inter_oracle.py: random clips and switch settings through the oracle and through the compiled reference encoder (how the forced-split rule of
+    search.c:702-713 was found: 8x8 inter CUs at the edge of pictures whose size is 8 mod 16 under `ultrafast` / `superfast`)"""
+    if not os.path.exists(os.path.join(flatapi.ROOT, "oracle", "_ref", "kvazaar_ref")):
+        pytest.skip("oracle/_ref not built (the GPU box): the committed digests are the check there")
+    import subprocess, sys
+    r = subprocess.run([sys.executable, os.path.join(flatapi.ROOT, "tools", "fuzz_inter_oracle.py"), "40", "5"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 of 40 rounds differ" in r.stdout
+
+
 def test_default_threading_gives_the_constrained_result():
     """kvazaar's output depends on --owf only through the motion-vector restriction of overlapped pictures (search_inter.c:85): the default CLI (threads and owf
     auto) and --threads 0 --owf 2 write the same reconstruction, which is why the fixtures can be recorded single-threaded"""

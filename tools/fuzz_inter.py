@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Fuzz of the inter CTU pass's device sources (host simulation, tests/hostsim) against the sequence oracle: random small clips (pan speed, noise, moving objects),
+random picture sizes that cut CTUs, --qp 10..44 (picture QPs on both sides of fast-residual-cost), the four presets of the low-delay configuration (ultrafast /
+superfast / veryfast / faster: subme 0 / 2 / 2 / 4, PUs down to 16x16 / 16x16 / 8x8 / 8x8, fast-residual-cost 28 / 28 / 28 / 0), low-delay GOPs of 2, 3, 4 and 8 pictures,
+slow and fast pans, loop filters and the overlapped-picture motion restriction on or off, --no-wpp.  Every B picture is searched by
+the simulated device program from the oracle's reference picture and CU records; reconstruction and every CU decision must be the oracle's.
+usage: tools/fuzz_inter.py [rounds] [seed]"""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import flatapi, ctu_common as cc, inter_common as ic
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+oracle = flatapi.load_oracle()
+sim = C.CDLL(os.path.join(ROOT, "tests", "hostsim", "libkvz_hostsim.so"))
+f = sim.kvz_hostsim_inter_frame
+f.restype = None
+f.argtypes = [C.c_int] * 4 + [C.c_uint64, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p] * 5
+mc = cc.model_constants()
+fb = np.array(mc["entropy_fbits"], np.float32)
+
+bad = 0
+for r in range(rounds):
+    w, h = int(rng.choice([64, 72, 136, 200])), int(rng.choice([64, 88, 136]))
+    n = int(rng.integers(2, 4))
+    qp = int(rng.integers(10, 45))
+    preset = str(rng.choice(["ultrafast", "superfast", "veryfast", "faster"]))
+    dbk, sao, no_wpp = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 4) == 0)
+    owf = int(rng.integers(0, 2)) if not no_wpp else 0  # the motion restriction is cfg.owf && cfg.wpp
+    gop = [(4, 3), (4, 3), (8, 4), (2, 2), (3, 2)][int(rng.integers(0, 5))]
+    speed = float(rng.choice([6, 6, 24]))
+    frames = ic.clip(w, h, n, int(rng.integers(1, 1 << 30)), float(rng.uniform(0, 3)), (float(rng.uniform(-speed, speed)), float(rng.uniform(-speed, speed))))
+    rs, rf, cu, qps = ic.oracle_encode(oracle, w, h, frames, qp, preset=preset, deblock=bool(dbk), sao=bool(sao), mv_constraint=bool(owf), gop=gop, no_wpp=bool(no_wpp))
+    p = ic.PRESETS[preset]
+    ok = True
+    for k in range(1, n):
+        rec = np.zeros(w * h * 3 // 2, np.uint8)
+        out = np.zeros((h // 4, w // 4), ic.CU_DTYPE)
+        f(w, h, int(qps[k]), k, int(mc["coeff_weights"][str(int(qps[k]))]), fb.ctypes.data, owf, sao, dbk, p["fme_level"], p["pu_depth_inter_max"], no_wpp, p["fast_residual_cost"],
+          np.ascontiguousarray(frames[k]).ctypes.data, np.ascontiguousarray(rf[k - 1]).ctypes.data, np.ascontiguousarray(cu[k - 1]).ctypes.data, rec.ctypes.data, out.ctypes.data)
+        ok = ok and ic.first_difference(out[None], cu[k][None]) is None and np.array_equal(rec, rs[k])
+    b = cu[1:]
+    print("round %d: %dx%d x %d %s lp-g%dd%d qp %d (pictures %s) dbk %d sao %d owf %d no_wpp %d: intra %d skipped %d merged %d amvp %d -> %s" % (
+        r, w, h, n, preset, gop[0], gop[1], qp, list(map(int, qps)), dbk, sao, owf, no_wpp, int((b["type"] == 1).sum()), int(((b["type"] == 2) & (b["skipped"] == 1)).sum()),
+        int(((b["type"] == 2) & (b["merged"] == 1)).sum()), int(((b["type"] == 2) & (b["merged"] == 0) & (b["skipped"] == 0)).sum()), "equal" if ok else "DIFFERENT"), flush=True)
+    bad += not ok
+print("%d of %d rounds differ" % (bad, rounds))
+sys.exit(1 if bad else 0)
