@@ -188,6 +188,17 @@ def test_frozen_contexts_do_not_reproduce_the_encoder(oracle):
     assert got != GOLDEN[mg.clip_key(w, h, n, seed, kind, qp, 0)]
 
 
+def test_fuzz_of_the_oracle_against_the_reference_encoder():
+    """tools/fuzz_intra_oracle.py: random pictures, every way a multiple of 8 can cut a CTU, QP 0..51, the searches of ultrafast / faster / fast / medium, deblocking and
+    WPP on / off -- the oracle's picture must be what the compiled reference encoder writes with --debug"""
+    if not os.path.exists(os.path.join(flatapi.ROOT, "oracle", "_ref", "kvazaar_ref")):
+        pytest.skip("oracle/_ref not built (the GPU box): the committed digests are the check there")
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(flatapi.ROOT, "tools", "fuzz_intra_oracle.py"), "60", "4"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 of 60 rounds differ" in r.stdout
+
+
 def test_encoder_fixture_matches_reference_build(tmp_path):
     """where oracle/_ref exists, the committed fixture is what the reference CLI produces today (two small clips)"""
     if not os.path.exists(os.path.join(flatapi.ROOT, "oracle", "_ref", "kvazaar_ref")):
