@@ -196,7 +196,7 @@ def test_fuzz_of_the_oracle_against_the_reference_encoder():
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(flatapi.ROOT, "tools", "fuzz_intra_oracle.py"), "60", "4"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "0 of 60 rounds differ" in r.stdout
+    assert "0 of 90 rounds differ" in r.stdout
 
 
 def test_encoder_fixture_matches_reference_build(tmp_path):

@@ -39,5 +39,20 @@ for r in range(rounds):
     ok = np.array_equal(np.asarray(got).reshape(-1), want)
     print("round %d: %dx%d %s qp %d dbk %d no_wpp %d -> %s" % (r, w, h, preset, qp, dbk, no_wpp, "equal" if ok else "DIFFERENT"), flush=True)
     bad += not ok
-print("%d of %d rounds differ" % (bad, rounds))
+# ... and the presets as they are, through to the bitstream: the oracle's CTU pass, its SAO parameter decision (presets with --sao full) and its entropy coder must write the
+# slice data behind the encoder's slice headers (tests/entropy_common.py's chain on random clips instead of the fixture's)
+import entropy_common as ec
+ref_exe = os.path.join(ROOT, "oracle", "_ref", "kvazaar_ref")
+for r in range(rounds // 2):
+    w, h = int(rng.choice([64, 72, 136, 200, 264])), int(rng.choice([64, 88, 136, 200]))
+    case = ("fuzz", w, h, int(rng.integers(1, 3)), int(rng.integers(0, 1 << 20)), str(rng.choice(["small", "large"])), int(rng.integers(4, 48)),
+            str(rng.choice(["ultrafast", "veryfast", "medium"])), ["--no-wpp"] if rng.integers(0, 4) == 0 else [])
+    with tempfile.TemporaryDirectory() as d:
+        payloads = ec.reference_slice_payloads(ref_exe, case, d)
+    ok = True
+    for payload, (data, sizes) in zip(payloads, ec.oracle_slice_data(oracle, case)):
+        ok = ok and payload[len(payload) - sum(sizes):] == data and ec.header_ends_with_entry_points(payload[:len(payload) - sum(sizes)], sizes, "--no-wpp" not in case[8])
+    print("bitstream round %d: %dx%d x %d %s qp %d %s -> %s" % (r, w, h, case[3], case[7], case[6], " ".join(case[8]), "equal" if ok else "DIFFERENT"), flush=True)
+    bad += not ok
+print("%d of %d rounds differ" % (bad, rounds + rounds // 2))
 sys.exit(1 if bad else 0)
