@@ -77,3 +77,14 @@ def test_pipeline_quality_is_sane(oracle, model22):
     psnr = 10 * np.log10(255 ** 2 / np.mean((y - ry) ** 2))
     assert 39.0 < psnr < 40.5, psnr
     assert set(np.unique(o["depth"])) <= {0, 1, 2, 3}
+
+
+def test_fuzz_of_the_ctu_program_against_the_oracle(hostsim):
+    """tools/fuzz_ctu_sim.py: random pictures and sizes, QP 0..51, every switch of the cost model (CABAC coefficient cost, 32x32 CUs, RDOQ, NxN partitions, WPP, frozen
+    contexts) -- the device sources in host simulation must equal the oracle on every output"""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(flatapi.ROOT, "tools", "fuzz_ctu_sim.py"), "120", "6"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "0 of 120 cases differ" in r.stdout
