@@ -116,3 +116,15 @@ def test_binding_with_device_entropy_coding_writes_the_reference_bitstream(tmp_p
         assert got == "9aeb72382ab3092e285ce3f97f51d4ea"
     coded = int(open(str(tmp_path / "trace")).read()) if os.path.exists(str(tmp_path / "trace")) else 0
     assert (coded >= frames) if on_device else coded == 0
+
+
+def test_fuzz_of_the_binding_against_the_reference_encoder():
+    """tools/fuzz_binding.py: random command lines (every preset, all-intra or a low-delay GOP, --qp, --owf, --no-wpp, tiles, SAO modes, RDOQ, PU depths, --subme,
+    --fast-residual-cost, motion-search switches, rate control ...) through kvazaar_hipsim and kvazaar_ref: whatever the binding decides -- take the pictures or leave them to
+    kvz_search_lcu -- the file must be the reference encoder's"""
+    if not os.path.exists(os.path.join(REF, "kvazaar_hipsim")):
+        pytest.skip("oracle/_ref/kvazaar_hipsim not built (oracle/Makefile, where /root/reference exists)")
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(flatapi.ROOT, "tools", "fuzz_binding.py"), "40", "8"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert "0 of 40 rounds differ" in r.stdout
