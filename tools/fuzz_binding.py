@@ -59,13 +59,16 @@ for r in range(rounds):
         if want.startswith("rc"):
             print("round %d: %s: the reference rejects these options (%s)" % (r, " ".join(opts), err.strip().splitlines()[-1] if err.strip() else ""), flush=True)
             continue
-        got, err = encode("kvazaar_hipsim", yuv, "%dx%d" % (w, h), os.path.join(d, "sim.hevc"), common,
-                          {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1", "KVZ_HIP_BATCH_TRACE": os.path.join(d, "ti"), "KVZ_HIP_INTER_TRACE": os.path.join(d, "tb")})
+        env = {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1", "KVZ_HIP_BATCH_TRACE": os.path.join(d, "ti"), "KVZ_HIP_INTER_TRACE": os.path.join(d, "tb")}
+        entropy = int(rng.integers(0, 3) == 0)  # a third of the rounds also hand the slice data of the batched pictures to the (oracle-served) device coder
+        if entropy:
+            env["KVZ_HIP_BATCH_ENTROPY"] = "1"
+        got, err = encode("kvazaar_hipsim", yuv, "%dx%d" % (w, h), os.path.join(d, "sim.hevc"), common, env)
         ti = int(open(os.path.join(d, "ti")).read().split()[0]) if os.path.exists(os.path.join(d, "ti")) else 0
         tb = int(open(os.path.join(d, "tb")).read().split()[0]) if os.path.exists(os.path.join(d, "tb")) else 0
     used_intra += ti > 0; used_inter += tb > 0
     ok = got == want
-    print("round %d: %dx%d x %d %s: device pictures %d I / %d B -> %s" % (r, w, h, n, " ".join(opts), ti, tb, "equal" if ok else "DIFFERENT %s" % err), flush=True)
+    print("round %d: %dx%d x %d %s%s: device pictures %d I / %d B -> %s" % (r, w, h, n, " ".join(opts), " [device entropy coding]" if entropy else "", ti, tb, "equal" if ok else "DIFFERENT %s" % err), flush=True)
     bad += not ok
 print("%d of %d rounds differ (the binding took I pictures in %d rounds, B pictures in %d)" % (bad, rounds, used_intra, used_inter))
 sys.exit(1 if bad else 0)
