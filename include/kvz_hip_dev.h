@@ -148,7 +148,7 @@ typedef struct kvz_hip_inter_params {
   int32_t poc;                 /* picture order count inside the intra period (> 0); temporal AMVP candidates need poc > 1 (inter.c:1290) */
   int32_t mv_constraint;       /* cfg.owf && cfg.wpp */
   int32_t sao, deblock;        /* cfg.sao_type != 0, cfg.deblock_enable (the margin of that restriction) */
-  int32_t fme_level;           /* cfg.fme_level (--subme): 4 `faster`, 2 `veryfast`, 0 `ultrafast` */
+  int32_t fme_level;           /* cfg.fme_level (--subme) 0 .. 4: 4 `faster`, 2 `veryfast`, 0 `ultrafast` -- the steps search_frac takes (search_inter.c:1088) */
   int32_t pu_depth_inter_max;  /* 3 `veryfast`, 2 `ultrafast` */
   int32_t no_wpp;              /* one coder runs through the picture in raster order (--no-wpp) */
   int32_t fast_residual_cost;  /* cfg.fast_residual_cost_limit: 28 `ultrafast` .. `veryfast`, 0 `faster` -- below it (and below 50) coefficients are priced by kvz_fast_coeff_cost */
@@ -193,7 +193,7 @@ typedef struct kvz_hip_me_params {
   double  lambda_sqrt;     /* state->lambda_sqrt of the picture */
   int32_t mv_constraint;   /* cfg.owf && cfg.wpp */
   int32_t sao, deblock;    /* cfg.sao_type != 0, cfg.deblock_enable: the margin of that restriction */
-  int32_t fme_level;       /* 0 (`ultrafast`), 2 (`veryfast`) or 4 (`faster`) */
+  int32_t fme_level;       /* 0 .. 4: 0 (`ultrafast`), 2 (`veryfast`), 4 (`faster`) */
 } kvz_hip_me_params;
 typedef struct kvz_hip_me_result {
   int32_t mv[2];           /* after the integer search, quarter samples */

@@ -103,7 +103,7 @@ static int eligible(const encoder_state_t *state)
   REQUIRE(!cfg->ml_pu_depth_intra);  /* (intra_bit_allocation, which lp GOPs switch on, only acts under rate control: rate_control.c:352-705) */
   if (state->frame->slicetype == KVZ_SLICE_I) return 1;
   /* B pictures: the inter CTU pass (include/kvz_hip_dev.h kvz_hip_dev_inter_ctu_pass) is the search of `--preset faster|veryfast|superfast|ultrafast --gop lp-gNd*t1`:
-   * one reference picture -- the previous one -- in both lists, hexagon search with the `sensitive` early termination, fme level 0, 2 or 4, bi-prediction through
+   * one reference picture -- the previous one -- in both lists, hexagon search with the `sensitive` early termination, any fme level, bi-prediction through
    * merge candidates only, early skip, 2Nx2N PUs of 8..32 samples, coefficients priced as kvz_get_coeff_cost does with the configuration's fast-residual-cost.  --owf 0: the pass searches the whole
    * picture when its first LCU arrives, so the reference picture has to be complete by then. */
   const encoder_state_config_frame_t *fr = state->frame;
@@ -111,7 +111,7 @@ static int eligible(const encoder_state_t *state)
   REQUIRE(fr->ref->used_size == 1 && fr->ref_LX_size[0] == 1 && fr->ref_LX_size[1] == 1 && fr->ref->pocs[0] == fr->poc - 1);
   REQUIRE(cfg->gop_len > 0 && cfg->gop_lowdelay && cfg->bipred && cfg->fast_bipred && cfg->tmvp_enable);
   REQUIRE(cfg->ime_algorithm == KVZ_IME_HEXBS && cfg->me_early_termination == KVZ_ME_EARLY_TERMINATION_SENSITIVE && cfg->me_max_steps == (uint32_t)-1);
-  REQUIRE((cfg->fme_level == 0 || cfg->fme_level == 2 || cfg->fme_level == 4) && !cfg->mv_rdo && cfg->mv_constraint == KVZ_MV_CONSTRAIN_NONE);
+  REQUIRE(cfg->fme_level >= 0 && cfg->fme_level <= 4 && !cfg->mv_rdo && cfg->mv_constraint == KVZ_MV_CONSTRAIN_NONE);
   REQUIRE(cfg->early_skip && cfg->max_merge == 5 && cfg->zero_coeff_rdo && !cfg->smp_enable && !cfg->amp_enable && !cfg->rdoq_enable);
   REQUIRE(cfg->pu_depth_inter.min[0] == 1 && (cfg->pu_depth_inter.max[0] == 2 || cfg->pu_depth_inter.max[0] == 3));
   REQUIRE(cfg->pu_depth_intra.min[0] == 2 && cfg->pu_depth_intra.max[0] == 3);

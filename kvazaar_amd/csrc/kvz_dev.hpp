@@ -1246,7 +1246,7 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
   if (n_pictures <= 0) return 0;
   if (!p || width <= 0 || height <= 0 || (width & 7) || (height & 7) || width > 64 * 255 || height > 64 * 255 || n_pictures > 65535) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: bad geometry\n"); return -1; }
   if (p->qp < 0 || p->qp > 51) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: picture QP %d outside 0..51\n", p->qp); return -1; }
-  if ((p->fme_level != 0 && p->fme_level != 2 && p->fme_level != 4) || p->pu_depth_inter_max < 1 || p->pu_depth_inter_max > 3 || p->poc < 1 || p->fast_residual_cost < 0 || p->fast_residual_cost > 51) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: unsupported parameters\n"); return -1; }
+  if (p->fme_level < 0 || p->fme_level > 4 || p->pu_depth_inter_max < 1 || p->pu_depth_inter_max > 3 || p->poc < 1 || p->fast_residual_cost < 0 || p->fast_residual_cost > 51) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: unsupported parameters\n"); return -1; }
   hipStream_t st = be().stream;
   const int wc = (width + 63) / 64, hc = (height + 63) / 64, ctus = wc * hc;
   const long total = (long)ctus * n_pictures;
@@ -1322,7 +1322,7 @@ int kvz_hip_dev_pu_search(const uint8_t *cur, const uint8_t *ref, int width, int
                           const kvz_hip_me_params *params, kvz_hip_me_result *out)
 {
   if (count <= 0) return 0;
-  if (!params || (params->fme_level != 0 && params->fme_level != 2 && params->fme_level != 4)) { fprintf(stderr, "kvz_hip_dev_pu_search: fme_level must be 0, 2 or 4\n"); return -1; }
+  if (!params || params->fme_level < 0 || params->fme_level > 4) { fprintf(stderr, "kvz_hip_dev_pu_search: fme_level must be 0 .. 4\n"); return -1; }
   const dim3 grid((unsigned)count), block(256);
   const kvz::Tables *tb = kvz::device_tables();
   // PU sizes are mixed within a picture's list: the instantiation is sized for the largest one (pu-depth-inter 1-3: 32)

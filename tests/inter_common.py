@@ -60,9 +60,10 @@ def clip(w, h, n, seed, noise=1.5, pan=(1.25, -0.5)):
     return out
 
 
-def oracle_encode(oracle, w, h, frames, qp, preset="veryfast", deblock=True, sao=None, mv_constraint=False, gop=(4, 3), no_wpp=False):
-    """-> (rec_search [n, fs], rec_final [n, fs], cu [n, h/4, w/4] of CU_DTYPE, qps)"""
+def oracle_encode(oracle, w, h, frames, qp, preset="veryfast", deblock=True, sao=None, mv_constraint=False, gop=(4, 3), no_wpp=False, overrides=None):
+    """-> (rec_search [n, fs], rec_final [n, fs], cu [n, h/4, w/4] of CU_DTYPE, qps); overrides: search options that differ from the preset's (fme_level, fast_residual_cost ...)"""
     p = dict(PRESETS[preset])
+    p.update(overrides or {})
     if sao is not None:
         p["sao"] = int(sao)
     cfg = LowdelayCfg(qp=qp, gop_len=gop[0], gop_depth=gop[1], intra_period=64, deblock=int(deblock), mv_constraint=int(mv_constraint), no_wpp=int(no_wpp), ra8_qp_model=1, **p)
@@ -255,9 +256,10 @@ def me_results_differ(a, b, fme_level):
     return np.flatnonzero(bad)
 
 
-def oracle_encode_bits(oracle, w, h, frames, qp, preset="veryfast", deblock=True, sao=None, mv_constraint=False, gop=(4, 3), no_wpp=False):
+def oracle_encode_bits(oracle, w, h, frames, qp, preset="veryfast", deblock=True, sao=None, mv_constraint=False, gop=(4, 3), no_wpp=False, overrides=None):
     """kvz_oracle_lowdelay_encode_bits -> [(slice data of the picture, [substream sizes])] per picture"""
     p = dict(PRESETS[preset])
+    p.update(overrides or {})
     if sao is not None:
         p["sao"] = int(sao)
     cfg = LowdelayCfg(qp=qp, gop_len=gop[0], gop_depth=gop[1], intra_period=64, deblock=int(deblock), mv_constraint=int(mv_constraint), no_wpp=int(no_wpp), ra8_qp_model=1, **p)

@@ -208,6 +208,6 @@ def test_device_pass_rejects_what_it_does_not_cover():
     lib.kvz_hip_dev_inter_ctu_pass.restype = C.c_int
     lib.kvz_hip_dev_inter_ctu_pass.argtypes = [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_void_p]
     ok = InterParams(qp=25, poc=1, mv_constraint=0, sao=1, deblock=1, fme_level=2, pu_depth_inter_max=3, no_wpp=0, fast_residual_cost=28)
-    for bad in (dict(qp=52), dict(qp=-1), dict(fme_level=3), dict(fast_residual_cost=52), dict(poc=0), dict(pu_depth_inter_max=4)):
+    for bad in (dict(qp=52), dict(qp=-1), dict(fme_level=5), dict(fast_residual_cost=52), dict(poc=0), dict(pu_depth_inter_max=4)):
         p = InterParams(**{**{n: getattr(ok, n) for n, _ in InterParams._fields_}, **bad})
         assert lib.kvz_hip_dev_inter_ctu_pass(None, None, None, None, None, None, 64, 64, 1, C.addressof(p)) == -1

@@ -70,7 +70,7 @@ def test_contract_function_reproduces_every_traced_search(oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fme_level,constraint", [(2, 0), (2, 1), (0, 0), (0, 1), (4, 0), (4, 1)])
+@pytest.mark.parametrize("fme_level,constraint", [(2, 0), (2, 1), (0, 0), (0, 1), (4, 0), (4, 1), (1, 0), (3, 1)])
 def test_device_search_equals_oracle_on_random_pus(oracle, fme_level, constraint):
     import kvazaar_amd
     from kvazaar_amd.dev import Dev

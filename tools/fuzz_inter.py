@@ -37,8 +37,14 @@ for r in range(rounds):
     speed = float(rng.choice([6, 6, 24]))
     src = ("motion", int(rng.integers(1, 1 << 30)), float(rng.uniform(0, 3)), (float(rng.uniform(-speed, speed)), float(rng.uniform(-speed, speed))))
     frames = ic.clip(w, h, n, src[1], src[2], src[3])
-    rs, rf, cu, qps = ic.oracle_encode(oracle, w, h, frames, qp, preset=preset, deblock=bool(dbk), sao=bool(sao), mv_constraint=bool(owf), gop=gop, no_wpp=bool(no_wpp))
-    p = ic.PRESETS[preset]
+    ov = {}  # options that differ from the preset's: --subme 0..4, --fast-residual-cost
+    if rng.integers(0, 3) == 0:
+        ov["fme_level"] = int(rng.integers(0, 5))
+    if rng.integers(0, 3) == 0:
+        ov["fast_residual_cost"] = int(rng.choice([0, 20, 28, 35, 51]))
+    rs, rf, cu, qps = ic.oracle_encode(oracle, w, h, frames, qp, preset=preset, deblock=bool(dbk), sao=bool(sao), mv_constraint=bool(owf), gop=gop, no_wpp=bool(no_wpp), overrides=ov)
+    p = dict(ic.PRESETS[preset])
+    p.update(ov)
     ok = True
     for k in range(1, n):
         rec = np.zeros(w * h * 3 // 2, np.uint8)
@@ -46,7 +52,7 @@ for r in range(rounds):
         f(w, h, int(qps[k]), k, int(mc["coeff_weights"][str(int(qps[k]))]), fb.ctypes.data, owf, sao, dbk, p["fme_level"], p["pu_depth_inter_max"], no_wpp, p["fast_residual_cost"],
           np.ascontiguousarray(frames[k]).ctypes.data, np.ascontiguousarray(rf[k - 1]).ctypes.data, np.ascontiguousarray(cu[k - 1]).ctypes.data, rec.ctypes.data, out.ctypes.data)
         ok = ok and ic.first_difference(out[None], cu[k][None]) is None and np.array_equal(rec, rs[k])
-    if gop == (4, 3) and not no_wpp:  # (what tests/inter_common.py oracle_sequence_for_entropy covers) the slice data of every B picture: simulated device coder == the oracle's coder
+    if gop == (4, 3) and not no_wpp and not ov:  # (what tests/inter_common.py oracle_sequence_for_entropy covers) the slice data of every B picture: simulated device coder == the oracle's coder
         parts = ic.oracle_sequence_for_entropy(oracle, ("fuzz", w, h, n, qp, preset, dbk, sao, 2 * owf, src))
         bits = ic.oracle_encode_bits(oracle, w, h, frames, qp, preset=preset, deblock=bool(dbk), sao=bool(sao), mv_constraint=bool(owf))
         hc = (h + 63) // 64
@@ -62,8 +68,8 @@ for r in range(rounds):
                        merge.ctypes.data if merge is not None else None, 49152, out.ctypes.data, sizes.ctypes.data)
             ok = ok and total >= 0 and out[:total].tobytes() == bits[k][0] and [int(v) for v in sizes] == list(bits[k][1])
     b = cu[1:]
-    print("round %d: %dx%d x %d %s lp-g%dd%d qp %d (pictures %s) dbk %d sao %d owf %d no_wpp %d: intra %d skipped %d merged %d amvp %d -> %s" % (
-        r, w, h, n, preset, gop[0], gop[1], qp, list(map(int, qps)), dbk, sao, owf, no_wpp, int((b["type"] == 1).sum()), int(((b["type"] == 2) & (b["skipped"] == 1)).sum()),
+    print("round %d: %dx%d x %d %s lp-g%dd%d qp %d (pictures %s) dbk %d sao %d owf %d no_wpp %d %s: intra %d skipped %d merged %d amvp %d -> %s" % (
+        r, w, h, n, preset, gop[0], gop[1], qp, list(map(int, qps)), dbk, sao, owf, no_wpp, ov, int((b["type"] == 1).sum()), int(((b["type"] == 2) & (b["skipped"] == 1)).sum()),
         int(((b["type"] == 2) & (b["merged"] == 1)).sum()), int(((b["type"] == 2) & (b["merged"] == 0) & (b["skipped"] == 0)).sum()), "equal" if ok else "DIFFERENT"), flush=True)
     bad += not ok
 print("%d of %d rounds differ" % (bad, rounds))
