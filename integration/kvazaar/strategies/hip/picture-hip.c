@@ -18,6 +18,16 @@ int kvz_hip_strategy_usable(uint8_t bitdepth)
   return usable;
 }
 
+int kvz_hip_strategy_priority(void)
+{
+  static int priority = -1;
+  if (priority < 0) {
+    const char *on = getenv("KVZ_HIP_DROPIN");
+    priority = (on && on[0] == '1') ? 50 : 0;
+  }
+  return priority;
+}
+
 /* inter_recon_bipred_func (strategies-picture.h:136-148): pick the planes out of lcu_t / yuv_t / yuv_im_t exactly as
  * bipred_average_generic does (picture-generic.c:616-668) and hand each plane to the device. */
 static void bipred_average_hip(lcu_t *const lcu, const yuv_t *const px_L0, const yuv_t *const px_L1,

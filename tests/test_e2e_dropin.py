@@ -46,7 +46,7 @@ def test_bitstream_identical_to_generic(tmp_path, frames, preset):
     synth.write_yuv(yuv, 416, 240, frames, 1234, "small")
     common = preset + ["--threads", "4"]
     md5_gen, t_gen, _ = _encode("kvazaar_ref", yuv, str(tmp_path / "gen.hevc"), common + ["--no-cpuid"])
-    md5_hip, t_hip, err = _encode("kvazaar_hip", yuv, str(tmp_path / "hip.hevc"), common, {"KVZ_HIP_STATS": "1"})
+    md5_hip, t_hip, err = _encode("kvazaar_hip", yuv, str(tmp_path / "hip.hevc"), common, {"KVZ_HIP_STATS": "1", "KVZ_HIP_DROPIN": "1"})  # the per-call strategies are opt-in (hip-common.h)
     assert os.path.getsize(str(tmp_path / "hip.hevc")) > 2000
     print(f"generic {t_gen:.2f}s  hip {t_hip:.2f}s  {[l for l in err.splitlines() if 'kvz_hip' in l]}")
     assert "strategy calls served" in err and " 0 strategy calls" not in err, "hip strategy was not exercised"
@@ -58,7 +58,8 @@ def test_golden_md5_416x240(tmp_path):
     _need_hip_encoder()
     yuv = str(tmp_path / "syn.yuv")
     assert synth.write_yuv(yuv, 416, 240, 8, 1234, "small") == synth.MD5["416x240"]
-    md5_hip, t, err = _encode("kvazaar_hip", yuv, str(tmp_path / "hip.hevc"), ["--preset", "ultrafast", "-p", "1", "--threads", "8"])
+    md5_hip, t, err = _encode("kvazaar_hip", yuv, str(tmp_path / "hip.hevc"), ["--preset", "ultrafast", "-p", "1", "--threads", "8"], {"KVZ_HIP_DROPIN": "1", "KVZ_HIP_STATS": "1"})
+    assert "strategy calls served" in err and " 0 strategy calls" not in err, "hip strategy was not exercised"
     assert md5_hip == GOLDEN_416x240_8F
 
 

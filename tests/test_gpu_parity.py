@@ -1,6 +1,8 @@
 """Parity tests proper (-m gpu): every per-call entry point of libkvz_hip.so (include/kvz_hip.h), running its HIP
 kernels on the MI355X, against the oracle on the seeded cases of tests/cases.py -- bit-exact, no tolerances
 (pixel_var included: the summation order is part of the contract)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -35,6 +37,41 @@ def test_hip_find_last_scanpos(oracle, hip):
         return np.ctypeslib.as_array(oracle.lib.kvz_oracle_scan_table(scan_idx, l2), shape=(n,)).copy()
     bad = [label for label, run in cases.cases_find_last_scanpos(st) if run(oracle) != run(hip)]
     assert not bad, bad[:10]
+
+
+def test_hip_get_optimized_sad(oracle, hip):
+    """get_optimized_sad (strategies-picture.h:128, picture-generic.c:671, AVX2: picture-avx2.c): the pointer the strategy hands back for every width it serves is
+    CALLED here -- against reg_sad of that width and, where oracle/_ref is built, against whatever the compiled reference's own AVX2 strategy returns for it -- and a
+    width no PU can have must be refused with NULL (search_inter.c:1656 then falls back to reg_sad)."""
+    import ctypes as C
+    from flatapi import ptr, u8p
+    get = hip.lib.kvz_hip_get_optimized_sad
+    get.restype = C.c_void_p
+    get.argtypes = [C.c_int32]
+    proto = C.CFUNCTYPE(C.c_uint32, u8p, u8p, C.c_int32, C.c_uint32, C.c_uint32)
+    ref = None
+    if os.path.exists(flatapi.refshim_path()):
+        ref = flatapi.load_ref(1)
+    rng = np.random.default_rng(7)
+    a = rng.integers(0, 256, 80 * 70, dtype=np.uint8)
+    b = rng.integers(0, 256, 90 * 70, dtype=np.uint8)
+    served = 0
+    for w in (4, 8, 12, 16, 24, 32, 48, 64):
+        addr = get(w)
+        assert addr, w
+        fn = proto(addr)
+        served += 1
+        for h in (1, 4, 8, 16, 63, 64):
+            for (oa, ob) in ((0, 0), (3, 5), (81, 7)):
+                pa, pb = ptr(a[oa:]), ptr(b[ob:])
+                got = fn(pa, pb, h, 80, 90)
+                assert got == oracle.reg_sad(pa, pb, w, h, 80, 90), (w, h, oa, ob)
+                if ref is not None:
+                    r = ref.lib.kvz_ref_optimized_sad(w, pa, pb, h, 80, 90)
+                    assert r == 0xFFFFFFFF or r == got, (w, h, oa, ob)
+    assert served == 8
+    for w in (0, 1, 2, 6, 20, 40, 65, 128, -8):
+        assert not get(w), w
 
 
 def test_hip_golden_satd(hip):
