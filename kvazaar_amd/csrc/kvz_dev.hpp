@@ -936,7 +936,15 @@ struct InterScratch {
   unsigned *ticket = nullptr;  // [0] ticket, [1] error
   InterModel *model = nullptr;
 };
-inline InterScratch &inter_scratch() { static InterScratch s; return s; }
+// One set per calling thread and device, like the stream the work is queued on (be() is thread_local): two threads, or two devices of one process, never share
+// ticket / done / slab buffers, and a buffer is only ever freed by the thread whose (synchronised) stream used it.
+inline InterScratch &inter_scratch()
+{
+  static thread_local InterScratch s[64];
+  int device = 0;
+  KVZ_HIP_CHECK(hipGetDevice(&device));
+  return s[device & 63];
+}
 }  // namespace kvz
 namespace kvz {
 
@@ -1134,7 +1142,15 @@ struct LoopScratch {
   SaoStats *stats = nullptr; SaoCand *cand = nullptr; SaoRec *recs = nullptr; u8 *merge = nullptr; size_t lcus = 0;
   float *fbits = nullptr;
 };
-inline LoopScratch &loop_scratch() { static LoopScratch s; return s; }
+// per calling thread and device (see inter_scratch): kvz_hip_dev_entropy_code_inter reads the SAO decisions the LAST kvz_hip_dev_loop_filters_inter of the same thread
+// left on the same device
+inline LoopScratch &loop_scratch()
+{
+  static thread_local LoopScratch s[64];
+  int device = 0;
+  KVZ_HIP_CHECK(hipGetDevice(&device));
+  return s[device & 63];
+}
 }  // namespace kvz
 int kvz_hip_dev_loop_filters_inter(const uint8_t *src, uint8_t *rec, int width, int height, int n_pictures, const kvz_hip_cu_dbk *info, int qp, int slice_is_b, int deblock,
                                    int beta_offset_div2, int tc_offset_div2, int sao, int no_wpp, kvz_hip_sao_params *luma, kvz_hip_sao_params *chroma, uint8_t *merge)
@@ -1255,7 +1271,8 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
   KVZ_HIP_CHECK(hipGetDevice(&dev_id));
   KVZ_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id));
   const char *env = getenv("KVZ_HIP_INTER_WG_PER_CU");
-  const int per_cu = env ? atoi(env) : 8;  // one wavefront per workgroup at up to 256 registers: two wavefronts per SIMD = eight workgroups per CU (15 KB of LDS each)
+  const int lds_fit = (int)(160 * 1024 / (sizeof(kvz::InterLds) + sizeof(kvz::InterCtu) + 64));
+  const int per_cu = env ? atoi(env) : (lds_fit < 8 ? lds_fit : 8);  // one wavefront per workgroup at up to 256 registers: two wavefronts per SIMD = eight workgroups per CU, LDS permitting
   int n_wg = n_cu * (per_cu > 0 ? per_cu : 8);
   if ((long)n_wg > total) n_wg = (int)total;
   if (n_wg > sc.n_slabs) {
@@ -1283,7 +1300,7 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
   kvz::InterModel m;
   float fbits[128];
   for (int i = 0; i < 128; i++) fbits[i] = (float)kvz::kEntropyBits[i] / 32768.0f;
-  kvz::inter_model_init(&m, p->qp, p->poc, kvz::kDefaultCoeffWeights[p->qp], fbits, p->mv_constraint, p->sao, p->deblock, p->fme_level, p->pu_depth_inter_max, p->no_wpp, p->fast_residual_cost);
+  kvz::inter_model_init(&m, p->qp, p->poc, kvz_hip_default_coeff_weights(p->qp) /* 0 from QP 50 on, where kvz_fast_coeff_cost is never used (rdo.c:311-340) */, fbits, p->mv_constraint, p->sao, p->deblock, p->fme_level, p->pu_depth_inter_max, p->no_wpp, p->fast_residual_cost);
   KVZ_HIP_CHECK(hipMemcpyAsync(sc.items, items.data(), (size_t)total * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   KVZ_HIP_CHECK(hipMemcpyAsync(sc.model, &m, sizeof m, hipMemcpyHostToDevice, st));
   KVZ_HIP_CHECK(hipMemsetAsync(sc.done, 0, (size_t)total * sizeof(unsigned), st));

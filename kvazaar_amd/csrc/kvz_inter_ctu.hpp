@@ -6,13 +6,15 @@
 // next CTU's contexts.  oracle/kvz_oracle_inter.inc is the function-by-function CPU restatement it is checked against (itself equal to the reference encoder CU
 // for CU, tests/test_inter_oracle.py); function names below are the oracle's, which cites the reference lines.
 //
-// FIRST VERSION, written for correctness: the program is the reference's own control flow executed uniformly by all lanes of the workgroup -- every lane holds
-// the scalar state (the CU being evaluated, candidate lists, costs, contexts) in registers / private memory and takes the same decisions --, and every loop over
-// samples is a phase `IC_FOR(tid) { ... } IC_SYNC();` spread over the lanes: probes of the motion search, interpolation, SATD / SSD, residual -> DCT -> quantisation
-// -> reconstruction (the item-parallel ops of kvz_ops.hpp, which the per-call strategy API already runs and checks), intra prediction.  The work tree (lcu_t x 5:
-// reconstruction, coefficients, CU info of every depth) is a slab in HBM per resident workgroup; LDS holds the sample buffers of the stage at hand.  CTUs of a
-// picture run in WPP order under the ticket schedule of kvz_ctu_kernels.hpp; pictures of one sequence are launches in order, the launch carries picture k of many
-// independent sequences.  tests/hostsim compiles this file for the host (a phase = a loop over tid), which is how it was brought up against the oracle without a GPU.
+// One wavefront per CTU.  The decisions are the reference's, taken uniformly by all lanes on scalar state that lives once in LDS; every loop over samples is a phase
+// `IC_FOR(tid) { ... } IC_SYNC();` spread over the lanes.  THE WORK TREE IS IN LDS (round 4; rounds 1-3 kept search.c:1220-1225's lcu_t x 5 as a 126 KB slab in HBM
+// per workgroup, and 65 % of a wavefront's time was s_waitcnt on it -- profiles/r04_a_inter_pmc_before.json: 94 GB moved per launch for 1.2 GB of pictures): what the
+// five levels can differ in is one DECIDED picture (every finished CU, whatever its depth: level 3's view) plus ONE candidate per depth, the CU under evaluation
+// there -- 32x32 (level 1), 16x16 (level 2); an 8x8 CU is evaluated in place.  Copying a level down (search.c:943-1063 work-tree copies) is candidate -> decided
+// picture, copying up is nothing at all; CU records likewise (one record per 8x8 of the decided picture + the CU under evaluation per depth), the source samples
+// are staged per 32x32 quadrant, the candidates' quantised levels wait in a small HBM scratch of the workgroup (written, never read on the way) and go to the output
+// block when their CU wins.  CTUs of a picture run in WPP order under the ticket schedule of kvz_ctu_kernels.hpp; pictures of one sequence are launches in order, the
+// launch carries picture k of many independent sequences.  tests/hostsim compiles this file for the host (a phase = a loop over tid).
 // Coefficients are priced as kvz_get_coeff_cost does (rdo.c:311-340): kvz_fast_coeff_cost while the picture QP lies below fast-residual-cost 28 (fused with the
 // quantisation), the residual coder in counting mode on the search contexts from there on (coeff_bits_cabac: kvz_residual.hpp's syntax walk into a price sink).
 // Restrictions of this version: square PUs, one reference picture.
@@ -78,11 +80,11 @@ struct InterModel {  // per picture
   float fbits[128];                 // kvz_f_entropy_bits
 };
 
-struct InterSlab {  // the work tree of one CTU in flight: lcu_t x 5 (search.c:1220-1225)
-  u8 rec[5][64 * 64 + 2 * 32 * 32];
-  i16 coeff[5][64 * 64 + 2 * 32 * 32];
-  CuInfo cu[5][256];
-  u8 org[64 * 64 + 2 * 32 * 32];
+struct InterSlab {  // HBM scratch of one resident workgroup: the quantised levels of the candidates of depth 1 and 2 (Y | U | V, z-order inside the CU), written when
+                    // the CU is quantised and copied to the output block if it wins; `out` stands in for the output block when the caller wants no coefficients
+  i16 cand1[32 * 32 + 2 * 16 * 16];
+  i16 cand2[16 * 16 + 2 * 8 * 8];
+  i16 out[64 * 64 + 2 * 32 * 32];
 };
 
 struct InterFrames {
@@ -105,12 +107,20 @@ struct PuSearch { int x, y, w; i16 mv_cand[2][2]; MCand merge[5]; int num_merge;
 struct UMap { CuInfo unit[5]; double cost[5], bits[5]; int8_t keys[5]; int size; };
 struct Nbr { CuInfo a[2], b[3], c3, h; bool va[2], vb[3], vc3, vh; };  // merge_candidates_t
 
+struct PView { u8 *p; int s; };  // a plane of a block in LDS: sample (x, y) at p[y * s + x]
+
 struct InterLds {
+  // ---- the work tree ----
+  alignas(8) u8 D[64 * 64 + 2 * 32 * 32];    // the decided picture: Y 64x64 | U 32x32 | V 32x32 (level 3's view; an 8x8 CU is evaluated in place)
+  alignas(8) u8 orgq[32 * 32 + 2 * 16 * 16]; // source samples of the 32x32 quadrant being searched: Y | U | V (every sample loop runs inside one depth-1 CU)
+  alignas(8) u8 C1[32 * 32 + 2 * 16 * 16];   // the depth-1 CU under evaluation
+  alignas(8) u8 C2[16 * 16 + 2 * 8 * 8];     // the depth-2 CU under evaluation
+  alignas(8) u8 Z3[8 * 8 + 2 * 4 * 4];       // cu_zero_coeff_cost's copy of a depth-3 CU's prediction (search.c:222 puts it into level 4)
+  CuInfo Dcu[64];                            // CU records of the decided picture, one per 8x8 (the smallest CU)
   alignas(8) u8 win[40 * IC_WS + 16];  // reference window (motion compensation, fractional search): rows staged from a dword-aligned column, sample (r, c) at
                                        // win[r * IC_WS + win_xo + c]; 16 bytes of slack behind the last row for the horizontal pass's whole-dword reads
   int win_xo;
   i16 g[40 * 33];                  // 14-bit horizontal intermediates, stride 33
-  alignas(8) u8 cur[32 * 32];      // the PU's source block, contiguous
   union {                          // the sample buffers of stages that never overlap in time
     struct {
       alignas(8) u8 pred[4][32 * 32];  // the candidate planes of a fractional step
@@ -138,9 +148,6 @@ struct InterLds {
   int level_holds;     // after search_pu_inter: bit 0 / 1 = the level's luma / chroma samples are the prediction of the best merge candidate (merge.keys[0])
   int px[8], py[8];
   u32 sad[8];
-#ifdef KVZ_ICTU_ORG_LDS
-  alignas(8) u8 org[64 * 64 + 2 * 32 * 32];  // the CTU's source samples
-#endif
   ICtx ctx;  // state->search_cabac's contexts (indexed at run time on every priced bin)
   ICtx pre[4], post[4];  // search_cu's copies of them, per depth (search.c:655, 956)
   ICtx row;              // the row coder's contexts at the start of the CTU (the finished CTU's syntax runs on them)
@@ -164,16 +171,37 @@ struct InterCtu {
 #define cab (L->ctx)  /* the search contexts */
 
   // ---- small things ----
-  KVZ_DEV u8 *rec(int lv, int c) const { return S->rec[lv] + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)); }
-  KVZ_DEV i16 *coef(int lv, int c) const { return S->coeff[lv] + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)); }
-#ifdef KVZ_ICTU_ORG_LDS
-  KVZ_DEV u8 *org(int c) const { return L->org + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)); }
-#else
-  KVZ_DEV u8 *org(int c) const { return S->org + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)); }
-#endif
+  // Level lv's samples of plane c of the CU whose luma origin inside the LCU is (xl, yl) -- the CU under evaluation at depth lv (levels 1, 2: its candidate buffer;
+  // level 3: in place in the decided picture; level 4: the 8x8 side buffer) or, for level 3, any finished block
+  KVZ_DEV PView lvl(int lv, int c, int xl, int yl) const
+  {
+    const int sh = c ? 1 : 0;
+    if (lv == 1) return PView{ L->C1 + (c == 0 ? 0 : (c == 1 ? 1024 : 1280)), 32 >> sh };
+    if (lv == 2) return PView{ L->C2 + (c == 0 ? 0 : (c == 1 ? 256 : 320)), 16 >> sh };
+    if (lv == 4) return PView{ L->Z3 + (c == 0 ? 0 : (c == 1 ? 64 : 80)), 8 >> sh };
+    return PView{ L->D + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)) + (yl >> sh) * (64 >> sh) + (xl >> sh), 64 >> sh };
+  }
+  // where cu_zero_coeff_cost parks the prediction of the depth-lv CU (search.c:222: the next level): the CU's own region of the decided picture, which its children
+  // will overwrite and nothing reads before them; the side buffer for a depth-3 CU, whose candidate IS that region
+  KVZ_DEV PView parked(int lv, int c, int xl, int yl) const { return lvl(lv == 3 ? 4 : 3, c, xl, yl); }
+  // the source samples at LCU position (xl, yl) [luma coordinates] of plane c: inside the quadrant staged by load_org_quadrant
+  KVZ_DEV PView orgv(int c, int xl, int yl) const
+  {
+    const int sh = c ? 1 : 0;
+    return PView{ L->orgq + (c == 0 ? 0 : (c == 1 ? 1024 : 1280)) + ((yl & 31) >> sh) * (32 >> sh) + ((xl & 31) >> sh), 32 >> sh };
+  }
+  // the quantised levels of the depth-lv CU at (xl, yl): candidates of depth 1 and 2 in the workgroup's scratch, a depth-3 CU's straight in the output block
+  KVZ_DEV i16 *out_coef() const { return F.coeff ? F.coeff + ((long)frame * F.wc * F.hc + (cy >> 6) * F.wc + (cx >> 6)) * 6144 : S->out; }
+  KVZ_DEV i16 *coef(int lv, int c, int xl, int yl) const
+  {
+    const int sh = c ? 1 : 0;
+    if (lv == 1) return S->cand1 + (c == 0 ? 0 : (c == 1 ? 1024 : 1280));
+    if (lv == 2) return S->cand2 + (c == 0 ? 0 : (c == 1 ? 256 : 320));
+    return out_coef() + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)) + zorder(xl >> sh, yl >> sh);
+  }
   KVZ_DEV const u8 *refp(int c) const { return F.ref + frame * F.frame_px + (c == 0 ? 0 : (c == 1 ? (long)F.W * F.H : (long)F.W * F.H * 5 / 4)); }
   KVZ_DEV const u8 *srcp(int c) const { return F.src + frame * F.frame_px + (c == 0 ? 0 : (c == 1 ? (long)F.W * F.H : (long)F.W * F.H * 5 / 4)); }
-  KVZ_DEV CuInfo *cell(int lv, int xl, int yl) const { return &S->cu[lv][(yl >> 2) * 16 + (xl >> 2)]; }
+  KVZ_DEV CuInfo *dcell(int xl, int yl) const { return &L->Dcu[(yl >> 3) * 8 + (xl >> 3)]; }
   KVZ_DEV static unsigned zorder(int x, int y)
   {
     unsigned r = 0;
@@ -237,10 +265,11 @@ struct InterCtu {
   KVZ_DEV static int dot4(u32 a, u32 b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
 #endif
 
-  // the CU info of luma position (fx, fy): inside this CTU from the work-tree level, else from the frame (finished CTUs)
-  KVZ_DEV CuInfo cell_at(int lv, int fx, int fy) const
+  // the CU info of luma position (fx, fy), which lies outside the CU under evaluation (a neighbour: every caller asks for one): inside this CTU the decided picture's
+  // record -- a finished CU looks the same from every level --, else the frame's (finished CTUs)
+  KVZ_DEV CuInfo cell_at(int, int fx, int fy) const
   {
-    if (fx >= cx && fx < cx + 64 && fy >= cy && fy < cy + 64) return *cell(lv, fx - cx, fy - cy);
+    if (fx >= cx && fx < cx + 64 && fy >= cy && fy < cy + 64) return *dcell(fx - cx, fy - cy);
     return F.cu[frame * F.cells + (long)(fy >> 2) * (F.W >> 2) + (fx >> 2)];
   }
 
