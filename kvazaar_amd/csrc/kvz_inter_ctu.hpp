@@ -7,14 +7,21 @@
 // for CU, tests/test_inter_oracle.py); function names below are the oracle's, which cites the reference lines.
 //
 // One wavefront per CTU.  The decisions are the reference's, taken uniformly by all lanes on scalar state that lives once in LDS; every loop over samples is a phase
-// `IC_FOR(tid) { ... } IC_SYNC();` spread over the lanes.  THE WORK TREE IS IN LDS (round 4; rounds 1-3 kept search.c:1220-1225's lcu_t x 5 as a 126 KB slab in HBM
-// per workgroup, and 65 % of a wavefront's time was s_waitcnt on it -- profiles/r04_a_inter_pmc_before.json: 94 GB moved per launch for 1.2 GB of pictures): what the
-// five levels can differ in is one DECIDED picture (every finished CU, whatever its depth: level 3's view) plus ONE candidate per depth, the CU under evaluation
-// there -- 32x32 (level 1), 16x16 (level 2); an 8x8 CU is evaluated in place.  Copying a level down (search.c:943-1063 work-tree copies) is candidate -> decided
-// picture, copying up is nothing at all; CU records likewise (one record per 8x8 of the decided picture + the CU under evaluation per depth), the source samples
-// are staged per 32x32 quadrant, the candidates' quantised levels wait in a small HBM scratch of the workgroup (written, never read on the way) and go to the output
-// block when their CU wins.  CTUs of a picture run in WPP order under the ticket schedule of kvz_ctu_kernels.hpp; pictures of one sequence are launches in order, the
-// launch carries picture k of many independent sequences.  tests/hostsim compiles this file for the host (a phase = a loop over tid).
+// `IC_FOR(tid) { ... } IC_SYNC();` spread over the lanes.
+//
+// EVERYTHING THE PROGRAM TOUCHES WHILE IT DECIDES IS IN LDS AND ADDRESSED AS LDS (round 4).  Rounds 1-3 kept search.c:1220-1225's lcu_t x 5 as a 126 KB slab in HBM per
+// workgroup, the program object behind a generic `this`, and the tables / per-picture model behind generic pointers: 65 % of a wavefront's time was s_waitcnt
+// (profiles/r04_a_inter_pmc_before.json: 94 GB moved per launch for 1.2 GB of pictures; every LDS access a flat_load, every table look-up a trip to L2).  Now:
+//  * the work tree is what its five levels can differ in: one DECIDED picture (every finished CU, whatever its depth: level 3's view) plus ONE candidate per depth,
+//    the CU under evaluation there -- 32x32 (level 1), 16x16 (level 2); an 8x8 CU is evaluated in place.  Copying a level down (search.c:943-1063) is candidate ->
+//    decided picture, copying up is nothing at all; CU records likewise (one record per 8x8 of the decided picture + the CU under evaluation per depth); the source
+//    samples are staged per 32x32 quadrant; the candidates' quantised levels wait in a small HBM scratch of the workgroup (written, never read on the way) and go
+//    to the output block when their CU wins;
+//  * the program's state (g_ic), the LDS block (g_il) and in it copies of the per-picture model and of the small tables (transform matrix, filters, the CABAC state
+//    machine, reference availability) are workgroup-scope variables: every access is a ds_read / ds_write at a constant offset, none goes through a generic pointer;
+//    pointers into LDS that cross a call are typed as such (KVZ_LDS), pointers to pictures as global (KVZ_GLB).
+// CTUs of a picture run in WPP order under the ticket schedule of kvz_ctu_kernels.hpp; pictures of one sequence are launches in order, the launch carries picture k
+// of many independent sequences.  tests/hostsim compiles this file for the host (a phase = a loop over tid).
 // Coefficients are priced as kvz_get_coeff_cost does (rdo.c:311-340): kvz_fast_coeff_cost while the picture QP lies below fast-residual-cost 28 (fused with the
 // quantisation), the residual coder in counting mode on the search contexts from there on (coeff_bits_cabac: kvz_residual.hpp's syntax walk into a price sink).
 // Restrictions of this version: square PUs, one reference picture.
@@ -30,27 +37,35 @@
 namespace kvz {
 
 #ifndef KVZ_ICTU_THREADS
-#define KVZ_ICTU_THREADS 64  // lanes per CTU, any multiple of 64.  Measured on the MI355X with 256 sequences in flight (416x240): 64 lanes 20.9 k CTUs/s, 128: 18.8 k, 256: 11.9 k
-                             // -- the program is a chain of short phases, and with one wavefront per CTU a barrier costs nothing and four CTUs share a CU
+#define KVZ_ICTU_THREADS 64  // lanes per CTU.  Measured on the MI355X with 256 sequences in flight (416x240): 64 lanes 20.9 k CTUs/s, 128: 18.8 k, 256: 11.9 k
+                             // -- the program is a chain of short phases, and with one wavefront per CTU a barrier costs nothing and more CTUs share a CU
 #endif
 #ifdef KVZ_HOSTSIM
 #define IC_FOR(tid) for (int tid = 0; tid < KVZ_ICTU_THREADS; ++tid)
 #define IC_SYNC()
 #define IC_LDS_ADD(p, v) (*(p) += (v))
+#define KVZ_LDS
+#define KVZ_GLB
+#define IC_WGVAR static
 #else
 #define IC_FOR(tid) for (int tid = threadIdx.x, once_ = 1; once_; once_ = 0)
 #define IC_SYNC() __syncthreads()
 #define IC_LDS_ADD(p, v) atomicAdd((p), (v))
+#define KVZ_LDS __attribute__((address_space(3)))  // a pointer into the workgroup's LDS block: ds_read / ds_write, not flat
+#define KVZ_GLB __attribute__((address_space(1)))  // a pointer into HBM (pictures, CU records, levels): global_load / global_store, not flat
+#define IC_WGVAR __shared__
 #endif
-// IC_FN: the program's larger functions are real calls on the device (one copy each; inlined, the four depths of search_cu_b would each carry a copy of everything)
+// IC_FN: the program's larger functions are real calls on the device (one copy each; inlined, the four depths of search_cu_b would each carry a copy of everything).
+// Arguments are values and indices: an LDS object is named, not passed.
 #ifdef KVZ_HOSTSIM
-#define IC_FN inline
+#define IC_FN static inline
 #else
 #ifndef KVZ_ICTU_WAVES_PER_EU
 #define KVZ_ICTU_WAVES_PER_EU 2
 #endif
-#define IC_FN __device__ __noinline__
+#define IC_FN static __device__ __noinline__
 #endif
+#define IC_DEV static KVZ_DEV
 // stage profile (developer builds, -DKVZ_ICTU_PROFILE): ticks of the 100 MHz clock per category, lane 0 of every workgroup adds into F.prof[]
 #if defined(KVZ_ICTU_PROFILE) && !defined(KVZ_HOSTSIM)
 #define IC_PROF(cat, stmt) do { const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime(); stmt; if (threadIdx.x == 0 && F.prof) atomicAdd(&F.prof[cat], __builtin_amdgcn_s_memrealtime() - t0_); } while (0)
@@ -58,9 +73,12 @@ namespace kvz {
 #define IC_PROF(cat, stmt) do { stmt; } while (0)
 #endif
 enum { IP_MERGE = 0, IP_EARLY_SKIP, IP_ME, IP_FME, IP_CAND, IP_INTRA_SEARCH, IP_INTRA_RECON, IP_INTER_RECON, IP_COST, IP_COPY, IP_IO, IP_TOTAL, IP_COUNT };
-#define IC_RUN(op, n) do { IC_FOR(tid) { for (int i_ = tid; i_ < (n); i_ += KVZ_ICTU_THREADS) (op)(i_); } IC_SYNC(); } while (0)
 
 typedef kvz_hip_cu_info CuInfo;  // one 4x4 unit of the frame's CU info (include/kvz_hip_dev.h)
+typedef KVZ_LDS u8 lu8;
+typedef KVZ_LDS i16 li16;
+typedef KVZ_GLB u8 gu8;
+typedef KVZ_GLB i16 gi16;
 
 // compact context numbering of a B slice (cabac.h:63-100): the CU / transform-tree syntax in the first 32 bytes -- all that moves while coefficients are priced with the
 // fast estimate --, then the residual coder's contexts, KVZ_HIP_CX_SIG_CG .. KVZ_HIP_CX_ABS_CHROMA + 1 of include/kvz_hip_types.h in that order (picture QP >= 28)
@@ -79,9 +97,10 @@ struct InterModel {  // per picture
   QuantScalars qf[2][4], qi[2][4];  // forward / inverse scalars, [luma, chroma][log2 size - 2]
   float fbits[128];                 // kvz_f_entropy_bits
 };
+static_assert(sizeof(InterModel) % 4 == 0, "the model is copied into LDS as 32-bit words");
 
-struct InterSlab {  // HBM scratch of one resident workgroup: the quantised levels of the candidates of depth 1 and 2 (Y | U | V, z-order inside the CU), written when
-                    // the CU is quantised and copied to the output block if it wins; `out` stands in for the output block when the caller wants no coefficients
+struct InterSlab {  // HBM scratch of one resident workgroup: the quantised levels of the candidates of depth 1 and 2 (Y | U | V, raster inside each plane's block), written
+                    // when the CU is quantised and copied to the output block if it wins; `out` stands in for the output block when the caller wants no coefficients
   i16 cand1[32 * 32 + 2 * 16 * 16];
   i16 cand2[16 * 16 + 2 * 8 * 8];
   i16 out[64 * 64 + 2 * 32 * 32];
@@ -107,7 +126,19 @@ struct PuSearch { int x, y, w; i16 mv_cand[2][2]; MCand merge[5]; int num_merge;
 struct UMap { CuInfo unit[5]; double cost[5], bits[5]; int8_t keys[5]; int size; };
 struct Nbr { CuInfo a[2], b[3], c3, h; bool va[2], vb[3], vc3, vh; };  // merge_candidates_t
 
-struct PView { u8 *p; int s; };  // a plane of a block in LDS: sample (x, y) at p[y * s + x]
+struct PView { lu8 *p; int s; };  // a plane of a block in LDS: sample (x, y) at p[y * s + x]
+
+// Per-picture constants and the small tables, copied into LDS once per workgroup (the kernel is persistent): a table look-up on the decision path is an LDS read, not a
+// round trip to L2 / HBM.
+struct InterConst {
+  InterModel m;
+  int8_t dct32[32 * 32];       // kvz_g_dct_32 (dct-generic.c:83-120) as signed bytes; the N-point matrix is its rows 0, 32 / N, 2 * 32 / N .. and first N columns
+  int8_t dst4[16];             // dct-generic.c:38-44
+  u8 ctx_next[2][128];         // the CABAC state machine (kvz_tables.hpp)
+  int8_t luma_filter[4][8];    // filter.c:66-72
+  int8_t chroma_filter[8][4];  // filter.c:74-84
+  u8 avail_top[16][16], avail_left[16][16];  // intra.c:47-82 as regenerated by kvz_tables.hpp
+};
 
 struct InterLds {
   // ---- the work tree ----
@@ -120,7 +151,7 @@ struct InterLds {
   alignas(8) u8 win[40 * IC_WS + 16];  // reference window (motion compensation, fractional search): rows staged from a dword-aligned column, sample (r, c) at
                                        // win[r * IC_WS + win_xo + c]; 16 bytes of slack behind the last row for the horizontal pass's whole-dword reads
   int win_xo;
-  i16 g[40 * 33];                  // 14-bit horizontal intermediates, stride 33
+  alignas(8) i16 g[40 * 33];       // 14-bit horizontal intermediates, stride 33
   union {                          // the sample buffers of stages that never overlap in time
     struct {
       alignas(8) u8 pred[4][32 * 32];  // the candidate planes of a fractional step
@@ -131,100 +162,111 @@ struct InterLds {
   };
   u32 acc[16];
   u32 tsum[8];                     // satd_tiles: the eight tiles of a round
-  u32 cost[4];
   u32 mcost[36];                   // SATD of every intra mode of the CU under evaluation
   u8 top[65], left[65], ftop[65], fleft[65];
-  float fbits[128];
   // Scalar work memory.  Every lane runs the same control flow on the same values, and with one wavefront per CTU the lanes are in lockstep: small arrays that are
-  // indexed at run time live here once instead of 64 times in private (scratch) memory, whose round trips were most of the decision code's time
+  // indexed at run time live here once instead of 64 times in private (scratch) memory
   UMap amvp[3], merge;
   PuSearch pu;
   Nbr nb;
   double costs[36];
   int8_t modes[36];
   int8_t todo[36];
+  unsigned long long intra_done;  // the modes L->mcost holds for the CU under evaluation
   int mvc_key[4];      // the PU and list L->mvc holds the AMVP predictors of ({x, y, w, list}; w = 0: none) -- the search asks for the same pair up to three times
   i16 mvc[2][2];
   int level_holds;     // after search_pu_inter: bit 0 / 1 = the level's luma / chroma samples are the prediction of the best merge candidate (merge.keys[0])
   int px[8], py[8];
   u32 sad[8];
+  u32 ssd[2];          // ssd_cu's result: luma, U + V
   ICtx ctx;  // state->search_cabac's contexts (indexed at run time on every priced bin)
   ICtx pre[4], post[4];  // search_cu's copies of them, per depth (search.c:655, 956)
   ICtx row;              // the row coder's contexts at the start of the CTU (the finished CTU's syntax runs on them)
   CuInfo cur_cu[4];      // the CU under evaluation at each depth of the recursion
   struct { int mvx, mvy; double cost, bits; } best;  // check_mv_cost's best so far
+  struct { int mv[2]; double cost, bits; } frac;     // me_fractional's result
+  double inter_cost, inter_bitcost, intra_cost;      // results of search_cu_inter / search_cu_intra
+  double ccost[3];  // kvz_fast_coeff_cost of the transform units the CU under evaluation was last quantised into (one per plane: its transform tree is one unit); unused when coeff_cabac
+  InterConst k;
 };
 static_assert(KVZ_ICTU_THREADS == 64, "the scalar work memory in LDS relies on one wavefront per CTU");
 
+// the program's state: picture geometry and pointers (the kernel arguments), the CTU at hand
+struct InterState {
+  InterFrames F;
+  const Tables *tb;   // the large tables that stay in HBM: the coefficient scans (the residual coder's walk, picture QP >= 28 only)
+  InterSlab *S;
+  int frame, cx, cy;
+  int acc_slot;
+};
+
+IC_WGVAR InterLds g_il;
+IC_WGVAR InterState g_ic;
 
 #define IC_MAX_COST 1.7e+308
 #define IC_MAX_INT 2147483647.0
 
-struct InterCtu {
-  InterFrames F;
-  const InterModel *M;
-  const Tables *tb;
-  InterLds *L;
-  InterSlab *S;
-  int frame, cx, cy;
-  int acc_slot;
-#define cab (L->ctx)  /* the search contexts */
+// Names the program text uses (they end with this file): L-> the LDS block, M-> the picture's model, K-> the tables, F. the frames, S-> the HBM scratch
+#define L (&g_il)
+#define M (&g_il.k.m)
+#define K (&g_il.k)
+#define F (g_ic.F)
+#define S (g_ic.S)
+#define cab (g_il.ctx)  /* the search contexts */
+#define frame (g_ic.frame)
+#define cx (g_ic.cx)
+#define cy (g_ic.cy)
 
+struct InterCtu {
   // ---- small things ----
   // Level lv's samples of plane c of the CU whose luma origin inside the LCU is (xl, yl) -- the CU under evaluation at depth lv (levels 1, 2: its candidate buffer;
   // level 3: in place in the decided picture; level 4: the 8x8 side buffer) or, for level 3, any finished block
-  KVZ_DEV PView lvl(int lv, int c, int xl, int yl) const
+  IC_DEV PView lvl(int lv, int c, int xl, int yl)
   {
     const int sh = c ? 1 : 0;
-    if (lv == 1) return PView{ L->C1 + (c == 0 ? 0 : (c == 1 ? 1024 : 1280)), 32 >> sh };
-    if (lv == 2) return PView{ L->C2 + (c == 0 ? 0 : (c == 1 ? 256 : 320)), 16 >> sh };
-    if (lv == 4) return PView{ L->Z3 + (c == 0 ? 0 : (c == 1 ? 64 : 80)), 8 >> sh };
-    return PView{ L->D + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)) + (yl >> sh) * (64 >> sh) + (xl >> sh), 64 >> sh };
+    if (lv == 1) return PView{ (lu8 *)L->C1 + (c == 0 ? 0 : (c == 1 ? 1024 : 1280)), 32 >> sh };
+    if (lv == 2) return PView{ (lu8 *)L->C2 + (c == 0 ? 0 : (c == 1 ? 256 : 320)), 16 >> sh };
+    if (lv == 4) return PView{ (lu8 *)L->Z3 + (c == 0 ? 0 : (c == 1 ? 64 : 80)), 8 >> sh };
+    return PView{ (lu8 *)L->D + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)) + (yl >> sh) * (64 >> sh) + (xl >> sh), 64 >> sh };
   }
   // where cu_zero_coeff_cost parks the prediction of the depth-lv CU (search.c:222: the next level): the CU's own region of the decided picture, which its children
   // will overwrite and nothing reads before them; the side buffer for a depth-3 CU, whose candidate IS that region
-  KVZ_DEV PView parked(int lv, int c, int xl, int yl) const { return lvl(lv == 3 ? 4 : 3, c, xl, yl); }
+  IC_DEV PView parked(int lv, int c, int xl, int yl) { return lvl(lv == 3 ? 4 : 3, c, xl, yl); }
   // the source samples at LCU position (xl, yl) [luma coordinates] of plane c: inside the quadrant staged by load_org_quadrant
-  KVZ_DEV PView orgv(int c, int xl, int yl) const
+  IC_DEV PView orgv(int c, int xl, int yl)
   {
     const int sh = c ? 1 : 0;
-    return PView{ L->orgq + (c == 0 ? 0 : (c == 1 ? 1024 : 1280)) + ((yl & 31) >> sh) * (32 >> sh) + ((xl & 31) >> sh), 32 >> sh };
+    return PView{ (lu8 *)L->orgq + (c == 0 ? 0 : (c == 1 ? 1024 : 1280)) + ((yl & 31) >> sh) * (32 >> sh) + ((xl & 31) >> sh), 32 >> sh };
   }
-  // the quantised levels of the depth-lv CU at (xl, yl): candidates of depth 1 and 2 in the workgroup's scratch, a depth-3 CU's straight in the output block
-  KVZ_DEV i16 *out_coef() const { return F.coeff ? F.coeff + ((long)frame * F.wc * F.hc + (cy >> 6) * F.wc + (cx >> 6)) * 6144 : S->out; }
-  KVZ_DEV i16 *coef(int lv, int c, int xl, int yl) const
-  {
-    const int sh = c ? 1 : 0;
-    if (lv == 1) return S->cand1 + (c == 0 ? 0 : (c == 1 ? 1024 : 1280));
-    if (lv == 2) return S->cand2 + (c == 0 ? 0 : (c == 1 ? 256 : 320));
-    return out_coef() + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)) + zorder(xl >> sh, yl >> sh);
-  }
-  KVZ_DEV const u8 *refp(int c) const { return F.ref + frame * F.frame_px + (c == 0 ? 0 : (c == 1 ? (long)F.W * F.H : (long)F.W * F.H * 5 / 4)); }
-  KVZ_DEV const u8 *srcp(int c) const { return F.src + frame * F.frame_px + (c == 0 ? 0 : (c == 1 ? (long)F.W * F.H : (long)F.W * F.H * 5 / 4)); }
-  KVZ_DEV CuInfo *dcell(int xl, int yl) const { return &L->Dcu[(yl >> 3) * 8 + (xl >> 3)]; }
-  KVZ_DEV static unsigned zorder(int x, int y)
+  IC_DEV unsigned zorder(int x, int y)
   {
     unsigned r = 0;
     for (int b = 0; b < 4; b++) r |= (((unsigned)(x >> (2 + b)) & 1u) << (2 * b)) | (((unsigned)(y >> (2 + b)) & 1u) << (2 * b + 1));
     return r * 16;
   }
-  KVZ_DEV static bool cbf_is_set(unsigned cbf, int depth, int plane)
+  // the quantised levels of the depth-lv CU at (xl, yl): candidates of depth 1 and 2 in the workgroup's scratch, a depth-3 CU's straight in the output block
+  IC_DEV gi16 *out_coef() { return F.coeff ? (gi16 *)F.coeff + ((long)frame * F.wc * F.hc + (cy >> 6) * F.wc + (cx >> 6)) * 6144 : (gi16 *)S->out; }
+  IC_DEV gi16 *coef(int lv, int c, int xl, int yl)
   {
-    const unsigned masks[5] = { 0x1f, 0x0f, 0x07, 0x03, 0x1 };
-    return (cbf & (masks[depth] << (5 * plane))) != 0;
+    const int sh = c ? 1 : 0;
+    if (lv == 1) return (gi16 *)S->cand1 + (c == 0 ? 0 : (c == 1 ? 1024 : 1280));
+    if (lv == 2) return (gi16 *)S->cand2 + (c == 0 ? 0 : (c == 1 ? 256 : 320));
+    return out_coef() + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)) + zorder(xl >> sh, yl >> sh);
   }
-  KVZ_DEV static bool cbf_any(unsigned cbf, int depth) { return cbf_is_set(cbf, depth, 0) || cbf_is_set(cbf, depth, 1) || cbf_is_set(cbf, depth, 2); }
-  KVZ_DEV static void cbf_set(uint16_t *cbf, int depth, int plane) { *cbf = (uint16_t)(*cbf | ((0x10 >> depth) << (5 * plane))); }
-  KVZ_DEV static void cbf_clear(uint16_t *cbf, int depth, int plane)
-  {
-    const unsigned masks[5] = { 0x1f, 0x0f, 0x07, 0x03, 0x1 };
-    *cbf = (uint16_t)(*cbf & ~(masks[depth] << (5 * plane)));
-  }
+  IC_DEV long plane_off(int c) { return c == 0 ? 0 : (c == 1 ? (long)F.W * F.H : (long)F.W * F.H * 5 / 4); }
+  IC_DEV const gu8 *refp(int c) { return (const gu8 *)F.ref + frame * F.frame_px + plane_off(c); }
+  IC_DEV const gu8 *srcp(int c) { return (const gu8 *)F.src + frame * F.frame_px + plane_off(c); }
+  IC_DEV gu8 *recp(int c) { return (gu8 *)F.rec + frame * F.frame_px + plane_off(c); }
+  IC_DEV CuInfo *dcell(int xl, int yl) { return &L->Dcu[(yl >> 3) * 8 + (xl >> 3)]; }
+  IC_DEV bool cbf_is_set(unsigned cbf, int depth, int plane) { return (cbf & ((0x1fu >> depth) << (5 * plane))) != 0; }
+  IC_DEV bool cbf_any(unsigned cbf, int depth) { return cbf_is_set(cbf, depth, 0) || cbf_is_set(cbf, depth, 1) || cbf_is_set(cbf, depth, 2); }
+  IC_DEV uint16_t cbf_set(unsigned cbf, int depth, int plane) { return (uint16_t)(cbf | ((0x10u >> depth) << (5 * plane))); }
+  IC_DEV uint16_t cbf_clear(unsigned cbf, int depth, int plane) { return (uint16_t)(cbf & ~((0x1fu >> depth) << (5 * plane))); }
 
   // Sum over the lanes of a value accumulated inside a phase.  The idiom is
   //   u32 part = 0;  IC_FOR(tid) { ... part += ...; }  const u32 total = lanes_sum(part);
   // on the host the phase is a loop over tid around ONE `part`, which therefore already holds the total; on the device every lane has its own.
-  KVZ_DEV u32 lanes_sum(u32 part)
+  IC_DEV u32 lanes_sum(u32 part)
   {
 #ifdef KVZ_HOSTSIM
     return part;
@@ -234,86 +276,129 @@ struct InterCtu {
     x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
     x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
     x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
-    const u32 wave = (u32)(__builtin_amdgcn_readlane(x, 15) + __builtin_amdgcn_readlane(x, 31) + __builtin_amdgcn_readlane(x, 47) + __builtin_amdgcn_readlane(x, 63));
-    if (KVZ_ICTU_THREADS == 64) return wave;
-    u32 *a = acc_begin();
-    if ((threadIdx.x & 63) == 0) atomicAdd(a, wave);
-    __syncthreads();
-    return *a;
+    return (u32)(__builtin_amdgcn_readlane(x, 15) + __builtin_amdgcn_readlane(x, 31) + __builtin_amdgcn_readlane(x, 47) + __builtin_amdgcn_readlane(x, 63));
 #endif
-  }
-  // a zeroed LDS word for sums that lanes add into directly (a slot is only reused sixteen reductions later)
-  KVZ_DEV u32 *acc_begin()
-  {
-    acc_slot = (acc_slot + 1) & 15;
-    u32 *a = &L->acc[acc_slot];
-    IC_FOR(tid) { if (tid == 0) *a = 0; }
-    IC_SYNC();
-    return a;
   }
 
   // byte-string helpers of the horizontal interpolation pass (v_alignbyte_b32, v_dot4_i32_i8; plain C++ for the host simulation)
 #ifdef KVZ_HOSTSIM
-  KVZ_DEV static u32 alignbyte(u32 hi, u32 lo, u32 n) { return (u32)(((((unsigned long long)hi) << 32) | lo) >> (8 * (n & 3))); }
-  KVZ_DEV static int dot4(u32 a, u32 b, int c)
+  IC_DEV u32 alignbyte(u32 hi, u32 lo, u32 n) { return (u32)(((((unsigned long long)hi) << 32) | lo) >> (8 * (n & 3))); }
+  IC_DEV int dot4(u32 a, u32 b, int c)
   {
     for (int k = 0; k < 4; k++) c += (int)(int8_t)(a >> (8 * k)) * (int)(int8_t)(b >> (8 * k));
     return c;
   }
 #else
-  KVZ_DEV static u32 alignbyte(u32 hi, u32 lo, u32 n) { return __builtin_amdgcn_alignbyte(hi, lo, n); }
-  KVZ_DEV static int dot4(u32 a, u32 b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
+  IC_DEV u32 alignbyte(u32 hi, u32 lo, u32 n) { return __builtin_amdgcn_alignbyte(hi, lo, n); }
+  IC_DEV int dot4(u32 a, u32 b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
 #endif
 
+  // a CU record of a picture in HBM (22 bytes, 2-byte aligned), as eleven global 16-bit loads
+  IC_DEV CuInfo load_cu(const CuInfo *p)
+  {
+    union { CuInfo c; uint16_t h[11]; } u;
+    static_assert(sizeof(CuInfo) == 22, "CU records are copied as eleven half-words");
+    for (int i = 0; i < 11; i++) u.h[i] = ((const KVZ_GLB uint16_t *)p)[i];
+    return u.c;
+  }
+  IC_DEV void store_cu(CuInfo *p, const CuInfo &c)
+  {
+    union { CuInfo c; uint16_t h[11]; } u;
+    u.c = c;
+    for (int i = 0; i < 11; i++) ((KVZ_GLB uint16_t *)p)[i] = u.h[i];
+  }
   // the CU info of luma position (fx, fy), which lies outside the CU under evaluation (a neighbour: every caller asks for one): inside this CTU the decided picture's
   // record -- a finished CU looks the same from every level --, else the frame's (finished CTUs)
-  KVZ_DEV CuInfo cell_at(int, int fx, int fy) const
+  IC_DEV CuInfo cell_at(int fx, int fy)
   {
     if (fx >= cx && fx < cx + 64 && fy >= cy && fy < cy + 64) return *dcell(fx - cx, fy - cy);
-    return F.cu[frame * F.cells + (long)(fy >> 2) * (F.W >> 2) + (fx >> 2)];
+    return load_cu((const CuInfo *)F.cu + frame * F.cells + (long)(fy >> 2) * (F.W >> 2) + (fx >> 2));
   }
 
   // CABAC_FBITS_UPDATE on the search contexts (cabac.h:133-139)
-  KVZ_DEV double price(int idx, int bin, bool update)
+  IC_DEV double price(int idx, int bin, bool update)
   {
     const u8 st = cab.s[idx];
-    const double bits = L->fbits[st ^ bin];
-    if (update) cab.s[idx] = tb->ctx_next[bin != (st & 1)][st];
+    const double bits = M->fbits[st ^ bin];
+    if (update) cab.s[idx] = K->ctx_next[bin != (st & 1)][st];
     return bits;
   }
 
-  // A context set copied by the lanes, a word each: the syntax contexts always, the residual coder's only when they can have moved
-  KVZ_DEV void ctx_copy(ICtx *dst, const ICtx *src)
+  // A context set copied by the lanes, a word each: the syntax contexts always, the residual coder's only when they can have moved.  (Inlined: the address spaces of
+  // the two sets are the call site's.)
+  template <class PD, class PS> IC_DEV void ctx_copy_words(PD dst, PS src)
   {
     const int words = M->coeff_cabac ? IX_COUNT / 4 : IX_SYNTAX / 4;
-    IC_FOR(tid) { for (int i = tid; i < words; i += KVZ_ICTU_THREADS) ((u32 *)dst->s)[i] = ((const u32 *)src->s)[i]; }
+    IC_FOR(tid) { for (int i = tid; i < words; i += KVZ_ICTU_THREADS) dst[i] = src[i]; }
     IC_SYNC();
   }
+#define IC_CTX_L(set) ((KVZ_LDS u32 *)(set).s)
+#define IC_CTX_G(ptr) ((KVZ_GLB u32 *)(ptr)->s)
   // get_coeff_cabac_cost (rdo.c:220-263): kvz_encode_coeff_nxn in counting mode on the search contexts -- every context-coded bin at CABAC_FBITS_UPDATE's price
   // (cabac.h:133-139; the state moves only while the search has updates on), every bypass bin one bit.  The prices are multiples of 2^-15 below 2^20, so their
   // sum in a double does not depend on the order the reference adds them in.
   struct PriceSink {
-    InterLds *L; const Tables *tb; bool update; double bits;
+    bool update; double bits;
     KVZ_DEV void ctx(int c, int v)
     {
       const int idx = IX_RES + c - KVZ_HIP_CX_SIG_CG;
-      const u8 st = L->ctx.s[idx];
-      bits += L->fbits[st ^ (v ? 1 : 0)];
-      if (update) L->ctx.s[idx] = tb->ctx_next[(v ? 1 : 0) != (st & 1)][st];
+      const u8 st = cab.s[idx];
+      bits += M->fbits[st ^ (v ? 1 : 0)];
+      if (update) cab.s[idx] = K->ctx_next[(v ? 1 : 0) != (st & 1)][st];
     }
     KVZ_DEV void ep(u32, int n) { bits += n; }
   };
-  IC_FN double coeff_bits_cabac(const i16 *coeff, int width, int type, int scan_mode, bool update)
+  IC_FN double coeff_bits_cabac(const gi16 *coeff, int log2w, int type, int scan_mode, bool update)
   {
-    PriceSink s{ L, tb, update, 0.0 };
-    entropy_coeff_nxn(s, tb, coeff, ilog2i(width), type, scan_mode);
+    PriceSink s{ update, 0.0 };
+    entropy_coeff_nxn(s, g_ic.tb, (const i16 *)coeff, log2w, type, scan_mode);
     return s.bits;
   }
 
 #include "kvz_inter_ctu_cand.inc"
 #include "kvz_inter_ctu_pix.inc"
 #include "kvz_inter_ctu_search.inc"
-#undef cab
+
+  // the workgroup's constants, once per launch: the picture's model and the small tables into LDS
+  IC_FN void load_constants(const InterModel *model, const Tables *tb)
+  {
+    IC_FOR(tid) {
+      for (int i = tid; i < (int)(sizeof(InterModel) / 4); i += KVZ_ICTU_THREADS) ((KVZ_LDS u32 *)&L->k.m)[i] = ((const KVZ_GLB u32 *)model)[i];
+      for (int i = tid; i < 1024; i += KVZ_ICTU_THREADS) L->k.dct32[i] = (int8_t)((const KVZ_GLB i16 *)tb->dct[3])[i];
+      for (int i = tid; i < 16; i += KVZ_ICTU_THREADS) L->k.dst4[i] = (int8_t)((const KVZ_GLB i16 *)tb->dst4)[i];
+      for (int i = tid; i < 256; i += KVZ_ICTU_THREADS) {
+        (&L->k.ctx_next[0][0])[i] = ((const KVZ_GLB u8 *)&tb->ctx_next[0][0])[i];
+        (&L->k.avail_top[0][0])[i] = ((const KVZ_GLB u8 *)&tb->avail_top[0][0])[i];
+        (&L->k.avail_left[0][0])[i] = ((const KVZ_GLB u8 *)&tb->avail_left[0][0])[i];
+      }
+      for (int i = tid; i < 32; i += KVZ_ICTU_THREADS) {
+        (&L->k.luma_filter[0][0])[i] = ((const KVZ_GLB int8_t *)&tb->luma_filter[0][0])[i];
+        (&L->k.chroma_filter[0][0])[i] = ((const KVZ_GLB int8_t *)&tb->chroma_filter[0][0])[i];
+      }
+    }
+    IC_SYNC();
+  }
+  IC_DEV void begin_launch(const InterFrames &frames, const InterModel *model, const Tables *tb, InterSlab *slab)
+  {
+    IC_FOR(tid) { if (tid == 0) { F = frames; g_ic.tb = tb; S = slab; g_ic.acc_slot = 0; } }
+    IC_SYNC();
+    load_constants(model, tb);
+  }
+  IC_DEV void begin_ctu(int frame_, int cx_, int cy_)
+  {
+    IC_FOR(tid) { if (tid == 0) { frame = frame_; cx = cx_; cy = cy_; } }
+    IC_SYNC();
+  }
 };
+
+#undef L
+#undef M
+#undef K
+#undef F
+#undef S
+#undef cab
+#undef frame
+#undef cx
+#undef cy
 
 }  // namespace kvz

@@ -24,10 +24,9 @@ __global__ void __launch_bounds__(KVZ_ICTU_THREADS) __attribute__((amdgpu_waves_
 ;
 #else
 {
-  __shared__ InterLds lds;
-  __shared__ InterCtu prog;  // the program's own members (picture geometry, pointers, position): in LDS, not behind a private `this`
   __shared__ int s_ticket;
   const int ctus = F.wc * F.hc;
+  InterCtu::begin_launch(F, model, tb, F.slabs + blockIdx.x);  // the program's state and constants: workgroup-scope variables in LDS (kvz_inter_ctu.hpp)
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0) s_ticket = (int)atomicAdd(sched.ticket, 1u);
@@ -60,10 +59,8 @@ __global__ void __launch_bounds__(KVZ_ICTU_THREADS) __attribute__((amdgpu_waves_
     }
     __syncthreads();
     if (s_ticket != 0) {
-      InterCtu &p = prog;
-      p.F = F; p.M = model; p.tb = tb; p.L = &lds; p.S = F.slabs + blockIdx.x; p.frame = frame; p.cx = x * 64; p.cy = y * 64;
-      __syncthreads();
-      p.run();
+      InterCtu::begin_ctu(frame, x * 64, y * 64);
+      InterCtu::run();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();

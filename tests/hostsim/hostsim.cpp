@@ -164,16 +164,15 @@ extern "C" void kvz_hostsim_inter_frame(int width, int height, int qp, int poc, 
   F.src = src; F.ref = ref; F.ref_cu = ref_cu; F.rec = rec; F.cu = cu; F.coeff = nullptr;
   F.ctx_out = (kvz::ICtx *)calloc((size_t)F.wc * F.hc, sizeof(kvz::ICtx));
   kvz::InterSlab *slab = (kvz::InterSlab *)calloc(1, sizeof(kvz::InterSlab));
-  kvz::InterLds *lds = (kvz::InterLds *)calloc(1, sizeof(kvz::InterLds));
   F.slabs = slab;
   memset(cu, 0, (size_t)F.cells * sizeof(kvz_hip_cu_info));
+  kvz::InterCtu::begin_launch(F, &m, &tb, slab);
   for (int cy = 0; cy < F.hc; cy++)
     for (int cx = 0; cx < F.wc; cx++) {
-      kvz::InterCtu p;
-      p.F = F; p.M = &m; p.tb = &tb; p.L = lds; p.S = slab; p.frame = 0; p.cx = cx * 64; p.cy = cy * 64;
-      p.run();
+      kvz::InterCtu::begin_ctu(0, cx * 64, cy * 64);
+      kvz::InterCtu::run();
     }
-  free(F.ctx_out); free(slab); free(lds);
+  free(F.ctx_out); free(slab);
 }
 
 // ---- the entropy coder's three stages (kvz_entropy.hpp) run on the host: every lane a loop iteration ----
