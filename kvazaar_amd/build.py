@@ -1,6 +1,6 @@
 """Builds libkvz_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
-The library is eight translation units compiled in parallel: kvz_hip.hip (C ABI, per-call ops, streaming kernels, host side of the batch; with
+The library is nine translation units compiled in parallel: kvz_hip.hip (C ABI, per-call ops, streaming kernels, host side of the batch; with
 -DKVZ_CTU_SEPARATE_TUS it only declares the CTU kernels) and kvz_ctu_tu.hip six times, one CTU kernel instantiation each (-DKVZ_CTU_KERNEL_TU=0..5,
 csrc/kvz_ctu_kernels.hpp).  Objects are rebuilt when one of the files they include (hipcc -MD) is newer."""
 import os
@@ -17,7 +17,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 # (object name, source, extra defines)
 UNITS = ([("kvz_hip", "kvz_hip.hip", ["-DKVZ_CTU_SEPARATE_TUS"])] + [(f"kvz_ctu_tu{k}", "kvz_ctu_tu.hip", [f"-DKVZ_CTU_KERNEL_TU={k}"]) for k in range(6)]
-         + [("kvz_inter_tu", "kvz_inter_tu.hip", [])])  # the inter CTU pass (csrc/kvz_inter_kernels.hpp)
+         + [("kvz_inter_tu0", "kvz_inter_tu.hip", ["-DKVZ_ICTU_CABAC=0"]), ("kvz_inter_tu1", "kvz_inter_tu.hip", ["-DKVZ_ICTU_CABAC=1"])])  # the inter CTU pass's two builds (csrc/kvz_inter_kernels.hpp)
 
 
 def _deps(dfile):

@@ -1271,7 +1271,12 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
   KVZ_HIP_CHECK(hipGetDevice(&dev_id));
   KVZ_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev_id));
   const char *env = getenv("KVZ_HIP_INTER_WG_PER_CU");
-  const int lds_fit = (int)(160 * 1024 / (sizeof(kvz::InterLds) + sizeof(kvz::InterCtu) + 64));
+  // the kernel's build: with the residual coder's contexts in the LDS context sets only where the picture's coefficients are priced with them (kvz_inter_ctu.hpp)
+  const bool cabac_build = !(p->qp < p->fast_residual_cost && p->qp < 50);
+  const void *kernel = cabac_build ? (const void *)kvz::inter_ctu_ticket_kernel_cabac : (const void *)kvz::inter_ctu_ticket_kernel_fast;
+  hipFuncAttributes fa;
+  KVZ_HIP_CHECK(hipFuncGetAttributes(&fa, kernel));
+  const int lds_fit = fa.sharedSizeBytes > 0 ? (int)(160 * 1024 / fa.sharedSizeBytes) : 8;
   const int per_cu = env ? atoi(env) : (lds_fit < 8 ? lds_fit : 8);  // one wavefront per workgroup at up to 256 registers: two wavefronts per SIMD = eight workgroups per CU, LDS permitting
   int n_wg = n_cu * (per_cu > 0 ? per_cu : 8);
   if ((long)n_wg > total) n_wg = (int)total;
@@ -1319,7 +1324,8 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
   kvz::InterSched sched;
   sched.items = sc.items; sched.ticket = sc.ticket; sched.done = sc.done; sched.error = sc.ticket + 1; sched.total = (unsigned)total; sched.no_wpp = p->no_wpp;
   sched.wait_ticks = 3000000000ull;  // 30 s of the 100 MHz clock
-  hipLaunchKernelGGL(kvz::inter_ctu_ticket_kernel, dim3((unsigned)n_wg), dim3(KVZ_ICTU_THREADS), 0, st, F, sc.model, kvz::device_tables(), sched);
+  if (cabac_build) hipLaunchKernelGGL(kvz::inter_ctu_ticket_kernel_cabac, dim3((unsigned)n_wg), dim3(KVZ_ICTU_THREADS), 0, st, F, sc.model, kvz::device_tables(), sched);
+  else hipLaunchKernelGGL(kvz::inter_ctu_ticket_kernel_fast, dim3((unsigned)n_wg), dim3(KVZ_ICTU_THREADS), 0, st, F, sc.model, kvz::device_tables(), sched);
   KVZ_HIP_CHECK(hipGetLastError());
   unsigned flags[2] = { 0, 0 };
   KVZ_HIP_CHECK(hipMemcpyAsync(flags, sc.ticket, sizeof flags, hipMemcpyDeviceToHost, st));

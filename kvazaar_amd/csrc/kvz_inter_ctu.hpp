@@ -87,6 +87,12 @@ enum { IX_SPLIT = 0 /* 3 */, IX_SKIP = 3 /* 3 */, IX_MERGE_FLAG = 6, IX_MERGE_ID
        IX_RES = 32 /* 136 */, IX_COUNT = IX_RES + (KVZ_HIP_CX_ABS_CHROMA + 2 - KVZ_HIP_CX_SIG_CG) };
 struct alignas(8) ICtx { u8 s[IX_COUNT]; };
 static_assert(IX_COUNT == 168 && sizeof(ICtx) == 168, "context sets are copied as 32-bit words");
+// The kernel comes in two builds (kvz_inter_tu.hip, -DKVZ_ICTU_CABAC=0 / 1; the host picks by the picture's coeff_cabac): the context sets in LDS -- the search's, two
+// copies per depth, the row coder's -- carry the residual coder's 136 states only where coefficients are priced with them; without, 32 bytes each and 1.3 KB of LDS less
+#ifndef KVZ_ICTU_CABAC
+#define KVZ_ICTU_CABAC 1
+#endif
+struct alignas(8) ICtxL { u8 s[KVZ_ICTU_CABAC ? IX_COUNT : IX_SYNTAX]; };
 
 struct InterModel {  // per picture
   double lambda, lambda_sqrt;
@@ -97,7 +103,6 @@ struct InterModel {  // per picture
   QuantScalars qf[2][4], qi[2][4];  // forward / inverse scalars, [luma, chroma][log2 size - 2]
   float fbits[128];                 // kvz_f_entropy_bits
 };
-static_assert(sizeof(InterModel) % 4 == 0, "the model is copied into LDS as 32-bit words");
 
 struct InterSlab {  // HBM scratch of one resident workgroup: the quantised levels of the candidates of depth 1 and 2 (Y | U | V, raster inside each plane's block), written
                     // when the CU is quantised and copied to the output block if it wins; `out` stands in for the output block when the caller wants no coefficients
@@ -120,7 +125,8 @@ struct InterFrames {
   unsigned long long *prof;  // [IP_COUNT] or NULL (KVZ_ICTU_PROFILE)
 };
 
-#define IC_WS 44  /* window stride: 3 bytes of alignment + up to 40 samples, rounded to dwords */
+#define IC_WS 28  /* window stride: 3 bytes of alignment + up to 24 samples (a 16x16 tile + 8), rounded to dwords */
+#define IC_GS 17  /* stride of the horizontal intermediates: up to 16 + 1 columns */
 struct MCand { i16 mv[2][2]; u8 ref[2], dir; };                         // inter_merge_cand_t
 struct PuSearch { int x, y, w; i16 mv_cand[2][2]; MCand merge[5]; int num_merge; };
 struct UMap { CuInfo unit[5]; double cost[5], bits[5]; int8_t keys[5]; int size; };
@@ -130,8 +136,13 @@ struct PView { lu8 *p; int s; };  // a plane of a block in LDS: sample (x, y) at
 
 // Per-picture constants and the small tables, copied into LDS once per workgroup (the kernel is persistent): a table look-up on the decision path is an LDS read, not a
 // round trip to L2 / HBM.
+struct QScal { int flat_q, add, q_bits, dq_scale, dq_shift; };  // kvz_quant / kvz_dequant with flat lists (quant-generic.c:57-81, 335-339)
 struct InterConst {
-  InterModel m;
+  double lambda, lambda_sqrt;
+  uint64_t coeff_weights;
+  int qp, poc, mv_constraint, sao, deblock, fme_level, pu_depth_inter_max, no_wpp, coeff_cabac;
+  QScal q[2][4];               // [luma, chroma][log2 size - 2]
+  float fbits[128];            // kvz_f_entropy_bits
   int8_t dct32[32 * 32];       // kvz_g_dct_32 (dct-generic.c:83-120) as signed bytes; the N-point matrix is its rows 0, 32 / N, 2 * 32 / N .. and first N columns
   int8_t dst4[16];             // dct-generic.c:38-44
   u8 ctx_next[2][128];         // the CABAC state machine (kvz_tables.hpp)
@@ -140,6 +151,7 @@ struct InterConst {
   u8 avail_top[16][16], avail_left[16][16];  // intra.c:47-82 as regenerated by kvz_tables.hpp
 };
 
+// A 32x32 block is interpolated, compared and transformed in 16x16 TILES (its four quadrants; smaller blocks are one tile): the sample buffers below are sized for a tile.
 struct InterLds {
   // ---- the work tree ----
   alignas(8) u8 D[64 * 64 + 2 * 32 * 32];    // the decided picture: Y 64x64 | U 32x32 | V 32x32 (level 3's view; an 8x8 CU is evaluated in place)
@@ -148,25 +160,24 @@ struct InterLds {
   alignas(8) u8 C2[16 * 16 + 2 * 8 * 8];     // the depth-2 CU under evaluation
   alignas(8) u8 Z3[8 * 8 + 2 * 4 * 4];       // cu_zero_coeff_cost's copy of a depth-3 CU's prediction (search.c:222 puts it into level 4)
   CuInfo Dcu[64];                            // CU records of the decided picture, one per 8x8 (the smallest CU)
-  alignas(8) u8 win[40 * IC_WS + 16];  // reference window (motion compensation, fractional search): rows staged from a dword-aligned column, sample (r, c) at
+  alignas(8) u8 win[24 * IC_WS + 16];  // reference window of a tile (motion compensation, fractional search): rows staged from a dword-aligned column, sample (r, c) at
                                        // win[r * IC_WS + win_xo + c]; 16 bytes of slack behind the last row for the horizontal pass's whole-dword reads
   int win_xo;
-  alignas(8) i16 g[40 * 33];       // 14-bit horizontal intermediates, stride 33
+  alignas(8) i16 g[8 * 72];        // 14-bit horizontal intermediates of a tile (24 rows, stride IC_GS); the SATD's eight slots of 72
   union {                          // the sample buffers of stages that never overlap in time
     struct {
-      alignas(8) u8 pred[4][32 * 32];  // the candidate planes of a fractional step
-      i16 im[2][32 * 32];              // 14-bit predictions of the two lists
+      alignas(8) u8 pred[4][16 * 16];  // the candidate planes of a fractional step (tile)
+      i16 im[2][16 * 16];              // 14-bit predictions of the two lists (tile)
     };
-    struct { i16 resid[32 * 32], coefa[32 * 32], tmpb[32 * 32]; };  // the transform path
-    u8 planes[35 * 256];               // the 35 intra predictions of a 16x16 CU (intra_all_mode_costs)
+    alignas(8) i16 tb[32 * 32];        // the transform path: one block, every pass in place
+    alignas(8) u8 planes[8 * 256];     // intra predictions being scored: eight 16x16 blocks or thirty-two 8x8
   };
-  u32 acc[16];
   u32 tsum[8];                     // satd_tiles: the eight tiles of a round
   u32 mcost[36];                   // SATD of every intra mode of the CU under evaluation
   u8 top[65], left[65], ftop[65], fleft[65];
   // Scalar work memory.  Every lane runs the same control flow on the same values, and with one wavefront per CTU the lanes are in lockstep: small arrays that are
   // indexed at run time live here once instead of 64 times in private (scratch) memory
-  UMap amvp[3], merge;
+  UMap amvp[2], merge;
   PuSearch pu;
   Nbr nb;
   double costs[36];
@@ -179,9 +190,9 @@ struct InterLds {
   int px[8], py[8];
   u32 sad[8];
   u32 ssd[2];          // ssd_cu's result: luma, U + V
-  ICtx ctx;  // state->search_cabac's contexts (indexed at run time on every priced bin)
-  ICtx pre[4], post[4];  // search_cu's copies of them, per depth (search.c:655, 956)
-  ICtx row;              // the row coder's contexts at the start of the CTU (the finished CTU's syntax runs on them)
+  ICtxL ctx;  // state->search_cabac's contexts (indexed at run time on every priced bin)
+  ICtxL pre[4], post[4];  // search_cu's copies of them, per depth (search.c:655, 956)
+  ICtxL row;              // the row coder's contexts at the start of the CTU (the finished CTU's syntax runs on them)
   CuInfo cur_cu[4];      // the CU under evaluation at each depth of the recursion
   struct { int mvx, mvy; double cost, bits; } best;  // check_mv_cost's best so far
   struct { int mv[2]; double cost, bits; } frac;     // me_fractional's result
@@ -194,6 +205,7 @@ static_assert(KVZ_ICTU_THREADS == 64, "the scalar work memory in LDS relies on o
 // the program's state: picture geometry and pointers (the kernel arguments), the CTU at hand
 struct InterState {
   InterFrames F;
+  const InterModel *model;  // in HBM: the slice's initial context states are read from it where a coder starts (two copies per CTU row)
   const Tables *tb;   // the large tables that stay in HBM: the coefficient scans (the residual coder's walk, picture QP >= 28 only)
   InterSlab *S;
   int frame, cx, cy;
@@ -208,7 +220,7 @@ IC_WGVAR InterState g_ic;
 
 // Names the program text uses (they end with this file): L-> the LDS block, M-> the picture's model, K-> the tables, F. the frames, S-> the HBM scratch
 #define L (&g_il)
-#define M (&g_il.k.m)
+#define M (&g_il.k)
 #define K (&g_il.k)
 #define F (g_ic.F)
 #define S (g_ic.S)
@@ -350,6 +362,7 @@ struct InterCtu {
   };
   IC_FN double coeff_bits_cabac(const gi16 *coeff, int log2w, int type, int scan_mode, bool update)
   {
+    if (!KVZ_ICTU_CABAC) return 0.0;  // (this build's context sets do not hold the residual coder's states; the host never sends it a picture priced with them)
     PriceSink s{ update, 0.0 };
     entropy_coeff_nxn(s, g_ic.tb, (const i16 *)coeff, log2w, type, scan_mode);
     return s.bits;
@@ -363,24 +376,33 @@ struct InterCtu {
   IC_FN void load_constants(const InterModel *model, const Tables *tb)
   {
     IC_FOR(tid) {
-      for (int i = tid; i < (int)(sizeof(InterModel) / 4); i += KVZ_ICTU_THREADS) ((KVZ_LDS u32 *)&L->k.m)[i] = ((const KVZ_GLB u32 *)model)[i];
-      for (int i = tid; i < 1024; i += KVZ_ICTU_THREADS) L->k.dct32[i] = (int8_t)((const KVZ_GLB i16 *)tb->dct[3])[i];
-      for (int i = tid; i < 16; i += KVZ_ICTU_THREADS) L->k.dst4[i] = (int8_t)((const KVZ_GLB i16 *)tb->dst4)[i];
+      if (tid == 0) {
+        K->lambda = model->lambda; K->lambda_sqrt = model->lambda_sqrt; K->coeff_weights = model->coeff_weights;
+        K->qp = model->qp; K->poc = model->poc; K->mv_constraint = model->mv_constraint; K->sao = model->sao; K->deblock = model->deblock; K->fme_level = model->fme_level;
+        K->pu_depth_inter_max = model->pu_depth_inter_max; K->no_wpp = model->no_wpp; K->coeff_cabac = model->coeff_cabac;
+      }
+      if (tid < 8) {
+        const QuantScalars f = model->qf[tid >> 2][tid & 3], iv = model->qi[tid >> 2][tid & 3];
+        K->q[tid >> 2][tid & 3] = QScal{ f.flat_q, f.add, f.q_bits, iv.dq_scale, iv.dq_shift };
+      }
+      for (int i = tid; i < 128; i += KVZ_ICTU_THREADS) K->fbits[i] = ((const KVZ_GLB float *)model->fbits)[i];
+      for (int i = tid; i < 1024; i += KVZ_ICTU_THREADS) K->dct32[i] = (int8_t)((const KVZ_GLB i16 *)tb->dct[3])[i];
+      for (int i = tid; i < 16; i += KVZ_ICTU_THREADS) K->dst4[i] = (int8_t)((const KVZ_GLB i16 *)tb->dst4)[i];
       for (int i = tid; i < 256; i += KVZ_ICTU_THREADS) {
-        (&L->k.ctx_next[0][0])[i] = ((const KVZ_GLB u8 *)&tb->ctx_next[0][0])[i];
-        (&L->k.avail_top[0][0])[i] = ((const KVZ_GLB u8 *)&tb->avail_top[0][0])[i];
-        (&L->k.avail_left[0][0])[i] = ((const KVZ_GLB u8 *)&tb->avail_left[0][0])[i];
+        (&K->ctx_next[0][0])[i] = ((const KVZ_GLB u8 *)&tb->ctx_next[0][0])[i];
+        (&K->avail_top[0][0])[i] = ((const KVZ_GLB u8 *)&tb->avail_top[0][0])[i];
+        (&K->avail_left[0][0])[i] = ((const KVZ_GLB u8 *)&tb->avail_left[0][0])[i];
       }
       for (int i = tid; i < 32; i += KVZ_ICTU_THREADS) {
-        (&L->k.luma_filter[0][0])[i] = ((const KVZ_GLB int8_t *)&tb->luma_filter[0][0])[i];
-        (&L->k.chroma_filter[0][0])[i] = ((const KVZ_GLB int8_t *)&tb->chroma_filter[0][0])[i];
+        (&K->luma_filter[0][0])[i] = ((const KVZ_GLB int8_t *)&tb->luma_filter[0][0])[i];
+        (&K->chroma_filter[0][0])[i] = ((const KVZ_GLB int8_t *)&tb->chroma_filter[0][0])[i];
       }
     }
     IC_SYNC();
   }
   IC_DEV void begin_launch(const InterFrames &frames, const InterModel *model, const Tables *tb, InterSlab *slab)
   {
-    IC_FOR(tid) { if (tid == 0) { F = frames; g_ic.tb = tb; S = slab; g_ic.acc_slot = 0; } }
+    IC_FOR(tid) { if (tid == 0) { F = frames; g_ic.model = model; g_ic.tb = tb; S = slab; g_ic.acc_slot = 0; } }
     IC_SYNC();
     load_constants(model, tb);
   }

@@ -19,10 +19,18 @@ struct InterSched {
   unsigned long long wait_ticks;
 };
 
-__global__ void __launch_bounds__(KVZ_ICTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_ICTU_WAVES_PER_EU, KVZ_ICTU_WAVES_PER_EU))) inter_ctu_ticket_kernel(const InterFrames F, const InterModel *model, const Tables *tb, const InterSched sched)
+// two builds of the kernel (kvz_inter_ctu.hpp KVZ_ICTU_CABAC): `_fast` for pictures whose coefficients are priced by kvz_fast_coeff_cost (small context sets: 20 KB of LDS,
+// eight workgroups per CU), `_cabac` for those priced with the residual coder's contexts
+#define KVZ_ICTU_KERNEL(name) __global__ void __launch_bounds__(KVZ_ICTU_THREADS) __attribute__((amdgpu_waves_per_eu(KVZ_ICTU_WAVES_PER_EU, KVZ_ICTU_WAVES_PER_EU))) name(const InterFrames F, const InterModel *model, const Tables *tb, const InterSched sched)
 #ifndef KVZ_INTER_KERNEL_BODY
-;
+KVZ_ICTU_KERNEL(inter_ctu_ticket_kernel_fast);
+KVZ_ICTU_KERNEL(inter_ctu_ticket_kernel_cabac);
 #else
+#if KVZ_ICTU_CABAC
+KVZ_ICTU_KERNEL(inter_ctu_ticket_kernel_cabac)
+#else
+KVZ_ICTU_KERNEL(inter_ctu_ticket_kernel_fast)
+#endif
 {
   __shared__ int s_ticket;
   const int ctus = F.wc * F.hc;
