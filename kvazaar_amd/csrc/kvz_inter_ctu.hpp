@@ -42,7 +42,12 @@ namespace kvz {
 #endif
 #ifdef KVZ_HOSTSIM
 #define IC_FOR(tid) for (int tid = 0; tid < KVZ_ICTU_THREADS; ++tid)
+#ifdef KVZ_ICTU_COUNT_PHASES  // developer build of the host simulation: barriers per stage (tools/inter_phase_count.py)
+static long g_ic_phases[32]; static int g_ic_cat = 31;
+#define IC_SYNC() (++g_ic_phases[g_ic_cat])
+#else
 #define IC_SYNC()
+#endif
 #define IC_LDS_ADD(p, v) (*(p) += (v))
 #define KVZ_LDS
 #define KVZ_GLB
@@ -69,6 +74,8 @@ namespace kvz {
 // stage profile (developer builds, -DKVZ_ICTU_PROFILE): ticks of the 100 MHz clock per category, lane 0 of every workgroup adds into F.prof[]
 #if defined(KVZ_ICTU_PROFILE) && !defined(KVZ_HOSTSIM)
 #define IC_PROF(cat, stmt) do { const unsigned long long t0_ = __builtin_amdgcn_s_memrealtime(); stmt; if (threadIdx.x == 0 && F.prof) atomicAdd(&F.prof[cat], __builtin_amdgcn_s_memrealtime() - t0_); } while (0)
+#elif defined(KVZ_ICTU_COUNT_PHASES)
+#define IC_PROF(cat, stmt) do { const int c0_ = g_ic_cat; g_ic_cat = (cat); stmt; g_ic_cat = c0_; } while (0)
 #else
 #define IC_PROF(cat, stmt) do { stmt; } while (0)
 #endif
@@ -127,6 +134,8 @@ struct InterFrames {
 
 #define IC_WS 28  /* window stride: 3 bytes of alignment + up to 24 samples (a 16x16 tile + 8), rounded to dwords */
 #define IC_GS 17  /* stride of the horizontal intermediates: up to 16 + 1 columns */
+#define IC_MREF_STRIDE 36  /* q in [-16, 17] for a 16x16 CU (an odd number of dwords: the modes fall into different banks) */
+#define IC_MREF_ORG 16
 struct MCand { i16 mv[2][2]; u8 ref[2], dir; };                         // inter_merge_cand_t
 struct PuSearch { int x, y, w; i16 mv_cand[2][2]; MCand merge[5]; int num_merge; };
 struct UMap { CuInfo unit[5]; double cost[5], bits[5]; int8_t keys[5]; int size; };
@@ -171,6 +180,11 @@ struct InterLds {
     };
     alignas(8) i16 tb[32 * 32];        // the transform path: one block, every pass in place
     alignas(8) u8 planes[8 * 256];     // intra predictions being scored: eight 16x16 blocks or thirty-two 8x8
+    struct {                           // intra_all_mode_costs: all 35 modes of a CU scored at once
+      alignas(8) u8 flat[3][256];      // the predictions of planar, DC and mode 34 (scored through satd_tiles)
+      alignas(8) u8 org_t[256];        // the CU's source block transposed (horizontal modes are predicted and scored on the transposed problem)
+      alignas(4) u8 mref[15][IC_MREF_STRIDE];  // the extended main reference of the modes with a negative displacement, 11 .. 25: [mode - 11][IC_MREF_ORG + q] = ref_main[q], q in [-w, w + 1]
+    };
   };
   u32 tsum[8];                     // satd_tiles: the eight tiles of a round
   u32 mcost[36];                   // SATD of every intra mode of the CU under evaluation
@@ -189,6 +203,7 @@ struct InterLds {
   int level_holds;     // after search_pu_inter: bit 0 / 1 = the level's luma / chroma samples are the prediction of the best merge candidate (merge.keys[0])
   int px[8], py[8];
   u32 sad[8];
+  int pbits[8];        // per probe: MVD bits against the cheaper predictor, -1 where the vector is not allowed
   u32 ssd[2];          // ssd_cu's result: luma, U + V
   ICtxL ctx;  // state->search_cabac's contexts (indexed at run time on every priced bin)
   ICtxL pre[4], post[4];  // search_cu's copies of them, per depth (search.c:655, 956)

@@ -174,6 +174,9 @@ extern "C" void kvz_hostsim_inter_frame(int width, int height, int qp, int poc, 
     }
   free(F.ctx_out); free(slab);
 }
+#ifdef KVZ_ICTU_COUNT_PHASES
+extern "C" void kvz_hostsim_inter_phases(long *out) { for (int i = 0; i < 32; i++) { out[i] = kvz::g_ic_phases[i]; kvz::g_ic_phases[i] = 0; } }
+#endif
 
 // ---- the entropy coder's three stages (kvz_entropy.hpp) run on the host: every lane a loop iteration ----
 #include "../../kvazaar_amd/csrc/kvz_entropy.hpp"
