@@ -143,6 +143,75 @@ def limiter(args, launches):
     return out
 
 
+INTER_BYTES_PER_CTU = 42824  # the all-intra 24 576 + the reference window of one list, (64 + 2 * 32 + 7)^2 = 18 225 luma samples, + 23 B rounding: "~42.8 KB"
+
+
+def pmc_leg(leg):
+    """The committed counters of an auxiliary leg's kernels (profiles/<round>_pmc_leg_<leg>.json, written by tools/pmc_leg.sh from rocprofv3 --pmc passes of
+    `bench.py --only <leg>`; newest round wins): per UNIT of the leg (CTU or picture), so that they scale to the launch measured here."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_leg_{leg}.json")))
+    if not paths:
+        return None
+    try:
+        return paths[-1], json.load(open(paths[-1]))
+    except (OSError, ValueError):
+        return None
+
+
+def leg_roofline(leg, kernel, bytes_per_unit, units, kernel_s, unit="CTU"):
+    """`roofline` of an auxiliary leg: achieved = algorithmic bytes of the launch / the kernel's time (HIP events on its stream), against the HBM peak; traffic and the SQ
+    issue / wait shares from the committed counters of the same kernel (per unit x this launch's units)."""
+    achieved = bytes_per_unit * units / kernel_s / 1e9
+    out = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+           "algorithmic_bytes_per_launch": bytes_per_unit * units, f"algorithmic_bytes_per_{unit}": bytes_per_unit, "avg_launch_us": kernel_s * 1e6, "launches_per_step": 1}
+    got = pmc_leg(leg)
+    if got is not None:
+        path, d = got
+        pu = d.get("per_unit", {})
+        if "FETCH_SIZE" in pu and "WRITE_SIZE" in pu:
+            out["traffic"] = (pu["FETCH_SIZE"] + pu["WRITE_SIZE"]) * 1024.0 * units
+            out["traffic_over_algorithmic"] = out["traffic"] / out["algorithmic_bytes_per_launch"]
+            out["traffic_source"] = os.path.relpath(path, ROOT) + f": rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KB, raw) of `bench.py --only {leg}`, per {unit} x this launch's {unit}s"
+        if "SQ_WAVE_CYCLES" in pu:
+            wc = pu["SQ_WAVE_CYCLES"]
+            lim = {"kind": "wave time: issuing / waiting / stalled", "source": os.path.relpath(path, ROOT),
+                   "wave_issue_frac": pu.get("SQ_ACTIVE_INST_ANY", 0) / wc, "wave_wait_frac": pu.get("SQ_WAIT_ANY", 0) / wc, "wave_issue_stall_frac": pu.get("SQ_WAIT_INST_ANY", 0) / wc,
+                   f"insts_valu_per_{unit}": pu.get("SQ_INSTS_VALU"), f"insts_salu_per_{unit}": pu.get("SQ_INSTS_SALU"), f"insts_lds_per_{unit}": pu.get("SQ_INSTS_LDS"),
+                   f"insts_vmem_rd_per_{unit}": pu.get("SQ_INSTS_VMEM_RD"), f"insts_vmem_wr_per_{unit}": pu.get("SQ_INSTS_VMEM_WR"),
+                   "note": d.get("note", "shares of SQ_WAVE_CYCLES a resident wavefront spends issuing (SQ_ACTIVE_INST_ANY), parked on s_waitcnt / a barrier (SQ_WAIT_ANY), stalled at issue (SQ_WAIT_INST_ANY)")}
+            out["limiter"] = lim
+    return out
+
+
+def cpu_reference(w, h, pictures, cli, n_each, note=""):
+    """kvazaar's own encoder (oracle/_ref/kvazaar_ref, AVX2 strategies, whole encoder) on this box's schedulable CPUs for an auxiliary leg, bounded: one single-thread encoder,
+    then as many concurrent single-thread encoders as CPUs are granted (`independent`: what the host's cores can do at best, no thread queue or output order between them)."""
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "kvazaar_ref")
+    if not os.path.exists(ref_bin):
+        return None
+    import tempfile
+    cpus = host_cpu_facts()["schedulable_cpus"]
+    ctus = ((w + 63) // 64) * ((h + 63) // 64)
+    with tempfile.NamedTemporaryFile(suffix=".yuv", dir="/tmp") as tmp:
+        for i in range(max(n_each, len(pictures))):
+            tmp.write(pictures[i % len(pictures)].tobytes())
+        tmp.flush()
+        base = [ref_bin, "-i", tmp.name, "--input-res", f"{w}x{h}"] + cli + ["-n", str(n_each), "--threads", "0", "--owf", "0", "-o", "/dev/null"]
+
+        def timed(n_proc):
+            t0 = time.time()
+            ps = [subprocess.Popen(base, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for _ in range(n_proc)]
+            ok = all(p.wait() == 0 for p in ps)
+            return time.time() - t0, ok
+        s1, ok1 = timed(1)
+        sn, okn = timed(cpus)
+    return {"unit": "CTUs/s", "kind": "reference", "cpus": cpus, "cli": " ".join(cli),
+            "one_thread": {"value": n_each * ctus / s1 if ok1 else None, "sample": f"{n_each} pictures, --threads 0 --owf 0 ({s1:.1f} s)"},
+            "independent_one_thread_encoders": {"value": cpus * n_each * ctus / sn if okn else None, "sample": f"{cpus} concurrent encoders x {n_each} pictures, --threads 0 --owf 0 ({sn:.1f} s)"},
+            "value": (cpus * n_each * ctus / sn if okn else None), "note": note}
+
+
 def run_encoder(ref_bin, yuv, w, h, qp, extra, n_frames, preset="ultrafast"):
     """one reference encoder process -> (seconds, ok)"""
     cmd = [ref_bin, "-i", yuv, "--input-res", f"{w}x{h}"] + PRESET_CLI[preset] + ["-p", "1", "-q", str(qp), "-n", str(n_frames), "-o", "/dev/null"] + extra
@@ -357,6 +426,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-encoder", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the auxiliary legs (chain, chain_d2h, configs_extra); they only run at --gpus 1")
+    ap.add_argument("--only", default="", choices=["", "inter", "medium", "intra4k", "entropy"], help="developer / profiling: run ONE auxiliary leg at a reduced size and print its "
+                    "entry (tools/pmc_leg.sh collects the leg's counters this way); the headline is not measured")
     ap.add_argument("--wpp", action="store_true", help="with --tiles: keep WPP on (kvazaar --tiles CxR --wpp); by default tiles imply --no-wpp as in kvazaar (cfg.c:925-978): "
                                                        "one coder per tile in raster order, i.e. one serial CTU chain per tile")
     ap.add_argument("--no-wpp", action="store_true", help="kvazaar --no-wpp: one serial CTU chain per picture (contexts run from the end of a row into the next)")
@@ -396,6 +467,9 @@ def main():
         m.search_32x32, m.rdoq, m.search_nxn = s32, rdoq, nxn
         return m
 
+    if args.only:
+        only_leg(args, lib, model_for, HipBatch)
+        return
     model = model_for(args.qp, args.tiles)
     # HBM the batch needs on this rank: source + reconstruction (1.5 B / pixel each) + two coefficient blocks (3 B / pixel each) + borders and CU maps
     per_picture = args.width * args.height * 9.3
@@ -505,6 +579,33 @@ def main():
         sys.exit(1)
 
 
+def only_leg(args, lib, model_for, HipBatch):
+    """one auxiliary leg at a reduced size (the kernels' counters per CTU / picture do not depend on the batch)"""
+    if args.only == "inter":
+        out = inter_leg(args, lib, model_for, HipBatch, synth_frames(3840, 2160, 4, clip_seed(3840, 2160)), sequences=96)
+        out.pop("chain", None)
+    elif args.only == "medium":
+        out = leg_medium(args, lib, model_for, HipBatch, n_med=48)
+    elif args.only == "intra4k":
+        out = leg_intra4k(args, lib, model_for, HipBatch, n4k=192, steps=1)
+    else:
+        n = 384
+        frames = synth_frames(args.width, args.height, args.distinct, clip_seed(args.width, args.height))
+        b0 = HipBatch(lib, args.width, args.height, n)
+        for i in range(n):
+            b0.upload(i, frames[i % len(frames)])
+        model = model_for(args.qp)
+        b0.launch(model)
+        b0.sync()
+        b0.entropy_code(model)
+        t0 = time.perf_counter()
+        data, sizes = b0.entropy_code(model)
+        ent_s = time.perf_counter() - t0
+        out = {"workload": f"entropy coder of {n} {args.width}x{args.height} pictures", "value": n / ent_s, "unit": "pictures/s", "ms": ent_s * 1e3, "units_per_launch": n}
+        b0.close()
+    print(json.dumps(out))
+
+
 def inter_leg(args, lib, model_for, HipBatch, pictures, sequences=192):
     """BASELINE config 4 (3840x2160 `--preset veryfast --gop lp-g4d3t1 -q 22`) on the device, as far as the inter CTU pass goes: the I picture through the batched
     intra pass + deblocking + SAO (picture QP 21: intra_qp_offset -1), then the first B picture (picture QP 25: GOP layer 3) of `sequences` independent sequences in
@@ -546,6 +647,8 @@ def inter_leg(args, lib, model_for, HipBatch, pictures, sequences=192):
     t = time.perf_counter()
     ip.run(prm)
     s = time.perf_counter() - t
+    lib.kvz_hip_dev_inter_kernel_ms.restype = C.c_float
+    kernel_s = float(lib.kvz_hip_dev_inter_kernel_ms()) / 1e3
     _, cu_first = ip.download(0)
     _, cu_last = ip.download(sequences - 1)
     cu_ok = inter.cu_digest(cu_first) == gold["cu"][1]
@@ -590,7 +693,7 @@ def inter_leg(args, lib, model_for, HipBatch, pictures, sequences=192):
     # as the box grants CPUs.  Whole encoder (I picture, entropy coding, loop filters included): a reported baseline, bounded to a few seconds each
     cpu = None
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "kvazaar_ref")
-    if os.path.exists(ref_bin) and not args.no_ref_encoder and not args.no_cpu_baseline:
+    if os.path.exists(ref_bin) and not args.no_ref_encoder and not args.no_cpu_baseline and not getattr(args, "only", ""):
         import tempfile
         with tempfile.NamedTemporaryFile(suffix=".yuv") as tmp:
             nfr = 8
@@ -620,12 +723,13 @@ def inter_leg(args, lib, model_for, HipBatch, pictures, sequences=192):
     return {"cpu_reference": cpu, "workload": f"{w}x{h} --preset veryfast --gop lp-g4d3t1 -q {args.qp} (BASELINE config 4): CTU pass of the first B picture (QP {args.qp + 3}; merge / AMVP / temporal "
                         f"candidates, hexbs + half-pel search, early skip, uni- and bi-prediction, the intra alternative, zero-coefficient RDO, CABAC-context life cycle) of "
                         f"{sequences} independent sequences in one launch, from the I picture's reconstruction (intra pass + deblocking + SAO at QP {args.qp - 1}, on the device)",
-            "value": sequences * ip.ctus / s, "unit": "CTUs/s", "fps": sequences / s, "ms": s * 1e3,
+            "value": sequences * ip.ctus / s, "unit": "CTUs/s", "fps": sequences / s, "ms": s * 1e3, "kernel_ms": kernel_s * 1e3, "units_per_launch": sequences * ip.ctus,
+            "roofline": leg_roofline("inter", "inter_ctu_ticket_kernel_fast", INTER_BYTES_PER_CTU, sequences * ip.ctus, kernel_s),
             "verified": bool(i_ok and cu_ok and np.array_equal(cu_first, cu_last)),
             "verify": {"i_picture_reconstruction_equals_reference_encoder": bool(i_ok), "b_picture_cu_decisions_equal_reference_encoder": bool(cu_ok),
                        "copies_consistent": bool(np.array_equal(cu_first, cu_last))},
             "chain": chain,
-            "note": "one wavefront per CTU, the reference's control flow in every lane (DESIGN.md 3.8); `chain` carries the sequence on through the loop filters and the next pictures"}
+            "note": "one wavefront per CTU, work tree / program state / tables in LDS, eight CTUs per CU (DESIGN.md 3.8); `chain` carries the sequence on through the loop filters and the next pictures"}
 
 
 def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedResults):
@@ -685,7 +789,10 @@ def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedRes
         result["entropy"] = {"stages": "kvz_encode_coding_tree + kvz_encode_coeff_nxn + CABAC of every picture's slice data on the device from the resident results of the CTU pass "
                                        "(bins per CTU, row-start contexts, one arithmetic coder per WPP substream), substreams and entry points downloaded",
                              "value": b0.n / ent_s, "unit": "pictures/s", "ctus_per_s": b0.ctus_per_frame * b0.n / ent_s, "ms": ent_s * 1e3,
-                             "slice_data_bytes_per_picture": len(data) / b0.n, "levels_bytes_per_picture": b0.ctus_per_frame * 12288,
+                             "slice_data_bytes_per_picture": len(data) / b0.n, "levels_bytes_per_picture": b0.ctus_per_frame * 12288, "units_per_launch": b0.n,
+                             "roofline": dict(leg_roofline("entropy", "dev_entropy_bins_kernel + dev_entropy_row_contexts_kernel + dev_entropy_code_kernel",
+                                                           b0.ctus_per_frame * 12288 + 2 * (args.width * args.height // 64) + len(data) / b0.n, b0.n, ent_s, unit="picture"),
+                                              note="achieved = (levels + CU depth / mode maps read, slice data written) per picture / the call's wall time, which includes the download of the slice data"),
                              "verified": ent_ok, "verify": "slice data and entry points of the clip's pictures equal the reference encoder's bitstream (tests/golden/entropy.json)"}
     except Exception as e:  # auxiliary: never take the headline down
         result["entropy"] = {"error": repr(e)}
@@ -733,71 +840,107 @@ def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedRes
         pinned.close()
     # ---- the north-star size ----
     if (args.width, args.height) != (3840, 2160):
-        w, h, n4k = 3840, 2160, 384
-        m4 = model_for(args.qp)
-        d4 = synth_frames(w, h, 4, clip_seed(w, h))
-        b4 = HipBatch(lib, w, h, n4k)
-        for i in range(n4k):
-            b4.upload(i, d4[i % len(d4)])
-        b4.run(m4)
-        steps = 3
-        t = time.perf_counter()
-        for _ in range(steps):
-            b4.run(m4)
-        s = time.perf_counter() - t
-        v = verify_batches([(b4, [(i % len(d4), None) for i in range(n4k)])], len(d4), lambda tile, picture=0: golden_digest(w, h, clip_seed(w, h), args.qp, 0, picture=picture))
-        result["configs_extra"] = [{"workload": f"{w}x{h} yuv420p 8-bit all-intra ultrafast CTU pass, QP {args.qp}, {n4k} frames resident, {steps} steps",
-                                    "value": steps * n4k * b4.ctus_per_frame / s, "unit": "CTUs/s", "fps": steps * n4k / s, "kernel_ms": b4.kernel_ms(),
-                                    "verified": bool(v["copies_consistent"] and v["golden_ok"] is not False), "verify": v}]
-        b4.close()
-        # ---- BASELINE config 5 at one GPU: the same 4K pictures cut into kvazaar's --tiles 4x2 (8 tiles of 15x17 CTUs, no WPP inside a tile: 3 072 serial chains) ----
-        import types
-        from kvazaar_amd import sharding
-        mt = model_for(args.qp, "4x2")
-        targs = types.SimpleNamespace(distinct=4)
-        tb, _, ctus_pf, _ = build_batches(targs, lib, 0, 1, w, h, n4k, "4x2", HipBatch)
-
-        def tile_step():
-            for b, _ in tb:
-                b.launch(mt)
-            for b, _ in tb:
-                b.sync()
-        tile_step()
-        t = time.perf_counter()
-        for _ in range(steps):
-            tile_step()
-        s = time.perf_counter() - t
-        per_tile = golden_digest(w, h, clip_seed(w, h), args.qp, 0, "4x2", False)
-        v = verify_batches(tb, 4, lambda tile, picture=0: (per_tile[tile] if per_tile and picture == 0 else None))
-        result["configs_extra"].append({"workload": f"{w}x{h} --tiles 4x2 (BASELINE config 5 on ONE GPU; tiles imply --no-wpp as in kvazaar) all-intra ultrafast CTU pass, QP {args.qp}, "
-                                                    f"{n4k} pictures = {8 * n4k} tile chains resident, {steps} steps", "value": steps * n4k * ctus_pf / s, "unit": "CTUs/s",
-                                        "fps": steps * n4k / s, "verified": bool(v["copies_consistent"] and v["golden_ok"] is not False), "verify": v})
-        for b, _ in tb:
-            b.close()
+        result["configs_extra"] = [leg_intra4k(args, lib, model_for, HipBatch), leg_tiles4k(args, lib, model_for, HipBatch)]
         # ---- BASELINE config 4: `--preset veryfast --gop lp-g4d3t1` at 3840x2160: the first B picture of many independent sequences ----
         try:
-            result["configs_extra"].append(inter_leg(args, lib, model_for, HipBatch, d4))
+            result["configs_extra"].append(inter_leg(args, lib, model_for, HipBatch, synth_frames(3840, 2160, 4, clip_seed(3840, 2160))))
         except Exception as e:  # auxiliary: never take the headline down
             result["configs_extra"].append({"workload": "3840x2160 --preset veryfast --gop lp-g4d3t1 (BASELINE config 4)", "error": repr(e)})
-        # ---- BASELINE config 3: `--preset medium` (32x32 search, RDOQ, NxN partitions) at 3840x2160 ----
-        n_med = 96
-        mm = model_for(args.qp)
-        mm.coeff_cabac, mm.search_32x32, mm.rdoq, mm.search_nxn = 1, 1, 1, 1
-        bm = HipBatch(lib, w, h, n_med)
-        for i in range(n_med):
-            bm.upload(i, d4[i % len(d4)])
-        bm.run(mm)
-        t = time.perf_counter()
-        bm.run(mm)
-        s = time.perf_counter() - t
-        vm = verify_batches([(bm, [(i % len(d4), None) for i in range(n_med)])], len(d4),
-                            lambda tile, picture=0: golden_digest(w, h, clip_seed(w, h), args.qp, 0, suffix="/medium") if picture == 0 else None)
-        result["configs_extra"].append({"workload": f"{w}x{h} yuv420p 8-bit all-intra `--preset medium` CTU pass (32x32 CUs searched, kvz_rdoq in every quantisation, 8x8 CUs also "
-                                                    f"as four 4x4 PUs), QP {args.qp}, {n_med} frames resident, 1 step", "value": n_med * bm.ctus_per_frame / s, "unit": "CTUs/s",
-                                        "fps": n_med / s, "kernel_ms": bm.kernel_ms(), "verified": bool(vm["copies_consistent"] and vm["golden_ok"] is not False), "verify": vm,
-                                        "matrix_cores": "every 16- and 32-point transform of this pass runs on v_mfma_i32_*_i8 (kvz_mfma.hpp); their share of the pass and the MFMA "
-                                                        "rate of the transform kernels alone: DESIGN.md 5, bench_kernels.py"})
-        bm.close()
+        result["configs_extra"].append(leg_medium(args, lib, model_for, HipBatch))
+
+
+def leg_intra4k(args, lib, model_for, HipBatch, n4k=384, steps=3):
+    """the headline pass at the north star's size, 3840x2160 all-intra ultrafast, verified against the reference encoder's 4K digests; with kvazaar's own encoder on the
+    host's CPUs beside it (the north star's >= 10x is quoted on this workload)"""
+    w, h = 3840, 2160
+    m4 = model_for(args.qp)
+    d4 = synth_frames(w, h, 4, clip_seed(w, h))
+    b4 = HipBatch(lib, w, h, n4k)
+    for i in range(n4k):
+        b4.upload(i, d4[i % len(d4)])
+    b4.run(m4)
+    t = time.perf_counter()
+    kms = []
+    for _ in range(steps):
+        b4.run(m4)
+        kms.append(b4.kernel_ms())
+    s = time.perf_counter() - t
+    v = verify_batches([(b4, [(i % len(d4), None) for i in range(n4k)])], len(d4), lambda tile, picture=0: golden_digest(w, h, clip_seed(w, h), args.qp, 0, picture=picture))
+    units = n4k * b4.ctus_per_frame
+    value = steps * units / s
+    out = {"workload": f"{w}x{h} yuv420p 8-bit all-intra ultrafast CTU pass, QP {args.qp}, {n4k} frames resident, {steps} steps",
+           "value": value, "unit": "CTUs/s", "fps": steps * n4k / s, "kernel_ms": float(np.mean(kms)), "units_per_launch": units,
+           "roofline": leg_roofline("intra4k", "intra_ctu_ticket_kernel", BYTES_PER_CTU, units, float(np.mean(kms)) / 1e3),
+           "verified": bool(v["copies_consistent"] and v["golden_ok"] is not False), "verify": v}
+    b4.close()
+    if not args.no_cpu_baseline and not args.no_ref_encoder and not getattr(args, "only", ""):
+        out["cpu_reference"] = cpu_reference(w, h, d4, ["--preset", "ultrafast", "-p", "1", "-q", str(args.qp)], 4)
+        if out["cpu_reference"] and out["cpu_reference"].get("value"):
+            out["vs_cpu_reference"] = value / out["cpu_reference"]["value"]
+    return out
+
+
+def leg_tiles4k(args, lib, model_for, HipBatch, n4k=384, steps=3):
+    """BASELINE config 5 at one GPU: the 4K pictures cut into kvazaar's --tiles 4x2 (8 tiles of 15x17 CTUs, no WPP inside a tile: 3 072 serial chains)"""
+    import types
+    w, h = 3840, 2160
+    mt = model_for(args.qp, "4x2")
+    targs = types.SimpleNamespace(distinct=4)
+    tb, _, ctus_pf, _ = build_batches(targs, lib, 0, 1, w, h, n4k, "4x2", HipBatch)
+
+    def tile_step():
+        for b, _ in tb:
+            b.launch(mt)
+        for b, _ in tb:
+            b.sync()
+    tile_step()
+    t = time.perf_counter()
+    for _ in range(steps):
+        tile_step()
+    s = time.perf_counter() - t
+    per_tile = golden_digest(w, h, clip_seed(w, h), args.qp, 0, "4x2", False)
+    v = verify_batches(tb, 4, lambda tile, picture=0: (per_tile[tile] if per_tile and picture == 0 else None))
+    k_s = sum(b.kernel_ms() for b, _ in tb) / 1e3
+    out = {"workload": f"{w}x{h} --tiles 4x2 (BASELINE config 5 on ONE GPU; tiles imply --no-wpp as in kvazaar) all-intra ultrafast CTU pass, QP {args.qp}, "
+                       f"{n4k} pictures = {8 * n4k} tile chains resident, {steps} steps", "value": steps * n4k * ctus_pf / s, "unit": "CTUs/s",
+           "fps": steps * n4k / s, "kernel_ms": k_s * 1e3,
+           "roofline": leg_roofline("intra4k", "intra_ctu_ticket_kernel", BYTES_PER_CTU, n4k * ctus_pf, k_s),
+           "verified": bool(v["copies_consistent"] and v["golden_ok"] is not False), "verify": v}
+    for b, _ in tb:
+        b.close()
+    return out
+
+
+def leg_medium(args, lib, model_for, HipBatch, n_med=96):
+    """BASELINE config 3: `--preset medium` (32x32 search, RDOQ, NxN partitions) at 3840x2160"""
+    w, h = 3840, 2160
+    d4 = synth_frames(w, h, 4, clip_seed(w, h))
+    mm = model_for(args.qp)
+    mm.coeff_cabac, mm.search_32x32, mm.rdoq, mm.search_nxn = 1, 1, 1, 1
+    bm = HipBatch(lib, w, h, n_med)
+    for i in range(n_med):
+        bm.upload(i, d4[i % len(d4)])
+    bm.run(mm)
+    t = time.perf_counter()
+    bm.run(mm)
+    s = time.perf_counter() - t
+    vm = verify_batches([(bm, [(i % len(d4), None) for i in range(n_med)])], len(d4),
+                        lambda tile, picture=0: golden_digest(w, h, clip_seed(w, h), args.qp, 0, suffix="/medium") if picture == 0 else None)
+    units = n_med * bm.ctus_per_frame
+    value = units / s
+    out = {"workload": f"{w}x{h} yuv420p 8-bit all-intra `--preset medium` CTU pass (32x32 CUs searched, kvz_rdoq in every quantisation, 8x8 CUs also "
+                       f"as four 4x4 PUs), QP {args.qp}, {n_med} frames resident, 1 step", "value": value, "unit": "CTUs/s",
+           "fps": n_med / s, "kernel_ms": bm.kernel_ms(), "units_per_launch": units,
+           "roofline": leg_roofline("medium", "intra_ctu_ticket_kernel<true, true, true>", BYTES_PER_CTU, units, bm.kernel_ms() / 1e3),
+           "verified": bool(vm["copies_consistent"] and vm["golden_ok"] is not False), "verify": vm,
+           "matrix_cores": "every 16- and 32-point transform of this pass runs on v_mfma_i32_*_i8 (kvz_mfma.hpp); their share of the pass and the MFMA "
+                           "rate of the transform kernels alone: DESIGN.md 5, bench_kernels.py"}
+    bm.close()
+    if not args.no_cpu_baseline and not args.no_ref_encoder and not getattr(args, "only", ""):
+        out["cpu_reference"] = cpu_reference(w, h, d4, ["--preset", "medium", "-p", "1", "-q", str(args.qp)], 1, note="one picture per encoder: `medium` all-intra at 3840x2160 runs at a fraction of a picture per second and thread")
+        if out["cpu_reference"] and out["cpu_reference"].get("value"):
+            out["vs_cpu_reference"] = value / out["cpu_reference"]["value"]
+    return out
 
 
 if __name__ == "__main__":

@@ -155,6 +155,8 @@ typedef struct kvz_hip_inter_params {
 } kvz_hip_inter_params;
 int  kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz_hip_cu_info *ref_cu, uint8_t *rec, kvz_hip_cu_info *cu, int16_t *coeff, int width,
                                 int height, int n_pictures, const kvz_hip_inter_params *params);
+/* milliseconds the kernel of the calling thread's last kvz_hip_dev_inter_ctu_pass took on the device (HIP events on its stream around the launch) */
+float kvz_hip_dev_inter_kernel_ms(void);
 /* The slice data of n B pictures -- kvz_encode_coding_tree with the inter syntax (encode_coding_tree.c:745-900, kvz_encode_inter_prediction_unit :311-421, kvz_encode_mvd
  * :1062-1112), the residual coder and the arithmetic coder, as kvz_hip_batch_entropy_code does it for I pictures (kvz_hip_batch.h) -- from what the inter CTU pass left on
  * the device: cu (its CU records), ref_cu (the reference pictures' records: the temporal MV predictor), coeff (its levels; the pass must have been given a coeff buffer).

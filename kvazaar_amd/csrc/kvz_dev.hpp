@@ -966,6 +966,8 @@ __global__ void __launch_bounds__(64) dev_md5_kernel(const u8 *frames, const int
 
 struct DevTimer { hipEvent_t e0 = nullptr, e1 = nullptr; };
 static DevTimer &dev_timer() { static thread_local DevTimer t; return t; }
+static DevTimer &inter_timer() { static thread_local DevTimer t; return t; }
+static float &inter_kernel_ms() { static thread_local float ms = 0; return ms; }  // the last inter CTU pass's kernel, HIP events on its stream
 
 }  // namespace kvz
 
@@ -1324,12 +1326,17 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
   kvz::InterSched sched;
   sched.items = sc.items; sched.ticket = sc.ticket; sched.done = sc.done; sched.error = sc.ticket + 1; sched.total = (unsigned)total; sched.no_wpp = p->no_wpp;
   sched.wait_ticks = 3000000000ull;  // 30 s of the 100 MHz clock
+  kvz::DevTimer &tm = kvz::inter_timer();
+  if (!tm.e0) { KVZ_HIP_CHECK(hipEventCreate(&tm.e0)); KVZ_HIP_CHECK(hipEventCreate(&tm.e1)); }
+  KVZ_HIP_CHECK(hipEventRecord(tm.e0, st));
   if (cabac_build) hipLaunchKernelGGL(kvz::inter_ctu_ticket_kernel_cabac, dim3((unsigned)n_wg), dim3(KVZ_ICTU_THREADS), 0, st, F, sc.model, kvz::device_tables(), sched);
   else hipLaunchKernelGGL(kvz::inter_ctu_ticket_kernel_fast, dim3((unsigned)n_wg), dim3(KVZ_ICTU_THREADS), 0, st, F, sc.model, kvz::device_tables(), sched);
   KVZ_HIP_CHECK(hipGetLastError());
+  KVZ_HIP_CHECK(hipEventRecord(tm.e1, st));
   unsigned flags[2] = { 0, 0 };
   KVZ_HIP_CHECK(hipMemcpyAsync(flags, sc.ticket, sizeof flags, hipMemcpyDeviceToHost, st));
   KVZ_HIP_CHECK(hipStreamSynchronize(st));
+  KVZ_HIP_CHECK(hipEventElapsedTime(&kvz::inter_kernel_ms(), tm.e0, tm.e1));
 #ifdef KVZ_ICTU_PROFILE
   {
     unsigned long long hp[kvz::IP_COUNT];
@@ -1340,6 +1347,8 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
 #endif
   return flags[1] ? -2 : 0;
 }
+
+float kvz_hip_dev_inter_kernel_ms(void) { return kvz::inter_kernel_ms(); }
 
 int kvz_hip_dev_pu_search(const uint8_t *cur, const uint8_t *ref, int width, int height, const kvz_hip_me_pu *pus, int count, int max_pu_size,
                           const kvz_hip_me_params *params, kvz_hip_me_result *out)

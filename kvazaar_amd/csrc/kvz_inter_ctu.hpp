@@ -64,11 +64,41 @@ static long g_ic_phases[32]; static int g_ic_cat = 31;
 // Arguments are values and indices: an LDS object is named, not passed.
 #ifdef KVZ_HOSTSIM
 #define IC_FN static inline
+#define IC_FN_CALL static inline
+#define IC_FN_INTER static inline
+#define IC_FN_INTRA static inline
 #else
 #ifndef KVZ_ICTU_WAVES_PER_EU
 #define KVZ_ICTU_WAVES_PER_EU 2
 #endif
+// KVZ_ICTU_INLINE: 0 -- every IC_FN a call; 1 -- the compiler decides; 2 -- everything inlined but the recursion (IC_FN_CALL).  A call whose callee needs more than the
+// caller-saved registers spills to scratch (HBM) in its prologue: calls are round trips to memory
+#ifndef KVZ_ICTU_INLINE
+#define KVZ_ICTU_INLINE 2
+#endif
+#if KVZ_ICTU_INLINE == 2
+#define IC_FN static __device__ __forceinline__
+#elif KVZ_ICTU_INLINE == 1
+#define IC_FN static __device__ inline
+#else
 #define IC_FN static __device__ __noinline__
+#endif
+// the two halves of a CU's evaluation that every depth shares: as calls (one copy) or inlined into each depth's search_cu_b
+#ifdef KVZ_ICTU_INTER_CALL
+#define IC_FN_INTER static __device__ __noinline__
+#else
+#define IC_FN_INTER IC_FN
+#endif
+#ifdef KVZ_ICTU_INTRA_CALL
+#define IC_FN_INTRA static __device__ __noinline__
+#else
+#define IC_FN_INTRA IC_FN
+#endif
+#ifdef KVZ_ICTU_RECURSION_INLINE
+#define IC_FN_CALL static __device__ __forceinline__
+#else
+#define IC_FN_CALL static __device__ __noinline__
+#endif
 #endif
 #define IC_DEV static KVZ_DEV
 // stage profile (developer builds, -DKVZ_ICTU_PROFILE): ticks of the 100 MHz clock per category, lane 0 of every workgroup adds into F.prof[]
