@@ -152,6 +152,14 @@ typedef struct kvz_hip_inter_params {
   int32_t pu_depth_inter_max;  /* 3 `veryfast`, 2 `ultrafast` */
   int32_t no_wpp;              /* one coder runs through the picture in raster order (--no-wpp) */
   int32_t fast_residual_cost;  /* cfg.fast_residual_cost_limit: 28 `ultrafast` .. `veryfast`, 0 `faster` -- below it (and below 50) coefficients are priced by kvz_fast_coeff_cost */
+  /* Tiles (kvazaar --tiles CxR; encoderstate.c:944-979): the pictures handed to the pass are ONE TILE each -- an independent sub-picture for prediction, neighbours, contexts
+   * and CTU order -- while `ref` / `ref_cu` are whole FRAMES of ref_width x ref_height (frame_bytes = ref_width * ref_height * 3 / 2, (ref_width / 4) * (ref_height / 4)
+   * records): motion vectors may leave the tile (search_inter.c:94-187: mv-constraint none), reference samples are read at tile offset + position and replicated at the
+   * FRAME's edges (inter.c:80-81, search_inter.c:217-218), the co-located record of the search's starting point likewise (search_inter.c:1286-1287).  The temporal merge /
+   * AMVP candidates are read at the TILE-LOCAL position of the frame's array and checked against the frame's size, as the reference does (inter.c:836-905 takes x, y of
+   * the tile and encoder_control->in.width).  All zero: the picture is the frame. */
+  int32_t ref_width, ref_height, tile_x, tile_y;
+  int32_t no_tmvp;             /* !cfg.tmvp_enable: no temporal merge / AMVP candidates (inter.c:1295-1302, 1471-1476) -- kvazaar switches TMVP off whenever tiles are used (cfg.c:920-975) */
 } kvz_hip_inter_params;
 int  kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz_hip_cu_info *ref_cu, uint8_t *rec, kvz_hip_cu_info *cu, int16_t *coeff, int width,
                                 int height, int n_pictures, const kvz_hip_inter_params *params);

@@ -1265,6 +1265,12 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
   if (!p || width <= 0 || height <= 0 || (width & 7) || (height & 7) || width > 64 * 255 || height > 64 * 255 || n_pictures > 65535) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: bad geometry\n"); return -1; }
   if (p->qp < 0 || p->qp > 51) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: picture QP %d outside 0..51\n", p->qp); return -1; }
   if (p->fme_level < 0 || p->fme_level > 4 || p->pu_depth_inter_max < 1 || p->pu_depth_inter_max > 3 || p->poc < 1 || p->fast_residual_cost < 0 || p->fast_residual_cost > 51) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: unsupported parameters\n"); return -1; }
+  if (p->ref_width || p->ref_height) {  // the pictures are tiles of a ref_width x ref_height frame
+    if ((p->ref_width & 7) || (p->ref_height & 7) || p->tile_x < 0 || p->tile_y < 0 || (p->tile_x & 7) || (p->tile_y & 7) || p->tile_x + width > p->ref_width || p->tile_y + height > p->ref_height) {
+      fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: the %dx%d tile at (%d, %d) does not lie in the %dx%d reference frame\n", width, height, p->tile_x, p->tile_y, p->ref_width, p->ref_height);
+      return -1;
+    }
+  }
   hipStream_t st = be().stream;
   const int wc = (width + 63) / 64, hc = (height + 63) / 64, ctus = wc * hc;
   const long total = (long)ctus * n_pictures;
@@ -1307,7 +1313,8 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
   kvz::InterModel m;
   float fbits[128];
   for (int i = 0; i < 128; i++) fbits[i] = (float)kvz::kEntropyBits[i] / 32768.0f;
-  kvz::inter_model_init(&m, p->qp, p->poc, kvz_hip_default_coeff_weights(p->qp) /* 0 from QP 50 on, where kvz_fast_coeff_cost is never used (rdo.c:311-340) */, fbits, p->mv_constraint, p->sao, p->deblock, p->fme_level, p->pu_depth_inter_max, p->no_wpp, p->fast_residual_cost);
+  kvz::inter_model_init(&m, p->qp, p->poc, kvz_hip_default_coeff_weights(p->qp) /* 0 from QP 50 on, where kvz_fast_coeff_cost is never used (rdo.c:311-340) */, fbits, p->mv_constraint, p->sao, p->deblock, p->fme_level, p->pu_depth_inter_max, p->no_wpp, p->fast_residual_cost,
+                        width, height, p->ref_width, p->ref_height, p->tile_x, p->tile_y, p->no_tmvp);
   KVZ_HIP_CHECK(hipMemcpyAsync(sc.items, items.data(), (size_t)total * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   KVZ_HIP_CHECK(hipMemcpyAsync(sc.model, &m, sizeof m, hipMemcpyHostToDevice, st));
   KVZ_HIP_CHECK(hipMemsetAsync(sc.done, 0, (size_t)total * sizeof(unsigned), st));
@@ -1653,7 +1660,7 @@ long kvz_hip_dev_entropy_code_inter(const kvz_hip_cu_info *cu, const kvz_hip_cu_
     kvz::EntropyJob J;
     memset(&J, 0, sizeof J);
     J.W = width; J.H = height; J.wc = wc; J.hc = hc; J.n_frames = nf; J.no_wpp = params->no_wpp;
-    J.cu = cu + f0 * cells4; J.ref_cu = ref_cu + f0 * cells4; J.poc = params->poc;
+    J.cu = cu + f0 * cells4; J.ref_cu = ref_cu + f0 * cells4; J.poc = params->no_tmvp ? 0 : params->poc;  // (the coder only asks the POC whether temporal predictors exist)
     J.coeff = coeff + (size_t)f0 * ctus * KVZ_HIP_CTU_COEFFS;
     J.sao = params->sao ? ls.recs + (size_t)f0 * ctus * 3 : nullptr; J.sao_merge = params->sao ? ls.merge + (size_t)f0 * ctus : nullptr;
     memcpy(J.ctx_init, init, sizeof init);

@@ -136,6 +136,8 @@ struct InterModel {  // per picture
   uint64_t coeff_weights;
   int qp, poc, mv_constraint, sao, deblock, fme_level, pu_depth_inter_max, no_wpp;
   int coeff_cabac;  // qp >= fast-residual-cost (28 `ultrafast` .. `veryfast`, 0 `faster`: cfg.c:509-593): get_coeff_cabac_cost instead of kvz_fast_coeff_cost
+  int ref_w, ref_h, tile_x, tile_y;  // the reference FRAME's size and this picture's (tile's) origin in it (include/kvz_hip_dev.h kvz_hip_inter_params); not tiled: the picture's size, 0, 0
+  int no_tmvp;
   alignas(8) u8 ctx_init[IX_COUNT];  // an ICtx: the slice's initial states
   QuantScalars qf[2][4], qi[2][4];  // forward / inverse scalars, [luma, chroma][log2 size - 2]
   float fbits[128];                 // kvz_f_entropy_bits
@@ -180,6 +182,8 @@ struct InterConst {
   double lambda, lambda_sqrt;
   uint64_t coeff_weights;
   int qp, poc, mv_constraint, sao, deblock, fme_level, pu_depth_inter_max, no_wpp, coeff_cabac;
+  int ref_w, ref_h, tile_x, tile_y;  // the reference frame and the picture's origin in it (tiles)
+  int no_tmvp;
   QScal q[2][4];               // [luma, chroma][log2 size - 2]
   float fbits[128];            // kvz_f_entropy_bits
   int8_t dct32[32 * 32];       // kvz_g_dct_32 (dct-generic.c:83-120) as signed bytes; the N-point matrix is its rows 0, 32 / N, 2 * 32 / N .. and first N columns
@@ -311,7 +315,9 @@ struct InterCtu {
     return out_coef() + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)) + zorder(xl >> sh, yl >> sh);
   }
   IC_DEV long plane_off(int c) { return c == 0 ? 0 : (c == 1 ? (long)F.W * F.H : (long)F.W * F.H * 5 / 4); }
-  IC_DEV const gu8 *refp(int c) { return (const gu8 *)F.ref + frame * F.frame_px + plane_off(c); }
+  // plane c of the picture's reference FRAME (K->ref_w x K->ref_h; the picture lies at (K->tile_x, K->tile_y) in it)
+  IC_DEV const gu8 *refp(int c) { const long n = (long)K->ref_w * K->ref_h; return (const gu8 *)F.ref + frame * (n * 3 / 2) + (c == 0 ? 0 : (c == 1 ? n : n * 5 / 4)); }
+  IC_DEV const CuInfo *ref_cu_frame() { return F.ref_cu + frame * ((long)(K->ref_w >> 2) * (K->ref_h >> 2)); }
   IC_DEV const gu8 *srcp(int c) { return (const gu8 *)F.src + frame * F.frame_px + plane_off(c); }
   IC_DEV gu8 *recp(int c) { return (gu8 *)F.rec + frame * F.frame_px + plane_off(c); }
   IC_DEV CuInfo *dcell(int xl, int yl) { return &L->Dcu[(yl >> 3) * 8 + (xl >> 3)]; }
@@ -425,6 +431,7 @@ struct InterCtu {
         K->lambda = model->lambda; K->lambda_sqrt = model->lambda_sqrt; K->coeff_weights = model->coeff_weights;
         K->qp = model->qp; K->poc = model->poc; K->mv_constraint = model->mv_constraint; K->sao = model->sao; K->deblock = model->deblock; K->fme_level = model->fme_level;
         K->pu_depth_inter_max = model->pu_depth_inter_max; K->no_wpp = model->no_wpp; K->coeff_cabac = model->coeff_cabac;
+        K->ref_w = model->ref_w; K->ref_h = model->ref_h; K->tile_x = model->tile_x; K->tile_y = model->tile_y; K->no_tmvp = model->no_tmvp;
       }
       if (tid < 8) {
         const QuantScalars f = model->qf[tid >> 2][tid & 3], iv = model->qi[tid >> 2][tid & 3];

@@ -42,7 +42,7 @@ inline void b_slice_residual_init_values(uint8_t v[KVZ_HIP_CX_ABS_CHROMA + 2 - K
 }
 
 inline void inter_model_init(InterModel *m, int qp, int poc, uint64_t coeff_weights, const float fbits[128], int mv_constraint, int sao, int deblock, int fme_level,
-                             int pu_depth_inter_max, int no_wpp, int fast_residual_cost)
+                             int pu_depth_inter_max, int no_wpp, int fast_residual_cost, int pic_w = 0, int pic_h = 0, int ref_w = 0, int ref_h = 0, int tile_x = 0, int tile_y = 0, int no_tmvp = 0)
 {
   memset(m, 0, sizeof *m);
   m->qp = qp; m->poc = poc;
@@ -50,6 +50,8 @@ inline void inter_model_init(InterModel *m, int qp, int poc, uint64_t coeff_weig
   m->lambda_sqrt = sqrt(m->lambda);
   m->coeff_weights = coeff_weights;
   m->coeff_cabac = !(qp < fast_residual_cost && qp < 50);  // rdo.c:311-340: cfg.fast_residual_cost_limit (28 `ultrafast` .. `veryfast`, 0 `faster`), MAX_FAST_COEFF_COST_QP
+  m->ref_w = ref_w > 0 ? ref_w : pic_w; m->ref_h = ref_h > 0 ? ref_h : pic_h; m->tile_x = ref_w > 0 ? tile_x : 0; m->tile_y = ref_h > 0 ? tile_y : 0;
+  m->no_tmvp = no_tmvp;
   m->mv_constraint = mv_constraint; m->sao = sao; m->deblock = deblock; m->fme_level = fme_level; m->pu_depth_inter_max = pu_depth_inter_max; m->no_wpp = no_wpp;
   uint8_t init[IX_COUNT];
   memset(init, 154, sizeof init);

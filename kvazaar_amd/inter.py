@@ -11,7 +11,8 @@ assert CU_DTYPE.itemsize == 22
 
 
 class InterParams(C.Structure):  # kvz_hip_inter_params
-    _fields_ = [(n, C.c_int32) for n in ("qp", "poc", "mv_constraint", "sao", "deblock", "fme_level", "pu_depth_inter_max", "no_wpp", "fast_residual_cost")]
+    _fields_ = [(n, C.c_int32) for n in ("qp", "poc", "mv_constraint", "sao", "deblock", "fme_level", "pu_depth_inter_max", "no_wpp", "fast_residual_cost",
+                                                "ref_width", "ref_height", "tile_x", "tile_y", "no_tmvp")]  # the last four: tiles (include/kvz_hip_dev.h), zero = the picture is the frame
 
 
 def veryfast_params(qp, poc, mv_constraint=True):

@@ -160,6 +160,34 @@ class ReferenceExchange:
         return self.frame
 
 
+def allgather_cu_records(dist, plan, rank, world, local, width, height, dtype):
+    """The CU records of a picture whose tiles were searched on different ranks, assembled on every rank (what the next picture's motion search reads of its reference
+    picture: the co-located CU of search_inter.c:1286-1339; kvz_hip_inter_params::ref_width / tile_x).  local: {tile index: (h / 4, w / 4) array of `dtype` records} for this
+    rank's tiles.  One all_gather of fixed-size slots (a record per 4x4 unit: 1/8 of the picture's bytes) and a paste, host side."""
+    import numpy as np
+    import torch
+    tiles, per_rank = plan["tiles"], plan["slots_per_rank"]
+    item = np.dtype(dtype).itemsize
+    slot = max((t[2] // 4) * (t[3] // 4) for t in tiles) * item
+    send = torch.zeros(per_rank * slot, dtype=torch.uint8)
+    for k, ti in enumerate(tiles_of_rank(len(tiles), rank, world)):
+        b = np.ascontiguousarray(local[ti]).view(np.uint8).reshape(-1)
+        send[k * slot:k * slot + b.size] = torch.from_numpy(b.copy())
+    if world > 1:
+        recv = torch.empty(world * per_rank * slot, dtype=torch.uint8)
+        dist.all_gather_into_tensor(recv, send)
+    else:
+        recv = send
+    out = np.zeros((height // 4, width // 4), dtype)
+    raw = recv.numpy()
+    for r in range(world):
+        for k, ti in enumerate(tiles_of_rank(len(tiles), r, world)):
+            x, y, w, h = tiles[ti]
+            base = (r * per_rank + k) * slot
+            out[y // 4:(y + h) // 4, x // 4:(x + w) // 4] = raw[base:base + (w // 4) * (h // 4) * item].view(dtype).reshape(h // 4, w // 4)
+    return out
+
+
 def allgather_reference_frame(dist, plan, rank, world, local_tiles, width, height, out_frame=None, state=None, lib=None):
     """local_tiles: {tile index: 1-D uint8 torch tensor holding that tile's planar picture} for this rank's tiles (any device).
     Returns the full planar reference frame (1-D uint8 tensor on the same device) assembled from every rank's tiles.  One-shot convenience around

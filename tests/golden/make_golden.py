@@ -289,6 +289,25 @@ def update_inter():
     json.dump(out, open(os.path.join(HERE, "inter_recon.json"), "w"), indent=0, sort_keys=True)
 
 
+# the tiled inter configuration (BASELINE config 4 sharded by tile): (name, width, height, pictures, qp, tiles, clip seed, noise, pan)
+INTER_TILE_CLIPS = [("tiles2x1-pan", 256, 128, 4, 22, "2x1", 21, 1.5, (1.25, -0.5)), ("tiles2x2-fast-pan-qp27", 256, 256, 4, 27, "2x2", 23, 2.0, (-5.0, 11.0))]
+
+
+def update_inter_tiles():
+    """tests/golden/inter_tiles.json: the reference encoder with `--tiles CxR --preset veryfast --gop lp-g4d3t1` (--threads 0 for the ref_cudump.c interposer, which writes
+    frame positions): digests of every picture's final reconstruction and CU decisions.  tests/test_dist_cpu.py chains I -> B -> B -> B tile by tile on two ranks against it."""
+    import tempfile
+    import inter_common as ic
+    out = {}
+    for (name, w, h, n, qp, tiles, seed, noise, pan) in INTER_TILE_CLIPS:
+        frames = ic.clip(w, h, n, seed, noise, pan)
+        with tempfile.TemporaryDirectory() as d:
+            rec, cu = ic.reference_encode(w, h, frames, qp, d, preset="veryfast", deblock=True, sao=True, owf=0, extra=("--tiles", tiles))
+            out[name] = dict(ic.digests(rec, cu), bitstream_md5=hashlib.md5(open(os.path.join(d, "out.hevc"), "rb").read()).hexdigest())
+        print(name, out[name]["bitstream_md5"], flush=True)
+    json.dump(out, open(os.path.join(HERE, "inter_tiles.json"), "w"), indent=0, sort_keys=True)
+
+
 def update_entropy():
     """tests/golden/entropy.json: the slice data of the reference encoder's bitstreams for tests/entropy_common.py CASES.  Per picture: sha256 of the slice NAL's payload
     behind the slice header (the bytes are taken from the REFERENCE bitstream; where the header ends follows from the substream sizes, which the header's own entry
@@ -343,6 +362,8 @@ def update_entropy_inter():
 def main():
     if "--entropy-inter" in sys.argv:
         return update_entropy_inter()
+    if "--inter-tiles" in sys.argv:
+        return update_inter_tiles()
     if "--inter" in sys.argv:
         return update_inter()
     if "--entropy" in sys.argv:

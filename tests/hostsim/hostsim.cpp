@@ -150,14 +150,24 @@ extern "C" unsigned long long kvz_hostsim_syncs(void) { return g_kvz_syncs; }
 
 // ---- the inter CTU pass (kvz_inter_ctu.hpp) run on the host: one B picture, CTUs in raster order, every phase a loop over its 256 "lanes" ----
 #include "../../kvazaar_amd/csrc/kvz_inter_host.hpp"
+// the pictures handed over are ONE TILE of a ref_w x ref_h frame at (tile_x, tile_y) (ref / ref_cu: that frame; all zero: the picture is the frame)
+extern "C" void kvz_hostsim_inter_tile(int width, int height, int qp, int poc, uint64_t coeff_weights, const float *fbits, int mv_constraint, int sao, int deblock, int fme_level,
+                                       int pu_depth_inter_max, int no_wpp, int fast_residual_cost, const uint8_t *src, const uint8_t *ref, const kvz_hip_cu_info *ref_cu, uint8_t *rec,
+                                       kvz_hip_cu_info *cu, int ref_w, int ref_h, int tile_x, int tile_y, int no_tmvp);
 extern "C" void kvz_hostsim_inter_frame(int width, int height, int qp, int poc, uint64_t coeff_weights, const float *fbits, int mv_constraint, int sao, int deblock, int fme_level,
                                         int pu_depth_inter_max, int no_wpp, int fast_residual_cost, const uint8_t *src, const uint8_t *ref, const kvz_hip_cu_info *ref_cu, uint8_t *rec,
                                         kvz_hip_cu_info *cu)
 {
+  kvz_hostsim_inter_tile(width, height, qp, poc, coeff_weights, fbits, mv_constraint, sao, deblock, fme_level, pu_depth_inter_max, no_wpp, fast_residual_cost, src, ref, ref_cu, rec, cu, 0, 0, 0, 0, 0);
+}
+extern "C" void kvz_hostsim_inter_tile(int width, int height, int qp, int poc, uint64_t coeff_weights, const float *fbits, int mv_constraint, int sao, int deblock, int fme_level,
+                                       int pu_depth_inter_max, int no_wpp, int fast_residual_cost, const uint8_t *src, const uint8_t *ref, const kvz_hip_cu_info *ref_cu, uint8_t *rec,
+                                       kvz_hip_cu_info *cu, int ref_w, int ref_h, int tile_x, int tile_y, int no_tmvp)
+{
   static kvz::Tables tb;
   kvz::build_tables(&tb);
   kvz::InterModel m;
-  kvz::inter_model_init(&m, qp, poc, coeff_weights, fbits, mv_constraint, sao, deblock, fme_level, pu_depth_inter_max, no_wpp, fast_residual_cost);
+  kvz::inter_model_init(&m, qp, poc, coeff_weights, fbits, mv_constraint, sao, deblock, fme_level, pu_depth_inter_max, no_wpp, fast_residual_cost, width, height, ref_w, ref_h, tile_x, tile_y, no_tmvp);
   kvz::InterFrames F;
   memset(&F, 0, sizeof F);
   F.W = width; F.H = height; F.wc = (width + 63) / 64; F.hc = (height + 63) / 64; F.frame_px = (long)width * height * 3 / 2; F.cells = (long)(width / 4) * (height / 4);

@@ -185,6 +185,28 @@ def case_frames(case):
     return [np.concatenate([p.reshape(-1) for p in f]) for f in synth.frames(w, h, n, src[1], src[2])]
 
 
+DBK_DTYPE = np.dtype([("type", "u1"), ("depth", "u1"), ("tr_depth", "u1"), ("part_size", "u1"), ("cbf_y", "u1"), ("mv_dir", "u1"), ("mv_ref", "i1", (2,)), ("ref_id", "<i2", (2,)),
+                      ("mv", "<i2", (2, 2))], align=True)  # kvz_hip_cu_dbk (include/kvz_hip_dev.h)
+
+
+def cu_dbk_records(cu):
+    """what the deblocking filter reads of CU records (kvz_hip_dev_cu_dbk_from_info, kvz_dev.hpp dev_cu_dbk_kernel), on the host"""
+    assert DBK_DTYPE.itemsize == 20
+    flat = np.ascontiguousarray(cu).reshape(-1)
+    out = np.zeros(flat.size, DBK_DTYPE)
+    masks = np.array([0x1f, 0x0f, 0x07, 0x03, 0x1], np.uint16)
+    out["type"], out["depth"], out["tr_depth"] = flat["type"], flat["depth"], flat["tr_depth"]
+    out["cbf_y"] = (flat["cbf"] & masks[np.minimum(flat["tr_depth"], 4)]) != 0
+    inter = flat["type"] == 2
+    out["mv_dir"] = np.where(inter, flat["mv_dir"], 0)
+    for l in range(2):
+        used = inter & ((flat["mv_dir"] >> l) & 1 > 0)
+        out["mv_ref"][:, l] = np.where(used, flat["mv_ref"][:, l].astype(np.int8), 0)
+        out["mv"][:, l, 0] = np.where(inter, flat["mv"][:, l, 0], 0)
+        out["mv"][:, l, 1] = np.where(inter, flat["mv"][:, l, 1], 0)
+    return out
+
+
 def cu_bytes(cu):
     """the decisions of one picture as bytes, motion and flags only where they mean something"""
     inter = cu["type"] == 2

@@ -204,3 +204,53 @@ def test_single_process_exchange_is_identity():
     frame = np.random.default_rng(3).integers(0, 256, w * h * 3 // 2, dtype=np.uint8)
     local = {i: torch.from_numpy(sharding.crop_tile(frame, w, h, t)) for i, t in enumerate(plan["tiles"])}
     assert np.array_equal(sharding.allgather_reference_frame(None, plan, 0, 1, local, w, h).numpy(), frame)
+
+
+# ---- BASELINE config 4 sharded by tile: I -> B -> B -> B of a tiled clip on two ranks, every picture through pass -> loop filters -> exchange -> next picture ----
+def _tiled_inter_worker(rank, world, port, clip, out):
+    """each rank: the CTU pass of its tiles (the device sources in host simulation: kvz_hostsim_intra_frame for the I picture, kvz_hostsim_inter_tile -- the inter CTU pass with
+    the tile's origin in the reference FRAME -- for the B pictures), the loop filters of its tiles (the oracle's picture-level deblocking + SAO decision + SAO: loop filters do
+    not cross tiles), then ReferenceExchange.exchange(): all ranks' filtered tiles -> every rank's full reference frame (and the CU records the same way) for the next picture"""
+    import inter_common as ic
+    import tile_common as tc
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sim = tc.load_hostsim()
+    pictures, records = tc.tiled_inter_chain(clip, rank, world, dist, tc.hostsim_tile_pass(sim), sim)
+    if rank == 0:
+        out.put(ic.digests(pictures, records))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("clip", __import__("json").load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inter_tiles.json"))).keys())
+def test_two_rank_tiled_inter_chain_equals_reference_encoder(clip):
+    """kvazaar --tiles CxR --preset veryfast --gop lp-g4d3t1 on two ranks, one tile (or two) each: every picture's final reconstruction and CU decisions equal the reference
+    encoder's (tests/golden/inter_tiles.json) -- motion vectors leave the tile into the other rank's part of the reference frame, which only the exchange provides"""
+    import json
+    import golden.make_golden as mg
+    from test_hostsim import HOSTSIM_SO
+    if not os.path.exists(HOSTSIM_SO):
+        pytest.skip("tests/hostsim/libkvz_hostsim.so not built")
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inter_tiles.json")))[clip]
+    spec = [c for c in mg.INTER_TILE_CLIPS if c[0] == clip][0]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_tiled_inter_worker, args=(r, 2, port, spec, out)) for r in range(2)]
+    [p.start() for p in procs]
+    got = None
+    for _ in range(300):  # a worker that died must not leave the test waiting for its answer
+        try:
+            got = out.get(timeout=2)
+            break
+        except Exception:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                break
+    [p.join(timeout=60) for p in procs]
+    [p.kill() for p in procs if p.is_alive()]
+    assert got is not None, "a rank failed"
+    assert got["rec"] == want["rec"], "final pictures differ from the reference encoder's"
+    assert got["cu"] == want["cu"], "CU decisions differ from the reference encoder's"

@@ -17,7 +17,8 @@ import inter_common as ic
 
 
 class InterParams(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("qp", "poc", "mv_constraint", "sao", "deblock", "fme_level", "pu_depth_inter_max", "no_wpp", "fast_residual_cost")]
+    _fields_ = [(n, C.c_int32) for n in ("qp", "poc", "mv_constraint", "sao", "deblock", "fme_level", "pu_depth_inter_max", "no_wpp", "fast_residual_cost",
+                                                "ref_width", "ref_height", "tile_x", "tile_y", "no_tmvp")]  # the last four: tiles (include/kvz_hip_dev.h), zero = the picture is the frame
 
 
 FAST_COST_CASES = ["pan", "ultrafast", "vertical-pan-owf", "static-qp17", "no-loop-filters", "survey-416x240"]  # every picture QP below 28: kvz_fast_coeff_cost
@@ -211,3 +212,52 @@ def test_device_pass_rejects_what_it_does_not_cover():
     for bad in (dict(qp=52), dict(qp=-1), dict(fme_level=5), dict(fast_residual_cost=52), dict(poc=0), dict(pu_depth_inter_max=4)):
         p = InterParams(**{**{n: getattr(ok, n) for n, _ in InterParams._fields_}, **bad})
         assert lib.kvz_hip_dev_inter_ctu_pass(None, None, None, None, None, None, 64, 64, 1, C.addressof(p)) == -1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("clip", ["tiles2x1-pan", "tiles2x2-fast-pan-qp27"])
+def test_device_tile_pass_in_the_tiled_chain(clip):
+    """kvazaar --tiles CxR --preset veryfast --gop lp-g4d3t1: the DEVICE's inter CTU pass with the tile geometry of kvz_hip_inter_params (the pictures are tiles, the reference
+    a whole frame: motion vectors and the co-located starting point reach into the other tiles; no TMVP) inside the chain of tests/tile_common.py -- every tile's
+    reconstruction and CU records equal the device sources in host simulation, and the assembled pictures / CU decisions of the sequence equal the REFERENCE ENCODER's
+    (tests/golden/inter_tiles.json).  Several copies of the tile per launch, so that workgroups of different sequences interleave."""
+    import kvazaar_amd
+    from kvazaar_amd.dev import Dev
+    import golden.make_golden as mg
+    import tile_common as tc
+    lib = kvazaar_amd.load_library()
+    dev = Dev(lib)
+    sim = tc.load_hostsim()
+    host = tc.hostsim_tile_pass(sim)
+    copies = 3
+
+    def device_tile_pass(tw, th, pq, k, src, ref_frame, ref_cu, w, h, tx, ty):
+        prm = InterParams(qp=int(pq), poc=k, mv_constraint=0, sao=1, deblock=1, fme_level=2, pu_depth_inter_max=3, no_wpp=1, fast_residual_cost=28,
+                          ref_width=w, ref_height=h, tile_x=tx, tile_y=ty, no_tmvp=1)
+        rec, cu = device_pass(lib, dev, tw, th, [src] * copies, [ref_frame] * copies, [ref_cu] * copies, prm)
+        want_rec, want_cu = host(tw, th, pq, k, src, ref_frame, ref_cu, w, h, tx, ty)
+        for i in range(copies):
+            assert ic.first_difference(cu[i][None], want_cu[None]) is None, (k, tx, ty, i)
+            assert np.array_equal(rec[i], want_rec), (k, tx, ty, i)
+        return rec[0], cu[0]
+
+    spec = [c for c in mg.INTER_TILE_CLIPS if c[0] == clip][0]
+    pictures, records = tc.tiled_inter_chain(spec, 0, 1, None, device_tile_pass, sim)
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "inter_tiles.json")))[clip]
+    got = ic.digests(pictures, records)
+    assert got["rec"] == want["rec"] and got["cu"] == want["cu"]
+
+
+@pytest.mark.gpu
+def test_device_pass_refuses_a_tile_outside_its_frame():
+    import kvazaar_amd
+    from kvazaar_amd.dev import Dev
+    lib = kvazaar_amd.load_library()
+    dev = Dev(lib)
+    lib.kvz_hip_dev_inter_ctu_pass.restype = C.c_int
+    lib.kvz_hip_dev_inter_ctu_pass.argtypes = [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_void_p]
+    d = dev.empty(64 * 64 * 3)
+    for bad in (dict(ref_width=128, ref_height=64, tile_x=128, tile_y=0), dict(ref_width=128, ref_height=64, tile_x=4, tile_y=0), dict(ref_width=100, ref_height=64, tile_x=0, tile_y=0)):
+        prm = InterParams(qp=22, poc=1, mv_constraint=0, sao=1, deblock=1, fme_level=2, pu_depth_inter_max=3, no_wpp=1, fast_residual_cost=28, no_tmvp=1, **bad)
+        assert lib.kvz_hip_dev_inter_ctu_pass(d, d, d, d, d, None, 64, 64, 1, C.addressof(prm)) == -1
+    dev.free(d)
