@@ -299,7 +299,7 @@ template <class B> struct Api {
     be.upload();
     be.run(ResidualOp{ ref, pred, width, width, resid }, n);
     transform_dev(be, idx, p->bitdepth, resid, tmp, coeff, 1);
-    be.run(RdoqOp{ be.tables(), cx, lambda, p->qp, coeff, co, l2, color == 0 ? 0 : 2, scan_order, tr_depth, cost3 }, 1);  // writes every level of the block
+    be.run_wave(RdoqOp{ be.tables(), cx, lambda, p->qp, coeff, co, l2, color == 0 ? 0 : 2, scan_order, tr_depth, cost3 }, 1);  // writes every level of the block
     be.run(AnyNonzeroOp{ co, acc + 1 }, n);
     be.run(DequantOp{ qi, co, nullptr, coeff, n }, n);
     transform_dev(be, KVZ_HIP_IDCT_4 + idx, p->bitdepth, coeff, tmp, resid, 1);
@@ -406,7 +406,7 @@ template <class B> struct Api {
     be.upload();
     int log2w = 2;
     while ((1 << log2w) < width) log2w++;
-    be.run(RdoqOp{ be.tables(), cx, lambda, qp, c, d, log2w, type, scan_mode, tr_depth, tmp }, count);
+    be.run_wave(RdoqOp{ be.tables(), cx, lambda, qp, c, d, log2w, type, scan_mode, tr_depth, tmp }, count);
     be.download();
     memcpy(dest, be.host(d), (size_t)n * count * sizeof(i16));
   }

@@ -24,6 +24,9 @@ template <class Op> __global__ void __launch_bounds__(256) item_kernel(const Op 
   if (i < n) op(i);
 }
 
+// one wavefront per item: op.wave(item, lane) with wavefront-uniform arguments (RdoqOp)
+template <class Op> __global__ void __launch_bounds__(64) wave_item_kernel(const Op op) { op.wave((int)blockIdx.x, (int)threadIdx.x); }
+
 struct HipBackend : ArenaBase {
   hipStream_t stream = nullptr;
   const Tables *tb = nullptr;
@@ -52,6 +55,12 @@ struct HipBackend : ArenaBase {
   {
     if (n <= 0) return;
     hipLaunchKernelGGL(item_kernel<Op>, dim3((n + 255) / 256), dim3(256), 0, stream, op, n);
+    KVZ_HIP_CHECK(hipGetLastError());
+  }
+  template <class Op> void run_wave(const Op &op, int n)
+  {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(wave_item_kernel<Op>, dim3(n), dim3(64), 0, stream, op);
     KVZ_HIP_CHECK(hipGetLastError());
   }
 };

@@ -6,20 +6,13 @@
 // coefficient from the last significant scan position down (kvz_get_coded_level: distortion err^2 * err_scale + lambda * rate, rates from
 // the Q15 entropy table on the CALLER's context states -- state->cabac, not the search copy), then whole coefficient groups are tested
 // against zeroing, then the best last position is chosen.  All costs are doubles combined in the reference's order (-ffp-contract=off).
-// One lane per block in the batched form; the three per-position cost arrays live in caller-provided scratch (3 * w * w doubles per block).
+// ONE routine, wavefront-cooperative (rdoq_block_wave below): the CTU pass calls it from its quantisation stage, the per-call entry points (kvz_hip_rdoq,
+// kvz_hip_rdoq_blocks, kvz_hip_quantize_residual_rdoq) run it one wavefront per block (RdoqOp).  Rounds 2-3 also carried a one-lane transcription of rdo.c:661-1000 for the
+// per-call path; it is gone.
 #pragma once
 #include "kvz_ops.hpp"
 
 namespace kvz {
-
-struct RdoqCtx {
-  const u8 *ctx;        // uc_state of the contexts in KVZ_HIP_CX_* order (include/kvz_hip_types.h)
-  const u32 *bits;      // kvz_entropy_bits (rdo.c:69-80): Q15 price of coding `bin` in state s = bits[s ^ bin]
-  double lambda;
-  const i32 *ptab = nullptr;     // prices of both bins of every context at the caller's states, [2 * idx + bin] (the CTU kernel builds it once per CTU in LDS:
-                                 // the states do not move while a CTU is searched); used instead of ctx / bits when set
-  KVZ_DEV i32 price(int idx, int bin) const { return ptab ? ptab[2 * idx + bin] : (i32)bits[ctx[idx] ^ bin]; }
-};
 
 // The coefficient scans by arithmetic (HEVC scans are hierarchical: 4x4 groups in group order, sixteen positions inside a group): no table in memory on the
 // chain from one coefficient to the next.  diag8: the up-right diagonal order of an 8x8 grid (Tables::diag8), the group order of a 32x32 block.
@@ -45,65 +38,6 @@ template <class PtrU8> struct RdoqScanT {
   }
 };
 using RdoqScan = RdoqScanT<const u8 *>;
-
-// rdo.c:345-392 kvz_get_ic_rate
-KVZ_DEV i32 rdoq_ic_rate(const RdoqCtx &c, u32 abs_level, int ctx_one, int ctx_abs, int go_rice, u32 c1_idx, u32 c2_idx, int type)
-{
-  i32 rate = 1 << 15;
-  const u32 base_level = c1_idx < 8 ? (2 + (c2_idx < 1)) : 1;  // C1FLAG_NUMBER 8, C2FLAG_NUMBER 1
-  const int one0 = (type == 0 ? KVZ_HIP_CX_ONE_LUMA : KVZ_HIP_CX_ONE_CHROMA) + ctx_one, abs0 = (type == 0 ? KVZ_HIP_CX_ABS_LUMA : KVZ_HIP_CX_ABS_CHROMA) + ctx_abs;
-  if (abs_level >= base_level) {
-    i32 symbol = (i32)(abs_level - base_level), length;
-    if (symbol < (3 << go_rice)) {
-      length = symbol >> go_rice;
-      rate += (length + 1 + go_rice) * (1 << 15);
-    } else {
-      length = go_rice;
-      symbol = symbol - (3 << go_rice);
-      while (symbol >= (1 << length)) symbol -= (1 << (length++));
-      rate += (3 + length + 1 - go_rice + length) * (1 << 15);
-    }
-    if (c1_idx < 8) {
-      rate += c.price(one0, 1);
-      if (c2_idx < 1) rate += c.price(abs0, 1);
-    }
-  } else if (abs_level == 1) {
-    rate += c.price(one0, 0);
-  } else if (abs_level == 2) {
-    rate += c.price(one0, 1);
-    rate += c.price(abs0, 0);
-  }
-  return rate;
-}
-
-// rdo.c:413-459 kvz_get_coded_level
-KVZ_DEV u32 rdoq_coded_level(const RdoqCtx &c, double *coded_cost, double *coded_cost0, double *coded_cost_sig, i32 level_double, u32 max_abs_level, int ctx_sig, int ctx_one,
-                             int ctx_abs, int go_rice, u32 c1_idx, u32 c2_idx, i32 q_bits, double temp, bool last, int type)
-{
-  double cur_cost_sig = 0;
-  u32 best_abs_level = 0;
-  const int sig0 = (type ? KVZ_HIP_CX_SIG_CHROMA : KVZ_HIP_CX_SIG_LUMA) + ctx_sig;
-  if (!last && max_abs_level < 3) {
-    *coded_cost_sig = c.lambda * c.price(sig0, 0);
-    *coded_cost = *coded_cost0 + *coded_cost_sig;
-    if (max_abs_level == 0) return best_abs_level;
-  } else {
-    *coded_cost = 1.7e+308;  // MAX_DOUBLE (global.h)
-  }
-  if (!last) cur_cost_sig = c.lambda * c.price(sig0, 1);
-  const i32 min_abs_level = max_abs_level > 1 ? (i32)max_abs_level - 1 : 1;
-  for (i32 abs_level = (i32)max_abs_level; abs_level >= min_abs_level; abs_level--) {
-    const double err = (double)(level_double - (abs_level * (1 << q_bits)));
-    double cur_cost = err * err * temp + c.lambda * rdoq_ic_rate(c, (u32)abs_level, ctx_one, ctx_abs, go_rice, c1_idx, c2_idx, type);
-    cur_cost += cur_cost_sig;
-    if (cur_cost < *coded_cost) {
-      best_abs_level = (u32)abs_level;
-      *coded_cost = cur_cost;
-      *coded_cost_sig = cur_cost_sig;
-    }
-  }
-  return best_abs_level;
-}
 
 KVZ_DEV int rdoq_group_idx(int pos)  // g_group_idx (rdo.c:60): index of the last-position prefix group
 {
@@ -145,228 +79,12 @@ KVZ_DEV int rdoq_sig_ctx_inc(int pattern, int scan_idx, int pos_x, int pos_y, in
   return ((type == 0 && ((pos_x >> 2) + (pos_y >> 2)) > 0) ? 3 : 0) + offset + cnt;
 }
 
-// The block.  coef: transform coefficients (row-major w x w); dest: quantised levels (out); diag8: Tables::diag8; cost3: 3 * w * w doubles of scratch.
-// -DKVZ_RDOQ_CALL: a real function call on the device instead of a dozen inlined copies in the CTU program (A/B: 20.2 k vs 22.4 k CTUs/s -- the callee's 256+
-// registers leave one wavefront per SIMD; the instruction cache is not what limits the pass).
-#if defined(KVZ_RDOQ_CALL) && !defined(KVZ_HOSTSIM)
-#define KVZ_RDOQ_NOINLINE __attribute__((noinline))
-#else
-#define KVZ_RDOQ_NOINLINE
-#endif
-KVZ_DEV KVZ_RDOQ_NOINLINE void rdoq_block(const RdoqCtx &c, int qp, const i16 *coef, i16 *dest, int log2w, int type /* 0 luma, 2 chroma */, int scan_mode, int tr_depth, const u8 *diag8, double *cost3)
-{
-  const int width = 1 << log2w, n = width * width;
-  const int transform_shift = 15 - 8 - log2w;
-  const int qp_scaled = rdoq_scaled_qp(type, qp);
-  const i32 q_bits = 14 + qp_scaled / 6 + transform_shift;
-  const i32 q = rdoq_quant_scale(qp_scaled % 6);
-  // scalinglist.c:349-367: err_scale = 2^15 * 2^(-2 transform_shift) / q / q
-  double scale = 32768.0;
-  for (int i = 0; i < 2 * transform_shift; i++) scale = scale * 0.5;  // pow(2.0, -2.0 * transform_shift): exact either way
-  for (int i = 0; i > 2 * transform_shift; i--) scale = scale * 2.0;
-  const double temp = scale / (double)q / (double)q;
-  double *cost_coeff = cost3, *cost_sig = cost3 + n, *cost_coeff0 = cost3 + 2 * n;
-  const int num_blk_side = width >> 2, cg_num = n >> 4;
-  double cost_coeffgroup_sig[64];
-  const RdoqScan sc{ log2w, scan_mode, diag8 };
-  unsigned long long sig_groups = 0;  // sig_coeffgroup_flag, bit = raster index of the group
-  int ctx_set = 0, c1 = 1, c2 = 0, go_rice = 0;
-  double base_cost = 0, block_uncoded_cost = 0;
-  u32 c1_idx = 0, c2_idx = 0;
-  // quant-generic.c:379-399 find_last_scanpos (zeroes dest above the last position it finds)
-  int cg_last_scanpos = -1, last_scanpos = -1, cg_scanpos;
-  for (cg_scanpos = cg_num - 1; cg_scanpos >= 0 && last_scanpos < 0; cg_scanpos--) {
-    for (int in_cg = 15; in_cg >= 0; in_cg--) {
-      const int scanpos = cg_scanpos * 16 + in_cg;
-      const u32 blkpos = sc.pos(scanpos);
-      i32 level_double = coef[blkpos];
-      level_double = imin(iabs(level_double) * q, 0x7fffffff - (1 << (q_bits - 1)));
-      if (((level_double + (1 << (q_bits - 1))) >> q_bits) > 0) {
-        last_scanpos = scanpos;
-        ctx_set = (scanpos > 0 && type == 0) ? 2 : 0;
-        cg_last_scanpos = cg_scanpos;
-        break;
-      }
-      dest[blkpos] = 0;
-    }
-    if (last_scanpos >= 0) break;
-  }
-  if (last_scanpos == -1) return;
-  for (; cg_scanpos >= 0; cg_scanpos--) cost_coeffgroup_sig[cg_scanpos] = 0;
-  // rdo.c:480-509 calc_last_bits
-  i32 last_x_bits[32], last_y_bits[32];
-  {
-    const int cb = log2w - 2;
-    const int off = type ? 0 : (cb * 3 + ((cb + 1) >> 2)), shift = type ? cb : ((cb + 3) >> 2);
-    const int bx = (type ? KVZ_HIP_CX_LAST_X_CHROMA : KVZ_HIP_CX_LAST_X_LUMA) + off, by = (type ? KVZ_HIP_CX_LAST_Y_CHROMA : KVZ_HIP_CX_LAST_Y_LUMA) + off;
-    i32 bits_x = 0, bits_y = 0;
-    int k;
-    for (k = 0; k < rdoq_group_idx(width - 1); k++) {
-      last_x_bits[k] = bits_x + c.price(bx + (k >> shift), 0);
-      bits_x += c.price(bx + (k >> shift), 1);
-    }
-    last_x_bits[k] = bits_x;
-    for (k = 0; k < rdoq_group_idx(width - 1); k++) {
-      last_y_bits[k] = bits_y + c.price(by + (k >> shift), 0);
-      bits_y += c.price(by + (k >> shift), 1);
-    }
-    last_y_bits[k] = bits_y;
-  }
-  const int cg0 = KVZ_HIP_CX_SIG_CG + type;
-  for (int cgs = cg_last_scanpos; cgs >= 0; cgs--) {
-    const u32 cg_blkpos = sc.cg(cgs), cg_pos_y = cg_blkpos / num_blk_side, cg_pos_x = cg_blkpos - cg_pos_y * num_blk_side;
-    // context.c:339-351 / 315-327
-    u32 right = 0, lower = 0;
-    if ((int)cg_pos_x < num_blk_side - 1) right = (sig_groups >> (cg_pos_y * num_blk_side + cg_pos_x + 1)) & 1;
-    if ((int)cg_pos_y < num_blk_side - 1) lower = (sig_groups >> ((cg_pos_y + 1) * num_blk_side + cg_pos_x)) & 1;
-    const int pattern_sig_ctx = width == 4 ? -1 : (int)(right + (lower << 1));
-    double rd_coded_level_and_dist = 0, rd_uncoded_dist = 0, rd_sig_cost = 0, rd_sig_cost_0 = 0;
-    int rd_nnz_before_pos0 = 0;
-    for (int in_cg = 15; in_cg >= 0; in_cg--) {
-      const int scanpos = cgs * 16 + in_cg;
-      if (scanpos > last_scanpos) continue;
-      const u32 blkpos = sc.pos(scanpos);
-      i32 level_double = coef[blkpos];
-      level_double = imin(iabs(level_double) * q, 0x7fffffff - (1 << (q_bits - 1)));
-      const u32 max_abs_level = (u32)((level_double + (1 << (q_bits - 1))) >> q_bits);
-      const double err = (double)level_double;
-      // the position's three costs stay in registers while they are used here; the arrays are only written (the later passes read them back)
-      double c0v = err * err * temp, ccv, csv = 0;
-      block_uncoded_cost += c0v;
-      const int one_ctx = 4 * ctx_set + c1, abs_ctx = ctx_set + c2;
-      i32 level;
-      if (scanpos == last_scanpos) {
-        level = (i32)rdoq_coded_level(c, &ccv, &c0v, &csv, level_double, max_abs_level, 0, one_ctx, abs_ctx, go_rice, c1_idx, c2_idx, q_bits, temp, true, type);
-      } else {
-        const u32 pos_y = blkpos >> log2w, pos_x = blkpos - (pos_y << log2w);
-        const int ctx_sig = rdoq_sig_ctx_inc(pattern_sig_ctx, scan_mode, (int)pos_x, (int)pos_y, log2w, type);
-        level = (i32)rdoq_coded_level(c, &ccv, &c0v, &csv, level_double, max_abs_level, ctx_sig, one_ctx, abs_ctx, go_rice, c1_idx, c2_idx, q_bits, temp, false, type);
-      }
-      cost_coeff[scanpos] = ccv; cost_coeff0[scanpos] = c0v; cost_sig[scanpos] = csv;
-      dest[blkpos] = (i16)level;
-      base_cost += ccv;
-      const i32 base_level = c1_idx < 8 ? (2 + (c2_idx < 1)) : 1;
-      if (level >= base_level && level > 3 * (1 << go_rice)) go_rice = imin(go_rice + 1, 4);
-      if (level >= 1) c1_idx++;
-      if (level > 1) {
-        c1 = 0;
-        c2 += (c2 < 2);
-        c2_idx++;
-      } else if (c1 < 3 && c1 > 0 && level) {
-        c1++;
-      }
-      if ((scanpos % 16 == 0) && scanpos > 0) {
-        c2 = 0;
-        go_rice = 0;
-        c1_idx = 0;
-        c2_idx = 0;
-        ctx_set = (scanpos == 16 || type != 0) ? 0 : 2;
-        if (c1 == 0) ctx_set++;
-        c1 = 1;
-      }
-      rd_sig_cost += csv;
-      if (in_cg == 0) rd_sig_cost_0 = csv;
-      if (level) {
-        sig_groups |= 1ull << cg_blkpos;
-        rd_coded_level_and_dist += ccv - csv;
-        rd_uncoded_dist += c0v;
-        if (in_cg != 0) rd_nnz_before_pos0++;
-      }
-    }
-    if (cgs) {
-      // the flags may have changed inside the loop above only for this group: right / lower are those of the groups coded before
-      const int ctx_sig = (int)(right || lower);
-      if (((sig_groups >> cg_blkpos) & 1) == 0) {
-        cost_coeffgroup_sig[cgs] = c.lambda * c.price(cg0 + ctx_sig, 0);
-        base_cost += cost_coeffgroup_sig[cgs] - rd_sig_cost;
-      } else if (cgs < cg_last_scanpos) {
-        if (rd_nnz_before_pos0 == 0) {
-          base_cost -= rd_sig_cost_0;
-          rd_sig_cost -= rd_sig_cost_0;
-        }
-        double cost_zero_cg = base_cost;
-        cost_coeffgroup_sig[cgs] = c.lambda * c.price(cg0 + ctx_sig, 1);
-        base_cost += cost_coeffgroup_sig[cgs];
-        cost_zero_cg += c.lambda * c.price(cg0 + ctx_sig, 0);
-        cost_zero_cg += rd_uncoded_dist;
-        cost_zero_cg -= rd_coded_level_and_dist;
-        cost_zero_cg -= rd_sig_cost;
-        if (cost_zero_cg < base_cost) {
-          sig_groups &= ~(1ull << cg_blkpos);
-          base_cost = cost_zero_cg;
-          cost_coeffgroup_sig[cgs] = c.lambda * c.price(cg0 + ctx_sig, 0);
-          for (int in_cg = 15; in_cg >= 0; in_cg--) {
-            const int scanpos = cgs * 16 + in_cg;
-            const u32 blkpos = sc.pos(scanpos);
-            if (dest[blkpos]) {
-              dest[blkpos] = 0;
-              cost_coeff[scanpos] = cost_coeff0[scanpos];
-              cost_sig[scanpos] = 0;
-            }
-          }
-        }
-      }
-    } else {
-      sig_groups |= 1ull << cg_blkpos;
-    }
-  }
-  // ---- the last position (rdo.c:903-957), intra block: coded block flag of the transform unit
-  double best_cost;
-  int best_last_idx_p1 = 0;
-  bool found_last = false;
-  {
-    // luma: qt_cbf_model_luma[!tr_depth]; chroma: qt_cbf_model_chroma[tr_depth] (rdo.c:907-915) -- entries 2..3 of the latter (the blocks of an NxN CU come
-    // with tr_depth 2, quant-generic.c:237-238) sit behind the other contexts in the KVZ_HIP_CX_* layout
-    const int ctx_cbf = type == 0 ? KVZ_HIP_CX_CBF_LUMA + !tr_depth : (tr_depth < 2 ? KVZ_HIP_CX_CBF_CHROMA + tr_depth : KVZ_HIP_CX_CBF_CHROMA_DEEP + imin(tr_depth, 3) - 2);
-    best_cost = block_uncoded_cost + c.lambda * c.price(ctx_cbf, 0);
-    base_cost += c.lambda * c.price(ctx_cbf, 1);
-  }
-  for (int cgs = cg_last_scanpos; cgs >= 0; cgs--) {
-    const u32 cg_blkpos = sc.cg(cgs);
-    base_cost -= cost_coeffgroup_sig[cgs];
-    if ((sig_groups >> cg_blkpos) & 1) {
-      for (int in_cg = 15; in_cg >= 0; in_cg--) {
-        const int scanpos = cgs * 16 + in_cg;
-        if (scanpos > last_scanpos) continue;
-        const u32 blkpos = sc.pos(scanpos);
-        if (dest[blkpos]) {
-          const u32 pos_y = blkpos >> log2w, pos_x = blkpos - (pos_y << log2w);
-          const u32 px = scan_mode == 2 ? pos_y : pos_x, py = scan_mode == 2 ? pos_x : pos_y;  // SCAN_VER swaps (rdo.c:934)
-          // rdo.c:465-478 get_rate_last
-          const int gx = rdoq_group_idx((int)px), gy = rdoq_group_idx((int)py);
-          double ui_cost = last_x_bits[gx] + last_y_bits[gy];
-          if (gx > 3) ui_cost += (double)((1 << 15) * ((gx - 2) >> 1));
-          if (gy > 3) ui_cost += (double)((1 << 15) * ((gy - 2) >> 1));
-          const double cost_last = c.lambda * ui_cost;
-          const double total = base_cost + cost_last - cost_sig[scanpos];
-          if (total < best_cost) {
-            best_last_idx_p1 = scanpos + 1;
-            best_cost = total;
-          }
-          if (dest[blkpos] > 1) { found_last = true; break; }
-          base_cost -= cost_coeff[scanpos];
-          base_cost += cost_coeff0[scanpos];
-        } else {
-          base_cost -= cost_sig[scanpos];
-        }
-      }
-      if (found_last) break;
-    }
-  }
-  for (int scanpos = 0; scanpos < best_last_idx_p1; scanpos++) {
-    const u32 blkpos = sc.pos(scanpos);
-    const i32 level = dest[blkpos];
-    dest[blkpos] = (i16)(coef[blkpos] < 0 ? -level : level);
-  }
-  for (int scanpos = best_last_idx_p1; scanpos <= last_scanpos; scanpos++) dest[sc.pos(scanpos)] = 0;
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
-// The same block by a whole WAVEFRONT (the CTU pass, kvz_ctu.hpp recon_tus).  kvz_rdoq is a chain of decisions, but most of what it computes per coefficient does not
+// The block by a whole WAVEFRONT (the CTU pass, kvz_ctu.hpp recon_tus; RdoqOp at the end of this file).  kvz_rdoq is a chain of decisions, but most of what it computes per coefficient does not
 // depend on the chain at all.  What is serial, and is kept in the reference's order:
 //   * the (c1, c2, go_rice, c1_idx, c2_idx) state inside a 4x4 group, which only positions that can quantise to a non-zero level move or read;
 //   * the double-precision running sums (base_cost, block_uncoded_cost, the group sums): floating-point addition is not associative, so they are added one term at a
-//     time in scan order -- an addition per position, not the ~270 dependent instructions per position of the one-lane routine above;
+//     time in scan order -- an addition per position, not a few hundred dependent instructions per position as a one-lane walk would have;
 //   * the zero-the-group and best-last-position decisions, which compare those sums.
 // What is per-position runs on the lanes, 64 scan positions (four 4x4 groups) at a time: scan position -> block position, level_double, max_abs_level,
 // err^2 * temp, the distortion of the two candidate levels; and per group, once its pattern_sig_ctx is known, the significance context and lambda times the price
@@ -912,14 +630,40 @@ KVZ_RDOQ_WAVE_FN void rdoq_block_wave(const RdoqWaveArgs c, int lane)
   KVZ_RQ_PROF_END();
 }
 
-// one item = one block of a batch of equally shaped blocks
+// One item = one block of a batch of equally shaped blocks, ONE WAVEFRONT PER BLOCK (the per-call entry points kvz_hip_rdoq / kvz_hip_rdoq_blocks /
+// kvz_hip_quantize_residual_rdoq run the same routine as the CTU pass): the prices of both bins of every context at the caller's states, the block's coefficients and its
+// levels staged in LDS around rdoq_block_wave.  Backends launch it with run_wave (64 lanes per item; the host simulation calls lane 0).
 struct RdoqOp {
   const Tables *tb; const u8 *ctx; double lambda; int qp; const i16 *coef; i16 *dest; int log2w, type, scan_mode, tr_depth; double *tmp;
-  KVZ_DEV void operator()(int item) const
+  KVZ_DEV void wave(int item, int lane) const
   {
     const int n = 1 << (2 * log2w);
-    const RdoqCtx c{ ctx, tb->entropy_bits, lambda };
-    rdoq_block(c, qp, coef + (long)item * n, dest + (long)item * n, log2w, type, scan_mode, tr_depth, tb->diag8, tmp + (long)item * 3 * n);
+#ifdef KVZ_HOSTSIM
+    i32 ptab[2 * 148];
+    i16 s_coef[32 * 32], s_dest[32 * 32];
+    u8 s_diag8[64];
+    const int lanes = 1;
+#else
+    __shared__ i32 ptab[2 * 148];
+    __shared__ alignas(8) i16 s_coef[32 * 32];
+    __shared__ alignas(8) i16 s_dest[32 * 32];
+    __shared__ u8 s_diag8[64];
+    const int lanes = 64;
+#endif
+    for (int v = lane; v < 2 * 148; v += lanes) ptab[v] = (i32)tb->entropy_bits[ctx[v >> 1] ^ (v & 1)];
+    for (int i = lane; i < n; i += lanes) { s_coef[i] = coef[(long)item * n + i]; s_dest[i] = dest[(long)item * n + i]; }
+    for (int i = lane; i < 64; i += lanes) s_diag8[i] = tb->diag8[i];
+#ifndef KVZ_HOSTSIM
+    __syncthreads();
+#endif
+    RdoqWaveArgs ra;
+    ra.ptab = (KVZ_LDS_PTR(const i32))ptab; ra.coef = (KVZ_LDS_PTR(const i16))s_coef; ra.dest = (KVZ_LDS_PTR(i16))s_dest; ra.diag8 = (KVZ_LDS_PTR(const u8))s_diag8;
+    ra.cost3 = tmp + (long)item * 3 * n; ra.lambda = lambda; ra.qp = qp; ra.log2w = log2w; ra.type = type; ra.scan_mode = scan_mode; ra.tr_depth = tr_depth;
+    rdoq_block_wave(ra, lane);
+#ifndef KVZ_HOSTSIM
+    __syncthreads();
+#endif
+    for (int i = lane; i < n; i += lanes) dest[(long)item * n + i] = s_dest[i];
   }
 };
 

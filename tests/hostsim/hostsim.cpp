@@ -21,6 +21,7 @@ struct HostBackend : kvz::ArenaBase {
   void download() {}
   const kvz::Tables *tables() { return &tb; }
   template <class Op> void run(const Op &op, int n) { for (int i = 0; i < n; i++) op(i); }
+  template <class Op> void run_wave(const Op &op, int n) { for (int i = 0; i < n; i++) op.wave(i, 0); }
 };
 HostBackend &be() { static thread_local HostBackend b; return b; }
 typedef kvz::Api<HostBackend> A;
