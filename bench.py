@@ -419,7 +419,9 @@ def main():
                     "3072 (every GPU of an 8-GPU node then still holds 3072 serial tile chains, what saturates it; 231 GB at one GPU) or 384 with --wpp")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic frames generated on the host; the batch cycles through them")
     ap.add_argument("--qp", type=int, default=22)
-    ap.add_argument("--preset", default="ultrafast", choices=sorted(PRESETS), help="which of kvazaar's all-intra searches the pass runs (the headline metric is ultrafast): "
+    ap.add_argument("--preset", default="ultrafast", choices=sorted(PRESETS) + ["veryfast-inter"], help="veryfast-inter (with --tiles CxR, 3840x2160): BASELINE config 4 sharded by tile "
+                    "-- `--preset veryfast --gop lp-g4d3t1`, every rank searches its tiles of --frames independent sequences, the reference frames are exchanged after every picture.  "
+                    "Otherwise which of kvazaar's all-intra searches the pass runs (the headline metric is ultrafast): "
                     "faster = CABAC coefficient cost at every QP; fast = + 32x32 CUs searched; medium-pu13 = + RDOQ (`--preset medium --pu-depth-intra 1-3`); "
                     "medium = + 8x8 CUs tried as four 4x4 PUs: BASELINE config 3's preset as it is")
     ap.add_argument("--cpu-frames", type=int, default=8)
@@ -469,6 +471,11 @@ def main():
 
     if args.only:
         only_leg(args, lib, model_for, HipBatch)
+        return
+    if args.preset == "veryfast-inter":
+        tiled_inter_bench(args, lib, dist, torch, rank, world, HipBatch, cost_model)
+        if dist is not None:
+            dist.destroy_process_group()
         return
     model = model_for(args.qp, args.tiles)
     # HBM the batch needs on this rank: source + reconstruction (1.5 B / pixel each) + two coefficient blocks (3 B / pixel each) + borders and CU maps
@@ -575,6 +582,98 @@ def main():
         b.close()
     if dist is not None:
         dist.destroy_process_group()
+    if not ok_all:
+        sys.exit(1)
+
+
+def tiled_inter_bench(args, lib, dist, torch, rank, world, HipBatch, cost_model):
+    """BASELINE config 4 sharded by tile (`--preset veryfast-inter --tiles 4x2 [--gpus N]`): 3840x2160 `--preset veryfast --gop lp-g4d3t1 -q 22 --tiles CxR`, every
+    rank holding its tiles of --frames independent sequences.  A step = ONE B picture of every sequence: the inter CTU pass of the rank's tiles (tile geometry: the reference
+    is the whole frame), their loop filters, then the exchange -- all-gather of the filtered tiles and of their CU records (RCCL over xGMI), pasted into every rank's
+    reference frames.  value = CTUs of B pictures per second, whole job (strong scaling: the tiles are dealt to the ranks).  Verified: the assembled pictures and CU decisions
+    of the first three B pictures against the reference encoder's `--tiles` run (tests/golden/inter_tiles.json)."""
+    from kvazaar_amd import inter, sharding
+    w, h = 3840, 2160
+    cols, rows = (int(v) for v in (args.tiles or "4x2").split("x"))
+    n = args.frames if args.frames and args.frames not in (1536, 3072, 384) else 256  # x 8 tiles = 2 048 chains: without WPP a tile offers one CTU at a time
+    tiles = sharding.tile_grid(w, h, cols, rows)
+    pictures = synth_frames(w, h, 4, clip_seed(w, h))
+    qps = [inter.lowdelay_picture_qp(args.qp, k) for k in range(4)]
+    seq = inter.TiledInterSequences(lib, w, h, cols, rows, n, rank, world, dist)
+    # the I picture: every tile through the intra pass + its loop filters (tiles: --no-wpp), once -- the sequences are copies of one clip
+    rec0 = np.zeros(w * h * 3 // 2, np.uint8)
+    ys, cs = w * h, (w // 2) * (h // 2)
+    for (x, y, tw, th) in tiles:
+        mi = cost_model(lib, qps[0])
+        mi.no_wpp = 1
+        bi = HipBatch(lib, tw, th, 1)
+        bi.upload(0, sharding.crop_tile(pictures[0], w, h, (x, y, tw, th)))
+        bi.launch(mi)
+        bi.loop_filters(mi, deblock=True, sao=True)
+        t = bi.download(0)["rec"]
+        bi.close()
+        c = (tw // 2) * (th // 2)
+        rec0[:ys].reshape(h, w)[y:y + th, x:x + tw] = t[:tw * th].reshape(th, tw)
+        rec0[ys:ys + cs].reshape(h // 2, w // 2)[y // 2:(y + th) // 2, x // 2:(x + tw) // 2] = t[tw * th:tw * th + c].reshape(th // 2, tw // 2)
+        rec0[ys + cs:].reshape(h // 2, w // 2)[y // 2:(y + th) // 2, x // 2:(x + tw) // 2] = t[tw * th + c:].reshape(th // 2, tw // 2)
+    cu0 = inter.intra_picture_cu_info(w, h)
+    try:
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "inter_tiles.json"))).get(f"baseline-c4-2160p-tiles{cols}x{rows}") if args.qp == 22 else None
+    except (OSError, ValueError):
+        gold = None
+    i_ok = None if gold is None else hashlib.sha256(rec0.tobytes()).hexdigest()[:24] == gold["rec"][0]
+
+    def start():
+        seq.set_reference(np.broadcast_to(rec0, (n, rec0.size)), np.broadcast_to(cu0, (n,) + cu0.shape))
+
+    def picture(k):
+        seq.upload_sources(lambda i: pictures[k % len(pictures)])
+        seq.run_picture(inter.veryfast_params(qps[min(k, 3)], k, mv_constraint=False))
+
+    # verification chain: B pictures 1..3 from the I picture, sequence 0 and the last one against the reference encoder / each other
+    start()
+    checks = []
+    for k in range(1, 4):
+        picture(k)
+        f0, c0 = seq.download_reference(0)
+        f1, c1 = seq.download_reference(n - 1)
+        ok = bool(np.array_equal(f0, f1) and np.array_equal(c0, c1))
+        if gold is not None:
+            ok = ok and hashlib.sha256(f0.tobytes()).hexdigest()[:24] == gold["rec"][k] and inter.cu_digest(c0) == gold["cu"][k]
+        checks.append(ok)
+    # timing: `steps` B pictures (the chain simply goes on: picture k's sources cycle through the clip), sources uploaded before the clock starts
+    start()
+    for _ in range(args.warmup):
+        picture(1)
+    start()
+    seq.upload_sources(lambda i: pictures[1])
+    prm = inter.veryfast_params(qps[1], 1, mv_constraint=False)
+    pass_ms = []
+
+    def step():
+        seq.run_picture(prm)
+        pass_ms.append(seq.pass_ms)
+    dt = sharding.timed_steps(step, args.steps, dist, torch.cuda.synchronize, "cuda")
+    job_ctus = n * sum(((t[2] + 63) // 64) * ((t[3] + 63) // 64) for t in tiles)
+    ok_all = all(checks) and i_ok is not False
+    if dist is not None:
+        t = torch.tensor([1 if ok_all else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        ok_all = bool(t[0].item())
+    if rank == 0:
+        value = job_ctus * args.steps / dt
+        k_s = float(np.mean(pass_ms)) / 1e3
+        print(json.dumps({
+            "metric": "CTUs/s (inter CTU pass + loop filters + reference exchange, BASELINE config 4 sharded by tile)", "value": value, "unit": "CTUs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8/i16 (f64 RD costs)", "data": "synthetic", "fps": value / (((w + 63) // 64) * ((h + 63) // 64)),
+            "verified": bool(ok_all), "verify": {"i_picture_equals_reference_encoder": i_ok, "b_pictures_equal_reference_encoder_and_between_sequences": checks,
+                                                "golden": "tests/golden/inter_tiles.json" if gold is not None else None},
+            "config": {"workload": f"{w}x{h} --preset veryfast --gop lp-g4d3t1 -q {args.qp} --tiles {cols}x{rows}: one B picture (QP {qps[1]}) of {n} sequences per step", "sequences": n,
+                       "tiles": len(tiles), "tiles_per_rank": seq.per_rank, "parallelism": f"--tiles {cols}x{rows} dealt to {world} GPU(s); one all-gather of pictures + one of CU records per picture"},
+            "exchange": {"recv_bytes_per_rank_per_step": (world - 1) * seq.per_rank * n * (seq.slot_px + seq.slot_cu), "frame_bytes": seq.fs, "sequences": n},
+            "roofline": leg_roofline("inter", "inter_ctu_ticket_kernel_fast", INTER_BYTES_PER_CTU, n * seq.ctus, k_s),
+        }))
     if not ok_all:
         sys.exit(1)
 

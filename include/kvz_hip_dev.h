@@ -163,6 +163,11 @@ typedef struct kvz_hip_inter_params {
 } kvz_hip_inter_params;
 int  kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz_hip_cu_info *ref_cu, uint8_t *rec, kvz_hip_cu_info *cu, int16_t *coeff, int width,
                                 int height, int n_pictures, const kvz_hip_inter_params *params);
+/* ... with every picture's own tile origin: tile_xy (DEVICE pointer, n_pictures x {x, y}, multiples of 8 inside the reference frame; NULL: params->tile_x / tile_y for
+ * all) -- the tiles of one size of MANY places of the grid in one launch (without WPP a tile offers one CTU at a time: the launch needs that many more chains).
+ * n_references (0: one per picture): `ref` / `ref_cu` hold that many frames and picture p predicts from frame p % n_references -- several tiles of the same frame. */
+int  kvz_hip_dev_inter_ctu_pass_tiles(const uint8_t *src, const uint8_t *ref, const kvz_hip_cu_info *ref_cu, uint8_t *rec, kvz_hip_cu_info *cu, int16_t *coeff, int width,
+                                      int height, int n_pictures, const kvz_hip_inter_params *params, const int32_t *tile_xy, int n_references);
 /* milliseconds the kernel of the calling thread's last kvz_hip_dev_inter_ctu_pass took on the device (HIP events on its stream around the launch) */
 float kvz_hip_dev_inter_kernel_ms(void);
 /* The slice data of n B pictures -- kvz_encode_coding_tree with the inter syntax (encode_coding_tree.c:745-900, kvz_encode_inter_prediction_unit :311-421, kvz_encode_mvd

@@ -1261,6 +1261,11 @@ void kvz_hip_dev_cu_dbk_from_info(const kvz_hip_cu_info *cu, int count, kvz_hip_
 int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz_hip_cu_info *ref_cu, uint8_t *rec, kvz_hip_cu_info *cu, int16_t *coeff, int width,
                                int height, int n_pictures, const kvz_hip_inter_params *p)
 {
+  return kvz_hip_dev_inter_ctu_pass_tiles(src, ref, ref_cu, rec, cu, coeff, width, height, n_pictures, p, nullptr, 0);
+}
+int kvz_hip_dev_inter_ctu_pass_tiles(const uint8_t *src, const uint8_t *ref, const kvz_hip_cu_info *ref_cu, uint8_t *rec, kvz_hip_cu_info *cu, int16_t *coeff, int width,
+                                     int height, int n_pictures, const kvz_hip_inter_params *p, const int32_t *tile_xy, int n_references)
+{
   if (n_pictures <= 0) return 0;
   if (!p || width <= 0 || height <= 0 || (width & 7) || (height & 7) || width > 64 * 255 || height > 64 * 255 || n_pictures > 65535) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: bad geometry\n"); return -1; }
   if (p->qp < 0 || p->qp > 51) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: picture QP %d outside 0..51\n", p->qp); return -1; }
@@ -1324,6 +1329,8 @@ int kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz
   F.W = width; F.H = height; F.wc = wc; F.hc = hc; F.frame_px = (long)width * height * 3 / 2; F.cells = (long)(width / 4) * (height / 4);
   F.src = src; F.ref = ref; F.ref_cu = ref_cu; F.rec = rec; F.cu = cu; F.coeff = coeff; F.ctx_out = sc.ctx; F.slabs = sc.slabs;
   F.prof = nullptr;
+  F.tile_xy = (p->ref_width || p->ref_height) ? tile_xy : nullptr;
+  F.ref_count = n_references > 0 ? n_references : 0;
 #ifdef KVZ_ICTU_PROFILE
   static unsigned long long *d_prof = nullptr;
   if (!d_prof) KVZ_HIP_CHECK(hipMalloc((void **)&d_prof, kvz::IP_COUNT * sizeof(unsigned long long)));

@@ -161,6 +161,8 @@ struct InterFrames {
   i16 *coeff;            // [n] out: KVZ_HIP_CTU_COEFFS per CTU (raster CTU order), z-order inside as lcu_coeff_t
   ICtx *ctx_out;         // [n][CTUs]: the row coder's contexts after each CTU
   InterSlab *slabs;      // one per resident workgroup
+  const int *tile_xy;    // NULL, or [n][2]: every picture's own origin in its reference frame (tiles of one size from different places of the grid in one launch)
+  int ref_count;         // 0, or the number of reference frames: picture p predicts from frame p % ref_count (several tiles of one frame in the launch)
   unsigned long long *prof;  // [IP_COUNT] or NULL (KVZ_ICTU_PROFILE)
 };
 
@@ -316,8 +318,9 @@ struct InterCtu {
   }
   IC_DEV long plane_off(int c) { return c == 0 ? 0 : (c == 1 ? (long)F.W * F.H : (long)F.W * F.H * 5 / 4); }
   // plane c of the picture's reference FRAME (K->ref_w x K->ref_h; the picture lies at (K->tile_x, K->tile_y) in it)
-  IC_DEV const gu8 *refp(int c) { const long n = (long)K->ref_w * K->ref_h; return (const gu8 *)F.ref + frame * (n * 3 / 2) + (c == 0 ? 0 : (c == 1 ? n : n * 5 / 4)); }
-  IC_DEV const CuInfo *ref_cu_frame() { return F.ref_cu + frame * ((long)(K->ref_w >> 2) * (K->ref_h >> 2)); }
+  IC_DEV int ref_index() { return F.ref_count ? frame % F.ref_count : frame; }
+  IC_DEV const gu8 *refp(int c) { const long n = (long)K->ref_w * K->ref_h; return (const gu8 *)F.ref + ref_index() * (n * 3 / 2) + (c == 0 ? 0 : (c == 1 ? n : n * 5 / 4)); }
+  IC_DEV const CuInfo *ref_cu_frame() { return F.ref_cu + ref_index() * ((long)(K->ref_w >> 2) * (K->ref_h >> 2)); }
   IC_DEV const gu8 *srcp(int c) { return (const gu8 *)F.src + frame * F.frame_px + plane_off(c); }
   IC_DEV gu8 *recp(int c) { return (gu8 *)F.rec + frame * F.frame_px + plane_off(c); }
   IC_DEV CuInfo *dcell(int xl, int yl) { return &L->Dcu[(yl >> 3) * 8 + (xl >> 3)]; }
@@ -460,7 +463,7 @@ struct InterCtu {
   }
   IC_DEV void begin_ctu(int frame_, int cx_, int cy_)
   {
-    IC_FOR(tid) { if (tid == 0) { frame = frame_; cx = cx_; cy = cy_; } }
+    IC_FOR(tid) { if (tid == 0) { frame = frame_; cx = cx_; cy = cy_; if (F.tile_xy) { K->tile_x = ((const KVZ_GLB int *)F.tile_xy)[2 * frame_]; K->tile_y = ((const KVZ_GLB int *)F.tile_xy)[2 * frame_ + 1]; } } }
     IC_SYNC();
   }
 };

@@ -169,3 +169,134 @@ class InterPictures:
             self.dev.free(self.d_dbk)
         if self.d_coeff is not None:
             self.dev.free(self.d_coeff)
+
+
+class TiledInterSequences:
+    """BASELINE config 4 sharded by tile: picture k of `n` independent sequences of a width x height frame cut into kvazaar's uniform --tiles grid.  This rank's
+    tiles are resident as pictures of their own (source, reconstruction, CU records: the tile is an independent sub-picture for prediction, neighbours, contexts and loop
+    filters); the REFERENCE frames and their CU records are whole frames on every rank -- motion vectors leave the tile --, rebuilt after every picture by THE collective of the
+    configuration: one all-gather of the ranks' filtered tiles (RCCL over xGMI when world > 1) and a paste, and the same for the CU records.
+    Buffers are torch tensors (the collective is torch.distributed's); the passes run through the C ABI on the library's stream of this thread."""
+
+    def __init__(self, lib, width, height, cols, rows, n, rank=0, world=1, dist=None, device="cuda"):
+        import torch
+        from . import sharding
+        self.lib, self.w, self.h, self.n, self.rank, self.world, self.dist, self.torch = lib, width, height, n, rank, world, dist, torch
+        self.plan = sharding.exchange_plan(width, height, cols, rows, world)
+        self.tiles = self.plan["tiles"]
+        self.mine = sharding.tiles_of_rank(len(self.tiles), rank, world)
+        self.per_rank = self.plan["slots_per_rank"]
+        self.fs, self.cells = width * height * 3 // 2, (width // 4) * (height // 4)
+        self.rec_item = CU_DTYPE.itemsize
+        dev = torch.device(device)
+        e = lambda nbytes: torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.ref, self.ref_cu = e(n * self.fs), e(n * self.cells * self.rec_item)
+        self.slot_px = max(t[2] * t[3] * 3 // 2 for t in self.tiles)
+        self.slot_cu = max((t[2] // 4) * (t[3] // 4) for t in self.tiles) * self.rec_item
+        # send / receive buffers of the two all-gathers: [slot of the rank][sequence][bytes of the largest tile]
+        self.send_px, self.send_cu = torch.zeros(self.per_rank * n * self.slot_px, dtype=torch.uint8, device=dev), torch.zeros(self.per_rank * n * self.slot_cu, dtype=torch.uint8, device=dev)
+        self.recv_px = e(world * self.per_rank * n * self.slot_px) if world > 1 else self.send_px
+        self.recv_cu = e(world * self.per_rank * n * self.slot_cu) if world > 1 else self.send_cu
+        # this rank's tiles grouped by size: one launch of the pass (and of the loop filters) per group, picture j * n + i = tile j of the group, sequence i
+        self.groups = {}
+        for ti in self.mine:
+            self.groups.setdefault((self.tiles[ti][2], self.tiles[ti][3]), []).append(ti)
+        self.src, self.rec, self.cu, self.dbk, self.xy = {}, {}, {}, {}, {}
+        for (tw, th), members in self.groups.items():
+            m = len(members) * n
+            self.src[(tw, th)], self.rec[(tw, th)] = e(m * tw * th * 3 // 2), e(m * tw * th * 3 // 2)
+            self.cu[(tw, th)], self.dbk[(tw, th)] = e(m * (tw // 4) * (th // 4) * self.rec_item), e(m * (tw // 4) * (th // 4) * 20)
+            xy = np.array([[self.tiles[ti][0], self.tiles[ti][1]] for ti in members for _ in range(n)], np.int32)
+            self.xy[(tw, th)] = torch.from_numpy(xy).to(dev)
+        lib.kvz_hip_dev_inter_ctu_pass_tiles.restype = C.c_int
+        lib.kvz_hip_dev_inter_ctu_pass_tiles.argtypes = [C.c_void_p] * 6 + [C.c_int] * 3 + [C.c_void_p, C.c_void_p, C.c_int]
+        lib.kvz_hip_dev_cu_dbk_from_info.restype = None
+        lib.kvz_hip_dev_cu_dbk_from_info.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.kvz_hip_dev_loop_filters_inter.restype = C.c_int
+        lib.kvz_hip_dev_loop_filters_inter.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p] * 3
+        self.ctus = sum(((self.tiles[ti][2] + 63) // 64) * ((self.tiles[ti][3] + 63) // 64) for ti in self.mine)  # of this rank, per sequence
+        self.pass_ms = 0.0
+
+    def group_params(self, base):
+        return InterParams(qp=base.qp, poc=base.poc, mv_constraint=0, sao=base.sao, deblock=base.deblock, fme_level=base.fme_level, pu_depth_inter_max=base.pu_depth_inter_max,
+                           no_wpp=1, fast_residual_cost=base.fast_residual_cost, ref_width=self.w, ref_height=self.h, tile_x=0, tile_y=0, no_tmvp=1)  # tiles: --no-wpp, no TMVP (cfg.c:920-975)
+
+    def upload_sources(self, frames_of_sequence):
+        """frames_of_sequence(i) -> the planar frame of sequence i for the picture about to be encoded; every tile of this rank gets its part"""
+        from . import sharding
+        torch = self.torch
+        for (tw, th), members in self.groups.items():
+            ts = tw * th * 3 // 2
+            host = np.empty((len(members), self.n, ts), np.uint8)
+            for j, ti in enumerate(members):
+                cache = {}
+                for i in range(self.n):
+                    f = frames_of_sequence(i)
+                    k = id(f)
+                    if k not in cache:
+                        cache[k] = sharding.crop_tile(f, self.w, self.h, self.tiles[ti])
+                    host[j, i] = cache[k]
+            self.src[(tw, th)].copy_(torch.from_numpy(host).reshape(-1))
+
+    def set_reference(self, frames, cu):
+        """whole reference frames [n, fs] and their CU records [n, h/4, w/4] (host arrays): the start of a chain"""
+        torch = self.torch
+        self.ref.copy_(torch.from_numpy(np.ascontiguousarray(frames).reshape(-1)))
+        self.ref_cu.copy_(torch.from_numpy(np.ascontiguousarray(cu).view(np.uint8).reshape(-1)))
+
+    def run_picture(self, base):
+        """one B picture of every sequence: the CTU pass of this rank's tiles, their loop filters, then the exchange that turns the result into the next picture's reference"""
+        torch = self.torch
+        torch.cuda.synchronize()
+        self.pass_ms = 0.0
+        self.lib.kvz_hip_dev_inter_kernel_ms.restype = C.c_float
+        prm = self.group_params(base)
+        for (tw, th), members in self.groups.items():
+            g, m = (tw, th), len(members) * self.n
+            rc = self.lib.kvz_hip_dev_inter_ctu_pass_tiles(self.src[g].data_ptr(), self.ref.data_ptr(), self.ref_cu.data_ptr(), self.rec[g].data_ptr(), self.cu[g].data_ptr(), None, tw, th,
+                                                           m, C.addressof(prm), self.xy[g].data_ptr(), self.n)
+            if rc != 0:
+                raise RuntimeError(f"kvz_hip_dev_inter_ctu_pass_tiles returned {rc}")
+            self.pass_ms += float(self.lib.kvz_hip_dev_inter_kernel_ms())
+            self.lib.kvz_hip_dev_cu_dbk_from_info(self.cu[g].data_ptr(), m * (tw // 4) * (th // 4), self.dbk[g].data_ptr())
+            rc = self.lib.kvz_hip_dev_loop_filters_inter(self.src[g].data_ptr(), self.rec[g].data_ptr(), tw, th, m, self.dbk[g].data_ptr(), prm.qp, 1, prm.deblock, 0, 0, prm.sao, 1, None, None, None)
+            if rc != 0:
+                raise RuntimeError(f"kvz_hip_dev_loop_filters_inter returned {rc}")
+        self.lib.kvz_hip_dev_sync()
+        self.exchange()
+
+    def exchange(self):
+        """all-gather of the tiles' pictures and CU records, pasted into every rank's reference frames"""
+        torch = self.torch
+        n = self.n
+        slot_of = {ti: k for k, ti in enumerate(self.mine)}
+        for (tw, th), members in self.groups.items():
+            ts, tc = tw * th * 3 // 2, (tw // 4) * (th // 4) * self.rec_item
+            for j, ti in enumerate(members):
+                self.send_px.view(self.per_rank, n, self.slot_px)[slot_of[ti], :, :ts] = self.rec[(tw, th)].view(len(members), n, ts)[j]
+                self.send_cu.view(self.per_rank, n, self.slot_cu)[slot_of[ti], :, :tc] = self.cu[(tw, th)].view(len(members), n, tc)[j]
+        if self.world > 1:
+            self.dist.all_gather_into_tensor(self.recv_px, self.send_px)
+            self.dist.all_gather_into_tensor(self.recv_cu, self.send_cu)
+        from . import sharding
+        ys, cs = self.w * self.h, (self.w // 2) * (self.h // 2)
+        fr = self.ref.view(n, self.fs)
+        Y, U, V = fr[:, :ys].view(n, self.h, self.w), fr[:, ys:ys + cs].view(n, self.h // 2, self.w // 2), fr[:, ys + cs:].view(n, self.h // 2, self.w // 2)
+        CU = self.ref_cu.view(n, self.h // 4, self.w // 4, self.rec_item)
+        px, cu = self.recv_px.view(self.world, self.per_rank, n, self.slot_px), self.recv_cu.view(self.world, self.per_rank, n, self.slot_cu)
+        for r in range(self.world):
+            for k, ti in enumerate(sharding.tiles_of_rank(len(self.tiles), r, self.world)):
+                x, y, tw, th = self.tiles[ti]
+                c = (tw // 2) * (th // 2)
+                t = px[r, k]
+                Y[:, y:y + th, x:x + tw] = t[:, :tw * th].view(n, th, tw)
+                U[:, y // 2:(y + th) // 2, x // 2:(x + tw) // 2] = t[:, tw * th:tw * th + c].view(n, th // 2, tw // 2)
+                V[:, y // 2:(y + th) // 2, x // 2:(x + tw) // 2] = t[:, tw * th + c:tw * th + 2 * c].view(n, th // 2, tw // 2)
+                CU[:, y // 4:(y + th) // 4, x // 4:(x + tw) // 4] = cu[r, k][:, :(tw // 4) * (th // 4) * self.rec_item].view(n, th // 4, tw // 4, self.rec_item)
+        torch.cuda.synchronize()
+
+    def download_reference(self, i):
+        """the assembled frame and CU records of sequence i after the last exchange"""
+        frame = self.ref.view(self.n, self.fs)[i].cpu().numpy().copy()
+        cu = self.ref_cu.view(self.n, self.cells * self.rec_item)[i].cpu().numpy().copy().view(CU_DTYPE).reshape(self.h // 4, self.w // 4)
+        return frame, cu

@@ -299,8 +299,16 @@ def update_inter_tiles():
     import tempfile
     import inter_common as ic
     out = {}
-    for (name, w, h, n, qp, tiles, seed, noise, pan) in INTER_TILE_CLIPS:
-        frames = ic.clip(w, h, n, seed, noise, pan)
+    clips = list(INTER_TILE_CLIPS)
+    if "--with-4k" in sys.argv:  # BASELINE config 4's own clip under --tiles 4x2 (what `bench.py --preset veryfast-inter --tiles 4x2` verifies): minutes of the reference encoder
+        clips.append(("baseline-c4-2160p-tiles4x2", 3840, 2160, 4, 22, "4x2", None, None, None))
+    else:
+        try:
+            out.update({k: v for k, v in json.load(open(os.path.join(HERE, "inter_tiles.json"))).items() if k.startswith("baseline-")})
+        except (OSError, ValueError):
+            pass
+    for (name, w, h, n, qp, tiles, seed, noise, pan) in clips:
+        frames = ic.clip(w, h, n, seed, noise, pan) if seed is not None else ic.case_frames([c for c in ic.CASES if c[0] == "baseline-c4-2160p"][0])
         with tempfile.TemporaryDirectory() as d:
             rec, cu = ic.reference_encode(w, h, frames, qp, d, preset="veryfast", deblock=True, sao=True, owf=0, extra=("--tiles", tiles))
             out[name] = dict(ic.digests(rec, cu), bitstream_md5=hashlib.md5(open(os.path.join(d, "out.hevc"), "rb").read()).hexdigest())
