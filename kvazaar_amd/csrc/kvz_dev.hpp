@@ -1355,7 +1355,7 @@ int kvz_hip_dev_inter_ctu_pass_tiles(const uint8_t *src, const uint8_t *ref, con
   {
     unsigned long long hp[kvz::IP_COUNT];
     KVZ_HIP_CHECK(hipMemcpy(hp, d_prof, sizeof hp, hipMemcpyDeviceToHost));
-    static const char *names[kvz::IP_COUNT] = { "merge MC+SATD", "early skip", "integer ME", "fractional ME", "candidates", "intra search", "intra recon", "inter quant/recon", "mock+rd cost", "copies", "io", "total search" };
+    static const char *names[kvz::IP_COUNT] = { "merge MC+SATD", "early skip", "integer ME", "fractional ME", "candidates", "intra search", "intra recon", "inter quant/recon", "mock+rd cost", "copies", "io", "total search", "winner MC", "context copies", "zero-coeff alternative", "final syntax" };
     for (int i = 0; i < kvz::IP_COUNT; i++) fprintf(stderr, "ictu-profile %-18s %10.3f ms (sum over workgroups) %5.1f %%\n", names[i], hp[i] / 1e5, 100.0 * hp[i] / (double)hp[kvz::IP_TOTAL]);
   }
 #endif

@@ -109,7 +109,7 @@ static long g_ic_phases[32]; static int g_ic_cat = 31;
 #else
 #define IC_PROF(cat, stmt) do { stmt; } while (0)
 #endif
-enum { IP_MERGE = 0, IP_EARLY_SKIP, IP_ME, IP_FME, IP_CAND, IP_INTRA_SEARCH, IP_INTRA_RECON, IP_INTER_RECON, IP_COST, IP_COPY, IP_IO, IP_TOTAL, IP_COUNT };
+enum { IP_MERGE = 0, IP_EARLY_SKIP, IP_ME, IP_FME, IP_CAND, IP_INTRA_SEARCH, IP_INTRA_RECON, IP_INTER_RECON, IP_COST, IP_COPY, IP_IO, IP_TOTAL, IP_WINNER_MC, IP_CTX, IP_ZERO_COEFF, IP_SYNTAX, IP_COUNT };
 
 typedef kvz_hip_cu_info CuInfo;  // one 4x4 unit of the frame's CU info (include/kvz_hip_dev.h)
 typedef KVZ_LDS u8 lu8;

@@ -6,5 +6,5 @@ timeout 300 python tools/inter_ctu_probe.py survey-416x240 $copies > gpurun_out/
 grep picture gpurun_out/${tag}_inter_probe.log
 if [ -f kvazaar_amd/lib/variants/libkvz_hip_ictu_prof.so ]; then
   KVZ_HIP_LIB=$PWD/kvazaar_amd/lib/variants/libkvz_hip_ictu_prof.so timeout 300 python tools/inter_ctu_probe.py survey-416x240 $copies > gpurun_out/${tag}_ictu_stage_profile.log 2>&1
-  grep -E "ictu-profile|picture 1" gpurun_out/${tag}_ictu_stage_profile.log | head -14
+  grep -E "ictu-profile|picture 1" gpurun_out/${tag}_ictu_stage_profile.log | head -20
 fi
