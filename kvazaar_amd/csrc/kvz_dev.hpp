@@ -1287,11 +1287,12 @@ int kvz_hip_dev_inter_ctu_pass_tiles(const uint8_t *src, const uint8_t *ref, con
   // the kernel's build: with the residual coder's contexts in the LDS context sets only where the picture's coefficients are priced with them (kvz_inter_ctu.hpp)
   const bool cabac_build = !(p->qp < p->fast_residual_cost && p->qp < 50);
   const void *kernel = cabac_build ? (const void *)kvz::inter_ctu_ticket_kernel_cabac : (const void *)kvz::inter_ctu_ticket_kernel_fast;
-  hipFuncAttributes fa;
-  KVZ_HIP_CHECK(hipFuncGetAttributes(&fa, kernel));
-  const int lds_fit = fa.sharedSizeBytes > 0 ? (int)(160 * 1024 / fa.sharedSizeBytes) : 8;
-  const int per_cu = env ? atoi(env) : (lds_fit < 8 ? lds_fit : 8);  // one wavefront per workgroup at up to 256 registers: two wavefronts per SIMD = eight workgroups per CU, LDS permitting
+  // resident workgroups (= wavefronts) per CU: what the kernel's registers and LDS allow -- a persistent grid, one workgroup per slot
+  int fit = 0;
+  KVZ_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, kernel, KVZ_ICTU_THREADS, 0));
+  const int per_cu = env ? atoi(env) : (fit > 0 ? fit : 8);
   int n_wg = n_cu * (per_cu > 0 ? per_cu : 8);
+  if (getenv("KVZ_HIP_INTER_VERBOSE")) fprintf(stderr, "kvz_hip inter pass: %s build, %d workgroups per CU x %d CUs\n", cabac_build ? "cabac" : "fast", per_cu, n_cu);
   if ((long)n_wg > total) n_wg = (int)total;
   if (n_wg > sc.n_slabs) {
     if (sc.slabs) KVZ_HIP_CHECK(hipFree(sc.slabs));

@@ -69,7 +69,7 @@ static long g_ic_phases[32]; static int g_ic_cat = 31;
 #define IC_FN_INTRA static inline
 #else
 #ifndef KVZ_ICTU_WAVES_PER_EU
-#define KVZ_ICTU_WAVES_PER_EU 2
+#define KVZ_ICTU_WAVES_PER_EU 3  /* 13.3 KB of LDS: 12 workgroups (wavefronts) per CU = 3 on a SIMD, at <= 168 VGPRs */
 #endif
 // KVZ_ICTU_INLINE: 0 -- every IC_FN a call; 1 -- the compiler decides; 2 -- everything inlined but the recursion (IC_FN_CALL).  A call whose callee needs more than the
 // caller-saved registers spills to scratch (HBM) in its prologue: calls are round trips to memory
@@ -199,16 +199,29 @@ struct InterConst {
 // A 32x32 block is interpolated, compared and transformed in 16x16 TILES (its four quadrants; smaller blocks are one tile): the sample buffers below are sized for a tile.
 struct InterLds {
   // ---- the work tree ----
-  alignas(8) u8 D[64 * 64 + 2 * 32 * 32];    // the decided picture: Y 64x64 | U 32x32 | V 32x32 (level 3's view; an 8x8 CU is evaluated in place)
+  // (the decided picture itself is the frame's reconstruction in HBM: a finished CU is written there once, commit_down, and read back one reference sample per lane)
   alignas(8) u8 orgq[32 * 32 + 2 * 16 * 16]; // source samples of the 32x32 quadrant being searched: Y | U | V (every sample loop runs inside one depth-1 CU)
   alignas(8) u8 C1[32 * 32 + 2 * 16 * 16];   // the depth-1 CU under evaluation
   alignas(8) u8 C2[16 * 16 + 2 * 8 * 8];     // the depth-2 CU under evaluation
+  alignas(8) u8 C3[8 * 8 + 2 * 4 * 4];       // the depth-3 CU under evaluation
   alignas(8) u8 Z3[8 * 8 + 2 * 4 * 4];       // cu_zero_coeff_cost's copy of a depth-3 CU's prediction (search.c:222 puts it into level 4)
   CuInfo Dcu[64];                            // CU records of the decided picture, one per 8x8 (the smallest CU)
-  alignas(8) u8 win[24 * IC_WS + 16];  // reference window of a tile (motion compensation, fractional search): rows staged from a dword-aligned column, sample (r, c) at
-                                       // win[r * IC_WS + win_xo + c]; 16 bytes of slack behind the last row for the horizontal pass's whole-dword reads
+  union {                               // the inter side's tile buffers | the parked prediction | the intra side's references and scores
+    struct {
+      alignas(8) u8 win[24 * IC_WS + 16];  // reference window of a tile (motion compensation, fractional search): rows staged from a dword-aligned column, sample (r, c) at
+                                           // win[r * IC_WS + win_xo + c]; 16 bytes of slack behind the last row for the horizontal pass's whole-dword reads
+      alignas(8) i16 g[8 * 72];            // 14-bit horizontal intermediates of a tile (24 rows, stride IC_GS); the SATD's eight slots of 72
+    };
+    alignas(8) u8 park[32 * 32 + 2 * 16 * 16];  // cu_zero_coeff_cost's copy of a depth-1 / depth-2 CU's prediction (search.c:222): between parking and the decision
+                                                // the CU is quantised and priced, nothing is predicted
+    struct {                               // (behind `win` only: the intra scores run the SATD, whose host form goes through g)
+      u32 mcost[36];                       // SATD of every intra mode of the CU under evaluation
+      u8 top[65], left[65], ftop[65], fleft[65];
+      int8_t modes[36];
+      int8_t todo[36];
+    };
+  };
   int win_xo;
-  alignas(8) i16 g[8 * 72];        // 14-bit horizontal intermediates of a tile (24 rows, stride IC_GS); the SATD's eight slots of 72
   union {                          // the sample buffers of stages that never overlap in time
     struct {
       alignas(8) u8 pred[4][16 * 16];  // the candidate planes of a fractional step (tile)
@@ -223,21 +236,20 @@ struct InterLds {
     };
   };
   u32 tsum[8];                     // satd_tiles: the eight tiles of a round
-  u32 mcost[36];                   // SATD of every intra mode of the CU under evaluation
-  u8 top[65], left[65], ftop[65], fleft[65];
   // Scalar work memory.  Every lane runs the same control flow on the same values, and with one wavefront per CTU the lanes are in lockstep: small arrays that are
   // indexed at run time live here once instead of 64 times in private (scratch) memory
-  UMap amvp[2], merge;
+  union {
+    UMap amvp[2];      // search_pu_inter's candidates of the two lists (dead once search_cu_inter has returned)
+    double costs[36];  // search_cu_intra's sort
+  };
+  UMap merge;
   PuSearch pu;
   Nbr nb;
-  double costs[36];
-  int8_t modes[36];
-  int8_t todo[36];
   unsigned long long intra_done;  // the modes L->mcost holds for the CU under evaluation
   int mvc_key[4];      // the PU and list L->mvc holds the AMVP predictors of ({x, y, w, list}; w = 0: none) -- the search asks for the same pair up to three times
   i16 mvc[2][2];
   int level_holds;     // after search_pu_inter: bit 0 / 1 = the level's luma / chroma samples are the prediction of the best merge candidate (merge.keys[0])
-  int px[8], py[8];
+  i16 px[8], py[8];   // the probes of a round: integer displacements
   u32 sad[8];
   int pbits[8];        // per probe: MVD bits against the cheaper predictor, -1 where the vector is not allowed
   u32 ssd[2];          // ssd_cu's result: luma, U + V
@@ -254,6 +266,7 @@ struct InterLds {
 static_assert(KVZ_ICTU_THREADS == 64, "the scalar work memory in LDS relies on one wavefront per CTU");
 
 // the program's state: picture geometry and pointers (the kernel arguments), the CTU at hand
+static_assert(sizeof(u32) * 36 + 4 * 65 + 72 <= 24 * IC_WS + 16, "the intra side's scratch must fit behind the window");
 struct InterState {
   InterFrames F;
   const InterModel *model;  // in HBM: the slice's initial context states are read from it where a coder starts (two copies per CTU row)
@@ -283,18 +296,24 @@ IC_WGVAR InterState g_ic;
 struct InterCtu {
   // ---- small things ----
   // Level lv's samples of plane c of the CU whose luma origin inside the LCU is (xl, yl) -- the CU under evaluation at depth lv (levels 1, 2: its candidate buffer;
-  // level 3: in place in the decided picture; level 4: the 8x8 side buffer) or, for level 3, any finished block
+  // level 3: the 8x8 candidate buffer; level 4: the 8x8 side buffer)
   IC_DEV PView lvl(int lv, int c, int xl, int yl)
   {
     const int sh = c ? 1 : 0;
     if (lv == 1) return PView{ (lu8 *)L->C1 + (c == 0 ? 0 : (c == 1 ? 1024 : 1280)), 32 >> sh };
     if (lv == 2) return PView{ (lu8 *)L->C2 + (c == 0 ? 0 : (c == 1 ? 256 : 320)), 16 >> sh };
     if (lv == 4) return PView{ (lu8 *)L->Z3 + (c == 0 ? 0 : (c == 1 ? 64 : 80)), 8 >> sh };
-    return PView{ (lu8 *)L->D + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)) + (yl >> sh) * (64 >> sh) + (xl >> sh), 64 >> sh };
+    return PView{ (lu8 *)L->C3 + (c == 0 ? 0 : (c == 1 ? 64 : 80)), 8 >> sh };
   }
-  // where cu_zero_coeff_cost parks the prediction of the depth-lv CU (search.c:222: the next level): the CU's own region of the decided picture, which its children
-  // will overwrite and nothing reads before them; the side buffer for a depth-3 CU, whose candidate IS that region
-  IC_DEV PView parked(int lv, int c, int xl, int yl) { return lvl(lv == 3 ? 4 : 3, c, xl, yl); }
+  // where cu_zero_coeff_cost parks the prediction of the depth-lv CU (search.c:222: the next level)
+  IC_DEV PView parked(int lv, int c, int xl, int yl)
+  {
+    if (lv == 3) return lvl(4, c, xl, yl);
+    const int w = 64 >> lv, sh = c ? 1 : 0;
+    return PView{ (lu8 *)L->park + (c == 0 ? 0 : (c == 1 ? w * w : w * w + (w * w >> 2))), w >> sh };
+  }
+  // the luma prediction of the best merge candidate so far (search_pu_inter): the fractional search's candidate planes, which nothing uses before the motion search
+  IC_DEV PView best_luma(int lv) { return PView{ (lu8 *)&L->pred[0][0], 64 >> lv }; }
   // the source samples at LCU position (xl, yl) [luma coordinates] of plane c: inside the quadrant staged by load_org_quadrant
   IC_DEV PView orgv(int c, int xl, int yl)
   {
