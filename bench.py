@@ -430,6 +430,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the auxiliary legs (chain, chain_d2h, configs_extra); they only run at --gpus 1")
     ap.add_argument("--only", default="", choices=["", "inter", "medium", "intra4k", "entropy"], help="developer / profiling: run ONE auxiliary leg at a reduced size and print its "
                     "entry (tools/pmc_leg.sh collects the leg's counters this way); the headline is not measured")
+    ap.add_argument("--inter-sequences", type=int, default=0, help="developer: sequences per launch of the inter leg (default 384; 96 with --only inter)")
     ap.add_argument("--wpp", action="store_true", help="with --tiles: keep WPP on (kvazaar --tiles CxR --wpp); by default tiles imply --no-wpp as in kvazaar (cfg.c:925-978): "
                                                        "one coder per tile in raster order, i.e. one serial CTU chain per tile")
     ap.add_argument("--no-wpp", action="store_true", help="kvazaar --no-wpp: one serial CTU chain per picture (contexts run from the end of a row into the next)")
@@ -681,7 +682,7 @@ def tiled_inter_bench(args, lib, dist, torch, rank, world, HipBatch, cost_model)
 def only_leg(args, lib, model_for, HipBatch):
     """one auxiliary leg at a reduced size (the kernels' counters per CTU / picture do not depend on the batch)"""
     if args.only == "inter":
-        out = inter_leg(args, lib, model_for, HipBatch, synth_frames(3840, 2160, 4, clip_seed(3840, 2160)), sequences=96)
+        out = inter_leg(args, lib, model_for, HipBatch, synth_frames(3840, 2160, 4, clip_seed(3840, 2160)), sequences=args.inter_sequences or 96)
         out.pop("chain", None)
     elif args.only == "medium":
         out = leg_medium(args, lib, model_for, HipBatch, n_med=48)
@@ -705,7 +706,7 @@ def only_leg(args, lib, model_for, HipBatch):
     print(json.dumps(out))
 
 
-def inter_leg(args, lib, model_for, HipBatch, pictures, sequences=192):
+def inter_leg(args, lib, model_for, HipBatch, pictures, sequences=384):
     """BASELINE config 4 (3840x2160 `--preset veryfast --gop lp-g4d3t1 -q 22`) on the device, as far as the inter CTU pass goes: the I picture through the batched
     intra pass + deblocking + SAO (picture QP 21: intra_qp_offset -1), then the first B picture (picture QP 25: GOP layer 3) of `sequences` independent sequences in
     one launch of kvz_hip_dev_inter_ctu_pass -- every sequence the same clip, so that one result can be checked against the reference encoder's CU decisions
@@ -828,7 +829,7 @@ def inter_leg(args, lib, model_for, HipBatch, pictures, sequences=192):
             "verify": {"i_picture_reconstruction_equals_reference_encoder": bool(i_ok), "b_picture_cu_decisions_equal_reference_encoder": bool(cu_ok),
                        "copies_consistent": bool(np.array_equal(cu_first, cu_last))},
             "chain": chain,
-            "note": "one wavefront per CTU, work tree / program state / tables in LDS, eight CTUs per CU (DESIGN.md 3.8); `chain` carries the sequence on through the loop filters and the next pictures"}
+            "note": f"one wavefront per CTU, candidates / program state / tables in LDS, twelve CTUs per CU (DESIGN.md 3.8); {sequences} sequences per launch: a 4K picture alone is a WPP chain of 127 CTU steps (~0.94 s); `chain` carries the sequence on through the loop filters and the next pictures"}
 
 
 def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedResults):
@@ -942,7 +943,7 @@ def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedRes
         result["configs_extra"] = [leg_intra4k(args, lib, model_for, HipBatch), leg_tiles4k(args, lib, model_for, HipBatch)]
         # ---- BASELINE config 4: `--preset veryfast --gop lp-g4d3t1` at 3840x2160: the first B picture of many independent sequences ----
         try:
-            result["configs_extra"].append(inter_leg(args, lib, model_for, HipBatch, synth_frames(3840, 2160, 4, clip_seed(3840, 2160))))
+            result["configs_extra"].append(inter_leg(args, lib, model_for, HipBatch, synth_frames(3840, 2160, 4, clip_seed(3840, 2160)), sequences=args.inter_sequences or 384))
         except Exception as e:  # auxiliary: never take the headline down
             result["configs_extra"].append({"workload": "3840x2160 --preset veryfast --gop lp-g4d3t1 (BASELINE config 4)", "error": repr(e)})
         result["configs_extra"].append(leg_medium(args, lib, model_for, HipBatch))

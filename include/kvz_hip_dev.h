@@ -163,6 +163,10 @@ typedef struct kvz_hip_inter_params {
 } kvz_hip_inter_params;
 int  kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kvz_hip_cu_info *ref_cu, uint8_t *rec, kvz_hip_cu_info *cu, int16_t *coeff, int width,
                                 int height, int n_pictures, const kvz_hip_inter_params *params);
+/* Threads and devices: the pass keeps its work memory (ticket list, done flags, contexts, the workgroups' level slabs) per CALLING THREAD and per DEVICE, like the
+ * stream it is queued on -- two threads, or two devices of one process, never share it; calls of one thread are serialised on its stream.  `rec` is read back by the pass
+ * itself (a finished CU is the intra reference of the next): it must not alias `ref`.  The struct grows at the end: zero it before filling it, and compile the caller
+ * against the headers of the library it links (a caller built with a shorter struct hands the pass whatever lies behind it). */
 /* ... with every picture's own tile origin: tile_xy (DEVICE pointer, n_pictures x {x, y}, multiples of 8 inside the reference frame; NULL: params->tile_x / tile_y for
  * all) -- the tiles of one size of MANY places of the grid in one launch (without WPP a tile offers one CTU at a time: the launch needs that many more chains).
  * n_references (0: one per picture): `ref` / `ref_cu` hold that many frames and picture p predicts from frame p % n_references -- several tiles of the same frame. */

@@ -365,6 +365,26 @@ struct InterCtu {
 #endif
   }
 
+  // four samples of HBM at any alignment; acc + the sum of absolute differences of two groups of four samples (v_sad_u8)
+  IC_DEV u32 glb_read32u(const gu8 *p)
+  {
+#ifdef KVZ_HOSTSIM
+    return (u32)p[0] | (u32)p[1] << 8 | (u32)p[2] << 16 | (u32)p[3] << 24;
+#else
+    typedef u32 __attribute__((aligned(1))) u32_any;
+    return *(const KVZ_GLB u32_any *)p;
+#endif
+  }
+  IC_DEV u32 sad4(u32 a, u32 b, u32 acc)
+  {
+#ifdef KVZ_HOSTSIM
+    for (int j = 0; j < 4; j++) { const int d = (int)((a >> (8 * j)) & 255u) - (int)((b >> (8 * j)) & 255u); acc += (u32)(d < 0 ? -d : d); }
+    return acc;
+#else
+    return __builtin_amdgcn_sad_u8(a, b, acc);
+#endif
+  }
+
   // byte-string helpers of the horizontal interpolation pass (v_alignbyte_b32, v_dot4_i32_i8; plain C++ for the host simulation)
 #ifdef KVZ_HOSTSIM
   IC_DEV u32 alignbyte(u32 hi, u32 lo, u32 n) { return (u32)(((((unsigned long long)hi) << 32) | lo) >> (8 * (n & 3))); }
