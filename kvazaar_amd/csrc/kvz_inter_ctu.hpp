@@ -251,10 +251,12 @@ struct InterLds {
   int level_holds;     // after search_pu_inter: bit 0 / 1 = the level's luma / chroma samples are the prediction of the best merge candidate (merge.keys[0])
   i16 px[8], py[8];   // the probes of a round: integer displacements
   u32 sad[8];
-  int pbits[8];        // per probe: MVD bits against the cheaper predictor, -1 where the vector is not allowed
+  i16 pbits[8];        // per probe: MVD bits against the cheaper predictor, -1 where the vector is not allowed
   u32 ssd[2];          // ssd_cu's result: luma, U + V
   ICtxL ctx;  // state->search_cabac's contexts (indexed at run time on every priced bin)
-  ICtxL pre[4], post[4];  // search_cu's copies of them, per depth (search.c:655, 956)
+  ICtxL pre[4], post[3];  // search_cu's copies of them, per depth (search.c:655, 956; a depth-3 CU is never split)
+  struct { double cost, split_cost; } fr[3];  // search_cu's locals that live across its children (depth 0 .. 2): nothing of a depth is held in registers while its
+  u8 child[4];                               // children run; a depth's position follows from the child indices above it
   ICtxL row;              // the row coder's contexts at the start of the CTU (the finished CTU's syntax runs on them)
   CuInfo cur_cu[4];      // the CU under evaluation at each depth of the recursion
   struct { int mvx, mvy; double cost, bits; } best;  // check_mv_cost's best so far
