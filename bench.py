@@ -829,7 +829,7 @@ def inter_leg(args, lib, model_for, HipBatch, pictures, sequences=384):
             "verify": {"i_picture_reconstruction_equals_reference_encoder": bool(i_ok), "b_picture_cu_decisions_equal_reference_encoder": bool(cu_ok),
                        "copies_consistent": bool(np.array_equal(cu_first, cu_last))},
             "chain": chain,
-            "note": f"one wavefront per CTU, candidates / program state / tables in LDS, twelve CTUs per CU (DESIGN.md 3.8); {sequences} sequences per launch: a 4K picture alone is a WPP chain of 127 CTU steps (~0.94 s); `chain` carries the sequence on through the loop filters and the next pictures"}
+            "note": f"one wavefront per CTU, candidates / program state / tables in LDS, twelve CTUs per CU (DESIGN.md 3.8); {sequences} sequences per launch: a 4K picture alone is a WPP chain of 127 CTU steps (~0.94 s); `chain` carries the sequence on through the loop filters and the next pictures; the traffic above the algorithmic bytes is scratch: the 85 recursion calls of a CTU each save the callee-saved registers their body clobbers (~1.1 MB written, ~0.5 MB read per CTU; profiles/experiments/README.md r04_v for the forms without calls, all slower)"}
 
 
 def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedResults):
