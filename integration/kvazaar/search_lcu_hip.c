@@ -115,6 +115,13 @@ static int eligible(const encoder_state_t *state)
   REQUIRE(cfg->early_skip && cfg->max_merge == 5 && cfg->zero_coeff_rdo && !cfg->smp_enable && !cfg->amp_enable && !cfg->rdoq_enable);
   REQUIRE(cfg->pu_depth_inter.min[0] == 1 && (cfg->pu_depth_inter.max[0] == 2 || cfg->pu_depth_inter.max[0] == 3));
   REQUIRE(cfg->pu_depth_intra.min[0] == 2 && cfg->pu_depth_intra.max[0] == 3);
+  {  /* search.c:674-687 takes the depths of the picture's GOP layer where the configuration sets them (>= 0): the pass is handed layer 0's */
+    const int layer = cfg->gop_len != 0 ? cfg->gop[fr->gop_offset].layer - 1 : 0;
+    REQUIRE(layer >= 0 && layer < KVZ_MAX_GOP_LAYERS);
+    REQUIRE((cfg->pu_depth_inter.min[layer] < 0 || cfg->pu_depth_inter.min[layer] == cfg->pu_depth_inter.min[0]) && (cfg->pu_depth_inter.max[layer] < 0 || cfg->pu_depth_inter.max[layer] == cfg->pu_depth_inter.max[0]));
+    REQUIRE((cfg->pu_depth_intra.min[layer] < 0 || cfg->pu_depth_intra.min[layer] == cfg->pu_depth_intra.min[0]) && (cfg->pu_depth_intra.max[layer] < 0 || cfg->pu_depth_intra.max[layer] == cfg->pu_depth_intra.max[0]));
+  }
+  REQUIRE(!cfg->fast_coeff_table_fn);  /* the pass prices with the built-in fast-coefficient-cost weights (kvz_hip_default_coeff_weights): a custom --fast-coeff-table stays with kvz_search_lcu */
   REQUIRE(cfg->fast_residual_cost_limit >= 0 && cfg->fast_residual_cost_limit <= 51 && !cfg->intra_rdo_et);  /* the pass prices coefficients either way (rdo.c:311-340) */
   REQUIRE(state->tile->frame->width % 8 == 0 && state->tile->frame->height % 8 == 0);
 #undef REQUIRE
@@ -343,6 +350,7 @@ static unsigned zorder16(int x, int y) /* cu.h:385-421 xy_to_zorder for 4-sample
 static struct {
   int w, h, ready, busy;
   int32_t num;
+  const void *owner;  /* the picture's videoframe: with the frame number the key of what the buffers hold (two encoders of one process count the same numbers) */
   uint8_t *src, *ref, *rec;
   kvz_hip_cu_info *ref_cu, *cu;
   int16_t *coeff;
@@ -445,8 +453,8 @@ static void search_lcu_inter(encoder_state_t *state, int x, int y)
   videoframe_t *frame = state->tile->frame;
   pthread_mutex_lock(&g_lock);
   while (g_inter.busy) pthread_cond_wait(&g_cond, &g_lock);
-  if (g_inter.num != state->frame->num || !g_inter.ready) {
-    g_inter.busy = 1; g_inter.ready = 0; g_inter.num = state->frame->num;
+  if (g_inter.num != state->frame->num || g_inter.owner != (const void *)frame || !g_inter.ready) {
+    g_inter.busy = 1; g_inter.ready = 0; g_inter.num = state->frame->num; g_inter.owner = frame;
     pthread_mutex_unlock(&g_lock);
     inter_picture(state);
     pthread_mutex_lock(&g_lock);

@@ -40,8 +40,10 @@ static void encode_coeff_nxn_hip(encoder_state_t *const state, cabac_data_t *con
   }
   enum { CAPACITY = 8192 };  /* a 32x32 block: 64 groups x (16 + 1 + 8 + 1 + 1 + 48) records at the very worst */
   static __thread uint32_t records[CAPACITY];
-  const int n = kvz_hip_coeff_nxn_bins(coeff, width, type, scan_mode, records, CAPACITY);
-  if (n > CAPACITY) { kvz_encode_coeff_nxn_generic(state, cabac, coeff, width, type, scan_mode, tr_skip, bits_out); return; }
+  /* the buffer the call moves both ways is sized by the block: per 4x4 group at most 59 records (16 + 1 + 8 + 1 + 1 + 32), the last position 22: 6 per coefficient covers it */
+  const int cap = width * width * 6 < CAPACITY ? width * width * 6 : CAPACITY;
+  const int n = kvz_hip_coeff_nxn_bins(coeff, width, type, scan_mode, records, cap);
+  if (n > cap) { kvz_encode_coeff_nxn_generic(state, cabac, coeff, width, type, scan_mode, tr_skip, bits_out); return; }
   for (int i = 0; i < n; i++) {
     const uint32_t r = records[i];
     if ((r >> 30) == 0) {

@@ -127,9 +127,10 @@ class HipBatch:
         flags = None if not_last is None else np.ascontiguousarray(not_last, np.uint8)  # tiles: 1 = other tiles of the slice follow
         assert flags is None or flags.size == self.n
         rows = 1 if model.no_wpp else (self.h + 63) // 64
-        capacity = capacity or self.n * self.w * self.h * 2 + 65536
+        capacity = capacity or entropy_capacity(self.n, self.w, self.h)
         if getattr(self, "_entropy_out", None) is None or self._entropy_out.nbytes < capacity:
-            self._entropy_out = np.empty(capacity, np.uint8)
+            pinned_free(self.lib, getattr(self, "_entropy_ptr", None))
+            self._entropy_ptr, self._entropy_out = pinned_bytes(self.lib, capacity)  # the slice data is downloaded by the call: a pinned destination, no staging copy
         sizes = np.zeros((self.n, rows), np.uint32)
         total = f(self.handle, C.byref(model), int(sao), flags.ctypes.data if flags is not None else None, self._entropy_out.ctypes.data, capacity, sizes.ctypes.data)
         if total < 0:
@@ -188,6 +189,31 @@ class HipBatch:
         if self.handle:
             self.lib.kvz_hip_batch_destroy(self.handle)
             self.handle = None
+        pinned_free(self.lib, getattr(self, "_entropy_ptr", None))
+        self._entropy_ptr = self._entropy_out = None
+
+
+def entropy_capacity(n, w, h):
+    """room for the slice data of n pictures: generous for small batches (noise at a low QP codes to more than the pictures' own bytes), half the pictures' bytes for big
+    ones (pinned memory; the call fails with a message when a batch outgrows it and the caller can pass its own capacity)"""
+    full = n * w * h * 2 + 65536
+    return full if full <= (256 << 20) else n * w * h * 3 // 4 + 65536
+
+
+def pinned_bytes(lib, nbytes):
+    """kvz_hip_host_alloc'ed (hipHostMalloc) byte buffer -> (pointer, numpy view)"""
+    lib.kvz_hip_host_alloc.restype = C.c_void_p
+    lib.kvz_hip_host_alloc.argtypes = [C.c_size_t]
+    p = lib.kvz_hip_host_alloc(nbytes)
+    if not p:
+        raise MemoryError(f"kvz_hip_host_alloc({nbytes})")
+    return p, np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(p))
+
+
+def pinned_free(lib, p):
+    if p:
+        lib.kvz_hip_host_free.argtypes = [C.c_void_p]
+        lib.kvz_hip_host_free(p)
 
 
 class PinnedResults:

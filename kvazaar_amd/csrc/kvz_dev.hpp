@@ -9,6 +9,7 @@
 
 #include <functional>
 #include <mutex>
+#include <chrono>
 #include <vector>
 
 #include "../../include/kvz_hip_dev.h"
@@ -1537,6 +1538,9 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
 {
   EntropyScratch &S = entropy_scratch(device);
   std::lock_guard<std::mutex> guard(S.lock);
+  static const bool times = getenv("KVZ_HIP_ENTROPY_TIMES") != nullptr;  // developer: host-side phase clock on stderr
+  auto t_last = std::chrono::steady_clock::now();
+  auto mark = [&](const char *what) { if (!times) return; const auto now = std::chrono::steady_clock::now(); fprintf(stderr, "kvz_hip entropy: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count()); t_last = now; };
   const int ctus = wc * hc, rows = no_wpp ? 1 : hc;
   size_t budget = 49152;
   if (const char *e = getenv("KVZ_HIP_ENTROPY_SCRATCH_MB")) { const long v = atol(e); if (v > 0) budget = (size_t)v; }
@@ -1566,6 +1570,7 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
     KVZ_HIP_CHECK(hipMemcpyAsync(counts.data(), d_nbins, (size_t)items * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     KVZ_HIP_CHECK(hipMemcpyAsync(bound_bits.data(), d_nbits, (size_t)items * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     KVZ_HIP_CHECK(hipStreamSynchronize(stream));
+    mark("bins + counts down");
     uint32_t most = 0;
     for (uint32_t c : counts) most = c > most ? c : most;
     const bool again = most > cap;
@@ -1581,6 +1586,7 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
         scratch_bytes += (((bits + 7) / 8 + 16) * 3 / 2 + 15) & ~15ull;
       }
       d_scratch = (uint8_t *)S.need(S.scratch, scratch_bytes ? scratch_bytes : 16);
+      mark("host: bounds");
       KVZ_HIP_CHECK(hipMemcpyAsync(d_bound_offsets, bound_offsets.data(), (size_t)streams * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
       static const int lanes = [] { const char *e = getenv("KVZ_HIP_ENTROPY_LANES"); const int v = e ? atoi(e) : 16; return v == 64 || v == 32 || v == 8 ? v : 16; }();
       if (!no_wpp) hipLaunchKernelGGL(dev_entropy_row_ctx_kernel<8>, dim3((unsigned)((nf + 7) / 8)), dim3(8), 0, stream, J, device_tables());
@@ -1594,6 +1600,7 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
       sizes.resize((size_t)streams);
       KVZ_HIP_CHECK(hipMemcpyAsync(sizes.data(), d_sizes, (size_t)streams * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       KVZ_HIP_CHECK(hipStreamSynchronize(stream));
+      mark("row contexts + coder");
       offsets.resize((size_t)streams);
       unsigned long long chunk_bytes = 0;
       for (long i = 0; i < streams; i++) { offsets[(size_t)i] = chunk_bytes; chunk_bytes += sizes[(size_t)i]; }
@@ -1607,6 +1614,7 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
         KVZ_HIP_CHECK(hipGetLastError());
         KVZ_HIP_CHECK(hipMemcpyAsync(out + total, d_out, chunk_bytes, hipMemcpyDeviceToHost, stream));
         KVZ_HIP_CHECK(hipStreamSynchronize(stream));
+        mark("compact + slice data down");
         memcpy(substream_bytes + (size_t)f0 * rows, sizes.data(), (size_t)streams * sizeof(uint32_t));
         total += chunk_bytes;
         f0 += nf;

@@ -139,9 +139,11 @@ class InterPictures:
         if self.d_coeff is None:
             raise RuntimeError("InterPictures(..., with_levels=True) keeps the levels the entropy coder needs")
         rows = 1 if params.no_wpp else (self.h + 63) // 64
-        capacity = self.n * self.w * self.h * 2 + 65536
+        from .batch import entropy_capacity
+        capacity = entropy_capacity(self.n, self.w, self.h)
         if self._entropy_out is None:
-            self._entropy_out = np.empty(capacity, np.uint8)
+            from .batch import pinned_bytes
+            self._entropy_ptr, self._entropy_out = pinned_bytes(self.lib, capacity)  # pinned: the call downloads the slice data straight into it
         sizes = np.zeros((self.n, rows), np.uint32)
         total = self.lib.kvz_hip_dev_entropy_code_inter(self.d_cu, self.d_ref_cu, self.d_coeff, self.w, self.h, self.n, C.addressof(params), self._entropy_out.ctypes.data,
                                                         capacity, sizes.ctypes.data)
@@ -169,6 +171,10 @@ class InterPictures:
             self.dev.free(self.d_dbk)
         if self.d_coeff is not None:
             self.dev.free(self.d_coeff)
+        if getattr(self, "_entropy_ptr", None):
+            from .batch import pinned_free
+            pinned_free(self.lib, self._entropy_ptr)
+            self._entropy_ptr = self._entropy_out = None
 
 
 class TiledInterSequences:
