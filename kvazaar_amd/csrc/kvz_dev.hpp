@@ -1565,7 +1565,9 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
     if (not_last) KVZ_HIP_CHECK(hipMemcpyAsync(d_not_last, not_last + f0, (size_t)nf, hipMemcpyHostToDevice, stream));
     EntropyJob J = job(f0, nf);
     J.bins = d_bins; J.nbins = d_nbins; J.nbits = d_nbits; J.cap = cap; J.row_ctx = d_rowctx; J.not_last = d_not_last;
-    hipLaunchKernelGGL(dev_entropy_bins_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, stream, J, device_tables(), items);
+    static const bool serial_bins = [] { const char *e = getenv("KVZ_HIP_ENTROPY_BINS"); return e && !strcmp(e, "serial"); }();  // developer: the one-lane-walks-it-all form of stage 1
+    if (serial_bins) hipLaunchKernelGGL(dev_entropy_bins_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, stream, J, device_tables(), items);
+    else hipLaunchKernelGGL(dev_entropy_bins_phased_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, stream, J, device_tables(), items);
     counts.resize((size_t)items); bound_bits.resize((size_t)items);
     KVZ_HIP_CHECK(hipMemcpyAsync(counts.data(), d_nbins, (size_t)items * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     KVZ_HIP_CHECK(hipMemcpyAsync(bound_bits.data(), d_nbits, (size_t)items * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));

@@ -66,6 +66,40 @@ struct BinSink {
     if (bits > 0) put(KVZ_EB_EP(value, bits));
   }
   KVZ_DEV void trm(int v) { put(KVZ_EB_TRM(v)); bits += 7; }
+  // the residual of the transform block whose levels start `off` into the CTU's block: here and now
+  KVZ_DEV void tu(const Tables *tb, const i16 *ctu, int off, int log2_size, int type, int scan_mode) { entropy_coeff_nxn(*this, tb, ctu + off, log2_size, type, scan_mode); }
+};
+// ... or later: a sink that queues what follows the first transform block of a CU -- records as they are, blocks as descriptors (kind 3: offset | log2 - 2 << 13 |
+// chroma << 15 | scan << 16) -- so that the bin stage can run the blocks of all its lanes a coefficient group at a time (entropy_ctu_bins_phased).  A CU queues at most
+// 26 items (a 64x64 CU: two flags, then four times two chroma flags, a luma flag and three blocks).
+#define KVZ_EB_TU(off, log2_size, type, scan) (0xc0000000u | (u32)(off) | ((u32)((log2_size) - 2) << 13) | ((u32)((type) != 0) << 15) | ((u32)(scan) << 16))
+struct DeferSink {
+  enum { QCAP = 32 };
+  BinSink out;
+  u32 *q;  // QCAP items of this lane, `qs` words apart (LDS: item-major, the lanes of a wavefront side by side)
+  int qs, head, tail;
+  KVZ_DEV bool queued() const { return head < tail; }
+  KVZ_DEV u32 front() const { return q[head * qs]; }
+  KVZ_DEV void item(u32 r) { if (head == tail) head = tail = 0; q[tail++ * qs] = r; }
+  KVZ_DEV void ctx(int c, int v) { if (queued()) item(KVZ_EB_CTX(c, v ? 1 : 0)); else out.ctx(c, v); }
+  KVZ_DEV void ep(u32 value, int bits)
+  {
+    if (!queued()) { out.ep(value, bits); return; }
+    while (bits > 16) { bits -= 16; item(KVZ_EB_EP(value >> bits, 16)); value &= (1u << bits) - 1; }
+    if (bits > 0) item(KVZ_EB_EP(value, bits));
+  }
+  KVZ_DEV void trm(int v) { if (queued()) item(KVZ_EB_TRM(v)); else out.trm(v); }
+  KVZ_DEV void tu(const Tables *, const i16 *, int off, int log2_size, int type, int scan_mode) { item(KVZ_EB_TU(off, log2_size, type, scan_mode)); }
+  // the records in front of the queue go out; true: a block is at its head now
+  KVZ_DEV bool flush_records()
+  {
+    while (head < tail && (front() >> 30) != 3u) {
+      const u32 r = q[head++ * qs], kind = r >> 30;
+      out.put(r);
+      out.bits += kind == 0 ? 6u : (kind == 1 ? ((r >> 16) & 0x3fu) : 7u);
+    }
+    return head < tail;
+  }
 };
 
 KVZ_DEV unsigned entropy_zorder(int x, int y)  // cu.h:385-421 with width 64: Morton index of the 4x4 block times 16
@@ -117,22 +151,22 @@ struct EntropyCtu {  // one CTU of one picture
   KVZ_DEV bool cbf(int c, int xl, int yl, int depth) const
   {
     const int w = 64 >> depth;
-    if (c == 0) return entropy_any(ctu + entropy_zorder(xl, yl), w * w);
     const int cw = depth >= 3 ? 4 : w / 2;
+    if (c == 0) return entropy_any(ctu + entropy_zorder(xl, yl), w * w);
     return entropy_any(ctu + (c == 1 ? 4096 : 5120) + entropy_zorder((xl & ~7) / 2, (yl & ~7) / 2), cw * cw);
   }
   // encode_transform_unit (encode_coding_tree.c:117-190) of the block at (x, y), tree depth `depth`
-  KVZ_DEV void transform_unit(BinSink &s, int x, int y, int depth, bool cb_y, bool cu_u, bool cu_v) const
+  template <class S> KVZ_DEV void transform_unit(S &s, int x, int y, int depth, bool cb_y, bool cu_u, bool cu_v) const
   {
     const int xl = x & 63, yl = y & 63, log2w = 6 - depth, log2c = depth == 4 ? 2 : log2w - 1;
-    if (cb_y) entropy_coeff_nxn(s, tb, ctu + entropy_zorder(xl, yl), log2w, 0, entropy_scan_order(mode_at(x, y), depth));
+    if (cb_y) s.tu(tb, ctu, (int)entropy_zorder(xl, yl), log2w, 0, entropy_scan_order(mode_at(x, y), depth));
     if (depth == 4 && (x % 8 == 0 || y % 8 == 0)) return;  // the 4x4 chroma blocks follow the last luma block, under the first PU's mode
     const int cscan = entropy_scan_order(mode_at(x & ~7, y & ~7), depth), cxl = (xl & ~7) / 2, cyl = (yl & ~7) / 2;
-    if (cu_u) entropy_coeff_nxn(s, tb, ctu + 4096 + entropy_zorder(cxl, cyl), log2c, 2, cscan);
-    if (cu_v) entropy_coeff_nxn(s, tb, ctu + 5120 + entropy_zorder(cxl, cyl), log2c, 2, cscan);
+    if (cu_u) s.tu(tb, ctu, 4096 + (int)entropy_zorder(cxl, cyl), log2c, 2, cscan);
+    if (cu_v) s.tu(tb, ctu, 5120 + (int)entropy_zorder(cxl, cyl), log2c, 2, cscan);
   }
   // encode_transform_coeff (encode_coding_tree.c:193-310) of an intra CU: one level of implicit split at most (64x64 CUs, NxN CUs), no split_transform_flag is ever coded
-  KVZ_DEV void transform_tree(BinSink &s, int x, int y, int depth, bool nxn) const
+  template <class S> KVZ_DEV void transform_tree(S &s, int x, int y, int depth, bool nxn) const
   {
     const int xl = x & 63, yl = y & 63;
     const bool cu_u = cbf(1, xl, yl, depth), cu_v = cbf(2, xl, yl, depth);
@@ -171,7 +205,7 @@ struct EntropyCtu {  // one CTU of one picture
     }
   }
   // the leaf of kvz_encode_coding_tree: part_mode, encode_intra_coding_unit (encode_coding_tree.c:467-652), the transform tree
-  KVZ_DEV void coding_unit(BinSink &s, int x, int y, int depth) const
+  template <class S> KVZ_DEV void coding_unit(S &s, int x, int y, int depth) const
   {
     const bool nxn = depth == 3 && part && part[(y >> 3) * w8 + (x >> 3)];
     if (depth == 3) s.ctx(KVZ_HIP_CX_PART, !nxn);
@@ -204,11 +238,17 @@ struct EntropyCtu {  // one CTU of one picture
     transform_tree(s, x, y, depth, nxn);
   }
   // kvz_encode_coding_tree (encode_coding_tree.c:745-900) without recursion: a stack of (x, y, depth) nodes, children pushed in reverse coding order
-  KVZ_DEV void coding_tree(BinSink &s, int cx, int cy) const
+  // ... one node of it: a split node pushes its children, a leaf is coded (node: x offset >> 3 in bits 0..3, y offset >> 3 in bits 4..7, depth in bits 8..9)
+  template <class S> KVZ_DEV void coding_tree(S &s, int cx, int cy) const
   {
-    int stack[16], sp = 0;
-    stack[sp++] = 0;  // node: x offset >> 3 in bits 0..3, y offset >> 3 in bits 4..7, depth in bits 8..9
-    while (sp > 0) {
+    u16 stack[16];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp > 0) tree_step(s, stack, sp, cx, cy);
+  }
+  template <class S, class STK> KVZ_DEV void tree_step(S &s, STK &stack, int &sp, int cx, int cy) const
+  {
+    {
       const int node = stack[--sp], depth = node >> 8, x = cx + ((node & 15) << 3), y = cy + (((node >> 4) & 15) << 3);
       const int w = 64 >> depth, half = w >> 1;
       const int cur_depth = this->depth[(y >> 3) * w8 + (x >> 3)];
@@ -224,18 +264,18 @@ struct EntropyCtu {  // one CTU of one picture
         }
         if (split_flag || border) {
           const int h8 = half >> 3, base = (node & 0xff) | ((depth + 1) << 8);
-          if (!border || (border_split_x && border_split_y)) stack[sp++] = base + h8 + (h8 << 4);
-          if (!border_y || border_split_y) stack[sp++] = base + (h8 << 4);
-          if (!border_x || border_split_x) stack[sp++] = base + h8;
-          stack[sp++] = base;
-          continue;
+          if (!border || (border_split_x && border_split_y)) stack[sp++] = (u16)(base + h8 + (h8 << 4));
+          if (!border_y || border_split_y) stack[sp++] = (u16)(base + (h8 << 4));
+          if (!border_x || border_split_x) stack[sp++] = (u16)(base + h8);
+          stack[sp++] = (u16)base;
+          return;
         }
       }
       coding_unit(s, x, y, depth);
     }
   }
   // encode_sao_color (encoderstate.c:467-517) from the packed decision records (kvz_sao.hpp SaoRec: type | class << 8 | band << 16 | five offsets from bit 24)
-  KVZ_DEV static void sao_color(BinSink &s, SaoRec first, SaoRec own, int color)
+  template <class S> KVZ_DEV static void sao_color(S &s, SaoRec first, SaoRec own, int color)
   {
     const int type = (int)(first & 0xff);
     if (color != 2) {
@@ -344,7 +384,7 @@ struct EntropyCtuB {
     }
     while (n < 2) { mv_cand[n][0] = 0; mv_cand[n][1] = 0; n++; }
   }
-  KVZ_DEV static void merge_idx(BinSink &s, int idx)  // encode_coding_tree.c:323-338
+  template <class S> KVZ_DEV static void merge_idx(S &s, int idx)  // encode_coding_tree.c:323-338
   {
     for (int ui = 0; ui < 4; ui++) {
       const int symbol = ui != idx;
@@ -352,7 +392,7 @@ struct EntropyCtuB {
       if (!symbol) break;
     }
   }
-  KVZ_DEV static void ex_golomb(BinSink &s, u32 symbol, u32 count)  // cabac.c:556-586 kvz_cabac_write_ep_ex_golomb
+  template <class S> KVZ_DEV static void ex_golomb(S &s, u32 symbol, u32 count)  // cabac.c:556-586 kvz_cabac_write_ep_ex_golomb
   {
     u32 bins = 0;
     int num_bins = 0;
@@ -361,7 +401,7 @@ struct EntropyCtuB {
     bins = (bins << count) | symbol;
     s.ep(bins, num_bins + (int)count);
   }
-  KVZ_DEV static void mvd(BinSink &s, int hor, int ver)  // encode_coding_tree.c:1062-1112 kvz_encode_mvd
+  template <class S> KVZ_DEV static void mvd(S &s, int hor, int ver)  // encode_coding_tree.c:1062-1112 kvz_encode_mvd
   {
     const u32 ah = (u32)iabs(hor), av = (u32)iabs(ver);
     s.ctx(KVZ_EB_CX_MVD, hor != 0);
@@ -372,7 +412,7 @@ struct EntropyCtuB {
     if (ver) { if (av > 1) ex_golomb(s, av - 2, 1); s.ep(ver > 0 ? 0 : 1, 1); }
   }
   KVZ_DEV static bool cbf_set(u32 cbf, int depth, int plane) { const u32 masks[5] = { 0x1f, 0x0f, 0x07, 0x03, 0x1 }; return (cbf & (masks[depth] << (5 * plane))) != 0; }  // cu.h:510-569
-  KVZ_DEV void coding_unit(BinSink &s, int x, int y, int depth) const
+  template <class S> KVZ_DEV void coding_unit(S &s, int x, int y, int depth) const
   {
     const kvz_hip_cu_info &cur = at(x, y);
     const int w = 64 >> depth, xl = x - cx, yl = y - cy, log2w = 6 - depth, log2c = depth == 3 ? 2 : log2w - 1;
@@ -431,15 +471,20 @@ struct EntropyCtuB {
       s.ctx(KVZ_HIP_CX_CBF_LUMA + 1, cb_y);
       scan = entropy_scan_order(cur.mode, depth);
     }
-    if (cb_y) entropy_coeff_nxn(s, tb, ctu + entropy_zorder(xl, yl), log2w, 0, scan);
-    if (cb_u) entropy_coeff_nxn(s, tb, ctu + 4096 + entropy_zorder(xl / 2, yl / 2), log2c, 2, scan);
-    if (cb_v) entropy_coeff_nxn(s, tb, ctu + 5120 + entropy_zorder(xl / 2, yl / 2), log2c, 2, scan);
+    if (cb_y) s.tu(tb, ctu, (int)entropy_zorder(xl, yl), log2w, 0, scan);
+    if (cb_u) s.tu(tb, ctu, 4096 + (int)entropy_zorder(xl / 2, yl / 2), log2c, 2, scan);
+    if (cb_v) s.tu(tb, ctu, 5120 + (int)entropy_zorder(xl / 2, yl / 2), log2c, 2, scan);
   }
-  KVZ_DEV void coding_tree(BinSink &s) const
+  template <class S> KVZ_DEV void coding_tree(S &s) const
   {
-    int stack[16], sp = 0;
+    u16 stack[16];
+    int sp = 0;
     stack[sp++] = 0;
-    while (sp > 0) {
+    while (sp > 0) tree_step(s, stack, sp);
+  }
+  template <class S, class STK> KVZ_DEV void tree_step(S &s, STK &stack, int &sp) const
+  {
+    {
       const int node = stack[--sp], depth = node >> 8, x = cx + ((node & 15) << 3), y = cy + (((node >> 4) & 15) << 3);
       const int w = 64 >> depth, half = w >> 1;
       const bool split_flag = at(x, y).depth > depth;
@@ -454,11 +499,11 @@ struct EntropyCtuB {
         }
         if (split_flag || border) {
           const int h8 = half >> 3, base = (node & 0xff) | ((depth + 1) << 8);
-          if (!border || (border_split_x && border_split_y)) stack[sp++] = base + h8 + (h8 << 4);
-          if (!border_y || border_split_y) stack[sp++] = base + (h8 << 4);
-          if (!border_x || border_split_x) stack[sp++] = base + h8;
-          stack[sp++] = base;
-          continue;
+          if (!border || (border_split_x && border_split_y)) stack[sp++] = (u16)(base + h8 + (h8 << 4));
+          if (!border_y || border_split_y) stack[sp++] = (u16)(base + (h8 << 4));
+          if (!border_x || border_split_x) stack[sp++] = (u16)(base + h8);
+          stack[sp++] = (u16)base;
+          return;
         }
       }
       coding_unit(s, x, y, depth);
@@ -497,6 +542,80 @@ KVZ_DEV void entropy_ctu_bins(const EntropyJob &J, const Tables *tb, long item)
   if ((end_of_picture || (!J.no_wpp && last_col)) && !end_of_slice) s.trm(1);       // end_of_subset_one_bit: the substream ends, the slice does not (:716-724)
   J.nbins[item] = s.n;
   J.nbits[item] = s.bits;
+}
+
+// ... the same list written another way.  One lane per CTU walking its whole syntax leaves a wavefront's 64 lanes in 64 different places of the program (7 of 64 lanes
+// active per instruction on average: profiles/r04_l_pmc_leg_entropy.json) -- and nine tenths of the walk is the residual of the transform blocks.  Here the lanes of a
+// wavefront agree on WHAT they do next, most urgent first: (1) a coefficient group of the block a lane is in (entropy_tu_cg: the bulk, now run by every lane that has a
+// block open), (2) flush queued records and open the next queued block (entropy_tu_begin), (3) the next node of the coding tree, whose CU queues its flags and blocks
+// (DeferSink).  A lane with nothing to do at the level the wavefront is on waits; the records of a lane come out in the same order either way.
+#ifdef KVZ_HOSTSIM
+KVZ_DEV bool entropy_any_lane(bool v) { return v; }  // a lane is a loop iteration: it agrees with itself
+#else
+__device__ __forceinline__ bool entropy_any_lane(bool v) { return __builtin_amdgcn_ballot_w64(v) != 0; }
+#endif
+struct EntropyBinsLds {  // per workgroup of 64 lanes: the lanes' queues and tree stacks, item-major
+  u32 q[DeferSink::QCAP][64];
+  u16 stack[16][64];
+};
+struct LaneStack { u16 *p; int stride; KVZ_DEV u16 &operator[](int i) { return p[i * stride]; } };
+KVZ_DEV void entropy_ctu_bins_phased(const EntropyJob &J, const Tables *tb, long item, bool live, u32 *queue, u16 *stack_mem, int stride)
+{
+  const int ctus = J.wc * J.hc;
+  if (!live) item = 0;  // (a lane past the end keeps the wavefront's votes company and writes nothing)
+  const int f = (int)(item / ctus), k = (int)(item - (long)f * ctus), lx = k % J.wc, ly = k / J.wc;
+  const long cells8 = (long)(J.H >> 3) * (J.W >> 3), cells4 = (long)(J.H >> 2) * (J.W >> 2);
+  DeferSink s{ BinSink{ J.bins + item * J.cap, 0, live ? J.cap : 0u, 0 }, queue, stride, 0, 0 };
+  if (live && J.sao) {  // encode_sao (encoderstate.c:519-552)
+    const int merge = J.sao_merge[item];
+    if (lx > 0) s.ctx(KVZ_HIP_CX_SAO_MERGE, merge == 1);
+    if (ly > 0 && merge != 1) s.ctx(KVZ_HIP_CX_SAO_MERGE, merge == 2);
+    if (!merge) {
+      const SaoRec *r = J.sao + item * 3;
+      EntropyCtu::sao_color(s, r[0], r[0], 0);
+      EntropyCtu::sao_color(s, r[1], r[1], 1);
+      EntropyCtu::sao_color(s, r[1], r[2], 2);
+    }
+  }
+  const i16 *ctu = J.coeff + item * KVZ_HIP_CTU_COEFFS;
+  const EntropyCtuB cb{ J, tb, J.cu ? J.cu + f * cells4 : nullptr, J.cu ? J.ref_cu + f * cells4 : nullptr, ctu, J.W >> 2, lx * 64, ly * 64 };
+  const EntropyCtu ci{ J, tb, J.cu ? nullptr : J.depth + f * cells8, J.cu ? nullptr : J.mode + f * cells8, J.part ? J.part + f * cells8 : nullptr,
+                       J.mode4 ? J.mode4 + f * cells4 : nullptr, ctu, J.W >> 3, J.W >> 2 };
+  LaneStack stack{ stack_mem, stride };
+  int sp = 0;
+  if (live) stack[sp++] = 0;
+  TuWalk t;
+  t.i = -1;
+  bool open = false;
+  for (;;) {
+    if (entropy_any_lane(open)) {
+      if (open) {
+        entropy_tu_cg(s.out, tb, t);
+        if (t.i < 0) { open = false; s.head++; }
+      }
+      continue;
+    }
+    const bool queued = s.queued();
+    if (entropy_any_lane(queued)) {
+      if (queued && s.flush_records()) {
+        const u32 d = s.front();
+        t.coeff = ctu + (d & 0x1fffu); t.log2_size = 2 + (int)((d >> 13) & 3u); t.type = (d >> 15) & 1u ? 2 : 0; t.scan_mode = (int)((d >> 16) & 3u);
+        entropy_tu_begin(s.out, tb, t);
+        open = true;
+      }
+      continue;
+    }
+    const bool more = sp > 0;
+    if (!entropy_any_lane(more)) break;
+    if (more) { if (J.cu) cb.tree_step(s, stack, sp); else ci.tree_step(s, stack, sp, lx * 64, ly * 64); }
+  }
+  if (!live) return;
+  const bool last_col = lx == J.wc - 1, last_row = ly == J.hc - 1, end_of_picture = last_col && last_row;
+  const bool end_of_slice = end_of_picture && !(J.not_last && J.not_last[f]);
+  s.trm(end_of_slice);                                                              // end_of_slice_segment_flag (encoderstate.c:699-712)
+  if ((end_of_picture || (!J.no_wpp && last_col)) && !end_of_slice) s.trm(1);       // end_of_subset_one_bit: the substream ends, the slice does not (:716-724)
+  J.nbins[item] = s.out.n;
+  J.nbits[item] = s.out.bits;
 }
 
 // Four records per load: a lane walks its own list, so what bounds it is the latency of its loads -- 16 bytes at a time, the next four requested before these are coded
@@ -697,6 +816,15 @@ __global__ void __launch_bounds__(64) dev_entropy_bins_kernel(const EntropyJob J
 {
   const long item = (long)blockIdx.x * 64 + threadIdx.x;
   if (item < total) entropy_ctu_bins(J, tb, item);
+}
+#ifndef KVZ_ENTROPY_BINS_WAVES
+#define KVZ_ENTROPY_BINS_WAVES 4  /* 128 VGPRs: four wavefronts per SIMD, which is also what 10 KB of LDS per workgroup allow (88 ms against 102 at three; five and more: no gain) */
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KVZ_ENTROPY_BINS_WAVES, KVZ_ENTROPY_BINS_WAVES))) dev_entropy_bins_phased_kernel(const EntropyJob J, const Tables *tb, long total)
+{
+  __shared__ EntropyBinsLds L;
+  const long item = (long)blockIdx.x * 64 + threadIdx.x;
+  entropy_ctu_bins_phased(J, tb, item, item < total, &L.q[0][threadIdx.x], &L.stack[0][threadIdx.x], 64);
 }
 // Lanes per workgroup of the two serial stages: every lane runs a long dependent chain of its own (its list's records, its coder's state), so what fills the chip is
 // the number of wavefronts, not their width -- 16 lanes per wavefront gives four times as many of them and a quarter of the divergence inside each

@@ -191,6 +191,16 @@ extern "C" void kvz_hostsim_inter_phases(long *out) { for (int i = 0; i < 32; i+
 
 // ---- the entropy coder's three stages (kvz_entropy.hpp) run on the host: every lane a loop iteration ----
 #include "../../kvazaar_amd/csrc/kvz_entropy.hpp"
+// stage 1 of the entropy coder as the device runs it by default (a lane = a call: the phased walk's votes are the lane's own), or the serial walk (KVZ_HIP_ENTROPY_BINS=serial)
+static void hostsim_ctu_bins(const kvz::EntropyJob &J, const kvz::Tables *tb, long item)
+{
+  static const bool serial = [] { const char *e = getenv("KVZ_HIP_ENTROPY_BINS"); return e && !strcmp(e, "serial"); }();
+  if (serial) { kvz::entropy_ctu_bins(J, tb, item); return; }
+  uint32_t queue[kvz::DeferSink::QCAP];
+  uint16_t stack[16];
+  kvz::entropy_ctu_bins_phased(J, tb, item, true, queue, stack, 1);
+}
+
 extern "C" long kvz_hostsim_entropy_code(const kvz_hip_intra_cost_model *m, int width, int height, int n_frames, const uint8_t *cu_depth, const uint8_t *cu_mode, const uint8_t *part,
                                          const uint8_t *mode4, const int16_t *coeff, const unsigned long long *sao_recs, const uint8_t *sao_merge, uint32_t cap, uint8_t *out,
                                          uint32_t *substream_bytes, uint32_t *most_records)
@@ -209,7 +219,7 @@ extern "C" long kvz_hostsim_entropy_code(const kvz_hip_intra_cost_model *m, int 
   const kvz::EntropyTabs T{ &tb.ctx_next[0][0], kvz::kLpsPacked };
   uint8_t ctx[KVZ_ENTROPY_CTXS];
   *most_records = 0;
-  for (long i = 0; i < items; i++) { kvz::entropy_ctu_bins(J, &tb, i); if (J.nbins[i] > *most_records) *most_records = J.nbins[i]; }
+  for (long i = 0; i < items; i++) { hostsim_ctu_bins(J, &tb, i); if (J.nbins[i] > *most_records) *most_records = J.nbins[i]; }
   long total = -1;
   if (*most_records <= cap) {
     if (!m->no_wpp) for (int f = 0; f < n_frames; f++) kvz::entropy_row_contexts(J, T, f, ctx);
@@ -250,7 +260,7 @@ extern "C" long kvz_hostsim_entropy_code_inter(const uint8_t *ctx_init /* KVZ_EN
   const kvz::EntropyTabs T{ &tb.ctx_next[0][0], kvz::kLpsPacked };
   uint8_t ctx[KVZ_ENTROPY_CTXS];
   long total = 0;
-  for (long i = 0; i < items; i++) { kvz::entropy_ctu_bins(J, &tb, i); if (J.nbins[i] > cap) total = -1; }
+  for (long i = 0; i < items; i++) { hostsim_ctu_bins(J, &tb, i); if (J.nbins[i] > cap) total = -1; }
   if (total == 0) {
     if (!no_wpp) kvz::entropy_row_contexts(J, T, 0, ctx);
     for (long i = 0; i < streams; i++) { substream_bytes[i] = kvz::entropy_code_row(J, T, i, ctx, out + total); total += substream_bytes[i]; }
