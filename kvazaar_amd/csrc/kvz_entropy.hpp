@@ -57,15 +57,26 @@ struct EntropyJob {
 struct BinSink {
   u32 *out; u32 n, cap;
   u32 bits;  // upper bound of the bits these records make the coder emit: 6 per context-coded bin (the longest renormalisation), 7 per terminating bin, bypass bins as they are
+  // Runs of bypass bins that follow each other (the signs of a group, then the prefix and the suffix of every remaining level) are gathered into records of up to 16 bins:
+  // kvz_cabac_encode_bins_ep of a run codes the same bytes however the run is cut (low' = (low << n) + range * value is exact), and the coder's serial chain is one step
+  // per record.  pend_v / pend_n: the run being gathered.
+  u32 pend_v = 0; int pend_n = 0;
   KVZ_DEV void put(u32 r) { if (n < cap) out[n] = r; n++; }
-  KVZ_DEV void ctx(int c, int v) { put(KVZ_EB_CTX(c, v ? 1 : 0)); bits += 6; }
-  KVZ_DEV void ep(u32 value, int bits)  // kvz_cabac_encode_bins_ep: any split of a run into pieces codes the same bytes (the coder's interval arithmetic is exact)
+  KVZ_DEV void finish() { if (pend_n > 0) { put(KVZ_EB_EP(pend_v, pend_n)); pend_n = 0; pend_v = 0; } }
+  KVZ_DEV void ctx(int c, int v) { finish(); put(KVZ_EB_CTX(c, v ? 1 : 0)); bits += 6; }
+  KVZ_DEV void ep(u32 value, int bits)
   {
     this->bits += (u32)bits;
-    while (bits > 16) { bits -= 16; put(KVZ_EB_EP(value >> bits, 16)); value &= (1u << bits) - 1; }
-    if (bits > 0) put(KVZ_EB_EP(value, bits));
+    while (bits > 0) {
+      const int take = bits < 16 - pend_n ? bits : 16 - pend_n;  // the leading `take` bins of the run join the record being gathered
+      bits -= take;
+      pend_v = (pend_v << take) | (value >> bits);
+      pend_n += take;
+      value &= (1u << bits) - 1;
+      if (pend_n == 16) finish();
+    }
   }
-  KVZ_DEV void trm(int v) { put(KVZ_EB_TRM(v)); bits += 7; }
+  KVZ_DEV void trm(int v) { finish(); put(KVZ_EB_TRM(v)); bits += 7; }
   // the residual of the transform block whose levels start `off` into the CTU's block: here and now
   KVZ_DEV void tu(const Tables *tb, const i16 *ctu, int off, int log2_size, int type, int scan_mode) { entropy_coeff_nxn(*this, tb, ctu + off, log2_size, type, scan_mode); }
 };
@@ -95,8 +106,7 @@ struct DeferSink {
   {
     while (head < tail && (front() >> 30) != 3u) {
       const u32 r = q[head++ * qs], kind = r >> 30;
-      out.put(r);
-      out.bits += kind == 0 ? 6u : (kind == 1 ? ((r >> 16) & 0x3fu) : 7u);
+      if (kind == 0) out.ctx((int)(r & 0xff), (int)((r >> 8) & 1)); else if (kind == 1) out.ep(r & 0xffffu, (int)((r >> 16) & 0x3fu)); else out.trm((int)(r & 1));
     }
     return head < tail;
   }
@@ -132,6 +142,7 @@ struct CoeffBinsOp {
   {
     BinSink s{ out + 1, 0, cap, 0 };
     entropy_coeff_nxn(s, tb, coeff, log2_size, type, scan_mode);
+    s.finish();
     out[0] = s.n;
   }
 };
