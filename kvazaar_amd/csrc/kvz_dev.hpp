@@ -1518,6 +1518,8 @@ struct EntropyScratch {
   std::mutex lock;
   struct Buf { void *p = nullptr; size_t bytes = 0; };
   Buf bins, nbins, nbits, sizes, offsets, bound_offsets, rowctx, scratch, out, not_last;
+  hipStream_t side = nullptr;          // stage 2 beside stage 1's second part
+  hipEvent_t ev_first = nullptr, ev_rows = nullptr;
   static void *need(Buf &b, size_t bytes)
   {
     if (bytes > b.bytes) {
@@ -1566,8 +1568,22 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
     EntropyJob J = job(f0, nf);
     J.bins = d_bins; J.nbins = d_nbins; J.nbits = d_nbits; J.cap = cap; J.row_ctx = d_rowctx; J.not_last = d_not_last;
     static const bool serial_bins = [] { const char *e = getenv("KVZ_HIP_ENTROPY_BINS"); return e && !strcmp(e, "serial"); }();  // developer: the one-lane-walks-it-all form of stage 1
+    // WPP: the row contexts (stage 2: one lane per picture, a long chain) need the bins of the first two CTUs of every row only -- those and stage 2 run on a second
+    // stream beside the bins of all the other CTUs
+    const bool early_rows = !serial_bins && !no_wpp && wc > 2;
     if (serial_bins) hipLaunchKernelGGL(dev_entropy_bins_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, stream, J, device_tables(), items);
-    else hipLaunchKernelGGL(dev_entropy_bins_phased_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, stream, J, device_tables(), items);
+    else if (!early_rows) hipLaunchKernelGGL(dev_entropy_bins_phased_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, stream, J, device_tables(), items, 0);
+    else {
+      const long first = (long)nf * hc * 2, rest = items - first;
+      if (!S.side) { KVZ_HIP_CHECK(hipStreamCreateWithFlags(&S.side, hipStreamNonBlocking)); KVZ_HIP_CHECK(hipEventCreateWithFlags(&S.ev_first, hipEventDisableTiming)); KVZ_HIP_CHECK(hipEventCreateWithFlags(&S.ev_rows, hipEventDisableTiming)); }
+      KVZ_HIP_CHECK(hipEventRecord(S.ev_first, stream));  // (what the caller queued before -- the pass, the loop filters -- comes first on both streams)
+      KVZ_HIP_CHECK(hipStreamWaitEvent(S.side, S.ev_first, 0));
+      hipLaunchKernelGGL(dev_entropy_bins_phased_kernel, dim3((unsigned)((first + 63) / 64)), dim3(64), 0, S.side, J, device_tables(), first, 1);
+      hipLaunchKernelGGL(dev_entropy_row_ctx_kernel<8>, dim3((unsigned)((nf + 7) / 8)), dim3(8), 0, S.side, J, device_tables());
+      KVZ_HIP_CHECK(hipEventRecord(S.ev_rows, S.side));
+      hipLaunchKernelGGL(dev_entropy_bins_phased_kernel, dim3((unsigned)((rest + 63) / 64)), dim3(64), 0, stream, J, device_tables(), rest, 2);
+      KVZ_HIP_CHECK(hipStreamWaitEvent(stream, S.ev_rows, 0));  // the counts of every CTU are read next
+    }
     counts.resize((size_t)items); bound_bits.resize((size_t)items);
     KVZ_HIP_CHECK(hipMemcpyAsync(counts.data(), d_nbins, (size_t)items * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     KVZ_HIP_CHECK(hipMemcpyAsync(bound_bits.data(), d_nbits, (size_t)items * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -1591,7 +1607,7 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
       mark("host: bounds");
       KVZ_HIP_CHECK(hipMemcpyAsync(d_bound_offsets, bound_offsets.data(), (size_t)streams * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
       static const int lanes = [] { const char *e = getenv("KVZ_HIP_ENTROPY_LANES"); const int v = e ? atoi(e) : 16; return v == 64 || v == 32 || v == 8 ? v : 16; }();
-      if (!no_wpp) hipLaunchKernelGGL(dev_entropy_row_ctx_kernel<8>, dim3((unsigned)((nf + 7) / 8)), dim3(8), 0, stream, J, device_tables());
+      if (!early_rows && !no_wpp) hipLaunchKernelGGL(dev_entropy_row_ctx_kernel<8>, dim3((unsigned)((nf + 7) / 8)), dim3(8), 0, stream, J, device_tables());
       {
         const dim3 grid((unsigned)((streams + lanes - 1) / lanes)), block((unsigned)lanes);
         if (lanes == 64) hipLaunchKernelGGL(dev_entropy_code_kernel<64>, grid, block, 0, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
@@ -1622,7 +1638,9 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
         f0 += nf;
       }
     }
-    if (again) cap = (most + 1023u) & ~1023u;  // this chunk again, with room for its largest CTU
+    if (again) {
+      cap = (most + 1023u) & ~1023u;  // this chunk again, with room for its largest CTU
+    }
   }
   return rc ? rc : (long)total;
 }

@@ -754,6 +754,16 @@ __device__ const u32 kLpsPacked[64] = {
   0x0D0B0908u, 0x0C0B0907u, 0x0C0A0907u, 0x0B0A0807u, 0x0B090806u, 0x0A090706u, 0x09080706u, 0x02020202u };
 KVZ_DEV u32 entropy_lps_row(int state) { return kLpsPacked[state]; }
 
+// When the coder moves a byte out (kvz_cabac_write, cabac.c:138-177, called at bits_left < 12).  The bytes are the digits of the code value: moving one out is exact
+// whenever eight bits have gathered (bits_left <= 15: nine bits stay in `low`, the width of `range`, and a carry still reaches the moved byte through buffered_byte).
+// The byte path is ~45 instructions that a wavefront runs whenever ANY of its lanes is in it -- with sixteen substreams per wavefront that was nearly every step.  So the
+// lanes move their bytes together: when one of them must, every lane that can does, and the next time is several records away.
+#ifdef KVZ_HOSTSIM
+static int entropy_write_threshold() { static const int t = getenv("KVZ_HOSTSIM_EARLY_WRITE") ? 16 : 12; return t; }  // test hook: every lane always as early as it may
+KVZ_DEV void entropy_move_bytes(ArithCoder &a) { if (a.bits_left < entropy_write_threshold()) a.write(); }
+#else
+__device__ __forceinline__ void entropy_move_bytes(ArithCoder &a) { if (__builtin_amdgcn_ballot_w64(a.bits_left < 12) != 0 && a.bits_left < 16) a.write(); }
+#endif
 // one record through the coder (cabac.c:104-133 kvz_cabac_encode_bin, :231-254 kvz_cabac_encode_bins_ep, :193-210 kvz_cabac_encode_bin_trm)
 KVZ_DEV void entropy_code_record(ArithCoder &a, u8 *ctx, const EntropyTabs T, u32 rec)
 {
@@ -792,7 +802,7 @@ KVZ_DEV void entropy_code_record(ArithCoder &a, u8 *ctx, const EntropyTabs T, u3
     else if (a.range >= 256) return;
     else { a.low <<= 1; a.range <<= 1; a.bits_left--; }
   }
-  if (a.bits_left < 12) a.write();
+  entropy_move_bytes(a);
 }
 
 // stage 3: the substream `item` -- (picture, CTU row) with WPP, the picture without; returns its size in bytes.  ctx: KVZ_ENTROPY_CTXS bytes of work memory
@@ -831,11 +841,19 @@ __global__ void __launch_bounds__(64) dev_entropy_bins_kernel(const EntropyJob J
 #ifndef KVZ_ENTROPY_BINS_WAVES
 #define KVZ_ENTROPY_BINS_WAVES 4  /* 128 VGPRs: four wavefronts per SIMD, which is also what 10 KB of LDS per workgroup allow (88 ms against 102 at three; five and more: no gain) */
 #endif
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KVZ_ENTROPY_BINS_WAVES, KVZ_ENTROPY_BINS_WAVES))) dev_entropy_bins_phased_kernel(const EntropyJob J, const Tables *tb, long total)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KVZ_ENTROPY_BINS_WAVES, KVZ_ENTROPY_BINS_WAVES))) dev_entropy_bins_phased_kernel(const EntropyJob J, const Tables *tb, long total, int columns)
 {
   __shared__ EntropyBinsLds L;
-  const long item = (long)blockIdx.x * 64 + threadIdx.x;
-  entropy_ctu_bins_phased(J, tb, item, item < total, &L.q[0][threadIdx.x], &L.stack[0][threadIdx.x], 64);
+  // columns: 0 -- every CTU; 1 -- the first two CTUs of every row (what the row contexts are made from: that part goes first, and stage 2 runs beside the rest);
+  // 2 -- the others.  `total`: the lanes of this launch
+  long item = (long)blockIdx.x * 64 + threadIdx.x;
+  const bool live = item < total;
+  if (columns != 0 && live) {
+    const int per_row = columns == 1 ? 2 : J.wc - 2;
+    const long row = item / per_row;  // picture-major: f * hc + ly
+    item = row * J.wc + (columns == 1 ? 0 : 2) + (item - row * per_row);
+  }
+  entropy_ctu_bins_phased(J, tb, item, live, &L.q[0][threadIdx.x], &L.stack[0][threadIdx.x], 64);
 }
 // Lanes per workgroup of the two serial stages: every lane runs a long dependent chain of its own (its list's records, its coder's state), so what fills the chip is
 // the number of wavefronts, not their width -- 16 lanes per wavefront gives four times as many of them and a quarter of the divergence inside each
