@@ -823,8 +823,12 @@ KVZ_DEV u32 entropy_code_row(const EntropyJob &J, const EntropyTabs T, long item
     for (u32 i0 = 0; i0 < n; i0 += 16) {
       const Rec16 nxt = i0 + 16 < n ? entropy_load16(b, (i0 >> 4) + 1) : cur;
       const u32 m = n - i0 < 16 ? n - i0 : 16;
-#pragma unroll 1
+#ifdef KVZ_HOSTSIM
       for (u32 q = 0; q < m; q++) entropy_code_record(a, ctx, T, cur.next());
+#else
+#pragma unroll
+      for (u32 q = 0; q < 16; q++) { if (q >= m) break; entropy_code_record(a, ctx, T, cur.w[q]); }  // unrolled: the line under constant indices (shifting it down was 15 moves per record)
+#endif
       cur = nxt;
     }
   }
