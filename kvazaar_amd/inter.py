@@ -17,7 +17,12 @@ class InterParams(C.Structure):  # kvz_hip_inter_params
 
 def veryfast_params(qp, poc, mv_constraint=True):
     """`--preset veryfast` (cfg.c:541-568) for a B picture of the low-delay GOP"""
-    return InterParams(qp=qp, poc=poc, mv_constraint=int(mv_constraint), sao=1, deblock=1, fme_level=2, pu_depth_inter_max=3, no_wpp=0, fast_residual_cost=28)
+    p = InterParams(qp=qp, poc=poc, mv_constraint=int(mv_constraint), sao=1, deblock=1, fme_level=2, pu_depth_inter_max=3, no_wpp=0, fast_residual_cost=28)
+    import os
+    for k in os.environ.get("KVZ_DEBUG_INTER_PARAMS", "").split(","):  # developer: timing experiments (e.g. no_tmvp=1,mv_constraint=0); the results no longer verify
+        if "=" in k:
+            setattr(p, k.split("=")[0], int(k.split("=")[1]))
+    return p
 
 
 def lowdelay_picture_qp(qp, frame, gop_len=4, gop_depth=3, intra_period=0, preset_given=True):
