@@ -642,16 +642,20 @@ def tiled_inter_bench(args, lib, dist, torch, rank, world, HipBatch, cost_model)
         if gold is not None:
             ok = ok and hashlib.sha256(f0.tobytes()).hexdigest()[:24] == gold["rec"][k] and inter.cu_digest(c0) == gold["cu"][k]
         checks.append(ok)
-    # timing: `steps` B pictures (the chain simply goes on: picture k's sources cycle through the clip), sources uploaded before the clock starts
+    # timing: every step is the FIRST B picture again, from the I picture's reconstruction -- the reference frames and CU records are put back from a device copy inside
+    # the step (a few ms of device-to-device copies, counted), because run_picture leaves the coded picture as the reference and the same source coded against its own
+    # reconstruction is a picture of skipped CUs (which the first version of this line timed for all steps but the first)
     start()
+    seq.save_reference()
     for _ in range(args.warmup):
         picture(1)
-    start()
+        seq.restore_reference()
     seq.upload_sources(lambda i: pictures[1])
     prm = inter.veryfast_params(qps[1], 1, mv_constraint=False)
     pass_ms = []
 
     def step():
+        seq.restore_reference()
         seq.run_picture(prm)
         pass_ms.append(seq.pass_ms)
     dt = sharding.timed_steps(step, args.steps, dist, torch.cuda.synchronize, "cuda")

@@ -255,6 +255,14 @@ class TiledInterSequences:
         self.ref.copy_(torch.from_numpy(np.ascontiguousarray(frames).reshape(-1)))
         self.ref_cu.copy_(torch.from_numpy(np.ascontiguousarray(cu).view(np.uint8).reshape(-1)))
 
+    def save_reference(self):
+        """keep a device copy of the reference frames and their CU records as they are now (restore_reference puts them back: a bench step that codes the same picture again)"""
+        self._saved = (self.ref.clone(), self.ref_cu.clone())
+
+    def restore_reference(self):
+        self.ref.copy_(self._saved[0])
+        self.ref_cu.copy_(self._saved[1])
+
     def run_picture(self, base):
         """one B picture of every sequence: the CTU pass of this rank's tiles, their loop filters, then the exchange that turns the result into the next picture's reference"""
         torch = self.torch
