@@ -254,3 +254,29 @@ def test_two_rank_tiled_inter_chain_equals_reference_encoder(clip):
     assert got is not None, "a rank failed"
     assert got["rec"] == want["rec"], "final pictures differ from the reference encoder's"
     assert got["cu"] == want["cu"], "CU decisions differ from the reference encoder's"
+
+
+def test_bench_gpus_2_self_launch_starts_two_ranks():
+    """`python bench.py --gpus 2` on its own starts two ranks (torch.distributed.run, 127.0.0.1) and rank 0 prints `n_gpus` = 2 from the process group: the launch
+    path with the device work stubbed (KVZ_BENCH_STUB=1: gloo, sharding.timed_steps with its barrier + MAX over ranks).  A launcher that disagrees with --gpus is refused."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KVZ_BENCH_STUB="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "KVZ_HIP_DEVICE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames", "7", "--no-extra"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1
+    # MAX over ranks: rank 1's step sleeps 4 ms, rank 0's 2 ms
+    assert out["ms_per_step"] >= 3.9
+    assert abs(out["value"] - 14 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-6 * out["value"]
+    # world size and --gpus must agree
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "WORLD_SIZE" in r2.stderr
