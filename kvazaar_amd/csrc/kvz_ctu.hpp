@@ -1156,12 +1156,27 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   // predicts and row-transforms its four rows, the lanes swap them (DPP quad_perm) for the butterfly stage that pairs row r with
   // row r + 4 -- the even lane keeps the sums, the odd one the differences --, finish their halves alone and add up.  Both lanes
   // return the block's total.  Device only (the host simulation has no cross-lane operations and runs the one-lane form).
+#ifndef KVZ_HOSTSIM
+  // Two u16 per register for the row generators below (v_pk_mad_u16 / v_pk_lshrrev_b16; bytes widened by v_perm_b32, whose selector value 0x0c reads as a zero byte)
+  typedef unsigned short U16x2 __attribute__((ext_vector_type(2)));
+  KVZ_DEV static U16x2 u16x2_of(unsigned v) { U16x2 r; __builtin_memcpy(&r, &v, 4); return r; }
+  KVZ_DEV static U16x2 splat16(int v) { U16x2 r; r.x = (unsigned short)v; r.y = (unsigned short)v; return r; }
+  KVZ_DEV static U16x2 widen(unsigned hi, unsigned lo, unsigned sel) { return u16x2_of(__builtin_amdgcn_perm(hi, lo, sel)); }
+  KVZ_DEV static Pk16 as_pk16(U16x2 v) { Pk16 r; __builtin_memcpy(&r, &v, 4); return r; }
+  // The eight bytes at p (any alignment) as four u16 pairs
+  KVZ_DEV static void widen8(const u8 *p, U16x2 out[4])
+  {
+    unsigned w[2];
+    __builtin_memcpy(w, p, 8);
+    out[0] = widen(0, w[0], 0x0c010c00u); out[1] = widen(0, w[0], 0x0c030c02u); out[2] = widen(0, w[1], 0x0c010c00u); out[3] = widen(0, w[1], 0x0c030c02u);
+  }
+#endif
   template <bool PAIR>
   KVZ_DEV u32 angular_block_satd(int log2w, int mode, int bx, int by, int xl, int yl, int half) const
   {
     const int w = 1 << log2w;
-    const bool big = S32 && log2w == 5;  // a 32x32 CU: no edge filters (intra.c:207-219), and planar / DC are scored here too (below)
-    const bool flat = big && mode < 2;
+    const bool big = S32 && log2w == 5;  // a 32x32 CU: no edge filters (intra.c:207-219)
+    const bool flat = mode < 2;          // planar and DC have row generators of their own, in the vertical orientation
     const bool vertical = mode >= 18 || flat;
     const int disp = s->mode_disp[mode];
     const int p0 = vertical ? bx : by, q0 = vertical ? by : bx;  // block origin along / across the main reference
@@ -1175,10 +1190,72 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     const u8 *org = vertical ? org_at(0, xl + bx, yl + by) : (big ? org_t32() : s->org_t) + bx * w + by;
     const int ostride = vertical ? 32 : w;
     const u8 *side = vertical ? s->ref[0][1] : s->ref[0][0];  // intra.c:207-219: modes 10 / 26 use the unfiltered references
-    const bool edge = !big && disp == 0 && p0 == 0;
+    const bool edge = !big && !flat && disp == 0 && p0 == 0;
     constexpr int NR = PAIR ? 4 : 8;
     const int r0 = PAIR ? 4 * half : 0;
     Pk16 d[NR][4];
+#ifndef KVZ_HOSTSIM
+    if (!big) {
+      // Packed rows (8x8 and 16x16 CUs): the eight predicted samples of a row as four u16 pairs, minus the source row widened the same way.  Every intermediate
+      // fits 16 bits ((32 - f) a + f b + 16 <= 8176; the planar sum <= 2 w 255 + w), so the arithmetic is that of intra-generic.c sample for sample.
+      if (flat) {
+        if (mode == 0) {  // planar (intra-generic.c:165-201) on the filtered references: (w-1-x) L + (x+1) TR + (w-1-y) T[x] + (y+1) BL + w
+          const u8 *top = s->fref[0], *left = s->fref[1];
+          const int tr = top[w + 1], bl = left[w + 1];
+          U16x2 tp[4], xs[4];
+          widen8(top + bx + 1, tp);
+#pragma unroll
+          for (int j = 0; j < 4; j++) { xs[j].x = (unsigned short)(bx + 2 * j); xs[j].y = (unsigned short)(bx + 2 * j + 1); }
+#pragma unroll
+          for (int i = 0; i < NR; i++) {
+            const int y = by + r0 + i, l = left[y + 1];
+            const U16x2 dl = splat16(tr - l), wy = splat16(w - 1 - y), hb = splat16((w - 1) * l + tr + (y + 1) * bl + w);
+            U16x2 o[4];
+            widen8(org + (r0 + i) * ostride, o);
+#pragma unroll
+            for (int j = 0; j < 4; j++) d[i][j] = as_pk16(((xs[j] * dl + (tp[j] * wy + hb)) >> (unsigned short)(log2w + 1)) - o[j]);
+          }
+        } else {  // DC with its edge smoothing (intra-generic.c:210-241) on the unfiltered references
+          const u8 *top = s->ref[0][0], *left = s->ref[0][1];
+          const int dc = s->dcval[0];
+          U16x2 tp[4];
+          widen8(top + bx + 1, tp);
+#pragma unroll
+          for (int i = 0; i < NR; i++) {
+            const int y = by + r0 + i;
+            U16x2 o[4], v[4];
+            widen8(org + (r0 + i) * ostride, o);
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = y == 0 ? (U16x2)((tp[j] + splat16(3 * dc + 2)) >> (unsigned short)2) : splat16(dc);
+            if (bx == 0) v[0].x = (unsigned short)(y == 0 ? (left[1] + 2 * dc + top[1] + 2) >> 2 : (left[y + 1] + 3 * dc + 2) >> 2);
+#pragma unroll
+            for (int j = 0; j < 4; j++) d[i][j] = as_pk16(v[j] - o[j]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < NR; i++) {
+          const int qa = q0 + r0 + i + 1, delta = qa * disp, di = delta >> 5, df = delta & 31;
+          const u8 *m = mr + di;
+          unsigned mw[2];
+          __builtin_memcpy(mw, m, 8);
+          const unsigned m8 = m[8];
+          const U16x2 c1 = splat16(df), c0 = splat16(32 - df), rnd = splat16(16);
+          U16x2 pa[4], pb[4], o[4];
+          pa[0] = widen(0, mw[0], 0x0c010c00u); pa[1] = widen(0, mw[0], 0x0c030c02u); pa[2] = widen(0, mw[1], 0x0c010c00u); pa[3] = widen(0, mw[1], 0x0c030c02u);
+          pb[0] = widen(0, mw[0], 0x0c020c01u); pb[1] = widen(mw[1], mw[0], 0x0c040c03u); pb[2] = widen(0, mw[1], 0x0c020c01u); pb[3] = widen(m8, mw[1], 0x0c040c03u);
+          widen8(org + (r0 + i) * ostride, o);
+          U16x2 v[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) v[j] = (pa[j] * c0 + (pb[j] * c1 + rnd)) >> (unsigned short)5;
+          if (edge) v[0].x = (unsigned short)iclip(0, 255, (int)v[0].x + (((int)side[qa] - (int)side[0]) >> 1));
+#pragma unroll
+          for (int j = 0; j < 4; j++) d[i][j] = as_pk16(v[j] - o[j]);
+        }
+      }
+    } else
+#endif
+    {
 #pragma unroll
     for (int i = 0; i < NR; i++) {
       const int r = r0 + i;
@@ -1189,12 +1266,15 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       __builtin_memcpy(&ow, __builtin_assume_aligned(org + r * ostride, 8), 8);
       int v[8];
       if (flat) {
-        // planar (intra-generic.c:190-228, on the filtered references) and DC (a 32x32 block has no DC edge filter) of a 32x32 CU
-        if (mode == 1) { for (int k = 0; k < 8; k++) v[k] = s->dcval[0]; }
-        else {
+        // planar (intra-generic.c:165-201, on the filtered references) and DC (intra-generic.c:210-241 with its edge smoothing below 32x32, on the unfiltered ones)
+        const int y = by + r;
+        if (mode == 1) {
+          const u8 *top = s->ref[0][0], *left = s->ref[0][1];
+          const int dc = s->dcval[0];
+          for (int k = 0; k < 8; k++) v[k] = big ? dc : (int)filtered_dc_pixel(dc, bx + k, y, top, left);
+        } else {
           const u8 *top = s->fref[0], *left = s->fref[1];
-          const int y = by + r, ly = left[y + 1], tr = top[33], bl = left[33];
-          for (int k = 0; k < 8; k++) { const int x = bx + k; v[k] = ((31 - x) * ly + (x + 1) * tr + (31 - y) * top[x + 1] + (y + 1) * bl + 32) >> 6; }
+          for (int k = 0; k < 8; k++) v[k] = planar_pixel(log2w, bx + k, y, top, left);
         }
       } else {
         int a = m[0];
@@ -1207,6 +1287,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       if (edge) v[0] = iclip(0, 255, v[0] + (((int)side[qa] - (int)side[0]) >> 1));
       for (int j = 0; j < 4; j++) d[i][j] = pk_make(v[2 * j] - (int)((ow >> (16 * j)) & 0xff), v[2 * j + 1] - (int)((ow >> (16 * j + 8)) & 0xff));
     }
+    }
 #pragma unroll
     for (int i = 0; i < NR; i++) {  // along the rows: columns k and k + 4, then k and k + 2 (k and k + 1 is the folded stage)
       const Pk16 a0 = pk_add(d[i][0], d[i][2]), a1 = pk_add(d[i][1], d[i][3]), a2 = pk_sub(d[i][0], d[i][2]), a3 = pk_sub(d[i][1], d[i][3]);
@@ -1215,17 +1296,20 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     u32 sum = 0;
     if constexpr (PAIR) {
 #ifndef KVZ_HOSTSIM
+      // rows r and r + 4 live in the two lanes of the pair: the even lane keeps the sums d + o, the odd one d - o, which is the NEGATED difference of the
+      // rows -- only magnitudes are summed below -- so both are one multiply-add with a per-lane sign
+      const Pk16 sgn = pk_make(half ? -1 : 1, half ? -1 : 1);
 #pragma unroll
       for (int j = 0; j < 4; j++) {  // down the columns, two columns per register
         Pk16 e[4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {  // rows r and r + 4 live in the two lanes of the pair
+        for (int i = 0; i < 4; i++) {
           int mine;
           __builtin_memcpy(&mine, &d[i][j], 4);
           const int theirs = __builtin_amdgcn_update_dpp(0, mine, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
           Pk16 o;
           __builtin_memcpy(&o, &theirs, 4);
-          e[i] = half ? pk_sub(o, d[i][j]) : pk_add(d[i][j], o);
+          e[i] = o * sgn + d[i][j];
         }
         const Pk16 b0 = pk_add(e[0], e[2]), b1 = pk_add(e[1], e[3]), b2 = pk_sub(e[0], e[2]), b3 = pk_sub(e[1], e[3]);
         sum += pk_absmax(pk_add(b0, b1)) + pk_absmax(pk_sub(b0, b1)) + pk_absmax(pk_add(b2, b3)) + pk_absmax(pk_sub(b2, b3));
@@ -1453,14 +1537,6 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         const int ex = e >> log2w, ey = e & (w - 1);
         s->org_t[e] = *org_at(0, xl + ex, yl + ey);
       }
-      // planar and DC go through LDS + column SATD.  So does mode 34 of a 16x16 CU: 33 angular modes x 4 blocks are 132 lane tasks,
-      // four more than there are lanes, and a second round of the in-lane predict + SATD for those four costs every lane's issue slots
-      const int lds_modes = 3;
-      for (int i = tid; i < lds_modes * w * w; i += KVZ_CTU_THREADS) {
-        const int mi = i >> (2 * log2w), e = i & (w * w - 1);
-        s->pred[mi * 256 + e] = predict_pixel(log2w, mi == 2 ? 34 : mi, 0, e & (w - 1), e >> log2w);
-      }
-      for (int v = tid; v < 3 * 4; v += KVZ_CTU_THREADS) s->satd_raw[v < 8 ? v >> 2 : 34][v & 3] = 0;
       if (tid == KVZ_CTU_THREADS - 1) {
         const int left = x >= 4 ? neighbour_cu(lv, x - 1, y) : -1, above = (y >= 4 && yl > 0) ? neighbour_cu(lv, x, y - 1) : -1;
         mpm_candidates(y, left, above, s->preds);
@@ -1470,27 +1546,22 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     KVZ_PROF(KVZ_P_PRED35);
     KVZ_FOR_THREADS(tid) {
       const int lb = 2 * (log2w - 3);  // log2(nblk)
+      // All 35 modes predicted and Hadamard-scored in registers (angular_block_satd), the angular ones first, then planar and DC (task index 33, 34): the lanes of
+      // those two share the last round, where the wavefront walks through their row generators one after the other
 #ifdef KVZ_HOSTSIM
-      for (int t = tid; t < 32 * nblk; t += KVZ_CTU_THREADS) {  // angular modes 2..33: one thread per (mode, block)
-        const int mode = 2 + (t >> lb), b = t & (nblk - 1), bx = (b & ((w >> 3) - 1)) * 8, by = (b >> (log2w - 3)) * 8;
+      for (int t = tid; t < 35 * nblk; t += KVZ_CTU_THREADS) {  // one thread per (mode, block)
+        const int mi = t >> lb, mode = mi < 33 ? mi + 2 : mi - 33, b = t & (nblk - 1), bx = (b & ((w >> 3) - 1)) * 8, by = (b >> (log2w - 3)) * 8;
         s->satd_raw[mode][b] = angular_block_satd<false>(log2w, mode, bx, by, xl, yl, 0);
       }
 #else
-      // angular modes 2..33: TWO lanes per (mode, block), rows 0..3 and 4..7 of the block (angular_block_satd<true>): 64 lane tasks
-      // for an 8x8 CU, 256 for a 16x16 one -- whole wavefronts, half the instructions per wavefront
-      for (int t = tid; t < 64 * nblk; t += KVZ_CTU_THREADS) {
-        const int p = t >> 1, mode = 2 + (p >> lb), b = p & (nblk - 1), bx = (b & ((w >> 3) - 1)) * 8, by = (b >> (log2w - 3)) * 8;
+      // TWO lanes per (mode, block), rows 0..3 and 4..7 of the block (angular_block_satd<true>): 70 lane tasks for an 8x8 CU -- the 64 of modes 2..33 fill one
+      // wavefront --, 280 for a 16x16 one
+      for (int t = tid; t < 70 * nblk; t += KVZ_CTU_THREADS) {
+        const int p = t >> 1, mi = p >> lb, mode = mi < 33 ? mi + 2 : mi - 33, b = p & (nblk - 1), bx = (b & ((w >> 3) - 1)) * 8, by = (b >> (log2w - 3)) * 8;
         const u32 v = angular_block_satd<true>(log2w, mode, bx, by, xl, yl, t & 1);
         if (!(t & 1)) s->satd_raw[mode][b] = v;
       }
 #endif
-      // planar and DC: one lane per (mode, block, Hadamard column), taken from the far end of the thread ids so that
-      // they land on another wavefront than the angular lanes
-      for (int t = KVZ_CTU_THREADS - 1 - tid; t < 3 * nblk * 8; t += KVZ_CTU_THREADS) {
-        const int col = t & 7, mb = t >> 3, mi = mb >> lb, b = mb & (nblk - 1), bx = (b & ((w >> 3) - 1)) * 8, by = (b >> (log2w - 3)) * 8;
-        const u32 v = satd8_column(s->pred + mi * 256 + by * w + bx, w, org_at(0, xl + bx, yl + by), 32, col);
-        KVZ_LDS_ADD(&s->satd_raw[mi == 2 ? 34 : mi][b], v);
-      }
     }
     }
     KVZ_SYNC();
