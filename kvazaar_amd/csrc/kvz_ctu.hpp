@@ -220,7 +220,8 @@ template <bool CABAC> struct CtuSharedT {
       alignas(16) i16 tb_small[2 * 384];
       alignas(8) u8 org_t[256];  // the CU's source block transposed (horizontal modes are predicted and scored transposed)
       u8 c2[384];              // depth-2 candidate (16x16 CU):     Y 256 | U 64 | V 64
-      u8 c3[384];              // depth-3 candidates (the four 8x8 CUs of the current 16x16)
+      // (the depth-3 candidates -- the four 8x8 CUs of the current 16x16 -- are written straight into `dec`: nothing reads that region of the decided picture
+      // before the 16x16 decision, which either keeps them or overwrites them with c2)
       alignas(8) u8 pred[3 * 256];  // planar, DC and -- for 16x16 CUs -- mode 34 (see rough_search); the rest: planar and DC predictions of the CU being searched (<= 16x16)
       // Rough search, the 15 angular modes with a negative displacement (11..25): the main reference with its projected
       // extension (intra-generic.c:97-123), already picked from the filtered / unfiltered, top / left arrays.  Entry
@@ -264,8 +265,12 @@ template <bool CABAC> struct CtuSharedT {
 };
 
 using CtuShared = CtuSharedT<true>;
+static_assert(__builtin_offsetof(CtuSharedT<true>, fref) == __builtin_offsetof(CtuSharedT<true>, ref) + 408 && __builtin_offsetof(CtuSharedT<false>, fref) == __builtin_offsetof(CtuSharedT<false>, ref) + 408,
+              "Tables::mref_tab addresses the filtered references 408 bytes behind the unfiltered ones");
 
-static const int kPlaneOff[3] = { 0, 4096, 5120 };
+// Offset of plane c (0 Y, 1 U, 2 V) in a CTU's 6144-entry block: 0, 4096, 5120.  Arithmetic, not a table: indexed by a per-lane plane a constant array is a
+// load from global memory on the critical path of the phase.
+KVZ_HD int plane_off(int c) { return c ? 3072 + (c << 10) : 0; }
 
 // What the RDOQ instantiation keeps in LDS on top of CtuSharedT: the price of both bins of every context at the row coder's states, fixed for the CTU.
 // (kvz_rdoq's per-position cost arrays were tried here too, for blocks up to 16x16: no gain -- the routine is bound by its own serial instruction stream --
@@ -345,8 +350,8 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       v.bias[0] = -(rl->a3y * 8 + rl->a3x);
       v.bias[1] = 64 - ((rl->a3y >> 1) * 4 + (rl->a3x >> 1));
       v.bias[2] = v.bias[1] + 16;
-    } else if (lv == 0) {
-      v.buf = s->dec;  // see CtuShared::dec
+    } else if (lv == 0 || lv == 3) {
+      v.buf = s->dec;  // see CtuShared::dec, CtuShared::c2
       v.lw[0] = 6; v.lw[1] = v.lw[2] = 5;
       v.bias[0] = 0; v.bias[1] = 4096; v.bias[2] = 5120;
     } else if (lv == 1) {
@@ -356,7 +361,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       v.bias[1] = 1024 - ((a1y >> 1) * 16 + (a1x >> 1));
       v.bias[2] = v.bias[1] + 256;
     } else {
-      v.buf = lv == 2 ? s->c2 : s->c3;
+      v.buf = s->c2;
       v.lw[0] = 4; v.lw[1] = v.lw[2] = 3;
       v.bias[0] = -(a2y * 16 + a2x);
       v.bias[1] = 256 - ((a2y >> 1) * 8 + (a2x >> 1));
@@ -413,34 +418,33 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     const int mode = (nxn_on() && side == 0) ? (int)rl->nb_mode4_left[(fy - cy) >> 2] : (int)s->nb_mode[side][i];
     return 1 | ((int)s->nb_depth[side][i] << 1) | (mode << 8);
   }
-  // Reconstructed sample (px, py) of plane c (plane coordinates of the frame) as work-tree level lv sees it.  The four places it can
-  // live in -- decided picture, the 8x8 siblings' candidates, the left / top border of the neighbour CTUs -- are all in CtuShared,
-  // so the choice is made on the byte offset and ONE load follows: lanes of a reference row disagree about the place all the time,
-  // and as branches every lane would walk through every alternative.
-  KVZ_DEV u8 rec_px(int lv, int c, int px, int py) const
-  {
+  // Where the reconstructed sample (px, py) of plane c (plane coordinates of the frame) lives as work-tree level lv sees it, as a byte offset into CtuShared: the
+  // decided picture (which also holds the 8x8 candidates of the 16x16 CU being split) or the left / top border of the neighbour CTUs.  The choice is made on the
+  // offset and ONE load follows: lanes of a reference row disagree about the place all the time, and as branches every lane would walk through every
+  // alternative.  *dv: distance from a U sample to the V sample at the same position.
 #ifdef KVZ_HOSTSIM
-    typedef long lds_off;  // the host build's "LDS" objects are ordinary allocations, any distance apart
+  typedef long lds_off;  // the host build's "LDS" objects are ordinary allocations, any distance apart
 #else
-    typedef int lds_off;
+  typedef int lds_off;
 #endif
+  KVZ_DEV lds_off rec_off(int lv, int c, int px, int py, int *dv = nullptr) const
+  {
     const int sh = c ? 1 : 0, w = 64 >> sh, pxl = px - (cx >> sh), pyl = py - (cy >> sh);
     const u8 *base = (const u8 *)s;
-    const lds_off o_dec = (lds_off)(s->dec - base) + kPlaneOff[c] + pyl * w + pxl;  // depths 0..2 never look inside their own CU; the 64x64 merge predicts its units from each other
-    // an 8x8 CU sees its already-tried siblings inside the current 16x16, decided pixels elsewhere
-    const int rx = a2x >> sh, ry = a2y >> sh, rw = 16 >> sh;
-    const bool in3 = lv >= 3 && (unsigned)(pxl - rx) < (unsigned)rw && (unsigned)(pyl - ry) < (unsigned)rw;
-    const lds_off o_c3 = (lds_off)(s->c3 - base) + (c == 0 ? 0 : (c == 1 ? 256 : 320)) + (pyl - ry) * rw + pxl - rx;
+    const lds_off o_dec = (lds_off)(s->dec - base) + plane_off(c) + pyl * w + pxl;
     // neighbour CTUs: left column (pxl == -1) or top row (pyl == -1), staged in LDS by init()
     const lds_off o_left = (lds_off)(&s->bpx_left[0][0] - base) + c * 66 + pyl + 1, o_top = (lds_off)(&s->bpx_top[0][0] - base) + c * 98 + pxl + 1;
     const bool inside = (unsigned)pxl < (unsigned)w && (unsigned)pyl < (unsigned)w;
-    lds_off off = inside ? (in3 ? o_c3 : o_dec) : (pxl < 0 ? o_left : o_top);
+    lds_off off = inside ? o_dec : (pxl < 0 ? o_left : o_top);
+    if (dv) *dv = inside ? 1024 : (pxl < 0 ? 66 : 98);
     if (NXN && lv == 4) {  // a 4x4 PU also sees the PUs of its own CU that came before it
       const int qx = rl->a3x >> sh, qy = rl->a3y >> sh, qw = 8 >> sh;
-      if ((unsigned)(pxl - qx) < (unsigned)qw && (unsigned)(pyl - qy) < (unsigned)qw)
+      if ((unsigned)(pxl - qx) < (unsigned)qw && (unsigned)(pyl - qy) < (unsigned)qw) {
         off = (lds_off)(rl->c4 - base) + (c == 0 ? 0 : (c == 1 ? 64 : 80)) + (pyl - qy) * qw + pxl - qx;
+        if (dv) *dv = 16;
+      }
     }
-    return base[off];
+    return off;
   }
 
   // intra.c:84-126 kvz_intra_get_dir_luma_predictor
@@ -1019,12 +1023,12 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   }
 
   // ---------------------------------------------------------------- phases
-  // One reference sample of intra.c:305-425 kvz_intra_build_reference_any.  side 0 = top, 1 = left; i in [0, 2w].
+  // One reference sample of intra.c:305-425 kvz_intra_build_reference_any: where it comes from, as plane coordinates of the frame; false = no neighbour at all
+  // (the sample is mid-grey).  side 0 = top, 1 = left; i in [0, 2w].
   // avail_top / avail_left: Tables::avail_* of the block origin in luma samples (uniform for the call, hoisted by build_refs)
-  KVZ_DEV u8 ref_sample(int lv, int log2w, int c, int lx, int ly, int side, int i, int avail_top, int avail_left) const
+  KVZ_DEV bool ref_coords(int log2w, int sh, int lx, int ly, int side, int i, int avail_top, int avail_left, int *qx_out, int *qy_out) const
   {
-    const int sh = c ? 1 : 0, w = 1 << log2w, px = lx >> sh, py = ly >> sh;
-    // where the sample comes from, as coordinates: one rec_px() for every lane whatever its side
+    const int w = 1 << log2w, px = lx >> sh, py = ly >> sh;
     const bool corner = i == 0 && lx > 0 && ly > 0;
     if (i == 0 && !corner) { i = 1; side = 1; }  // corner = left[1]
     const int k = i - 1;
@@ -1038,8 +1042,8 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       qy = ly > 0 ? py - 1 : py;
     }
     if (corner) { qx = px - 1; qy = py - 1; }
-    if (lx <= 0 && ly <= 0) return 128;
-    return rec_px(lv, c, qx, qy);
+    *qx_out = qx; *qy_out = qy;
+    return !(lx <= 0 && ly <= 0);
   }
 
   // Builds the unfiltered references of the listed planes; second phase: the [1 2 1]-filtered luma references
@@ -1049,16 +1053,26 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   template <class First = NoHook>
   KVZ_DEV void build_refs(int lv, int x, int y, int log2w_y, int log2w_c, bool luma, bool chroma, First first = First())
   {
-    const int avail_top = tb->avail_top[(y & 63) >> 2][(x & 63) >> 2], avail_left = tb->avail_left[(y & 63) >> 2][(x & 63) >> 2];
+    // intra.c:47-82 num_ref_pixels_top / _left (Tables::avail_*) in closed form -- a unit above-right / below-left is usable iff it comes earlier in z-order:
+    // above, the units up to the end of the aligned group of 2^(t+1) columns, t = trailing zeros of the row; to the left, down to the end of the aligned group of
+    // 2^t rows, t = trailing zeros of the column.  Scalar arithmetic instead of two loads from global memory in front of every reference build.
+    const int ur = (y & 63) >> 2, uc = (x & 63) >> 2;
+    const int gt = ur ? 2 * (ur & -ur) : 0, gl = uc ? (uc & -uc) : 0;
+    const int avail_top = ur ? 4 * (gt - (uc & (gt - 1))) : 64, avail_left = uc ? 4 * (gl - (ur & (gl - 1))) : 64 - 4 * ur;
     KVZ_FOR_THREADS(tid) {
       first(tid);
-      // one index space over the samples of all listed planes (luma, then U, then V; top then left inside a plane): the loop body
-      // -- long and branchy -- then runs once or twice per CU instead of once per plane
+      // one index space over the luma samples and the chroma POSITIONS (top then left inside a plane): U and V samples sit at the same coordinates, a fixed
+      // distance apart wherever they live (rec_off), so one lane fetches both -- 52 lane tasks for an 8x8 CU (one wavefront), 100 for a 16x16 one
       const int ny = luma ? 2 * (2 * (1 << log2w_y) + 1) : 0, nc = chroma ? 2 * (2 * (1 << log2w_c) + 1) : 0;
-      for (int g = tid; g < ny + 2 * nc; g += KVZ_CTU_THREADS) {
-        const int c = g < ny ? 0 : (g < ny + nc ? 1 : 2), i = g - (c == 0 ? 0 : (c == 1 ? ny : ny + nc));
+      const u8 *base = (const u8 *)s;
+      for (int g = tid; g < ny + nc; g += KVZ_CTU_THREADS) {
+        const int c = g < ny ? 0 : 1, i = g - (c == 0 ? 0 : ny);
         const int l2 = c ? log2w_c : log2w_y, n = 2 * (1 << l2) + 1, side = i >= n, k = side ? i - n : i;
-        s->ref[c][side][k] = ref_sample(lv, l2, c, x, y, side, k, avail_top, avail_left);
+        int qx, qy, dv;
+        const bool have = ref_coords(l2, c, x, y, side, k, avail_top, avail_left, &qx, &qy);
+        const lds_off off = rec_off(lv, c, qx, qy, &dv);
+        s->ref[c][side][k] = have ? base[off] : (u8)128;
+        if (c) s->ref[2][side][k] = have ? base[off + dv] : (u8)128;
       }
     }
     KVZ_SYNC();
@@ -1076,7 +1090,23 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         }
       }
       const int c = tid - (KVZ_CTU_THREADS - 3);  // the last three lanes: one DC value each
-      if (c >= 0 && ((c == 0 && luma) || (c > 0 && chroma))) s->dcval[c] = (u8)dc_value(c ? log2w_c : log2w_y, s->ref[c][0], s->ref[c][1]);
+      if (c >= 0 && ((c == 0 && luma) || (c > 0 && chroma))) {
+        const int l2 = c ? log2w_c : log2w_y, w = 1 << l2;
+#ifdef KVZ_HOSTSIM
+        s->dcval[c] = (u8)dc_value(l2, s->ref[c][0], s->ref[c][1]);
+#else
+        // intra-generic.c:219-225: four samples per v_sad_u8 (|x - 0| summed over the bytes of a dword)
+        u32 sum = 0;
+        for (int i = 0; i < w; i += 4) {
+          u32 a, b;
+          __builtin_memcpy(&a, &s->ref[c][0][1 + i], 4);
+          __builtin_memcpy(&b, &s->ref[c][1][1 + i], 4);
+          sum = __builtin_amdgcn_sad_u8(a, 0u, sum);
+          sum = __builtin_amdgcn_sad_u8(b, 0u, sum);
+        }
+        s->dcval[c] = (u8)((sum + w) >> (l2 + 1));
+#endif
+      }
     }
     KVZ_SYNC();
     KVZ_PROF(KVZ_P_REFS);
@@ -1331,11 +1361,25 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
 
   // Extended main reference of the angular modes 11..25 (see CtuShared::mref) for a 2^L2 CU.  All reads first, then all
   // writes: the loop bounds are compile-time constants, so the LDS round trips of different entries overlap.
+  // 8x8 and 16x16 CUs: which reference sample an entry copies is a constant of (mode, q, CU size) -- filtered or not, top or left, projected index -- so it comes
+  // out of Tables::mref_tab together with where it goes: a table load, a byte load and a byte store per entry instead of forty instructions of index arithmetic.
+  // `pre`: the lane's table entries, fetched by the caller before the reference build (device: they are loads from global memory, and two barriers lie between
+  // the request and the use)
   template <int L2>
-  KVZ_DEV void build_mref(int tid)
+  KVZ_DEV void build_mref(int tid, const u32 *pre = nullptr)
   {
     constexpr int W = 1 << L2, NQ = 2 * W + 2, THRES = L2 == 3 ? 7 : (L2 == 4 ? 1 : 0), N = (15 * NQ + KVZ_CTU_THREADS - 1) / KVZ_CTU_THREADS;
     u8 vals[N];
+    if constexpr (L2 != 5) {
+      static_assert(N * KVZ_CTU_THREADS <= 512, "Tables::mref_tab rows");
+      const u8 *src = &s->ref[0][0][0];
+      u8 *dst = &s->mref[0][0];
+      u32 e[N];
+      for (int k = 0; k < N; k++) e[k] = pre ? pre[k] : tb->mref_tab[L2 - 3][tid + k * KVZ_CTU_THREADS];
+      for (int k = 0; k < N; k++) vals[k] = src[e[k] & 0xffff];
+      for (int k = 0; k < N; k++) dst[e[k] >> 16] = vals[k];
+      return;
+    }
     for (int k = 0; k < N; k++) {
       const int i = imin(tid + k * KVZ_CTU_THREADS, 15 * NQ - 1), mode = 11 + i / NQ, q = i % NQ - W;
       const bool vertical = mode >= 18, filt = imin(iabs(mode - 26), iabs(mode - 10)) > THRES;
@@ -1346,10 +1390,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     }
     for (int k = 0; k < N; k++) {
       const int i = tid + k * KVZ_CTU_THREADS;
-      if (i < 15 * NQ) {
-        if (L2 == 5) mref32()[(i / NQ) * KVZ_MREF32_STRIDE + KVZ_MREF32_ORG + i % NQ - W] = vals[k];
-        else s->mref[i / NQ][KVZ_MREF_ORG + i % NQ - W] = vals[k];
-      }
+      if (i < 15 * NQ) mref32()[(i / NQ) * KVZ_MREF32_STRIDE + KVZ_MREF32_ORG + i % NQ - W] = vals[k];
     }
   }
   // 32x32 rough search (S32): the transposed source block and the extended references sit in the 32-point transform scratch, idle until the reconstruction
@@ -1498,6 +1539,13 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   KVZ_DEV void rough_search(int lv, int x, int y, int depth, First first)
   {
     const int log2w = 6 - depth, w = 1 << log2w, xl = x - cx, yl = y - cy, nblk = (w >> 3) * (w >> 3);
+#ifndef KVZ_HOSTSIM
+    u32 mref_pre[4] = { 0, 0, 0, 0 };  // build_mref's table entries of this lane, requested ahead of the reference build
+    if (!(S32 && log2w == 5)) {
+      const u32 *row = tb->mref_tab[log2w - 3] + ((threadIdx.x + lane_rot) & (KVZ_CTU_THREADS - 1));
+      for (int k = 0; k < 4; k++) mref_pre[k] = row[k * KVZ_CTU_THREADS];
+    }
+#endif
     build_refs(lv, x, y, log2w, depth == 3 ? 2 : log2w - 1, true, true, first);
     if (S32 && log2w == 5) {
       // 32x32 CU: all 35 modes x 16 blocks predicted and Hadamard-scored in registers like the angular modes of the smaller CUs
@@ -1532,7 +1580,11 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     } else {
     KVZ_FOR_THREADS(tid) {
       // extended main reference per angular mode
+#ifdef KVZ_HOSTSIM
       if (log2w == 3) build_mref<3>(tid); else build_mref<4>(tid);
+#else
+      if (log2w == 3) build_mref<3>(tid, mref_pre); else build_mref<4>(tid, mref_pre);
+#endif
       for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) {
         const int ex = e >> log2w, ey = e & (w - 1);
         s->org_t[e] = *org_at(0, xl + ex, yl + ey);
@@ -1711,7 +1763,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         int level = (int)(((u32)iabs(cf) * (u32)q.flat_q + (u32)q.add) >> q.q_bits);
         if (cf < 0) level = -level;
         level = iclip(-32768, 32767, level);
-        (coeff_level(lv) + kPlaneOff[c] + zorder(xl >> sh, yl >> sh))[e] = (i16)level;
+        (coeff_level(lv) + plane_off(c) + zorder(xl >> sh, yl >> sh))[e] = (i16)level;
         if (cabac_on()) levels_lds(lv, c)[e] = (i16)level;
         int al = iabs(level);
         nz = al != 0;
@@ -1773,7 +1825,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     const int sh = c ? 1 : 0;
     if (NXN && lv == 4) return levels_lds(4, c);
     return lv == 2 ? s->lv2_coeff + (c == 0 ? 0 : (c == 1 ? 256 : 320))
-         : lv == 1 ? s->lv1_coeff + (c == 0 ? 0 : (c == 1 ? 1024 : 1280)) : coeff_level(lv) + kPlaneOff[c] + zorder(xl >> sh, yl >> sh);
+         : lv == 1 ? s->lv1_coeff + (c == 0 ? 0 : (c == 1 ? 1024 : 1280)) : coeff_level(lv) + plane_off(c) + zorder(xl >> sh, yl >> sh);
   }
   // Entry (k, i) of the transform of a 2^l2 block of plane c: the DCT, except 4x4 intra luma (strategies-dct.c:82-86, 111-115: the DST), which only the PUs of
   // an NxN CU have
@@ -2154,22 +2206,22 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         }
         for (int e = tid; e < 2 * cw * cw; e += KVZ_CTU_THREADS) {
           const int c = 1 + (e >= cw * cw), k = e & (cw * cw - 1), px = (xl >> 1) + (k & (cw - 1)), py = (yl >> 1) + (k >> (lw - 1));
-          s->dec[kPlaneOff[c] + py * 32 + px] = cv.at(c, px, py);
+          s->dec[plane_off(c) + py * 32 + px] = cv.at(c, px, py);
         }
       }
       if (coeffs) {
         i16 *dst = coeff_level(3);
         const unsigned zy = zorder(xl, yl), zc = zorder(xl >> 1, yl >> 1);
         if (w == 16) {  // the 16x16 / 32x32 challenger's levels never left LDS
-          for (int e = tid; e < 384; e += KVZ_CTU_THREADS) dst[e < 256 ? zy + e : kPlaneOff[1 + ((e - 256) >> 6)] + zc + ((e - 256) & 63)] = s->lv2_coeff[e];
+          for (int e = tid; e < 384; e += KVZ_CTU_THREADS) dst[e < 256 ? zy + e : plane_off(1 + ((e - 256) >> 6)) + zc + ((e - 256) & 63)] = s->lv2_coeff[e];
         } else if (w == 32) {
-          for (int e = tid; e < 1536; e += KVZ_CTU_THREADS) dst[e < 1024 ? zy + e : kPlaneOff[1 + ((e - 1024) >> 8)] + zc + ((e - 1024) & 255)] = s->lv1_coeff[e];
+          for (int e = tid; e < 1536; e += KVZ_CTU_THREADS) dst[e < 1024 ? zy + e : plane_off(1 + ((e - 1024) >> 8)) + zc + ((e - 1024) & 255)] = s->lv1_coeff[e];
         } else {
           const i16 *src = coeff_level(0);
           for (int e = tid; e < w * w; e += KVZ_CTU_THREADS) dst[zy + e] = src[zy + e];
           for (int e = tid; e < 2 * cw * cw; e += KVZ_CTU_THREADS) {
             const int c = e >= cw * cw, k = c ? e - cw * cw : e;
-            dst[kPlaneOff[1 + c] + zc + k] = src[kPlaneOff[1 + c] + zc + k];
+            dst[plane_off(1 + c) + zc + k] = src[plane_off(1 + c) + zc + k];
           }
         }
       }
@@ -2304,7 +2356,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
           const int c = tid < 64 ? 0 : (tid < 80 ? 1 : 2), e = tid - (c == 0 ? 0 : (c == 1 ? 64 : 80)), sh = c ? 1 : 0, l2 = 3 - sh;
           const int px = (xl >> sh) + (e & ((1 << l2) - 1)), py = (yl >> sh) + (e >> l2);
           c3v.at(c, px, py) = c4v.at(c, px, py);
-          i16 *dst = coeff_level(3) + kPlaneOff[c] + zorder(xl >> sh, yl >> sh);
+          i16 *dst = coeff_level(3) + plane_off(c) + zorder(xl >> sh, yl >> sh);
           dst[e] = rl->lv4_coeff[tid];
         }
         if (tid == 0) {
@@ -2434,14 +2486,14 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         u8 *dst = const_cast<u8 *>(frame_rec(c));
         for (int e = tid; e < lw * lw; e += KVZ_CTU_THREADS) {
           const int px = ox + e % lw, py = oy + e / lw;
-          if (px < fw && py < fh) dst[(long)py * fw + px] = fin[kPlaneOff[c] + e];
+          if (px < fw && py < fh) dst[(long)py * fw + px] = fin[plane_off(c) + e];
         }
       }
       u8 *r = F.border + ((long)frame * F.wc * F.hc + ctu_index()) * KVZ_BORDER_BYTES;
       for (int v = tid; v < 128; v += KVZ_CTU_THREADS) {
         const int c = v < 64 ? 0 : (v < 96 ? 1 : 2), i = v < 64 ? v : (v - 64) & 31, lw = c ? 32 : 64;
-        r[v] = fin[kPlaneOff[c] + (lw - 1) * lw + i];        // bottom row
-        r[128 + v] = fin[kPlaneOff[c] + i * lw + lw - 1];    // right column
+        r[v] = fin[plane_off(c) + (lw - 1) * lw + i];        // bottom row
+        r[128 + v] = fin[plane_off(c) + i * lw + lw - 1];    // right column
       }
     }
     KVZ_SYNC();
@@ -2537,7 +2589,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       if (cx + qxl >= F.W || cy + qyl >= F.H) continue;
       KVZ_FOR_THREADS(tid) {
         for (int e = tid; e < 1536; e += KVZ_CTU_THREADS)
-          s->lv1_coeff[e] = fin[e < 1024 ? q * 1024 + e : kPlaneOff[1 + ((e - 1024) >> 8)] + q * 256 + ((e - 1024) & 255)];
+          s->lv1_coeff[e] = fin[e < 1024 ? q * 1024 + e : plane_off(1 + ((e - 1024) >> 8)) + q * 256 + ((e - 1024) & 255)];
       }
       KVZ_SYNC();
       KVZ_FOR_THREADS(tid) {
@@ -2792,7 +2844,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     // (the host simulation cannot show such a race).
     const bool split_wins2 = s->split_cost[2] < s->cost[2];
     if (split_wins2) {
-      commit(3, 2, 2, 3, false, xl, yl, 16, 2, true);   // work_tree_copy_up: the 8x8 CUs win (their coefficients are already in place)
+      commit(3, 2, 2, -1, false, xl, yl, 16, 2, true);  // work_tree_copy_up: the 8x8 CUs win (their pixels and coefficients are already in place)
     } else {
       commit(2, 3, 3, 2, true, xl, yl, 16, 2, false);   // work_tree_copy_down: the 16x16 CU wins
     }

@@ -68,6 +68,10 @@ struct Tables {
   // CABAC context state machine (H.265 table 9-41) on kvazaar's packed state (state << 1 | MPS, cabac.c:40-62):
   // [0] after coding the more probable symbol, [1] after the less probable one
   u8 ctx_next[2][128];
+  // CTU pass, rough search: where every entry of the extended main references of the angular modes 11..25 comes from (CtuShared::mref; intra-generic.c:97-123) for an
+  // 8x8 [0] / 16x16 [1] CU.  Entry i (mode 11 + i / NQ, q = i % NQ - W, NQ = 2 W + 2) = source byte offset from CtuShared::ref (unfiltered top 0 / left 68, the
+  // filtered ones 408 / 476 behind them) | destination byte offset from CtuShared::mref << 16
+  u32 mref_tab[2][512];
   u8 diag8[64];  // up-right diagonal order of an 8x8 grid: the coefficient groups of a 32x32 block (tables.h:66-79 g_sig_last_scan_32x32)
   u32 entropy_bits[128];       // kvz_entropy_bits (rdo.c:69-80): Q15 price of a bin, index = context state ^ bin
   int8_t luma_filter[4][8];    // filter.c:66-72
