@@ -1359,6 +1359,71 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     return 2 * sum;
   }
 
+#ifndef KVZ_HOSTSIM
+  // Planar, DC or mode 34 on one 8x8 block of an 8x8 / 16x16 CU by EIGHT neighbouring lanes, one row each (lane & 7 = the row): the three modes that do not fit
+  // the wavefront of the 32 other ones (two lanes a block, angular_block_satd) would otherwise cost a second round of that routine's four-rows-a-lane code for a
+  // handful of lanes.  Row generator (the same integers as angular_block_satd's), the row's butterflies in the lane, the column's through three DPP exchanges
+  // (partner 7 - i, then i ^ 2, i ^ 1: pairing with the mirrored lane instead of i ^ 4 only swaps outputs between the two halves and flips signs, and magnitudes
+  // are what is summed), the last row stage folded into the sum as there.  Every lane returns the block's total.
+  KVZ_DEV u32 flat_block_satd8(int log2w, int mode, int bx, int by, int xl, int yl, int lane) const
+  {
+    const int w = 1 << log2w, r = lane & 7, y = by + r;
+    U16x2 o[4], v[4];
+    widen8(org_at(0, xl + bx, yl + y), o);
+    if (mode == 0) {  // planar
+      const u8 *top = s->fref[0], *left = s->fref[1];
+      const int tr = top[w + 1], bl = left[w + 1], l = left[y + 1];
+      U16x2 tp[4];
+      widen8(top + bx + 1, tp);
+      const U16x2 dl = splat16(tr - l), wy = splat16(w - 1 - y), hb = splat16((w - 1) * l + tr + (y + 1) * bl + w);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        U16x2 xs;
+        xs.x = (unsigned short)(bx + 2 * j); xs.y = (unsigned short)(bx + 2 * j + 1);
+        v[j] = (xs * dl + (tp[j] * wy + hb)) >> (unsigned short)(log2w + 1);
+      }
+    } else if (mode == 1) {  // DC with its edge smoothing
+      const u8 *top = s->ref[0][0], *left = s->ref[0][1];
+      const int dc = s->dcval[0];
+      U16x2 tp[4];
+      widen8(top + bx + 1, tp);
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = y == 0 ? (U16x2)((tp[j] + splat16(3 * dc + 2)) >> (unsigned short)2) : splat16(dc);
+      if (bx == 0) v[0].x = (unsigned short)(y == 0 ? (left[1] + 2 * dc + top[1] + 2) >> 2 : (left[y + 1] + 3 * dc + 2) >> 2);
+    } else {  // mode 34: displacement 32 a row on the filtered top reference (thresholds 7 and 1 are both below its distance 8), no fraction
+      widen8(s->fref[0] + bx + y + 2, v);
+    }
+    Pk16 d[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) d[j] = as_pk16(v[j] - o[j]);
+    {
+      const Pk16 a0 = pk_add(d[0], d[2]), a1 = pk_add(d[1], d[3]), a2 = pk_sub(d[0], d[2]), a3 = pk_sub(d[1], d[3]);
+      d[0] = pk_add(a0, a1); d[1] = pk_sub(a0, a1); d[2] = pk_add(a2, a3); d[3] = pk_sub(a2, a3);
+    }
+#define KVZ_FLAT8_STAGE(ctrl, bit)                                                                          \
+    {                                                                                                       \
+      const Pk16 sgn = pk_make((lane & (bit)) ? -1 : 1, (lane & (bit)) ? -1 : 1);                           \
+      _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                       \
+        int mine;                                                                                           \
+        __builtin_memcpy(&mine, &d[j], 4);                                                                  \
+        const int theirs = __builtin_amdgcn_update_dpp(0, mine, ctrl, 0xF, 0xF, true);                       \
+        Pk16 ot;                                                                                            \
+        __builtin_memcpy(&ot, &theirs, 4);                                                                  \
+        d[j] = ot * sgn + d[j];                                                                             \
+      }                                                                                                     \
+    }
+    KVZ_FLAT8_STAGE(0x141 /* row_half_mirror */, 4)
+    KVZ_FLAT8_STAGE(0x4E /* quad_perm [2,3,0,1] */, 2)
+    KVZ_FLAT8_STAGE(0xB1 /* quad_perm [1,0,3,2] */, 1)
+#undef KVZ_FLAT8_STAGE
+    u32 sum = pk_absmax(d[0]) + pk_absmax(d[1]) + pk_absmax(d[2]) + pk_absmax(d[3]);
+    sum += (u32)__builtin_amdgcn_update_dpp(0, (int)sum, 0xB1, 0xF, 0xF, true);
+    sum += (u32)__builtin_amdgcn_update_dpp(0, (int)sum, 0x4E, 0xF, 0xF, true);
+    sum += (u32)__builtin_amdgcn_update_dpp(0, (int)sum, 0x141, 0xF, 0xF, true);
+    return 2 * sum;
+  }
+#endif
+
   // Extended main reference of the angular modes 11..25 (see CtuShared::mref) for a 2^L2 CU.  All reads first, then all
   // writes: the loop bounds are compile-time constants, so the LDS round trips of different entries overlap.
   // 8x8 and 16x16 CUs: which reference sample an entry copies is a constant of (mode, q, CU size) -- filtered or not, top or left, projected index -- so it comes
@@ -1606,12 +1671,22 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         s->satd_raw[mode][b] = angular_block_satd<false>(log2w, mode, bx, by, xl, yl, 0);
       }
 #else
-      // TWO lanes per (mode, block), rows 0..3 and 4..7 of the block (angular_block_satd<true>): 70 lane tasks for an 8x8 CU -- the 64 of modes 2..33 fill one
-      // wavefront --, 280 for a 16x16 one
-      for (int t = tid; t < 70 * nblk; t += KVZ_CTU_THREADS) {
-        const int p = t >> 1, mi = p >> lb, mode = mi < 33 ? mi + 2 : mi - 33, b = p & (nblk - 1), bx = (b & ((w >> 3) - 1)) * 8, by = (b >> (log2w - 3)) * 8;
+      // modes 2..33: TWO lanes per (mode, block), rows 0..3 and 4..7 of the block (angular_block_satd<true>): 64 lane tasks for an 8x8 CU -- one wavefront --,
+      // 256 for a 16x16 one
+      for (int t = tid; t < 64 * nblk; t += KVZ_CTU_THREADS) {
+        const int p = t >> 1, mode = 2 + (p >> lb), b = p & (nblk - 1), bx = (b & ((w >> 3) - 1)) * 8, by = (b >> (log2w - 3)) * 8;
         const u32 v = angular_block_satd<true>(log2w, mode, bx, by, xl, yl, t & 1);
         if (!(t & 1)) s->satd_raw[mode][b] = v;
+      }
+      // mode 34, planar, DC: EIGHT lanes per (mode, block), one row each (flat_block_satd8), taken from the far end of the thread ids -- the other wavefront of an
+      // 8x8 CU (24 lane tasks; 96 for a 16x16 one)
+      {
+        const int t = KVZ_CTU_THREADS - 1 - tid;  // groups of eight tasks are groups of eight lanes
+        if (t < 24 * nblk) {
+          const int mb = t >> 3, mi = mb >> lb, mode = mi == 0 ? 34 : mi - 1, b = mb & (nblk - 1), bx = (b & ((w >> 3) - 1)) * 8, by = (b >> (log2w - 3)) * 8;
+          const u32 v = flat_block_satd8(log2w, mode, bx, by, xl, yl, tid);
+          if ((tid & 7) == 0) s->satd_raw[mode][b] = v;
+        }
       }
 #endif
     }
