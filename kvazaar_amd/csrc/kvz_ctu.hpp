@@ -60,6 +60,14 @@ static unsigned long long g_kvz_syncs;
 #define KVZ_SYNC() __syncthreads()
 #define KVZ_LDS_ADD(p, v) atomicAdd((p), (v))
 #endif
+// End of a phase whose results only the lanes of the SAME wavefront read next (the planes of the fused 8x8 CU: one wavefront is all luma, the other all chroma):
+// a wavefront's LDS operations execute in order, so what is needed is only that the compiler keeps them in order -- no s_barrier, and neither wavefront
+// waits for the other.  The host build runs a phase as a loop over the threads either way.
+#ifdef KVZ_HOSTSIM
+#define KVZ_WAVE_SYNC()
+#else
+#define KVZ_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
 
 // Sum of `v` over the workgroup added to the LDS word *dst.  Must be reached by every lane of the wave (uniform control
 // flow): wave64 DPP reduction, then one LDS atomic per wave.  Integer adds, so the result does not depend on the order.
@@ -222,7 +230,10 @@ template <bool CABAC> struct CtuSharedT {
       u8 c2[384];              // depth-2 candidate (16x16 CU):     Y 256 | U 64 | V 64
       // (the depth-3 candidates -- the four 8x8 CUs of the current 16x16 -- are written straight into `dec`: nothing reads that region of the decided picture
       // before the 16x16 decision, which either keeps them or overwrites them with c2)
-      alignas(8) u8 pred[3 * 256];  // planar, DC and -- for 16x16 CUs -- mode 34 (see rough_search); the rest: planar and DC predictions of the CU being searched (<= 16x16)
+      // quantised levels of the four 8x8 CUs of the current 16x16, laid out like lv2_coeff (Y 4 x 64 | U 4 x 16 | V 4 x 16, children in z-order): like the larger
+      // challengers' they only go to HBM if the split wins (commit()) -- every evaluated 8x8 CU storing its levels was three quarters of the pass's write traffic.
+      // Also what the CABAC coefficient cost of an 8x8 CU reads (levels_lds()).
+      alignas(8) i16 lv3_coeff[384];
       // Rough search, the 15 angular modes with a negative displacement (11..25): the main reference with its projected
       // extension (intra-generic.c:97-123), already picked from the filtered / unfiltered, top / left arrays.  Entry
       // [mode - 11][KVZ_MREF_ORG + q] is ref_main[q], q in [-w, w + 1] -- all such a mode can touch.  The other modes read
@@ -306,6 +317,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   KVZ_DEV bool cabac_on() const { return CABAC && m->coeff_cabac; }  // coefficients priced with the CABAC model (rdo.c:311-340)
   int frame, cx, cy;  // CTU origin (luma px)
   int a1x, a1y, a2x, a2y;  // CTU-local luma origin of the depth-1 / depth-2 CU whose candidates are live (uniform)
+  int a3q = 0;             // which 8x8 child of the depth-2 CU is being evaluated (z-order; uniform): its slot in CtuShared::lv3_coeff
   int lane_rot = 0;        // see KVZ_FOR_THREADS
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
   unsigned long long t_last;
@@ -326,8 +338,8 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   KVZ_DEV int ctu_index() const { return (cy >> 6) * F.wc + (cx >> 6); }
   KVZ_DEV i16 *coeff_level(int level) const
   {
-    // 8x8 CUs write straight into the CTU's output block; every larger CU is a challenger whose levels are copied over only
-    // if it wins (commit()): a 16x16 CU and a 32x32 merge keep them in LDS (CtuShared::lv2_coeff / lv1_coeff), the 64x64
+    // Level 3 is the CTU's output block; every CU is a challenger whose levels are copied over only when it wins (commit()):
+    // 8x8 CUs, a 16x16 CU and a 32x32 merge keep them in LDS (CtuShared::lv3_coeff / lv2_coeff / lv1_coeff), the 64x64
     // merge writes the scratch block in HBM.  One scratch block is enough: a depth's challenger is dead by the time the next shallower depth writes
     // the same z-order range.
     const long ci = (long)frame * F.wc * F.hc + ctu_index();
@@ -1011,13 +1023,12 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     }
     return 0;
   }
-  // Levels of the unit being priced, in LDS: 16x16 CUs and 32x32 merges keep theirs there anyway (lv2_coeff / lv1_coeff); with the
-  // CABAC model the 8x8 CUs stage a copy in the (by then dead) rough-search prediction buffer and the 32x32 units of the 64x64
-  // attempt in lv1_coeff (recon_tus stage 4)
+  // Levels of the unit being evaluated / priced, in LDS: 8x8 CUs (the child a3q of the current 16x16), 16x16 CUs and 32x32 merges keep theirs there anyway
+  // (lv3_coeff / lv2_coeff / lv1_coeff); with the CABAC model the 32x32 units of the 64x64 attempt stage a copy in lv1_coeff (recon_tus stage 4)
   KVZ_DEV i16 *levels_lds(int lv, int c) const
   {
     if (NXN && lv == 4) return rl->lv4_coeff + (c == 0 ? 16 * rl->n_pu : (c == 1 ? 64 : 80));  // the PU being evaluated (n_pu counts the finished ones)
-    if (lv == 3) return (i16 *)s->pred + (c == 0 ? 0 : (c == 1 ? 64 : 80));
+    if (lv == 3) return s->lv3_coeff + (c == 0 ? 64 * a3q : (c == 1 ? 256 : 320) + 16 * a3q);
     if (lv == 2) return s->lv2_coeff + (c == 0 ? 0 : (c == 1 ? 256 : 320));
     return s->lv1_coeff + (c == 0 ? 0 : (c == 1 ? 1024 : 1280));
   }
@@ -1799,8 +1810,11 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     const bool on = (tid) < 96;                                                                                         \
     const int c = (tid) < 64 ? 0 : ((tid) < 80 ? 1 : 2), e = (tid) - (c == 0 ? 0 : (c == 1 ? 64 : 80)), l2 = c ? 2 : 3, n = 1 << l2, sh = c ? 1 : 0; \
     (void)sh; (void)n
+    // The five stages below synchronise per wavefront only (KVZ_WAVE_SYNC): luma lives on one wavefront, U and V on the other, and nothing crosses between the
+    // planes before the cost -- each wavefront clears and fills its own sums (acc[0, 3, 6] luma, the others chroma).
     KVZ_FOR_THREADS(tid) {
-      if (tid < 16) s->acc[tid] = 0;
+      if (tid < 3) s->acc[3 * tid] = 0;
+      if (tid >= 64 && tid < 70) s->acc[1 + (tid - 64) + ((tid - 64) >> 1)] = 0;  // 1, 2, 4, 5, 7, 8
       KVZ_CU8_ROLE(tid);
       if (on) {
         const int px = e & (n - 1), py = e >> l2;
@@ -1809,7 +1823,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         tbuf(t, 0, c)[e] = (i16)((int)*org_at(c, (xl >> sh) + px, (yl >> sh) + py) - (int)p);
       }
     }
-    KVZ_SYNC();
+    KVZ_WAVE_SYNC();
     KVZ_PROF(KVZ_P_RPRED);
     KVZ_FOR_THREADS(tid) {  // forward transform (dct-generic.c:559-568), first pass
       KVZ_CU8_ROLE(tid);
@@ -1821,7 +1835,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         tbuf(t, 1, c)[e] = (i16)((a + add) >> shift);
       }
     }
-    KVZ_SYNC();
+    KVZ_WAVE_SYNC();
     KVZ_PROF(KVZ_P_FDCT);
     // second pass, and -- the coefficient a lane produces is the one it quantises -- straight on: quantise (quant-generic.c:57-81)
     // -> coefficient store + cost sums; dequantise (:335-339)
@@ -1838,22 +1852,22 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         int level = (int)(((u32)iabs(cf) * (u32)q.flat_q + (u32)q.add) >> q.q_bits);
         if (cf < 0) level = -level;
         level = iclip(-32768, 32767, level);
-        (coeff_level(lv) + plane_off(c) + zorder(xl >> sh, yl >> sh))[e] = (i16)level;
-        if (cabac_on()) levels_lds(lv, c)[e] = (i16)level;
+        levels_lds(lv, c)[e] = (i16)level;  // lv == 3 here
         int al = iabs(level);
         nz = al != 0;
         if (al > 3) al = 3;
         wsum = (u32)((m->coeff_weights >> (16 * al)) & 0xffff);
         tbuf(t, 0, c)[e] = (i16)iclip(-32768, 32767, (level * q.dq_scale + (1 << (q.dq_shift - 1))) >> q.dq_shift);
       }
-      plane_add(&s->acc[3], wsum, tid);
-      plane_add(&s->acc[6], nz, tid);
+      // the plane's weight sum (< 2^22) and its count of levels travel in ONE word: one reduction instead of two.  (Per-lane LDS atomics instead of the DPP
+      // reduction -- profiles/experiments, r05_g -- take 7 k instructions per CTU off the vector pipe and cost 6 % throughput: 64 lanes on one address.)
+      plane_add(&s->acc[3], wsum | (nz << 24), tid);
     }
-    KVZ_SYNC();
+    KVZ_WAVE_SYNC();
     KVZ_PROF(KVZ_P_QUANT);
     KVZ_FOR_THREADS(tid) {  // inverse transform (dct-generic.c:570-579), first pass; only observable when the plane has coefficients
       KVZ_CU8_ROLE(tid);
-      if (on && s->acc[6 + c]) {
+      if (on && (s->acc[3 + c] >> 24)) {
         const int shift = 7, add = 1 << (shift - 1), j = e >> l2, i = e & (n - 1);
         const i16 *src = tbuf(t, 0, c);
         int a = 0;
@@ -1861,7 +1875,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         tbuf(t, 1, c)[e] = (i16)iclip(-32768, 32767, (a + add) >> shift);
       }
     }
-    KVZ_SYNC();
+    KVZ_WAVE_SYNC();
     KVZ_PROF(KVZ_P_IDCT);
     // second pass, and straight on with the sample it produces: reconstruction (quant-generic.c:266-277) + SSD against the source
     // (search.c:500-505, 512-523)
@@ -1871,7 +1885,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       if (on) {
         u8 *rp = &cv.at(c, (xl >> sh) + (e & (n - 1)), (yl >> sh) + (e >> l2));
         int v = *rp;
-        if (s->acc[6 + c]) {
+        if (s->acc[3 + c] >> 24) {
           const int shift = 12, add = 1 << (shift - 1), j = e >> l2, i = e & (n - 1);
           const i16 *src = tbuf(t, 1, c);
           int a = 0;
@@ -1884,12 +1898,21 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         ssd = (u32)(d * d);
       }
       plane_add(&s->acc[0], ssd, tid);
-      if (tid == 0) {  // cbf bits of the TU's top-left CU entry (transform.c:314, 409-411)
-        CtuCu *cu = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
-        for (int cc = 0; cc < 3; cc++) { cbf_clear(&cu->cbf, depth, cc); if (s->acc[6 + cc]) cbf_set(&cu->cbf, depth, cc); }
-      }
     }
     KVZ_SYNC();
+    KVZ_FOR_THREADS(tid) {
+      if (tid == 0) {  // cbf bits of the TU's top-left CU entry (transform.c:314, 409-411): all three planes' counts, so behind the barrier; only thread 0 reads them
+                       // next (eval_cu's cost phase, same thread: no barrier in between)
+        CtuCu *cu = &s->cu[lv][(yl >> 3) * 8 + (xl >> 3)];
+        for (int cc = 0; cc < 3; cc++) {
+          const u32 packed = s->acc[3 + cc];  // unpacked for the cost: weight sum, count
+          s->acc[3 + cc] = packed & 0xffffffu; s->acc[6 + cc] = packed >> 24;
+          cbf_clear(&cu->cbf, depth, cc);
+          if (packed >> 24) cbf_set(&cu->cbf, depth, cc);
+        }
+      }
+    }
+    if (cabac_on()) KVZ_SYNC();  // the counting-mode coder runs on every lane and asks acc[6..8] which planes have levels (price_unit_coeffs)
     KVZ_PROF(KVZ_P_RECON);
 #undef KVZ_CU8_ROLE
   }
@@ -1898,7 +1921,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   KVZ_DEV i16 *coeff_dst(int lv, int c, int xl, int yl) const
   {
     const int sh = c ? 1 : 0;
-    if (NXN && lv == 4) return levels_lds(4, c);
+    if ((NXN && lv == 4) || lv == 3) return levels_lds(lv, c);
     return lv == 2 ? s->lv2_coeff + (c == 0 ? 0 : (c == 1 ? 256 : 320))
          : lv == 1 ? s->lv1_coeff + (c == 0 ? 0 : (c == 1 ? 1024 : 1280)) : coeff_level(lv) + plane_off(c) + zorder(xl >> sh, yl >> sh);
   }
@@ -1999,7 +2022,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         const QuantScalars qf = s->qs[l2 - 2][c ? 1 : 0];  // forward and inverse share the plane's scaled QP (U and V alike)
         const QuantScalars qi = qf;
         i16 *cout = coeff_dst(lv, c, xl, yl);
-        i16 *stage = (cabac_on() && (lv == 3 || lv == 0)) ? levels_lds(lv, c) : nullptr;  // see levels_lds()
+        i16 *stage = (cabac_on() && lv == 0) ? levels_lds(lv, c) : nullptr;  // see levels_lds(); an 8x8 CU's destination IS its LDS slot
         const i16 *src = tbuf(t, 0, c);
         i16 *dq = tbuf(t, 1, c);
         u32 wsum = 0, nz = 0;
@@ -2284,11 +2307,16 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
           s->dec[plane_off(c) + py * 32 + px] = cv.at(c, px, py);
         }
       }
-      if (coeffs) {
+      if (coeffs || (split_won && res_depth == 2)) {
         i16 *dst = coeff_level(3);
         const unsigned zy = zorder(xl, yl), zc = zorder(xl >> 1, yl >> 1);
-        if (w == 16) {  // the 16x16 / 32x32 challenger's levels never left LDS
-          for (int e = tid; e < 384; e += KVZ_CTU_THREADS) dst[e < 256 ? zy + e : plane_off(1 + ((e - 256) >> 6)) + zc + ((e - 256) & 63)] = s->lv2_coeff[e];
+        if (w == 16) {  // the challengers' levels never left LDS: the 16x16 CU's, or -- the split wins -- those of the 8x8 CUs that lie inside the picture
+          const i16 *src = split_won ? s->lv3_coeff : s->lv2_coeff;
+          for (int e = tid; e < 384; e += KVZ_CTU_THREADS) {
+            const int q = e < 256 ? e >> 6 : ((e - 256) >> 4) & 3;
+            if (split_won && (cx + xl + 8 * (q & 1) >= F.W || cy + yl + 8 * (q >> 1) >= F.H)) continue;  // never evaluated (search_d2): the output block keeps its zeros
+            dst[e < 256 ? zy + e : plane_off(1 + ((e - 256) >> 6)) + zc + ((e - 256) & 63)] = src[e];
+          }
         } else if (w == 32) {
           for (int e = tid; e < 1536; e += KVZ_CTU_THREADS) dst[e < 1024 ? zy + e : plane_off(1 + ((e - 1024) >> 8)) + zc + ((e - 1024) & 255)] = s->lv1_coeff[e];
         } else {
@@ -2431,8 +2459,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
           const int c = tid < 64 ? 0 : (tid < 80 ? 1 : 2), e = tid - (c == 0 ? 0 : (c == 1 ? 64 : 80)), sh = c ? 1 : 0, l2 = 3 - sh;
           const int px = (xl >> sh) + (e & ((1 << l2) - 1)), py = (yl >> sh) + (e >> l2);
           c3v.at(c, px, py) = c4v.at(c, px, py);
-          i16 *dst = coeff_level(3) + plane_off(c) + zorder(xl >> sh, yl >> sh);
-          dst[e] = rl->lv4_coeff[tid];
+          levels_lds(3, c)[e] = rl->lv4_coeff[tid];
         }
         if (tid == 0) {
           CtuCu *cu = &s->cu[3][cell];
@@ -2887,6 +2914,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         if (!(s->split_cost[2] < s->cost[2])) break;  // uniform: both are LDS scalars
         const int qx = x + (q & 1) * 8, qy = y + (q >> 1) * 8;
         if (qx >= F.W || qy >= F.H) continue;  // child outside the picture costs 0
+        a3q = q;
         if (nxn_on()) {
           if constexpr (NXN) {
             // search_cu at depth 3 with pu_depth_intra.max = 4: the 8x8 CU as 2Nx2N, then -- if it has coefficients (cu-split-termination zero, search.c:975-984)
