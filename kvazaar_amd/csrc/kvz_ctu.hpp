@@ -317,6 +317,9 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   KVZ_DEV bool cabac_on() const { return CABAC && m->coeff_cabac; }  // coefficients priced with the CABAC model (rdo.c:311-340)
   int frame, cx, cy;  // CTU origin (luma px)
   int a1x, a1y, a2x, a2y;  // CTU-local luma origin of the depth-1 / depth-2 CU whose candidates are live (uniform)
+  // The thread that runs a CU's scalar bookkeeping inside the first phase of its reference build (cu_header, price_modes: a serial chain of LDS lookups and
+  // double-precision products): one of the OTHER wavefront than the one whose lanes fetch the reference samples of an 8x8 CU, so the two run side by side
+  static constexpr int kHookThread = KVZ_CTU_THREADS > 64 ? 64 : 0;
   int a3q = 0;             // which 8x8 child of the depth-2 CU is being evaluated (z-order; uniform): its slot in CtuShared::lv3_coeff
   int lane_rot = 0;        // see KVZ_FOR_THREADS
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
@@ -2892,7 +2895,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     const bool inside = x + 16 <= F.W && y + 16 <= F.H;
     // thread-0 bookkeeping around the 16x16 CU: header + cost initialisation before, split cost after
     auto d2_first = [&](int tid) {
-      if (tid == 0) { cu_header(2, xl, yl, 2); s->cost[2] = 1.7e+308; s->cbf_any = 0; price_modes(); }
+      if (tid == kHookThread) { cu_header(2, xl, yl, 2); s->cost[2] = 1.7e+308; s->cbf_any = 0; price_modes(); }
       ctx_copy_lanes(&s->pre[2], &s->cab, tid);
     };
     auto d2_last = [&](int tid) {
@@ -2939,7 +2942,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
             nxn_attempt(qx, qy);
           }
         } else
-        eval_cu(3, qx, qy, 3, &s->cost[3], &s->cbf_any, [&](int tid) { if (tid == 0) { cu_header(3, qx - cx, qy - cy, 3); price_modes(); } }, [&](int tid) { if (tid == 0) s->split_cost[2] += s->cost[3]; });
+        eval_cu(3, qx, qy, 3, &s->cost[3], &s->cbf_any, [&](int tid) { if (tid == kHookThread) { cu_header(3, qx - cx, qy - cy, 3); price_modes(); } }, [&](int tid) { if (tid == 0) s->split_cost[2] += s->cost[3]; });
       }
     }
     // Every lane reads the verdict here; thread 0 only touches its operands again after the barrier that ends commit()
