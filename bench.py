@@ -398,6 +398,10 @@ def build_batches(args, lib, rank, world, width, height, frames, tiles_arg, HipB
                     b.upload(i * len(tis) + j, subs[j][i % len(distinct)])
                     slots.append((i % len(distinct), ti))
             batches.append((b, slots))
+        # kvazaar's uniform grid gives tiles of up to two heights and two widths: the batches of this rank run side by side, each on its share of the workgroup slots
+        # (the persistent pass of the first one launched would otherwise fill the device, and the passes would run one after the other)
+        for b, _ in batches:
+            b.set_device_share(1, len(batches))
         ctus_per_frame = sum(((t[2] + 63) // 64) * ((t[3] + 63) // 64) for t in tiles)
         return batches, distinct, ctus_per_frame, frames * ctus_per_frame
     distinct = synth_frames(width, height, max(1, min(args.distinct, frames)), seed + rank)
@@ -625,6 +629,8 @@ def main():
                                       f"(--gpus 1) for them; this run: {world} rank(s), preset {args.preset}")
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, distinct, model)
+            if result.get("chain_full", {}).get("value") and result["cpu_baseline"].get("value"):  # like for like: both sides search, filter and code
+                result["chain_full"]["vs_cpu_baseline"] = result["chain_full"]["value"] / result["cpu_baseline"]["value"]
         print(json.dumps(result))
     for b, _ in batches:
         b.close()
@@ -989,6 +995,36 @@ def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedRes
                                      f"{half} frames alternating on two streams", "value": ctus / s_d2h, "unit": "CTUs/s", "fps": ctus / s_d2h / main_batch.ctus_per_frame,
                            "without_d2h": ctus / s_plain, "payload_bytes_per_frame": payload, "pcie_GBps": 2 * reps * half * payload / s_d2h / 1e9,
                            "host_copy_verified": (got == want) if want else None}
+    # ---- the whole all-intra chain: pass -> deblocking -> entropy coder -> slice data on the host (what the CPU baseline's encoder does) ----
+    try:
+        try:
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "entropy.json"))).get("bench-1080p")
+        except (OSError, ValueError):
+            gold = None
+        applies = (args.width, args.height, args.qp, args.preset) == (1920, 1080, 22, "ultrafast") and not args.no_wpp and not args.frozen_contexts
+        for b, pinned in pair:  # the D2H leg's batches make room
+            b.close()
+            pinned.close()
+        pair = []
+        half_full = max(1, args.frames // 2)  # the coder's third stage is one lane per WPP substream: its latency wants big batches (384 pictures: 155 ms, 768: 190 ms)
+        full = []
+        for _ in range(2):
+            b = HipBatch(lib, args.width, args.height, half_full)
+            for i in range(half_full):
+                b.upload(i, distinct[i % len(distinct)])
+            full.append(b)
+        s_full, pictures, per_pic, ok = chain_full(full, model, args.qp, 2, gold if applies else None, len(distinct))
+        for b in full:
+            b.close()
+        result["chain_full"] = {"stages": "CTU pass -> deblocking -> entropy coder on the device -> slice data and entry points downloaded into pinned host memory; two batches of "
+                                          f"{half_full} pictures alternating on two streams, one batch's coder (a worker thread's blocking call) beside the other batch's pass",
+                                "value": pictures * main_batch.ctus_per_frame / s_full, "unit": "CTUs/s", "fps": pictures / s_full, "ms_per_batch": s_full / 4 * 1e3,
+                                "slice_data_bytes_per_picture": per_pic, "verified": ok,
+                                "verify": "slice data and entry points of the clip's pictures equal the reference encoder's bitstream (tests/golden/entropy.json bench-1080p)",
+                                "note": "the like-for-like line against cpu_baseline (kvazaar's whole encoder: search, deblocking, CABAC, bitstream); parameter sets, slice "
+                                        "headers and NAL framing (a few dozen bytes per picture) stay on the host"}
+    except Exception as e:  # auxiliary: never take the headline down
+        result["chain_full"] = {"error": repr(e)}
     for b, pinned in pair:
         b.close()
         pinned.close()
@@ -1001,6 +1037,53 @@ def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedRes
         except Exception as e:  # auxiliary: never take the headline down
             result["configs_extra"].append({"workload": "3840x2160 --preset veryfast --gop lp-g4d3t1 (BASELINE config 4)", "error": repr(e)})
         result["configs_extra"].append(leg_medium(args, lib, model_for, HipBatch))
+
+
+def chain_full(pair, model, qp, reps, gold, n_distinct):
+    """CTU pass -> deblocking -> entropy coder on the device -> slice data + entry points downloaded, for two resident batches alternating on their own streams: one
+    batch's slice data is coded and downloaded (a blocking call, on a worker thread) while the other batch's pass runs (tools/chain_probe.py: 768-picture batches,
+    serial 355 ms per batch, overlapped 279 ms).  What the host gets per picture is what kvazaar's
+    encoder_state_worker_encode_lcu_bitstream wrote (encoderstate.c:636-745) -- the like-for-like counterpart of the reference encoder timed on the CPU, which also
+    searches, filters and codes.  Returns (seconds, pictures, slice-data bytes per picture, verified)."""
+    for b in pair:
+        b.sync()
+    for b in pair:                 # first use: the coder's scratch allocations
+        b.launch(model)
+        b.deblock(qp, wait=False)
+        b.entropy_code(model)
+    import threading
+    last = {}
+
+    def code(b):
+        last[id(b)] = b.entropy_code(model)  # blocks on b's pass + deblocking, codes, downloads (ctypes releases the GIL)
+    t = time.perf_counter()
+    worker = None
+    for _ in range(reps):
+        for b in pair:
+            if worker is not None:
+                time.sleep(0.003)  # the coder's first kernels are queued before the other batch's pass: a persistent launch that takes every CU it finds
+            b.launch(model)
+            b.deblock(qp, wait=False)
+            if worker is not None:
+                worker.join()
+            worker = threading.Thread(target=code, args=(b,))
+            worker.start()
+    worker.join()
+    s_full = time.perf_counter() - t
+    pictures = reps * sum(b.n for b in pair)
+    ok, nbytes = None, 0
+    for b in pair:
+        data, sizes = last[id(b)]
+        nbytes += len(data)
+        if gold:
+            good, at = True, 0
+            for i in range(min(b.n, len(gold), n_distinct)):  # picture i of a batch is frame i of the clip
+                total = int(sizes[i].sum())
+                good = good and [int(v) for v in sizes[i]] == gold[i]["sizes"] and hashlib.sha256(bytes(data[at:at + total])).hexdigest()[:24] == gold[i]["sha"]
+                at += total
+            good = bool(good and all(np.array_equal(sizes[i], sizes[i % n_distinct]) for i in range(b.n)))
+            ok = good if ok is None else (ok and good)
+    return s_full, pictures, nbytes / sum(b.n for b in pair), ok
 
 
 def leg_intra4k(args, lib, model_for, HipBatch, n4k=384, steps=3):
@@ -1027,10 +1110,34 @@ def leg_intra4k(args, lib, model_for, HipBatch, n4k=384, steps=3):
            "roofline": leg_roofline("intra4k", "intra_ctu_ticket_kernel", BYTES_PER_CTU, units, float(np.mean(kms)) / 1e3),
            "verified": bool(v["copies_consistent"] and v["golden_ok"] is not False), "verify": v}
     b4.close()
+    # the whole chain at this size (chain_full): two batches of n4k / 2 pictures
+    if not getattr(args, "only", ""):
+        try:
+            try:
+                gold = json.load(open(os.path.join(ROOT, "tests", "golden", "entropy.json"))).get("bench-2160p")
+            except (OSError, ValueError):
+                gold = None
+            half = n4k // 2
+            pair = []
+            for _ in range(2):
+                b = HipBatch(lib, w, h, half)
+                for i in range(half):
+                    b.upload(i, d4[i % len(d4)])
+                pair.append(b)
+            s_full, pictures, per_pic, ok = chain_full(pair, m4, args.qp, 2, gold if (args.qp == 22 and not args.no_wpp and not args.frozen_contexts) else None, len(d4))
+            out["chain_full"] = {"stages": f"CTU pass -> deblocking -> entropy coder on the device -> slice data downloaded; two batches of {half} pictures alternating on two streams",
+                                 "value": pictures * pair[0].ctus_per_frame / s_full, "unit": "CTUs/s", "fps": pictures / s_full, "slice_data_bytes_per_picture": per_pic, "verified": ok,
+                                 "verify": "slice data and entry points of the clip's pictures equal the reference encoder's bitstream (tests/golden/entropy.json bench-2160p)"}
+            for b in pair:
+                b.close()
+        except Exception as e:  # auxiliary
+            out["chain_full"] = {"error": repr(e)}
     if not args.no_cpu_baseline and not args.no_ref_encoder and not getattr(args, "only", ""):
         out["cpu_reference"] = cpu_reference(w, h, d4, ["--preset", "ultrafast", "-p", "1", "-q", str(args.qp)], 4)
         if out["cpu_reference"] and out["cpu_reference"].get("value"):
             out["vs_cpu_reference"] = value / out["cpu_reference"]["value"]
+            if out.get("chain_full", {}).get("value"):  # like for like: both sides search, filter and code
+                out["chain_full"]["vs_cpu_reference"] = out["chain_full"]["value"] / out["cpu_reference"]["value"]
     return out
 
 

@@ -62,6 +62,12 @@ void kvz_hip_batch_download_all_async(kvz_hip_batch *b, uint8_t *rec, int16_t *c
  * previous batch's follow-up kernels, and queue the download behind that point (bench.py chain_d2h): the copy engines then run during
  * the next pass. */
 void kvz_hip_batch_order_after(kvz_hip_batch *b, kvz_hip_batch *other);
+/* The share of the device this batch's persistent pass takes: `num` of every `den` workgroup slots per CU (1 <= num <= den; (1, 1) = all of them, the default).
+ * Batches of different geometry that are meant to run side by side -- the two tile sizes of kvazaar's uniform tile grid (encoderstate.c:944-979: 960x1088 and
+ * 960x1072 at 3840x2160 --tiles 4x2) -- each take their share; with the default the first launch fills the device and the second one only moves in when the
+ * first one's workgroups retire, i.e. the two passes run one after the other, each on fewer serial CTU chains than the device has slots.  Takes effect with
+ * the next kvz_hip_intra_frames. */
+void kvz_hip_batch_set_device_share(kvz_hip_batch *b, int num, int den);
 
 /* The hot path: search + reconstruct every CTU of every frame in the batch.  Asynchronous on the batch's stream;
  * kvz_hip_batch_sync() waits.  Returns the number of kernel launches issued (1; one per CTU anti-diagonal with the older

@@ -93,6 +93,12 @@ class HipBatch:
         self.lib.kvz_hip_batch_order_after.restype = None
         self.lib.kvz_hip_batch_order_after(self.handle, other.handle)
 
+    def set_device_share(self, num, den):
+        """this batch's persistent pass takes num / den of the device's workgroup slots (kvz_hip_batch_set_device_share): batches of different geometry side by side"""
+        self.lib.kvz_hip_batch_set_device_share.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self.lib.kvz_hip_batch_set_device_share.restype = None
+        self.lib.kvz_hip_batch_set_device_share(self.handle, num, den)
+
     def sync(self):
         if self.lib.kvz_hip_batch_sync(self.handle) != 0:
             raise BatchError("kvz_hip_batch_sync: a CTU hand-off wait timed out; results invalid")

@@ -29,6 +29,7 @@ struct kvz_hip_batch {
   unsigned *d_ticket, *d_done, *d_error;
   unsigned total_items, epoch;
   int sched_ticket, grid_ticket;
+  int slots_per_cu, cus;  // what the persistent pass may occupy at most (occupancy x CU count); grid_ticket = its share of that (kvz_hip_batch_set_device_share)
   // SAO (kvz_hip_batch_loop_filters with sao != 0; allocated on first use): the picture after the vertical edges and after all edges,
   // statistics / context-free candidates / packed parameter records per (LCU, plane), merge choice per LCU
   uint8_t *d_ver, *d_dbk, *d_sao_merge;
@@ -218,6 +219,7 @@ kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
     KVZ_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (per_cu < 1) per_cu = 1;
     if (const char *lim = getenv("KVZ_HIP_WG_PER_CU")) { const int v = atoi(lim); if (v >= 1 && v < per_cu) per_cu = v; }  // occupancy experiments
+    b->slots_per_cu = per_cu; b->cus = cus;
     b->grid_ticket = per_cu * cus;
     if ((unsigned)b->grid_ticket > b->total_items) b->grid_ticket = (int)b->total_items;
   }
@@ -303,6 +305,15 @@ void kvz_hip_batch_download_all_async(kvz_hip_batch *b, uint8_t *rec, int16_t *c
   if (cu_mode) KVZ_HIP_CHECK(hipMemcpyAsync(cu_mode, b->d_mode, ncu, hipMemcpyDeviceToHost, b->stream));
 }
 
+void kvz_hip_batch_set_device_share(kvz_hip_batch *b, int num, int den)
+{
+  if (!b || !b->sched_ticket || num < 1 || den < num) return;
+  int per_cu = b->slots_per_cu * num / den;
+  if (per_cu < 1) per_cu = 1;
+  b->grid_ticket = per_cu * b->cus;
+  if ((unsigned)b->grid_ticket > b->total_items) b->grid_ticket = (int)b->total_items;
+}
+
 void kvz_hip_batch_order_after(kvz_hip_batch *b, kvz_hip_batch *other)
 {
   kvz::batch_enter(b);
@@ -336,7 +347,7 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
     // two instantiations: the one without the CABAC coefficient model carries none of its code, registers or context storage
     // (the instantiations that search 32x32 CUs, --pu-depth-intra 1-3, are separate ones too: the others stay as they were)
     if (cm.rdoq || cm.search_nxn) {  // --rdoq and / or NxN partitions (preset `medium`): their own instantiation (32x32 search and the coefficient cost model switched by the model)
-      if (cm.rdoq && !b->d_rdoq) KVZ_HIP_CHECK(hipMalloc((void **)&b->d_rdoq, (size_t)b->grid_ticket * 3 * KVZ_RDOQ_SCRATCH_DOUBLES * sizeof(double)));
+      if (cm.rdoq && !b->d_rdoq) KVZ_HIP_CHECK(hipMalloc((void **)&b->d_rdoq, (size_t)b->slots_per_cu * b->cus * 3 * KVZ_RDOQ_SCRATCH_DOUBLES * sizeof(double)));
       if (cm.search_nxn && !b->d_part) {
         KVZ_HIP_CHECK(hipMalloc((void **)&b->d_part, (size_t)(F.W / 8) * (F.H / 8) * b->n_frames));
         KVZ_HIP_CHECK(hipMalloc((void **)&b->d_mode4, (size_t)(F.W / 4) * (F.H / 4) * b->n_frames));

@@ -108,7 +108,8 @@ CASES = [
 
 # the pictures bench.py keeps resident (the first 8 frames of SURVEY.md App. C's 1080p clip): fixture entries only -- the device's coder is checked against them on the GPU
 # and by bench.py's entropy leg; the oracle's on the build machine when the fixture is made
-BENCH_CASES = [("bench-1080p", 1920, 1080, 8, 1, "large", 22, "ultrafast", [])]
+BENCH_CASES = [("bench-1080p", 1920, 1080, 8, 1, "large", 22, "ultrafast", []),
+               ("bench-2160p", 3840, 2160, 4, 2, "large", 22, "ultrafast", [])]  # ... and the four pictures of its 3840x2160 legs (App. C's 2160p clip)
 
 
 def case_model(oracle, case):

@@ -324,7 +324,12 @@ def update_entropy():
     import entropy_common as ec
     oracle = flatapi.load_oracle()
     out = {}
+    only = [a for a in sys.argv[sys.argv.index("--entropy") + 1:] if not a.startswith("-")]  # `--entropy name ...`: (re)make these cases only, keep the others as they are
+    if only:
+        out = json.load(open(os.path.join(HERE, "entropy.json")))
     for case in ec.CASES + ec.BENCH_CASES:
+        if only and case[0] not in only:
+            continue
         with tempfile.TemporaryDirectory() as d:
             payloads = ec.reference_slice_payloads(os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "kvazaar_ref"), case, d)
         pictures = []
