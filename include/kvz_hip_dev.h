@@ -174,6 +174,10 @@ int  kvz_hip_dev_inter_ctu_pass_tiles(const uint8_t *src, const uint8_t *ref, co
                                       int height, int n_pictures, const kvz_hip_inter_params *params, const int32_t *tile_xy, int n_references);
 /* milliseconds the kernel of the calling thread's last kvz_hip_dev_inter_ctu_pass took on the device (HIP events on its stream around the launch) */
 float kvz_hip_dev_inter_kernel_ms(void);
+/* Workgroups of the inter CTU pass's kernel that fit one CU (its occupancy on the current device; the pass is a persistent launch of that many per CU).  Two passes
+ * that are to run side by side -- the two tile sizes of a uniform tile grid, from two host threads -- each take half: KVZ_HIP_INTER_WG_PER_CU in the environment of the
+ * calls (kvazaar_amd/inter.py TiledInterSequences.run_picture). */
+int kvz_hip_dev_inter_slots_per_cu(void);
 /* The slice data of n B pictures -- kvz_encode_coding_tree with the inter syntax (encode_coding_tree.c:745-900, kvz_encode_inter_prediction_unit :311-421, kvz_encode_mvd
  * :1062-1112), the residual coder and the arithmetic coder, as kvz_hip_batch_entropy_code does it for I pictures (kvz_hip_batch.h) -- from what the inter CTU pass left on
  * the device: cu (its CU records), ref_cu (the reference pictures' records: the temporal MV predictor), coeff (its levels; the pass must have been given a coeff buffer).

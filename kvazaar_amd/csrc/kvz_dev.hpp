@@ -1365,6 +1365,12 @@ int kvz_hip_dev_inter_ctu_pass_tiles(const uint8_t *src, const uint8_t *ref, con
 }
 
 float kvz_hip_dev_inter_kernel_ms(void) { return kvz::inter_kernel_ms(); }
+int kvz_hip_dev_inter_slots_per_cu(void)
+{
+  int fit = 0;
+  KVZ_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, (const void *)kvz::inter_ctu_ticket_kernel_fast, KVZ_ICTU_THREADS, 0));
+  return fit > 0 ? fit : 8;
+}
 
 int kvz_hip_dev_pu_search(const uint8_t *cur, const uint8_t *ref, int width, int height, const kvz_hip_me_pu *pus, int count, int max_pu_size,
                           const kvz_hip_me_params *params, kvz_hip_me_result *out)

@@ -1,6 +1,7 @@
 """Host side of the inter CTU pass (include/kvz_hip_dev.h kvz_hip_dev_inter_ctu_pass): the CU record layout, the per-picture parameters and a thin wrapper that
 keeps the pictures of many independent sequences on the device.  The product path: no oracle, no CPU fallback -- the library call fails if the HIP kernels are missing."""
 import ctypes as C
+import os
 import hashlib
 
 import numpy as np
@@ -267,22 +268,48 @@ class TiledInterSequences:
         """one B picture of every sequence: the CTU pass of this rank's tiles, their loop filters, then the exchange that turns the result into the next picture's reference"""
         torch = self.torch
         torch.cuda.synchronize()
-        self.pass_ms = 0.0
         self.lib.kvz_hip_dev_inter_kernel_ms.restype = C.c_float
         prm = self.group_params(base)
-        for (tw, th), members in self.groups.items():
-            g, m = (tw, th), len(members) * self.n
+
+        def group_pass(g, members):
+            tw, th = g
+            m = len(members) * self.n
             rc = self.lib.kvz_hip_dev_inter_ctu_pass_tiles(self.src[g].data_ptr(), self.ref.data_ptr(), self.ref_cu.data_ptr(), self.rec[g].data_ptr(), self.cu[g].data_ptr(), None, tw, th,
                                                            m, C.addressof(prm), self.xy[g].data_ptr(), self.n)
             if rc != 0:
                 raise RuntimeError(f"kvz_hip_dev_inter_ctu_pass_tiles returned {rc}")
-            self.pass_ms += float(self.lib.kvz_hip_dev_inter_kernel_ms())
+            ms = float(self.lib.kvz_hip_dev_inter_kernel_ms())
             self.lib.kvz_hip_dev_cu_dbk_from_info(self.cu[g].data_ptr(), m * (tw // 4) * (th // 4), self.dbk[g].data_ptr())
             rc = self.lib.kvz_hip_dev_loop_filters_inter(self.src[g].data_ptr(), self.rec[g].data_ptr(), tw, th, m, self.dbk[g].data_ptr(), prm.qp, 1, prm.deblock, 0, 0, prm.sao, 1, None, None, None)
             if rc != 0:
                 raise RuntimeError(f"kvz_hip_dev_loop_filters_inter returned {rc}")
-        self.lib.kvz_hip_dev_sync()
+            self.lib.kvz_hip_dev_sync()  # this thread's stream of the library
+            return ms
+        groups = list(self.groups.items())
+        if len(groups) > 1:
+            # kvazaar's uniform grid gives this rank tiles of two sizes: their passes are two persistent launches, and the first one launched fills the device while
+            # each holds fewer serial tile chains than the device has workgroup slots.  So: side by side, each on its share of the slots (KVZ_HIP_INTER_WG_PER_CU), from
+            # two host threads -- a thread has its own stream and scratch in the library, and the blocking calls release the GIL.
+            if getattr(self, "_pool", None) is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=len(groups))
+            saved = os.environ.get("KVZ_HIP_INTER_WG_PER_CU")
+            os.environ["KVZ_HIP_INTER_WG_PER_CU"] = str(max(1, int(saved or self.slots_per_cu()) // len(groups)))
+            try:
+                self.pass_ms = max(f.result() for f in [self._pool.submit(group_pass, g, mem) for g, mem in groups])
+            finally:
+                if saved is None:
+                    os.environ.pop("KVZ_HIP_INTER_WG_PER_CU", None)
+                else:
+                    os.environ["KVZ_HIP_INTER_WG_PER_CU"] = saved
+        else:
+            self.pass_ms = sum(group_pass(g, mem) for g, mem in groups)
         self.exchange()
+
+    def slots_per_cu(self):
+        """workgroups of the inter pass's kernel that fit a CU (kvz_hip_dev_inter_slots_per_cu: its occupancy; 12 with the round-4 build)"""
+        self.lib.kvz_hip_dev_inter_slots_per_cu.restype = C.c_int
+        return int(self.lib.kvz_hip_dev_inter_slots_per_cu())
 
     def exchange(self):
         """all-gather of the tiles' pictures and CU records, pasted into every rank's reference frames"""
