@@ -183,7 +183,10 @@ int kvz_hip_dev_inter_slots_per_cu(void);
  * the device: cu (its CU records), ref_cu (the reference pictures' records: the temporal MV predictor), coeff (its levels; the pass must have been given a coeff buffer).
  * params: the pass's (qp, poc, no_wpp; sao != 0: the SAO syntax of the decisions the last kvz_hip_dev_loop_filters_inter(..., sao = 1) made on the same pictures).  The MV
  * predictors the MVDs are coded against are derived again from the records (kvz_inter_get_mv_cand_cua, inter.c:1330-1352).  out (HOST) / substream_bytes (HOST, n_pictures x
- * (CTU rows | 1)): as kvz_hip_batch_entropy_code.  Returns the total size, -1 on failure. */
+ * (CTU rows | 1)): as kvz_hip_batch_entropy_code.  Returns the total size, -1 on failure.
+ * With sao != 0 the call reads the SAO records and merge flags that kvz_hip_dev_loop_filters_inter left in the CALLING THREAD's scratch of the current device: the two
+ * calls must come from the same host thread, the filter call on these pictures directly before -- a thread that filtered other pictures in between codes THEIR SAO syntax,
+ * a thread that never filtered gets -1. */
 long kvz_hip_dev_entropy_code_inter(const kvz_hip_cu_info *cu, const kvz_hip_cu_info *ref_cu, const int16_t *coeff, int width, int height, int n_pictures,
                                     const kvz_hip_inter_params *params, uint8_t *out, size_t capacity, uint32_t *substream_bytes);
 /* what the deblocking filter reads (kvz_hip_cu_dbk) of `count` CU records: type, depth, tr_depth, the luma coded block flag at tr_depth, motion */

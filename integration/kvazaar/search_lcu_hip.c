@@ -121,7 +121,9 @@ static int eligible(const encoder_state_t *state)
     REQUIRE((cfg->pu_depth_inter.min[layer] < 0 || cfg->pu_depth_inter.min[layer] == cfg->pu_depth_inter.min[0]) && (cfg->pu_depth_inter.max[layer] < 0 || cfg->pu_depth_inter.max[layer] == cfg->pu_depth_inter.max[0]));
     REQUIRE((cfg->pu_depth_intra.min[layer] < 0 || cfg->pu_depth_intra.min[layer] == cfg->pu_depth_intra.min[0]) && (cfg->pu_depth_intra.max[layer] < 0 || cfg->pu_depth_intra.max[layer] == cfg->pu_depth_intra.max[0]));
   }
-  REQUIRE(!cfg->fast_coeff_table_fn);  /* the pass prices with the built-in fast-coefficient-cost weights (kvz_hip_default_coeff_weights): a custom --fast-coeff-table stays with kvz_search_lcu */
+  /* the pass prices with the built-in fast-coefficient-cost weights (kvz_hip_default_coeff_weights): a custom --fast-coeff-table stays with kvz_search_lcu.  The test is on the
+   * PARSED table: encoder.c:168 clears cfg.fast_coeff_table_fn once the file has been read into ctrl->fast_coeff_table, so the file name says nothing here. */
+  REQUIRE(state->qp < 0 || state->qp >= MAX_FAST_COEFF_COST_QP || ctrl->fast_coeff_table.wts_by_qp[state->qp] == kvz_hip_default_coeff_weights(state->qp));
   REQUIRE(cfg->fast_residual_cost_limit >= 0 && cfg->fast_residual_cost_limit <= 51 && !cfg->intra_rdo_et);  /* the pass prices coefficients either way (rdo.c:311-340) */
   REQUIRE(state->tile->frame->width % 8 == 0 && state->tile->frame->height % 8 == 0);
 #undef REQUIRE

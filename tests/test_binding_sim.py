@@ -89,6 +89,27 @@ def test_binding_inter_pictures_write_the_reference_bitstream(tmp_path, res, fra
         assert got == "1e7a81653d1157ce05e9ffd85c7cd5cf"  # 416x240 x 8 --preset veryfast --gop lp-g4d3t1
 
 
+def test_binding_leaves_b_pictures_with_a_custom_coeff_table_to_kvazaar(tmp_path):
+    """--fast-coeff-table: the inter pass prices with the built-in weights, so B pictures under a custom table must stay with kvz_search_lcu (the I pictures take the table's
+    weights through the cost model).  encoder.c:168 clears cfg.fast_coeff_table_fn after parsing, so the binding has to look at the parsed table: the bitstream is the
+    reference encoder's, and no B picture went through the pass."""
+    if not os.path.exists(os.path.join(REF, "kvazaar_hipsim")):
+        pytest.skip("oracle/_ref/kvazaar_hipsim not built (oracle/Makefile, where /root/reference exists)")
+    table = str(tmp_path / "weights.txt")
+    with open(table, "w") as f:
+        for qp in range(50):  # fast_coeff_cost.c:56-72: fifty lines of four weights
+            f.write(f"{0.16 + 0.001 * qp:.6f} {4.2 + 0.01 * qp:.6f} {3.1 + 0.02 * qp:.6f} {6.5 + 0.03 * qp:.6f}\n")
+    yuv = str(tmp_path / "syn.yuv")
+    synth.write_yuv(yuv, 416, 240, 6, 1234, "small")
+    opts = ["--preset", "veryfast", "--gop", "lp-g4d3t1", "--owf", "0", "--fast-coeff-table", table, "--threads", "4"]
+    want = _encode("kvazaar_ref", yuv, "416x240", str(tmp_path / "ref.hevc"), opts)
+    got = _encode("kvazaar_hipsim", yuv, "416x240", str(tmp_path / "sim.hevc"), opts, {"KVZ_HIP_DISABLE": "1", "KVZ_HIP_BATCH_SEARCH": "1", "KVZ_HIP_INTER_TRACE": str(tmp_path / "trace")})
+    assert got == want
+    assert not os.path.exists(str(tmp_path / "trace")) or int(open(str(tmp_path / "trace")).read() or 0) == 0, "B pictures went through the inter pass under a custom table"
+    plain = _encode("kvazaar_ref", yuv, "416x240", str(tmp_path / "plain.hevc"), [o for o in opts if o not in ("--fast-coeff-table", table)])
+    assert plain != want, "the table does not change the encode: the case tests nothing"
+
+
 # ---- the device's entropy coder behind the binding (KVZ_HIP_BATCH_ENTROPY=1): levels stay on the device, kvz_encode_coding_tree is skipped, the row coders' streams are
 # replaced by the device's substreams before the slice header takes its entry points from them ----
 ENTROPY_CASES = [(8, ["--preset", "ultrafast", "-p", "1"], True),                                  # BASELINE config 1: the survey's md5
