@@ -1117,7 +1117,7 @@ def leg_intra4k(args, lib, model_for, HipBatch, n4k=384, steps=3):
                 gold = json.load(open(os.path.join(ROOT, "tests", "golden", "entropy.json"))).get("bench-2160p")
             except (OSError, ValueError):
                 gold = None
-            half = n4k // 2
+            half = n4k  # 2 x 384 pictures of 3840x2160: the coder's third stage wants big batches (one lane per WPP substream)
             pair = []
             for _ in range(2):
                 b = HipBatch(lib, w, h, half)

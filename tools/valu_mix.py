@@ -18,9 +18,12 @@ with tempfile.TemporaryDirectory() as d:
     tmp = os.path.join(d, "lib.so")
     os.symlink(lib, tmp)
     subprocess.run([objdump, "--offloading", tmp], cwd=d, capture_output=True)
-    co = [f for f in os.listdir(d) if "gfx950" in f][0]
-    dis = subprocess.run([objdump, "-d", os.path.join(d, co)], capture_output=True, text=True).stdout
-m = re.search(r"\n[0-9a-f]+ <_ZN3kvz23intra_ctu_ticket_kernelILb0E[^>]*>:\n(.*?)\n[0-9a-f]+ <[^>]*>:\n", dis, re.S)  # up to the next symbol
+    m = None
+    for co in sorted(f for f in os.listdir(d) if "gfx950" in f):  # one code object per translation unit (kvazaar_amd/build.py): the kernel is in one of them
+        dis = subprocess.run([objdump, "-d", os.path.join(d, co)], capture_output=True, text=True).stdout
+        m = re.search(r"\n[0-9a-f]+ <_ZN3kvz23intra_ctu_ticket_kernelILb0ELb0ELb0E[^>]*>:\n(.*?)(?:\n[0-9a-f]+ <[^>]*>:\n|\Z)", dis, re.S)  # up to the next symbol
+        if m:
+            break
 ops = collections.Counter(line.split()[0] for line in m.group(1).splitlines() if line.strip() and line.split()[0][:2] in ("v_", "s_", "ds", "gl", "bu", "fl", "sc"))
 # measured ~1.0-1.1 ns class (tools/valu_issue_bench.hip): e32 encodings of the plain integer / logic / move / f32-fma ops
 FAST = re.compile(r"^v_(mov_b32|add_u32|sub_u32|subrev_u32|and_b32|or_b32|xor_b32|lshrrev_b32|ashrrev_i32|not_b32|fma_f32|add_f32|mul_f32|max_u32|min_u32|max_i32|min_i32)_e32$")
