@@ -55,40 +55,42 @@ template <int N> __device__ __forceinline__ void dev_product(const int *v, const
     dev_int4 lo, hi;
     for (int q = 0; q < 4; q++) { u32 l, h; dev_byte_planes(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3], l, h); lo[q] = (int)l; hi[q] = (int)h; }
     const dev_int4 tv = *reinterpret_cast<const dev_int4 *>(tab + M::idx(lane) * 32 + (lane >> 5) * 16);
-    dev_int16 al, ah;
-    for (int r = 0; r < 16; r++) ah[r] = 0;
+    // ONE accumulator: the high plane's product first, then 256 x it + the bias as the accumulator the low plane's product adds to -- half the registers of two
+    // accumulators and a combining pass (the 32-point products were where the CTU kernel's register allocation spilled)
+    dev_int16 acc;
+    for (int r = 0; r < 16; r++) acc[r] = 0;
     if (table_is_a) {
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(tv, hi, acc, 0, 0, 0);
       for (int q = 0; q < 4; q++) {
         const dev_int4 s4 = *reinterpret_cast<const dev_int4 *>(sums + M::row(lane, 4 * q));
-        for (int i = 0; i < 4; i++) al[4 * q + i] = 128 * s4[i] + add;
+        for (int i = 0; i < 4; i++) acc[4 * q + i] = acc[4 * q + i] * 256 + (128 * s4[i] + add);
       }
-      al = __builtin_amdgcn_mfma_i32_32x32x32_i8(tv, lo, al, 0, 0, 0);
-      ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(tv, hi, ah, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(tv, lo, acc, 0, 0, 0);
     } else {
       const int c = 128 * sums[M::idx(lane)] + add;
-      for (int r = 0; r < 16; r++) al[r] = c;
-      al = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, tv, al, 0, 0, 0);
-      ah = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, tv, ah, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(hi, tv, acc, 0, 0, 0);
+      for (int r = 0; r < 16; r++) acc[r] = acc[r] * 256 + c;
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(lo, tv, acc, 0, 0, 0);
     }
-    for (int r = 0; r < 16; r++) out[r] = ah[r] * 256 + al[r];
+    for (int r = 0; r < 16; r++) out[r] = acc[r];
   } else {
     u32 l, h;
     dev_byte_planes(v[0], v[1], v[2], v[3], l, h);
     const long lo = (long)(unsigned long long)l, hi = (long)(unsigned long long)h;
     const long tv = (long)(unsigned long long)*reinterpret_cast<const u32 *>(tab + M::idx(lane) * 16 + 4 * (lane >> 4));
-    dev_int4 al, ah = { 0, 0, 0, 0 };
+    dev_int4 acc = { 0, 0, 0, 0 };
     if (table_is_a) {
       const dev_int4 s4 = *reinterpret_cast<const dev_int4 *>(sums + M::row(lane, 0));
-      for (int i = 0; i < 4; i++) al[i] = 128 * s4[i] + add;
-      al = __builtin_amdgcn_mfma_i32_16x16x32_i8(tv, lo, al, 0, 0, 0);
-      ah = __builtin_amdgcn_mfma_i32_16x16x32_i8(tv, hi, ah, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(tv, hi, acc, 0, 0, 0);
+      for (int i = 0; i < 4; i++) acc[i] = acc[i] * 256 + (128 * s4[i] + add);
+      acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(tv, lo, acc, 0, 0, 0);
     } else {
       const int c = 128 * sums[M::idx(lane)] + add;
-      for (int i = 0; i < 4; i++) al[i] = c;
-      al = __builtin_amdgcn_mfma_i32_16x16x32_i8(lo, tv, al, 0, 0, 0);
-      ah = __builtin_amdgcn_mfma_i32_16x16x32_i8(hi, tv, ah, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(hi, tv, acc, 0, 0, 0);
+      for (int i = 0; i < 4; i++) acc[i] = acc[i] * 256 + c;
+      acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(lo, tv, acc, 0, 0, 0);
     }
-    for (int r = 0; r < 4; r++) out[r] = ah[r] * 256 + al[r];
+    for (int r = 0; r < 4; r++) out[r] = acc[r];
   }
 }
 
