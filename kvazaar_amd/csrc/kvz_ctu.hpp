@@ -31,6 +31,7 @@
 // as threads of one phase do not communicate, which is the discipline followed here (LDS atomics are integer adds; the few
 // places that use cross-lane operations on the device have a plain form for the host next to them).
 #pragma once
+#include <type_traits>
 #include "../../include/kvz_hip_types.h"
 #include "kvz_ops.hpp"
 #include "kvz_rdoq.hpp"
@@ -1809,89 +1810,105 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   {
     const int xl = t.x - cx, yl = t.y - cy;
     const CandView cv = cand_view(lv);
+    // A lane's role is fixed by its wavefront: threads 0..63 are the luma samples (8-point transform), 64..79 / 80..95 the U / V samples (4-point).  Every stage
+    // below is written once and instantiated per role (`luma` a compile-time constant), so that inside a wavefront plane, block size, shifts and trip counts are
+    // constants -- as one body with a per-lane plane they were selects and counted loops.
+#define KVZ_CU8_STAGE(body) KVZ_FOR_THREADS(tid) { if (tid < 64) { body(std::true_type(), tid); } else if (tid < 96) { body(std::false_type(), tid); } }
 #define KVZ_CU8_ROLE(tid)                                                                                               \
-    const bool on = (tid) < 96;                                                                                         \
-    const int c = (tid) < 64 ? 0 : ((tid) < 80 ? 1 : 2), e = (tid) - (c == 0 ? 0 : (c == 1 ? 64 : 80)), l2 = c ? 2 : 3, n = 1 << l2, sh = c ? 1 : 0; \
-    (void)sh; (void)n
+    constexpr bool LUMA = decltype(luma)::value;                                                                        \
+    constexpr int l2 = LUMA ? 3 : 2, n = 1 << l2, sh = LUMA ? 0 : 1;                                                    \
+    const int c = LUMA ? 0 : ((tid) < 80 ? 1 : 2), e = LUMA ? (tid) : ((tid) & 15);                                     \
+    (void)sh; (void)n; (void)c; (void)e
     // The five stages below synchronise per wavefront only (KVZ_WAVE_SYNC): luma lives on one wavefront, U and V on the other, and nothing crosses between the
-    // planes before the cost -- each wavefront clears and fills its own sums (acc[0, 3, 6] luma, the others chroma).
+    // planes before the cost -- each wavefront clears and fills its own sums (acc[0, 3] luma, acc[1, 2, 4, 5] chroma).
     KVZ_FOR_THREADS(tid) {
-      if (tid < 3) s->acc[3 * tid] = 0;
-      if (tid >= 64 && tid < 70) s->acc[1 + (tid - 64) + ((tid - 64) >> 1)] = 0;  // 1, 2, 4, 5, 7, 8
-      KVZ_CU8_ROLE(tid);
-      if (on) {
-        const int px = e & (n - 1), py = e >> l2;
-        const u8 p = predict_pixel(l2, mode, c, px, py);
-        cv.at(c, (xl >> sh) + px, (yl >> sh) + py) = p;
-        tbuf(t, 0, c)[e] = (i16)((int)*org_at(c, (xl >> sh) + px, (yl >> sh) + py) - (int)p);
-      }
+      if (tid < 2) s->acc[3 * tid] = 0;
+      if (tid >= 64 && tid < 68) s->acc[1 + (tid - 64) + ((tid - 64) >> 1)] = 0;  // 1, 2, 4, 5
     }
+    auto stage1 = [&](auto luma, int tid) {
+      KVZ_CU8_ROLE(tid);
+      const int px = e & (n - 1), py = e >> l2;
+      const u8 p = predict_pixel(l2, mode, c, px, py);
+      cv.at(c, (xl >> sh) + px, (yl >> sh) + py) = p;
+      tbuf(t, 0, c)[e] = (i16)((int)*org_at(c, (xl >> sh) + px, (yl >> sh) + py) - (int)p);
+    };
+    KVZ_CU8_STAGE(stage1)
     KVZ_WAVE_SYNC();
     KVZ_PROF(KVZ_P_RPRED);
-    KVZ_FOR_THREADS(tid) {  // forward transform (dct-generic.c:559-568), first pass
+    auto stage2 = [&](auto luma, int tid) {  // forward transform (dct-generic.c:559-568), first pass
       KVZ_CU8_ROLE(tid);
-      if (on) {
-        const int shift = l2 - 1, add = 1 << (shift - 1), k = e >> l2, j = e & (n - 1);
-        const i16 *src = tbuf(t, 0, c);
-        int a = 0;
-        for (int i = 0; i < n; i++) a += dct_at(l2, k, i) * (int)src[(j << l2) + i];
-        tbuf(t, 1, c)[e] = (i16)((a + add) >> shift);
-      }
-    }
+      constexpr int shift = l2 - 1, add = 1 << (shift - 1);
+      const int k = e >> l2, j = e & (n - 1);
+      const i16 *src = tbuf(t, 0, c);
+      int a = 0;
+#pragma unroll
+      for (int i = 0; i < n; i++) a += dct_at(l2, k, i) * (int)src[(j << l2) + i];
+      tbuf(t, 1, c)[e] = (i16)((a + add) >> shift);
+    };
+    KVZ_CU8_STAGE(stage2)
     KVZ_WAVE_SYNC();
     KVZ_PROF(KVZ_P_FDCT);
     // second pass, and -- the coefficient a lane produces is the one it quantises -- straight on: quantise (quant-generic.c:57-81)
     // -> coefficient store + cost sums; dequantise (:335-339)
     KVZ_FOR_THREADS(tid) {
-      KVZ_CU8_ROLE(tid);
-      u32 wsum = 0, nz = 0;
-      if (on) {
-        const int shift = l2 + 6, add = 1 << (shift - 1), k = e >> l2, j = e & (n - 1);
+      u32 packed = 0;
+      auto stage3 = [&](auto luma, int tid_) {
+        KVZ_CU8_ROLE(tid_);
+        constexpr int shift = l2 + 6, add = 1 << (shift - 1);
+        const int k = e >> l2, j = e & (n - 1);
         const i16 *src = tbuf(t, 1, c);
         int a = 0;
+#pragma unroll
         for (int i = 0; i < n; i++) a += dct_at(l2, k, i) * (int)src[(j << l2) + i];
         const int cf = (i16)((a + add) >> shift);
-        const QuantScalars q = s->qs[l2 - 2][c ? 1 : 0];
+        const QuantScalars q = s->qs[l2 - 2][LUMA ? 0 : 1];
         int level = (int)(((u32)iabs(cf) * (u32)q.flat_q + (u32)q.add) >> q.q_bits);
         if (cf < 0) level = -level;
         level = iclip(-32768, 32767, level);
         levels_lds(lv, c)[e] = (i16)level;  // lv == 3 here
         int al = iabs(level);
-        nz = al != 0;
+        const u32 nz = al != 0;
         if (al > 3) al = 3;
-        wsum = (u32)((m->coeff_weights >> (16 * al)) & 0xffff);
+        const u32 wsum = (u32)((m->coeff_weights >> (16 * al)) & 0xffff);
         tbuf(t, 0, c)[e] = (i16)iclip(-32768, 32767, (level * q.dq_scale + (1 << (q.dq_shift - 1))) >> q.dq_shift);
-      }
+        packed = wsum | (nz << 24);
+      };
+      if (tid < 64) stage3(std::true_type(), tid); else if (tid < 96) stage3(std::false_type(), tid);
       // the plane's weight sum (< 2^22) and its count of levels travel in ONE word: one reduction instead of two.  (Per-lane LDS atomics instead of the DPP
       // reduction -- profiles/experiments, r05_g -- take 7 k instructions per CTU off the vector pipe and cost 6 % throughput: 64 lanes on one address.)
-      plane_add(&s->acc[3], wsum | (nz << 24), tid);
+      plane_add(&s->acc[3], packed, tid);
     }
     KVZ_WAVE_SYNC();
     KVZ_PROF(KVZ_P_QUANT);
-    KVZ_FOR_THREADS(tid) {  // inverse transform (dct-generic.c:570-579), first pass; only observable when the plane has coefficients
+    auto stage4 = [&](auto luma, int tid) {  // inverse transform (dct-generic.c:570-579), first pass; only observable when the plane has coefficients
       KVZ_CU8_ROLE(tid);
-      if (on && (s->acc[3 + c] >> 24)) {
-        const int shift = 7, add = 1 << (shift - 1), j = e >> l2, i = e & (n - 1);
+      if (s->acc[3 + c] >> 24) {
+        constexpr int shift = 7, add = 1 << (shift - 1);
+        const int j = e >> l2, i = e & (n - 1);
         const i16 *src = tbuf(t, 0, c);
         int a = 0;
+#pragma unroll
         for (int k = 0; k < n; k++) a += dct_at(l2, k, i) * (int)src[(k << l2) + j];
         tbuf(t, 1, c)[e] = (i16)iclip(-32768, 32767, (a + add) >> shift);
       }
-    }
+    };
+    KVZ_CU8_STAGE(stage4)
     KVZ_WAVE_SYNC();
     KVZ_PROF(KVZ_P_IDCT);
     // second pass, and straight on with the sample it produces: reconstruction (quant-generic.c:266-277) + SSD against the source
     // (search.c:500-505, 512-523)
     KVZ_FOR_THREADS(tid) {
-      KVZ_CU8_ROLE(tid);
       u32 ssd = 0;
-      if (on) {
+      auto stage5 = [&](auto luma, int tid_) {
+        KVZ_CU8_ROLE(tid_);
         u8 *rp = &cv.at(c, (xl >> sh) + (e & (n - 1)), (yl >> sh) + (e >> l2));
         int v = *rp;
         if (s->acc[3 + c] >> 24) {
-          const int shift = 12, add = 1 << (shift - 1), j = e >> l2, i = e & (n - 1);
+          constexpr int shift = 12, add = 1 << (shift - 1);
+          const int j = e >> l2, i = e & (n - 1);
           const i16 *src = tbuf(t, 1, c);
           int a = 0;
+#pragma unroll
           for (int k = 0; k < n; k++) a += dct_at(l2, k, i) * (int)src[(k << l2) + j];
           const i16 res = (i16)iclip(-32768, 32767, (a + add) >> shift);
           v = iclip(0, 255, (int)(i16)(res + v));
@@ -1899,7 +1916,8 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         }
         const int d = (int)*org_at(c, (xl >> sh) + (e & (n - 1)), (yl >> sh) + (e >> l2)) - v;
         ssd = (u32)(d * d);
-      }
+      };
+      if (tid < 64) stage5(std::true_type(), tid); else if (tid < 96) stage5(std::false_type(), tid);
       plane_add(&s->acc[0], ssd, tid);
     }
     KVZ_SYNC();
@@ -1918,6 +1936,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     if (cabac_on()) KVZ_SYNC();  // the counting-mode coder runs on every lane and asks acc[6..8] which planes have levels (price_unit_coeffs)
     KVZ_PROF(KVZ_P_RECON);
 #undef KVZ_CU8_ROLE
+#undef KVZ_CU8_STAGE
   }
 
   // Where the quantised levels of plane c of a transform unit at (xl, yl) go when work-tree level lv evaluates it (see coeff_level())

@@ -504,7 +504,12 @@ struct InterCtu {
   }
   IC_DEV void begin_ctu(int frame_, int cx_, int cy_)
   {
-    IC_FOR(tid) { if (tid == 0) { frame = frame_; cx = cx_; cy = cy_; if (F.tile_xy) { K->tile_x = ((const KVZ_GLB int *)F.tile_xy)[2 * frame_]; K->tile_y = ((const KVZ_GLB int *)F.tile_xy)[2 * frame_ + 1]; } } }
+    IC_FOR(tid) { if (tid == 0) { frame = frame_; cx = cx_; cy = cy_; if (F.tile_xy) {
+      // the origin is a DEVICE-side input nobody validated: brought inside the reference frame here (multiples of 8, the tile inside the frame), so that no read of
+      // the reference picture or of its CU records can leave them whatever the table holds; a valid table is unchanged
+      const int tx = ((const KVZ_GLB int *)F.tile_xy)[2 * frame_], ty = ((const KVZ_GLB int *)F.tile_xy)[2 * frame_ + 1];
+      K->tile_x = imax(0, imin(tx, K->ref_w - F.W)) & ~7; K->tile_y = imax(0, imin(ty, K->ref_h - F.H)) & ~7;
+    } } }
     IC_SYNC();
   }
 };
