@@ -1688,6 +1688,12 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
 #else
       // modes 2..33: TWO lanes per (mode, block), rows 0..3 and 4..7 of the block (angular_block_satd<true>): 64 lane tasks for an 8x8 CU -- one wavefront --,
       // 256 for a 16x16 one
+      if (log2w == 4 && KVZ_CTU_THREADS == 128) {
+        // a 16x16 CU has 128 (mode, block) pairs: ONE lane each, all eight rows in the lane (angular_block_satd<false>) -- one round of the two wavefronts where the
+        // paired form needs two, and no exchange stage
+        const int mode = 2 + (tid >> 2), b = tid & 3;
+        s->satd_raw[mode][b] = angular_block_satd<false>(4, mode, (b & 1) * 8, (b >> 1) * 8, xl, yl, 0);
+      } else
       for (int t = tid; t < 64 * nblk; t += KVZ_CTU_THREADS) {
         const int p = t >> 1, mode = 2 + (p >> lb), b = p & (nblk - 1), bx = (b & ((w >> 3) - 1)) * 8, by = (b >> (log2w - 3)) * 8;
         const u32 v = angular_block_satd<true>(log2w, mode, bx, by, xl, yl, t & 1);
