@@ -197,3 +197,32 @@ def test_c_host_example_matches_oracle_chain(oracle, hiplib, tmp_path):
         want.append((oracle.plane_checksum(flatapi.ptr(r), h, w, w), oracle.plane_checksum(flatapi.ptr(r, offset=ys), h // 2, w // 2, w // 2),
                      oracle.plane_checksum(flatapi.ptr(r, offset=ys + cs), h // 2, w // 2, w // 2)))
     assert got == want, out
+
+
+def test_two_geometries_side_by_side_on_their_shares_of_the_device(oracle, hiplib):
+    """kvz_hip_batch_set_device_share: batches of two geometries (the two tile heights of a --tiles grid) launched back to back, each on half the workgroup slots, give
+    what each gives alone -- every picture against the oracle -- and a share of (1, 1) afterwards restores the whole device"""
+    model = _model(hiplib, oracle, 22)
+    model.no_wpp = 1  # tiles: one coder per tile in raster order (cfg.c:925-978)
+    geo = [(192, 136), (192, 120)]
+    frames = [cc.yuv_frames(w, h, 24, 77 + k, "small") for k, (w, h) in enumerate(geo)]
+    batches = [cc.HipBatch(hiplib, w, h, len(f)) for (w, h), f in zip(geo, frames)]
+    try:
+        for b, f in zip(batches, frames):
+            for i, fr in enumerate(f):
+                b.upload(i, fr)
+            b.set_device_share(1, 2)
+        for b in batches:  # asynchronous: the two persistent launches are resident together
+            b.launch(model)
+        for b in batches:
+            b.sync()
+        for (w, h), b, f in zip(geo, batches, frames):
+            for i in (0, 11, 23):
+                want = cc.run_oracle(oracle, model, w, h, f[i])
+                assert not cc.compare(want, b.download(i)), ((w, h), i)
+        batches[0].set_device_share(1, 1)
+        batches[0].run(model)
+        assert not cc.compare(cc.run_oracle(oracle, model, geo[0][0], geo[0][1], frames[0][5]), batches[0].download(5))
+    finally:
+        for b in batches:
+            b.close()
