@@ -112,6 +112,23 @@ KVZ_DEV u32 pk_absmax(Pk16 a)
   const Pk16 m = __builtin_elementwise_max(a, -a);
   return (u32)imax((int)m.x, (int)m.y);
 }
+// acc + |lo + hi| + |lo - hi| of a packed pair whose LOW half carries the block's bias: 0x8000 added to ONE input sample of an 8x8 Hadamard transform -- the sample
+// (0, 0), which enters every output with weight +1 or, after a stage that keeps a negated difference, -1, and -0x8000 == 0x8000 in 16 bits -- arrives in every output,
+// and |x| of a 16-bit value then is the unsigned distance of x + 0x8000 from 0x8000: v_sad_u16 takes both halves' magnitudes and the running sum in one instruction,
+// where sign flip, maximum, half extraction and addition were four.  The last butterfly stage (the one across the halves) is spelled out here instead of folded.
+KVZ_DEV u32 pk_abs2_biased(Pk16 a, u32 acc)
+{
+  unsigned x;
+  __builtin_memcpy(&x, &a, 4);
+  const unsigned t = __builtin_amdgcn_alignbit(x, x, 16);  // [hi, lo]
+  Pk16 sw, r;
+  __builtin_memcpy(&sw, &t, 4);
+  r = a * pk_make(1, -1) + sw;  // [lo + hi, lo - hi]
+  unsigned rr;
+  __builtin_memcpy(&rr, &r, 4);
+  return __builtin_amdgcn_sad_u16(rr, 0x80008000u, acc);
+}
+#define KVZ_PK_BIAS pk_make(-32768, 0)
 #endif
 
 #ifndef KVZ_HOSTSIM
@@ -1333,8 +1350,11 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       for (int j = 0; j < 4; j++) d[i][j] = pk_make(v[2 * j] - (int)((ow >> (16 * j)) & 0xff), v[2 * j + 1] - (int)((ow >> (16 * j + 8)) & 0xff));
     }
     }
+#ifndef KVZ_HOSTSIM
+    if (PAIR ? half == 0 : true) d[0][0] = pk_add(d[0][0], KVZ_PK_BIAS);  // sample (0, 0), in the lane that holds row 0: see pk_abs2_biased
+#endif
 #pragma unroll
-    for (int i = 0; i < NR; i++) {  // along the rows: columns k and k + 4, then k and k + 2 (k and k + 1 is the folded stage)
+    for (int i = 0; i < NR; i++) {  // along the rows: columns k and k + 4, then k and k + 2 (k and k + 1 is the last stage: folded into the sum / spelled out in pk_abs2_biased)
       const Pk16 a0 = pk_add(d[i][0], d[i][2]), a1 = pk_add(d[i][1], d[i][3]), a2 = pk_sub(d[i][0], d[i][2]), a3 = pk_sub(d[i][1], d[i][3]);
       d[i][0] = pk_add(a0, a1); d[i][1] = pk_sub(a0, a1); d[i][2] = pk_add(a2, a3); d[i][3] = pk_sub(a2, a3);
     }
@@ -1357,9 +1377,10 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
           e[i] = o * sgn + d[i][j];
         }
         const Pk16 b0 = pk_add(e[0], e[2]), b1 = pk_add(e[1], e[3]), b2 = pk_sub(e[0], e[2]), b3 = pk_sub(e[1], e[3]);
-        sum += pk_absmax(pk_add(b0, b1)) + pk_absmax(pk_sub(b0, b1)) + pk_absmax(pk_add(b2, b3)) + pk_absmax(pk_sub(b2, b3));
+        sum = pk_abs2_biased(pk_add(b0, b1), sum); sum = pk_abs2_biased(pk_sub(b0, b1), sum); sum = pk_abs2_biased(pk_add(b2, b3), sum); sum = pk_abs2_biased(pk_sub(b2, b3), sum);
       }
       sum += (u32)__builtin_amdgcn_update_dpp(0, (int)sum, 0xB1, 0xF, 0xF, true);
+      return sum;
 #endif
     } else {
       for (int j = 0; j < 4; j++) {  // down the columns, two columns per register
@@ -1367,9 +1388,17 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
         const Pk16 a4 = pk_sub(d[0][j], d[4 % NR][j]), a5 = pk_sub(d[1][j], d[5 % NR][j]), a6 = pk_sub(d[2][j], d[6 % NR][j]), a7 = pk_sub(d[3][j], d[7 % NR][j]);
         const Pk16 b0 = pk_add(a0, a2), b1 = pk_add(a1, a3), b2 = pk_sub(a0, a2), b3 = pk_sub(a1, a3);
         const Pk16 b4 = pk_add(a4, a6), b5 = pk_add(a5, a7), b6 = pk_sub(a4, a6), b7 = pk_sub(a5, a7);
+#ifdef KVZ_HOSTSIM
         sum += pk_absmax(pk_add(b0, b1)) + pk_absmax(pk_sub(b0, b1)) + pk_absmax(pk_add(b2, b3)) + pk_absmax(pk_sub(b2, b3));
         sum += pk_absmax(pk_add(b4, b5)) + pk_absmax(pk_sub(b4, b5)) + pk_absmax(pk_add(b6, b7)) + pk_absmax(pk_sub(b6, b7));
+#else
+        sum = pk_abs2_biased(pk_add(b0, b1), sum); sum = pk_abs2_biased(pk_sub(b0, b1), sum); sum = pk_abs2_biased(pk_add(b2, b3), sum); sum = pk_abs2_biased(pk_sub(b2, b3), sum);
+        sum = pk_abs2_biased(pk_add(b4, b5), sum); sum = pk_abs2_biased(pk_sub(b4, b5), sum); sum = pk_abs2_biased(pk_add(b6, b7), sum); sum = pk_abs2_biased(pk_sub(b6, b7), sum);
+#endif
       }
+#ifndef KVZ_HOSTSIM
+      return sum;
+#endif
     }
     return 2 * sum;
   }
@@ -1411,6 +1440,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     Pk16 d[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) d[j] = as_pk16(v[j] - o[j]);
+    if (r == 0) d[0] = pk_add(d[0], KVZ_PK_BIAS);  // see pk_abs2_biased
     {
       const Pk16 a0 = pk_add(d[0], d[2]), a1 = pk_add(d[1], d[3]), a2 = pk_sub(d[0], d[2]), a3 = pk_sub(d[1], d[3]);
       d[0] = pk_add(a0, a1); d[1] = pk_sub(a0, a1); d[2] = pk_add(a2, a3); d[3] = pk_sub(a2, a3);
@@ -1431,11 +1461,11 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     KVZ_FLAT8_STAGE(0x4E /* quad_perm [2,3,0,1] */, 2)
     KVZ_FLAT8_STAGE(0xB1 /* quad_perm [1,0,3,2] */, 1)
 #undef KVZ_FLAT8_STAGE
-    u32 sum = pk_absmax(d[0]) + pk_absmax(d[1]) + pk_absmax(d[2]) + pk_absmax(d[3]);
+    u32 sum = pk_abs2_biased(d[3], pk_abs2_biased(d[2], pk_abs2_biased(d[1], pk_abs2_biased(d[0], 0))));
     sum += (u32)__builtin_amdgcn_update_dpp(0, (int)sum, 0xB1, 0xF, 0xF, true);
     sum += (u32)__builtin_amdgcn_update_dpp(0, (int)sum, 0x4E, 0xF, 0xF, true);
     sum += (u32)__builtin_amdgcn_update_dpp(0, (int)sum, 0x141, 0xF, 0xF, true);
-    return 2 * sum;
+    return sum;
   }
 #endif
 
