@@ -466,6 +466,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the auxiliary legs (chain, chain_d2h, configs_extra); they only run at --gpus 1")
     ap.add_argument("--only", default="", choices=["", "inter", "medium", "intra4k", "entropy"], help="developer / profiling: run ONE auxiliary leg at a reduced size and print its "
                     "entry (tools/pmc_leg.sh collects the leg's counters this way); the headline is not measured")
+    ap.add_argument("--entropy-pictures", type=int, default=384, help="developer: pictures of `--only entropy`")
     ap.add_argument("--inter-sequences", type=int, default=0, help="developer: sequences per launch of the inter leg (default 384; 96 with --only inter)")
     ap.add_argument("--wpp", action="store_true", help="with --tiles: keep WPP on (kvazaar --tiles CxR --wpp); by default tiles imply --no-wpp as in kvazaar (cfg.c:925-978): "
                                                        "one coder per tile in raster order, i.e. one serial CTU chain per tile")
@@ -749,7 +750,7 @@ def only_leg(args, lib, model_for, HipBatch):
     elif args.only == "intra4k":
         out = leg_intra4k(args, lib, model_for, HipBatch, n4k=192, steps=1)
     else:
-        n = 384
+        n = args.entropy_pictures
         frames = synth_frames(args.width, args.height, args.distinct, clip_seed(args.width, args.height))
         b0 = HipBatch(lib, args.width, args.height, n)
         for i in range(n):

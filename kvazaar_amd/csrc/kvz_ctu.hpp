@@ -1295,6 +1295,8 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
           }
         }
       } else {
+        unsigned rnd_bits = 0x00100010u;
+        asm("" : "+v"(rnd_bits));  // opaque, or the compiler pulls the constant out of the multiply-add chain: mul + mad + add where two mads do
 #pragma unroll
         for (int i = 0; i < NR; i++) {
           const int qa = q0 + r0 + i + 1, delta = qa * disp, di = delta >> 5, df = delta & 31;
@@ -1302,7 +1304,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
           unsigned mw[2];
           __builtin_memcpy(mw, m, 8);
           const unsigned m8 = m[8];
-          const U16x2 c1 = splat16(df), c0 = splat16(32 - df), rnd = splat16(16);
+          const U16x2 c1 = splat16(df), c0 = splat16(32 - df), rnd = u16x2_of(rnd_bits);
           U16x2 pa[4], pb[4], o[4];
           pa[0] = widen(0, mw[0], 0x0c010c00u); pa[1] = widen(0, mw[0], 0x0c030c02u); pa[2] = widen(0, mw[1], 0x0c010c00u); pa[3] = widen(0, mw[1], 0x0c030c02u);
           pb[0] = widen(0, mw[0], 0x0c020c01u); pb[1] = widen(mw[1], mw[0], 0x0c040c03u); pb[2] = widen(0, mw[1], 0x0c020c01u); pb[3] = widen(m8, mw[1], 0x0c040c03u);

@@ -1523,7 +1523,7 @@ inline void entropy_b_slice_contexts(int qp, uint8_t out[KVZ_ENTROPY_CTXS])
 struct EntropyScratch {
   std::mutex lock;
   struct Buf { void *p = nullptr; size_t bytes = 0; };
-  Buf bins, nbins, nbits, sizes, offsets, bound_offsets, rowctx, scratch, out, not_last;
+  Buf bins, nbins, nbits, sizes, ins, offsets, bound_offsets, rowctx, scratch, out, not_last;
   hipStream_t side = nullptr;          // stage 2 beside stage 1's second part
   hipEvent_t ev_first = nullptr, ev_rows = nullptr;
   static void *need(Buf &b, size_t bytes)
@@ -1612,14 +1612,16 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
       d_scratch = (uint8_t *)S.need(S.scratch, scratch_bytes ? scratch_bytes : 16);
       mark("host: bounds");
       KVZ_HIP_CHECK(hipMemcpyAsync(d_bound_offsets, bound_offsets.data(), (size_t)streams * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
-      static const int lanes = [] { const char *e = getenv("KVZ_HIP_ENTROPY_LANES"); const int v = e ? atoi(e) : 16; return v == 64 || v == 32 || v == 8 ? v : 16; }();
+      static const int lanes = [] { const char *e = getenv("KVZ_HIP_ENTROPY_LANES"); const int v = e ? atoi(e) : 64; return v == 32 || v == 16 || v == 8 ? v : 64; }();
+      uint32_t *d_ins = (uint32_t *)S.need(S.ins, (size_t)streams * sizeof(uint32_t));
       if (!early_rows && !no_wpp) hipLaunchKernelGGL(dev_entropy_row_ctx_kernel<8>, dim3((unsigned)((nf + 7) / 8)), dim3(8), 0, stream, J, device_tables());
       {
         const dim3 grid((unsigned)((streams + lanes - 1) / lanes)), block((unsigned)lanes);
-        if (lanes == 64) hipLaunchKernelGGL(dev_entropy_code_kernel<64>, grid, block, 0, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
-        else if (lanes == 32) hipLaunchKernelGGL(dev_entropy_code_kernel<32>, grid, block, 0, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
-        else if (lanes == 8) hipLaunchKernelGGL(dev_entropy_code_kernel<8>, grid, block, 0, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
-        else hipLaunchKernelGGL(dev_entropy_code_kernel<16>, grid, block, 0, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
+        if (lanes == 64) hipLaunchKernelGGL(dev_entropy_code_wide_kernel<64>, grid, block, 0, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
+        else if (lanes == 32) hipLaunchKernelGGL(dev_entropy_code_wide_kernel<32>, grid, block, 0, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
+        else if (lanes == 8) hipLaunchKernelGGL(dev_entropy_code_wide_kernel<8>, grid, block, 0, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
+        else hipLaunchKernelGGL(dev_entropy_code_wide_kernel<16>, grid, block, 0, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
+        hipLaunchKernelGGL(dev_entropy_escape_count_kernel, dim3((unsigned)streams), dim3(256), 0, stream, d_scratch, d_bound_offsets, d_sizes, d_ins);
       }
       sizes.resize((size_t)streams);
       KVZ_HIP_CHECK(hipMemcpyAsync(sizes.data(), d_sizes, (size_t)streams * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -1634,7 +1636,7 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
       } else {
         d_out = (uint8_t *)S.need(S.out, chunk_bytes ? chunk_bytes : 1);
         KVZ_HIP_CHECK(hipMemcpyAsync(d_offsets, offsets.data(), (size_t)streams * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(dev_entropy_compact_kernel, dim3((unsigned)streams), dim3(256), 0, stream, d_scratch, d_bound_offsets, d_sizes, d_offsets, d_out);
+        hipLaunchKernelGGL(dev_entropy_compact_kernel, dim3((unsigned)streams), dim3(256), 0, stream, d_scratch, d_bound_offsets, d_sizes, d_ins, d_offsets, d_out);
         KVZ_HIP_CHECK(hipGetLastError());
         KVZ_HIP_CHECK(hipMemcpyAsync(out + total, d_out, chunk_bytes, hipMemcpyDeviceToHost, stream));
         KVZ_HIP_CHECK(hipStreamSynchronize(stream));

@@ -13,9 +13,11 @@
 //                            capacity (6-9 k records at QP 22, 24 k for noise at QP 12); a list that outgrows it is reported and the host runs the chunk again.
 //   2. entropy_row_contexts  one lane per picture: the context states each CTU row starts from -- the state machine run over the first two CTUs' context-coded bins
 //                            of every row, row after row (with --no-wpp there is nothing to do).
-//   3. entropy_code_row      one lane per substream (picture x CTU row; one per picture without WPP): the arithmetic coder proper over the row's records -- range
-//                            subdivision, renormalisation, carry propagation, emulation prevention -- into scratch sized by an upper bound stage 1 keeps
-//                            (6 bits per context-coded bin, 7 per terminating bin, the bypass bins); a copy kernel then packs the substreams back to back.
+//   3. entropy_code_row_wide one lane per substream (picture x CTU row; one per picture without WPP): the arithmetic coder proper over the row's records -- range
+//                            subdivision, renormalisation, the code value leaving 32 bits at a time with its carries -- into scratch sized by an upper bound
+//                            stage 1 keeps (6 bits per context-coded bin, 7 per terminating bin, the bypass bins);
+//   4. emulation prevention  one workgroup per substream counts the 0x03 bytes it needs (a property of the finished bytes, decided by position); a copy kernel then
+//                            packs the substreams back to back, with them.
 // The same functions compile for the host (tests/hostsim) where every lane is a loop iteration.
 #pragma once
 #include "kvz_ops.hpp"
@@ -648,9 +650,8 @@ KVZ_DEV Rec16 entropy_load16(const Rec4 *b, u32 block)
   for (int k = 0; k < 4; k++) { const Rec4 q = b[4 * block + k]; r.w[4 * k] = q.v[0]; r.w[4 * k + 1] = q.v[1]; r.w[4 * k + 2] = q.v[2]; r.w[4 * k + 3] = q.v[3]; }
   return r;
 }
-struct EntropyTabs {       // where the coder's two tables live: LDS copies on the device, the originals on the host
+struct EntropyTabs {       // where the state machine's table lives: an LDS copy on the device, the original on the host
   const u8 *next;          // Tables::ctx_next as [2][128]
-  const u32 *lps;          // kLpsPacked
 };
 
 // stage 2: the contexts every row of picture f starts from (WPP)
@@ -686,58 +687,6 @@ KVZ_DEV void entropy_row_contexts(const EntropyJob &J, const EntropyTabs T, int 
   }
 }
 
-// the arithmetic coder (cabac.c:85-270)
-struct ArithCoder {
-  u32 low, range, buffered_byte;
-  int bits_left, num_buffered_bytes;
-  u8 *out;   // null: count only
-  u32 n;
-  int zerocount;
-  KVZ_DEV void start() { low = 0; range = 510; bits_left = 23; num_buffered_bytes = 0; buffered_byte = 0xff; zerocount = 0; }
-  KVZ_DEV void raw_byte(u32 b) { if (out) out[n] = (u8)b; n++; }
-  KVZ_DEV void put_byte(u32 b)  // kvz_bitstream_put_byte (bitstream.c:212-223): emulation prevention as the substream is written
-  {
-    b &= 0xff;
-    if (zerocount == 2 && b < 4) { raw_byte(3); zerocount = 0; }
-    zerocount = b == 0 ? zerocount + 1 : 0;
-    raw_byte(b);
-  }
-  KVZ_DEV void write()  // kvz_cabac_write
-  {
-    const u32 lead_byte = low >> (24 - bits_left);
-    bits_left += 8;
-    low &= 0xffffffffu >> bits_left;
-    if (lead_byte == 0xff) { num_buffered_bytes++; return; }
-    if (num_buffered_bytes > 0) {
-      const u32 carry = lead_byte >> 8;
-      put_byte(buffered_byte + carry);
-      buffered_byte = lead_byte & 0xff;
-      const u32 fill = (0xff + carry) & 0xff;
-      while (num_buffered_bytes > 1) { put_byte(fill); num_buffered_bytes--; }
-    } else {
-      num_buffered_bytes = 1;
-      buffered_byte = lead_byte;
-    }
-  }
-  KVZ_DEV void finish_and_align()  // kvz_cabac_finish, then the stop bit and the zero bits up to the byte boundary (encoderstate.c:726-732)
-  {
-    if (low >> (32 - bits_left)) {
-      put_byte(buffered_byte + 1);
-      while (num_buffered_bytes > 1) { put_byte(0); num_buffered_bytes--; }
-      low -= 1u << (32 - bits_left);
-    } else {
-      if (num_buffered_bytes > 0) put_byte(buffered_byte);
-      while (num_buffered_bytes > 1) { put_byte(0xff); num_buffered_bytes--; }
-    }
-    const int nb = 24 - bits_left;  // kvz_bitstream_put(stream, low >> 8, nb), then "1" and the alignment
-    unsigned long long w = (((unsigned long long)(low >> 8) & ((1ull << nb) - 1)) << 1) | 1ull;
-    int bits = nb + 1;
-    const int pad = (8 - (bits & 7)) & 7;
-    w <<= pad; bits += pad;
-    for (int sh = bits - 8; sh >= 0; sh -= 8) put_byte((u32)(w >> sh) & 0xff);
-  }
-};
-
 // Range of the less probable symbol, H.265 table 9-46 (cabac.c:66-82 kvz_g_auc_lpst_table), four bytes per state
 #ifdef KVZ_HOSTSIM
 static const u32 kLpsPacked[64] = {
@@ -752,88 +701,205 @@ __device__ const u32 kLpsPacked[64] = {
   0x1E1A1612u, 0x1C191511u, 0x1B171410u, 0x1916130Fu, 0x1815120Eu, 0x1714110Eu, 0x1613100Du, 0x15120F0Cu,
   0x14110E0Cu, 0x13100E0Bu, 0x120F0D0Bu, 0x110F0C0Au, 0x100E0C0Au, 0x0F0D0B09u, 0x0E0C0B09u, 0x0E0C0A08u,
   0x0D0B0908u, 0x0C0B0907u, 0x0C0A0907u, 0x0B0A0807u, 0x0B090806u, 0x0A090706u, 0x09080706u, 0x02020202u };
-KVZ_DEV u32 entropy_lps_row(int state) { return kLpsPacked[state]; }
 
-// When the coder moves a byte out (kvz_cabac_write, cabac.c:138-177, called at bits_left < 12).  The bytes are the digits of the code value: moving one out is exact
-// whenever eight bits have gathered (bits_left <= 15: nine bits stay in `low`, the width of `range`, and a carry still reaches the moved byte through buffered_byte).
-// The byte path is ~45 instructions that a wavefront runs whenever ANY of its lanes is in it -- with sixteen substreams per wavefront that was nearly every step.  So the
-// lanes move their bytes together: when one of them must, every lane that can does, and the next time is several records away.
-#ifdef KVZ_HOSTSIM
-static int entropy_write_threshold() { static const int t = getenv("KVZ_HOSTSIM_EARLY_WRITE") ? 16 : 12; return t; }  // test hook: every lane always as early as it may
-KVZ_DEV void entropy_move_bytes(ArithCoder &a) { if (a.bits_left < entropy_write_threshold()) a.write(); }
-#else
-__device__ __forceinline__ void entropy_move_bytes(ArithCoder &a) { if (__builtin_amdgcn_ballot_w64(a.bits_left < 12) != 0 && a.bits_left < 16) a.write(); }
-#endif
-// one record through the coder (cabac.c:104-133 kvz_cabac_encode_bin, :231-254 kvz_cabac_encode_bins_ep, :193-210 kvz_cabac_encode_bin_trm)
-KVZ_DEV void entropy_code_record(ArithCoder &a, u8 *ctx, const EntropyTabs T, u32 rec)
+// ---- stage 3, the wide form: the same code value, moved out 32 bits at a time, every record through ONE branch-free step ----
+// What a wavefront of substreams costs per record is the instructions of the step times the paths its lanes take; the byte-wise coder above has three record kinds, two
+// renormalisation paths and a byte path with emulation prevention in it, and sixteen lanes are enough to visit all of them at nearly every step.  Here:
+//  * a terminating bin is a context-coded bin on a context that never moves: state 63 | MPS 0, whose LPS range is 2 in every range class (cabac.c:193-210 against :104-133:
+//    range -= 2, "LPS" = low += range, seven bits of renormalisation = clz(2) - 23); bypass records use the same pseudo-context and ignore what it says.  So every record
+//    reads a context, and what differs between the kinds is three selects;
+//  * the code value is a number whose digits leave at the top (cabac.c:138-177 moves a byte when 13 bits have gathered and keeps 0xff bytes back for a carry).  WHEN digits
+//    leave does not change them: `low` is 64 bits wide here, 32 bits go at a time (a lane may from 32 pending bits on and must at 38; when one lane must, every lane that may
+//    does), the carry is the bit above the pending ones, looked at when digits leave, and goes into the unit kept back from the last time -- and on through memory in the one
+//    case in 2^32 where that unit is all ones;
+//  * emulation prevention (bitstream.c:212-223) is a property of the finished bytes: a pass of its own over the substream (entropy_escape_chunk below);
+//  * the context's state for the NEXT record is fetched while this one is coded: per state one 64-bit table entry (the four LPS ranges, both successors, the state itself),
+//    read as soon as the successor of the current context is known, and the state byte of the record after that one step earlier.
+#define KVZ_ENTROPY_CTX_NEUTRAL KVZ_ENTROPY_CTXS
+#define KVZ_ENTROPY_CTX_STRIDE 172  // bytes of context states per lane: 43 dwords, odd, so lanes reading the same context hit different LDS banks
+#define KVZ_EB_NOP KVZ_EB_EP(0, 0)   // a run of no bypass bins: low << 0 + range * 0
+// entry of state s = sigma << 1 | mps
+KVZ_DEV unsigned long long entropy_state_entry(const u8 *next /* [2][128] */, int s)
 {
-  const u32 kind = rec >> 30;
-  if (kind == 0) {
-    const int c = (int)(rec & 0xff), bin = (int)((rec >> 8) & 1), st = ctx[c];
-    const u32 lps = (T.lps[st >> 1] >> (8 * ((a.range >> 6) & 3))) & 0xff;
-    a.range -= lps;
-    if (bin != (st & 1)) {
-      const int num_bits = lps < 8 ? 6 : (int)__builtin_clz(lps) - 23;  // kvz_g_auc_renorm_table[lps >> 3] (cabac.c:84-88): the shift that brings lps back to >= 256
-      a.low = (a.low + a.range) << num_bits;
-      a.range = lps << num_bits;
-      a.bits_left -= num_bits;
-      ctx[c] = T.next[128 + st];
-    } else {
-      ctx[c] = T.next[st];
-      if (a.range >= 256) return;
-      a.low <<= 1; a.range <<= 1; a.bits_left--;
-    }
-  } else if (kind == 1) {
-    int nb = (int)((rec >> 16) & 0x3f);
-    u32 v = rec & 0xffff;
-    if (nb > 8) {
-      nb -= 8;
-      const u32 pattern = v >> nb;
-      a.low = (a.low << 8) + a.range * pattern;
-      v -= pattern << nb;
-      a.bits_left -= 8;
-      if (a.bits_left < 12) a.write();
-    }
-    a.low = (a.low << nb) + a.range * v;
-    a.bits_left -= nb;
-  } else {
-    a.range -= 2;
-    if (rec & 1) { a.low += a.range; a.low <<= 7; a.range = 2 << 7; a.bits_left -= 7; }
-    else if (a.range >= 256) return;
-    else { a.low <<= 1; a.range <<= 1; a.bits_left--; }
-  }
-  entropy_move_bytes(a);
+  const int nm = s >= 126 ? s : next[s], nl = s >= 126 ? s : next[128 + s];
+  return (unsigned long long)kLpsPacked[s >> 1] | (unsigned long long)nm << 32 | (unsigned long long)nl << 40 | (unsigned long long)s << 48;
 }
-
-// stage 3: the substream `item` -- (picture, CTU row) with WPP, the picture without; returns its size in bytes.  ctx: KVZ_ENTROPY_CTXS bytes of work memory
-KVZ_DEV u32 entropy_code_row(const EntropyJob &J, const EntropyTabs T, long item, u8 *ctx, u8 *out)
+struct WideLine { u32 w[16]; };
+// a lane's cursor over the records of its substream, a 64-byte line at a time; slots past a CTU's last record read as KVZ_EB_NOP
+struct WideCursor {
+  const u32 *bins, *nbins; u32 cap;
+  long ctu, end;   // CTU index (into bins / nbins), one past the last
+  u32 n, i0;
+  KVZ_DEV void enter() { if (ctu < end) { n = nbins[ctu] < cap ? nbins[ctu] : cap; i0 = 0; } }
+  KVZ_DEV void open(const EntropyJob &J, long first, long count) { bins = J.bins; nbins = J.nbins; cap = J.cap; ctu = first; end = first + count; n = 0; i0 = 0; enter(); }
+  KVZ_DEV bool fetch(WideLine &l)  // false: past the end (the line is all KVZ_EB_NOP)
+  {
+    const bool real = ctu < end;
+    u32 valid = 0;
+    if (real) {
+      const Rec4 *b = (const Rec4 *)(bins + ctu * cap) + (i0 >> 2);
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const Rec4 q = b[k]; l.w[4 * k] = q.v[0]; l.w[4 * k + 1] = q.v[1]; l.w[4 * k + 2] = q.v[2]; l.w[4 * k + 3] = q.v[3]; }
+      valid = n > i0 ? n - i0 : 0;
+      i0 += 16;
+      if (i0 >= n) { ctu++; enter(); }
+    }
+#pragma unroll
+    for (u32 q = 0; q < 16; q++) l.w[q] = q < valid ? l.w[q] : KVZ_EB_NOP;
+    return real;
+  }
+};
+#ifdef KVZ_HOSTSIM
+#define KVZ_WAVE_ANY(c) (c)
+static int entropy_wide_must() { static const int t = getenv("KVZ_HOSTSIM_WIDE_EARLY") ? 32 : 38; return t; }  // test hook: every lane as early as it may / as late as it must
+#else
+#define KVZ_WAVE_ANY(c) (__builtin_amdgcn_ballot_w64(c) != 0)
+__device__ __forceinline__ constexpr int entropy_wide_must() { return 38; }
+#endif
+template <int W> struct WideCoder {  // W: bits per unit moved out (32; 8 in tests, where a carry into an all-ones unit happens all the time)
+  static_assert(W == 32 || W == 8, "");
+  unsigned long long low;   // bits [0, 8 + pend), and above them what has been carried out of them since the last unit left (0 or 1; with byte units up to 2)
+  u32 range, cache, n;      // cache: the unit moved out last, kept back for a carry; n: units in memory
+  int pend, have;           // pend = 24 - bits_left of cabac.c: bits above bit 8 that have not left yet
+  u8 *out;                  // 4-byte aligned; null: count only
+  KVZ_DEV void start(u8 *o) { low = 0; range = 510; pend = 1; have = 0; cache = 0; n = 0; out = o; }
+  KVZ_DEV u32 load_unit(long j) const
+  {
+    if (W == 8) return out[j];
+    const u8 *p = out + 4 * j;
+    return (u32)p[0] << 24 | (u32)p[1] << 16 | (u32)p[2] << 8 | (u32)p[3];
+  }
+  KVZ_DEV void store_unit(long j, u32 v)
+  {
+    if (!out) return;
+    if (W == 8) { out[j] = (u8)v; return; }
+#ifdef KVZ_HOSTSIM
+    u8 *p = out + 4 * j;
+    p[0] = (u8)(v >> 24); p[1] = (u8)(v >> 16); p[2] = (u8)(v >> 8); p[3] = (u8)v;
+#else
+    reinterpret_cast<u32 *>(out)[j] = __builtin_bswap32(v);
+#endif
+  }
+  KVZ_DEV void push(u32 carry)  // the kept unit, with what was carried into it since it left `low`, goes to memory
+  {
+    const u32 mask = W == 32 ? 0xffffffffu : 0xffu;
+    const unsigned long long sum = (unsigned long long)cache + carry;
+    if ((sum >> W) != 0 && out) {  // it overflowed: the carry goes on through the units in memory (it always stops: the code value's top bit never carries out)
+      for (long j = (long)n - 1; j >= 0; j--) { const u32 u = (load_unit(j) + 1) & mask; store_unit(j, u); if (u) break; }
+    }
+    store_unit(n, (u32)sum & mask);
+    n++;
+  }
+  KVZ_DEV void move_unit()
+  {
+    const int top = 8 + pend;
+    const u32 carry = (u32)(low >> top);
+    const u32 unit = (u32)(low >> (top - W)) & (W == 32 ? 0xffffffffu : 0xffu);
+    low &= (1ull << (top - W)) - 1;
+    pend -= W;
+    if (have) push(carry);
+    cache = unit; have = 1;
+  }
+  KVZ_DEV void move_units()
+  {
+    if (W == 32) { if (KVZ_WAVE_ANY(pend >= entropy_wide_must()) && pend >= 32) move_unit(); }
+    else while (pend >= W) move_unit();
+  }
+  // kvz_cabac_finish, the stop bit and the zero bits up to the byte boundary (encoderstate.c:726-732); returns the bytes of the substream before emulation prevention
+  KVZ_DEV u32 finish()
+  {
+    const int top = 8 + pend;
+    const u32 carry = (u32)(low >> top);
+    low &= (1ull << top) - 1;
+    if (have) push(carry);
+    unsigned long long w = ((low >> 8) << 1) | 1ull;
+    int bits = pend + 1;
+    const int pad = (8 - (bits & 7)) & 7;
+    w <<= pad; bits += pad;
+    u32 bytes = (W / 8) * n;
+    for (int sh = bits - 8; sh >= 0; sh -= 8) { if (out) out[bytes] = (u8)(w >> sh); bytes++; }
+    return bytes;
+  }
+};
+KVZ_DEV int entropy_rec_ctx(u32 rec) { return (rec >> 30) ? KVZ_ENTROPY_CTX_NEUTRAL : (int)(rec & 0xff); }
+// the substream `item` without emulation prevention, at `out` (room for its upper bound, 4-byte aligned); ctx: KVZ_ENTROPY_CTX_STRIDE bytes of work memory;
+// tab: entropy_state_entry of the 128 states.  Returns the bytes written.
+template <int W> KVZ_DEV u32 entropy_code_row_wide(const EntropyJob &J, const unsigned long long *tab, long item, u8 *ctx, u8 *out)
 {
   const int ctus = J.wc * J.hc;
   const int f = J.no_wpp ? (int)item : (int)(item / J.hc), row = J.no_wpp ? 0 : (int)(item - (long)f * J.hc);
   const long first = (long)f * ctus + (long)row * J.wc, count = J.no_wpp ? ctus : J.wc;
   const u8 *start = J.no_wpp ? J.ctx_init : J.row_ctx + ((long)f * J.hc + row) * KVZ_ENTROPY_CTXS;
   for (int i = 0; i < KVZ_ENTROPY_CTXS; i++) ctx[i] = start[i];
-  ArithCoder a;
-  a.out = out; a.n = 0;
-  a.start();
-  for (long k = 0; k < count; k++) {
-    const Rec4 *b = (const Rec4 *)(J.bins + (first + k) * J.cap);
-    const u32 n = J.nbins[first + k] < J.cap ? J.nbins[first + k] : J.cap;
-    Rec16 cur = entropy_load16(b, 0);
-    for (u32 i0 = 0; i0 < n; i0 += 16) {
-      const Rec16 nxt = i0 + 16 < n ? entropy_load16(b, (i0 >> 4) + 1) : cur;
-      const u32 m = n - i0 < 16 ? n - i0 : 16;
-#ifdef KVZ_HOSTSIM
-      for (u32 q = 0; q < m; q++) entropy_code_record(a, ctx, T, cur.next());
-#else
+  ctx[KVZ_ENTROPY_CTX_NEUTRAL] = 126;
+  WideCoder<W> a;
+  a.start(out);
+  WideCursor cu;
+  cu.open(J, first, count);
+  WideLine cur, nxt;
+  bool cur_real = cu.fetch(cur), nxt_real = cu.fetch(nxt);
+  unsigned long long E = tab[ctx[entropy_rec_ctx(cur.w[0])]];  // the entry of the record about to be coded
+  u32 P = ctx[entropy_rec_ctx(cur.w[1])];                       // the state of the next record's context as it was before this record
+  while (KVZ_WAVE_ANY(cur_real)) {
 #pragma unroll
-      for (u32 q = 0; q < 16; q++) { if (q >= m) break; entropy_code_record(a, ctx, T, cur.w[q]); }  // unrolled: the line under constant indices (shifting it down was 15 moves per record)
-#endif
-      cur = nxt;
+    for (int q = 0; q < 16; q++) {
+      const u32 rec = cur.w[q], rec1 = q < 15 ? cur.w[q + 1] : nxt.w[0], rec2 = q < 14 ? cur.w[q + 2] : nxt.w[q - 14];
+      const int c = entropy_rec_ctx(rec), c1 = entropy_rec_ctx(rec1), c2 = entropy_rec_ctx(rec2);
+      const u32 kind = rec >> 30;
+      const bool byp = kind == 1;
+      const u32 st = (u32)(E >> 48) & 0xff, bin = (kind ? rec : rec >> 8) & 1;
+      const u32 lps = ((u32)E >> ((a.range >> 3) & 24)) & 0xff;
+      const bool is_lps = ((bin ^ st) & 1) != 0;
+      // the context moves on, and the next record's entry is asked for before this record's arithmetic
+      const u32 s_new = (u32)(E >> (is_lps ? 40 : 32)) & 0xff;
+      ctx[c] = (u8)s_new;
+      const u32 s1 = c1 == c ? s_new : P;
+      const unsigned long long E1 = tab[s1];
+      P = ctx[c2];
+      // the interval (cabac.c:104-133, :231-254)
+      const u32 rm = a.range - lps;
+      const int nbits = (int)__builtin_clz(lps) - 23;
+      const int small = rm < 256 ? 1 : 0;
+      const int nb = (int)((rec >> 16) & 0x3f);
+      const int sh = byp ? nb : is_lps ? nbits : small;
+      const u32 add = byp ? a.range * (rec & 0xffffu) : is_lps ? rm << nbits : 0u;
+      a.range = byp ? a.range : is_lps ? lps << nbits : rm << small;
+      a.low = (a.low << sh) + add;
+      a.pend += sh;
+      a.move_units();
+      E = E1;
     }
+    cur = nxt; cur_real = nxt_real;
+    nxt_real = cu.fetch(nxt);
   }
-  a.finish_and_align();
-  return a.n;
+  return a.finish();
+}
+
+// Emulation prevention (bitstream.c:212-223: a byte below 4 that follows two zero bytes gets 0x03 in front, and the count of zeros starts again) over the finished bytes
+// b[0, n), by position: with z zero bytes directly in front of b[i], the serial rule puts an 0x03 in front of b[i] exactly when b[i] < 4, z >= 2 and z is even (inside a
+// run of zeros the count restarts after every insertion, so every second zero from the third on gets one; a byte 1..3 behind the run gets one when the run's length is
+// even).  A thread takes the bytes [lo, hi): counts its insertions (dst null) or writes its part at dst, which is where b[lo] lands.
+KVZ_DEV u32 entropy_escape_chunk(const u8 *b, u32 lo, u32 hi, u8 *dst)
+{
+  if (lo >= hi) return 0;
+  u32 z = 0;
+  for (u32 j = lo; j > 0 && b[j - 1] == 0; j--) z++;
+  u32 ins = 0;
+  for (u32 i = lo; i < hi; i++) {
+    const u32 v = b[i];
+    if (v < 4 && z >= 2 && (z & 1) == 0) { if (dst) dst[i - lo + ins] = 3; ins++; }
+    if (dst) dst[i - lo + ins] = (u8)v;
+    z = v == 0 ? z + 1 : 0;
+  }
+  return ins;
+}
+// does the serial rule put an 0x03 in front of b[i]?  (entropy_escape_chunk's rule, asked of one position)
+KVZ_DEV bool entropy_escape_at(const u8 *b, u32 i)
+{
+  if (i < 2 || b[i] >= 4 || b[i - 1] != 0 || b[i - 2] != 0) return false;
+  u32 z = 2;
+  for (u32 j = i - 2; j > 0 && b[j - 1] == 0; j--) z++;
+  return (z & 1) == 0;
 }
 
 #ifndef KVZ_HOSTSIM
@@ -859,43 +925,66 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(KVZ_ENT
   }
   entropy_ctu_bins_phased(J, tb, item, live, &L.q[0][threadIdx.x], &L.stack[0][threadIdx.x], 64);
 }
-// Lanes per workgroup of the two serial stages: every lane runs a long dependent chain of its own (its list's records, its coder's state), so what fills the chip is
-// the number of wavefronts, not their width -- 16 lanes per wavefront gives four times as many of them and a quarter of the divergence inside each
+// Stage 2 is one long dependent chain per picture (its rows' first two CTUs, row after row): few lanes per workgroup spread the pictures over the chip
 template <int LANES> struct EntropyLds {
   u8 ctx[LANES][KVZ_ENTROPY_CTXS];
   u8 next[256];
-  u32 lps[64];
 };
-template <int LANES> KVZ_DEV EntropyTabs entropy_stage_tables(EntropyLds<LANES> *L, const Tables *tb)
-{
-  for (int i = threadIdx.x; i < 256; i += LANES) L->next[i] = tb->ctx_next[i >> 7][i & 127];
-  for (int i = threadIdx.x; i < 64; i += LANES) L->lps[i] = kLpsPacked[i];
-  __syncthreads();
-  return EntropyTabs{ L->next, L->lps };
-}
 template <int LANES> __global__ void __launch_bounds__(LANES) dev_entropy_row_ctx_kernel(const EntropyJob J, const Tables *tb)
 {
   __shared__ EntropyLds<LANES> L;
-  const EntropyTabs T = entropy_stage_tables(&L, tb);
+  for (int i = threadIdx.x; i < 256; i += LANES) L.next[i] = tb->ctx_next[i >> 7][i & 127];
+  __syncthreads();
   const int f = blockIdx.x * LANES + threadIdx.x;
-  if (f < J.n_frames) entropy_row_contexts(J, T, f, L.ctx[threadIdx.x]);
+  if (f < J.n_frames) entropy_row_contexts(J, EntropyTabs{ L.next }, f, L.ctx[threadIdx.x]);
 }
-// every substream coded once, at out + offsets[item] (room for its upper bound); sizes: what it came to
-template <int LANES> __global__ void __launch_bounds__(LANES) dev_entropy_code_kernel(const EntropyJob J, const Tables *tb, long total, u32 *sizes, const unsigned long long *offsets, u8 *out)
+// Stage 3: every substream coded once, at out + offsets[item] (room for its upper bound, 4-byte aligned), without emulation prevention; sizes: the bytes it came to.
+// A step costs a wavefront the same whatever the number of its lanes: 64 substreams per wavefront (measured: 48 ms for the 26 112 substreams of 1 536 1080p pictures
+// at 64 lanes, 54 at 32, 66 at 16; the byte-at-a-time coder this replaces: 105 ms at its best width, 16)
+template <int LANES> struct EntropyWideLds {
+  u8 ctx[LANES][KVZ_ENTROPY_CTX_STRIDE];
+  unsigned long long tab[128];
+};
+template <int LANES> __global__ void __launch_bounds__(LANES) dev_entropy_code_wide_kernel(const EntropyJob J, const Tables *tb, long total, u32 *sizes, const unsigned long long *offsets, u8 *out)
 {
-  __shared__ EntropyLds<LANES> L;
-  const EntropyTabs T = entropy_stage_tables(&L, tb);
+  __shared__ EntropyWideLds<LANES> L;
+  for (int i = threadIdx.x; i < 128; i += LANES) L.tab[i] = entropy_state_entry(&tb->ctx_next[0][0], i);
+  __syncthreads();
   const long item = (long)blockIdx.x * LANES + threadIdx.x;
   if (item >= total) return;
-  sizes[item] = entropy_code_row(J, T, item, L.ctx[threadIdx.x], out + offsets[item]);
+  sizes[item] = entropy_code_row_wide<32>(J, L.tab, item, L.ctx[threadIdx.x], out + offsets[item]);
 }
-// ... and moved back to back: one workgroup per substream
-__global__ void __launch_bounds__(256) dev_entropy_compact_kernel(const u8 *src, const unsigned long long *src_off, const u32 *sizes, const unsigned long long *dst_off, u8 *dst)
+// one workgroup per substream: the emulation prevention bytes it needs; sizes: in the bytes the coder wrote, out the substream's final size
+__global__ void __launch_bounds__(256) dev_entropy_escape_count_kernel(const u8 *src, const unsigned long long *src_off, u32 *sizes, u32 *ins)
+{
+  __shared__ u32 total;
+  if (threadIdx.x == 0) total = 0;
+  __syncthreads();
+  const u8 *s = src + src_off[blockIdx.x];
+  const u32 n = sizes[blockIdx.x];
+  u32 mine = 0;
+  for (u32 i = threadIdx.x; i < n; i += 256) mine += entropy_escape_at(s, i) ? 1u : 0u;
+  if (mine) atomicAdd(&total, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) { ins[blockIdx.x] = total; sizes[blockIdx.x] = n + total; }
+}
+// ... and moved back to back, with them: one workgroup per substream (sizes: final; ins: the emulation prevention bytes among them)
+__global__ void __launch_bounds__(256) dev_entropy_compact_kernel(const u8 *src, const unsigned long long *src_off, const u32 *sizes, const u32 *ins, const unsigned long long *dst_off, u8 *dst)
 {
   const u8 *s = src + src_off[blockIdx.x];
   u8 *d = dst + dst_off[blockIdx.x];
-  const u32 n = sizes[blockIdx.x];
-  for (u32 i = threadIdx.x; i < n; i += 256) d[i] = s[i];
+  const u32 n = sizes[blockIdx.x] - ins[blockIdx.x];
+  if (ins[blockIdx.x] == 0) {  // (nearly every substream)
+    for (u32 i = threadIdx.x; i < n; i += 256) d[i] = s[i];
+    return;
+  }
+  __shared__ u32 before[256];
+  const u32 chunk = (n + 255) / 256, lo = threadIdx.x * chunk < n ? threadIdx.x * chunk : n, hi = lo + chunk < n ? lo + chunk : n;
+  before[threadIdx.x] = entropy_escape_chunk(s, lo, hi, nullptr);
+  __syncthreads();
+  if (threadIdx.x == 0) { u32 acc = 0; for (int t = 0; t < 256; t++) { const u32 v = before[t]; before[t] = acc; acc += v; } }
+  __syncthreads();
+  entropy_escape_chunk(s, lo, hi, d + lo + before[threadIdx.x]);
 }
 #endif
 

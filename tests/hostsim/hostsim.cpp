@@ -201,6 +201,44 @@ static void hostsim_ctu_bins(const kvz::EntropyJob &J, const kvz::Tables *tb, lo
   kvz::entropy_ctu_bins_phased(J, tb, item, true, queue, stack, 1);
 }
 
+// stage 3 as the device runs it: the wide coder (32-bit units; KVZ_HOSTSIM_WIDE_UNIT=8: byte units, where carries into all-ones units are common;
+// KVZ_HOSTSIM_WIDE_EARLY: units leave as early as they may instead of as late as they must), then emulation prevention by the serial rule of bitstream.c:212-223.
+// out null: count only.
+static uint32_t hostsim_code_row(const kvz::EntropyJob &J, const kvz::Tables &tb, long item, uint8_t *out, size_t room)
+{
+  static const bool unit8 = [] { const char *e = getenv("KVZ_HOSTSIM_WIDE_UNIT"); return e && atoi(e) == 8; }();
+  static unsigned long long tab[128];
+  for (int i = 0; i < 128; i++) tab[i] = kvz::entropy_state_entry(&tb.ctx_next[0][0], i);
+  uint8_t ctx[KVZ_ENTROPY_CTX_STRIDE];
+  std::vector<uint8_t> raw(room + 64);
+  const uint32_t n = unit8 ? kvz::entropy_code_row_wide<8>(J, tab, item, ctx, raw.data()) : kvz::entropy_code_row_wide<32>(J, tab, item, ctx, raw.data());
+  uint32_t o = 0;
+  int zerocount = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    const uint8_t b = raw[i];
+    if (zerocount == 2 && b < 4) { if (out) out[o] = 3; o++; zerocount = 0; }
+    zerocount = b == 0 ? zerocount + 1 : 0;
+    if (out) out[o] = b;
+    o++;
+  }
+  return o;
+}
+// the device's emulation prevention pass (escape count by position, then 256 chunks written at their offsets) on n bytes; returns the size, or -1 if the two rules disagree
+extern "C" long kvz_hostsim_escape(const uint8_t *raw, uint32_t n, uint8_t *out)
+{
+  uint32_t by_position = 0;
+  for (uint32_t i = 0; i < n; i++) by_position += kvz::entropy_escape_at(raw, i) ? 1u : 0u;
+  const uint32_t chunk = (n + 255) / 256;
+  uint32_t before = 0;
+  for (uint32_t t = 0; t < 256; t++) {
+    const uint32_t lo = t * chunk < n ? t * chunk : n, hi = lo + chunk < n ? lo + chunk : n;
+    const uint32_t counted = kvz::entropy_escape_chunk(raw, lo, hi, nullptr);
+    if (kvz::entropy_escape_chunk(raw, lo, hi, out + lo + before) != counted) return -1;
+    before += counted;
+  }
+  return before == by_position ? (long)n + before : -1;
+}
+
 extern "C" long kvz_hostsim_entropy_code(const kvz_hip_intra_cost_model *m, int width, int height, int n_frames, const uint8_t *cu_depth, const uint8_t *cu_mode, const uint8_t *part,
                                          const uint8_t *mode4, const int16_t *coeff, const unsigned long long *sao_recs, const uint8_t *sao_merge, uint32_t cap, uint8_t *out,
                                          uint32_t *substream_bytes, uint32_t *most_records)
@@ -216,7 +254,7 @@ extern "C" long kvz_hostsim_entropy_code(const kvz_hip_intra_cost_model *m, int 
   J.bins = (uint32_t *)aligned_alloc(64, (size_t)items * cap * sizeof(uint32_t)); J.nbins = (uint32_t *)malloc((size_t)items * sizeof(uint32_t)); J.nbits = (uint32_t *)malloc((size_t)items * sizeof(uint32_t)); J.cap = cap;
   J.row_ctx = (uint8_t *)malloc((size_t)n_frames * J.hc * KVZ_ENTROPY_CTXS);
   memcpy(J.ctx_init, m->ctx_init, sizeof m->ctx_init < sizeof J.ctx_init ? sizeof m->ctx_init : sizeof J.ctx_init);
-  const kvz::EntropyTabs T{ &tb.ctx_next[0][0], kvz::kLpsPacked };
+  const kvz::EntropyTabs T{ &tb.ctx_next[0][0] };
   uint8_t ctx[KVZ_ENTROPY_CTXS];
   *most_records = 0;
   for (long i = 0; i < items; i++) { hostsim_ctu_bins(J, &tb, i); if (J.nbins[i] > *most_records) *most_records = J.nbins[i]; }
@@ -225,12 +263,13 @@ extern "C" long kvz_hostsim_entropy_code(const kvz_hip_intra_cost_model *m, int 
     if (!m->no_wpp) for (int f = 0; f < n_frames; f++) kvz::entropy_row_contexts(J, T, f, ctx);
     total = 0;
     for (long i = 0; i < streams; i++) {
-      const uint32_t counted = kvz::entropy_code_row(J, T, i, ctx, nullptr);
-      substream_bytes[i] = kvz::entropy_code_row(J, T, i, ctx, out + total);
       // the bound the device sizes its scratch with (kvz_hip_batch_entropy_code) must hold
       unsigned long long bits = 0;
       const long per_stream = m->no_wpp ? (long)J.wc * J.hc : J.wc;
       for (long k = 0; k < per_stream; k++) bits += J.nbits[i * per_stream + k];
+      const size_t room = (size_t)(((bits + 7) / 8 + 16) * 3 / 2);
+      const uint32_t counted = hostsim_code_row(J, tb, i, nullptr, room);
+      substream_bytes[i] = hostsim_code_row(J, tb, i, out + total, room);
       if (counted != substream_bytes[i]) { total = -2; break; }
       if (substream_bytes[i] > ((bits + 7) / 8 + 16) * 3 / 2) { total = -3; break; }
       total += substream_bytes[i];
@@ -257,13 +296,19 @@ extern "C" long kvz_hostsim_entropy_code_inter(const uint8_t *ctx_init /* KVZ_EN
   J.nbits = (uint32_t *)malloc((size_t)items * sizeof(uint32_t)); J.cap = cap;
   J.row_ctx = (uint8_t *)malloc((size_t)J.hc * KVZ_ENTROPY_CTXS);
   memcpy(J.ctx_init, ctx_init, KVZ_ENTROPY_CTXS);
-  const kvz::EntropyTabs T{ &tb.ctx_next[0][0], kvz::kLpsPacked };
+  const kvz::EntropyTabs T{ &tb.ctx_next[0][0] };
   uint8_t ctx[KVZ_ENTROPY_CTXS];
   long total = 0;
   for (long i = 0; i < items; i++) { hostsim_ctu_bins(J, &tb, i); if (J.nbins[i] > cap) total = -1; }
   if (total == 0) {
     if (!no_wpp) kvz::entropy_row_contexts(J, T, 0, ctx);
-    for (long i = 0; i < streams; i++) { substream_bytes[i] = kvz::entropy_code_row(J, T, i, ctx, out + total); total += substream_bytes[i]; }
+    const long per_stream = no_wpp ? items : J.wc;
+    for (long i = 0; i < streams; i++) {
+      unsigned long long bits = 0;
+      for (long k = 0; k < per_stream; k++) bits += J.nbits[i * per_stream + k];
+      substream_bytes[i] = hostsim_code_row(J, tb, i, out + total, (size_t)(((bits + 7) / 8 + 16) * 3 / 2));
+      total += substream_bytes[i];
+    }
   }
   free(J.bins); free(J.nbins); free(J.nbits); free(J.row_ctx);
   return total;
