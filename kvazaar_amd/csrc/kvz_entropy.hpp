@@ -54,7 +54,7 @@ struct EntropyJob {
 };
 #define KVZ_EB_CTX(ctx, v) ((u32)(ctx) | ((u32)(v) << 8))
 #define KVZ_EB_EP(value, n) (0x40000000u | ((u32)(n) << 16) | ((u32)(value) & 0xffffu))
-#define KVZ_EB_TRM(v) (0x80000000u | (u32)(v))
+#define KVZ_EB_TRM(v) (0x80000000u | ((u32)(v) << 8) | 168u)  /* the value where a context-coded bin has it, on the coder's pseudo-context (KVZ_ENTROPY_CTX_NEUTRAL) */
 
 struct BinSink {
   u32 *out; u32 n, cap;
@@ -108,7 +108,7 @@ struct DeferSink {
   {
     while (head < tail && (front() >> 30) != 3u) {
       const u32 r = q[head++ * qs], kind = r >> 30;
-      if (kind == 0) out.ctx((int)(r & 0xff), (int)((r >> 8) & 1)); else if (kind == 1) out.ep(r & 0xffffu, (int)((r >> 16) & 0x3fu)); else out.trm((int)(r & 1));
+      if (kind == 0) out.ctx((int)(r & 0xff), (int)((r >> 8) & 1)); else if (kind == 1) out.ep(r & 0xffffu, (int)((r >> 16) & 0x3fu)); else out.trm((int)((r >> 8) & 1));
     }
     return head < tail;
   }
@@ -716,6 +716,7 @@ __device__ const u32 kLpsPacked[64] = {
 //  * the context's state for the NEXT record is fetched while this one is coded: per state one 64-bit table entry (the four LPS ranges, both successors, the state itself),
 //    read as soon as the successor of the current context is known, and the state byte of the record after that one step earlier.
 #define KVZ_ENTROPY_CTX_NEUTRAL KVZ_ENTROPY_CTXS
+static_assert(KVZ_ENTROPY_CTX_NEUTRAL == 168, "KVZ_EB_TRM names it");
 #define KVZ_ENTROPY_CTX_STRIDE 172  // bytes of context states per lane: 43 dwords, odd, so lanes reading the same context hit different LDS banks
 #define KVZ_EB_NOP KVZ_EB_EP(0, 0)   // a run of no bypass bins: low << 0 + range * 0
 // entry of state s = sigma << 1 | mps
@@ -821,7 +822,7 @@ template <int W> struct WideCoder {  // W: bits per unit moved out (32; 8 in tes
     return bytes;
   }
 };
-KVZ_DEV int entropy_rec_ctx(u32 rec) { return (rec >> 30) ? KVZ_ENTROPY_CTX_NEUTRAL : (int)(rec & 0xff); }
+KVZ_DEV int entropy_rec_ctx(u32 rec) { return (rec & 0xc0000000u) == 0x40000000u ? KVZ_ENTROPY_CTX_NEUTRAL : (int)(rec & 0xff); }  // (a bypass record has bins where the others have their context)
 // the substream `item` without emulation prevention, at `out` (room for its upper bound, 4-byte aligned); ctx: KVZ_ENTROPY_CTX_STRIDE bytes of work memory;
 // tab: entropy_state_entry of the 128 states.  Returns the bytes written.
 template <int W> KVZ_DEV u32 entropy_code_row_wide(const EntropyJob &J, const unsigned long long *tab, long item, u8 *ctx, u8 *out)
@@ -845,27 +846,27 @@ template <int W> KVZ_DEV u32 entropy_code_row_wide(const EntropyJob &J, const un
     for (int q = 0; q < 16; q++) {
       const u32 rec = cur.w[q], rec1 = q < 15 ? cur.w[q + 1] : nxt.w[0], rec2 = q < 14 ? cur.w[q + 2] : nxt.w[q - 14];
       const int c = entropy_rec_ctx(rec), c1 = entropy_rec_ctx(rec1), c2 = entropy_rec_ctx(rec2);
-      const u32 kind = rec >> 30;
-      const bool byp = kind == 1;
-      const u32 st = (u32)(E >> 48) & 0xff, bin = (kind ? rec : rec >> 8) & 1;
+      // masks instead of branches: mb = the record is a run of bypass bins, ml = the bin is the less probable symbol (a terminating bin's value sits where a
+      // context-coded bin's does, KVZ_EB_TRM; a bypass record's pseudo-context does not care)
+      const u32 mb = (rec & 0xc0000000u) == 0x40000000u ? ~0u : 0u;
+      const u32 hi = (u32)(E >> 32);  // successor after an MPS | after an LPS << 8 | the state << 16
+      const u32 ml = 0u - (((rec >> 8) ^ (hi >> 16)) & 1u);
       const u32 lps = ((u32)E >> ((a.range >> 3) & 24)) & 0xff;
-      const bool is_lps = ((bin ^ st) & 1) != 0;
       // the context moves on, and the next record's entry is asked for before this record's arithmetic
-      const u32 s_new = (u32)(E >> (is_lps ? 40 : 32)) & 0xff;
+      const u32 s_new = (hi >> (ml & 8)) & 0xff;
       ctx[c] = (u8)s_new;
       const u32 s1 = c1 == c ? s_new : P;
       const unsigned long long E1 = tab[s1];
       P = ctx[c2];
-      // the interval (cabac.c:104-133, :231-254)
+      // the interval (cabac.c:104-133, :231-254): an LPS shifts by clz(lps) - 23 and continues with lps, an MPS by one if the range fell below 256
       const u32 rm = a.range - lps;
-      const int nbits = (int)__builtin_clz(lps) - 23;
-      const int small = rm < 256 ? 1 : 0;
-      const int nb = (int)((rec >> 16) & 0x3f);
-      const int sh = byp ? nb : is_lps ? nbits : small;
-      const u32 add = byp ? a.range * (rec & 0xffffu) : is_lps ? rm << nbits : 0u;
-      a.range = byp ? a.range : is_lps ? lps << nbits : rm << small;
+      const u32 nbits = (u32)__builtin_clz(lps) - 23u, small = rm < 256 ? 1u : 0u;
+      const u32 sh_ctx = (nbits & ml) | (small & ~ml);
+      const u32 sh = (((rec >> 16) & 0x3f) & mb) | (sh_ctx & ~mb);
+      const u32 add = ((a.range * (rec & 0xffffu)) & mb) | (((rm & ml) << sh_ctx) & ~mb);
+      a.range = (a.range & mb) | ((((lps & ml) | (rm & ~ml)) << sh_ctx) & ~mb);
       a.low = (a.low << sh) + add;
-      a.pend += sh;
+      a.pend += (int)sh;
       a.move_units();
       E = E1;
     }
