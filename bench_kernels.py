@@ -86,7 +86,7 @@ def main():
             ms = time_call(dev, lambda: dev.lib.kvz_hip_dev_transform(kind, di, dt, do, count, mfma), args.reps, args.warmup)
             if mfma == 0:
                 suffix, extra = "_scalar", {"path": "one lane per coefficient, two passes through HBM"}
-            elif mfma == 1 and n <= 16:
+            elif (mfma == 1 and n < 16) or (mfma == 2 and n == 16):               # (the vector ALU form is the product's for 4- and 8-point blocks, the A/B form at 16)
                 suffix, extra = "_rows", {"path": "vector ALU, one lane per block row: v_dot2_i32_i16 on packed pairs, transposes through LDS"}
             else:
                 if mfma == 2 and n == 32:
@@ -97,7 +97,7 @@ def main():
                 k_issued = 32                                                      # K of both int8 instructions (16 x 16 x 32 runs half empty for 16-point rows)
                 ops = count * 4 * n ** 3 / (ms * 1e-3)                             # 2 products x 2 n^3 multiply-adds' worth of operations
                 issued = count / blocks_per_issue * 2 * 2 * 2 * per_issue * per_issue * k_issued / (ms * 1e-3)  # 2 products x 2 byte planes
-                extra = {"path": "matrix cores, v_mfma_i32_*_i8 on byte planes" + ("" if n >= 16 else " (small blocks on a block diagonal; A/B path)"),
+                extra = {"path": "matrix cores, v_mfma_i32_*_i8 on byte planes" + ("" if n == 32 else ", four blocks per wavefront" if n == 16 else " (small blocks on a block diagonal; A/B path)"),
                          "mfma_algorithmic_frac": round(ops / I8_DENSE_PEAK, 5), "mfma_issued_frac": round(issued / I8_DENSE_PEAK, 5)}
             report(f"{name}{suffix}", n, count, ms, 4 * n * n, extra)
         dev.free(di, dt, do)

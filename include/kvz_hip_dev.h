@@ -38,9 +38,10 @@ int  kvz_hip_dev_sad_nxn(int n, const uint8_t *a, const uint8_t *b, int count, u
 int  kvz_hip_dev_satd_nxn(int n, const uint8_t *a, const uint8_t *b, int count, uint32_t *out);
 
 /* kvz_dct_NxN / kvz_idct_NxN / 4x4 DST (dct-generic.c:559-630), 8-bit: `kind` = enum kvz_hip_transform_kind.
- * use_matrix_cores == 1 (the product path): 32-point blocks on the matrix cores (v_mfma_i32_32x32x32_i8 on byte planes, exact integer arithmetic, one block per
- * wavefront), 4-, 8- and 16-point blocks on the vector ALU, one lane per block row (v_dot2_i32_i16, transposes through LDS).
- * == 2: every size on the matrix cores, the small ones 4 or 2 blocks on the diagonal of a 16 x 16 product (kept for A/B).
+ * use_matrix_cores == 1 (the product path): 16- and 32-point blocks on the matrix cores (v_mfma_i32_16x16x32_i8 / 32x32x32_i8 on byte planes, exact integer
+ * arithmetic; four 16-point blocks or one 32-point block per wavefront), 4- and 8-point blocks on the vector ALU, one lane per block row (v_dot2_i32_i16, transposes
+ * through LDS).
+ * == 2 (kept for A/B): the small sizes on the matrix cores too, 4 or 2 blocks on the diagonal of a 16 x 16 product; 16-point blocks on the vector ALU.
  * == 0: one lane per coefficient, two launches through `tmp` (count * n^2 int16 of scratch; may be NULL otherwise). */
 int  kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *out, int count, int use_matrix_cores);
 

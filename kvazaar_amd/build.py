@@ -16,7 +16,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: pixel_var / cost arithmetic must not be contracted into FMAs (bit-exact double results)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 # (object name, source, extra defines)
-UNITS = ([("kvz_hip", "kvz_hip.hip", ["-DKVZ_CTU_SEPARATE_TUS"])] + [(f"kvz_ctu_tu{k}", "kvz_ctu_tu.hip", [f"-DKVZ_CTU_KERNEL_TU={k}"]) for k in range(6)]
+UNITS = ([("kvz_hip", "kvz_hip.hip", ["-DKVZ_CTU_SEPARATE_TUS", "-mllvm", "-amdgpu-mfma-vgpr-form"])]  # (the streaming transform kernels: accumulators in VGPRs, no v_accvgpr moves around the bias pass)
+         + [(f"kvz_ctu_tu{k}", "kvz_ctu_tu.hip", [f"-DKVZ_CTU_KERNEL_TU={k}"]) for k in range(6)]
          + [("kvz_inter_tu0", "kvz_inter_tu.hip", ["-DKVZ_ICTU_CABAC=0"]), ("kvz_inter_tu1", "kvz_inter_tu.hip", ["-DKVZ_ICTU_CABAC=1"])])  # the inter CTU pass's two builds (csrc/kvz_inter_kernels.hpp)
 
 

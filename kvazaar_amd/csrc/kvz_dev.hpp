@@ -137,22 +137,34 @@ __global__ void __launch_bounds__(256) dev_satd4_kernel(const u8 *a, const u8 *b
 // 16 narrow global accesses per lane when done against HBM directly.
 template <int N> __global__ void __launch_bounds__(256) dev_transform_mfma_kernel(const i16 *in, i16 *out, const int count, const int inverse, const Tables *tb)
 {
-  __shared__ alignas(16) i16 s_blk[4][N * N];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long blk = (long)blockIdx.x * 4 + wave;
-  const bool have = blk < count;  // wavefront-uniform
-  constexpr int L2 = N == 16 ? 4 : 5, VEC = N * N / 8 / 64;  // uint4 (8 coefficients) per lane: 2 for 32x32; 16x16 blocks: half a uint4 -> uint2
-  i16 *sb = s_blk[wave];
-  if (have) {
-    if (N == 32) { const uint4 *src = reinterpret_cast<const uint4 *>(in + blk * (N * N)); for (int k = 0; k < (VEC ? VEC : 1); k++) reinterpret_cast<uint4 *>(sb)[k * 64 + lane] = src[k * 64 + lane]; }
-    else reinterpret_cast<uint2 *>(sb)[lane] = reinterpret_cast<const uint2 *>(in + blk * (N * N))[lane];
-  }
-  __syncthreads();
-  if (have) mfma_transform_block<N>(sb, sb, inverse != 0, tb, lane);
-  __syncthreads();
-  if (have) {
-    if (N == 32) { uint4 *dst = reinterpret_cast<uint4 *>(out + blk * (N * N)); for (int k = 0; k < (VEC ? VEC : 1); k++) dst[k * 64 + lane] = reinterpret_cast<const uint4 *>(sb)[k * 64 + lane]; }
-    else reinterpret_cast<uint2 *>(out + blk * (N * N))[lane] = reinterpret_cast<const uint2 *>(sb)[lane];
+  if constexpr (N == 16) {
+    // FOUR blocks per wavefront (2 KB: two dwordx4 per lane each way); nothing is shared between wavefronts, so they synchronise on their own (a wavefront's LDS
+    // operations execute in order: a compiler fence, no s_barrier), load the table operands once and run the four blocks' product chains side by side
+    __shared__ alignas(16) i16 s_blk[4][4 * 256];
+    i16 *sb = s_blk[wave];
+    const long blk = ((long)blockIdx.x * 4 + wave) * 4;
+    const long left = (long)count - blk;  // wavefront-uniform
+    if (left <= 0) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(in + blk * 256);
+    uint4 *dst = reinterpret_cast<uint4 *>(out + blk * 256);
+#pragma unroll
+    for (int k = 0; k < 2; k++) { const int j = k * 64 + lane; if ((j >> 5) < left) reinterpret_cast<uint4 *>(sb)[j] = src[j]; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    mfma_transform_blocks16<4>(sb, sb, inverse != 0, tb, lane);  // (blocks past the end: whatever the LDS holds, never stored)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < 2; k++) { const int j = k * 64 + lane; if ((j >> 5) < left) dst[j] = reinterpret_cast<const uint4 *>(sb)[j]; }
+  } else {
+    __shared__ alignas(16) i16 s_blk[4][N * N];
+    const long blk = (long)blockIdx.x * 4 + wave;
+    const bool have = blk < count;  // wavefront-uniform
+    i16 *sb = s_blk[wave];
+    if (have) { const uint4 *src = reinterpret_cast<const uint4 *>(in + blk * (N * N)); for (int k = 0; k < 2; k++) reinterpret_cast<uint4 *>(sb)[k * 64 + lane] = src[k * 64 + lane]; }
+    __syncthreads();
+    if (have) mfma_transform_block<N>(sb, sb, inverse != 0, tb, lane);
+    __syncthreads();
+    if (have) { uint4 *dst = reinterpret_cast<uint4 *>(out + blk * (N * N)); for (int k = 0; k < 2; k++) dst[k * 64 + lane] = reinterpret_cast<const uint4 *>(sb)[k * 64 + lane]; }
   }
 }
 
@@ -1078,15 +1090,14 @@ int kvz_hip_dev_transform(int kind, const int16_t *in, int16_t *tmp, int16_t *ou
 {
   static const int sizes[5] = { 4, 8, 16, 32, 4 };
   const int inverse = kind >= KVZ_HIP_IDCT_4, idx = inverse ? kind - KVZ_HIP_IDCT_4 : kind, n = sizes[idx];
-  if (use_matrix_cores == 1 && n == 16) {  // 16-point blocks: one lane per row on v_dot2_i32_i16 as well (5 TB/s against 3.4 TB/s on the matrix cores, which use_matrix_cores == 2 keeps)
+  if (use_matrix_cores == 2 && n == 16) {  // 16-point blocks, A/B: one lane per row on v_dot2_i32_i16 (4.9 / 4.4 TB/s forward / inverse against 5.1 / 5.0 TB/s on the matrix cores, four blocks per wavefront)
     const long rows = (long)count * 16;
     KVZ_DEV_LAUNCH(kvz::dev_transform_rows_kernel<16>, (rows + 511) / 512 * 256, in, out, rows, inverse, &kvz::device_tables()->pairs16[0][0][0]);
     return 0;
   }
   if (use_matrix_cores && (n == 16 || n == 32) && idx != 4) {
-    const long threads = ((long)count + 3) / 4 * 256;
-    if (n == 16) KVZ_DEV_LAUNCH(kvz::dev_transform_mfma_kernel<16>, threads, in, out, count, inverse, kvz::device_tables());
-    else KVZ_DEV_LAUNCH(kvz::dev_transform_mfma_kernel<32>, threads, in, out, count, inverse, kvz::device_tables());
+    if (n == 16) KVZ_DEV_LAUNCH(kvz::dev_transform_mfma_kernel<16>, ((long)count + 15) / 16 * 256, in, out, count, inverse, kvz::device_tables());  // four blocks per wavefront
+    else KVZ_DEV_LAUNCH(kvz::dev_transform_mfma_kernel<32>, ((long)count + 3) / 4 * 256, in, out, count, inverse, kvz::device_tables());
     return 0;
   }
   if (use_matrix_cores == 1) {  // the small sizes run on the vector ALU (v_dot2_i32_i16); use_matrix_cores == 2 keeps the block-diagonal MFMA form for A/B

@@ -46,6 +46,47 @@ template <> struct DevMma<32> {  // v_mfma_i32_32x32x32_i8
   static constexpr int STEPS = 4;
 };
 
+// The 16-point product's operands that do not depend on the block -- this lane's slot of the table and the biases of its accumulator registers --, so that a wavefront
+// with several blocks loads them once
+struct DevTable16 {
+  long tv;       // the table's bytes of this lane's k slots (the upper four slots stay zero: the contraction is over 16)
+  int c;         // 128 x the sum of the table row this lane's column meets (register matrix x table)
+  dev_int4 s4;   // 128 x the sums of the table rows this lane's four accumulator rows are (table x register matrix)
+};
+__device__ __forceinline__ DevTable16 dev_table16(const int8_t *tab, const i32 *sums, int lane)
+{
+  typedef DevMma<16> M;
+  DevTable16 t;
+  t.tv = (long)(unsigned long long)*reinterpret_cast<const u32 *>(tab + M::idx(lane) * 16 + 4 * (lane >> 4));
+  t.c = 128 * sums[M::idx(lane)];
+  t.s4 = *reinterpret_cast<const dev_int4 *>(sums + M::row(lane, 0));
+  for (int i = 0; i < 4; i++) t.s4[i] *= 128;
+  return t;
+}
+// l, h: the byte planes of the lane's four 16-bit values (dev_byte_planes)
+__device__ __forceinline__ void dev_product16_planes(u32 l, u32 h, const DevTable16 &t, bool table_is_a, int add, int *out)
+{
+  const long lo = (long)(unsigned long long)l, hi = (long)(unsigned long long)h;
+  dev_int4 acc = { 0, 0, 0, 0 };
+  // ONE accumulator: the high plane's product, times 256 plus the bias, is what the low plane's product adds to
+  if (table_is_a) {
+    acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(t.tv, hi, acc, 0, 0, 0);
+    for (int i = 0; i < 4; i++) acc[i] = acc[i] * 256 + (t.s4[i] + add);
+    acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(t.tv, lo, acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(hi, t.tv, acc, 0, 0, 0);
+    for (int i = 0; i < 4; i++) acc[i] = acc[i] * 256 + (t.c + add);
+    acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(lo, t.tv, acc, 0, 0, 0);
+  }
+  for (int r = 0; r < 4; r++) out[r] = acc[r];
+}
+__device__ __forceinline__ void dev_product16(const int *v, const DevTable16 &t, bool table_is_a, int add, int *out)
+{
+  u32 l, h;
+  dev_byte_planes(v[0], v[1], v[2], v[3], l, h);
+  dev_product16_planes(l, h, t, table_is_a, add, out);
+}
+
 // out[] = (register matrix v, accumulator layout) x (table) when table_is_a == false, (table) x (register matrix) otherwise, + add.
 // tab: the table's rows in slot order (16 or 32 signed bytes per row), sums: the row sums of the table.
 template <int N> __device__ __forceinline__ void dev_product(const int *v, const int8_t *tab, const i32 *sums, bool table_is_a, int lane, int add, int *out)
@@ -74,23 +115,8 @@ template <int N> __device__ __forceinline__ void dev_product(const int *v, const
     }
     for (int r = 0; r < 16; r++) out[r] = acc[r];
   } else {
-    u32 l, h;
-    dev_byte_planes(v[0], v[1], v[2], v[3], l, h);
-    const long lo = (long)(unsigned long long)l, hi = (long)(unsigned long long)h;
-    const long tv = (long)(unsigned long long)*reinterpret_cast<const u32 *>(tab + M::idx(lane) * 16 + 4 * (lane >> 4));
-    dev_int4 acc = { 0, 0, 0, 0 };
-    if (table_is_a) {
-      const dev_int4 s4 = *reinterpret_cast<const dev_int4 *>(sums + M::row(lane, 0));
-      acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(tv, hi, acc, 0, 0, 0);
-      for (int i = 0; i < 4; i++) acc[i] = acc[i] * 256 + (128 * s4[i] + add);
-      acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(tv, lo, acc, 0, 0, 0);
-    } else {
-      const int c = 128 * sums[M::idx(lane)] + add;
-      acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(hi, tv, acc, 0, 0, 0);
-      for (int i = 0; i < 4; i++) acc[i] = acc[i] * 256 + c;
-      acc = __builtin_amdgcn_mfma_i32_16x16x32_i8(lo, tv, acc, 0, 0, 0);
-    }
-    for (int r = 0; r < 4; r++) out[r] = acc[r];
+    const DevTable16 t = dev_table16(tab, sums, lane);
+    dev_product16(v, t, table_is_a, add, out);
   }
 }
 
@@ -123,6 +149,33 @@ template <int N> __device__ __forceinline__ void mfma_transform_block(const i16 
     dev_product<N>(v, Tt, sTt, false, lane, 2048, t);   // the accumulator read as A is U^T
     for (int r = 0; r < M::NREG; r++) o[M::row(lane, r) * N + col] = (i16)iclip(-32768, 32767, t[r] >> 12);
   }
+}
+
+// NB 16x16 blocks that follow each other in x / o (LDS), one wavefront: the table operands are loaded once and the blocks' chains are independent, so the products of
+// one block fill the latency of the others'.  Same arithmetic as mfma_transform_block<16>.
+template <int NB> __device__ __forceinline__ void mfma_transform_blocks16(const i16 *x, i16 *o, bool inverse, const Tables *tb, int lane)
+{
+  typedef DevMma<16> M;
+  const int col = M::idx(lane), k0 = M::k0(lane, 0);
+  const DevTable16 t = dev_table16(tb->dct_i8[0][inverse ? 1 : 0], tb->dct_sum[0][inverse ? 1 : 0], lane);
+  int v[NB][4], w[NB][4];
+  const u16 *xu = reinterpret_cast<const u16 *>(x);
+#pragma unroll
+  for (int b = 0; b < NB; b++) {  // the byte planes come straight out of the 16-bit values as they lie in memory: no sign extension in between
+    u32 l, h;
+    if (!inverse) {
+      const uint2 q = *reinterpret_cast<const uint2 *>(x + b * 256 + col * 16 + k0);
+      l = __builtin_amdgcn_perm(q.y, q.x, 0x06040200u) ^ 0x80808080u;
+      h = __builtin_amdgcn_perm(q.y, q.x, 0x07050301u);
+    } else dev_byte_planes((int)xu[b * 256 + k0 * 16 + col], (int)xu[b * 256 + (k0 + 1) * 16 + col], (int)xu[b * 256 + (k0 + 2) * 16 + col], (int)xu[b * 256 + (k0 + 3) * 16 + col], l, h);
+    dev_product16_planes(l, h, t, false, inverse ? 64 : 4, w[b]);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; b++) for (int r = 0; r < 4; r++) v[b][r] = inverse ? iclip(-32768, 32767, w[b][r] >> 7) : w[b][r] >> 3;
+#pragma unroll
+  for (int b = 0; b < NB; b++) dev_product16(v[b], t, !inverse, inverse ? 2048 : 512, w[b]);
+#pragma unroll
+  for (int b = 0; b < NB; b++) for (int r = 0; r < 4; r++) o[b * 256 + M::row(lane, r) * 16 + col] = (i16)(inverse ? iclip(-32768, 32767, w[b][r] >> 12) : w[b][r] >> 10);
 }
 
 }  // namespace kvz
