@@ -1007,19 +1007,20 @@ def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedRes
             b.close()
             pinned.close()
         pair = []
-        half_full = max(1, args.frames // 2)  # the coder's third stage is one lane per WPP substream: its latency wants big batches (384 pictures: 155 ms, 768: 190 ms)
+        half_full = max(1, args.frames // 2)  # the coder's third stage is one lane per WPP substream, bound by the chain: big batches (768 pictures: 37 ms, 1 536: 40 ms)
         full = []
         for _ in range(2):
             b = HipBatch(lib, args.width, args.height, half_full)
             for i in range(half_full):
                 b.upload(i, distinct[i % len(distinct)])
             full.append(b)
-        s_full, pictures, per_pic, ok = chain_full(full, model, args.qp, 2, gold if applies else None, len(distinct))
+        reps_full = 4  # eight turns: the pipeline's first pass and last coder have nothing beside them
+        s_full, pictures, per_pic, ok = chain_full(full, model, args.qp, reps_full, gold if applies else None, len(distinct))
         for b in full:
             b.close()
         result["chain_full"] = {"stages": "CTU pass -> deblocking -> entropy coder on the device -> slice data and entry points downloaded into pinned host memory; two batches of "
-                                          f"{half_full} pictures alternating on two streams, one batch's coder (a worker thread's blocking call) beside the other batch's pass",
-                                "value": pictures * main_batch.ctus_per_frame / s_full, "unit": "CTUs/s", "fps": pictures / s_full, "ms_per_batch": s_full / 4 * 1e3,
+                                          f"{half_full} pictures in turn, a batch's pass started when the other batch's coder has queued its chain-bound third stage (kvz_hip_batch_entropy_code_then)",
+                                "value": pictures * main_batch.ctus_per_frame / s_full, "unit": "CTUs/s", "fps": pictures / s_full, "ms_per_batch": s_full / (2 * reps_full) * 1e3, "batches_timed": 2 * reps_full,
                                 "slice_data_bytes_per_picture": per_pic, "verified": ok,
                                 "verify": "slice data and entry points of the clip's pictures equal the reference encoder's bitstream (tests/golden/entropy.json bench-1080p)",
                                 "note": "the like-for-like line against cpu_baseline (kvazaar's whole encoder: search, deblocking, CABAC, bitstream); parameter sets, slice "
@@ -1041,9 +1042,11 @@ def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedRes
 
 
 def chain_full(pair, model, qp, reps, gold, n_distinct):
-    """CTU pass -> deblocking -> entropy coder on the device -> slice data + entry points downloaded, for two resident batches alternating on their own streams: one
-    batch's slice data is coded and downloaded (a blocking call, on a worker thread) while the other batch's pass runs (tools/chain_probe.py: 768-picture batches,
-    serial 355 ms per batch, overlapped 279 ms).  What the host gets per picture is what kvazaar's
+    """CTU pass -> deblocking -> entropy coder on the device -> slice data + entry points downloaded, for two resident batches in turn.  The coder's first stage wants
+    the whole device and so does the pass (one persistent launch that takes every workgroup slot it finds); the coder's third stage is a few hundred wavefronts that
+    each follow one substream's chain, and then there is the download.  So the other batch's pass is started when this batch's coder has queued its third stage
+    (kvz_hip_batch_entropy_code_then) and runs beside the rest of it (tools/chain_probe.py: 768-picture batches, one after the other 258 ms per batch, this way 239 ms;
+    a pass started any earlier keeps the coder's first stage waiting: no gain).  What the host gets per picture is what kvazaar's
     encoder_state_worker_encode_lcu_bitstream wrote (encoderstate.c:636-745) -- the like-for-like counterpart of the reference encoder timed on the CPU, which also
     searches, filters and codes.  Returns (seconds, pictures, slice-data bytes per picture, verified)."""
     for b in pair:
@@ -1052,24 +1055,19 @@ def chain_full(pair, model, qp, reps, gold, n_distinct):
         b.launch(model)
         b.deblock(qp, wait=False)
         b.entropy_code(model)
-    import threading
     last = {}
-
-    def code(b):
-        last[id(b)] = b.entropy_code(model)  # blocks on b's pass + deblocking, codes, downloads (ctypes releases the GIL)
     t = time.perf_counter()
-    worker = None
-    for _ in range(reps):
-        for b in pair:
-            if worker is not None:
-                time.sleep(0.003)  # the coder's first kernels are queued before the other batch's pass: a persistent launch that takes every CU it finds
-            b.launch(model)
-            b.deblock(qp, wait=False)
-            if worker is not None:
-                worker.join()
-            worker = threading.Thread(target=code, args=(b,))
-            worker.start()
-    worker.join()
+    turns = reps * len(pair)
+    cur = pair[0]
+    cur.launch(model)
+    cur.deblock(qp, wait=False)
+    for i in range(turns):
+        nxt = pair[(i + 1) % len(pair)]
+        more = i + 1 < turns
+        last[id(cur)] = cur.entropy_code(model, then=(nxt, model) if more else None)  # waits for cur's pass + deblocking, codes, starts nxt's pass, downloads
+        if more:
+            nxt.deblock(qp, wait=False)  # queued behind the pass the call above started
+        cur = nxt
     s_full = time.perf_counter() - t
     pictures = reps * sum(b.n for b in pair)
     ok, nbytes = None, 0
@@ -1125,8 +1123,8 @@ def leg_intra4k(args, lib, model_for, HipBatch, n4k=384, steps=3):
                 for i in range(half):
                     b.upload(i, d4[i % len(d4)])
                 pair.append(b)
-            s_full, pictures, per_pic, ok = chain_full(pair, m4, args.qp, 2, gold if (args.qp == 22 and not args.no_wpp and not args.frozen_contexts) else None, len(d4))
-            out["chain_full"] = {"stages": f"CTU pass -> deblocking -> entropy coder on the device -> slice data downloaded; two batches of {half} pictures alternating on two streams",
+            s_full, pictures, per_pic, ok = chain_full(pair, m4, args.qp, 3, gold if (args.qp == 22 and not args.no_wpp and not args.frozen_contexts) else None, len(d4))
+            out["chain_full"] = {"stages": f"CTU pass -> deblocking -> entropy coder on the device -> slice data downloaded; two batches of {half} pictures in turn, a batch's pass started when the other batch's coder has queued its third stage",
                                  "value": pictures * pair[0].ctus_per_frame / s_full, "unit": "CTUs/s", "fps": pictures / s_full, "slice_data_bytes_per_picture": per_pic, "verified": ok,
                                  "verify": "slice data and entry points of the clip's pictures equal the reference encoder's bitstream (tests/golden/entropy.json bench-2160p)"}
             for b in pair:

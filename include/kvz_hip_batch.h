@@ -138,6 +138,13 @@ long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model
  * (encoderstate.c:699-724).  not_last == NULL: every picture is a slice of its own (the function above). */
 long kvz_hip_batch_entropy_code_tiles(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, const uint8_t *not_last, uint8_t *out, size_t capacity,
                                       uint32_t *substream_bytes);
+/* ... and a pipeline's form of it: once the coder's first stage is through and its third is queued -- a few hundred wavefronts that each follow one substream's chain,
+ * then the download: the device is nearly idle from there on --, the CTU pass of `next` is started with `next_model` (kvz_hip_intra_frames(next, next_model); another
+ * batch on the same device), so that it runs beside the rest of this call.  Started any earlier, the pass -- one persistent launch that takes every workgroup slot it
+ * finds -- would keep the coder's first stage, which wants the whole device, waiting until it is done.  next == NULL: kvz_hip_batch_entropy_code_tiles.  Returns as that
+ * does; -1 also if the pass could not be launched. */
+long kvz_hip_batch_entropy_code_then(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, const uint8_t *not_last, uint8_t *out, size_t capacity,
+                                     uint32_t *substream_bytes, kvz_hip_batch *next, const kvz_hip_intra_cost_model *next_model);
 uint64_t kvz_hip_default_coeff_weights(int qp);
 
 #ifdef __cplusplus

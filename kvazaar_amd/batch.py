@@ -124,11 +124,12 @@ class HipBatch:
         if wait:
             self.sync()
 
-    def entropy_code(self, model, sao=False, capacity=None, not_last=None):
+    def entropy_code(self, model, sao=False, capacity=None, not_last=None, then=None):
         """kvz_hip_batch_entropy_code: the slice data of every picture of the batch, coded on the device from the results of the last launch (and, with sao, of the
-        last loop_filters(sao=True)).  -> (bytes of all substreams back to back, sizes as an array [frame][substream])"""
-        f = self.lib.kvz_hip_batch_entropy_code_tiles
-        f.argtypes = [C.c_void_p, C.POINTER(CostModel), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        last loop_filters(sao=True)).  -> (bytes of all substreams back to back, sizes as an array [frame][substream]).  then = (batch, model): that batch's pass is
+        started once this coder's first stage is through (kvz_hip_batch_entropy_code_then)"""
+        f = self.lib.kvz_hip_batch_entropy_code_then
+        f.argtypes = [C.c_void_p, C.POINTER(CostModel), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         f.restype = C.c_long
         flags = None if not_last is None else np.ascontiguousarray(not_last, np.uint8)  # tiles: 1 = other tiles of the slice follow
         assert flags is None or flags.size == self.n
@@ -138,7 +139,8 @@ class HipBatch:
             pinned_free(self.lib, getattr(self, "_entropy_ptr", None))
             self._entropy_ptr, self._entropy_out = pinned_bytes(self.lib, capacity)  # the slice data is downloaded by the call: a pinned destination, no staging copy
         sizes = np.zeros((self.n, rows), np.uint32)
-        total = f(self.handle, C.byref(model), int(sao), flags.ctypes.data if flags is not None else None, self._entropy_out.ctypes.data, capacity, sizes.ctypes.data)
+        total = f(self.handle, C.byref(model), int(sao), flags.ctypes.data if flags is not None else None, self._entropy_out.ctypes.data, capacity, sizes.ctypes.data,
+                  then[0].handle if then else None, C.addressof(then[1]) if then else None)
         if total < 0:
             raise BatchError("kvz_hip_batch_entropy_code failed")
         return self._entropy_out[:total], sizes

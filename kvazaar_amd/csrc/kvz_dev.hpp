@@ -1553,7 +1553,7 @@ namespace kvz {
 // The stages of kvz_entropy.hpp over n_frames pictures, in chunks whose bin records fit the scratch budget.  job(f0, nf): the chunk's inputs (everything of EntropyJob but
 // the scratch pointers); not_last: host flags or null.
 inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc, int hc, int no_wpp, const uint8_t *not_last, const std::function<EntropyJob(int, int)> &job,
-                                  uint8_t *out, size_t capacity, uint32_t *substream_bytes)
+                                  uint8_t *out, size_t capacity, uint32_t *substream_bytes, const std::function<void()> &chain_queued = nullptr)
 {
   EntropyScratch &S = entropy_scratch(device);
   std::lock_guard<std::mutex> guard(S.lock);
@@ -1634,6 +1634,8 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
         else hipLaunchKernelGGL(dev_entropy_code_wide_kernel<16>, grid, block, 0, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
         hipLaunchKernelGGL(dev_entropy_escape_count_kernel, dim3((unsigned)streams), dim3(256), 0, stream, d_scratch, d_bound_offsets, d_sizes, d_ins);
       }
+      // from here on the device is nearly idle -- stage 3 is a few hundred wavefronts on their own chains, then a copy --: the caller's moment to queue other work
+      if (chain_queued && f0 + nf >= n) chain_queued();
       sizes.resize((size_t)streams);
       KVZ_HIP_CHECK(hipMemcpyAsync(sizes.data(), d_sizes, (size_t)streams * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       KVZ_HIP_CHECK(hipStreamSynchronize(stream));
@@ -1672,6 +1674,11 @@ long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model
 long kvz_hip_batch_entropy_code_tiles(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, const uint8_t *not_last, uint8_t *out, size_t capacity,
                                       uint32_t *substream_bytes)
 {
+  return kvz_hip_batch_entropy_code_then(b, model, sao, not_last, out, capacity, substream_bytes, nullptr, nullptr);
+}
+long kvz_hip_batch_entropy_code_then(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, const uint8_t *not_last, uint8_t *out, size_t capacity,
+                                     uint32_t *substream_bytes, kvz_hip_batch *next, const kvz_hip_intra_cost_model *next_model)
+{
   kvz::batch_enter(b);
   const kvz::CtuFrames &F = b->F;
   const int ctus = F.wc * F.hc;
@@ -1691,7 +1698,10 @@ long kvz_hip_batch_entropy_code_tiles(kvz_hip_batch *b, const kvz_hip_intra_cost
     memcpy(J.ctx_init, model->ctx_init, sizeof model->ctx_init < sizeof J.ctx_init ? sizeof model->ctx_init : sizeof J.ctx_init);
     return J;
   };
-  return kvz::entropy_code_pictures(b->stream, b->device, b->n_frames, F.wc, F.hc, model->no_wpp, not_last, job, out, capacity, substream_bytes);
+  int launched = 0;
+  const long total = kvz::entropy_code_pictures(b->stream, b->device, b->n_frames, F.wc, F.hc, model->no_wpp, not_last, job, out, capacity, substream_bytes,
+                                                next ? std::function<void()>([&] { launched = kvz_hip_intra_frames(next, next_model); }) : std::function<void()>());
+  return next && launched < 0 ? -1 : total;
 }
 
 // ... of B pictures: the CU records, levels and (with sao) the SAO decisions of the last kvz_hip_dev_loop_filters_inter as the inter CTU pass / the loop filters left them

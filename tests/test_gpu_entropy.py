@@ -130,3 +130,33 @@ def test_device_slice_data_of_tiles():
         assert got[i] == (want, want_sizes), i
     assert got[2] != split(*b.entropy_code(model, not_last=[1, 1, 1, 1]))[2]
     b.close()
+
+
+def test_coder_starts_the_next_batchs_pass():
+    """kvz_hip_batch_entropy_code_then: batch A's slice data is what the plain call writes, and batch B's pass -- started by A's coder once its third stage is
+    queued -- leaves what a pass launched the usual way leaves (two geometries, so that nothing of A can be mistaken for B)"""
+    import kvazaar_amd
+    from kvazaar_amd.batch import HipBatch, cost_model
+    lib = kvazaar_amd.load_library()
+    model = cost_model(lib, 22, cc.coeff_weights(22))
+    fa, fb = cc.yuv_frames(416, 240, 3, 5, "small"), cc.yuv_frames(256, 192, 2, 6, "small")
+    a, b = HipBatch(lib, 416, 240, 3), HipBatch(lib, 256, 192, 2)
+    for i, f in enumerate(fa):
+        a.upload(i, f)
+    for i, f in enumerate(fb):
+        b.upload(i, f)
+    a.run(model)
+    b.run(model)
+    want_b = [b.download(i) for i in range(2)]
+    want_data, want_sizes = a.entropy_code(model)
+    want_data = bytes(want_data)
+    b.run(cost_model(lib, 37, cc.coeff_weights(37)))  # (other results in B's buffers: the pass below has to overwrite them)
+    a.run(model)
+    data, sizes = a.entropy_code(model, then=(b, model))
+    b.sync()
+    got_b = [b.download(i) for i in range(2)]
+    assert bytes(data) == want_data and np.array_equal(sizes, want_sizes)
+    for g, w_ in zip(got_b, want_b):
+        assert cc.compare(g, w_) == []
+    a.close()
+    b.close()

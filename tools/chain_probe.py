@@ -72,3 +72,19 @@ def threaded(reps):
             worker = threading.Thread(target=b.entropy_code, args=(model,)); worker.start()
     worker.join()
 stamp("threaded overlap", threaded)
+def then(reps):
+    # the other batch's pass started by the coder itself when its third stage is queued (kvz_hip_batch_entropy_code_then): bench.py's chain_full
+    turns = 2 * reps
+    cur = pair[0]
+    cur.launch(model); cur.deblock(22, wait=False)
+    for i in range(turns):
+        nxt = pair[(i + 1) & 1]
+        more = i + 1 < turns
+        cur.entropy_code(model, then=(nxt, model) if more else None)
+        if more: nxt.deblock(22, wait=False)
+        cur = nxt
+stamp("pass started by the coder", then)
+for share in ((7, 8), (15, 16)):
+    for b in pair: b.set_device_share(*share)
+    stamp(f"... the pass on {share[0]}/{share[1]} of the slots", then)
+for b in pair: b.set_device_share(1, 1)
