@@ -561,7 +561,9 @@ KVZ_DEV void entropy_ctu_bins(const EntropyJob &J, const Tables *tb, long item)
 // active per instruction on average: profiles/r04_l_pmc_leg_entropy.json) -- and nine tenths of the walk is the residual of the transform blocks.  Here the lanes of a
 // wavefront agree on WHAT they do next, most urgent first: (1) a coefficient group of the block a lane is in (entropy_tu_cg: the bulk, now run by every lane that has a
 // block open), (2) flush queued records and open the next queued block (entropy_tu_begin), (3) the next node of the coding tree, whose CU queues its flags and blocks
-// (DeferSink).  A lane with nothing to do at the level the wavefront is on waits; the records of a lane come out in the same order either way.
+// (DeferSink).  Every lane takes one step of the piece it is at per round (waiting for the wavefront to agree on ONE piece per round -- groups first -- left a lane
+// that had finished its block idle until the longest block of the wavefront was through: 53.5 against 40.9 ms for 768 1080p pictures); the records of a lane come out
+// in the same order either way.
 #ifdef KVZ_HOSTSIM
 KVZ_DEV bool entropy_any_lane(bool v) { return v; }  // a lane is a loop iteration: it agrees with itself
 #else
@@ -600,15 +602,16 @@ KVZ_DEV void entropy_ctu_bins_phased(const EntropyJob &J, const Tables *tb, long
   TuWalk t;
   t.i = -1;
   bool open = false;
+  // every lane takes a step of whatever it is at in every round: the wavefront runs the three pieces one after the other, each for the lanes that are there
   for (;;) {
-    if (entropy_any_lane(open)) {
-      if (open) {
+    const bool cg = open, queued = !open && s.queued(), more = !open && !queued && sp > 0;
+    if (!entropy_any_lane(cg || queued || more)) break;
+    if (entropy_any_lane(cg)) {
+      if (cg) {
         entropy_tu_cg(s.out, tb, t);
         if (t.i < 0) { open = false; s.head++; }
       }
-      continue;
     }
-    const bool queued = s.queued();
     if (entropy_any_lane(queued)) {
       if (queued && s.flush_records()) {
         const u32 d = s.front();
@@ -616,11 +619,10 @@ KVZ_DEV void entropy_ctu_bins_phased(const EntropyJob &J, const Tables *tb, long
         entropy_tu_begin(s.out, tb, t);
         open = true;
       }
-      continue;
     }
-    const bool more = sp > 0;
-    if (!entropy_any_lane(more)) break;
-    if (more) { if (J.cu) cb.tree_step(s, stack, sp); else ci.tree_step(s, stack, sp, lx * 64, ly * 64); }
+    if (entropy_any_lane(more)) {
+      if (more) { if (J.cu) cb.tree_step(s, stack, sp); else ci.tree_step(s, stack, sp, lx * 64, ly * 64); }
+    }
   }
   if (!live) return;
   const bool last_col = lx == J.wc - 1, last_row = ly == J.hc - 1, end_of_picture = last_col && last_row;
