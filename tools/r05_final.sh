@@ -12,5 +12,5 @@ timeout 300 python bench.py --width 3840 --height 2160 --tiles 4x2 --frames 384 
 timeout 600 python bench.py --preset veryfast-inter --tiles 4x2 --frames 400 --steps 3 --warmup 1 > gpurun_out/${T}_bench_tiles4x2_veryfast_inter_400.json 2>/dev/null
 for f in gpurun_out/${T}_bench_*.json; do python -c "import sys,json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', round(d['value']), d['verified'])"; done
 timeout 400 python bench_kernels.py > gpurun_out/${T}_micro_kernels.jsonl 2> gpurun_out/${T}_micro.err; wc -l gpurun_out/${T}_micro_kernels.jsonl
-for leg in intra4k medium; do timeout 900 tools/pmc_leg.sh $T $leg > gpurun_out/${T}_pmc_leg_${leg}.log 2>&1; tail -2 gpurun_out/${T}_pmc_leg_${leg}.log; done
+for leg in intra4k medium entropy; do timeout 900 tools/pmc_leg.sh $T $leg > gpurun_out/${T}_pmc_leg_${leg}.log 2>&1; tail -2 gpurun_out/${T}_pmc_leg_${leg}.log; done
 ( KVZ_PROFILE_RDOQ=1 KVZ_PROFILE_NXN=1 KVZ_PROFILE_QP=22 timeout 200 python tools/ctu_profile.py 24 ) > gpurun_out/${T}_prof_medium.log 2>&1
