@@ -948,10 +948,10 @@ def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedRes
                 at += total
             ent_ok = bool(ent_ok and all(np.array_equal(sizes[i], sizes[i % args.distinct]) for i in range(b0.n)))
         result["entropy"] = {"stages": "kvz_encode_coding_tree + kvz_encode_coeff_nxn + CABAC of every picture's slice data on the device from the resident results of the CTU pass "
-                                       "(bins per CTU, row-start contexts, one arithmetic coder per WPP substream), substreams and entry points downloaded",
+                                       "(bins per CTU, row-start contexts, one arithmetic coder per WPP substream moving its code value out 32 bits at a time, emulation prevention by position), substreams and entry points downloaded",
                              "value": b0.n / ent_s, "unit": "pictures/s", "ctus_per_s": b0.ctus_per_frame * b0.n / ent_s, "ms": ent_s * 1e3,
                              "slice_data_bytes_per_picture": len(data) / b0.n, "levels_bytes_per_picture": b0.ctus_per_frame * 12288, "units_per_launch": b0.n,
-                             "roofline": dict(leg_roofline("entropy", "dev_entropy_bins_phased_kernel + dev_entropy_row_ctx_kernel + dev_entropy_code_kernel",
+                             "roofline": dict(leg_roofline("entropy", "dev_entropy_bins_phased_kernel + dev_entropy_row_ctx_kernel + dev_entropy_code_wide_kernel + dev_entropy_escape_count_kernel + dev_entropy_compact_kernel",
                                                            b0.ctus_per_frame * 12288 + 2 * (args.width * args.height // 64) + len(data) / b0.n, b0.n, ent_s, unit="picture"),
                                               note="achieved = (levels + CU depth / mode maps read, slice data written) per picture / the call's wall time, which includes the download of the slice data"),
                              "verified": ent_ok, "verify": "slice data and entry points of the clip's pictures equal the reference encoder's bitstream (tests/golden/entropy.json)"}
