@@ -35,6 +35,9 @@ extern "C" {
 /* ---- runtime ---------------------------------------------------------------------------------------------------- */
 int         kvz_hip_device_count(void);        /* usable devices; 0 when there is none (no abort)                    */
 int         kvz_hip_init(int device);          /* bind this process to `device` (default 0 / $KVZ_HIP_DEVICE); 1 = ok */
+/* One process, one device: the first call that touches HIP binds the process (device < 0: $KVZ_HIP_DEVICE, else $LOCAL_RANK, else 0) and every entry point of the
+ * library selects that device for the calling thread.  The per-thread streams, events and scratch buffers of kvz_hip_dev.h live on it and stay allocated for the life of
+ * the thread's process; a caller that wants several GPUs runs one process per GPU (bench.py --gpus N, torch.distributed.run). */
 const char *kvz_hip_version(void);
 unsigned long long kvz_hip_call_count(void); /* per-call entry points served so far (KVZ_HIP_STATS=1 prints it at exit) */
 
