@@ -635,16 +635,7 @@ KVZ_DEV void entropy_ctu_bins_phased(const EntropyJob &J, const Tables *tb, long
 
 // Four records per load: a lane walks its own list, so what bounds it is the latency of its loads -- 16 bytes at a time, the next four requested before these are coded
 struct alignas(16) Rec4 { u32 v[4]; };
-struct Rec16 {  // one 64-byte line of a list, consumed front first: next() shifts the rest down (register moves; indexing the line with a variable would put it in scratch)
-  u32 w[16];
-  KVZ_DEV u32 next()
-  {
-    const u32 r = w[0];
-#pragma unroll
-    for (int k = 0; k < 15; k++) w[k] = w[k + 1];
-    return r;
-  }
-};
+struct Rec16 { u32 w[16]; };  // one 64-byte line of a list: consumed under constant indices (indexing the line with a variable would put it in scratch)
 KVZ_DEV Rec16 entropy_load16(const Rec4 *b, u32 block)
 {
   Rec16 r;

@@ -1,6 +1,7 @@
 #!/bin/bash
 # On the GPU box: the entropy coder's two forms of stage 3 side by side (byte-at-a-time / 32-bit units, lanes per wavefront), its parity tests, and the headline's
-# quick loop.  usage: tools/r05_entropy_ab.sh <tag>   results under gpurun_out/<tag>_*
+# quick loop.  How profiles/r05_ea_* were made, at commit 85c7276 where both forms were in the library (KVZ_HIP_ENTROPY_CODER=bytes selected the old one; it has
+# been removed since: the variable is ignored now and every line of this script measures the 32-bit form).  usage: tools/r05_entropy_ab.sh <tag>   results under gpurun_out/<tag>_*
 tag=$1
 timeout 900 python -m pytest tests/test_gpu_entropy.py tests/test_entropy_inter.py -x -q -m gpu > gpurun_out/${tag}_gputest_entropy.log 2>&1; echo "pytest entropy rc=$?"; tail -3 gpurun_out/${tag}_gputest_entropy.log
 for n in 768 1536; do
