@@ -1007,14 +1007,14 @@ def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedRes
             b.close()
             pinned.close()
         pair = []
-        half_full = max(1, args.frames // 2)  # the coder's third stage is one lane per WPP substream, bound by the chain: big batches (768 pictures: 37 ms, 1 536: 40 ms)
+        half_full = args.frames  # batches of the headline's own size: the coder's third stage is one lane per WPP substream, bound by the chain (768 pictures: 37 ms, 1 536: 40 ms)
         full = []
         for _ in range(2):
             b = HipBatch(lib, args.width, args.height, half_full)
             for i in range(half_full):
                 b.upload(i, distinct[i % len(distinct)])
             full.append(b)
-        reps_full = 4  # eight turns: the pipeline's first pass and last coder have nothing beside them
+        reps_full = 3  # six turns: the pipeline's first pass and last coder have nothing beside them
         s_full, pictures, per_pic, ok = chain_full(full, model, args.qp, reps_full, gold if applies else None, len(distinct))
         for b in full:
             b.close()
