@@ -1045,7 +1045,7 @@ def chain_full(pair, model, qp, reps, gold, n_distinct):
     """CTU pass -> deblocking -> entropy coder on the device -> slice data + entry points downloaded, for two resident batches in turn.  The coder's first stage wants
     the whole device and so does the pass (one persistent launch that takes every workgroup slot it finds); the coder's third stage is a few hundred wavefronts that
     each follow one substream's chain, and then there is the download.  So the other batch's pass is started when this batch's coder has queued its third stage
-    (kvz_hip_batch_entropy_code_then) and runs beside the rest of it (tools/chain_probe.py: 768-picture batches, one after the other 243 ms per batch, this way 223 ms; 1 536-picture batches 422 ms either way;
+    (kvz_hip_batch_entropy_code_then) and runs beside the rest of it (tools/chain_probe.py: 1 536-picture batches, one after the other 427 ms per batch, this way 402 ms;
     a pass started any earlier keeps the coder's first stage waiting: no gain).  What the host gets per picture is what kvazaar's
     encoder_state_worker_encode_lcu_bitstream wrote (encoderstate.c:636-745) -- the like-for-like counterpart of the reference encoder timed on the CPU, which also
     searches, filters and codes.  Returns (seconds, pictures, slice-data bytes per picture, verified)."""

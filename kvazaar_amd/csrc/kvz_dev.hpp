@@ -1628,10 +1628,14 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
       if (!early_rows && !no_wpp) hipLaunchKernelGGL(dev_entropy_row_ctx_kernel<8>, dim3((unsigned)((nf + 7) / 8)), dim3(8), 0, stream, J, device_tables());
       {
         const dim3 grid((unsigned)((streams + lanes - 1) / lanes)), block((unsigned)lanes);
-        if (lanes == 64) hipLaunchKernelGGL(dev_entropy_code_wide_kernel<64>, grid, block, 0, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
-        else if (lanes == 32) hipLaunchKernelGGL(dev_entropy_code_wide_kernel<32>, grid, block, 0, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
-        else if (lanes == 8) hipLaunchKernelGGL(dev_entropy_code_wide_kernel<8>, grid, block, 0, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
-        else hipLaunchKernelGGL(dev_entropy_code_wide_kernel<16>, grid, block, 0, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
+        // LDS: a workgroup of this stage takes exactly what a workgroup of the CTU pass takes (unused dynamic LDS on top of its 12 KB).  A pass started beside this stage
+        // (kvz_hip_batch_entropy_code_then) is one persistent launch whose workgroups never leave: the 12 KB hole a workgroup of this stage left behind fitted none of them,
+        // and every CU that had hosted one ran the rest of the pass with seven workgroups instead of eight
+        const unsigned pad = 20480u - (unsigned)(lanes * KVZ_ENTROPY_CTX_STRIDE + 1024);
+        if (lanes == 64) hipLaunchKernelGGL(dev_entropy_code_wide_kernel<64>, grid, block, pad, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
+        else if (lanes == 32) hipLaunchKernelGGL(dev_entropy_code_wide_kernel<32>, grid, block, pad, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
+        else if (lanes == 8) hipLaunchKernelGGL(dev_entropy_code_wide_kernel<8>, grid, block, pad, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
+        else hipLaunchKernelGGL(dev_entropy_code_wide_kernel<16>, grid, block, pad, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
         hipLaunchKernelGGL(dev_entropy_escape_count_kernel, dim3((unsigned)streams), dim3(256), 0, stream, d_scratch, d_bound_offsets, d_sizes, d_ins);
       }
       // from here on the device is nearly idle -- stage 3 is a few hundred wavefronts on their own chains, then a copy --: the caller's moment to queue other work

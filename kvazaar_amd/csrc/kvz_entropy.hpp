@@ -939,6 +939,7 @@ template <int LANES> struct EntropyWideLds {
   u8 ctx[LANES][KVZ_ENTROPY_CTX_STRIDE];
   unsigned long long tab[128];
 };
+static_assert(sizeof(EntropyWideLds<64>) == 64 * KVZ_ENTROPY_CTX_STRIDE + 1024 && sizeof(EntropyWideLds<64>) <= 20480, "the launch pads this to a CTU-pass workgroup's LDS (kvz_dev.hpp)");
 template <int LANES> __global__ void __launch_bounds__(LANES) dev_entropy_code_wide_kernel(const EntropyJob J, const Tables *tb, long total, u32 *sizes, const unsigned long long *offsets, u8 *out)
 {
   __shared__ EntropyWideLds<LANES> L;
