@@ -68,6 +68,26 @@ const int16_t *kvz_ref_dst_matrix(void) { extern const int16_t kvz_g_dst_4[4][4]
 const uint32_t *kvz_ref_scan_table(int scan_idx, int log2_size) { return kvz_g_sig_last_scan[scan_idx][log2_size - 1]; }
 uint64_t kvz_ref_fast_coeff_weights(int qp) { return g_ctrl.fast_coeff_table.wts_by_qp[qp]; }
 const int16_t *kvz_ref_quant_coeff(int log2_size, int list, int qp_rem) { return g_ctrl.scaling_list.quant_coeff[log2_size - 2][list][qp_rem]; }
+const int16_t *kvz_ref_dequant_coeff(int log2_size, int list, int qp_rem) { return g_ctrl.scaling_list.de_quant_coeff[log2_size - 2][list][qp_rem]; }
+/* The scaling lists of the encoder control every wrapper below runs on (encoder.c:257-311): mode 0 = --scaling-list off (flat), 1 = --scaling-list default
+ * (enable + use_default_list), 2 = custom lists -- coeff[size][list][64] (16 used at size 0) and dc[size][list] as kvz_scalinglist_parse would leave them, stored
+ * as coeff_t directly (scalinglist.c:202 writes the parsed values through an int32_t pointer into coeff_t storage, so a cqm FILE never reaches
+ * kvz_scalinglist_process intact; the processing itself -- scalinglist.c:289-425 -- is what is pinned here).  Lists are re-processed on every call. */
+void kvz_ref_set_scaling_list(int mode, const int16_t *coeff, const int32_t *dc)
+{
+  scaling_list_t *sl = &g_ctrl.scaling_list;
+  sl->enable = mode != 0;
+  sl->use_default_list = mode == 1;
+  for (int size = 0; size < 4; size++) {
+    for (int list = 0; list < (size == 3 ? 2 : 6); list++) {
+      coeff_t *dst = (coeff_t *)sl->scaling_list_coeff[size][list];
+      const int n = size == 0 ? 16 : 64;
+      for (int i = 0; i < n; i++) dst[i] = (mode == 2) ? coeff[(size * 6 + list) * 64 + i] : 0;
+      sl->scaling_list_dc[size][list] = (mode == 2) ? dc[size * 6 + list] : 0;
+    }
+  }
+  kvz_scalinglist_process(sl, KVZ_BIT_DEPTH);
+}
 float kvz_ref_entropy_fbits(int i) { extern const float kvz_f_entropy_bits[128]; return kvz_f_entropy_bits[i]; }
 
 /* ---- picture ---- */

@@ -12,6 +12,7 @@ import ctypes as C
 
 import numpy as np
 
+import scaling_lists
 from flatapi import (A, EpolParams, IPOL_COL_LEN, IPOL_IM_PLANE, QuantParams, SaoParams, i16p, ptr, u8p)
 
 SIZES = (4, 8, 16, 32, 64)
@@ -239,6 +240,109 @@ def cases_quant():
                             lib.dequant(C.byref(p), ptr(q), ptr(d), w, w, typ if typ == 0 else 3, 1)
                             return (q.tobytes(), d.tobytes())
                         yield (f"quant{w}-qp{qp}-i{intra}-s{signhide}-t{typ}", run)
+
+
+def _chroma_qp(qp):
+    """kvz_get_scaled_qp (transform.c:141-155) for a chroma type at 8 bit, H.265 table 8-10"""
+    q = min(max(qp, 0), 57)
+    return q if q < 30 else (q - 6 if q >= 43 else (29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37)[q - 30])
+
+
+class _Lists:
+    """--scaling-list on for the calls inside: the oracle and the product take the per-coefficient tables through kvz_hip_quant_params (tests/scaling_lists.py
+    builds them); the compiled reference reads its encoder control, which load_ref()'s set_scaling_list switches (and back to flat afterwards)"""
+
+    def __init__(self, lib, name):
+        self.lib, self.lists = lib, scaling_lists.get(name)
+
+    def __enter__(self):
+        if hasattr(self.lib, "set_scaling_list"):
+            self.lib.set_scaling_list(self.lists)
+        return self.lists
+
+    def __exit__(self, *exc):
+        if hasattr(self.lib, "set_scaling_list"):
+            self.lib.set_scaling_list(None)
+
+
+def _qp_lists(lists, w, qp, slice_intra, signhide, cu_intra, type_fwd, type_inv):
+    """kvz_hip_quant_params as the kvazaar-side shim fills it with lists on (integration/kvazaar/strategies/hip/quant-hip.c fill_params): the forward table
+    of list type_fwd, the inverse one of type_inv (quant-generic.c:59-60, 312-314); returns the arrays too (the struct only holds pointers)"""
+    l2 = w.bit_length() - 1
+    qf = qp if type_fwd == 0 else _chroma_qp(qp)
+    qi = qp if type_inv == 0 else _chroma_qp(qp)
+    qt = A(lists.tables(l2, scaling_lists.list_type(cu_intra, type_fwd), qf % 6)[0])
+    dt = A(lists.tables(l2, scaling_lists.list_type(cu_intra, type_inv), qi % 6)[1])
+    p = QuantParams(qp=qp, bitdepth=8, slice_is_intra=slice_intra, signhide=signhide, scaling_list=1, cu_is_intra=cu_intra,
+                    quant_coeff=ptr(qt), dequant_coeff=ptr(dt))
+    return p, (qt, dt)
+
+
+def cases_quant_lists():
+    """quant / dequant with scaling lists (quant-generic.c:59-60 forward table, :309-333 inverse: both branches of `shift > qp_scaled / 6` -- the second one needs
+    4x4 blocks at QP >= 42, where shift = 6 + 4 - ... drops to the QP period)"""
+    rng = _rng(208)
+    for name in ("default", "custom"):
+        for w in (4, 8, 16, 32):
+            for qp in (0, 10, 22, 27, 37, 44, 51):
+                for cu_intra in (1, 0):
+                    for signhide in (0, 1):
+                        for typ in (0, 2, 3):
+                            if w == 32 and typ != 0:
+                                continue  # no 32x32 chroma lists (scalinglist.c:42: two lists at that size)
+                            amp = [40, 600, 32767][int(rng.integers(0, 3))]
+                            coef = A(rng.integers(-amp, amp + 1, w * w).astype(np.int16))
+                            if amp == 32767:
+                                coef[0], coef[1] = 32767, -32768
+                            scan = int(rng.integers(0, 3))
+
+                            def run(lib, name=name, w=w, qp=qp, cu_intra=cu_intra, signhide=signhide, typ=typ, coef=coef, scan=scan):
+                                with _Lists(lib, name) as lists:
+                                    p, keep = _qp_lists(lists, w, qp, cu_intra, signhide, cu_intra, typ, typ)
+                                    q = A(np.zeros(w * w, np.int16))
+                                    lib.quant(C.byref(p), ptr(coef), ptr(q), w, w, typ, scan, 1 if cu_intra else 2)
+                                    d = A(np.zeros(w * w, np.int16))
+                                    lib.dequant(C.byref(p), ptr(q), ptr(d), w, w, typ, 1 if cu_intra else 2)
+                                    del keep
+                                    return (q.tobytes(), d.tobytes())
+                            yield (f"quant-{name}{w}-qp{qp}-i{cu_intra}-s{signhide}-t{typ}", run)
+
+
+def cases_quantize_residual_lists():
+    """kvz_quantize_residual with scaling lists: forward table of type 0 / 2, inverse of type 0 / 2 / 3 (a V block quantises with U's list and dequantises with
+    its own, quant-generic.c:241, 263)"""
+    rng = _rng(209)
+    for name in ("default", "custom"):
+        for w in (4, 8, 16, 32):
+            for color in (0, 1, 2):
+                if w == 32 and color != 0:
+                    continue
+                for qp in (12, 22, 32, 45):
+                    for rep in range(3):
+                        stride = 64 if color == 0 else 32
+                        n = stride * 32 + 64
+                        ref = A(rng.integers(0, 256, n, dtype=np.uint8))
+                        noise = [3, 25, 255][rep]
+                        pred = A(np.clip(ref.astype(np.int32) + rng.integers(-noise, noise + 1, n), 0, 255).astype(np.uint8))
+                        alias = rep == 1
+                        cu_intra = 1 if rep != 2 else 0
+                        signhide = int(rep == 2)
+                        scan = int(rng.integers(0, 3)) if w <= 8 else 0
+                        early = int(rep == 2 and w == 8)
+                        trskip = int(w == 4 and rep == 1)
+
+                        def run(lib, name=name, w=w, color=color, qp=qp, ref=ref, pred=pred, alias=alias, cu_intra=cu_intra,
+                                signhide=signhide, scan=scan, early=early, trskip=trskip, stride=stride):
+                            with _Lists(lib, name) as lists:
+                                p, keep = _qp_lists(lists, w, qp, cu_intra, signhide, cu_intra, 0 if color == 0 else 2, (0, 2, 3)[color])
+                                pr = A(pred.copy())
+                                rec = A(pr if alias else np.full(len(pr), 7, np.uint8))
+                                co = A(np.full(w * w, 99, np.int16))
+                                has = lib.quantize_residual(C.byref(p), w, color, scan, trskip, stride, stride, ptr(ref), ptr(pr),
+                                                            ptr(rec), ptr(co), early)
+                                del keep
+                                return (has, rec.tobytes(), co.tobytes())
+                        yield (f"qres-{name}{w}-c{color}-qp{qp}-{rep}", run)
 
 
 def cases_quantize_residual():
@@ -512,7 +616,7 @@ def cases_plane_checksum():
 
 
 ALL_GENERATORS = [cases_plane_checksum, cases_sad_satd_nxn, cases_dual, cases_reg_sad, cases_any_size, cases_ssd_versad_horsad_var,
-                  cases_image_calc_sad, cases_bipred, cases_transform, cases_quant, cases_quantize_residual,
+                  cases_image_calc_sad, cases_bipred, cases_transform, cases_quant, cases_quantize_residual, cases_quant_lists, cases_quantize_residual_lists,
                   cases_coeff_misc, cases_intra, cases_ipol_sample, cases_ipol_blocks, cases_extended_block, cases_sao]
 
 

@@ -53,6 +53,19 @@ def load_ref(cpuid):
         lib.lib.kvz_ref_fast_coeff_weights.argtypes = [C.c_int]
         lib.lib.kvz_ref_quant_coeff.restype = i16p
         lib.lib.kvz_ref_quant_coeff.argtypes = [C.c_int, C.c_int, C.c_int]
+        lib.lib.kvz_ref_dequant_coeff.restype = i16p
+        lib.lib.kvz_ref_dequant_coeff.argtypes = [C.c_int, C.c_int, C.c_int]
+        lib.lib.kvz_ref_set_scaling_list.restype = None
+        lib.lib.kvz_ref_set_scaling_list.argtypes = [C.c_int, i16p, i32p]
+
+        def set_scaling_list(lists):
+            """the encoder control the reference's wrappers run on: a tests/scaling_lists.py ListSet, or None = --scaling-list off"""
+            if lists is None:
+                lib.lib.kvz_ref_set_scaling_list(0, None, None)
+            else:
+                mode, coeff, dc = lists.ref_args()
+                lib.lib.kvz_ref_set_scaling_list(mode, ptr(coeff), ptr(dc))
+        lib.set_scaling_list = set_scaling_list
         lib.lib.kvz_ref_entropy_fbits.restype = C.c_float
         lib.lib.kvz_ref_entropy_fbits.argtypes = [C.c_int]
         lib.lib.kvz_ref_optimized_sad.restype = C.c_uint32

@@ -38,8 +38,11 @@ def _encode(binary, yuv, out, extra, env=None, res="416x240"):
 @pytest.mark.parametrize("frames,preset", [(2, ["--preset", "ultrafast", "-p", "1"]),            # BASELINE config 1
                                            (1, ["--preset", "medium", "-p", "1"]),               # config 3: rdoq, sao, 4x4 DST
                                            (3, ["--preset", "veryfast", "--gop", "lp-g4d3t1"]),  # config 4: ME, FME, bipred
-                                           (1, ["--preset", "ultrafast", "-p", "1", "--tiles", "2x2"])],  # config 5 (tiles)
-                         ids=["ultrafast-intra", "medium-intra", "veryfast-inter", "ultrafast-tiles"])
+                                           (1, ["--preset", "ultrafast", "-p", "1", "--tiles", "2x2"]),  # config 5 (tiles)
+                                           # --scaling-list default: quant / dequant / quantize_residual take the per-coefficient tables (quant-generic.c:59-60, 309-333)
+                                           (1, ["--preset", "ultrafast", "-p", "1", "--scaling-list", "default"]),
+                                           (2, ["--preset", "veryfast", "--gop", "lp-g4d3t1", "--scaling-list", "default"])],  # ... the inter lists too
+                         ids=["ultrafast-intra", "medium-intra", "veryfast-inter", "ultrafast-tiles", "ultrafast-scaling-list", "veryfast-inter-scaling-list"])
 def test_bitstream_identical_to_generic(tmp_path, frames, preset):
     _need_hip_encoder()
     yuv = str(tmp_path / "syn.yuv")

@@ -30,6 +30,28 @@ def test_tables_match_reference(oracle, reflib):
             assert np.array_equal(a, b), f"scan {scan} log2 {l2}"
 
 
+@pytest.mark.parametrize("name", ["default", "custom"])
+def test_scaling_lists_match_reference(reflib, name):
+    """tests/scaling_lists.py (what the scaling-list cases hand the oracle and the product) against the tables of the reference's own encoder control after
+    kvz_scalinglist_process (scalinglist.c:407-425): every size, list and QP remainder, forward and inverse"""
+    import scaling_lists
+    lists = scaling_lists.get(name)
+    reflib.set_scaling_list(lists)
+    try:
+        for l2 in (2, 3, 4, 5):
+            n = 1 << (2 * l2)
+            for lst in range(6):
+                if l2 == 5 and lst not in (0, 1, 3):
+                    continue
+                for rem in range(6):
+                    q, d = lists.tables(l2, lst, rem)
+                    a = np.ctypeslib.as_array(reflib.lib.kvz_ref_quant_coeff(l2, lst, rem), shape=(n,))
+                    b = np.ctypeslib.as_array(reflib.lib.kvz_ref_dequant_coeff(l2, lst, rem), shape=(n,))
+                    assert np.array_equal(q, a) and np.array_equal(d, b), (l2, lst, rem)
+    finally:
+        reflib.set_scaling_list(None)
+
+
 def _scan_table(oracle):
     def f(scan_idx, l2):
         n = 1 << (2 * l2)
