@@ -424,6 +424,7 @@ def self_launch(n):
            os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("KVZ_HIP_DEVICE", None)  # every rank takes the device of its LOCAL_RANK
     return subprocess.call(cmd, env=env)
 
 
@@ -488,8 +489,9 @@ def main():
     if world != args.gpus:
         sys.exit(f"bench: --gpus {args.gpus} but WORLD_SIZE is {world}: launch one rank per GPU (python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}), "
                  "or run `python bench.py --gpus N` without a launcher")
-    os.environ.setdefault("KVZ_HIP_DEVICE", str(local_rank))
-    if os.environ["KVZ_HIP_DEVICE"] != str(local_rank):
+    if world > 1:
+        os.environ.setdefault("KVZ_HIP_DEVICE", str(local_rank))
+    if world > 1 and os.environ["KVZ_HIP_DEVICE"] != str(local_rank):  # (a single-GPU run picks its device with KVZ_HIP_DEVICE as include/kvz_hip.h says)
         sys.exit(f"bench: rank {rank} is bound to device {os.environ['KVZ_HIP_DEVICE']} but LOCAL_RANK is {local_rank}: one GPU per rank")
     if os.environ.get("KVZ_BENCH_STUB"):  # tests/test_dist_cpu.py: the launch path without a GPU (gloo, a stubbed step)
         stub_bench(args, rank, world)
@@ -497,7 +499,7 @@ def main():
 
     import torch
     dist = None
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(int(os.environ.get("KVZ_HIP_DEVICE", local_rank)) % max(1, torch.cuda.device_count()))  # torch's tensors and the library's kernels on one device
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl")

@@ -35,9 +35,14 @@ extern "C" {
 /* ---- runtime ---------------------------------------------------------------------------------------------------- */
 int         kvz_hip_device_count(void);        /* usable devices; 0 when there is none (no abort)                    */
 int         kvz_hip_init(int device);          /* bind this process to `device` (default 0 / $KVZ_HIP_DEVICE); 1 = ok */
-/* One process, one device: the first call that touches HIP binds the process (device < 0: $KVZ_HIP_DEVICE, else $LOCAL_RANK, else 0) and every entry point of the
- * library selects that device for the calling thread.  The per-thread streams, events and scratch buffers of kvz_hip_dev.h live on it and stay allocated for the life of
- * the thread's process; a caller that wants several GPUs runs one process per GPU (bench.py --gpus N, torch.distributed.run). */
+/* Devices and threads.  The first call that touches HIP picks the process DEFAULT device (kvz_hip_init's argument; < 0: $KVZ_HIP_DEVICE, else $LOCAL_RANK, else 0).
+ * Every calling thread has a current device: the default until the thread selects another one with kvz_hip_set_thread_device() or calls an entry point that takes a
+ * kvz_hip_batch (kvz_hip_batch.h), which binds the thread to the batch's device.  The per-call entry points of this header and the device-pointer entry points of
+ * kvz_hip_dev.h run on the calling thread's current device with a stream, staging arenas and grow-only scratch of their own per (thread, device); a worker thread
+ * that exits gives them back.  So ONE process can drive several GPUs -- kvazaar's tile threads (encoderstate.c:944-1013, threadqueue.c:275-355) with tile i on GPU
+ * i % kvz_hip_device_count() -- and one process per GPU (bench.py --gpus N under torch.distributed.run) keeps working through the default. */
+int         kvz_hip_set_thread_device(int device);  /* 1 = ok, 0 = no such device (the thread keeps its current one)         */
+int         kvz_hip_thread_device(void);            /* the calling thread's current device                                    */
 const char *kvz_hip_version(void);
 unsigned long long kvz_hip_call_count(void); /* per-call entry points served so far (KVZ_HIP_STATS=1 prints it at exit) */
 

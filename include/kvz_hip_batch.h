@@ -31,6 +31,11 @@ typedef struct kvz_hip_batch kvz_hip_batch; /* device buffers for n_frames pictu
 
 /* width and height must be multiples of 8 (kvazaar pads its input the same way).  NULL on failure. */
 kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames);
+/* ... on a given device (0 .. kvz_hip_device_count() - 1; -1 = the calling thread's current one, which is what kvz_hip_batch_create does).  The reference runs the
+ * tiles of a picture as jobs of ONE process (encoderstate.c:944-1013 builds one sub-encoder per tile, threadqueue.c:275-355 runs them on its workers): a host that
+ * wants tile i on GPU i % count creates tile i's batch with this and calls it from any thread -- every entry point taking a kvz_hip_batch binds the calling thread
+ * to the batch's device first, and its buffers, stream and kernels stay there.  NULL when the device does not exist. */
+kvz_hip_batch *kvz_hip_batch_create_on(int device, int width, int height, int n_frames);
 void           kvz_hip_batch_destroy(kvz_hip_batch *b);
 
 /* Host <-> HBM.  Planes are tightly packed (stride = width; chroma width/2 x height/2). */
@@ -141,8 +146,11 @@ long kvz_hip_batch_entropy_code_tiles(kvz_hip_batch *b, const kvz_hip_intra_cost
 /* ... and a pipeline's form of it: once the coder's first stage is through and its third is queued -- a few hundred wavefronts that each follow one substream's chain,
  * then the download: the device is nearly idle from there on --, the CTU pass of `next` is started with `next_model` (kvz_hip_intra_frames(next, next_model); another
  * batch on the same device), so that it runs beside the rest of this call.  Started any earlier, the pass -- one persistent launch that takes every workgroup slot it
- * finds -- would keep the coder's first stage, which wants the whole device, waiting until it is done.  next == NULL: kvz_hip_batch_entropy_code_tiles.  Returns as that
- * does; -1 also if the pass could not be launched. */
+ * finds -- would keep the coder's first stage, which wants the whole device, waiting until it is done.  next == NULL: kvz_hip_batch_entropy_code_tiles.
+ * Returns: the total size; -1 the coder failed (as kvz_hip_batch_entropy_code_tiles); -2 the coder succeeded but kvz_hip_intra_frames(next, next_model) returned an
+ * error; -3 next_model is NULL or of an unknown struct_size -- checked first, nothing has been queued on either batch.  In every other case, -1 and -2 included,
+ * `next`'s pass HAS been queued exactly once when the call returns (at the coder's quiet moment, or at the end of the call when the coder never reached it): the
+ * caller synchronises `next` (kvz_hip_batch_sync) whatever this call returned. */
 long kvz_hip_batch_entropy_code_then(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, const uint8_t *not_last, uint8_t *out, size_t capacity,
                                      uint32_t *substream_bytes, kvz_hip_batch *next, const kvz_hip_intra_cost_model *next_model);
 uint64_t kvz_hip_default_coeff_weights(int qp);

@@ -145,6 +145,7 @@ typedef struct kvz_hip_cu_info {
  * config 4's preset, whose QP 22 runs its pictures at 21-25), the residual coder in counting mode on the search contexts from there on.  Returns -1 on a bad argument, -2 when a CTU
  * hand-off timed out. */
 typedef struct kvz_hip_inter_params {
+  uint32_t struct_size;        /* sizeof(kvz_hip_inter_params) of the caller's headers: set it after zeroing the struct; an unknown size is refused with -1 */
   int32_t qp;                  /* the picture's QP (state->frame->QP; kvz_oracle_lowdelay_qp states how kvazaar derives it from --qp and the GOP) */
   int32_t poc;                 /* picture order count inside the intra period (> 0); temporal AMVP candidates need poc > 1 (inter.c:1290) */
   int32_t mv_constraint;       /* cfg.owf && cfg.wpp */
@@ -166,8 +167,8 @@ int  kvz_hip_dev_inter_ctu_pass(const uint8_t *src, const uint8_t *ref, const kv
                                 int height, int n_pictures, const kvz_hip_inter_params *params);
 /* Threads and devices: the pass keeps its work memory (ticket list, done flags, contexts, the workgroups' level slabs) per CALLING THREAD and per DEVICE, like the
  * stream it is queued on -- two threads, or two devices of one process, never share it; calls of one thread are serialised on its stream.  `rec` is read back by the pass
- * itself (a finished CU is the intra reference of the next): it must not alias `ref`.  The struct grows at the end: zero it before filling it, and compile the caller
- * against the headers of the library it links (a caller built with a shorter struct hands the pass whatever lies behind it). */
+ * itself (a finished CU is the intra reference of the next): it must not alias `ref`.  The struct grows at the end: zero it, set struct_size = sizeof(kvz_hip_inter_params), then fill it -- a caller
+ * built against other headers than the library's is refused (-1) instead of handing the pass whatever lies behind a shorter struct. */
 /* ... with every picture's own tile origin: tile_xy (DEVICE pointer, n_pictures x {x, y}, multiples of 8 inside the reference frame; NULL: params->tile_x / tile_y for
  * all) -- the tiles of one size of MANY places of the grid in one launch (without WPP a tile offers one CTU at a time: the launch needs that many more chains).
  * n_references (0: one per picture): `ref` / `ref_cu` hold that many frames and picture p predicts from frame p % n_references -- several tiles of the same frame. */
@@ -175,9 +176,12 @@ int  kvz_hip_dev_inter_ctu_pass_tiles(const uint8_t *src, const uint8_t *ref, co
                                       int height, int n_pictures, const kvz_hip_inter_params *params, const int32_t *tile_xy, int n_references);
 /* milliseconds the kernel of the calling thread's last kvz_hip_dev_inter_ctu_pass took on the device (HIP events on its stream around the launch) */
 float kvz_hip_dev_inter_kernel_ms(void);
-/* Workgroups of the inter CTU pass's kernel that fit one CU (its occupancy on the current device; the pass is a persistent launch of that many per CU).  Two passes
- * that are to run side by side -- the two tile sizes of a uniform tile grid, from two host threads -- each take half: KVZ_HIP_INTER_WG_PER_CU in the environment of the
- * calls (kvazaar_amd/inter.py TiledInterSequences.run_picture). */
+/* The pass is a persistent launch of as many workgroups per CU as the kernel build it launches fits (its occupancy on the current device).  Passes that are to run
+ * side by side -- the two tile sizes of a uniform tile grid, from two host threads -- each take a share: kvz_hip_dev_inter_set_share(parts) makes the CALLING THREAD's
+ * later passes launch 1 / parts of what their kernel fits (at least one workgroup per CU; parts <= 1: all of it, the default).  Per thread, like the stream and the
+ * scratch of the pass: nothing process-global changes.  ($KVZ_HIP_INTER_WG_PER_CU, a developer override of the count, is clamped to the occupancy.) */
+void kvz_hip_dev_inter_set_share(int parts);
+/* workgroups of the pass's kernel (the build without the residual coder's contexts) that fit one CU of the calling thread's device: informational */
 int kvz_hip_dev_inter_slots_per_cu(void);
 /* The slice data of n B pictures -- kvz_encode_coding_tree with the inter syntax (encode_coding_tree.c:745-900, kvz_encode_inter_prediction_unit :311-421, kvz_encode_mvd
  * :1062-1112), the residual coder and the arithmetic coder, as kvz_hip_batch_entropy_code does it for I pictures (kvz_hip_batch.h) -- from what the inter CTU pass left on

@@ -100,6 +100,9 @@ enum {
 };
 
 typedef struct kvz_hip_intra_cost_model {
+  /* sizeof(kvz_hip_intra_cost_model) of the headers the CALLER was compiled against (kvz_hip_intra_cost_model_init sets it).  The struct grows at the end between
+   * versions: an entry point that is handed a size it does not know returns -1 instead of reading whatever lies behind a shorter struct. */
+  uint32_t struct_size;
   double   lambda;            /* state->lambda: 0.57 * 2^((qp-12)/3) at constant QP (rate_control.c:678-691) */
   double   lambda_sqrt;       /* state->lambda_sqrt */
   /* fbits[val] of each context at its slice-start state (= entropy_fbits[ctx_init[i] ^ val]; informational, the pass prices

@@ -412,6 +412,7 @@ static void inter_picture(const encoder_state_t *state)
   kvz_hip_dev_upload(g_inter.d_ref_cu, g_inter.ref_cu, cells * sizeof(kvz_hip_cu_info));
   kvz_hip_inter_params prm;
   memset(&prm, 0, sizeof prm);
+  prm.struct_size = sizeof prm;
   prm.qp = state->qp; prm.poc = state->frame->poc;
   prm.mv_constraint = cfg->owf && cfg->wpp;  /* search_inter.c:75-152 */
   prm.sao = cfg->sao_type != 0; prm.deblock = cfg->deblock_enable != 0;

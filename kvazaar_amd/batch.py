@@ -10,7 +10,7 @@ from .capi import i16p, ptr, u8p
 
 class CostModel(C.Structure):
     """kvz_hip_intra_cost_model (include/kvz_hip_types.h)"""
-    _fields_ = [("lambda_", C.c_double), ("lambda_sqrt", C.c_double), ("split_flag", (C.c_float * 2) * 3),
+    _fields_ = [("struct_size", C.c_uint32), ("lambda_", C.c_double), ("lambda_sqrt", C.c_double), ("split_flag", (C.c_float * 2) * 3),
                 ("part_size", C.c_float * 2), ("intra_mode", C.c_float * 2), ("chroma_mode", C.c_float * 2),
                 ("cbf_luma", (C.c_float * 2) * 2), ("cbf_chroma", (C.c_float * 2) * 2), ("coeff_weights", C.c_uint64),
                 ("qp", C.c_int32), ("adaptive", C.c_int32), ("coeff_cabac", C.c_int32), ("no_wpp", C.c_int32), ("search_32x32", C.c_int32), ("rdoq", C.c_int32), ("search_nxn", C.c_int32), ("ctx_init", C.c_uint8 * 160),
@@ -51,7 +51,8 @@ class BatchError(RuntimeError):
 class HipBatch:
     """kvz_hip_batch_* through ctypes"""
 
-    def __init__(self, lib, width, height, n_frames):
+    def __init__(self, lib, width, height, n_frames, device=-1):
+        """device: kvz_hip_batch_create_on -- -1 = the calling thread's current device (the process default unless the thread chose another)"""
         self.lib, self.w, self.h, self.n = lib, width, height, n_frames
         vp, ci = C.c_void_p, C.c_int
         lib.kvz_hip_batch_create.restype = vp
@@ -74,9 +75,11 @@ class HipBatch:
         lib.kvz_hip_batch_deblock.restype = None
         lib.kvz_hip_batch_checksums.argtypes = [vp, vp]
         lib.kvz_hip_batch_checksums.restype = ci
-        self.handle = lib.kvz_hip_batch_create(width, height, n_frames)
+        lib.kvz_hip_batch_create_on.restype = vp
+        lib.kvz_hip_batch_create_on.argtypes = [ci, ci, ci, ci]
+        self.handle = lib.kvz_hip_batch_create_on(device, width, height, n_frames)
         if not self.handle:
-            raise RuntimeError(f"kvz_hip_batch_create({width}, {height}, {n_frames}) failed")
+            raise RuntimeError(f"kvz_hip_batch_create_on({device}, {width}, {height}, {n_frames}) failed")
         self.ctus_per_frame = lib.kvz_hip_batch_ctus_per_frame(self.handle)
 
     def upload(self, frame, yuv):
@@ -142,7 +145,8 @@ class HipBatch:
         total = f(self.handle, C.byref(model), int(sao), flags.ctypes.data if flags is not None else None, self._entropy_out.ctypes.data, capacity, sizes.ctypes.data,
                   then[0].handle if then else None, C.addressof(then[1]) if then else None)
         if total < 0:
-            raise BatchError("kvz_hip_batch_entropy_code failed")
+            # -1 the coder, -2 the next batch's launch (in both cases that pass is queued and wants a sync), -3 bad next model (nothing queued)
+            raise BatchError(f"kvz_hip_batch_entropy_code failed ({total})")
         return self._entropy_out[:total], sizes
 
     def sao_params(self, frame):

@@ -16,7 +16,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: pixel_var / cost arithmetic must not be contracted into FMAs (bit-exact double results)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"]
 # (object name, source, extra defines)
-UNITS = ([("kvz_hip", "kvz_hip.hip", ["-DKVZ_CTU_SEPARATE_TUS", "-mllvm", "-amdgpu-mfma-vgpr-form"])]  # (the streaming transform kernels: accumulators in VGPRs, no v_accvgpr moves around the bias pass)
+MFMA_VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]  # an internal LLVM option, only a tuning of the streaming transform kernels: dropped where hipcc does not know it (_probe_flags)
+UNITS = ([("kvz_hip", "kvz_hip.hip", ["-DKVZ_CTU_SEPARATE_TUS"] + MFMA_VGPR_FORM)]  # (the streaming transform kernels: accumulators in VGPRs, no v_accvgpr moves around the bias pass)
          + [(f"kvz_ctu_tu{k}", "kvz_ctu_tu.hip", [f"-DKVZ_CTU_KERNEL_TU={k}"]) for k in range(6)]
          + [("kvz_inter_tu0", "kvz_inter_tu.hip", ["-DKVZ_ICTU_CABAC=0"]), ("kvz_inter_tu1", "kvz_inter_tu.hip", ["-DKVZ_ICTU_CABAC=1"])])  # the inter CTU pass's two builds (csrc/kvz_inter_kernels.hpp)
 
@@ -42,13 +43,32 @@ def _stale():
     return not os.path.exists(LIB_PATH) or any(_unit_stale(n) or os.path.getmtime(os.path.join(OBJ_DIR, n + ".o")) > os.path.getmtime(LIB_PATH) for n, _, _ in UNITS)
 
 
+_flag_ok = {}
+
+
+def _probe_flags(flags):
+    """does this hipcc accept `flags`?  (an empty translation unit, host side only; cached per process)"""
+    key = tuple(flags)
+    if key not in _flag_ok:
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, "probe.hip")
+            open(src, "w").write("int kvz_probe;\n")
+            r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-c", "-o", os.path.join(d, "probe.o"), src] + list(flags), capture_output=True)
+            _flag_ok[key] = r.returncode == 0
+    return _flag_ok[key]
+
+
 def _compile_and_link(obj_dir, lib_path, extra_flags, only_stale, verbose):
     os.makedirs(obj_dir, exist_ok=True)
+    mfma_form = _probe_flags(MFMA_VGPR_FORM) and not os.environ.get("KVZ_HIP_NO_MFMA_VGPR_FORM")
 
     def compile_unit(unit):
         name, src, defs = unit
         if only_stale and not _unit_stale(name):
             return
+        if not mfma_form:
+            defs = [d for d in defs if d not in MFMA_VGPR_FORM]
         obj = os.path.join(obj_dir, name + ".o")
         cmd = [HIPCC] + FLAGS + defs + list(extra_flags) + ["-c", "-MD", "-MF", os.path.join(obj_dir, name + ".d"), "-o", obj, os.path.join(CSRC, src)]
         if verbose:

@@ -43,7 +43,7 @@ struct kvz_hip_batch {
 
 namespace kvz {
 // kvazaar worker threads other than the creating one call into a batch (search_lcu_hip.c): bind them to the batch's device
-inline void batch_enter(const kvz_hip_batch *b) { KVZ_HIP_CHECK(hipSetDevice(b->device)); }
+inline void batch_enter(const kvz_hip_batch *b) { KVZ_HIP_CHECK(hipSetDevice(b->device)); thread_state().bound = true; }
 // after the stream has drained: did a hand-off wait time out?  0 ok, -1 invalid results (reported, never fatal: the embedding
 // encoder decides what to do)
 inline int batch_check(kvz_hip_batch *b)
@@ -89,6 +89,15 @@ inline int ctx_state(int qp, int init_value)
   return st >= 64 ? ((st - 64) << 1) + 1 : (63 - st) << 1;
 }
 
+// the struct versions this library knows (include/kvz_hip_types.h struct_size): the current one
+inline bool cost_model_known(const kvz_hip_intra_cost_model *m, const char *who)
+{
+  if (m && m->struct_size == sizeof(kvz_hip_intra_cost_model)) return true;
+  fprintf(stderr, "%s: kvz_hip_intra_cost_model.struct_size %u is not this library's %zu (caller built against other headers, or the struct was not set up by kvz_hip_intra_cost_model_init)\n",
+          who, m ? m->struct_size : 0u, sizeof(kvz_hip_intra_cost_model));
+  return false;
+}
+
 inline void cost_model_init(int qp, uint64_t coeff_weights, kvz_hip_intra_cost_model *m)
 {
   // I-slice rows of context.c:96-193 (HEVC spec tables 9-5 ff.); 154 = CNU, never coded
@@ -101,6 +110,7 @@ inline void cost_model_init(int qp, uint64_t coeff_weights, kvz_hip_intra_cost_m
   static const uint8_t init_one[24] = { 140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166, 182, 140, 227, 122, 197 };
   static const uint8_t init_abs[6] = { 138, 153, 136, 167, 152, 152 };
   memset(m, 0, sizeof *m);
+  m->struct_size = (uint32_t)sizeof *m;
   m->qp = qp;
   m->lambda = 0.57 * pow(2.0, (qp - 12) / 3.0);
   m->lambda_sqrt = sqrt(m->lambda);
@@ -148,15 +158,22 @@ extern "C" {
 void kvz_hip_intra_cost_model_init(int qp, uint64_t coeff_weights, kvz_hip_intra_cost_model *model) { kvz::cost_model_init(qp, coeff_weights, model); }
 uint64_t kvz_hip_default_coeff_weights(int qp) { return qp >= 0 && qp < 50 ? kvz::kDefaultCoeffWeights[qp] : 0; }
 
-kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames)
+kvz_hip_batch *kvz_hip_batch_create(int width, int height, int n_frames) { return kvz_hip_batch_create_on(-1, width, height, n_frames); }
+
+kvz_hip_batch *kvz_hip_batch_create_on(int device, int width, int height, int n_frames)
 {
   if (width <= 0 || height <= 0 || n_frames <= 0 || (width & 7) || (height & 7)) {
     fprintf(stderr, "kvz_hip_batch_create: width and height must be positive multiples of 8\n");
     return nullptr;
   }
   kvz::runtime_init(-1);
+  if (device >= kvz::runtime().n_devices) {
+    fprintf(stderr, "kvz_hip_batch_create_on: device %d of %d\n", device, kvz::runtime().n_devices);
+    return nullptr;
+  }
+  if (device >= 0) KVZ_HIP_CHECK(hipSetDevice(device));  // (the calling thread stays on it, as after any call on the batch)
   kvz_hip_batch *b = new kvz_hip_batch();
-  b->device = kvz::runtime().device;
+  b->device = kvz::current_device();
   b->failed = 0;
   {
     const char *e = getenv("KVZ_HIP_WAIT_MS");  // bound of one hand-off wait (wall clock); a whole 4K picture without WPP is a 2.5 s chain
@@ -326,6 +343,7 @@ void kvz_hip_batch_order_after(kvz_hip_batch *b, kvz_hip_batch *other)
 
 int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model)
 {
+  if (!b || !kvz::cost_model_known(model, "kvz_hip_intra_frames")) return -1;
   kvz::batch_enter(b);
   const kvz::CtuFrames &F = b->F;
   int launches = 0;

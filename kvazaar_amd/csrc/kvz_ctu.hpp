@@ -296,6 +296,9 @@ template <bool CABAC> struct CtuSharedT {
 using CtuShared = CtuSharedT<true>;
 static_assert(__builtin_offsetof(CtuSharedT<true>, fref) == __builtin_offsetof(CtuSharedT<true>, ref) + 408 && __builtin_offsetof(CtuSharedT<false>, fref) == __builtin_offsetof(CtuSharedT<false>, ref) + 408,
               "Tables::mref_tab addresses the filtered references 408 bytes behind the unfiltered ones");
+static_assert(KVZ_MREF_STRIDE == kMrefStride && KVZ_MREF_ORG == kMrefOrg && sizeof(((CtuSharedT<true> *)0)->ref[0][0]) == kMrefRefRow && kMrefFiltered == 408,
+              "Tables::mref_tab (kvz_tables.hpp) is built for this layout of the reference arrays");
+static_assert(KVZ_CTU_THREADS >= 128, "rough_search requests four table entries per lane ahead of build_mref (mref_pre[4]): 510 entries need at least 128 lanes");
 
 // Offset of plane c (0 Y, 1 U, 2 V) in a CTU's 6144-entry block: 0, 4096, 5120.  Arithmetic, not a table: indexed by a per-lane plane a constant array is a
 // load from global memory on the critical path of the phase.

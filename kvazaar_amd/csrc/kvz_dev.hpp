@@ -951,12 +951,25 @@ struct InterScratch {
 };
 // One set per calling thread and device, like the stream the work is queued on (be() is thread_local): two threads, or two devices of one process, never share
 // ticket / done / slab buffers, and a buffer is only ever freed by the thread whose (synchronised) stream used it.
+// A worker thread that exits frees its sets (kvz_runtime.hpp ThreadState): registered the first time a thread asks for one.
 inline InterScratch &inter_scratch()
 {
   static thread_local InterScratch s[64];
-  int device = 0;
-  KVZ_HIP_CHECK(hipGetDevice(&device));
-  return s[device & 63];
+  static thread_local bool registered = false;
+  if (!registered) {
+    registered = true;
+    InterScratch *all = s;
+    thread_state().cleanups.push_back([all]() {
+      for (int d = 0; d < 64; d++) {
+        InterScratch &x = all[d];
+        if (!x.slabs && !x.ctx && !x.ticket) continue;
+        (void)hipSetDevice(d);
+        (void)hipFree(x.slabs); (void)hipFree(x.ctx); (void)hipFree(x.done); (void)hipFree(x.items); (void)hipFree(x.ticket); (void)hipFree(x.model);
+        x = InterScratch();
+      }
+    });
+  }
+  return s[current_device() & 63];
 }
 }  // namespace kvz
 namespace kvz {
@@ -977,10 +990,25 @@ __global__ void __launch_bounds__(64) dev_md5_kernel(const u8 *frames, const int
   for (int k = 0; k < 16; k++) out[i * 16 + k] = (u8)(st[k >> 2] >> (8 * (k & 3)));
 }
 
+// timing events per calling thread and device (an event belongs to the device it was created on)
 struct DevTimer { hipEvent_t e0 = nullptr, e1 = nullptr; };
-static DevTimer &dev_timer() { static thread_local DevTimer t; return t; }
-static DevTimer &inter_timer() { static thread_local DevTimer t; return t; }
-static float &inter_kernel_ms() { static thread_local float ms = 0; return ms; }  // the last inter CTU pass's kernel, HIP events on its stream
+static DevTimer &thread_timer(int which)
+{
+  static thread_local DevTimer t[2][64];
+  static thread_local bool registered = false;
+  if (!registered) {
+    registered = true;
+    DevTimer *all = &t[0][0];
+    thread_state().cleanups.push_back([all]() {
+      for (int i = 0; i < 128; i++) if (all[i].e0) { (void)hipSetDevice(i & 63); (void)hipEventDestroy(all[i].e0); (void)hipEventDestroy(all[i].e1); all[i] = DevTimer(); }
+    });
+  }
+  return t[which][current_device() & 63];
+}
+static DevTimer &dev_timer() { return thread_timer(0); }
+static DevTimer &inter_timer() { return thread_timer(1); }
+static float &inter_kernel_ms() { static thread_local float ms = 0; return ms; }
+static int &inter_share() { static thread_local int parts = 1; return parts; }  // kvz_hip_dev_inter_set_share  // the last inter CTU pass's kernel, HIP events on its stream
 
 }  // namespace kvz
 
@@ -1161,9 +1189,21 @@ struct LoopScratch {
 inline LoopScratch &loop_scratch()
 {
   static thread_local LoopScratch s[64];
-  int device = 0;
-  KVZ_HIP_CHECK(hipGetDevice(&device));
-  return s[device & 63];
+  static thread_local bool registered = false;
+  if (!registered) {
+    registered = true;
+    LoopScratch *all = s;
+    thread_state().cleanups.push_back([all]() {
+      for (int d = 0; d < 64; d++) {
+        LoopScratch &x = all[d];
+        if (!x.ver && !x.stats && !x.fbits) continue;
+        (void)hipSetDevice(d);
+        (void)hipFree(x.ver); (void)hipFree(x.dbk); (void)hipFree(x.stats); (void)hipFree(x.cand); (void)hipFree(x.recs); (void)hipFree(x.merge); (void)hipFree(x.fbits);
+        x = LoopScratch();
+      }
+    });
+  }
+  return s[current_device() & 63];
 }
 }  // namespace kvz
 int kvz_hip_dev_loop_filters_inter(const uint8_t *src, uint8_t *rec, int width, int height, int n_pictures, const kvz_hip_cu_dbk *info, int qp, int slice_is_b, int deblock,
@@ -1279,6 +1319,10 @@ int kvz_hip_dev_inter_ctu_pass_tiles(const uint8_t *src, const uint8_t *ref, con
                                      int height, int n_pictures, const kvz_hip_inter_params *p, const int32_t *tile_xy, int n_references)
 {
   if (n_pictures <= 0) return 0;
+  if (!p || p->struct_size != sizeof(kvz_hip_inter_params)) {
+    fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: kvz_hip_inter_params.struct_size %u is not this library's %zu (zero the struct, set struct_size = sizeof, build against the library's headers)\n", p ? p->struct_size : 0u, sizeof(kvz_hip_inter_params));
+    return -1;
+  }
   if (!p || width <= 0 || height <= 0 || (width & 7) || (height & 7) || width > 64 * 255 || height > 64 * 255 || n_pictures > 65535) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: bad geometry\n"); return -1; }
   if (p->qp < 0 || p->qp > 51) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: picture QP %d outside 0..51\n", p->qp); return -1; }
   if (p->fme_level < 0 || p->fme_level > 4 || p->pu_depth_inter_max < 1 || p->pu_depth_inter_max > 3 || p->poc < 1 || p->fast_residual_cost < 0 || p->fast_residual_cost > 51) { fprintf(stderr, "kvz_hip_dev_inter_ctu_pass: unsupported parameters\n"); return -1; }
@@ -1302,8 +1346,12 @@ int kvz_hip_dev_inter_ctu_pass_tiles(const uint8_t *src, const uint8_t *ref, con
   // resident workgroups (= wavefronts) per CU: what the kernel's registers and LDS allow -- a persistent grid, one workgroup per slot
   int fit = 0;
   KVZ_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, kernel, KVZ_ICTU_THREADS, 0));
-  const int per_cu = env ? atoi(env) : (fit > 0 ? fit : 8);
-  int n_wg = n_cu * (per_cu > 0 ? per_cu : 8);
+  // what THIS kernel build fits is the ceiling: a share (kvz_hip_dev_inter_set_share, per calling thread) divides it, the developer's environment value is clamped to it
+  if (fit <= 0) fit = 8;
+  int per_cu = fit / kvz::inter_share();
+  if (env && atoi(env) > 0) per_cu = atoi(env) < fit ? atoi(env) : fit;
+  if (per_cu < 1) per_cu = 1;
+  int n_wg = n_cu * per_cu;
   if (getenv("KVZ_HIP_INTER_VERBOSE")) fprintf(stderr, "kvz_hip inter pass: %s build, %d workgroups per CU x %d CUs\n", cabac_build ? "cabac" : "fast", per_cu, n_cu);
   if ((long)n_wg > total) n_wg = (int)total;
   if (n_wg > sc.n_slabs) {
@@ -1376,8 +1424,10 @@ int kvz_hip_dev_inter_ctu_pass_tiles(const uint8_t *src, const uint8_t *ref, con
 }
 
 float kvz_hip_dev_inter_kernel_ms(void) { return kvz::inter_kernel_ms(); }
+void kvz_hip_dev_inter_set_share(int parts) { kvz::inter_share() = parts > 1 ? parts : 1; }
 int kvz_hip_dev_inter_slots_per_cu(void)
 {
+  kvz::runtime_init(-1);
   int fit = 0;
   KVZ_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&fit, (const void *)kvz::inter_ctu_ticket_kernel_fast, KVZ_ICTU_THREADS, 0));
   return fit > 0 ? fit : 8;
@@ -1454,6 +1504,7 @@ void kvz_hip_batch_deblock(kvz_hip_batch *b, int qp, int beta_offset_div2, int t
 
 void kvz_hip_batch_loop_filters(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int deblock, int beta_offset_div2, int tc_offset_div2, int sao)
 {
+  if (!kvz::cost_model_known(model, "kvz_hip_batch_loop_filters")) { b->failed = 1; return; }  // no return value: the batch reports it (kvz_hip_batch_sync -> -1)
   kvz::batch_enter(b);
   const kvz::CtuFrames &F = b->F;
   const int n = b->n_frames;
@@ -1683,9 +1734,16 @@ long kvz_hip_batch_entropy_code_tiles(kvz_hip_batch *b, const kvz_hip_intra_cost
 long kvz_hip_batch_entropy_code_then(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, const uint8_t *not_last, uint8_t *out, size_t capacity,
                                      uint32_t *substream_bytes, kvz_hip_batch *next, const kvz_hip_intra_cost_model *next_model)
 {
+  if (!b || !kvz::cost_model_known(model, "kvz_hip_batch_entropy_code")) return -1;
+  if (next && !kvz::cost_model_known(next_model, "kvz_hip_batch_entropy_code_then (next_model)")) return -3;  // nothing has been queued anywhere
   kvz::batch_enter(b);
   const kvz::CtuFrames &F = b->F;
   const int ctus = F.wc * F.hc;
+  // `next`'s pass is queued exactly once on every path below (the caller synchronises `next` whatever this call returns): by the coder at its quiet moment, or here
+  int launched = 0;
+  bool started = false;
+  auto start_next = [&] { if (next && !started) { started = true; launched = kvz_hip_intra_frames(next, next_model); kvz::batch_enter(b); } };
+  struct StartOnExit { decltype(start_next) &f; ~StartOnExit() { f(); } } start_on_exit{ start_next };
   if (sao && !b->d_sao_recs) { fprintf(stderr, "kvz_hip_batch_entropy_code: kvz_hip_batch_loop_filters(..., sao = 1) has not run on this batch\n"); return -1; }
   if (model->search_nxn && !b->d_part) { fprintf(stderr, "kvz_hip_batch_entropy_code: the batch has no NxN partition maps\n"); return -1; }
   KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
@@ -1702,10 +1760,10 @@ long kvz_hip_batch_entropy_code_then(kvz_hip_batch *b, const kvz_hip_intra_cost_
     memcpy(J.ctx_init, model->ctx_init, sizeof model->ctx_init < sizeof J.ctx_init ? sizeof model->ctx_init : sizeof J.ctx_init);
     return J;
   };
-  int launched = 0;
   const long total = kvz::entropy_code_pictures(b->stream, b->device, b->n_frames, F.wc, F.hc, model->no_wpp, not_last, job, out, capacity, substream_bytes,
-                                                next ? std::function<void()>([&] { launched = kvz_hip_intra_frames(next, next_model); }) : std::function<void()>());
-  return next && launched < 0 ? -1 : total;
+                                                next ? std::function<void()>(start_next) : std::function<void()>());
+  start_next();  // the coder failed before its last chunk: the pass starts now
+  return next && launched < 0 ? -2 : total;
 }
 
 // ... of B pictures: the CU records, levels and (with sao) the SAO decisions of the last kvz_hip_dev_loop_filters_inter as the inter CTU pass / the loop filters left them
@@ -1713,6 +1771,7 @@ long kvz_hip_dev_entropy_code_inter(const kvz_hip_cu_info *cu, const kvz_hip_cu_
                                     const kvz_hip_inter_params *params, uint8_t *out, size_t capacity, uint32_t *substream_bytes)
 {
   if (n_pictures <= 0) return 0;
+  if (params && params->struct_size != sizeof(kvz_hip_inter_params)) { fprintf(stderr, "kvz_hip_dev_entropy_code_inter: kvz_hip_inter_params.struct_size %u is not this library's %zu\n", params->struct_size, sizeof(kvz_hip_inter_params)); return -1; }
   if (!cu || !ref_cu || !coeff || !params || width <= 0 || height <= 0 || (width & 7) || (height & 7) || params->qp < 0 || params->qp > 51 || params->poc < 1) {
     fprintf(stderr, "kvz_hip_dev_entropy_code_inter: bad argument\n");
     return -1;

@@ -30,16 +30,22 @@ template <class Op> __global__ void __launch_bounds__(64) wave_item_kernel(const
 struct HipBackend : ArenaBase {
   hipStream_t stream = nullptr;
   const Tables *tb = nullptr;
-  HipBackend()
+  HipBackend()  // on the calling thread's current device
   {
-    runtime_init(-1);
     cap = 1u << 20;
     KVZ_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     KVZ_HIP_CHECK(hipHostMalloc((void **)&h, cap, hipHostMallocDefault));
     KVZ_HIP_CHECK(hipMalloc((void **)&d, cap));
     tb = device_tables();
   }
-  // intentionally no destructor: thread_local teardown may run after the HIP runtime is gone
+  // released by the owning thread's ThreadState when a worker thread exits (be() below), never from a static destructor
+  void release()
+  {
+    if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+    if (h) (void)hipHostFree(h);
+    if (d) (void)hipFree(d);
+    stream = nullptr; h = d = nullptr;
+  }
   void begin() { reset(); runtime().calls.fetch_add(1, std::memory_order_relaxed); }
   void upload()
   {
@@ -65,9 +71,18 @@ struct HipBackend : ArenaBase {
   }
 };
 
+// The calling thread's backend on its current device (one per thread and device: a thread that drives batches on several devices has a stream on each)
 static HipBackend &be()
 {
-  static thread_local HipBackend *b = new HipBackend();
+  static thread_local HipBackend *per_device[64] = {};
+  runtime_init(-1);
+  const int dev = current_device() & 63;
+  HipBackend *&b = per_device[dev];
+  if (!b) {
+    b = new HipBackend();
+    HipBackend **slot = &b;
+    thread_state().cleanups.push_back([slot, dev]() { (void)hipSetDevice(dev); (*slot)->release(); delete *slot; *slot = nullptr; });
+  }
   return *b;
 }
 typedef Api<HipBackend> A;
@@ -161,6 +176,8 @@ int kvz_hip_init(int device)
   kvz::runtime_init(device);
   return 1;
 }
+int kvz_hip_set_thread_device(int device) { return kvz::thread_set_device(device); }
+int kvz_hip_thread_device(void) { kvz::runtime_init(-1); return kvz::current_device(); }
 const char *kvz_hip_version(void) { return "kvz_hip 0.1 (gfx950)"; }
 unsigned long long kvz_hip_call_count(void) { return kvz::runtime().calls.load(); }
 }

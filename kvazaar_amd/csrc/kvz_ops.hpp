@@ -45,6 +45,10 @@ KVZ_DEV u8 clip_pixel(int v) { return (u8)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 // ------------------------------------------------------------------------------------------------
 // Constant tables, uploaded once (kvz_tables.hpp builds them on the host).
 // ------------------------------------------------------------------------------------------------
+// Layout the entries of Tables::mref_tab address (kvz_ctu.hpp CtuShared): a row of the extended main references is kMrefStride bytes with ref_main[0] at kMrefOrg,
+// the top / left reference arrays of a plane are kMrefRefRow bytes apart, the filtered set lies kMrefFiltered bytes behind the unfiltered one.
+constexpr unsigned kMrefStride = 36, kMrefOrg = 16, kMrefRefRow = 68, kMrefFiltered = 408;
+
 struct Tables {
   i16 dct[4][32 * 32];   // [log2n-2] row-major n*n (dct-generic.c:46-120)
   i16 dst4[16];          // dct-generic.c:38-44

@@ -126,7 +126,7 @@ inline void build_tables(Tables *t)
     int n = 0;
     for (int d = 0; d < 15; d++) for (int x = 0; x <= d; x++) if (x < 8 && d - x < 8) t->diag8[n++] = (u8)((d - x) * 8 + x);
   }
-  for (int l2 = 3; l2 <= 4; l2++) {  // Tables::mref_tab (kvz_ctu.hpp build_mref: strides KVZ_MREF_STRIDE 36, origin KVZ_MREF_ORG 16, references 68 bytes apart)
+  for (int l2 = 3; l2 <= 4; l2++) {  // Tables::mref_tab (kvz_ctu.hpp build_mref; the layout constants kMref* below are asserted against the kernel's there)
     static const int inv_tab[9] = { 0, 4096, 1638, 910, 630, 482, 390, 315, 256 };
     const int w = 1 << l2, nq = 2 * w + 2, thres = l2 == 3 ? 7 : 1;
     for (int i = 0; i < 15 * nq; i++) {
@@ -135,7 +135,7 @@ inline void build_tables(Tables *t)
       int idx = q >= 0 ? q : (128 + (-q) * inv_tab[ad]) >> 8;
       if (idx > 2 * w) idx = 2 * w;
       const int main_side = vertical ? 0 : 1, side = q >= 0 ? main_side : 1 - main_side;  // 0 top, 1 left
-      const unsigned src = (filt ? 408u : 0u) + 68u * side + idx, dst = 36u * (i / nq) + 16u + i % nq - w;
+      const unsigned src = (filt ? kMrefFiltered : 0u) + kMrefRefRow * side + idx, dst = kMrefStride * (i / nq) + kMrefOrg + i % nq - w;
       t->mref_tab[l2 - 3][i] = src | dst << 16;
     }
     for (int i = 15 * nq; i < 512; i++) t->mref_tab[l2 - 3][i] = t->mref_tab[l2 - 3][15 * nq - 1];  // the lanes past the end repeat the last entry: no bounds test in the kernel

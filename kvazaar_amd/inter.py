@@ -12,8 +12,14 @@ assert CU_DTYPE.itemsize == 22
 
 
 class InterParams(C.Structure):  # kvz_hip_inter_params
-    _fields_ = [(n, C.c_int32) for n in ("qp", "poc", "mv_constraint", "sao", "deblock", "fme_level", "pu_depth_inter_max", "no_wpp", "fast_residual_cost",
+    _fields_ = [("struct_size", C.c_uint32)] + [(n, C.c_int32) for n in ("qp", "poc", "mv_constraint", "sao", "deblock", "fme_level", "pu_depth_inter_max", "no_wpp", "fast_residual_cost",
                                                 "ref_width", "ref_height", "tile_x", "tile_y", "no_tmvp")]  # the last four: tiles (include/kvz_hip_dev.h), zero = the picture is the frame
+
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        if "struct_size" not in kw:
+            self.struct_size = C.sizeof(InterParams)  # the version of the struct this binding was written against (include/kvz_hip_dev.h)
 
 
 def veryfast_params(qp, poc, mv_constraint=True):
@@ -271,9 +277,10 @@ class TiledInterSequences:
         self.lib.kvz_hip_dev_inter_kernel_ms.restype = C.c_float
         prm = self.group_params(base)
 
-        def group_pass(g, members):
+        def group_pass(g, members, parts=1):
             tw, th = g
             m = len(members) * self.n
+            self.lib.kvz_hip_dev_inter_set_share(parts)  # per calling thread: this pass's share of the workgroup slots (the pool's threads stay alive)
             rc = self.lib.kvz_hip_dev_inter_ctu_pass_tiles(self.src[g].data_ptr(), self.ref.data_ptr(), self.ref_cu.data_ptr(), self.rec[g].data_ptr(), self.cu[g].data_ptr(), None, tw, th,
                                                            m, C.addressof(prm), self.xy[g].data_ptr(), self.n)
             if rc != 0:
@@ -288,20 +295,12 @@ class TiledInterSequences:
         groups = list(self.groups.items())
         if len(groups) > 1:
             # kvazaar's uniform grid gives this rank tiles of two sizes: their passes are two persistent launches, and the first one launched fills the device while
-            # each holds fewer serial tile chains than the device has workgroup slots.  So: side by side, each on its share of the slots (KVZ_HIP_INTER_WG_PER_CU), from
+            # each holds fewer serial tile chains than the device has workgroup slots.  So: side by side, each on its share of the slots (kvz_hip_dev_inter_set_share), from
             # two host threads -- a thread has its own stream and scratch in the library, and the blocking calls release the GIL.
             if getattr(self, "_pool", None) is None:
                 from concurrent.futures import ThreadPoolExecutor
                 self._pool = ThreadPoolExecutor(max_workers=len(groups))
-            saved = os.environ.get("KVZ_HIP_INTER_WG_PER_CU")
-            os.environ["KVZ_HIP_INTER_WG_PER_CU"] = str(max(1, int(saved or self.slots_per_cu()) // len(groups)))
-            try:
-                self.pass_ms = max(f.result() for f in [self._pool.submit(group_pass, g, mem) for g, mem in groups])
-            finally:
-                if saved is None:
-                    os.environ.pop("KVZ_HIP_INTER_WG_PER_CU", None)
-                else:
-                    os.environ["KVZ_HIP_INTER_WG_PER_CU"] = saved
+            self.pass_ms = max(f.result() for f in [self._pool.submit(group_pass, g, mem, len(groups)) for g, mem in groups])
         else:
             self.pass_ms = sum(group_pass(g, mem) for g, mem in groups)
         self.exchange()

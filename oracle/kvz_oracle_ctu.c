@@ -964,6 +964,7 @@ void kvz_oracle_intra_cost_model(int qp, const float entropy_fbits[128], uint64_
   static const uint8_t init_split[3] = { 139, 141, 157 }, init_part = 184, init_intra = 184, init_chroma = 63;
   static const uint8_t init_cbf_luma[2] = { 111, 141 }, init_cbf_chroma[2] = { 94, 138 };
   memset(m, 0, sizeof *m);
+  m->struct_size = (uint32_t)sizeof *m;
   m->qp = qp;
   m->lambda = 0.57 * pow(2.0, (qp - 12) / 3.0);
   m->lambda_sqrt = sqrt(m->lambda);

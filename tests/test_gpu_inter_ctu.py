@@ -16,9 +16,7 @@ import flatapi
 import inter_common as ic
 
 
-class InterParams(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("qp", "poc", "mv_constraint", "sao", "deblock", "fme_level", "pu_depth_inter_max", "no_wpp", "fast_residual_cost",
-                                                "ref_width", "ref_height", "tile_x", "tile_y", "no_tmvp")]  # the last four: tiles (include/kvz_hip_dev.h), zero = the picture is the frame
+from kvazaar_amd.inter import InterParams  # noqa: E402  (kvz_hip_inter_params; sets struct_size)
 
 
 FAST_COST_CASES = ["pan", "ultrafast", "vertical-pan-owf", "static-qp17", "no-loop-filters", "survey-416x240"]  # every picture QP below 28: kvz_fast_coeff_cost
