@@ -196,8 +196,8 @@ kvz_hip_batch *kvz_hip_batch_create_on(int device, int width, int height, int n_
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_mode, ncu));
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_cost, nctu * sizeof(double)));
   KVZ_HIP_CHECK(hipMemsetAsync(b->d_rec, 0, F.frame_px * n_frames, b->stream));  // on the batch's stream: a non-blocking stream does not order against the null stream
-  KVZ_HIP_CHECK(hipMalloc((void **)&b->d_prof, (2 * kvz::KVZ_P_COUNT + 8) * sizeof(unsigned long long)));  // + 8: the sections of rdoq_block_wave
-  KVZ_HIP_CHECK(hipMemsetAsync(b->d_prof, 0, (2 * kvz::KVZ_P_COUNT + 8) * sizeof(unsigned long long), b->stream));
+  KVZ_HIP_CHECK(hipMalloc((void **)&b->d_prof, KVZ_PROF_WORDS * sizeof(unsigned long long)));  // + 8: the sections of rdoq_block_wave
+  KVZ_HIP_CHECK(hipMemsetAsync(b->d_prof, 0, KVZ_PROF_WORDS * sizeof(unsigned long long), b->stream));
   F.prof = b->d_prof;
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_entropy, 128 * sizeof(float) + sizeof(((kvz_hip_intra_cost_model *)0)->ctx_init)));
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_border, nctu * KVZ_BORDER_BYTES));
@@ -425,9 +425,9 @@ int kvz_hip_batch_profile(kvz_hip_batch *b, unsigned long long *out, int n)
 {
   kvz::batch_enter(b);
   KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
-  if (n > 2 * kvz::KVZ_P_COUNT + 8) n = 2 * kvz::KVZ_P_COUNT + 8;  // cycles per category, marks per category, the eight sections of rdoq_block_wave
+  if (n > KVZ_PROF_WORDS) n = KVZ_PROF_WORDS;  // cycles per category, marks per category, rdoq_block_wave's sections and sizes, the same two tables inside eval_pu (kvz_ctu.hpp KVZ_PROF_PU_AT)
   KVZ_HIP_CHECK(hipMemcpy(out, b->d_prof, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  KVZ_HIP_CHECK(hipMemsetAsync(b->d_prof, 0, (2 * kvz::KVZ_P_COUNT + 8) * sizeof(unsigned long long), b->stream));
+  KVZ_HIP_CHECK(hipMemsetAsync(b->d_prof, 0, KVZ_PROF_WORDS * sizeof(unsigned long long), b->stream));
   KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
   return kvz::KVZ_P_COUNT;
 }

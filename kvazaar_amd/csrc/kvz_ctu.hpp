@@ -139,6 +139,8 @@ namespace kvz {
 
 // Optional in-kernel timeline (build with -DKVZ_CTU_PROFILE): lane 0 of every workgroup adds the shader-clock cycles
 // spent since the previous mark to a per-category counter in HBM.  Categories are the KVZ_P_* constants.
+#define KVZ_PROF_PU_AT (2 * KVZ_P_COUNT + 16)  /* F.prof: [0, 2 COUNT) stages, then 16 words of rdoq_block_wave (8 sections, 4 + 4 cycles / calls by block size), then the stages inside eval_pu */
+#define KVZ_PROF_WORDS (4 * KVZ_P_COUNT + 16)
 enum { KVZ_P_INIT = 0, KVZ_P_REFS, KVZ_P_PRED35, KVZ_P_SATD, KVZ_P_SELECT, KVZ_P_RPRED, KVZ_P_FDCT, KVZ_P_QUANT, KVZ_P_IDCT, KVZ_P_RECON,
        KVZ_P_COST, KVZ_P_COPY, KVZ_P_FINISH, KVZ_P_MISC, KVZ_P_COEFFBITS, KVZ_P_RDOQ, KVZ_P_COUNT };
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
@@ -227,7 +229,8 @@ template <bool CABAC> struct CtuSharedT {
   u8 dec[6144];              // decided pixels, Y 64x64 | U 32x32 | V 32x32.  The depth-0 candidate (64x64 merge) reuses it:
                              // by then the split result has been written to the frame (run()).
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
-  unsigned long long prof_acc[32];  // [category] cycles, [KVZ_P_COUNT + category] marks
+  unsigned long long prof_acc[64];  // [category] cycles, [KVZ_P_COUNT + category] marks; [32 + ...] the same inside the 4x4 PUs of the NxN attempt (eval_pu)
+  int prof_pu;
 #endif
   CtuCu cu[4][64];
   u8 ref[3][2][68];          // [plane][0 top / 1 left][2w+1], w <= 32
@@ -349,8 +352,9 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   {
     if (threadIdx.x == 0) {
       const unsigned long long t = __builtin_amdgcn_s_memtime();
-      s->prof_acc[cat] += t - t_last;  // LDS: a global atomic per mark would dominate what is being measured
-      s->prof_acc[KVZ_P_COUNT + cat] += 1;
+      const int at = s->prof_pu ? 32 : 0;
+      s->prof_acc[at + cat] += t - t_last;  // LDS: a global atomic per mark would dominate what is being measured
+      s->prof_acc[at + KVZ_P_COUNT + cat] += 1;
       t_last = __builtin_amdgcn_s_memtime();
     }
   }
@@ -2474,6 +2478,9 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   // search_cu at depth 4 (search.c:646-1063 with depth > MAX_DEPTH: cu depth stays 3, search.c:691): PU j of the 8x8 CU at (rl->a3x, rl->a3y)
   KVZ_DEV void eval_pu(int j)
   {
+#if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
+    struct InPu { CtuShared *s; __device__ InPu(CtuShared *s_) : s(s_) { if (threadIdx.x == 0) s->prof_pu = 1; } __device__ ~InPu() { if (threadIdx.x == 0) s->prof_pu = 0; } } in_pu(s);
+#endif
     lane_rot = (lane_rot + 64) & (KVZ_CTU_THREADS - 1);
     const int xl = rl->a3x + 4 * (j & 1), yl = rl->a3y + 4 * (j >> 1), x = cx + xl, y = cy + yl;
     // references of the 4x4 luma block from level 4's view; with the first PU the CU's 4x4 chroma blocks (transform.c:306-312)
@@ -3063,7 +3070,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   KVZ_DEV void run()
   {
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
-    if (threadIdx.x == 0) for (int i = 0; i < 2 * KVZ_P_COUNT; i++) s->prof_acc[i] = 0;
+    if (threadIdx.x == 0) { for (int i = 0; i < 64; i++) s->prof_acc[i] = 0; s->prof_pu = 0; }
     t_last = __builtin_amdgcn_s_memtime();
 #endif
     init();
@@ -3114,7 +3121,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     finish_info();
     KVZ_PROF(KVZ_P_FINISH);
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
-    if (threadIdx.x == 0) for (int i = 0; i < 2 * KVZ_P_COUNT; i++) atomicAdd(&F.prof[i], s->prof_acc[i]);
+    if (threadIdx.x == 0) for (int i = 0; i < 2 * KVZ_P_COUNT; i++) { atomicAdd(&F.prof[i], s->prof_acc[i]); atomicAdd(&F.prof[KVZ_PROF_PU_AT + i], s->prof_acc[32 + i]); }
 #endif
   }
 };

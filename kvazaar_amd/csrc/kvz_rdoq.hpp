@@ -241,7 +241,8 @@ struct RdoqWaveArgs {
 // Device: every lane of the wavefront calls it, converged, with wavefront-uniform arguments; lane = its index in the wavefront.  Host: one call (lane 0).
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
 #define KVZ_RQ_PROF(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); rq_t[i] += t_ - rq_last; rq_last = __builtin_amdgcn_s_memtime(); } while (0)
-#define KVZ_RQ_PROF_END() do { if (lane == 0 && c.type == 0 && c.prof) for (int i_ = 0; i_ < 8; i_++) atomicAdd(&c.prof[i_], rq_t[i_]); } while (0)
+#define KVZ_RQ_PROF_END() do { if (lane == 0 && c.type == 0 && c.prof) { unsigned long long all_ = 0; for (int i_ = 0; i_ < 8; i_++) { atomicAdd(&c.prof[i_], rq_t[i_]); all_ += rq_t[i_]; } \
+    atomicAdd(&c.prof[8 + c.log2w - 2], all_); atomicAdd(&c.prof[12 + c.log2w - 2], 1ull); } } while (0)
 #else
 #define KVZ_RQ_PROF(i)
 #define KVZ_RQ_PROF_END()

@@ -41,22 +41,35 @@ def main():
     for i in range(n):
         b.upload(i, frames[i % len(frames)])
     b.run(model)
-    buf = (C.c_ulonglong * 40)()
+    NW = 4 * len(NAMES) + 16
+    buf = (C.c_ulonglong * NW)()
     n_cat = len(NAMES)
     lib.kvz_hip_batch_profile.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int]
-    lib.kvz_hip_batch_profile(b.handle, buf, 40)
+    lib.kvz_hip_batch_profile(b.handle, buf, NW)
     b.run(model)
-    lib.kvz_hip_batch_profile(b.handle, buf, 40)
+    lib.kvz_hip_batch_profile(b.handle, buf, NW)
     tot = sum(buf[:len(NAMES)])
+    tot_all = tot + sum(buf[2 * len(NAMES) + 16:3 * len(NAMES) + 16])
     nctu = n * 510
-    print(f"kernel_ms {b.kernel_ms():.2f}  cycles/CTU {tot / nctu:.0f}")
+    print(f"kernel_ms {b.kernel_ms():.2f}  cycles/CTU {tot_all / nctu:.0f} (outside the 4x4 PUs {tot / nctu:.0f})")
     for i, nm in enumerate(NAMES):
-        print(f"{nm:11s} {buf[i] / nctu:10.0f} cyc/CTU  {100.0 * buf[i] / tot:5.1f}%  {buf[len(NAMES) + i] / nctu:7.1f} marks/CTU")
+        print(f"{nm:11s} {buf[i] / nctu:10.0f} cyc/CTU  {100.0 * buf[i] / tot_all:5.1f}%  {buf[len(NAMES) + i] / nctu:7.1f} marks/CTU")
     rq = [buf[2 * len(NAMES) + i] for i in range(8)]
     if sum(rq):
         print("rdoq_block_wave, luma blocks (cycles of the wavefront's own clock per CTU):")
         for i, nm in enumerate(RDOQ_SECTIONS):
             print(f"  {nm:28s} {rq[i] / nctu:10.0f}  {100.0 * rq[i] / sum(rq):5.1f}%")
+        base = 2 * len(NAMES) + 8
+        for k in range(4):
+            calls = buf[base + 4 + k]
+            if calls:
+                print(f"  luma {4 << k:2d}x{4 << k:<2d} blocks: {calls / nctu:7.1f} per CTU, {buf[base + k] / calls:9.0f} cycles each, {buf[base + k] / nctu:10.0f} per CTU")
+    pu = 2 * len(NAMES) + 16
+    if sum(buf[pu:pu + len(NAMES)]):
+        print("inside the 4x4 PUs of the NxN attempt (eval_pu; included in the table above? no: listed separately, the table above is the rest):")
+        for i, nm in enumerate(NAMES):
+            if buf[pu + i]:
+                print(f"  {nm:11s} {buf[pu + i] / nctu:10.0f} cyc/CTU  {100.0 * buf[pu + i] / (tot + sum(buf[pu:pu + len(NAMES)])):5.1f}%  {buf[pu + len(NAMES) + i] / nctu:7.1f} marks/CTU")
 
 
 if __name__ == "__main__":
