@@ -295,11 +295,10 @@ template <class B> struct Api {
     i16 *co = be.template out<i16>(n);
     u8 *rec = be.template out<u8>(n);
     i16 *resid = be.template scratch<i16>(n), *coeff = be.template scratch<i16>(n), *tmp = be.template scratch<i16>(n);
-    double *cost3 = be.template scratch<double>((size_t)3 * n);
     be.upload();
     be.run(ResidualOp{ ref, pred, width, width, resid }, n);
     transform_dev(be, idx, p->bitdepth, resid, tmp, coeff, 1);
-    be.run_wave(RdoqOp{ be.tables(), cx, lambda, p->qp, coeff, co, l2, color == 0 ? 0 : 2, scan_order, tr_depth, cost3 }, 1);  // writes every level of the block
+    be.run_wave(RdoqOp{ be.tables(), cx, lambda, p->qp, coeff, co, l2, color == 0 ? 0 : 2, scan_order, tr_depth }, 1);  // writes every level of the block
     be.run(AnyNonzeroOp{ co, acc + 1 }, n);
     be.run(DequantOp{ qi, co, nullptr, coeff, n }, n);
     transform_dev(be, KVZ_HIP_IDCT_4 + idx, p->bitdepth, coeff, tmp, resid, 1);
@@ -402,11 +401,10 @@ template <class B> struct Api {
     memcpy(be.host_rw(d), dest, (size_t)n * count * sizeof(i16));
     be.mark_download_from(d);
     be.dl_end = be.cur;
-    double *tmp = be.template scratch<double>((size_t)3 * n * count);
     be.upload();
     int log2w = 2;
     while ((1 << log2w) < width) log2w++;
-    be.run_wave(RdoqOp{ be.tables(), cx, lambda, qp, c, d, log2w, type, scan_mode, tr_depth, tmp }, count);
+    be.run_wave(RdoqOp{ be.tables(), cx, lambda, qp, c, d, log2w, type, scan_mode, tr_depth }, count);
     be.download();
     memcpy(dest, be.host(d), (size_t)n * count * sizeof(i16));
   }

@@ -2067,7 +2067,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
           i16 *cout = (lv == 3 || lv == 0) ? levels_lds(lv, c) : coeff_dst(lv, c, xl, yl);
           RdoqWaveArgs ra;
           ra.ptab = (KVZ_LDS_PTR(const i32))rl->ptab; ra.coef = (KVZ_LDS_PTR(const i16))tbuf(t, 0, c); ra.dest = (KVZ_LDS_PTR(i16))cout;
-          ra.diag8 = (KVZ_LDS_PTR(const u8))rl->diag8; ra.cost3 = rdoq_scratch(c); ra.lambda = m->lambda; ra.qp = m->qp; ra.log2w = l2; ra.type = c ? 2 : 0;
+          ra.diag8 = (KVZ_LDS_PTR(const u8))rl->diag8; ra.lambda = m->lambda; ra.qp = m->qp; ra.log2w = l2; ra.type = c ? 2 : 0;
           ra.scan_mode = scan_order(mode, depth);
           // tr_depth = cu->tr_depth - cu->depth: 1 for the 32x32 units of the 64x64 attempt (level 0), 0 otherwise -- plus one for an NxN CU
           // (quant-generic.c:237-238): 2 for the blocks of its PUs (level 4)

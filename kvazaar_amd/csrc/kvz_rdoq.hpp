@@ -80,24 +80,28 @@ KVZ_DEV int rdoq_sig_ctx_inc(int pattern, int scan_idx, int pos_x, int pos_y, in
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------------
-// The block by a whole WAVEFRONT (the CTU pass, kvz_ctu.hpp recon_tus; RdoqOp at the end of this file).  kvz_rdoq is a chain of decisions, but most of what it computes per coefficient does not
-// depend on the chain at all.  What is serial, and is kept in the reference's order:
-//   * the (c1, c2, go_rice, c1_idx, c2_idx) state inside a 4x4 group, which only positions that can quantise to a non-zero level move or read;
-//   * the double-precision running sums (base_cost, block_uncoded_cost, the group sums): floating-point addition is not associative, so they are added one term at a
-//     time in scan order -- an addition per position, not a few hundred dependent instructions per position as a one-lane walk would have;
-//   * the zero-the-group and best-last-position decisions, which compare those sums.
-// What is per-position runs on the lanes, 64 scan positions (four 4x4 groups) at a time: scan position -> block position, level_double, max_abs_level,
-// err^2 * temp, the distortion of the two candidate levels; and per group, once its pattern_sig_ctx is known, the significance context and lambda times the price
-// of both its bins, and the cost of coding a zero (coded_cost0 + the zero flag) -- for a position whose max_abs_level is 0, the common case, that IS its result.
+// The block by a whole WAVEFRONT (the CTU pass, kvz_ctu.hpp recon_tus; RdoqOp at the end of this file), one 4x4 coefficient group at a time.
 //
-// The chain itself is executed by ALL lanes in lock step on wavefront-uniform values: a per-position operand is fetched from the lane that holds it with
-// v_readlane (a scalar register, no LDS round trip on the chain), results that a later pass needs go back into lane-held storage with v_writelane -- the level of
-// a position into its own lane, the coded cost of every non-zero level into a 64-entry FIFO (one entry per lane; the last-position pass meets the non-zero
-// levels in the order the first pass produced them), the cost of each coded-group flag into the lane of its group.  Nothing per-position is kept in memory: the
-// last pass recomputes what is a pure function of the coefficient and the group's pattern (cost_coeff0, cost_sig) and takes the rest from the FIFO.  Levels are
-// written where the caller wants them (LDS in the CTU pass) by the lanes, sixteen at a time.
+// kvz_rdoq is a chain of decisions -- the level chosen for a coefficient moves the (c1, go_rice, number of levels) state that prices the next one -- but the chain
+// carries very little.  Inside a group the rate of a candidate level depends on the state only through thirteen classes (kvz_get_ic_rate, rdo.c:345-392):
+//     0..2   no level above 1 yet, c1 = 1, 2, 3                     (greater-1 context c1, the greater-2 flag still to come, escape codes with rice parameter 0)
+//     3..7   a level above 1 has been seen (c1 = 0), go_rice 0..4
+//     8..12  eight levels coded already (no context-coded flags left), go_rice 0..4
+// and nothing else a position's decision reads depends on the positions before it.  So per group:
+//   1. all 64 lanes -- lane = (position k = lane & 15, replica j = lane >> 4), every per-position quantity computed on all four replicas -- take the position's
+//      coefficient, its distortions and its significance prices (the group's neighbour pattern is known by now);
+//   2. replica j decides the position's level for the classes j and j + 4 (the classes 8..12 only when a group reaches eight levels): two bits per class;
+//   3. the chain itself is a scalar walk over the positions that may code a level: look the decision of (position, class) up with v_readlane, move the state -- some
+//      twenty scalar instructions a position, where the one-lane transcription of rdo.c:760-840 had several hundred dependent vector instructions;
+//   4. every lane evaluates its position once more for the class the walk met it in, now with its costs (kvz_get_coded_level, rdo.c:413-459, exactly);
+//   5. the five ordered double-precision sums of the group (block_uncoded_cost, base_cost, rd_sig_cost, rd_coded_level_and_dist, rd_uncoded_dist) are sixteen
+//      additions each, in scan order as the reference adds them (floating-point addition is not associative): the terms of sum r lie along row r of a register, the
+//      sum on lane 15 of the row, the register rotated by DPP row_ror:1 between additions -- all four rows at once, the fifth sum in a second register;
+//   6. the zero-the-group decision (rdo.c:842-900) on wavefront-uniform values.
+// Kept per group for the last pass (rdo.c:903-957: the best last position, which usually stops at the first level above 1): the classes its positions were decided
+// in (4 bits each) and its context set, on the lane of the group's index; that pass recomputes the costs it meets from them.
 //
-// The host simulation runs the same source: lane-held storage is an array there (WaveArr), a "lane loop" a plain loop, the chain runs once.
+// The host simulation runs the same source: lane-held storage is an array there (WaveArr), a "lane loop" a plain loop, uniform code runs once.
 #ifdef KVZ_HOSTSIM
 #define KVZ_LDS_PTR(T) T *
 template <class T> struct WaveArr { T v[64]; };
@@ -135,37 +139,37 @@ KVZ_DEV double wave_readlane(double v, int l)
 #else
 #define KVZ_RDOQ_WAVE_FN __device__ __attribute__((noinline))
 #endif
-// The ordered sums of the first pass -- block_uncoded_cost, base_cost, the group's rd_sig_cost -- take one term per scan position, in scan order; for a position
-// that can only be zero (the common case) the three terms are known before the chain starts.  On the device the three sums sit on lane 15 of the first three
-// 16-lane rows of one register; the group's sixteen terms of each sum are laid out along the same row, so a zero position is ONE double-precision addition for
-// all three sums and a rotation of the term register within its rows (DPP row_ror:1) -- against three additions and six v_readlane.  A position that may quantise to a
-// level adds its terms as a constant on the three lanes.  The host build keeps three scalars and adds in the same order.
+
+// Step 5 above.  Device: accA holds block_uncoded_cost / base_cost / rd_sig_cost / rd_coded_level_and_dist on lanes 15 / 31 / 47 / 63, accB rd_uncoded_dist on lane 15.
+// Host: five scalars, the same additions in the same order.  A position outside the block's chain (beyond the last position) contributes +0.0 terms, which
+// leave a sum as it is.
 #ifdef KVZ_HOSTSIM
-struct RdoqSums3 {
-  double uncoded = 0, base = 0, sig = 0;
-  const WaveArr<double> *c0v = nullptr, *ccv0 = nullptr, *sig0 = nullptr;
-  const WaveArr<i32> *max_abs = nullptr;
-  int group = 0;
-  void begin_group(int gi, const WaveArr<double> &a, const WaveArr<double> &b, const WaveArr<double> &c, const WaveArr<i32> &m, int) { c0v = &a; ccv0 = &b; sig0 = &c; max_abs = &m; sig = 0; group = gi; }
-  bool may_code(int L) const { return max_abs->v[L] > 0; }
-  int next_coded(int k) const { while (k >= 0 && !(max_abs->v[group * 16 + k] > 0)) k--; return k; }  // the highest position <= k of the group that may code a level, -1: none
-  void zero_step(int L) { if (max_abs->v[L] == 0) { uncoded += c0v->v[L]; base += ccv0->v[L]; sig += sig0->v[L]; } }
-  void add(double c0, double ccv, double csv) { uncoded += c0; base += ccv; sig += csv; }
-  void rotate() {}
+struct RdoqSums5 {
+  double uncoded = 0, base = 0, sig = 0, coded = 0, udist = 0;
+  void group(const WaveArr<double> &c0v, const WaveArr<double> &ccv, const WaveArr<double> &csv, const WaveArr<i32> &level, int)
+  {
+    sig = 0; coded = 0; udist = 0;
+    for (int k = 15; k >= 0; k--) {
+      const bool nz = level.v[k] > 0;
+      uncoded += c0v.v[k]; base += ccv.v[k]; sig += csv.v[k];
+      coded += nz ? ccv.v[k] - csv.v[k] : 0.0;
+      udist += nz ? c0v.v[k] : 0.0;
+    }
+  }
+  double get_uncoded() const { return uncoded; }
   double get_base() const { return base; }
   double get_sig() const { return sig; }
-  double get_uncoded() const { return uncoded; }
-  void set_base(double v) { base = v; }
+  double get_coded() const { return coded; }
+  double get_udist() const { return udist; }
+  void set_base(double v, int) { base = v; }
 };
 // ... and the one of the last pass: base_cost minus the zero flag's cost of every zero position on the way down
 struct RdoqSums1 {
   double base = 0;
   const WaveArr<double> *sigc = nullptr;
   const WaveArr<i32> *lvl = nullptr;
-  void begin_group(int gi, const WaveArr<double> &a, const WaveArr<i32> &l, int) { sigc = &a; lvl = &l; group = gi; }
-  bool is_level(int L) const { return lvl->v[L] > 0; }
-  int group = 0;
-  int next_level(int k) const { while (k >= 0 && !(lvl->v[group * 16 + k] > 0)) k--; return k; }
+  void begin_group(const WaveArr<double> &a, const WaveArr<i32> &l, int) { sigc = &a; lvl = &l; }
+  int next_level(int k) const { while (k >= 0 && !(lvl->v[k] > 0)) k--; return k; }
   void zero_step(int L) { if (lvl->v[L] == 0) base -= sigc->v[L]; }
   void add(double v) { base += v; }
   void rotate() {}
@@ -178,45 +182,39 @@ KVZ_DEV double dpp_row_ror1(double v)
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x121, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
-struct RdoqSums3 {
-  double acc = 0, term = 0;  // per lane: lanes 15 / 31 / 47 hold the sums; `term`: the next term of each sum on those lanes
-  unsigned coded = 0;        // positions of the group that may quantise to a level (wavefront-uniform)
-  int lane;
-  // row r of `term` := row gi of the r-th array, zero where the position is not a plain zero (beyond the last position, or handled by the caller)
-  KVZ_DEV void begin_group(int gi, const WaveArr<double> &c0v, const WaveArr<double> &ccv0, const WaveArr<double> &sig0, const WaveArr<i32> &max_abs, int lane_)
+struct RdoqSums5 {
+  double accA = 0, accB = 0;
+  KVZ_DEV void group(const WaveArr<double> &c0v, const WaveArr<double> &ccv, const WaveArr<double> &csv, const WaveArr<i32> &level, int lane)
   {
-    lane = lane_;
-    const int src = (lane & 15) + 16 * gi;
-    const double r0 = __shfl(c0v.v, src), r1 = __shfl(ccv0.v, src), r2 = __shfl(sig0.v, src);
-    const int ma = __shfl(max_abs.v, src);
-    coded = (unsigned)(__ballot(max_abs.v > 0) >> (16 * gi)) & 0xffffu;
-    term = (ma != 0 || lane >= 48) ? 0.0 : (lane < 16 ? r0 : (lane < 32 ? r1 : r2));
-    acc = lane == 47 ? 0.0 : acc;
+    const int row = lane >> 4;
+    const bool nz = level.v > 0;
+    double tA = row == 0 ? c0v.v : (row == 1 ? ccv.v : (row == 2 ? csv.v : (nz ? ccv.v - csv.v : 0.0)));
+    double tB = (row == 0 && nz) ? c0v.v : 0.0;
+    accA = row >= 2 ? 0.0 : accA;  // the group's own sums start over
+    accB = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      accA += tA; accB += tB;
+      tA = dpp_row_ror1(tA); tB = dpp_row_ror1(tB);
+    }
   }
-  KVZ_DEV bool may_code(int L) const { return (coded >> (L & 15)) & 1; }
-  KVZ_DEV int next_coded(int k) const { const unsigned below = coded & ((2u << k) - 1u); return below ? 31 - __builtin_clz(below) : -1; }
-  KVZ_DEV void zero_step(int) { acc += term; }
-  KVZ_DEV void add(double c0, double ccv, double csv) { acc += lane == 15 ? c0 : (lane == 31 ? ccv : (lane == 47 ? csv : 0.0)); }
-  KVZ_DEV void rotate() { term = dpp_row_ror1(term); }
-  KVZ_DEV double get_base() const { return wave_readlane(acc, 31); }
-  KVZ_DEV double get_sig() const { return wave_readlane(acc, 47); }
-  KVZ_DEV double get_uncoded() const { return wave_readlane(acc, 15); }
-  KVZ_DEV void set_base(double v) { acc = lane == 31 ? v : acc; }
+  KVZ_DEV double get_uncoded() const { return wave_readlane(accA, 15); }
+  KVZ_DEV double get_base() const { return wave_readlane(accA, 31); }
+  KVZ_DEV double get_sig() const { return wave_readlane(accA, 47); }
+  KVZ_DEV double get_coded() const { return wave_readlane(accA, 63); }
+  KVZ_DEV double get_udist() const { return wave_readlane(accB, 15); }
+  KVZ_DEV void set_base(double v, int lane) { accA = lane == 31 ? v : accA; }
 };
 struct RdoqSums1 {
   double acc = 0, term = 0;  // lane 15 holds base_cost
   unsigned levels = 0;
   int lane;
-  KVZ_DEV void begin_group(int gi, const WaveArr<double> &sigc, const WaveArr<i32> &lvl, int lane_)
+  KVZ_DEV void begin_group(const WaveArr<double> &sigc, const WaveArr<i32> &lvl, int lane_)
   {
     lane = lane_;
-    const int src = (lane & 15) + 16 * gi;
-    const double r0 = __shfl(sigc.v, src);
-    const int lv = __shfl(lvl.v, src);
-    levels = (unsigned)(__ballot(lvl.v > 0) >> (16 * gi)) & 0xffffu;
-    term = (lv != 0 || lane >= 16) ? 0.0 : -r0;
+    levels = (unsigned)__ballot(lvl.v > 0) & 0xffffu;
+    term = (lvl.v != 0 || lane >= 16) ? 0.0 : -sigc.v;
   }
-  KVZ_DEV bool is_level(int L) const { return (levels >> (L & 15)) & 1; }
   KVZ_DEV int next_level(int k) const { const unsigned below = levels & ((2u << k) - 1u); return below ? 31 - __builtin_clz(below) : -1; }
   KVZ_DEV void zero_step(int) { acc += term; }
   KVZ_DEV void add(double v) { acc += lane == 15 ? v : 0.0; }
@@ -226,18 +224,56 @@ struct RdoqSums1 {
 #endif
 
 // What the wavefront routine is given, by value: prices of both bins of every context at the caller's states ([2 * idx + bin], Q15) and the block's coefficients / levels,
-// all three in LDS; cost3: scratch in memory, only touched when a block holds more than 64 non-zero levels (the FIFO's overflow), w * w doubles.
+// all three in LDS.
 struct RdoqWaveArgs {
   KVZ_LDS_PTR(const i32) ptab;
   KVZ_LDS_PTR(const i16) coef;
   KVZ_LDS_PTR(i16) dest;
   KVZ_LDS_PTR(const u8) diag8;
-  double *cost3;
   double lambda;
   int qp, log2w, type /* 0 luma, 2 chroma */, scan_mode, tr_depth;
   unsigned long long *prof = nullptr;  // -DKVZ_CTU_PROFILE builds: eight cycle counters of this routine's sections (luma blocks), else unused
   KVZ_DEV i32 price(int idx, int bin) const { return ptab[2 * idx + bin]; }
 };
+
+// rdo.c:358-371: the bypass bins of the escape code of `symbol` with rice parameter g (the loop there finds the length of the exp-Golomb suffix: floor(log2(symbol - 3 * 2^g + 2^g)))
+KVZ_DEV i32 rdoq_escape_bins(i32 symbol, int g)
+{
+  if (symbol < (3 << g)) return (symbol >> g) + 1 + g;
+  const int len = 31 - __builtin_clz((unsigned)(symbol - (3 << g) + (1 << g)));
+  return 3 + len + 1 - g + len;
+}
+
+// The prices of a group's level contexts (its context set is fixed while it is walked): greater-1 flag of c1 = 0..3, greater-2 flag, both bins.  Uniform.
+struct RdoqLevelPrices { i32 one0[4], one1[4], abs0, abs1; };
+
+// kvz_get_coded_level (rdo.c:413-459) of one position in chain-state class r (see the head of this section): the level, and with COSTS its coded cost and the cost of its
+// significance flag.  ma > 0.
+template <bool COSTS>
+KVZ_DEV i32 rdoq_decide(int r, i32 ma, bool last, double c0, double dhi, double dlo, double s0, double s1, double lambda, const RdoqLevelPrices &P, double *ccv_out, double *csv_out)
+{
+  const int cls = r < 3 ? 0 : (r < 8 ? 1 : 2), g = cls == 0 ? 0 : (cls == 1 ? r - 3 : r - 8), c1 = cls == 0 ? r + 1 : 0, base_level = 3 - cls;
+  const i32 p_one0 = c1 == 0 ? P.one0[0] : (c1 == 1 ? P.one0[1] : (c1 == 2 ? P.one0[2] : P.one0[3]));
+  const i32 p_one1 = c1 == 0 ? P.one1[0] : (c1 == 1 ? P.one1[1] : (c1 == 2 ? P.one1[2] : P.one1[3]));
+  const i32 at_base = cls == 0 ? p_one1 + P.abs1 : (cls == 1 ? p_one1 : 0);  // rdo.c:373-380: what the context-coded flags of a level >= base_level cost
+  const double sadd = last ? 0.0 : s1;
+  double ccv = 1.7e+308, csv = 0;  // MAX_DOUBLE (global.h)
+  i32 level = 0;
+  if (!last && ma < 3) { csv = s0; ccv = c0 + s0; }
+  const i32 min_abs = ma > 1 ? ma - 1 : 1;
+  for (i32 a = ma; a >= min_abs; a--) {
+    i32 rate = 1 << 15;
+    if (a >= base_level) rate += rdoq_escape_bins(a - base_level, g) * (1 << 15) + at_base;
+    else if (a == 1) rate += p_one0;
+    else rate += p_one1 + P.abs0;  // a == 2 below base_level 3
+    double cur = (a == ma ? dhi : dlo) + lambda * rate;
+    cur += sadd;
+    if (cur < ccv) { level = a; ccv = cur; csv = sadd; }
+  }
+  if (COSTS) { *ccv_out = ccv; *csv_out = csv; }
+  return level;
+}
+
 // Device: every lane of the wavefront calls it, converged, with wavefront-uniform arguments; lane = its index in the wavefront.  Host: one call (lane 0).
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
 #define KVZ_RQ_PROF(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); rq_t[i] += t_ - rq_last; rq_last = __builtin_amdgcn_s_memtime(); } while (0)
@@ -255,7 +291,6 @@ KVZ_RDOQ_WAVE_FN void rdoq_block_wave(const RdoqWaveArgs c, int lane)
   const int qp = c.qp, log2w = c.log2w, type = c.type, scan_mode = c.scan_mode, tr_depth = c.tr_depth;
   KVZ_LDS_PTR(const i16) coef = c.coef;
   KVZ_LDS_PTR(i16) dest = c.dest;
-  double *cost3 = c.cost3;
   (void)lane;
   const int width = 1 << log2w, n = width * width;
   const int transform_shift = 15 - 8 - log2w;
@@ -305,244 +340,202 @@ KVZ_RDOQ_WAVE_FN void rdoq_block_wave(const RdoqWaveArgs c, int lane)
   }
   const int cg0 = KVZ_HIP_CX_SIG_CG + type;
   const int sig_base = type ? KVZ_HIP_CX_SIG_CHROMA : KVZ_HIP_CX_SIG_LUMA;
-  // prices the chain needs, on lanes (a memory access on the chain costs more than the arithmetic of a position): lambda times both bins of the two
-  // coded-group-flag contexts on lanes 0..3 for the whole block; per group, both bins of its four greater-1 contexts (lanes 0..7) and of its greater-2 context (8, 9)
+  const int one0 = type == 0 ? KVZ_HIP_CX_ONE_LUMA : KVZ_HIP_CX_ONE_CHROMA, abs0 = type == 0 ? KVZ_HIP_CX_ABS_LUMA : KVZ_HIP_CX_ABS_CHROMA;
+  // prices held on lanes for the whole block (a memory access on the chain costs more than the arithmetic of a position): lambda times both bins of the two
+  // coded-group-flag contexts on lanes 0..3; both bins of the greater-1 contexts of every context set on lanes 0..31 ([set][c1][bin]), of the greater-2 contexts on
+  // lanes 32..39 ([set][bin]).  Chroma has two context sets (context.c: 8 + 2 contexts).
   WaveArr<double> cg_price;
   WaveArr<i32> lvl_price;
-  KVZ_WAVE_LANES(l, 64) { KVZ_WA_SET(cg_price, l, c.lambda * c.price(cg0 + ((l >> 1) & 1), l & 1)); KVZ_WA_SET(lvl_price, l, 0); }
-  const int one0 = type == 0 ? KVZ_HIP_CX_ONE_LUMA : KVZ_HIP_CX_ONE_CHROMA, abs0 = type == 0 ? KVZ_HIP_CX_ABS_LUMA : KVZ_HIP_CX_ABS_CHROMA;
-  // lane-held storage that lives across the passes
-  WaveArr<double> fifo, cg_cost_of;   // coded cost of the non-zero levels in the order they are decided; cost of the coded-group flag of group g on lane g
-  WaveArr<i32> level_of;              // the level decided for the position a lane holds (valid during its super-group)
-  KVZ_WAVE_LANES(l, 64) { KVZ_WA_SET(fifo, l, 0.0); KVZ_WA_SET(cg_cost_of, l, 0.0); KVZ_WA_SET(level_of, l, 0); }
-  int fifo_n = 0;
+  KVZ_WAVE_LANES(l, 64) {
+    KVZ_WA_SET(cg_price, l, c.lambda * c.price(cg0 + ((l >> 1) & 1), l & 1));
+    const int set_mask = type ? 1 : 3;
+    i32 v = 0;
+    if (l < 32) v = c.price(one0 + 4 * ((l >> 3) & set_mask) + ((l >> 1) & 3), l & 1);
+    else if (l < 40) v = c.price(abs0 + (((l - 32) >> 1) & set_mask), l & 1);
+    KVZ_WA_SET(lvl_price, l, v);
+  }
+  // per group, on the lane of its scan index, for the last pass: the classes its positions were decided in, its context set, the cost of its coded-group flag
+  WaveArr<i32> rst_lo_of, rst_hi_of, ctx_set_of;
+  WaveArr<double> cg_cost_of;
+  KVZ_WAVE_LANES(l, 64) { KVZ_WA_SET(rst_lo_of, l, 0); KVZ_WA_SET(rst_hi_of, l, 0); KVZ_WA_SET(ctx_set_of, l, 0); KVZ_WA_SET(cg_cost_of, l, 0.0); }
   unsigned long long sig_groups = 0;  // sig_coeffgroup_flag, bit = raster index of the group
   unsigned long long pat_lo = 0, pat_hi = 0;  // pattern_sig_ctx of every group in scan order, two bits each (the last pass prices the zero flags again)
-  // the chain's state (uniform)
-  int ctx_set = (last_scanpos > 0 && type == 0) ? 2 : 0, c1 = 1, c2 = 0, go_rice = 0;
-  u32 c1_idx = 0, c2_idx = 0;
-  RdoqSums3 sums;
+  // the chain's state between groups (uniform)
+  int ctx_set = (last_scanpos > 0 && type == 0) ? 2 : 0, c1 = 1;
+  RdoqSums5 sums;
+  // One group's per-position values, computed by every lane for the position lane & 15 of group cgs (all four replicas alike): `level`, `ccv` (cost_coeff) and `csv`
+  // (cost_sig) only for a position that cannot code a level; the others get theirs from rdoq_decide.
+  struct Pos { i32 ma, blkpos; double c0, dhi, dlo, s0, s1; bool last; };
+  auto position = [&](int cgs, int l, int pattern_sig_ctx) {
+    Pos p;
+    const int scanpos = cgs * 16 + (l & 15);
+    const bool in_chain = scanpos <= last_scanpos;
+    const u32 blkpos = in_chain ? sc.pos(scanpos) : 0;
+    const i32 ld = imin(iabs((i32)coef[blkpos]) * q, 0x7fffffff - round);
+    p.blkpos = (i32)blkpos;
+    p.ma = in_chain ? (ld + round) >> q_bits : -1;  // -1: beyond the last position, not part of the block's chain
+    p.last = scanpos == last_scanpos;
+    const double err = (double)ld;
+    const double e_hi = (double)(ld - (p.ma * (1 << q_bits))), e_lo = (double)(ld - ((p.ma - 1) * (1 << q_bits)));
+    p.c0 = in_chain ? err * err * temp : 0.0;
+    p.dhi = e_hi * e_hi * temp; p.dlo = e_lo * e_lo * temp;
+    const u32 pos_y = blkpos >> log2w, pos_x = blkpos - (pos_y << log2w);
+    const int ctx_sig = p.last ? 0 : rdoq_sig_ctx_inc(pattern_sig_ctx, scan_mode, (int)pos_x, (int)pos_y, log2w, type);
+    p.s0 = in_chain ? c.lambda * c.price(sig_base + ctx_sig, 0) : 0.0;
+    p.s1 = c.lambda * c.price(sig_base + ctx_sig, 1);
+    return p;
+  };
+  auto level_prices = [&](int set) {
+    RdoqLevelPrices P;
+    for (int j = 0; j < 4; j++) { P.one0[j] = KVZ_WA_GET(lvl_price, 8 * set + 2 * j); P.one1[j] = KVZ_WA_GET(lvl_price, 8 * set + 2 * j + 1); }
+    P.abs0 = KVZ_WA_GET(lvl_price, 32 + 2 * set); P.abs1 = KVZ_WA_GET(lvl_price, 33 + 2 * set);
+    return P;
+  };
   KVZ_RQ_PROF(0);
-  for (int sg = cg_last_scanpos >> 2; sg >= 0; sg--) {
-    // ---- 64 positions, one per lane: everything that does not depend on a decision
-    WaveArr<double> c0v, dhi, dlo, sig0, sig1, ccv0, pre_ccv1, pre_ccv2, pre_ccv3;
-    WaveArr<i32> max_abs, blkpos_of, pre_lvl1, pre_lvl2, pre_lvl3;
+  for (int cgs = cg_last_scanpos; cgs >= 0; cgs--) {
+    const u32 cg_blkpos = sc.cg(cgs), cg_pos_y = cg_blkpos / num_blk_side, cg_pos_x = cg_blkpos - cg_pos_y * num_blk_side;
+    u32 right = 0, lower = 0;  // context.c:339-351 / 315-327
+    if ((int)cg_pos_x < num_blk_side - 1) right = (u32)(sig_groups >> (cg_pos_y * num_blk_side + cg_pos_x + 1)) & 1;
+    if ((int)cg_pos_y < num_blk_side - 1) lower = (u32)(sig_groups >> ((cg_pos_y + 1) * num_blk_side + cg_pos_x)) & 1;
+    const int pattern_sig_ctx = width == 4 ? -1 : (int)(right + (lower << 1));
+    if (cgs < 32) pat_lo |= (unsigned long long)(pattern_sig_ctx & 3) << (2 * cgs); else pat_hi |= (unsigned long long)(pattern_sig_ctx & 3) << (2 * (cgs - 32));
+    // ---- 1. the positions
+    WaveArr<double> c0v, dhi, dlo, s0v, s1v, ccv, csv;
+    WaveArr<i32> max_abs, blkpos_of, level_of, ch_a, ch_b;
+    unsigned coded = 0;  // positions of the group that may quantise to a level
     KVZ_WAVE_LANES(l, 64) {
-      const int scanpos = sg * 64 + l;
-      const bool in_block = scanpos < n;
-      const u32 blkpos = in_block ? sc.pos(scanpos) : 0;
-      const i32 ld = imin(iabs((i32)coef[blkpos]) * q, 0x7fffffff - round);
-      const i32 ma = (!in_block || scanpos > last_scanpos) ? -1 : (ld + round) >> q_bits;  // -1: beyond the last position, not part of the block's chain
-      const double err = (double)ld;
-      const double e_hi = (double)(ld - (ma * (1 << q_bits))), e_lo = (double)(ld - ((ma - 1) * (1 << q_bits)));
-      KVZ_WA_SET(blkpos_of, l, (i32)blkpos); KVZ_WA_SET(max_abs, l, ma);
-      KVZ_WA_SET(c0v, l, err * err * temp);
-      KVZ_WA_SET(dhi, l, e_hi * e_hi * temp); KVZ_WA_SET(dlo, l, e_lo * e_lo * temp);
-      KVZ_WA_SET(sig0, l, 0.0); KVZ_WA_SET(sig1, l, 0.0); KVZ_WA_SET(ccv0, l, 0.0);
-      KVZ_WA_SET(pre_ccv1, l, 0.0); KVZ_WA_SET(pre_ccv2, l, 0.0); KVZ_WA_SET(pre_ccv3, l, 0.0); KVZ_WA_SET(pre_lvl1, l, 0); KVZ_WA_SET(pre_lvl2, l, 0); KVZ_WA_SET(pre_lvl3, l, 0);
+      const Pos p = position(cgs, l, pattern_sig_ctx);
+      KVZ_WA_SET(max_abs, l, p.ma); KVZ_WA_SET(blkpos_of, l, p.blkpos);
+      KVZ_WA_SET(c0v, l, p.c0); KVZ_WA_SET(dhi, l, p.dhi); KVZ_WA_SET(dlo, l, p.dlo); KVZ_WA_SET(s0v, l, p.s0); KVZ_WA_SET(s1v, l, p.s1);
+      KVZ_WA_SET(level_of, l, 0); KVZ_WA_SET(ch_a, l, 0); KVZ_WA_SET(ch_b, l, 0);
+      KVZ_WA_SET(ccv, l, p.c0 + p.s0); KVZ_WA_SET(csv, l, p.s0);  // what a position that can only be zero costs (rdo.c:424-428); +0.0 twice outside the chain
+#ifdef KVZ_HOSTSIM
+      if (l < 16 && p.ma > 0) coded |= 1u << l;
+#endif
     }
+#ifndef KVZ_HOSTSIM
+    coded = (unsigned)__ballot(max_abs.v > 0) & 0xffffu;
+#endif
     KVZ_RQ_PROF(1);
-    for (int gi = 3; gi >= 0; gi--) {
-      const int cgs = sg * 4 + gi;
-      if (cgs > cg_last_scanpos) continue;
-      const u32 cg_blkpos = sc.cg(cgs), cg_pos_y = cg_blkpos / num_blk_side, cg_pos_x = cg_blkpos - cg_pos_y * num_blk_side;
-      u32 right = 0, lower = 0;  // context.c:339-351 / 315-327
-      if ((int)cg_pos_x < num_blk_side - 1) right = (u32)(sig_groups >> (cg_pos_y * num_blk_side + cg_pos_x + 1)) & 1;
-      if ((int)cg_pos_y < num_blk_side - 1) lower = (u32)(sig_groups >> ((cg_pos_y + 1) * num_blk_side + cg_pos_x)) & 1;
-      const int pattern_sig_ctx = width == 4 ? -1 : (int)(right + (lower << 1));
-      if (cgs < 32) pat_lo |= (unsigned long long)(pattern_sig_ctx & 3) << (2 * cgs); else pat_hi |= (unsigned long long)(pattern_sig_ctx & 3) << (2 * (cgs - 32));
-      // the group's sixteen lanes: the significance flag's two prices, and the cost of a zero
+    unsigned long long rstates = 0;
+    if (coded) {
+      const RdoqLevelPrices P = level_prices(ctx_set);
+      // ---- 2. the decisions of the classes 0..7: replica j takes j and j + 4
       KVZ_WAVE_LANES(l, 64) {
-        if ((l >> 4) == gi && KVZ_WA_OWN(max_abs, l) >= 0) {
-          const int scanpos = sg * 64 + l;
-          const u32 blkpos = (u32)KVZ_WA_OWN(blkpos_of, l), pos_y = blkpos >> log2w, pos_x = blkpos - (pos_y << log2w);
-          const int ctx_sig = scanpos == last_scanpos ? 0 : rdoq_sig_ctx_inc(pattern_sig_ctx, scan_mode, (int)pos_x, (int)pos_y, log2w, type);
-          const double s0 = c.lambda * c.price(sig_base + ctx_sig, 0), s1 = c.lambda * c.price(sig_base + ctx_sig, 1);
-          KVZ_WA_SET(sig0, l, s0); KVZ_WA_SET(sig1, l, s1); KVZ_WA_SET(ccv0, l, KVZ_WA_OWN(c0v, l) + s0);
-        }
-      }
-      // the group's level prices (its context set is fixed by now: it only changes where a group ends)
-      KVZ_WAVE_LANES(l, 64) {
-        if (l < 10) KVZ_WA_SET(lvl_price, l, l < 8 ? c.price(one0 + 4 * ctx_set + (l >> 1), l & 1) : c.price(abs0 + ctx_set, l & 1));
-      }
-      // The decision of every position that may quantise to a level, for the three states the chain is in until the group sees its first level above 1
-      // (c1 = 1, 2, 3 with c2 = 0, go_rice = 0, fewer than eight levels so far -- by far the most common ones): rdo.c:413-459 kvz_get_coded_level with
-      // rdo.c:345-392 kvz_get_ic_rate, all sixteen positions at once.  The chain then only picks the result of its state; any other state takes the general path.
-      {
-        const i32 p_abs0 = KVZ_WA_GET(lvl_price, 8), p_abs1 = KVZ_WA_GET(lvl_price, 9);
-        i32 p_one0[3], p_one1[3];
-        for (int j = 0; j < 3; j++) { p_one0[j] = KVZ_WA_GET(lvl_price, 2 * (j + 1)); p_one1[j] = KVZ_WA_GET(lvl_price, 2 * (j + 1) + 1); }
-        KVZ_WAVE_LANES(l, 64) {
-          const i32 ma = KVZ_WA_OWN(max_abs, l);
-          if ((l >> 4) == gi && ma > 0) {
-            const bool last = sg * 64 + l == last_scanpos;
-            const double cur_cost_sig = last ? 0.0 : KVZ_WA_OWN(sig1, l);
-            const i32 min_abs = ma > 1 ? ma - 1 : 1;
-            for (int j = 0; j < 3; j++) {
-              double ccv = (!last && ma < 3) ? KVZ_WA_OWN(ccv0, l) : 1.7e+308;
-              i32 level = 0;
-              for (i32 a = ma; a >= min_abs; a--) {
-                i32 rate = 1 << 15;
-                if (a >= 3) {
-                  i32 symbol = a - 3, length;
-                  if (symbol < 3) rate += (symbol + 1) * (1 << 15);
-                  else {
-                    length = 0;
-                    symbol = symbol - 3;
-                    while (symbol >= (1 << length)) symbol -= (1 << (length++));
-                    rate += (3 + length + 1 + length) * (1 << 15);
-                  }
-                  rate += p_one1[j] + p_abs1;
-                } else if (a == 1) rate += p_one0[j];
-                else rate += p_one1[j] + p_abs0;
-                double cur = (a == ma ? KVZ_WA_OWN(dhi, l) : KVZ_WA_OWN(dlo, l)) + c.lambda * rate;
-                cur += cur_cost_sig;
-                if (cur < ccv) { level = a; ccv = cur; }
-              }
-              if (j == 0) { KVZ_WA_SET(pre_ccv1, l, ccv); KVZ_WA_SET(pre_lvl1, l, level); }
-              else if (j == 1) { KVZ_WA_SET(pre_ccv2, l, ccv); KVZ_WA_SET(pre_lvl2, l, level); }
-              else { KVZ_WA_SET(pre_ccv3, l, ccv); KVZ_WA_SET(pre_lvl3, l, level); }
-            }
+        const i32 ma = KVZ_WA_OWN(max_abs, l);
+        if (ma > 0) {
+          const bool last = cgs * 16 + (l & 15) == last_scanpos;
+          i32 w = 0;
+          for (int t = 0; t < 2; t++) {
+            const i32 lv = rdoq_decide<false>((l >> 4) + 4 * t, ma, last, KVZ_WA_OWN(c0v, l), KVZ_WA_OWN(dhi, l), KVZ_WA_OWN(dlo, l), KVZ_WA_OWN(s0v, l), KVZ_WA_OWN(s1v, l), c.lambda, P, nullptr, nullptr);
+            w |= (lv == 0 ? 0 : (lv == ma ? 1 : 2)) << (2 * t);
           }
+          KVZ_WA_SET(ch_a, l, w);
         }
       }
       KVZ_RQ_PROF(2);
-      // ---- the chain: rdo.c:760-840 for this group, then its coded-group decision (rdo.c:842-900)
-      double rd_coded_level_and_dist = 0, rd_uncoded_dist = 0, rd_sig_cost_0 = 0;
-      int rd_nnz_before_pos0 = 0, any_level = 0;
-      const int fifo_group_start = fifo_n;
-      sums.begin_group(gi, c0v, ccv0, sig0, max_abs, lane);
-      for (int k = 15; k >= 0;) {
-        // the run of positions that can only be zero (or lie beyond the last position: no term), down to the next one that may code a level: one addition each
-        const int next = sums.next_coded(k);
-        for (int z = k; z > next; z--) { sums.zero_step(gi * 16 + z); sums.rotate(); }
-        k = next;
-        if (k < 0) break;
-        const int L = gi * 16 + k, scanpos = cgs * 16 + k;
-        {
-          const i32 ma = KVZ_WA_GET(max_abs, L);
-          const double c0 = KVZ_WA_GET(c0v, L);
-          double ccv, csv = 0;
-          i32 level = 0;
-          if (c1 >= 1 && c1_idx < 8) {
-            // the common states: decided by the position's lane beforehand (above)
-            const bool last = scanpos == last_scanpos;
-            if (c1 == 1) { ccv = KVZ_WA_GET(pre_ccv1, L); level = KVZ_WA_GET(pre_lvl1, L); }
-            else if (c1 == 2) { ccv = KVZ_WA_GET(pre_ccv2, L); level = KVZ_WA_GET(pre_lvl2, L); }
-            else { ccv = KVZ_WA_GET(pre_ccv3, L); level = KVZ_WA_GET(pre_lvl3, L); }
-            csv = level ? (last ? 0.0 : KVZ_WA_GET(sig1, L)) : KVZ_WA_GET(sig0, L);
-          } else {
-            // rdo.c:413-459 kvz_get_coded_level on the precomputed pieces
-            const bool last = scanpos == last_scanpos;
-            double cur_cost_sig = 0;
-            if (!last && ma < 3) { csv = KVZ_WA_GET(sig0, L); ccv = KVZ_WA_GET(ccv0, L); }
-            else ccv = 1.7e+308;
-            if (!last) cur_cost_sig = KVZ_WA_GET(sig1, L);
-            const i32 min_abs = ma > 1 ? ma - 1 : 1;
-            for (i32 a = ma; a >= min_abs; a--) {
-              // rdo.c:345-392 kvz_get_ic_rate with the prices of this group's contexts taken from their lanes (abs_ctx = ctx_set + c2 is only ever priced with c2 == 0)
-              i32 rate = 1 << 15;
-              {
-                const i32 base_level = c1_idx < 8 ? (2 + (c2_idx < 1)) : 1;
-                if (a >= base_level) {
-                  i32 symbol = a - base_level, length;
-                  if (symbol < (3 << go_rice)) { length = symbol >> go_rice; rate += (length + 1 + go_rice) * (1 << 15); }
-                  else {
-                    length = go_rice;
-                    symbol = symbol - (3 << go_rice);
-                    while (symbol >= (1 << length)) symbol -= (1 << (length++));
-                    rate += (3 + length + 1 - go_rice + length) * (1 << 15);
-                  }
-                  if (c1_idx < 8) {
-                    rate += KVZ_WA_GET(lvl_price, 2 * c1 + 1);
-                    if (c2_idx < 1) rate += KVZ_WA_GET(lvl_price, 9);
-                  }
-                } else if (a == 1) rate += KVZ_WA_GET(lvl_price, 2 * c1);
-                else if (a == 2) { rate += KVZ_WA_GET(lvl_price, 2 * c1 + 1); rate += KVZ_WA_GET(lvl_price, 8); }
+      // ---- 3. the chain (rdo.c:760-840 for this group)
+      int c1_idx = 0, go_rice = 0;
+      bool have_b = false;
+      for (unsigned rem = coded; rem;) {
+        const int k = 31 - __builtin_clz(rem);
+        rem &= ~(1u << k);
+        const bool few = c1_idx < 8;
+        if (!few && !have_b) {
+          // the classes 8..12, now that the group has coded eight levels: replica j takes 8 + j, replica 0 also 12
+          have_b = true;
+          KVZ_WAVE_LANES(l, 64) {
+            const i32 ma = KVZ_WA_OWN(max_abs, l);
+            if (ma > 0) {
+              const bool last = cgs * 16 + (l & 15) == last_scanpos;
+              i32 w = 0;
+              for (int t = 0; t < 2; t++) {
+                const int r = 8 + (l >> 4) + 4 * t;
+                if (r > 12) break;
+                const i32 lv = rdoq_decide<false>(r, ma, last, KVZ_WA_OWN(c0v, l), KVZ_WA_OWN(dhi, l), KVZ_WA_OWN(dlo, l), KVZ_WA_OWN(s0v, l), KVZ_WA_OWN(s1v, l), c.lambda, P, nullptr, nullptr);
+                w |= (lv == 0 ? 0 : (lv == ma ? 1 : 2)) << (2 * t);
               }
-              double cur = (a == ma ? KVZ_WA_GET(dhi, L) : KVZ_WA_GET(dlo, L)) + c.lambda * rate;
-              cur += cur_cost_sig;
-              if (KVZ_UNI_INT(cur < ccv)) { level = a; ccv = cur; csv = cur_cost_sig; }
+              KVZ_WA_SET(ch_b, l, w);
             }
-          }
-          const i32 base_level = c1_idx < 8 ? (2 + (c2_idx < 1)) : 1;
-          if (level >= base_level && level > 3 * (1 << go_rice)) go_rice = imin(go_rice + 1, 4);
-          if (level >= 1) c1_idx++;
-          if (level > 1) { c1 = 0; c2 += (c2 < 2); c2_idx++; }
-          else if (c1 < 3 && c1 > 0 && level) c1++;
-          KVZ_WA_PUT(level_of, L, level);
-          sums.add(c0, ccv, csv);  // block_uncoded_cost += cost_coeff0; base_cost += cost_coeff; rd_sig_cost += cost_sig
-          if (k == 0) rd_sig_cost_0 = csv;
-          if (level) {
-            any_level = 1;
-            rd_coded_level_and_dist += ccv - csv;
-            rd_uncoded_dist += c0;
-            if (k != 0) rd_nnz_before_pos0++;
-            if (fifo_n < 64) KVZ_WA_PUT(fifo, fifo_n, ccv);
-            else {
-#ifdef KVZ_HOSTSIM
-              cost3[fifo_n - 64] = ccv;
-#else
-              if (lane == 0) cost3[fifo_n - 64] = ccv;
-#endif
-            }
-            fifo_n++;
           }
         }
-        sums.rotate();
-        k--;
-      }
-      if (!sums.may_code(gi * 16)) rd_sig_cost_0 = KVZ_WA_GET(sig0, gi * 16);  // the group's first position only coded a zero flag
-      if (cgs > 0) {  // rdo.c:822-833, at the group's first scan position
-        c2 = 0; go_rice = 0; c1_idx = 0; c2_idx = 0;
-        ctx_set = (cgs == 1 || type != 0) ? 0 : 2;
-        if (c1 == 0) ctx_set++;
-        c1 = 1;
+        const int r = few ? (c1 ? c1 - 1 : 3 + go_rice) : 8 + go_rice, rr = r & 7;
+        const i32 word = few ? KVZ_WA_GET(ch_a, k + 16 * (rr & 3)) : KVZ_WA_GET(ch_b, k + 16 * (rr & 3));
+        const int ch = (word >> (2 * (rr >> 2))) & 3;
+        const i32 ma = KVZ_WA_GET(max_abs, k);
+        const i32 level = ch == 0 ? 0 : (ch == 1 ? ma : ma - 1);
+        rstates |= (unsigned long long)r << (4 * k);
+        const i32 base_level = few ? (2 + (c1 != 0)) : 1;
+        if (level >= base_level && level > 3 * (1 << go_rice)) go_rice = imin(go_rice + 1, 4);
+        if (level >= 1) c1_idx++;
+        if (level > 1) c1 = 0;
+        else if (c1 < 3 && c1 > 0 && level) c1++;
       }
       KVZ_RQ_PROF(3);
-      double base_cost = sums.get_base(), rd_sig_cost = sums.get_sig();
-      if (any_level) sig_groups |= 1ull << cg_blkpos;
-      int zeroed = 0;
-      double cg_cost = 0;
-      if (cgs) {
-        const int ctx_sig = (int)(right || lower);
-        if (!any_level) {
-          cg_cost = KVZ_WA_GET(cg_price, 2 * ctx_sig);
-          base_cost += cg_cost - rd_sig_cost;
-        } else if (cgs < cg_last_scanpos) {
-          if (rd_nnz_before_pos0 == 0) { base_cost -= rd_sig_cost_0; rd_sig_cost -= rd_sig_cost_0; }
-          double cost_zero_cg = base_cost;
-          cg_cost = KVZ_WA_GET(cg_price, 2 * ctx_sig + 1);
-          base_cost += cg_cost;
-          cost_zero_cg += KVZ_WA_GET(cg_price, 2 * ctx_sig);
-          cost_zero_cg += rd_uncoded_dist;
-          cost_zero_cg -= rd_coded_level_and_dist;
-          cost_zero_cg -= rd_sig_cost;
-          if (KVZ_UNI_INT(cost_zero_cg < base_cost)) {
-            sig_groups &= ~(1ull << cg_blkpos);
-            base_cost = cost_zero_cg;
-            cg_cost = KVZ_WA_GET(cg_price, 2 * ctx_sig);
-            zeroed = 1;
-            fifo_n = fifo_group_start;  // rdo.c:888-897: its levels are gone; the last pass skips the group
-          }
-        }
-      } else sig_groups |= 1ull << cg_blkpos;
-      KVZ_WA_PUT(cg_cost_of, cgs, cg_cost);
-      sums.set_base(base_cost);
-      KVZ_RQ_PROF(4);
-      // ---- the group's levels, sixteen lanes
+      // ---- 4. every position once more, in the class the chain met it in, with its costs
       KVZ_WAVE_LANES(l, 64) {
-        if ((l >> 4) == gi) {
-          const i32 ma = KVZ_WA_OWN(max_abs, l);
-          if (ma >= 0) dest[KVZ_WA_OWN(blkpos_of, l)] = (i16)((zeroed || ma == 0) ? 0 : KVZ_WA_OWN(level_of, l));
+        const i32 ma = KVZ_WA_OWN(max_abs, l);
+        if (ma > 0) {
+          const bool last = cgs * 16 + (l & 15) == last_scanpos;
+          double cc, cs;
+          const i32 lv = rdoq_decide<true>((int)((rstates >> (4 * (l & 15))) & 15), ma, last, KVZ_WA_OWN(c0v, l), KVZ_WA_OWN(dhi, l), KVZ_WA_OWN(dlo, l), KVZ_WA_OWN(s0v, l), KVZ_WA_OWN(s1v, l), c.lambda, P, &cc, &cs);
+          KVZ_WA_SET(level_of, l, lv); KVZ_WA_SET(ccv, l, cc); KVZ_WA_SET(csv, l, cs);
         }
       }
-      KVZ_RQ_PROF(5);
     }
-  }
-#ifndef KVZ_HOSTSIM
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the levels just written (LDS in the CTU pass) are read back below by other lanes: one wavefront's LDS operations execute in order
+    KVZ_WA_PUT(rst_lo_of, cgs, (i32)(u32)rstates); KVZ_WA_PUT(rst_hi_of, cgs, (i32)(u32)(rstates >> 32)); KVZ_WA_PUT(ctx_set_of, cgs, ctx_set);
+    if (cgs > 0) {  // rdo.c:822-833, at the group's first scan position
+      ctx_set = (cgs == 1 || type != 0) ? 0 : 2;
+      if (c1 == 0) ctx_set++;
+      c1 = 1;
+    }
+    KVZ_RQ_PROF(4);
+    // ---- 5. the ordered sums
+    sums.group(c0v, ccv, csv, level_of, lane);
+    unsigned levels = 0;
+#ifdef KVZ_HOSTSIM
+    for (int k = 0; k < 16; k++) if (level_of.v[k] > 0) levels |= 1u << k;
+#else
+    levels = (unsigned)__ballot(level_of.v > 0) & 0xffffu;
 #endif
+    KVZ_RQ_PROF(5);
+    // ---- 6. the coded-group decision (rdo.c:842-900)
+    double base_cost = sums.get_base();
+    const bool any_level = levels != 0;
+    if (any_level) sig_groups |= 1ull << cg_blkpos;
+    int zeroed = 0;
+    double cg_cost = 0;
+    if (cgs) {
+      const int ctx_sig = (int)(right || lower);
+      double rd_sig_cost = sums.get_sig();
+      if (!any_level) {
+        cg_cost = KVZ_WA_GET(cg_price, 2 * ctx_sig);
+        base_cost += cg_cost - rd_sig_cost;
+      } else if (cgs < cg_last_scanpos) {
+        if ((levels & 0xfffeu) == 0) { const double rd_sig_cost_0 = KVZ_WA_GET(csv, 0); base_cost -= rd_sig_cost_0; rd_sig_cost -= rd_sig_cost_0; }  // rd_nnz_before_pos0 == 0
+        double cost_zero_cg = base_cost;
+        cg_cost = KVZ_WA_GET(cg_price, 2 * ctx_sig + 1);
+        base_cost += cg_cost;
+        cost_zero_cg += KVZ_WA_GET(cg_price, 2 * ctx_sig);
+        cost_zero_cg += sums.get_udist();
+        cost_zero_cg -= sums.get_coded();
+        cost_zero_cg -= rd_sig_cost;
+        if (KVZ_UNI_INT(cost_zero_cg < base_cost)) {
+          sig_groups &= ~(1ull << cg_blkpos);
+          base_cost = cost_zero_cg;
+          cg_cost = KVZ_WA_GET(cg_price, 2 * ctx_sig);
+          zeroed = 1;  // rdo.c:888-897: its levels are gone; the last pass skips the group
+        }
+      }
+    } else sig_groups |= 1ull << cg_blkpos;
+    KVZ_WA_PUT(cg_cost_of, cgs, cg_cost);
+    sums.set_base(base_cost, lane);
+    // ---- the group's levels, sixteen lanes
+    KVZ_WAVE_LANES(l, 16) {
+      if (KVZ_WA_OWN(max_abs, l) >= 0) dest[KVZ_WA_OWN(blkpos_of, l)] = (i16)(zeroed ? 0 : KVZ_WA_OWN(level_of, l));
+    }
+    KVZ_RQ_PROF(6);
+  }
   // ---- the last position (rdo.c:903-957), intra block: coded block flag of the transform unit
   double best_cost;
   int best_last_idx_p1 = 0;
@@ -558,67 +551,56 @@ KVZ_RDOQ_WAVE_FN void rdoq_block_wave(const RdoqWaveArgs c, int lane)
     walk.lane = lane; walk.acc = base_cost;
 #endif
   }
-  int fifo_r = 0, found_last = 0;
-  for (int sg = cg_last_scanpos >> 2; sg >= 0 && !found_last; sg--) {
-    // per position: the level; for a level its costs are recomputed (cost_coeff0, the flag's price) and lambda times the rate of ending the block there
-    // (rdo.c:465-478 get_rate_last); for a zero the price of its zero flag
-    WaveArr<double> c0v, sigc, lastc;
+  int found_last = 0;
+  for (int cgs = cg_last_scanpos; cgs >= 0 && !found_last; cgs--) {
+    walk.add(-KVZ_WA_GET(cg_cost_of, cgs));
+    if (!((sig_groups >> sc.cg(cgs)) & 1)) continue;
+    // the group's positions again: levels and costs from the classes the first pass decided them in, and lambda times the rate of ending the block at a level
+    // (rdo.c:465-478 get_rate_last)
+    const int pat2 = (int)(((cgs < 32 ? pat_lo >> (2 * cgs) : pat_hi >> (2 * (cgs - 32)))) & 3);
+    const unsigned long long rstates = (unsigned long long)(u32)KVZ_WA_GET(rst_lo_of, cgs) | (unsigned long long)(u32)KVZ_WA_GET(rst_hi_of, cgs) << 32;
+    const RdoqLevelPrices P = level_prices(KVZ_WA_GET(ctx_set_of, cgs));
+    WaveArr<double> c0v, ccv, sigc, lastc;
     WaveArr<i32> lvl;
     KVZ_WAVE_LANES(l, 64) {
-      const int scanpos = sg * 64 + l, cgs = scanpos >> 4;
-      const bool in_chain = scanpos <= last_scanpos;
-      const u32 blkpos = in_chain ? sc.pos(scanpos) : 0, pos_y = blkpos >> log2w, pos_x = blkpos - (pos_y << log2w);
+      const Pos p = position(cgs, l, width == 4 ? -1 : pat2);
+      const u32 pos_y = (u32)p.blkpos >> log2w, pos_x = (u32)p.blkpos - (pos_y << log2w);
       const u32 px = scan_mode == 2 ? pos_y : pos_x, py = scan_mode == 2 ? pos_x : pos_y;  // SCAN_VER swaps (rdo.c:934)
       const int gx = rdoq_group_idx((int)px), gy = rdoq_group_idx((int)py);
       const i32 lxb = KVZ_WA_AT(lx_bits, l, gx), lyb = KVZ_WA_AT(ly_bits, l, gy);  // every lane takes part in the exchange (converged here)
-      i32 level = -1;
-      double c0 = 0, sgc = 0, lc = 0;
-      if (in_chain) {
-        level = dest[blkpos];
-        const int pat2 = (int)(((cgs < 32 ? pat_lo >> (2 * cgs) : pat_hi >> (2 * (cgs - 32)))) & 3);
-        const int ctx_sig = scanpos == last_scanpos ? 0 : rdoq_sig_ctx_inc(width == 4 ? -1 : pat2, scan_mode, (int)pos_x, (int)pos_y, log2w, type);
-        sgc = scanpos == last_scanpos ? 0.0 : c.lambda * c.price(sig_base + ctx_sig, level != 0);  // cost_sig of the position: its flag as it was coded
-        if (level) {
-          const i32 ld = imin(iabs((i32)coef[blkpos]) * q, 0x7fffffff - round);
-          const double err = (double)ld;
-          c0 = err * err * temp;
-          double ui_cost = lxb + lyb;
-          if (gx > 3) ui_cost += (double)((1 << 15) * ((gx - 2) >> 1));
-          if (gy > 3) ui_cost += (double)((1 << 15) * ((gy - 2) >> 1));
-          lc = c.lambda * ui_cost;
-        }
+      i32 level = p.ma < 0 ? -1 : 0;
+      double cc = p.c0 + p.s0, cs = p.s0, lc = 0;
+      if (p.ma > 0) level = rdoq_decide<true>((int)((rstates >> (4 * (l & 15))) & 15), p.ma, p.last, p.c0, p.dhi, p.dlo, p.s0, p.s1, c.lambda, P, &cc, &cs);
+      if (level > 0) {
+        double ui_cost = lxb + lyb;
+        if (gx > 3) ui_cost += (double)((1 << 15) * ((gx - 2) >> 1));
+        if (gy > 3) ui_cost += (double)((1 << 15) * ((gy - 2) >> 1));
+        lc = c.lambda * ui_cost;
       }
-      KVZ_WA_SET(lvl, l, level); KVZ_WA_SET(c0v, l, c0); KVZ_WA_SET(sigc, l, sgc); KVZ_WA_SET(lastc, l, lc);
+      KVZ_WA_SET(lvl, l, level); KVZ_WA_SET(c0v, l, p.c0); KVZ_WA_SET(ccv, l, cc); KVZ_WA_SET(sigc, l, cs); KVZ_WA_SET(lastc, l, lc);
     }
     KVZ_RQ_PROF(6);
-    for (int gi = 3; gi >= 0 && !found_last; gi--) {
-      const int cgs = sg * 4 + gi;
-      if (cgs > cg_last_scanpos) continue;
-      walk.add(-KVZ_WA_GET(cg_cost_of, cgs));
-      if (!((sig_groups >> sc.cg(cgs)) & 1)) continue;
-      walk.begin_group(gi, sigc, lvl, lane);
-      for (int k = 15; k >= 0;) {
-        const int next = walk.next_level(k);  // zero positions down to the next level: base_cost -= cost_sig each
-        for (int z = k; z > next; z--) { walk.zero_step(gi * 16 + z); walk.rotate(); }
-        k = next;
-        if (k < 0) break;
-        const int L = gi * 16 + k;
-        const i32 level = KVZ_WA_GET(lvl, L);
-        const double csv = KVZ_WA_GET(sigc, L);
-        const double total = walk.get_base() + KVZ_WA_GET(lastc, L) - csv;
-        if (KVZ_UNI_INT(total < best_cost)) { best_last_idx_p1 = cgs * 16 + k + 1; best_cost = total; }
-        if (level > 1) { found_last = 1; break; }
-        double ccv;
-        if (fifo_r < 64) ccv = KVZ_WA_GET(fifo, fifo_r); else ccv = cost3[fifo_r - 64];
-        fifo_r++;
-        walk.add(-ccv);
-        walk.add(KVZ_WA_GET(c0v, L));
-        walk.rotate();
-        k--;
-      }
+    walk.begin_group(sigc, lvl, lane);
+    for (int k = 15; k >= 0;) {
+      const int next = walk.next_level(k);  // zero positions down to the next level: base_cost -= cost_sig each
+      for (int z = k; z > next; z--) { walk.zero_step(z); walk.rotate(); }
+      k = next;
+      if (k < 0) break;
+      const i32 level = KVZ_WA_GET(lvl, k);
+      const double cs = KVZ_WA_GET(sigc, k);
+      const double total = walk.get_base() + KVZ_WA_GET(lastc, k) - cs;
+      if (KVZ_UNI_INT(total < best_cost)) { best_last_idx_p1 = cgs * 16 + k + 1; best_cost = total; }
+      if (level > 1) { found_last = 1; break; }
+      walk.add(-KVZ_WA_GET(ccv, k));
+      walk.add(KVZ_WA_GET(c0v, k));
+      walk.rotate();
+      k--;
     }
     KVZ_RQ_PROF(7);
   }
+#ifndef KVZ_HOSTSIM
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the levels written above (LDS in the CTU pass) are read back below by other lanes: one wavefront's LDS operations execute in order
+#endif
   KVZ_WAVE_STRIDE(sp, last_scanpos + 1) {
     const u32 blkpos = sc.pos(sp);
     if (sp < best_last_idx_p1) { const i32 level = dest[blkpos]; dest[blkpos] = (i16)(coef[blkpos] < 0 ? -level : level); }
@@ -635,7 +617,7 @@ KVZ_RDOQ_WAVE_FN void rdoq_block_wave(const RdoqWaveArgs c, int lane)
 // kvz_hip_quantize_residual_rdoq run the same routine as the CTU pass): the prices of both bins of every context at the caller's states, the block's coefficients and its
 // levels staged in LDS around rdoq_block_wave.  Backends launch it with run_wave (64 lanes per item; the host simulation calls lane 0).
 struct RdoqOp {
-  const Tables *tb; const u8 *ctx; double lambda; int qp; const i16 *coef; i16 *dest; int log2w, type, scan_mode, tr_depth; double *tmp;
+  const Tables *tb; const u8 *ctx; double lambda; int qp; const i16 *coef; i16 *dest; int log2w, type, scan_mode, tr_depth;
   KVZ_DEV void wave(int item, int lane) const
   {
     const int n = 1 << (2 * log2w);
@@ -659,7 +641,7 @@ struct RdoqOp {
 #endif
     RdoqWaveArgs ra;
     ra.ptab = (KVZ_LDS_PTR(const i32))ptab; ra.coef = (KVZ_LDS_PTR(const i16))s_coef; ra.dest = (KVZ_LDS_PTR(i16))s_dest; ra.diag8 = (KVZ_LDS_PTR(const u8))s_diag8;
-    ra.cost3 = tmp + (long)item * 3 * n; ra.lambda = lambda; ra.qp = qp; ra.log2w = log2w; ra.type = type; ra.scan_mode = scan_mode; ra.tr_depth = tr_depth;
+    ra.lambda = lambda; ra.qp = qp; ra.log2w = log2w; ra.type = type; ra.scan_mode = scan_mode; ra.tr_depth = tr_depth;
     rdoq_block_wave(ra, lane);
 #ifndef KVZ_HOSTSIM
     __syncthreads();
