@@ -468,6 +468,7 @@ def main():
     ap.add_argument("--only", default="", choices=["", "inter", "medium", "intra4k", "entropy"], help="developer / profiling: run ONE auxiliary leg at a reduced size and print its "
                     "entry (tools/pmc_leg.sh collects the leg's counters this way); the headline is not measured")
     ap.add_argument("--entropy-pictures", type=int, default=384, help="developer: pictures of `--only entropy`")
+    ap.add_argument("--medium-frames", type=int, default=48, help="developer: pictures of `--only medium` (the default run's C3 leg takes 96)")
     ap.add_argument("--inter-sequences", type=int, default=0, help="developer: sequences per launch of the inter leg (default 384; 96 with --only inter)")
     ap.add_argument("--wpp", action="store_true", help="with --tiles: keep WPP on (kvazaar --tiles CxR --wpp); by default tiles imply --no-wpp as in kvazaar (cfg.c:925-978): "
                                                        "one coder per tile in raster order, i.e. one serial CTU chain per tile")
@@ -748,7 +749,7 @@ def only_leg(args, lib, model_for, HipBatch):
         out = inter_leg(args, lib, model_for, HipBatch, synth_frames(3840, 2160, 4, clip_seed(3840, 2160)), sequences=args.inter_sequences or 96)
         out.pop("chain", None)
     elif args.only == "medium":
-        out = leg_medium(args, lib, model_for, HipBatch, n_med=48)
+        out = leg_medium(args, lib, model_for, HipBatch, n_med=args.medium_frames)
     elif args.only == "intra4k":
         out = leg_intra4k(args, lib, model_for, HipBatch, n4k=192, steps=1)
     else:

@@ -91,12 +91,34 @@ def build_library(force=False, verbose=False):
     return _compile_and_link(OBJ_DIR, LIB_PATH, [], not force, verbose)
 
 
-def build_variant(name, extra_flags, verbose=False):
+def build_variant(name, extra_flags, verbose=False, only_units=None):
     """Developer builds with extra compiler flags (-DKVZ_CTU_PROFILE, occupancy experiments ...): kvazaar_amd/lib/variants/libkvz_hip_<name>.so, always rebuilt.
-    Use with KVZ_HIP_LIB=<path> (bench.py, tools/)."""
+    only_units: names of the translation units the flags matter for (e.g. ["kvz_ctu_tu5"], the RDOQ kernel) -- only those are compiled, the rest are the default
+    build's objects.  Use with KVZ_HIP_LIB=<path> (bench.py, tools/)."""
     vdir = os.path.join(LIB_DIR, "variants")
     os.makedirs(vdir, exist_ok=True)
-    return _compile_and_link(os.path.join(vdir, "obj_" + name), os.path.join(vdir, f"libkvz_hip_{name}.so"), extra_flags, False, verbose)
+    lib_path = os.path.join(vdir, f"libkvz_hip_{name}.so")
+    if not only_units:
+        return _compile_and_link(os.path.join(vdir, "obj_" + name), lib_path, extra_flags, False, verbose)
+    build_library()
+    obj_dir = os.path.join(vdir, "obj_" + name)
+    os.makedirs(obj_dir, exist_ok=True)
+    mfma_form = _probe_flags(MFMA_VGPR_FORM) and not os.environ.get("KVZ_HIP_NO_MFMA_VGPR_FORM")
+    objs = []
+    for uname, src, defs in UNITS:
+        if uname not in only_units:
+            objs.append(os.path.join(OBJ_DIR, uname + ".o"))
+            continue
+        if not mfma_form:
+            defs = [d for d in defs if d not in MFMA_VGPR_FORM]
+        obj = os.path.join(obj_dir, uname + ".o")
+        cmd = [HIPCC] + FLAGS + defs + list(extra_flags) + ["-c", "-o", obj, os.path.join(CSRC, src)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs)
+    return lib_path
 
 
 TOOLS = {"valu_issue_bench": os.path.join(os.path.dirname(PKG), "tools", "valu_issue_bench.hip")}

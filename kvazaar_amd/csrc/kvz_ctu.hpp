@@ -229,6 +229,7 @@ template <bool CABAC> struct CtuSharedT {
   u8 dec[6144];              // decided pixels, Y 64x64 | U 32x32 | V 32x32.  The depth-0 candidate (64x64 merge) reuses it:
                              // by then the split result has been written to the frame (run()).
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
+  unsigned long long prof_rq[16];   // rdoq_block_wave's sections and sizes (luma blocks, so one wavefront adds), flushed with prof_acc
   unsigned long long prof_acc[64];  // [category] cycles, [KVZ_P_COUNT + category] marks; [32 + ...] the same inside the 4x4 PUs of the NxN attempt (eval_pu)
   int prof_pu;
 #endif
@@ -614,7 +615,8 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     if (log2w == 2) return 0;
     if (log2w == 3) return scan == 1 ? i : ((0x3120 >> (4 * i)) & 3);
     if (log2w == 4) return scan_in_group(0, i);
-    return tb->diag8[i];
+    if constexpr (RDOQ) return rl->diag8[i];  // staged per CTU (run()): a load from global memory in front of every group of a 32x32 block otherwise
+    else return tb->diag8[i];
   }
   KVZ_DEV double coeff_bin(CtxSet *c, bool update, int idx, int bin) const
   {
@@ -2073,9 +2075,15 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
           // (quant-generic.c:237-238): 2 for the blocks of its PUs (level 4)
           ra.tr_depth = lv == 4 ? 2 : (lv == 0 ? 1 : 0);
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
-          ra.prof = F.prof + 2 * KVZ_P_COUNT;
+          ra.prof = s->prof_rq;  // LDS: one global atomic per call and section would be the hottest cache line of the device
 #endif
+#if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
+          const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
           rdoq_block_wave(ra, lane);
+          if (c == 0 && lane == 0) ra.prof[7] += __builtin_amdgcn_s_memtime() - tc0;  // the call as the caller sees it: minus the routine's own clock = what calling it costs
+#else
+          rdoq_block_wave(ra, lane);
+#endif
         }
       }
       KVZ_SYNC();
@@ -2475,7 +2483,20 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     cost += luma_ssd * 0.8 + chroma_ssd * 1.5 + tbits * m->lambda;
     return cost;
   }
-  // search_cu at depth 4 (search.c:646-1063 with depth > MAX_DEPTH: cu depth stays 3, search.c:691): PU j of the 8x8 CU at (rl->a3x, rl->a3y)
+  // Entry (k, i) of the 4x4 DST of intra luma (dct-generic.c:38-44, Tables::dst4) by arithmetic: the table lives in global memory, and a load from there in front of
+  // every product is what a 4x4 PU's transform stages waited for
+  KVZ_DEV static int dst4_at(int k, int i)
+  {
+    // { 29, 55, 74, 84 }, { 74, 74, 0, -74 }, { 84, -29, -74, 55 }, { 55, -84, 74, -29 }: one signed byte each, entry 0 lowest
+    const unsigned long long lo = 0xb6004a4a544a371dull, hi = 0xe34aac3737b6e354ull;
+    const int idx = 4 * k + i;
+    return (int)(int8_t)(u8)((idx < 8 ? lo : hi) >> (8 * (idx & 7)));
+  }
+  // search_cu at depth 4 (search.c:646-1063 with depth > MAX_DEPTH: cu depth stays 3, search.c:691): PU j of the 8x8 CU at (rl->a3x, rl->a3y).
+  // ONE pass per wavefront instead of the general stages of build_refs / recon_tus with a workgroup barrier each (a 4x4 block occupies sixteen lanes): the wavefront
+  // playing threads 0..63 takes the luma block from its references to its reconstruction, the other one -- with the first PU -- the CU's 4x4 U and V blocks
+  // (transform.c:306-312); the two meet when the luma mode is known (the chroma blocks are predicted with it), before the coefficient bits (whose luma part the two
+  // share) and at the cost.  Same arithmetic, sample by sample, as the general stages.
   KVZ_DEV void eval_pu(int j)
   {
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
@@ -2483,25 +2504,191 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
 #endif
     lane_rot = (lane_rot + 64) & (KVZ_CTU_THREADS - 1);
     const int xl = rl->a3x + 4 * (j & 1), yl = rl->a3y + 4 * (j >> 1), x = cx + xl, y = cy + yl;
-    // references of the 4x4 luma block from level 4's view; with the first PU the CU's 4x4 chroma blocks (transform.c:306-312)
-    build_refs(4, x, y, 2, 2, true, j == 0, [&](int tid) { if (tid == 0) price_modes(); });
+    const bool chroma = j == 0;
+    const CandView cv = cand_view(4);
+    const TuSet t{ x, y, 2, chroma ? 2 : 0 };
+    // intra.c:47-82 in closed form (build_refs)
+    const int ur = (y & 63) >> 2, uc = (x & 63) >> 2;
+    const int gt = ur ? 2 * (ur & -ur) : 0, gl = uc ? (uc & -uc) : 0;
+    const int avail_top = ur ? 4 * (gt - (uc & (gt - 1))) : 64, avail_left = uc ? 4 * (gl - (ur & (gl - 1))) : 64 - 4 * ur;
+    // ---- references (unfiltered: a 4x4 block never reads the filtered ones, intra.c:252-301), the scalars of the search
     KVZ_FOR_THREADS(tid) {
-      if (tid < 35) s->satd_raw[tid][0] = pu_mode_satd(tid, xl, yl);
-      if (tid == KVZ_CTU_THREADS - 1) {
+      const u8 *base = (const u8 *)s;
+      if (tid < 18) {
+        const int side = tid >= 9, k = side ? tid - 9 : tid;
+        int qx, qy;
+        const bool have = ref_coords(2, 0, x, y, side, k, avail_top, avail_left, &qx, &qy);
+        s->ref[0][side][k] = have ? base[rec_off(4, 0, qx, qy)] : (u8)128;
+      }
+      if (tid == 32) price_modes();
+      if (tid == 33) {
         const int left = x >= 4 ? neighbour_cu(4, x - 1, y) : -1, above = (y >= 4 && yl > 0) ? neighbour_cu(4, x, y - 1) : -1;
         mpm_candidates(y, left, above, s->preds);
       }
+      if (tid == 34) { s->acc[0] = 0; s->acc[3] = 0; s->acc[6] = 0; }
+      if (tid >= 64 && tid < 70) s->acc[1 + (tid - 64) + (tid - 64) / 2] = 0;  // 1, 2, 4, 5, 7, 8
+      if (chroma && tid >= 64 && tid < 82) {
+        const int i = tid - 64, side = i >= 9, k = side ? i - 9 : i;
+        int qx, qy, dv;
+        const bool have = ref_coords(2, 1, x, y, side, k, avail_top, avail_left, &qx, &qy);
+        const lds_off off = rec_off(4, 1, qx, qy, &dv);
+        s->ref[1][side][k] = have ? base[off] : (u8)128;
+        s->ref[2][side][k] = have ? base[off + dv] : (u8)128;
+      }
     }
-    KVZ_SYNC();
+    KVZ_WAVE_SYNC();
+    KVZ_FOR_THREADS(tid) {  // intra-generic.c:219-225: the DC value of each plane's references
+      const int c = tid == 0 ? 0 : (tid == 64 ? 1 : (tid == 65 ? 2 : -1));
+      if (c == 0 || (c > 0 && chroma)) s->dcval[c] = (u8)dc_value(2, s->ref[c][0], s->ref[c][1]);
+    }
+    KVZ_WAVE_SYNC();
+    KVZ_PROF(KVZ_P_REFS);
+    // ---- search_intra_rough at width 4: every mode's SATD, the reference's selection order on the table
+    KVZ_FOR_THREADS(tid) { if (tid < 35) s->satd_raw[tid][0] = pu_mode_satd(tid, xl, yl); }
+    KVZ_WAVE_SYNC();
     KVZ_FOR_THREADS(tid) {
       const int final_mode = replay_selection(tid, 2, 0);
       if (tid == 0) { s->best_mode = final_mode; rl->pu_mode[j] = (u8)final_mode; }
     }
-    KVZ_SYNC();
+    KVZ_SYNC();  // the chroma blocks are predicted with the luma mode
+    KVZ_PROF(KVZ_P_SELECT);
     const int mode = s->best_mode;
-    TuSet t{ x, y, 2, j == 0 ? 2 : 0 };
-    recon_tus(4, t, 4, mode, true);
-    if (cabac_on()) price_unit_coeffs(&s->cab, true, 4, 4, mode, &s->child_bits[0]);
+    // a lane's role: threads 0..15 the luma samples, 64..79 / 80..95 the U / V samples
+#define KVZ_PU_ROLE(tid) const int c = (tid) < 16 ? 0 : (((tid) >= 64 && (tid) < 96 && chroma) ? 1 + (((tid) - 64) >> 4) : -1), e = (tid) & 15, sh = c > 0 ? 1 : 0; (void)sh
+    // ---- prediction -> candidate (as kvazaar blits it before quantising) and residual
+    KVZ_FOR_THREADS(tid) {
+      KVZ_PU_ROLE(tid);
+      if (c >= 0) {
+        const int px = e & 3, py = e >> 2;
+        const u8 p = predict_pixel(2, mode, c, px, py);
+        cv.at(c, (xl >> sh) + px, (yl >> sh) + py) = p;
+        tbuf(t, 0, c)[e] = (i16)((int)*org_at(c, (xl >> sh) + px, (yl >> sh) + py) - (int)p);
+      }
+    }
+    KVZ_WAVE_SYNC();
+    KVZ_PROF(KVZ_P_RPRED);
+    // ---- forward transform (dct-generic.c:559-568): the DST for luma (strategies-dct.c:82-86), the DCT for chroma
+    for (int pass = 0; pass < 2; pass++) {
+      KVZ_FOR_THREADS(tid) {
+        KVZ_PU_ROLE(tid);
+        if (c >= 0) {
+          const int shift = pass == 0 ? 1 : 8, add = 1 << (shift - 1);
+          const i16 *src = tbuf(t, pass, c);
+          const int k = e >> 2, jj = e & 3;
+          int a = 0;
+#pragma unroll
+          for (int i = 0; i < 4; i++) a += (c == 0 ? dst4_at(k, i) : dct_at(2, k, i)) * (int)src[(jj << 2) + i];
+          tbuf(t, pass ^ 1, c)[e] = (i16)((a + add) >> shift);
+        }
+      }
+      KVZ_WAVE_SYNC();
+    }
+    KVZ_PROF(KVZ_P_FDCT);
+    // ---- kvz_rdoq (quant-generic.c:234-244), a block per wavefront: luma | U then V
+    const bool rdoq = m->rdoq != 0;
+    KVZ_FOR_THREADS(tid) {
+#ifdef KVZ_HOSTSIM
+      const int wv = tid == 0 ? 0 : (tid == 64 ? 1 : -1), lane = 0;
+#else
+      const int wv = tid >> 6, lane = tid & 63;
+#endif
+      for (int c = 0; c < 3; c++) {
+        if (!rdoq || wv != (c ? 1 : 0) || (c && !chroma)) continue;
+        RdoqWaveArgs ra;
+        ra.ptab = (KVZ_LDS_PTR(const i32))rl->ptab; ra.coef = (KVZ_LDS_PTR(const i16))tbuf(t, 0, c); ra.dest = (KVZ_LDS_PTR(i16))levels_lds(4, c);
+        ra.diag8 = (KVZ_LDS_PTR(const u8))rl->diag8; ra.lambda = m->lambda; ra.qp = m->qp; ra.log2w = 2; ra.type = c ? 2 : 0;
+        ra.scan_mode = scan_order(mode, 4);
+        ra.tr_depth = 2;  // cu->tr_depth - cu->depth + 1 for an NxN CU (quant-generic.c:237-238)
+#if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
+        ra.prof = s->prof_rq;
+        const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
+        rdoq_block_wave(ra, lane);
+        if (c == 0 && lane == 0) ra.prof[7] += __builtin_amdgcn_s_memtime() - tc0;
+#else
+        rdoq_block_wave(ra, lane);
+#endif
+      }
+    }
+    KVZ_WAVE_SYNC();
+    KVZ_PROF(KVZ_P_RDOQ);
+    // ---- (without RDOQ: quantise;) cost sums of the levels; dequantise (quant-generic.c:335-339)
+    KVZ_FOR_THREADS(tid) {
+      KVZ_PU_ROLE(tid);
+      u32 packed = 0;
+      if (c >= 0) {
+        const QuantScalars q = s->qs[0][c ? 1 : 0];
+        int level;
+        if (rdoq) level = levels_lds(4, c)[e];
+        else {  // quant-generic.c:57-81
+          const int cf = tbuf(t, 0, c)[e];
+          level = (int)(((u32)iabs(cf) * (u32)q.flat_q + (u32)q.add) >> q.q_bits);
+          if (cf < 0) level = -level;
+          level = iclip(-32768, 32767, level);
+          levels_lds(4, c)[e] = (i16)level;
+        }
+        int al = iabs(level);
+        const u32 nz = al != 0;
+        if (al > 3) al = 3;
+        const u32 wsum = (u32)((m->coeff_weights >> (16 * al)) & 0xffff);
+        tbuf(t, 1, c)[e] = (i16)iclip(-32768, 32767, (level * q.dq_scale + (1 << (q.dq_shift - 1))) >> q.dq_shift);
+        packed = wsum | (nz << 24);
+      }
+      plane_add(&s->acc[3], packed, tid);  // weight sum (< 2^22) and count of levels in one word
+    }
+    KVZ_WAVE_SYNC();
+    KVZ_PROF(KVZ_P_QUANT);
+    // ---- inverse transform (dct-generic.c:570-579), only observable when the plane has levels; reconstruction (quant-generic.c:266-277) + SSD (search.c:500-505, 512-523)
+    KVZ_FOR_THREADS(tid) {
+      KVZ_PU_ROLE(tid);
+      if (c >= 0 && (s->acc[3 + c] >> 24)) {
+        const i16 *src = tbuf(t, 1, c);
+        const int jj = e >> 2, i = e & 3;
+        int a = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) a += (c == 0 ? dst4_at(k, i) : dct_at(2, k, i)) * (int)src[(k << 2) + jj];
+        tbuf(t, 0, c)[e] = (i16)iclip(-32768, 32767, (a + 64) >> 7);
+      }
+    }
+    KVZ_WAVE_SYNC();
+    KVZ_PROF(KVZ_P_IDCT);
+    KVZ_FOR_THREADS(tid) {
+      KVZ_PU_ROLE(tid);
+      u32 ssd = 0;
+      if (c >= 0) {
+        u8 *rp = &cv.at(c, (xl >> sh) + (e & 3), (yl >> sh) + (e >> 2));
+        int v = *rp;
+        if (s->acc[3 + c] >> 24) {
+          const i16 *src = tbuf(t, 0, c);
+          const int jj = e >> 2, i = e & 3;
+          int a = 0;
+#pragma unroll
+          for (int k = 0; k < 4; k++) a += (c == 0 ? dst4_at(k, i) : dct_at(2, k, i)) * (int)src[(k << 2) + jj];
+          const i16 res = (i16)iclip(-32768, 32767, (a + 2048) >> 12);
+          v = iclip(0, 255, (int)(i16)(res + v));
+          *rp = (u8)v;
+        }
+        const int d = (int)*org_at(c, (xl >> sh) + (e & 3), (yl >> sh) + (e >> 2)) - v;
+        ssd = (u32)(d * d);
+      }
+      plane_add(&s->acc[0], ssd, tid);
+    }
+    KVZ_WAVE_SYNC();
+    KVZ_FOR_THREADS(tid) {  // each wavefront unpacks its planes' sums; the coded-block flags wait in RdoqLds until the partition wins (nxn_attempt)
+      if (tid == 0) {
+        const u32 pk = s->acc[3];
+        s->acc[3] = pk & 0xffffffu; s->acc[6] = pk >> 24;
+        rl->pu_cbf[rl->n_pu] = (pk >> 24) != 0;
+      }
+      if (tid == 64 && chroma) {
+        const u32 pu = s->acc[4], pv = s->acc[5];
+        s->acc[4] = pu & 0xffffffu; s->acc[7] = pu >> 24; s->acc[5] = pv & 0xffffffu; s->acc[8] = pv >> 24;
+        rl->pu_cbf_c[0] = (pu >> 24) != 0; rl->pu_cbf_c[1] = (pv >> 24) != 0;
+      }
+    }
+    KVZ_SYNC();
+    KVZ_PROF(KVZ_P_RECON);
+#undef KVZ_PU_ROLE
+    if (cabac_on()) { price_unit_coeffs(&s->cab, true, 4, 4, mode, &s->child_bits[0]); KVZ_PROF(KVZ_P_COEFFBITS); }
     KVZ_FOR_THREADS(tid) {
       if (tid == 0) {
         rl->split_cost3 += pu_cost(j, mode, cabac_on() ? &s->child_bits[0] : nullptr);
@@ -2509,6 +2696,7 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
       }
     }
     KVZ_SYNC();
+    KVZ_PROF(KVZ_P_COST);
   }
   // The split alternative of an 8x8 CU (search.c:943-1063 at depth 3 with pu_depth_intra.max = 4).  On entry the CU has been evaluated as 2Nx2N at level 3
   // (cost in s->cost[3]; d3_last has saved the contexts after it, gone back to those at entry and priced part_size NxN into rl->split_cost3); on exit the cheaper
@@ -3070,13 +3258,13 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   KVZ_DEV void run()
   {
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
-    if (threadIdx.x == 0) { for (int i = 0; i < 64; i++) s->prof_acc[i] = 0; s->prof_pu = 0; }
+    if (threadIdx.x == 0) { for (int i = 0; i < 64; i++) s->prof_acc[i] = 0; for (int i = 0; i < 16; i++) s->prof_rq[i] = 0; s->prof_pu = 0; }
     t_last = __builtin_amdgcn_s_memtime();
 #endif
     init();
-    if (RDOQ && m->rdoq) {  // kvz_rdoq prices on state->cabac's contexts as they stand now (pre[0]): both bins of every context, once per CTU
+    if constexpr (RDOQ) {  // kvz_rdoq prices on state->cabac's contexts as they stand now (pre[0]): both bins of every context, once per CTU
       KVZ_FOR_THREADS(tid) {
-        for (int v = tid; v < 2 * KVZ_CX_COUNT; v += KVZ_CTU_THREADS) rl->ptab[v] = (i32)(s->entropy_fbits[s->pre[0].s[v >> 1] ^ (v & 1)] * 32768.0f);
+        if (m->rdoq) for (int v = tid; v < 2 * KVZ_CX_COUNT; v += KVZ_CTU_THREADS) rl->ptab[v] = (i32)(s->entropy_fbits[s->pre[0].s[v >> 1] ^ (v & 1)] * 32768.0f);
         if (tid < 64) rl->diag8[tid] = tb->diag8[tid];
       }
       KVZ_SYNC();
@@ -3121,7 +3309,11 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
     finish_info();
     KVZ_PROF(KVZ_P_FINISH);
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
-    if (threadIdx.x == 0) for (int i = 0; i < 2 * KVZ_P_COUNT; i++) { atomicAdd(&F.prof[i], s->prof_acc[i]); atomicAdd(&F.prof[KVZ_PROF_PU_AT + i], s->prof_acc[32 + i]); }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int i = 0; i < 2 * KVZ_P_COUNT; i++) { atomicAdd(&F.prof[i], s->prof_acc[i]); atomicAdd(&F.prof[KVZ_PROF_PU_AT + i], s->prof_acc[32 + i]); }
+      for (int i = 0; i < 16; i++) atomicAdd(&F.prof[2 * KVZ_P_COUNT + i], s->prof_rq[i]);
+    }
 #endif
   }
 };

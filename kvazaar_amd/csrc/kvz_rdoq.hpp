@@ -244,18 +244,19 @@ KVZ_DEV i32 rdoq_escape_bins(i32 symbol, int g)
   return 3 + len + 1 - g + len;
 }
 
-// The prices of a group's level contexts (its context set is fixed while it is walked): greater-1 flag of c1 = 0..3, greater-2 flag, both bins.  Uniform.
-struct RdoqLevelPrices { i32 one0[4], one1[4], abs0, abs1; };
+// The prices a position's decision reads, per lane: both bins of the greater-1 context of its class (c1 of the class within the group's context set) and of the group's
+// greater-2 context.  Plain scalars on purpose: an array indexed by the class ends up in scratch memory, and a scratch load under a full device costs more than the
+// rest of the decision.
+struct RdoqLevelPrices { i32 one0, one1, abs0, abs1; };
+KVZ_DEV int rdoq_class_c1(int r) { return r < 3 ? r + 1 : 0; }
 
 // kvz_get_coded_level (rdo.c:413-459) of one position in chain-state class r (see the head of this section): the level, and with COSTS its coded cost and the cost of its
 // significance flag.  ma > 0.
 template <bool COSTS>
-KVZ_DEV i32 rdoq_decide(int r, i32 ma, bool last, double c0, double dhi, double dlo, double s0, double s1, double lambda, const RdoqLevelPrices &P, double *ccv_out, double *csv_out)
+KVZ_DEV i32 rdoq_decide(int r, i32 ma, bool last, double c0, double dhi, double dlo, double s0, double s1, double lambda, const RdoqLevelPrices P, double *ccv_out, double *csv_out)
 {
-  const int cls = r < 3 ? 0 : (r < 8 ? 1 : 2), g = cls == 0 ? 0 : (cls == 1 ? r - 3 : r - 8), c1 = cls == 0 ? r + 1 : 0, base_level = 3 - cls;
-  const i32 p_one0 = c1 == 0 ? P.one0[0] : (c1 == 1 ? P.one0[1] : (c1 == 2 ? P.one0[2] : P.one0[3]));
-  const i32 p_one1 = c1 == 0 ? P.one1[0] : (c1 == 1 ? P.one1[1] : (c1 == 2 ? P.one1[2] : P.one1[3]));
-  const i32 at_base = cls == 0 ? p_one1 + P.abs1 : (cls == 1 ? p_one1 : 0);  // rdo.c:373-380: what the context-coded flags of a level >= base_level cost
+  const int cls = r < 3 ? 0 : (r < 8 ? 1 : 2), g = cls == 0 ? 0 : (cls == 1 ? r - 3 : r - 8), base_level = 3 - cls;
+  const i32 at_base = cls == 0 ? P.one1 + P.abs1 : (cls == 1 ? P.one1 : 0);  // rdo.c:373-380: what the context-coded flags of a level >= base_level cost
   const double sadd = last ? 0.0 : s1;
   double ccv = 1.7e+308, csv = 0;  // MAX_DOUBLE (global.h)
   i32 level = 0;
@@ -264,8 +265,8 @@ KVZ_DEV i32 rdoq_decide(int r, i32 ma, bool last, double c0, double dhi, double 
   for (i32 a = ma; a >= min_abs; a--) {
     i32 rate = 1 << 15;
     if (a >= base_level) rate += rdoq_escape_bins(a - base_level, g) * (1 << 15) + at_base;
-    else if (a == 1) rate += p_one0;
-    else rate += p_one1 + P.abs0;  // a == 2 below base_level 3
+    else if (a == 1) rate += P.one0;
+    else rate += P.one1 + P.abs0;  // a == 2 below base_level 3
     double cur = (a == ma ? dhi : dlo) + lambda * rate;
     cur += sadd;
     if (cur < ccv) { level = a; ccv = cur; csv = sadd; }
@@ -277,8 +278,8 @@ KVZ_DEV i32 rdoq_decide(int r, i32 ma, bool last, double c0, double dhi, double 
 // Device: every lane of the wavefront calls it, converged, with wavefront-uniform arguments; lane = its index in the wavefront.  Host: one call (lane 0).
 #if defined(KVZ_CTU_PROFILE) && !defined(KVZ_HOSTSIM)
 #define KVZ_RQ_PROF(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); rq_t[i] += t_ - rq_last; rq_last = __builtin_amdgcn_s_memtime(); } while (0)
-#define KVZ_RQ_PROF_END() do { if (lane == 0 && c.type == 0 && c.prof) { unsigned long long all_ = 0; for (int i_ = 0; i_ < 8; i_++) { atomicAdd(&c.prof[i_], rq_t[i_]); all_ += rq_t[i_]; } \
-    atomicAdd(&c.prof[8 + c.log2w - 2], all_); atomicAdd(&c.prof[12 + c.log2w - 2], 1ull); } } while (0)
+#define KVZ_RQ_PROF_END() do { if (lane == 0 && c.type == 0 && c.prof) { unsigned long long all_ = 0; for (int i_ = 0; i_ < 8; i_++) { c.prof[i_] += rq_t[i_]; all_ += rq_t[i_]; } \
+    c.prof[8 + c.log2w - 2] += all_; c.prof[12 + c.log2w - 2] += 1ull; } } while (0)
 #else
 #define KVZ_RQ_PROF(i)
 #define KVZ_RQ_PROF_END()
@@ -297,39 +298,51 @@ KVZ_RDOQ_WAVE_FN void rdoq_block_wave(const RdoqWaveArgs c, int lane)
   const int qp_scaled = rdoq_scaled_qp(type, qp);
   const i32 q_bits = 14 + qp_scaled / 6 + transform_shift;
   const i32 q = rdoq_quant_scale(qp_scaled % 6);
-  double scale = 32768.0;  // scalinglist.c:349-367: err_scale = 2^15 * 2^(-2 transform_shift) / q / q
-  for (int i = 0; i < 2 * transform_shift; i++) scale = scale * 0.5;
-  for (int i = 0; i > 2 * transform_shift; i--) scale = scale * 2.0;
-  const double temp = scale / (double)q / (double)q;
+  // scalinglist.c:349-367: err_scale = 2^15 * 2^(-2 transform_shift) / q / q -- two IEEE divisions of a power of two, and a power of two goes through a rounding
+  // unchanged: the result is ((1 / q) / q) * 2^(15 - 2 transform_shift) exactly, the first factor one of six constants (folded at compile time, IEEE double), the product
+  // exact.  (Two double-precision divisions per block were some eighty instructions in front of everything else.)
+  const int qr = qp_scaled % 6;
+  const double inv_qq = qr == 0 ? (1.0 / 26214.0) / 26214.0 : (qr == 1 ? (1.0 / 23302.0) / 23302.0 : (qr == 2 ? (1.0 / 20560.0) / 20560.0
+                      : (qr == 3 ? (1.0 / 18396.0) / 18396.0 : (qr == 4 ? (1.0 / 16384.0) / 16384.0 : (1.0 / 14564.0) / 14564.0))));
+  const double temp = inv_qq * (double)(1 << (15 - 2 * transform_shift));  // 15 - 2 transform_shift = 5 .. 11
   const int num_blk_side = width >> 2;
   const RdoqScanT<KVZ_LDS_PTR(const u8)> sc{ log2w, scan_mode, c.diag8 };
   const i32 round = 1 << (q_bits - 1);
-  // ---- quant-generic.c:379-399 find_last_scanpos: the highest scan position that does not quantise to zero; everything above it is zero in dest
-  int my_last = -1;
-  KVZ_WAVE_STRIDE(sp, n) {
-    const u32 blkpos = sc.pos(sp);
-    const i32 ld = imin(iabs((i32)coef[blkpos]) * q, 0x7fffffff - round);
-    if (((ld + round) >> q_bits) > 0) my_last = imax(my_last, sp);
-  }
-#ifndef KVZ_HOSTSIM
-  {  // wavefront maximum (values >= -1)
-    int x = my_last + 1;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) x = imax(x, __shfl_xor(x, off));
-    my_last = __builtin_amdgcn_readfirstlane(x) - 1;
-  }
+  // ---- quant-generic.c:379-399 find_last_scanpos: the highest scan position that does not quantise to zero; everything above it is zero in dest.  Sixty-four
+  // positions at a time from the top: the first chunk with a level ends the search (one ballot and a count of leading zeros, not a wavefront maximum over shuffles)
+  int last_scanpos = -1;
+  for (int base = n > 64 ? n - 64 : 0; base >= 0 && last_scanpos < 0; base -= 64) {
+#ifdef KVZ_HOSTSIM
+    for (int sp = imin(base + 63, n - 1); sp >= base && last_scanpos < 0; sp--) {
+      const i32 ld = imin(iabs((i32)coef[sc.pos(sp)]) * q, 0x7fffffff - round);
+      if (((ld + round) >> q_bits) > 0) last_scanpos = sp;
+    }
+    for (int sp = base; sp < imin(base + 64, n); sp++) if (sp > last_scanpos) dest[sc.pos(sp)] = 0;
+#else
+    const int sp = base + lane;
+    bool level = false;
+    u32 blkpos = 0;
+    if (sp < n) {
+      blkpos = sc.pos(sp);
+      const i32 ld = imin(iabs((i32)coef[blkpos]) * q, 0x7fffffff - round);
+      level = ((ld + round) >> q_bits) > 0;
+    }
+    const unsigned long long mask = __ballot(level);
+    if (mask) last_scanpos = base + 63 - __builtin_clzll(mask);
+    if (sp < n && sp > last_scanpos) dest[blkpos] = 0;
 #endif
-  const int last_scanpos = my_last;
-  KVZ_WAVE_STRIDE(sp, n) { if (sp > last_scanpos) dest[sc.pos(sp)] = 0; }
+  }
+  last_scanpos = KVZ_UNI_INT(last_scanpos);  // a scalar for everything that follows from it (the group loop's counter first of all)
   if (last_scanpos < 0) { KVZ_RQ_PROF(0); KVZ_RQ_PROF_END(); return; }
   const int cg_last_scanpos = last_scanpos >> 4;
-  // rdo.c:480-509 calc_last_bits: entry k of the x / y table on lane k (k <= 9)
+  // rdo.c:480-509 calc_last_bits: entry k of the x / y table on lane k (k <= 9): the prices of the prefix's 1-bins before k, and of the 0-bin that ends it
   WaveArr<i32> lx_bits, ly_bits;
   {
     const int cb = log2w - 2;
     const int off = type ? 0 : (cb * 3 + ((cb + 1) >> 2)), shift = type ? cb : ((cb + 3) >> 2);
     const int bx = (type ? KVZ_HIP_CX_LAST_X_CHROMA : KVZ_HIP_CX_LAST_X_LUMA) + off, by = (type ? KVZ_HIP_CX_LAST_Y_CHROMA : KVZ_HIP_CX_LAST_Y_LUMA) + off;
     const int kmax = rdoq_group_idx(width - 1);
+#ifdef KVZ_HOSTSIM
     KVZ_WAVE_LANES(l, 64) {
       i32 bits_x = 0, bits_y = 0;
       const int kk = imin(l, kmax);
@@ -337,23 +350,25 @@ KVZ_RDOQ_WAVE_FN void rdoq_block_wave(const RdoqWaveArgs c, int lane)
       if (kk < kmax) { bits_x += c.price(bx + (kk >> shift), 0); bits_y += c.price(by + (kk >> shift), 0); }
       KVZ_WA_SET(lx_bits, l, bits_x); KVZ_WA_SET(ly_bits, l, bits_y);
     }
+#else
+    // every lane its own entry's two bins (four independent reads), the sums before it by a prefix scan along the row (DPP row_shr, zeros shifted in)
+    const bool in = lane < kmax;
+    const int cxk = (lane & 15) >> shift;
+    const i32 x1 = in ? c.price(bx + cxk, 1) : 0, x0 = in ? c.price(bx + cxk, 0) : 0, y1 = in ? c.price(by + cxk, 1) : 0, y0 = in ? c.price(by + cxk, 0) : 0;
+    i32 sx = x1, sy = y1;
+    sx += __builtin_amdgcn_update_dpp(0, sx, 0x111, 0xF, 0xF, true); sy += __builtin_amdgcn_update_dpp(0, sy, 0x111, 0xF, 0xF, true);
+    sx += __builtin_amdgcn_update_dpp(0, sx, 0x112, 0xF, 0xF, true); sy += __builtin_amdgcn_update_dpp(0, sy, 0x112, 0xF, 0xF, true);
+    sx += __builtin_amdgcn_update_dpp(0, sx, 0x114, 0xF, 0xF, true); sy += __builtin_amdgcn_update_dpp(0, sy, 0x114, 0xF, 0xF, true);
+    sx += __builtin_amdgcn_update_dpp(0, sx, 0x118, 0xF, 0xF, true); sy += __builtin_amdgcn_update_dpp(0, sy, 0x118, 0xF, 0xF, true);
+    lx_bits.v = sx - x1 + x0; ly_bits.v = sy - y1 + y0;  // lanes up to kmax (<= 9, the first row) are read
+#endif
   }
   const int cg0 = KVZ_HIP_CX_SIG_CG + type;
   const int sig_base = type ? KVZ_HIP_CX_SIG_CHROMA : KVZ_HIP_CX_SIG_LUMA;
   const int one0 = type == 0 ? KVZ_HIP_CX_ONE_LUMA : KVZ_HIP_CX_ONE_CHROMA, abs0 = type == 0 ? KVZ_HIP_CX_ABS_LUMA : KVZ_HIP_CX_ABS_CHROMA;
-  // prices held on lanes for the whole block (a memory access on the chain costs more than the arithmetic of a position): lambda times both bins of the two
-  // coded-group-flag contexts on lanes 0..3; both bins of the greater-1 contexts of every context set on lanes 0..31 ([set][c1][bin]), of the greater-2 contexts on
-  // lanes 32..39 ([set][bin]).  Chroma has two context sets (context.c: 8 + 2 contexts).
+  // lambda times both bins of the two coded-group-flag contexts on lanes 0..3, for the whole block (a memory access on the chain costs more than the arithmetic of a position)
   WaveArr<double> cg_price;
-  WaveArr<i32> lvl_price;
-  KVZ_WAVE_LANES(l, 64) {
-    KVZ_WA_SET(cg_price, l, c.lambda * c.price(cg0 + ((l >> 1) & 1), l & 1));
-    const int set_mask = type ? 1 : 3;
-    i32 v = 0;
-    if (l < 32) v = c.price(one0 + 4 * ((l >> 3) & set_mask) + ((l >> 1) & 3), l & 1);
-    else if (l < 40) v = c.price(abs0 + (((l - 32) >> 1) & set_mask), l & 1);
-    KVZ_WA_SET(lvl_price, l, v);
-  }
+  KVZ_WAVE_LANES(l, 64) { KVZ_WA_SET(cg_price, l, c.lambda * c.price(cg0 + ((l >> 1) & 1), l & 1)); }
   // per group, on the lane of its scan index, for the last pass: the classes its positions were decided in, its context set, the cost of its coded-group flag
   WaveArr<i32> rst_lo_of, rst_hi_of, ctx_set_of;
   WaveArr<double> cg_cost_of;
@@ -385,10 +400,11 @@ KVZ_RDOQ_WAVE_FN void rdoq_block_wave(const RdoqWaveArgs c, int lane)
     p.s1 = c.lambda * c.price(sig_base + ctx_sig, 1);
     return p;
   };
-  auto level_prices = [&](int set) {
+  // the level prices of class r in context set `set`, read by the lane from the price table in LDS (one 8-byte read per context: both bins)
+  auto level_prices = [&](int r, int set) {
     RdoqLevelPrices P;
-    for (int j = 0; j < 4; j++) { P.one0[j] = KVZ_WA_GET(lvl_price, 8 * set + 2 * j); P.one1[j] = KVZ_WA_GET(lvl_price, 8 * set + 2 * j + 1); }
-    P.abs0 = KVZ_WA_GET(lvl_price, 32 + 2 * set); P.abs1 = KVZ_WA_GET(lvl_price, 33 + 2 * set);
+    const int i1 = one0 + 4 * set + rdoq_class_c1(r), i2 = abs0 + set;
+    P.one0 = c.price(i1, 0); P.one1 = c.price(i1, 1); P.abs0 = c.price(i2, 0); P.abs1 = c.price(i2, 1);
     return P;
   };
   KVZ_RQ_PROF(0);
@@ -401,13 +417,13 @@ KVZ_RDOQ_WAVE_FN void rdoq_block_wave(const RdoqWaveArgs c, int lane)
     if (cgs < 32) pat_lo |= (unsigned long long)(pattern_sig_ctx & 3) << (2 * cgs); else pat_hi |= (unsigned long long)(pattern_sig_ctx & 3) << (2 * (cgs - 32));
     // ---- 1. the positions
     WaveArr<double> c0v, dhi, dlo, s0v, s1v, ccv, csv;
-    WaveArr<i32> max_abs, blkpos_of, level_of, ch_a, ch_b;
+    WaveArr<i32> max_abs, blkpos_of, level_of;
     unsigned coded = 0;  // positions of the group that may quantise to a level
     KVZ_WAVE_LANES(l, 64) {
       const Pos p = position(cgs, l, pattern_sig_ctx);
       KVZ_WA_SET(max_abs, l, p.ma); KVZ_WA_SET(blkpos_of, l, p.blkpos);
       KVZ_WA_SET(c0v, l, p.c0); KVZ_WA_SET(dhi, l, p.dhi); KVZ_WA_SET(dlo, l, p.dlo); KVZ_WA_SET(s0v, l, p.s0); KVZ_WA_SET(s1v, l, p.s1);
-      KVZ_WA_SET(level_of, l, 0); KVZ_WA_SET(ch_a, l, 0); KVZ_WA_SET(ch_b, l, 0);
+      KVZ_WA_SET(level_of, l, 0);
       KVZ_WA_SET(ccv, l, p.c0 + p.s0); KVZ_WA_SET(csv, l, p.s0);  // what a position that can only be zero costs (rdo.c:424-428); +0.0 twice outside the chain
 #ifdef KVZ_HOSTSIM
       if (l < 16 && p.ma > 0) coded |= 1u << l;
@@ -419,57 +435,61 @@ KVZ_RDOQ_WAVE_FN void rdoq_block_wave(const RdoqWaveArgs c, int lane)
     KVZ_RQ_PROF(1);
     unsigned long long rstates = 0;
     if (coded) {
-      const RdoqLevelPrices P = level_prices(ctx_set);
-      // ---- 2. the decisions of the classes 0..7: replica j takes j and j + 4
-      KVZ_WAVE_LANES(l, 64) {
-        const i32 ma = KVZ_WA_OWN(max_abs, l);
-        if (ma > 0) {
-          const bool last = cgs * 16 + (l & 15) == last_scanpos;
-          i32 w = 0;
-          for (int t = 0; t < 2; t++) {
-            const i32 lv = rdoq_decide<false>((l >> 4) + 4 * t, ma, last, KVZ_WA_OWN(c0v, l), KVZ_WA_OWN(dhi, l), KVZ_WA_OWN(dlo, l), KVZ_WA_OWN(s0v, l), KVZ_WA_OWN(s1v, l), c.lambda, P, nullptr, nullptr);
-            w |= (lv == 0 ? 0 : (lv == ma ? 1 : 2)) << (2 * t);
+      // ---- 2. the decisions per class as bit masks over (replica, position): what the chain needs to know of a decision is whether the level is non-zero (it
+      // counts), above 1 (c1 falls to 0) and whether it moves the rice parameter (rdo.c:808-811) -- three wavefront ballots per set of four classes.
+      // Set t holds the classes 4 t + replica: 0 and 1 before the chain, 2 (and 3: class 12, replica 0 only) once a group has coded eight levels.
+      unsigned long long NZ[4] = { 0, 0, 0, 0 }, G1[4] = { 0, 0, 0, 0 }, RC[4] = { 0, 0, 0, 0 };
+      auto decide_set = [&](int t) {
+#ifdef KVZ_HOSTSIM
+        unsigned long long nzb = 0, g1b = 0, rcb = 0;
+#endif
+        bool nz = false, g1 = false, rc = false;
+        KVZ_WAVE_LANES(l, 64) {
+          const i32 ma = KVZ_WA_OWN(max_abs, l);
+          const int r = (l >> 4) + 4 * t;
+          nz = g1 = rc = false;
+          if (ma > 0 && r <= 12) {
+            const bool last = cgs * 16 + (l & 15) == last_scanpos;
+            const i32 lv = rdoq_decide<false>(r, ma, last, KVZ_WA_OWN(c0v, l), KVZ_WA_OWN(dhi, l), KVZ_WA_OWN(dlo, l), KVZ_WA_OWN(s0v, l), KVZ_WA_OWN(s1v, l), c.lambda, level_prices(r, ctx_set), nullptr, nullptr);
+            const int g = r < 3 ? 0 : (r < 8 ? r - 3 : r - 8), base_level = r < 3 ? 3 : (r < 8 ? 2 : 1);
+            nz = lv > 0; g1 = lv > 1; rc = lv >= base_level && lv > (3 << g);
           }
-          KVZ_WA_SET(ch_a, l, w);
+#ifdef KVZ_HOSTSIM
+          nzb |= (unsigned long long)nz << l; g1b |= (unsigned long long)g1 << l; rcb |= (unsigned long long)rc << l;
+#endif
         }
-      }
+#ifdef KVZ_HOSTSIM
+        NZ[t] = nzb; G1[t] = g1b; RC[t] = rcb;
+#else
+        NZ[t] = __ballot(nz); G1[t] = __ballot(g1); RC[t] = __ballot(rc);
+#endif
+      };
+      decide_set(0); decide_set(1);
       KVZ_RQ_PROF(2);
-      // ---- 3. the chain (rdo.c:760-840 for this group)
+      // ---- 3. the chain (rdo.c:760-840 for this group), from one level that is coded to the next: positions that stay zero in the class they are met in move nothing
       int c1_idx = 0, go_rice = 0;
+      int r = c1 ? c1 - 1 : 3;  // the class the group starts in
+      rstates = 0x1111111111111111ull * (unsigned)r;  // every position not met yet: the current class
       bool have_b = false;
       for (unsigned rem = coded; rem;) {
-        const int k = 31 - __builtin_clz(rem);
-        rem &= ~(1u << k);
-        const bool few = c1_idx < 8;
-        if (!few && !have_b) {
-          // the classes 8..12, now that the group has coded eight levels: replica j takes 8 + j, replica 0 also 12
-          have_b = true;
-          KVZ_WAVE_LANES(l, 64) {
-            const i32 ma = KVZ_WA_OWN(max_abs, l);
-            if (ma > 0) {
-              const bool last = cgs * 16 + (l & 15) == last_scanpos;
-              i32 w = 0;
-              for (int t = 0; t < 2; t++) {
-                const int r = 8 + (l >> 4) + 4 * t;
-                if (r > 12) break;
-                const i32 lv = rdoq_decide<false>(r, ma, last, KVZ_WA_OWN(c0v, l), KVZ_WA_OWN(dhi, l), KVZ_WA_OWN(dlo, l), KVZ_WA_OWN(s0v, l), KVZ_WA_OWN(s1v, l), c.lambda, P, nullptr, nullptr);
-                w |= (lv == 0 ? 0 : (lv == ma ? 1 : 2)) << (2 * t);
-              }
-              KVZ_WA_SET(ch_b, l, w);
-            }
-          }
+        if (c1_idx >= 8 && !have_b) { decide_set(2); decide_set(3); have_b = true; }
+        const int t = r >> 2, sh = 16 * (r & 3);
+        const unsigned long long nzs = t == 0 ? NZ[0] : (t == 1 ? NZ[1] : (t == 2 ? NZ[2] : NZ[3]));
+        const unsigned nz = (unsigned)(nzs >> sh) & rem;
+        if (!nz) break;
+        const int k = 31 - __builtin_clz(nz);
+        const unsigned long long g1s = t == 0 ? G1[0] : (t == 1 ? G1[1] : (t == 2 ? G1[2] : G1[3])), rcs = t == 0 ? RC[0] : (t == 1 ? RC[1] : (t == 2 ? RC[2] : RC[3]));
+        const unsigned g1 = (unsigned)(g1s >> (sh + k)) & 1u, rc = (unsigned)(rcs >> (sh + k)) & 1u;
+        rem &= (1u << k) - 1u;
+        c1_idx++;
+        go_rice = imin(go_rice + (int)rc, 4);
+        c1 = g1 ? 0 : (c1 == 1 || c1 == 2 ? c1 + 1 : c1);
+        const int r2 = c1_idx < 8 ? (c1 ? c1 - 1 : 3 + go_rice) : 8 + go_rice;
+        if (r2 != r) {  // the positions below k are met in the new class
+          const unsigned x = (unsigned)(r ^ r2) * 0x11111111u;
+          rstates ^= (((unsigned long long)x << 32) | x) & ((1ull << (4 * k)) - 1ull);
+          r = r2;
         }
-        const int r = few ? (c1 ? c1 - 1 : 3 + go_rice) : 8 + go_rice, rr = r & 7;
-        const i32 word = few ? KVZ_WA_GET(ch_a, k + 16 * (rr & 3)) : KVZ_WA_GET(ch_b, k + 16 * (rr & 3));
-        const int ch = (word >> (2 * (rr >> 2))) & 3;
-        const i32 ma = KVZ_WA_GET(max_abs, k);
-        const i32 level = ch == 0 ? 0 : (ch == 1 ? ma : ma - 1);
-        rstates |= (unsigned long long)r << (4 * k);
-        const i32 base_level = few ? (2 + (c1 != 0)) : 1;
-        if (level >= base_level && level > 3 * (1 << go_rice)) go_rice = imin(go_rice + 1, 4);
-        if (level >= 1) c1_idx++;
-        if (level > 1) c1 = 0;
-        else if (c1 < 3 && c1 > 0 && level) c1++;
       }
       KVZ_RQ_PROF(3);
       // ---- 4. every position once more, in the class the chain met it in, with its costs
@@ -478,7 +498,8 @@ KVZ_RDOQ_WAVE_FN void rdoq_block_wave(const RdoqWaveArgs c, int lane)
         if (ma > 0) {
           const bool last = cgs * 16 + (l & 15) == last_scanpos;
           double cc, cs;
-          const i32 lv = rdoq_decide<true>((int)((rstates >> (4 * (l & 15))) & 15), ma, last, KVZ_WA_OWN(c0v, l), KVZ_WA_OWN(dhi, l), KVZ_WA_OWN(dlo, l), KVZ_WA_OWN(s0v, l), KVZ_WA_OWN(s1v, l), c.lambda, P, &cc, &cs);
+          const int r = (int)((rstates >> (4 * (l & 15))) & 15);
+          const i32 lv = rdoq_decide<true>(r, ma, last, KVZ_WA_OWN(c0v, l), KVZ_WA_OWN(dhi, l), KVZ_WA_OWN(dlo, l), KVZ_WA_OWN(s0v, l), KVZ_WA_OWN(s1v, l), c.lambda, level_prices(r, ctx_set), &cc, &cs);
           KVZ_WA_SET(level_of, l, lv); KVZ_WA_SET(ccv, l, cc); KVZ_WA_SET(csv, l, cs);
         }
       }
@@ -559,7 +580,7 @@ KVZ_RDOQ_WAVE_FN void rdoq_block_wave(const RdoqWaveArgs c, int lane)
     // (rdo.c:465-478 get_rate_last)
     const int pat2 = (int)(((cgs < 32 ? pat_lo >> (2 * cgs) : pat_hi >> (2 * (cgs - 32)))) & 3);
     const unsigned long long rstates = (unsigned long long)(u32)KVZ_WA_GET(rst_lo_of, cgs) | (unsigned long long)(u32)KVZ_WA_GET(rst_hi_of, cgs) << 32;
-    const RdoqLevelPrices P = level_prices(KVZ_WA_GET(ctx_set_of, cgs));
+    const int set_of_group = KVZ_WA_GET(ctx_set_of, cgs);
     WaveArr<double> c0v, ccv, sigc, lastc;
     WaveArr<i32> lvl;
     KVZ_WAVE_LANES(l, 64) {
@@ -570,7 +591,10 @@ KVZ_RDOQ_WAVE_FN void rdoq_block_wave(const RdoqWaveArgs c, int lane)
       const i32 lxb = KVZ_WA_AT(lx_bits, l, gx), lyb = KVZ_WA_AT(ly_bits, l, gy);  // every lane takes part in the exchange (converged here)
       i32 level = p.ma < 0 ? -1 : 0;
       double cc = p.c0 + p.s0, cs = p.s0, lc = 0;
-      if (p.ma > 0) level = rdoq_decide<true>((int)((rstates >> (4 * (l & 15))) & 15), p.ma, p.last, p.c0, p.dhi, p.dlo, p.s0, p.s1, c.lambda, P, &cc, &cs);
+      if (p.ma > 0) {
+        const int r = (int)((rstates >> (4 * (l & 15))) & 15);
+        level = rdoq_decide<true>(r, p.ma, p.last, p.c0, p.dhi, p.dlo, p.s0, p.s1, c.lambda, level_prices(r, set_of_group), &cc, &cs);
+      }
       if (level > 0) {
         double ui_cost = lxb + lyb;
         if (gx > 3) ui_cost += (double)((1 << 15) * ((gx - 2) >> 1));
@@ -596,7 +620,7 @@ KVZ_RDOQ_WAVE_FN void rdoq_block_wave(const RdoqWaveArgs c, int lane)
       walk.rotate();
       k--;
     }
-    KVZ_RQ_PROF(7);
+    KVZ_RQ_PROF(6);
   }
 #ifndef KVZ_HOSTSIM
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the levels written above (LDS in the CTU pass) are read back below by other lanes: one wavefront's LDS operations execute in order

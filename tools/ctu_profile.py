@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 NAMES = ["init", "refs", "pred35+replay", "satd", "select", "recon_pred", "fdct", "quant", "idct", "recon", "cost", "copy", "finish", "misc", "coeffbits", "rdoq"]
 
-RDOQ_SECTIONS = ["setup / last position / final", "group: positions", "group: decisions per class", "group: chain walk", "group: costs", "group: ordered sums", "group: decision, levels out; last pass: positions", "last-position walk"]
+RDOQ_SECTIONS = ["setup / last position / final", "group: positions", "group: decisions per class", "group: chain walk", "group: costs", "group: ordered sums", "group: decision, levels out; last pass", "the calls as the caller sees them (routine + call overhead)"]
 
 
 def main():
