@@ -465,7 +465,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ref-encoder", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the auxiliary legs (chain, chain_d2h, configs_extra); they only run at --gpus 1")
-    ap.add_argument("--only", default="", choices=["", "inter", "medium", "intra4k", "entropy"], help="developer / profiling: run ONE auxiliary leg at a reduced size and print its "
+    ap.add_argument("--only", default="", choices=["", "inter", "medium", "intra4k", "tiles4k", "entropy"], help="developer / profiling: run ONE auxiliary leg at a reduced size and print its "
                     "entry (tools/pmc_leg.sh collects the leg's counters this way); the headline is not measured")
     ap.add_argument("--entropy-pictures", type=int, default=384, help="developer: pictures of `--only entropy`")
     ap.add_argument("--medium-frames", type=int, default=48, help="developer: pictures of `--only medium` (the default run's C3 leg takes 96)")
@@ -752,6 +752,8 @@ def only_leg(args, lib, model_for, HipBatch):
         out = leg_medium(args, lib, model_for, HipBatch, n_med=args.medium_frames)
     elif args.only == "intra4k":
         out = leg_intra4k(args, lib, model_for, HipBatch, n4k=192, steps=1)
+    elif args.only == "tiles4k":
+        out = leg_tiles4k(args, lib, model_for, HipBatch, n4k=192, steps=1)
     else:
         n = args.entropy_pictures
         frames = synth_frames(args.width, args.height, args.distinct, clip_seed(args.width, args.height))
@@ -1018,12 +1020,26 @@ def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedRes
                 b.upload(i, distinct[i % len(distinct)])
             full.append(b)
         reps_full = 3  # six turns: the pipeline's first pass and last coder have nothing beside them
-        s_full, pictures, per_pic, ok = chain_full(full, model, args.qp, reps_full, gold if applies else None, len(distinct))
+        s_res, pictures_res, _, ok_res = chain_full(full, model, args.qp, reps_full, gold if applies else None, len(distinct))
+        # ... and with the source pictures arriving over PCIe inside the timed region, as the reference encoder reads its input: every batch but a batch's first gets its
+        # pictures from a pinned host buffer on the batch's upload queue (kvz_hip_batch_upload_all_async), beside the other batch's pass
+        from kvazaar_amd.batch import pinned_bytes, pinned_free
+        frame_bytes = args.width * args.height * 3 // 2
+        src_ptr, src_view = pinned_bytes(lib, half_full * frame_bytes)
+        for i in range(half_full):
+            src_view[i * frame_bytes:(i + 1) * frame_bytes] = distinct[i % len(distinct)]
+        s_full, pictures, per_pic, ok, n_up = chain_full(full, model, args.qp, reps_full, gold if applies else None, len(distinct), src_ptr=src_ptr)
         for b in full:
             b.close()
-        result["chain_full"] = {"stages": "CTU pass -> deblocking -> entropy coder on the device -> slice data and entry points downloaded into pinned host memory; two batches of "
-                                          f"{half_full} pictures in turn, a batch's pass started when the other batch's coder has queued its chain-bound third stage (kvz_hip_batch_entropy_code_then)",
+        pinned_free(lib, src_ptr)
+        result["chain_full"] = {"stages": "source pictures uploaded from pinned host memory -> CTU pass -> deblocking -> entropy coder on the device -> slice data and entry points downloaded into "
+                                          f"pinned host memory; two batches of {half_full} pictures in turn, a batch's pass started when the other batch's coder has queued its chain-bound third "
+                                          "stage (kvz_hip_batch_entropy_code_then), its next pictures uploaded beside the other batch's pass (kvz_hip_batch_upload_all_async)",
                                 "value": pictures * main_batch.ctus_per_frame / s_full, "unit": "CTUs/s", "fps": pictures / s_full, "ms_per_batch": s_full / (2 * reps_full) * 1e3, "batches_timed": 2 * reps_full,
+                                "h2d": {"batches_uploaded_in_timed_region": n_up, "bytes_per_batch": half_full * frame_bytes, "h2d_GBps": n_up * half_full * frame_bytes / s_full / 1e9,
+                                        "note": "averaged over the timed region; the first pass of each of the two batches runs on pictures already resident"},
+                                "source_resident": {"value": pictures_res * main_batch.ctus_per_frame / s_res, "fps": pictures_res / s_res, "ms_per_batch": s_res / (2 * reps_full) * 1e3, "verified": ok_res,
+                                                    "note": "the same chain with the pictures resident in HBM across all batches (what round 5 reported)"},
                                 "slice_data_bytes_per_picture": per_pic, "verified": ok,
                                 "verify": "slice data and entry points of the clip's pictures equal the reference encoder's bitstream (tests/golden/entropy.json bench-1080p)",
                                 "note": "the like-for-like line against cpu_baseline (kvazaar's whole encoder: search, deblocking, CABAC, bitstream); parameter sets, slice "
@@ -1033,6 +1049,14 @@ def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedRes
     for b, pinned in pair:
         b.close()
         pinned.close()
+    # ---- the headline on 64 distinct pictures, checked against the reference encoder run here ----
+    if args.preset == "ultrafast" and not args.no_wpp and not args.frozen_contexts and not args.tiles:
+        try:
+            result["distinct64"] = leg_distinct(args, lib, model, HipBatch)
+            if result["distinct64"].get("value"):
+                result["distinct64"]["vs_headline"] = result["distinct64"]["value"] / result["value"]
+        except Exception as e:  # auxiliary: never take the headline down
+            result["distinct64"] = {"error": repr(e)}
     # ---- the north-star size ----
     if (args.width, args.height) != (3840, 2160):
         result["configs_extra"] = [leg_intra4k(args, lib, model_for, HipBatch), leg_tiles4k(args, lib, model_for, HipBatch)]
@@ -1044,7 +1068,7 @@ def extra_legs(args, lib, result, batches, model, model_for, HipBatch, PinnedRes
         result["configs_extra"].append(leg_medium(args, lib, model_for, HipBatch))
 
 
-def chain_full(pair, model, qp, reps, gold, n_distinct):
+def chain_full(pair, model, qp, reps, gold, n_distinct, src_ptr=None):
     """CTU pass -> deblocking -> entropy coder on the device -> slice data + entry points downloaded, for two resident batches in turn.  The coder's first stage wants
     the whole device and so does the pass (one persistent launch that takes every workgroup slot it finds); the coder's third stage is a few hundred wavefronts that
     each follow one substream's chain, and then there is the download.  So the other batch's pass is started when this batch's coder has queued its third stage
@@ -1059,6 +1083,7 @@ def chain_full(pair, model, qp, reps, gold, n_distinct):
         b.deblock(qp, wait=False)
         b.entropy_code(model)
     last = {}
+    uploads = [0]
     t = time.perf_counter()
     turns = reps * len(pair)
     cur = pair[0]
@@ -1070,6 +1095,9 @@ def chain_full(pair, model, qp, reps, gold, n_distinct):
         last[id(cur)] = cur.entropy_code(model, then=(nxt, model) if more else None)  # waits for cur's pass + deblocking, codes, starts nxt's pass, downloads
         if more:
             nxt.deblock(qp, wait=False)  # queued behind the pass the call above started
+        if src_ptr is not None and i + len(pair) < turns:
+            cur.upload_all_async(src_ptr)  # the pictures of cur's NEXT pass: its last pass is long over, so the copy runs beside nxt's pass; that next pass waits for it
+            uploads[0] += 1
         cur = nxt
     s_full = time.perf_counter() - t
     pictures = reps * sum(b.n for b in pair)
@@ -1085,7 +1113,90 @@ def chain_full(pair, model, qp, reps, gold, n_distinct):
                 at += total
             good = bool(good and all(np.array_equal(sizes[i], sizes[i % n_distinct]) for i in range(b.n)))
             ok = good if ok is None else (ok and good)
+    if src_ptr is not None:
+        return s_full, pictures, nbytes / sum(b.n for b in pair), ok, uploads[0]
     return s_full, pictures, nbytes / sum(b.n for b in pair), ok
+
+
+def nal_payloads(stream):
+    """the payloads of the VCL NAL units (types 0..21) of an Annex B byte stream as they stand in it (emulation prevention included), in order"""
+    starts, i, n = [], 0, len(stream)
+    while True:
+        i = stream.find(b"\x00\x00\x01", i)
+        if i < 0:
+            break
+        starts.append(i + 3)
+        i += 3
+    out = []
+    for k, st in enumerate(starts):
+        e = starts[k + 1] - 3 if k + 1 < len(starts) else n
+        while e > st and stream[e - 1] == 0:
+            e -= 1
+        if ((stream[st] >> 1) & 0x3F) <= 21:
+            out.append(stream[st + 2:e])
+    return out
+
+
+def leg_distinct(args, lib, model, HipBatch, n_distinct=64, steps=3):
+    """The headline pass on a batch that cycles through 64 DISTINCT pictures (the default batch repeats 8), every one of them checked against the reference encoder run
+    inside this bench on the same pictures -- not against fixtures: kvazaar_ref (oracle/_ref, AVX2, all granted CPUs) codes the 64-picture clip once with --debug;
+    the device's deblocked reconstruction of each distinct picture must hash like the encoder's, and the device coder's slice data must be the tail of the encoder's slice
+    NAL unit for that picture."""
+    import subprocess
+    import tempfile
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "kvazaar_ref")
+    w, h, n = args.width, args.height, args.frames
+    if not os.path.exists(ref_bin):
+        return {"skipped": "oracle/_ref/kvazaar_ref not built"}
+    frames = synth_frames(w, h, n_distinct, clip_seed(w, h))
+    fb = w * h * 3 // 2
+    cpus = host_cpu_facts()["schedulable_cpus"]
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as d:
+        yuv, rec, out = os.path.join(d, "in.yuv"), os.path.join(d, "rec.yuv"), os.path.join(d, "out.hevc")
+        with open(yuv, "wb") as f:
+            for fr in frames:
+                f.write(fr.tobytes())
+        t0 = time.perf_counter()
+        r = subprocess.run([ref_bin, "-i", yuv, "--input-res", f"{w}x{h}", "--preset", "ultrafast", "-p", "1", "-q", str(args.qp), "--threads", str(cpus), "--debug", rec, "-o", out],
+                           capture_output=True, text=True)
+        ref_s = time.perf_counter() - t0
+        if r.returncode != 0:
+            return {"error": "kvazaar_ref: " + r.stderr[-300:]}
+        recon = np.fromfile(rec, np.uint8)
+        want_rec = [sha(recon[i * fb:(i + 1) * fb]) for i in range(n_distinct)]
+        payloads = nal_payloads(open(out, "rb").read())
+    if len(payloads) != n_distinct:
+        return {"error": f"{len(payloads)} slice NAL units for {n_distinct} pictures"}
+    b = HipBatch(lib, w, h, n)
+    for i in range(n):
+        b.upload(i, frames[i % n_distinct])
+    b.run(model)
+    t0 = time.perf_counter()
+    kms = []
+    for _ in range(steps):
+        b.run(model)
+        kms.append(b.kernel_ms())
+    s = time.perf_counter() - t0
+    b.deblock(args.qp, wait=False)
+    data, sizes = b.entropy_code(model)
+    sums = b.checksums()
+    consistent = all(bool((sums[i] == sums[i % n_distinct]).all()) for i in range(n))
+    rec_ok = all(sha(b.download(i)["rec"]) == want_rec[i] for i in range(n_distinct))
+    ent_ok, at = True, 0
+    for i in range(n_distinct):
+        total = int(sizes[i].sum())
+        ent_ok = ent_ok and payloads[i].endswith(bytes(data[at:at + total])) and total > 0
+        at += total
+    ent_ok = bool(ent_ok and all(np.array_equal(sizes[i], sizes[i % n_distinct]) for i in range(n)))
+    units = n * b.ctus_per_frame
+    res = {"workload": f"{w}x{h} all-intra ultrafast CTU pass, QP {args.qp}, {n} frames resident cycling through {n_distinct} distinct pictures, {steps} steps",
+           "value": steps * units / s, "unit": "CTUs/s", "fps": steps * n / s, "ms_per_step": s / steps * 1e3, "kernel_ms": float(np.mean(kms)),
+           "verified": bool(consistent and rec_ok and ent_ok),
+           "verify": {"reference": f"oracle/_ref/kvazaar_ref --preset ultrafast -q {args.qp} --threads {cpus} --debug on the same {n_distinct} pictures, run inside this bench ({ref_s:.1f} s)",
+                      "distinct_pictures_reconstruction_hashed": n_distinct, "reconstruction_ok": bool(rec_ok), "distinct_pictures_slice_data_compared": n_distinct, "slice_data_ok": bool(ent_ok),
+                      "copies_consistent": bool(consistent), "frames_checksummed": n}}
+    b.close()
+    return res
 
 
 def leg_intra4k(args, lib, model_for, HipBatch, n4k=384, steps=3):
@@ -1167,7 +1278,8 @@ def leg_tiles4k(args, lib, model_for, HipBatch, n4k=384, steps=3):
     out = {"workload": f"{w}x{h} --tiles 4x2 (BASELINE config 5 on ONE GPU; tiles imply --no-wpp as in kvazaar) all-intra ultrafast CTU pass, QP {args.qp}, "
                        f"{n4k} pictures = {8 * n4k} tile chains resident, {steps} steps", "value": steps * n4k * ctus_pf / s, "unit": "CTUs/s",
            "fps": steps * n4k / s, "kernel_ms": k_s * 1e3,
-           "roofline": leg_roofline("intra4k", "intra_ctu_ticket_kernel", BYTES_PER_CTU, n4k * ctus_pf, k_s),
+           "units_per_launch": n4k * ctus_pf, "dispatches_per_step": len(tb),
+           "roofline": leg_roofline("tiles4k" if pmc_leg("tiles4k") else "intra4k", "intra_ctu_ticket_kernel", BYTES_PER_CTU, n4k * ctus_pf, k_s),
            "verified": bool(v["copies_consistent"] and v["golden_ok"] is not False), "verify": v}
     for b, _ in tb:
         b.close()

@@ -40,6 +40,12 @@ void           kvz_hip_batch_destroy(kvz_hip_batch *b);
 
 /* Host <-> HBM.  Planes are tightly packed (stride = width; chroma width/2 x height/2). */
 void kvz_hip_batch_upload(kvz_hip_batch *b, int frame, const uint8_t *y, const uint8_t *u, const uint8_t *v);
+/* All n_frames pictures at once, asynchronously: `src` holds them back to back, each Y | U | V tightly packed (kvz_image_alloc's planar buffer, image.c:62-95),
+ * preferably in kvz_hip_host_alloc'ed memory.  The copy runs on a queue of its own and starts when the batch's LAST pass has ended -- the pass is the only reader
+ * of the source pictures (SAO's statistics aside: not while kvz_hip_batch_loop_filters with sao is in flight) -- so it overlaps the batch's own deblocking and
+ * entropy coding and another batch's pass; the batch's NEXT kvz_hip_intra_frames waits for it.  `src` must stay untouched until that pass has been synced.
+ * What a host feeding the device from its reader thread (encoder.c / input frame queue) does per batch instead of n_frames synchronous uploads. */
+void kvz_hip_batch_upload_all_async(kvz_hip_batch *b, const uint8_t *src);
 /* Any output pointer may be NULL.  coeff: KVZ_HIP_CTU_COEFFS int16 per CTU (raster CTU order, lcu_t z-order inside);
  * cu_depth / cu_mode: one byte per 8x8 block (raster, stride width/8); ctu_cost: one double per CTU.
  * Returns 0, or -1 when the run that produced the data was invalid (see kvz_hip_batch_sync). */

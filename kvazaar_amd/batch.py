@@ -86,6 +86,13 @@ class HipBatch:
         ys, cs = self.w * self.h, self.w * self.h // 4
         self.lib.kvz_hip_batch_upload(self.handle, frame, ptr(yuv), ptr(yuv, offset=ys), ptr(yuv, offset=ys + cs))
 
+    def upload_all_async(self, src_ptr):
+        """kvz_hip_batch_upload_all_async: all n pictures (back to back, Y | U | V each) from host memory at address `src_ptr` -- pinned_bytes() -- on the batch's upload
+        queue; starts when the batch's last pass has ended, the next launch waits for it"""
+        self.lib.kvz_hip_batch_upload_all_async.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.kvz_hip_batch_upload_all_async.restype = None
+        self.lib.kvz_hip_batch_upload_all_async(self.handle, src_ptr)
+
     def launch(self, model):
         """asynchronous on the batch's stream; returns the number of kernel launches"""
         return self.lib.kvz_hip_intra_frames(self.handle, C.byref(model))

@@ -17,6 +17,9 @@ struct kvz_hip_batch {
   int n_frames;
   hipStream_t stream;
   hipEvent_t ev0, ev1;
+  hipStream_t up_stream = nullptr;  // kvz_hip_batch_upload_all_async: the copy engine's queue, and the event the next pass waits for
+  hipEvent_t ev_up = nullptr;
+  int up_pending = 0;
   uint8_t *d_src, *d_rec, *d_depth, *d_mode;
   uint8_t *d_part, *d_mode4;  // search_nxn: NxN flag per 8x8 CU, luma mode per 4x4 unit (allocated with the first model that has it set)
   int16_t *d_coeff, *d_scratch;
@@ -255,6 +258,7 @@ void kvz_hip_batch_destroy(kvz_hip_batch *b)
   (void)hipFree(b->d_border); (void)hipFree(b->d_items); (void)hipFree(b->d_items_raster); (void)hipFree(b->d_done); (void)hipFree(b->d_ticket); (void)hipFree(b->d_prof); (void)hipFree(b->d_entropy); (void)hipFree(b->d_rdoq);
   (void)hipFree(b->d_src); (void)hipFree(b->d_rec); (void)hipFree(b->d_coeff); (void)hipFree(b->d_scratch); (void)hipFree(b->d_depth); (void)hipFree(b->d_mode); (void)hipFree(b->d_cost); (void)hipFree(b->d_part); (void)hipFree(b->d_mode4);
   (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1);
+  if (b->up_stream) { (void)hipStreamSynchronize(b->up_stream); (void)hipEventDestroy(b->ev_up); (void)hipStreamDestroy(b->up_stream); }
   (void)hipStreamDestroy(b->stream);
   delete b;
 }
@@ -270,6 +274,21 @@ void kvz_hip_batch_upload(kvz_hip_batch *b, int frame, const uint8_t *y, const u
   KVZ_HIP_CHECK(hipMemcpyAsync(dst + ys, u, cs, hipMemcpyHostToDevice, b->stream));
   KVZ_HIP_CHECK(hipMemcpyAsync(dst + ys + cs, v, cs, hipMemcpyHostToDevice, b->stream));
   KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+}
+
+void kvz_hip_batch_upload_all_async(kvz_hip_batch *b, const uint8_t *src)
+{
+  kvz::batch_enter(b);
+  if (!b->up_stream) {
+    KVZ_HIP_CHECK(hipStreamCreateWithFlags(&b->up_stream, hipStreamNonBlocking));
+    KVZ_HIP_CHECK(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
+  }
+  // the source pictures are only read by the CTU pass (and by SAO's statistics): the copy may start as soon as the batch's last pass has ended (ev1; a no-op
+  // before the first pass), whatever its stream still holds behind it -- deblocking, the entropy coder, downloads
+  KVZ_HIP_CHECK(hipStreamWaitEvent(b->up_stream, b->ev1, 0));
+  KVZ_HIP_CHECK(hipMemcpyAsync(b->d_src, src, (size_t)b->n_frames * b->F.frame_px, hipMemcpyHostToDevice, b->up_stream));
+  KVZ_HIP_CHECK(hipEventRecord(b->ev_up, b->up_stream));
+  b->up_pending = 1;
 }
 
 int kvz_hip_batch_download(kvz_hip_batch *b, int frame, uint8_t *rec_y, uint8_t *rec_u, uint8_t *rec_v, int16_t *coeff, uint8_t *cu_depth,
@@ -351,6 +370,7 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
   kvz::ctu_model_from(model, &cm);
   cm.entropy_fbits = b->d_entropy;
   cm.ctx_init = (const uint8_t *)(b->d_entropy + 128);
+  if (b->up_pending) { KVZ_HIP_CHECK(hipStreamWaitEvent(b->stream, b->ev_up, 0)); b->up_pending = 0; }  // pictures on their way (kvz_hip_batch_upload_all_async)
   KVZ_HIP_CHECK(hipMemcpyAsync(b->d_entropy, model->entropy_fbits, 128 * sizeof(float), hipMemcpyHostToDevice, b->stream));
   KVZ_HIP_CHECK(hipMemcpyAsync(b->d_entropy + 128, model->ctx_init, sizeof model->ctx_init, hipMemcpyHostToDevice, b->stream));
   // argument errors are reported, not fatal (a HIP failure still aborts: there is no error channel for it and no CPU path to fall back to)

@@ -226,3 +226,31 @@ def test_two_geometries_side_by_side_on_their_shares_of_the_device(oracle, hipli
     finally:
         for b in batches:
             b.close()
+
+
+def test_upload_all_async_feeds_the_next_pass(oracle, hiplib):
+    """kvz_hip_batch_upload_all_async: a batch that has run a pass on one set of pictures gets another set from pinned host memory on its upload queue; the next pass
+    (launched right behind, with no host synchronisation in between) waits for the copy and its results are those of the NEW pictures, frame for frame"""
+    from kvazaar_amd.batch import HipBatch, pinned_bytes, pinned_free
+    w, h, n = 200, 136, 6
+    model = _model(hiplib, oracle, 27)
+    first = cc.yuv_frames(w, h, n, 3, "small")
+    second = cc.yuv_frames(w, h, n, 11, "small")
+    assert any(not np.array_equal(a, b) for a, b in zip(first, second))
+    b = HipBatch(hiplib, w, h, n)
+    fb = w * h * 3 // 2
+    ptr_, view = pinned_bytes(hiplib, n * fb)
+    try:
+        for i, f in enumerate(first):
+            b.upload(i, f)
+        b.launch(model)
+        for i, f in enumerate(second):
+            view[i * fb:(i + 1) * fb] = f
+        b.upload_all_async(ptr_)  # queued behind the pass in flight
+        b.launch(model)
+        b.sync()
+        for i, f in enumerate(second):
+            assert not cc.compare(cc.run_oracle(oracle, model, w, h, f), b.download(i)), i
+    finally:
+        b.close()
+        pinned_free(hiplib, ptr_)

@@ -22,6 +22,12 @@ with open(yuv, "wb") as f:
     for i in range(frames):
         f.write(distinct[i % 8])
 threads = len(os.sched_getaffinity(0))
+try:  # the CPUs the container is granted (cgroup v2), not the ones it can see: both encoders get that many threads
+    quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+    if quota != "max":
+        threads = max(1, min(threads, int(int(quota) / int(period))))
+except (OSError, ValueError):
+    pass
 
 
 def run(binary, extra, env=None):

@@ -4,13 +4,14 @@ divided by the leg's units (CTUs or pictures; `units_per_launch` of the JSON `be
 usage: tools/make_pmc_leg_json.py <tag> <leg>"""
 import collections, csv, glob, json, sys
 tag, leg = sys.argv[1], sys.argv[2]
-KERNELS = {"inter": ["inter_ctu_ticket_kernel"], "medium": ["intra_ctu_ticket_kernel"], "intra4k": ["intra_ctu_ticket_kernel"], "entropy": ["dev_entropy_"]}[leg]
-units = None
+KERNELS = {"inter": ["inter_ctu_ticket_kernel"], "medium": ["intra_ctu_ticket_kernel"], "intra4k": ["intra_ctu_ticket_kernel"], "tiles4k": ["intra_ctu_ticket_kernel"], "entropy": ["dev_entropy_"]}[leg]
+units, dps = None, 1  # dps: dispatches of the leg's kernel per invocation (the tiled leg launches one batch per tile size side by side)
 for line in open(f"gpurun_out/{tag}_{leg}_pmc_a.log"):
     line = line.strip()
     if line.startswith("{"):
         try:
             units = json.loads(line).get("units_per_launch")
+            dps = json.loads(line).get("dispatches_per_step", 1)
         except ValueError:
             pass
 per_unit, launches = {}, {}
@@ -23,7 +24,7 @@ for p in sorted(glob.glob(f"gpurun_out/{tag}_{leg}_pmc_*/**/*counter_collection.
     names = sorted({k for k, _ in next(iter(disp.values()), set())})
     for c in acc:
         # invocations of the leg inside one process = dispatches of the first kernel name
-        n_inv = max(1, len([1 for k, _ in disp[c] if k == names[0]])) if names else 1
+        n_inv = max(1, len([1 for k, _ in disp[c] if k == names[0]]) // dps) if names else 1
         per_unit[c] = acc[c] / n_inv / units if units else None
         launches[c] = n_inv
 durations = {}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# On the GPU box: the counters of one auxiliary leg of bench.py (inter | medium | intra4k | entropy) -> gpurun_out/<tag>_pmc_leg_<leg>.json (copy to profiles/): three
+# On the GPU box: the counters of one auxiliary leg of bench.py (inter | medium | intra4k | tiles4k | entropy) -> gpurun_out/<tag>_pmc_leg_<leg>.json (copy to profiles/): three
 # rocprofv3 --pmc passes (SQ issue / wait, FETCH_SIZE, WRITE_SIZE; no trace domains) of `python bench.py --only <leg>`, then a --kernel-trace --stats pass for the durations.
 # usage: tools/pmc_leg.sh <tag> <leg>
 tag=$1; leg=$2
