@@ -1092,12 +1092,16 @@ def chain_full(pair, model, qp, reps, gold, n_distinct, src_ptr=None):
     for i in range(turns):
         nxt = pair[(i + 1) % len(pair)]
         more = i + 1 < turns
+        if src_ptr is not None and i + len(pair) < turns:
+            # the pictures of cur's NEXT pass, which is due one turn from now, 65 ms after nxt's pass has ended: the copy (84 ms on the copy engine) waits on the device
+            # for the end of cur's pass in flight -- the only reader of the source pictures -- and runs beside cur's coder and the start of nxt's pass.  Nothing on the
+            # chain may queue a host-to-device copy of its own behind it: the coder computes its offset lists on the device, the pass keeps the model's tables, the
+            # hand-off check reads a pinned word (tools/chain_h2d_trace.sh shows what each of those cost)
+            cur.upload_all_async(src_ptr)
+            uploads[0] += 1
         last[id(cur)] = cur.entropy_code(model, then=(nxt, model) if more else None)  # waits for cur's pass + deblocking, codes, starts nxt's pass, downloads
         if more:
             nxt.deblock(qp, wait=False)  # queued behind the pass the call above started
-        if src_ptr is not None and i + len(pair) < turns:
-            cur.upload_all_async(src_ptr)  # the pictures of cur's NEXT pass: its last pass is long over, so the copy runs beside nxt's pass; that next pass waits for it
-            uploads[0] += 1
         cur = nxt
     s_full = time.perf_counter() - t
     pictures = reps * sum(b.n for b in pair)

@@ -44,7 +44,10 @@ void kvz_hip_batch_upload(kvz_hip_batch *b, int frame, const uint8_t *y, const u
  * preferably in kvz_hip_host_alloc'ed memory.  The copy runs on a queue of its own and starts when the batch's LAST pass has ended -- the pass is the only reader
  * of the source pictures (SAO's statistics aside: not while kvz_hip_batch_loop_filters with sao is in flight) -- so it overlaps the batch's own deblocking and
  * entropy coding and another batch's pass; the batch's NEXT kvz_hip_intra_frames waits for it.  `src` must stay untouched until that pass has been synced.
- * What a host feeding the device from its reader thread (encoder.c / input frame queue) does per batch instead of n_frames synchronous uploads. */
+ * What a host feeding the device from its reader thread (encoder.c / input frame queue) does per batch instead of n_frames synchronous uploads.
+ * All batches of a device share ONE upload queue.  The HIP runtime runs a process's streams on GPU_MAX_HW_QUEUES hardware queues (default 4) and streams sharing one
+ * wait for each other: a double-buffered chain (two batches, the entropy coder's side stream, the upload queue, the calling thread's own stream) needs more, so the
+ * library sets GPU_MAX_HW_QUEUES=8 when it is loaded unless the variable is already set -- effective when that happens before the process's first HIP call. */
 void kvz_hip_batch_upload_all_async(kvz_hip_batch *b, const uint8_t *src);
 /* Any output pointer may be NULL.  coeff: KVZ_HIP_CTU_COEFFS int16 per CTU (raster CTU order, lcu_t z-order inside);
  * cu_depth / cu_mode: one byte per 8x8 block (raster, stride width/8); ctu_cost: one double per CTU.

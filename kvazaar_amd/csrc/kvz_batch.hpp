@@ -17,8 +17,7 @@ struct kvz_hip_batch {
   int n_frames;
   hipStream_t stream;
   hipEvent_t ev0, ev1;
-  hipStream_t up_stream = nullptr;  // kvz_hip_batch_upload_all_async: the copy engine's queue, and the event the next pass waits for
-  hipEvent_t ev_up = nullptr;
+  hipEvent_t ev_up = nullptr;  // kvz_hip_batch_upload_all_async: what the next pass waits for
   int up_pending = 0;
   uint8_t *d_src, *d_rec, *d_depth, *d_mode;
   uint8_t *d_part, *d_mode4;  // search_nxn: NxN flag per 8x8 CU, luma mode per 4x4 unit (allocated with the first model that has it set)
@@ -30,6 +29,9 @@ struct kvz_hip_batch {
   float *d_entropy;  // the model's entropy_fbits [128 floats] followed by its ctx_init [160 bytes] of the run in flight
   uint32_t *d_items, *d_items_raster;  // ticket order with WPP (anti-diagonals) / without (raster order per picture)
   unsigned *d_ticket, *d_done, *d_error;
+  unsigned *h_error = nullptr;  // pinned: the error word as the last pass left it, copied behind every pass on the batch's stream (batch_check reads it without a copy of its own)
+  float last_entropy[128 + 40];  // the price table and initial contexts d_entropy holds (a launch with the same model skips the copy)
+  int entropy_valid = 0;
   unsigned total_items, epoch;
   int sched_ticket, grid_ticket;
   int slots_per_cu, cus;  // what the persistent pass may occupy at most (occupancy x CU count); grid_ticket = its share of that (kvz_hip_batch_set_device_share)
@@ -52,8 +54,8 @@ inline void batch_enter(const kvz_hip_batch *b) { KVZ_HIP_CHECK(hipSetDevice(b->
 inline int batch_check(kvz_hip_batch *b)
 {
   if (b->sched_ticket && !b->failed) {
-    unsigned err = 0;
-    KVZ_HIP_CHECK(hipMemcpy(&err, b->d_error, sizeof err, hipMemcpyDeviceToHost));
+    // a synchronous hipMemcpy here waited for everything the copy engine held -- 84 ms of another batch's pictures on their way up in the double-buffered chain
+    const unsigned err = *(volatile unsigned *)b->h_error;
     if (err) {
       b->failed = 1;
       fprintf(stderr, "kvz_hip: a CTU hand-off wait timed out (KVZ_HIP_WAIT_MS to raise the bound) -- the results of this batch are invalid\n");
@@ -231,6 +233,8 @@ kvz_hip_batch *kvz_hip_batch_create_on(int device, int width, int height, int n_
     KVZ_HIP_CHECK(hipMalloc((void **)&b->d_ticket, 2 * sizeof(unsigned)));
     KVZ_HIP_CHECK(hipMemsetAsync(b->d_ticket, 0, 2 * sizeof(unsigned), b->stream));
     b->d_error = b->d_ticket + 1;
+    KVZ_HIP_CHECK(hipHostMalloc((void **)&b->h_error, 64, hipHostMallocDefault));
+    *b->h_error = 0;
     const char *e = getenv("KVZ_HIP_SCHED");  // "wave": one launch per anti-diagonal (the simpler schedule, kept for A/B)
     b->sched_ticket = !(e && e[0] == 'w') && n_frames < 65536 && F.wc < 256 && F.hc < 256;
     int per_cu = 0, dev = 0, cus = 0;
@@ -258,7 +262,8 @@ void kvz_hip_batch_destroy(kvz_hip_batch *b)
   (void)hipFree(b->d_border); (void)hipFree(b->d_items); (void)hipFree(b->d_items_raster); (void)hipFree(b->d_done); (void)hipFree(b->d_ticket); (void)hipFree(b->d_prof); (void)hipFree(b->d_entropy); (void)hipFree(b->d_rdoq);
   (void)hipFree(b->d_src); (void)hipFree(b->d_rec); (void)hipFree(b->d_coeff); (void)hipFree(b->d_scratch); (void)hipFree(b->d_depth); (void)hipFree(b->d_mode); (void)hipFree(b->d_cost); (void)hipFree(b->d_part); (void)hipFree(b->d_mode4);
   (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1);
-  if (b->up_stream) { (void)hipStreamSynchronize(b->up_stream); (void)hipEventDestroy(b->ev_up); (void)hipStreamDestroy(b->up_stream); }
+  if (b->h_error) (void)hipHostFree(b->h_error);
+  if (b->ev_up) { (void)hipEventSynchronize(b->ev_up); (void)hipEventDestroy(b->ev_up); }
   (void)hipStreamDestroy(b->stream);
   delete b;
 }
@@ -276,18 +281,31 @@ void kvz_hip_batch_upload(kvz_hip_batch *b, int frame, const uint8_t *y, const u
   KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
 }
 
+namespace kvz {
+// ONE upload queue per device, shared by its batches: the runtime multiplexes streams onto four hardware queues, and a stream that lands on the queue of an upload
+// stream waits for the copy in front of it (a fifth stream -- two batches, the coder's side stream, an upload stream per batch -- made the coder's kernels wait 84 ms
+// for another batch's pictures: tools/chain_h2d_trace.sh)
+inline hipStream_t upload_stream(int device)
+{
+  static std::mutex lock;
+  static hipStream_t streams[64] = {};
+  std::lock_guard<std::mutex> guard(lock);
+  hipStream_t &st = streams[device & 63];
+  if (!st) KVZ_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  return st;
+}
+}  // namespace kvz
+
 void kvz_hip_batch_upload_all_async(kvz_hip_batch *b, const uint8_t *src)
 {
   kvz::batch_enter(b);
-  if (!b->up_stream) {
-    KVZ_HIP_CHECK(hipStreamCreateWithFlags(&b->up_stream, hipStreamNonBlocking));
-    KVZ_HIP_CHECK(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
-  }
+  const hipStream_t up = kvz::upload_stream(b->device);
+  if (!b->ev_up) KVZ_HIP_CHECK(hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming));
   // the source pictures are only read by the CTU pass (and by SAO's statistics): the copy may start as soon as the batch's last pass has ended (ev1; a no-op
   // before the first pass), whatever its stream still holds behind it -- deblocking, the entropy coder, downloads
-  KVZ_HIP_CHECK(hipStreamWaitEvent(b->up_stream, b->ev1, 0));
-  KVZ_HIP_CHECK(hipMemcpyAsync(b->d_src, src, (size_t)b->n_frames * b->F.frame_px, hipMemcpyHostToDevice, b->up_stream));
-  KVZ_HIP_CHECK(hipEventRecord(b->ev_up, b->up_stream));
+  KVZ_HIP_CHECK(hipStreamWaitEvent(up, b->ev1, 0));
+  KVZ_HIP_CHECK(hipMemcpyAsync(b->d_src, src, (size_t)b->n_frames * b->F.frame_px, hipMemcpyHostToDevice, up));
+  KVZ_HIP_CHECK(hipEventRecord(b->ev_up, up));
   b->up_pending = 1;
 }
 
@@ -371,8 +389,19 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
   cm.entropy_fbits = b->d_entropy;
   cm.ctx_init = (const uint8_t *)(b->d_entropy + 128);
   if (b->up_pending) { KVZ_HIP_CHECK(hipStreamWaitEvent(b->stream, b->ev_up, 0)); b->up_pending = 0; }  // pictures on their way (kvz_hip_batch_upload_all_async)
-  KVZ_HIP_CHECK(hipMemcpyAsync(b->d_entropy, model->entropy_fbits, 128 * sizeof(float), hipMemcpyHostToDevice, b->stream));
-  KVZ_HIP_CHECK(hipMemcpyAsync(b->d_entropy + 128, model->ctx_init, sizeof model->ctx_init, hipMemcpyHostToDevice, b->stream));
+  {  // the model's tables: copied when they differ from what the device holds (a small host-to-device copy waits behind whatever the copy engine is busy with)
+    static_assert(sizeof model->ctx_init <= 40 * sizeof(float), "last_entropy");
+    float now[128 + 40] = { 0 };
+    memcpy(now, model->entropy_fbits, 128 * sizeof(float));
+    memcpy(now + 128, model->ctx_init, sizeof model->ctx_init);
+    if (!b->entropy_valid || memcmp(now, b->last_entropy, sizeof now) != 0) {
+      KVZ_HIP_CHECK(hipMemcpyAsync(b->d_entropy, model->entropy_fbits, 128 * sizeof(float), hipMemcpyHostToDevice, b->stream));
+      KVZ_HIP_CHECK(hipMemcpyAsync(b->d_entropy + 128, model->ctx_init, sizeof model->ctx_init, hipMemcpyHostToDevice, b->stream));
+      KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));  // the sources are the caller's: staged before this call returns
+      memcpy(b->last_entropy, now, sizeof now);
+      b->entropy_valid = 1;
+    }
+  }
   // argument errors are reported, not fatal (a HIP failure still aborts: there is no error channel for it and no CPU path to fall back to)
   if (!b->sched_ticket && (cm.search_32x32 || cm.rdoq || cm.search_nxn)) { fprintf(stderr, "kvz_hip_intra_frames: search_32x32 / rdoq / search_nxn need the ticket schedule\n"); return -1; }
   if (!b->sched_ticket && cm.no_wpp) { fprintf(stderr, "kvz_hip_intra_frames: the one-launch-per-diagonal schedule (KVZ_HIP_SCHED=wave) needs WPP\n"); return -1; }
@@ -401,6 +430,7 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
     else hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel<false>, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);
     KVZ_HIP_CHECK(hipGetLastError());
     KVZ_HIP_CHECK(hipEventRecord(b->ev1, b->stream));
+    KVZ_HIP_CHECK(hipMemcpyAsync(b->h_error, b->d_error, sizeof(unsigned), hipMemcpyDeviceToHost, b->stream));  // what batch_check reads once the stream has drained
     return 1;
   }
   KVZ_HIP_CHECK(hipEventRecord(b->ev0, b->stream));
@@ -436,6 +466,7 @@ int kvz_hip_batch_reset(kvz_hip_batch *b)
   kvz::batch_enter(b);
   KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
   KVZ_HIP_CHECK(hipMemset(b->d_error, 0, sizeof(unsigned)));
+  *b->h_error = 0;
   b->failed = 0;
   return 0;
 }

@@ -1585,9 +1585,9 @@ inline void entropy_b_slice_contexts(int qp, uint8_t out[KVZ_ENTROPY_CTXS])
 struct EntropyScratch {
   std::mutex lock;
   struct Buf { void *p = nullptr; size_t bytes = 0; };
-  Buf bins, nbins, nbits, sizes, ins, offsets, bound_offsets, rowctx, scratch, out, not_last;
+  Buf bins, nbins, nbits, sizes, ins, offsets, bound_offsets, room, rowctx, scratch, out, not_last;
   hipStream_t side = nullptr;          // stage 2 beside stage 1's second part
-  hipEvent_t ev_first = nullptr, ev_rows = nullptr;
+  hipEvent_t ev_first = nullptr, ev_rows = nullptr, ev_pre = nullptr;  // ev_pre: everything in front of stage 3 has run (see chain_queued)
   static void *need(Buf &b, size_t bytes)
   {
     if (bytes > b.bytes) {
@@ -1673,7 +1673,13 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
       }
       d_scratch = (uint8_t *)S.need(S.scratch, scratch_bytes ? scratch_bytes : 16);
       mark("host: bounds");
-      KVZ_HIP_CHECK(hipMemcpyAsync(d_bound_offsets, bound_offsets.data(), (size_t)streams * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+      uint32_t *d_room = (uint32_t *)S.need(S.room, (size_t)streams * sizeof(uint32_t));
+      hipLaunchKernelGGL(dev_entropy_stream_room_kernel, dim3((unsigned)((streams + 255) / 256)), dim3(256), 0, stream, d_nbits, streams, per_stream, d_room);
+      hipLaunchKernelGGL(dev_entropy_offsets_kernel, dim3(1), dim3(1024), 0, stream, d_room, streams, d_bound_offsets);  // == bound_offsets, without a copy
+      if (chain_queued && f0 + nf >= n) {
+        if (!S.ev_pre) KVZ_HIP_CHECK(hipEventCreateWithFlags(&S.ev_pre, hipEventDisableTiming));
+        KVZ_HIP_CHECK(hipEventRecord(S.ev_pre, stream));
+      }
       static const int lanes = [] { const char *e = getenv("KVZ_HIP_ENTROPY_LANES"); const int v = e ? atoi(e) : 64; return v == 32 || v == 16 || v == 8 ? v : 64; }();
       uint32_t *d_ins = (uint32_t *)S.need(S.ins, (size_t)streams * sizeof(uint32_t));
       if (!early_rows && !no_wpp) hipLaunchKernelGGL(dev_entropy_row_ctx_kernel<8>, dim3((unsigned)((nf + 7) / 8)), dim3(8), 0, stream, J, device_tables());
@@ -1690,7 +1696,10 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
         hipLaunchKernelGGL(dev_entropy_escape_count_kernel, dim3((unsigned)streams), dim3(256), 0, stream, d_scratch, d_bound_offsets, d_sizes, d_ins);
       }
       // from here on the device is nearly idle -- stage 3 is a few hundred wavefronts on their own chains, then a copy --: the caller's moment to queue other work
-      if (chain_queued && f0 + nf >= n) chain_queued();
+      // The caller's work is a persistent pass that takes every free workgroup slot the moment it starts: stage 3 must have its slots first (it then runs 39 ms beside
+      // the pass; started behind it, it waits 310 ms for the pass to end).  So the pass is queued only when everything in front of stage 3 has run -- stage 3 is then
+      // dispatched at once, the pass a launch latency later.
+      if (chain_queued && f0 + nf >= n) { KVZ_HIP_CHECK(hipEventSynchronize(S.ev_pre)); chain_queued(); }
       sizes.resize((size_t)streams);
       KVZ_HIP_CHECK(hipMemcpyAsync(sizes.data(), d_sizes, (size_t)streams * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       KVZ_HIP_CHECK(hipStreamSynchronize(stream));
@@ -1703,7 +1712,7 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
         rc = -1;
       } else {
         d_out = (uint8_t *)S.need(S.out, chunk_bytes ? chunk_bytes : 1);
-        KVZ_HIP_CHECK(hipMemcpyAsync(d_offsets, offsets.data(), (size_t)streams * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(dev_entropy_offsets_kernel, dim3(1), dim3(1024), 0, stream, d_sizes, streams, d_offsets);  // == offsets, without a copy
         hipLaunchKernelGGL(dev_entropy_compact_kernel, dim3((unsigned)streams), dim3(256), 0, stream, d_scratch, d_bound_offsets, d_sizes, d_ins, d_offsets, d_out);
         KVZ_HIP_CHECK(hipGetLastError());
         KVZ_HIP_CHECK(hipMemcpyAsync(out + total, d_out, chunk_bytes, hipMemcpyDeviceToHost, stream));

@@ -984,6 +984,38 @@ __global__ void __launch_bounds__(256) dev_entropy_compact_kernel(const u8 *src,
   __syncthreads();
   entropy_escape_chunk(s, lo, hi, d + lo + before[threadIdx.x]);
 }
+// Where every substream starts, on the device: the exclusive prefix sum of a per-substream byte count -- the worst-case room of a substream's code (the bound of each
+// of its per_stream CTUs' bits, rounded as the host's scratch_bytes loop rounds it: dev_entropy_stream_room_kernel) or its final size.  The host used to compute both lists
+// and copy them up, and a small host-to-device copy queues behind whatever the copy engine holds -- the next batch's pictures on their way (kvz_hip_batch_upload_all_async).
+__global__ void __launch_bounds__(256) dev_entropy_stream_room_kernel(const u32 *bits, long streams, long per_stream, u32 *room)
+{
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= streams) return;
+  unsigned long long b = 0;
+  for (long k = 0; k < per_stream; k++) b += bits[i * per_stream + k];
+  room[i] = (u32)((((b + 7) / 8 + 16) * 3 / 2 + 15) & ~15ull);
+}
+__global__ void __launch_bounds__(1024) dev_entropy_offsets_kernel(const u32 *bytes, long streams, unsigned long long *offsets)  // one workgroup
+{
+  __shared__ unsigned long long part[1024];
+  // thread t takes the entries t, t + 1024, ... of every block of 1024 x `rounds`: coalesced reads; the scan runs block by block with a running base
+  unsigned long long base = 0;
+  for (long at = 0; at < streams; at += 1024) {
+    const long i = at + threadIdx.x;
+    const unsigned long long v = i < streams ? bytes[i] : 0;
+    part[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {  // inclusive scan of the block
+      const unsigned long long w = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0;
+      __syncthreads();
+      part[threadIdx.x] += w;
+      __syncthreads();
+    }
+    if (i < streams) offsets[i] = base + part[threadIdx.x] - v;
+    base += part[1023];
+    __syncthreads();
+  }
+}
 #endif
 
 }  // namespace kvz

@@ -83,6 +83,13 @@ inline void runtime_once(int device)
   });
 }
 
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues per device, four by default; streams that share one run in its order.  The
+// double-buffered chain has five in flight (two batches, the coder's side stream, the upload queue, the thread's own): with four queues the coder's kernels sat behind
+// 84 ms of another batch's pictures on their way up (tools/chain_h2d_trace.sh; with eight the upload costs nothing).  The runtime reads the variable when it initialises,
+// at the first HIP call of the process: the library asks for eight when it is loaded, unless the host has set the variable itself.
+struct HwQueuesDefault { HwQueuesDefault() { setenv("GPU_MAX_HW_QUEUES", "8", 0); } };
+static HwQueuesDefault g_hw_queues_default;
+
 // Every entry point that touches HIP starts here (directly or through be()): the first caller of the process picks the default device (device < 0: $KVZ_HIP_DEVICE,
 // else $LOCAL_RANK -- one process per GPU under torch.distributed.run --, else 0); a thread that has not chosen a device yet (kvz_hip_set_thread_device, or a call
 // on a batch, which binds the thread to the batch's device) is bound to the default.  A bound thread keeps the device it last selected.
