@@ -2441,19 +2441,74 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   // 10 / 26 post-filter) minus source, 4x4 Hadamard, (sum + 1) >> 1 (picture-generic.c:117-208).  One lane, everything in registers.
   KVZ_DEV u32 pu_mode_satd(int mode, int xl, int yl) const
   {
+    // One lane per mode, and what a lane does per sample is as little as the mode allows: the references it can touch come into registers once (an angular mode:
+    // the thirteen samples ref_main[-4 .. 8] of intra-generic.c:82-104, packed into four words; a row of the block is then five consecutive bytes of them), the
+    // horizontal modes run on the transposed problem (the sum of the Hadamard magnitudes of a block and of its transpose are the same).  The per-sample routine
+    // (predict_pixel) decided the mode's class, its references and its projection again for each of the sixteen samples.
+    const u8 *top = s->ref[0][0], *left = s->ref[0][1];
+    u32 o[4];
+    for (int r = 0; r < 4; r++) __builtin_memcpy(&o[r], org_at(0, xl, yl + r), 4);
+    int p[4][4];
+    if (mode == 0) {  // intra-generic.c:165-201
+      const int tr = top[5], bl = left[5];
+      int t4[4], l4[4];
+      for (int i = 0; i < 4; i++) { t4[i] = top[i + 1]; l4[i] = left[i + 1]; }
+#pragma unroll
+      for (int y = 0; y < 4; y++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) p[y][x] = ((3 - x) * l4[y] + (x + 1) * tr + (3 - y) * t4[x] + (y + 1) * bl + 4) >> 3;
+    } else if (mode == 1) {  // intra-generic.c:210-241
+      const int dc = s->dcval[0];
+#pragma unroll
+      for (int y = 0; y < 4; y++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) p[y][x] = dc;
+      p[0][0] = ((int)left[1] + 2 * dc + (int)top[1] + 2) >> 2;
+#pragma unroll
+      for (int i = 1; i < 4; i++) { p[0][i] = ((int)top[i + 1] + 3 * dc + 2) >> 2; p[i][0] = ((int)left[i + 1] + 3 * dc + 2) >> 2; }
+    } else {  // intra-generic.c:49-155 (and the edge filter of the pure horizontal / vertical mode, intra.c:207-219)
+      const bool vertical = mode >= 18;
+      const u8 *main_ref = vertical ? top : left, *side_ref = vertical ? left : top;
+      const int disp = s->mode_disp[mode], inv = s->mode_inv[mode];
+      u32 m0, m1, m2, s0, s1;
+      __builtin_memcpy(&m0, main_ref, 4); __builtin_memcpy(&m1, main_ref + 4, 4); __builtin_memcpy(&m2, main_ref + 8, 4);
+      __builtin_memcpy(&s0, side_ref, 4); __builtin_memcpy(&s1, side_ref + 4, 4);
+      // E[k] = ref_main[k - 4]: three projected samples (only reached by the modes whose projection stays inside the side reference), then main_ref[0 ..]
+      const u32 e0 = side_ref[(128 + 3 * inv) >> 8], e1 = side_ref[(128 + 2 * inv) >> 8], e2 = side_ref[(128 + inv) >> 8];
+      const u32 w0 = e0 | (e1 << 8) | (e2 << 16) | (m0 << 24), w1 = (m0 >> 8) | (m1 << 24), w2 = (m1 >> 8) | (m2 << 24), w3 = m2 >> 8;
+      if (!vertical) {  // the transposed source
+        u32 t[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) t[r] = ((o[0] >> (8 * r)) & 0xffu) | (((o[1] >> (8 * r)) & 0xffu) << 8) | (((o[2] >> (8 * r)) & 0xffu) << 16) | (((o[3] >> (8 * r)) & 0xffu) << 24);
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[r] = t[r];
+      }
+      const unsigned long long side5 = ((unsigned long long)s1 << 32) | s0;
+      const int side_0 = (int)(s0 & 0xffu);
+#pragma unroll
+      for (int py = 0; py < 4; py++) {
+        const int dp = (py + 1) * disp, k0 = (dp >> 5) + 4, df = dp & 31, q = k0 >> 2;
+        const u32 lo = q == 0 ? w0 : (q == 1 ? w1 : w2), hi = q == 0 ? w1 : (q == 1 ? w2 : w3);
+        const unsigned long long win = (((unsigned long long)hi << 32) | lo) >> (8 * (k0 & 3));
+        int bb[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) bb[i] = (int)((win >> (8 * i)) & 0xffu);
+#pragma unroll
+        for (int px = 0; px < 4; px++) p[py][px] = ((32 - df) * bb[px] + df * bb[px + 1] + 16) >> 5;
+        if (disp == 0) p[py][0] = iclip(0, 255, p[py][0] + ((((int)((side5 >> (8 * (py + 1))) & 0xffu)) - side_0) >> 1));
+      }
+    }
     int t[4][4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      const u8 *o = org_at(0, xl, yl + r);
-      const int d0 = (int)predict_pixel(2, mode, 0, 0, r) - o[0], d1 = (int)predict_pixel(2, mode, 0, 1, r) - o[1];
-      const int d2 = (int)predict_pixel(2, mode, 0, 2, r) - o[2], d3 = (int)predict_pixel(2, mode, 0, 3, r) - o[3];
+      const int d0 = p[r][0] - (int)(o[r] & 0xffu), d1 = p[r][1] - (int)((o[r] >> 8) & 0xffu), d2 = p[r][2] - (int)((o[r] >> 16) & 0xffu), d3 = p[r][3] - (int)(o[r] >> 24);
       t[r][0] = d0 + d1 + d2 + d3; t[r][1] = d0 - d1 + d2 - d3; t[r][2] = d0 + d1 - d2 - d3; t[r][3] = d0 - d1 - d2 + d3;
     }
     int sum = 0;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-      const int p = t[0][c], q = t[1][c], r = t[2][c], v = t[3][c];
-      sum += iabs(p + q + r + v) + iabs(p - q + r - v) + iabs(p + q - r - v) + iabs(p - q - r + v);
+      const int pp = t[0][c], q = t[1][c], r = t[2][c], v = t[3][c];
+      sum += iabs(pp + q + r + v) + iabs(pp - q + r - v) + iabs(pp + q - r - v) + iabs(pp - q - r + v);
     }
     return (u32)((sum + 1) >> 1);
   }

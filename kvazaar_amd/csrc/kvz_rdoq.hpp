@@ -239,9 +239,10 @@ struct RdoqWaveArgs {
 // rdo.c:358-371: the bypass bins of the escape code of `symbol` with rice parameter g (the loop there finds the length of the exp-Golomb suffix: floor(log2(symbol - 3 * 2^g + 2^g)))
 KVZ_DEV i32 rdoq_escape_bins(i32 symbol, int g)
 {
-  if (symbol < (3 << g)) return (symbol >> g) + 1 + g;
-  const int len = 31 - __builtin_clz((unsigned)(symbol - (3 << g) + (1 << g)));
-  return 3 + len + 1 - g + len;
+  // both forms computed, one selected: the callers' lanes disagree about the branch all the time (symbol >= 0)
+  const i32 pre = (symbol >> g) + 1 + g;
+  const int len = 31 - __builtin_clz((unsigned)imax(1, symbol - (3 << g) + (1 << g)));
+  return symbol < (3 << g) ? pre : 3 + len + 1 - g + len;
 }
 
 // The prices a position's decision reads, per lane: both bins of the greater-1 context of its class (c1 of the class within the group's context set) and of the group's
@@ -258,19 +259,22 @@ KVZ_DEV i32 rdoq_decide(int r, i32 ma, bool last, double c0, double dhi, double 
   const int cls = r < 3 ? 0 : (r < 8 ? 1 : 2), g = cls == 0 ? 0 : (cls == 1 ? r - 3 : r - 8), base_level = 3 - cls;
   const i32 at_base = cls == 0 ? P.one1 + P.abs1 : (cls == 1 ? P.one1 : 0);  // rdo.c:373-380: what the context-coded flags of a level >= base_level cost
   const double sadd = last ? 0.0 : s1;
-  double ccv = 1.7e+308, csv = 0;  // MAX_DOUBLE (global.h)
+  // rdo.c:345-392 kvz_get_ic_rate of a candidate level a >= 1
+  auto rate_of = [&](i32 a) {
+    const i32 hi = rdoq_escape_bins(imax(0, a - base_level), g) * (1 << 15) + at_base, lo = a == 1 ? P.one0 : P.one1 + P.abs0;  // (a == 2 below base_level 3: greater-1 set, greater-2 clear)
+    return (1 << 15) + (a >= base_level ? hi : lo);
+  };
+  // the candidates in the reference's order -- zero (only below 3, never at the last position), max_abs_level, max_abs_level - 1 -- each taken when strictly cheaper;
+  // straight-line on purpose: as a loop over one or two candidates the lanes of a wavefront walked every branch combination
+  const bool zero_ok = !last && ma < 3;
+  double ccv = zero_ok ? c0 + s0 : 1.7e+308, csv = zero_ok ? s0 : 0;  // MAX_DOUBLE (global.h)
   i32 level = 0;
-  if (!last && ma < 3) { csv = s0; ccv = c0 + s0; }
-  const i32 min_abs = ma > 1 ? ma - 1 : 1;
-  for (i32 a = ma; a >= min_abs; a--) {
-    i32 rate = 1 << 15;
-    if (a >= base_level) rate += rdoq_escape_bins(a - base_level, g) * (1 << 15) + at_base;
-    else if (a == 1) rate += P.one0;
-    else rate += P.one1 + P.abs0;  // a == 2 below base_level 3
-    double cur = (a == ma ? dhi : dlo) + lambda * rate;
-    cur += sadd;
-    if (cur < ccv) { level = a; ccv = cur; csv = sadd; }
-  }
+  double cur = dhi + lambda * rate_of(ma);
+  cur += sadd;
+  if (cur < ccv) { level = ma; ccv = cur; csv = sadd; }
+  double cur2 = dlo + lambda * rate_of(imax(1, ma - 1));
+  cur2 += sadd;
+  if (ma > 1 && cur2 < ccv) { level = ma - 1; ccv = cur2; csv = sadd; }
   if (COSTS) { *ccv_out = ccv; *csv_out = csv; }
   return level;
 }
@@ -464,30 +468,59 @@ KVZ_RDOQ_WAVE_FN void rdoq_block_wave(const RdoqWaveArgs c, int lane)
         NZ[t] = __ballot(nz); G1[t] = __ballot(g1); RC[t] = __ballot(rc);
 #endif
       };
-      decide_set(0); decide_set(1);
+      decide_set(0);  // classes 0..3: what a group's first levels can meet; the sets of the moved rice parameter (1) and of the ninth level on (2, 3) when the chain gets there
       KVZ_RQ_PROF(2);
-      // ---- 3. the chain (rdo.c:760-840 for this group), from one level that is coded to the next: positions that stay zero in the class they are met in move nothing
+      // ---- 3. the chain (rdo.c:760-840 for this group), from one EVENT to the next.  Positions that stay zero in the class they are met in move nothing; a coded
+      // level always counts (c1_idx), but it changes the class only when c1 moves (the first levels of a group: 1 -> 2 -> 3, or -> 0 at a level above 1), when the
+      // rice parameter moves, or when it is the eighth: the coded levels between two such events are counted with one s_bcnt1 instead of one step each (a group of
+      // this content holds thirteen coded levels on average and three or four events).
       int c1_idx = 0, go_rice = 0;
       int r = c1 ? c1 - 1 : 3;  // the class the group starts in
       rstates = 0x1111111111111111ull * (unsigned)r;  // every position not met yet: the current class
-      bool have_b = false;
-      for (unsigned rem = coded; rem;) {
-        if (c1_idx >= 8 && !have_b) { decide_set(2); decide_set(3); have_b = true; }
+      unsigned have_sets = 1;
+      unsigned rem = coded;
+      while (rem) {
         const int t = r >> 2, sh = 16 * (r & 3);
-        const unsigned long long nzs = t == 0 ? NZ[0] : (t == 1 ? NZ[1] : (t == 2 ? NZ[2] : NZ[3]));
-        const unsigned nz = (unsigned)(nzs >> sh) & rem;
-        if (!nz) break;
-        const int k = 31 - __builtin_clz(nz);
-        const unsigned long long g1s = t == 0 ? G1[0] : (t == 1 ? G1[1] : (t == 2 ? G1[2] : G1[3])), rcs = t == 0 ? RC[0] : (t == 1 ? RC[1] : (t == 2 ? RC[2] : RC[3]));
-        const unsigned g1 = (unsigned)(g1s >> (sh + k)) & 1u, rc = (unsigned)(rcs >> (sh + k)) & 1u;
-        rem &= (1u << k) - 1u;
+        if (!((have_sets >> t) & 1)) {  // 1: classes 4..7 (the rice parameter has moved), 2: 8..11 (eight levels coded), 3: class 12 (both, the parameter at its cap)
+          if (t == 1) decide_set(1); else if (t == 2) decide_set(2); else decide_set(3);
+          have_sets |= 1u << t;
+        }
+        const unsigned nz16 = (unsigned)((t == 0 ? NZ[0] : (t == 1 ? NZ[1] : (t == 2 ? NZ[2] : NZ[3]))) >> sh) & 0xffffu;
+        const unsigned g116 = (unsigned)((t == 0 ? G1[0] : (t == 1 ? G1[1] : (t == 2 ? G1[2] : G1[3]))) >> sh) & 0xffffu;
+        const unsigned rc16 = (unsigned)((t == 0 ? RC[0] : (t == 1 ? RC[1] : (t == 2 ? RC[2] : RC[3]))) >> sh) & 0xffffu;
+        const unsigned nzr = nz16 & rem;
+        if (!nzr) break;
+        // where the class can change next: with c1 at 1 or 2 at every level, with c1 at 3 at a level above 1, else where the rice parameter moves (below its cap)
+        const unsigned ev = ((c1_idx < 8 && c1 != 0) ? (c1 == 3 ? g116 : nz16) : (go_rice < 4 ? rc16 : 0u)) & nzr;
+        const int e = ev ? 31 - __builtin_clz(ev) : -1;
+        const unsigned above = e < 0 ? nzr : nzr & ~((2u << e) - 1u);  // the coded levels in front of it
+        const int cnt = __builtin_popcount(above);
+        if (c1_idx < 8 && c1_idx + cnt >= 8) {
+          // the eighth level of the group lies among them: the positions behind it are met in class 8 + go_rice.  (c1 is 0 or 3 here -- with c1 at 1 or 2 `above` is
+          // empty -- and none of these levels is above 1 when it is 3: c1 stays.)
+          unsigned x = above;
+          for (int j = 8 - c1_idx; j > 1; j--) x &= ~(1u << (31 - __builtin_clz(x)));
+          const int p = 31 - __builtin_clz(x);
+          c1_idx = 8;
+          rem &= (1u << p) - 1u;
+          const int r2 = 8 + go_rice;
+          const unsigned xr = (unsigned)(r ^ r2) * 0x11111111u;
+          rstates ^= (((unsigned long long)xr << 32) | xr) & ((1ull << (4 * p)) - 1ull);
+          r = r2;
+          continue;
+        }
+        c1_idx += cnt;
+        if (c1 != 0 && cnt) c1 = (g116 & above) ? 0 : imin(3, c1 + cnt);  // (only past the eighth level can these move c1: it matters for the next group's context set)
+        if (e < 0) break;
+        const unsigned bit = 1u << e;
         c1_idx++;
-        go_rice = imin(go_rice + (int)rc, 4);
-        c1 = g1 ? 0 : (c1 == 1 || c1 == 2 ? c1 + 1 : c1);
+        if (rc16 & bit) go_rice = imin(go_rice + 1, 4);
+        c1 = (g116 & bit) ? 0 : (c1 == 1 || c1 == 2 ? c1 + 1 : c1);
+        rem &= bit - 1u;
         const int r2 = c1_idx < 8 ? (c1 ? c1 - 1 : 3 + go_rice) : 8 + go_rice;
-        if (r2 != r) {  // the positions below k are met in the new class
-          const unsigned x = (unsigned)(r ^ r2) * 0x11111111u;
-          rstates ^= (((unsigned long long)x << 32) | x) & ((1ull << (4 * k)) - 1ull);
+        if (r2 != r) {  // the positions below e are met in the new class
+          const unsigned xr = (unsigned)(r ^ r2) * 0x11111111u;
+          rstates ^= (((unsigned long long)xr << 32) | xr) & ((1ull << (4 * e)) - 1ull);
           r = r2;
         }
       }
