@@ -1082,6 +1082,8 @@ def chain_full(pair, model, qp, reps, gold, n_distinct, src_ptr=None):
         b.launch(model)
         b.deblock(qp, wait=False)
         b.entropy_code(model)
+    for b in pair:  # the slice data of a batch comes down beside the next batch's deblocking and coder (13 ms per 1 536 1080p pictures that sat between two passes)
+        b.entropy_defer_download(True)
     last = {}
     uploads = [0]
     t = time.perf_counter()
@@ -1103,7 +1105,11 @@ def chain_full(pair, model, qp, reps, gold, n_distinct, src_ptr=None):
         if more:
             nxt.deblock(qp, wait=False)  # queued behind the pass the call above started
         cur = nxt
+    for b in pair:  # the last downloads
+        b.sync()
     s_full = time.perf_counter() - t
+    for b in pair:
+        b.entropy_defer_download(False)
     pictures = reps * sum(b.n for b in pair)
     ok, nbytes = None, 0
     for b in pair:
@@ -1290,8 +1296,9 @@ def leg_tiles4k(args, lib, model_for, HipBatch, n4k=384, steps=3):
     return out
 
 
-def leg_medium(args, lib, model_for, HipBatch, n_med=96):
-    """BASELINE config 3: `--preset medium` (32x32 search, RDOQ, NxN partitions) at 3840x2160"""
+def leg_medium(args, lib, model_for, HipBatch, n_med=192):
+    """BASELINE config 3: `--preset medium` (32x32 search, RDOQ, NxN partitions) at 3840x2160.  192 pictures resident: a CTU of this pass takes ~20 ms and a 4K picture
+    offers ~17 of them at a time, so the 96 pictures of rounds 4-5 left a quarter of the 1 792 workgroup slots idle (96: 93.7 k CTUs/s, 144: 105 k, 192: 110 k, 384: 115 k)"""
     w, h = 3840, 2160
     d4 = synth_frames(w, h, 4, clip_seed(w, h))
     mm = model_for(args.qp)

@@ -156,6 +156,12 @@ class HipBatch:
             raise BatchError(f"kvz_hip_batch_entropy_code failed ({total})")
         return self._entropy_out[:total], sizes
 
+    def entropy_defer_download(self, on=True):
+        """kvz_hip_batch_entropy_defer_download: entropy_code returns with the slice data's download queued; sync() before reading the bytes"""
+        self.lib.kvz_hip_batch_entropy_defer_download.argtypes = [C.c_void_p, C.c_int]
+        self.lib.kvz_hip_batch_entropy_defer_download.restype = None
+        self.lib.kvz_hip_batch_entropy_defer_download(self.handle, int(bool(on)))
+
     def sao_params(self, frame):
         """-> (luma records, chroma records, merge flags) of one frame, one entry per LCU in raster order"""
         from .capi import SaoParams

@@ -12,6 +12,8 @@
 
 #include "kvz_ctu_kernels.hpp"
 
+namespace kvz { struct DevBuf { void *p = nullptr; size_t bytes = 0; }; }  // a grow-only device buffer (kvz_dev.hpp EntropyScratch::need)
+
 struct kvz_hip_batch {
   kvz::CtuFrames F;
   int n_frames;
@@ -32,6 +34,8 @@ struct kvz_hip_batch {
   unsigned *h_error = nullptr;  // pinned: the error word as the last pass left it, copied behind every pass on the batch's stream (batch_check reads it without a copy of its own)
   float last_entropy[128 + 40];  // the price table and initial contexts d_entropy holds (a launch with the same model skips the copy)
   int entropy_valid = 0;
+  int entropy_deferred = 0;     // kvz_hip_batch_entropy_defer_download: the coder's calls return with the slice data's download queued, not finished
+  kvz::DevBuf entropy_out;      // ... and compact into this buffer of the batch's own instead of the device's shared one
   unsigned total_items, epoch;
   int sched_ticket, grid_ticket;
   int slots_per_cu, cus;  // what the persistent pass may occupy at most (occupancy x CU count); grid_ticket = its share of that (kvz_hip_batch_set_device_share)
@@ -263,6 +267,7 @@ void kvz_hip_batch_destroy(kvz_hip_batch *b)
   (void)hipFree(b->d_src); (void)hipFree(b->d_rec); (void)hipFree(b->d_coeff); (void)hipFree(b->d_scratch); (void)hipFree(b->d_depth); (void)hipFree(b->d_mode); (void)hipFree(b->d_cost); (void)hipFree(b->d_part); (void)hipFree(b->d_mode4);
   (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1);
   if (b->h_error) (void)hipHostFree(b->h_error);
+  if (b->entropy_out.p) (void)hipFree(b->entropy_out.p);
   if (b->ev_up) { (void)hipEventSynchronize(b->ev_up); (void)hipEventDestroy(b->ev_up); }
   (void)hipStreamDestroy(b->stream);
   delete b;

@@ -1584,10 +1584,12 @@ inline void entropy_b_slice_contexts(int qp, uint8_t out[KVZ_ENTROPY_CTXS])
 // scratch of the entropy coder, kept between calls (grow-only; hipMalloc / hipFree per call cost more than a small batch's kernels): one caller at a time
 struct EntropyScratch {
   std::mutex lock;
-  struct Buf { void *p = nullptr; size_t bytes = 0; };
+  using Buf = DevBuf;
   Buf bins, nbins, nbits, sizes, ins, offsets, bound_offsets, room, rowctx, scratch, out, not_last;
   hipStream_t side = nullptr;          // stage 2 beside stage 1's second part
   hipEvent_t ev_first = nullptr, ev_rows = nullptr, ev_pre = nullptr;  // ev_pre: everything in front of stage 3 has run (see chain_queued)
+  hipEvent_t ev_tail = nullptr;        // behind a call's last kernel, when the call returned with its download in flight
+  bool ev_tail_set = false;
   static void *need(Buf &b, size_t bytes)
   {
     if (bytes > b.bytes) {
@@ -1603,11 +1605,15 @@ inline EntropyScratch &entropy_scratch(int device) { static EntropyScratch s[64]
 namespace kvz {
 // The stages of kvz_entropy.hpp over n_frames pictures, in chunks whose bin records fit the scratch budget.  job(f0, nf): the chunk's inputs (everything of EntropyJob but
 // the scratch pointers); not_last: host flags or null.
+// own_out: a compaction buffer of the caller's instead of the shared one (grown here); with `defer` the call returns when the LAST chunk's download has been queued on
+// `stream` -- the caller synchronises the stream before it reads `out` -- which needs such a buffer: the next call, on another stream, compacts into the shared one at once.
 inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc, int hc, int no_wpp, const uint8_t *not_last, const std::function<EntropyJob(int, int)> &job,
-                                  uint8_t *out, size_t capacity, uint32_t *substream_bytes, const std::function<void()> &chain_queued = nullptr)
+                                  uint8_t *out, size_t capacity, uint32_t *substream_bytes, const std::function<void()> &chain_queued = nullptr,
+                                  EntropyScratch::Buf *own_out = nullptr, bool defer = false)
 {
   EntropyScratch &S = entropy_scratch(device);
   std::lock_guard<std::mutex> guard(S.lock);
+  if (S.ev_tail_set) KVZ_HIP_CHECK(hipStreamWaitEvent(stream, S.ev_tail, 0));  // the previous call's last kernels (on its own stream) read scratch this call writes
   static const bool times = getenv("KVZ_HIP_ENTROPY_TIMES") != nullptr;  // developer: host-side phase clock on stderr
   auto t_last = std::chrono::steady_clock::now();
   auto mark = [&](const char *what) { if (!times) return; const auto now = std::chrono::steady_clock::now(); fprintf(stderr, "kvz_hip entropy: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count()); t_last = now; };
@@ -1711,12 +1717,18 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
         fprintf(stderr, "kvz_hip_batch_entropy_code: the output buffer is too small (%zu bytes needed so far)\n", (size_t)(total + chunk_bytes));
         rc = -1;
       } else {
-        d_out = (uint8_t *)S.need(S.out, chunk_bytes ? chunk_bytes : 1);
+        d_out = (uint8_t *)S.need(own_out ? *own_out : S.out, chunk_bytes ? chunk_bytes : 1);
         hipLaunchKernelGGL(dev_entropy_offsets_kernel, dim3(1), dim3(1024), 0, stream, d_sizes, streams, d_offsets);  // == offsets, without a copy
         hipLaunchKernelGGL(dev_entropy_compact_kernel, dim3((unsigned)streams), dim3(256), 0, stream, d_scratch, d_bound_offsets, d_sizes, d_ins, d_offsets, d_out);
         KVZ_HIP_CHECK(hipGetLastError());
+        const bool in_flight = defer && own_out && f0 + nf >= n;
+        if (in_flight) {
+          if (!S.ev_tail) KVZ_HIP_CHECK(hipEventCreateWithFlags(&S.ev_tail, hipEventDisableTiming));
+          KVZ_HIP_CHECK(hipEventRecord(S.ev_tail, stream));
+          S.ev_tail_set = true;
+        }
         KVZ_HIP_CHECK(hipMemcpyAsync(out + total, d_out, chunk_bytes, hipMemcpyDeviceToHost, stream));
-        KVZ_HIP_CHECK(hipStreamSynchronize(stream));
+        if (!in_flight) KVZ_HIP_CHECK(hipStreamSynchronize(stream));
         mark("compact + slice data down");
         memcpy(substream_bytes + (size_t)f0 * rows, sizes.data(), (size_t)streams * sizeof(uint32_t));
         total += chunk_bytes;
@@ -1730,6 +1742,8 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
   return rc ? rc : (long)total;
 }
 }  // namespace kvz
+
+void kvz_hip_batch_entropy_defer_download(kvz_hip_batch *b, int on) { if (b) b->entropy_deferred = on != 0; }
 
 long kvz_hip_batch_entropy_code(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model, int sao, uint8_t *out, size_t capacity, uint32_t *substream_bytes)
 {
@@ -1770,7 +1784,8 @@ long kvz_hip_batch_entropy_code_then(kvz_hip_batch *b, const kvz_hip_intra_cost_
     return J;
   };
   const long total = kvz::entropy_code_pictures(b->stream, b->device, b->n_frames, F.wc, F.hc, model->no_wpp, not_last, job, out, capacity, substream_bytes,
-                                                next ? std::function<void()>(start_next) : std::function<void()>());
+                                                next ? std::function<void()>(start_next) : std::function<void()>(),
+                                                b->entropy_deferred ? &b->entropy_out : nullptr, b->entropy_deferred != 0);
   start_next();  // the coder failed before its last chunk: the pass starts now
   return next && launched < 0 ? -2 : total;
 }

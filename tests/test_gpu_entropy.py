@@ -160,3 +160,33 @@ def test_coder_starts_the_next_batchs_pass():
         assert cc.compare(g, w_) == []
     a.close()
     b.close()
+
+
+def test_deferred_download_in_a_two_batch_pipeline():
+    """kvz_hip_batch_entropy_defer_download: the calls return with the slice data's download queued; two batches coded in turn (the second call compacts while the first
+    batch's bytes are still on their way down: each batch has a compaction buffer of its own in this mode) deliver, after their sync, the bytes of the plain calls"""
+    import kvazaar_amd
+    from kvazaar_amd.batch import HipBatch, cost_model
+    lib = kvazaar_amd.load_library()
+    model = cost_model(lib, 22, cc.coeff_weights(22))
+    fa, fb = cc.yuv_frames(416, 240, 4, 5, "small"), cc.yuv_frames(416, 240, 4, 9, "small")
+    a, b = HipBatch(lib, 416, 240, 4), HipBatch(lib, 416, 240, 4)
+    for i in range(4):
+        a.upload(i, fa[i])
+        b.upload(i, fb[i])
+    a.run(model)
+    b.run(model)
+    want = [(bytes(d), s.copy()) for d, s in (a.entropy_code(model), b.entropy_code(model))]
+    assert want[0][0] != want[1][0]
+    for x in (a, b):
+        x.entropy_defer_download(True)
+    for turn in range(3):
+        a.launch(model)
+        da, sa = a.entropy_code(model, then=(b, model))
+        db, sb = b.entropy_code(model)
+        a.sync()
+        b.sync()
+        assert bytes(da) == want[0][0] and np.array_equal(sa, want[0][1]), turn
+        assert bytes(db) == want[1][0] and np.array_equal(sb, want[1][1]), turn
+    a.close()
+    b.close()
