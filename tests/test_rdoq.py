@@ -115,6 +115,29 @@ def test_hostsim_rdoq_equals_oracle(oracle, hostsim):
     assert not bad, f"{len(bad)}/{len(cases)} blocks differ: {[(cases[i][0], cases[i][4], cases[i][5], cases[i][6]) for i in bad[:8]]}"
 
 
+def test_hostsim_rdoq_dense_blocks_and_every_class(oracle, hostsim):
+    """the chain of kvz_rdoq.hpp moves from event to event and decides its class sets on demand: a larger draw of blocks, a good part of them with more than half of their
+    positions coded (groups that pass their eighth level, rice parameters that climb to the cap), must still equal the oracle block for block"""
+    fo, fh = oracle.lib.kvz_oracle_rdoq, hostsim.lib.kvz_hostsim_rdoq
+    fo.restype = fh.restype = None
+    fo.argtypes = fh.argtypes = RDOQ_ARGS
+    fb = _fbits()
+    cases = rdoq_cases(60) + rdoq_cases_nxn(200)
+    rng = np.random.default_rng(99)
+    for w, typ in ((4, 0), (8, 0), (16, 0), (32, 0), (8, 2)):  # very large levels: escape codes at every rice parameter
+        for _ in range(6):
+            coef = np.clip(rng.laplace(0, 6000, (w, w)), -32000, 32000).astype(np.int16)
+            cases.append((int(rng.choice([12, 22])), 4.0, A(rng.integers(0, 126, 160).astype(np.uint8)), A(coef.reshape(-1)), w, typ, 0, 0))
+    dense, bad = 0, []
+    for i, c in enumerate(cases):
+        a = run_rdoq(fo, fb, c)
+        dense += np.count_nonzero(np.frombuffer(a, np.int16)) > c[4] * c[4] // 2
+        if a != run_rdoq(fh, fb, c):
+            bad.append(i)
+    assert not bad, f"{len(bad)}/{len(cases)} blocks differ: {[(cases[i][0], cases[i][4], cases[i][5], cases[i][6]) for i in bad[:8]]}"
+    assert dense > 100
+
+
 @pytest.mark.gpu
 def test_hip_rdoq_equals_oracle(oracle):
     """on the MI355X: one block per call, and the same blocks grouped by shape through the batched entry point"""
@@ -127,6 +150,14 @@ def test_hip_rdoq_equals_oracle(oracle):
     cases = rdoq_cases(6) + rdoq_cases_nxn(24)
     want = [run_rdoq(fo, fb, c) for c in cases]
     assert [run_rdoq(fh, fb, c) for c in cases] == want
+    # dense blocks and very large levels: groups that pass their eighth level, every rice parameter (the class sets the chain decides on demand)
+    rng = np.random.default_rng(99)
+    big = []
+    for w, typ in ((4, 0), (8, 0), (16, 0), (32, 0), (8, 2)):
+        for scale in (6000, 800):
+            coef = np.clip(rng.laplace(0, scale, (w, w)), -32000, 32000).astype(np.int16)
+            big.append((int(rng.choice([12, 22])), 4.0, A(rng.integers(0, 126, 160).astype(np.uint8)), A(coef.reshape(-1)), w, typ, 0, 0))
+    assert [run_rdoq(fh, fb, c) for c in big] == [run_rdoq(fo, fb, c) for c in big]
     lib.kvz_hip_rdoq_blocks.restype = None
     lib.kvz_hip_rdoq_blocks.argtypes = [C.c_int, C.c_double, flatapi.u8p, flatapi.i16p, flatapi.i16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     # batches share qp / lambda / contexts / shape: re-run groups of cases with the first member's parameters
