@@ -27,7 +27,6 @@ struct kvz_hip_batch {
   double *d_cost;
   uint8_t *d_border;
   unsigned long long *d_prof;
-  double *d_rdoq;    // kvz_rdoq's cost arrays, 72 KB per workgroup of the persistent launch (allocated with the first model that has rdoq set)
   float *d_entropy;  // the model's entropy_fbits [128 floats] followed by its ctx_init [160 bytes] of the run in flight
   uint32_t *d_items, *d_items_raster;  // ticket order with WPP (anti-diagonals) / without (raster order per picture)
   unsigned *d_ticket, *d_done, *d_error;
@@ -212,7 +211,6 @@ kvz_hip_batch *kvz_hip_batch_create_on(int device, int width, int height, int n_
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_border, nctu * KVZ_BORDER_BYTES));
   KVZ_HIP_CHECK(hipMemsetAsync(b->d_border, 0, nctu * KVZ_BORDER_BYTES, b->stream));
   F.border = b->d_border;
-  F.rdoq_scratch = nullptr;
   {  // ticket schedule: items in dependency order (anti-diagonal, frame, row)
     std::vector<uint32_t> items;
     items.reserve(nctu);
@@ -263,7 +261,7 @@ void kvz_hip_batch_destroy(kvz_hip_batch *b)
   kvz::batch_enter(b);
   (void)hipStreamSynchronize(b->stream);
   (void)hipFree(b->d_ver); (void)hipFree(b->d_dbk); (void)hipFree(b->d_sao_merge); (void)hipFree(b->d_sao_stats); (void)hipFree(b->d_sao_cand); (void)hipFree(b->d_sao_recs); (void)hipFree(b->d_sao_fbits);
-  (void)hipFree(b->d_border); (void)hipFree(b->d_items); (void)hipFree(b->d_items_raster); (void)hipFree(b->d_done); (void)hipFree(b->d_ticket); (void)hipFree(b->d_prof); (void)hipFree(b->d_entropy); (void)hipFree(b->d_rdoq);
+  (void)hipFree(b->d_border); (void)hipFree(b->d_items); (void)hipFree(b->d_items_raster); (void)hipFree(b->d_done); (void)hipFree(b->d_ticket); (void)hipFree(b->d_prof); (void)hipFree(b->d_entropy);
   (void)hipFree(b->d_src); (void)hipFree(b->d_rec); (void)hipFree(b->d_coeff); (void)hipFree(b->d_scratch); (void)hipFree(b->d_depth); (void)hipFree(b->d_mode); (void)hipFree(b->d_cost); (void)hipFree(b->d_part); (void)hipFree(b->d_mode4);
   (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1);
   if (b->h_error) (void)hipHostFree(b->h_error);
@@ -419,13 +417,11 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
     // two instantiations: the one without the CABAC coefficient model carries none of its code, registers or context storage
     // (the instantiations that search 32x32 CUs, --pu-depth-intra 1-3, are separate ones too: the others stay as they were)
     if (cm.rdoq || cm.search_nxn) {  // --rdoq and / or NxN partitions (preset `medium`): their own instantiation (32x32 search and the coefficient cost model switched by the model)
-      if (cm.rdoq && !b->d_rdoq) KVZ_HIP_CHECK(hipMalloc((void **)&b->d_rdoq, (size_t)b->slots_per_cu * b->cus * 3 * KVZ_RDOQ_SCRATCH_DOUBLES * sizeof(double)));
       if (cm.search_nxn && !b->d_part) {
         KVZ_HIP_CHECK(hipMalloc((void **)&b->d_part, (size_t)(F.W / 8) * (F.H / 8) * b->n_frames));
         KVZ_HIP_CHECK(hipMalloc((void **)&b->d_mode4, (size_t)(F.W / 4) * (F.H / 4) * b->n_frames));
       }
       kvz::CtuFrames Fr = F;
-      Fr.rdoq_scratch = b->d_rdoq;
       Fr.cu_part = b->d_part; Fr.cu_mode4 = b->d_mode4;
       hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel_rdoq, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, Fr, cm, kvz::device_tables(), sc);
     } else if (cm.search_32x32) {

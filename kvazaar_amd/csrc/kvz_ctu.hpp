@@ -217,7 +217,6 @@ struct CtuFrames {
   // Neighbour data is exchanged ONLY through these records: the frame-level rec / cu arrays share cache lines between CTUs
   // produced on different XCDs, and a line that is dirty in the reader's L2 cannot be invalidated by its acquire.
   u8 *border;                // [frames][ctu][KVZ_BORDER_BYTES]
-  double *rdoq_scratch;      // [workgroup][plane][KVZ_RDOQ_SCRATCH_DOUBLES]: the per-position cost arrays of kvz_rdoq (RDOQ instantiation only, else unused)
 };
 #define KVZ_BORDER_BYTES 512
 
@@ -1780,16 +1779,6 @@ template <bool CABAC, bool S32 = false, bool RDOQ = false> struct CtuProgramT {
   {
     if (t.lw == 5) return s->tb_big + (c == 0 ? 0 : (c == 1 ? 1024 : 1280));  // one buffer, every stage in place
     return s->tb_small + p * 384 + (c == 0 ? 0 : (c == 1 ? 256 : 320));
-  }
-  // kvz_rdoq's three per-position cost arrays + one entry per 4x4 group for plane c of this workgroup (HBM: 24.5 KB per plane at 32x32)
-#define KVZ_RDOQ_SCRATCH_DOUBLES (3 * 1024 + 64)
-  KVZ_DEV double *rdoq_scratch(int c) const
-  {
-#ifdef KVZ_HOSTSIM
-    return F.rdoq_scratch + (long)c * KVZ_RDOQ_SCRATCH_DOUBLES;
-#else
-    return F.rdoq_scratch + ((long)blockIdx.x * 3 + c) * KVZ_RDOQ_SCRATCH_DOUBLES;
-#endif
   }
   // Entry (k, i) of the 2^l2-point transform matrix
   KVZ_DEV int dct_at(int l2, int k, int i) const

@@ -46,8 +46,6 @@ extern "C" void kvz_hostsim_intra_frame_nxn(const kvz_hip_intra_cost_model *m, i
   F.border = border;
   int16_t *scratch = (int16_t *)calloc((size_t)F.wc * F.hc * 6144, sizeof(int16_t));
   F.coeff_scratch = scratch;
-  double *rdoq_scratch = (double *)calloc((size_t)3 * KVZ_RDOQ_SCRATCH_DOUBLES, sizeof(double));
-  F.rdoq_scratch = rdoq_scratch;
   // like the device, two instantiations of the program: with and without the CABAC coefficient model (kvz_batch.hpp picks by model)
   void *sh = calloc(1, sizeof(kvz::CtuSharedT<true>) > sizeof(kvz::CtuSharedT<false>) ? sizeof(kvz::CtuSharedT<true>) : sizeof(kvz::CtuSharedT<false>));
   kvz::CtuModel cm;
@@ -82,7 +80,6 @@ extern "C" void kvz_hostsim_intra_frame_nxn(const kvz_hip_intra_cost_model *m, i
     }
   free(sh);
   free(scratch);
-  free(rdoq_scratch);
   free(border);
 }
 extern "C" void kvz_hostsim_intra_frame(const kvz_hip_intra_cost_model *m, int width, int height, const uint8_t *src, uint8_t *rec, int16_t *coeff, uint8_t *cu_depth,
