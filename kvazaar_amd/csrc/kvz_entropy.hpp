@@ -353,7 +353,7 @@ struct EntropyCtuB {
     for (int i = 0; i < 2; i++) {
       const int l = i == 0 ? reflist : !reflist;
       if ((c.mv_dir & (1 << l)) == 0) continue;
-      out[0] = c.mv[l][0]; out[1] = c.mv[l][1];
+      out[0] = l ? c.mv[1][0] : c.mv[0][0]; out[1] = l ? c.mv[1][1] : c.mv[0][1];  // (selects: an index computed at run time puts the record on the stack)
       return true;
     }
     return false;
@@ -392,7 +392,7 @@ struct EntropyCtuB {
     if (J.poc > 1 && n < 2 && vcol) {
       int col_list = reflist;
       if ((col.mv_dir & (col_list + 1)) == 0) col_list = 1 - col_list;
-      mv_cand[n][0] = col.mv[col_list][0]; mv_cand[n][1] = col.mv[col_list][1];
+      mv_cand[n][0] = col_list ? col.mv[1][0] : col.mv[0][0]; mv_cand[n][1] = col_list ? col.mv[1][1] : col.mv[0][1];
       n++;
     }
     while (n < 2) { mv_cand[n][0] = 0; mv_cand[n][1] = 0; n++; }
