@@ -328,7 +328,7 @@ struct EntropyCtuB {
     int size = (width & -width) < (height & -height) ? (width & -width) : (height & -height);
     if (height != size) y = y + height - size;
     while (size < 64) {
-      const int parent = 2 * size, idx = (x % parent != 0) + 2 * (y % parent != 0);
+      const int parent = 2 * size, idx = ((x & (parent - 1)) != 0) + 2 * ((y & (parent - 1)) != 0);
       if (idx == 0) return true;
       if (idx == 1 || idx == 3) return false;
       y -= size; size = parent;
@@ -340,7 +340,7 @@ struct EntropyCtuB {
     int size = (width & -width) < (height & -height) ? (width & -width) : (height & -height);
     if (width != size) x = x + width - size;
     while (size < 64) {
-      const int parent = 2 * size, idx = (x % parent != 0) + 2 * (y % parent != 0);
+      const int parent = 2 * size, idx = ((x & (parent - 1)) != 0) + 2 * ((y & (parent - 1)) != 0);
       if (idx == 0 || idx == 2) return true;
       if (idx == 3) return false;
       x -= size; size = parent;

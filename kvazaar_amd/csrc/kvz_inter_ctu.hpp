@@ -194,6 +194,7 @@ struct InterConst {
   int8_t luma_filter[4][8];    // filter.c:66-72
   int8_t chroma_filter[8][4];  // filter.c:74-84
   u8 avail_top[16][16], avail_left[16][16];  // intra.c:47-82 as regenerated by kvz_tables.hpp
+  u32 div_magic[48];           // 2^20 / d + 1 (div_by's multiplier, kvz_inter_ctu_pix.inc): there is no integer division in hardware, and one per staged window was ~25 instructions
 };
 
 // A 32x32 block is interpolated, compared and transformed in 16x16 TILES (its four quadrants; smaller blocks are one tile): the sample buffers below are sized for a tile.
@@ -275,6 +276,7 @@ struct InterState {
   const Tables *tb;   // the large tables that stay in HBM: the coefficient scans (the residual coder's walk, picture QP >= 28 only)
   InterSlab *S;
   int frame, cx, cy;
+  int ref_idx;  // frame % F.ref_count (several tiles of one reference frame), once per CTU: every address into the reference went through a division otherwise
   int acc_slot;
 };
 
@@ -339,7 +341,7 @@ struct InterCtu {
   }
   IC_DEV long plane_off(int c) { return c == 0 ? 0 : (c == 1 ? (long)F.W * F.H : (long)F.W * F.H * 5 / 4); }
   // plane c of the picture's reference FRAME (K->ref_w x K->ref_h; the picture lies at (K->tile_x, K->tile_y) in it)
-  IC_DEV int ref_index() { return F.ref_count ? frame % F.ref_count : frame; }
+  IC_DEV int ref_index() { return g_ic.ref_idx; }
   IC_DEV const gu8 *refp(int c) { const long n = (long)K->ref_w * K->ref_h; return (const gu8 *)F.ref + ref_index() * (n * 3 / 2) + (c == 0 ? 0 : (c == 1 ? n : n * 5 / 4)); }
   IC_DEV const CuInfo *ref_cu_frame() { return F.ref_cu + ref_index() * ((long)(K->ref_w >> 2) * (K->ref_h >> 2)); }
   IC_DEV const gu8 *srcp(int c) { return (const gu8 *)F.src + frame * F.frame_px + plane_off(c); }
@@ -489,6 +491,7 @@ struct InterCtu {
         (&K->avail_top[0][0])[i] = ((const KVZ_GLB u8 *)&tb->avail_top[0][0])[i];
         (&K->avail_left[0][0])[i] = ((const KVZ_GLB u8 *)&tb->avail_left[0][0])[i];
       }
+      for (int i = tid; i < 48; i += KVZ_ICTU_THREADS) K->div_magic[i] = i ? (1u << 20) / (unsigned)i + 1u : 0u;
       for (int i = tid; i < 32; i += KVZ_ICTU_THREADS) {
         (&K->luma_filter[0][0])[i] = ((const KVZ_GLB int8_t *)&tb->luma_filter[0][0])[i];
         (&K->chroma_filter[0][0])[i] = ((const KVZ_GLB int8_t *)&tb->chroma_filter[0][0])[i];
@@ -504,7 +507,7 @@ struct InterCtu {
   }
   IC_DEV void begin_ctu(int frame_, int cx_, int cy_)
   {
-    IC_FOR(tid) { if (tid == 0) { frame = frame_; cx = cx_; cy = cy_; if (F.tile_xy) {
+    IC_FOR(tid) { if (tid == 0) { frame = frame_; cx = cx_; cy = cy_; g_ic.ref_idx = F.ref_count ? frame_ % F.ref_count : frame_; if (F.tile_xy) {
       // the origin is a DEVICE-side input nobody validated: brought inside the reference frame here (multiples of 8, the tile inside the frame), so that no read of
       // the reference picture or of its CU records can leave them whatever the table holds; a valid table is unchanged
       const int tx = ((const KVZ_GLB int *)F.tile_xy)[2 * frame_], ty = ((const KVZ_GLB int *)F.tile_xy)[2 * frame_ + 1];
