@@ -206,7 +206,8 @@ struct InterLds {
   alignas(8) u8 C2[16 * 16 + 2 * 8 * 8];     // the depth-2 CU under evaluation
   alignas(8) u8 C3[8 * 8 + 2 * 4 * 4];       // the depth-3 CU under evaluation
   alignas(8) u8 Z3[8 * 8 + 2 * 4 * 4];       // cu_zero_coeff_cost's copy of a depth-3 CU's prediction (search.c:222 puts it into level 4)
-  CuInfo Dcu[64];                            // CU records of the decided picture, one per 8x8 (the smallest CU)
+  struct alignas(8) DCell { CuInfo c; uint16_t pad; };  // 24 bytes: a record of the decided picture is read whole with three 8-byte LDS reads (cell_at), not as eleven half-words
+  DCell Dcu[64];                             // CU records of the decided picture, one per 8x8 (the smallest CU)
   union {                               // the inter side's tile buffers | the parked prediction | the intra side's references and scores
     struct {
       alignas(8) u8 win[24 * IC_WS + 16];  // reference window of a tile (motion compensation, fractional search): rows staged from a dword-aligned column, sample (r, c) at
@@ -276,6 +277,7 @@ struct InterState {
   const Tables *tb;   // the large tables that stay in HBM: the coefficient scans (the residual coder's walk, picture QP >= 28 only)
   InterSlab *S;
   int frame, cx, cy;
+  const CuInfo *cu_frame;  // F.cu + frame * F.cells: the picture's CU records (neighbours in finished CTUs), once per CTU
   int ref_idx;  // frame % F.ref_count (several tiles of one reference frame), once per CTU: every address into the reference went through a division otherwise
   int acc_slot;
 };
@@ -346,7 +348,14 @@ struct InterCtu {
   IC_DEV const CuInfo *ref_cu_frame() { return F.ref_cu + ref_index() * ((long)(K->ref_w >> 2) * (K->ref_h >> 2)); }
   IC_DEV const gu8 *srcp(int c) { return (const gu8 *)F.src + frame * F.frame_px + plane_off(c); }
   IC_DEV gu8 *recp(int c) { return (gu8 *)F.rec + frame * F.frame_px + plane_off(c); }
-  IC_DEV CuInfo *dcell(int xl, int yl) { return &L->Dcu[(yl >> 3) * 8 + (xl >> 3)]; }
+  IC_DEV CuInfo *dcell(int xl, int yl) { return &L->Dcu[(yl >> 3) * 8 + (xl >> 3)].c; }
+  IC_DEV CuInfo load_dcell(int xl, int yl)  // *dcell(xl, yl), the whole record
+  {
+    union { CuInfo c; unsigned long long q[3]; } u;
+    const KVZ_LDS unsigned long long *p = (const KVZ_LDS unsigned long long *)&L->Dcu[(yl >> 3) * 8 + (xl >> 3)];
+    u.q[0] = p[0]; u.q[1] = p[1]; u.q[2] = p[2];
+    return u.c;
+  }
   IC_DEV bool cbf_is_set(unsigned cbf, int depth, int plane) { return (cbf & ((0x1fu >> depth) << (5 * plane))) != 0; }
   IC_DEV bool cbf_any(unsigned cbf, int depth) { return cbf_is_set(cbf, depth, 0) || cbf_is_set(cbf, depth, 1) || cbf_is_set(cbf, depth, 2); }
   IC_DEV uint16_t cbf_set(unsigned cbf, int depth, int plane) { return (uint16_t)(cbf | ((0x10u >> depth) << (5 * plane))); }
@@ -405,10 +414,18 @@ struct InterCtu {
   // a CU record of a picture in HBM (22 bytes, 2-byte aligned), as eleven global 16-bit loads
   IC_DEV CuInfo load_cu(const CuInfo *p)
   {
-    union { CuInfo c; uint16_t h[11]; } u;
-    static_assert(sizeof(CuInfo) == 22, "CU records are copied as eleven half-words");
-    for (int i = 0; i < 11; i++) u.h[i] = ((const KVZ_GLB uint16_t *)p)[i];
+    static_assert(sizeof(CuInfo) == 22, "CU records are copied as five words and a half-word");
+#ifdef KVZ_HOSTSIM
+    return *p;
+#else
+    // 2-byte aligned: five unaligned 32-bit loads and a 16-bit one (global memory takes unaligned words), not eleven half-words and their packing
+    struct __attribute__((packed, aligned(2))) W { u32 v; };
+    union { CuInfo c; u32 w[6]; } u;
+    const KVZ_GLB W *q = (const KVZ_GLB W *)p;
+    for (int i = 0; i < 5; i++) u.w[i] = q[i].v;
+    u.w[5] = ((const KVZ_GLB uint16_t *)p)[10];
     return u.c;
+#endif
   }
   IC_DEV void store_cu(CuInfo *p, const CuInfo &c)
   {
@@ -420,8 +437,8 @@ struct InterCtu {
   // record -- a finished CU looks the same from every level --, else the frame's (finished CTUs)
   IC_DEV CuInfo cell_at(int fx, int fy)
   {
-    if (fx >= cx && fx < cx + 64 && fy >= cy && fy < cy + 64) return *dcell(fx - cx, fy - cy);
-    return load_cu((const CuInfo *)F.cu + frame * F.cells + (long)(fy >> 2) * (F.W >> 2) + (fx >> 2));
+    if (fx >= cx && fx < cx + 64 && fy >= cy && fy < cy + 64) return load_dcell(fx - cx, fy - cy);
+    return load_cu(g_ic.cu_frame + ((fy >> 2) * (F.W >> 2) + (fx >> 2)));  // (a 32-bit index: a picture has fewer than 2^31 4x4 units)
   }
 
   // CABAC_FBITS_UPDATE on the search contexts (cabac.h:133-139)
@@ -507,7 +524,7 @@ struct InterCtu {
   }
   IC_DEV void begin_ctu(int frame_, int cx_, int cy_)
   {
-    IC_FOR(tid) { if (tid == 0) { frame = frame_; cx = cx_; cy = cy_; g_ic.ref_idx = F.ref_count ? frame_ % F.ref_count : frame_; if (F.tile_xy) {
+    IC_FOR(tid) { if (tid == 0) { frame = frame_; cx = cx_; cy = cy_; g_ic.ref_idx = F.ref_count ? frame_ % F.ref_count : frame_; g_ic.cu_frame = (const CuInfo *)F.cu + (long)frame_ * F.cells; if (F.tile_xy) {
       // the origin is a DEVICE-side input nobody validated: brought inside the reference frame here (multiples of 8, the tile inside the frame), so that no read of
       // the reference picture or of its CU records can leave them whatever the table holds; a valid table is unchanged
       const int tx = ((const KVZ_GLB int *)F.tile_xy)[2 * frame_], ty = ((const KVZ_GLB int *)F.tile_xy)[2 * frame_ + 1];
