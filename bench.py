@@ -1247,10 +1247,23 @@ def leg_intra4k(args, lib, model_for, HipBatch, n4k=384, steps=3):
                 for i in range(half):
                     b.upload(i, d4[i % len(d4)])
                 pair.append(b)
-            s_full, pictures, per_pic, ok = chain_full(pair, m4, args.qp, 3, gold if (args.qp == 22 and not args.no_wpp and not args.frozen_contexts) else None, len(d4))
+            g4 = gold if (args.qp == 22 and not args.no_wpp and not args.frozen_contexts) else None
+            retried = None
+            try:
+                s_full, pictures, per_pic, ok = chain_full(pair, m4, args.qp, 3, g4, len(d4))
+            except Exception as e:  # seen once in twenty runs, right behind four profiler passes on the same box, never on its own (tools/chain4k_stress.py): say so and measure again
+                retried = repr(e)
+                for b in pair:
+                    try:
+                        b.sync()
+                    except Exception:
+                        pass
+                s_full, pictures, per_pic, ok = chain_full(pair, m4, args.qp, 3, g4, len(d4))
             out["chain_full"] = {"stages": f"CTU pass -> deblocking -> entropy coder on the device -> slice data downloaded; two batches of {half} pictures in turn, a batch's pass started when the other batch's coder has queued its third stage",
                                  "value": pictures * pair[0].ctus_per_frame / s_full, "unit": "CTUs/s", "fps": pictures / s_full, "slice_data_bytes_per_picture": per_pic, "verified": ok,
                                  "verify": "slice data and entry points of the clip's pictures equal the reference encoder's bitstream (tests/golden/entropy.json bench-2160p)"}
+            if retried:
+                out["chain_full"]["first_attempt_failed"] = retried
             for b in pair:
                 b.close()
         except Exception as e:  # auxiliary
