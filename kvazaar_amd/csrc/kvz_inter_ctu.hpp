@@ -52,7 +52,15 @@ static long g_ic_phases[32]; static int g_ic_cat = 31;
 #define KVZ_LDS
 #define KVZ_GLB
 #define IC_WGVAR static
+static inline int mul24(int a, int b) { return a * b; }
+static inline unsigned umul24(unsigned a, unsigned b) { return a * b; }
+static inline int mul24v(int a, int b) { return a * b; }
 #else
+// a 32-bit multiply is a quarter-rate instruction, the 24-bit one a full-rate one: rows, strides, cell indices and the div_by products all fit
+__device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
+__device__ __forceinline__ unsigned umul24(unsigned a, unsigned b) { return __umul24(a, b); }
+// ... and where the compiler would not take it (one factor in a scalar register: it falls back to the 32-bit multiply) the instruction by name
+__device__ __forceinline__ int mul24v(int a, int b) { int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 #define IC_FOR(tid) for (int tid = threadIdx.x, once_ = 1; once_; once_ = 0)
 #define IC_SYNC() __syncthreads()
 #define IC_LDS_ADD(p, v) atomicAdd((p), (v))
@@ -194,7 +202,7 @@ struct InterConst {
   int8_t luma_filter[4][8];    // filter.c:66-72
   int8_t chroma_filter[8][4];  // filter.c:74-84
   u8 avail_top[16][16], avail_left[16][16];  // intra.c:47-82 as regenerated by kvz_tables.hpp
-  u32 div_magic[48];           // 2^20 / d + 1 (div_by's multiplier, kvz_inter_ctu_pix.inc): there is no integer division in hardware, and one per staged window was ~25 instructions
+  u32 div_magic[32];           // 2^20 / d + 1 (div_by's multiplier, kvz_inter_ctu_pix.inc): there is no integer division in hardware, and one per staged window was ~25 instructions
 };
 
 // A 32x32 block is interpolated, compared and transformed in 16x16 TILES (its four quadrants; smaller blocks are one tile): the sample buffers below are sized for a tile.
@@ -279,6 +287,11 @@ struct InterState {
   int frame, cx, cy;
   const CuInfo *cu_frame;  // F.cu + frame * F.cells: the picture's CU records (neighbours in finished CTUs), once per CTU
   int ref_idx;  // frame % F.ref_count (several tiles of one reference frame), once per CTU: every address into the reference went through a division otherwise
+  // the luma planes of the picture's reference frame, source and reconstruction, once per CTU: (long) frame x plane-size products behind every sample address otherwise
+  const uint8_t *ref_base, *src_base;
+  uint8_t *rec_base;
+  const CuInfo *ref_cu_base;  // the reference frame's CU records
+  int16_t *coef_out;  // the CTU's 6144 levels: F.coeff's slot of it, or the workgroup's scratch
   int acc_slot;
 };
 
@@ -333,7 +346,7 @@ struct InterCtu {
     return r * 16;
   }
   // the quantised levels of the depth-lv CU at (xl, yl): candidates of depth 1 and 2 in the workgroup's scratch, a depth-3 CU's straight in the output block
-  IC_DEV gi16 *out_coef() { return F.coeff ? (gi16 *)F.coeff + ((long)frame * F.wc * F.hc + (cy >> 6) * F.wc + (cx >> 6)) * 6144 : (gi16 *)S->out; }
+  IC_DEV gi16 *out_coef() { return (gi16 *)g_ic.coef_out; }
   IC_DEV gi16 *coef(int lv, int c, int xl, int yl)
   {
     const int sh = c ? 1 : 0;
@@ -341,18 +354,18 @@ struct InterCtu {
     if (lv == 2) return (gi16 *)S->cand2 + (c == 0 ? 0 : (c == 1 ? 256 : 320));
     return out_coef() + (c == 0 ? 0 : (c == 1 ? 4096 : 5120)) + zorder(xl >> sh, yl >> sh);
   }
-  IC_DEV long plane_off(int c) { return c == 0 ? 0 : (c == 1 ? (long)F.W * F.H : (long)F.W * F.H * 5 / 4); }
+  IC_DEV int plane_off(int c) { const int n = F.W * F.H; return c == 0 ? 0 : (c == 1 ? n : n + (n >> 2)); }  // (W, H even: n * 5 / 4 exactly)
   // plane c of the picture's reference FRAME (K->ref_w x K->ref_h; the picture lies at (K->tile_x, K->tile_y) in it)
   IC_DEV int ref_index() { return g_ic.ref_idx; }
-  IC_DEV const gu8 *refp(int c) { const long n = (long)K->ref_w * K->ref_h; return (const gu8 *)F.ref + ref_index() * (n * 3 / 2) + (c == 0 ? 0 : (c == 1 ? n : n * 5 / 4)); }
-  IC_DEV const CuInfo *ref_cu_frame() { return F.ref_cu + ref_index() * ((long)(K->ref_w >> 2) * (K->ref_h >> 2)); }
-  IC_DEV const gu8 *srcp(int c) { return (const gu8 *)F.src + frame * F.frame_px + plane_off(c); }
-  IC_DEV gu8 *recp(int c) { return (gu8 *)F.rec + frame * F.frame_px + plane_off(c); }
-  IC_DEV CuInfo *dcell(int xl, int yl) { return &L->Dcu[(yl >> 3) * 8 + (xl >> 3)].c; }
+  IC_DEV const gu8 *refp(int c) { const int n = K->ref_w * K->ref_h; return (const gu8 *)g_ic.ref_base + (c == 0 ? 0 : (c == 1 ? n : n + (n >> 2))); }
+  IC_DEV const CuInfo *ref_cu_frame() { return g_ic.ref_cu_base; }
+  IC_DEV const gu8 *srcp(int c) { return (const gu8 *)g_ic.src_base + plane_off(c); }
+  IC_DEV gu8 *recp(int c) { return (gu8 *)g_ic.rec_base + plane_off(c); }
+  IC_DEV CuInfo *dcell(int xl, int yl) { return &L->Dcu[((yl >> 3) & 7) * 8 + ((xl >> 3) & 7)].c; }  // (& 7: nothing for a position inside the CTU; the index's range lets the record size multiply at full rate)
   IC_DEV CuInfo load_dcell(int xl, int yl)  // *dcell(xl, yl), the whole record
   {
     union { CuInfo c; unsigned long long q[3]; } u;
-    const KVZ_LDS unsigned long long *p = (const KVZ_LDS unsigned long long *)&L->Dcu[(yl >> 3) * 8 + (xl >> 3)];
+    const KVZ_LDS unsigned long long *p = (const KVZ_LDS unsigned long long *)&L->Dcu[((yl >> 3) & 7) * 8 + ((xl >> 3) & 7)];
     u.q[0] = p[0]; u.q[1] = p[1]; u.q[2] = p[2];
     return u.c;
   }
@@ -438,7 +451,7 @@ struct InterCtu {
   IC_DEV CuInfo cell_at(int fx, int fy)
   {
     if (fx >= cx && fx < cx + 64 && fy >= cy && fy < cy + 64) return load_dcell(fx - cx, fy - cy);
-    return load_cu(g_ic.cu_frame + ((fy >> 2) * (F.W >> 2) + (fx >> 2)));  // (a 32-bit index: a picture has fewer than 2^31 4x4 units)
+    return load_cu((const CuInfo *)((const uint8_t *)g_ic.cu_frame + mul24(mul24(fy >> 2, F.W >> 2) + (fx >> 2), (int)sizeof(CuInfo))));  // (a 32-bit index: a picture has fewer than 2^31 4x4 units)
   }
 
   // CABAC_FBITS_UPDATE on the search contexts (cabac.h:133-139)
@@ -508,7 +521,7 @@ struct InterCtu {
         (&K->avail_top[0][0])[i] = ((const KVZ_GLB u8 *)&tb->avail_top[0][0])[i];
         (&K->avail_left[0][0])[i] = ((const KVZ_GLB u8 *)&tb->avail_left[0][0])[i];
       }
-      for (int i = tid; i < 48; i += KVZ_ICTU_THREADS) K->div_magic[i] = i ? (1u << 20) / (unsigned)i + 1u : 0u;
+      for (int i = tid; i < 32; i += KVZ_ICTU_THREADS) K->div_magic[i] = i ? (1u << 20) / (unsigned)i + 1u : 0u;
       for (int i = tid; i < 32; i += KVZ_ICTU_THREADS) {
         (&K->luma_filter[0][0])[i] = ((const KVZ_GLB int8_t *)&tb->luma_filter[0][0])[i];
         (&K->chroma_filter[0][0])[i] = ((const KVZ_GLB int8_t *)&tb->chroma_filter[0][0])[i];
@@ -524,7 +537,10 @@ struct InterCtu {
   }
   IC_DEV void begin_ctu(int frame_, int cx_, int cy_)
   {
-    IC_FOR(tid) { if (tid == 0) { frame = frame_; cx = cx_; cy = cy_; g_ic.ref_idx = F.ref_count ? frame_ % F.ref_count : frame_; g_ic.cu_frame = (const CuInfo *)F.cu + (long)frame_ * F.cells; if (F.tile_xy) {
+    IC_FOR(tid) { if (tid == 0) { frame = frame_; cx = cx_; cy = cy_; g_ic.ref_idx = F.ref_count ? frame_ % F.ref_count : frame_; g_ic.cu_frame = (const CuInfo *)F.cu + (long)frame_ * F.cells;
+      g_ic.ref_base = (const uint8_t *)F.ref + g_ic.ref_idx * ((long)K->ref_w * K->ref_h * 3 / 2); g_ic.ref_cu_base = F.ref_cu + g_ic.ref_idx * ((long)(K->ref_w >> 2) * (K->ref_h >> 2)); g_ic.src_base = (const uint8_t *)F.src + frame_ * F.frame_px; g_ic.rec_base = (uint8_t *)F.rec + frame_ * F.frame_px;
+      g_ic.coef_out = F.coeff ? (int16_t *)F.coeff + ((long)frame_ * F.wc * F.hc + (cy_ >> 6) * F.wc + (cx_ >> 6)) * 6144 : (int16_t *)S->out;
+      if (F.tile_xy) {
       // the origin is a DEVICE-side input nobody validated: brought inside the reference frame here (multiples of 8, the tile inside the frame), so that no read of
       // the reference picture or of its CU records can leave them whatever the table holds; a valid table is unchanged
       const int tx = ((const KVZ_GLB int *)F.tile_xy)[2 * frame_], ty = ((const KVZ_GLB int *)F.tile_xy)[2 * frame_ + 1];
