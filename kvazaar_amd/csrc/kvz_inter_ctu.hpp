@@ -181,7 +181,6 @@ struct InterFrames {
 struct MCand { i16 mv[2][2]; u8 ref[2], dir; };                         // inter_merge_cand_t
 struct PuSearch { int x, y, w; i16 mv_cand[2][2]; MCand merge[5]; int num_merge; };
 struct UMap { CuInfo unit[5]; double cost[5], bits[5]; int8_t keys[5]; int size; };
-struct Nbr { CuInfo a[2], b[3], c3, h; bool va[2], vb[3], vc3, vh; };  // merge_candidates_t
 
 struct PView { lu8 *p; int s; };  // a plane of a block in LDS: sample (x, y) at p[y * s + x]
 
@@ -254,7 +253,6 @@ struct InterLds {
   };
   UMap merge;
   PuSearch pu;
-  Nbr nb;
   unsigned long long intra_done;  // the modes L->mcost holds for the CU under evaluation
   int mvc_key[4];      // the PU and list L->mvc holds the AMVP predictors of ({x, y, w, list}; w = 0: none) -- the search asks for the same pair up to three times
   i16 mvc[2][2];
