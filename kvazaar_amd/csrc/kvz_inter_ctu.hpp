@@ -45,8 +45,12 @@ namespace kvz {
 #ifdef KVZ_ICTU_COUNT_PHASES  // developer build of the host simulation: barriers per stage (tools/inter_phase_count.py)
 static long g_ic_phases[32]; static int g_ic_cat = 31;
 #define IC_SYNC() (++g_ic_phases[g_ic_cat])
+#define IC_COUNT(slot) (++g_ic_phases[slot])  /* events per CTU, slots 16 .. 30 (tools/inter_phase_count.py names them) */
 #else
 #define IC_SYNC()
+#endif
+#ifndef IC_COUNT
+#define IC_COUNT(slot)
 #endif
 #define IC_LDS_ADD(p, v) (*(p) += (v))
 #define KVZ_LDS
@@ -62,7 +66,8 @@ __device__ __forceinline__ unsigned umul24(unsigned a, unsigned b) { return __um
 // ... and where the compiler would not take it (one factor in a scalar register: it falls back to the 32-bit multiply) the instruction by name
 __device__ __forceinline__ int mul24v(int a, int b) { int r; asm("v_mul_i32_i24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 #define IC_FOR(tid) for (int tid = threadIdx.x, once_ = 1; once_; once_ = 0)
-#define IC_SYNC() __syncthreads()
+#define IC_SYNC() __syncthreads()  /* (one wavefront: the compiler drops the s_barrier; a wavefront-scope fence in its place measured the same, profiles/experiments) */
+#define IC_COUNT(slot)
 #define IC_LDS_ADD(p, v) atomicAdd((p), (v))
 #define KVZ_LDS __attribute__((address_space(3)))  // a pointer into the workgroup's LDS block: ds_read / ds_write, not flat
 #define KVZ_GLB __attribute__((address_space(1)))  // a pointer into HBM (pictures, CU records, levels): global_load / global_store, not flat
@@ -448,6 +453,7 @@ struct InterCtu {
   // record -- a finished CU looks the same from every level --, else the frame's (finished CTUs)
   IC_DEV CuInfo cell_at(int fx, int fy)
   {
+    IC_COUNT(17);
     if (fx >= cx && fx < cx + 64 && fy >= cy && fy < cy + 64) return load_dcell(fx - cx, fy - cy);
     return load_cu((const CuInfo *)((const uint8_t *)g_ic.cu_frame + mul24(mul24(fy >> 2, F.W >> 2) + (fx >> 2), (int)sizeof(CuInfo))));  // (a 32-bit index: a picture has fewer than 2^31 4x4 units)
   }
@@ -455,6 +461,7 @@ struct InterCtu {
   // CABAC_FBITS_UPDATE on the search contexts (cabac.h:133-139)
   IC_DEV double price(int idx, int bin, bool update)
   {
+    IC_COUNT(16);
     const u8 st = cab.s[idx];
     const double bits = M->fbits[st ^ bin];
     if (update) cab.s[idx] = K->ctx_next[bin != (st & 1)][st];

@@ -38,8 +38,8 @@ struct TuWalk {
 };
 KVZ_DEV int entropy_cg_of(const u32 *scan, int i, int log2_size)  // g_sig_last_scan_cg: the scan is group-major
 {
-  const int width = 1 << log2_size, nbs = width >> 2, p = (int)scan[i << 4];
-  return ((p >> log2_size) >> 2) * nbs + ((p & (width - 1)) >> 2);
+  const int width = 1 << log2_size, p = (int)scan[i << 4];
+  return (((p >> log2_size) >> 2) << (log2_size - 2)) + ((p & (width - 1)) >> 2);
 }
 // The scan of a block is group-major with the 4x4 pattern of its type inside every group (kvz_tables.hpp: scan[n] = group origin + pattern[n & 15]): position y * 4 + x of
 // scan index i inside a group is nibble i of these constants -- diagonal, horizontal, vertical.  A group's sixteen levels are four 8-byte rows: loaded once, looked up in
@@ -76,7 +76,7 @@ template <class Sink> KVZ_DEV void entropy_tu_begin(Sink &s, const Tables *tb, T
   while (!((sig_cg >> entropy_cg_of(scan, scan_cg_last, log2_size)) & 1)) scan_cg_last--;
   int scan_pos_last = scan_cg_last * 16 + 15;
   const unsigned long long pat = entropy_scan_pattern(scan_mode);
-  const int last_cg = entropy_cg_of(scan, scan_cg_last, log2_size), last_cg_y = last_cg / nbs, last_cg_x = last_cg - last_cg_y * nbs;
+  const int last_cg = entropy_cg_of(scan, scan_cg_last, log2_size), last_cg_y = last_cg >> (log2_size - 2), last_cg_x = last_cg & (nbs - 1);  // (nbs = 2^(log2_size - 2): a division by it is ~25 instructions where the compiler cannot see that)
   CgRows rows;
   rows.load(coeff, width, last_cg_x, last_cg_y);
   while (!rows.at((int)((pat >> (4 * (scan_pos_last & 15))) & 15))) scan_pos_last--;
@@ -110,7 +110,7 @@ template <class Sink> KVZ_DEV void entropy_tu_cg(Sink &s, const Tables *tb, TuWa
   int scan_pos_sig = t.scan_pos_sig, c1 = t.c1;
   const int scan_cg_last = t.scan_pos_last >> 4, scan_pos_last = t.scan_pos_last;
   {
-    const int sub_pos = i << 4, cg_blk_pos = entropy_cg_of(scan, i, log2_size), cg_pos_y = cg_blk_pos / nbs, cg_pos_x = cg_blk_pos - cg_pos_y * nbs;
+    const int sub_pos = i << 4, cg_blk_pos = entropy_cg_of(scan, i, log2_size), cg_pos_y = cg_blk_pos >> (log2_size - 2), cg_pos_x = cg_blk_pos & (nbs - 1);
     int abs_coeff[16], num_non_zero = 0;
     u32 coeff_signs = 0, go_rice = 0;
     const unsigned long long pat = entropy_scan_pattern(scan_mode);
