@@ -21,7 +21,7 @@ rs, rf, cu, qps = ic.oracle_encode(oracle, w, h, frames, qp, preset=preset, debl
 mc = cc.model_constants()
 fb = np.array(mc["entropy_fbits"], np.float32)
 p = ic.PRESETS[preset]
-names = ["merge MC+SATD", "early skip", "integer ME", "fractional ME", "candidates", "intra search", "intra recon", "inter quant/recon", "mock+rd cost", "copies", "io", "total (unattributed)"] + ["cat%d" % i for i in range(12, 16)] + ["EVENTS price()", "EVENTS cell_at", "EVENTS candidate gathers", "EVENTS mv_candidates calls", "EVENTS probe groups", "EVENTS staged windows", "EVENTS hor_pass_ref", "EVENTS predict_tile"] + ["cat%d" % i for i in range(24, 31)] + ["outside"]
+names = ["merge MC+SATD", "early skip", "integer ME", "fractional ME", "candidates", "intra search", "intra recon", "inter quant/recon", "mock+rd cost", "copies", "io", "total (unattributed)"] + ["cat%d" % i for i in range(12, 16)] + ["EVENTS price()", "EVENTS cell_at", "EVENTS candidate gathers", "EVENTS mv_candidates calls", "EVENTS probe groups", "EVENTS staged windows", "EVENTS hor_pass_ref", "EVENTS predict_tile", "EVENTS   of those: integer vector", "EVENTS   one direction integer", "EVENTS   of two lists", "EVENTS tiles of two lists with one vector"] + ["cat%d" % i for i in range(28, 31)] + ["outside"]
 tot = np.zeros(32, np.int64)
 ctus = ((w + 63) // 64) * ((h + 63) // 64)
 for k in range(1, n):
@@ -34,13 +34,13 @@ for k in range(1, n):
     sim.kvz_hostsim_inter_phases(ph)
     tot += np.array(ph[:], np.int64)
 per = tot / float(ctus * (n - 1))
-ev = per[16:24].copy(); per[16:24] = 0
+ev = per[16:28].copy(); per[16:28] = 0
 print("%s: phases per CTU (%d pictures x %d CTUs)" % (name, n - 1, ctus))
 for i in np.argsort(-per):
     if per[i] > 0:
         print("  %-24s %9.1f  %5.1f %%" % (names[i], per[i], 100 * per[i] / per.sum()))
 print("  %-24s %9.1f" % ("sum", per.sum()))
-for i in range(8):
+for i in range(12):
     print("  %-28s %9.1f per CTU" % (names[16 + i], ev[i]))
 b = cu[1:]
 print("  CU records (4x4 units) per picture: intra %d, skipped %d, merged %d, amvp %d" % tuple(int(v) // (n - 1) for v in ((b["type"] == 1).sum(), ((b["type"] == 2) & (b["skipped"] == 1)).sum(), ((b["type"] == 2) & (b["merged"] == 1)).sum(), ((b["type"] == 2) & (b["merged"] == 0) & (b["skipped"] == 0)).sum())))
