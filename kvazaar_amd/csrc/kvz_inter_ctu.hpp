@@ -184,7 +184,7 @@ struct InterFrames {
 #define IC_MREF_STRIDE 36  /* q in [-16, 17] for a 16x16 CU (an odd number of dwords: the modes fall into different banks) */
 #define IC_MREF_ORG 16
 struct MCand { i16 mv[2][2]; u8 ref[2], dir; };                         // inter_merge_cand_t
-struct PuSearch { int x, y, w; i16 mv_cand[2][2]; MCand merge[5]; int num_merge; };
+struct PuSearch { int x, y, w; i16 mv_cand[2][2]; MCand merge[5]; int num_merge, merge_dup; };  // merge_dup: bit k = merge[k] repeats an earlier entry
 struct UMap { CuInfo unit[5]; double cost[5], bits[5]; int8_t keys[5]; int size; };
 
 struct PView { lu8 *p; int s; };  // a plane of a block in LDS: sample (x, y) at p[y * s + x]
