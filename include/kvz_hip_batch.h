@@ -97,6 +97,8 @@ int  kvz_hip_batch_sync(kvz_hip_batch *b);
  * waits again) and the batch stays invalid -- sticky, so that no later call can mistake its contents for results -- until this call clears the condition.  The
  * pictures uploaded to the batch are untouched: the caller may simply run the pass again.  Returns 0. */
 int  kvz_hip_batch_reset(kvz_hip_batch *b);
+/* developer diagnostics: every CTU's hand-off flag (= the number of the last pass that completed it) into out [n_frames x CTUs per frame]; returns the number of the batch's last pass */
+unsigned kvz_hip_batch_debug_flags(kvz_hip_batch *b, unsigned *out);
 /* Device time of the launches of the last kvz_hip_intra_frames call, from HIP events recorded on the batch's own
  * stream around the launch sequence (milliseconds); call after kvz_hip_batch_sync(). */
 float kvz_hip_batch_last_kernel_ms(kvz_hip_batch *b);

@@ -67,6 +67,8 @@ class HipBatch:
         lib.kvz_hip_intra_frames.restype = ci
         lib.kvz_hip_batch_sync.argtypes = [vp]
         lib.kvz_hip_batch_sync.restype = ci
+        lib.kvz_hip_batch_reset.argtypes = [vp]
+        lib.kvz_hip_batch_reset.restype = ci
         lib.kvz_hip_batch_last_kernel_ms.argtypes = [vp]
         lib.kvz_hip_batch_last_kernel_ms.restype = C.c_float
         lib.kvz_hip_batch_ctus_per_frame.argtypes = [vp]
@@ -112,6 +114,10 @@ class HipBatch:
     def sync(self):
         if self.lib.kvz_hip_batch_sync(self.handle) != 0:
             raise BatchError("kvz_hip_batch_sync: a CTU hand-off wait timed out; results invalid")
+
+    def reset(self):
+        """after a BatchError: drains the batch's stream and clears the (sticky) error word -- the batch can run again (kvz_hip_batch_reset)"""
+        self.lib.kvz_hip_batch_reset(self.handle)
 
     def run(self, model):
         n = self.launch(model)

@@ -61,7 +61,8 @@ inline int batch_check(kvz_hip_batch *b)
     const unsigned err = *(volatile unsigned *)b->h_error;
     if (err) {
       b->failed = 1;
-      fprintf(stderr, "kvz_hip: a CTU hand-off wait timed out (KVZ_HIP_WAIT_MS to raise the bound) -- the results of this batch are invalid\n");
+      fprintf(stderr, "kvz_hip: a CTU hand-off wait timed out (KVZ_HIP_WAIT_MS to raise the bound) -- the results of this batch are invalid [first to give up waited for CTU x %u y %u of picture %u (%s), pass %u of the batch; that CTU's flag read at the memory side then: %u; tickets drawn then: %u of %u]\n",
+              err & 0xffu, (err >> 8) & 0xffu, (err >> 16) & 0x1fffu, (err & 0x20000000u) ? "its above-right neighbour" : ((err & 0x40000000u) ? "the end of the row above" : "its left neighbour"), b->epoch, ((volatile unsigned *)b->h_error)[1], ((volatile unsigned *)b->h_error)[2], b->total_items);
     }
   }
   return b->failed ? -1 : 0;
@@ -204,8 +205,13 @@ kvz_hip_batch *kvz_hip_batch_create_on(int device, int width, int height, int n_
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_mode, ncu));
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_cost, nctu * sizeof(double)));
   KVZ_HIP_CHECK(hipMemsetAsync(b->d_rec, 0, F.frame_px * n_frames, b->stream));  // on the batch's stream: a non-blocking stream does not order against the null stream
+#ifdef KVZ_CTU_TRACE
+  KVZ_HIP_CHECK(hipMalloc((void **)&b->d_prof, (size_t)nctu * sizeof(unsigned long long)));  // a word per CTU: where it is (kvz_ctu_kernels.hpp KVZ_TRACE)
+  KVZ_HIP_CHECK(hipMemsetAsync(b->d_prof, 0, (size_t)nctu * sizeof(unsigned long long), b->stream));
+#else
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_prof, KVZ_PROF_WORDS * sizeof(unsigned long long)));  // + 8: the sections of rdoq_block_wave
   KVZ_HIP_CHECK(hipMemsetAsync(b->d_prof, 0, KVZ_PROF_WORDS * sizeof(unsigned long long), b->stream));
+#endif
   F.prof = b->d_prof;
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_entropy, 128 * sizeof(float) + sizeof(((kvz_hip_intra_cost_model *)0)->ctx_init)));
   KVZ_HIP_CHECK(hipMalloc((void **)&b->d_border, nctu * KVZ_BORDER_BYTES));
@@ -232,8 +238,8 @@ kvz_hip_batch *kvz_hip_batch_create_on(int device, int width, int height, int n_
     KVZ_HIP_CHECK(hipMemcpy(b->d_items_raster, items.data(), items.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     KVZ_HIP_CHECK(hipMalloc((void **)&b->d_done, nctu * sizeof(unsigned)));
     KVZ_HIP_CHECK(hipMemsetAsync(b->d_done, 0, nctu * sizeof(unsigned), b->stream));
-    KVZ_HIP_CHECK(hipMalloc((void **)&b->d_ticket, 2 * sizeof(unsigned)));
-    KVZ_HIP_CHECK(hipMemsetAsync(b->d_ticket, 0, 2 * sizeof(unsigned), b->stream));
+    KVZ_HIP_CHECK(hipMalloc((void **)&b->d_ticket, 4 * sizeof(unsigned)));  // the ticket, the error word, two words of what the first CTU to give up saw
+    KVZ_HIP_CHECK(hipMemsetAsync(b->d_ticket, 0, 4 * sizeof(unsigned), b->stream));
     b->d_error = b->d_ticket + 1;
     KVZ_HIP_CHECK(hipHostMalloc((void **)&b->h_error, 64, hipHostMallocDefault));
     *b->h_error = 0;
@@ -431,7 +437,7 @@ int kvz_hip_intra_frames(kvz_hip_batch *b, const kvz_hip_intra_cost_model *model
     else hipLaunchKernelGGL(kvz::intra_ctu_ticket_kernel<false>, dim3(b->grid_ticket), dim3(KVZ_CTU_THREADS), 0, b->stream, F, cm, kvz::device_tables(), sc);
     KVZ_HIP_CHECK(hipGetLastError());
     KVZ_HIP_CHECK(hipEventRecord(b->ev1, b->stream));
-    KVZ_HIP_CHECK(hipMemcpyAsync(b->h_error, b->d_error, sizeof(unsigned), hipMemcpyDeviceToHost, b->stream));  // what batch_check reads once the stream has drained
+    KVZ_HIP_CHECK(hipMemcpyAsync(b->h_error, b->d_error, 3 * sizeof(unsigned), hipMemcpyDeviceToHost, b->stream));  // what batch_check reads once the stream has drained
     return 1;
   }
   KVZ_HIP_CHECK(hipEventRecord(b->ev0, b->stream));
@@ -462,11 +468,29 @@ int kvz_hip_batch_sync(kvz_hip_batch *b)
   return kvz::batch_check(b);
 }
 
+/* developer diagnostics (tools/chain_stress.py): the hand-off flags of every CTU as they stand in memory -- a CTU's flag holds the number of the last pass that completed
+ * it -- into out [n_frames x ctus_per_frame]; returns the number of the batch's last pass */
+#ifdef KVZ_CTU_TRACE
+extern "C" void kvz_hip_batch_debug_trace(kvz_hip_batch *b, unsigned long long *out)
+{
+  kvz::batch_enter(b);
+  KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+  KVZ_HIP_CHECK(hipMemcpy(out, b->d_prof, (size_t)b->n_frames * b->F.wc * b->F.hc * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+}
+#endif
+unsigned kvz_hip_batch_debug_flags(kvz_hip_batch *b, unsigned *out)
+{
+  kvz::batch_enter(b);
+  KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
+  KVZ_HIP_CHECK(hipMemcpy(out, b->d_done, (size_t)b->n_frames * b->F.wc * b->F.hc * sizeof(unsigned), hipMemcpyDeviceToHost));
+  return b->epoch;
+}
+
 int kvz_hip_batch_reset(kvz_hip_batch *b)
 {
   kvz::batch_enter(b);
   KVZ_HIP_CHECK(hipStreamSynchronize(b->stream));
-  KVZ_HIP_CHECK(hipMemset(b->d_error, 0, sizeof(unsigned)));
+  KVZ_HIP_CHECK(hipMemset(b->d_error, 0, 3 * sizeof(unsigned)));
   *b->h_error = 0;
   b->failed = 0;
   return 0;

@@ -67,17 +67,33 @@ struct CtuSched {
 };
 
 #if KVZ_CTU_KERNEL_BODIES
-__device__ __forceinline__ bool wait_done(unsigned *flag, unsigned epoch, unsigned *error, unsigned long long wait_ticks)
+#ifdef KVZ_CTU_TRACE  /* developer build (tools/chain_stress.py): where every CTU of the pass is -- F.prof holds a word per CTU: epoch << 8 | stage */
+#define KVZ_TRACE(stage) do { if (threadIdx.x == 0 && __hip_atomic_load(sched.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __hip_atomic_store(&F.prof[(long)frame * ctus + y * F.wc + x], (unsigned long long)sched.epoch << 8 | (stage), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+#else
+#define KVZ_TRACE(stage) do { } while (0)
+#endif
+__device__ __forceinline__ bool wait_done(unsigned *flag, unsigned epoch, unsigned *error, unsigned long long wait_ticks, unsigned tag)
 {
   unsigned long long t0 = 0;
   for (unsigned spins = 0;; ++spins) {
     if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return true;
     if ((spins & 1023u) == 1023u) {  // bounded: a lost hand-off must not hang the GPU
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (every half millisecond of waiting: whatever this XCD's L2 holds of the flags' lines goes -- insurance, the poll is an agent-scope load)
       const unsigned long long now = __builtin_amdgcn_s_memrealtime();
       if (!t0) t0 = now;
-      else if (now - t0 > wait_ticks) { atomicExch(error, 1u); return false; }
+      else if (now - t0 > wait_ticks) {
+        if (atomicCAS(error, 0u, 0x80000000u | tag) == 0u) {  // the first to give up leaves what it can see: the flag as a read-modify-write at the memory side returns it, and how far the tickets are
+          error[1] = atomicAdd(flag, 0u);
+          error[2] = __hip_atomic_load(error - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return false;
+      }  // the first CTU that gave up: which neighbour (bits 29-30), frame << 16 | y << 8 | x of the CTU waited FOR
     }
-    __builtin_amdgcn_s_sleep(16);
+    // back off after the first half millisecond: a wait that long is on nobody's critical path (hand-offs arrive within microseconds), and where a pass has stalled --
+    // tools/chain_stress.py, profiles/README.md round 6: an eighth of the workgroups standing still in their searches for seconds -- the other seven eighths
+    // should not poll the memory system two thousand times a microsecond meanwhile
+    if (spins < 1024u) __builtin_amdgcn_s_sleep(16);
+    else { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
   }
 }
 
@@ -101,18 +117,20 @@ template <bool CABAC, bool S32, bool RDOQ> __device__ __forceinline__ void ticke
     if (t >= sched.total) break;
     const uint32_t item = sched.items[t];
     const int frame = item >> 16, y = (item >> 8) & 0xff, x = item & 0xff;
+    KVZ_TRACE(1);  // ticket drawn
     if (threadIdx.x == 0) {
       unsigned *done = sched.done + (long)frame * ctus;
       // a hand-off that timed out anywhere (this launch or an earlier one: the word is sticky until kvz_hip_batch_reset) poisons the pass: from then on
       // tickets are only drained -- no search on stale neighbour data, no further 30-second waits -- and every CTU still publishes its flag
       bool ok = __hip_atomic_load(sched.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-      if (ok && x > 0) ok = wait_done(&done[y * F.wc + x - 1], sched.epoch, sched.error, sched.wait_ticks);
-      if (ok && y > 0) ok = wait_done(&done[(y - 1) * F.wc + (x + 1 < F.wc ? x + 1 : x)], sched.epoch, sched.error, sched.wait_ticks);  // above-right implies above and above-left
-      if (ok && sched.no_wpp && x == 0 && y > 0) ok = wait_done(&done[(y - 1) * F.wc + F.wc - 1], sched.epoch, sched.error, sched.wait_ticks);  // its contexts come from there
+      if (ok && x > 0) ok = wait_done(&done[y * F.wc + x - 1], sched.epoch, sched.error, sched.wait_ticks, ((unsigned)frame << 16 | (unsigned)y << 8 | (unsigned)(x - 1)) & 0x1fffffffu);
+      if (ok && y > 0) ok = wait_done(&done[(y - 1) * F.wc + (x + 1 < F.wc ? x + 1 : x)], sched.epoch, sched.error, sched.wait_ticks, 0x20000000u | (((unsigned)frame << 16 | (unsigned)(y - 1) << 8 | (unsigned)(x + 1 < F.wc ? x + 1 : x)) & 0x1fffffffu));  // above-right implies above and above-left
+      if (ok && sched.no_wpp && x == 0 && y > 0) ok = wait_done(&done[(y - 1) * F.wc + F.wc - 1], sched.epoch, sched.error, sched.wait_ticks, 0x40000000u | (((unsigned)frame << 16 | (unsigned)(y - 1) << 8 | (unsigned)(F.wc - 1)) & 0x1fffffffu));  // its contexts come from there
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       shared.best_mode = ok ? 1 : 0;
     }
     __syncthreads();
+    KVZ_TRACE(2);  // neighbours there
     const bool run_it = shared.best_mode != 0;  // uniform.  (run() first writes the field behind several barriers of its own: no lane can still be reading it here)
     if (run_it) {
       CtuProgramT<CABAC, S32, RDOQ> p;
@@ -122,12 +140,16 @@ template <bool CABAC, bool S32, bool RDOQ> __device__ __forceinline__ void ticke
       p.lane_rot = (t * 64) & (KVZ_CTU_THREADS - 1);
       p.run();
     }
+    KVZ_TRACE(3);  // searched
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave drains its stores (reconstruction, CU info, coefficients)
     __syncthreads();
+    KVZ_TRACE(4);  // stores drained, both wavefronts there
     if (threadIdx.x == 0) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      KVZ_TRACE(5);  // released
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __hip_atomic_store(&sched.done[(long)frame * ctus + y * F.wc + x], sched.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      KVZ_TRACE(6);  // flag stored
     }
   }
 }

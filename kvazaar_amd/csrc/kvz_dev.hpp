@@ -1681,7 +1681,7 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
       mark("host: bounds");
       uint32_t *d_room = (uint32_t *)S.need(S.room, (size_t)streams * sizeof(uint32_t));
       hipLaunchKernelGGL(dev_entropy_stream_room_kernel, dim3((unsigned)((streams + 255) / 256)), dim3(256), 0, stream, d_nbits, streams, per_stream, d_room);
-      hipLaunchKernelGGL(dev_entropy_offsets_kernel, dim3(1), dim3(1024), 0, stream, d_room, streams, d_bound_offsets);  // == bound_offsets, without a copy
+      hipLaunchKernelGGL(dev_entropy_offsets_kernel, dim3(1), dim3(KVZ_ENTROPY_SCAN_THREADS), 0, stream, d_room, streams, d_bound_offsets);  // == bound_offsets, without a copy
       if (chain_queued && f0 + nf >= n) {
         if (!S.ev_pre) KVZ_HIP_CHECK(hipEventCreateWithFlags(&S.ev_pre, hipEventDisableTiming));
         KVZ_HIP_CHECK(hipEventRecord(S.ev_pre, stream));
@@ -1718,7 +1718,7 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
         rc = -1;
       } else {
         d_out = (uint8_t *)S.need(own_out ? *own_out : S.out, chunk_bytes ? chunk_bytes : 1);
-        hipLaunchKernelGGL(dev_entropy_offsets_kernel, dim3(1), dim3(1024), 0, stream, d_sizes, streams, d_offsets);  // == offsets, without a copy
+        hipLaunchKernelGGL(dev_entropy_offsets_kernel, dim3(1), dim3(KVZ_ENTROPY_SCAN_THREADS), 0, stream, d_sizes, streams, d_offsets);  // == offsets, without a copy
         hipLaunchKernelGGL(dev_entropy_compact_kernel, dim3((unsigned)streams), dim3(256), 0, stream, d_scratch, d_bound_offsets, d_sizes, d_ins, d_offsets, d_out);
         KVZ_HIP_CHECK(hipGetLastError());
         const bool in_flight = defer && own_out && f0 + nf >= n;

@@ -995,24 +995,26 @@ __global__ void __launch_bounds__(256) dev_entropy_stream_room_kernel(const u32 
   for (long k = 0; k < per_stream; k++) b += bits[i * per_stream + k];
   room[i] = (u32)((((b + 7) / 8 + 16) * 3 / 2 + 15) & ~15ull);
 }
-__global__ void __launch_bounds__(1024) dev_entropy_offsets_kernel(const u32 *bytes, long streams, unsigned long long *offsets)  // one workgroup
+#define KVZ_ENTROPY_SCAN_THREADS 256  /* four wavefronts: a 1024-thread workgroup needs a whole CU's wave slots at once, and queued beside a persistent pass it stood at the head of its queue until the pass ended */
+__global__ void __launch_bounds__(KVZ_ENTROPY_SCAN_THREADS) dev_entropy_offsets_kernel(const u32 *bytes, long streams, unsigned long long *offsets)  // one workgroup
 {
-  __shared__ unsigned long long part[1024];
-  // thread t takes the entries t, t + 1024, ... of every block of 1024 x `rounds`: coalesced reads; the scan runs block by block with a running base
+  constexpr int T = KVZ_ENTROPY_SCAN_THREADS;
+  __shared__ unsigned long long part[T];
+  // thread t takes the entries t, t + T, ... block by block: coalesced reads; the scan runs block by block with a running base
   unsigned long long base = 0;
-  for (long at = 0; at < streams; at += 1024) {
+  for (long at = 0; at < streams; at += T) {
     const long i = at + threadIdx.x;
     const unsigned long long v = i < streams ? bytes[i] : 0;
     part[threadIdx.x] = v;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {  // inclusive scan of the block
+    for (int d = 1; d < T; d <<= 1) {  // inclusive scan of the block
       const unsigned long long w = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0;
       __syncthreads();
       part[threadIdx.x] += w;
       __syncthreads();
     }
     if (i < streams) offsets[i] = base + part[threadIdx.x] - v;
-    base += part[1023];
+    base += part[T - 1];
     __syncthreads();
   }
 }

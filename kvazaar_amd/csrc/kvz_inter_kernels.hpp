@@ -51,11 +51,13 @@ KVZ_ICTU_KERNEL(inter_ctu_ticket_kernel_fast)
         for (unsigned spins = 0;; ++spins) {
           if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u) return true;
           if ((spins & 1023u) == 1023u) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // (as in the intra pass: kvz_ctu_kernels.hpp wait_done)
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
             if (!t0) t0 = now;
             else if (now - t0 > sched.wait_ticks) { atomicExch(sched.error, 1u); return false; }
           }
-          __builtin_amdgcn_s_sleep(16);
+          if (spins < 1024u) __builtin_amdgcn_s_sleep(16);  // (backs off as the intra pass does: kvz_ctu_kernels.hpp wait_done)
+          else { __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); }
         }
       };
       bool ok = __hip_atomic_load(sched.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
