@@ -949,7 +949,9 @@ template <int LANES> __global__ void __launch_bounds__(LANES) dev_entropy_code_w
   if (item >= total) return;
   // A chain, not a rate: this wavefront needs a fifth of a SIMD's issue slots, but every one of them late is a step late.  Beside another kernel's wavefronts (the next
   // batch's CTU pass, kvz_hip_batch_entropy_code_then) it goes first
+#ifndef KVZ_ENTROPY_NO_SETPRIO  /* (developer switch: tools/chain_stress.py's hunt) */
   __builtin_amdgcn_s_setprio(3);
+#endif
   sizes[item] = entropy_code_row_wide<32>(J, L.tab, item, L.ctx[threadIdx.x], out + offsets[item]);
 }
 // one workgroup per substream: the emulation prevention bytes it needs; sizes: in the bytes the coder wrote, out the substream's final size

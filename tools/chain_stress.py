@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool (GPU box): bench.py's 1920x1080 like-for-like chain (two batches of 1 536 pictures in turn, every batch uploaded from pinned host memory inside the timed
-region) over and over, each attempt's wall time and the library's messages -- what a failed or slow attempt looked like.  usage: tools/chain_stress.py [rounds=20] [pictures=1536] [up|resident]"""
+region) over and over, each attempt's wall time and the library's messages -- what a failed or slow attempt looked like.  usage: tools/chain_stress.py [rounds=20] [pictures=1536] [up|resident] [swap|notfirst]"""
 import os, sys, json, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,6 +15,7 @@ lib = kvazaar_amd.load_library()
 model = cost_model(lib, 22)
 frames = bench.synth_frames(w, h, 4, bench.clip_seed(w, h))
 gold = json.load(open(os.path.join(ROOT, "tests", "golden", "entropy.json"))).get("bench-1080p")
+dummy = HipBatch(lib, w, h, 8) if len(sys.argv) > 4 and sys.argv[4] == "notfirst" else None  # neither of the two is the process's first batch (first stream, first allocations)
 pair = [HipBatch(lib, w, h, n) for _ in range(2)]
 if len(sys.argv) > 4 and sys.argv[4] == "swap":
     pair = pair[::-1]  # the batch created second takes the first turn
