@@ -1699,13 +1699,13 @@ inline long entropy_code_pictures(hipStream_t stream, int device, int n, int wc,
         else if (lanes == 32) hipLaunchKernelGGL(dev_entropy_code_wide_kernel<32>, grid, block, pad, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
         else if (lanes == 8) hipLaunchKernelGGL(dev_entropy_code_wide_kernel<8>, grid, block, pad, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
         else hipLaunchKernelGGL(dev_entropy_code_wide_kernel<16>, grid, block, pad, stream, J, device_tables(), streams, d_sizes, d_bound_offsets, d_scratch);
-        hipLaunchKernelGGL(dev_entropy_escape_count_kernel, dim3((unsigned)streams), dim3(256), 0, stream, d_scratch, d_bound_offsets, d_sizes, d_ins);
       }
       // from here on the device is nearly idle -- stage 3 is a few hundred wavefronts on their own chains, then a copy --: the caller's moment to queue other work
       // The caller's work is a persistent pass that takes every free workgroup slot the moment it starts: stage 3 must have its slots first (it then runs 39 ms beside
       // the pass; started behind it, it waits 310 ms for the pass to end).  So the pass is queued only when everything in front of stage 3 has run -- stage 3 is then
       // dispatched at once, the pass a launch latency later.
       if (chain_queued && f0 + nf >= n) { KVZ_HIP_CHECK(hipEventSynchronize(S.ev_pre)); chain_queued(); }
+      hipLaunchKernelGGL(dev_entropy_escape_count_kernel, dim3((unsigned)streams), dim3(256), 0, stream, d_scratch, d_bound_offsets, d_sizes, d_ins);  // (behind the caller's pass, if it queued one: see kvz_hip_batch_entropy_code_then)
       sizes.resize((size_t)streams);
       KVZ_HIP_CHECK(hipMemcpyAsync(sizes.data(), d_sizes, (size_t)streams * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       KVZ_HIP_CHECK(hipStreamSynchronize(stream));
@@ -1765,7 +1765,17 @@ long kvz_hip_batch_entropy_code_then(kvz_hip_batch *b, const kvz_hip_intra_cost_
   // `next`'s pass is queued exactly once on every path below (the caller synchronises `next` whatever this call returns): by the coder at its quiet moment, or here
   int launched = 0;
   bool started = false;
-  auto start_next = [&] { if (next && !started) { started = true; launched = kvz_hip_intra_frames(next, next_model); kvz::batch_enter(b); } };
+  // ... and what this call queues behind it on its own stream waits for that pass to end: the coder's last kernels could not run beside a persistent pass anyway (no free
+  // workgroup slot), and kernels standing at the head of ANOTHER hardware queue while the pass runs are what one two-batch chain in forty stalled on (DESIGN.md section 8
+  // item 8: none with one hardware queue) -- behind an event the queue holds a barrier packet instead of a dispatch
+  auto start_next = [&] {
+    if (next && !started) {
+      started = true;
+      launched = kvz_hip_intra_frames(next, next_model);
+      kvz::batch_enter(b);
+      if (launched > 0) KVZ_HIP_CHECK(hipStreamWaitEvent(b->stream, next->ev1, 0));
+    }
+  };
   struct StartOnExit { decltype(start_next) &f; ~StartOnExit() { f(); } } start_on_exit{ start_next };
   if (sao && !b->d_sao_recs) { fprintf(stderr, "kvz_hip_batch_entropy_code: kvz_hip_batch_loop_filters(..., sao = 1) has not run on this batch\n"); return -1; }
   if (model->search_nxn && !b->d_part) { fprintf(stderr, "kvz_hip_batch_entropy_code: the batch has no NxN partition maps\n"); return -1; }
